@@ -1,0 +1,305 @@
+"""ctypes bindings of the CHECKERS: oracle/liboracle.so (CPU restatement) and
+oracle/_ref/libref_oracle.so (the reference's own code, built by oracle/ref/build_ref.sh).
+
+Test infrastructure only -- never imported by the product package.
+"""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORC_DIR = os.path.join(ROOT, "oracle")
+
+SFPOINT = np.dtype([("x", "<f4"), ("y", "<f4"), ("id", "<i4")])
+KEYPOINT = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
+                     ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])
+CHIPINFO = np.dtype([("x0", "<i4"), ("y0", "<i4"), ("w", "<i4"), ("h", "<i4"), ("img", "<i4"),
+                     ("sx", "<f4"), ("sy", "<f4"), ("quad", "<f4", (8,))])
+
+fp = C.POINTER(C.c_float)
+ip = C.POINTER(C.c_int)
+u8p = C.POINTER(C.c_uint8)
+
+
+def _p(a, t=C.c_void_p):
+    return a.ctypes.data_as(t)
+
+
+def sfpoints(xy, ids=None):
+    xy = np.asarray(xy, np.float32)
+    out = np.zeros(len(xy), SFPOINT)
+    out["x"] = xy[:, 0]
+    out["y"] = xy[:, 1]
+    out["id"] = np.arange(len(xy)) if ids is None else ids
+    return out
+
+
+def build_oracle():
+    so = os.path.join(ORC_DIR, "liboracle.so")
+    srcs = [os.path.join(ORC_DIR, f) for f in os.listdir(ORC_DIR) if f.endswith((".c", ".h"))]
+    if (not os.path.exists(so)) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        subprocess.check_call(["make", "-C", ORC_DIR, "liboracle.so", "liboracle_v3.so"])
+    return so
+
+
+class Oracle:
+    def __init__(self, path):
+        self.L = C.CDLL(path)
+        L = self.L
+        L.orc_rand.restype = C.c_int
+
+    # ---- homography -------------------------------------------------------
+    def inverse_matrix(self, a, eps):
+        a = np.ascontiguousarray(a, np.float32)
+        n = a.shape[0]
+        out = np.zeros((n, n), np.float32)
+        rc = self.L.orc_inverse_matrix(_p(a), n, _p(out), C.c_float(eps))
+        return rc, out
+
+    def solve_homography(self, p1, p2):
+        H = np.zeros(9, np.float32)
+        rc = self.L.orc_solve_homography(_p(p1), _p(p2), len(p1), _p(H))
+        return rc, H
+
+    def nlls(self, p1, p2, H0, stop=1e-10):
+        H = np.zeros(9, np.float32)
+        H0 = np.ascontiguousarray(H0, np.float32)
+        rc = self.L.orc_nlls_projection2(_p(p1), _p(p2), len(p1), _p(H), _p(H0), C.c_float(stop))
+        return rc, H
+
+    def rand_stream(self, seed, n):
+        st = (C.c_int32 * 40)()
+        self.L.orc_srand(st, C.c_uint(seed))
+        return np.array([self.L.orc_rand(st) for _ in range(n)], np.int64)
+
+    def ransac2d(self, p1, p2, dist, sample_times, seed):
+        n = len(p1)
+        i1 = np.zeros(max(n, 1), SFPOINT)
+        i2 = np.zeros(max(n, 1), SFPOINT)
+        nin = C.c_int(0)
+        H = np.zeros(9, np.float32)
+        ok = self.L.orc_ransac2d(_p(p1), _p(p2), n, C.c_float(dist), sample_times, C.c_uint(seed),
+                                 _p(i1), _p(i2), C.byref(nin), _p(H))
+        return ok, i1[:nin.value].copy(), i2[:nin.value].copy(), H
+
+    # ---- selection / matching --------------------------------------------
+    def select(self, matches, kp1, kp2, nMatch, w, h, gx=3, gy=3):
+        matches = np.ascontiguousarray(matches, np.int32)
+        kp1 = np.ascontiguousarray(kp1, np.float32)
+        kp2 = np.ascontiguousarray(kp2, np.float32)
+        n = len(matches)
+        o1 = np.zeros(max(n, 1), SFPOINT)
+        o2 = np.zeros(max(n, 1), SFPOINT)
+        no = C.c_int(0)
+        self.L.orc_select_match_pairs(_p(matches), n, _p(kp1), _p(kp2), nMatch, w, h, gx, gy, _p(o1), _p(o2), C.byref(no))
+        return o1[:no.value].copy(), o2[:no.value].copy()
+
+    def bf_match(self, d1, d2):
+        d1 = np.ascontiguousarray(d1, np.uint8)
+        d2 = np.ascontiguousarray(d2, np.uint8)
+        n1 = len(d1)
+        idx = np.zeros(n1, np.int32)
+        b1 = np.zeros(n1, np.int32)
+        b2 = np.zeros(n1, np.int32)
+        self.L.orc_bf_match(_p(d1), n1, _p(d2), len(d2), _p(idx), _p(b1), _p(b2))
+        return idx, b1, b2
+
+    def sort_matches(self, idx, d2):
+        out = np.zeros((len(idx), 2), np.int32)
+        self.L.orc_sort_matches(_p(np.ascontiguousarray(idx, np.int32)), _p(np.ascontiguousarray(d2, np.int32)), len(idx), _p(out))
+        return out
+
+    def match_pair(self, kp1, d1, kp2, d2, w, h, dist, seed):
+        kp1 = np.ascontiguousarray(kp1, np.float32)
+        kp2 = np.ascontiguousarray(kp2, np.float32)
+        d1 = np.ascontiguousarray(d1, np.uint8)
+        d2 = np.ascontiguousarray(d2, np.uint8)
+        n1 = len(kp1)
+        i1 = np.zeros(max(n1, 1), SFPOINT)
+        i2 = np.zeros(max(n1, 1), SFPOINT)
+        H = np.zeros(9, np.float32)
+        ns = C.c_int(0)
+        self.L.orc_match_pair.restype = C.c_int
+        nin = self.L.orc_match_pair(_p(kp1), _p(d1), n1, _p(kp2), _p(d2), len(kp2), w, h, C.c_float(dist), C.c_uint(seed),
+                                    _p(i1), _p(i2), _p(H), C.byref(ns))
+        return nin, i1, i2, H, ns.value
+
+    # ---- warps -------------------------------------------------------------
+    def image_projection_transform(self, img, h9):
+        img = np.ascontiguousarray(img)
+        hh, ws = img.shape[0], img.strides[0]
+        ch = img.shape[2] if img.ndim == 3 else 1
+        w = img.shape[1]
+        h9 = np.ascontiguousarray(h9, np.float32)
+        dst = C.c_void_p()
+        dw, dh, dws = C.c_int(), C.c_int(), C.c_int()
+        rc = self.L.orc_image_projection_transform(_p(img), w, hh, ws, ch, _p(h9), C.byref(dst), C.byref(dw), C.byref(dh), C.byref(dws))
+        if rc != 0:
+            return rc, None
+        buf = np.ctypeslib.as_array(C.cast(dst, u8p), shape=(dh.value, dws.value)).copy()
+        self.L.orc_free(dst)
+        return rc, (buf, dw.value, dh.value, dws.value)
+
+    def mosaic_images_refined(self, imgs, h9s):
+        n = len(imgs)
+        imgs = [np.ascontiguousarray(i) for i in imgs]
+        ptrs = (C.c_void_p * n)(*[i.ctypes.data for i in imgs])
+        w = np.array([i.shape[1] for i in imgs], np.int32)
+        h = np.array([i.shape[0] for i in imgs], np.int32)
+        ws = np.array([i.strides[0] for i in imgs], np.int32)
+        h9s = np.ascontiguousarray(h9s, np.float32)
+        cw, ch, cws = C.c_int(), C.c_int(), C.c_int()
+        rc = self.L.orc_mosaic_images_refined(ptrs, _p(w), _p(h), _p(ws), n, _p(h9s), None, C.byref(cw), C.byref(ch), C.byref(cws))
+        if rc != 0:
+            return rc, None
+        canvas = np.zeros((ch.value, cws.value), np.uint8)
+        rc = self.L.orc_mosaic_images_refined(ptrs, _p(w), _p(h), _p(ws), n, _p(h9s), _p(canvas), C.byref(cw), C.byref(ch), C.byref(cws))
+        return rc, (canvas, cw.value, ch.value, cws.value)
+
+    def chips_and_masks(self, imgs, h9s, keep=None, find_masks=True):
+        n = len(imgs)
+        imgs = [np.ascontiguousarray(i) for i in imgs]
+        w = np.array([i.shape[1] for i in imgs], np.int32)
+        h = np.array([i.shape[0] for i in imgs], np.int32)
+        h9s = np.ascontiguousarray(h9s, np.float32)
+        keep = np.ones(n, np.uint8) if keep is None else np.ascontiguousarray(keep, np.uint8)
+        chips = np.zeros(n, CHIPINFO)
+        cw, ch = C.c_int(), C.c_int()
+        dG = np.zeros(2, np.float32)
+        self.L.orc_chip_layout.restype = C.c_int
+        nv = self.L.orc_chip_layout(_p(w), _p(h), n, _p(h9s), _p(keep), C.byref(cw), C.byref(ch), _p(dG), _p(chips))
+        chips = chips[:nv].copy()
+        cimgs, masks = [], []
+        for c in chips:
+            k = int(c["img"])
+            cws = (int(c["w"]) * 3 + 3) & ~3
+            mws = (int(c["w"]) + 3) & ~3
+            chip = np.zeros((int(c["h"]), cws), np.uint8)
+            mask = np.zeros((int(c["h"]), mws), np.uint8)
+            ci = np.array([c], CHIPINFO)
+            rc = self.L.orc_chip_warp(_p(imgs[k]), int(w[k]), int(h[k]), imgs[k].strides[0], _p(h9s[k]), _p(dG), _p(ci),
+                                      _p(chip), cws, _p(mask), mws)
+            assert rc == 0
+            cimgs.append(chip)
+            masks.append(mask)
+        valid = [m.copy() for m in masks]
+        if find_masks and nv:
+            mp = (C.c_void_p * nv)(*[m.ctypes.data for m in masks])
+            mws = np.array([m.strides[0] for m in masks], np.int32)
+            self.L.orc_find_masks_by_distmap(mp, _p(mws), _p(chips), nv, cw.value, ch.value)
+        return dict(cw=cw.value, ch=ch.value, dG=dG, chips=chips, chip_imgs=cimgs, valid=valid, masks=masks)
+
+    def sift(self, bgr, nfeatures=2000, max_kp=None):
+        bgr = np.ascontiguousarray(bgr, np.uint8)
+        h, w = bgr.shape[:2]
+        max_kp = max_kp or nfeatures
+        kp = np.zeros(max_kp, KEYPOINT)
+        desc = np.zeros((max_kp, 128), np.uint8)
+        self.L.orc_sift.restype = C.c_int
+        n = self.L.orc_sift(_p(bgr), w, h, bgr.strides[0], nfeatures, _p(kp), _p(desc), max_kp)
+        return kp[:n].copy(), desc[:n].copy()
+
+
+class Ref:
+    """The reference's own code (oracle/_ref)."""
+
+    def __init__(self, path):
+        self.L = C.CDLL(path)
+
+    def inverse_matrix(self, a, eps):
+        a = np.ascontiguousarray(a, np.float32)
+        n = a.shape[0]
+        out = np.zeros((n, n), np.float32)
+        rc = self.L.ref_inverse_matrix(_p(a), n, _p(out), C.c_float(eps))
+        return rc, out
+
+    def solve_homography(self, p1, p2):
+        a = np.ascontiguousarray(np.stack([p1["x"], p1["y"]], 1), np.float32)
+        b = np.ascontiguousarray(np.stack([p2["x"], p2["y"]], 1), np.float32)
+        H = np.zeros(9, np.float32)
+        rc = self.L.ref_solve_homography(_p(a), _p(b), len(a), _p(H))
+        return rc, H
+
+    def nlls(self, p1, p2, H0):
+        a = np.ascontiguousarray(np.stack([p1["x"], p1["y"]], 1), np.float32)
+        b = np.ascontiguousarray(np.stack([p2["x"], p2["y"]], 1), np.float32)
+        H = np.zeros(9, np.float32)
+        H0 = np.ascontiguousarray(H0, np.float32)
+        rc = self.L.ref_nlls(_p(a), _p(b), len(a), _p(H0), _p(H))
+        return rc, H
+
+    def ransac2d(self, p1, p2, dist, sample_times, seed):
+        n = len(p1)
+        i1 = np.zeros(max(n, 1), SFPOINT)
+        i2 = np.zeros(max(n, 1), SFPOINT)
+        nin = C.c_int(0)
+        H = np.zeros(9, np.float32)
+        ok = self.L.ref_ransac2d(_p(p1), _p(p2), n, C.c_float(dist), sample_times, C.c_uint(seed),
+                                 _p(i1), _p(i2), C.byref(nin), _p(H))
+        return ok, i1[:nin.value].copy(), i2[:nin.value].copy(), H
+
+    def select(self, matches, kp1, kp2, nMatch, w, h, gx=3, gy=3):
+        matches = np.ascontiguousarray(matches, np.int32)
+        kp1 = np.ascontiguousarray(kp1, np.float32)
+        kp2 = np.ascontiguousarray(kp2, np.float32)
+        n = len(matches)
+        o1 = np.zeros(max(n, 1), SFPOINT)
+        o2 = np.zeros(max(n, 1), SFPOINT)
+        no = C.c_int(0)
+        self.L.ref_select_match_pairs(_p(matches), n, _p(kp1), len(kp1), _p(kp2), len(kp2), nMatch, w, h, gx, gy,
+                                      _p(o1), _p(o2), C.byref(no))
+        return o1[:no.value].copy(), o2[:no.value].copy()
+
+    def image_projection_transform(self, img, h9):
+        img = np.ascontiguousarray(img)
+        hh, ws = img.shape[0], img.strides[0]
+        ch = img.shape[2] if img.ndim == 3 else 1
+        w = img.shape[1]
+        h9 = np.ascontiguousarray(h9, np.float32).copy()
+        dst = C.c_void_p()
+        dw, dh, dws = C.c_int(), C.c_int(), C.c_int()
+        rc = self.L.ref_image_projection_transform(_p(img), w, hh, ws, ch, _p(h9), C.byref(dst), C.byref(dw), C.byref(dh), C.byref(dws))
+        if rc != 0 or not dst.value:
+            return rc, None
+        buf = np.ctypeslib.as_array(C.cast(dst, u8p), shape=(dh.value, dws.value)).copy()
+        self.L.ref_free_u8(dst)
+        return rc, (buf, dw.value, dh.value, dws.value)
+
+    def mosaic_images_refined(self, imgs, h9s):
+        n = len(imgs)
+        imgs = [np.ascontiguousarray(i) for i in imgs]
+        ptrs = (C.c_void_p * n)(*[i.ctypes.data for i in imgs])
+        w = np.array([i.shape[1] for i in imgs], np.int32)
+        h = np.array([i.shape[0] for i in imgs], np.int32)
+        ws = np.array([i.strides[0] for i in imgs], np.int32)
+        h9s = np.ascontiguousarray(h9s, np.float32)
+        cw, ch, cws = C.c_int(), C.c_int(), C.c_int()
+        self.L.ref_mosaic_images_refined(ptrs, _p(w), _p(h), _p(ws), n, _p(h9s), None, C.byref(cw), C.byref(ch), C.byref(cws))
+        canvas = np.zeros((ch.value, cws.value), np.uint8)
+        rc = self.L.ref_mosaic_images_refined(ptrs, _p(w), _p(h), _p(ws), n, _p(h9s), _p(canvas), C.byref(cw), C.byref(ch), C.byref(cws))
+        return rc, (canvas, cw.value, ch.value, cws.value)
+
+
+_ORC = None
+_REF = None
+
+
+def load_oracle():
+    global _ORC
+    if _ORC is None:
+        _ORC = Oracle(build_oracle())
+    return _ORC
+
+
+def load_ref():
+    global _REF
+    if _REF is None:
+        so = os.path.join(ORC_DIR, "_ref", "libref_oracle.so")
+        if not os.path.exists(so):
+            if os.path.isdir("/root/reference"):
+                subprocess.check_call(["bash", os.path.join(ORC_DIR, "ref", "build_ref.sh")])
+            else:
+                return None
+        _REF = Ref(so)
+    return _REF

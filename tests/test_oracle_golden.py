@@ -1,0 +1,80 @@
+"""CPU: the oracle restatement (oracle/*.c) against the golden vectors produced by the reference's
+own code (tests/golden/make_golden.py).  Bit-exact everywhere."""
+import numpy as np
+import pytest
+from tests import oracle_lib as ol
+from tests.golden_util import math_golden, warp_golden, bits
+from tests.synth import texture, warp_cases, mosaic_case
+
+
+def test_glibc_rand_stream_matches_libc(oracle):
+    import ctypes
+    libc = ctypes.CDLL("libc.so.6")
+    for seed in (0, 1, 12345, 2**31 + 5):
+        libc.srand(seed)
+        want = np.array([libc.rand() for _ in range(3000)])
+        assert np.array_equal(oracle.rand_stream(seed, 3000), want)
+
+
+def test_inverse_matrix(oracle):
+    g = math_golden()
+    for a, o, eps, (order, rc) in zip(g["inv_in"], g["inv_out"], g["inv_eps"], g["inv_rc"]):
+        rc2, o2 = oracle.inverse_matrix(a[:order, :order], float(eps))
+        assert rc2 == rc
+        if rc == 1:
+            assert np.array_equal(bits(o2), bits(o[:order, :order]))
+
+
+def test_solve_homography_and_nlls(oracle):
+    g = math_golden()
+    for p1, p2, n, H, N in zip(g["h_p1"], g["h_p2"], g["h_n"], g["h_H"], g["h_N"]):
+        rc, H2 = oracle.solve_homography(p1[:n].copy(), p2[:n].copy())
+        assert rc == 1 and np.array_equal(bits(H2), bits(H))
+        rc, N2 = oracle.nlls(p1[:n].copy(), p2[:n].copy(), H2)
+        assert np.array_equal(bits(N2), bits(N))
+
+
+def test_ransac2d(oracle):
+    g = math_golden()
+    for p1, p2, n, seed, ok, nin, ids, H in zip(g["r_p1"], g["r_p2"], g["r_n"], g["r_seed"], g["r_ok"], g["r_nin"], g["r_ids"], g["r_H"]):
+        ok2, i1, i2, H2 = oracle.ransac2d(p1[:n].copy(), p2[:n].copy(), 2.5, 1000, int(seed))
+        assert ok2 == ok and len(i1) == nin
+        assert np.array_equal(i1["id"], ids[:nin])
+        if nin >= 4:
+            assert np.array_equal(bits(H2), bits(H))
+
+
+def test_select_match_pairs(oracle):
+    g = math_golden()
+    for kp1, kp2, m, (w, h, K), nm, o1, o2, no in zip(g["s_kp1"], g["s_kp2"], g["s_m"], g["s_wh"], g["s_nm"], g["s_o1"], g["s_o2"], g["s_no"]):
+        a1, a2 = oracle.select(m[:K], kp1[:K], kp2[:K], int(nm), int(w), int(h))
+        assert len(a1) == no
+        assert np.array_equal(a1, o1[:no]) and np.array_equal(a2, o2[:no])
+
+
+def test_image_projection_transform(oracle):
+    g = warp_golden()
+    img = texture(320, 240, seed=3)
+    for k, H in enumerate(warp_cases()):
+        rc, (buf, dw, dh, dws) = oracle.image_projection_transform(img, H)
+        assert rc == 0 and [dw, dh, dws] == g[f"ipt{k}_dims"].tolist()
+        assert np.array_equal(buf, g[f"ipt{k}"])
+    gray = np.ascontiguousarray(img[..., 1])
+    rc, (buf, dw, dh, dws) = oracle.image_projection_transform(gray, warp_cases()[3])
+    assert [dw, dh, dws] == g["ipt_gray_dims"].tolist() and np.array_equal(buf, g["ipt_gray"])
+
+
+def test_mosaic_images_refined(oracle):
+    g = warp_golden()
+    imgs, h9s = mosaic_case()
+    rc, (canvas, cw, ch, cws) = oracle.mosaic_images_refined(imgs, h9s)
+    assert [cw, ch, cws] == g["mosaic_dims"].tolist() and np.array_equal(canvas, g["mosaic"])
+    h9s[2, 8] = 0       # the reference's "invalid image" convention (MosaicWithoutPos.cpp:4646-4652)
+    rc, (canvas, cw, ch, cws) = oracle.mosaic_images_refined(imgs, h9s)
+    assert [cw, ch, cws] == g["mosaic_skip_dims"].tolist() and np.array_equal(canvas, g["mosaic_skip"])
+
+
+def test_ransac_rejects_small_inputs(oracle):
+    p = ol.sfpoints(np.zeros((3, 2)))
+    ok, i1, i2, H = oracle.ransac2d(p, p, 2.5, 1000, 1)
+    assert ok == 0 and len(i1) == 0
