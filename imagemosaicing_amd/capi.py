@@ -1,0 +1,379 @@
+"""ctypes binding of libmi355mosaic.so (include/mi355_mosaic.h).  No torch types cross this boundary:
+device buffers are passed as integer addresses (e.g. tensor.data_ptr())."""
+import ctypes as C
+import os
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+SFPOINT = np.dtype([("x", "<f4"), ("y", "<f4"), ("id", "<i4")])
+KEYPOINT = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"),
+                     ("octave", "<i4"), ("class_id", "<i4")])
+DMATCH = np.dtype([("queryIdx", "<i4"), ("trainIdx", "<i4"), ("imgIdx", "<i4"), ("distance", "<f4")])
+MATCHPAIR = np.dtype([("ax", "<f4"), ("ay", "<f4"), ("aid", "<i4"), ("ai", "<i4"), ("af", "<i4"),
+                      ("bx", "<f4"), ("by", "<f4"), ("bid", "<i4"), ("bi", "<i4"), ("bf", "<i4")])
+PAIR_RESULT = np.dtype([("i", "<i4"), ("j", "<i4"), ("n_in", "<i4"), ("n_selected", "<i4"), ("ok", "<i4"),
+                        ("accepted", "<i4"), ("H", "<f4", (9,)), ("_pad", "<i4"),
+                        ("a", SFPOINT, (400,)), ("b", SFPOINT, (400,))])
+CHIPINFO = np.dtype([("x0", "<i4"), ("y0", "<i4"), ("w", "<i4"), ("h", "<i4"), ("img", "<i4"),
+                     ("sx", "<f4"), ("sy", "<f4"), ("quad", "<f4", (8,))])
+IMAGE_TRANSFORM = np.dtype([("m", "<f4", (9,)), ("fixed", "<i4")])
+assert SFPOINT.itemsize == 12 and KEYPOINT.itemsize == 28 and MATCHPAIR.itemsize == 40 and PAIR_RESULT.itemsize == 9664
+
+
+class Params(C.Structure):
+    _fields_ = [("nfeatures", C.c_int32), ("n_octave_layers", C.c_int32), ("contrast_threshold", C.c_float),
+                ("edge_threshold", C.c_float), ("sigma", C.c_float), ("max_selected", C.c_int32),
+                ("select_fraction", C.c_float), ("grid_x", C.c_int32), ("grid_y", C.c_int32), ("min_inliers", C.c_int32),
+                ("ransac_dist", C.c_float), ("sample_times", C.c_int32), ("pair_window", C.c_int32), ("ratio", C.c_float)]
+
+
+class Mi355Error(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("mi355 error %d: %s" % (code, msg))
+        self.code = code
+
+
+def lib_path():
+    return os.path.join(_HERE, "libmi355mosaic.so")
+
+
+def load_library():
+    """Loads the in-tree HIP library.  Fails loudly when it has not been built (python -m imagemosaicing_amd.build)."""
+    global _LIB
+    if _LIB is None:
+        p = lib_path()
+        if not os.path.exists(p):
+            raise ImportError("libmi355mosaic.so is not built: run `python -m imagemosaicing_amd.build` "
+                              "(there is no CPU fallback for the HIP path)")
+        L = C.CDLL(p)
+        L.mi355_last_error.restype = C.c_char_p
+        L.mi355_last_error.argtypes = [C.c_void_p]
+        L.mi355_create.argtypes = [C.POINTER(C.c_void_p), C.c_void_p, C.c_int]
+        L.mi355_destroy.argtypes = [C.c_void_p]
+        L.mi355_free.argtypes = [C.c_void_p]
+        _LIB = L
+    return _LIB
+
+
+def default_params():
+    p = Params()
+    load_library().mi355_default_params(C.byref(p))
+    return p
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def _img_geom(img):
+    img = np.ascontiguousarray(img, np.uint8)
+    h, w = img.shape[:2]
+    ch = img.shape[2] if img.ndim == 3 else 1
+    return img, w, h, img.strides[0], ch
+
+
+def _copy_out(ptr, nbytes, dtype):
+    """Copies nbytes from a library-owned host buffer into a fresh numpy array of dtype."""
+    if nbytes == 0:
+        return np.zeros(0, dtype)
+    raw = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(nbytes,)).copy()
+    return raw.view(dtype)
+
+
+class Context:
+    """One GPU context (mi355_create).  Methods are named after the reference functions they replace."""
+
+    def __init__(self, device=0, params=None):
+        self.L = load_library()
+        self._h = C.c_void_p()
+        rc = self.L.mi355_create(C.byref(self._h), C.byref(params) if params is not None else None, int(device))
+        if rc != 0:
+            raise Mi355Error(rc, (self.L.mi355_last_error(None) or b"").decode())
+        self.params = params if params is not None else default_params()
+
+    def close(self):
+        if self._h:
+            self.L.mi355_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc < 0:
+            raise Mi355Error(rc, (self.L.mi355_last_error(self._h) or b"").decode())
+        return rc
+
+    # ---- plumbing ----------------------------------------------------------------------------
+    def set_stream(self, hip_stream):
+        self._chk(self.L.mi355_set_stream(self._h, C.c_void_p(hip_stream or 0)))
+
+    def synchronize(self):
+        self._chk(self.L.mi355_synchronize(self._h))
+
+    def profile_enable(self, on=True):
+        self._chk(self.L.mi355_profile_enable(self._h, int(bool(on))))
+
+    def profile_reset(self):
+        self._chk(self.L.mi355_profile_reset(self._h))
+
+    def profile_get(self, cls):
+        ms, n, b = C.c_double(), C.c_int64(), C.c_double()
+        self._chk(self.L.mi355_profile_get(self._h, cls.encode(), C.byref(ms), C.byref(n), C.byref(b)))
+        return ms.value, n.value, b.value
+
+    # ---- features (SiftExtraction_Thread, MosaicWithoutPos.cpp:4832-4887) ------------------------
+    def SiftExtract(self, img_id, bgr, max_kp=None):
+        img, w, h, ws, ch = _img_geom(bgr)
+        assert ch == 3
+        max_kp = max_kp or int(self.params.nfeatures)
+        kp = np.zeros(max_kp, KEYPOINT)
+        desc = np.zeros((max_kp, 128), np.float32)
+        n = C.c_int(0)
+        self._chk(self.L.mi355_sift_extract(self._h, int(img_id), _p(img), w, h, ws, _p(kp), _p(desc), max_kp, C.byref(n)))
+        k = min(n.value, max_kp)
+        return kp[:k].copy(), desc[:k].copy()
+
+    def SiftExtractDev(self, img_id, d_bgr, w, h, ws):
+        n = C.c_int(0)
+        self._chk(self.L.mi355_sift_extract_dev(self._h, int(img_id), C.c_void_p(int(d_bgr)), int(w), int(h), int(ws), C.byref(n)))
+        return n.value
+
+    def GetFeatures(self, img_id, max_kp=4096):
+        kp = np.zeros(max_kp, KEYPOINT)
+        desc = np.zeros((max_kp, 128), np.float32)
+        n = C.c_int(0)
+        self._chk(self.L.mi355_get_features(self._h, int(img_id), _p(kp), _p(desc), max_kp, C.byref(n)))
+        return kp[:n.value].copy(), desc[:n.value].copy()
+
+    def SetFeatures(self, img_id, kp, desc, w, h):
+        kp = np.ascontiguousarray(kp, KEYPOINT)
+        desc = np.ascontiguousarray(desc, np.float32)
+        self._chk(self.L.mi355_set_features(self._h, int(img_id), _p(kp), _p(desc), len(kp), int(w), int(h)))
+
+    def DropFeatures(self, img_id=-1):
+        self._chk(self.L.mi355_drop_features(self._h, int(img_id)))
+
+    # ---- match (GetMatchedPairsOneToAllSIFTThread j-loop, MosaicWithoutPos.cpp:5084-5232) ----------
+    def MatchPairs(self, pairs, ransac_dist=2.5, seed=1):
+        pairs = np.ascontiguousarray(pairs, np.int32).reshape(-1, 2)
+        out = np.zeros(len(pairs), PAIR_RESULT)
+        self._chk(self.L.mi355_match_pairs(self._h, _p(pairs), len(pairs), C.c_float(ransac_dist), C.c_uint32(seed), _p(out)))
+        return out
+
+    def MatchPairsDev(self, pairs, d_out, ransac_dist=2.5, seed=1):
+        pairs = np.ascontiguousarray(pairs, np.int32).reshape(-1, 2)
+        self._chk(self.L.mi355_match_pairs_dev(self._h, _p(pairs), len(pairs), C.c_float(ransac_dist), C.c_uint32(seed), C.c_void_p(int(d_out))))
+
+    def BFMatch(self, img_i, img_j, sorted_=True, max_matches=2048):
+        m = np.zeros(max_matches, DMATCH)
+        d2 = np.zeros(max_matches, np.int32)
+        s2 = np.zeros(max_matches, np.int32)
+        n = C.c_int(0)
+        self._chk(self.L.mi355_bf_match(self._h, int(img_i), int(img_j), int(bool(sorted_)), _p(m), _p(d2), _p(s2), max_matches, C.byref(n)))
+        k = min(n.value, max_matches)
+        return m[:k].copy(), d2[:k].copy(), s2[:k].copy()
+
+    # ---- stand-alone reference functions ------------------------------------------------------------
+    def SelectMatchPairs(self, matches, kp1_xy, kp2_xy, nMatch, width, height, gridX=3, gridY=3):
+        """MosaicWithoutPos.cpp:4977-5028.  matches: DMATCH array (already sorted) or (n,2) int array."""
+        matches = np.asarray(matches)
+        if matches.dtype != DMATCH:
+            mm = np.zeros(len(matches), DMATCH)
+            mm["queryIdx"] = matches[:, 0]
+            mm["trainIdx"] = matches[:, 1]
+            matches = mm
+        matches = np.ascontiguousarray(matches)
+        kp1 = np.ascontiguousarray(kp1_xy, np.float32)
+        kp2 = np.ascontiguousarray(kp2_xy, np.float32)
+        v1 = np.zeros(400, SFPOINT)
+        v2 = np.zeros(400, SFPOINT)
+        n = C.c_int(0)
+        self._chk(self.L.mi355_select_grid(self._h, _p(matches), len(matches), _p(kp1), len(kp1), _p(kp2), len(kp2), int(nMatch),
+                                           int(width), int(height), int(gridX), int(gridY), _p(v1), _p(v2), C.byref(n)))
+        return v1[:n.value].copy(), v2[:n.value].copy()
+
+    def Ransac2D(self, p1, p2, fRansacDist=1.0, sampleTimes=1000, seed=1):
+        """mosaicimage.h:1729-2035.  Returns (ok, inliers1, inliers2, H[9])."""
+        p1 = np.ascontiguousarray(p1, SFPOINT)
+        p2 = np.ascontiguousarray(p2, SFPOINT)
+        n = len(p1)
+        i1 = np.zeros(400, SFPOINT)
+        i2 = np.zeros(400, SFPOINT)
+        nin = C.c_int(0)
+        H = np.zeros(9, np.float32)
+        ok = self._chk(self.L.mi355_ransac2d(self._h, _p(p1), _p(p2), n, C.c_float(fRansacDist), int(sampleTimes), C.c_uint32(seed),
+                                             _p(i1), _p(i2), C.byref(nin), _p(H)))
+        return ok, i1[:nin.value].copy(), i2[:nin.value].copy(), H
+
+    def ImageProjectionTransform(self, img, h9):
+        """MosaicImage.cpp:1613-1758.  Returns (rows x widthStep u8 buffer, width, height, widthStep)."""
+        img, w, h, ws, ch = _img_geom(img)
+        h9 = np.ascontiguousarray(h9, np.float32)
+        dst = C.c_void_p()
+        dw, dh, dws = C.c_int(), C.c_int(), C.c_int()
+        self._chk(self.L.mi355_warp_image(self._h, _p(img), w, h, ws, ch, _p(h9), C.byref(dst), C.byref(dw), C.byref(dh), C.byref(dws)))
+        buf = _copy_out(dst, dh.value * dws.value, np.uint8).reshape(dh.value, dws.value)
+        self.L.mi355_free(dst)
+        return buf, dw.value, dh.value, dws.value
+
+    def MosaicImagesRefined(self, imgs, h9s):
+        """CMosaicByPose::MosaicImagesRefined (float), MosaicWithoutPos.cpp:2194-2352."""
+        n = len(imgs)
+        imgs = [np.ascontiguousarray(i, np.uint8) for i in imgs]
+        ptrs = (C.c_void_p * n)(*[i.ctypes.data for i in imgs])
+        w = np.array([i.shape[1] for i in imgs], np.int32)
+        h = np.array([i.shape[0] for i in imgs], np.int32)
+        ws = np.array([i.strides[0] for i in imgs], np.int32)
+        h9s = np.ascontiguousarray(h9s, np.float32)
+        canvas = C.c_void_p()
+        cw, ch, cws = C.c_int(), C.c_int(), C.c_int()
+        self._chk(self.L.mi355_mosaic_refined(self._h, ptrs, _p(w), _p(h), _p(ws), n, _p(h9s), C.byref(canvas), C.byref(cw), C.byref(ch), C.byref(cws)))
+        buf = _copy_out(canvas, ch.value * cws.value, np.uint8).reshape(ch.value, cws.value)
+        self.L.mi355_free(canvas)
+        return buf, cw.value, ch.value, cws.value
+
+    def MosaicImagesRefinedDev(self, d_imgs, w, h, ws, h9s, d_canvas, cw, ch, cws, row0=0, rows=-1):
+        n = len(d_imgs)
+        ptrs = (C.c_void_p * n)(*[int(p) for p in d_imgs])
+        w = np.ascontiguousarray(w, np.int32)
+        h = np.ascontiguousarray(h, np.int32)
+        ws = np.ascontiguousarray(ws, np.int32)
+        h9s = np.ascontiguousarray(h9s, np.float32)
+        self._chk(self.L.mi355_mosaic_refined_dev(self._h, ptrs, _p(w), _p(h), _p(ws), n, _p(h9s), C.c_void_p(int(d_canvas)),
+                                                  int(cw), int(ch), int(cws), int(row0), int(rows if rows >= 0 else ch)))
+
+    def ChipsAndMasks(self, imgs, h9s, keep=None, find_masks=True):
+        """LaplacianPyramidBlending warp stage + FindMasksByDistMap (MosaicImage.cpp:2233-2460, 1761-1881)."""
+        n = len(imgs)
+        imgs = [np.ascontiguousarray(i, np.uint8) for i in imgs]
+        ptrs = (C.c_void_p * n)(*[i.ctypes.data for i in imgs])
+        w = np.array([i.shape[1] for i in imgs], np.int32)
+        h = np.array([i.shape[0] for i in imgs], np.int32)
+        ws = np.array([i.strides[0] for i in imgs], np.int32)
+        h9s = np.ascontiguousarray(h9s, np.float32)
+        keep_a = None if keep is None else np.ascontiguousarray(keep, np.uint8)
+        nch = C.c_int(0)
+        chips = C.c_void_p()
+        cimgs = C.POINTER(C.c_void_p)()
+        masks = C.POINTER(C.c_void_p)()
+        cw, ch = C.c_int(), C.c_int()
+        self._chk(self.L.mi355_chips_and_masks(self._h, ptrs, _p(w), _p(h), _p(ws), n, _p(h9s), _p(keep_a), int(bool(find_masks)),
+                                               C.byref(nch), C.byref(chips), C.byref(cimgs), C.byref(masks), C.byref(cw), C.byref(ch)))
+        nv = nch.value
+        info = _copy_out(chips, nv * CHIPINFO.itemsize, CHIPINFO)
+        out_c, out_m = [], []
+        for v in range(nv):
+            cwv, chv = int(info[v]["w"]), int(info[v]["h"])
+            cws_, mws = (cwv * 3 + 3) & ~3, (cwv + 3) & ~3
+            out_c.append(_copy_out(cimgs[v], chv * cws_, np.uint8).reshape(chv, cws_))
+            out_m.append(_copy_out(masks[v], chv * mws, np.uint8).reshape(chv, mws))
+            self.L.mi355_free(C.c_void_p(cimgs[v]))
+            self.L.mi355_free(C.c_void_p(masks[v]))
+        self.L.mi355_free(chips)
+        self.L.mi355_free(C.cast(cimgs, C.c_void_p))
+        self.L.mi355_free(C.cast(masks, C.c_void_p))
+        return dict(cw=cw.value, ch=ch.value, chips=info, chip_imgs=out_c, masks=out_m)
+
+
+# ---- host-only helpers (no ctx) ---------------------------------------------------------------------------
+def mosaic_layout(w, h, h9s):
+    L = load_library()
+    w = np.ascontiguousarray(w, np.int32)
+    h = np.ascontiguousarray(h, np.int32)
+    h9s = np.ascontiguousarray(h9s, np.float32)
+    cw, ch, cws = C.c_int(), C.c_int(), C.c_int()
+    dG = np.zeros(2, np.float32)
+    rc = L.mi355_mosaic_layout(_p(w), _p(h), len(w), _p(h9s), C.byref(cw), C.byref(ch), C.byref(cws), _p(dG))
+    if rc != 0:
+        raise Mi355Error(rc, "mosaic_layout")
+    return cw.value, ch.value, cws.value, dG
+
+
+def pair_schedule(n_images, window, rank=0, world=1):
+    L = load_library()
+    n = C.c_int(0)
+    L.mi355_pair_schedule(int(n_images), int(window), int(rank), int(world), None, 0, C.byref(n))
+    out = np.zeros((max(n.value, 1), 2), np.int32)
+    rc = L.mi355_pair_schedule(int(n_images), int(window), int(rank), int(world), _p(out), n.value, C.byref(n))
+    if rc != 0:
+        raise Mi355Error(rc, "pair_schedule")
+    return out[:n.value]
+
+
+def write_match_pairs(path, v):
+    v = np.ascontiguousarray(v, MATCHPAIR)
+    rc = load_library().mi355_write_match_pairs(path.encode(), _p(v), len(v))
+    if rc != 0:
+        raise Mi355Error(rc, "write_match_pairs")
+
+
+def load_match_pairs(path):
+    L = load_library()
+    ptr, n = C.c_void_p(), C.c_int(0)
+    rc = L.mi355_load_match_pairs(path.encode(), C.byref(ptr), C.byref(n))
+    if rc != 0:
+        raise Mi355Error(rc, "load_match_pairs")
+    out = _copy_out(ptr, n.value * 40, MATCHPAIR)
+    L.mi355_free(ptr)
+    return out
+
+
+def write_match_pairs_txt(path, v):
+    v = np.ascontiguousarray(v, MATCHPAIR)
+    rc = load_library().mi355_write_match_pairs_txt(path.encode(), _p(v), len(v))
+    if rc != 0:
+        raise Mi355Error(rc, "write_match_pairs_txt")
+
+
+def write_transforms(path, t):
+    t = np.ascontiguousarray(t, IMAGE_TRANSFORM)
+    rc = load_library().mi355_write_transforms(path.encode(), _p(t), len(t))
+    if rc != 0:
+        raise Mi355Error(rc, "write_transforms")
+
+
+def write_keypoints(path, kp):
+    kp = np.ascontiguousarray(kp, KEYPOINT)
+    rc = load_library().mi355_write_keypoints(path.encode(), _p(kp), len(kp))
+    if rc != 0:
+        raise Mi355Error(rc, "write_keypoints")
+
+
+def load_keypoints(path):
+    L = load_library()
+    ptr, n = C.c_void_p(), C.c_int(0)
+    rc = L.mi355_load_keypoints(path.encode(), C.byref(ptr), C.byref(n))
+    if rc != 0:
+        raise Mi355Error(rc, "load_keypoints")
+    out = _copy_out(ptr, n.value * 28, KEYPOINT)
+    L.mi355_free(ptr)
+    return out
+
+
+def results_to_match_pairs(results, fixed_flags=None):
+    L = load_library()
+    results = np.ascontiguousarray(results, PAIR_RESULT)
+    ff = None if fixed_flags is None else np.ascontiguousarray(fixed_flags, np.int32)
+    ptr, n = C.c_void_p(), C.c_int(0)
+    rc = L.mi355_results_to_match_pairs(_p(results), len(results), _p(ff), C.byref(ptr), C.byref(n))
+    if rc != 0:
+        raise Mi355Error(rc, "results_to_match_pairs")
+    out = _copy_out(ptr, n.value * 40, MATCHPAIR)
+    L.mi355_free(ptr)
+    return out
+
+
+def global_affine_align(match_pairs, n_images, fixed=None):
+    v = np.ascontiguousarray(match_pairs, MATCHPAIR)
+    ff = None if fixed is None else np.ascontiguousarray(fixed, np.int32)
+    out = np.zeros(n_images, IMAGE_TRANSFORM)
+    rc = load_library().mi355_global_affine_align(_p(v), len(v), int(n_images), _p(ff), _p(out))
+    if rc != 0:
+        raise Mi355Error(rc, "global_affine_align")
+    return out

@@ -1,0 +1,298 @@
+// csrc/api.hip -- the extern "C" surface of libmi355mosaic.so (include/mi355_mosaic.h): argument checks,
+// locking, host<->device staging around the kernels of warp.hip / ransac.hip / match.hip / sift.hip.
+// There is no CPU compute path in this library: without a usable gfx950 device mi355_create fails.
+#include "common.h"
+#include <new>
+
+static std::string g_create_error;
+
+extern "C" void mi355_default_params(mi355_params* p) {
+    if (!p) return;
+    p->nfeatures = 2000; p->n_octave_layers = 3; p->contrast_threshold = 0.01f; p->edge_threshold = 20.0f; p->sigma = 1.6f;
+    p->max_selected = 400; p->select_fraction = 0.3f; p->grid_x = 3; p->grid_y = 3; p->min_inliers = 30;
+    p->ransac_dist = 2.5f; p->sample_times = 1000; p->pair_window = 182; p->ratio = 0.0f;
+}
+
+void mi355_ctx::prof_begin(const char* cls, double alg_bytes) {
+    ProfClass& pc = prof[cls];
+    if (pc.used == pc.ev.size()) {
+        hipEvent_t a, b;
+        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+        pc.ev.emplace_back(a, b);
+    }
+    pc.bytes += alg_bytes;
+    (void)hipEventRecord(pc.ev[pc.used].first, stream);
+}
+void mi355_ctx::prof_end(const char* cls) {
+    ProfClass& pc = prof[cls];
+    if (pc.used < pc.ev.size()) { (void)hipEventRecord(pc.ev[pc.used].second, stream); pc.used++; }
+}
+
+extern "C" int mi355_create(mi355_ctx** out, const mi355_params* params, int device_ordinal) {
+    if (!out) return MI355_ERR_ARG;
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) { g_create_error = std::string("no HIP device: ") + hipGetErrorString(e); return MI355_ERR_DEVICE; }
+    if (device_ordinal < 0 || device_ordinal >= ndev) { g_create_error = "device ordinal out of range"; return MI355_ERR_ARG; }
+    hipDeviceProp_t prop;
+    e = hipGetDeviceProperties(&prop, device_ordinal);
+    if (e != hipSuccess) { g_create_error = hipGetErrorString(e); return MI355_ERR_DEVICE; }
+    if (std::string(prop.gcnArchName).find("gfx950") == std::string::npos) {
+        g_create_error = std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only";
+        return MI355_ERR_DEVICE;
+    }
+    e = hipSetDevice(device_ordinal);
+    if (e != hipSuccess) { g_create_error = hipGetErrorString(e); return MI355_ERR_DEVICE; }
+    mi355_ctx* c = new (std::nothrow) mi355_ctx();
+    if (!c) return MI355_ERR_NOMEM;
+    c->device = device_ordinal;
+    c->num_cu = prop.multiProcessorCount;
+    if (params) c->p = *params; else mi355_default_params(&c->p);
+    e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { g_create_error = hipGetErrorString(e); delete c; return MI355_ERR_DEVICE; }
+    c->stream = c->own_stream;
+    *out = c;
+    return MI355_OK;
+}
+
+extern "C" void mi355_destroy(mi355_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    mi_sift_release(ctx);
+    for (auto& kv : ctx->feats) kv.second.release();
+    for (auto& kv : ctx->ws) kv.second.release();
+    for (auto& kv : ctx->draw_tables) kv.second.release();
+    for (auto& kv : ctx->prof) for (auto& ev : kv.second.ev) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+}
+
+extern "C" const char* mi355_last_error(mi355_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+extern "C" int mi355_set_stream(mi355_ctx* ctx, void* hip_stream) {
+    if (!ctx) return MI355_ERR_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    (void)hipStreamSynchronize(ctx->stream);
+    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    return MI355_OK;
+}
+
+extern "C" int mi355_synchronize(mi355_ctx* ctx) {
+    if (!ctx) return MI355_ERR_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    MI_HIP(hipStreamSynchronize(ctx->stream));
+    return MI355_OK;
+}
+
+extern "C" void mi355_free(void* p) { free(p); }
+
+#define LOCKED_PROLOGUE                                  \
+    if (!ctx) return MI355_ERR_ARG;                      \
+    std::lock_guard<std::mutex> lk(ctx->mu);             \
+    if (hipSetDevice(ctx->device) != hipSuccess) { ctx->set_error("hipSetDevice failed"); return MI355_ERR_DEVICE; }
+
+// ---- features --------------------------------------------------------------------------------------------------
+extern "C" int mi355_sift_extract_dev(mi355_ctx* ctx, int img_id, const uint8_t* d_bgr, int w, int h, int width_step, int* n_kp) {
+    LOCKED_PROLOGUE
+    if (!d_bgr || w < 16 || h < 16 || width_step < 3 * w) { ctx->set_error("sift_extract: bad image geometry"); return MI355_ERR_ARG; }
+    return mi_sift_extract_dev(ctx, img_id, d_bgr, w, h, width_step, n_kp);
+}
+
+extern "C" int mi355_sift_extract(mi355_ctx* ctx, int img_id, const uint8_t* bgr, int w, int h, int width_step,
+                                  mi355_keypoint* kp, float* desc128, int max_kp, int* n_kp) {
+    int n = 0;
+    {
+        LOCKED_PROLOGUE
+        if (!bgr || w < 16 || h < 16 || width_step < 3 * w) { ctx->set_error("sift_extract: bad image geometry"); return MI355_ERR_ARG; }
+        DevBuf& dimg = ctx->buf("sift_host_img");
+        const size_t bytes = (size_t)width_step * h;
+        MI_HIP(dimg.reserve(bytes + 16));
+        MI_HIP(hipMemcpyAsync(dimg.p, bgr, bytes, hipMemcpyHostToDevice, ctx->stream));
+        int rc = mi_sift_extract_dev(ctx, img_id, dimg.as<uint8_t>(), w, h, width_step, &n);
+        if (rc != MI355_OK) return rc;
+    }
+    if (n_kp) *n_kp = n;
+    if (kp || desc128) return mi355_get_features(ctx, img_id, kp, desc128, max_kp, nullptr);
+    return MI355_OK;
+}
+
+extern "C" int mi355_set_features(mi355_ctx* ctx, int img_id, const mi355_keypoint* kp, const float* desc128, int n_kp, int w, int h) {
+    LOCKED_PROLOGUE
+    return mi_set_features(ctx, img_id, kp, desc128, n_kp, w, h);
+}
+
+extern "C" int mi355_drop_features(mi355_ctx* ctx, int img_id) {
+    LOCKED_PROLOGUE
+    MI_HIP(hipStreamSynchronize(ctx->stream));
+    if (img_id < 0) { for (auto& kv : ctx->feats) kv.second.release(); ctx->feats.clear(); }
+    else { auto it = ctx->feats.find(img_id); if (it != ctx->feats.end()) { it->second.release(); ctx->feats.erase(it); } }
+    return MI355_OK;
+}
+
+// ---- match ------------------------------------------------------------------------------------------------------
+extern "C" int mi355_match_pairs_dev(mi355_ctx* ctx, const int32_t* pairs_ij, int n_pairs, float ransac_dist, uint32_t seed, mi355_pair_result* d_out) {
+    LOCKED_PROLOGUE
+    if (n_pairs < 0 || (n_pairs > 0 && (!pairs_ij || !d_out))) return MI355_ERR_ARG;
+    return mi_match_pairs_dev(ctx, pairs_ij, n_pairs, ransac_dist, seed, d_out);
+}
+
+extern "C" int mi355_match_pairs(mi355_ctx* ctx, const int32_t* pairs_ij, int n_pairs, float ransac_dist, uint32_t seed, mi355_pair_result* out) {
+    LOCKED_PROLOGUE
+    if (n_pairs < 0 || (n_pairs > 0 && (!pairs_ij || !out))) return MI355_ERR_ARG;
+    if (n_pairs == 0) return MI355_OK;
+    DevBuf& dres = ctx->buf("pair_results");
+    MI_HIP(dres.reserve(sizeof(mi355_pair_result) * (size_t)n_pairs));
+    int rc = mi_match_pairs_dev(ctx, pairs_ij, n_pairs, ransac_dist, seed, dres.as<mi355_pair_result>());
+    if (rc != MI355_OK) return rc;
+    MI_HIP(hipMemcpyAsync(out, dres.p, sizeof(mi355_pair_result) * (size_t)n_pairs, hipMemcpyDeviceToHost, ctx->stream));
+    MI_HIP(hipStreamSynchronize(ctx->stream));
+    return MI355_OK;
+}
+
+extern "C" int mi355_bf_match(mi355_ctx* ctx, int img_i, int img_j, int sorted, mi355_dmatch* matches, int32_t* d2, int32_t* second_d2,
+                              int max_matches, int* n_matches) {
+    LOCKED_PROLOGUE
+    return mi_bf_match(ctx, img_i, img_j, sorted, matches, d2, second_d2, max_matches, n_matches);
+}
+
+extern "C" int mi355_select_grid(mi355_ctx* ctx, const mi355_dmatch* sorted, int n, const float* kp1_xy, int n_kp1,
+                                 const float* kp2_xy, int n_kp2, int nMatch, int width, int height, int gridX, int gridY,
+                                 mi355_sfpoint* v1, mi355_sfpoint* v2, int* n_out) {
+    LOCKED_PROLOGUE
+    if (nMatch < 0 || nMatch > MI355_MAX_SELECTED) { ctx->set_error("select_grid: nMatch must be in [0,400]"); return MI355_ERR_ARG; }
+    return mi_select_grid(ctx, sorted, n, kp1_xy, n_kp1, kp2_xy, n_kp2, nMatch, width, height, gridX, gridY, v1, v2, n_out);
+}
+
+extern "C" int mi355_ransac2d(mi355_ctx* ctx, const mi355_sfpoint* p1, const mi355_sfpoint* p2, int n, float dist, int sample_times,
+                              uint32_t seed, mi355_sfpoint* in1, mi355_sfpoint* in2, int* n_in, float H[9]) {
+    LOCKED_PROLOGUE
+    if (!n_in || !H) return MI355_ERR_ARG;
+    *n_in = 0;
+    for (int i = 0; i < 9; i++) H[i] = 0.0f;
+    if (n <= 0 || !p1 || !p2) return 0;                                // Ransac2D: empty input -> false (mosaicimage.h:1739-1744)
+    if (n > MI355_MAX_SELECTED) { ctx->set_error("ransac2d: at most 400 correspondences (maxNum, MosaicWithoutPos.cpp:5146)"); return MI355_ERR_ARG; }
+    DevBuf& d1 = ctx->buf("r1_p1"); DevBuf& d2 = ctx->buf("r1_p2"); DevBuf& dn = ctx->buf("r1_n"); DevBuf& dres = ctx->buf("pair_results");
+    MI_HIP(d1.reserve(sizeof(mi355_sfpoint) * MI355_MAX_SELECTED)); MI_HIP(d2.reserve(sizeof(mi355_sfpoint) * MI355_MAX_SELECTED));
+    MI_HIP(dn.reserve(sizeof(int))); MI_HIP(dres.reserve(sizeof(mi355_pair_result)));
+    MI_HIP(hipMemcpyAsync(d1.p, p1, sizeof(mi355_sfpoint) * n, hipMemcpyHostToDevice, ctx->stream));
+    MI_HIP(hipMemcpyAsync(d2.p, p2, sizeof(mi355_sfpoint) * n, hipMemcpyHostToDevice, ctx->stream));
+    MI_HIP(hipMemcpyAsync(dn.p, &n, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    int rc = mi_ransac_batch(ctx, d1.as<mi355_sfpoint>(), d2.as<mi355_sfpoint>(), dn.as<int>(), &n, 1, MI355_MAX_SELECTED, dist, sample_times, seed,
+                             dres.as<mi355_pair_result>());
+    if (rc != MI355_OK) return rc;
+    mi355_pair_result* r = (mi355_pair_result*)malloc(sizeof(mi355_pair_result));
+    if (!r) return MI355_ERR_NOMEM;
+    hipError_t e = hipMemcpyAsync(r, dres.p, sizeof(mi355_pair_result), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) { free(r); ctx->set_error(hipGetErrorString(e)); return MI355_ERR_DEVICE; }
+    *n_in = r->n_in;
+    if (in1) memcpy(in1, r->a, sizeof(mi355_sfpoint) * r->n_in);
+    if (in2) memcpy(in2, r->b, sizeof(mi355_sfpoint) * r->n_in);
+    memcpy(H, r->H, sizeof(float) * 9);
+    const int ok = r->ok;
+    free(r);
+    return ok;
+}
+
+// ---- warps ------------------------------------------------------------------------------------------------------
+extern "C" int mi355_warp_image(mi355_ctx* ctx, const uint8_t* src, int w, int h, int ws, int ch, const float h9[9],
+                                uint8_t** dst, int* dw, int* dh, int* dws) {
+    LOCKED_PROLOGUE
+    if (!dst || !dw || !dh || !dws) return MI355_ERR_ARG;
+    return mi_warp_image(ctx, src, w, h, ws, ch, h9, dst, dw, dh, dws);
+}
+
+extern "C" int mi355_mosaic_refined_dev(mi355_ctx* ctx, const uint8_t* const* d_imgs, const int* w, const int* h, const int* ws, int n,
+                                        const float* h9s, uint8_t* d_canvas, int cw, int ch, int cws, int row0, int rows) {
+    LOCKED_PROLOGUE
+    if (!d_imgs || !w || !h || !ws || !h9s || !d_canvas || n <= 0) return MI355_ERR_ARG;
+    return mi_mosaic_refined_dev(ctx, d_imgs, w, h, ws, n, h9s, d_canvas, cw, ch, cws, row0, rows);
+}
+
+extern "C" int mi355_mosaic_refined(mi355_ctx* ctx, const uint8_t* const* imgs, const int* w, const int* h, const int* ws, int n,
+                                    const float* h9s, uint8_t** canvas, int* cw, int* ch, int* cws) {
+    LOCKED_PROLOGUE
+    if (!imgs || !w || !h || !ws || !h9s || !canvas || !cw || !ch || !cws) return MI355_ERR_ARG;
+    if (n <= 1) { ctx->set_error("mosaic_refined: needs more than one image"); return MI355_ERR_FAILED; }   // MergeImagesRefined convention (:2164-2167)
+    int lw, lh, lws;
+    int rc = mi355_mosaic_layout(w, h, n, h9s, &lw, &lh, &lws, nullptr);
+    if (rc != MI355_OK) { ctx->set_error("mosaic_refined: empty canvas"); return rc; }
+    // stage every contributing image in HBM (frames stay resident: 288 GB), then composite in index order
+    size_t total = 0;
+    std::vector<size_t> off(n, 0);
+    for (int k = 0; k < n; k++) { if (h9s[9 * k + 8] == 0.0f) continue; if (!imgs[k] || w[k] < 2 || h[k] < 2 || ws[k] < 3 * w[k]) return MI355_ERR_ARG; off[k] = total; total += ((size_t)ws[k] * h[k] + 255) & ~(size_t)255; }
+    DevBuf& dall = ctx->buf("mosaic_srcs");
+    DevBuf& dcan = ctx->buf("mosaic_canvas");
+    MI_HIP(dall.reserve(total + 16));
+    MI_HIP(dcan.reserve((size_t)lws * lh));
+    std::vector<const uint8_t*> dptr(n, nullptr);
+    for (int k = 0; k < n; k++) {
+        if (h9s[9 * k + 8] == 0.0f) continue;
+        dptr[k] = dall.as<uint8_t>() + off[k];
+        MI_HIP(hipMemcpyAsync((void*)dptr[k], imgs[k], (size_t)ws[k] * h[k], hipMemcpyHostToDevice, ctx->stream));
+    }
+    rc = mi_mosaic_refined_dev(ctx, dptr.data(), w, h, ws, n, h9s, dcan.as<uint8_t>(), lw, lh, lws, 0, lh);
+    if (rc != MI355_OK) return rc;
+    uint8_t* out = (uint8_t*)malloc((size_t)lws * lh);
+    if (!out) return MI355_ERR_NOMEM;
+    hipError_t e = hipMemcpyAsync(out, dcan.p, (size_t)lws * lh, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) { free(out); ctx->set_error(hipGetErrorString(e)); return MI355_ERR_DEVICE; }
+    *canvas = out; *cw = lw; *ch = lh; *cws = lws;
+    return MI355_OK;
+}
+
+extern "C" int mi355_chips_and_masks(mi355_ctx* ctx, const uint8_t* const* imgs, const int* w, const int* h, const int* ws, int n,
+                                     const float* h9s, const uint8_t* keep, int find_masks,
+                                     int* n_chips, mi355_chip_info** chips, uint8_t*** chip_imgs, uint8_t*** masks, int* canvas_w, int* canvas_h) {
+    LOCKED_PROLOGUE
+    return mi_chips_and_masks(ctx, imgs, w, h, ws, n, h9s, keep, find_masks, n_chips, chips, chip_imgs, masks, canvas_w, canvas_h);
+}
+
+// ---- measurement hooks --------------------------------------------------------------------------------------------
+extern "C" int mi355_profile_enable(mi355_ctx* ctx, int on) {
+    LOCKED_PROLOGUE
+    ctx->profiling = on != 0;
+    return MI355_OK;
+}
+extern "C" int mi355_profile_reset(mi355_ctx* ctx) {
+    LOCKED_PROLOGUE
+    MI_HIP(hipStreamSynchronize(ctx->stream));
+    for (auto& kv : ctx->prof) { kv.second.used = 0; kv.second.bytes = 0.0; }
+    return MI355_OK;
+}
+extern "C" int mi355_profile_get(mi355_ctx* ctx, const char* kernel_class, double* total_ms, int64_t* launches, double* alg_bytes) {
+    LOCKED_PROLOGUE
+    if (!kernel_class) return MI355_ERR_ARG;
+    MI_HIP(hipStreamSynchronize(ctx->stream));
+    double ms = 0.0; int64_t cnt = 0; double bytes = 0.0;
+    auto it = ctx->prof.find(kernel_class);
+    if (it != ctx->prof.end()) {
+        for (size_t i = 0; i < it->second.used; i++) {
+            float t = 0.0f;
+            if (hipEventElapsedTime(&t, it->second.ev[i].first, it->second.ev[i].second) == hipSuccess) ms += t;
+        }
+        cnt = (int64_t)it->second.used; bytes = it->second.bytes;
+    }
+    if (total_ms) *total_ms = ms;
+    if (launches) *launches = cnt;
+    if (alg_bytes) *alg_bytes = bytes;
+    return MI355_OK;
+}
+
+// ---- multi-GPU pair schedule ----------------------------------------------------------------------------------------
+extern "C" int mi355_pair_schedule(int n_images, int window, int rank, int world, int32_t* pairs_ij, int max_pairs, int* n_pairs) {
+    if (n_images < 0 || window < 2 || world < 1 || rank < 0 || rank >= world || !n_pairs) return MI355_ERR_ARG;
+    int cnt = 0;
+    for (int i = rank; i < n_images; i += world) {                       // MosaicWithoutPos.cpp:5066 (thread k takes i = k mod T)
+        const int jEnd = n_images < i + window ? n_images : i + window;   // :5083
+        for (int j = i + 1; j < jEnd; j++) {
+            if (pairs_ij && cnt < max_pairs) { pairs_ij[2 * cnt] = i; pairs_ij[2 * cnt + 1] = j; }
+            cnt++;
+        }
+    }
+    *n_pairs = cnt;
+    return (pairs_ij && cnt > max_pairs) ? MI355_ERR_ARG : MI355_OK;
+}

@@ -1,0 +1,110 @@
+// csrc/common.h -- internal declarations shared by the HIP translation units of libmi355mosaic.so
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <cstdlib>
+#include <map>
+#include <mutex>
+#include <string>
+#include <unordered_map>
+#include <vector>
+#include "../../include/mi355_mosaic.h"
+
+#define MI_HIP(call)                                                                       \
+    do {                                                                                   \
+        hipError_t e_ = (call);                                                            \
+        if (e_ != hipSuccess) {                                                            \
+            ctx->set_error(std::string(#call) + ": " + hipGetErrorString(e_));             \
+            return MI355_ERR_DEVICE;                                                       \
+        }                                                                                  \
+    } while (0)
+
+// grow-only device buffer (workspaces live as long as the ctx: no hipMalloc in steady state)
+struct DevBuf {
+    void*  p = nullptr;
+    size_t cap = 0;
+    hipError_t reserve(size_t bytes) {
+        if (bytes <= cap) return hipSuccess;
+        if (p) { hipError_t e = hipFree(p); if (e != hipSuccess) return e; p = nullptr; cap = 0; }
+        size_t want = bytes + bytes / 4 + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+// device-resident features of one image (what the reference keeps in d:/feature_temp files)
+struct Features {
+    int n = 0;          // keypoints
+    int npad = 0;       // rows of the bf16 matrix (multiple of 64, zero padded)
+    int w = 0, h = 0;   // image size (grid selection needs it)
+    DevBuf kp;          // n x mi355_keypoint
+    DevBuf xy;          // n x float2
+    DevBuf d8;          // n x 128 u8   (the integers OpenCV's SIFT stores in its float Mat)
+    DevBuf bf;          // npad x 128 bf16 (same integers, exact in bf16)
+    DevBuf nrm;         // npad x int32  squared norms
+    void release() { kp.release(); xy.release(); d8.release(); bf.release(); nrm.release(); }
+};
+
+struct ProfClass {
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
+    size_t used = 0;
+    double bytes = 0.0;
+};
+
+struct SiftWork;   // sift.hip
+
+struct mi355_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;      // the stream every kernel is launched on
+    hipStream_t own_stream = nullptr;  // created by the ctx
+    std::mutex mu;
+    mi355_params p;
+    std::string err;
+    std::unordered_map<int, Features> feats;
+    std::map<std::string, DevBuf> ws;                  // named grow-only workspaces
+    std::map<std::pair<uint32_t, int>, DevBuf> draw_tables;   // (seed, n) -> RANSAC draw table
+    bool profiling = false;
+    std::map<std::string, ProfClass> prof;
+    SiftWork* sift = nullptr;
+    int num_cu = 256;
+
+    void set_error(const std::string& s) { err = s; }
+    DevBuf& buf(const std::string& name) { return ws[name]; }
+    // profiling brackets
+    void prof_begin(const char* cls, double alg_bytes);
+    void prof_end(const char* cls);
+};
+
+struct ProfScope {
+    mi355_ctx* c; const char* cls;
+    ProfScope(mi355_ctx* c_, const char* cls_, double bytes) : c(c_), cls(cls_) { if (c->profiling) c->prof_begin(cls, bytes); }
+    ~ProfScope() { if (c->profiling) c->prof_end(cls); }
+};
+
+// ---- internal entry points implemented by the .hip files (ctx lock already held) -----------------------
+int mi_warp_image(mi355_ctx*, const uint8_t* src, int w, int h, int ws, int ch, const float* h9,
+                  uint8_t** dst, int* dw, int* dh, int* dws);
+int mi_mosaic_refined_dev(mi355_ctx*, const uint8_t* const* d_imgs, const int* w, const int* h, const int* ws, int n,
+                          const float* h9s, uint8_t* d_canvas, int cw, int ch, int cws, int row0, int rows);
+int mi_chips_and_masks(mi355_ctx*, const uint8_t* const* imgs, const int* w, const int* h, const int* ws, int n,
+                       const float* h9s, const uint8_t* keep, int find_masks, int* n_chips, mi355_chip_info** chips,
+                       uint8_t*** chip_imgs, uint8_t*** masks, int* cw, int* ch);
+int mi_ransac_batch(mi355_ctx*, const mi355_sfpoint* d_p1, const mi355_sfpoint* d_p2, const int* d_n, const int* h_n,
+                    int n_pairs, int stride, float dist, int sample_times, uint32_t seed, mi355_pair_result* d_out);
+int mi_match_pairs_dev(mi355_ctx*, const int32_t* pairs, int n_pairs, float dist, uint32_t seed, mi355_pair_result* d_out);
+int mi_bf_match(mi355_ctx*, int img_i, int img_j, int sorted, mi355_dmatch* matches, int32_t* d2, int32_t* second, int maxm, int* nm);
+int mi_select_grid(mi355_ctx*, const mi355_dmatch* sorted, int n, const float* kp1, int nk1, const float* kp2, int nk2,
+                   int nMatch, int width, int height, int gx, int gy, mi355_sfpoint* v1, mi355_sfpoint* v2, int* n_out);
+int mi_set_features(mi355_ctx*, int img_id, const mi355_keypoint* kp, const float* desc, int n, int w, int h);
+int mi_finish_features(mi355_ctx*, Features& f);   // builds xy / bf16 / norms from kp + d8 on device
+int mi_sift_extract_dev(mi355_ctx*, int img_id, const uint8_t* d_bgr, int w, int h, int ws, int* n_kp);
+void mi_sift_release(mi355_ctx*);
+
+// host helpers
+int  mi_inverse_matrix_host(const float* src, int order, float* dst, float eps);   // matrix.h:147-296 (host side of the warps)
+void mi_glibc_draw_table(uint32_t seed, int n, int max_draws, uint16_t* out4);       // mosaicimage.h:1777-1813

@@ -1,0 +1,207 @@
+// csrc/hmath.h -- float32 homography arithmetic with the reference's operation order, usable from host
+// and device code.  The translation units including this header are compiled with -ffp-contract=off and
+// HIP's default correctly-rounded fp32 division / sqrt, so every operation below is one IEEE rounding on
+// both the x86 host and gfx950: results are bit-identical to the reference compiled with g++ (SSE2).
+//
+// Reference semantics reproduced here (paths relative to code/MosaicingCode/mosaicing/):
+//   InverseMatrix                       matrix.h:147-296   (first-pivot Gauss-Jordan + exact-1 row permutation)
+//   MulMatrix                           matrix.h:93-120    (acc = 0; acc += a*b, ascending k)
+//   SolveLinearLeastSquare2             matrix.h:334-403   (explicit A^T, (A^T A)^-1 A^T b, eps 1e-20)
+//   SolveHomographyMatrix               matrix.h:783-877   (H[8] = max residual, double bookkeeping)
+//   NonlinearLeastSquareProjection2     LeastSquare.h:353-531
+//   ApplyProjectMat2 / 3 / 9            matrix.h:1003-1036 ; ApplyProject9  MosaicWithoutPos.h:331-336
+#pragma once
+#include <hip/hip_runtime.h>
+#include <math.h>
+
+#define HD __host__ __device__ __forceinline__
+
+namespace hm {
+
+// reciprocal-multiply form with implicit m8 = 1 (ApplyProjectMat2)
+HD void apply_recip1(const float* M, float x, float y, float& X, float& Y) {
+    float inv = 1.0f / (M[6] * x + M[7] * y + 1.0f);
+    X = (M[0] * x + M[1] * y + M[2]) * inv;
+    Y = (M[3] * x + M[4] * y + M[5]) * inv;
+}
+// true-division form with implicit m8 = 1 (ApplyProjectMat3)
+HD void apply_div1(const float* M, float x, float y, float& X, float& Y) {
+    X = (M[0] * x + M[1] * y + M[2]) / (M[6] * x + M[7] * y + 1.0f);
+    Y = (M[3] * x + M[4] * y + M[5]) / (M[6] * x + M[7] * y + 1.0f);
+}
+// two true divisions with explicit m8 (ApplyProject9 and the inline spellings in the warps)
+HD void apply_div9(const float* M, float x, float y, float& X, float& Y) {
+    X = (M[0] * x + M[1] * y + M[2]) / (M[6] * x + M[7] * y + M[8]);
+    Y = (M[3] * x + M[4] * y + M[5]) / (M[6] * x + M[7] * y + M[8]);
+}
+// one reciprocal with explicit m8 (ApplyProjectMat9)
+HD void apply_recip9(const float* M, float x, float y, float& X, float& Y) {
+    float inv = 1.0f / (M[6] * x + M[7] * y + M[8]);
+    X = (M[0] * x + M[1] * y + M[2]) * inv;
+    Y = (M[3] * x + M[4] * y + M[5]) * inv;
+}
+
+// InverseMatrix.  t: caller scratch of 2*order*order floats.  Returns 1 ok, 0 no pivot, -1 bad order.
+template <int MAXO>
+HD int inverse_matrix(const float* src, int order, float* dst, float eps, float* t) {
+    if (order > 13 || order < 2 || order > MAXO) return -1;
+    const int o2 = order * 2;
+    bool used[MAXO];
+    for (int i = 0; i < order * o2; i++) t[i] = 0.0f;
+    for (int i = 0; i < order; i++) {
+        used[i] = false;
+        t[i * o2 + order + i] = 1.0f;
+        for (int j = 0; j < order; j++) t[i * o2 + j] = src[i * order + j];
+    }
+    for (int i = 0; i < order; i++) {
+        float ei = 0.0f;
+        int rowI = 0;
+        for (int j = 0; j < order; j++) {
+            if (used[j]) continue;
+            if (fabsf(t[j * o2 + i]) > eps) { used[j] = true; ei = t[j * o2 + i]; rowI = j; break; }
+        }
+        if (fabsf(ei) < eps) return 0;
+        for (int c = 0; c < o2; c++) t[rowI * o2 + c] = t[rowI * o2 + c] / ei;
+        for (int j = 0; j < order; j++) {
+            if (j == rowI) continue;
+            if (fabsf(t[j * o2 + i]) < eps) continue;
+            float ne = -t[j * o2 + i];
+            for (int c = 0; c < o2; c++) {
+                float prod = ne * t[rowI * o2 + c];
+                t[j * o2 + c] = t[j * o2 + c] + prod;
+            }
+        }
+    }
+    for (int r = 0; r < order; r++) {
+        int target = -1;
+        for (int i = 0; i < order; i++)
+            if (t[i * o2 + r] == 1.0f) { target = i; break; }
+        if (target >= 0 && target != r)
+            for (int j = 0; j < o2; j++) { float s = t[r * o2 + j]; t[r * o2 + j] = t[target * o2 + j]; t[target * o2 + j] = s; }
+    }
+    for (int i = 0; i < order; i++)
+        for (int j = 0; j < order; j++) dst[i * order + j] = t[i * o2 + order + j];
+    return 1;
+}
+
+// 4-point SolveHomographyMatrix: p = {x1,y1,x2,y2} x 4 (1 = target image i, 2 = source image j).
+// scratch: >= 64+64+128+64 = 320 floats.
+HD void solve_h4(const float* p, float* H, float* scratch) {
+    float* A = scratch;            // 8x8
+    float* ATA = scratch + 64;     // 8x8
+    float* t = scratch + 128;      // 8x16
+    float* inv = scratch + 256;    // 8x8
+    float B[8];
+    for (int i = 0; i < 64; i++) A[i] = 0.0f;
+    for (int r = 0; r < 4; r++) {
+        float x1 = p[4 * r], y1 = p[4 * r + 1], x2 = p[4 * r + 2], y2 = p[4 * r + 3];
+        float* a0 = A + 2 * r * 8;
+        float* a1 = A + (2 * r + 1) * 8;
+        a0[0] = x2; a0[1] = y2; a0[2] = 1.0f; a0[6] = (-x1) * x2; a0[7] = (-x1) * y2;
+        a1[3] = x2; a1[4] = y2; a1[5] = 1.0f; a1[6] = (-y1) * x2; a1[7] = (-y1) * y2;
+        B[2 * r] = x1; B[2 * r + 1] = y1;
+    }
+    // ATA = A^T A
+    for (int r = 0; r < 8; r++)
+        for (int c = 0; c < 8; c++) {
+            float acc = 0.0f;
+            for (int k = 0; k < 8; k++) { float pr = A[k * 8 + r] * A[k * 8 + c]; acc = acc + pr; }
+            ATA[r * 8 + c] = acc;
+        }
+    for (int i = 0; i < 64; i++) inv[i] = 0.0f;
+    inverse_matrix<8>(ATA, 8, inv, 1e-20f, t);          // failure ignored like matrix.h:377 (inv stays 0)
+    // invAT = inv * A^T (8x8), reuse ATA storage
+    float* invAT = ATA;
+    for (int r = 0; r < 8; r++)
+        for (int c = 0; c < 8; c++) {
+            float acc = 0.0f;
+            for (int k = 0; k < 8; k++) { float pr = inv[r * 8 + k] * A[c * 8 + k]; acc = acc + pr; }
+            invAT[r * 8 + c] = acc;
+        }
+    for (int r = 0; r < 8; r++) {
+        float acc = 0.0f;
+        for (int k = 0; k < 8; k++) { float pr = invAT[r * 8 + k] * B[k]; acc = acc + pr; }
+        H[r] = acc;
+    }
+    double emax = 0.0;
+    for (int i = 0; i < 4; i++) {
+        float fx, fy;
+        apply_recip1(H, p[4 * i + 2], p[4 * i + 3], fx, fy);
+        double dx = (double)p[4 * i] - (double)fx, dy = (double)p[4 * i + 1] - (double)fy;
+        double d = sqrt(dx * dx + dy * dy);
+        if (d > emax) emax = d;
+    }
+    H[8] = (float)emax;
+}
+
+// 4-point NonlinearLeastSquareProjection2 (stop 1e-10f). scratch: >= 320 floats.
+HD void nlls4(const float* p, const float* H0, float* Hout, float* scratch) {
+    float* J = scratch;            // 8x8 (2N x 8 with N = 4)
+    float* T1 = scratch + 64;      // J^T J
+    float* t = scratch + 128;      // 8x16
+    float* T2 = scratch + 256;     // inverse (stale contents survive a failed inversion, zero initially)
+    float w[8], C[8], dX[8];
+    for (int i = 0; i < 64; i++) T2[i] = 0.0f;
+    for (int i = 0; i < 8; i++) w[i] = H0[i];
+    for (int it = 0; it < 15; it++) {
+        for (int i = 0; i < 4; i++) {
+            float x2 = p[4 * i], y2 = p[4 * i + 1], x1 = p[4 * i + 2], y1 = p[4 * i + 3];
+            float d = w[6] * x1 + w[7] * y1 + 1.0f;
+            float nx = w[0] * x1 + w[1] * y1 + w[2];
+            float ny = w[3] * x1 + w[4] * y1 + w[5];
+            float* j = J + i * 16;
+            j[0] = x1 / d; j[1] = y1 / d; j[2] = 1.0f / d; j[3] = 0.0f; j[4] = 0.0f; j[5] = 0.0f;
+            j[6] = ((-x1) * nx) / (d * d); j[7] = ((-y1) * nx) / (d * d);
+            j[8] = 0.0f; j[9] = 0.0f; j[10] = 0.0f; j[11] = x1 / d; j[12] = y1 / d; j[13] = 1.0f / d;
+            j[14] = ((-x1) * ny) / (d * d); j[15] = ((-y1) * ny) / (d * d);
+            C[2 * i] = x2 - nx / d; C[2 * i + 1] = y2 - ny / d;
+        }
+        for (int r = 0; r < 8; r++)
+            for (int c = 0; c < 8; c++) {
+                float acc = 0.0f;
+                for (int k = 0; k < 8; k++) { float pr = J[k * 8 + r] * J[k * 8 + c]; acc = acc + pr; }
+                T1[r * 8 + c] = acc;
+            }
+        inverse_matrix<8>(T1, 8, T2, 1e-6f, t);
+        // JL = T2 * J^T (8x8) into T1, then dX = JL * C
+        for (int r = 0; r < 8; r++)
+            for (int c = 0; c < 8; c++) {
+                float acc = 0.0f;
+                for (int k = 0; k < 8; k++) { float pr = T2[r * 8 + k] * J[c * 8 + k]; acc = acc + pr; }
+                T1[r * 8 + c] = acc;
+            }
+        bool done = true;
+        for (int r = 0; r < 8; r++) {
+            float acc = 0.0f;
+            for (int k = 0; k < 8; k++) { float pr = T1[r * 8 + k] * C[k]; acc = acc + pr; }
+            dX[r] = acc;
+            w[r] = w[r] + acc;
+            if (!(fabsf(acc) < 1e-10f)) done = false;
+        }
+        if (done) break;
+    }
+    for (int i = 0; i < 8; i++) Hout[i] = w[i];
+    float emax = 0.0f;
+    for (int i = 0; i < 4; i++) {
+        float fx, fy;
+        apply_recip1(Hout, p[4 * i + 2], p[4 * i + 3], fx, fy);
+        float dx = p[4 * i] - fx, dy = p[4 * i + 1] - fy;
+        float d = sqrtf(dx * dx + dy * dy);
+        if (d > emax) emax = d;
+    }
+    Hout[8] = emax;
+}
+
+// the pixel expression of every warp (MosaicWithoutPos.cpp:2331-2334, MosaicImage.cpp:1715-1719):
+// (uchar)( s00*(1-p)*(1-q) + s01*(1-p)*q + s10*p*(1-q) + s11*p*q ), terms ((s*a)*b), summed left to right
+HD unsigned char bilin(float s00, float s01, float s10, float s11, float p, float q) {
+    float omp = 1.0f - p, omq = 1.0f - q;
+    float t0 = (s00 * omp) * omq;
+    float t1 = (s01 * omp) * q;
+    float t2 = (s10 * p) * omq;
+    float t3 = (s11 * p) * q;
+    float v = ((t0 + t1) + t2) + t3;
+    return (unsigned char)(int)v;
+}
+
+}  // namespace hm

@@ -1,0 +1,205 @@
+// csrc/host_io.cpp -- the formats and the caller either side of the hot path.
+// Host-only code (no device work): byte-compatible readers/writers of the reference's files and the
+// linear system of the global affine alignment.
+//
+//   matchPairs.match   WriteMatchPairs / LoadMatchPairs     MosaicWithoutPos.cpp:4736-4749, 4774-4797
+//   matchPairs.txt     WriteMatchPairs_ASC2                 MosaicWithoutPos.cpp:4751-4772
+//   tran0.txt          OutTransform                         MosaicWithoutPos.cpp:2798-2818
+//   keypoint_%d.key    WriteSurfKeyPoints/LoadSurfKeyPoints MosaicWithoutPos.cpp:4682-4734
+//   BundleAdjustmentSparse (affine, image 0 fixed)          MosaicWithoutPos.cpp:6971-7202
+#include "../../include/mi355_mosaic.h"
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <vector>
+
+static_assert(sizeof(mi355_match_point_pairs) == 40, "MatchPointPairs must be 40 bytes (matchPairs.match record)");
+static_assert(sizeof(mi355_keypoint) == 28, "cv::KeyPoint must be 28 bytes (keypoint_%d.key record)");
+static_assert(sizeof(mi355_pair_result) == 9664, "pair result record size");
+
+extern "C" int mi355_write_match_pairs(const char* path, const mi355_match_point_pairs* v, int n) {
+    if (!path || n < 0 || (n > 0 && !v)) return MI355_ERR_ARG;
+    if (n == 0) return MI355_OK;                    // the reference writes nothing for an empty vector (:4739)
+    FILE* f = fopen(path, "wb");
+    if (!f) return MI355_ERR_FAILED;
+    const int32_t cnt = n;
+    bool ok = fwrite(&cnt, sizeof(cnt), 1, f) == 1 && fwrite(v, sizeof(*v), (size_t)n, f) == (size_t)n;
+    ok = (fclose(f) == 0) && ok;
+    return ok ? MI355_OK : MI355_ERR_FAILED;
+}
+
+extern "C" int mi355_load_match_pairs(const char* path, mi355_match_point_pairs** v, int* n) {
+    if (!path || !v || !n) return MI355_ERR_ARG;
+    *v = nullptr; *n = 0;
+    FILE* f = fopen(path, "rb");
+    if (!f) return MI355_ERR_ARG;                   // LoadMatchPairs returns -1 when the count cannot be read (:4781-4782)
+    int32_t cnt = 0;
+    if (fread(&cnt, sizeof(cnt), 1, f) != 1 || cnt < 0) { fclose(f); return MI355_ERR_ARG; }
+    mi355_match_point_pairs* buf = (mi355_match_point_pairs*)malloc(sizeof(*buf) * (size_t)(cnt > 0 ? cnt : 1));
+    if (!buf) { fclose(f); return MI355_ERR_NOMEM; }
+    const size_t got = fread(buf, sizeof(*buf), (size_t)cnt, f);
+    fclose(f);
+    if (got != (size_t)cnt) { free(buf); return MI355_ERR_FAILED; }
+    *v = buf; *n = cnt;
+    return MI355_OK;
+}
+
+// operator<< of a float on a default ofstream: %g with 6 significant digits
+extern "C" int mi355_write_match_pairs_txt(const char* path, const mi355_match_point_pairs* v, int n) {
+    if (!path || n < 0 || (n > 0 && !v)) return MI355_ERR_ARG;
+    std::ofstream out(path, std::ios::trunc);
+    if (!out) return MI355_ERR_FAILED;
+    for (int i = 0; i < n; i++)
+        out << v[i].ptA_i << " " << v[i].ptA.x << " " << v[i].ptA.y << " " << v[i].ptA_Fixed << " "
+            << v[i].ptB_i << " " << v[i].ptB.x << " " << v[i].ptB.y << " " << v[i].ptB_Fixed << std::endl;
+    out.close();
+    return out.fail() ? MI355_ERR_FAILED : MI355_OK;
+}
+
+extern "C" int mi355_write_transforms(const char* path, const mi355_image_transform* t, int n) {
+    if (!path || n < 0 || (n > 0 && !t)) return MI355_ERR_ARG;
+    std::ofstream out(path, std::ios::trunc);
+    if (!out) return MI355_ERR_FAILED;
+    for (int i = 1; i < n; i++) {                   // image 0 is the fixed reference and is not written (:2804)
+        for (int j = 0; j < 8; j++) out << t[i].m[j] << " ";
+        out << t[i].fixed;
+        out << std::endl;
+    }
+    out.close();
+    return out.fail() ? MI355_ERR_FAILED : MI355_OK;
+}
+
+extern "C" int mi355_write_keypoints(const char* path, const mi355_keypoint* kp, int n) {
+    if (!path || n < 0 || (n > 0 && !kp)) return MI355_ERR_ARG;
+    if (n == 0) return MI355_OK;                    // :4691 only written when non-empty
+    FILE* f = fopen(path, "wb");
+    if (!f) return MI355_ERR_FAILED;
+    const int32_t cnt = n;
+    bool ok = fwrite(&cnt, sizeof(cnt), 1, f) == 1 && fwrite(kp, sizeof(*kp), (size_t)n, f) == (size_t)n;
+    ok = (fclose(f) == 0) && ok;
+    return ok ? MI355_OK : MI355_ERR_FAILED;
+}
+
+extern "C" int mi355_load_keypoints(const char* path, mi355_keypoint** kp, int* n) {
+    if (!path || !kp || !n) return MI355_ERR_ARG;
+    *kp = nullptr; *n = 0;
+    FILE* f = fopen(path, "rb");
+    if (!f) return MI355_ERR_ARG;
+    int32_t cnt = 0;
+    if (fread(&cnt, sizeof(cnt), 1, f) != 1 || cnt < 0) { fclose(f); return MI355_ERR_ARG; }
+    mi355_keypoint* buf = (mi355_keypoint*)malloc(sizeof(*buf) * (size_t)(cnt > 0 ? cnt : 1));
+    if (!buf) { fclose(f); return MI355_ERR_NOMEM; }
+    const size_t got = fread(buf, sizeof(*buf), (size_t)cnt, f);
+    fclose(f);
+    if (got != (size_t)cnt) { free(buf); return MI355_ERR_FAILED; }
+    *kp = buf; *n = cnt;
+    return MI355_OK;
+}
+
+// MosaicWithoutPos.cpp:5201-5221: accepted pairs only, inlier order, ptA <- image i, ptB <- image j
+extern "C" int mi355_results_to_match_pairs(const mi355_pair_result* r, int n_pairs, const int32_t* fixed_flags,
+                                            mi355_match_point_pairs** v, int* n) {
+    if (n_pairs < 0 || (n_pairs > 0 && !r) || !v || !n) return MI355_ERR_ARG;
+    size_t total = 0;
+    for (int p = 0; p < n_pairs; p++) if (r[p].accepted) total += (size_t)r[p].n_in;
+    mi355_match_point_pairs* out = (mi355_match_point_pairs*)malloc(sizeof(*out) * (total > 0 ? total : 1));
+    if (!out) return MI355_ERR_NOMEM;
+    size_t k = 0;
+    for (int p = 0; p < n_pairs; p++) {
+        if (!r[p].accepted) continue;
+        for (int q = 0; q < r[p].n_in; q++, k++) {
+            out[k].ptA = r[p].a[q]; out[k].ptA_i = r[p].i; out[k].ptA_Fixed = fixed_flags ? fixed_flags[r[p].i] : 0;
+            out[k].ptB = r[p].b[q]; out[k].ptB_i = r[p].j; out[k].ptB_Fixed = fixed_flags ? fixed_flags[r[p].j] : 0;
+        }
+    }
+    *v = out; *n = (int)total;
+    return MI355_OK;
+}
+
+// Global affine alignment.  Every correspondence (A in image a, B in image b) contributes the two equations
+//   T_a(A) - T_b(B) = 0,  T_k(x,y) = (m0 x + m1 y + m2, m3 x + m4 y + m5),
+// with T_k = identity for fixed images (their terms move to the right-hand side) -- the system
+// BundleAdjustmentSparse builds as a sparse 2P x 6(N-F) matrix and solves through CHOLMOD's normal
+// equations (MosaicWithoutPos.cpp:6971-7202, test_cholmod.cpp:180-262).  Here the 6(N-F) normal matrix
+// is accumulated directly in double (x- and y-rows decouple into two identical 3(N-F) systems) and
+// factorised by dense Cholesky.  Known answer: tests/golden/matchPairs.txt -> tran0.txt.
+extern "C" int mi355_global_affine_align(const mi355_match_point_pairs* v, int n, int n_images, const int32_t* fixed,
+                                         mi355_image_transform* out) {
+    if (n < 0 || n_images <= 0 || (n > 0 && !v) || !out) return MI355_ERR_ARG;
+    std::vector<int> col(n_images, -1);
+    int nf = 0;
+    for (int k = 0; k < n_images; k++) {
+        const bool fx = fixed ? fixed[k] != 0 : (k == 0);
+        if (!fx) col[k] = nf++;
+    }
+    for (int k = 0; k < n_images; k++) {
+        for (int i = 0; i < 9; i++) out[k].m[i] = 0.0f;
+        out[k].m[0] = out[k].m[4] = out[k].m[8] = 1.0f;
+        out[k].fixed = col[k] < 0 ? 1 : 0;
+    }
+    if (nf == 0) return MI355_OK;
+    const int D = 3 * nf;
+    std::vector<double> N((size_t)D * D, 0.0), bx(D, 0.0), by(D, 0.0);
+    for (int p = 0; p < n; p++) {
+        const int a = v[p].ptA_i, b = v[p].ptB_i;
+        if (a < 0 || a >= n_images || b < 0 || b >= n_images) return MI355_ERR_ARG;
+        // row: coefficients [xa ya 1] on image a's columns, -[xb yb 1] on image b's columns
+        double ca[3] = {v[p].ptA.x, v[p].ptA.y, 1.0}, cb[3] = {-(double)v[p].ptB.x, -(double)v[p].ptB.y, -1.0};
+        double rx = 0.0, ry = 0.0;                     // right-hand sides after moving the fixed image's identity terms
+        const int oa = col[a], ob = col[b];
+        if (oa < 0) { rx -= v[p].ptA.x; ry -= v[p].ptA.y; }
+        if (ob < 0) { rx += v[p].ptB.x; ry += v[p].ptB.y; }
+        if (oa < 0 && ob < 0) continue;
+        for (int s = 0; s < 2; s++) {
+            const int os = s == 0 ? oa : ob;
+            if (os < 0) continue;
+            const double* cs = s == 0 ? ca : cb;
+            for (int i = 0; i < 3; i++) {
+                bx[3 * os + i] += cs[i] * rx; by[3 * os + i] += cs[i] * ry;
+                for (int t = 0; t < 2; t++) {
+                    const int ot = t == 0 ? oa : ob;
+                    if (ot < 0) continue;
+                    const double* ct = t == 0 ? ca : cb;
+                    for (int j = 0; j < 3; j++) N[(size_t)(3 * os + i) * D + 3 * ot + j] += cs[i] * ct[j];
+                }
+            }
+        }
+    }
+    // images without any correspondence would make N singular: pin them to identity (the driver flags them
+    // invalid through Select_Connected_Matched_Images before calling, MosaicWithoutPos.cpp:4503-4523)
+    for (int k = 0; k < n_images; k++) {
+        const int o = col[k];
+        if (o < 0) continue;
+        if (N[(size_t)(3 * o + 2) * D + 3 * o + 2] == 0.0) {
+            for (int i = 0; i < 3; i++) N[(size_t)(3 * o + i) * D + 3 * o + i] = 1.0;
+            bx[3 * o + 0] = 1.0; by[3 * o + 1] = 1.0;
+        }
+    }
+    // dense Cholesky N = L L^T (lower), in place
+    for (int j = 0; j < D; j++) {
+        double d = N[(size_t)j * D + j];
+        for (int k = 0; k < j; k++) d -= N[(size_t)j * D + k] * N[(size_t)j * D + k];
+        if (!(d > 0.0)) return MI355_ERR_FAILED;
+        d = std::sqrt(d);
+        N[(size_t)j * D + j] = d;
+        for (int i = j + 1; i < D; i++) {
+            double s = N[(size_t)i * D + j];
+            for (int k = 0; k < j; k++) s -= N[(size_t)i * D + k] * N[(size_t)j * D + k];
+            N[(size_t)i * D + j] = s / d;
+        }
+    }
+    auto solve = [&](std::vector<double>& b) {
+        for (int i = 0; i < D; i++) { double s = b[i]; for (int k = 0; k < i; k++) s -= N[(size_t)i * D + k] * b[k]; b[i] = s / N[(size_t)i * D + i]; }
+        for (int i = D - 1; i >= 0; i--) { double s = b[i]; for (int k = i + 1; k < D; k++) s -= N[(size_t)k * D + i] * b[k]; b[i] = s / N[(size_t)i * D + i]; }
+    };
+    solve(bx); solve(by);
+    for (int k = 0; k < n_images; k++) {
+        const int o = col[k];
+        if (o < 0) continue;
+        out[k].m[0] = (float)bx[3 * o]; out[k].m[1] = (float)bx[3 * o + 1]; out[k].m[2] = (float)bx[3 * o + 2];
+        out[k].m[3] = (float)by[3 * o]; out[k].m[4] = (float)by[3 * o + 1]; out[k].m[5] = (float)by[3 * o + 2];
+    }
+    return MI355_OK;
+}

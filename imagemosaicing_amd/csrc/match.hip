@@ -1,0 +1,426 @@
+// csrc/match.hip -- K6 exact brute-force descriptor matching on the matrix cores + K7 sort / grid selection,
+// and the per-pair orchestration match -> select -> RANSAC (gfx950).
+//
+// Replaces the j-loop body of GetMatchedPairsOneToAllSIFTThread, MosaicWithoutPos.cpp:5084-5232:
+//   cv::FlannBasedMatcher().match (:5108-5110, approximate 1-NN)  -> exact 1-NN / 2-NN (what FLANN approximates)
+//   std::sort(matches) (:5111)                                    -> total order (squared distance, queryIdx)
+//   SelectMatchPairs grid walk (:4977-5028, call :5146-5153)      -> same walk, 64 matches per step with ballots
+//   Ransac2D (:5169)                                              -> csrc/ransac.hip
+//   accept when inliers > 30 (:5049, :5201)
+//
+// Why bf16 MFMA is EXACT here: SIFT descriptors are the integers 0..255 (OpenCV stores saturate_cast<uchar>
+// values in a float Mat).  bf16 has 8 significand bits, so 0..255 are exact; every product <= 65025 and every
+// 128-term dot product <= 8.33e6 < 2^24 is exact in the f32 accumulator in any summation order; the squared
+// norms are exact integers too.  d2 = |a|^2 + |b|^2 - 2 a.b is therefore the exact integer squared distance
+// and the arg-min (ties -> lowest train index) equals a CPU integer brute force bit for bit.
+//
+// Kernel shape (v_mfma_f32_32x32x16_bf16): the TRAIN tile is the A operand (rows) and the QUERY tile the B
+// operand (columns), so after the MFMA lane l holds 16 train rows of ONE query (column l&31): the running
+// top-2 is lane-local (no cross-lane traffic in the loop) and the two half-waves are merged once at the end.
+#include "common.h"
+
+namespace {
+
+typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 bf16x8;
+typedef __attribute__((__vector_size__(16 * sizeof(float)))) float f32x16;
+
+constexpr int KSTRIDE = 2048;        // per-pair stride of the nn arrays (>= nfeatures rounded up)
+constexpr int QTILE = 128;           // queries per workgroup (4 waves x 32)
+
+struct PairDesc {
+    const uint16_t* bf_i; const int* nrm_i; const float2* xy_i; int n_i; int npad_i;
+    const uint16_t* bf_j; const int* nrm_j; const float2* xy_j; int n_j; int npad_j;
+    int img_i, img_j, width, height;
+};
+
+__device__ __forceinline__ void top2_update(int s, int j, int& best, int& second, int& bi) {
+    if (s < best) { second = best; best = s; bi = j; }
+    else if (s < second) second = s;
+}
+
+__global__ __launch_bounds__(256) void bf_match_kernel(const PairDesc* pairs, int* nn_idx, int* nn_d2, int* nn_2nd) {
+    __shared__ int s_nrm[KSTRIDE];
+    const PairDesc pd = pairs[blockIdx.y];
+    const int q_base = blockIdx.x * QTILE;
+    if (q_base >= pd.n_i) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int hi = lane >> 5, col = lane & 31;
+    for (int i = tid; i < pd.npad_j; i += 256) s_nrm[i] = pd.nrm_j[i];
+    __syncthreads();
+    const int q = q_base + wave * 32 + col;              // this lane's query (rows beyond n_i are zero padding)
+    const bool q_ok = q < pd.npad_i;
+    bf16x8 bq[8];
+#pragma unroll
+    for (int ks = 0; ks < 8; ks++) {
+        if (q_ok) bq[ks] = *reinterpret_cast<const bf16x8*>(pd.bf_i + (size_t)q * 128 + ks * 16 + hi * 8);
+        else for (int e = 0; e < 8; e++) bq[ks][e] = (__bf16)0.0f;
+    }
+    const float nq = q_ok ? (float)pd.nrm_i[q] : 0.0f;
+    int best = 0x7fffffff, second = 0x7fffffff, bi = -1;
+    for (int t0 = 0; t0 < pd.npad_j; t0 += 32) {
+        f32x16 acc;
+#pragma unroll
+        for (int e = 0; e < 16; e++) acc[e] = 0.0f;
+        const uint16_t* arow = pd.bf_j + (size_t)(t0 + col) * 128 + hi * 8;
+#pragma unroll
+        for (int ks = 0; ks < 8; ks++) {
+            const bf16x8 at = *reinterpret_cast<const bf16x8*>(arow + ks * 16);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at, bq[ks], acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int m = t0 + (r & 3) + 8 * (r >> 2) + 4 * hi;       // C/D layout of the 32x32 MFMA
+            const float d = (nq + (float)s_nrm[m]) - 2.0f * acc[r];   // exact integers below 2^24
+            const int s = (m < pd.n_j) ? (int)d : 0x7fffffff;
+            top2_update(s, m, best, second, bi);
+        }
+    }
+    // merge the two half-waves (same query, disjoint train rows); ties -> lowest train index
+    const int ob = __shfl_xor(best, 32), os = __shfl_xor(second, 32), oi = __shfl_xor(bi, 32);
+    const bool other_wins = (ob < best) || (ob == best && oi >= 0 && (bi < 0 || oi < bi));
+    const int nb = other_wins ? ob : best, ni = other_wins ? oi : bi;
+    const int loser_best = other_wins ? best : ob;
+    const int min_sec = os < second ? os : second;
+    const int ns = loser_best < min_sec ? loser_best : min_sec;
+    if (hi == 0 && q < pd.n_i) {
+        const size_t o = (size_t)blockIdx.y * KSTRIDE + q;
+        nn_idx[o] = ni; nn_d2[o] = nb; nn_2nd[o] = ns;
+    }
+}
+
+// ---- K7: sort by (d2, queryIdx) + grid walk -----------------------------------------------------------------
+struct SelectParams { int max_selected; float fraction; int gx, gy; float ratio2; };
+
+__global__ __launch_bounds__(256) void select_kernel(const PairDesc* pairs, const int* nn_idx, const int* nn_d2, const int* nn_2nd,
+                                                     SelectParams sp, mi355_sfpoint* sel1, mi355_sfpoint* sel2, int* nsel,
+                                                     unsigned long long* sorted_keys /* optional [pair][KSTRIDE] */) {
+    __shared__ unsigned long long key[KSTRIDE];
+    __shared__ int s_label[64];
+    const int pair = blockIdx.x, tid = threadIdx.x;
+    const PairDesc pd = pairs[pair];
+    const int M = (pd.n_j > 0) ? pd.n_i : 0;                       // one match per query descriptor
+    const size_t o = (size_t)pair * KSTRIDE;
+    for (int i = tid; i < KSTRIDE; i += 256)
+        key[i] = (i < M) ? (((unsigned long long)(unsigned)nn_d2[o + i] << 32) | (unsigned)i) : ~0ull;
+    __syncthreads();
+    // bitonic sort of 2048 64-bit keys in LDS
+    for (int k = 2; k <= KSTRIDE; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < KSTRIDE; i += 256) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const unsigned long long a = key[i], b = key[ixj];
+                    const bool up = (i & k) == 0;
+                    if ((a > b) == up) { key[i] = b; key[ixj] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    if (sorted_keys) for (int i = tid; i < KSTRIDE; i += 256) sorted_keys[o + i] = key[i];
+    if (tid >= 64) return;
+    // grid walk by one wave, 64 sorted matches per step (MosaicWithoutPos.cpp:4977-5028)
+    const int lane = tid;
+    const int nGrids = sp.gx * sp.gy;
+    const double lim = (double)sp.fraction * (double)M;                        // Min(400, 0.3*M) evaluated in double (:5146-5147)
+    const int nMatch = (int)((double)sp.max_selected < lim ? (double)sp.max_selected : lim);
+    const int perGrid = (int)((float)nMatch / (float)nGrids);                    // :4990
+    const int stepX = pd.width / sp.gx, stepY = pd.height / sp.gy;               // :4994-4995
+    if (lane < 64) s_label[lane] = 0;
+    int count = 0;
+    mi355_sfpoint* o1 = sel1 + (size_t)pair * MI355_MAX_SELECTED;
+    mi355_sfpoint* o2 = sel2 + (size_t)pair * MI355_MAX_SELECTED;
+    for (int base = 0; base < M; base += 64) {
+        const int i = base + lane;
+        bool valid = i < M;
+        int q = 0, t = 0, cell = 0; float x = 0.0f, y = 0.0f;
+        if (valid) {
+            q = (int)(unsigned)(key[i] & 0xffffffffull);
+            t = nn_idx[o + q];
+            const float2 pxy = pd.xy_i[q];
+            x = pxy.x; y = pxy.y;
+            const int nX = (int)(x / (float)stepX), nY = (int)(y / (float)stepY);      // :5008-5009
+            cell = sp.gx * nY + nX;                       // aliases into the next row when nX == gridX, like the reference
+            if (cell < 0) cell = 0;
+            if (cell >= nGrids) cell = nGrids - 1;        // the reference would index label[] out of bounds here
+            if (sp.ratio2 > 0.0f) {                       // optional Lowe ratio test (north_star), squared distances
+                const float d1 = (float)nn_d2[o + q], d2 = (float)nn_2nd[o + q];
+                if (!(d1 < sp.ratio2 * d2)) valid = false;
+            }
+        }
+        bool keep = false;
+        for (int cc = 0; cc < nGrids; cc++) {
+            const unsigned long long m = __ballot(valid && cell == cc);
+            if (m == 0) continue;
+            const int lab = s_label[cc];
+            const int rank = __popcll(m & ((1ull << lane) - 1ull));
+            if (valid && cell == cc && lab + rank < perGrid) keep = true;
+            int add = __popcll(m);
+            const int room = perGrid - lab;
+            if (add > room) add = room > 0 ? room : 0;
+            if (lane == 0) s_label[cc] = lab + add;
+        }
+        const unsigned long long km = __ballot(keep);
+        const int pos = count + __popcll(km & ((1ull << lane) - 1ull));
+        if (keep && pos < MI355_MAX_SELECTED) {
+            const float2 p2 = pd.xy_j[t];
+            o1[pos].x = x; o1[pos].y = y; o1[pos].id = q;
+            o2[pos].x = p2.x; o2[pos].y = p2.y; o2[pos].id = t;
+        }
+        count += __popcll(km);
+    }
+    if (lane == 0) nsel[pair] = count < MI355_MAX_SELECTED ? count : MI355_MAX_SELECTED;
+}
+
+__global__ void finalize_kernel(const PairDesc* pairs, const int* nsel, int n_pairs, int min_inliers, mi355_pair_result* out) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_pairs) return;
+    out[p].i = pairs[p].img_i; out[p].j = pairs[p].img_j;
+    out[p].n_selected = nsel[p];
+    out[p].accepted = out[p].n_in > min_inliers ? 1 : 0;          // MosaicWithoutPos.cpp:5201
+    out[p]._pad = 0;
+}
+
+// ---- features ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(128) void finish_features_kernel(const mi355_keypoint* kp, const uint8_t* d8, int n, int npad,
+                                                              float2* xy, uint16_t* bf, int* nrm) {
+    const int row = blockIdx.x, k = threadIdx.x;            // one row per block, 128 lanes = 128 dims
+    unsigned v = 0;
+    if (row < n) v = d8[(size_t)row * 128 + k];
+    // integer 0..255 -> bf16 bits (exact): f32 bits >> 16
+    bf[(size_t)row * 128 + k] = (uint16_t)(__float_as_uint((float)v) >> 16);
+    int s = (int)(v * v);
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    __shared__ int part[2];
+    if ((k & 63) == 0) part[k >> 6] = s;
+    __syncthreads();
+    if (k == 0) {
+        nrm[row] = part[0] + part[1];
+        if (row < n) xy[row] = make_float2(kp[row].x, kp[row].y);
+    }
+}
+
+__global__ void desc_f32_to_u8_kernel(const float* f, uint8_t* d8, size_t count) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    float v = f[i];
+    v = v < 0.0f ? 0.0f : (v > 255.0f ? 255.0f : v);
+    d8[i] = (uint8_t)(int)(v + 0.5f);
+}
+
+__global__ void desc_u8_to_f32_kernel(const uint8_t* d8, float* f, size_t count) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) f[i] = (float)d8[i];
+}
+
+int build_pair_table(mi355_ctx* ctx, const int32_t* pairs, int n_pairs, std::vector<PairDesc>& pd) {
+    pd.resize(n_pairs);
+    for (int p = 0; p < n_pairs; p++) {
+        const int i = pairs[2 * p], j = pairs[2 * p + 1];
+        auto fi = ctx->feats.find(i), fj = ctx->feats.find(j);
+        if (fi == ctx->feats.end() || fj == ctx->feats.end()) { ctx->set_error("match_pairs: no resident features for image " + std::to_string(fi == ctx->feats.end() ? i : j)); return MI355_ERR_ARG; }
+        const Features &a = fi->second, &b = fj->second;
+        if (a.n > KSTRIDE || b.n > KSTRIDE) { ctx->set_error("match_pairs: more than 2048 keypoints per image"); return MI355_ERR_ARG; }
+        PairDesc& d = pd[p];
+        d.bf_i = a.bf.as<uint16_t>(); d.nrm_i = a.nrm.as<int>(); d.xy_i = a.xy.as<float2>(); d.n_i = a.n; d.npad_i = a.npad;
+        d.bf_j = b.bf.as<uint16_t>(); d.nrm_j = b.nrm.as<int>(); d.xy_j = b.xy.as<float2>(); d.n_j = b.n; d.npad_j = b.npad;
+        d.img_i = i; d.img_j = j; d.width = a.w; d.height = a.h;        // the cell comes from the image-i point (:5002-5009)
+    }
+    return MI355_OK;
+}
+
+}  // namespace
+
+int mi_finish_features(mi355_ctx* ctx, Features& f) {
+    f.npad = ((f.n + QTILE - 1) / QTILE) * QTILE;
+    if (f.npad == 0) f.npad = QTILE;
+    MI_HIP(f.xy.reserve(sizeof(float2) * (size_t)(f.n > 0 ? f.n : 1)));
+    MI_HIP(f.bf.reserve(sizeof(uint16_t) * 128 * (size_t)f.npad));
+    MI_HIP(f.nrm.reserve(sizeof(int) * (size_t)f.npad));
+    ProfScope ps(ctx, "features", (double)f.npad * 128 * 3);
+    hipLaunchKernelGGL(finish_features_kernel, dim3(f.npad), dim3(128), 0, ctx->stream,
+                       f.kp.as<mi355_keypoint>(), f.d8.as<uint8_t>(), f.n, f.npad, f.xy.as<float2>(), f.bf.as<uint16_t>(), f.nrm.as<int>());
+    MI_HIP(hipGetLastError());
+    return MI355_OK;
+}
+
+int mi_set_features(mi355_ctx* ctx, int img_id, const mi355_keypoint* kp, const float* desc, int n, int w, int h) {
+    if (n < 0 || n > KSTRIDE || (n > 0 && (!kp || !desc)) || w <= 0 || h <= 0) { ctx->set_error("set_features: bad arguments (n must be <= 2048)"); return MI355_ERR_ARG; }
+    Features& f = ctx->feats[img_id];
+    f.n = n; f.w = w; f.h = h;
+    const size_t cnt = (size_t)n * 128;
+    MI_HIP(f.kp.reserve(sizeof(mi355_keypoint) * (size_t)(n > 0 ? n : 1)));
+    MI_HIP(f.d8.reserve(cnt > 0 ? cnt : 1));
+    if (n > 0) {
+        DevBuf& tmp = ctx->buf("desc_f32");
+        MI_HIP(tmp.reserve(cnt * sizeof(float)));
+        MI_HIP(hipMemcpyAsync(f.kp.p, kp, sizeof(mi355_keypoint) * n, hipMemcpyHostToDevice, ctx->stream));
+        MI_HIP(hipMemcpyAsync(tmp.p, desc, cnt * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+        hipLaunchKernelGGL(desc_f32_to_u8_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, ctx->stream, tmp.as<float>(), f.d8.as<uint8_t>(), cnt);
+    }
+    int rc = mi_finish_features(ctx, f);
+    if (rc != MI355_OK) return rc;
+    MI_HIP(hipStreamSynchronize(ctx->stream));
+    return MI355_OK;
+}
+
+extern "C" int mi355_get_features(mi355_ctx* ctx, int img_id, mi355_keypoint* kp, float* desc128, int max_kp, int* n_kp) {
+    if (!ctx) return MI355_ERR_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    auto it = ctx->feats.find(img_id);
+    if (it == ctx->feats.end()) { ctx->set_error("get_features: unknown image id"); return MI355_ERR_ARG; }
+    Features& f = it->second;
+    if (n_kp) *n_kp = f.n;
+    const int n = f.n < max_kp ? f.n : max_kp;
+    if (n <= 0) return MI355_OK;
+    if (kp) MI_HIP(hipMemcpyAsync(kp, f.kp.p, sizeof(mi355_keypoint) * n, hipMemcpyDeviceToHost, ctx->stream));
+    if (desc128) {
+        const size_t cnt = (size_t)n * 128;
+        DevBuf& tmp = ctx->buf("desc_f32");
+        MI_HIP(tmp.reserve(cnt * sizeof(float)));
+        hipLaunchKernelGGL(desc_u8_to_f32_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, ctx->stream, f.d8.as<uint8_t>(), tmp.as<float>(), cnt);
+        MI_HIP(hipMemcpyAsync(desc128, tmp.p, cnt * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    }
+    MI_HIP(hipStreamSynchronize(ctx->stream));
+    return MI355_OK;
+}
+
+static int run_match_select(mi355_ctx* ctx, const std::vector<PairDesc>& pd, int n_pairs, bool want_sorted_keys) {
+    DevBuf& dpd = ctx->buf("pair_desc");
+    DevBuf& didx = ctx->buf("nn_idx");
+    DevBuf& dd2 = ctx->buf("nn_d2");
+    DevBuf& d2nd = ctx->buf("nn_2nd");
+    DevBuf& ds1 = ctx->buf("sel1");
+    DevBuf& ds2 = ctx->buf("sel2");
+    DevBuf& dns = ctx->buf("nsel");
+    DevBuf& dkeys = ctx->buf("sorted_keys");
+    const size_t nn = (size_t)n_pairs * KSTRIDE;
+    MI_HIP(dpd.reserve(sizeof(PairDesc) * n_pairs));
+    MI_HIP(didx.reserve(nn * 4)); MI_HIP(dd2.reserve(nn * 4)); MI_HIP(d2nd.reserve(nn * 4));
+    MI_HIP(ds1.reserve(sizeof(mi355_sfpoint) * MI355_MAX_SELECTED * (size_t)n_pairs));
+    MI_HIP(ds2.reserve(sizeof(mi355_sfpoint) * MI355_MAX_SELECTED * (size_t)n_pairs));
+    MI_HIP(dns.reserve(sizeof(int) * n_pairs));
+    if (want_sorted_keys) MI_HIP(dkeys.reserve(nn * 8));
+    MI_HIP(hipMemcpyAsync(dpd.p, pd.data(), sizeof(PairDesc) * n_pairs, hipMemcpyHostToDevice, ctx->stream));
+    MI_HIP(hipStreamSynchronize(ctx->stream));
+    int max_ni = 1;
+    double flops_bytes = 0.0;
+    for (int p = 0; p < n_pairs; p++) { if (pd[p].n_i > max_ni) max_ni = pd[p].n_i; flops_bytes += (double)(pd[p].npad_i + pd[p].npad_j) * 256.0 + 8.0 * pd[p].n_i; }
+    {
+        ProfScope ps(ctx, "match", flops_bytes);
+        hipLaunchKernelGGL(bf_match_kernel, dim3((max_ni + QTILE - 1) / QTILE, n_pairs), dim3(256), 0, ctx->stream,
+                           dpd.as<PairDesc>(), didx.as<int>(), dd2.as<int>(), d2nd.as<int>());
+    }
+    SelectParams sp;
+    sp.max_selected = ctx->p.max_selected; sp.fraction = ctx->p.select_fraction; sp.gx = ctx->p.grid_x; sp.gy = ctx->p.grid_y;
+    sp.ratio2 = ctx->p.ratio > 0.0f ? ctx->p.ratio * ctx->p.ratio : 0.0f;
+    {
+        ProfScope ps(ctx, "select", (double)n_pairs * (KSTRIDE * 12.0 + 9600.0));
+        hipLaunchKernelGGL(select_kernel, dim3(n_pairs), dim3(256), 0, ctx->stream, dpd.as<PairDesc>(), didx.as<int>(), dd2.as<int>(), d2nd.as<int>(),
+                           sp, ds1.as<mi355_sfpoint>(), ds2.as<mi355_sfpoint>(), dns.as<int>(),
+                           want_sorted_keys ? dkeys.as<unsigned long long>() : (unsigned long long*)nullptr);
+    }
+    MI_HIP(hipGetLastError());
+    return MI355_OK;
+}
+
+int mi_match_pairs_dev(mi355_ctx* ctx, const int32_t* pairs, int n_pairs, float dist, uint32_t seed, mi355_pair_result* d_out) {
+    if (n_pairs <= 0) return MI355_OK;
+    if (!pairs || !d_out) return MI355_ERR_ARG;
+    if (ctx->p.grid_x * ctx->p.grid_y > 64 || ctx->p.grid_x < 1 || ctx->p.grid_y < 1 || ctx->p.max_selected > MI355_MAX_SELECTED) { ctx->set_error("match_pairs: grid > 64 cells or max_selected > 400"); return MI355_ERR_ARG; }
+    const int BATCH = 8192;                                   // bounds the nn workspaces (8192 x 2048 x 12 B = 192 MiB)
+    std::vector<PairDesc> pd;
+    for (int b0 = 0; b0 < n_pairs; b0 += BATCH) {
+        const int nb = (n_pairs - b0) < BATCH ? (n_pairs - b0) : BATCH;
+        int rc = build_pair_table(ctx, pairs + 2 * b0, nb, pd);
+        if (rc != MI355_OK) return rc;
+        rc = run_match_select(ctx, pd, nb, false);
+        if (rc != MI355_OK) return rc;
+        rc = mi_ransac_batch(ctx, ctx->buf("sel1").as<mi355_sfpoint>(), ctx->buf("sel2").as<mi355_sfpoint>(), ctx->buf("nsel").as<int>(), nullptr,
+                             nb, MI355_MAX_SELECTED, dist, ctx->p.sample_times, seed, d_out + b0);
+        if (rc != MI355_OK) return rc;
+        hipLaunchKernelGGL(finalize_kernel, dim3((nb + 255) / 256), dim3(256), 0, ctx->stream, ctx->buf("pair_desc").as<PairDesc>(), ctx->buf("nsel").as<int>(),
+                           nb, ctx->p.min_inliers, d_out + b0);
+        MI_HIP(hipGetLastError());
+        if (b0 + BATCH < n_pairs) MI_HIP(hipStreamSynchronize(ctx->stream));     // workspaces are reused by the next batch
+    }
+    return MI355_OK;
+}
+
+int mi_bf_match(mi355_ctx* ctx, int img_i, int img_j, int sorted, mi355_dmatch* matches, int32_t* d2, int32_t* second, int maxm, int* nm) {
+    const int32_t pr[2] = {img_i, img_j};
+    std::vector<PairDesc> pd;
+    int rc = build_pair_table(ctx, pr, 1, pd);
+    if (rc != MI355_OK) return rc;
+    rc = run_match_select(ctx, pd, 1, true);
+    if (rc != MI355_OK) return rc;
+    const int M = pd[0].n_j > 0 ? pd[0].n_i : 0;
+    std::vector<int> idx(KSTRIDE), dd(KSTRIDE), d2nd(KSTRIDE);
+    std::vector<unsigned long long> keys(KSTRIDE);
+    MI_HIP(hipMemcpyAsync(idx.data(), ctx->buf("nn_idx").p, KSTRIDE * 4, hipMemcpyDeviceToHost, ctx->stream));
+    MI_HIP(hipMemcpyAsync(dd.data(), ctx->buf("nn_d2").p, KSTRIDE * 4, hipMemcpyDeviceToHost, ctx->stream));
+    MI_HIP(hipMemcpyAsync(d2nd.data(), ctx->buf("nn_2nd").p, KSTRIDE * 4, hipMemcpyDeviceToHost, ctx->stream));
+    MI_HIP(hipMemcpyAsync(keys.data(), ctx->buf("sorted_keys").p, KSTRIDE * 8, hipMemcpyDeviceToHost, ctx->stream));
+    MI_HIP(hipStreamSynchronize(ctx->stream));
+    const int n = M < maxm ? M : maxm;
+    for (int k = 0; k < n; k++) {
+        const int q = sorted ? (int)(keys[k] & 0xffffffffull) : k;
+        if (matches) { matches[k].queryIdx = q; matches[k].trainIdx = idx[q]; matches[k].imgIdx = 0; matches[k].distance = sqrtf((float)dd[q]); }
+        if (d2) d2[k] = dd[q];
+        if (second) second[k] = d2nd[q];
+    }
+    if (nm) *nm = M;
+    return MI355_OK;
+}
+
+// stand-alone SelectMatchPairs: host arrays in, the same select kernel on one synthetic "pair"
+int mi_select_grid(mi355_ctx* ctx, const mi355_dmatch* sorted, int n, const float* kp1, int nk1, const float* kp2, int nk2,
+                   int nMatch, int width, int height, int gx, int gy, mi355_sfpoint* v1, mi355_sfpoint* v2, int* n_out) {
+    if (n < 0 || n > KSTRIDE || !kp1 || !kp2 || !v1 || !v2 || !n_out || gx < 1 || gy < 1 || gx * gy > 64 || width < gx || height < gy) { ctx->set_error("select_grid: bad arguments"); return MI355_ERR_ARG; }
+    // The kernel sorts by (d2, queryIdx); feed it ranks so that the given order is kept: d2 := position.
+    // Queries are remapped to 0..n-1 in the given order (x/y/id carried through).
+    std::vector<float2> xy1(n > 0 ? n : 1), xy2(n > 0 ? n : 1);
+    std::vector<int> idx(KSTRIDE, 0), dd(KSTRIDE, 0), d2nd(KSTRIDE, 0);
+    for (int k = 0; k < n; k++) {
+        const int q = sorted[k].queryIdx, t = sorted[k].trainIdx;
+        if (q < 0 || q >= nk1 || t < 0 || t >= nk2) { ctx->set_error("select_grid: match index out of range"); return MI355_ERR_ARG; }
+        xy1[k] = make_float2(kp1[2 * q], kp1[2 * q + 1]);
+        xy2[k] = make_float2(kp2[2 * t], kp2[2 * t + 1]);
+        idx[k] = k; dd[k] = k;
+    }
+    DevBuf& dx1 = ctx->buf("sg_xy1"); DevBuf& dx2 = ctx->buf("sg_xy2");
+    DevBuf& dpd = ctx->buf("pair_desc"); DevBuf& didx = ctx->buf("nn_idx"); DevBuf& dd2 = ctx->buf("nn_d2"); DevBuf& d2n = ctx->buf("nn_2nd");
+    DevBuf& ds1 = ctx->buf("sel1"); DevBuf& ds2 = ctx->buf("sel2"); DevBuf& dns = ctx->buf("nsel");
+    MI_HIP(dx1.reserve(sizeof(float2) * xy1.size())); MI_HIP(dx2.reserve(sizeof(float2) * xy2.size()));
+    MI_HIP(dpd.reserve(sizeof(PairDesc))); MI_HIP(didx.reserve(KSTRIDE * 4)); MI_HIP(dd2.reserve(KSTRIDE * 4)); MI_HIP(d2n.reserve(KSTRIDE * 4));
+    MI_HIP(ds1.reserve(sizeof(mi355_sfpoint) * MI355_MAX_SELECTED)); MI_HIP(ds2.reserve(sizeof(mi355_sfpoint) * MI355_MAX_SELECTED)); MI_HIP(dns.reserve(sizeof(int)));
+    PairDesc pd;
+    memset(&pd, 0, sizeof(pd));
+    pd.xy_i = dx1.as<float2>(); pd.xy_j = dx2.as<float2>(); pd.n_i = n; pd.n_j = n > 0 ? 1 : 0; pd.width = width; pd.height = height;
+    MI_HIP(hipMemcpyAsync(dx1.p, xy1.data(), sizeof(float2) * xy1.size(), hipMemcpyHostToDevice, ctx->stream));
+    MI_HIP(hipMemcpyAsync(dx2.p, xy2.data(), sizeof(float2) * xy2.size(), hipMemcpyHostToDevice, ctx->stream));
+    MI_HIP(hipMemcpyAsync(dpd.p, &pd, sizeof(pd), hipMemcpyHostToDevice, ctx->stream));
+    MI_HIP(hipMemcpyAsync(didx.p, idx.data(), KSTRIDE * 4, hipMemcpyHostToDevice, ctx->stream));
+    MI_HIP(hipMemcpyAsync(dd2.p, dd.data(), KSTRIDE * 4, hipMemcpyHostToDevice, ctx->stream));
+    MI_HIP(hipMemcpyAsync(d2n.p, d2nd.data(), KSTRIDE * 4, hipMemcpyHostToDevice, ctx->stream));
+    // nMatch is given by the caller here: choose (max_selected, fraction) that reproduce it: min(nMatch, 1.0*M)
+    SelectParams sp;
+    sp.max_selected = nMatch; sp.fraction = 2.0f; sp.gx = gx; sp.gy = gy; sp.ratio2 = 0.0f;
+    if (nMatch > 2 * n) sp.max_selected = 2 * n;       // the caller's nMatch always wins below; keep Min() on its first branch
+    sp.max_selected = nMatch;
+    hipLaunchKernelGGL(select_kernel, dim3(1), dim3(256), 0, ctx->stream, dpd.as<PairDesc>(), didx.as<int>(), dd2.as<int>(), d2n.as<int>(),
+                       sp, ds1.as<mi355_sfpoint>(), ds2.as<mi355_sfpoint>(), dns.as<int>(), (unsigned long long*)nullptr);
+    int cnt = 0;
+    std::vector<mi355_sfpoint> h1(MI355_MAX_SELECTED), h2(MI355_MAX_SELECTED);
+    MI_HIP(hipMemcpyAsync(&cnt, dns.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    MI_HIP(hipMemcpyAsync(h1.data(), ds1.p, sizeof(mi355_sfpoint) * MI355_MAX_SELECTED, hipMemcpyDeviceToHost, ctx->stream));
+    MI_HIP(hipMemcpyAsync(h2.data(), ds2.p, sizeof(mi355_sfpoint) * MI355_MAX_SELECTED, hipMemcpyDeviceToHost, ctx->stream));
+    MI_HIP(hipStreamSynchronize(ctx->stream));
+    for (int k = 0; k < cnt; k++) {
+        const int pos = h1[k].id;                       // position in the caller's sorted list
+        v1[k].x = h1[k].x; v1[k].y = h1[k].y; v1[k].id = sorted[pos].queryIdx;
+        v2[k].x = h2[k].x; v2[k].y = h2[k].y; v2[k].id = sorted[pos].trainIdx;
+    }
+    *n_out = cnt;
+    return MI355_OK;
+}

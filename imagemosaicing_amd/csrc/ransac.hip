@@ -1,0 +1,366 @@
+// csrc/ransac.hip -- K8: batched Ransac2D (mosaicimage.h:1729-2035) on gfx950, one workgroup per image pair.
+//
+// What is reproduced exactly:
+//  * the glibc rand() stream after srand(seed) and the "redraw all four until pairwise distinct" rule
+//    (mosaicimage.h:1777-1813): the stream is consumed in aligned groups of four, so the k-th draw is the
+//    k-th group whose four values are distinct mod n -- the host builds that table once per (seed, n);
+//  * every draw is an independent 4-point SolveHomographyMatrix (+ NonlinearLeastSquareProjection2 when
+//    0.01 < H[8] < 5) in float32 with the reference's operation order (csrc/hmath.h): one lane per draw;
+//  * the sequential bookkeeping of the loop -- a draw with H[8] > 5 is skipped without consuming a
+//    hypothesis slot, at most sample_times accepted hypotheses, at most 4999 draws, first strict maximum of
+//    the support wins, stop as soon as support/n > 0.99 -- is replayed in draw order over each chunk of 256
+//    evaluated draws, so the winner is the one the sequential reference finds;
+//  * support uses the reciprocal form (ApplyProjectMat2), the final inlier split the true-division form
+//    (ApplyProjectMat3); inliers keep input order; the result is NLLS from the WINNING hypothesis over all
+//    inliers (the inlier least-squares refit at :1958 only decides success and is not computed).
+//
+// CDNA4 mapping: points of the pair live in LDS (<= 16 KB), support counting is a per-lane loop over LDS
+// broadcast reads (all lanes read the same point => conflict-free broadcast), inlier compaction uses wave
+// ballots + popcounts, the final Gauss-Newton keeps J / J* in LDS and gives each of the 64 entries of
+// J^T J to one lane of a wave so that the k-ordered accumulation of the reference is preserved per entry.
+#include "common.h"
+#include "hmath.h"
+
+namespace {
+
+constexpr int RB = 256;            // threads per workgroup = draws per chunk
+constexpr int MAX_DRAWS = 4999;    // realSamTimes >= 5000 breaks before drawing (mosaicimage.h:1787-1792)
+
+struct RansacArgs {
+    const mi355_sfpoint* p1;       // [pair][stride]
+    const mi355_sfpoint* p2;
+    const int* n;                  // [pair]
+    const uint16_t* tables;        // concatenated draw tables (MAX_DRAWS x 4 each)
+    const int* table_of;           // [pair] table index, -1 = none (n < 4)
+    int stride;
+    float dist;
+    int sample_times;
+    mi355_pair_result* out;        // [pair]
+};
+
+__device__ __forceinline__ int block_exclusive_scan_flags(bool flag, int tid, int* wave_tot /*LDS[RB/64+1]*/, int& total) {
+    const unsigned long long m = __ballot(flag);
+    const int lane = tid & 63, wv = tid >> 6;
+    const int before = __popcll(m & ((1ull << lane) - 1ull));
+    if (lane == 0) wave_tot[wv] = __popcll(m);
+    __syncthreads();
+    int off = 0, tot = 0;
+    for (int i = 0; i < RB / 64; i++) { int c = wave_tot[i]; if (i < wv) off += c; tot += c; }
+    __syncthreads();
+    total = tot;
+    return off + before;
+}
+
+__global__ __launch_bounds__(RB) void ransac_kernel(RansacArgs a) {
+    extern __shared__ float lds[];
+    __shared__ int   s_sup[RB];
+    __shared__ int   s_flag[RB];
+    __shared__ float s_bestH[9], s_firstH[9], s_w[8], s_dX[8], s_T1[64], s_T2[64], s_t[128];
+    __shared__ int   s_state[8];      // 0 t_acc, 1 maxSupport, 2 bestDraw, 3 firstAcc, 4 finished, 5 newBest, 6 newFirst, 7 done
+    __shared__ int   s_wtot[RB / 64 + 1];
+
+    const int pair = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int n = a.n[pair];
+    mi355_pair_result* out = a.out + pair;
+    const mi355_sfpoint* P1 = a.p1 + (size_t)pair * a.stride;
+    const mi355_sfpoint* P2 = a.p2 + (size_t)pair * a.stride;
+
+    if (tid < 9) out->H[tid] = 0.0f;
+    if (n < 4 || a.sample_times < 1) {                     // mosaicimage.h:1739-1761
+        if (tid == 0) { out->n_in = 0; out->ok = 0; }
+        return;
+    }
+    float* x1 = lds;            // targets (image i)
+    float* y1 = x1 + n;
+    float* x2 = y1 + n;         // sources (image j)
+    float* y2 = x2 + n;
+    float* J  = y2 + n;         // 2n x 8
+    float* JL = J + 16 * n;     // 8 x 2n
+    float* C  = JL + 16 * n;    // 2n
+    for (int i = tid; i < n; i += RB) { x1[i] = P1[i].x; y1[i] = P1[i].y; x2[i] = P2[i].x; y2[i] = P2[i].y; }
+    if (tid < 8) s_state[tid] = (tid == 2 || tid == 3) ? -1 : 0;
+    if (tid < 9) { s_bestH[tid] = 0.0f; s_firstH[tid] = 0.0f; }
+    __syncthreads();
+
+    const float d2 = a.dist * a.dist;                      // :1757
+    const float invn = 1.0f / (float)n;                    // :1763
+    const int sample_times = a.sample_times > 5000 ? 5000 : a.sample_times;
+    const uint16_t* table = a.tables + (size_t)(a.table_of ? a.table_of[pair] : (n - 4)) * MAX_DRAWS * 4;
+
+    float scratch[320];
+    float h[9];
+    for (int base = 0; ; base += RB) {
+        const int r = base + tid;
+        int flag = 2, support = 0;                         // 2 = no such draw (stream of 4999 draws exhausted)
+        if (r < MAX_DRAWS) {
+            float p[16];
+            const uint16_t* s = table + 4 * r;
+#pragma unroll
+            for (int i = 0; i < 4; i++) { const int k = s[i]; p[4 * i] = x1[k]; p[4 * i + 1] = y1[k]; p[4 * i + 2] = x2[k]; p[4 * i + 3] = y2[k]; }
+            hm::solve_h4(p, h, scratch);                   // :1863
+            if (h[8] > 5.0f) flag = 0;                     // :1864-1867 skipped, no slot consumed
+            else {
+                flag = 1;
+                if (h[8] < 5.0f && h[8] > 0.01f) {         // :1868-1876
+                    float fine[9];
+                    hm::nlls4(p, h, fine, scratch);
+#pragma unroll
+                    for (int i = 0; i < 9; i++) h[i] = fine[i];
+                }
+                for (int i = 0; i < n; i++) {              // :1890-1904
+                    float bx, by;
+                    hm::apply_recip1(h, x2[i], y2[i], bx, by);
+                    const float dx = bx - x1[i], dy = by - y1[i];
+                    const float dd = dx * dx + dy * dy;
+                    if (dd < d2) support++;
+                }
+            }
+        }
+        s_flag[tid] = flag; s_sup[tid] = support;
+        __syncthreads();
+        if (tid == 0) {                                    // replay of the sequential loop over this chunk
+            int t = s_state[0], mx = s_state[1], best = s_state[2], first = s_state[3], fin = 0;
+            int newBest = -1, newFirst = -1;
+            for (int k = 0; k < RB; k++) {
+                const int f = s_flag[k];
+                if (f == 2) { fin = 1; break; }
+                if (f == 0) continue;
+                if (first < 0) { first = base + k; newFirst = k; }
+                if (s_sup[k] > mx) {                       // :1905
+                    mx = s_sup[k]; best = base + k; newBest = k;
+                    if ((float)mx * invn > 0.99f) { fin = 1; break; }      // :1913
+                }
+                t++;
+                if (t >= sample_times) { fin = 1; break; }
+            }
+            s_state[0] = t; s_state[1] = mx; s_state[2] = best; s_state[3] = first; s_state[4] = fin;
+            s_state[5] = newBest; s_state[6] = newFirst;
+        }
+        __syncthreads();
+        if (s_state[5] == tid) { for (int i = 0; i < 9; i++) s_bestH[i] = h[i]; }
+        if (s_state[6] == tid) { for (int i = 0; i < 9; i++) s_firstH[i] = h[i]; }
+        const int fin = s_state[4];
+        __syncthreads();
+        if (fin) break;
+    }
+    // winner: hyp[maxSupportIndex]; maxSupportIndex stays 0 when no support was ever positive (:1783) -> first accepted
+    float W[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) W[i] = (s_state[2] >= 0) ? s_bestH[i] : s_firstH[i];
+
+    // ---- inlier split, true-division form (:1922-1944), order preserving compaction ----
+    int cnt = 0;
+    for (int base = 0; base < n; base += RB) {
+        const int i = base + tid;
+        bool in = false;
+        if (i < n) {
+            float bx, by;
+            hm::apply_div1(W, x2[i], y2[i], bx, by);
+            const float dx = bx - x1[i], dy = by - y1[i];
+            const float dd = dx * dx + dy * dy;
+            in = dd < d2;
+        }
+        int tot;
+        const int pos = cnt + block_exclusive_scan_flags(in, tid, s_wtot, tot);
+        if (in && pos < MI355_MAX_SELECTED) { out->a[pos] = P1[i]; out->b[pos] = P2[i]; }
+        if (in) { C[pos] = (float)i; }                      // remember source index (C reused later)
+        cnt += tot;
+    }
+    __syncthreads();
+    if (cnt < 4) {                                          // :1953-1961 refit fails below 4 -> no H; :2024-2032
+        if (tid == 0) { out->n_in = cnt; out->ok = 0; }
+        return;
+    }
+    // inlier coordinates, compacted in place into the head of the LDS arrays: read (<= 2 per lane since
+    // cnt <= 400), barrier, write
+    float ix1[2], iy1[2], ix2[2], iy2[2];
+    {
+        int m = 0;
+        for (int i = tid; i < cnt; i += RB) { const int s = (int)C[i]; ix1[m] = x1[s]; iy1[m] = y1[s]; ix2[m] = x2[s]; iy2[m] = y2[s]; m++; }
+    }
+    __syncthreads();
+    {
+        int m = 0;
+        for (int i = tid; i < cnt; i += RB) { x1[i] = ix1[m]; y1[i] = iy1[m]; x2[i] = ix2[m]; y2[i] = iy2[m]; m++; }
+    }
+    if (tid < 8) s_w[tid] = W[tid];
+    if (tid < 64) s_T2[tid] = 0.0f;
+    __syncthreads();
+
+    // ---- NonlinearLeastSquareProjection2 over the inliers from the winning hypothesis (:1977-1986) ----
+    const int rows = 2 * cnt;
+    for (int it = 0; it < 15; it++) {
+        for (int i = tid; i < cnt; i += RB) {
+            const float X2 = x1[i], Y2 = y1[i], X1 = x2[i], Y1 = y2[i];      // LeastSquare.h naming: 1 = source, 2 = target
+            const float d = s_w[6] * X1 + s_w[7] * Y1 + 1.0f;
+            const float nx = s_w[0] * X1 + s_w[1] * Y1 + s_w[2];
+            const float ny = s_w[3] * X1 + s_w[4] * Y1 + s_w[5];
+            float* j = J + i * 16;
+            j[0] = X1 / d; j[1] = Y1 / d; j[2] = 1.0f / d; j[3] = 0.0f; j[4] = 0.0f; j[5] = 0.0f;
+            j[6] = ((-X1) * nx) / (d * d); j[7] = ((-Y1) * nx) / (d * d);
+            j[8] = 0.0f; j[9] = 0.0f; j[10] = 0.0f; j[11] = X1 / d; j[12] = Y1 / d; j[13] = 1.0f / d;
+            j[14] = ((-X1) * ny) / (d * d); j[15] = ((-Y1) * ny) / (d * d);
+            C[2 * i] = X2 - nx / d; C[2 * i + 1] = Y2 - ny / d;
+        }
+        __syncthreads();
+        if (tid < 64) {                                     // J^T J, entry (r,c): k-ordered accumulation
+            const int r = tid >> 3, c = tid & 7;
+            float acc = 0.0f;
+            for (int k = 0; k < rows; k++) { const float pr = J[k * 8 + r] * J[k * 8 + c]; acc = acc + pr; }
+            s_T1[tid] = acc;
+        }
+        __syncthreads();
+        if (tid == 0) hm::inverse_matrix<8>(s_T1, 8, s_T2, 1e-6f, s_t);      // LeastSquare.h:451 (stale T2 on failure)
+        __syncthreads();
+        for (int e = tid; e < 8 * rows; e += RB) {         // J* = (J^T J)^-1 J^T
+            const int r = e / rows, k = e - r * rows;
+            float acc = 0.0f;
+#pragma unroll
+            for (int m = 0; m < 8; m++) { const float pr = s_T2[r * 8 + m] * J[k * 8 + m]; acc = acc + pr; }
+            JL[e] = acc;
+        }
+        __syncthreads();
+        if (tid < 8) {
+            float acc = 0.0f;
+            for (int k = 0; k < rows; k++) { const float pr = JL[tid * rows + k] * C[k]; acc = acc + pr; }
+            s_dX[tid] = acc;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int done = 1;
+            for (int i = 0; i < 8; i++) { s_w[i] = s_w[i] + s_dX[i]; if (!(fabsf(s_dX[i]) < 1e-10f)) done = 0; }
+            s_state[7] = done;
+        }
+        __syncthreads();
+        if (s_state[7]) break;
+    }
+    // motion[8] = max residual in float (LeastSquare.h:503-519): max is order independent
+    float emax = 0.0f;
+    for (int i = tid; i < cnt; i += RB) {
+        float fx, fy;
+        hm::apply_recip1(s_w, x2[i], y2[i], fx, fy);
+        const float dx = x1[i] - fx, dy = y1[i] - fy;
+        const float d = sqrtf(dx * dx + dy * dy);
+        if (d > emax) emax = d;
+    }
+    unsigned bits = __float_as_uint(emax);                  // non-negative floats order like their bit patterns
+    if (emax != emax) bits = 0;                             // NaN never wins `d > max` in the reference
+    for (int off = 32; off > 0; off >>= 1) { const unsigned o = __shfl_xor(bits, off); bits = o > bits ? o : bits; }
+    if ((tid & 63) == 0) s_wtot[tid >> 6] = (int)bits;
+    __syncthreads();
+    if (tid == 0) {
+        unsigned m = 0;
+        for (int i = 0; i < RB / 64; i++) { const unsigned v = (unsigned)s_wtot[i]; m = v > m ? v : m; }
+        for (int i = 0; i < 8; i++) out->H[i] = s_w[i];
+        out->H[8] = __uint_as_float(m);
+        out->n_in = cnt;
+        out->ok = 1;
+    }
+}
+
+}  // namespace
+
+// ---- host: glibc rand() (TYPE_3 additive feedback, stdlib/random_r.c) and the draw table ------------------
+namespace {
+struct GlibcRand {
+    int32_t r[34]; int f, b;
+    void seed(uint32_t s) {
+        if (s == 0) s = 1;
+        r[0] = (int32_t)s;
+        for (int i = 1; i < 31; i++) {
+            const long hi = r[i - 1] / 127773, lo = r[i - 1] % 127773;
+            long word = 16807 * lo - 2836 * hi;
+            if (word < 0) word += 2147483647;
+            r[i] = (int32_t)word;
+        }
+        f = 3; b = 0;
+        for (int i = 0; i < 310; i++) (void)next();
+    }
+    int next() {
+        const uint32_t v = (uint32_t)r[f] + (uint32_t)r[b];
+        r[f] = (int32_t)v;
+        if (++f >= 31) f = 0;
+        if (++b >= 31) b = 0;
+        return (int)(v >> 1);
+    }
+};
+}  // namespace
+
+// mosaicimage.h:1777-1813: srand(seed); per draw: four rand()%n, all four redrawn until pairwise distinct
+void mi_glibc_draw_table(uint32_t seed, int n, int max_draws, uint16_t* out4) {
+    GlibcRand g;
+    g.seed(seed);
+    for (int d = 0; d < max_draws; d++) {
+        int s[4];
+        do { for (int i = 0; i < 4; i++) s[i] = g.next() % n; }
+        while (s[0] == s[1] || s[0] == s[2] || s[0] == s[3] || s[1] == s[2] || s[1] == s[3] || s[2] == s[3]);
+        for (int i = 0; i < 4; i++) out4[4 * d + i] = (uint16_t)s[i];
+    }
+}
+
+int mi_ransac_batch(mi355_ctx* ctx, const mi355_sfpoint* d_p1, const mi355_sfpoint* d_p2, const int* d_n, const int* h_n,
+                    int n_pairs, int stride, float dist, int sample_times, uint32_t seed, mi355_pair_result* d_out) {
+    if (n_pairs <= 0) return MI355_OK;
+    const size_t one = (size_t)MAX_DRAWS * 4;
+    const uint16_t* d_tables = nullptr;
+    const int* d_table_of = nullptr;
+    int nmax = MI355_MAX_SELECTED;
+    if (h_n) {
+        // host knows every n: one draw table per distinct n (the stream itself depends only on the seed)
+        std::map<int, int> table_idx;
+        nmax = 4;
+        for (int i = 0; i < n_pairs; i++) {
+            const int n = h_n[i];
+            if (n > MI355_MAX_SELECTED) { ctx->set_error("ransac: more than 400 correspondences in one pair"); return MI355_ERR_ARG; }
+            if (n >= 4 && !table_idx.count(n)) { const int id = (int)table_idx.size(); table_idx[n] = id; }
+            if (n > nmax) nmax = n;
+        }
+        DevBuf& dtab = ctx->buf("ransac_tables");
+        DevBuf& dof = ctx->buf("ransac_table_of");
+        std::vector<uint16_t> tabs(one * (table_idx.empty() ? 1 : table_idx.size()));
+        for (auto& kv : table_idx) mi_glibc_draw_table(seed, kv.first, MAX_DRAWS, tabs.data() + one * kv.second);
+        std::vector<int> tof(n_pairs);
+        for (int i = 0; i < n_pairs; i++) tof[i] = h_n[i] >= 4 ? table_idx[h_n[i]] : 0;
+        MI_HIP(dtab.reserve(tabs.size() * sizeof(uint16_t)));
+        MI_HIP(dof.reserve(sizeof(int) * n_pairs));
+        MI_HIP(hipMemcpyAsync(dtab.p, tabs.data(), tabs.size() * sizeof(uint16_t), hipMemcpyHostToDevice, ctx->stream));
+        MI_HIP(hipMemcpyAsync(dof.p, tof.data(), sizeof(int) * n_pairs, hipMemcpyHostToDevice, ctx->stream));
+        MI_HIP(hipStreamSynchronize(ctx->stream));              // host vectors go out of scope
+        d_tables = dtab.as<uint16_t>(); d_table_of = dof.as<int>();
+    } else {
+        // n is only known on the device (output of the selection kernel): tables for every n in [4, 400],
+        // indexed by n - 4, built once per seed and cached in HBM (397 x 40 KB = 15.9 MB)
+        auto key = std::make_pair(seed, 0);
+        auto it = ctx->draw_tables.find(key);
+        if (it == ctx->draw_tables.end()) {
+            if (ctx->draw_tables.size() >= 4) {             // keep at most 4 seeds resident
+                MI_HIP(hipStreamSynchronize(ctx->stream));
+                for (auto& kv : ctx->draw_tables) kv.second.release();
+                ctx->draw_tables.clear();
+            }
+            const int ntab = MI355_MAX_SELECTED - 4 + 1;
+            std::vector<uint16_t> tabs(one * ntab);
+            for (int n = 4; n <= MI355_MAX_SELECTED; n++) mi_glibc_draw_table(seed, n, MAX_DRAWS, tabs.data() + one * (n - 4));
+            DevBuf& b = ctx->draw_tables[key];
+            MI_HIP(b.reserve(tabs.size() * sizeof(uint16_t)));
+            MI_HIP(hipMemcpyAsync(b.p, tabs.data(), tabs.size() * sizeof(uint16_t), hipMemcpyHostToDevice, ctx->stream));
+            MI_HIP(hipStreamSynchronize(ctx->stream));
+            it = ctx->draw_tables.find(key);
+        }
+        d_tables = it->second.as<uint16_t>();
+    }
+    RansacArgs a;
+    a.p1 = d_p1; a.p2 = d_p2; a.n = d_n; a.tables = d_tables; a.table_of = d_table_of;
+    a.stride = stride; a.dist = dist; a.sample_times = sample_times; a.out = d_out;
+    const size_t lds_bytes = (size_t)38 * nmax * sizeof(float);
+    if (lds_bytes > 48 * 1024) {
+        MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ransac_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    }
+    {
+        ProfScope ps(ctx, "ransac", (double)n_pairs * (24.0 * nmax + sizeof(mi355_pair_result)));
+        hipLaunchKernelGGL(ransac_kernel, dim3(n_pairs), dim3(RB), lds_bytes, ctx->stream, a);
+    }
+    MI_HIP(hipGetLastError());
+    return MI355_OK;
+}

@@ -1,0 +1,449 @@
+// csrc/warp.hip -- K9 inverse-mapping bilinear warps and K10 distance-map masks (gfx950).
+//
+// Replaces the reference's hand-written warps (paths relative to code/MosaicingCode/mosaicing/):
+//   ImageProjectionTransform             MosaicImage.cpp:1613-1758       -> mi_warp_image
+//   CMosaicByPose::MosaicImagesRefined   MosaicWithoutPos.cpp:2194-2352  -> mi_mosaic_refined_dev
+//   LaplacianPyramidBlending warp stage  MosaicImage.cpp:2233-2460       -> mi_chips_and_masks (chips)
+//   FindMasksByDistMap                   MosaicImage.cpp:1761-1881       -> mi_chips_and_masks (masks)
+//
+// Parity contract: bit-exact pixels.  The source coordinate is two true float divisions by the same
+// denominator, truncated with (int); the pixel is the 4-term float expression of hm::bilin.  This TU is
+// compiled with -ffp-contract=off; HIP's fp32 division is correctly rounded by default.
+//
+// Kernel shape: HBM-bound gather.  One thread produces 4 horizontally adjacent destination pixels
+// (12 bytes = three aligned dwords for BGR) so that interior groups are written with dword stores and
+// never read the canvas; only partially covered groups (image borders) fall back to byte stores, which is
+// what preserves the reference's "later image overwrites earlier only where it has a valid sample".
+// A wave covers 256 consecutive destination pixels of one row: its source footprint is a short, nearly
+// contiguous run of the source row pair, so the 6-byte neighbourhood loads hit the same cache lines.
+#include "common.h"
+#include "hmath.h"
+
+namespace {
+
+struct WarpArgs {
+    const uint8_t* src; int w, h, ws;          // source image
+    uint8_t* dst; int dws;                      // destination (canvas / chip / tight image), row stride
+    uint8_t* mask; int mws;                     // chip validity mask (CHIP mode) or nullptr
+    int x_beg, x_end, y_beg, y_end;             // inclusive destination range to visit
+    float inv[9];                               // inverse homography (destination -> source)
+    float dx, dy;                               // mode 0: xs = (float)xD - dx
+    float sx, sy; int x0, y0;                   // mode 1 (chips): ((float)xD - dx) - sx + (float)x0
+};
+
+template <int CH>
+__device__ __forceinline__ void load_pair(const uint8_t* s, float& a, float& b, float& c, float& a1, float& b1, float& c1);
+
+// 6 bytes (two BGR pixels) with one dword + one ushort load; the device handles unaligned addresses.
+template <>
+__device__ __forceinline__ void load_pair<3>(const uint8_t* s, float& b0, float& g0, float& r0, float& b1, float& g1, float& r1) {
+    uint32_t lo; uint16_t hi;
+    __builtin_memcpy(&lo, s, 4);
+    __builtin_memcpy(&hi, s + 4, 2);
+    b0 = (float)(lo & 0xff); g0 = (float)((lo >> 8) & 0xff); r0 = (float)((lo >> 16) & 0xff);
+    b1 = (float)(lo >> 24);  g1 = (float)(hi & 0xff);        r1 = (float)(hi >> 8);
+}
+
+template <int CH, bool CHIP>
+__global__ __launch_bounds__(256) void warp_kernel(WarpArgs a) {
+    const int gx = blockIdx.x * blockDim.x + threadIdx.x;          // group of 4 pixels
+    const int yD = a.y_beg + blockIdx.y * blockDim.y + threadIdx.y;
+    const int xg = (a.x_beg & ~3) + gx * 4;
+    if (yD > a.y_end || xg > a.x_end) return;
+    const float w1 = (float)(a.w - 1), h1 = (float)(a.h - 1);
+    uint8_t out[4 * CH];
+    bool valid[4];
+    int nvalid = 0, ninside = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int xD = xg + k;
+        valid[k] = false;
+        const bool inside = (xD >= a.x_beg) && (xD <= a.x_end);
+        if (!inside) continue;
+        ninside++;
+        float xf, yf;
+        if (CHIP) {
+            xf = (((float)xD - a.dx) - a.sx) + (float)a.x0;
+            yf = (((float)yD - a.dy) - a.sy) + (float)a.y0;
+        } else {
+            xf = (float)xD - a.dx;
+            yf = (float)yD - a.dy;
+        }
+        float xs, ys;
+        hm::apply_div9(a.inv, xf, yf, xs, ys);
+        if (!(xs >= 0.0f && xs < w1 && ys >= 0.0f && ys < h1)) continue;      // also rejects NaN
+        const int xi = (int)xs, yi = (int)ys;
+        const float p = ys - (float)yi, q = xs - (float)xi;
+        const uint8_t* s = a.src + (size_t)yi * a.ws + (size_t)CH * xi;
+        if (CH == 3) {
+            float b00, g00, r00, b01, g01, r01, b10, g10, r10, b11, g11, r11;
+            load_pair<3>(s, b00, g00, r00, b01, g01, r01);
+            load_pair<3>(s + a.ws, b10, g10, r10, b11, g11, r11);
+            out[3 * k + 0] = hm::bilin(b00, b01, b10, b11, p, q);
+            out[3 * k + 1] = hm::bilin(g00, g01, g10, g11, p, q);
+            out[3 * k + 2] = hm::bilin(r00, r01, r10, r11, p, q);
+        } else {
+            uint16_t t0, t1;
+            __builtin_memcpy(&t0, s, 2);
+            __builtin_memcpy(&t1, s + a.ws, 2);
+            out[k] = hm::bilin((float)(t0 & 0xff), (float)(t0 >> 8), (float)(t1 & 0xff), (float)(t1 >> 8), p, q);
+        }
+        valid[k] = true;
+        nvalid++;
+    }
+    uint8_t* drow = a.dst + (size_t)yD * a.dws + (size_t)CH * xg;
+    if (nvalid == 4) {
+        // whole group valid: aligned dword stores (xg % 4 == 0 and dws % 4 == 0)
+        uint32_t* d32 = reinterpret_cast<uint32_t*>(drow);
+        const uint32_t* o32 = reinterpret_cast<const uint32_t*>(out);
+#pragma unroll
+        for (int i = 0; i < CH; i++) d32[i] = o32[i];
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            if (valid[k])
+                for (int c = 0; c < CH; c++) drow[CH * k + c] = out[CH * k + c];
+    }
+    if (CHIP) {
+        // mask = 255 where a sample exists, 0 elsewhere (MosaicImage.cpp:2345, 2444-2447); chip pixels
+        // without a sample are zeroed (the reference leaves them uninitialised)
+        uint8_t* mrow = a.mask + (size_t)yD * a.mws + xg;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int xD = xg + k;
+            if (xD < a.x_beg || xD > a.x_end) continue;
+            mrow[k] = valid[k] ? 255 : 0;
+            if (!valid[k]) for (int c = 0; c < CH; c++) drow[CH * k + c] = 0;
+        }
+    }
+    (void)ninside;
+}
+
+template <int CH, bool CHIP>
+void launch_warp(mi355_ctx* ctx, const WarpArgs& a) {
+    if (a.x_end < a.x_beg || a.y_end < a.y_beg) return;
+    const int groups = (a.x_end - (a.x_beg & ~3)) / 4 + 1;
+    const int rows = a.y_end - a.y_beg + 1;
+    dim3 block(64, 4);
+    dim3 grid((groups + 63) / 64, (rows + 3) / 4);
+    const double bytes = (double)CH * ((double)(a.x_end - a.x_beg + 1) * rows) * 2.0;   // read ~P + write P
+    ProfScope ps(ctx, "warp", bytes);
+    hipLaunchKernelGGL((warp_kernel<CH, CHIP>), grid, block, 0, ctx->stream, a);
+}
+
+inline float big() { return (float)(1 << 29); }
+
+// corners (0,0) (w-1,0) (w-1,h-1) (0,h-1) through the two-division form
+void corner_bbox(const float* m, int w, int h, float& minX, float& minY, float& maxX, float& maxY, float* quad = nullptr) {
+    const float cx[4] = {0.0f, (float)(w - 1), (float)(w - 1), 0.0f};
+    const float cy[4] = {0.0f, 0.0f, (float)(h - 1), (float)(h - 1)};
+    for (int i = 0; i < 4; i++) {
+        float X, Y;
+        hm::apply_div9(m, cx[i], cy[i], X, Y);
+        if (quad) { quad[2 * i] = X; quad[2 * i + 1] = Y; }
+        if (X < minX) minX = X;
+        if (X > maxX) maxX = X;
+        if (Y < minY) minY = Y;
+        if (Y > maxY) maxY = Y;
+    }
+}
+
+}  // namespace
+
+int mi_inverse_matrix_host(const float* src, int order, float* dst, float eps) {
+    float t[2 * 13 * 13];
+    return hm::inverse_matrix<13>(src, order, dst, eps, t);
+}
+
+// MosaicWithoutPos.cpp:2199-2249
+extern "C" int mi355_mosaic_layout(const int* w, const int* h, int n, const float* h9s, int* cw, int* ch, int* cws, float* dGxy) {
+    if (!w || !h || !h9s || n <= 0) return MI355_ERR_ARG;
+    float minX = big(), minY = big(), maxX = -big(), maxY = -big();
+    bool any = false;
+    for (int k = 0; k < n; k++) {
+        const float* m = h9s + 9 * k;
+        if (m[8] == 0.0f) continue;                 // "invalid image" convention, MosaicWithoutPos.cpp:2205, 4646-4652
+        corner_bbox(m, w[k], h[k], minX, minY, maxX, maxY);
+        any = true;
+    }
+    if (!any) return MI355_ERR_FAILED;
+    const int mw = (int)(maxX - minX + 1.5f), mh = (int)(maxY - minY + 1.5f);
+    if (mw <= 0 || mh <= 0) return MI355_ERR_FAILED;
+    if (cw) *cw = mw;
+    if (ch) *ch = mh;
+    if (cws) *cws = (mw * 3 + 3) & ~3;              // IplImage rows are padded to 4 bytes
+    if (dGxy) { dGxy[0] = -minX; dGxy[1] = -minY; }
+    return MI355_OK;
+}
+
+int mi_mosaic_refined_dev(mi355_ctx* ctx, const uint8_t* const* d_imgs, const int* w, const int* h, const int* ws, int n,
+                          const float* h9s, uint8_t* d_canvas, int cw, int ch, int cws, int row0, int rows) {
+    int lw, lh, lws; float dG[2];
+    int rc = mi355_mosaic_layout(w, h, n, h9s, &lw, &lh, &lws, dG);
+    if (rc != MI355_OK) { ctx->set_error("mosaic_refined: no image with h[8] != 0 / empty canvas"); return rc; }
+    if (lw != cw || lh != ch || cws < cw * 3 || (cws & 3)) { ctx->set_error("mosaic_refined: canvas geometry does not match mi355_mosaic_layout"); return MI355_ERR_ARG; }
+    if (row0 < 0) row0 = 0;
+    if (rows < 0 || row0 + rows > ch) rows = ch - row0;
+    MI_HIP(hipMemsetAsync(d_canvas + (size_t)row0 * cws, 0, (size_t)rows * cws, ctx->stream));
+    for (int k = 0; k < n; k++) {                  // ascending image order = overwrite order (MosaicWithoutPos.cpp:2254)
+        const float* m = h9s + 9 * k;
+        if (m[8] == 0.0f) continue;
+        WarpArgs a;
+        memset(&a, 0, sizeof(a));
+        if (mi_inverse_matrix_host(m, 3, a.inv, 1e-12f) != 1) continue;   // MosaicWithoutPos.cpp:2275 (reference: garbage invH)
+        float bminX = big(), bminY = big(), bmaxX = -big(), bmaxY = -big();
+        {
+            const float cx[4] = {0.0f, (float)(w[k] - 1), (float)(w[k] - 1), 0.0f};
+            const float cy[4] = {0.0f, 0.0f, (float)(h[k] - 1), (float)(h[k] - 1)};
+            for (int i = 0; i < 4; i++) {
+                float X, Y;
+                hm::apply_div9(m, cx[i], cy[i], X, Y);
+                X = X + (0.0f + dG[0]); Y = Y + (0.0f + dG[1]);
+                if (X < bminX) bminX = X;
+                if (X > bmaxX) bmaxX = X;
+                if (Y < bminY) bminY = Y;
+                if (Y > bmaxY) bmaxY = Y;
+            }
+        }
+        int begY = (int)(bminY - 0.5f), endY = (int)(bmaxY + 0.5f);       // :2305-2306
+        int begX = (int)(bminX - 0.5f), endX = (int)(bmaxX + 0.5f);
+        if (begX < 0) begX = 0;
+        if (begY < 0) begY = 0;
+        if (endX > cw - 1) endX = cw - 1;
+        if (endY > ch - 1) endY = ch - 1;
+        if (begY < row0) begY = row0;                                   // canvas stripe
+        if (endY > row0 + rows - 1) endY = row0 + rows - 1;
+        a.src = d_imgs[k]; a.w = w[k]; a.h = h[k]; a.ws = ws[k];
+        a.dst = d_canvas; a.dws = cws; a.mask = nullptr; a.mws = 0;
+        a.x_beg = begX; a.x_end = endX; a.y_beg = begY; a.y_end = endY;
+        a.dx = dG[0]; a.dy = dG[1];
+        launch_warp<3, false>(ctx, a);
+    }
+    MI_HIP(hipGetLastError());
+    return MI355_OK;
+}
+
+int mi_warp_image(mi355_ctx* ctx, const uint8_t* src, int w, int h, int ws, int ch, const float* h9,
+                  uint8_t** dst, int* dw, int* dh, int* dws) {
+    if (!src || !h9 || !dst || w < 2 || h < 2 || (ch != 1 && ch != 3) || ws < w * ch) { ctx->set_error("warp_image: bad arguments"); return MI355_ERR_ARG; }
+    float minX = big(), minY = big(), maxX = -big(), maxY = -big();
+    corner_bbox(h9, w, h, minX, minY, maxX, maxY);
+    const int nw = (int)(maxX - minX + 1.5f), nh = (int)(maxY - minY + 1.5f);       // MosaicImage.cpp:1653-1654
+    if (nw <= 0 || nh <= 0) { ctx->set_error("warp_image: empty result"); return MI355_ERR_ARG; }     // CreateBitmap8U -> NULL
+    const int nws = (nw * ch + 3) / 4 * 4;                                               // ImageIO.cpp:70
+    WarpArgs a;
+    memset(&a, 0, sizeof(a));
+    if (mi_inverse_matrix_host(h9, 3, a.inv, 1e-6f) != 1) { ctx->set_error("warp_image: homography not invertible"); return MI355_ERR_SINGULAR; }
+    DevBuf& dsrc = ctx->buf("warp_src");
+    DevBuf& ddst = ctx->buf("warp_dst");
+    const size_t src_bytes = (size_t)ws * h, dst_bytes = (size_t)nws * nh;
+    MI_HIP(dsrc.reserve(src_bytes + 16));
+    MI_HIP(ddst.reserve(dst_bytes));
+    MI_HIP(hipMemcpyAsync(dsrc.p, src, src_bytes, hipMemcpyHostToDevice, ctx->stream));
+    MI_HIP(hipMemsetAsync(ddst.p, 0, dst_bytes, ctx->stream));                            // ZeroImage, MosaicImage.cpp:1659
+    a.src = dsrc.as<uint8_t>(); a.w = w; a.h = h; a.ws = ws;
+    a.dst = ddst.as<uint8_t>(); a.dws = nws;
+    a.x_beg = 0; a.x_end = nw - 1; a.y_beg = 0; a.y_end = nh - 1;
+    a.dx = -minX; a.dy = -minY;
+    if (ch == 3) launch_warp<3, false>(ctx, a); else launch_warp<1, false>(ctx, a);
+    uint8_t* out = (uint8_t*)malloc(dst_bytes);
+    if (!out) return MI355_ERR_NOMEM;
+    hipError_t e = hipMemcpyAsync(out, ddst.p, dst_bytes, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) { free(out); ctx->set_error(hipGetErrorString(e)); return MI355_ERR_DEVICE; }
+    *dst = out; *dw = nw; *dh = nh; *dws = nws;
+    return MI355_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// chips + masks
+// ---------------------------------------------------------------------------------------------------------
+namespace {
+
+struct ChipDev { int x0, y0, w, h, mws; size_t map_off; };
+
+// ImageMath.cpp:88-103 LineOf2Points1
+void line_of_2_points(float& a, float& b, float& c, float x1, float y1, float x2, float y2) {
+    if (fabs((double)(x1 - x2)) < 0.000001) { a = 1.0f; b = 0.0f; c = -x1; }
+    else { a = (y1 - y2) / (x1 - x2); b = -1.0f; c = y1 - a * x1; }
+}
+
+struct LineSet { float A[4], B[4], C[4], inv[4]; };
+
+// per chip: min distance to the 4 quad edges for valid pixels, and the chip-wide max (float bits, all >= 0)
+__global__ __launch_bounds__(256) void distmap_kernel(const uint8_t* mask, int mws, int w, int h, LineSet L, float* map, unsigned* maxbits) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    const int r = blockIdx.y * blockDim.y + threadIdx.y;
+    float v = 0.0f;
+    if (c < w && r < h) {
+        if (mask[(size_t)r * mws + c] != 0) {
+            float minDist = (float)(1 << 29);
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                float d = fabsf(L.A[i] * (float)c + L.B[i] * (float)r + L.C[i]) * L.inv[i];
+                if (d < minDist) minDist = d;
+            }
+            v = minDist;
+        }
+        map[(size_t)r * mws + c] = v;
+    }
+    // wave max via shuffles, then one atomic per wave
+    unsigned bits = __float_as_uint(v);
+    for (int off = 32; off > 0; off >>= 1) { unsigned o = __shfl_xor(bits, off); bits = o > bits ? o : bits; }
+    if (((threadIdx.y * blockDim.x + threadIdx.x) & 63) == 0 && bits) atomicMax(maxbits, bits);
+}
+
+__global__ __launch_bounds__(256) void distmap_norm_kernel(float* map, int mws, int w, int h, const unsigned* maxbits) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    const int r = blockIdx.y * blockDim.y + threadIdx.y;
+    if (c >= w || r >= h) return;
+    const float mx = __uint_as_float(*maxbits);
+    map[(size_t)r * mws + c] = map[(size_t)r * mws + c] / mx;               // MosaicImage.cpp:1828
+}
+
+// per canvas pixel: chip with the strictly largest normalised distance (first wins, start 0) -> owner index
+__global__ __launch_bounds__(256) void owner_kernel(const ChipDev* chips, int n, const float* maps, int rectW, int rectH, uint8_t* const* masks) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    const int r = blockIdx.y * blockDim.y + threadIdx.y;
+    if (c >= rectW || r >= rectH) return;
+    int best = -1; float bd = 0.0f;
+    for (int k = 0; k < n; k++) {
+        const int yC = r - chips[k].y0, xC = c - chips[k].x0;
+        if (yC >= 0 && yC < chips[k].h && xC >= 0 && xC < chips[k].w) {
+            const float d = maps[chips[k].map_off + (size_t)yC * chips[k].mws + xC];
+            if (d > bd) { bd = d; best = k; }
+        }
+    }
+    if (best >= 0) masks[best][(size_t)(r - chips[best].y0) * chips[best].mws + (c - chips[best].x0)] = 255;
+}
+
+}  // namespace
+
+int mi_chips_and_masks(mi355_ctx* ctx, const uint8_t* const* imgs, const int* w, const int* h, const int* ws, int n,
+                       const float* h9s, const uint8_t* keep, int find_masks, int* n_chips, mi355_chip_info** chips_out,
+                       uint8_t*** chip_imgs, uint8_t*** masks_out, int* cw_out, int* ch_out) {
+    if (!imgs || !w || !h || !ws || !h9s || n <= 0 || !n_chips || !chips_out || !chip_imgs || !masks_out) return MI355_ERR_ARG;
+    // ---- layout, MosaicImage.cpp:2233-2343 (host, same float ops) ----
+    float maxX = 0.0f, maxY = 0.0f, minX = 0.0f, minY = 0.0f;                     // :2234 (canvas always contains the origin)
+    std::vector<float> bx0(n), by0(n), bx1(n), by1(n);
+    std::vector<int> kept;
+    for (int k = 0; k < n; k++) {
+        const float* m = h9s + 9 * k;
+        if ((keep && !keep[k]) || m[8] == 0.0f) continue;
+        float bMinX = big(), bMinY = big(), bMaxX = -big(), bMaxY = -big();
+        corner_bbox(m, w[k], h[k], bMinX, bMinY, bMaxX, bMaxY);
+        if (bMaxX > maxX) maxX = bMaxX;
+        if (bMinX < minX) minX = bMinX;
+        if (bMaxY > maxY) maxY = bMaxY;
+        if (bMinY < minY) minY = bMinY;
+        bx0[k] = bMinX; by0[k] = bMinY; bx1[k] = bMaxX; by1[k] = bMaxY;
+        kept.push_back(k);
+    }
+    const float dGx = -minX, dGy = -minY;
+    const int newW = (int)(maxX - minX + 1.5f), newH = (int)(maxY - minY + 1.5f);
+    const int nv = (int)kept.size();
+    mi355_chip_info* ci = (mi355_chip_info*)calloc((size_t)(nv > 0 ? nv : 1), sizeof(mi355_chip_info));
+    uint8_t** cimg = (uint8_t**)calloc((size_t)(nv > 0 ? nv : 1), sizeof(uint8_t*));
+    uint8_t** cmask = (uint8_t**)calloc((size_t)(nv > 0 ? nv : 1), sizeof(uint8_t*));
+    if (!ci || !cimg || !cmask) return MI355_ERR_NOMEM;
+    std::vector<ChipDev> cd(nv);
+    size_t map_total = 0, chip_total = 0, mask_total = 0;
+    std::vector<size_t> chip_off(nv), mask_off(nv);
+    for (int v = 0; v < nv; v++) {
+        const int k = kept[v];
+        const float* m = h9s + 9 * k;
+        const float bX = bx0[k] + dGx, bY = by0[k] + dGy, eX = bx1[k] + dGx, eY = by1[k] + dGy;     // :2314-2317
+        const int begX = (int)bX, begY = (int)bY, endX = (int)(eX + 0.5f), endY = (int)(eY + 0.5f);
+        const float sx = (float)begX - bX, sy = (float)begY - bY;
+        mi355_chip_info& c = ci[v];
+        c.x0 = begX; c.y0 = begY; c.w = endX - begX + 1; c.h = endY - begY + 1; c.img = k; c.sx = sx; c.sy = sy;
+        const float ox[4] = {0.0f, (float)(w[k] - 1), (float)(w[k] - 1), 0.0f};
+        const float oy[4] = {0.0f, 0.0f, (float)(h[k] - 1), (float)(h[k] - 1)};
+        for (int i = 0; i < 4; i++) {
+            float tx, ty;
+            hm::apply_recip9(m, ox[i], oy[i], tx, ty);                                               // :2334
+            c.quad[2 * i] = ((tx + dGx) + sx) - (float)begX;
+            c.quad[2 * i + 1] = ((ty + dGy) + sy) - (float)begY;
+        }
+        if (c.w <= 0 || c.h <= 0) { ctx->set_error("chips: empty chip"); return MI355_ERR_FAILED; }
+        const int cws = (c.w * 3 + 3) & ~3, mws = (c.w + 3) & ~3;
+        chip_off[v] = chip_total; mask_off[v] = mask_total;
+        chip_total += (size_t)cws * c.h; mask_total += (size_t)mws * c.h;
+        cd[v] = ChipDev{c.x0, c.y0, c.w, c.h, mws, map_total};
+        map_total += (size_t)mws * c.h;
+    }
+    DevBuf& dchips = ctx->buf("chip_imgs");
+    DevBuf& dmasks = ctx->buf("chip_masks");
+    DevBuf& dmaps = ctx->buf("chip_maps");
+    DevBuf& dsrc = ctx->buf("warp_src");
+    DevBuf& dmeta = ctx->buf("chip_meta");
+    MI_HIP(dchips.reserve(chip_total + 16));
+    MI_HIP(dmasks.reserve(mask_total + 16));
+    MI_HIP(hipMemsetAsync(dchips.p, 0, chip_total, ctx->stream));
+    MI_HIP(hipMemsetAsync(dmasks.p, 0, mask_total, ctx->stream));
+    for (int v = 0; v < nv; v++) {
+        const int k = kept[v];
+        const mi355_chip_info& c = ci[v];
+        WarpArgs a;
+        memset(&a, 0, sizeof(a));
+        if (mi_inverse_matrix_host(h9s + 9 * k, 3, a.inv, 1e-12f) != 1) { ctx->set_error("chips: homography not invertible"); return MI355_ERR_SINGULAR; }  // :2348
+        const size_t src_bytes = (size_t)ws[k] * h[k];
+        MI_HIP(hipStreamSynchronize(ctx->stream));               // previous chip may still read warp_src
+        MI_HIP(dsrc.reserve(src_bytes + 16));
+        MI_HIP(hipMemcpyAsync(dsrc.p, imgs[k], src_bytes, hipMemcpyHostToDevice, ctx->stream));
+        a.src = dsrc.as<uint8_t>(); a.w = w[k]; a.h = h[k]; a.ws = ws[k];
+        a.dst = dchips.as<uint8_t>() + chip_off[v]; a.dws = (c.w * 3 + 3) & ~3;
+        a.mask = dmasks.as<uint8_t>() + mask_off[v]; a.mws = cd[v].mws;
+        a.x_beg = 0; a.x_end = c.w - 1; a.y_beg = 0; a.y_end = c.h - 1;
+        a.dx = dGx; a.dy = dGy; a.sx = c.sx; a.sy = c.sy; a.x0 = c.x0; a.y0 = c.y0;
+        launch_warp<3, true>(ctx, a);
+    }
+    // validity masks are final here unless the distance-map ownership is requested
+    if (find_masks && nv > 0) {
+        MI_HIP(dmaps.reserve(map_total * sizeof(float) + 16));
+        const size_t meta_bytes = sizeof(ChipDev) * nv + sizeof(uint8_t*) * nv + sizeof(unsigned) * nv;
+        MI_HIP(dmeta.reserve(meta_bytes + 64));
+        ChipDev* d_cd = dmeta.as<ChipDev>();
+        uint8_t** d_mptr = reinterpret_cast<uint8_t**>(dmeta.as<uint8_t>() + sizeof(ChipDev) * nv);
+        unsigned* d_max = reinterpret_cast<unsigned*>(dmeta.as<uint8_t>() + sizeof(ChipDev) * nv + sizeof(uint8_t*) * nv);
+        std::vector<uint8_t*> mptr(nv);
+        for (int v = 0; v < nv; v++) mptr[v] = dmasks.as<uint8_t>() + mask_off[v];
+        MI_HIP(hipMemcpyAsync(d_cd, cd.data(), sizeof(ChipDev) * nv, hipMemcpyHostToDevice, ctx->stream));
+        MI_HIP(hipMemcpyAsync(d_mptr, mptr.data(), sizeof(uint8_t*) * nv, hipMemcpyHostToDevice, ctx->stream));
+        MI_HIP(hipMemsetAsync(d_max, 0, sizeof(unsigned) * nv, ctx->stream));
+        dim3 block(64, 4);
+        for (int v = 0; v < nv; v++) {
+            const float* q = ci[v].quad;
+            LineSet L;
+            line_of_2_points(L.A[0], L.B[0], L.C[0], q[0], q[1], q[2], q[3]);
+            line_of_2_points(L.A[1], L.B[1], L.C[1], q[2], q[3], q[4], q[5]);
+            line_of_2_points(L.A[2], L.B[2], L.C[2], q[4], q[5], q[6], q[7]);
+            line_of_2_points(L.A[3], L.B[3], L.C[3], q[6], q[7], q[0], q[1]);
+            for (int i = 0; i < 4; i++) L.inv[i] = 1.0f / sqrtf(L.A[i] * L.A[i] + L.B[i] * L.B[i]);       // :1786
+            dim3 grid((ci[v].w + 63) / 64, (ci[v].h + 3) / 4);
+            float* map = dmaps.as<float>() + cd[v].map_off;
+            ProfScope ps(ctx, "distmap", (double)ci[v].w * ci[v].h * 9.0);
+            hipLaunchKernelGGL(distmap_kernel, grid, block, 0, ctx->stream, mptr[v], cd[v].mws, ci[v].w, ci[v].h, L, map, d_max + v);
+            hipLaunchKernelGGL(distmap_norm_kernel, grid, block, 0, ctx->stream, map, cd[v].mws, ci[v].w, ci[v].h, d_max + v);
+        }
+        MI_HIP(hipMemsetAsync(dmasks.p, 0, mask_total, ctx->stream));                                      // cvZero, :1836-1839
+        dim3 grid((newW + 63) / 64, (newH + 3) / 4);
+        {
+            ProfScope ps(ctx, "owner", (double)newW * newH * (4.0 * nv + 1.0));
+            hipLaunchKernelGGL(owner_kernel, grid, block, 0, ctx->stream, d_cd, nv, dmaps.as<float>(), newW, newH, d_mptr);
+        }
+    }
+    for (int v = 0; v < nv; v++) {
+        const size_t cb = (size_t)((ci[v].w * 3 + 3) & ~3) * ci[v].h, mb = (size_t)cd[v].mws * ci[v].h;
+        cimg[v] = (uint8_t*)malloc(cb);
+        cmask[v] = (uint8_t*)malloc(mb);
+        if (!cimg[v] || !cmask[v]) return MI355_ERR_NOMEM;
+        MI_HIP(hipMemcpyAsync(cimg[v], dchips.as<uint8_t>() + chip_off[v], cb, hipMemcpyDeviceToHost, ctx->stream));
+        MI_HIP(hipMemcpyAsync(cmask[v], dmasks.as<uint8_t>() + mask_off[v], mb, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    MI_HIP(hipStreamSynchronize(ctx->stream));
+    *n_chips = nv; *chips_out = ci; *chip_imgs = cimg; *masks_out = cmask;
+    if (cw_out) *cw_out = newW;
+    if (ch_out) *ch_out = newH;
+    return MI355_OK;
+}

@@ -1,0 +1,198 @@
+/* include/mi355_mosaic.h -- C ABI of libmi355mosaic.so
+ *
+ * MI355X-native (gfx950 / CDNA4, HIP) replacement for ONE hot path of YuhuaXu/ImageMosaicing:
+ *   detect+describe -> descriptor match + selection -> RANSAC homography -> inverse-warp into the canvas.
+ * Every entry point names the reference interface it replaces; paths are relative to
+ * code/MosaicingCode/mosaicing/ of the reference.  INTEGRATION.md shows the binding a maintainer adds
+ * on the reference side (mi355_adaptor.h re-exports the reference's own C++ signatures on top of this ABI).
+ *
+ * Conventions
+ *  - plain pointers and sizes, no C++/torch types, no exceptions across the boundary;
+ *  - return 0 on success, <0 on error (MosaicVavImages convention, MosaicWithoutPos.h:631:
+ *    -1 bad arguments, -2 operation failed); mi355_last_error() gives the text;
+ *    bool-like reference functions (Ransac2D) return 1/0;
+ *  - images are caller-owned, BGR u8, rows padded to widthStep bytes (IplImage / BitmapImage layout);
+ *  - homographies are row-major float[9]; pair homographies map image-j points onto image-i points and
+ *    carry H[8] = max residual (matrix.h:866, LeastSquare.h:519), exactly like the reference;
+ *  - there is NO CPU fallback: every compute entry point runs HIP kernels on the ctx's device and
+ *    fails with MI355_ERR_DEVICE when no gfx950 device is usable;
+ *  - a ctx is thread-safe (one internal lock + one HIP stream); results do not depend on call order.
+ */
+#ifndef MI355_MOSAIC_H
+#define MI355_MOSAIC_H
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MI355_OK            0
+#define MI355_ERR_ARG      (-1)   /* bad arguments            (MosaicVavImages: -1) */
+#define MI355_ERR_FAILED   (-2)   /* operation failed         (MosaicVavImages: -2) */
+#define MI355_ERR_SINGULAR (-3)   /* homography not invertible (reference: undefined behaviour) */
+#define MI355_ERR_DEVICE   (-4)   /* no usable gfx950 device / HIP error */
+#define MI355_ERR_NOMEM    (-5)
+
+#define MI355_MAX_SELECTED 400    /* maxNum, MosaicWithoutPos.cpp:5146 */
+#define MI355_DESC_DIM     128
+
+typedef struct mi355_ctx mi355_ctx;
+
+/* Point.h:27-47 SfPoint */
+typedef struct { float x, y; int32_t id; } mi355_sfpoint;
+/* MosaicWithoutPos.h:135-153 MatchPointPairs (40 bytes; the record of matchPairs.match) */
+typedef struct { mi355_sfpoint ptA; int32_t ptA_i, ptA_Fixed; mi355_sfpoint ptB; int32_t ptB_i, ptB_Fixed; } mi355_match_point_pairs;
+/* cv::KeyPoint, OpenCV 2.4.0 features2d.hpp (28 bytes; the record of keypoint_%d.key, MosaicWithoutPos.cpp:4691-4700) */
+typedef struct { float x, y, size, angle, response; int32_t octave, class_id; } mi355_keypoint;
+/* cv::DMatch */
+typedef struct { int32_t queryIdx, trainIdx, imgIdx; float distance; } mi355_dmatch;
+/* MosaicWithoutPos.h:224-228 ImageTransform {ProjectMat h; int fixed;} */
+typedef struct { float m[9]; int32_t fixed; } mi355_image_transform;
+
+/* Result of one image pair (i,j): what GetMatchedPairsOneToAllSIFTThread appends (MosaicWithoutPos.cpp:5201-5221)
+ * plus the homography Ransac2D returned.  Fixed size (9664 B) so that ranks can all-gather arrays of it. */
+typedef struct {
+    int32_t i, j;            /* image indices (ptA_i, ptB_i) */
+    int32_t n_in;            /* inlier count; the reference accepts the pair iff n_in > min_inliers (30) */
+    int32_t n_selected;      /* correspondences after grid selection (<= 396) */
+    int32_t ok;              /* Ransac2D's bool */
+    int32_t accepted;        /* n_in > min_inliers */
+    float   H[9];            /* image j -> image i, H[8] = max residual */
+    int32_t _pad;
+    mi355_sfpoint a[MI355_MAX_SELECTED];   /* inliers in image i (id = keypoint index) */
+    mi355_sfpoint b[MI355_MAX_SELECTED];   /* inliers in image j */
+} mi355_pair_result;
+
+/* Literals of the live path; mi355_default_params() fills the reference's values. */
+typedef struct {
+    int32_t nfeatures;         /* 2000   SIFT(2000,3,0.01,20)            MosaicWithoutPos.cpp:4852 */
+    int32_t n_octave_layers;   /* 3 */
+    float   contrast_threshold;/* 0.01 */
+    float   edge_threshold;    /* 20 */
+    float   sigma;             /* 1.6    cv::SIFT default */
+    int32_t max_selected;      /* 400    maxNum                           MosaicWithoutPos.cpp:5146 */
+    float   select_fraction;   /* 0.3                                     MosaicWithoutPos.cpp:5147 */
+    int32_t grid_x, grid_y;    /* 3,3                                     MosaicWithoutPos.cpp:5041-5042 */
+    int32_t min_inliers;       /* 30     MIN_INNER_POINTS                 MosaicWithoutPos.cpp:5049 */
+    float   ransac_dist;       /* 2.5    UavMatchParam.ransacDist         MosaicWithoutPos.h:74 */
+    int32_t sample_times;      /* 1000                                    mosaicimage.h:1735 */
+    int32_t pair_window;       /* 182    j in (i, min(N, i+182))          MosaicWithoutPos.cpp:5083 */
+    float   ratio;             /* 0 = reference-compatible sort+grid selection; >0: Lowe ratio test on
+                                  squared distances (d1 < ratio^2 * d2) before the grid walk (north_star option) */
+} mi355_params;
+
+void mi355_default_params(mi355_params* p);
+
+/* ---- context -------------------------------------------------------------------------------------- */
+int  mi355_create(mi355_ctx** out, const mi355_params* params /* NULL = defaults */, int device_ordinal);
+void mi355_destroy(mi355_ctx* ctx);
+const char* mi355_last_error(mi355_ctx* ctx);          /* ctx may be NULL: last creation error */
+/* Run on a caller-provided hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); NULL = ctx-owned stream. */
+int  mi355_set_stream(mi355_ctx* ctx, void* hip_stream);
+int  mi355_synchronize(mi355_ctx* ctx);
+void mi355_free(void* p);                               /* frees host buffers returned by this library */
+
+/* ---- features: replaces the body of SiftExtraction_Thread, MosaicWithoutPos.cpp:4861-4881 ----------- */
+/* BGR u8 host image in, keypoints + 128-D descriptors out (desc128: n x 128 floats holding the integers
+ * 0..255 like OpenCV's SIFT; either output may be NULL).  Features stay device-resident under img_id for
+ * mi355_match_pairs (the reference round-trips them through d:/feature_temp files instead). */
+int  mi355_sift_extract(mi355_ctx* ctx, int img_id, const uint8_t* bgr, int w, int h, int width_step,
+                        mi355_keypoint* kp, float* desc128, int max_kp, int* n_kp);
+/* Same, image already in HBM (device pointer); nothing is copied back. */
+int  mi355_sift_extract_dev(mi355_ctx* ctx, int img_id, const uint8_t* d_bgr, int w, int h, int width_step, int* n_kp);
+/* Fetch / install device-resident features (LoadSurfKeyPoints / WriteSurfKeyPoints counterparts,
+ * MosaicWithoutPos.cpp:4682-4734).  desc128 holds integer-valued floats. */
+int  mi355_get_features(mi355_ctx* ctx, int img_id, mi355_keypoint* kp, float* desc128, int max_kp, int* n_kp);
+int  mi355_set_features(mi355_ctx* ctx, int img_id, const mi355_keypoint* kp, const float* desc128, int n_kp, int w, int h);
+int  mi355_drop_features(mi355_ctx* ctx, int img_id);   /* img_id < 0: all */
+
+/* ---- match + select + RANSAC for a batch of pairs ------------------------------------------------------
+ * replaces the j-loop body MosaicWithoutPos.cpp:5084-5232 (FLANN match -> sort -> SelectMatchPairs ->
+ * Ransac2D -> accept).  pairs: n_pairs x {i,j} image ids with features resident.  seed plays the role of
+ * time(0) in srand((unsigned)time(0)), mosaicimage.h:1777 (every pair of the batch uses it, as all pairs the
+ * reference processes within one second do).  out: host array of n_pairs results. */
+int  mi355_match_pairs(mi355_ctx* ctx, const int32_t* pairs_ij, int n_pairs, float ransac_dist, uint32_t seed,
+                       mi355_pair_result* out);
+/* Same, results left in HBM at d_out (device pointer to n_pairs records), e.g. as the RCCL all-gather input. */
+int  mi355_match_pairs_dev(mi355_ctx* ctx, const int32_t* pairs_ij, int n_pairs, float ransac_dist, uint32_t seed,
+                           mi355_pair_result* d_out);
+/* Exact brute-force 1-NN / 2-NN (replaces cv::FlannBasedMatcher().match, MosaicWithoutPos.cpp:5108-5110,
+ * with the exact answer): squared L2 distances as int32, sorted=1 orders the output by (distance, queryIdx)
+ * like std::sort(matches) at :5111.  second_d2 may be NULL. Returns number of matches in *n_matches (= K_i). */
+int  mi355_bf_match(mi355_ctx* ctx, int img_i, int img_j, int sorted, mi355_dmatch* matches, int32_t* d2, int32_t* second_d2,
+                    int max_matches, int* n_matches);
+
+/* ---- stand-alone pieces with the reference's semantics ------------------------------------------------ */
+/* SelectMatchPairs (grid form), MosaicWithoutPos.cpp:4977-5028. sorted: matches already ordered. */
+int  mi355_select_grid(mi355_ctx* ctx, const mi355_dmatch* sorted, int n, const float* kp1_xy, int n_kp1,
+                       const float* kp2_xy, int n_kp2, int nMatch, int width, int height, int gridX, int gridY,
+                       mi355_sfpoint* v1, mi355_sfpoint* v2, int* n_out);
+/* Ransac2D<SfPoint>, mosaicimage.h:1729-2035.  Returns 1/0 like the bool (or <0 on error). */
+int  mi355_ransac2d(mi355_ctx* ctx, const mi355_sfpoint* p1, const mi355_sfpoint* p2, int n, float dist, int sample_times,
+                    uint32_t seed, mi355_sfpoint* in1, mi355_sfpoint* in2, int* n_in, float H[9]);
+/* ImageProjectionTransform(BitmapImage*, BitmapImage*&, float h[9]), MosaicImage.cpp:1613-1758.
+ * *dst is allocated by the library (rows padded to (w*ch+3)/4*4 like CreateBitmap8U) -> mi355_free. */
+int  mi355_warp_image(mi355_ctx* ctx, const uint8_t* src, int w, int h, int ws, int ch, const float h9[9],
+                      uint8_t** dst, int* dw, int* dh, int* dws);
+/* CMosaicByPose::MosaicImagesRefined (float), MosaicWithoutPos.cpp:2194-2352: bbox of all images with
+ * h[8]!=0, zeroed 3-channel canvas, per-image inverse bilinear warp, later images overwrite earlier ones.
+ * *canvas allocated by the library -> mi355_free. */
+int  mi355_mosaic_refined(mi355_ctx* ctx, const uint8_t* const* imgs, const int* w, const int* h, const int* ws, int n,
+                          const float* h9s /* n x 9 */, uint8_t** canvas, int* cw, int* ch, int* cws);
+/* Canvas geometry only (MosaicWithoutPos.cpp:2199-2249): size and the (dGX,dGY) shift. */
+int  mi355_mosaic_layout(const int* w, const int* h, int n, const float* h9s, int* cw, int* ch, int* cws, float* dGxy);
+/* Device-resident form: d_imgs[k] and d_canvas are device pointers; canvas must hold cws*ch bytes and is
+ * zeroed by the call.  Only canvas rows [row0, row0+rows) are rendered (canvas stripes for multi-GPU,
+ * SURVEY 8e); pass 0, ch for the whole canvas. */
+int  mi355_mosaic_refined_dev(mi355_ctx* ctx, const uint8_t* const* d_imgs, const int* w, const int* h, const int* ws, int n,
+                              const float* h9s, uint8_t* d_canvas, int cw, int ch, int cws, int row0, int rows);
+
+/* LaplacianPyramidBlending warp stage (MosaicImage.cpp:2233-2460) + FindMasksByDistMap (:1761-1881):
+ * per kept image a tight chip (3ch u8; the reference then converts to CV_16S), its validity mask and, with
+ * find_masks!=0, the exclusive distance-map ownership masks.  h9s must carry the resScale multiplication of
+ * m[0..5] (:2216-2223); keep[k] = vecAbandonInd (NULL = keep all). Outputs are library-allocated arrays of
+ * n_chips buffers (free each and the arrays with mi355_free). */
+typedef struct { int32_t x0, y0, w, h, img; float sx, sy; float quad[8]; } mi355_chip_info;
+int  mi355_chips_and_masks(mi355_ctx* ctx, const uint8_t* const* imgs, const int* w, const int* h, const int* ws, int n,
+                           const float* h9s, const uint8_t* keep, int find_masks,
+                           int* n_chips, mi355_chip_info** chips, uint8_t*** chip_imgs, uint8_t*** masks,
+                           int* canvas_w, int* canvas_h);
+
+/* ---- callers / formats either side of the path ("next" rows f1, f2 of SURVEY 8f) ---------------------- */
+/* matchPairs.match: int32 n + n x 40-byte records (WriteMatchPairs / LoadMatchPairs, MosaicWithoutPos.cpp:4736-4797) */
+int  mi355_write_match_pairs(const char* path, const mi355_match_point_pairs* v, int n);
+int  mi355_load_match_pairs(const char* path, mi355_match_point_pairs** v, int* n);          /* *v -> mi355_free */
+/* matchPairs.txt (WriteMatchPairs_ASC2, MosaicWithoutPos.cpp:4751-4772) */
+int  mi355_write_match_pairs_txt(const char* path, const mi355_match_point_pairs* v, int n);
+/* tran0.txt (OutTransform, MosaicWithoutPos.cpp:2798-2818): rows for images 1..n-1: m0..m7 fixed */
+int  mi355_write_transforms(const char* path, const mi355_image_transform* t, int n);
+/* keypoint_%d.key (WriteSurfKeyPoints, MosaicWithoutPos.cpp:4691-4700): int32 n + n x 28-byte cv::KeyPoint */
+int  mi355_write_keypoints(const char* path, const mi355_keypoint* kp, int n);
+int  mi355_load_keypoints(const char* path, mi355_keypoint** kp, int* n);
+/* Flatten accepted pair results into the driver's m_vecMatchPairs order (pair order, inlier order). */
+int  mi355_results_to_match_pairs(const mi355_pair_result* r, int n_pairs, const int32_t* fixed_flags /* per image or NULL */,
+                                  mi355_match_point_pairs** v, int* n);
+/* Global affine alignment: Select_Connected_Matched_Images is the caller's; this is BundleAdjustmentSparse's
+ * linear system (MosaicWithoutPos.cpp:6971-7202) solved by dense Cholesky of the normal equations.
+ * Image 0 (and every image with fixed[k]!=0) is held at identity. out: n_images transforms. */
+int  mi355_global_affine_align(const mi355_match_point_pairs* v, int n, int n_images, const int32_t* fixed,
+                               mi355_image_transform* out);
+
+/* ---- multi-GPU ------------------------------------------------------------------------------------------ */
+/* Deterministic shard of the reference's pair schedule (i strided by rank like the threads at
+ * MosaicWithoutPos.cpp:5066, j in (i, min(N, i+window))): writes pairs of rank `rank` of `world`. */
+int  mi355_pair_schedule(int n_images, int window, int rank, int world, int32_t* pairs_ij, int max_pairs, int* n_pairs);
+
+/* ---- measurement hooks (bench.py) ----------------------------------------------------------------------- */
+/* When enabled, every launch of the named kernel class is bracketed by hipEvents on the ctx stream. */
+int  mi355_profile_enable(mi355_ctx* ctx, int on);
+int  mi355_profile_reset(mi355_ctx* ctx);
+/* class: "gauss", "extrema", "orient", "describe", "match", "select", "ransac", "warp", "gray" ...
+ * Synchronises the stream. total_ms/launches may be NULL. */
+int  mi355_profile_get(mi355_ctx* ctx, const char* kernel_class, double* total_ms, int64_t* launches, double* alg_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI355_MOSAIC_H */

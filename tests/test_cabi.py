@@ -1,0 +1,115 @@
+"""CPU: the C-ABI library loads and exports every symbol include/mi355_mosaic.h declares; host-only entry
+points (formats, schedule, global alignment known answer) work without a GPU."""
+import os
+import re
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.fixture(scope="module")
+def im():
+    from imagemosaicing_amd import build
+    build.build()
+    import imagemosaicing_amd
+    return imagemosaicing_amd
+
+
+def test_every_declared_symbol_is_exported(im):
+    hdr = open(os.path.join(ROOT, "include", "mi355_mosaic.h")).read()
+    names = sorted(set(re.findall(r"\b(mi355_[a-z0-9_]+)\s*\(", hdr)))
+    assert len(names) >= 30
+    L = im.load_library()
+    missing = [n for n in names if not hasattr(L, n)]
+    assert not missing, missing
+
+
+def test_no_device_fails_loudly(im):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(im.Mi355Error) as e:
+        im.Context(0)
+    assert e.value.code == -4
+
+
+def test_match_pairs_file_roundtrip_is_byte_identical(im, tmp_path):
+    src = os.path.join(GOLD, "matchPairs.match")
+    rec = im.load_match_pairs(src)
+    assert len(rec) == 5918
+    out = str(tmp_path / "mp.match")
+    im.write_match_pairs(out, rec)
+    assert open(out, "rb").read() == open(src, "rb").read()
+
+
+def test_match_pairs_txt_matches_reference_file(im, tmp_path):
+    """WriteMatchPairs_ASC2 formatting (MosaicWithoutPos.cpp:4751-4772): re-writing the values parsed from
+    the reference's own matchPairs.txt reproduces the file (modulo the CRLF of the Windows build)."""
+    src = os.path.join(GOLD, "matchPairs.txt")
+    txt = np.loadtxt(src)
+    mp = np.zeros(len(txt), im.MATCHPAIR)
+    for k, f in enumerate(["ai", "ax", "ay", "af", "bi", "bx", "by", "bf"]):
+        mp[f] = txt[:, k]
+    out = str(tmp_path / "mp.txt")
+    im.write_match_pairs_txt(out, mp)
+    want = open(src, "rb").read().replace(b"\r\n", b"\n")
+    assert open(out, "rb").read() == want
+
+
+def test_global_affine_align_known_answer(im, tmp_path):
+    """matchPairs.txt -> tran0.txt, the one known-answer fixture of the reference."""
+    txt = np.loadtxt(os.path.join(GOLD, "matchPairs.txt"))
+    mp = np.zeros(len(txt), im.MATCHPAIR)
+    for k, f in enumerate(["ai", "ax", "ay", "af", "bi", "bx", "by", "bf"]):
+        mp[f] = txt[:, k]
+    T = im.global_affine_align(mp, 20)
+    want = np.loadtxt(os.path.join(GOLD, "tran0.txt"))
+    assert T["fixed"][0] == 1 and np.array_equal(T["m"][0], np.eye(3, dtype=np.float32).reshape(9))
+    assert np.abs(T["m"][1:, :6] - want[:, :6]).max() < 6e-3       # 6 significant digits in the text file
+    out = str(tmp_path / "tran.txt")
+    im.write_transforms(out, T)
+    got = np.loadtxt(out)
+    assert got.shape == want.shape and np.abs(got[:, :6] - want[:, :6]).max() < 6e-3
+
+
+def test_keypoint_file_roundtrip(im, tmp_path):
+    kp = np.zeros(5, im.KEYPOINT)
+    kp["x"] = np.arange(5) + 0.5
+    kp["octave"] = 0x01ff00
+    p = str(tmp_path / "keypoint_0.key")
+    im.write_keypoints(p, kp)
+    raw = open(p, "rb").read()
+    assert len(raw) == 4 + 5 * 28 and np.frombuffer(raw[:4], np.int32)[0] == 5
+    assert np.array_equal(im.load_keypoints(p), kp)
+
+
+def test_pair_schedule_matches_reference_window(im):
+    # MosaicWithoutPos.cpp:5066,5083: i strided by thread, j in (i, min(N, i+182))
+    allp = im.pair_schedule(500, 182)
+    assert len(allp) == 74029
+    parts = [im.pair_schedule(500, 182, r, 8) for r in range(8)]
+    assert sum(len(p) for p in parts) == 74029
+    merged = np.concatenate(parts)
+    assert len({(int(a), int(b)) for a, b in merged}) == 74029
+    assert all((p[:, 0] % 8 == r).all() for r, p in enumerate(parts))
+    assert len(im.pair_schedule(2000, 182)) == 345529   # C5
+
+
+def test_mosaic_layout_matches_oracle(im, oracle):
+    from tests.synth import mosaic_case
+    imgs, h9s = mosaic_case()
+    w = [i.shape[1] for i in imgs]; h = [i.shape[0] for i in imgs]
+    cw, ch, cws, dG = im.mosaic_layout(w, h, h9s)
+    rc, (canvas, ow, oh, ows) = oracle.mosaic_images_refined(imgs, h9s)
+    assert (cw, ch, cws) == (ow, oh, ows)
+
+
+def test_results_to_match_pairs(im):
+    r = np.zeros(3, im.PAIR_RESULT)
+    r["i"] = [0, 0, 1]; r["j"] = [1, 2, 2]; r["n_in"] = [40, 10, 35]; r["accepted"] = [1, 0, 1]
+    r["a"]["x"][0, :40] = np.arange(40); r["b"]["id"][2, :35] = np.arange(35)
+    v = im.results_to_match_pairs(r, fixed_flags=[1, 0, 0])
+    assert len(v) == 75 and (v["ai"][:40] == 0).all() and (v["af"][:40] == 1).all() and (v["bi"][40:] == 2).all()
+    assert np.array_equal(v["ax"][:40], np.arange(40, dtype=np.float32)) and np.array_equal(v["bid"][40:], np.arange(35))

@@ -1,0 +1,220 @@
+"""GPU parity tests proper: the HIP path, called through the C ABI (libmi355mosaic.so via ctypes),
+against (a) the golden vectors the reference's own code produced and (b) the CPU oracle on seeded inputs.
+Everything here is bit-exact: float results are compared by bit pattern."""
+import numpy as np
+import pytest
+
+from tests.golden_util import math_golden, warp_golden, bits
+from tests.synth import synth_pairs, texture, warp_cases, mosaic_case
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import imagemosaicing_amd as im
+    c = im.Context(0)
+    yield c
+    c.close()
+
+
+def _rand_desc(rng, n):
+    """SIFT-like integer descriptors: sparse-ish 0..255 values with clipped peaks."""
+    d = rng.gamma(0.6, 25.0, size=(n, 128))
+    return np.clip(d, 0, 255).astype(np.uint8)
+
+
+# ---------------------------------------------------------------------------------------------- warps
+def test_image_projection_transform_golden(ctx):
+    g = warp_golden()
+    img = texture(320, 240, seed=3)
+    for k, H in enumerate(warp_cases()):
+        buf, dw, dh, dws = ctx.ImageProjectionTransform(img, H)
+        assert [dw, dh, dws] == g[f"ipt{k}_dims"].tolist()
+        assert np.array_equal(buf, g[f"ipt{k}"]), f"case {k}: {(buf != g[f'ipt{k}']).sum()} bytes differ"
+    gray = np.ascontiguousarray(img[..., 1])
+    buf, dw, dh, dws = ctx.ImageProjectionTransform(gray, warp_cases()[3])
+    assert [dw, dh, dws] == g["ipt_gray_dims"].tolist() and np.array_equal(buf, g["ipt_gray"])
+
+
+def test_mosaic_images_refined_golden(ctx):
+    g = warp_golden()
+    imgs, h9s = mosaic_case()
+    canvas, cw, ch, cws = ctx.MosaicImagesRefined(imgs, h9s)
+    assert [cw, ch, cws] == g["mosaic_dims"].tolist()
+    assert np.array_equal(canvas, g["mosaic"])
+    h9s[2, 8] = 0
+    canvas, cw, ch, cws = ctx.MosaicImagesRefined(imgs, h9s)
+    assert [cw, ch, cws] == g["mosaic_skip_dims"].tolist() and np.array_equal(canvas, g["mosaic_skip"])
+
+
+def test_warp_vs_oracle_random(ctx, oracle):
+    rng = np.random.default_rng(11)
+    for (w, h) in [(640, 480), (333, 257)]:
+        img = texture(w, h, seed=w)
+        for _ in range(4):
+            H = np.eye(3) + rng.normal(0, 0.06, (3, 3))
+            H[0, 2] = rng.uniform(-60, 60); H[1, 2] = rng.uniform(-60, 60)
+            H[2, 0] = rng.normal(0, 1e-4); H[2, 1] = rng.normal(0, 1e-4); H[2, 2] = 1
+            h9 = H.reshape(9).astype(np.float32)
+            rc, ref = oracle.image_projection_transform(img, h9)
+            buf, dw, dh, dws = ctx.ImageProjectionTransform(img, h9)
+            assert (dw, dh, dws) == ref[1:] and np.array_equal(buf, ref[0])
+
+
+def test_mosaic_stripes_equal_whole(ctx):
+    """canvas stripes (multi-GPU decomposition) reproduce the monolithic canvas"""
+    import torch
+    import imagemosaicing_amd as im
+    imgs, h9s = mosaic_case()
+    whole, cw, ch, cws = ctx.MosaicImagesRefined(imgs, h9s)
+    d_imgs = [torch.from_numpy(np.ascontiguousarray(i)).cuda() for i in imgs]
+    w = [i.shape[1] for i in imgs]; h = [i.shape[0] for i in imgs]; ws = [i.strides[0] for i in imgs]
+    lw, lh, lws, dG = im.mosaic_layout(w, h, h9s)
+    assert (lw, lh, lws) == (cw, ch, cws)
+    canvas = torch.full((ch, cws), 77, dtype=torch.uint8, device="cuda")
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    bounds = [0, ch // 3, 2 * ch // 3, ch]
+    for a, b in zip(bounds[:-1], bounds[1:]):
+        ctx.MosaicImagesRefinedDev([t.data_ptr() for t in d_imgs], w, h, ws, h9s, canvas.data_ptr(), cw, ch, cws, a, b - a)
+    ctx.synchronize()
+    ctx.set_stream(None)
+    assert np.array_equal(canvas.cpu().numpy(), whole)
+
+
+def test_chips_and_masks_vs_oracle(ctx, oracle):
+    imgs, h9s = mosaic_case()
+    ref = oracle.chips_and_masks(imgs, h9s, find_masks=True)
+    got = ctx.ChipsAndMasks(imgs, h9s, find_masks=True)
+    assert (got["cw"], got["ch"]) == (ref["cw"], ref["ch"])
+    assert len(got["chips"]) == len(ref["chips"])
+    for k in range(len(ref["chips"])):
+        for f in ("x0", "y0", "w", "h", "img"):
+            assert int(got["chips"][k][f]) == int(ref["chips"][k][f])
+        assert np.array_equal(bits(got["chips"][k]["quad"]), bits(ref["chips"][k]["quad"]))
+        assert np.array_equal(got["chip_imgs"][k], ref["chip_imgs"][k])
+        assert np.array_equal(got["masks"][k], ref["masks"][k])
+    got_v = ctx.ChipsAndMasks(imgs, h9s, find_masks=False)
+    for k in range(len(ref["chips"])):
+        assert np.array_equal(got_v["masks"][k], ref["valid"][k])
+
+
+# ---------------------------------------------------------------------------------------------- RANSAC
+def test_ransac2d_golden(ctx):
+    g = math_golden()
+    for p1, p2, n, seed, ok, nin, ids, H in zip(g["r_p1"], g["r_p2"], g["r_n"], g["r_seed"], g["r_ok"], g["r_nin"], g["r_ids"], g["r_H"]):
+        ok2, i1, i2, H2 = ctx.Ransac2D(p1[:n].copy(), p2[:n].copy(), 2.5, 1000, int(seed))
+        assert ok2 == ok and len(i1) == nin, (n, seed, ok2, ok, len(i1), nin)
+        assert np.array_equal(i1["id"], ids[:nin])
+        if nin >= 4:
+            assert np.array_equal(bits(H2), bits(H)), (n, seed, H2, H)
+
+
+def test_ransac2d_vs_oracle_random(ctx, oracle):
+    for n, of in [(396, 0.35), (396, 0.8), (123, 0.5), (9, 0.0), (4, 0.0)]:
+        for seed in (21, 22):
+            p1, p2 = synth_pairs(n, of, seed=seed * 13 + n, size=(4000, 3000))
+            a = oracle.ransac2d(p1, p2, 2.5, 1000, seed)
+            b = ctx.Ransac2D(p1, p2, 2.5, 1000, seed)
+            assert a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+            if len(a[1]) >= 4:
+                assert np.array_equal(bits(a[3]), bits(b[3]))
+
+
+def test_ransac2d_edge_cases(ctx):
+    from tests.oracle_lib import sfpoints
+    p = sfpoints(np.zeros((3, 2)))
+    ok, i1, i2, H = ctx.Ransac2D(p, p, 2.5, 1000, 1)
+    assert ok == 0 and len(i1) == 0
+    ok, i1, i2, H = ctx.Ransac2D(p[:0], p[:0], 2.5, 1000, 1)
+    assert ok == 0
+
+
+# ---------------------------------------------------------------------------------------------- selection
+def test_select_match_pairs_golden(ctx):
+    g = math_golden()
+    for kp1, kp2, m, (w, h, K), nm, o1, o2, no in zip(g["s_kp1"], g["s_kp2"], g["s_m"], g["s_wh"], g["s_nm"], g["s_o1"], g["s_o2"], g["s_no"]):
+        a1, a2 = ctx.SelectMatchPairs(m[:K], kp1[:K], kp2[:K], int(nm), int(w), int(h))
+        assert len(a1) == no
+        assert np.array_equal(a1, o1[:no]) and np.array_equal(a2, o2[:no])
+
+
+# ---------------------------------------------------------------------------------------------- matching
+def test_bf_match_exact(ctx, oracle):
+    """bf16 MFMA distances are exact integers: indices, 1-NN and 2-NN squared distances equal the CPU
+    integer brute force bit for bit, including ties (duplicated descriptors) and ragged sizes."""
+    rng = np.random.default_rng(5)
+    from imagemosaicing_amd import KEYPOINT
+    for (n1, n2) in [(2000, 2000), (1999, 1531), (130, 70), (1, 5), (64, 64)]:
+        d1, d2 = _rand_desc(rng, n1), _rand_desc(rng, n2)
+        if n2 > 40:
+            d2[37] = d2[3]              # exact tie -> lowest train index must win
+            d1[0] = d2[3]
+        kp1 = np.zeros(n1, KEYPOINT); kp2 = np.zeros(n2, KEYPOINT)
+        kp1["x"] = rng.uniform(5, 995, n1); kp1["y"] = rng.uniform(5, 745, n1)
+        kp2["x"] = rng.uniform(5, 995, n2); kp2["y"] = rng.uniform(5, 745, n2)
+        ctx.SetFeatures(100, kp1, d1.astype(np.float32), 1000, 750)
+        ctx.SetFeatures(101, kp2, d2.astype(np.float32), 1000, 750)
+        idx, b1, b2 = oracle.bf_match(d1, d2)
+        m, g1, g2 = ctx.BFMatch(100, 101, sorted_=False)
+        assert len(m) == n1
+        assert np.array_equal(m["trainIdx"], idx) and np.array_equal(g1, b1)
+        if n2 > 1:
+            assert np.array_equal(g2, b2)
+        ms, s1, _ = ctx.BFMatch(100, 101, sorted_=True)
+        want = oracle.sort_matches(idx, b1)
+        assert np.array_equal(np.stack([ms["queryIdx"], ms["trainIdx"]], 1), want)
+        fk, fd = ctx.GetFeatures(100)
+        assert np.array_equal(fd.astype(np.uint8), d1) and np.array_equal(fk["x"], kp1["x"])
+    ctx.DropFeatures(100); ctx.DropFeatures(101)
+
+
+def _synthetic_feature_pair(rng, n=2000, w=4000, h=3000, overlap=0.7):
+    """two keypoint sets related by a homography, matching descriptors for the shared part + noise"""
+    from imagemosaicing_amd import KEYPOINT
+    H = np.array([1.01, 0.02, 300, -0.015, 0.99, -200, 2e-6, -3e-6, 1.0])
+    kp2 = np.zeros(n, KEYPOINT); kp1 = np.zeros(n, KEYPOINT)
+    kp2["x"] = rng.uniform(5, w - 5, n); kp2["y"] = rng.uniform(5, h - 5, n)
+    d = H[6] * kp2["x"] + H[7] * kp2["y"] + 1
+    x1 = (H[0] * kp2["x"] + H[1] * kp2["y"] + H[2]) / d + rng.normal(0, 0.4, n)
+    y1 = (H[3] * kp2["x"] + H[4] * kp2["y"] + H[5]) / d + rng.normal(0, 0.4, n)
+    d2 = _rand_desc(rng, n)
+    d1 = np.clip(d2.astype(np.int32) + rng.integers(-6, 7, d2.shape), 0, 255).astype(np.uint8)
+    ns = int(overlap * n)
+    inside = (x1 > 5) & (x1 < w - 5) & (y1 > 5) & (y1 < h - 5)
+    shared = np.where(inside)[0][:ns]
+    kp1["x"] = rng.uniform(5, w - 5, n); kp1["y"] = rng.uniform(5, h - 5, n)
+    d1r = _rand_desc(rng, n)
+    perm = rng.permutation(n)
+    tgt = perm[:len(shared)]
+    kp1["x"][tgt] = x1[shared]; kp1["y"][tgt] = y1[shared]
+    d1r[tgt] = d1[shared]
+    return kp1, d1r, kp2, d2
+
+
+def test_match_pairs_vs_oracle(ctx, oracle):
+    """whole j-loop body (match -> sort -> grid select -> Ransac2D -> accept) on device-resident features"""
+    rng = np.random.default_rng(77)
+    feats = []
+    for k in range(3):
+        kp1, d1, kp2, d2 = _synthetic_feature_pair(rng, n=2000 if k < 2 else 777)
+        feats.append((kp1, d1, kp2, d2))
+        ctx.SetFeatures(2 * k, kp1, d1.astype(np.float32), 4000, 3000)
+        ctx.SetFeatures(2 * k + 1, kp2, d2.astype(np.float32), 4000, 3000)
+    pairs = [(0, 1), (2, 3), (4, 5), (0, 3)]       # the last one is an unrelated pair -> rejected
+    seed = 4242
+    res = ctx.MatchPairs(pairs, 2.5, seed)
+    for r, (i, j) in zip(res, pairs):
+        kp1, d1 = feats[i // 2][0], feats[i // 2][1]
+        kp2, d2 = feats[j // 2][2], feats[j // 2][3]
+        xy1 = np.stack([kp1["x"], kp1["y"]], 1); xy2 = np.stack([kp2["x"], kp2["y"]], 1)
+        nin, i1, i2, H, ns = oracle.match_pair(xy1, d1, xy2, d2, 4000, 3000, 2.5, seed)
+        assert (int(r["i"]), int(r["j"])) == (i, j)
+        assert int(r["n_selected"]) == ns
+        n_in = int(r["n_in"])
+        assert (n_in if n_in > 30 else 0) == nin and int(r["accepted"]) == (1 if nin > 0 else 0)
+        if nin > 0:
+            assert np.array_equal(r["a"][:n_in], i1[:n_in]) and np.array_equal(r["b"][:n_in], i2[:n_in])
+            assert np.array_equal(bits(r["H"]), bits(H))
+    assert int(res[0]["accepted"]) == 1 and int(res[3]["accepted"]) == 0
+    ctx.DropFeatures(-1)
