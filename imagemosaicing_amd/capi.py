@@ -47,6 +47,14 @@ def load_library():
         if not os.path.exists(p):
             raise ImportError("libmi355mosaic.so is not built: run `python -m imagemosaicing_amd.build` "
                               "(there is no CPU fallback for the HIP path)")
+        # One HIP runtime per process: PyTorch-ROCm wheels bundle their own libamdhip64.so.7 / libhsa-runtime64.
+        # When torch is present (bench.py, tests: device memory + torch.distributed), import it FIRST so that this
+        # library's DT_NEEDED libamdhip64.so.7 resolves to the runtime torch already loaded instead of a second copy
+        # from /opt/rocm (two runtimes in one process cannot both own the GPU).
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(p)
         L.mi355_last_error.restype = C.c_char_p
         L.mi355_last_error.argtypes = [C.c_void_p]

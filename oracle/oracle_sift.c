@@ -1,0 +1,476 @@
+/* oracle/oracle_sift.c -- TEST INFRASTRUCTURE ONLY (see oracle.h).   PARITY UNPINNED.
+ *
+ * CPU restatement of the SIFT detect+describe step the reference runs through OpenCV 2.4.0:
+ *     SiftFeatureDetector detector(2000, 3, 0.01, 20); detector.detect(img, kp);
+ *     SiftDescriptorExtractor extractor;               extractor.compute(img, kp, desc);
+ *                                                      (MosaicWithoutPos.cpp:4852-4872)
+ * The arithmetic lives in OpenCV 2.4.0's nonfree module (pinned by the vendored headers
+ * 3rdparty/opencv240/.../core/version.hpp:50-52), of which the reference tree holds only headers and
+ * Win32 binaries: it can neither be compiled nor run here, and the reference has no test or golden
+ * vector at this boundary.  This file therefore restates the PUBLISHED algorithm (D. Lowe, "Distinctive
+ * image features from scale-invariant keypoints", IJCV 2004) in the structure and with the constants of
+ * the cv::SIFT class the reference instantiates (class declaration: nonfree/features2d.hpp:58-100;
+ * parameters nfeatures=2000, nOctaveLayers=3, contrastThreshold=0.01, edgeThreshold=20, sigma=1.6):
+ *   1. gray = (1868 B + 9617 G + 4899 R + 8192) >> 14, as float              (8-bit BGR2GRAY fixed point)
+ *   2. base = 2x bilinear upsample (pixel centres, edge clamp), Gaussian blur with
+ *      sqrt(sigma^2 - (2*0.5)^2)                                               (first octave = -1)
+ *   3. per octave 6 Gaussian levels built incrementally, sigma_i = sqrt((s k^i)^2 - (s k^(i-1))^2),
+ *      k = 2^(1/3); kernel width round(8 sigma + 1) | 1, taps exp(-x^2 / 2 sigma^2) normalised in double,
+ *      border reflect-101; next octave = every second pixel of level 3
+ *   4. DoG extrema over 26 neighbours (>= / <=), |D| > floor(0.5*0.01/3*255) = 0, 5 px border
+ *   5. sub-pixel quadratic fit (<= 5 steps), contrast |D(x^)|*3 >= 0.01 and edge tr^2/det < 21^2/20
+ *   6. 36-bin orientation histogram (radius round(4.5 s), weight sigma 1.5 s), [1 4 6 4 1]/16
+ *      smoothing, every peak >= 0.8 max becomes a keypoint with parabolic bin interpolation
+ *   7. duplicates removed, the nfeatures strongest responses kept
+ *   8. 4x4x8 descriptor (bin width 3 s, window sigma 2 bins, trilinear), unit norm, clip 0.2, renorm,
+ *      x512 -> u8 (the integers OpenCV stores in its float descriptor Mat)
+ *
+ * DEFINED HERE (where the publication leaves freedom), so that the HIP implementation can be compared
+ * bit for bit instead of "approximately":
+ *   - all image arithmetic is IEEE binary32; convolutions accumulate tap by tap in ascending tap order
+ *     with one fused multiply-add per tap (fmaf), row pass then column pass;
+ *   - exp / atan2 / sin / cos are the fixed polynomial approximations below (OpenCV also uses
+ *     approximations there: cv::exp, fastAtan2), evaluated with fmaf in a fixed order;
+ *   - histogram accumulation runs in raster order of the sample window (row by row, as the loops are
+ *     written below), every contribution added separately;
+ *   - the 3x3 solve is Gaussian elimination with partial pivoting (first largest pivot);
+ *   - keypoints are ordered by (response descending, octave, layer, row, column, orientation bin) and
+ *     that is also the output order; duplicates = same (octave, layer, row, column, bin).
+ */
+#include "oracle.h"
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include <float.h>
+
+#define N_LAYERS 3
+#define N_LEVELS (N_LAYERS + 3)
+#define IMG_BORDER 5
+#define MAX_INTERP 5
+#define ORI_BINS 36
+#define MAX_OCT 16
+
+/* ---------- fixed transcendental approximations (part of the definition) ----------------------- */
+static inline float det_exp2f(float x)
+{
+    if (x < -126.0f) return 0.0f;
+    if (x > 127.0f) x = 127.0f;
+    float n = rintf(x);
+    float f = x - n;                           /* [-0.5, 0.5] */
+    float p = 1.535336188319500e-4f;           /* Cephes exp2f polynomial */
+    p = fmaf(p, f, 1.339887440266574e-3f);
+    p = fmaf(p, f, 9.618437357674640e-3f);
+    p = fmaf(p, f, 5.550332471162809e-2f);
+    p = fmaf(p, f, 2.402264791363012e-1f);
+    p = fmaf(p, f, 6.931472028550421e-1f);
+    p = fmaf(p, f, 1.0f);
+    union { uint32_t u; float f; } s;
+    s.u = (uint32_t)((int)n + 127) << 23;
+    return p * s.f;
+}
+static inline float det_expf(float x) { return det_exp2f(x * 1.4426950408889634f); }
+
+/* angle of (x, y) in degrees, [0, 360]; 7th order odd polynomial on the smaller/larger ratio */
+static inline float det_atan2deg(float y, float x)
+{
+    const float p1 = 57.283627f, p3 = -18.667446f, p5 = 8.9140005f, p7 = -2.5397246f;
+    float ax = fabsf(x), ay = fabsf(y), a, c, c2;
+    if (ax >= ay) {
+        c = ay / (ax + 2.220446e-16f); c2 = c * c;
+        a = fmaf(fmaf(fmaf(p7, c2, p5), c2, p3), c2, p1) * c;
+    } else {
+        c = ax / (ay + 2.220446e-16f); c2 = c * c;
+        a = 90.0f - fmaf(fmaf(fmaf(p7, c2, p5), c2, p3), c2, p1) * c;
+    }
+    if (x < 0.0f) a = 180.0f - a;
+    if (y < 0.0f) a = 360.0f - a;
+    return a;
+}
+
+static inline void det_sincosdeg(float deg, float* sn, float* cs)
+{
+    float q = rintf(deg * (1.0f / 90.0f));
+    float r = fmaf(-90.0f, q, deg);            /* [-45, 45] */
+    float t = r * 0.017453292519943295f;
+    float t2 = t * t;
+    float sp = fmaf(t2, 2.7557319e-6f, -1.9841270e-4f);
+    sp = fmaf(sp, t2, 8.3333333e-3f);
+    sp = fmaf(sp, t2, -1.6666667e-1f);
+    float s = fmaf(sp * t2, t, t);
+    float cp = fmaf(t2, 2.4801587e-5f, -1.3888889e-3f);
+    cp = fmaf(cp, t2, 4.1666667e-2f);
+    cp = fmaf(cp, t2, -0.5f);
+    float c = fmaf(cp, t2, 1.0f);
+    int k = ((int)q) & 3;
+    if (k == 0) { *sn = s; *cs = c; }
+    else if (k == 1) { *sn = c; *cs = -s; }
+    else if (k == 2) { *sn = -s; *cs = -c; }
+    else { *sn = -c; *cs = s; }
+}
+
+/* ---------- Gaussian pyramid -------------------------------------------------------------------- */
+static inline int reflect101(int p, int n)
+{
+    if (n == 1) return 0;
+    while (p < 0 || p >= n) { if (p < 0) p = -p; else p = 2 * n - 2 - p; }
+    return p;
+}
+
+static int gauss_kernel(double sigma, float* k)      /* returns radius */
+{
+    int ksize = ((int)lrint(sigma * 8.0 + 1.0)) | 1;
+    int r = ksize / 2;
+    double tmp[64], sum = 0.0;
+    double scale2x = -0.5 / (sigma * sigma);
+    for (int i = 0; i < ksize; i++) { double x = (double)i - (double)(ksize - 1) * 0.5; tmp[i] = exp(scale2x * x * x); sum += tmp[i]; }
+    sum = 1.0 / sum;
+    for (int i = 0; i < ksize; i++) k[i] = (float)(tmp[i] * sum);
+    return r;
+}
+
+static void gauss_blur(const float* src, float* dst, float* tmp, int w, int h, double sigma)
+{
+    float k[64];
+    int r = gauss_kernel(sigma, k);
+    /* row pass: tmp(y,x) = sum_i k[i] * src(y, reflect(x + i - r)), ascending i, one fmaf per tap */
+    float* ext = (float*)malloc(sizeof(float) * (size_t)(w + 2 * r));
+    for (int y = 0; y < h; y++) {
+        const float* s = src + (size_t)y * w;
+        for (int x = -r; x < w + r; x++) ext[x + r] = s[reflect101(x, w)];
+        float* t = tmp + (size_t)y * w;
+        for (int x = 0; x < w; x++) t[x] = 0.0f;
+        for (int i = 0; i <= 2 * r; i++) { const float ki = k[i]; const float* e = ext + i; for (int x = 0; x < w; x++) t[x] = fmaf(ki, e[x], t[x]); }
+    }
+    free(ext);
+    /* column pass */
+    for (int y = 0; y < h; y++) {
+        float* d = dst + (size_t)y * w;
+        for (int x = 0; x < w; x++) d[x] = 0.0f;
+        for (int i = 0; i <= 2 * r; i++) {
+            const float ki = k[i];
+            const float* t = tmp + (size_t)reflect101(y + i - r, h) * w;
+            for (int x = 0; x < w; x++) d[x] = fmaf(ki, t[x], d[x]);
+        }
+    }
+}
+
+typedef struct { int w, h; float* lv[N_LEVELS]; } octave_t;
+
+typedef struct {
+    uint32_t resp_bits; int o, layer, r, c, bin;
+    float x, y, size, angle, response, xi, scl;
+    float ptx, pty;      /* octave coordinates c + xc, r + xr */
+} cand_t;
+
+static inline float dogv(const octave_t* oc, int lvl, int r, int c)      /* DoG[lvl] = G[lvl+1] - G[lvl] */
+{
+    size_t o = (size_t)r * oc->w + c;
+    return oc->lv[lvl + 1][o] - oc->lv[lvl][o];
+}
+
+/* x = A^-1 b, Gaussian elimination with partial pivoting; singular -> x = 0 */
+static void solve3(float A[3][3], float b[3], float x[3])
+{
+    int p[3] = {0, 1, 2};
+    for (int k = 0; k < 3; k++) {
+        int m = k; float best = fabsf(A[p[k]][k]);
+        for (int r = k + 1; r < 3; r++) { float v = fabsf(A[p[r]][k]); if (v > best) { best = v; m = r; } }
+        if (!(best > 1e-30f)) { x[0] = x[1] = x[2] = 0.0f; return; }
+        int t = p[k]; p[k] = p[m]; p[m] = t;
+        for (int r = k + 1; r < 3; r++) {
+            float f = A[p[r]][k] / A[p[k]][k];
+            for (int c = k + 1; c < 3; c++) A[p[r]][c] = A[p[r]][c] - f * A[p[k]][c];
+            b[p[r]] = b[p[r]] - f * b[p[k]];
+        }
+    }
+    x[2] = b[p[2]] / A[p[2]][2];
+    x[1] = (b[p[1]] - A[p[1]][2] * x[2]) / A[p[1]][1];
+    x[0] = ((b[p[0]] - A[p[0]][1] * x[1]) - A[p[0]][2] * x[2]) / A[p[0]][0];
+}
+
+/* sub-pixel refinement + contrast / edge rejection. returns 1 and fills (layer,r,c,xi,xr,xc,contr) */
+static int adjust_extremum(const octave_t* oc, int* layer, int* r, int* c, float* xi, float* xr, float* xc, float* contr,
+                           float contrast_thr, float edge_thr)
+{
+    const float img_scale = 1.0f / 255.0f;
+    const float deriv_scale = img_scale * 0.5f, second_scale = img_scale, cross_scale = img_scale * 0.25f;
+    int it = 0;
+    float dD[3], X[3] = {0, 0, 0};
+    for (; it < MAX_INTERP; it++) {
+        int L = *layer, R = *r, Cc = *c;
+        dD[0] = (dogv(oc, L, R, Cc + 1) - dogv(oc, L, R, Cc - 1)) * deriv_scale;
+        dD[1] = (dogv(oc, L, R + 1, Cc) - dogv(oc, L, R - 1, Cc)) * deriv_scale;
+        dD[2] = (dogv(oc, L + 1, R, Cc) - dogv(oc, L - 1, R, Cc)) * deriv_scale;
+        float v2 = dogv(oc, L, R, Cc) * 2.0f;
+        float dxx = (dogv(oc, L, R, Cc + 1) + dogv(oc, L, R, Cc - 1) - v2) * second_scale;
+        float dyy = (dogv(oc, L, R + 1, Cc) + dogv(oc, L, R - 1, Cc) - v2) * second_scale;
+        float dss = (dogv(oc, L + 1, R, Cc) + dogv(oc, L - 1, R, Cc) - v2) * second_scale;
+        float dxy = (dogv(oc, L, R + 1, Cc + 1) - dogv(oc, L, R + 1, Cc - 1) - dogv(oc, L, R - 1, Cc + 1) + dogv(oc, L, R - 1, Cc - 1)) * cross_scale;
+        float dxs = (dogv(oc, L + 1, R, Cc + 1) - dogv(oc, L + 1, R, Cc - 1) - dogv(oc, L - 1, R, Cc + 1) + dogv(oc, L - 1, R, Cc - 1)) * cross_scale;
+        float dys = (dogv(oc, L + 1, R + 1, Cc) - dogv(oc, L + 1, R - 1, Cc) - dogv(oc, L - 1, R + 1, Cc) + dogv(oc, L - 1, R - 1, Cc)) * cross_scale;
+        float A[3][3] = {{dxx, dxy, dxs}, {dxy, dyy, dys}, {dxs, dys, dss}};
+        float b[3] = {dD[0], dD[1], dD[2]};
+        solve3(A, b, X);
+        *xi = -X[2]; *xr = -X[1]; *xc = -X[0];
+        if (fabsf(*xi) < 0.5f && fabsf(*xr) < 0.5f && fabsf(*xc) < 0.5f) break;
+        if (fabsf(*xi) > 7.0e8f || fabsf(*xr) > 7.0e8f || fabsf(*xc) > 7.0e8f) return 0;      /* INT_MAX/3 */
+        if (!(*xi == *xi) || !(*xr == *xr) || !(*xc == *xc)) return 0;
+        *c += (int)rintf(*xc); *r += (int)rintf(*xr); *layer += (int)rintf(*xi);
+        if (*layer < 1 || *layer > N_LAYERS || *c < IMG_BORDER || *c >= oc->w - IMG_BORDER || *r < IMG_BORDER || *r >= oc->h - IMG_BORDER) return 0;
+    }
+    if (it >= MAX_INTERP) return 0;
+    {
+        int L = *layer, R = *r, Cc = *c;
+        dD[0] = (dogv(oc, L, R, Cc + 1) - dogv(oc, L, R, Cc - 1)) * deriv_scale;
+        dD[1] = (dogv(oc, L, R + 1, Cc) - dogv(oc, L, R - 1, Cc)) * deriv_scale;
+        dD[2] = (dogv(oc, L + 1, R, Cc) - dogv(oc, L - 1, R, Cc)) * deriv_scale;
+        float t = (dD[0] * (*xc) + dD[1] * (*xr)) + dD[2] * (*xi);
+        *contr = dogv(oc, L, R, Cc) * img_scale + t * 0.5f;
+        if (fabsf(*contr) * (float)N_LAYERS < contrast_thr) return 0;
+        float v2 = dogv(oc, L, R, Cc) * 2.0f;
+        float dxx = (dogv(oc, L, R, Cc + 1) + dogv(oc, L, R, Cc - 1) - v2) * second_scale;
+        float dyy = (dogv(oc, L, R + 1, Cc) + dogv(oc, L, R - 1, Cc) - v2) * second_scale;
+        float dxy = (dogv(oc, L, R + 1, Cc + 1) - dogv(oc, L, R + 1, Cc - 1) - dogv(oc, L, R - 1, Cc + 1) + dogv(oc, L, R - 1, Cc - 1)) * cross_scale;
+        float tr = dxx + dyy, det = dxx * dyy - dxy * dxy;
+        if (det <= 0.0f || (tr * tr) * edge_thr >= ((edge_thr + 1.0f) * (edge_thr + 1.0f)) * det) return 0;
+    }
+    return 1;
+}
+
+static int cand_cmp(const void* a, const void* b)
+{
+    const cand_t* x = (const cand_t*)a; const cand_t* y = (const cand_t*)b;
+    if (x->resp_bits != y->resp_bits) return x->resp_bits > y->resp_bits ? -1 : 1;     /* response descending */
+    if (x->o != y->o) return x->o < y->o ? -1 : 1;
+    if (x->layer != y->layer) return x->layer < y->layer ? -1 : 1;
+    if (x->r != y->r) return x->r < y->r ? -1 : 1;
+    if (x->c != y->c) return x->c < y->c ? -1 : 1;
+    if (x->bin != y->bin) return x->bin < y->bin ? -1 : 1;
+    return 0;
+}
+
+static void describe(const octave_t* oc, const cand_t* k, uint8_t* out)
+{
+    const int d = 4, n = 8;
+    const float* img = oc->lv[k->layer];
+    const int rows = oc->h, cols = oc->w;
+    const float scl = k->scl;
+    const int px = (int)rintf(k->ptx), py = (int)rintf(k->pty);
+    float sin_t, cos_t;
+    det_sincosdeg(k->angle, &sin_t, &cos_t);
+    const float bins_per_deg = (float)n / 360.0f;
+    const float exp_scale = -1.0f / ((float)(d * d) * 0.5f);
+    const float hist_width = 3.0f * scl;
+    const int radius = (int)rintf(hist_width * 1.4142135623730951f * (float)(d + 1) * 0.5f);
+    cos_t = cos_t / hist_width; sin_t = sin_t / hist_width;
+    float hist[(4 + 2) * (4 + 2) * (8 + 2)];
+    for (int i = 0; i < (d + 2) * (d + 2) * (n + 2); i++) hist[i] = 0.0f;
+    for (int i = -radius; i <= radius; i++)
+        for (int j = -radius; j <= radius; j++) {
+            float c_rot = (float)j * cos_t - (float)i * sin_t;
+            float r_rot = (float)j * sin_t + (float)i * cos_t;
+            float rbin = r_rot + (float)(d / 2) - 0.5f;
+            float cbin = c_rot + (float)(d / 2) - 0.5f;
+            int r = py + i, c = px + j;
+            if (!(rbin > -1.0f && rbin < (float)d && cbin > -1.0f && cbin < (float)d && r > 0 && r < rows - 1 && c > 0 && c < cols - 1)) continue;
+            float dx = img[(size_t)r * cols + c + 1] - img[(size_t)r * cols + c - 1];
+            float dy = img[(size_t)(r - 1) * cols + c] - img[(size_t)(r + 1) * cols + c];
+            float ori = det_atan2deg(dy, dx);
+            float mag = sqrtf(dx * dx + dy * dy) * det_expf((c_rot * c_rot + r_rot * r_rot) * exp_scale);
+            float obin = (ori - k->angle) * bins_per_deg;
+            float r0f = floorf(rbin), c0f = floorf(cbin), o0f = floorf(obin);
+            rbin -= r0f; cbin -= c0f; obin -= o0f;
+            int r0 = (int)r0f, c0 = (int)c0f, o0 = (int)o0f;
+            if (o0 < 0) o0 += n;
+            if (o0 >= n) o0 -= n;
+            float v_r1 = mag * rbin, v_r0 = mag - v_r1;
+            float v_rc11 = v_r1 * cbin, v_rc10 = v_r1 - v_rc11;
+            float v_rc01 = v_r0 * cbin, v_rc00 = v_r0 - v_rc01;
+            float v_rco111 = v_rc11 * obin, v_rco110 = v_rc11 - v_rco111;
+            float v_rco101 = v_rc10 * obin, v_rco100 = v_rc10 - v_rco101;
+            float v_rco011 = v_rc01 * obin, v_rco010 = v_rc01 - v_rco011;
+            float v_rco001 = v_rc00 * obin, v_rco000 = v_rc00 - v_rco001;
+            int idx = ((r0 + 1) * (d + 2) + c0 + 1) * (n + 2) + o0;
+            hist[idx] += v_rco000; hist[idx + 1] += v_rco001;
+            hist[idx + (n + 2)] += v_rco010; hist[idx + (n + 3)] += v_rco011;
+            hist[idx + (d + 2) * (n + 2)] += v_rco100; hist[idx + (d + 2) * (n + 2) + 1] += v_rco101;
+            hist[idx + (d + 3) * (n + 2)] += v_rco110; hist[idx + (d + 3) * (n + 2) + 1] += v_rco111;
+        }
+    float dst[128];
+    for (int i = 0; i < d; i++)
+        for (int j = 0; j < d; j++) {
+            int idx = ((i + 1) * (d + 2) + (j + 1)) * (n + 2);
+            hist[idx] += hist[idx + n];
+            hist[idx + 1] += hist[idx + n + 1];
+            for (int q = 0; q < n; q++) dst[(i * d + j) * n + q] = hist[idx + q];
+        }
+    float nrm2 = 0.0f;
+    for (int q = 0; q < 128; q++) { float sq = dst[q] * dst[q]; nrm2 = nrm2 + sq; }
+    float thr = sqrtf(nrm2) * 0.2f;
+    nrm2 = 0.0f;
+    for (int q = 0; q < 128; q++) { float v = dst[q] < thr ? dst[q] : thr; dst[q] = v; float sq = v * v; nrm2 = nrm2 + sq; }
+    float nn = sqrtf(nrm2);
+    float fac = 512.0f / (nn > FLT_EPSILON ? nn : FLT_EPSILON);
+    for (int q = 0; q < 128; q++) {
+        float v = rintf(dst[q] * fac);
+        out[q] = (uint8_t)(v < 0.0f ? 0 : (v > 255.0f ? 255 : (int)v));
+    }
+}
+
+int orc_sift(const uint8_t* bgr, int w, int h, int ws, int nfeatures, orc_keypoint* kp_out, uint8_t* desc_out, int max_kp)
+{
+    const double sigma = 1.6;
+    const float contrast_thr = 0.01f, edge_thr = 20.0f;
+    const int W = 2 * w, H = 2 * h;
+    /* 1-2: gray, 2x upsample (weights 0.75/0.25, edge clamp) -- exact in binary32 */
+    float* gray = (float*)malloc(sizeof(float) * (size_t)w * h);
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            const uint8_t* p = bgr + (size_t)y * ws + 3 * x;
+            gray[(size_t)y * w + x] = (float)((1868 * p[0] + 9617 * p[1] + 4899 * p[2] + 8192) >> 14);
+        }
+    float* up = (float*)malloc(sizeof(float) * (size_t)W * H);
+    for (int Y = 0; Y < H; Y++) {
+        int y0 = (Y & 1) ? (Y >> 1) : (Y >> 1) - 1; float wy1 = (Y & 1) ? 0.25f : 0.75f;
+        int y1 = y0 + 1;
+        if (y0 < 0) y0 = 0;
+        if (y1 > h - 1) y1 = h - 1;
+        for (int X = 0; X < W; X++) {
+            int x0 = (X & 1) ? (X >> 1) : (X >> 1) - 1; float wx1 = (X & 1) ? 0.25f : 0.75f;
+            int x1 = x0 + 1;
+            if (x0 < 0) x0 = 0;
+            if (x1 > w - 1) x1 = w - 1;
+            float a = fmaf(gray[(size_t)y0 * w + x1], wx1, gray[(size_t)y0 * w + x0] * (1.0f - wx1));
+            float b = fmaf(gray[(size_t)y1 * w + x1], wx1, gray[(size_t)y1 * w + x0] * (1.0f - wx1));
+            up[(size_t)Y * W + X] = fmaf(b, wy1, a * (1.0f - wy1));
+        }
+    }
+    free(gray);
+    /* 3: pyramid */
+    int nOct = (int)lrint(log((double)(W < H ? W : H)) / log(2.0) - 2.0) + 1;
+    if (nOct > MAX_OCT) nOct = MAX_OCT;
+    double sig[N_LEVELS];
+    {
+        double k = pow(2.0, 1.0 / N_LAYERS);
+        sig[0] = sigma;
+        for (int i = 1; i < N_LEVELS; i++) { double sp = pow(k, (double)(i - 1)) * sigma, st = sp * k; sig[i] = sqrt(st * st - sp * sp); }
+    }
+    octave_t oc[MAX_OCT];
+    memset(oc, 0, sizeof(oc));
+    float* tmp = (float*)malloc(sizeof(float) * (size_t)W * H);
+    int no = 0;
+    for (int o = 0; o < nOct; o++) {
+        int ow = W >> o, oh = H >> o;
+        if (ow < 2 * IMG_BORDER + 2 || oh < 2 * IMG_BORDER + 2) break;      /* no keypoint can exist in smaller octaves */
+        oc[o].w = ow; oc[o].h = oh;
+        for (int i = 0; i < N_LEVELS; i++) oc[o].lv[i] = (float*)malloc(sizeof(float) * (size_t)ow * oh);
+        if (o == 0) {
+            double sd = sqrt(sigma * sigma - 1.0 > 0.01 ? sigma * sigma - 1.0 : 0.01);
+            gauss_blur(up, oc[0].lv[0], tmp, ow, oh, sd);
+        } else {
+            const float* s = oc[o - 1].lv[N_LAYERS];
+            int pw = oc[o - 1].w;
+            for (int y = 0; y < oh; y++) for (int x = 0; x < ow; x++) oc[o].lv[0][(size_t)y * ow + x] = s[(size_t)(2 * y) * pw + 2 * x];
+        }
+        for (int i = 1; i < N_LEVELS; i++) gauss_blur(oc[o].lv[i - 1], oc[o].lv[i], tmp, ow, oh, sig[i]);
+        no = o + 1;
+    }
+    free(up); free(tmp);
+    /* 4-6: extrema -> refined keypoints with orientations */
+    size_t cap = 1 << 16, ncand = 0;
+    cand_t* cand = (cand_t*)malloc(sizeof(cand_t) * cap);
+    for (int o = 0; o < no; o++) {
+        const octave_t* O = &oc[o];
+        /* duplicates: several start points may converge to one location; claim each final location once */
+        uint8_t* claimed = (uint8_t*)calloc((size_t)O->w * O->h, 1);
+        for (int layer = 1; layer <= N_LAYERS; layer++)
+            for (int r = IMG_BORDER; r < O->h - IMG_BORDER; r++)
+                for (int c = IMG_BORDER; c < O->w - IMG_BORDER; c++) {
+                    float val = dogv(O, layer, r, c);
+                    if (!(fabsf(val) > 0.0f)) continue;
+                    int ismax = val > 0.0f, ok = 1;
+                    for (int dl = -1; dl <= 1 && ok; dl++)
+                        for (int dr = -1; dr <= 1 && ok; dr++)
+                            for (int dc = -1; dc <= 1; dc++) {
+                                if (!dl && !dr && !dc) continue;
+                                float v = dogv(O, layer + dl, r + dr, c + dc);
+                                if (ismax ? !(val >= v) : !(val <= v)) { ok = 0; break; }
+                            }
+                    if (!ok) continue;
+                    int L = layer, R = r, Cc = c; float xi, xr, xc, contr;
+                    if (!adjust_extremum(O, &L, &R, &Cc, &xi, &xr, &xc, &contr, contrast_thr, edge_thr)) continue;
+                    uint8_t bit = (uint8_t)(1u << L);
+                    if (claimed[(size_t)R * O->w + Cc] & bit) continue;
+                    claimed[(size_t)R * O->w + Cc] |= bit;
+                    float scl = (float)sigma * det_exp2f(((float)L + xi) / (float)N_LAYERS);
+                    /* orientation histogram on the Gaussian level L of this octave */
+                    const float* img = O->lv[L];
+                    int radius = (int)rintf(4.5f * scl);
+                    float osig = 1.5f * scl;
+                    float expf_scale = -1.0f / (2.0f * osig * osig);
+                    float th[ORI_BINS], hs[ORI_BINS];
+                    for (int b = 0; b < ORI_BINS; b++) th[b] = 0.0f;
+                    for (int i = -radius; i <= radius; i++) {
+                        int y = R + i;
+                        if (y <= 0 || y >= O->h - 1) continue;
+                        for (int j = -radius; j <= radius; j++) {
+                            int x = Cc + j;
+                            if (x <= 0 || x >= O->w - 1) continue;
+                            float dx = img[(size_t)y * O->w + x + 1] - img[(size_t)y * O->w + x - 1];
+                            float dy = img[(size_t)(y - 1) * O->w + x] - img[(size_t)(y + 1) * O->w + x];
+                            float wgt = det_expf((float)(i * i + j * j) * expf_scale);
+                            float ang = det_atan2deg(dy, dx);
+                            float mag = sqrtf(dx * dx + dy * dy);
+                            int bin = (int)rintf(((float)ORI_BINS / 360.0f) * ang);
+                            if (bin >= ORI_BINS) bin -= ORI_BINS;
+                            if (bin < 0) bin += ORI_BINS;
+                            float t = wgt * mag;
+                            th[bin] = th[bin] + t;
+                        }
+                    }
+                    float omax = 0.0f;
+                    for (int b = 0; b < ORI_BINS; b++) {
+                        float m2 = th[(b + ORI_BINS - 2) % ORI_BINS], m1 = th[(b + ORI_BINS - 1) % ORI_BINS];
+                        float p1 = th[(b + 1) % ORI_BINS], p2 = th[(b + 2) % ORI_BINS];
+                        hs[b] = ((m2 + p2) * (1.0f / 16.0f) + (m1 + p1) * (4.0f / 16.0f)) + th[b] * (6.0f / 16.0f);
+                        if (hs[b] > omax) omax = hs[b];
+                    }
+                    float mag_thr = omax * 0.8f;
+                    for (int b = 0; b < ORI_BINS; b++) {
+                        int l = b > 0 ? b - 1 : ORI_BINS - 1, r2 = b < ORI_BINS - 1 ? b + 1 : 0;
+                        if (hs[b] > hs[l] && hs[b] > hs[r2] && hs[b] >= mag_thr) {
+                            float bf = (float)b + (0.5f * (hs[l] - hs[r2])) / ((hs[l] - 2.0f * hs[b]) + hs[r2]);
+                            bf = bf < 0.0f ? (float)ORI_BINS + bf : (bf >= (float)ORI_BINS ? bf - (float)ORI_BINS : bf);
+                            if (ncand == cap) { cap *= 2; cand = (cand_t*)realloc(cand, sizeof(cand_t) * cap); }
+                            cand_t* k = &cand[ncand++];
+                            float resp = fabsf(contr);
+                            memcpy(&k->resp_bits, &resp, 4);
+                            k->o = o; k->layer = L; k->r = R; k->c = Cc; k->bin = b;
+                            k->ptx = (float)Cc + xc; k->pty = (float)R + xr;
+                            /* image coordinates: octave o is scaled by 2^(o-1) relative to the input image */
+                            float s2 = o == 0 ? 0.5f : (float)(1 << (o - 1));
+                            k->x = k->ptx * s2; k->y = k->pty * s2;
+                            k->size = (scl * s2) * 2.0f;
+                            k->angle = (360.0f / (float)ORI_BINS) * bf;
+                            k->response = resp; k->xi = xi; k->scl = scl;
+                        }
+                    }
+                }
+        free(claimed);
+    }
+    /* 7: order, keep the strongest */
+    qsort(cand, ncand, sizeof(cand_t), cand_cmp);
+    size_t keep = ncand < (size_t)nfeatures ? ncand : (size_t)nfeatures;
+    if (keep > (size_t)max_kp) keep = (size_t)max_kp;
+    for (size_t i = 0; i < keep; i++) {
+        const cand_t* k = &cand[i];
+        kp_out[i].x = k->x; kp_out[i].y = k->y; kp_out[i].size = k->size; kp_out[i].angle = k->angle; kp_out[i].response = k->response;
+        /* OpenCV packing: octave (first octave = -1) | layer << 8 | round((xi + 0.5) * 255) << 16 */
+        kp_out[i].octave = ((k->o - 1) & 255) | (k->layer << 8) | (((int)rintf((k->xi + 0.5f) * 255.0f)) << 16);
+        kp_out[i].class_id = -1;
+        if (desc_out) describe(&oc[k->o], k, desc_out + 128 * i);      /* 8 */
+    }
+    free(cand);
+    for (int o = 0; o < no; o++) for (int i = 0; i < N_LEVELS; i++) free(oc[o].lv[i]);
+    return (int)keep;
+}
