@@ -31,8 +31,11 @@
  *     with one fused multiply-add per tap (fmaf), row pass then column pass;
  *   - exp / atan2 / sin / cos are the fixed polynomial approximations below (OpenCV also uses
  *     approximations there: cv::exp, fastAtan2), evaluated with fmaf in a fixed order;
- *   - histogram accumulation runs in raster order of the sample window (row by row, as the loops are
- *     written below), every contribution added separately;
+ *   - the orientation histogram accumulates in raster order of the sample window (row by row, as the
+ *     loops are written below), every contribution added separately;
+ *   - the descriptor histogram is accumulated ORDER-FREE: every trilinear contribution v is quantised to
+ *     q = rint(v * 2^20) and summed as a 64-bit integer; the bin value is (float)sum * 2^-20 (resolution
+ *     ~1e-6 of a grey level, far below the u8 quantisation of the descriptor);
  *   - the 3x3 solve is Gaussian elimination with partial pivoting (first largest pivot);
  *   - keypoints are ordered by (response descending, octave, layer, row, column, orientation bin) and
  *     that is also the output order; duplicates = same (octave, layer, row, column, bin).
@@ -263,8 +266,9 @@ static void describe(const octave_t* oc, const cand_t* k, uint8_t* out)
     const float hist_width = 3.0f * scl;
     const int radius = (int)rintf(hist_width * 1.4142135623730951f * (float)(d + 1) * 0.5f);
     cos_t = cos_t / hist_width; sin_t = sin_t / hist_width;
+    int64_t hq[(4 + 2) * (4 + 2) * (8 + 2)];
     float hist[(4 + 2) * (4 + 2) * (8 + 2)];
-    for (int i = 0; i < (d + 2) * (d + 2) * (n + 2); i++) hist[i] = 0.0f;
+    for (int i = 0; i < (d + 2) * (d + 2) * (n + 2); i++) hq[i] = 0;
     for (int i = -radius; i <= radius; i++)
         for (int j = -radius; j <= radius; j++) {
             float c_rot = (float)j * cos_t - (float)i * sin_t;
@@ -291,11 +295,13 @@ static void describe(const octave_t* oc, const cand_t* k, uint8_t* out)
             float v_rco011 = v_rc01 * obin, v_rco010 = v_rc01 - v_rco011;
             float v_rco001 = v_rc00 * obin, v_rco000 = v_rc00 - v_rco001;
             int idx = ((r0 + 1) * (d + 2) + c0 + 1) * (n + 2) + o0;
-            hist[idx] += v_rco000; hist[idx + 1] += v_rco001;
-            hist[idx + (n + 2)] += v_rco010; hist[idx + (n + 3)] += v_rco011;
-            hist[idx + (d + 2) * (n + 2)] += v_rco100; hist[idx + (d + 2) * (n + 2) + 1] += v_rco101;
-            hist[idx + (d + 3) * (n + 2)] += v_rco110; hist[idx + (d + 3) * (n + 2) + 1] += v_rco111;
+#define FIXQ(v) ((int64_t)llrintf((v) * 1048576.0f))
+            hq[idx] += FIXQ(v_rco000); hq[idx + 1] += FIXQ(v_rco001);
+            hq[idx + (n + 2)] += FIXQ(v_rco010); hq[idx + (n + 3)] += FIXQ(v_rco011);
+            hq[idx + (d + 2) * (n + 2)] += FIXQ(v_rco100); hq[idx + (d + 2) * (n + 2) + 1] += FIXQ(v_rco101);
+            hq[idx + (d + 3) * (n + 2)] += FIXQ(v_rco110); hq[idx + (d + 3) * (n + 2) + 1] += FIXQ(v_rco111);
         }
+    for (int i = 0; i < (d + 2) * (d + 2) * (n + 2); i++) hist[i] = (float)hq[i] * (1.0f / 1048576.0f);
     float dst[128];
     for (int i = 0; i < d; i++)
         for (int j = 0; j < d; j++) {

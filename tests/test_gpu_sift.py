@@ -1,0 +1,86 @@
+"""GPU: SIFT detect+describe (HIP) vs the CPU restatement oracle/oracle_sift.c -- bit for bit: same
+keypoints in the same order (every field of the 28-byte cv::KeyPoint record) and identical u8 descriptors.
+Parity of this stage is UNPINNED by the reference (OpenCV 2.4.0 arithmetic is not available); the oracle
+defines it (see its header)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import imagemosaicing_amd as im
+    c = im.Context(0)
+    yield c
+    c.close()
+
+
+def _check(ctx, oracle, img, tag):
+    kp, desc = ctx.SiftExtract(7, img)
+    okp, odesc = oracle.sift(img)
+    assert len(kp) == len(okp), f"{tag}: {len(kp)} vs {len(okp)} keypoints"
+    for f in ("octave", "x", "y", "size", "angle", "response", "class_id"):
+        a, b = kp[f], okp[f]
+        same = a.view(np.uint32) == b.view(np.uint32) if a.dtype.kind == "f" else a == b
+        assert same.all(), f"{tag}: field {f} differs at {np.where(~same)[0][:5]} ({a[~same][:3]} vs {b[~same][:3]})"
+    d8 = desc.astype(np.uint8)
+    assert np.array_equal(desc, d8.astype(np.float32)), "descriptors are not integer valued"
+    assert np.array_equal(d8, odesc), f"{tag}: {int((d8 != odesc).any(1).sum())} descriptors differ"
+    return kp, d8
+
+
+def test_sift_two_overlapping_tiles_c1(ctx, oracle):
+    """BASELINE config C1: 2 overlapping 640x480 tiles -> detect, describe, match, H"""
+    from tests.synth_frames import strip
+    frames, Hs = strip(2, 640, 480, seed=1)
+    k0, d0 = _check(ctx, oracle, frames[0], "tile0")
+    assert len(k0) == 2000
+    ctx.SiftExtract(0, frames[0]); ctx.SiftExtract(1, frames[1])
+    res = ctx.MatchPairs([(0, 1)], 2.5, 1)[0]
+    assert int(res["accepted"]) == 1 and int(res["n_in"]) > 100
+    # homography maps frame-1 pixels onto frame-0 pixels: compare with ground truth on the frame centre
+    Hgt = np.linalg.inv(Hs[0]) @ Hs[1]
+    H = res["H"].astype(np.float64).copy(); H[8] = 1.0; H = H.reshape(3, 3)
+    p = np.array([320.0, 240.0, 1.0])
+    a, b = H @ p, Hgt @ p
+    assert np.hypot(*(a[:2] / a[2] - b[:2] / b[2])) < 1.0
+    # whole pair vs the oracle pipeline on the oracle's own features
+    k1, d1 = oracle.sift(frames[1])
+    ok0, od0 = oracle.sift(frames[0])
+    nin, i1, i2, Ho, ns = oracle.match_pair(np.stack([ok0["x"], ok0["y"]], 1), od0, np.stack([k1["x"], k1["y"]], 1), d1, 640, 480, 2.5, 1)
+    assert nin == int(res["n_in"]) and ns == int(res["n_selected"])
+    assert np.array_equal(res["a"][:nin], i1[:nin]) and np.array_equal(res["H"].view(np.uint32), Ho.view(np.uint32))
+
+
+def test_sift_ragged_sizes(ctx, oracle):
+    from tests.synth_frames import terrain
+    for (w, h, seed) in [(333, 257, 3), (129, 200, 4), (64, 64, 5)]:
+        _check(ctx, oracle, terrain(w, h, seed=seed), f"{w}x{h}")
+
+
+def test_sift_flat_image_has_no_keypoints(ctx, oracle):
+    img = np.full((120, 160, 3), 128, np.uint8)
+    kp, desc = ctx.SiftExtract(3, img)
+    okp, _ = oracle.sift(img)
+    assert len(kp) == 0 and len(okp) == 0
+
+
+def test_sift_row_padding_is_ignored(ctx, oracle):
+    """widthStep > 3*w (IplImage rows padded to 4 bytes): bytes in the padding must not matter"""
+    from tests.synth_frames import terrain
+    img = terrain(201, 150, seed=9)
+    padded = np.zeros((150, 201 * 3 + 5), np.uint8)
+    padded[:, :603] = img.reshape(150, -1)
+    padded[:, 603:] = 255
+    view = np.lib.stride_tricks.as_strided(padded, shape=(150, 201, 3), strides=(padded.strides[0], 3, 1))
+    a = ctx.L  # noqa
+    import ctypes as C
+    import imagemosaicing_amd as im
+    kp = np.zeros(2000, im.KEYPOINT); desc = np.zeros((2000, 128), np.float32); n = C.c_int(0)
+    rc = ctx.L.mi355_sift_extract(ctx._h, 5, padded.ctypes.data_as(C.c_void_p), 201, 150, padded.strides[0],
+                                  kp.ctypes.data_as(C.c_void_p), desc.ctypes.data_as(C.c_void_p), 2000, C.byref(n))
+    assert rc == 0
+    kp2, desc2 = ctx.SiftExtract(6, img)
+    assert n.value == len(kp2) and np.array_equal(kp[:n.value], kp2) and np.array_equal(desc[:n.value], desc2)
+    del view
