@@ -1,0 +1,273 @@
+#!/usr/bin/env python3
+"""bench.py -- image-pairs/sec of the pairwise hot path (detect+describe, match+select, RANSAC-H, warp)
+on MI355X, the metric and workload of BASELINE.json.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+           bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over the whole batch of synthetic frames resident in HBM:
+  SIFT detect+describe of every frame once  ->  match + grid select + Ransac2D of every scheduled pair  ->
+  [N>1: RCCL all-gather of the fixed-size pair records]  ->  global affine alignment of the records on the host
+  (the reference's driver step between match and warp)  ->  inverse-warp of every frame once into the canvas.
+Workload at N=1: BASELINE configs[2] "500-frame 4000x3000 UAV set, all adjacent pairs" (C3), the configuration
+the metric is quoted on (4000x3000 frames).  With N ranks every rank owns one such strip of the survey
+(weak scaling): frames and pairs shard with no data-path collective; the only exchange is the all-gather of
+per-pair homographies + inliers that feed global alignment (north_star).  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import ctypes
+import json
+import math
+import os
+import sys
+import threading
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md (6.29 TB/s measured copy)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--frames", type=int, default=500, help="frames per rank (C3: 500)")
+    ap.add_argument("--width", type=int, default=4000)
+    ap.add_argument("--height", type=int, default=3000)
+    ap.add_argument("--window", type=int, default=2, help="pair window: j in (i, i+window); 2 = adjacent pairs (C3), 182 = reference window (C4)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile-all", action="store_true", help="bracket every kernel class with events (extra JSON field)")
+    return ap.parse_args()
+
+
+def frame_layout(n, w, h, rank, seed=0xC0FFEE):
+    """serpentine strip: 25 frames per row, 60 % forward / 30 % side overlap, +-3 deg yaw, +-2 % scale, +-5 % gain"""
+    rng = np.random.default_rng(seed + 7919 * rank)
+    per_row = 25
+    sx, sy = 0.4 * w, 0.7 * h
+    A, gains = [], []
+    for k in range(n):
+        row, col = divmod(k, per_row)
+        if row & 1:
+            col = per_row - 1 - col
+        cx = w / 2 + col * sx + rng.uniform(-0.01, 0.01) * w
+        cy = h / 2 + row * sy + rng.uniform(-0.01, 0.01) * h + rank * (sy * ((n + per_row - 1) // per_row) + h)
+        yaw = np.deg2rad(rng.uniform(-3, 3))
+        s = 1 + rng.uniform(-0.02, 0.02)
+        R = s * np.array([[np.cos(yaw), -np.sin(yaw)], [np.sin(yaw), np.cos(yaw)]])
+        t = np.array([cx, cy]) - R @ np.array([w / 2.0, h / 2.0])
+        A.append([R[0, 0], R[0, 1], t[0], R[1, 0], R[1, 1], t[1]])
+        gains.append(1 + rng.uniform(-0.05, 0.05))
+    return np.array(A, np.float64), np.array(gains)
+
+
+def affine3(a6):
+    return np.array([[a6[0], a6[1], a6[2]], [a6[3], a6[4], a6[5]], [0, 0, 1.0]])
+
+
+def cpu_has_v3():
+    try:
+        flags = open("/proc/cpuinfo").read()
+        return all(f in flags for f in (" avx2", " fma", " bmi2"))
+    except OSError:
+        return False
+
+
+def cpu_baseline(frames_host, A, w, h, ws):
+    """The oracle (CPU port of the same pipeline) on the GPU box's host cores: T = min(8, nproc-1) threads,
+    image-strided like the reference (MosaicWithoutPos.cpp:5246-5247, 4861).  Sample: T frames, T-1 adjacent pairs."""
+    from tests import oracle_lib as ol
+    ol.build_oracle()
+    lib = "liboracle_v3.so" if cpu_has_v3() and os.path.exists(os.path.join(ROOT, "oracle", "liboracle_v3.so")) else "liboracle.so"
+    T = len(frames_host)
+    orcs = [ol.Oracle(os.path.join(ROOT, "oracle", lib)) for _ in range(T)]
+    feats = [None] * T
+    done = [None] * T
+
+    def work_sift(k):
+        img = frames_host[k].reshape(h, ws)[:, :3 * w].reshape(h, w, 3)
+        feats[k] = orcs[k].sift(np.ascontiguousarray(img))
+
+    def work_pair(k):
+        img = np.ascontiguousarray(frames_host[k].reshape(h, ws)[:, :3 * w].reshape(h, w, 3))
+        if k + 1 < T:
+            (k0, d0), (k1, d1) = feats[k], feats[k + 1]
+            done[k] = orcs[k].match_pair(np.stack([k0["x"], k0["y"]], 1), d0, np.stack([k1["x"], k1["y"]], 1), d1, w, h, 2.5, 1)[0]
+        Hk = np.linalg.inv(affine3(A[0])) @ affine3(A[k])
+        orcs[k].image_projection_transform(img, Hk.reshape(9).astype(np.float32))
+
+    t0 = time.perf_counter()
+    for fn in (work_sift, work_pair):
+        th = [threading.Thread(target=fn, args=(k,)) for k in range(T)]
+        [t.start() for t in th]
+        [t.join() for t in th]
+    dt = time.perf_counter() - t0
+    pairs = max(T - 1, 1)
+    return {"value": pairs / dt, "unit": "image-pairs/s", "cores": T, "kind": "port",
+            "sample": "%d frames %dx%d / %d adjacent pairs of the same synthetic workload, %d threads image-strided, oracle/%s, %.1f s"
+                      % (T, w, h, pairs, T, lib, dt),
+            "inliers": [int(x) for x in done if x is not None]}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != max(args.gpus, 1) and world > 1:
+        raise SystemExit("WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    import imagemosaicing_amd as im
+    ctx = im.Context(local_rank)
+    # One explicit stream for everything (HIP kernels of the library, torch copies, RCCL): torch's default stream
+    # is the NULL stream, which the library's set_stream treats as "use the ctx-owned stream".
+    stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(stream)
+    assert stream.cuda_stream != 0
+    ctx.set_stream(stream.cuda_stream)
+
+    w, h, F = args.width, args.height, args.frames
+    ws = (3 * w + 3) & ~3
+    A, gains = frame_layout(F, w, h, rank)
+    # ---- synthetic frames, generated straight into HBM (never timed) ----
+    frames = torch.empty((F, h * ws), dtype=torch.uint8, device=dev)
+    for k in range(F):
+        ctx.SynthFrameDev(frames[k].data_ptr(), w, h, ws, A[k], 0xC0FFEE, (rank * 1000003 + k) & 0xffffffff, gains[k], 2.0)
+    ctx.synchronize()
+    fptr = [frames[k].data_ptr() for k in range(F)]
+    pairs = im.pair_schedule(F, args.window)
+    n_pairs = len(pairs)
+    results = torch.zeros((max(n_pairs, 1), im.PAIR_RESULT.itemsize), dtype=torch.uint8, device=dev)
+    gathered = torch.zeros((world * max(n_pairs, 1), im.PAIR_RESULT.itemsize), dtype=torch.uint8, device=dev) if world > 1 else None
+    res_host = torch.empty((max(n_pairs, 1), im.PAIR_RESULT.itemsize), dtype=torch.uint8).pin_memory()
+    # canvas big enough for the ground-truth layout with margin (the step computes the real layout)
+    Hgt = np.stack([(np.linalg.inv(affine3(A[0])) @ affine3(A[k])).reshape(9) for k in range(F)]).astype(np.float32)
+    gw, gh, gws, _ = im.mosaic_layout([w] * F, [h] * F, Hgt)
+    canvas_cap = int(1.2 * gws * gh) + (64 << 20)
+    canvas = torch.empty(canvas_cap, dtype=torch.uint8, device=dev)
+    wv, hv, wsv = [w] * F, [h] * F, [ws] * F
+    state = {}
+
+    def step(seed):
+        for k in range(F):
+            ctx.SiftExtractDev(k, fptr[k], w, h, ws)
+        ctx.MatchPairsDev(pairs, results.data_ptr(), 2.5, seed)
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, results)          # RCCL over xGMI: H + inliers of every pair of the survey
+        res_host.copy_(results, non_blocking=True)
+        stream.synchronize()
+        r = res_host.numpy().view(im.PAIR_RESULT).reshape(-1)[:n_pairs]
+        mp = im.results_to_match_pairs(r)
+        label = im.select_connected(mp, F) if len(mp) else np.zeros(F, np.int32)
+        label[0] = 1
+        keep = (label[mp["ai"]] > 0) & (label[mp["bi"]] > 0) if len(mp) else np.zeros(0, bool)
+        T = im.global_affine_align(mp[keep], F, fixed=[1 if (k == 0 or label[k] == 0) else 0 for k in range(F)])
+        h9 = T["m"].copy()
+        h9[label == 0, 8] = 0.0                                     # invalid images are skipped by the warp (MWP.cpp:4646-4652)
+        cw, ch, cws, _ = im.mosaic_layout(wv, hv, h9)
+        if cws * ch > canvas_cap:
+            raise RuntimeError("canvas larger than provisioned (%d x %d)" % (cw, ch))
+        ctx.MosaicImagesRefinedDev(fptr, wv, hv, wsv, h9, canvas.data_ptr(), cw, ch, cws)
+        state.update(r=r, cw=cw, ch=ch, n_valid=int(label.sum()))
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(1 + i)
+    ctx.profile_enable(True)
+    ctx.profile_only(None if args.profile_all else "gauss")
+    ctx.profile_reset()
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(100 + i)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    g_ms, g_n, g_bytes = ctx.profile_get("gauss")
+    prof_all = {}
+    if args.profile_all:
+        for cls in ("gauss", "downsample", "extrema", "refine", "orient", "topk", "describe", "features", "match", "select", "ransac", "warp"):
+            ms, n, b = ctx.profile_get(cls)
+            prof_all[cls] = {"ms_per_step": ms / max(args.steps, 1), "launches_per_step": n / max(args.steps, 1)}
+    ctx.profile_enable(False)
+
+    # quality of the last step against ground truth (accepted pairs): corner transfer error in pixels
+    r = state["r"]
+    errs = []
+    corners = np.array([[0, 0, 1], [w - 1, 0, 1], [w - 1, h - 1, 1], [0, h - 1, 1]], np.float64).T
+    for rec in r:
+        if not rec["accepted"]:
+            continue
+        i, j = int(rec["i"]), int(rec["j"])
+        Hg = np.linalg.inv(affine3(A[i])) @ affine3(A[j])
+        He = rec["H"].astype(np.float64).copy(); He[8] = 1.0; He = He.reshape(3, 3)
+        a, b = He @ corners, Hg @ corners
+        errs.append(float(np.abs(a[:2] / a[2] - b[:2] / b[2]).max()))
+    accepted = int(r["accepted"].sum()) if n_pairs else 0
+
+    out = None
+    if rank == 0:
+        total_pairs = n_pairs * world * args.steps
+        value = total_pairs / dt
+        achieved = (g_bytes / 1e9) / (g_ms / 1e3) if g_ms > 0 else 0.0
+        out = {
+            "metric": "image-pairs/sec (detect+match+H+warp), 4000x3000 UAV frames",
+            "value": value, "unit": "image-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / max(args.steps, 1) * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32 (pyramid/RANSAC/warp coordinates), bf16 MFMA exact-integer (descriptor distances), u8 (pixels)",
+            "data": "synthetic",
+            "config": {"workload": "C3: %d-frame %dx%d UAV strip per GPU, pair window %d (%d pairs per GPU), SIFT(2000,3,0.01,20) + exact BF match + 3x3 grid select + Ransac2D + MosaicImagesRefined warp"
+                                   % (F, w, h, args.window, n_pairs),
+                       "frames_per_gpu": F, "pairs_per_gpu": n_pairs, "frame": [w, h], "canvas": [state["cw"], state["ch"]],
+                       "sharding": "frames+pairs per rank, RCCL all-gather of pair records" if world > 1 else "single GPU"},
+            "roofline": {"bound": "hbm", "kernel": "blur_tile (fused separable Gaussian, SIFT pyramid)", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "launches": int(g_n), "avg_launch_us": (g_ms * 1e3 / g_n) if g_n else None,
+                         "algorithmic_bytes_per_frame": g_bytes / max(args.steps * F, 1)},
+            "quality": {"pairs_accepted": accepted, "pairs": n_pairs, "images_aligned": state["n_valid"],
+                        "h_corner_err_px_median": float(np.median(errs)) if errs else None,
+                        "h_corner_err_px_max": float(np.max(errs)) if errs else None},
+        }
+        if prof_all:
+            out["kernel_ms_per_step"] = prof_all
+    # ---- CPU baseline: rank 0 at N=1 only, bounded sample ----
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        T = max(1, min(8, (os.cpu_count() or 2) - 1))
+        T = min(T, F)
+        fh = frames[:T].cpu().numpy()
+        try:
+            out["cpu_baseline"] = cpu_baseline([fh[k] for k in range(T)], A, w, h, ws)
+            out["cpu_baseline"]["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+        except Exception as e:       # the baseline must never take the GPU number down with it
+            out["cpu_baseline"] = {"value": None, "unit": "image-pairs/s", "cores": T, "kind": "port", "sample": "failed: %r" % (e,)}
+    elif rank == 0:
+        out["cpu_baseline"] = None
+    if rank == 0:
+        print(json.dumps(out))
+    ctx.set_stream(None)
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -127,6 +127,9 @@ class Context:
     def profile_enable(self, on=True):
         self._chk(self.L.mi355_profile_enable(self._h, int(bool(on))))
 
+    def profile_only(self, cls=None):
+        self._chk(self.L.mi355_profile_only(self._h, (cls or "").encode()))
+
     def profile_reset(self):
         self._chk(self.L.mi355_profile_reset(self._h))
 
@@ -255,6 +258,11 @@ class Context:
         h9s = np.ascontiguousarray(h9s, np.float32)
         self._chk(self.L.mi355_mosaic_refined_dev(self._h, ptrs, _p(w), _p(h), _p(ws), n, _p(h9s), C.c_void_p(int(d_canvas)),
                                                   int(cw), int(ch), int(cws), int(row0), int(rows if rows >= 0 else ch)))
+
+    def SynthFrameDev(self, d_dst, w, h, ws, A6, seed, frame_seed, gain=1.0, noise=2.0):
+        A6 = np.ascontiguousarray(A6, np.float32)
+        self._chk(self.L.mi355_synth_frame_dev(self._h, C.c_void_p(int(d_dst)), int(w), int(h), int(ws), _p(A6), C.c_uint32(seed),
+                                               C.c_uint32(frame_seed), C.c_float(gain), C.c_float(noise)))
 
     def ChipsAndMasks(self, imgs, h9s, keep=None, find_masks=True):
         """LaplacianPyramidBlending warp stage + FindMasksByDistMap (MosaicImage.cpp:2233-2460, 1761-1881)."""
@@ -385,3 +393,12 @@ def global_affine_align(match_pairs, n_images, fixed=None):
     if rc != 0:
         raise Mi355Error(rc, "global_affine_align")
     return out
+
+
+def select_connected(match_pairs, n_images):
+    v = np.ascontiguousarray(match_pairs, MATCHPAIR)
+    label = np.zeros(n_images, np.int32)
+    rc = load_library().mi355_select_connected(_p(v), len(v), int(n_images), _p(label))
+    if rc != 0:
+        raise Mi355Error(rc, "select_connected")
+    return label

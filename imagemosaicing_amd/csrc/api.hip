@@ -257,6 +257,11 @@ extern "C" int mi355_profile_enable(mi355_ctx* ctx, int on) {
     ctx->profiling = on != 0;
     return MI355_OK;
 }
+extern "C" int mi355_profile_only(mi355_ctx* ctx, const char* kernel_class) {
+    LOCKED_PROLOGUE
+    ctx->prof_only = kernel_class ? kernel_class : "";
+    return MI355_OK;
+}
 extern "C" int mi355_profile_reset(mi355_ctx* ctx) {
     LOCKED_PROLOGUE
     MI_HIP(hipStreamSynchronize(ctx->stream));

@@ -69,6 +69,7 @@ struct mi355_ctx {
     std::map<std::string, DevBuf> ws;                  // named grow-only workspaces
     std::map<std::pair<uint32_t, int>, DevBuf> draw_tables;   // (seed, n) -> RANSAC draw table
     bool profiling = false;
+    std::string prof_only;                             // non-empty: bracket only this kernel class
     std::map<std::string, ProfClass> prof;
     SiftWork* sift = nullptr;
     int num_cu = 256;
@@ -82,8 +83,9 @@ struct mi355_ctx {
 
 struct ProfScope {
     mi355_ctx* c; const char* cls;
-    ProfScope(mi355_ctx* c_, const char* cls_, double bytes) : c(c_), cls(cls_) { if (c->profiling) c->prof_begin(cls, bytes); }
-    ~ProfScope() { if (c->profiling) c->prof_end(cls); }
+    bool on;
+    ProfScope(mi355_ctx* c_, const char* cls_, double bytes) : c(c_), cls(cls_) { on = c->profiling && (c->prof_only.empty() || c->prof_only == cls); if (on) c->prof_begin(cls, bytes); }
+    ~ProfScope() { if (on) c->prof_end(cls); }
 };
 
 // ---- internal entry points implemented by the .hip files (ctx lock already held) -----------------------

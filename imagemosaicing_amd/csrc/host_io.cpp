@@ -203,3 +203,26 @@ extern "C" int mi355_global_affine_align(const mi355_match_point_pairs* v, int n
     }
     return MI355_OK;
 }
+
+// Select_Connected_Matched_Images, MosaicWithoutPos.cpp:2754-2796: images are nodes, every image pair that has at
+// least one correspondence is an edge; label the largest connected group (union-find here instead of the
+// reference's O(E^2) cluster merge, same partition).
+extern "C" int mi355_select_connected(const mi355_match_point_pairs* v, int n, int n_images, int32_t* label) {
+    if (n < 0 || n_images <= 0 || (n > 0 && !v) || !label) return MI355_ERR_ARG;
+    std::vector<int> parent(n_images), size(n_images, 1), touched(n_images, 0);
+    for (int i = 0; i < n_images; i++) parent[i] = i;
+    auto find = [&](int x) { while (parent[x] != x) { parent[x] = parent[parent[x]]; x = parent[x]; } return x; };
+    for (int p = 0; p < n; p++) {
+        const int a = v[p].ptA_i, b = v[p].ptB_i;
+        if (a < 0 || a >= n_images || b < 0 || b >= n_images) return MI355_ERR_ARG;
+        touched[a] = touched[b] = 1;
+        int ra = find(a), rb = find(b);
+        if (ra == rb) continue;
+        if (ra > rb) { int t = ra; ra = rb; rb = t; }          // root = lowest index of the group
+        parent[rb] = ra; size[ra] += size[rb];
+    }
+    int best = -1, best_size = 0;
+    for (int i = 0; i < n_images; i++) if (touched[i] && find(i) == i && size[i] > best_size) { best = i; best_size = size[i]; }
+    for (int i = 0; i < n_images; i++) label[i] = (best >= 0 && touched[i] && find(i) == best) ? 1 : 0;
+    return MI355_OK;
+}

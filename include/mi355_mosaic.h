@@ -179,6 +179,11 @@ int  mi355_results_to_match_pairs(const mi355_pair_result* r, int n_pairs, const
 int  mi355_global_affine_align(const mi355_match_point_pairs* v, int n, int n_images, const int32_t* fixed,
                                mi355_image_transform* out);
 
+/* Select_Connected_Matched_Images (MosaicWithoutPos.cpp:2754-2796, ClusterMatchNode :2673-2752): label[k]=1 for
+ * the images of the largest group connected through match pairs, else 0 (the driver then drops the other pairs
+ * and flags those images invalid, h.m[8]=0, :4512-4523, 4646-4652).  Ties -> the group holding the lowest index. */
+int  mi355_select_connected(const mi355_match_point_pairs* v, int n, int n_images, int32_t* label);
+
 /* ---- multi-GPU ------------------------------------------------------------------------------------------ */
 /* Deterministic shard of the reference's pair schedule (i strided by rank like the threads at
  * MosaicWithoutPos.cpp:5066, j in (i, min(N, i+window))): writes pairs of rank `rank` of `world`. */
@@ -188,9 +193,15 @@ int  mi355_pair_schedule(int n_images, int window, int rank, int world, int32_t*
 /* When enabled, every launch of the named kernel class is bracketed by hipEvents on the ctx stream. */
 int  mi355_profile_enable(mi355_ctx* ctx, int on);
 int  mi355_profile_reset(mi355_ctx* ctx);
+int  mi355_profile_only(mi355_ctx* ctx, const char* kernel_class /* NULL or "" = every class */);
 /* class: "gauss", "extrema", "orient", "describe", "match", "select", "ransac", "warp", "gray" ...
  * Synchronises the stream. total_ms/launches may be NULL. */
 int  mi355_profile_get(mi355_ctx* ctx, const char* kernel_class, double* total_ms, int64_t* launches, double* alg_bytes);
+
+/* Synthetic input (bench / tests only, never timed): BGR frame sampled from a seeded procedural terrain through the
+ * affine map (u,v) = A6 (x,y,1), written straight into HBM at d_dst. */
+int  mi355_synth_frame_dev(mi355_ctx* ctx, uint8_t* d_dst, int w, int h, int ws, const float A6[6], uint32_t seed, uint32_t frame_seed,
+                           float gain, float noise_sigma);
 
 #ifdef __cplusplus
 }
