@@ -25,7 +25,7 @@ assert SFPOINT.itemsize == 12 and KEYPOINT.itemsize == 28 and MATCHPAIR.itemsize
 class Params(C.Structure):
     _fields_ = [("nfeatures", C.c_int32), ("n_octave_layers", C.c_int32), ("contrast_threshold", C.c_float),
                 ("edge_threshold", C.c_float), ("sigma", C.c_float), ("max_selected", C.c_int32),
-                ("select_fraction", C.c_float), ("grid_x", C.c_int32), ("grid_y", C.c_int32), ("min_inliers", C.c_int32),
+                ("select_fraction", C.c_double), ("grid_x", C.c_int32), ("grid_y", C.c_int32), ("min_inliers", C.c_int32),
                 ("ransac_dist", C.c_float), ("sample_times", C.c_int32), ("pair_window", C.c_int32), ("ratio", C.c_float)]
 
 

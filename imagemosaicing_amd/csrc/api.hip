@@ -9,11 +9,11 @@ static std::string g_create_error;
 extern "C" void mi355_default_params(mi355_params* p) {
     if (!p) return;
     p->nfeatures = 2000; p->n_octave_layers = 3; p->contrast_threshold = 0.01f; p->edge_threshold = 20.0f; p->sigma = 1.6f;
-    p->max_selected = 400; p->select_fraction = 0.3f; p->grid_x = 3; p->grid_y = 3; p->min_inliers = 30;
+    p->max_selected = 400; p->select_fraction = 0.3; p->grid_x = 3; p->grid_y = 3; p->min_inliers = 30;
     p->ransac_dist = 2.5f; p->sample_times = 1000; p->pair_window = 182; p->ratio = 0.0f;
 }
 
-void mi355_ctx::prof_begin(const char* cls, double alg_bytes) {
+void mi355_ctx::prof_begin(const char* cls, double alg_bytes, hipStream_t st) {
     ProfClass& pc = prof[cls];
     if (pc.used == pc.ev.size()) {
         hipEvent_t a, b;
@@ -21,11 +21,11 @@ void mi355_ctx::prof_begin(const char* cls, double alg_bytes) {
         pc.ev.emplace_back(a, b);
     }
     pc.bytes += alg_bytes;
-    (void)hipEventRecord(pc.ev[pc.used].first, stream);
+    (void)hipEventRecord(pc.ev[pc.used].first, st);
 }
-void mi355_ctx::prof_end(const char* cls) {
+void mi355_ctx::prof_end(const char* cls, hipStream_t st) {
     ProfClass& pc = prof[cls];
-    if (pc.used < pc.ev.size()) { (void)hipEventRecord(pc.ev[pc.used].second, stream); pc.used++; }
+    if (pc.used < pc.ev.size()) { (void)hipEventRecord(pc.ev[pc.used].second, st); pc.used++; }
 }
 
 extern "C" int mi355_create(mi355_ctx** out, const mi355_params* params, int device_ordinal) {
@@ -60,6 +60,7 @@ extern "C" void mi355_destroy(mi355_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    (void)mi_resolve_features(ctx);
     mi_sift_release(ctx);
     for (auto& kv : ctx->feats) kv.second.release();
     for (auto& kv : ctx->ws) kv.second.release();
@@ -82,6 +83,8 @@ extern "C" int mi355_set_stream(mi355_ctx* ctx, void* hip_stream) {
 extern "C" int mi355_synchronize(mi355_ctx* ctx) {
     if (!ctx) return MI355_ERR_ARG;
     std::lock_guard<std::mutex> lk(ctx->mu);
+    int rc = mi_resolve_features(ctx);
+    if (rc != MI355_OK) return rc;
     MI_HIP(hipStreamSynchronize(ctx->stream));
     return MI355_OK;
 }
@@ -125,6 +128,7 @@ extern "C" int mi355_set_features(mi355_ctx* ctx, int img_id, const mi355_keypoi
 
 extern "C" int mi355_drop_features(mi355_ctx* ctx, int img_id) {
     LOCKED_PROLOGUE
+    (void)mi_resolve_features(ctx);
     MI_HIP(hipStreamSynchronize(ctx->stream));
     if (img_id < 0) { for (auto& kv : ctx->feats) kv.second.release(); ctx->feats.clear(); }
     else { auto it = ctx->feats.find(img_id); if (it != ctx->feats.end()) { it->second.release(); ctx->feats.erase(it); } }
@@ -257,6 +261,12 @@ extern "C" int mi355_profile_enable(mi355_ctx* ctx, int on) {
     ctx->profiling = on != 0;
     return MI355_OK;
 }
+extern "C" int mi355_last_sift_counters(mi355_ctx* ctx, int32_t out8[8]) {
+    LOCKED_PROLOGUE
+    if (!out8) return MI355_ERR_ARG;
+    for (int i = 0; i < 8; i++) out8[i] = ctx->last_counts[i];
+    return MI355_OK;
+}
 extern "C" int mi355_profile_only(mi355_ctx* ctx, const char* kernel_class) {
     LOCKED_PROLOGUE
     ctx->prof_only = kernel_class ? kernel_class : "";
@@ -264,6 +274,7 @@ extern "C" int mi355_profile_only(mi355_ctx* ctx, const char* kernel_class) {
 }
 extern "C" int mi355_profile_reset(mi355_ctx* ctx) {
     LOCKED_PROLOGUE
+    (void)mi_resolve_features(ctx);
     MI_HIP(hipStreamSynchronize(ctx->stream));
     for (auto& kv : ctx->prof) { kv.second.used = 0; kv.second.bytes = 0.0; }
     return MI355_OK;
@@ -271,6 +282,7 @@ extern "C" int mi355_profile_reset(mi355_ctx* ctx) {
 extern "C" int mi355_profile_get(mi355_ctx* ctx, const char* kernel_class, double* total_ms, int64_t* launches, double* alg_bytes) {
     LOCKED_PROLOGUE
     if (!kernel_class) return MI355_ERR_ARG;
+    (void)mi_resolve_features(ctx);
     MI_HIP(hipStreamSynchronize(ctx->stream));
     double ms = 0.0; int64_t cnt = 0; double bytes = 0.0;
     auto it = ctx->prof.find(kernel_class);

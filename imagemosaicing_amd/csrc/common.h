@@ -47,6 +47,11 @@ struct Features {
     DevBuf d8;          // n x 128 u8   (the integers OpenCV's SIFT stores in its float Mat)
     DevBuf bf;          // npad x 128 bf16 (same integers, exact in bf16)
     DevBuf nrm;         // npad x int32  squared norms
+    // asynchronous SIFT: the keypoint count is produced on the device; it lands in pinned host memory and is
+    // adopted by mi_resolve_features() the first time the host needs it (match, get_features)
+    bool pending = false;
+    volatile int* h_cnt = nullptr;   // 8 ints: extrema, refined, keypoints, kept, overflow, ...
+    unsigned caps[3] = {0, 0, 0};
     void release() { kp.release(); xy.release(); d8.release(); bf.release(); nrm.release(); }
 };
 
@@ -71,21 +76,29 @@ struct mi355_ctx {
     bool profiling = false;
     std::string prof_only;                             // non-empty: bracket only this kernel class
     std::map<std::string, ProfClass> prof;
-    SiftWork* sift = nullptr;
+    std::vector<SiftWork*> sift_slots;                 // one work area + stream per in-flight frame
+    int sift_next = 0;
+    hipEvent_t sift_in_ev = nullptr;                   // orders a slot stream after the caller's stream
+    std::vector<int*> pinned_chunks;                   // pinned count slots, 8 ints per frame
+    size_t pinned_used = 0;
     int num_cu = 256;
+    int last_counts[8] = {0};                          // SIFT counters of the last frame: candidates, refined, keypoints, selected, overflow
 
     void set_error(const std::string& s) { err = s; }
     DevBuf& buf(const std::string& name) { return ws[name]; }
     // profiling brackets
-    void prof_begin(const char* cls, double alg_bytes);
-    void prof_end(const char* cls);
+    void prof_begin(const char* cls, double alg_bytes, hipStream_t st);
+    void prof_end(const char* cls, hipStream_t st);
 };
 
 struct ProfScope {
-    mi355_ctx* c; const char* cls;
+    mi355_ctx* c; const char* cls; hipStream_t st;
     bool on;
-    ProfScope(mi355_ctx* c_, const char* cls_, double bytes) : c(c_), cls(cls_) { on = c->profiling && (c->prof_only.empty() || c->prof_only == cls); if (on) c->prof_begin(cls, bytes); }
-    ~ProfScope() { if (on) c->prof_end(cls); }
+    ProfScope(mi355_ctx* c_, const char* cls_, double bytes, hipStream_t st_ = nullptr) : c(c_), cls(cls_), st(st_ ? st_ : c_->stream) {
+        on = c->profiling && (c->prof_only.empty() || c->prof_only == cls);
+        if (on) c->prof_begin(cls, bytes, st);
+    }
+    ~ProfScope() { if (on) c->prof_end(cls, st); }
 };
 
 // ---- internal entry points implemented by the .hip files (ctx lock already held) -----------------------
@@ -103,7 +116,8 @@ int mi_bf_match(mi355_ctx*, int img_i, int img_j, int sorted, mi355_dmatch* matc
 int mi_select_grid(mi355_ctx*, const mi355_dmatch* sorted, int n, const float* kp1, int nk1, const float* kp2, int nk2,
                    int nMatch, int width, int height, int gx, int gy, mi355_sfpoint* v1, mi355_sfpoint* v2, int* n_out);
 int mi_set_features(mi355_ctx*, int img_id, const mi355_keypoint* kp, const float* desc, int n, int w, int h);
-int mi_finish_features(mi355_ctx*, Features& f);   // builds xy / bf16 / norms from kp + d8 on device
+int mi_finish_features(mi355_ctx*, Features& f, const int* d_n = nullptr, hipStream_t st = nullptr);   // builds xy / bf16 / norms from kp + d8 on device
+int mi_resolve_features(mi355_ctx*);               // waits for in-flight SIFT frames and adopts their keypoint counts
 int mi_sift_extract_dev(mi355_ctx*, int img_id, const uint8_t* d_bgr, int w, int h, int ws, int* n_kp);
 void mi_sift_release(mi355_ctx*);
 

@@ -89,7 +89,7 @@ __global__ __launch_bounds__(256) void bf_match_kernel(const PairDesc* pairs, in
 }
 
 // ---- K7: sort by (d2, queryIdx) + grid walk -----------------------------------------------------------------
-struct SelectParams { int max_selected; float fraction; int gx, gy; float ratio2; };
+struct SelectParams { int max_selected; double fraction; int gx, gy; float ratio2; };
 
 __global__ __launch_bounds__(256) void select_kernel(const PairDesc* pairs, const int* nn_idx, const int* nn_d2, const int* nn_2nd,
                                                      SelectParams sp, mi355_sfpoint* sel1, mi355_sfpoint* sel2, int* nsel,
@@ -122,7 +122,7 @@ __global__ __launch_bounds__(256) void select_kernel(const PairDesc* pairs, cons
     // grid walk by one wave, 64 sorted matches per step (MosaicWithoutPos.cpp:4977-5028)
     const int lane = tid;
     const int nGrids = sp.gx * sp.gy;
-    const double lim = (double)sp.fraction * (double)M;                        // Min(400, 0.3*M) evaluated in double (:5146-5147)
+    const double lim = sp.fraction * (double)M;                        // Min(400, 0.3*M) evaluated in double (:5146-5147)
     const int nMatch = (int)((double)sp.max_selected < lim ? (double)sp.max_selected : lim);
     const int perGrid = (int)((float)nMatch / (float)nGrids);                    // :4990
     const int stepX = pd.width / sp.gx, stepY = pd.height / sp.gy;               // :4994-4995
@@ -182,9 +182,10 @@ __global__ void finalize_kernel(const PairDesc* pairs, const int* nsel, int n_pa
 }
 
 // ---- features ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(128) void finish_features_kernel(const mi355_keypoint* kp, const uint8_t* d8, int n, int npad,
+__global__ __launch_bounds__(128) void finish_features_kernel(const mi355_keypoint* kp, const uint8_t* d8, int n, const int* d_n, int npad,
                                                               float2* xy, uint16_t* bf, int* nrm) {
     const int row = blockIdx.x, k = threadIdx.x;            // one row per block, 128 lanes = 128 dims
+    if (d_n) n = *d_n;                                       // count still on the device (asynchronous SIFT)
     unsigned v = 0;
     if (row < n) v = d8[(size_t)row * 128 + k];
     // integer 0..255 -> bf16 bits (exact): f32 bits >> 16
@@ -214,6 +215,7 @@ __global__ void desc_u8_to_f32_kernel(const uint8_t* d8, float* f, size_t count)
 }
 
 int build_pair_table(mi355_ctx* ctx, const int32_t* pairs, int n_pairs, std::vector<PairDesc>& pd) {
+    { int rc = mi_resolve_features(ctx); if (rc != MI355_OK) return rc; }
     pd.resize(n_pairs);
     for (int p = 0; p < n_pairs; p++) {
         const int i = pairs[2 * p], j = pairs[2 * p + 1];
@@ -231,23 +233,26 @@ int build_pair_table(mi355_ctx* ctx, const int32_t* pairs, int n_pairs, std::vec
 
 }  // namespace
 
-int mi_finish_features(mi355_ctx* ctx, Features& f) {
-    f.npad = ((f.n + QTILE - 1) / QTILE) * QTILE;
+int mi_finish_features(mi355_ctx* ctx, Features& f, const int* d_n, hipStream_t st) {
+    if (!st) st = ctx->stream;
+    const int nmax = d_n ? KSTRIDE : f.n;
+    f.npad = ((nmax + QTILE - 1) / QTILE) * QTILE;
     if (f.npad == 0) f.npad = QTILE;
-    MI_HIP(f.xy.reserve(sizeof(float2) * (size_t)(f.n > 0 ? f.n : 1)));
+    MI_HIP(f.xy.reserve(sizeof(float2) * (size_t)(nmax > 0 ? nmax : 1)));
     MI_HIP(f.bf.reserve(sizeof(uint16_t) * 128 * (size_t)f.npad));
     MI_HIP(f.nrm.reserve(sizeof(int) * (size_t)f.npad));
-    ProfScope ps(ctx, "features", (double)f.npad * 128 * 3);
-    hipLaunchKernelGGL(finish_features_kernel, dim3(f.npad), dim3(128), 0, ctx->stream,
-                       f.kp.as<mi355_keypoint>(), f.d8.as<uint8_t>(), f.n, f.npad, f.xy.as<float2>(), f.bf.as<uint16_t>(), f.nrm.as<int>());
+    ProfScope ps(ctx, "features", (double)f.npad * 128 * 3, st);
+    hipLaunchKernelGGL(finish_features_kernel, dim3(f.npad), dim3(128), 0, st,
+                       f.kp.as<mi355_keypoint>(), f.d8.as<uint8_t>(), f.n, d_n, f.npad, f.xy.as<float2>(), f.bf.as<uint16_t>(), f.nrm.as<int>());
     MI_HIP(hipGetLastError());
     return MI355_OK;
 }
 
 int mi_set_features(mi355_ctx* ctx, int img_id, const mi355_keypoint* kp, const float* desc, int n, int w, int h) {
     if (n < 0 || n > KSTRIDE || (n > 0 && (!kp || !desc)) || w <= 0 || h <= 0) { ctx->set_error("set_features: bad arguments (n must be <= 2048)"); return MI355_ERR_ARG; }
+    (void)mi_resolve_features(ctx);
     Features& f = ctx->feats[img_id];
-    f.n = n; f.w = w; f.h = h;
+    f.n = n; f.w = w; f.h = h; f.pending = false;
     const size_t cnt = (size_t)n * 128;
     MI_HIP(f.kp.reserve(sizeof(mi355_keypoint) * (size_t)(n > 0 ? n : 1)));
     MI_HIP(f.d8.reserve(cnt > 0 ? cnt : 1));
@@ -267,6 +272,7 @@ int mi_set_features(mi355_ctx* ctx, int img_id, const mi355_keypoint* kp, const 
 extern "C" int mi355_get_features(mi355_ctx* ctx, int img_id, mi355_keypoint* kp, float* desc128, int max_kp, int* n_kp) {
     if (!ctx) return MI355_ERR_ARG;
     std::lock_guard<std::mutex> lk(ctx->mu);
+    { int rc = mi_resolve_features(ctx); if (rc != MI355_OK) return rc; }
     auto it = ctx->feats.find(img_id);
     if (it == ctx->feats.end()) { ctx->set_error("get_features: unknown image id"); return MI355_ERR_ARG; }
     Features& f = it->second;
@@ -405,9 +411,7 @@ int mi_select_grid(mi355_ctx* ctx, const mi355_dmatch* sorted, int n, const floa
     MI_HIP(hipMemcpyAsync(d2n.p, d2nd.data(), KSTRIDE * 4, hipMemcpyHostToDevice, ctx->stream));
     // nMatch is given by the caller here: choose (max_selected, fraction) that reproduce it: min(nMatch, 1.0*M)
     SelectParams sp;
-    sp.max_selected = nMatch; sp.fraction = 2.0f; sp.gx = gx; sp.gy = gy; sp.ratio2 = 0.0f;
-    if (nMatch > 2 * n) sp.max_selected = 2 * n;       // the caller's nMatch always wins below; keep Min() on its first branch
-    sp.max_selected = nMatch;
+    sp.max_selected = nMatch; sp.fraction = 1e9; sp.gx = gx; sp.gy = gy; sp.ratio2 = 0.0f;      // Min(nMatch, huge) = the caller's nMatch
     hipLaunchKernelGGL(select_kernel, dim3(1), dim3(256), 0, ctx->stream, dpd.as<PairDesc>(), didx.as<int>(), dd2.as<int>(), d2n.as<int>(),
                        sp, ds1.as<mi355_sfpoint>(), ds2.as<mi355_sfpoint>(), dns.as<int>(), (unsigned long long*)nullptr);
     int cnt = 0;

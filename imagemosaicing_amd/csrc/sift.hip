@@ -129,8 +129,9 @@ __device__ __forceinline__ int xcd_remap(int bid, int nb) {
     return base + local;
 }
 
+constexpr int BT = 512;                        // threads per blur workgroup (8 waves share one staged tile)
 template <int R, bool BGR>
-__global__ __launch_bounds__(256) void blur_tile(BlurArgs a) {
+__global__ __launch_bounds__(BT) void blur_tile(BlurArgs a) {
     constexpr int ROWS = TH + 2 * R;           // rows of the staged tile
     constexpr int COLS = TW + 2 * R;
     constexpr int PIN = COLS | 1;              // odd pitches: lanes walking rows hit distinct banks
@@ -141,18 +142,28 @@ __global__ __launch_bounds__(256) void blur_tile(BlurArgs a) {
     const int tile = xcd_remap(blockIdx.x, a.tiles_x * a.tiles_y);
     const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
     const int x0 = tx * TW, y0 = ty * TH;
-    // phase 1: stage the halo tile (reflect-101 at the image border)
-    for (int idx = tid; idx < ROWS * COLS; idx += 256) {
-        const int ry = idx / COLS, rx = idx - ry * COLS;
-        const int gy = reflect101(y0 - R + ry, a.h), gx = reflect101(x0 - R + rx, a.w);
-        float v;
-        if (BGR) v = load_base(a.bgr, a.bgr_ws, a.w >> 1, a.h >> 1, gx, gy);
-        else v = a.src[(size_t)gy * a.w + gx];
-        s_in[ry * PIN + rx] = v;
+    // phase 1: stage the halo tile (reflect-101 at the image border; interior tiles skip the reflection)
+    const bool interior = (x0 - R >= 0) && (y0 - R >= 0) && (x0 + TW + R <= a.w) && (y0 + TH + R <= a.h);
+    if (interior && !BGR) {
+        const float* base = a.src + (size_t)(y0 - R) * a.w + (x0 - R);
+#pragma unroll 6
+        for (int idx = tid; idx < ROWS * COLS; idx += BT) {
+            const int ry = idx / COLS, rx = idx - ry * COLS;
+            s_in[ry * PIN + rx] = base[(size_t)ry * a.w + rx];
+        }
+    } else {
+        for (int idx = tid; idx < ROWS * COLS; idx += BT) {
+            const int ry = idx / COLS, rx = idx - ry * COLS;
+            const int gy = reflect101(y0 - R + ry, a.h), gx = reflect101(x0 - R + rx, a.w);
+            float v;
+            if (BGR) v = load_base(a.bgr, a.bgr_ws, a.w >> 1, a.h >> 1, gx, gy);
+            else v = a.src[(size_t)gy * a.w + gx];
+            s_in[ry * PIN + rx] = v;
+        }
     }
     __syncthreads();
     // phase 2: row pass, 4 adjacent outputs per item from a sliding window (tap order ascending, fmaf)
-    for (int item = tid; item < ROWS * (TW / 4); item += 256) {
+    for (int item = tid; item < ROWS * (TW / 4); item += BT) {
         const int xg = item / ROWS, row = item - xg * ROWS;
         const float* in = s_in + row * PIN + 4 * xg;
         float acc0 = 0.0f, acc1 = 0.0f, acc2 = 0.0f, acc3 = 0.0f;
@@ -169,7 +180,7 @@ __global__ __launch_bounds__(256) void blur_tile(BlurArgs a) {
     }
     __syncthreads();
     // phase 3: column pass, 4 vertically adjacent outputs per item
-    for (int item = tid; item < TW * (TH / 4); item += 256) {
+    for (int item = tid; item < TW * (TH / 4); item += BT) {
         const int yg = item / TW, x = item - yg * TW;
         const float* mid = s_mid + (4 * yg) * PMID + x;
         float acc0 = 0.0f, acc1 = 0.0f, acc2 = 0.0f, acc3 = 0.0f;
@@ -200,21 +211,26 @@ __global__ __launch_bounds__(256) void downsample2(const float* src, int sw, flo
 // ---------- K3: DoG extrema -------------------------------------------------------------------------------------
 struct OctaveDev { float* lv[N_LEVELS]; int w, h; };
 
-constexpr int EW = 64, EH = 16;
+constexpr int EW = 64, EH = 16, ECAP = 128;
 __global__ __launch_bounds__(256) void extrema_kernel(OctaveDev oc, int octave, unsigned long long* cand, unsigned* count, unsigned cap) {
     constexpr int PW = EW + 2 + 1;             // 67: odd pitch
     __shared__ float s_d[5][(EH + 2) * PW];
+    __shared__ unsigned long long s_list[ECAP];   // candidates of this tile: one global atomic per workgroup
+    __shared__ unsigned s_n, s_base;
     const int tid = threadIdx.x;
     const int x0 = blockIdx.x * EW, y0 = blockIdx.y * EH;
+    if (tid == 0) s_n = 0;
     for (int idx = tid; idx < (EH + 2) * (EW + 2); idx += 256) {
         const int ry = idx / (EW + 2), rx = idx - ry * (EW + 2);
         int gy = y0 - 1 + ry, gx = x0 - 1 + rx;
         gy = gy < 0 ? 0 : (gy > oc.h - 1 ? oc.h - 1 : gy);          // clamped halo values are never used by valid pixels (5 px border)
         gx = gx < 0 ? 0 : (gx > oc.w - 1 ? oc.w - 1 : gx);
         const size_t o = (size_t)gy * oc.w + gx;
-        float prev = oc.lv[0][o];
+        float g[N_LEVELS];
 #pragma unroll
-        for (int l = 0; l < 5; l++) { const float nx = oc.lv[l + 1][o]; s_d[l][ry * PW + rx] = nx - prev; prev = nx; }
+        for (int l = 0; l < N_LEVELS; l++) g[l] = oc.lv[l][o];
+#pragma unroll
+        for (int l = 0; l < 5; l++) s_d[l][ry * PW + rx] = g[l + 1] - g[l];
     }
     __syncthreads();
     for (int p = tid; p < EW * EH; p += 256) {
@@ -226,25 +242,35 @@ __global__ __launch_bounds__(256) void extrema_kernel(OctaveDev oc, int octave, 
         for (int layer = 1; layer <= N_LAYERS; layer++) {
             const float val = s_d[layer][ctr];
             if (!(fabsf(val) > 0.0f)) continue;
+            // in-plane 8 neighbours first (rejects ~8/9 of the pixels), then the 18 of the adjacent layers
+            const float* q = &s_d[layer][ctr];
+            float mx = fmaxf(fmaxf(fmaxf(q[-PW - 1], q[-PW]), fmaxf(q[-PW + 1], q[-1])), fmaxf(fmaxf(q[1], q[PW - 1]), fmaxf(q[PW], q[PW + 1])));
+            float mn = fminf(fminf(fminf(q[-PW - 1], q[-PW]), fminf(q[-PW + 1], q[-1])), fminf(fminf(q[1], q[PW - 1]), fminf(q[PW], q[PW + 1])));
+            const bool ismax = val > 0.0f;
+            if (ismax ? !(val >= mx) : !(val <= mn)) continue;
             bool ok = true;
-            if (val > 0.0f) {
-                for (int dl = -1; dl <= 1 && ok; dl++)
-                    for (int dr = -1; dr <= 1 && ok; dr++) {
-                        const float* row = &s_d[layer + dl][ctr + dr * PW];
-                        ok = (val >= row[-1]) && (val >= row[0]) && (val >= row[1]);
-                    }
-            } else {
-                for (int dl = -1; dl <= 1 && ok; dl++)
-                    for (int dr = -1; dr <= 1 && ok; dr++) {
-                        const float* row = &s_d[layer + dl][ctr + dr * PW];
-                        ok = (val <= row[-1]) && (val <= row[0]) && (val <= row[1]);
-                    }
+#pragma unroll
+            for (int dl = -1; dl <= 1; dl += 2) {
+                const float* u = &s_d[layer + dl][ctr];
+#pragma unroll
+                for (int dr = -1; dr <= 1; dr++) {
+                    const float* row = u + dr * PW;
+                    if (ismax) ok = ok && (val >= row[-1]) && (val >= row[0]) && (val >= row[1]);
+                    else ok = ok && (val <= row[-1]) && (val <= row[0]) && (val <= row[1]);
+                }
             }
             if (!ok) continue;
-            const unsigned slot = atomicAdd(count, 1u);
-            if (slot < cap) cand[slot] = ((unsigned long long)octave << 48) | ((unsigned long long)layer << 40) | ((unsigned long long)r << 20) | (unsigned long long)c;
+            const unsigned long long rec = ((unsigned long long)octave << 48) | ((unsigned long long)layer << 40) | ((unsigned long long)r << 20) | (unsigned long long)c;
+            const unsigned slot = atomicAdd(&s_n, 1u);
+            if (slot < ECAP) s_list[slot] = rec;
+            else { const unsigned g = atomicAdd(count, 1u); if (g < cap) cand[g] = rec; }      // tile with > 128 extrema (flat image)
         }
     }
+    __syncthreads();
+    const unsigned nloc = s_n < ECAP ? s_n : ECAP;
+    if (tid == 0 && nloc) s_base = atomicAdd(count, nloc);
+    __syncthreads();
+    for (unsigned i = tid; i < nloc; i += 256) { const unsigned g = s_base + i; if (g < cap) cand[g] = s_list[i]; }
 }
 
 // ---------- K3b: sub-pixel refinement ---------------------------------------------------------------------------
@@ -358,76 +384,104 @@ struct KpRec {
     float ptx, pty, scl, angle, xi;
 };
 
-constexpr int ORI_MAX_RADIUS = 17;
-constexpr int ORI_MAX_SAMPLES = (2 * ORI_MAX_RADIUS + 1) * (2 * ORI_MAX_RADIUS + 1);
-
+constexpr int OCAP = 256;                     // emitted keypoints buffered per workgroup between flushes
 __global__ __launch_bounds__(256) void orient_kernel(PyrDev P, const Refined* ref, const unsigned* ref_count, unsigned ref_cap,
-                                                     KpRec* out, unsigned* out_count, unsigned out_cap) {
-    __shared__ float s_val[4][ORI_MAX_SAMPLES];
-    __shared__ unsigned char s_bin[4][ORI_MAX_SAMPLES];
+                                                     KpRec* out, unsigned* out_resp, unsigned* out_count, unsigned out_cap) {
+    __shared__ unsigned long long s_hq[4][ORI_BINS];
     __shared__ float s_hist[4][ORI_BINS + 4];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    __shared__ KpRec s_out[OCAP];             // one global atomic per flush instead of one per keypoint
+    __shared__ unsigned s_on, s_obase;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     unsigned n = *ref_count;
     if (n > ref_cap) n = ref_cap;
-    for (unsigned k = blockIdx.x * 4 + wv; k < n; k += gridDim.x * 4) {
-        const Refined rr = ref[k];
-        const OctaveDev& oc = P.oc[rr.o];
-        const float* img = oc.lv[rr.layer];
-        int radius = (int)rintf(4.5f * rr.scl);
-        if (radius > ORI_MAX_RADIUS) radius = ORI_MAX_RADIUS;       // unreachable with 3 layers / sigma 1.6 (max 16)
-        const float osig = 1.5f * rr.scl;
-        const float expf_scale = -1.0f / (2.0f * osig * osig);
-        const int side = 2 * radius + 1, S = side * side;
-        for (int s = lane; s < S; s += 64) {
-            const int ii = s / side, i = ii - radius, j = s - ii * side - radius;
-            const int y = rr.r + i, x = rr.c + j;
-            unsigned char bin = 255; float val = 0.0f;
-            if (!(y <= 0 || y >= oc.h - 1 || x <= 0 || x >= oc.w - 1)) {
-                const float dx = img[(size_t)y * oc.w + x + 1] - img[(size_t)y * oc.w + x - 1];
-                const float dy = img[(size_t)(y - 1) * oc.w + x] - img[(size_t)(y + 1) * oc.w + x];
-                const float wgt = det_expf((float)(i * i + j * j) * expf_scale);
-                const float ang = det_atan2deg(dy, dx);
-                const float mag = sqrtf(dx * dx + dy * dy);
-                int b = (int)rintf(((float)ORI_BINS / 360.0f) * ang);
-                if (b >= ORI_BINS) b -= ORI_BINS;
-                if (b < 0) b += ORI_BINS;
-                bin = (unsigned char)b; val = wgt * mag;
+    if (tid == 0) s_on = 0;
+    __syncthreads();
+    for (unsigned base = blockIdx.x * 4; base < n; base += gridDim.x * 4) {        // uniform trip count per workgroup
+        const unsigned k = base + wv;
+        if (k < n) {
+            const Refined rr = ref[k];
+            const OctaveDev& oc = P.oc[rr.o];
+            const float* img = oc.lv[rr.layer];
+            const int radius = (int)rintf(4.5f * rr.scl);
+            const float osig = 1.5f * rr.scl;
+            const float expf_scale = -1.0f / (2.0f * osig * osig);
+            const int side = 2 * radius + 1, S = side * side;
+            if (lane < ORI_BINS) s_hq[wv][lane] = 0ull;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            // 4 samples per lane per trip: the 16 gradient loads of a trip are issued before any is consumed
+            for (int s0 = lane; s0 < S; s0 += 256) {
+                float dxv[4], dyv[4]; int d2v[4]; bool okv[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int s = s0 + 64 * u;
+                    const int ii = s / side, i = ii - radius, j = s - ii * side - radius;
+                    const int y = rr.r + i, x = rr.c + j;
+                    okv[u] = (s < S) && !(y <= 0 || y >= oc.h - 1 || x <= 0 || x >= oc.w - 1);
+                    d2v[u] = i * i + j * j;
+                    dxv[u] = 0.0f; dyv[u] = 0.0f;
+                    if (okv[u]) {
+                        dxv[u] = img[(size_t)y * oc.w + x + 1] - img[(size_t)y * oc.w + x - 1];
+                        dyv[u] = img[(size_t)(y - 1) * oc.w + x] - img[(size_t)(y + 1) * oc.w + x];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    if (!okv[u]) continue;
+                    const float dx = dxv[u], dy = dyv[u];
+                    const float wgt = det_expf((float)d2v[u] * expf_scale);
+                    const float ang = det_atan2deg(dy, dx);
+                    const float mag = sqrtf(dx * dx + dy * dy);
+                    int b = (int)rintf(((float)ORI_BINS / 360.0f) * ang);
+                    if (b >= ORI_BINS) b -= ORI_BINS;
+                    if (b < 0) b += ORI_BINS;
+                    const float t = wgt * mag;
+                    atomicAdd(&s_hq[wv][b], (unsigned long long)(long long)rintf(t * 1048576.0f));      // order-free by definition
+                }
             }
-            s_bin[wv][s] = bin; s_val[wv][s] = val;
-        }
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-        float acc = 0.0f;
-        if (lane < ORI_BINS)
-            for (int s = 0; s < S; s++) if (s_bin[wv][s] == lane) acc = acc + s_val[wv][s];     // raster order per bin
-        if (lane < ORI_BINS) s_hist[wv][lane] = acc;
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-        float hs = 0.0f;
-        if (lane < ORI_BINS) {
-            const float m2 = s_hist[wv][(lane + ORI_BINS - 2) % ORI_BINS], m1 = s_hist[wv][(lane + ORI_BINS - 1) % ORI_BINS];
-            const float p1 = s_hist[wv][(lane + 1) % ORI_BINS], p2 = s_hist[wv][(lane + 2) % ORI_BINS];
-            hs = ((m2 + p2) * (1.0f / 16.0f) + (m1 + p1) * (4.0f / 16.0f)) + s_hist[wv][lane] * (6.0f / 16.0f);
-        }
-        float omax = hs;                                            // max over lanes (order independent)
-        for (int off = 32; off > 0; off >>= 1) { const float o2 = __shfl_xor(omax, off); omax = o2 > omax ? o2 : omax; }
-        const float hl = __shfl(hs, lane > 0 ? lane - 1 : ORI_BINS - 1);
-        const float hr = __shfl(hs, lane < ORI_BINS - 1 ? lane + 1 : 0);
-        const float mag_thr = omax * 0.8f;
-        if (lane < ORI_BINS && hs > hl && hs > hr && hs >= mag_thr) {
-            float bf = (float)lane + (0.5f * (hl - hr)) / ((hl - 2.0f * hs) + hr);
-            bf = bf < 0.0f ? (float)ORI_BINS + bf : (bf >= (float)ORI_BINS ? bf - (float)ORI_BINS : bf);
-            const unsigned slot = atomicAdd(out_count, 1u);
-            if (slot < out_cap) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            if (lane < ORI_BINS) s_hist[wv][lane] = (float)(long long)s_hq[wv][lane] * (1.0f / 1048576.0f);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            float hs = 0.0f;
+            if (lane < ORI_BINS) {
+                const float m2 = s_hist[wv][(lane + ORI_BINS - 2) % ORI_BINS], m1 = s_hist[wv][(lane + ORI_BINS - 1) % ORI_BINS];
+                const float p1 = s_hist[wv][(lane + 1) % ORI_BINS], p2 = s_hist[wv][(lane + 2) % ORI_BINS];
+                hs = ((m2 + p2) * (1.0f / 16.0f) + (m1 + p1) * (4.0f / 16.0f)) + s_hist[wv][lane] * (6.0f / 16.0f);
+            }
+            float omax = hs;                                            // max over lanes (order independent)
+            for (int off = 32; off > 0; off >>= 1) { const float o2 = __shfl_xor(omax, off); omax = o2 > omax ? o2 : omax; }
+            const float hl = __shfl(hs, lane > 0 ? lane - 1 : ORI_BINS - 1);
+            const float hr = __shfl(hs, lane < ORI_BINS - 1 ? lane + 1 : 0);
+            const float mag_thr = omax * 0.8f;
+            if (lane < ORI_BINS && hs > hl && hs > hr && hs >= mag_thr) {
+                float bf = (float)lane + (0.5f * (hl - hr)) / ((hl - 2.0f * hs) + hr);
+                bf = bf < 0.0f ? (float)ORI_BINS + bf : (bf >= (float)ORI_BINS ? bf - (float)ORI_BINS : bf);
                 KpRec kr;
                 kr.resp_bits = __float_as_uint(fabsf(rr.contr));
                 kr.o = rr.o; kr.layer = rr.layer; kr.r = rr.r; kr.c = rr.c; kr.bin = lane;
                 kr.ptx = (float)rr.c + rr.xc; kr.pty = (float)rr.r + rr.xr; kr.scl = rr.scl; kr.xi = rr.xi;
                 kr.angle = (360.0f / (float)ORI_BINS) * bf;
-                out[slot] = kr;
+                const unsigned slot = atomicAdd(&s_on, 1u);            // LDS counter; <= 18 peaks x 4 waves per trip
+                if (slot < OCAP) s_out[slot] = kr;
             }
         }
-        __builtin_amdgcn_wave_barrier();
+        __syncthreads();
+        // flush when the next trip (<= 4 x 18 peaks) might not fit, and after the last trip
+        const bool last = base + gridDim.x * 4 >= n;
+        if (s_on > OCAP - 72 || last) {
+            const unsigned cntl = s_on < OCAP ? s_on : OCAP;
+            if (tid == 0 && cntl) s_obase = atomicAdd(out_count, cntl);
+            __syncthreads();
+            for (unsigned i = tid; i < cntl; i += 256) {
+                const unsigned g = s_obase + i;
+                if (g < out_cap) { out[g] = s_out[i]; out_resp[g] = s_out[i].resp_bits; }
+            }
+            __syncthreads();
+            if (tid == 0) s_on = 0;
+            __syncthreads();
+        }
     }
 }
 
@@ -440,29 +494,47 @@ __device__ __forceinline__ unsigned long long tie_key(const KpRec& k) {
     return ((unsigned long long)k.o << 52) | ((unsigned long long)k.layer << 48) | ((unsigned long long)k.r << 28) | ((unsigned long long)k.c << 8) | (unsigned long long)k.bin;
 }
 
-__global__ __launch_bounds__(1024) void topk_kernel(const KpRec* kps, const unsigned* kp_count, unsigned kp_cap, int nfeatures,
+__global__ __launch_bounds__(1024) void topk_kernel(const KpRec* kps, const unsigned* resp, const unsigned* kp_count, unsigned kp_cap, int nfeatures,
                                                     mi355_keypoint* out_kp, SelRec* out_sel, int* out_n, int* overflow) {
     __shared__ unsigned s_hist[256];
     __shared__ unsigned s_misc[8];
     __shared__ unsigned long long s_k0[TOPK_CAP];      // ~resp_bits (descending response first)
     __shared__ unsigned long long s_k1[TOPK_CAP];      // tie key
     __shared__ unsigned s_idx[TOPK_CAP];
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63;
     unsigned N = *kp_count;
     if (N > kp_cap) { N = kp_cap; if (tid == 0) *overflow = 1; }
-    unsigned K = (unsigned)nfeatures;
+    const unsigned K = (unsigned)nfeatures;
     unsigned thresh = 0;                                // select everything with resp_bits >= thresh
     if (N > K) {
-        // radix select of the K-th largest resp_bits, MSB first
+        // radix select of the K-th largest resp_bits, MSB first; equal digits inside a wave are merged with
+        // ballots before touching the LDS histogram (responses share their exponent byte: one hot bin)
         unsigned prefix = 0, want = K;
+        const unsigned Nr = (N + 1023u) & ~1023u;
         for (int pass = 0; pass < 4; pass++) {
             const int shift = 24 - 8 * pass;
             for (int i = tid; i < 256; i += 1024) s_hist[i] = 0;
             __syncthreads();
             const unsigned himask = pass == 0 ? 0u : (0xffffffffu << (shift + 8));
-            for (unsigned i = tid; i < N; i += 1024) {
-                const unsigned v = kps[i].resp_bits;
-                if ((v & himask) == prefix) atomicAdd(&s_hist[(v >> shift) & 255], 1u);
+            for (unsigned i0 = tid; i0 < Nr; i0 += 8 * 1024) {
+                unsigned vv[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) { const unsigned i = i0 + 1024u * u; vv[u] = i < N ? resp[i] : 0u; }      // 8 loads in flight
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const unsigned i = i0 + 1024u * u;
+                    if (i0 + 1024u * u - tid >= Nr) break;                     // wave-uniform
+                    const unsigned v = vv[u];
+                    const bool valid = (i < N) && ((v & himask) == prefix);
+                    const unsigned d = (v >> shift) & 255u;
+                    unsigned long long peers = __ballot(valid);
+#pragma unroll
+                    for (int b = 0; b < 8; b++) {
+                        const unsigned long long m = __ballot(valid && ((d >> b) & 1u));
+                        peers &= ((d >> b) & 1u) ? m : ~m;
+                    }
+                    if (valid && (peers & ((1ull << lane) - 1ull)) == 0ull) atomicAdd(&s_hist[d], (unsigned)__popcll(peers));
+                }
             }
             __syncthreads();
             if (tid == 0) {
@@ -480,20 +552,29 @@ __global__ __launch_bounds__(1024) void topk_kernel(const KpRec* kps, const unsi
     if (tid == 0) s_misc[2] = 0;
     for (int i = tid; i < TOPK_CAP; i += 1024) { s_k0[i] = ~0ull; s_k1[i] = ~0ull; s_idx[i] = 0xffffffffu; }
     __syncthreads();
-    for (unsigned i = tid; i < N; i += 1024) {
-        const KpRec k = kps[i];
-        if (k.resp_bits >= thresh) {
-            const unsigned slot = atomicAdd(&s_misc[2], 1u);
-            if (slot < TOPK_CAP) { s_k0[slot] = (unsigned long long)(~k.resp_bits); s_k1[slot] = tie_key(k); s_idx[slot] = i; }
+    for (unsigned i0 = tid; i0 < N; i0 += 8 * 1024) {
+        unsigned vv[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) { const unsigned i = i0 + 1024u * u; vv[u] = i < N ? resp[i] : 0u; }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const unsigned i = i0 + 1024u * u;
+            if (i < N && vv[u] >= thresh) {
+                const KpRec k = kps[i];
+                const unsigned slot = atomicAdd(&s_misc[2], 1u);
+                if (slot < TOPK_CAP) { s_k0[slot] = (unsigned long long)(~k.resp_bits); s_k1[slot] = tie_key(k); s_idx[slot] = i; }
+            }
         }
     }
     __syncthreads();
     unsigned M = s_misc[2];
     if (M > TOPK_CAP) { M = TOPK_CAP; if (tid == 0) *overflow = 1; }
-    // bitonic sort of TOPK_CAP entries by (k0, k1)
-    for (int k = 2; k <= TOPK_CAP; k <<= 1) {
+    // bitonic sort by (k0, k1) of the smallest power of two >= M (padding keys are all-ones and stay last)
+    int SN = 64;
+    while ((unsigned)SN < M) SN <<= 1;
+    for (int k = 2; k <= SN; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = tid; i < TOPK_CAP; i += 1024) {
+            for (int i = tid; i < SN; i += 1024) {
                 const int ixj = i ^ j;
                 if (ixj > i) {
                     const unsigned long long a0 = s_k0[i], a1 = s_k1[i], b0 = s_k0[ixj], b1 = s_k1[ixj];
@@ -621,10 +702,10 @@ int gauss_kernel_host(double sigma, float* k) {
 }
 
 template <bool BGR>
-bool launch_blur(mi355_ctx* ctx, int R, const BlurArgs& a) {
-    const dim3 grid(a.tiles_x * a.tiles_y), block(256);
+bool launch_blur(hipStream_t st, int R, const BlurArgs& a) {
+    const dim3 grid(a.tiles_x * a.tiles_y), block(BT);
     switch (R) {
-#define CASE(RR) case RR: hipLaunchKernelGGL((blur_tile<RR, BGR>), grid, block, 0, ctx->stream, a); return true;
+#define CASE(RR) case RR: hipLaunchKernelGGL((blur_tile<RR, BGR>), grid, block, 0, st, a); return true;
         CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8) CASE(9) CASE(10) CASE(11) CASE(12) CASE(13) CASE(14) CASE(15) CASE(16)
 #undef CASE
         default: return false;
@@ -636,37 +717,77 @@ bool launch_blur(mi355_ctx* ctx, int R, const BlurArgs& a) {
 struct SiftWork {
     int w = 0, h = 0;                        // input frame size the buffers are sized for
     int n_oct = 0;
+    hipStream_t stream = nullptr;            // frames rotate over the slots; each slot is one in-order queue
     DevBuf pyr;                              // all Gaussian levels
     DevBuf claimed;                          // duplicate claim bitmaps
-    DevBuf cand, refined, kps, sel, counters;
+    DevBuf cand, refined, kps, kresp, sel, counters;
     PyrDev P;
     size_t claimed_bytes = 0;
     unsigned cand_cap = 0, ref_cap = 0, kp_cap = 0;
-    int* pinned = nullptr;                   // [0] n_kp, [1] overflow, [2..4] counters
     float kern[N_LEVELS][2 * MAX_R + 1];
     int radius[N_LEVELS];
     float kern0[2 * MAX_R + 1]; int radius0 = 0;
 };
 
+constexpr int SIFT_SLOTS = 3;                // frames in flight: small octaves / top-k of one frame overlap the big
+                                             // kernels of the next (each slot owns a ~5 GB work area at 12 MP)
+
 void mi_sift_release(mi355_ctx* ctx) {
-    SiftWork* s = ctx->sift;
-    if (!s) return;
-    s->pyr.release(); s->claimed.release(); s->cand.release(); s->refined.release(); s->kps.release(); s->sel.release(); s->counters.release();
-    if (s->pinned) (void)hipHostFree(s->pinned);
-    delete s;
-    ctx->sift = nullptr;
+    for (SiftWork* s : ctx->sift_slots) {
+        if (!s) continue;
+        if (s->stream) { (void)hipStreamSynchronize(s->stream); (void)hipStreamDestroy(s->stream); }
+        s->pyr.release(); s->claimed.release(); s->cand.release(); s->refined.release(); s->kps.release(); s->kresp.release(); s->sel.release(); s->counters.release();
+        delete s;
+    }
+    ctx->sift_slots.clear();
+    if (ctx->sift_in_ev) { (void)hipEventDestroy(ctx->sift_in_ev); ctx->sift_in_ev = nullptr; }
+    for (int* p : ctx->pinned_chunks) (void)hipHostFree(p);
+    ctx->pinned_chunks.clear();
+    ctx->pinned_used = 0;
 }
 
-static int sift_prepare(mi355_ctx* ctx, int w, int h) {
-    if (ctx->p.n_octave_layers != N_LAYERS || ctx->p.sigma != 1.6f) { ctx->set_error("sift: this build implements nOctaveLayers=3, sigma=1.6 (the reference's SIFT(2000,3,0.01,20))"); return MI355_ERR_ARG; }
-    if (ctx->p.nfeatures < 1 || ctx->p.nfeatures > 2048) { ctx->set_error("sift: nfeatures must be in [1,2048]"); return MI355_ERR_ARG; }
-    if (2 * (size_t)w >= (1u << 20) || 2 * (size_t)h >= (1u << 20)) { ctx->set_error("sift: image too large"); return MI355_ERR_ARG; }
-    if (!ctx->sift) {
-        ctx->sift = new SiftWork();
-        if (hipHostMalloc((void**)&ctx->sift->pinned, 64 * sizeof(int), hipHostMallocDefault) != hipSuccess) { ctx->set_error("sift: pinned alloc failed"); return MI355_ERR_NOMEM; }
+// waits for every in-flight frame and adopts the keypoint counts that landed in pinned memory
+int mi_resolve_features(mi355_ctx* ctx) {
+    bool any = false;
+    for (auto& kv : ctx->feats) if (kv.second.pending) { any = true; break; }
+    if (!any) return MI355_OK;
+    for (SiftWork* s : ctx->sift_slots) if (s && s->stream) MI_HIP(hipStreamSynchronize(s->stream));
+    int rc = MI355_OK;
+    for (auto& kv : ctx->feats) {
+        Features& f = kv.second;
+        if (!f.pending) continue;
+        f.pending = false;
+        const volatile int* c = f.h_cnt;
+        for (int i = 0; i < 8; i++) ctx->last_counts[i] = c[i];
+        if ((unsigned)c[0] > f.caps[0] || (unsigned)c[1] > f.caps[1] || (unsigned)c[2] > f.caps[2] || c[4]) {
+            ctx->set_error("sift: candidate buffer overflow (image " + std::to_string(kv.first) + " has more extrema than the buffers assume)");
+            f.n = 0; rc = MI355_ERR_FAILED;
+            continue;
+        }
+        f.n = c[3];
+    }
+    return rc;
+}
+
+static constexpr size_t PINNED_CHUNK = 4096;   // frames per pinned chunk
+
+static int* pinned_slot(mi355_ctx* ctx) {
+    const size_t chunk = ctx->pinned_used / PINNED_CHUNK, off = ctx->pinned_used % PINNED_CHUNK;
+    if (chunk >= ctx->pinned_chunks.size()) {
+        int* p = nullptr;
+        if (hipHostMalloc((void**)&p, PINNED_CHUNK * 8 * sizeof(int), hipHostMallocDefault) != hipSuccess) return nullptr;
+        ctx->pinned_chunks.push_back(p);
+    }
+    ctx->pinned_used++;
+    return ctx->pinned_chunks[chunk] + off * 8;
+}
+
+static int sift_prepare(mi355_ctx* ctx, SiftWork* s, int w, int h) {
+    if (s->w == w && s->h == h) return MI355_OK;
+    MI_HIP(hipStreamSynchronize(s->stream));
+    if (s->radius0 == 0) {
         // Gaussian kernels (double math on the host, like the oracle): sigma_i = sqrt((s k^i)^2 - (s k^(i-1))^2)
         const double sigma = 1.6, k = std::pow(2.0, 1.0 / N_LAYERS);
-        SiftWork* s = ctx->sift;
         for (int i = 1; i < N_LEVELS; i++) {
             const double sp = std::pow(k, (double)(i - 1)) * sigma, st = sp * k;
             s->radius[i] = gauss_kernel_host(std::sqrt(st * st - sp * sp), s->kern[i]);
@@ -674,9 +795,6 @@ static int sift_prepare(mi355_ctx* ctx, int w, int h) {
         const double sd = std::sqrt(sigma * sigma - 1.0 > 0.01 ? sigma * sigma - 1.0 : 0.01);
         s->radius0 = gauss_kernel_host(sd, s->kern0);
     }
-    SiftWork* s = ctx->sift;
-    if (s->w == w && s->h == h) return MI355_OK;
-    MI_HIP(hipStreamSynchronize(ctx->stream));
     const int W = 2 * w, H = 2 * h;
     int nOct = (int)lrint(std::log((double)(W < H ? W : H)) / std::log(2.0) - 2.0) + 1;
     if (nOct > MAX_OCT) nOct = MAX_OCT;
@@ -713,25 +831,47 @@ static int sift_prepare(mi355_ctx* ctx, int w, int h) {
     MI_HIP(s->cand.reserve((size_t)s->cand_cap * sizeof(unsigned long long)));
     MI_HIP(s->refined.reserve((size_t)s->ref_cap * sizeof(Refined)));
     MI_HIP(s->kps.reserve((size_t)s->kp_cap * sizeof(KpRec)));
+    MI_HIP(s->kresp.reserve((size_t)s->kp_cap * sizeof(unsigned)));
     MI_HIP(s->sel.reserve(2048 * sizeof(SelRec)));
     MI_HIP(s->counters.reserve(64 * sizeof(unsigned)));
     s->w = w; s->h = h;
     return MI355_OK;
 }
 
+// Enqueues detect+describe of one frame on the next slot stream and returns without waiting: the keypoint
+// count is adopted later by mi_resolve_features() (or right away when the caller asks for it through n_kp).
 int mi_sift_extract_dev(mi355_ctx* ctx, int img_id, const uint8_t* d_bgr, int w, int h, int ws, int* n_kp) {
-    int rc = sift_prepare(ctx, w, h);
+    if (ctx->p.n_octave_layers != N_LAYERS || ctx->p.sigma != 1.6f) { ctx->set_error("sift: this build implements nOctaveLayers=3, sigma=1.6 (the reference's SIFT(2000,3,0.01,20))"); return MI355_ERR_ARG; }
+    if (ctx->p.nfeatures < 1 || ctx->p.nfeatures > 2048) { ctx->set_error("sift: nfeatures must be in [1,2048]"); return MI355_ERR_ARG; }
+    if (2 * (size_t)w >= (1u << 20) || 2 * (size_t)h >= (1u << 20)) { ctx->set_error("sift: image too large"); return MI355_ERR_ARG; }
+    if (ctx->sift_slots.empty()) {
+        ctx->sift_slots.resize(SIFT_SLOTS, nullptr);
+        MI_HIP(hipEventCreateWithFlags(&ctx->sift_in_ev, hipEventDisableTiming));
+    }
+    const int slot = ctx->sift_next;
+    ctx->sift_next = (ctx->sift_next + 1) % SIFT_SLOTS;
+    if (!ctx->sift_slots[slot]) {
+        ctx->sift_slots[slot] = new SiftWork();
+        MI_HIP(hipStreamCreateWithFlags(&ctx->sift_slots[slot]->stream, hipStreamNonBlocking));
+    }
+    SiftWork* s = ctx->sift_slots[slot];
+    int rc = sift_prepare(ctx, s, w, h);
     if (rc != MI355_OK) return rc;
-    SiftWork* s = ctx->sift;
+    auto fit = ctx->feats.find(img_id);
+    if (fit != ctx->feats.end() && fit->second.pending) { rc = mi_resolve_features(ctx); if (rc != MI355_OK) return rc; }   // same id re-extracted while in flight
+    const hipStream_t st = s->stream;
     const int nf = ctx->p.nfeatures;
     Features& f = ctx->feats[img_id];
     f.w = w; f.h = h;
     MI_HIP(f.kp.reserve(sizeof(mi355_keypoint) * 2048));
     MI_HIP(f.d8.reserve(128 * 2048));
+    // the frame was produced on the caller's stream: order this slot after it
+    MI_HIP(hipEventRecord(ctx->sift_in_ev, ctx->stream));
+    MI_HIP(hipStreamWaitEvent(st, ctx->sift_in_ev, 0));
     unsigned* cnt = s->counters.as<unsigned>();      // [0] candidates [1] refined [2] keypoints [3] n_sel [4] overflow
-    MI_HIP(hipMemsetAsync(cnt, 0, 64 * sizeof(unsigned), ctx->stream));
-    MI_HIP(hipMemsetAsync(s->claimed.p, 0, s->claimed_bytes, ctx->stream));
-    MI_HIP(hipMemsetAsync(f.d8.p, 0, 128 * 2048, ctx->stream));
+    MI_HIP(hipMemsetAsync(cnt, 0, 64 * sizeof(unsigned), st));
+    MI_HIP(hipMemsetAsync(s->claimed.p, 0, s->claimed_bytes, st));
+    MI_HIP(hipMemsetAsync(f.d8.p, 0, 128 * 2048, st));
     // ---- pyramid ----
     for (int o = 0; o < s->n_oct; o++) {
         const OctaveDev& oc = s->P.oc[o];
@@ -742,53 +882,61 @@ int mi_sift_extract_dev(mi355_ctx* ctx, int img_id, const uint8_t* d_bgr, int w,
         if (o == 0) {
             a.bgr = d_bgr; a.bgr_ws = ws; a.dst = oc.lv[0];
             memcpy(a.k, s->kern0, sizeof(float) * (2 * s->radius0 + 1));
-            ProfScope ps(ctx, "gauss", level_bytes + (double)w * h * 3.0);          // read the u8 frame, write level 0
-            if (!launch_blur<true>(ctx, s->radius0, a)) { ctx->set_error("sift: unsupported kernel radius"); return MI355_ERR_FAILED; }
+            ProfScope ps(ctx, "gauss", level_bytes + (double)w * h * 3.0, st);      // read the u8 frame, write level 0
+            if (!launch_blur<true>(st, s->radius0, a)) { ctx->set_error("sift: unsupported kernel radius"); return MI355_ERR_FAILED; }
         } else {
             const OctaveDev& pv = s->P.oc[o - 1];
-            ProfScope ps(ctx, "downsample", level_bytes * 2.0);
-            hipLaunchKernelGGL(downsample2, dim3((oc.w + 63) / 64, (oc.h + 3) / 4), dim3(256), 0, ctx->stream, pv.lv[N_LAYERS], pv.w, oc.lv[0], oc.w, oc.h);
+            ProfScope ps(ctx, "downsample", level_bytes * 2.0, st);
+            hipLaunchKernelGGL(downsample2, dim3((oc.w + 63) / 64, (oc.h + 3) / 4), dim3(256), 0, st, pv.lv[N_LAYERS], pv.w, oc.lv[0], oc.w, oc.h);
         }
         for (int i = 1; i < N_LEVELS; i++) {
             a.bgr = nullptr; a.src = oc.lv[i - 1]; a.dst = oc.lv[i];
             memcpy(a.k, s->kern[i], sizeof(float) * (2 * s->radius[i] + 1));
-            ProfScope ps(ctx, "gauss", level_bytes * 2.0);                            // one read + one write of the level
-            if (!launch_blur<false>(ctx, s->radius[i], a)) { ctx->set_error("sift: unsupported kernel radius"); return MI355_ERR_FAILED; }
+            ProfScope ps(ctx, "gauss", level_bytes * 2.0, st);                        // one read + one write of the level
+            if (!launch_blur<false>(st, s->radius[i], a)) { ctx->set_error("sift: unsupported kernel radius"); return MI355_ERR_FAILED; }
         }
         {
-            ProfScope ps(ctx, "extrema", level_bytes * 6.0);
-            hipLaunchKernelGGL(extrema_kernel, dim3((oc.w + EW - 1) / EW, (oc.h + EH - 1) / EH), dim3(256), 0, ctx->stream,
+            ProfScope ps(ctx, "extrema", level_bytes * 6.0, st);
+            hipLaunchKernelGGL(extrema_kernel, dim3((oc.w + EW - 1) / EW, (oc.h + EH - 1) / EH), dim3(256), 0, st,
                                oc, o, s->cand.as<unsigned long long>(), cnt + 0, s->cand_cap);
         }
     }
     {
-        ProfScope ps(ctx, "refine", 0.0);
-        hipLaunchKernelGGL(refine_kernel, dim3(ctx->num_cu * 8), dim3(256), 0, ctx->stream, s->P, s->cand.as<unsigned long long>(), cnt + 0, s->cand_cap,
+        ProfScope ps(ctx, "refine", 0.0, st);
+        hipLaunchKernelGGL(refine_kernel, dim3(ctx->num_cu * 8), dim3(256), 0, st, s->P, s->cand.as<unsigned long long>(), cnt + 0, s->cand_cap,
                            ctx->p.contrast_threshold, ctx->p.edge_threshold, 1.6f, s->refined.as<Refined>(), cnt + 1, s->ref_cap);
     }
     {
-        ProfScope ps(ctx, "orient", 0.0);
-        hipLaunchKernelGGL(orient_kernel, dim3(ctx->num_cu * 4), dim3(256), 0, ctx->stream, s->P, s->refined.as<Refined>(), cnt + 1, s->ref_cap,
-                           s->kps.as<KpRec>(), cnt + 2, s->kp_cap);
+        ProfScope ps(ctx, "orient", 0.0, st);
+        hipLaunchKernelGGL(orient_kernel, dim3(ctx->num_cu * 4), dim3(256), 0, st, s->P, s->refined.as<Refined>(), cnt + 1, s->ref_cap,
+                           s->kps.as<KpRec>(), s->kresp.as<unsigned>(), cnt + 2, s->kp_cap);
     }
     {
-        ProfScope ps(ctx, "topk", 0.0);
-        hipLaunchKernelGGL(topk_kernel, dim3(1), dim3(1024), 0, ctx->stream, s->kps.as<KpRec>(), cnt + 2, s->kp_cap, nf,
+        ProfScope ps(ctx, "topk", 0.0, st);
+        hipLaunchKernelGGL(topk_kernel, dim3(1), dim3(1024), 0, st, s->kps.as<KpRec>(), s->kresp.as<unsigned>(), cnt + 2, s->kp_cap, nf,
                            f.kp.as<mi355_keypoint>(), s->sel.as<SelRec>(), reinterpret_cast<int*>(cnt + 3), reinterpret_cast<int*>(cnt + 4));
     }
     {
-        ProfScope ps(ctx, "describe", 0.0);
-        hipLaunchKernelGGL(describe_kernel, dim3(nf), dim3(256), 0, ctx->stream, s->P, s->sel.as<SelRec>(), reinterpret_cast<const int*>(cnt + 3), f.d8.as<uint8_t>());
+        ProfScope ps(ctx, "describe", 0.0, st);
+        hipLaunchKernelGGL(describe_kernel, dim3(nf), dim3(256), 0, st, s->P, s->sel.as<SelRec>(), reinterpret_cast<const int*>(cnt + 3), f.d8.as<uint8_t>());
     }
     MI_HIP(hipGetLastError());
-    // keypoint count: needed on the host to size the match launch.  One 20-byte read-back per frame.
-    MI_HIP(hipMemcpyAsync(s->pinned, cnt, 8 * sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
-    MI_HIP(hipStreamSynchronize(ctx->stream));
-    if ((unsigned)s->pinned[0] > s->cand_cap || (unsigned)s->pinned[1] > s->ref_cap || (unsigned)s->pinned[2] > s->kp_cap || s->pinned[4]) {
-        ctx->set_error("sift: candidate buffer overflow (image with more DoG extrema than the buffers assume)");
-        return MI355_ERR_FAILED;
+    rc = mi_finish_features(ctx, f, reinterpret_cast<const int*>(cnt + 3), st);
+    if (rc != MI355_OK) return rc;
+    int* hc = pinned_slot(ctx);
+    if (!hc) { ctx->set_error("sift: pinned alloc failed"); return MI355_ERR_NOMEM; }
+    MI_HIP(hipMemcpyAsync(hc, cnt, 8 * sizeof(unsigned), hipMemcpyDeviceToHost, st));
+    f.h_cnt = hc; f.pending = true; f.n = 0;
+    f.caps[0] = s->cand_cap; f.caps[1] = s->ref_cap; f.caps[2] = s->kp_cap;
+    if (ctx->pinned_used >= PINNED_CHUNK * 64) {           // recycle the pinned pool when nothing is pending any more
+        rc = mi_resolve_features(ctx);
+        if (rc != MI355_OK) return rc;
+        ctx->pinned_used = 0;
     }
-    f.n = s->pinned[3];
-    if (n_kp) *n_kp = f.n;
-    return mi_finish_features(ctx, f);
+    if (n_kp) {
+        rc = mi_resolve_features(ctx);
+        if (rc != MI355_OK) return rc;
+        *n_kp = f.n;
+    }
+    return MI355_OK;
 }

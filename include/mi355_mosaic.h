@@ -72,7 +72,7 @@ typedef struct {
     float   edge_threshold;    /* 20 */
     float   sigma;             /* 1.6    cv::SIFT default */
     int32_t max_selected;      /* 400    maxNum                           MosaicWithoutPos.cpp:5146 */
-    float   select_fraction;   /* 0.3                                     MosaicWithoutPos.cpp:5147 */
+    double  select_fraction;   /* 0.3 (double literal: Min(400, 0.3*M))   MosaicWithoutPos.cpp:5147 */
     int32_t grid_x, grid_y;    /* 3,3                                     MosaicWithoutPos.cpp:5041-5042 */
     int32_t min_inliers;       /* 30     MIN_INNER_POINTS                 MosaicWithoutPos.cpp:5049 */
     float   ransac_dist;       /* 2.5    UavMatchParam.ransacDist         MosaicWithoutPos.h:74 */
@@ -192,6 +192,9 @@ int  mi355_pair_schedule(int n_images, int window, int rank, int world, int32_t*
 /* ---- measurement hooks (bench.py) ----------------------------------------------------------------------- */
 /* When enabled, every launch of the named kernel class is bracketed by hipEvents on the ctx stream. */
 int  mi355_profile_enable(mi355_ctx* ctx, int on);
+/* SIFT stage populations of the last extracted frame: [0] DoG extrema, [1] refined points, [2] oriented keypoints,
+ * [3] kept (<= nfeatures), [4] overflow flag */
+int  mi355_last_sift_counters(mi355_ctx* ctx, int32_t out8[8]);
 int  mi355_profile_reset(mi355_ctx* ctx);
 int  mi355_profile_only(mi355_ctx* ctx, const char* kernel_class /* NULL or "" = every class */);
 /* class: "gauss", "extrema", "orient", "describe", "match", "select", "ransac", "warp", "gray" ...

@@ -31,11 +31,10 @@
  *     with one fused multiply-add per tap (fmaf), row pass then column pass;
  *   - exp / atan2 / sin / cos are the fixed polynomial approximations below (OpenCV also uses
  *     approximations there: cv::exp, fastAtan2), evaluated with fmaf in a fixed order;
- *   - the orientation histogram accumulates in raster order of the sample window (row by row, as the
- *     loops are written below), every contribution added separately;
- *   - the descriptor histogram is accumulated ORDER-FREE: every trilinear contribution v is quantised to
- *     q = rint(v * 2^20) and summed as a 64-bit integer; the bin value is (float)sum * 2^-20 (resolution
- *     ~1e-6 of a grey level, far below the u8 quantisation of the descriptor);
+ *   - both histograms (36-bin orientation, 4x4x8 descriptor) are accumulated ORDER-FREE: every contribution
+ *     v is quantised to q = rint(v * 2^20) and summed as a 64-bit integer; the bin value is
+ *     (float)sum * 2^-20 (resolution ~1e-6 of a grey level, far below the u8 quantisation of the
+ *     descriptor and the 0.8 peak ratio of the orientation histogram);
  *   - the 3x3 solve is Gaussian elimination with partial pivoting (first largest pivot);
  *   - keypoints are ordered by (response descending, octave, layer, row, column, orientation bin) and
  *     that is also the output order; duplicates = same (octave, layer, row, column, bin).
@@ -415,7 +414,8 @@ int orc_sift(const uint8_t* bgr, int w, int h, int ws, int nfeatures, orc_keypoi
                     float osig = 1.5f * scl;
                     float expf_scale = -1.0f / (2.0f * osig * osig);
                     float th[ORI_BINS], hs[ORI_BINS];
-                    for (int b = 0; b < ORI_BINS; b++) th[b] = 0.0f;
+                    int64_t tq[ORI_BINS];
+                    for (int b = 0; b < ORI_BINS; b++) tq[b] = 0;
                     for (int i = -radius; i <= radius; i++) {
                         int y = R + i;
                         if (y <= 0 || y >= O->h - 1) continue;
@@ -431,9 +431,10 @@ int orc_sift(const uint8_t* bgr, int w, int h, int ws, int nfeatures, orc_keypoi
                             if (bin >= ORI_BINS) bin -= ORI_BINS;
                             if (bin < 0) bin += ORI_BINS;
                             float t = wgt * mag;
-                            th[bin] = th[bin] + t;
+                            tq[bin] += (int64_t)llrintf(t * 1048576.0f);
                         }
                     }
+                    for (int b = 0; b < ORI_BINS; b++) th[b] = (float)tq[b] * (1.0f / 1048576.0f);
                     float omax = 0.0f;
                     for (int b = 0; b < ORI_BINS; b++) {
                         float m2 = th[(b + ORI_BINS - 2) % ORI_BINS], m1 = th[(b + ORI_BINS - 1) % ORI_BINS];
