@@ -130,6 +130,7 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     import imagemosaicing_amd as im
+    from imagemosaicing_amd import dist as md
     ctx = im.Context(local_rank)
     # One explicit stream for everything (HIP kernels of the library, torch copies, RCCL): torch's default stream
     # is the NULL stream, which the library's set_stream treats as "use the ctx-owned stream".
@@ -150,7 +151,6 @@ def main():
     pairs = im.pair_schedule(F, args.window)
     n_pairs = len(pairs)
     results = torch.zeros((max(n_pairs, 1), im.PAIR_RESULT.itemsize), dtype=torch.uint8, device=dev)
-    gathered = torch.zeros((world * max(n_pairs, 1), im.PAIR_RESULT.itemsize), dtype=torch.uint8, device=dev) if world > 1 else None
     res_host = torch.empty((max(n_pairs, 1), im.PAIR_RESULT.itemsize), dtype=torch.uint8).pin_memory()
     # canvas big enough for the ground-truth layout with margin (the step computes the real layout)
     Hgt = np.stack([(np.linalg.inv(affine3(A[0])) @ affine3(A[k])).reshape(9) for k in range(F)]).astype(np.float32)
@@ -165,7 +165,8 @@ def main():
             ctx.SiftExtractDev(k, fptr[k], w, h, ws)
         ctx.MatchPairsDev(pairs, results.data_ptr(), 2.5, seed)
         if world > 1:
-            dist.all_gather_into_tensor(gathered, results)          # RCCL over xGMI: H + inliers of every pair of the survey
+            # RCCL over xGMI: H + inlier lists of every pair of the survey, the only exchange of the path
+            state["gathered"], state["counts"] = md.allgather_pair_results(results[:max(n_pairs, 1)])
         res_host.copy_(results, non_blocking=True)
         stream.synchronize()
         r = res_host.numpy().view(im.PAIR_RESULT).reshape(-1)[:n_pairs]

@@ -113,3 +113,13 @@ def test_results_to_match_pairs(im):
     v = im.results_to_match_pairs(r, fixed_flags=[1, 0, 0])
     assert len(v) == 75 and (v["ai"][:40] == 0).all() and (v["af"][:40] == 1).all() and (v["bi"][40:] == 2).all()
     assert np.array_equal(v["ax"][:40], np.arange(40, dtype=np.float32)) and np.array_equal(v["bid"][40:], np.arange(35))
+
+
+def test_adaptor_header_compiles_as_cxx(tmp_path):
+    """include/mi355_adaptor.h (the reference's own signatures over the C ABI) is valid stand-alone C++"""
+    import subprocess
+    src = tmp_path / "t.cpp"
+    src.write_text('#include "mi355_adaptor.h"\nint main() { std::vector<mi355ref::SfPoint> a, b, c, d; float H[9];'
+                   ' return mi355::Ransac2D(a, b, c, d, H, 2.5f) ? 1 : 0; }\n')
+    r = subprocess.run(["g++", "-std=c++11", "-fsyntax-only", "-I", os.path.join(ROOT, "include"), str(src)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
