@@ -150,7 +150,12 @@ class Context:
         k = min(n.value, max_kp)
         return kp[:k].copy(), desc[:k].copy()
 
-    def SiftExtractDev(self, img_id, d_bgr, w, h, ws):
+    def SiftExtractDev(self, img_id, d_bgr, w, h, ws, want_count=False):
+        """Asynchronous unless want_count: the frame is enqueued on one of the library's SIFT streams and the call
+        returns; the keypoint count is adopted at the next MatchPairs / GetFeatures / synchronize."""
+        if not want_count:
+            self._chk(self.L.mi355_sift_extract_dev(self._h, int(img_id), C.c_void_p(int(d_bgr)), int(w), int(h), int(ws), None))
+            return None
         n = C.c_int(0)
         self._chk(self.L.mi355_sift_extract_dev(self._h, int(img_id), C.c_void_p(int(d_bgr)), int(w), int(h), int(ws), C.byref(n)))
         return n.value

@@ -78,7 +78,8 @@ struct mi355_ctx {
     std::map<std::string, ProfClass> prof;
     std::vector<SiftWork*> sift_slots;                 // one work area + stream per in-flight frame
     int sift_next = 0;
-    hipEvent_t sift_in_ev = nullptr;                   // orders a slot stream after the caller's stream
+    hipEvent_t sift_in_ev = nullptr;                   // orders the SIFT streams after the caller's stream
+    hipStream_t sift_heavy = nullptr;                  // stage A (pyramid + extrema) of every frame, in order
     std::vector<int*> pinned_chunks;                   // pinned count slots, 8 ints per frame
     size_t pinned_used = 0;
     int num_cu = 256;

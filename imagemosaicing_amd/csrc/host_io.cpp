@@ -177,22 +177,33 @@ extern "C" int mi355_global_affine_align(const mi355_match_point_pairs* v, int n
             bx[3 * o + 0] = 1.0; by[3 * o + 1] = 1.0;
         }
     }
-    // dense Cholesky N = L L^T (lower), in place
+    // Cholesky N = L L^T (lower), in place, restricted to the band of the image graph: with the free images in index
+    // order, N(i,j) != 0 only for |block(i) - block(j)| <= max |a - b| over the pairs (adjacent-pair strips: 1 block;
+    // the reference's window: 181 blocks), and the factor keeps that band.
+    int bwb = 0;
+    for (int p = 0; p < n; p++) {
+        const int oa = col[v[p].ptA_i], ob = col[v[p].ptB_i];
+        if (oa >= 0 && ob >= 0) { const int d = oa > ob ? oa - ob : ob - oa; if (d > bwb) bwb = d; }
+    }
+    const int bw = 3 * bwb + 2;                      // half bandwidth in scalar rows
     for (int j = 0; j < D; j++) {
+        const int k0 = j - bw > 0 ? j - bw : 0;
         double d = N[(size_t)j * D + j];
-        for (int k = 0; k < j; k++) d -= N[(size_t)j * D + k] * N[(size_t)j * D + k];
+        for (int k = k0; k < j; k++) d -= N[(size_t)j * D + k] * N[(size_t)j * D + k];
         if (!(d > 0.0)) return MI355_ERR_FAILED;
         d = std::sqrt(d);
         N[(size_t)j * D + j] = d;
-        for (int i = j + 1; i < D; i++) {
+        const int i1 = j + bw < D - 1 ? j + bw : D - 1;
+        for (int i = j + 1; i <= i1; i++) {
+            const int kk0 = i - bw > k0 ? i - bw : k0;
             double s = N[(size_t)i * D + j];
-            for (int k = 0; k < j; k++) s -= N[(size_t)i * D + k] * N[(size_t)j * D + k];
+            for (int k = kk0; k < j; k++) s -= N[(size_t)i * D + k] * N[(size_t)j * D + k];
             N[(size_t)i * D + j] = s / d;
         }
     }
     auto solve = [&](std::vector<double>& b) {
-        for (int i = 0; i < D; i++) { double s = b[i]; for (int k = 0; k < i; k++) s -= N[(size_t)i * D + k] * b[k]; b[i] = s / N[(size_t)i * D + i]; }
-        for (int i = D - 1; i >= 0; i--) { double s = b[i]; for (int k = i + 1; k < D; k++) s -= N[(size_t)k * D + i] * b[k]; b[i] = s / N[(size_t)i * D + i]; }
+        for (int i = 0; i < D; i++) { const int k0 = i - bw > 0 ? i - bw : 0; double s = b[i]; for (int k = k0; k < i; k++) s -= N[(size_t)i * D + k] * b[k]; b[i] = s / N[(size_t)i * D + i]; }
+        for (int i = D - 1; i >= 0; i--) { const int k1 = i + bw < D - 1 ? i + bw : D - 1; double s = b[i]; for (int k = i + 1; k <= k1; k++) s -= N[(size_t)k * D + i] * b[k]; b[i] = s / N[(size_t)i * D + i]; }
     };
     solve(bx); solve(by);
     for (int k = 0; k < n_images; k++) {

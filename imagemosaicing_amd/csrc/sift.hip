@@ -26,11 +26,21 @@
 //                         64-bit LDS atomics (order-free by definition), normalise / clip / renormalise -> u8
 #include "common.h"
 #include <cmath>
+#include <chrono>
 
 namespace {
 
 constexpr int N_LAYERS = 3, N_LEVELS = 6, IMG_BORDER = 5, MAX_INTERP = 5, ORI_BINS = 36, MAX_OCT = 16;
-constexpr int TW = 64, TH = 64;                 // blur tile
+#ifndef BLUR_TW
+#define BLUR_TW 64
+#endif
+#ifndef BLUR_TH
+#define BLUR_TH 64
+#endif
+#ifndef BLUR_BT
+#define BLUR_BT 512
+#endif
+constexpr int TW = BLUR_TW, TH = BLUR_TH;       // blur tile
 constexpr int MAX_R = 16;
 
 // ---------- fixed transcendental approximations (same definition as oracle/oracle_sift.c) -------------------
@@ -129,7 +139,10 @@ __device__ __forceinline__ int xcd_remap(int bid, int nb) {
     return base + local;
 }
 
-constexpr int BT = 512;                        // threads per blur workgroup (8 waves share one staged tile)
+#ifndef BLUR_PERSIST_BLOCKS
+#define BLUR_PERSIST_BLOCKS 512
+#endif
+constexpr int BT = BLUR_BT;                    // threads per blur workgroup (8 waves share one staged tile)
 template <int R, bool BGR>
 __global__ __launch_bounds__(BT) void blur_tile(BlurArgs a) {
     constexpr int ROWS = TH + 2 * R;           // rows of the staged tile
@@ -200,6 +213,124 @@ __global__ __launch_bounds__(BT) void blur_tile(BlurArgs a) {
             if (gy + 2 < a.h) d[2 * (size_t)a.w] = acc2;
             if (gy + 3 < a.h) d[3 * (size_t)a.w] = acc3;
         }
+    }
+}
+
+// ---- blur_tile2: the production variant -------------------------------------------------------------------------
+// Same arithmetic as blur_tile (per output: acc = 0; acc = fmaf(k[i], x[i], acc) for ascending i), restructured for
+// the CDNA4 issue limits: 128-bit LDS reads/writes, two FMAs per instruction (v_pk_fma_f32 through 2-wide vector
+// fma), and a 4x4 output block per lane in the column pass.  The staged tile starts at a 4-float aligned column
+// (halo RA = R rounded up to 4) so that global loads, LDS rows and the sliding windows are all 16-byte aligned.
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+template <int R, bool BGR>
+__global__ __launch_bounds__(256) void blur_tile2(BlurArgs a) {
+    constexpr int RA = (R + 3) & ~3;            // aligned halo
+    constexpr int S = RA - R;                   // first tap of output 0 inside the aligned window
+    constexpr int ROWS = 64 + 2 * R;
+    constexpr int COLS = 64 + 2 * RA;           // multiple of 4
+    constexpr int C4 = COLS / 4;
+    constexpr int NG = (S + 2 * R + 4 + 3) / 4; // float4 groups read per row-pass item
+    constexpr int PMID = 64 + 4;                // mid pitch (floats), multiple of 4
+    constexpr int NPF = (ROWS * C4 + 255) / 256; // float4 loads per lane to stage one tile
+    __shared__ v4f s_in4[ROWS * C4];
+    __shared__ v4f s_mid4[ROWS * (PMID / 4)];
+    float* s_in = reinterpret_cast<float*>(s_in4);
+    const int tid = threadIdx.x;
+    const int ntiles = a.tiles_x * a.tiles_y;
+    const bool vec_ok = !BGR && ((a.w & 3) == 0) && ((reinterpret_cast<uintptr_t>(a.src) & 15) == 0);
+    const bool vec_st = ((a.w & 3) == 0) && ((reinterpret_cast<uintptr_t>(a.dst) & 15) == 0);
+
+    // Persistent workgroups walk the tile list; the global loads of tile t+1 are issued into registers before the two
+    // passes of tile t run (their latency hides under ~1000 VALU instructions), and land in LDS after the passes.
+    v4f pf[NPF];
+    auto tile_origin = [&](int t, int& x0, int& y0) {
+        const int tile = xcd_remap(t, ntiles);
+        const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
+        x0 = tx * 64; y0 = ty * 64;
+    };
+    auto is_interior = [&](int x0, int y0) { return vec_ok && (x0 - RA >= 0) && (y0 - R >= 0) && (x0 + 64 + RA <= a.w) && (y0 + 64 + R <= a.h); };
+    auto prefetch = [&](int x0, int y0) {
+        const float* base = a.src + (size_t)(y0 - R) * a.w + (x0 - RA);
+#pragma unroll
+        for (int u = 0; u < NPF; u++) {
+            const int idx = tid + 256 * u;
+            if (idx < ROWS * C4) { const int ry = idx / C4, c4 = idx - ry * C4; pf[u] = *reinterpret_cast<const v4f*>(base + (size_t)ry * a.w + 4 * c4); }
+        }
+    };
+    int t = blockIdx.x;
+    int x0 = 0, y0 = 0;
+    bool cur_pf = false;
+    if (t < ntiles) { tile_origin(t, x0, y0); cur_pf = is_interior(x0, y0); if (cur_pf) prefetch(x0, y0); }
+    for (; t < ntiles; t += gridDim.x) {
+        // stage the current tile
+        if (cur_pf) {
+#pragma unroll
+            for (int u = 0; u < NPF; u++) { const int idx = tid + 256 * u; if (idx < ROWS * C4) s_in4[idx] = pf[u]; }
+        } else {
+            for (int idx = tid; idx < ROWS * COLS; idx += 256) {
+                const int ry = idx / COLS, rx = idx - ry * COLS;
+                const int gy = reflect101(y0 - R + ry, a.h), gx = reflect101(x0 - RA + rx, a.w);
+                float v;
+                if (BGR) v = load_base(a.bgr, a.bgr_ws, a.w >> 1, a.h >> 1, gx, gy);
+                else v = a.src[(size_t)gy * a.w + gx];
+                s_in[idx] = v;
+            }
+        }
+        __syncthreads();
+        // issue the next tile's loads
+        const int tn = t + gridDim.x;
+        int nx0 = 0, ny0 = 0; bool next_pf = false;
+        if (tn < ntiles) { tile_origin(tn, nx0, ny0); next_pf = is_interior(nx0, ny0); if (next_pf) prefetch(nx0, ny0); }
+        // row pass: item = 4 adjacent outputs of one staged row; lanes walk the 16 groups of a row (contiguous 16 B slots)
+        for (int item = tid; item < ROWS * 16; item += 256) {
+            const int row = item >> 4, xg = item & 15;
+            const v4f* in4 = s_in4 + row * C4 + xg;
+            float e[NG * 4];
+#pragma unroll
+            for (int g = 0; g < NG; g++) { const v4f tt = in4[g]; e[4 * g] = tt.x; e[4 * g + 1] = tt.y; e[4 * g + 2] = tt.z; e[4 * g + 3] = tt.w; }
+            v2f acc01 = {0.0f, 0.0f}, acc23 = {0.0f, 0.0f};
+#pragma unroll
+            for (int i = 0; i <= 2 * R; i++) {
+                const v2f kk = {a.k[i], a.k[i]};
+                const v2f e01 = {e[S + i], e[S + i + 1]}, e23 = {e[S + i + 2], e[S + i + 3]};
+                acc01 = __builtin_elementwise_fma(kk, e01, acc01);
+                acc23 = __builtin_elementwise_fma(kk, e23, acc23);
+            }
+            v4f o; o.x = acc01.x; o.y = acc01.y; o.z = acc23.x; o.w = acc23.y;
+            s_mid4[row * (PMID / 4) + xg] = o;
+        }
+        __syncthreads();
+        // column pass: one item per lane = 4 columns x 4 rows of outputs
+        {
+            const int xg = tid & 15, yg = tid >> 4;
+            const v4f* mid4 = s_mid4 + (4 * yg) * (PMID / 4) + xg;
+            v4f acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0}, acc2 = {0, 0, 0, 0}, acc3 = {0, 0, 0, 0};
+#pragma unroll
+            for (int m = 0; m < 2 * R + 4; m++) {
+                const v4f e = mid4[m * (PMID / 4)];
+                if (m <= 2 * R) { const v4f kk = {a.k[m], a.k[m], a.k[m], a.k[m]}; acc0 = __builtin_elementwise_fma(kk, e, acc0); }
+                if (m >= 1 && m - 1 <= 2 * R) { const v4f kk = {a.k[m - 1], a.k[m - 1], a.k[m - 1], a.k[m - 1]}; acc1 = __builtin_elementwise_fma(kk, e, acc1); }
+                if (m >= 2 && m - 2 <= 2 * R) { const v4f kk = {a.k[m - 2], a.k[m - 2], a.k[m - 2], a.k[m - 2]}; acc2 = __builtin_elementwise_fma(kk, e, acc2); }
+                if (m >= 3) { const v4f kk = {a.k[m - 3], a.k[m - 3], a.k[m - 3], a.k[m - 3]}; acc3 = __builtin_elementwise_fma(kk, e, acc3); }
+            }
+            const int gx = x0 + 4 * xg, gy = y0 + 4 * yg;
+            if (gx + 3 < a.w && vec_st) {
+                float* d = a.dst + (size_t)gy * a.w + gx;
+                if (gy < a.h) *reinterpret_cast<v4f*>(d) = acc0;
+                if (gy + 1 < a.h) *reinterpret_cast<v4f*>(d + (size_t)a.w) = acc1;
+                if (gy + 2 < a.h) *reinterpret_cast<v4f*>(d + 2 * (size_t)a.w) = acc2;
+                if (gy + 3 < a.h) *reinterpret_cast<v4f*>(d + 3 * (size_t)a.w) = acc3;
+            } else {
+                const v4f accs[4] = {acc0, acc1, acc2, acc3};
+                for (int r = 0; r < 4; r++)
+                    for (int c = 0; c < 4; c++)
+                        if (gy + r < a.h && gx + c < a.w) a.dst[(size_t)(gy + r) * a.w + gx + c] = accs[r][c];
+            }
+        }
+        __syncthreads();                        // s_in / s_mid are rewritten by the next trip
+        x0 = nx0; y0 = ny0; cur_pf = next_pf;
     }
 }
 
@@ -315,7 +446,7 @@ __device__ void solve3(float A[3][3], float b[3], float x[3]) {
 
 __global__ __launch_bounds__(256) void refine_kernel(PyrDev P, const unsigned long long* cand, const unsigned* cand_count, unsigned cand_cap,
                                                      float contrast_thr, float edge_thr, float sigma,
-                                                     Refined* out, unsigned* out_count, unsigned out_cap) {
+                                                     Refined* out, unsigned* out_count, unsigned out_cap, unsigned* resp_hist) {
     unsigned n = *cand_count;
     if (n > cand_cap) n = cand_cap;
     const float img_scale = 1.0f / 255.0f;
@@ -374,6 +505,8 @@ __global__ __launch_bounds__(256) void refine_kernel(PyrDev P, const unsigned lo
             rr.o = o; rr.layer = L; rr.r = R; rr.c = C; rr.xi = xi; rr.xr = xr; rr.xc = xc; rr.contr = contr;
             rr.scl = sigma * det_exp2f(((float)L + xi) / (float)N_LAYERS);
             out[slot] = rr;
+            atomicAdd(&resp_hist[(__float_as_uint(fabsf(contr)) >> 15) & 0xffffu], 1u);     // 8 exponent + 8 mantissa bits, result unused
+
         }
     }
 }
@@ -384,10 +517,46 @@ struct KpRec {
     float ptx, pty, scl, angle, xi;
 };
 
+// Only the nfeatures strongest keypoints survive, and the response is known before the orientation: a 65536-bin
+// histogram of the response bits (filled by refine_kernel) gives a threshold T such that at least `want` refined
+// points have response >= T.  Pass 0 orients those; if that turns out to yield fewer than nfeatures keypoints
+// (points without any histogram peak), top-k raises a flag and pass 1 orients the rest -- same final result as
+// orienting everything, ~40x less work in the common case.
+__global__ __launch_bounds__(1024) void resp_threshold_kernel(const unsigned* hist, const unsigned* ref_count, unsigned want, unsigned* ctrl /* [0]=T bits [1]=fallback flag */) {
+    __shared__ unsigned s_part[1024];
+    const int tid = threadIdx.x;
+    unsigned local[64], sum = 0;
+#pragma unroll
+    for (int u = 0; u < 64; u++) { local[u] = hist[tid * 64 + u]; sum += local[u]; }     // lane owns bins [64 tid, 64 tid + 64)
+    s_part[tid] = sum;
+    __syncthreads();
+    if (tid == 0) {
+        unsigned T = 0;
+        if (*ref_count > want) {
+            unsigned cum = 0; int b = 1023;
+            for (; b >= 0; b--) { if (cum + s_part[b] >= want) break; cum += s_part[b]; }
+            if (b < 0) b = 0;
+            s_part[0] = (unsigned)b; s_part[1] = cum;
+            T = 1;
+        }
+        ctrl[0] = T; ctrl[1] = 0;
+    }
+    __syncthreads();
+    if (ctrl[0] == 1 && (unsigned)tid == s_part[0]) {          // the owner of the crossing group refines to one bin
+        unsigned cum = s_part[1]; int u = 63;
+        for (; u >= 0; u--) { if (cum + local[u] >= want) break; cum += local[u]; }
+        if (u < 0) u = 0;
+        ctrl[0] = ((unsigned)(tid * 64 + u)) << 15;              // lower edge of that bin: everything >= T is oriented
+    }
+}
+
 constexpr int OCAP = 256;                     // emitted keypoints buffered per workgroup between flushes
 __global__ __launch_bounds__(256) void orient_kernel(PyrDev P, const Refined* ref, const unsigned* ref_count, unsigned ref_cap,
-                                                     KpRec* out, unsigned* out_resp, unsigned* out_count, unsigned out_cap) {
+                                                     KpRec* out, unsigned* out_resp, unsigned* out_count, unsigned out_cap,
+                                                     const unsigned* ctrl, int pass) {
     __shared__ unsigned long long s_hq[4][ORI_BINS];
+    const unsigned Tbits = ctrl[0];
+    if (pass == 1 && (ctrl[1] == 0 || Tbits == 0)) return;      // fallback pass not needed
     __shared__ float s_hist[4][ORI_BINS + 4];
     __shared__ KpRec s_out[OCAP];             // one global atomic per flush instead of one per keypoint
     __shared__ unsigned s_on, s_obase;
@@ -398,7 +567,12 @@ __global__ __launch_bounds__(256) void orient_kernel(PyrDev P, const Refined* re
     __syncthreads();
     for (unsigned base = blockIdx.x * 4; base < n; base += gridDim.x * 4) {        // uniform trip count per workgroup
         const unsigned k = base + wv;
+        bool take = false;
         if (k < n) {
+            const unsigned rb = __float_as_uint(fabsf(ref[k].contr));
+            take = pass == 0 ? (rb >= Tbits) : (rb < Tbits);
+        }
+        if (take) {
             const Refined rr = ref[k];
             const OctaveDev& oc = P.oc[rr.o];
             const float* img = oc.lv[rr.layer];
@@ -495,8 +669,9 @@ __device__ __forceinline__ unsigned long long tie_key(const KpRec& k) {
 }
 
 __global__ __launch_bounds__(1024) void topk_kernel(const KpRec* kps, const unsigned* resp, const unsigned* kp_count, unsigned kp_cap, int nfeatures,
-                                                    mi355_keypoint* out_kp, SelRec* out_sel, int* out_n, int* overflow) {
+                                                    mi355_keypoint* out_kp, SelRec* out_sel, int* out_n, int* overflow, unsigned* ctrl, int pass) {
     __shared__ unsigned s_hist[256];
+    if (pass == 1 && (ctrl[1] == 0 || ctrl[0] == 0)) return;     // fallback pass not needed
     __shared__ unsigned s_misc[8];
     __shared__ unsigned long long s_k0[TOPK_CAP];      // ~resp_bits (descending response first)
     __shared__ unsigned long long s_k1[TOPK_CAP];      // tie key
@@ -603,7 +778,12 @@ __global__ __launch_bounds__(1024) void topk_kernel(const KpRec* kps, const unsi
         SelRec sr; sr.ptx = k.ptx; sr.pty = k.pty; sr.scl = k.scl; sr.angle = k.angle; sr.o = k.o; sr.layer = k.layer;
         out_sel[i] = sr;
     }
-    if (tid == 0) *out_n = (int)keep;
+    if (tid == 0) {
+        *out_n = (int)keep;
+        // pass 0 oriented only the refined points with response >= T: fewer than nfeatures keypoints came out while
+        // weaker refined points exist -> orient those too (pass 1) and select again
+        if (pass == 0 && ctrl[0] != 0 && keep < K) ctrl[1] = 1;
+    }
 }
 
 // ---------- K5: descriptors -----------------------------------------------------------------------------------------
@@ -703,7 +883,25 @@ int gauss_kernel_host(double sigma, float* k) {
 
 template <bool BGR>
 bool launch_blur(hipStream_t st, int R, const BlurArgs& a) {
-    const dim3 grid(a.tiles_x * a.tiles_y), block(BT);
+    const int ntile = a.tiles_x * a.tiles_y;
+    // Large f32 levels: persistent 128-bit/packed-FMA variant with register prefetch (interior tiles dominate).
+    // Small levels (every tile touches the border) and the BGR base level: the 512-thread per-tile kernel.
+    const bool big = !BGR && a.w >= 1024 && a.h >= 768;
+#ifdef BLUR_LEGACY
+    const bool use2 = false;
+#else
+    const bool use2 = big;
+#endif
+    if (use2) {
+        const dim3 grid(ntile < BLUR_PERSIST_BLOCKS ? ntile : BLUR_PERSIST_BLOCKS), block(256);      // persistent: 2 workgroups per CU
+        switch (R) {
+#define CASE(RR) case RR: hipLaunchKernelGGL((blur_tile2<RR, false>), grid, block, 0, st, a); return true;
+            CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8) CASE(9) CASE(10) CASE(11) CASE(12) CASE(13) CASE(14) CASE(15) CASE(16)
+#undef CASE
+            default: return false;
+        }
+    }
+    const dim3 grid(ntile), block(BT);
     switch (R) {
 #define CASE(RR) case RR: hipLaunchKernelGGL((blur_tile<RR, BGR>), grid, block, 0, st, a); return true;
         CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8) CASE(9) CASE(10) CASE(11) CASE(12) CASE(13) CASE(14) CASE(15) CASE(16)
@@ -717,10 +915,12 @@ bool launch_blur(hipStream_t st, int R, const BlurArgs& a) {
 struct SiftWork {
     int w = 0, h = 0;                        // input frame size the buffers are sized for
     int n_oct = 0;
-    hipStream_t stream = nullptr;            // frames rotate over the slots; each slot is one in-order queue
+    hipStream_t stream = nullptr;            // stage B queue of this slot (refine .. describe): latency-bound kernels
+    hipEvent_t a_done = nullptr, b_done = nullptr;
+    bool used = false;
     DevBuf pyr;                              // all Gaussian levels
     DevBuf claimed;                          // duplicate claim bitmaps
-    DevBuf cand, refined, kps, kresp, sel, counters;
+    DevBuf cand, refined, kps, kresp, sel, counters, rhist;
     PyrDev P;
     size_t claimed_bytes = 0;
     unsigned cand_cap = 0, ref_cap = 0, kp_cap = 0;
@@ -729,18 +929,27 @@ struct SiftWork {
     float kern0[2 * MAX_R + 1]; int radius0 = 0;
 };
 
-constexpr int SIFT_SLOTS = 3;                // frames in flight: small octaves / top-k of one frame overlap the big
-                                             // kernels of the next (each slot owns a ~5 GB work area at 12 MP)
+// Two-stage software pipeline over frames.  Stage A (pyramid + extrema: the HBM-bound kernels, each of which fills
+// the chip) of every frame runs in order on ONE "heavy" stream, so those kernels never contend with each other.
+// Stage B (refine, orientation, top-k, descriptors: latency-bound, a few workgroups) runs on the slot's own stream
+// and overlaps stage A of the following frames.  Each slot owns a ~5 GB work area at 12 MP; a slot's pyramid is
+// reused by frame k+SIFT_SLOTS only after stage B of frame k finished (event).
+constexpr int SIFT_SLOTS_MAX = 4;
+static int sift_slots() { static int n = [] { const char* e = getenv("MI355_SIFT_SLOTS"); int v = e ? atoi(e) : 3; return v < 1 ? 1 : (v > SIFT_SLOTS_MAX ? SIFT_SLOTS_MAX : v); }(); return n; }
+#define SIFT_SLOTS (sift_slots())
 
 void mi_sift_release(mi355_ctx* ctx) {
     for (SiftWork* s : ctx->sift_slots) {
         if (!s) continue;
         if (s->stream) { (void)hipStreamSynchronize(s->stream); (void)hipStreamDestroy(s->stream); }
-        s->pyr.release(); s->claimed.release(); s->cand.release(); s->refined.release(); s->kps.release(); s->kresp.release(); s->sel.release(); s->counters.release();
+        if (s->a_done) (void)hipEventDestroy(s->a_done);
+        if (s->b_done) (void)hipEventDestroy(s->b_done);
+        s->pyr.release(); s->claimed.release(); s->cand.release(); s->refined.release(); s->kps.release(); s->kresp.release(); s->sel.release(); s->counters.release(); s->rhist.release();
         delete s;
     }
     ctx->sift_slots.clear();
     if (ctx->sift_in_ev) { (void)hipEventDestroy(ctx->sift_in_ev); ctx->sift_in_ev = nullptr; }
+    if (ctx->sift_heavy) { (void)hipStreamSynchronize(ctx->sift_heavy); (void)hipStreamDestroy(ctx->sift_heavy); ctx->sift_heavy = nullptr; }
     for (int* p : ctx->pinned_chunks) (void)hipHostFree(p);
     ctx->pinned_chunks.clear();
     ctx->pinned_used = 0;
@@ -751,6 +960,7 @@ int mi_resolve_features(mi355_ctx* ctx) {
     bool any = false;
     for (auto& kv : ctx->feats) if (kv.second.pending) { any = true; break; }
     if (!any) return MI355_OK;
+    if (ctx->sift_heavy) MI_HIP(hipStreamSynchronize(ctx->sift_heavy));
     for (SiftWork* s : ctx->sift_slots) if (s && s->stream) MI_HIP(hipStreamSynchronize(s->stream));
     int rc = MI355_OK;
     for (auto& kv : ctx->feats) {
@@ -784,6 +994,7 @@ static int* pinned_slot(mi355_ctx* ctx) {
 
 static int sift_prepare(mi355_ctx* ctx, SiftWork* s, int w, int h) {
     if (s->w == w && s->h == h) return MI355_OK;
+    MI_HIP(hipStreamSynchronize(ctx->sift_heavy));
     MI_HIP(hipStreamSynchronize(s->stream));
     if (s->radius0 == 0) {
         // Gaussian kernels (double math on the host, like the oracle): sigma_i = sqrt((s k^i)^2 - (s k^(i-1))^2)
@@ -834,6 +1045,7 @@ static int sift_prepare(mi355_ctx* ctx, SiftWork* s, int w, int h) {
     MI_HIP(s->kresp.reserve((size_t)s->kp_cap * sizeof(unsigned)));
     MI_HIP(s->sel.reserve(2048 * sizeof(SelRec)));
     MI_HIP(s->counters.reserve(64 * sizeof(unsigned)));
+    MI_HIP(s->rhist.reserve(65536 * sizeof(unsigned)));
     s->w = w; s->h = h;
     return MI355_OK;
 }
@@ -847,31 +1059,45 @@ int mi_sift_extract_dev(mi355_ctx* ctx, int img_id, const uint8_t* d_bgr, int w,
     if (ctx->sift_slots.empty()) {
         ctx->sift_slots.resize(SIFT_SLOTS, nullptr);
         MI_HIP(hipEventCreateWithFlags(&ctx->sift_in_ev, hipEventDisableTiming));
+        MI_HIP(hipStreamCreateWithFlags(&ctx->sift_heavy, hipStreamNonBlocking));
     }
     const int slot = ctx->sift_next;
     ctx->sift_next = (ctx->sift_next + 1) % SIFT_SLOTS;
     if (!ctx->sift_slots[slot]) {
         ctx->sift_slots[slot] = new SiftWork();
         MI_HIP(hipStreamCreateWithFlags(&ctx->sift_slots[slot]->stream, hipStreamNonBlocking));
+        MI_HIP(hipEventCreateWithFlags(&ctx->sift_slots[slot]->a_done, hipEventDisableTiming));
+        MI_HIP(hipEventCreateWithFlags(&ctx->sift_slots[slot]->b_done, hipEventDisableTiming));
     }
     SiftWork* s = ctx->sift_slots[slot];
     int rc = sift_prepare(ctx, s, w, h);
     if (rc != MI355_OK) return rc;
     auto fit = ctx->feats.find(img_id);
     if (fit != ctx->feats.end() && fit->second.pending) { rc = mi_resolve_features(ctx); if (rc != MI355_OK) return rc; }   // same id re-extracted while in flight
-    const hipStream_t st = s->stream;
+    // MI355_SIFT_TWO_STAGE=1 selects the two-stage pipeline (measured 12 % slower end to end than letting every slot
+    // run its whole frame on its own stream: the stage-B kernels take CUs from stage A either way)
+    static const bool two_stage = getenv("MI355_SIFT_TWO_STAGE") != nullptr;
+    const hipStream_t st = s->stream;                          // stage B
+    const hipStream_t sa = two_stage ? ctx->sift_heavy : st;   // stage A
+    static const bool host_timing = getenv("MI355_HOST_TIMING") != nullptr;
+    static double tacc[6] = {0}; static int tn = 0;
+    auto tnow = [] { return std::chrono::steady_clock::now(); };
+    auto tus = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+    auto T0 = tnow();
     const int nf = ctx->p.nfeatures;
     Features& f = ctx->feats[img_id];
     f.w = w; f.h = h;
     MI_HIP(f.kp.reserve(sizeof(mi355_keypoint) * 2048));
     MI_HIP(f.d8.reserve(128 * 2048));
-    // the frame was produced on the caller's stream: order this slot after it
+    // the frame was produced on the caller's stream: order stage A after it, and after stage B of the frame that
+    // used this slot's work area before
     MI_HIP(hipEventRecord(ctx->sift_in_ev, ctx->stream));
-    MI_HIP(hipStreamWaitEvent(st, ctx->sift_in_ev, 0));
+    MI_HIP(hipStreamWaitEvent(sa, ctx->sift_in_ev, 0));
+    if (s->used) MI_HIP(hipStreamWaitEvent(sa, s->b_done, 0));
+    s->used = true;
     unsigned* cnt = s->counters.as<unsigned>();      // [0] candidates [1] refined [2] keypoints [3] n_sel [4] overflow
-    MI_HIP(hipMemsetAsync(cnt, 0, 64 * sizeof(unsigned), st));
-    MI_HIP(hipMemsetAsync(s->claimed.p, 0, s->claimed_bytes, st));
-    MI_HIP(hipMemsetAsync(f.d8.p, 0, 128 * 2048, st));
+    MI_HIP(hipMemsetAsync(cnt, 0, 64 * sizeof(unsigned), sa));
+    auto T1 = tnow();
     // ---- pyramid ----
     for (int o = 0; o < s->n_oct; o++) {
         const OctaveDev& oc = s->P.oc[o];
@@ -882,51 +1108,67 @@ int mi_sift_extract_dev(mi355_ctx* ctx, int img_id, const uint8_t* d_bgr, int w,
         if (o == 0) {
             a.bgr = d_bgr; a.bgr_ws = ws; a.dst = oc.lv[0];
             memcpy(a.k, s->kern0, sizeof(float) * (2 * s->radius0 + 1));
-            ProfScope ps(ctx, "gauss", level_bytes + (double)w * h * 3.0, st);      // read the u8 frame, write level 0
-            if (!launch_blur<true>(st, s->radius0, a)) { ctx->set_error("sift: unsupported kernel radius"); return MI355_ERR_FAILED; }
+            ProfScope ps(ctx, "gauss", level_bytes + (double)w * h * 3.0, sa);      // read the u8 frame, write level 0
+            if (!launch_blur<true>(sa, s->radius0, a)) { ctx->set_error("sift: unsupported kernel radius"); return MI355_ERR_FAILED; }
         } else {
             const OctaveDev& pv = s->P.oc[o - 1];
-            ProfScope ps(ctx, "downsample", level_bytes * 2.0, st);
-            hipLaunchKernelGGL(downsample2, dim3((oc.w + 63) / 64, (oc.h + 3) / 4), dim3(256), 0, st, pv.lv[N_LAYERS], pv.w, oc.lv[0], oc.w, oc.h);
+            ProfScope ps(ctx, "downsample", level_bytes * 2.0, sa);
+            hipLaunchKernelGGL(downsample2, dim3((oc.w + 63) / 64, (oc.h + 3) / 4), dim3(256), 0, sa, pv.lv[N_LAYERS], pv.w, oc.lv[0], oc.w, oc.h);
         }
         for (int i = 1; i < N_LEVELS; i++) {
             a.bgr = nullptr; a.src = oc.lv[i - 1]; a.dst = oc.lv[i];
             memcpy(a.k, s->kern[i], sizeof(float) * (2 * s->radius[i] + 1));
-            ProfScope ps(ctx, "gauss", level_bytes * 2.0, st);                        // one read + one write of the level
-            if (!launch_blur<false>(st, s->radius[i], a)) { ctx->set_error("sift: unsupported kernel radius"); return MI355_ERR_FAILED; }
+            ProfScope ps(ctx, "gauss", level_bytes * 2.0, sa);                        // one read + one write of the level
+            if (!launch_blur<false>(sa, s->radius[i], a)) { ctx->set_error("sift: unsupported kernel radius"); return MI355_ERR_FAILED; }
         }
         {
-            ProfScope ps(ctx, "extrema", level_bytes * 6.0, st);
-            hipLaunchKernelGGL(extrema_kernel, dim3((oc.w + EW - 1) / EW, (oc.h + EH - 1) / EH), dim3(256), 0, st,
+            ProfScope ps(ctx, "extrema", level_bytes * 6.0, sa);
+            hipLaunchKernelGGL(extrema_kernel, dim3((oc.w + EW - 1) / EW, (oc.h + EH - 1) / EH), dim3(256), 0, sa,
                                oc, o, s->cand.as<unsigned long long>(), cnt + 0, s->cand_cap);
         }
     }
+    auto T2 = tnow();
+    MI_HIP(hipEventRecord(s->a_done, sa));
+    MI_HIP(hipStreamWaitEvent(st, s->a_done, 0));
+    MI_HIP(hipMemsetAsync(s->claimed.p, 0, s->claimed_bytes, st));
+    MI_HIP(hipMemsetAsync(f.d8.p, 0, 128 * 2048, st));
+    MI_HIP(hipMemsetAsync(s->rhist.p, 0, 65536 * sizeof(unsigned), st));
     {
         ProfScope ps(ctx, "refine", 0.0, st);
         hipLaunchKernelGGL(refine_kernel, dim3(ctx->num_cu * 8), dim3(256), 0, st, s->P, s->cand.as<unsigned long long>(), cnt + 0, s->cand_cap,
-                           ctx->p.contrast_threshold, ctx->p.edge_threshold, 1.6f, s->refined.as<Refined>(), cnt + 1, s->ref_cap);
+                           ctx->p.contrast_threshold, ctx->p.edge_threshold, 1.6f, s->refined.as<Refined>(), cnt + 1, s->ref_cap, s->rhist.as<unsigned>());
+        hipLaunchKernelGGL(resp_threshold_kernel, dim3(1), dim3(1024), 0, st, s->rhist.as<unsigned>(), cnt + 1, (unsigned)nf + 256u, cnt + 8);
     }
-    {
-        ProfScope ps(ctx, "orient", 0.0, st);
-        hipLaunchKernelGGL(orient_kernel, dim3(ctx->num_cu * 4), dim3(256), 0, st, s->P, s->refined.as<Refined>(), cnt + 1, s->ref_cap,
-                           s->kps.as<KpRec>(), s->kresp.as<unsigned>(), cnt + 2, s->kp_cap);
-    }
-    {
-        ProfScope ps(ctx, "topk", 0.0, st);
-        hipLaunchKernelGGL(topk_kernel, dim3(1), dim3(1024), 0, st, s->kps.as<KpRec>(), s->kresp.as<unsigned>(), cnt + 2, s->kp_cap, nf,
-                           f.kp.as<mi355_keypoint>(), s->sel.as<SelRec>(), reinterpret_cast<int*>(cnt + 3), reinterpret_cast<int*>(cnt + 4));
+    for (int pass = 0; pass < 2; pass++) {       // pass 1 (everything below the response threshold) exits at once unless top-k asked for it
+        {
+            ProfScope ps(ctx, "orient", 0.0, st);
+            hipLaunchKernelGGL(orient_kernel, dim3(ctx->num_cu * 4), dim3(256), 0, st, s->P, s->refined.as<Refined>(), cnt + 1, s->ref_cap,
+                               s->kps.as<KpRec>(), s->kresp.as<unsigned>(), cnt + 2, s->kp_cap, cnt + 8, pass);
+        }
+        {
+            ProfScope ps(ctx, "topk", 0.0, st);
+            hipLaunchKernelGGL(topk_kernel, dim3(1), dim3(1024), 0, st, s->kps.as<KpRec>(), s->kresp.as<unsigned>(), cnt + 2, s->kp_cap, nf,
+                               f.kp.as<mi355_keypoint>(), s->sel.as<SelRec>(), reinterpret_cast<int*>(cnt + 3), reinterpret_cast<int*>(cnt + 4), cnt + 8, pass);
+        }
     }
     {
         ProfScope ps(ctx, "describe", 0.0, st);
         hipLaunchKernelGGL(describe_kernel, dim3(nf), dim3(256), 0, st, s->P, s->sel.as<SelRec>(), reinterpret_cast<const int*>(cnt + 3), f.d8.as<uint8_t>());
     }
+    auto T3 = tnow();
     MI_HIP(hipGetLastError());
     rc = mi_finish_features(ctx, f, reinterpret_cast<const int*>(cnt + 3), st);
     if (rc != MI355_OK) return rc;
     int* hc = pinned_slot(ctx);
     if (!hc) { ctx->set_error("sift: pinned alloc failed"); return MI355_ERR_NOMEM; }
     MI_HIP(hipMemcpyAsync(hc, cnt, 8 * sizeof(unsigned), hipMemcpyDeviceToHost, st));
+    MI_HIP(hipEventRecord(s->b_done, st));
     f.h_cnt = hc; f.pending = true; f.n = 0;
+    if (host_timing) {
+        auto T4 = tnow();
+        tacc[0] += tus(T0, T1); tacc[1] += tus(T1, T2); tacc[2] += tus(T2, T3); tacc[3] += tus(T3, T4); tn++;
+        if (tn % 24 == 0) { fprintf(stderr, "[host timing us/frame] setup+memsets %.1f pyramid %.1f tail %.1f finish+copy %.1f\n", tacc[0] / tn, tacc[1] / tn, tacc[2] / tn, tacc[3] / tn); }
+    }
     f.caps[0] = s->cand_cap; f.caps[1] = s->ref_cap; f.caps[2] = s->kp_cap;
     if (ctx->pinned_used >= PINNED_CHUNK * 64) {           // recycle the pinned pool when nothing is pending any more
         rc = mi_resolve_features(ctx);

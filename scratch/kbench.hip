@@ -1,0 +1,42 @@
+// micro-benchmark of the SIFT stage-A kernels at the 12 MP octave-0 size (8000x6000): includes the product TU
+#include "../imagemosaicing_amd/csrc/sift.hip"
+#include <vector>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
+int main(int argc, char** argv) {
+    const int W = 8000, H = 6000;
+    const size_t px = (size_t)W * H;
+    float* lv[7];
+    for (int i = 0; i < 7; i++) CK(hipMalloc(&lv[i], px * 4));
+    std::vector<float> h(px);
+    unsigned s = 12345;
+    for (size_t i = 0; i < px; i++) { s = s * 1664525u + 1013904223u; h[i] = (float)(s >> 24); }
+    CK(hipMemcpy(lv[0], h.data(), px * 4, hipMemcpyHostToDevice));
+    hipStream_t st; CK(hipStreamCreate(&st));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    const double sigma = 1.6, k = std::pow(2.0, 1.0 / 3);
+    for (int i = 1; i < 6; i++) {
+        const double sp = std::pow(k, (double)(i - 1)) * sigma, stt = sp * k;
+        BlurArgs a; memset(&a, 0, sizeof(a));
+        const int R = gauss_kernel_host(std::sqrt(stt * stt - sp * sp), a.k);
+        a.src = lv[i - 1]; a.dst = lv[i]; a.w = W; a.h = H; a.tiles_x = (W + TW - 1) / TW; a.tiles_y = (H + TH - 1) / TH;
+        launch_blur<false>(st, R, a);
+        CK(hipStreamSynchronize(st));
+        CK(hipEventRecord(e0, st));
+        for (int it = 0; it < 10; it++) launch_blur<false>(st, R, a);
+        CK(hipEventRecord(e1, st)); CK(hipStreamSynchronize(st));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= 10;
+        printf("blur R=%2d: %.1f us  %.0f GB/s algorithmic\n", R, ms * 1e3, px * 8.0 / ms / 1e6);
+    }
+    OctaveDev oc; for (int i = 0; i < 6; i++) oc.lv[i] = lv[i]; oc.w = W; oc.h = H;
+    unsigned long long* cand; unsigned* cnt; CK(hipMalloc(&cand, 64 << 20)); CK(hipMalloc(&cnt, 256)); CK(hipMemset(cnt, 0, 256));
+    for (int rep = 0; rep < 2; rep++) {
+        CK(hipMemset(cnt, 0, 256));
+        CK(hipEventRecord(e0, st));
+        for (int it = 0; it < 5; it++) hipLaunchKernelGGL(extrema_kernel, dim3((W + EW - 1) / EW, (H + EH - 1) / EH), dim3(256), 0, st, oc, 0, cand, cnt, 8u << 20);
+        CK(hipEventRecord(e1, st)); CK(hipStreamSynchronize(st));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= 5;
+        unsigned c; CK(hipMemcpy(&c, cnt, 4, hipMemcpyDeviceToHost));
+        printf("extrema: %.1f us  %.0f GB/s algorithmic (6 levels)  cands/launch %u\n", ms * 1e3, px * 24.0 / ms / 1e6, c / 5);
+    }
+    return 0;
+}
