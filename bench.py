@@ -210,6 +210,23 @@ def main():
             ms, n, b = ctx.profile_get(cls)
             prof_all[cls] = {"ms_per_step": ms / max(args.steps, 1), "launches_per_step": n / max(args.steps, 1)}
     ctx.profile_enable(False)
+    # The timed region keeps several frames in flight, so the gauss launches above overlap other kernels and their
+    # event durations include the contention.  One extra UNTIMED pass over a few frames with a single frame in
+    # flight gives the same kernel's stand-alone figures (reported separately, never as `achieved`).
+    iso = None
+    if world == 1 or rank == 0:
+        ctx.synchronize()
+        ctx.set_option("sift_slots", 1)
+        ctx.profile_enable(True); ctx.profile_only("gauss"); ctx.profile_reset()
+        nf_iso = min(F, 24)
+        for k in range(nf_iso):
+            ctx.SiftExtractDev(k, fptr[k], w, h, ws)
+        i_ms, i_n, i_bytes = ctx.profile_get("gauss")
+        ctx.profile_enable(False)
+        ctx.set_option("sift_slots", 3)
+        if i_ms > 0:
+            iso = {"achieved": (i_bytes / 1e9) / (i_ms / 1e3), "frac": (i_bytes / 1e9) / (i_ms / 1e3) / HBM_PEAK_GBS, "frames": nf_iso,
+                   "avg_launch_us": i_ms * 1e3 / max(i_n, 1), "note": "same kernel, one frame in flight (no overlap with other kernels), untimed extra pass"}
 
     # quality of the last step against ground truth (accepted pairs): corner transfer error in pixels
     r = state["r"]
@@ -243,7 +260,8 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "blur_tile (fused separable Gaussian, SIFT pyramid)", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "launches": int(g_n), "avg_launch_us": (g_ms * 1e3 / g_n) if g_n else None,
-                         "algorithmic_bytes_per_frame": g_bytes / max(args.steps * F, 1)},
+                         "algorithmic_bytes_per_frame": g_bytes / max(args.steps * F, 1),
+                         "frames_in_flight": 3, "standalone": iso},
             "quality": {"pairs_accepted": accepted, "pairs": n_pairs, "images_aligned": state["n_valid"],
                         "h_corner_err_px_median": float(np.median(errs)) if errs else None,
                         "h_corner_err_px_max": float(np.max(errs)) if errs else None},

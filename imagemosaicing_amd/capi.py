@@ -124,6 +124,9 @@ class Context:
     def synchronize(self):
         self._chk(self.L.mi355_synchronize(self._h))
 
+    def set_option(self, name, value):
+        self._chk(self.L.mi355_set_option(self._h, name.encode(), int(value)))
+
     def profile_enable(self, on=True):
         self._chk(self.L.mi355_profile_enable(self._h, int(bool(on))))
 

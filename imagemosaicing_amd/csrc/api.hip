@@ -52,6 +52,7 @@ extern "C" int mi355_create(mi355_ctx** out, const mi355_params* params, int dev
     e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
     if (e != hipSuccess) { g_create_error = hipGetErrorString(e); delete c; return MI355_ERR_DEVICE; }
     c->stream = c->own_stream;
+    if (const char* e = getenv("MI355_SIFT_SLOTS")) { const int v = atoi(e); c->sift_nslots = v < 1 ? 1 : (v > 4 ? 4 : v); }
     *out = c;
     return MI355_OK;
 }
@@ -266,6 +267,18 @@ extern "C" int mi355_last_sift_counters(mi355_ctx* ctx, int32_t out8[8]) {
     if (!out8) return MI355_ERR_ARG;
     for (int i = 0; i < 8; i++) out8[i] = ctx->last_counts[i];
     return MI355_OK;
+}
+extern "C" int mi355_set_option(mi355_ctx* ctx, const char* name, int value) {
+    LOCKED_PROLOGUE
+    if (!name) return MI355_ERR_ARG;
+    if (std::string(name) == "sift_slots") {
+        int rc = mi_resolve_features(ctx);
+        if (rc != MI355_OK) return rc;
+        ctx->sift_nslots = value < 1 ? 1 : (value > 4 ? 4 : value);
+        return MI355_OK;
+    }
+    ctx->set_error(std::string("set_option: unknown option ") + name);
+    return MI355_ERR_ARG;
 }
 extern "C" int mi355_profile_only(mi355_ctx* ctx, const char* kernel_class) {
     LOCKED_PROLOGUE

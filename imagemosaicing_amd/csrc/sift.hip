@@ -103,6 +103,9 @@ __host__ __device__ __forceinline__ int reflect101(int p, int n) {
     return p;
 }
 
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+
 // ---------- K1/K2: fused separable Gaussian blur ------------------------------------------------------------------
 struct BlurArgs {
     const float* src;        // LOADER f32: source level (w x h)
@@ -221,8 +224,6 @@ __global__ __launch_bounds__(BT) void blur_tile(BlurArgs a) {
 // the CDNA4 issue limits: 128-bit LDS reads/writes, two FMAs per instruction (v_pk_fma_f32 through 2-wide vector
 // fma), and a 4x4 output block per lane in the column pass.  The staged tile starts at a 4-float aligned column
 // (halo RA = R rounded up to 4) so that global loads, LDS rows and the sliding windows are all 16-byte aligned.
-typedef float v2f __attribute__((ext_vector_type(2)));
-typedef float v4f __attribute__((ext_vector_type(4)));
 
 template <int R, bool BGR>
 __global__ __launch_bounds__(256) void blur_tile2(BlurArgs a) {
@@ -342,59 +343,119 @@ __global__ __launch_bounds__(256) void downsample2(const float* src, int sw, flo
 // ---------- K3: DoG extrema -------------------------------------------------------------------------------------
 struct OctaveDev { float* lv[N_LEVELS]; int w, h; };
 
-constexpr int EW = 64, EH = 16, ECAP = 128;
+#ifndef EXT_EH
+#define EXT_EH 16
+#endif
+constexpr int EW = 64, EH = EXT_EH, ECAP = 128;
 __global__ __launch_bounds__(256) void extrema_kernel(OctaveDev oc, int octave, unsigned long long* cand, unsigned* count, unsigned cap) {
-    constexpr int PW = EW + 2 + 1;             // 67: odd pitch
-    __shared__ float s_d[5][(EH + 2) * PW];
+    // staged window: rows y0-1 .. y0+EH, columns x0-4 .. x0+EW+3 (16-byte aligned so that interior tiles load float4)
+    constexpr int PC = EW + 8;                 // 72 columns
+    constexpr int P4 = PC / 4;                 // 18 float4 per row
+    constexpr int RW = EH + 2;                 // 18 rows
+    __shared__ v4f s_d4[5][RW * P4];
     __shared__ unsigned long long s_list[ECAP];   // candidates of this tile: one global atomic per workgroup
     __shared__ unsigned s_n, s_base;
     const int tid = threadIdx.x;
-    const int x0 = blockIdx.x * EW, y0 = blockIdx.y * EH;
+    // XCD-aware tile order: consecutive tiles (horizontal neighbours, which share their halo columns' cache lines) run on
+    // the same XCD, i.e. behind the same L2 -- with the default round-robin every halo line came from HBM again
+    // (measured: 2.2x the algorithmic bytes at the fabric).
+    const int tiles_x = (oc.w + EW - 1) / EW, tiles_y = (oc.h + EH - 1) / EH;
+    const int tile = xcd_remap(blockIdx.x, tiles_x * tiles_y);
+    const int tyy = tile / tiles_x, txx = tile - tyy * tiles_x;
+    const int x0 = txx * EW, y0 = tyy * EH;
     if (tid == 0) s_n = 0;
-    for (int idx = tid; idx < (EH + 2) * (EW + 2); idx += 256) {
-        const int ry = idx / (EW + 2), rx = idx - ry * (EW + 2);
-        int gy = y0 - 1 + ry, gx = x0 - 1 + rx;
-        gy = gy < 0 ? 0 : (gy > oc.h - 1 ? oc.h - 1 : gy);          // clamped halo values are never used by valid pixels (5 px border)
-        gx = gx < 0 ? 0 : (gx > oc.w - 1 ? oc.w - 1 : gx);
-        const size_t o = (size_t)gy * oc.w + gx;
-        float g[N_LEVELS];
+    const bool vec = ((oc.w & 3) == 0) && (x0 - 4 >= 0) && (x0 + EW + 4 <= oc.w) && ((reinterpret_cast<uintptr_t>(oc.lv[0]) & 15) == 0) &&
+                     ((((size_t)oc.w * oc.h) & 3) == 0);
+    if (vec) {
+        // centre columns x0 .. x0+EW-1: whole 256-byte runs (two 128-byte lines per row and level), float4 per lane
+        for (int idx = tid; idx < RW * (EW / 4); idx += 256) {
+            const int ry = idx / (EW / 4), c4 = idx - ry * (EW / 4);
+            int gy = y0 - 1 + ry;
+            gy = gy < 0 ? 0 : (gy > oc.h - 1 ? oc.h - 1 : gy);      // clamped halo rows are never used by valid pixels (5 px border)
+            const size_t o = (size_t)gy * oc.w + (x0 + 4 * c4);
+            v4f g[N_LEVELS];
 #pragma unroll
-        for (int l = 0; l < N_LEVELS; l++) g[l] = oc.lv[l][o];
+            for (int l = 0; l < N_LEVELS; l++) g[l] = *reinterpret_cast<const v4f*>(oc.lv[l] + o);
 #pragma unroll
-        for (int l = 0; l < 5; l++) s_d[l][ry * PW + rx] = g[l + 1] - g[l];
+            for (int l = 0; l < 5; l++) s_d4[l][ry * P4 + 1 + c4] = g[l + 1] - g[l];
+        }
+        // the two halo columns x0-1 and x0+EW (lines the neighbouring tiles fetch anyway)
+        if (tid < 2 * RW) {
+            const int ry = tid >> 1, side = tid & 1;
+            int gy = y0 - 1 + ry;
+            gy = gy < 0 ? 0 : (gy > oc.h - 1 ? oc.h - 1 : gy);
+            const size_t o = (size_t)gy * oc.w + (side ? x0 + EW : x0 - 1);
+            float g[N_LEVELS];
+#pragma unroll
+            for (int l = 0; l < N_LEVELS; l++) g[l] = oc.lv[l][o];
+#pragma unroll
+            for (int l = 0; l < 5; l++) reinterpret_cast<float*>(s_d4[l])[ry * PC + (side ? 4 + EW : 3)] = g[l + 1] - g[l];
+        }
+    } else {
+        for (int idx = tid; idx < RW * PC; idx += 256) {
+            const int ry = idx / PC, rx = idx - ry * PC;
+            int gy = y0 - 1 + ry, gx = x0 - 4 + rx;
+            gy = gy < 0 ? 0 : (gy > oc.h - 1 ? oc.h - 1 : gy);
+            gx = gx < 0 ? 0 : (gx > oc.w - 1 ? oc.w - 1 : gx);
+            const size_t o = (size_t)gy * oc.w + gx;
+            float g[N_LEVELS];
+#pragma unroll
+            for (int l = 0; l < N_LEVELS; l++) g[l] = oc.lv[l][o];
+#pragma unroll
+            for (int l = 0; l < 5; l++) reinterpret_cast<float*>(s_d4[l])[idx] = g[l + 1] - g[l];
+        }
     }
     __syncthreads();
-    for (int p = tid; p < EW * EH; p += 256) {
-        const int ly = p / EW, lx = p - ly * EW;
-        const int r = y0 + ly, c = x0 + lx;
-        if (r < IMG_BORDER || r >= oc.h - IMG_BORDER || c < IMG_BORDER || c >= oc.w - IMG_BORDER) continue;
-        const int ctr = (ly + 1) * PW + lx + 1;
+#ifdef EXT_NO_COMPUTE
+    if (reinterpret_cast<const float*>(s_d4[2])[tid] == 12345.678f) cand[0] = 1;
+    return;
+#endif
+    // one item per lane: 4 adjacent pixels of one row.  All 5 DoG planes' 3x6 windows go to registers (one 128-bit and two
+    // 32-bit LDS reads per row), column-wise 3-row max/min are shared by the 4 pixels, and the 26-neighbour test becomes
+    // "val >= max of the neighbours" / "val <= min of the neighbours" without data-dependent branches.
+    for (int item = tid; item < EH * (EW / 4); item += 256) {
+        const int ly = item / (EW / 4), xg = item - ly * (EW / 4);
+        const int r = y0 + ly;
+        float cm[5][6], cn[5][6], mid[5][6], top[5][6], bot[5][6];
 #pragma unroll
-        for (int layer = 1; layer <= N_LAYERS; layer++) {
-            const float val = s_d[layer][ctr];
-            if (!(fabsf(val) > 0.0f)) continue;
-            // in-plane 8 neighbours first (rejects ~8/9 of the pixels), then the 18 of the adjacent layers
-            const float* q = &s_d[layer][ctr];
-            float mx = fmaxf(fmaxf(fmaxf(q[-PW - 1], q[-PW]), fmaxf(q[-PW + 1], q[-1])), fmaxf(fmaxf(q[1], q[PW - 1]), fmaxf(q[PW], q[PW + 1])));
-            float mn = fminf(fminf(fminf(q[-PW - 1], q[-PW]), fminf(q[-PW + 1], q[-1])), fminf(fminf(q[1], q[PW - 1]), fminf(q[PW], q[PW + 1])));
-            const bool ismax = val > 0.0f;
-            if (ismax ? !(val >= mx) : !(val <= mn)) continue;
-            bool ok = true;
+        for (int pl = 0; pl < 5; pl++) {
+            const float* base = reinterpret_cast<const float*>(s_d4[pl]) + (ly + 1) * PC + 4 * xg + 4;
 #pragma unroll
-            for (int dl = -1; dl <= 1; dl += 2) {
-                const float* u = &s_d[layer + dl][ctr];
+            for (int rr = -1; rr <= 1; rr++) {
+                const float* q = base + rr * PC;
+                const v4f c4 = *reinterpret_cast<const v4f*>(q);
+                float v[6] = {q[-1], c4.x, c4.y, c4.z, c4.w, q[4]};
 #pragma unroll
-                for (int dr = -1; dr <= 1; dr++) {
-                    const float* row = u + dr * PW;
-                    if (ismax) ok = ok && (val >= row[-1]) && (val >= row[0]) && (val >= row[1]);
-                    else ok = ok && (val <= row[-1]) && (val <= row[0]) && (val <= row[1]);
-                }
+                for (int j = 0; j < 6; j++) { if (rr == -1) top[pl][j] = v[j]; else if (rr == 0) mid[pl][j] = v[j]; else bot[pl][j] = v[j]; }
             }
-            if (!ok) continue;
-            const unsigned long long rec = ((unsigned long long)octave << 48) | ((unsigned long long)layer << 40) | ((unsigned long long)r << 20) | (unsigned long long)c;
-            const unsigned slot = atomicAdd(&s_n, 1u);
-            if (slot < ECAP) s_list[slot] = rec;
-            else { const unsigned g = atomicAdd(count, 1u); if (g < cap) cand[g] = rec; }      // tile with > 128 extrema (flat image)
+#pragma unroll
+            for (int j = 0; j < 6; j++) {
+                cm[pl][j] = fmaxf(fmaxf(top[pl][j], mid[pl][j]), bot[pl][j]);
+                cn[pl][j] = fminf(fminf(top[pl][j], mid[pl][j]), bot[pl][j]);
+            }
+        }
+        if (r < IMG_BORDER || r >= oc.h - IMG_BORDER) continue;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int c = x0 + 4 * xg + k, j = k + 1;
+            if (c < IMG_BORDER || c >= oc.w - IMG_BORDER) continue;
+#pragma unroll
+            for (int layer = 1; layer <= N_LAYERS; layer++) {
+                const float val = mid[layer][j];
+                // neighbours: full 3x3 of the two adjacent planes + the 8 in-plane ones
+                float mx = fmaxf(fmaxf(cm[layer - 1][j - 1], cm[layer - 1][j]), cm[layer - 1][j + 1]);
+                mx = fmaxf(mx, fmaxf(fmaxf(cm[layer + 1][j - 1], cm[layer + 1][j]), cm[layer + 1][j + 1]));
+                mx = fmaxf(mx, fmaxf(fmaxf(cm[layer][j - 1], cm[layer][j + 1]), fmaxf(top[layer][j], bot[layer][j])));
+                float mn = fminf(fminf(cn[layer - 1][j - 1], cn[layer - 1][j]), cn[layer - 1][j + 1]);
+                mn = fminf(mn, fminf(fminf(cn[layer + 1][j - 1], cn[layer + 1][j]), cn[layer + 1][j + 1]));
+                mn = fminf(mn, fminf(fminf(cn[layer][j - 1], cn[layer][j + 1]), fminf(top[layer][j], bot[layer][j])));
+                const bool is_ext = (val > 0.0f && val >= mx) || (val < 0.0f && val <= mn);
+                if (!is_ext) continue;
+                const unsigned long long rec = ((unsigned long long)octave << 48) | ((unsigned long long)layer << 40) | ((unsigned long long)r << 20) | (unsigned long long)c;
+                const unsigned slot = atomicAdd(&s_n, 1u);
+                if (slot < ECAP) s_list[slot] = rec;
+                else { const unsigned g = atomicAdd(count, 1u); if (g < cap) cand[g] = rec; }      // tile with > 128 extrema (flat image)
+            }
         }
     }
     __syncthreads();
@@ -935,8 +996,7 @@ struct SiftWork {
 // and overlaps stage A of the following frames.  Each slot owns a ~5 GB work area at 12 MP; a slot's pyramid is
 // reused by frame k+SIFT_SLOTS only after stage B of frame k finished (event).
 constexpr int SIFT_SLOTS_MAX = 4;
-static int sift_slots() { static int n = [] { const char* e = getenv("MI355_SIFT_SLOTS"); int v = e ? atoi(e) : 3; return v < 1 ? 1 : (v > SIFT_SLOTS_MAX ? SIFT_SLOTS_MAX : v); }(); return n; }
-#define SIFT_SLOTS (sift_slots())
+#define SIFT_SLOTS (ctx->sift_nslots)
 
 void mi_sift_release(mi355_ctx* ctx) {
     for (SiftWork* s : ctx->sift_slots) {
@@ -1057,10 +1117,11 @@ int mi_sift_extract_dev(mi355_ctx* ctx, int img_id, const uint8_t* d_bgr, int w,
     if (ctx->p.nfeatures < 1 || ctx->p.nfeatures > 2048) { ctx->set_error("sift: nfeatures must be in [1,2048]"); return MI355_ERR_ARG; }
     if (2 * (size_t)w >= (1u << 20) || 2 * (size_t)h >= (1u << 20)) { ctx->set_error("sift: image too large"); return MI355_ERR_ARG; }
     if (ctx->sift_slots.empty()) {
-        ctx->sift_slots.resize(SIFT_SLOTS, nullptr);
+        ctx->sift_slots.resize(SIFT_SLOTS_MAX, nullptr);
         MI_HIP(hipEventCreateWithFlags(&ctx->sift_in_ev, hipEventDisableTiming));
         MI_HIP(hipStreamCreateWithFlags(&ctx->sift_heavy, hipStreamNonBlocking));
     }
+    if (ctx->sift_next >= SIFT_SLOTS) ctx->sift_next = 0;
     const int slot = ctx->sift_next;
     ctx->sift_next = (ctx->sift_next + 1) % SIFT_SLOTS;
     if (!ctx->sift_slots[slot]) {
@@ -1123,7 +1184,7 @@ int mi_sift_extract_dev(mi355_ctx* ctx, int img_id, const uint8_t* d_bgr, int w,
         }
         {
             ProfScope ps(ctx, "extrema", level_bytes * 6.0, sa);
-            hipLaunchKernelGGL(extrema_kernel, dim3((oc.w + EW - 1) / EW, (oc.h + EH - 1) / EH), dim3(256), 0, sa,
+            hipLaunchKernelGGL(extrema_kernel, dim3(((oc.w + EW - 1) / EW) * ((oc.h + EH - 1) / EH)), dim3(256), 0, sa,
                                oc, o, s->cand.as<unsigned long long>(), cnt + 0, s->cand_cap);
         }
     }

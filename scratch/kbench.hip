@@ -32,7 +32,7 @@ int main(int argc, char** argv) {
     for (int rep = 0; rep < 2; rep++) {
         CK(hipMemset(cnt, 0, 256));
         CK(hipEventRecord(e0, st));
-        for (int it = 0; it < 5; it++) hipLaunchKernelGGL(extrema_kernel, dim3((W + EW - 1) / EW, (H + EH - 1) / EH), dim3(256), 0, st, oc, 0, cand, cnt, 8u << 20);
+        for (int it = 0; it < 5; it++) hipLaunchKernelGGL(extrema_kernel, dim3(((W + EW - 1) / EW) * ((H + EH - 1) / EH)), dim3(256), 0, st, oc, 0, cand, cnt, 8u << 20);
         CK(hipEventRecord(e1, st)); CK(hipStreamSynchronize(st));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= 5;
         unsigned c; CK(hipMemcpy(&c, cnt, 4, hipMemcpyDeviceToHost));
