@@ -347,7 +347,9 @@ struct OctaveDev { float* lv[N_LEVELS]; int w, h; };
 #define EXT_EH 16
 #endif
 constexpr int EW = 64, EH = EXT_EH, ECAP = 128;
-__global__ __launch_bounds__(256) void extrema_kernel(OctaveDev oc, int octave, unsigned long long* cand, unsigned* count, unsigned cap) {
+constexpr int NREG = 64, REG_STRIDE = 32;   // candidate list split into 64 regions, one counter per 128-byte line:
+                                            // a single counter caps at ~1e8 returning atomics/s (one per tile = 0.5 ms)
+__global__ __launch_bounds__(256) void extrema_kernel(OctaveDev oc, int octave, unsigned long long* cand, unsigned* count, unsigned cap, unsigned* overflow) {
     // staged window: rows y0-1 .. y0+EH, columns x0-4 .. x0+EW+3 (16-byte aligned so that interior tiles load float4)
     constexpr int PC = EW + 8;                 // 72 columns
     constexpr int P4 = PC / 4;                 // 18 float4 per row
@@ -454,15 +456,20 @@ __global__ __launch_bounds__(256) void extrema_kernel(OctaveDev oc, int octave, 
                 const unsigned long long rec = ((unsigned long long)octave << 48) | ((unsigned long long)layer << 40) | ((unsigned long long)r << 20) | (unsigned long long)c;
                 const unsigned slot = atomicAdd(&s_n, 1u);
                 if (slot < ECAP) s_list[slot] = rec;
-                else { const unsigned g = atomicAdd(count, 1u); if (g < cap) cand[g] = rec; }      // tile with > 128 extrema (flat image)
+                else {                                                                           // tile with > 128 extrema (flat image)
+                    const unsigned reg = (unsigned)tile & (NREG - 1);
+                    const unsigned g = atomicAdd(&count[reg * REG_STRIDE], 1u);
+                    if (g < cap) cand[(size_t)reg * cap + g] = rec; else *overflow = 1;
+                }
             }
         }
     }
     __syncthreads();
     const unsigned nloc = s_n < ECAP ? s_n : ECAP;
-    if (tid == 0 && nloc) s_base = atomicAdd(count, nloc);
+    const unsigned reg = (unsigned)tile & (NREG - 1);
+    if (tid == 0 && nloc) s_base = atomicAdd(&count[reg * REG_STRIDE], nloc);
     __syncthreads();
-    for (unsigned i = tid; i < nloc; i += 256) { const unsigned g = s_base + i; if (g < cap) cand[g] = s_list[i]; }
+    for (unsigned i = tid; i < nloc; i += 256) { const unsigned g = s_base + i; if (g < cap) cand[(size_t)reg * cap + g] = s_list[i]; else *overflow = 1; }
 }
 
 // ---------- K3b: sub-pixel refinement ---------------------------------------------------------------------------
@@ -505,11 +512,19 @@ __device__ void solve3(float A[3][3], float b[3], float x[3]) {
     x[0] = ((b[p0] - A[p0][1] * x[1]) - A[p0][2] * x[2]) / A[p0][0];
 }
 
-__global__ __launch_bounds__(256) void refine_kernel(PyrDev P, const unsigned long long* cand, const unsigned* cand_count, unsigned cand_cap,
+__global__ __launch_bounds__(256) void refine_kernel(PyrDev P, const unsigned long long* cand_all, const unsigned* cand_counts, unsigned cand_cap, unsigned* cand_total,
                                                      float contrast_thr, float edge_thr, float sigma,
                                                      Refined* out, unsigned* out_count, unsigned out_cap, unsigned* resp_hist) {
-    unsigned n = *cand_count;
+    // blockIdx.y = region of the candidate list (extrema_kernel spreads its appends over NREG counters)
+    const unsigned reg = blockIdx.y;
+    unsigned n = cand_counts[reg * REG_STRIDE];
     if (n > cand_cap) n = cand_cap;
+    const unsigned long long* cand = cand_all + (size_t)reg * cand_cap;
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+        unsigned tot = 0;
+        for (int g = 0; g < NREG; g++) tot += cand_counts[g * REG_STRIDE];
+        *cand_total = tot;
+    }
     const float img_scale = 1.0f / 255.0f;
     const float deriv_scale = img_scale * 0.5f, second_scale = img_scale, cross_scale = img_scale * 0.25f;
     for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
@@ -981,7 +996,7 @@ struct SiftWork {
     bool used = false;
     DevBuf pyr;                              // all Gaussian levels
     DevBuf claimed;                          // duplicate claim bitmaps
-    DevBuf cand, refined, kps, kresp, sel, counters, rhist;
+    DevBuf cand, refined, kps, kresp, sel, counters, rhist, ccnt;
     PyrDev P;
     size_t claimed_bytes = 0;
     unsigned cand_cap = 0, ref_cap = 0, kp_cap = 0;
@@ -1004,7 +1019,7 @@ void mi_sift_release(mi355_ctx* ctx) {
         if (s->stream) { (void)hipStreamSynchronize(s->stream); (void)hipStreamDestroy(s->stream); }
         if (s->a_done) (void)hipEventDestroy(s->a_done);
         if (s->b_done) (void)hipEventDestroy(s->b_done);
-        s->pyr.release(); s->claimed.release(); s->cand.release(); s->refined.release(); s->kps.release(); s->kresp.release(); s->sel.release(); s->counters.release(); s->rhist.release();
+        s->pyr.release(); s->claimed.release(); s->cand.release(); s->refined.release(); s->kps.release(); s->kresp.release(); s->sel.release(); s->counters.release(); s->rhist.release(); s->ccnt.release();
         delete s;
     }
     ctx->sift_slots.clear();
@@ -1096,16 +1111,19 @@ static int sift_prepare(mi355_ctx* ctx, SiftWork* s, int w, int h) {
     // 288 GB).  Refined points / keypoints must survive the contrast test: a fraction of the pixels bounds them.
     const size_t px0 = (size_t)W * H;
     if (4 * px0 + 1024 > 0xfffffff0ull) { ctx->set_error("sift: image too large"); return MI355_ERR_ARG; }
-    s->cand_cap = (unsigned)(4 * px0 + 1024);
+    // per region: tiles hash over the regions (tile index mod 64); an octave with T tiles puts at most ceil(T/64) tiles
+    // x 3*EW*EH extrema into one region, so the worst case is total/64 + one full tile per octave
+    s->cand_cap = (unsigned)((4 * px0 + 1024 + NREG - 1) / NREG + (size_t)MAX_OCT * 3 * EW * EH + 1024);
     s->ref_cap = (unsigned)(px0 / 32 + 65536);
     s->kp_cap = (unsigned)(px0 / 32 + 65536);
-    MI_HIP(s->cand.reserve((size_t)s->cand_cap * sizeof(unsigned long long)));
+    MI_HIP(s->cand.reserve((size_t)s->cand_cap * NREG * sizeof(unsigned long long)));
     MI_HIP(s->refined.reserve((size_t)s->ref_cap * sizeof(Refined)));
     MI_HIP(s->kps.reserve((size_t)s->kp_cap * sizeof(KpRec)));
     MI_HIP(s->kresp.reserve((size_t)s->kp_cap * sizeof(unsigned)));
     MI_HIP(s->sel.reserve(2048 * sizeof(SelRec)));
     MI_HIP(s->counters.reserve(64 * sizeof(unsigned)));
     MI_HIP(s->rhist.reserve(65536 * sizeof(unsigned)));
+    MI_HIP(s->ccnt.reserve(NREG * REG_STRIDE * sizeof(unsigned)));
     s->w = w; s->h = h;
     return MI355_OK;
 }
@@ -1158,6 +1176,7 @@ int mi_sift_extract_dev(mi355_ctx* ctx, int img_id, const uint8_t* d_bgr, int w,
     s->used = true;
     unsigned* cnt = s->counters.as<unsigned>();      // [0] candidates [1] refined [2] keypoints [3] n_sel [4] overflow
     MI_HIP(hipMemsetAsync(cnt, 0, 64 * sizeof(unsigned), sa));
+    MI_HIP(hipMemsetAsync(s->ccnt.p, 0, NREG * REG_STRIDE * sizeof(unsigned), sa));
     auto T1 = tnow();
     // ---- pyramid ----
     for (int o = 0; o < s->n_oct; o++) {
@@ -1185,7 +1204,7 @@ int mi_sift_extract_dev(mi355_ctx* ctx, int img_id, const uint8_t* d_bgr, int w,
         {
             ProfScope ps(ctx, "extrema", level_bytes * 6.0, sa);
             hipLaunchKernelGGL(extrema_kernel, dim3(((oc.w + EW - 1) / EW) * ((oc.h + EH - 1) / EH)), dim3(256), 0, sa,
-                               oc, o, s->cand.as<unsigned long long>(), cnt + 0, s->cand_cap);
+                               oc, o, s->cand.as<unsigned long long>(), s->ccnt.as<unsigned>(), s->cand_cap, cnt + 4);
         }
     }
     auto T2 = tnow();
@@ -1196,7 +1215,7 @@ int mi_sift_extract_dev(mi355_ctx* ctx, int img_id, const uint8_t* d_bgr, int w,
     MI_HIP(hipMemsetAsync(s->rhist.p, 0, 65536 * sizeof(unsigned), st));
     {
         ProfScope ps(ctx, "refine", 0.0, st);
-        hipLaunchKernelGGL(refine_kernel, dim3(ctx->num_cu * 8), dim3(256), 0, st, s->P, s->cand.as<unsigned long long>(), cnt + 0, s->cand_cap,
+        hipLaunchKernelGGL(refine_kernel, dim3(32, NREG), dim3(256), 0, st, s->P, s->cand.as<unsigned long long>(), s->ccnt.as<unsigned>(), s->cand_cap, cnt + 0,
                            ctx->p.contrast_threshold, ctx->p.edge_threshold, 1.6f, s->refined.as<Refined>(), cnt + 1, s->ref_cap, s->rhist.as<unsigned>());
         hipLaunchKernelGGL(resp_threshold_kernel, dim3(1), dim3(1024), 0, st, s->rhist.as<unsigned>(), cnt + 1, (unsigned)nf + 256u, cnt + 8);
     }
@@ -1230,7 +1249,7 @@ int mi_sift_extract_dev(mi355_ctx* ctx, int img_id, const uint8_t* d_bgr, int w,
         tacc[0] += tus(T0, T1); tacc[1] += tus(T1, T2); tacc[2] += tus(T2, T3); tacc[3] += tus(T3, T4); tn++;
         if (tn % 24 == 0) { fprintf(stderr, "[host timing us/frame] setup+memsets %.1f pyramid %.1f tail %.1f finish+copy %.1f\n", tacc[0] / tn, tacc[1] / tn, tacc[2] / tn, tacc[3] / tn); }
     }
-    f.caps[0] = s->cand_cap; f.caps[1] = s->ref_cap; f.caps[2] = s->kp_cap;
+    f.caps[0] = 0xffffffffu; f.caps[1] = s->ref_cap; f.caps[2] = s->kp_cap;      // candidate overflow is flagged by the kernel (cnt[4])
     if (ctx->pinned_used >= PINNED_CHUNK * 64) {           // recycle the pinned pool when nothing is pending any more
         rc = mi_resolve_features(ctx);
         if (rc != MI355_OK) return rc;

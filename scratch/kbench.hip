@@ -28,11 +28,11 @@ int main(int argc, char** argv) {
         printf("blur R=%2d: %.1f us  %.0f GB/s algorithmic\n", R, ms * 1e3, px * 8.0 / ms / 1e6);
     }
     OctaveDev oc; for (int i = 0; i < 6; i++) oc.lv[i] = lv[i]; oc.w = W; oc.h = H;
-    unsigned long long* cand; unsigned* cnt; CK(hipMalloc(&cand, 64 << 20)); CK(hipMalloc(&cnt, 256)); CK(hipMemset(cnt, 0, 256));
+    unsigned long long* cand; unsigned* cnt; CK(hipMalloc(&cand, 64 << 20)); CK(hipMalloc(&cnt, 8192)); CK(hipMemset(cnt, 0, 8192));
     for (int rep = 0; rep < 2; rep++) {
-        CK(hipMemset(cnt, 0, 256));
+        CK(hipMemset(cnt, 0, 8192));
         CK(hipEventRecord(e0, st));
-        for (int it = 0; it < 5; it++) hipLaunchKernelGGL(extrema_kernel, dim3(((W + EW - 1) / EW) * ((H + EH - 1) / EH)), dim3(256), 0, st, oc, 0, cand, cnt, 8u << 20);
+        for (int it = 0; it < 5; it++) hipLaunchKernelGGL(extrema_kernel, dim3(((W + EW - 1) / EW) * ((H + EH - 1) / EH)), dim3(256), 0, st, oc, 0, cand, cnt, (8u << 20) / 64, cnt + 2047);
         CK(hipEventRecord(e1, st)); CK(hipStreamSynchronize(st));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= 5;
         unsigned c; CK(hipMemcpy(&c, cnt, 4, hipMemcpyDeviceToHost));
