@@ -105,6 +105,14 @@ __host__ __device__ __forceinline__ int reflect101(int p, int n) {
 
 typedef float v2f __attribute__((ext_vector_type(2)));
 typedef float v4f __attribute__((ext_vector_type(4)));
+#ifdef BLUR_SCALAR_FMA
+__device__ __forceinline__ float nopack(float x) { asm volatile("" : "+v"(x)); return x; }
+__device__ __forceinline__ v2f vfma(v2f a, v2f b, v2f c) { v2f r; r.x = nopack(fmaf(a.x, b.x, c.x)); r.y = nopack(fmaf(a.y, b.y, c.y)); return r; }
+__device__ __forceinline__ v4f vfma(v4f a, v4f b, v4f c) { v4f r; r.x = nopack(fmaf(a.x, b.x, c.x)); r.y = nopack(fmaf(a.y, b.y, c.y)); r.z = nopack(fmaf(a.z, b.z, c.z)); r.w = nopack(fmaf(a.w, b.w, c.w)); return r; }
+#else
+__device__ __forceinline__ v2f vfma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ v4f vfma(v4f a, v4f b, v4f c) { return __builtin_elementwise_fma(a, b, c); }
+#endif
 
 // ---------- K1/K2: fused separable Gaussian blur ------------------------------------------------------------------
 struct BlurArgs {
@@ -225,17 +233,24 @@ __global__ __launch_bounds__(BT) void blur_tile(BlurArgs a) {
 // fma), and a 4x4 output block per lane in the column pass.  The staged tile starts at a 4-float aligned column
 // (halo RA = R rounded up to 4) so that global loads, LDS rows and the sliding windows are all 16-byte aligned.
 
+#ifndef BLUR2_NT
+#define BLUR2_NT 512
+#endif
 template <int R, bool BGR>
-__global__ __launch_bounds__(256) void blur_tile2(BlurArgs a) {
+__global__ __launch_bounds__(BLUR2_NT) void blur_tile2(BlurArgs a) {
+    constexpr int NT = BLUR2_NT;                // threads per workgroup
+    constexpr int CR = 1024 / NT;               // output rows per column-pass item (4 columns x CR rows per lane)
     constexpr int RA = (R + 3) & ~3;            // aligned halo
     constexpr int S = RA - R;                   // first tap of output 0 inside the aligned window
     constexpr int ROWS = 64 + 2 * R;
     constexpr int COLS = 64 + 2 * RA;           // multiple of 4
-    constexpr int C4 = COLS / 4;
+    constexpr int C4 = COLS / 4;                // float4 per staged row
+    constexpr int P4 = (C4 + 15) & ~15;         // LDS row pitch in float4: multiple of 256 B => the 16-lane groups of a
+                                                // ds_read_b128 (two rows of 16-byte slots) never share a bank
     constexpr int NG = (S + 2 * R + 4 + 3) / 4; // float4 groups read per row-pass item
-    constexpr int PMID = 64 + 4;                // mid pitch (floats), multiple of 4
-    constexpr int NPF = (ROWS * C4 + 255) / 256; // float4 loads per lane to stage one tile
-    __shared__ v4f s_in4[ROWS * C4];
+    constexpr int PMID = 64;                    // mid pitch (floats): 256 B rows, conflict-free for the same reason
+    constexpr int NPF = (ROWS * C4 + NT - 1) / NT; // float4 loads per lane to stage one tile
+    __shared__ v4f s_in4[ROWS * P4];
     __shared__ v4f s_mid4[ROWS * (PMID / 4)];
     float* s_in = reinterpret_cast<float*>(s_in4);
     const int tid = threadIdx.x;
@@ -256,7 +271,7 @@ __global__ __launch_bounds__(256) void blur_tile2(BlurArgs a) {
         const float* base = a.src + (size_t)(y0 - R) * a.w + (x0 - RA);
 #pragma unroll
         for (int u = 0; u < NPF; u++) {
-            const int idx = tid + 256 * u;
+            const int idx = tid + NT * u;
             if (idx < ROWS * C4) { const int ry = idx / C4, c4 = idx - ry * C4; pf[u] = *reinterpret_cast<const v4f*>(base + (size_t)ry * a.w + 4 * c4); }
         }
     };
@@ -268,15 +283,15 @@ __global__ __launch_bounds__(256) void blur_tile2(BlurArgs a) {
         // stage the current tile
         if (cur_pf) {
 #pragma unroll
-            for (int u = 0; u < NPF; u++) { const int idx = tid + 256 * u; if (idx < ROWS * C4) s_in4[idx] = pf[u]; }
+            for (int u = 0; u < NPF; u++) { const int idx = tid + NT * u; if (idx < ROWS * C4) { const int ry = idx / C4, c4 = idx - ry * C4; s_in4[ry * P4 + c4] = pf[u]; } }
         } else {
-            for (int idx = tid; idx < ROWS * COLS; idx += 256) {
+            for (int idx = tid; idx < ROWS * COLS; idx += NT) {
                 const int ry = idx / COLS, rx = idx - ry * COLS;
                 const int gy = reflect101(y0 - R + ry, a.h), gx = reflect101(x0 - RA + rx, a.w);
                 float v;
                 if (BGR) v = load_base(a.bgr, a.bgr_ws, a.w >> 1, a.h >> 1, gx, gy);
                 else v = a.src[(size_t)gy * a.w + gx];
-                s_in[idx] = v;
+                s_in[ry * (P4 * 4) + rx] = v;
             }
         }
         __syncthreads();
@@ -285,9 +300,9 @@ __global__ __launch_bounds__(256) void blur_tile2(BlurArgs a) {
         int nx0 = 0, ny0 = 0; bool next_pf = false;
         if (tn < ntiles) { tile_origin(tn, nx0, ny0); next_pf = is_interior(nx0, ny0); if (next_pf) prefetch(nx0, ny0); }
         // row pass: item = 4 adjacent outputs of one staged row; lanes walk the 16 groups of a row (contiguous 16 B slots)
-        for (int item = tid; item < ROWS * 16; item += 256) {
+        for (int item = tid; item < ROWS * 16; item += NT) {
             const int row = item >> 4, xg = item & 15;
-            const v4f* in4 = s_in4 + row * C4 + xg;
+            const v4f* in4 = s_in4 + row * P4 + xg;
             float e[NG * 4];
 #pragma unroll
             for (int g = 0; g < NG; g++) { const v4f tt = in4[g]; e[4 * g] = tt.x; e[4 * g + 1] = tt.y; e[4 * g + 2] = tt.z; e[4 * g + 3] = tt.w; }
@@ -296,38 +311,36 @@ __global__ __launch_bounds__(256) void blur_tile2(BlurArgs a) {
             for (int i = 0; i <= 2 * R; i++) {
                 const v2f kk = {a.k[i], a.k[i]};
                 const v2f e01 = {e[S + i], e[S + i + 1]}, e23 = {e[S + i + 2], e[S + i + 3]};
-                acc01 = __builtin_elementwise_fma(kk, e01, acc01);
-                acc23 = __builtin_elementwise_fma(kk, e23, acc23);
+                acc01 = vfma(kk, e01, acc01);
+                acc23 = vfma(kk, e23, acc23);
             }
             v4f o; o.x = acc01.x; o.y = acc01.y; o.z = acc23.x; o.w = acc23.y;
             s_mid4[row * (PMID / 4) + xg] = o;
         }
         __syncthreads();
-        // column pass: one item per lane = 4 columns x 4 rows of outputs
+        // column pass: one item per lane = 4 columns x CR rows of outputs
         {
             const int xg = tid & 15, yg = tid >> 4;
-            const v4f* mid4 = s_mid4 + (4 * yg) * (PMID / 4) + xg;
-            v4f acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0}, acc2 = {0, 0, 0, 0}, acc3 = {0, 0, 0, 0};
+            const v4f* mid4 = s_mid4 + (CR * yg) * (PMID / 4) + xg;
+            v4f acc[CR];
 #pragma unroll
-            for (int m = 0; m < 2 * R + 4; m++) {
+            for (int q = 0; q < CR; q++) acc[q] = (v4f){0, 0, 0, 0};
+#pragma unroll
+            for (int m = 0; m < 2 * R + CR; m++) {
                 const v4f e = mid4[m * (PMID / 4)];
-                if (m <= 2 * R) { const v4f kk = {a.k[m], a.k[m], a.k[m], a.k[m]}; acc0 = __builtin_elementwise_fma(kk, e, acc0); }
-                if (m >= 1 && m - 1 <= 2 * R) { const v4f kk = {a.k[m - 1], a.k[m - 1], a.k[m - 1], a.k[m - 1]}; acc1 = __builtin_elementwise_fma(kk, e, acc1); }
-                if (m >= 2 && m - 2 <= 2 * R) { const v4f kk = {a.k[m - 2], a.k[m - 2], a.k[m - 2], a.k[m - 2]}; acc2 = __builtin_elementwise_fma(kk, e, acc2); }
-                if (m >= 3) { const v4f kk = {a.k[m - 3], a.k[m - 3], a.k[m - 3], a.k[m - 3]}; acc3 = __builtin_elementwise_fma(kk, e, acc3); }
+#pragma unroll
+                for (int q = 0; q < CR; q++)
+                    if (m - q >= 0 && m - q <= 2 * R) { const float kq = a.k[m - q]; const v4f kk = {kq, kq, kq, kq}; acc[q] = vfma(kk, e, acc[q]); }
             }
-            const int gx = x0 + 4 * xg, gy = y0 + 4 * yg;
+            const int gx = x0 + 4 * xg, gy = y0 + CR * yg;
             if (gx + 3 < a.w && vec_st) {
                 float* d = a.dst + (size_t)gy * a.w + gx;
-                if (gy < a.h) *reinterpret_cast<v4f*>(d) = acc0;
-                if (gy + 1 < a.h) *reinterpret_cast<v4f*>(d + (size_t)a.w) = acc1;
-                if (gy + 2 < a.h) *reinterpret_cast<v4f*>(d + 2 * (size_t)a.w) = acc2;
-                if (gy + 3 < a.h) *reinterpret_cast<v4f*>(d + 3 * (size_t)a.w) = acc3;
+#pragma unroll
+                for (int q = 0; q < CR; q++) if (gy + q < a.h) *reinterpret_cast<v4f*>(d + (size_t)q * a.w) = acc[q];
             } else {
-                const v4f accs[4] = {acc0, acc1, acc2, acc3};
-                for (int r = 0; r < 4; r++)
+                for (int r = 0; r < CR; r++)
                     for (int c = 0; c < 4; c++)
-                        if (gy + r < a.h && gx + c < a.w) a.dst[(size_t)(gy + r) * a.w + gx + c] = accs[r][c];
+                        if (gy + r < a.h && gx + c < a.w) a.dst[(size_t)(gy + r) * a.w + gx + c] = acc[r][c];
             }
         }
         __syncthreads();                        // s_in / s_mid are rewritten by the next trip
@@ -969,7 +982,7 @@ bool launch_blur(hipStream_t st, int R, const BlurArgs& a) {
     const bool use2 = big;
 #endif
     if (use2) {
-        const dim3 grid(ntile < BLUR_PERSIST_BLOCKS ? ntile : BLUR_PERSIST_BLOCKS), block(256);      // persistent: 2 workgroups per CU
+        const dim3 grid(ntile < BLUR_PERSIST_BLOCKS ? ntile : BLUR_PERSIST_BLOCKS), block(BLUR2_NT);      // persistent: 2 workgroups per CU
         switch (R) {
 #define CASE(RR) case RR: hipLaunchKernelGGL((blur_tile2<RR, false>), grid, block, 0, st, a); return true;
             CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8) CASE(9) CASE(10) CASE(11) CASE(12) CASE(13) CASE(14) CASE(15) CASE(16)
