@@ -175,6 +175,36 @@ __global__ __launch_bounds__(BT) void blur_tile(BlurArgs a) {
             const int ry = idx / COLS, rx = idx - ry * COLS;
             s_in[ry * PIN + rx] = base[(size_t)ry * a.w + rx];
         }
+    } else if (BGR && interior && ((x0 - R) >> 1) >= 1 && ((y0 - R) >> 1) >= 1 &&
+               ((x0 + TW - 1 + R) >> 1) + 1 <= (a.w >> 1) - 1 && ((y0 + TH - 1 + R) >> 1) + 1 <= (a.h >> 1) - 1) {
+        // interior tile of the base level: the fixed-point gray of the low-resolution patch is computed ONCE into LDS
+        // (each frame byte is read once per tile instead of ~4x per staged sample), then up-sampled from there with the
+        // same two fmaf per axis as load_base.
+        constexpr int GW = (TW + 2 * R) / 2 + 3, GH = (TH + 2 * R) / 2 + 3;
+        __shared__ float s_gray[GH * GW];
+        const int lxa = ((x0 - R) >> 1) - 1, lya = ((y0 - R) >> 1) - 1;
+        for (int idx = tid; idx < GH * GW; idx += BT) {
+            const int gy = idx / GW, gx = idx - gy * GW;
+            const int ly = lya + gy, lx = lxa + gx;
+            float v = 0.0f;
+            if (lx < (a.w >> 1) && ly < (a.h >> 1)) {
+                const uint8_t* p = a.bgr + (size_t)ly * a.bgr_ws + 3 * lx;
+                v = (float)((1868 * (int)p[0] + 9617 * (int)p[1] + 4899 * (int)p[2] + 8192) >> 14);
+            }
+            s_gray[idx] = v;
+        }
+        __syncthreads();
+        for (int idx = tid; idx < ROWS * COLS; idx += BT) {
+            const int ry = idx / COLS, rx = idx - ry * COLS;
+            const int X = x0 - R + rx, Y = y0 - R + ry;
+            const int xl0 = ((X & 1) ? (X >> 1) : (X >> 1) - 1) - lxa, yl0 = ((Y & 1) ? (Y >> 1) : (Y >> 1) - 1) - lya;
+            const float wx1 = (X & 1) ? 0.25f : 0.75f, wy1 = (Y & 1) ? 0.25f : 0.75f;
+            const float* g0 = s_gray + yl0 * GW + xl0;
+            const float* g1 = g0 + GW;
+            const float aa = fmaf(g0[1], wx1, g0[0] * (1.0f - wx1));
+            const float bb = fmaf(g1[1], wx1, g1[0] * (1.0f - wx1));
+            s_in[ry * PIN + rx] = fmaf(bb, wy1, aa * (1.0f - wy1));
+        }
     } else {
         for (int idx = tid; idx < ROWS * COLS; idx += BT) {
             const int ry = idx / COLS, rx = idx - ry * COLS;
