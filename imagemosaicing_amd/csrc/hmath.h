@@ -192,6 +192,168 @@ HD void nlls4(const float* p, const float* H0, float* Hout, float* scratch) {
     Hout[8] = emax;
 }
 
+// ---- register-resident fast path of the 4-point solve / NLLS ---------------------------------------------------------------
+// InverseMatrix for order 8 with every index static (fully unrolled): valid when the reference's pivot search picks row i
+// for column i (the first not-yet-used row whose entry exceeds eps -- rows 0..i-1 are used by then, so this is the case
+// iff |t[i][i]| > eps) and its final "row holding an exact 1 in column r" permutation is the identity.  Both are checked;
+// when either fails the function returns false and the caller re-runs the generic routine, so the result is always the
+// reference's.  The arithmetic (including the operations on structural zeros) is the generic routine's.
+HD bool inverse8_fast(const float* src, float* dst, float eps) {
+    float t[8][16];
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+#pragma unroll
+        for (int j = 0; j < 16; j++) t[i][j] = j < 8 ? src[i * 8 + j] : (j - 8 == i ? 1.0f : 0.0f);
+    bool ok = true;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const float ei = t[i][i];
+        if (!(fabsf(ei) > eps)) ok = false;
+#pragma unroll
+        for (int c = 0; c < 16; c++) t[i][c] = t[i][c] / ei;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            if (j == i) continue;
+            const float e2 = t[j][i];
+            if (!(fabsf(e2) < eps)) {
+                const float ne = -e2;
+#pragma unroll
+                for (int c = 0; c < 16; c++) { const float prod = ne * t[i][c]; t[j][c] = t[j][c] + prod; }
+            }
+        }
+    }
+    // identity permutation check: the first row with an exact 1 in column r must be r (or there is none)
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            if (i < r && t[i][r] == 1.0f) ok = false;
+            if (i > r && t[i][r] == 1.0f && !(t[r][r] == 1.0f)) ok = false;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+#pragma unroll
+        for (int j = 0; j < 8; j++) dst[i * 8 + j] = t[i][8 + j];
+    return ok;
+}
+
+// 4-point SolveHomographyMatrix + (when 0.01 < H[8] < 5) NonlinearLeastSquareProjection2, everything in registers.
+// Returns false when an inversion needs the generic routine (caller falls back to solve_h4 / nlls4).
+HD bool hypothesis4_fast(const float* p, float* H) {
+    float A[64], M[64], inv[64], B[8];
+#pragma unroll
+    for (int i = 0; i < 64; i++) A[i] = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const float x1 = p[4 * r], y1 = p[4 * r + 1], x2 = p[4 * r + 2], y2 = p[4 * r + 3];
+        A[2 * r * 8 + 0] = x2; A[2 * r * 8 + 1] = y2; A[2 * r * 8 + 2] = 1.0f; A[2 * r * 8 + 6] = (-x1) * x2; A[2 * r * 8 + 7] = (-x1) * y2;
+        A[(2 * r + 1) * 8 + 3] = x2; A[(2 * r + 1) * 8 + 4] = y2; A[(2 * r + 1) * 8 + 5] = 1.0f; A[(2 * r + 1) * 8 + 6] = (-y1) * x2; A[(2 * r + 1) * 8 + 7] = (-y1) * y2;
+        B[2 * r] = x1; B[2 * r + 1] = y1;
+    }
+#pragma unroll
+    for (int r = 0; r < 8; r++)
+#pragma unroll
+        for (int c = 0; c < 8; c++) {
+            float acc = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 8; k++) { const float pr = A[k * 8 + r] * A[k * 8 + c]; acc = acc + pr; }
+            M[r * 8 + c] = acc;
+        }
+    // matrix.h:377: on failure the reference multiplies with an all-zero inverse.  A missing pivot (|.| <= 1e-20) is the
+    // generic routine's business.
+    if (!inverse8_fast(M, inv, 1e-20f)) return false;
+#pragma unroll
+    for (int r = 0; r < 8; r++)
+#pragma unroll
+        for (int c = 0; c < 8; c++) {
+            float acc = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 8; k++) { const float pr = inv[r * 8 + k] * A[c * 8 + k]; acc = acc + pr; }
+            M[r * 8 + c] = acc;
+        }
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        float acc = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 8; k++) { const float pr = M[r * 8 + k] * B[k]; acc = acc + pr; }
+        H[r] = acc;
+    }
+    double emax = 0.0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        float fx, fy;
+        apply_recip1(H, p[4 * i + 2], p[4 * i + 3], fx, fy);
+        const double dx = (double)p[4 * i] - (double)fx, dy = (double)p[4 * i + 1] - (double)fy;
+        const double d = sqrt(dx * dx + dy * dy);
+        if (d > emax) emax = d;
+    }
+    H[8] = (float)emax;
+    if (!(H[8] < 5.0f && H[8] > 0.01f)) return true;             // no polish (mosaicimage.h:1864-1876)
+    // ---- Gauss-Newton polish, LeastSquare.h:353-531 (J is A's storage) ----
+    float w[8], C[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) w[i] = H[i];
+    bool finished = false;
+    for (int it = 0; it < 15 && !finished; it++) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const float x2 = p[4 * i], y2 = p[4 * i + 1], x1 = p[4 * i + 2], y1 = p[4 * i + 3];
+            const float d = w[6] * x1 + w[7] * y1 + 1.0f;
+            const float nx = w[0] * x1 + w[1] * y1 + w[2];
+            const float ny = w[3] * x1 + w[4] * y1 + w[5];
+            float* j = A + i * 16;
+            j[0] = x1 / d; j[1] = y1 / d; j[2] = 1.0f / d; j[3] = 0.0f; j[4] = 0.0f; j[5] = 0.0f;
+            j[6] = ((-x1) * nx) / (d * d); j[7] = ((-y1) * nx) / (d * d);
+            j[8] = 0.0f; j[9] = 0.0f; j[10] = 0.0f; j[11] = x1 / d; j[12] = y1 / d; j[13] = 1.0f / d;
+            j[14] = ((-x1) * ny) / (d * d); j[15] = ((-y1) * ny) / (d * d);
+            C[2 * i] = x2 - nx / d; C[2 * i + 1] = y2 - ny / d;
+        }
+#pragma unroll
+        for (int r = 0; r < 8; r++)
+#pragma unroll
+            for (int c = 0; c < 8; c++) {
+                float acc = 0.0f;
+#pragma unroll
+                for (int k = 0; k < 8; k++) { const float pr = A[k * 8 + r] * A[k * 8 + c]; acc = acc + pr; }
+                M[r * 8 + c] = acc;
+            }
+        if (!inverse8_fast(M, inv, 1e-6f)) return false;
+#pragma unroll
+        for (int r = 0; r < 8; r++)
+#pragma unroll
+            for (int c = 0; c < 8; c++) {
+                float acc = 0.0f;
+#pragma unroll
+                for (int k = 0; k < 8; k++) { const float pr = inv[r * 8 + k] * A[c * 8 + k]; acc = acc + pr; }
+                M[r * 8 + c] = acc;
+            }
+        bool done = true;
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            float acc = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 8; k++) { const float pr = M[r * 8 + k] * C[k]; acc = acc + pr; }
+            w[r] = w[r] + acc;
+            if (!(fabsf(acc) < 1e-10f)) done = false;
+        }
+        finished = done;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; i++) H[i] = w[i];
+    float em = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        float fx, fy;
+        apply_recip1(H, p[4 * i + 2], p[4 * i + 3], fx, fy);
+        const float dx = p[4 * i] - fx, dy = p[4 * i + 1] - fy;
+        const float d = sqrtf(dx * dx + dy * dy);
+        if (d > em) em = d;
+    }
+    H[8] = em;
+    return true;
+}
+
 // the pixel expression of every warp (MosaicWithoutPos.cpp:2331-2334, MosaicImage.cpp:1715-1719):
 // (uchar)( s00*(1-p)*(1-q) + s01*(1-p)*q + s10*p*(1-q) + s11*p*q ), terms ((s*a)*b), summed left to right
 HD unsigned char bilin(float s00, float s01, float s10, float s11, float p, float q) {

@@ -178,7 +178,6 @@ __global__ void finalize_kernel(const PairDesc* pairs, const int* nsel, int n_pa
     out[p].i = pairs[p].img_i; out[p].j = pairs[p].img_j;
     out[p].n_selected = nsel[p];
     out[p].accepted = out[p].n_in > min_inliers ? 1 : 0;          // MosaicWithoutPos.cpp:5201
-    out[p]._pad = 0;
 }
 
 // ---- features ------------------------------------------------------------------------------------------------

@@ -58,6 +58,7 @@ __global__ __launch_bounds__(RB) void ransac_kernel(RansacArgs a) {
     __shared__ float s_bestH[9], s_firstH[9], s_w[8], s_dX[8], s_T1[64], s_T2[64], s_t[128];
     __shared__ int   s_state[8];      // 0 t_acc, 1 maxSupport, 2 bestDraw, 3 firstAcc, 4 finished, 5 newBest, 6 newFirst, 7 done
     __shared__ int   s_wtot[RB / 64 + 1];
+    __shared__ int   s_fb;            // draws that needed the generic (private-memory) solve: diagnostic, reported in _pad
 
     const int pair = blockIdx.x;
     const int tid = threadIdx.x;
@@ -67,6 +68,7 @@ __global__ __launch_bounds__(RB) void ransac_kernel(RansacArgs a) {
     const mi355_sfpoint* P2 = a.p2 + (size_t)pair * a.stride;
 
     if (tid < 9) out->H[tid] = 0.0f;
+    if (tid == 0) { s_fb = 0; out->_pad = 0; }
     if (n < 4 || a.sample_times < 1) {                     // mosaicimage.h:1739-1761
         if (tid == 0) { out->n_in = 0; out->ok = 0; }
         return;
@@ -98,16 +100,22 @@ __global__ __launch_bounds__(RB) void ransac_kernel(RansacArgs a) {
             const uint16_t* s = table + 4 * r;
 #pragma unroll
             for (int i = 0; i < 4; i++) { const int k = s[i]; p[4 * i] = x1[k]; p[4 * i + 1] = y1[k]; p[4 * i + 2] = x2[k]; p[4 * i + 3] = y2[k]; }
-            hm::solve_h4(p, h, scratch);                   // :1863
-            if (h[8] > 5.0f) flag = 0;                     // :1864-1867 skipped, no slot consumed
-            else {
-                flag = 1;
-                if (h[8] < 5.0f && h[8] > 0.01f) {         // :1868-1876
+            // register-resident solve + polish; the (rare) draws whose inversion needs the reference's general pivot
+            // search re-run the generic private-memory routines, wave by wave
+            const bool fast_ok = hm::hypothesis4_fast(p, h);
+            if (!fast_ok) {
+                atomicAdd(&s_fb, 1);                        // statistics only (reported in _pad)
+                hm::solve_h4(p, h, scratch);               // :1863
+                if (!(h[8] > 5.0f) && h[8] < 5.0f && h[8] > 0.01f) {   // :1868-1876
                     float fine[9];
                     hm::nlls4(p, h, fine, scratch);
 #pragma unroll
                     for (int i = 0; i < 9; i++) h[i] = fine[i];
                 }
+            }
+            if (h[8] > 5.0f) flag = 0;                     // :1864-1867 skipped, no slot consumed
+            else {
+                flag = 1;
                 for (int i = 0; i < n; i++) {              // :1890-1904
                     float bx, by;
                     hm::apply_recip1(h, x2[i], y2[i], bx, by);
@@ -256,6 +264,7 @@ __global__ __launch_bounds__(RB) void ransac_kernel(RansacArgs a) {
         out->H[8] = __uint_as_float(m);
         out->n_in = cnt;
         out->ok = 1;
+        out->_pad = s_fb;
     }
 }
 

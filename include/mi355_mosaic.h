@@ -59,7 +59,7 @@ typedef struct {
     int32_t ok;              /* Ransac2D's bool */
     int32_t accepted;        /* n_in > min_inliers */
     float   H[9];            /* image j -> image i, H[8] = max residual */
-    int32_t _pad;
+    int32_t _pad;            /* diagnostic: RANSAC draws that took the generic solve path (0 in the common case) */
     mi355_sfpoint a[MI355_MAX_SELECTED];   /* inliers in image i (id = keypoint index) */
     mi355_sfpoint b[MI355_MAX_SELECTED];   /* inliers in image j */
 } mi355_pair_result;
