@@ -44,6 +44,8 @@ def parse():
     ap.add_argument("--window", type=int, default=2, help="pair window: j in (i, i+window); 2 = adjacent pairs (C3), 182 = reference window (C4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-all", action="store_true", help="bracket every kernel class with events (extra JSON field)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for single-GPU dry runs of the N>1 path)")
+    ap.add_argument("--all-ranks-on-device0", action="store_true", help="dry run of the N>1 path on a 1-GPU box (use with --backend gloo)")
     return ap.parse_args()
 
 
@@ -58,7 +60,7 @@ def frame_layout(n, w, h, rank, seed=0xC0FFEE):
         if row & 1:
             col = per_row - 1 - col
         cx = w / 2 + col * sx + rng.uniform(-0.01, 0.01) * w
-        cy = h / 2 + row * sy + rng.uniform(-0.01, 0.01) * h + rank * (sy * ((n + per_row - 1) // per_row) + h)
+        cy = h / 2 + row * sy + rng.uniform(-0.01, 0.01) * h      # every rank's strip uses its own terrain seed (below), same extent
         yaw = np.deg2rad(rng.uniform(-3, 3))
         s = 1 + rng.uniform(-0.02, 0.02)
         R = s * np.array([[np.cos(yaw), -np.sin(yaw)], [np.sin(yaw), np.cos(yaw)]])
@@ -123,11 +125,16 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != max(args.gpus, 1) and world > 1:
         raise SystemExit("WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus))
+    if args.all_ranks_on_device0:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
 
     import imagemosaicing_amd as im
     from imagemosaicing_amd import dist as md
@@ -145,7 +152,7 @@ def main():
     # ---- synthetic frames, generated straight into HBM (never timed) ----
     frames = torch.empty((F, h * ws), dtype=torch.uint8, device=dev)
     for k in range(F):
-        ctx.SynthFrameDev(frames[k].data_ptr(), w, h, ws, A[k], 0xC0FFEE, (rank * 1000003 + k) & 0xffffffff, gains[k], 2.0)
+        ctx.SynthFrameDev(frames[k].data_ptr(), w, h, ws, A[k], (0xC0FFEE + 977 * rank) & 0xffffffff, (rank * 1000003 + k) & 0xffffffff, gains[k], 2.0)
     ctx.synchronize()
     fptr = [frames[k].data_ptr() for k in range(F)]
     pairs = im.pair_schedule(F, args.window)
@@ -184,6 +191,7 @@ def main():
         state.update(r=r, cw=cw, ch=ch, n_valid=int(label.sum()))
 
     def barrier():
+        torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()

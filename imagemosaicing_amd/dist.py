@@ -22,6 +22,11 @@ def allgather_pair_results(local, n_local_max=None):
     world = dist.get_world_size() if dist.is_initialized() else 1
     if world == 1:
         return local.unsqueeze(0), [local.shape[0]]
+    if dist.get_backend() == "gloo" and local.is_cuda:
+        # gloo has no device all_gather: stage through the host (CPU tests and single-GPU dry runs of bench.py only;
+        # production uses backend "nccl" = RCCL, device to device over xGMI)
+        g, counts = allgather_pair_results(local.cpu(), n_local_max)
+        return g.to(local.device), counts
     n = torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device)
     counts = [torch.zeros_like(n) for _ in range(world)]
     dist.all_gather(counts, n)

@@ -1,0 +1,51 @@
+"""GPU: bench.py end to end on a small workload -- the JSON contract of the driver (fields, roofline and cpu_baseline
+objects) and the quality of the result against the synthetic ground truth."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_contract_small():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "1",
+                        "--frames", "6", "--width", "1000", "--height", "750"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 1 and d["higher_is_better"] is True and d["vs_baseline"] is None and d["data"] == "synthetic"
+    assert "workload" in d["config"] and "model" not in d["config"]
+    rf = d["roofline"]
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0
+    q = d["quality"]
+    assert q["pairs"] == 5 and q["pairs_accepted"] == 5 and q["images_aligned"] == 6
+    assert q["h_corner_err_px_median"] < 0.5
+    assert d["value"] > 0
+
+
+def test_bench_two_ranks_dry_run_on_one_gpu():
+    """the N>1 code path of bench.py (per-rank strips, all-gather of the pair records, max-over-ranks timing, rank-0 JSON)
+    with two processes sharing GPU 0 and gloo standing in for RCCL (RCCL refuses two ranks on one device)"""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
+           "--frames", "5", "--width", "1000", "--height", "750", "--backend", "gloo", "--all-ranks-on-device0"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "exactly one JSON line (rank 0)"
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["cpu_baseline"] is None
+    assert d["config"]["pairs_per_gpu"] == 4 and d["quality"]["pairs_accepted"] == 4
+    # whole-job aggregate: 2 ranks x 4 pairs per step
+    assert abs(d["value"] - 8 / (d["ms_per_step"] / 1e3)) / d["value"] < 1e-6
