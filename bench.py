@@ -30,6 +30,7 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+SLOTS = 4                  # frames in flight during the timed region (library default)
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md (6.29 TB/s measured copy)
 
 
@@ -139,6 +140,7 @@ def main():
     import imagemosaicing_amd as im
     from imagemosaicing_amd import dist as md
     ctx = im.Context(local_rank)
+    ctx.set_option("sift_slots", SLOTS)
     # One explicit stream for everything (HIP kernels of the library, torch copies, RCCL): torch's default stream
     # is the NULL stream, which the library's set_stream treats as "use the ctx-owned stream".
     stream = torch.cuda.Stream(device=dev)
@@ -231,7 +233,7 @@ def main():
             ctx.SiftExtractDev(k, fptr[k], w, h, ws)
         i_ms, i_n, i_bytes = ctx.profile_get("gauss")
         ctx.profile_enable(False)
-        ctx.set_option("sift_slots", 3)
+        ctx.set_option("sift_slots", SLOTS)
         if i_ms > 0:
             iso = {"achieved": (i_bytes / 1e9) / (i_ms / 1e3), "frac": (i_bytes / 1e9) / (i_ms / 1e3) / HBM_PEAK_GBS, "frames": nf_iso,
                    "avg_launch_us": i_ms * 1e3 / max(i_n, 1), "note": "same kernel, one frame in flight (no overlap with other kernels), untimed extra pass"}
@@ -269,7 +271,7 @@ def main():
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "launches": int(g_n), "avg_launch_us": (g_ms * 1e3 / g_n) if g_n else None,
                          "algorithmic_bytes_per_frame": g_bytes / max(args.steps * F, 1),
-                         "frames_in_flight": 3, "standalone": iso},
+                         "frames_in_flight": SLOTS, "standalone": iso},
             "quality": {"pairs_accepted": accepted, "pairs": n_pairs, "images_aligned": state["n_valid"],
                         "h_corner_err_px_median": float(np.median(errs)) if errs else None,
                         "h_corner_err_px_max": float(np.max(errs)) if errs else None},

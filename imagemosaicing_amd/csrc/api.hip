@@ -52,7 +52,7 @@ extern "C" int mi355_create(mi355_ctx** out, const mi355_params* params, int dev
     e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
     if (e != hipSuccess) { g_create_error = hipGetErrorString(e); delete c; return MI355_ERR_DEVICE; }
     c->stream = c->own_stream;
-    if (const char* e = getenv("MI355_SIFT_SLOTS")) { const int v = atoi(e); c->sift_nslots = v < 1 ? 1 : (v > 4 ? 4 : v); }
+    if (const char* e = getenv("MI355_SIFT_SLOTS")) { const int v = atoi(e); c->sift_nslots = v < 1 ? 1 : (v > 8 ? 8 : v); }
     *out = c;
     return MI355_OK;
 }
@@ -274,7 +274,7 @@ extern "C" int mi355_set_option(mi355_ctx* ctx, const char* name, int value) {
     if (std::string(name) == "sift_slots") {
         int rc = mi_resolve_features(ctx);
         if (rc != MI355_OK) return rc;
-        ctx->sift_nslots = value < 1 ? 1 : (value > 4 ? 4 : value);
+        ctx->sift_nslots = value < 1 ? 1 : (value > 8 ? 8 : value);
         return MI355_OK;
     }
     ctx->set_error(std::string("set_option: unknown option ") + name);

@@ -78,7 +78,7 @@ struct mi355_ctx {
     std::map<std::string, ProfClass> prof;
     std::vector<SiftWork*> sift_slots;                 // one work area + stream per in-flight frame
     int sift_next = 0;
-    int sift_nslots = 3;                               // frames in flight (mi355_set_option "sift_slots", env MI355_SIFT_SLOTS)
+    int sift_nslots = 4;                               // frames in flight (mi355_set_option "sift_slots", env MI355_SIFT_SLOTS)
     hipEvent_t sift_in_ev = nullptr;                   // orders the SIFT streams after the caller's stream
     hipStream_t sift_heavy = nullptr;                  // stage A (pyramid + extrema) of every frame, in order
     std::vector<int*> pinned_chunks;                   // pinned count slots, 8 ints per frame

@@ -266,13 +266,17 @@ __global__ __launch_bounds__(BT) void blur_tile(BlurArgs a) {
 #ifndef BLUR2_NT
 #define BLUR2_NT 512
 #endif
+#ifndef BLUR2_TH
+#define BLUR2_TH 64
+#endif
 template <int R, bool BGR>
 __global__ __launch_bounds__(BLUR2_NT) void blur_tile2(BlurArgs a) {
     constexpr int NT = BLUR2_NT;                // threads per workgroup
-    constexpr int CR = 1024 / NT;               // output rows per column-pass item (4 columns x CR rows per lane)
+    constexpr int TH2 = BLUR2_TH;               // tile height (width is 64)
+    constexpr int CR = TH2 * 16 / NT;           // output rows per column-pass item (4 columns x CR rows per lane)
     constexpr int RA = (R + 3) & ~3;            // aligned halo
     constexpr int S = RA - R;                   // first tap of output 0 inside the aligned window
-    constexpr int ROWS = 64 + 2 * R;
+    constexpr int ROWS = TH2 + 2 * R;
     constexpr int COLS = 64 + 2 * RA;           // multiple of 4
     constexpr int C4 = COLS / 4;                // float4 per staged row
     constexpr int P4 = (C4 + 15) & ~15;         // LDS row pitch in float4: multiple of 256 B => the 16-lane groups of a
@@ -294,9 +298,9 @@ __global__ __launch_bounds__(BLUR2_NT) void blur_tile2(BlurArgs a) {
     auto tile_origin = [&](int t, int& x0, int& y0) {
         const int tile = xcd_remap(t, ntiles);
         const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
-        x0 = tx * 64; y0 = ty * 64;
+        x0 = tx * 64; y0 = ty * TH2;
     };
-    auto is_interior = [&](int x0, int y0) { return vec_ok && (x0 - RA >= 0) && (y0 - R >= 0) && (x0 + 64 + RA <= a.w) && (y0 + 64 + R <= a.h); };
+    auto is_interior = [&](int x0, int y0) { return vec_ok && (x0 - RA >= 0) && (y0 - R >= 0) && (x0 + 64 + RA <= a.w) && (y0 + TH2 + R <= a.h); };
     auto prefetch = [&](int x0, int y0) {
         const float* base = a.src + (size_t)(y0 - R) * a.w + (x0 - RA);
 #pragma unroll
@@ -1012,9 +1016,12 @@ bool launch_blur(hipStream_t st, int R, const BlurArgs& a) {
     const bool use2 = big;
 #endif
     if (use2) {
-        const dim3 grid(ntile < BLUR_PERSIST_BLOCKS ? ntile : BLUR_PERSIST_BLOCKS), block(BLUR2_NT);      // persistent: 2 workgroups per CU
+        BlurArgs a2 = a;
+        a2.tiles_y = (a.h + BLUR2_TH - 1) / BLUR2_TH;
+        const int ntile2 = a2.tiles_x * a2.tiles_y;
+        const dim3 grid(ntile2 < BLUR_PERSIST_BLOCKS ? ntile2 : BLUR_PERSIST_BLOCKS), block(BLUR2_NT);      // persistent workgroups
         switch (R) {
-#define CASE(RR) case RR: hipLaunchKernelGGL((blur_tile2<RR, false>), grid, block, 0, st, a); return true;
+#define CASE(RR) case RR: hipLaunchKernelGGL((blur_tile2<RR, false>), grid, block, 0, st, a2); return true;
             CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8) CASE(9) CASE(10) CASE(11) CASE(12) CASE(13) CASE(14) CASE(15) CASE(16)
 #undef CASE
             default: return false;
@@ -1053,7 +1060,7 @@ struct SiftWork {
 // Stage B (refine, orientation, top-k, descriptors: latency-bound, a few workgroups) runs on the slot's own stream
 // and overlaps stage A of the following frames.  Each slot owns a ~5 GB work area at 12 MP; a slot's pyramid is
 // reused by frame k+SIFT_SLOTS only after stage B of frame k finished (event).
-constexpr int SIFT_SLOTS_MAX = 4;
+constexpr int SIFT_SLOTS_MAX = 8;
 #define SIFT_SLOTS (ctx->sift_nslots)
 
 void mi_sift_release(mi355_ctx* ctx) {

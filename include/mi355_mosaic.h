@@ -91,7 +91,7 @@ const char* mi355_last_error(mi355_ctx* ctx);          /* ctx may be NULL: last 
 /* Run on a caller-provided hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); NULL = ctx-owned stream. */
 int  mi355_set_stream(mi355_ctx* ctx, void* hip_stream);
 int  mi355_synchronize(mi355_ctx* ctx);
-/* Tunables: "sift_slots" = frames whose detect+describe may be in flight at once (1..4, default 3; each slot owns a
+/* Tunables: "sift_slots" = frames whose detect+describe may be in flight at once (1..8, default 4; each slot owns a
  * pyramid work area, 4.7 GB at 4000x3000). */
 int  mi355_set_option(mi355_ctx* ctx, const char* name, int value);
 void mi355_free(void* p);                               /* frees host buffers returned by this library */

@@ -60,6 +60,10 @@ int  orc_match_pair(const float* kp1xy, const uint8_t* d1, int n1, const float* 
                     int width, int height, float ransac_dist, unsigned seed,
                     orc_sfpoint* in1, orc_sfpoint* in2, float H[9], int* n_selected);
 
+int  orc_match_pair_ratio(const float* kp1xy, const uint8_t* d1, int n1, const float* kp2xy, const uint8_t* d2, int n2,
+                          int width, int height, float ransac_dist, unsigned seed, float ratio,
+                          orc_sfpoint* in1, orc_sfpoint* in2, float H[9], int* n_selected);
+
 /* ---- oracle_warp.c ------------------------------------------------------- */
 /* MosaicImage.cpp:1613-1758; *dst malloc'd (free with orc_free) */
 int  orc_image_projection_transform(const uint8_t* src, int w, int h, int ws, int ch, const float h9[9],

@@ -79,20 +79,42 @@ int orc_match_pair(const float* kp1xy, const uint8_t* d1, int n1, const float* k
                    int width, int height, float ransac_dist, unsigned seed,
                    orc_sfpoint* in1, orc_sfpoint* in2, float H[9], int* n_selected)
 {
+    return orc_match_pair_ratio(kp1xy, d1, n1, kp2xy, d2, n2, width, height, ransac_dist, seed, 0.0f, in1, in2, H, n_selected);
+}
+
+/* ratio > 0: Lowe's ratio test on squared distances (d1 < ratio^2 * d2, both as float) removes matches BEFORE the grid
+ * walk (north_star option; not in the reference, which has no ratio test -- SURVEY 0.1).  nMatch is still computed from the
+ * number of 1-NN matches M like MosaicWithoutPos.cpp:5146-5147. */
+int orc_match_pair_ratio(const float* kp1xy, const uint8_t* d1, int n1, const float* kp2xy, const uint8_t* d2, int n2,
+                         int width, int height, float ransac_dist, unsigned seed, float ratio,
+                         orc_sfpoint* in1, orc_sfpoint* in2, float H[9], int* n_selected)
+{
     if (n_selected) *n_selected = 0;
     for (int i = 0; i < 9; i++) H[i] = 0.0f;
     if (n1 <= 0 || n2 <= 0) return 0;
     int32_t* idx = (int32_t*)malloc(sizeof(int32_t) * (size_t)n1);
     int32_t* dd  = (int32_t*)malloc(sizeof(int32_t) * (size_t)n1);
     int32_t* m   = (int32_t*)malloc(sizeof(int32_t) * (size_t)n1 * 2);
-    orc_bf_match(d1, n1, d2, n2, idx, dd, NULL);
+    int32_t* d2nd = (int32_t*)malloc(sizeof(int32_t) * (size_t)n1);
+    orc_bf_match(d1, n1, d2, n2, idx, dd, d2nd);
     orc_sort_matches(idx, dd, n1, m);
+    int nm = n1;
+    if (ratio > 0.0f) {                              /* drop the matches failing the ratio test, order kept */
+        const float r2 = ratio * ratio;
+        int k = 0;
+        for (int i = 0; i < n1; i++) {
+            int q = m[2 * i];
+            if ((float)dd[q] < r2 * (float)d2nd[q]) { m[2 * k] = m[2 * i]; m[2 * k + 1] = m[2 * i + 1]; k++; }
+        }
+        nm = k;
+    }
+    free(d2nd);
     double lim = 0.3 * (double)n1;                                   /* :5146-5147  Min(400, 0.3*M) -> int */
     int nMatch = (int)(400.0 < lim ? 400.0 : lim);
     orc_sfpoint* s1 = (orc_sfpoint*)malloc(sizeof(orc_sfpoint) * (size_t)n1);
     orc_sfpoint* s2 = (orc_sfpoint*)malloc(sizeof(orc_sfpoint) * (size_t)n1);
     int ns = 0;
-    orc_select_match_pairs(m, n1, kp1xy, kp2xy, nMatch, width, height, 3, 3, s1, s2, &ns);   /* :5149-5153 */
+    orc_select_match_pairs(m, nm, kp1xy, kp2xy, nMatch, width, height, 3, 3, s1, s2, &ns);   /* :5149-5153 */
     if (n_selected) *n_selected = ns;
     int nin = 0;
     orc_ransac2d(s1, s2, ns, ransac_dist, 1000, seed, in1, in2, &nin, H);                     /* :5169 */

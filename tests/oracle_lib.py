@@ -110,6 +110,21 @@ class Oracle:
         self.L.orc_sort_matches(_p(np.ascontiguousarray(idx, np.int32)), _p(np.ascontiguousarray(d2, np.int32)), len(idx), _p(out))
         return out
 
+    def match_pair_ratio(self, kp1, d1, kp2, d2, w, h, dist, seed, ratio):
+        kp1 = np.ascontiguousarray(kp1, np.float32)
+        kp2 = np.ascontiguousarray(kp2, np.float32)
+        d1 = np.ascontiguousarray(d1, np.uint8)
+        d2 = np.ascontiguousarray(d2, np.uint8)
+        n1 = len(kp1)
+        i1 = np.zeros(max(n1, 1), SFPOINT)
+        i2 = np.zeros(max(n1, 1), SFPOINT)
+        H = np.zeros(9, np.float32)
+        ns = C.c_int(0)
+        self.L.orc_match_pair_ratio.restype = C.c_int
+        nin = self.L.orc_match_pair_ratio(_p(kp1), _p(d1), n1, _p(kp2), _p(d2), len(kp2), w, h, C.c_float(dist), C.c_uint(seed), C.c_float(ratio),
+                                          _p(i1), _p(i2), _p(H), C.byref(ns))
+        return nin, i1, i2, H, ns.value
+
     def match_pair(self, kp1, d1, kp2, d2, w, h, dist, seed):
         kp1 = np.ascontiguousarray(kp1, np.float32)
         kp2 = np.ascontiguousarray(kp2, np.float32)

@@ -218,3 +218,53 @@ def test_match_pairs_vs_oracle(ctx, oracle):
             assert np.array_equal(bits(r["H"]), bits(H))
     assert int(res[0]["accepted"]) == 1 and int(res[3]["accepted"]) == 0
     ctx.DropFeatures(-1)
+
+
+def test_match_pairs_ratio_option_vs_oracle(oracle):
+    """north_star option: Lowe ratio test before the grid walk (mi355_params.ratio)"""
+    import imagemosaicing_amd as im
+    p = im.default_params()
+    p.ratio = 0.8
+    c = im.Context(0, p)
+    rng = np.random.default_rng(3)
+    kp1, d1, kp2, d2 = _synthetic_feature_pair(rng, n=1500)
+    c.SetFeatures(0, kp1, d1.astype(np.float32), 4000, 3000)
+    c.SetFeatures(1, kp2, d2.astype(np.float32), 4000, 3000)
+    r = c.MatchPairs([(0, 1)], 2.5, 9)[0]
+    xy1 = np.stack([kp1["x"], kp1["y"]], 1); xy2 = np.stack([kp2["x"], kp2["y"]], 1)
+    nin, i1, i2, H, ns = oracle.match_pair_ratio(xy1, d1, xy2, d2, 4000, 3000, 2.5, 9, 0.8)
+    assert int(r["n_selected"]) == ns and ns > 0
+    n_in = int(r["n_in"])
+    assert (n_in if n_in > 30 else 0) == nin
+    assert np.array_equal(r["a"][:n_in], i1[:n_in]) and np.array_equal(bits(r["H"]), bits(H))
+    # the ratio test removes the unmatched third of the keypoints: fewer selected than without it
+    nin0, _, _, _, ns0 = oracle.match_pair(xy1, d1, xy2, d2, 4000, 3000, 2.5, 9)
+    assert ns <= ns0
+    c.close()
+
+
+def test_match_pairs_degenerate_inputs(ctx):
+    """empty / tiny feature sets: no crash, pair rejected (the reference appends nothing, MosaicWithoutPos.cpp:5222-5227)"""
+    from imagemosaicing_amd import KEYPOINT
+    rng = np.random.default_rng(8)
+    kp = np.zeros(3, KEYPOINT); kp["x"] = [10, 20, 30]; kp["y"] = [5, 6, 7]
+    d = _rand_desc(rng, 3).astype(np.float32)
+    ctx.SetFeatures(50, kp, d, 640, 480)
+    ctx.SetFeatures(51, kp[:0], d[:0], 640, 480)
+    ctx.SetFeatures(52, kp, d, 640, 480)
+    res = ctx.MatchPairs([(50, 51), (51, 50), (50, 52)], 2.5, 1)
+    assert (res["accepted"] == 0).all() and (res["n_in"] <= 3).all()
+    with pytest.raises(Exception):
+        ctx.MatchPairs([(50, 99)], 2.5, 1)          # unknown image id -> MI355_ERR_ARG
+    ctx.DropFeatures(-1)
+
+
+def test_chips_keep_and_invalid_flags(ctx, oracle):
+    imgs, h9s = mosaic_case()
+    keep = np.array([1, 0, 1, 1], np.uint8)
+    h9s[2, 8] = 0          # invalid image convention
+    ref = oracle.chips_and_masks(imgs, h9s, keep=keep, find_masks=True)
+    got = ctx.ChipsAndMasks(imgs, h9s, keep=keep, find_masks=True)
+    assert [int(c["img"]) for c in got["chips"]] == [int(c["img"]) for c in ref["chips"]] == [0, 3]
+    for k in range(2):
+        assert np.array_equal(got["chip_imgs"][k], ref["chip_imgs"][k]) and np.array_equal(got["masks"][k], ref["masks"][k])
