@@ -52,6 +52,7 @@ extern "C" int mi355_create(mi355_ctx** out, const mi355_params* params, int dev
     e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
     if (e != hipSuccess) { g_create_error = hipGetErrorString(e); delete c; return MI355_ERR_DEVICE; }
     c->stream = c->own_stream;
+    if (const char* e = getenv("MI355_BLUR_STREAM")) c->blur_stream = atoi(e) ? 1 : 0;
     if (const char* e = getenv("MI355_SIFT_SLOTS")) { const int v = atoi(e); c->sift_nslots = v < 1 ? 1 : (v > 8 ? 8 : v); }
     *out = c;
     return MI355_OK;
@@ -277,6 +278,7 @@ extern "C" int mi355_set_option(mi355_ctx* ctx, const char* name, int value) {
         ctx->sift_nslots = value < 1 ? 1 : (value > 8 ? 8 : value);
         return MI355_OK;
     }
+    if (std::string(name) == "blur_stream") { ctx->blur_stream = value ? 1 : 0; return MI355_OK; }
     ctx->set_error(std::string("set_option: unknown option ") + name);
     return MI355_ERR_ARG;
 }

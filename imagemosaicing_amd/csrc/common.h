@@ -78,6 +78,7 @@ struct mi355_ctx {
     std::map<std::string, ProfClass> prof;
     std::vector<SiftWork*> sift_slots;                 // one work area + stream per in-flight frame
     int sift_next = 0;
+    int blur_stream = 1;                               // big pyramid levels through blur_stream (0: tile kernel only); option "blur_stream"
     int sift_nslots = 4;                               // frames in flight (mi355_set_option "sift_slots", env MI355_SIFT_SLOTS)
     hipEvent_t sift_in_ev = nullptr;                   // orders the SIFT streams after the caller's stream
     hipStream_t sift_heavy = nullptr;                  // stage A (pyramid + extrema) of every frame, in order

@@ -26,6 +26,7 @@
 //                         64-bit LDS atomics (order-free by definition), normalise / clip / renormalise -> u8
 #include "common.h"
 #include <cmath>
+#include <type_traits>
 #include <chrono>
 
 namespace {
@@ -379,6 +380,121 @@ __global__ __launch_bounds__(BLUR2_NT) void blur_tile2(BlurArgs a) {
         }
         __syncthreads();                        // s_in / s_mid are rewritten by the next trip
         x0 = nx0; y0 = ny0; cur_pf = next_pf;
+    }
+}
+
+// ---- blur_stream: barrier-free streaming variant for the big levels ------------------------------------------------
+// Same arithmetic again (acc = 0; acc = fmaf(k[i], x[i], acc), ascending i, rows then columns).  One WAVE owns a strip
+// of 256 columns (4 per lane) and walks down L output rows of it: every input row is read once from HBM (prefetched D
+// rows ahead into registers), exchanged with the neighbour lanes through a wave-private LDS row (no workgroup barrier
+// anywhere: LDS operations of one wave execute in order), filtered horizontally from a sliding register window, and
+// scattered into the 2R+1 column accumulators that live in registers -- output row o receives its taps in ascending
+// order because the input rows arrive in ascending order.  The accumulator ring is NP >= 2R+1 slots and the row loop is
+// unrolled NP times, so every ring / prefetch index is a compile-time constant.
+// d = (k,k) * x + c with k the low / high float of an SGPR pair: op_sel broadcasts one half of the scalar operand, so the
+// 2R+1 taps cost R+1 SGPR pairs (the compiler's own lowering materialises a (k,k) pair per tap and runs out of SGPRs)
+__device__ __forceinline__ void pkfma_klo(v2f kp, v2f x, v2f& c) { asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(c) : "s"(kp), "v"(x)); }
+__device__ __forceinline__ void pkfma_khi(v2f kp, v2f x, v2f& c) { asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(c) : "s"(kp), "v"(x)); }
+// first tap of a chain: d = (k,k) * x + 0 (low half of the pair: tap 0)
+__device__ __forceinline__ v2f pkfma_klo0(v2f kp, v2f x) { v2f d; asm("v_pk_fma_f32 %0, %1, %2, 0 op_sel_hi:[0,1,0]" : "=v"(d) : "s"(kp), "v"(x)); return d; }
+
+// compile-time row loop (the unrolled body must see its ring slot as a constant; #pragma unroll gives up on bodies this large)
+template <int J, int NPP, class F> __device__ __forceinline__ bool static_rows(F& f) {
+    if constexpr (J < NPP) { if (!f(std::integral_constant<int, J>{})) return false; return static_rows<J + 1, NPP>(f); }
+    else return true;
+}
+
+template <int R, int D>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void blur_stream(BlurArgs a, int L, int nstrip, int nseg) {
+    constexpr int N = 2 * R + 1;
+    constexpr int NP0 = ((N + D - 1) / D) * D;
+    constexpr int NP = (NP0 & 1) ? NP0 + D : NP0;   // even (two LDS rows alternate) and a multiple of D
+    constexpr int RA = (R + 3) & ~3, S = RA - R, SW = 256, BW = SW + 2 * RA;
+    constexpr int NG = (S + 2 * R + 4 + 3) / 4;
+    static_assert(NP % D == 0 && NP % 2 == 0 && NP >= N, "ring");
+    __shared__ v4f s_buf[4][2][(BW + 64) / 4];      // + 64 floats: dump area for lanes that have no halo / fix-up work
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int unit = xcd_remap(blockIdx.x, gridDim.x) * 4 + wave;
+    const int seg = unit / nstrip, strip = unit - seg * nstrip;
+    if (seg >= nseg) return;
+    const int x0 = strip * SW, y0 = seg * L;
+    const int lact = (a.h - y0 < L) ? a.h - y0 : L;
+    const int nin = lact + 2 * R;
+    // columns: main float4 (clamped into the row for a partial last strip), one halo dword per lane (reflect-101),
+    // and for a partial last strip the reflected columns right of the image are patched inside LDS
+    const int xm = x0 + 4 * lane;
+    const int xl = xm < a.w - 4 ? xm : a.w - 4;
+    const int chalo = reflect101((lane < RA) ? x0 - RA + lane : (lane < 2 * RA ? x0 + SW + (lane - RA) : x0), a.w);
+    const int hpos = (lane < RA) ? lane : (lane < 2 * RA ? SW + lane : BW + lane - 2 * RA);
+    const int wv = a.w - x0;                         // valid columns of this strip (>= R + 1, checked by the launcher)
+    const bool patch = (wv < SW) && (lane < R);
+    const int p_src = patch ? RA + wv - 2 - lane : 0, p_dst = patch ? RA + wv + lane : BW + 32 + (lane & 31);
+    const int hm1 = a.h - 1;
+    auto row_ptr = [&](int i) {
+        int gy = y0 - R + i;
+        gy = gy < 0 ? -gy : gy;
+        gy = gy > hm1 ? 2 * hm1 - gy : gy;
+        gy = gy < 0 ? 0 : gy;                        // rows past the last needed one (clamped prefetch)
+        return a.src + (size_t)gy * a.w;
+    };
+    v4f pm[D]; float ph[D];
+#pragma unroll
+    for (int d = 0; d < D; d++) { const float* rp = row_ptr(d < nin ? d : nin - 1); pm[d] = *reinterpret_cast<const v4f*>(rp + xl); ph[d] = rp[chalo]; }
+    v2f acc01[NP], acc23[NP];
+#pragma unroll
+    for (int q = 0; q < NP; q++) { acc01[q] = (v2f){0.0f, 0.0f}; acc23[q] = (v2f){0.0f, 0.0f}; }
+    v2f kp[R + 1];
+#pragma unroll
+    for (int m = 0; m <= R; m++) { kp[m].x = a.k[2 * m]; kp[m].y = (2 * m + 1 <= 2 * R) ? a.k[2 * m + 1] : 0.0f; }
+    float* const bufs = reinterpret_cast<float*>(&s_buf[wave][0][0]);
+    for (int base = 0; base < nin; base += NP) {
+        auto step = [&](auto jc) -> bool {
+            constexpr int j = decltype(jc)::value;
+            const int i = base + j;
+            if (i >= nin) return false;
+            float* buf = bufs + (j & 1) * (BW + 64);
+            *reinterpret_cast<v4f*>(buf + RA + 4 * lane) = pm[j % D];
+            buf[hpos] = ph[j % D];
+            {
+                const int in = i + D < nin ? i + D : nin - 1;
+                const float* rp = row_ptr(in);
+                pm[j % D] = *reinterpret_cast<const v4f*>(rp + xl); ph[j % D] = rp[chalo];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            { const float t = buf[p_src]; buf[p_dst] = t; }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const v4f* w4 = reinterpret_cast<const v4f*>(buf) + lane;
+            float e[NG * 4];
+#pragma unroll
+            for (int g = 0; g < NG; g++) { const v4f tt = w4[g]; e[4 * g] = tt.x; e[4 * g + 1] = tt.y; e[4 * g + 2] = tt.z; e[4 * g + 3] = tt.w; }
+            v2f r01, r23;
+#pragma unroll
+            for (int t = 0; t <= 2 * R; t++) {
+                const v2f e01 = {e[S + t], e[S + t + 1]}, e23 = {e[S + t + 2], e[S + t + 3]};
+                if (t == 0) { r01 = pkfma_klo0(kp[0], e01); r23 = pkfma_klo0(kp[0], e23); }
+                else if (t & 1) { pkfma_khi(kp[t >> 1], e01, r01); pkfma_khi(kp[t >> 1], e23, r23); }
+                else { pkfma_klo(kp[t >> 1], e01, r01); pkfma_klo(kp[t >> 1], e23, r23); }
+            }
+#pragma unroll
+            for (int t = 0; t <= 2 * R; t++) {
+                const int slot = ((j - t) % NP + NP) % NP;
+                if (t == 0) { acc01[slot] = pkfma_klo0(kp[0], r01); acc23[slot] = pkfma_klo0(kp[0], r23); }
+                else if (t & 1) { pkfma_khi(kp[t >> 1], r01, acc01[slot]); pkfma_khi(kp[t >> 1], r23, acc23[slot]); }
+                else { pkfma_klo(kp[t >> 1], r01, acc01[slot]); pkfma_klo(kp[t >> 1], r23, acc23[slot]); }
+            }
+            if (i >= 2 * R) {
+                const int slot = ((j - 2 * R) % NP + NP) % NP;
+                const v4f o = {acc01[slot].x, acc01[slot].y, acc23[slot].x, acc23[slot].y};
+                if (xm < a.w) *reinterpret_cast<v4f*>(a.dst + (size_t)(y0 + i - 2 * R) * a.w + xm) = o;
+            }
+            __builtin_amdgcn_sched_barrier(0);       // keep the rows apart: the scheduler otherwise interleaves them and spills
+            return true;
+        };
+        if (!static_rows<0, NP>(step)) return;
     }
 }
 
@@ -1004,8 +1120,9 @@ int gauss_kernel_host(double sigma, float* k) {
     return r;
 }
 
+constexpr int STREAM_MIN_W = 2048, STREAM_MIN_H = 1536;
 template <bool BGR>
-bool launch_blur(hipStream_t st, int R, const BlurArgs& a) {
+bool launch_blur(hipStream_t st, int R, const BlurArgs& a, int stream_mode = 1) {
     const int ntile = a.tiles_x * a.tiles_y;
     // Large f32 levels: persistent 128-bit/packed-FMA variant with register prefetch (interior tiles dominate).
     // Small levels (every tile touches the border) and the BGR base level: the 512-thread per-tile kernel.
@@ -1015,6 +1132,23 @@ bool launch_blur(hipStream_t st, int R, const BlurArgs& a) {
 #else
     const bool use2 = big;
 #endif
+    const bool stream_ok = ((a.w & 3) == 0) && (((uintptr_t)a.src & 15) == 0) && (((uintptr_t)a.dst & 15) == 0) && ((a.w & 255) == 0 || (a.w & 255) > MAX_R);
+    if (use2 && stream_mode && stream_ok && a.w >= STREAM_MIN_W && a.h >= STREAM_MIN_H) {
+        // barrier-free streaming kernel: ~2 waves per SIMD over the whole chip (2048 waves), segments of >= 32 rows
+        const int nstrip = (a.w + 255) / 256;
+        int nseg = (2048 + nstrip - 1) / nstrip;
+        int L = (a.h + nseg - 1) / nseg;
+        if (L < 32) L = 32;
+        nseg = (a.h + L - 1) / L;
+        const int units = nstrip * nseg;
+        const dim3 grid((units + 3) / 4), block(256);
+        switch (R) {
+#define CASE(RR, DD) case RR: hipLaunchKernelGGL((blur_stream<RR, DD>), grid, block, 0, st, a, L, nstrip, nseg); return true;
+            CASE(5, 6) CASE(6, 8) CASE(8, 6) CASE(10, 6) CASE(13, 4)
+#undef CASE
+            default: break;
+        }
+    }
     if (use2) {
         BlurArgs a2 = a;
         a2.tiles_y = (a.h + BLUR2_TH - 1) / BLUR2_TH;
@@ -1239,7 +1373,7 @@ int mi_sift_extract_dev(mi355_ctx* ctx, int img_id, const uint8_t* d_bgr, int w,
             a.bgr = d_bgr; a.bgr_ws = ws; a.dst = oc.lv[0];
             memcpy(a.k, s->kern0, sizeof(float) * (2 * s->radius0 + 1));
             ProfScope ps(ctx, "gauss", level_bytes + (double)w * h * 3.0, sa);      // read the u8 frame, write level 0
-            if (!launch_blur<true>(sa, s->radius0, a)) { ctx->set_error("sift: unsupported kernel radius"); return MI355_ERR_FAILED; }
+            if (!launch_blur<true>(sa, s->radius0, a, ctx->blur_stream)) { ctx->set_error("sift: unsupported kernel radius"); return MI355_ERR_FAILED; }
         } else {
             const OctaveDev& pv = s->P.oc[o - 1];
             ProfScope ps(ctx, "downsample", level_bytes * 2.0, sa);
@@ -1249,7 +1383,7 @@ int mi_sift_extract_dev(mi355_ctx* ctx, int img_id, const uint8_t* d_bgr, int w,
             a.bgr = nullptr; a.src = oc.lv[i - 1]; a.dst = oc.lv[i];
             memcpy(a.k, s->kern[i], sizeof(float) * (2 * s->radius[i] + 1));
             ProfScope ps(ctx, "gauss", level_bytes * 2.0, sa);                        // one read + one write of the level
-            if (!launch_blur<false>(sa, s->radius[i], a)) { ctx->set_error("sift: unsupported kernel radius"); return MI355_ERR_FAILED; }
+            if (!launch_blur<false>(sa, s->radius[i], a, ctx->blur_stream)) { ctx->set_error("sift: unsupported kernel radius"); return MI355_ERR_FAILED; }
         }
         {
             ProfScope ps(ctx, "extrema", level_bytes * 6.0, sa);

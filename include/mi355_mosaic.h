@@ -92,7 +92,8 @@ const char* mi355_last_error(mi355_ctx* ctx);          /* ctx may be NULL: last 
 int  mi355_set_stream(mi355_ctx* ctx, void* hip_stream);
 int  mi355_synchronize(mi355_ctx* ctx);
 /* Tunables: "sift_slots" = frames whose detect+describe may be in flight at once (1..8, default 4; each slot owns a
- * pyramid work area, 4.7 GB at 4000x3000). */
+ * pyramid work area, 4.7 GB at 4000x3000); "blur_stream" = 1 (default) runs pyramid levels of >= 2048x1536 through the
+ * barrier-free streaming Gaussian, 0 forces the tiled kernel everywhere (same bits either way). */
 int  mi355_set_option(mi355_ctx* ctx, const char* name, int value);
 void mi355_free(void* p);                               /* frees host buffers returned by this library */
 

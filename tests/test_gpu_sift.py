@@ -84,3 +84,19 @@ def test_sift_row_padding_is_ignored(ctx, oracle):
     kp2, desc2 = ctx.SiftExtract(6, img)
     assert n.value == len(kp2) and np.array_equal(kp[:n.value], kp2) and np.array_equal(desc[:n.value], desc2)
     del view
+
+
+def test_sift_streaming_blur_levels(ctx, oracle):
+    """frames whose octave 0 is >= 2048x1536 go through blur_stream (wave-per-strip streaming Gaussian): partial last
+    strip (2200 = 8*256 + 152), several row segments with reflected top/bottom rows, and an exact multiple of 256"""
+    import imagemosaicing_amd as im
+    from tests.synth_frames import terrain
+    for (w, h, seed) in [(1100, 780, 21), (1024, 768, 22)]:
+        img = terrain(w, h, seed=seed)
+        kp, d8 = _check(ctx, oracle, img, f"{w}x{h}")
+        assert len(kp) == 2000
+        c0 = im.Context(0)
+        c0.set_option("blur_stream", 0)
+        kp0, desc0 = c0.SiftExtract(7, img)
+        c0.close()
+        assert np.array_equal(kp0.view(np.uint8), kp.view(np.uint8)) and np.array_equal(desc0.astype(np.uint8), d8)
