@@ -53,7 +53,8 @@ extern "C" int mi355_create(mi355_ctx** out, const mi355_params* params, int dev
     if (e != hipSuccess) { g_create_error = hipGetErrorString(e); delete c; return MI355_ERR_DEVICE; }
     c->stream = c->own_stream;
     if (const char* e = getenv("MI355_BLUR_STREAM")) c->blur_stream = atoi(e) ? 1 : 0;
-    if (const char* e = getenv("MI355_SIFT_SLOTS")) { const int v = atoi(e); c->sift_nslots = v < 1 ? 1 : (v > 8 ? 8 : v); }
+    if (const char* e = getenv("MI355_SIFT_SLOTS")) { const int v = atoi(e); c->sift_nslots = v < 1 ? 1 : (v > 4 ? 4 : v); }
+    if (const char* e = getenv("MI355_SIFT_BATCH")) { const int v = atoi(e); c->sift_batch = v < 1 ? 1 : (v > 8 ? 8 : v); }
     *out = c;
     return MI355_OK;
 }
@@ -78,7 +79,14 @@ extern "C" int mi355_set_stream(mi355_ctx* ctx, void* hip_stream) {
     if (!ctx) return MI355_ERR_ARG;
     std::lock_guard<std::mutex> lk(ctx->mu);
     (void)hipStreamSynchronize(ctx->stream);
-    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    if (hip_stream) {
+        // the context's own stream would only occupy a hardware queue from here on
+        if (ctx->own_stream) { (void)hipStreamDestroy(ctx->own_stream); ctx->own_stream = nullptr; }
+        ctx->stream = (hipStream_t)hip_stream;
+    } else {
+        if (!ctx->own_stream) MI_HIP(hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
+        ctx->stream = ctx->own_stream;
+    }
     return MI355_OK;
 }
 
@@ -275,7 +283,13 @@ extern "C" int mi355_set_option(mi355_ctx* ctx, const char* name, int value) {
     if (std::string(name) == "sift_slots") {
         int rc = mi_resolve_features(ctx);
         if (rc != MI355_OK) return rc;
-        ctx->sift_nslots = value < 1 ? 1 : (value > 8 ? 8 : value);
+        ctx->sift_nslots = value < 1 ? 1 : (value > 4 ? 4 : value);
+        return MI355_OK;
+    }
+    if (std::string(name) == "sift_batch") {
+        int rc = mi_resolve_features(ctx);
+        if (rc != MI355_OK) return rc;
+        ctx->sift_batch = value < 1 ? 1 : (value > 8 ? 8 : value);
         return MI355_OK;
     }
     if (std::string(name) == "blur_stream") { ctx->blur_stream = value ? 1 : 0; return MI355_OK; }

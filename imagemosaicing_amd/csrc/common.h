@@ -79,7 +79,8 @@ struct mi355_ctx {
     std::vector<SiftWork*> sift_slots;                 // one work area + stream per in-flight frame
     int sift_next = 0;
     int blur_stream = 1;                               // big pyramid levels through blur_stream (0: tile kernel only); option "blur_stream"
-    int sift_nslots = 4;                               // frames in flight (mi355_set_option "sift_slots", env MI355_SIFT_SLOTS)
+    int sift_nslots = 3;                               // batch work areas in flight, each on its own stream (option "sift_slots", env MI355_SIFT_SLOTS)
+    int sift_batch = 8;                                // frames per batch (option "sift_batch", env MI355_SIFT_BATCH)
     hipEvent_t sift_in_ev = nullptr;                   // orders the SIFT streams after the caller's stream
     hipStream_t sift_heavy = nullptr;                  // stage A (pyramid + extrema) of every frame, in order
     std::vector<int*> pinned_chunks;                   // pinned count slots, 8 ints per frame

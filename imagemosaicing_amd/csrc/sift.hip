@@ -124,6 +124,8 @@ struct BlurArgs {
     int w, h;                // size of the level being produced
     int tiles_x, tiles_y;
     float k[2 * MAX_R + 1];
+    size_t fstride;          // batched launch: frame f (blockIdx.y, or the tile index / tiles for the persistent kernel) reads
+    int nb;                  // src + f * fstride and writes dst + f * fstride (floats); nb = frames in the batch (0 or 1: single)
 };
 
 // 2x bilinear upsample of the fixed-point gray image, pixel-centre aligned, edge clamp (exact in binary32)
@@ -167,6 +169,8 @@ __global__ __launch_bounds__(BT) void blur_tile(BlurArgs a) {
     const int tile = xcd_remap(blockIdx.x, a.tiles_x * a.tiles_y);
     const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
     const int x0 = tx * TW, y0 = ty * TH;
+    if (!BGR) { a.src += (size_t)blockIdx.y * a.fstride; }
+    a.dst += (size_t)blockIdx.y * a.fstride;
     // phase 1: stage the halo tile (reflect-101 at the image border; interior tiles skip the reflection)
     const bool interior = (x0 - R >= 0) && (y0 - R >= 0) && (x0 + TW + R <= a.w) && (y0 + TH + R <= a.h);
     if (interior && !BGR) {
@@ -289,21 +293,24 @@ __global__ __launch_bounds__(BLUR2_NT) void blur_tile2(BlurArgs a) {
     __shared__ v4f s_mid4[ROWS * (PMID / 4)];
     float* s_in = reinterpret_cast<float*>(s_in4);
     const int tid = threadIdx.x;
-    const int ntiles = a.tiles_x * a.tiles_y;
+    const int ntiles1 = a.tiles_x * a.tiles_y;            // tiles of one frame
+    const int ntiles = ntiles1 * (a.nb > 1 ? a.nb : 1);   // batched launch: the tile list runs over all frames
     const bool vec_ok = !BGR && ((a.w & 3) == 0) && ((reinterpret_cast<uintptr_t>(a.src) & 15) == 0);
     const bool vec_st = ((a.w & 3) == 0) && ((reinterpret_cast<uintptr_t>(a.dst) & 15) == 0);
 
     // Persistent workgroups walk the tile list; the global loads of tile t+1 are issued into registers before the two
     // passes of tile t run (their latency hides under ~1000 VALU instructions), and land in LDS after the passes.
     v4f pf[NPF];
-    auto tile_origin = [&](int t, int& x0, int& y0) {
+    auto tile_origin = [&](int t, int& x0, int& y0, int& fr) {
         const int tile = xcd_remap(t, ntiles);
-        const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
+        fr = tile / ntiles1;
+        const int t1 = tile - fr * ntiles1;
+        const int ty = t1 / a.tiles_x, tx = t1 - ty * a.tiles_x;
         x0 = tx * 64; y0 = ty * TH2;
     };
     auto is_interior = [&](int x0, int y0) { return vec_ok && (x0 - RA >= 0) && (y0 - R >= 0) && (x0 + 64 + RA <= a.w) && (y0 + TH2 + R <= a.h); };
-    auto prefetch = [&](int x0, int y0) {
-        const float* base = a.src + (size_t)(y0 - R) * a.w + (x0 - RA);
+    auto prefetch = [&](int x0, int y0, int fr) {
+        const float* base = a.src + (size_t)fr * a.fstride + (size_t)(y0 - R) * a.w + (x0 - RA);
 #pragma unroll
         for (int u = 0; u < NPF; u++) {
             const int idx = tid + NT * u;
@@ -311,9 +318,9 @@ __global__ __launch_bounds__(BLUR2_NT) void blur_tile2(BlurArgs a) {
         }
     };
     int t = blockIdx.x;
-    int x0 = 0, y0 = 0;
+    int x0 = 0, y0 = 0, fr = 0;
     bool cur_pf = false;
-    if (t < ntiles) { tile_origin(t, x0, y0); cur_pf = is_interior(x0, y0); if (cur_pf) prefetch(x0, y0); }
+    if (t < ntiles) { tile_origin(t, x0, y0, fr); cur_pf = is_interior(x0, y0); if (cur_pf) prefetch(x0, y0, fr); }
     for (; t < ntiles; t += gridDim.x) {
         // stage the current tile
         if (cur_pf) {
@@ -325,15 +332,15 @@ __global__ __launch_bounds__(BLUR2_NT) void blur_tile2(BlurArgs a) {
                 const int gy = reflect101(y0 - R + ry, a.h), gx = reflect101(x0 - RA + rx, a.w);
                 float v;
                 if (BGR) v = load_base(a.bgr, a.bgr_ws, a.w >> 1, a.h >> 1, gx, gy);
-                else v = a.src[(size_t)gy * a.w + gx];
+                else v = a.src[(size_t)fr * a.fstride + (size_t)gy * a.w + gx];
                 s_in[ry * (P4 * 4) + rx] = v;
             }
         }
         __syncthreads();
         // issue the next tile's loads
         const int tn = t + gridDim.x;
-        int nx0 = 0, ny0 = 0; bool next_pf = false;
-        if (tn < ntiles) { tile_origin(tn, nx0, ny0); next_pf = is_interior(nx0, ny0); if (next_pf) prefetch(nx0, ny0); }
+        int nx0 = 0, ny0 = 0, nfr = 0; bool next_pf = false;
+        if (tn < ntiles) { tile_origin(tn, nx0, ny0, nfr); next_pf = is_interior(nx0, ny0); if (next_pf) prefetch(nx0, ny0, nfr); }
         // row pass: item = 4 adjacent outputs of one staged row; lanes walk the 16 groups of a row (contiguous 16 B slots)
         for (int item = tid; item < ROWS * 16; item += NT) {
             const int row = item >> 4, xg = item & 15;
@@ -369,17 +376,17 @@ __global__ __launch_bounds__(BLUR2_NT) void blur_tile2(BlurArgs a) {
             }
             const int gx = x0 + 4 * xg, gy = y0 + CR * yg;
             if (gx + 3 < a.w && vec_st) {
-                float* d = a.dst + (size_t)gy * a.w + gx;
+                float* d = a.dst + (size_t)fr * a.fstride + (size_t)gy * a.w + gx;
 #pragma unroll
                 for (int q = 0; q < CR; q++) if (gy + q < a.h) *reinterpret_cast<v4f*>(d + (size_t)q * a.w) = acc[q];
             } else {
                 for (int r = 0; r < CR; r++)
                     for (int c = 0; c < 4; c++)
-                        if (gy + r < a.h && gx + c < a.w) a.dst[(size_t)(gy + r) * a.w + gx + c] = acc[r][c];
+                        if (gy + r < a.h && gx + c < a.w) a.dst[(size_t)fr * a.fstride + (size_t)(gy + r) * a.w + gx + c] = acc[r][c];
             }
         }
         __syncthreads();                        // s_in / s_mid are rewritten by the next trip
-        x0 = nx0; y0 = ny0; cur_pf = next_pf;
+        x0 = nx0; y0 = ny0; fr = nfr; cur_pf = next_pf;
     }
 }
 
@@ -404,7 +411,21 @@ template <int J, int NPP, class F> __device__ __forceinline__ bool static_rows(F
     else return true;
 }
 
-template <int R, int D>
+// fixed-point gray of the frame as u8 (the values are integers 0..255), rows padded by 4 replicated pixels on each side
+// so that the 2x up-sampling below never clamps a column: gray[y * gp + 4 + x], x in [-4, w + 4)
+__global__ __launch_bounds__(256) void gray_pad_kernel(const uint8_t* bgr, int ws, int w, int h, uint8_t* gray, int gp) {
+    const int xp = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (xp >= gp) return;
+    int x = xp - 4;
+    x = x < 0 ? 0 : (x > w - 1 ? w - 1 : x);
+    const uint8_t* p = bgr + (size_t)y * ws + 3 * x;
+    gray[(size_t)y * gp + xp] = (uint8_t)((1868 * (int)p[0] + 9617 * (int)p[1] + 4899 * (int)p[2] + 8192) >> 14);
+}
+
+// UPS = true: the source is the padded u8 gray of the frame and the level being blurred is its 2x bilinear up-sampling
+// (pixel-centre aligned, weights 1/4 and 3/4, edge clamp: load_base above), formed on the fly -- every product and sum
+// is exact in binary32, so the order of evaluation is free.
+template <int R, int D, bool UPS>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void blur_stream(BlurArgs a, int L, int nstrip, int nseg) {
     constexpr int N = 2 * R + 1;
     constexpr int NP0 = ((N + D - 1) / D) * D;
@@ -430,16 +451,57 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const bool patch = (wv < SW) && (lane < R);
     const int p_src = patch ? RA + wv - 2 - lane : 0, p_dst = patch ? RA + wv + lane : BW + 32 + (lane & 31);
     const int hm1 = a.h - 1;
-    auto row_ptr = [&](int i) {
+    auto src_row = [&](int i) {                     // source row of step i: reflect-101, clamped for the prefetch past the end
         int gy = y0 - R + i;
         gy = gy < 0 ? -gy : gy;
         gy = gy > hm1 ? 2 * hm1 - gy : gy;
-        gy = gy < 0 ? 0 : gy;                        // rows past the last needed one (clamped prefetch)
-        return a.src + (size_t)gy * a.w;
+        return gy < 0 ? 0 : gy;
     };
-    v4f pm[D]; float ph[D];
+    // ---- prefetch ring: raw source data of the next D steps ----
+    struct Raw { v4f m; float h; unsigned ma, mb, ha, hb; };
+    const int gmain = 4 + (xl >> 1) - 1;                                   // UPS: byte column of the 4 gray pixels c-1..c+2
+    const int ghalo = 4 + ((chalo & 1) ? (chalo >> 1) : (chalo >> 1) - 1); // UPS: byte column of the halo pixel pair
+    const float hwx1 = (chalo & 1) ? 0.25f : 0.75f;
+    const int hl1 = (a.h >> 1) - 1;
+    auto load_raw = [&](int i, Raw& r) {
+        const int gy = src_row(i);
+        if constexpr (UPS) {
+            int ya = (gy & 1) ? (gy >> 1) : (gy >> 1) - 1;
+            int yb = ya + 1;
+            ya = ya < 0 ? 0 : ya;
+            yb = yb > hl1 ? hl1 : yb;
+            const uint8_t* ra = a.bgr + (size_t)ya * a.bgr_ws;
+            const uint8_t* rb = a.bgr + (size_t)yb * a.bgr_ws;
+            unsigned short ta, tb;
+            __builtin_memcpy(&r.ma, ra + gmain, 4); __builtin_memcpy(&r.mb, rb + gmain, 4);
+            __builtin_memcpy(&ta, ra + ghalo, 2); __builtin_memcpy(&tb, rb + ghalo, 2);
+            r.ha = ta; r.hb = tb;
+        } else {
+            const float* rp = a.src + (size_t)gy * a.w;
+            r.m = *reinterpret_cast<const v4f*>(rp + xl); r.h = rp[chalo];
+        }
+    };
+    auto row_values = [&](int i, const Raw& r, v4f& m, float& hv) {
+        if constexpr (UPS) {
+            const int gy = src_row(i);
+            const float wy1 = (gy & 1) ? 0.25f : 0.75f, wy0 = 1.0f - wy1;
+            auto hrow = [&](unsigned q, v4f& o) {
+                const float b0 = (float)(q & 255u), b1 = (float)((q >> 8) & 255u), b2 = (float)((q >> 16) & 255u), b3 = (float)(q >> 24);
+                o.x = fmaf(b1, 0.75f, b0 * 0.25f); o.y = fmaf(b2, 0.25f, b1 * 0.75f);
+                o.z = fmaf(b2, 0.75f, b1 * 0.25f); o.w = fmaf(b3, 0.25f, b2 * 0.75f);
+            };
+            v4f ha4, hb4;
+            hrow(r.ma, ha4); hrow(r.mb, hb4);
+            m.x = fmaf(hb4.x, wy1, ha4.x * wy0); m.y = fmaf(hb4.y, wy1, ha4.y * wy0);
+            m.z = fmaf(hb4.z, wy1, ha4.z * wy0); m.w = fmaf(hb4.w, wy1, ha4.w * wy0);
+            const float a0 = (float)(r.ha & 255u), a1 = (float)(r.ha >> 8), c0 = (float)(r.hb & 255u), c1 = (float)(r.hb >> 8);
+            const float qa = fmaf(a1, hwx1, a0 * (1.0f - hwx1)), qb = fmaf(c1, hwx1, c0 * (1.0f - hwx1));
+            hv = fmaf(qb, wy1, qa * wy0);
+        } else { m = r.m; hv = r.h; }
+    };
+    Raw pf[D];
 #pragma unroll
-    for (int d = 0; d < D; d++) { const float* rp = row_ptr(d < nin ? d : nin - 1); pm[d] = *reinterpret_cast<const v4f*>(rp + xl); ph[d] = rp[chalo]; }
+    for (int d = 0; d < D; d++) load_raw(d < nin ? d : nin - 1, pf[d]);
     v2f acc01[NP], acc23[NP];
 #pragma unroll
     for (int q = 0; q < NP; q++) { acc01[q] = (v2f){0.0f, 0.0f}; acc23[q] = (v2f){0.0f, 0.0f}; }
@@ -453,13 +515,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             const int i = base + j;
             if (i >= nin) return false;
             float* buf = bufs + (j & 1) * (BW + 64);
-            *reinterpret_cast<v4f*>(buf + RA + 4 * lane) = pm[j % D];
-            buf[hpos] = ph[j % D];
             {
-                const int in = i + D < nin ? i + D : nin - 1;
-                const float* rp = row_ptr(in);
-                pm[j % D] = *reinterpret_cast<const v4f*>(rp + xl); ph[j % D] = rp[chalo];
+                v4f m; float hv;
+                row_values(i, pf[j % D], m, hv);
+                *reinterpret_cast<v4f*>(buf + RA + 4 * lane) = m;
+                buf[hpos] = hv;
             }
+            load_raw(i + D < nin ? i + D : nin - 1, pf[j % D]);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -498,7 +560,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
 }
 
-__global__ __launch_bounds__(256) void downsample2(const float* src, int sw, float* dst, int dw, int dh) {
+__global__ __launch_bounds__(256) void downsample2(const float* src, int sw, float* dst, int dw, int dh, size_t fstride) {
+    src += (size_t)blockIdx.z * fstride; dst += (size_t)blockIdx.z * fstride;      // blockIdx.z = frame of the batch
     const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x < dw && y < dh) dst[(size_t)y * dw + x] = src[(size_t)(2 * y) * sw + 2 * x];
 }
@@ -512,7 +575,19 @@ struct OctaveDev { float* lv[N_LEVELS]; int w, h; };
 constexpr int EW = 64, EH = EXT_EH, ECAP = 128;
 constexpr int NREG = 64, REG_STRIDE = 32;   // candidate list split into 64 regions, one counter per 128-byte line:
                                             // a single counter caps at ~1e8 returning atomics/s (one per tile = 0.5 ms)
-__global__ __launch_bounds__(256) void extrema_kernel(OctaveDev oc, int octave, unsigned long long* cand, unsigned* count, unsigned cap, unsigned* overflow) {
+// batched launches: frame f = blockIdx.y (z for refine) works on its own copy of every buffer, a fixed stride apart
+struct BatchStride { size_t pyr, claimed, cand, refined, kps; };   // elements of the respective type
+constexpr size_t CNT_STRIDE = 64, CCNT_STRIDE = (size_t)64 * 32, RHIST_STRIDE = 65536, SEL_STRIDE = 2048;
+constexpr int SIFT_BATCH_MAX = 8;
+struct FrameOuts { mi355_keypoint* kp[SIFT_BATCH_MAX]; uint8_t* d8[SIFT_BATCH_MAX]; };
+
+__global__ __launch_bounds__(256) void extrema_kernel(OctaveDev oc, int octave, unsigned long long* cand, unsigned* count, unsigned cap, unsigned* overflow, BatchStride bs) {
+    {
+        const size_t f = blockIdx.y;
+#pragma unroll
+        for (int l = 0; l < N_LEVELS; l++) oc.lv[l] += f * bs.pyr;
+        cand += f * bs.cand; count += f * CCNT_STRIDE; overflow += f * CNT_STRIDE;
+    }
     // staged window: rows y0-1 .. y0+EH, columns x0-4 .. x0+EW+3 (16-byte aligned so that interior tiles load float4)
     constexpr int PC = EW + 8;                 // 72 columns
     constexpr int P4 = PC / 4;                 // 18 float4 per row
@@ -640,8 +715,8 @@ struct Refined { int o, layer, r, c; float xi, xr, xc, contr, scl; };
 
 struct PyrDev { OctaveDev oc[MAX_OCT]; unsigned* claimed[MAX_OCT]; int n_oct; };
 
-__device__ __forceinline__ float dogv(const OctaveDev& oc, int lvl, int r, int c) {
-    const size_t o = (size_t)r * oc.w + c;
+__device__ __forceinline__ float dogv(const OctaveDev& oc, size_t foff, int lvl, int r, int c) {
+    const size_t o = foff + (size_t)r * oc.w + c;
     return oc.lv[lvl + 1][o] - oc.lv[lvl][o];
 }
 
@@ -677,7 +752,10 @@ __device__ void solve3(float A[3][3], float b[3], float x[3]) {
 
 __global__ __launch_bounds__(256) void refine_kernel(PyrDev P, const unsigned long long* cand_all, const unsigned* cand_counts, unsigned cand_cap, unsigned* cand_total,
                                                      float contrast_thr, float edge_thr, float sigma,
-                                                     Refined* out, unsigned* out_count, unsigned out_cap, unsigned* resp_hist) {
+                                                     Refined* out, unsigned* out_count, unsigned out_cap, unsigned* resp_hist, BatchStride bs) {
+    const size_t fr = blockIdx.z, foff = fr * bs.pyr;             // frame of the batch
+    cand_all += fr * bs.cand; cand_counts += fr * CCNT_STRIDE; cand_total += fr * CNT_STRIDE;
+    out += fr * bs.refined; out_count += fr * CNT_STRIDE; resp_hist += fr * RHIST_STRIDE;
     // blockIdx.y = region of the candidate list (extrema_kernel spreads its appends over NREG counters)
     const unsigned reg = blockIdx.y;
     unsigned n = cand_counts[reg * REG_STRIDE];
@@ -700,16 +778,16 @@ __global__ __launch_bounds__(256) void refine_kernel(PyrDev P, const unsigned lo
         bool alive = true;
         for (; it < MAX_INTERP; it++) {
             float dD[3];
-            dD[0] = (dogv(oc, L, R, C + 1) - dogv(oc, L, R, C - 1)) * deriv_scale;
-            dD[1] = (dogv(oc, L, R + 1, C) - dogv(oc, L, R - 1, C)) * deriv_scale;
-            dD[2] = (dogv(oc, L + 1, R, C) - dogv(oc, L - 1, R, C)) * deriv_scale;
-            const float v2 = dogv(oc, L, R, C) * 2.0f;
-            const float dxx = (dogv(oc, L, R, C + 1) + dogv(oc, L, R, C - 1) - v2) * second_scale;
-            const float dyy = (dogv(oc, L, R + 1, C) + dogv(oc, L, R - 1, C) - v2) * second_scale;
-            const float dss = (dogv(oc, L + 1, R, C) + dogv(oc, L - 1, R, C) - v2) * second_scale;
-            const float dxy = (dogv(oc, L, R + 1, C + 1) - dogv(oc, L, R + 1, C - 1) - dogv(oc, L, R - 1, C + 1) + dogv(oc, L, R - 1, C - 1)) * cross_scale;
-            const float dxs = (dogv(oc, L + 1, R, C + 1) - dogv(oc, L + 1, R, C - 1) - dogv(oc, L - 1, R, C + 1) + dogv(oc, L - 1, R, C - 1)) * cross_scale;
-            const float dys = (dogv(oc, L + 1, R + 1, C) - dogv(oc, L + 1, R - 1, C) - dogv(oc, L - 1, R + 1, C) + dogv(oc, L - 1, R - 1, C)) * cross_scale;
+            dD[0] = (dogv(oc, foff, L, R, C + 1) - dogv(oc, foff, L, R, C - 1)) * deriv_scale;
+            dD[1] = (dogv(oc, foff, L, R + 1, C) - dogv(oc, foff, L, R - 1, C)) * deriv_scale;
+            dD[2] = (dogv(oc, foff, L + 1, R, C) - dogv(oc, foff, L - 1, R, C)) * deriv_scale;
+            const float v2 = dogv(oc, foff, L, R, C) * 2.0f;
+            const float dxx = (dogv(oc, foff, L, R, C + 1) + dogv(oc, foff, L, R, C - 1) - v2) * second_scale;
+            const float dyy = (dogv(oc, foff, L, R + 1, C) + dogv(oc, foff, L, R - 1, C) - v2) * second_scale;
+            const float dss = (dogv(oc, foff, L + 1, R, C) + dogv(oc, foff, L - 1, R, C) - v2) * second_scale;
+            const float dxy = (dogv(oc, foff, L, R + 1, C + 1) - dogv(oc, foff, L, R + 1, C - 1) - dogv(oc, foff, L, R - 1, C + 1) + dogv(oc, foff, L, R - 1, C - 1)) * cross_scale;
+            const float dxs = (dogv(oc, foff, L + 1, R, C + 1) - dogv(oc, foff, L + 1, R, C - 1) - dogv(oc, foff, L - 1, R, C + 1) + dogv(oc, foff, L - 1, R, C - 1)) * cross_scale;
+            const float dys = (dogv(oc, foff, L + 1, R + 1, C) - dogv(oc, foff, L + 1, R - 1, C) - dogv(oc, foff, L - 1, R + 1, C) + dogv(oc, foff, L - 1, R - 1, C)) * cross_scale;
             float A[3][3] = {{dxx, dxy, dxs}, {dxy, dyy, dys}, {dxs, dys, dss}};
             float b[3] = {dD[0], dD[1], dD[2]}, X[3];
             solve3(A, b, X);
@@ -721,22 +799,22 @@ __global__ __launch_bounds__(256) void refine_kernel(PyrDev P, const unsigned lo
             if (L < 1 || L > N_LAYERS || C < IMG_BORDER || C >= oc.w - IMG_BORDER || R < IMG_BORDER || R >= oc.h - IMG_BORDER) { alive = false; break; }
         }
         if (!alive || it >= MAX_INTERP) continue;
-        float dD0 = (dogv(oc, L, R, C + 1) - dogv(oc, L, R, C - 1)) * deriv_scale;
-        float dD1 = (dogv(oc, L, R + 1, C) - dogv(oc, L, R - 1, C)) * deriv_scale;
-        float dD2 = (dogv(oc, L + 1, R, C) - dogv(oc, L - 1, R, C)) * deriv_scale;
+        float dD0 = (dogv(oc, foff, L, R, C + 1) - dogv(oc, foff, L, R, C - 1)) * deriv_scale;
+        float dD1 = (dogv(oc, foff, L, R + 1, C) - dogv(oc, foff, L, R - 1, C)) * deriv_scale;
+        float dD2 = (dogv(oc, foff, L + 1, R, C) - dogv(oc, foff, L - 1, R, C)) * deriv_scale;
         const float t = (dD0 * xc + dD1 * xr) + dD2 * xi;
-        const float contr = dogv(oc, L, R, C) * img_scale + t * 0.5f;
+        const float contr = dogv(oc, foff, L, R, C) * img_scale + t * 0.5f;
         if (fabsf(contr) * (float)N_LAYERS < contrast_thr) continue;
-        const float v2 = dogv(oc, L, R, C) * 2.0f;
-        const float dxx = (dogv(oc, L, R, C + 1) + dogv(oc, L, R, C - 1) - v2) * second_scale;
-        const float dyy = (dogv(oc, L, R + 1, C) + dogv(oc, L, R - 1, C) - v2) * second_scale;
-        const float dxy = (dogv(oc, L, R + 1, C + 1) - dogv(oc, L, R + 1, C - 1) - dogv(oc, L, R - 1, C + 1) + dogv(oc, L, R - 1, C - 1)) * cross_scale;
+        const float v2 = dogv(oc, foff, L, R, C) * 2.0f;
+        const float dxx = (dogv(oc, foff, L, R, C + 1) + dogv(oc, foff, L, R, C - 1) - v2) * second_scale;
+        const float dyy = (dogv(oc, foff, L, R + 1, C) + dogv(oc, foff, L, R - 1, C) - v2) * second_scale;
+        const float dxy = (dogv(oc, foff, L, R + 1, C + 1) - dogv(oc, foff, L, R + 1, C - 1) - dogv(oc, foff, L, R - 1, C + 1) + dogv(oc, foff, L, R - 1, C - 1)) * cross_scale;
         const float tr = dxx + dyy, det = dxx * dyy - dxy * dxy;
         if (det <= 0.0f || (tr * tr) * edge_thr >= ((edge_thr + 1.0f) * (edge_thr + 1.0f)) * det) continue;
         // duplicates: several start points may converge to one location -> first claim wins (all claims carry identical values)
         const size_t bit = ((size_t)R * oc.w + C) * 4 + (size_t)L;
         const unsigned mask = 1u << (bit & 31);
-        const unsigned old = atomicOr(&P.claimed[o][bit >> 5], mask);
+        const unsigned old = atomicOr(&P.claimed[o][fr * bs.claimed + (bit >> 5)], mask);
         if (old & mask) continue;
         const unsigned slot = atomicAdd(out_count, 1u);
         if (slot < out_cap) {
@@ -762,6 +840,7 @@ struct KpRec {
 // (points without any histogram peak), top-k raises a flag and pass 1 orients the rest -- same final result as
 // orienting everything, ~40x less work in the common case.
 __global__ __launch_bounds__(1024) void resp_threshold_kernel(const unsigned* hist, const unsigned* ref_count, unsigned want, unsigned* ctrl /* [0]=T bits [1]=fallback flag */) {
+    hist += (size_t)blockIdx.x * RHIST_STRIDE; ref_count += (size_t)blockIdx.x * CNT_STRIDE; ctrl += (size_t)blockIdx.x * CNT_STRIDE;   // one workgroup per frame
     __shared__ unsigned s_part[1024];
     const int tid = threadIdx.x;
     unsigned local[64], sum = 0;
@@ -792,7 +871,9 @@ __global__ __launch_bounds__(1024) void resp_threshold_kernel(const unsigned* hi
 constexpr int OCAP = 256;                     // emitted keypoints buffered per workgroup between flushes
 __global__ __launch_bounds__(256) void orient_kernel(PyrDev P, const Refined* ref, const unsigned* ref_count, unsigned ref_cap,
                                                      KpRec* out, unsigned* out_resp, unsigned* out_count, unsigned out_cap,
-                                                     const unsigned* ctrl, int pass) {
+                                                     const unsigned* ctrl, int pass, BatchStride bs) {
+    const size_t fr = blockIdx.y, foff = fr * bs.pyr;             // frame of the batch
+    ref += fr * bs.refined; ref_count += fr * CNT_STRIDE; out += fr * bs.kps; out_resp += fr * bs.kps; out_count += fr * CNT_STRIDE; ctrl += fr * CNT_STRIDE;
     __shared__ unsigned long long s_hq[4][ORI_BINS];
     const unsigned Tbits = ctrl[0];
     if (pass == 1 && (ctrl[1] == 0 || Tbits == 0)) return;      // fallback pass not needed
@@ -814,7 +895,7 @@ __global__ __launch_bounds__(256) void orient_kernel(PyrDev P, const Refined* re
         if (take) {
             const Refined rr = ref[k];
             const OctaveDev& oc = P.oc[rr.o];
-            const float* img = oc.lv[rr.layer];
+            const float* img = oc.lv[rr.layer] + foff;
             const int radius = (int)rintf(4.5f * rr.scl);
             const float osig = 1.5f * rr.scl;
             const float expf_scale = -1.0f / (2.0f * osig * osig);
@@ -908,7 +989,12 @@ __device__ __forceinline__ unsigned long long tie_key(const KpRec& k) {
 }
 
 __global__ __launch_bounds__(1024) void topk_kernel(const KpRec* kps, const unsigned* resp, const unsigned* kp_count, unsigned kp_cap, int nfeatures,
-                                                    mi355_keypoint* out_kp, SelRec* out_sel, int* out_n, int* overflow, unsigned* ctrl, int pass) {
+                                                    FrameOuts outs, SelRec* out_sel, int* out_n, int* overflow, unsigned* ctrl, int pass, BatchStride bs) {
+    const size_t fr = blockIdx.x;                                 // one workgroup per frame of the batch
+    kps += fr * bs.kps; resp += fr * bs.kps; kp_count += fr * CNT_STRIDE; out_sel += fr * SEL_STRIDE; out_n += fr * CNT_STRIDE; overflow += fr * CNT_STRIDE; ctrl += fr * CNT_STRIDE;
+    mi355_keypoint* out_kp = outs.kp[0];
+#pragma unroll
+    for (int q = 1; q < SIFT_BATCH_MAX; q++) if ((int)fr == q) out_kp = outs.kp[q];
     __shared__ unsigned s_hist[256];
     if (pass == 1 && (ctrl[1] == 0 || ctrl[0] == 0)) return;     // fallback pass not needed
     __shared__ unsigned s_misc[8];
@@ -1026,7 +1112,12 @@ __global__ __launch_bounds__(1024) void topk_kernel(const KpRec* kps, const unsi
 }
 
 // ---------- K5: descriptors -----------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void describe_kernel(PyrDev P, const SelRec* sel, const int* n_sel, uint8_t* desc) {
+__global__ __launch_bounds__(256) void describe_kernel(PyrDev P, const SelRec* sel, const int* n_sel, FrameOuts outs, BatchStride bs) {
+    const size_t fr = blockIdx.y, foff = fr * bs.pyr;             // frame of the batch
+    sel += fr * SEL_STRIDE; n_sel += fr * CNT_STRIDE;
+    uint8_t* desc = outs.d8[0];
+#pragma unroll
+    for (int q = 1; q < SIFT_BATCH_MAX; q++) if ((int)fr == q) desc = outs.d8[q];
     constexpr int d = 4, n = 8, HB = (d + 2) * (d + 2) * (n + 2);
     __shared__ unsigned long long s_hq[HB];
     __shared__ float s_dst[128];
@@ -1035,7 +1126,7 @@ __global__ __launch_bounds__(256) void describe_kernel(PyrDev P, const SelRec* s
     if (kidx >= *n_sel) return;
     const SelRec k = sel[kidx];
     const OctaveDev& oc = P.oc[k.o];
-    const float* img = oc.lv[k.layer];
+    const float* img = oc.lv[k.layer] + foff;
     const int rows = oc.h, cols = oc.w;
     for (int i = tid; i < HB; i += 256) s_hq[i] = 0ull;
     __syncthreads();
@@ -1121,6 +1212,34 @@ int gauss_kernel_host(double sigma, float* k) {
 }
 
 constexpr int STREAM_MIN_W = 2048, STREAM_MIN_H = 1536;
+// does this level go through blur_stream?  (f32 source, 16-byte aligned rows, last strip wider than the largest radius)
+inline bool blur_streams(const BlurArgs& a, bool bgr, int R, int stream_mode) {
+    const bool stream_ok = ((a.w & 3) == 0) && (((uintptr_t)a.src & 15) == 0) && (((uintptr_t)a.dst & 15) == 0) && ((a.w & 255) == 0 || (a.w & 255) > MAX_R);
+    const bool has_r = R == 5 || R == 6 || R == 8 || R == 10 || R == 13;
+    return !bgr && stream_mode && stream_ok && has_r && a.w >= STREAM_MIN_W && a.h >= STREAM_MIN_H;
+}
+// base level (2x up-sampled gray of the frame, blurred): gray_pad_kernel + blur_stream<R, D, UPS> when the level is big
+inline bool base_streams(const BlurArgs& a, int R, int stream_mode) {
+    return stream_mode && R == 5 && ((a.w & 3) == 0) && (((uintptr_t)a.dst & 15) == 0) && ((a.w & 255) == 0 || (a.w & 255) > MAX_R) && a.w >= STREAM_MIN_W && a.h >= STREAM_MIN_H;
+}
+inline void stream_grid(int w, int h, int& L, int& nstrip, int& nseg) {
+    static const int units_target = [] { const char* e = getenv("MI355_STREAM_UNITS"); return e ? atoi(e) : 2048; }();
+    static const int stream_minl = [] { const char* e = getenv("MI355_STREAM_MINL"); return e ? atoi(e) : 32; }();
+    nstrip = (w + 255) / 256;
+    nseg = (units_target + nstrip - 1) / nstrip;
+    L = (h + nseg - 1) / nseg;
+    if (L < stream_minl) L = stream_minl;
+    nseg = (h + L - 1) / L;
+}
+inline void launch_base_stream(hipStream_t st, const BlurArgs& a /* bgr frame + dst level */, uint8_t* gray, int gp) {
+    const int w = a.w >> 1, h = a.h >> 1;
+    hipLaunchKernelGGL(gray_pad_kernel, dim3((gp + 255) / 256, h), dim3(256), 0, st, a.bgr, a.bgr_ws, w, h, gray, gp);
+    BlurArgs a2 = a;
+    a2.bgr = gray; a2.bgr_ws = gp;
+    int L, nstrip, nseg;
+    stream_grid(a.w, a.h, L, nstrip, nseg);
+    hipLaunchKernelGGL((blur_stream<5, 8, true>), dim3((nstrip * nseg + 3) / 4), dim3(256), 0, st, a2, L, nstrip, nseg);
+}
 template <bool BGR>
 bool launch_blur(hipStream_t st, int R, const BlurArgs& a, int stream_mode = 1) {
     const int ntile = a.tiles_x * a.tiles_y;
@@ -1132,18 +1251,14 @@ bool launch_blur(hipStream_t st, int R, const BlurArgs& a, int stream_mode = 1) 
 #else
     const bool use2 = big;
 #endif
-    const bool stream_ok = ((a.w & 3) == 0) && (((uintptr_t)a.src & 15) == 0) && (((uintptr_t)a.dst & 15) == 0) && ((a.w & 255) == 0 || (a.w & 255) > MAX_R);
-    if (use2 && stream_mode && stream_ok && a.w >= STREAM_MIN_W && a.h >= STREAM_MIN_H) {
+    if (use2 && blur_streams(a, BGR, R, stream_mode)) {
         // barrier-free streaming kernel: ~2 waves per SIMD over the whole chip (2048 waves), segments of >= 32 rows
-        const int nstrip = (a.w + 255) / 256;
-        int nseg = (2048 + nstrip - 1) / nstrip;
-        int L = (a.h + nseg - 1) / nseg;
-        if (L < 32) L = 32;
-        nseg = (a.h + L - 1) / L;
+        int L, nstrip, nseg;
+        stream_grid(a.w, a.h, L, nstrip, nseg);
         const int units = nstrip * nseg;
         const dim3 grid((units + 3) / 4), block(256);
         switch (R) {
-#define CASE(RR, DD) case RR: hipLaunchKernelGGL((blur_stream<RR, DD>), grid, block, 0, st, a, L, nstrip, nseg); return true;
+#define CASE(RR, DD) case RR: hipLaunchKernelGGL((blur_stream<RR, DD, false>), grid, block, 0, st, a, L, nstrip, nseg); return true;
             CASE(5, 6) CASE(6, 8) CASE(8, 6) CASE(10, 6) CASE(13, 4)
 #undef CASE
             default: break;
@@ -1152,7 +1267,7 @@ bool launch_blur(hipStream_t st, int R, const BlurArgs& a, int stream_mode = 1) 
     if (use2) {
         BlurArgs a2 = a;
         a2.tiles_y = (a.h + BLUR2_TH - 1) / BLUR2_TH;
-        const int ntile2 = a2.tiles_x * a2.tiles_y;
+        const int ntile2 = a2.tiles_x * a2.tiles_y * (a.nb > 1 ? a.nb : 1);
         const dim3 grid(ntile2 < BLUR_PERSIST_BLOCKS ? ntile2 : BLUR_PERSIST_BLOCKS), block(BLUR2_NT);      // persistent workgroups
         switch (R) {
 #define CASE(RR) case RR: hipLaunchKernelGGL((blur_tile2<RR, false>), grid, block, 0, st, a2); return true;
@@ -1161,7 +1276,7 @@ bool launch_blur(hipStream_t st, int R, const BlurArgs& a, int stream_mode = 1) 
             default: return false;
         }
     }
-    const dim3 grid(ntile), block(BT);
+    const dim3 grid(ntile, a.nb > 1 ? a.nb : 1), block(BT);
     switch (R) {
 #define CASE(RR) case RR: hipLaunchKernelGGL((blur_tile<RR, BGR>), grid, block, 0, st, a); return true;
         CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8) CASE(9) CASE(10) CASE(11) CASE(12) CASE(13) CASE(14) CASE(15) CASE(16)
@@ -1172,60 +1287,70 @@ bool launch_blur(hipStream_t st, int R, const BlurArgs& a, int stream_mode = 1) 
 
 }  // namespace
 
+// One batch work area: room for `nb` frames (every per-frame buffer nb times, a fixed stride apart) and one stream.
+// Frames handed to mi_sift_extract_dev() collect in `pend`; a full batch (or a flush) is enqueued as
+//   phase 1  per frame : the chip-filling kernels of the big octaves (base level, blur_stream, extrema)
+//   phase 2  per octave: the small octaves of ALL frames of the batch in one launch each (grid dimension = frame)
+//   phase 3  per stage : refine / threshold / orientation / top-k / descriptors of ALL frames in one launch each
+// so that the latency-bound launches (30 tiny blurs, single-workgroup selections) are paid once per batch instead of
+// once per frame, on ONE in-order stream -- no reliance on how the runtime maps streams to hardware queues.
 struct SiftWork {
     int w = 0, h = 0;                        // input frame size the buffers are sized for
+    int nb = 0;                              // frames the buffers hold
     int n_oct = 0;
-    hipStream_t stream = nullptr;            // stage B queue of this slot (refine .. describe): latency-bound kernels
-    hipEvent_t a_done = nullptr, b_done = nullptr;
-    bool used = false;
+    hipStream_t stream = nullptr;
     DevBuf pyr;                              // all Gaussian levels
     DevBuf claimed;                          // duplicate claim bitmaps
     DevBuf cand, refined, kps, kresp, sel, counters, rhist, ccnt;
-    PyrDev P;
-    size_t claimed_bytes = 0;
+    DevBuf gray; int gray_pitch = 0; size_t gray_stride = 0;   // padded u8 gray of the frame (source of the streamed base level)
+    PyrDev P;                                // pointers of frame 0
+    BatchStride bs;
     unsigned cand_cap = 0, ref_cap = 0, kp_cap = 0;
     float kern[N_LEVELS][2 * MAX_R + 1];
     int radius[N_LEVELS];
     float kern0[2 * MAX_R + 1]; int radius0 = 0;
+    struct Pend { int img_id; const uint8_t* d_bgr; int ws; };
+    std::vector<Pend> pend;
 };
 
-// Two-stage software pipeline over frames.  Stage A (pyramid + extrema: the HBM-bound kernels, each of which fills
-// the chip) of every frame runs in order on ONE "heavy" stream, so those kernels never contend with each other.
-// Stage B (refine, orientation, top-k, descriptors: latency-bound, a few workgroups) runs on the slot's own stream
-// and overlaps stage A of the following frames.  Each slot owns a ~5 GB work area at 12 MP; a slot's pyramid is
-// reused by frame k+SIFT_SLOTS only after stage B of frame k finished (event).
-constexpr int SIFT_SLOTS_MAX = 8;
+constexpr int SIFT_SLOTS_MAX = 4;            // batch work areas (each with its own stream) that may be in flight
 #define SIFT_SLOTS (ctx->sift_nslots)
 
 void mi_sift_release(mi355_ctx* ctx) {
     for (SiftWork* s : ctx->sift_slots) {
         if (!s) continue;
         if (s->stream) { (void)hipStreamSynchronize(s->stream); (void)hipStreamDestroy(s->stream); }
-        if (s->a_done) (void)hipEventDestroy(s->a_done);
-        if (s->b_done) (void)hipEventDestroy(s->b_done);
-        s->pyr.release(); s->claimed.release(); s->cand.release(); s->refined.release(); s->kps.release(); s->kresp.release(); s->sel.release(); s->counters.release(); s->rhist.release(); s->ccnt.release();
+        s->pyr.release(); s->claimed.release(); s->cand.release(); s->refined.release(); s->kps.release(); s->kresp.release(); s->sel.release(); s->counters.release(); s->rhist.release(); s->ccnt.release(); s->gray.release();
         delete s;
     }
     ctx->sift_slots.clear();
     if (ctx->sift_in_ev) { (void)hipEventDestroy(ctx->sift_in_ev); ctx->sift_in_ev = nullptr; }
-    if (ctx->sift_heavy) { (void)hipStreamSynchronize(ctx->sift_heavy); (void)hipStreamDestroy(ctx->sift_heavy); ctx->sift_heavy = nullptr; }
     for (int* p : ctx->pinned_chunks) (void)hipHostFree(p);
     ctx->pinned_chunks.clear();
     ctx->pinned_used = 0;
 }
 
+static int sift_run_batch(mi355_ctx* ctx, SiftWork* s);
+
+// enqueues every partly filled batch
+int mi_sift_flush(mi355_ctx* ctx) {
+    int rc = MI355_OK;
+    for (SiftWork* s : ctx->sift_slots) if (s && !s->pend.empty()) { const int r = sift_run_batch(ctx, s); if (r != MI355_OK) rc = r; }
+    return rc;
+}
+
 // waits for every in-flight frame and adopts the keypoint counts that landed in pinned memory
 int mi_resolve_features(mi355_ctx* ctx) {
+    int rc = mi_sift_flush(ctx);
     bool any = false;
     for (auto& kv : ctx->feats) if (kv.second.pending) { any = true; break; }
-    if (!any) return MI355_OK;
-    if (ctx->sift_heavy) MI_HIP(hipStreamSynchronize(ctx->sift_heavy));
+    if (!any) return rc;
     for (SiftWork* s : ctx->sift_slots) if (s && s->stream) MI_HIP(hipStreamSynchronize(s->stream));
-    int rc = MI355_OK;
     for (auto& kv : ctx->feats) {
         Features& f = kv.second;
         if (!f.pending) continue;
         f.pending = false;
+        if (!f.h_cnt) { f.n = 0; continue; }                   // its batch failed to launch
         const volatile int* c = f.h_cnt;
         for (int i = 0; i < 8; i++) ctx->last_counts[i] = c[i];
         if ((unsigned)c[0] > f.caps[0] || (unsigned)c[1] > f.caps[1] || (unsigned)c[2] > f.caps[2] || c[4]) {
@@ -1251,9 +1376,10 @@ static int* pinned_slot(mi355_ctx* ctx) {
     return ctx->pinned_chunks[chunk] + off * 8;
 }
 
-static int sift_prepare(mi355_ctx* ctx, SiftWork* s, int w, int h) {
-    if (s->w == w && s->h == h) return MI355_OK;
-    MI_HIP(hipStreamSynchronize(ctx->sift_heavy));
+static inline size_t up64(size_t v) { return (v + 63) & ~(size_t)63; }
+
+static int sift_prepare(mi355_ctx* ctx, SiftWork* s, int w, int h, int nb) {
+    if (s->w == w && s->h == h && s->nb == nb) return MI355_OK;
     MI_HIP(hipStreamSynchronize(s->stream));
     if (s->radius0 == 0) {
         // Gaussian kernels (double math on the host, like the oracle): sigma_i = sqrt((s k^i)^2 - (s k^(i-1))^2)
@@ -1273,23 +1399,10 @@ static int sift_prepare(mi355_ctx* ctx, SiftWork* s, int w, int h) {
     for (int o = 0; o < nOct; o++) {
         const int ow = W >> o, oh = H >> o;
         if (ow < 2 * IMG_BORDER + 2 || oh < 2 * IMG_BORDER + 2) break;
-        fl += (size_t)ow * oh * N_LEVELS;
+        fl += up64((size_t)ow * oh) * N_LEVELS;                     // every level starts on a 256-byte boundary
         cl += (((size_t)ow * oh * 4 + 31) / 32 + 63) & ~(size_t)63;
         no = o + 1;
     }
-    MI_HIP(s->pyr.reserve(fl * sizeof(float)));
-    MI_HIP(s->claimed.reserve(cl * sizeof(unsigned)));
-    s->claimed_bytes = cl * sizeof(unsigned);
-    memset(&s->P, 0, sizeof(s->P));
-    size_t fo = 0, co = 0;
-    for (int o = 0; o < no; o++) {
-        const int ow = W >> o, oh = H >> o;
-        s->P.oc[o].w = ow; s->P.oc[o].h = oh;
-        for (int i = 0; i < N_LEVELS; i++) { s->P.oc[o].lv[i] = s->pyr.as<float>() + fo; fo += (size_t)ow * oh; }
-        s->P.claimed[o] = s->claimed.as<unsigned>() + co;
-        co += (((size_t)ow * oh * 4 + 31) / 32 + 63) & ~(size_t)63;
-    }
-    s->P.n_oct = no; s->n_oct = no;
     // capacities.  Candidates: the DoG threshold is 0, so on a constant image EVERY pixel of every layer is a
     // (tied) extremum: the worst case 3 layers x sum_o px0 / 4^o <= 4 px0 is provisioned (1.5 GB at 12 MP, of
     // 288 GB).  Refined points / keypoints must survive the contrast test: a fraction of the pixels bounds them.
@@ -1300,20 +1413,38 @@ static int sift_prepare(mi355_ctx* ctx, SiftWork* s, int w, int h) {
     s->cand_cap = (unsigned)((4 * px0 + 1024 + NREG - 1) / NREG + (size_t)MAX_OCT * 3 * EW * EH + 1024);
     s->ref_cap = (unsigned)(px0 / 32 + 65536);
     s->kp_cap = (unsigned)(px0 / 32 + 65536);
-    MI_HIP(s->cand.reserve((size_t)s->cand_cap * NREG * sizeof(unsigned long long)));
-    MI_HIP(s->refined.reserve((size_t)s->ref_cap * sizeof(Refined)));
-    MI_HIP(s->kps.reserve((size_t)s->kp_cap * sizeof(KpRec)));
-    MI_HIP(s->kresp.reserve((size_t)s->kp_cap * sizeof(unsigned)));
-    MI_HIP(s->sel.reserve(2048 * sizeof(SelRec)));
-    MI_HIP(s->counters.reserve(64 * sizeof(unsigned)));
-    MI_HIP(s->rhist.reserve(65536 * sizeof(unsigned)));
-    MI_HIP(s->ccnt.reserve(NREG * REG_STRIDE * sizeof(unsigned)));
-    s->w = w; s->h = h;
+    s->bs.pyr = fl; s->bs.claimed = cl; s->bs.cand = (size_t)s->cand_cap * NREG; s->bs.refined = s->ref_cap; s->bs.kps = s->kp_cap;
+    s->gray_pitch = (w + 8 + 15) & ~15;
+    s->gray_stride = up64((size_t)s->gray_pitch * h + 64);
+    const size_t B = (size_t)nb;
+    MI_HIP(s->pyr.reserve(B * fl * sizeof(float)));
+    MI_HIP(s->claimed.reserve(B * cl * sizeof(unsigned)));
+    MI_HIP(s->cand.reserve(B * s->bs.cand * sizeof(unsigned long long)));
+    MI_HIP(s->refined.reserve(B * s->bs.refined * sizeof(Refined)));
+    MI_HIP(s->kps.reserve(B * s->bs.kps * sizeof(KpRec)));
+    MI_HIP(s->kresp.reserve(B * s->bs.kps * sizeof(unsigned)));
+    MI_HIP(s->sel.reserve(B * SEL_STRIDE * sizeof(SelRec)));
+    MI_HIP(s->counters.reserve(B * CNT_STRIDE * sizeof(unsigned)));
+    MI_HIP(s->rhist.reserve(B * RHIST_STRIDE * sizeof(unsigned)));
+    MI_HIP(s->ccnt.reserve(B * CCNT_STRIDE * sizeof(unsigned)));
+    MI_HIP(s->gray.reserve(B * s->gray_stride));
+    memset(&s->P, 0, sizeof(s->P));
+    size_t fo = 0, co = 0;
+    for (int o = 0; o < no; o++) {
+        const int ow = W >> o, oh = H >> o;
+        s->P.oc[o].w = ow; s->P.oc[o].h = oh;
+        for (int i = 0; i < N_LEVELS; i++) { s->P.oc[o].lv[i] = s->pyr.as<float>() + fo; fo += up64((size_t)ow * oh); }
+        s->P.claimed[o] = s->claimed.as<unsigned>() + co;
+        co += (((size_t)ow * oh * 4 + 31) / 32 + 63) & ~(size_t)63;
+    }
+    s->P.n_oct = no; s->n_oct = no;
+    s->w = w; s->h = h; s->nb = nb;
     return MI355_OK;
 }
 
-// Enqueues detect+describe of one frame on the next slot stream and returns without waiting: the keypoint
-// count is adopted later by mi_resolve_features() (or right away when the caller asks for it through n_kp).
+// Accepts one frame: it joins the current batch, which is enqueued once it holds ctx->sift_batch frames (or on a
+// flush: any call that needs features, mi355_synchronize, or n_kp != NULL).  The frame memory must stay valid and
+// unchanged until then.  Returns without waiting; the keypoint count is adopted later by mi_resolve_features().
 int mi_sift_extract_dev(mi355_ctx* ctx, int img_id, const uint8_t* d_bgr, int w, int h, int ws, int* n_kp) {
     if (ctx->p.n_octave_layers != N_LAYERS || ctx->p.sigma != 1.6f) { ctx->set_error("sift: this build implements nOctaveLayers=3, sigma=1.6 (the reference's SIFT(2000,3,0.01,20))"); return MI355_ERR_ARG; }
     if (ctx->p.nfeatures < 1 || ctx->p.nfeatures > 2048) { ctx->set_error("sift: nfeatures must be in [1,2048]"); return MI355_ERR_ARG; }
@@ -1321,119 +1452,31 @@ int mi_sift_extract_dev(mi355_ctx* ctx, int img_id, const uint8_t* d_bgr, int w,
     if (ctx->sift_slots.empty()) {
         ctx->sift_slots.resize(SIFT_SLOTS_MAX, nullptr);
         MI_HIP(hipEventCreateWithFlags(&ctx->sift_in_ev, hipEventDisableTiming));
-        MI_HIP(hipStreamCreateWithFlags(&ctx->sift_heavy, hipStreamNonBlocking));
     }
     if (ctx->sift_next >= SIFT_SLOTS) ctx->sift_next = 0;
     const int slot = ctx->sift_next;
-    ctx->sift_next = (ctx->sift_next + 1) % SIFT_SLOTS;
     if (!ctx->sift_slots[slot]) {
         ctx->sift_slots[slot] = new SiftWork();
         MI_HIP(hipStreamCreateWithFlags(&ctx->sift_slots[slot]->stream, hipStreamNonBlocking));
-        MI_HIP(hipEventCreateWithFlags(&ctx->sift_slots[slot]->a_done, hipEventDisableTiming));
-        MI_HIP(hipEventCreateWithFlags(&ctx->sift_slots[slot]->b_done, hipEventDisableTiming));
     }
     SiftWork* s = ctx->sift_slots[slot];
-    int rc = sift_prepare(ctx, s, w, h);
+    int rc = MI355_OK;
+    const int nb = ctx->sift_batch < 1 ? 1 : (ctx->sift_batch > SIFT_BATCH_MAX ? SIFT_BATCH_MAX : ctx->sift_batch);
+    if (!s->pend.empty() && (s->w != w || s->h != h || s->nb != nb)) { rc = sift_run_batch(ctx, s); if (rc != MI355_OK) return rc; }   // size change: close the batch
+    rc = sift_prepare(ctx, s, w, h, nb);
     if (rc != MI355_OK) return rc;
     auto fit = ctx->feats.find(img_id);
     if (fit != ctx->feats.end() && fit->second.pending) { rc = mi_resolve_features(ctx); if (rc != MI355_OK) return rc; }   // same id re-extracted while in flight
-    // MI355_SIFT_TWO_STAGE=1 selects the two-stage pipeline (measured 12 % slower end to end than letting every slot
-    // run its whole frame on its own stream: the stage-B kernels take CUs from stage A either way)
-    static const bool two_stage = getenv("MI355_SIFT_TWO_STAGE") != nullptr;
-    const hipStream_t st = s->stream;                          // stage B
-    const hipStream_t sa = two_stage ? ctx->sift_heavy : st;   // stage A
-    static const bool host_timing = getenv("MI355_HOST_TIMING") != nullptr;
-    static double tacc[6] = {0}; static int tn = 0;
-    auto tnow = [] { return std::chrono::steady_clock::now(); };
-    auto tus = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
-    auto T0 = tnow();
-    const int nf = ctx->p.nfeatures;
     Features& f = ctx->feats[img_id];
     f.w = w; f.h = h;
     MI_HIP(f.kp.reserve(sizeof(mi355_keypoint) * 2048));
     MI_HIP(f.d8.reserve(128 * 2048));
-    // the frame was produced on the caller's stream: order stage A after it, and after stage B of the frame that
-    // used this slot's work area before
-    MI_HIP(hipEventRecord(ctx->sift_in_ev, ctx->stream));
-    MI_HIP(hipStreamWaitEvent(sa, ctx->sift_in_ev, 0));
-    if (s->used) MI_HIP(hipStreamWaitEvent(sa, s->b_done, 0));
-    s->used = true;
-    unsigned* cnt = s->counters.as<unsigned>();      // [0] candidates [1] refined [2] keypoints [3] n_sel [4] overflow
-    MI_HIP(hipMemsetAsync(cnt, 0, 64 * sizeof(unsigned), sa));
-    MI_HIP(hipMemsetAsync(s->ccnt.p, 0, NREG * REG_STRIDE * sizeof(unsigned), sa));
-    auto T1 = tnow();
-    // ---- pyramid ----
-    for (int o = 0; o < s->n_oct; o++) {
-        const OctaveDev& oc = s->P.oc[o];
-        BlurArgs a;
-        memset(&a, 0, sizeof(a));
-        a.w = oc.w; a.h = oc.h; a.tiles_x = (oc.w + TW - 1) / TW; a.tiles_y = (oc.h + TH - 1) / TH;
-        const double level_bytes = (double)oc.w * oc.h * 4.0;
-        if (o == 0) {
-            a.bgr = d_bgr; a.bgr_ws = ws; a.dst = oc.lv[0];
-            memcpy(a.k, s->kern0, sizeof(float) * (2 * s->radius0 + 1));
-            ProfScope ps(ctx, "gauss", level_bytes + (double)w * h * 3.0, sa);      // read the u8 frame, write level 0
-            if (!launch_blur<true>(sa, s->radius0, a, ctx->blur_stream)) { ctx->set_error("sift: unsupported kernel radius"); return MI355_ERR_FAILED; }
-        } else {
-            const OctaveDev& pv = s->P.oc[o - 1];
-            ProfScope ps(ctx, "downsample", level_bytes * 2.0, sa);
-            hipLaunchKernelGGL(downsample2, dim3((oc.w + 63) / 64, (oc.h + 3) / 4), dim3(256), 0, sa, pv.lv[N_LAYERS], pv.w, oc.lv[0], oc.w, oc.h);
-        }
-        for (int i = 1; i < N_LEVELS; i++) {
-            a.bgr = nullptr; a.src = oc.lv[i - 1]; a.dst = oc.lv[i];
-            memcpy(a.k, s->kern[i], sizeof(float) * (2 * s->radius[i] + 1));
-            ProfScope ps(ctx, "gauss", level_bytes * 2.0, sa);                        // one read + one write of the level
-            if (!launch_blur<false>(sa, s->radius[i], a, ctx->blur_stream)) { ctx->set_error("sift: unsupported kernel radius"); return MI355_ERR_FAILED; }
-        }
-        {
-            ProfScope ps(ctx, "extrema", level_bytes * 6.0, sa);
-            hipLaunchKernelGGL(extrema_kernel, dim3(((oc.w + EW - 1) / EW) * ((oc.h + EH - 1) / EH)), dim3(256), 0, sa,
-                               oc, o, s->cand.as<unsigned long long>(), s->ccnt.as<unsigned>(), s->cand_cap, cnt + 4);
-        }
+    f.pending = true; f.h_cnt = nullptr; f.n = 0;
+    s->pend.push_back({img_id, d_bgr, ws});
+    if ((int)s->pend.size() >= nb) {
+        rc = sift_run_batch(ctx, s);
+        if (rc != MI355_OK) return rc;
     }
-    auto T2 = tnow();
-    MI_HIP(hipEventRecord(s->a_done, sa));
-    MI_HIP(hipStreamWaitEvent(st, s->a_done, 0));
-    MI_HIP(hipMemsetAsync(s->claimed.p, 0, s->claimed_bytes, st));
-    MI_HIP(hipMemsetAsync(f.d8.p, 0, 128 * 2048, st));
-    MI_HIP(hipMemsetAsync(s->rhist.p, 0, 65536 * sizeof(unsigned), st));
-    {
-        ProfScope ps(ctx, "refine", 0.0, st);
-        hipLaunchKernelGGL(refine_kernel, dim3(32, NREG), dim3(256), 0, st, s->P, s->cand.as<unsigned long long>(), s->ccnt.as<unsigned>(), s->cand_cap, cnt + 0,
-                           ctx->p.contrast_threshold, ctx->p.edge_threshold, 1.6f, s->refined.as<Refined>(), cnt + 1, s->ref_cap, s->rhist.as<unsigned>());
-        hipLaunchKernelGGL(resp_threshold_kernel, dim3(1), dim3(1024), 0, st, s->rhist.as<unsigned>(), cnt + 1, (unsigned)nf + 256u, cnt + 8);
-    }
-    for (int pass = 0; pass < 2; pass++) {       // pass 1 (everything below the response threshold) exits at once unless top-k asked for it
-        {
-            ProfScope ps(ctx, "orient", 0.0, st);
-            hipLaunchKernelGGL(orient_kernel, dim3(ctx->num_cu * 4), dim3(256), 0, st, s->P, s->refined.as<Refined>(), cnt + 1, s->ref_cap,
-                               s->kps.as<KpRec>(), s->kresp.as<unsigned>(), cnt + 2, s->kp_cap, cnt + 8, pass);
-        }
-        {
-            ProfScope ps(ctx, "topk", 0.0, st);
-            hipLaunchKernelGGL(topk_kernel, dim3(1), dim3(1024), 0, st, s->kps.as<KpRec>(), s->kresp.as<unsigned>(), cnt + 2, s->kp_cap, nf,
-                               f.kp.as<mi355_keypoint>(), s->sel.as<SelRec>(), reinterpret_cast<int*>(cnt + 3), reinterpret_cast<int*>(cnt + 4), cnt + 8, pass);
-        }
-    }
-    {
-        ProfScope ps(ctx, "describe", 0.0, st);
-        hipLaunchKernelGGL(describe_kernel, dim3(nf), dim3(256), 0, st, s->P, s->sel.as<SelRec>(), reinterpret_cast<const int*>(cnt + 3), f.d8.as<uint8_t>());
-    }
-    auto T3 = tnow();
-    MI_HIP(hipGetLastError());
-    rc = mi_finish_features(ctx, f, reinterpret_cast<const int*>(cnt + 3), st);
-    if (rc != MI355_OK) return rc;
-    int* hc = pinned_slot(ctx);
-    if (!hc) { ctx->set_error("sift: pinned alloc failed"); return MI355_ERR_NOMEM; }
-    MI_HIP(hipMemcpyAsync(hc, cnt, 8 * sizeof(unsigned), hipMemcpyDeviceToHost, st));
-    MI_HIP(hipEventRecord(s->b_done, st));
-    f.h_cnt = hc; f.pending = true; f.n = 0;
-    if (host_timing) {
-        auto T4 = tnow();
-        tacc[0] += tus(T0, T1); tacc[1] += tus(T1, T2); tacc[2] += tus(T2, T3); tacc[3] += tus(T3, T4); tn++;
-        if (tn % 24 == 0) { fprintf(stderr, "[host timing us/frame] setup+memsets %.1f pyramid %.1f tail %.1f finish+copy %.1f\n", tacc[0] / tn, tacc[1] / tn, tacc[2] / tn, tacc[3] / tn); }
-    }
-    f.caps[0] = 0xffffffffu; f.caps[1] = s->ref_cap; f.caps[2] = s->kp_cap;      // candidate overflow is flagged by the kernel (cnt[4])
     if (ctx->pinned_used >= PINNED_CHUNK * 64) {           // recycle the pinned pool when nothing is pending any more
         rc = mi_resolve_features(ctx);
         if (rc != MI355_OK) return rc;
@@ -1443,6 +1486,137 @@ int mi_sift_extract_dev(mi355_ctx* ctx, int img_id, const uint8_t* d_bgr, int w,
         rc = mi_resolve_features(ctx);
         if (rc != MI355_OK) return rc;
         *n_kp = f.n;
+    }
+    return MI355_OK;
+}
+
+static int sift_run_batch(mi355_ctx* ctx, SiftWork* s) {
+    std::vector<SiftWork::Pend> pend;
+    pend.swap(s->pend);
+    const int n = (int)pend.size();
+    if (n == 0) return MI355_OK;
+    ctx->sift_next = (ctx->sift_next + 1) % SIFT_SLOTS;     // the next batch collects in the next work area
+    const hipStream_t st = s->stream;
+    const int w = s->w, h = s->h;
+    const int nf = ctx->p.nfeatures;
+    const BatchStride bs = s->bs;
+    // the frames were produced on the caller's stream
+    MI_HIP(hipEventRecord(ctx->sift_in_ev, ctx->stream));
+    MI_HIP(hipStreamWaitEvent(st, ctx->sift_in_ev, 0));
+    unsigned* cnt = s->counters.as<unsigned>();      // per frame: [0] candidates [1] refined [2] keypoints [3] n_sel [4] overflow [8,9] ctrl
+    MI_HIP(hipMemsetAsync(cnt, 0, (size_t)n * CNT_STRIDE * sizeof(unsigned), st));
+    MI_HIP(hipMemsetAsync(s->ccnt.p, 0, (size_t)n * CCNT_STRIDE * sizeof(unsigned), st));
+    MI_HIP(hipMemsetAsync(s->claimed.p, 0, (size_t)n * bs.claimed * sizeof(unsigned), st));
+    MI_HIP(hipMemsetAsync(s->rhist.p, 0, (size_t)n * RHIST_STRIDE * sizeof(unsigned), st));
+    FrameOuts outs;
+    memset(&outs, 0, sizeof(outs));
+    std::vector<Features*> fs(n);
+    for (int k = 0; k < n; k++) {
+        fs[k] = &ctx->feats[pend[k].img_id];
+        outs.kp[k] = fs[k]->kp.as<mi355_keypoint>(); outs.d8[k] = fs[k]->d8.as<uint8_t>();
+        MI_HIP(hipMemsetAsync(fs[k]->d8.p, 0, 128 * 2048, st));
+    }
+    auto octave_big = [&](int o) { return s->P.oc[o].w >= STREAM_MIN_W && s->P.oc[o].h >= STREAM_MIN_H; };
+    const BatchStride bs1 = bs;                      // single-frame launches pre-offset their pointers on the host
+    auto blur_args = [&](const OctaveDev& oc) {
+        BlurArgs a; memset(&a, 0, sizeof(a));
+        a.w = oc.w; a.h = oc.h; a.tiles_x = (oc.w + TW - 1) / TW; a.tiles_y = (oc.h + TH - 1) / TH;
+        return a;
+    };
+    // ---- phase 1: per frame, the octaves whose kernels fill the chip (and the base level in any case) ----
+    int first_small = s->n_oct;
+    for (int o = 0; o < s->n_oct; o++) if (!octave_big(o)) { first_small = o; break; }
+    for (int k = 0; k < n; k++) {
+        const size_t fo = (size_t)k * bs.pyr;
+        for (int o = 0; o < s->n_oct && (o < first_small || o == 0); o++) {
+            OctaveDev oc = s->P.oc[o];
+            for (int i = 0; i < N_LEVELS; i++) oc.lv[i] += fo;
+            BlurArgs a = blur_args(oc);
+            const double level_bytes = (double)oc.w * oc.h * 4.0;
+            if (o == 0) {
+                a.bgr = pend[k].d_bgr; a.bgr_ws = pend[k].ws; a.dst = oc.lv[0];
+                memcpy(a.k, s->kern0, sizeof(float) * (2 * s->radius0 + 1));
+                ProfScope ps(ctx, "gauss", level_bytes + (double)w * h * 3.0, st);      // read the u8 frame, write level 0
+                if (base_streams(a, s->radius0, ctx->blur_stream)) launch_base_stream(st, a, s->gray.as<uint8_t>() + (size_t)k * s->gray_stride, s->gray_pitch);
+                else if (!launch_blur<true>(st, s->radius0, a, ctx->blur_stream)) { ctx->set_error("sift: unsupported kernel radius"); return MI355_ERR_FAILED; }
+            } else {
+                const OctaveDev& pv = s->P.oc[o - 1];
+                ProfScope ps(ctx, "downsample", level_bytes * 2.0, st);
+                hipLaunchKernelGGL(downsample2, dim3((oc.w + 63) / 64, (oc.h + 3) / 4, 1), dim3(256), 0, st, pv.lv[N_LAYERS] + fo, pv.w, oc.lv[0], oc.w, oc.h, (size_t)0);
+            }
+            if (o >= first_small) break;                 // small frame: only its base level is per frame
+            for (int i = 1; i < N_LEVELS; i++) {
+                a.bgr = nullptr; a.src = oc.lv[i - 1]; a.dst = oc.lv[i];
+                memcpy(a.k, s->kern[i], sizeof(float) * (2 * s->radius[i] + 1));
+                ProfScope ps(ctx, blur_streams(a, false, s->radius[i], ctx->blur_stream) ? "gauss_stream" : "gauss", level_bytes * 2.0, st);   // one read + one write of the level
+                if (!launch_blur<false>(st, s->radius[i], a, ctx->blur_stream)) { ctx->set_error("sift: unsupported kernel radius"); return MI355_ERR_FAILED; }
+            }
+            {
+                ProfScope ps(ctx, "extrema", level_bytes * 6.0, st);
+                BatchStride z = bs1; (void)z;
+                hipLaunchKernelGGL(extrema_kernel, dim3(((oc.w + EW - 1) / EW) * ((oc.h + EH - 1) / EH), 1), dim3(256), 0, st,
+                                   oc, o, s->cand.as<unsigned long long>() + (size_t)k * bs.cand, s->ccnt.as<unsigned>() + (size_t)k * CCNT_STRIDE, s->cand_cap,
+                                   cnt + (size_t)k * CNT_STRIDE + 4, bs);
+            }
+        }
+    }
+    // ---- phase 2: the small octaves of all n frames, one launch per level ----
+    for (int o = first_small; o < s->n_oct; o++) {
+        const OctaveDev& oc = s->P.oc[o];
+        BlurArgs a = blur_args(oc);
+        a.fstride = bs.pyr; a.nb = n;
+        const double level_bytes = (double)oc.w * oc.h * 4.0 * n;
+        if (o > 0) {
+            const OctaveDev& pv = s->P.oc[o - 1];
+            ProfScope ps(ctx, "downsample", level_bytes * 2.0, st);
+            hipLaunchKernelGGL(downsample2, dim3((oc.w + 63) / 64, (oc.h + 3) / 4, n), dim3(256), 0, st, pv.lv[N_LAYERS], pv.w, oc.lv[0], oc.w, oc.h, bs.pyr);
+        }
+        for (int i = 1; i < N_LEVELS; i++) {
+            a.bgr = nullptr; a.src = oc.lv[i - 1]; a.dst = oc.lv[i];
+            memcpy(a.k, s->kern[i], sizeof(float) * (2 * s->radius[i] + 1));
+            ProfScope ps(ctx, "gauss", level_bytes * 2.0, st);
+            if (!launch_blur<false>(st, s->radius[i], a, 0)) { ctx->set_error("sift: unsupported kernel radius"); return MI355_ERR_FAILED; }
+        }
+        {
+            ProfScope ps(ctx, "extrema", level_bytes * 6.0, st);
+            hipLaunchKernelGGL(extrema_kernel, dim3(((oc.w + EW - 1) / EW) * ((oc.h + EH - 1) / EH), n), dim3(256), 0, st,
+                               oc, o, s->cand.as<unsigned long long>(), s->ccnt.as<unsigned>(), s->cand_cap, cnt + 4, bs);
+        }
+    }
+    // ---- phase 3: keypoint stages of all n frames ----
+    {
+        ProfScope ps(ctx, "refine", 0.0, st);
+        hipLaunchKernelGGL(refine_kernel, dim3(32, NREG, n), dim3(256), 0, st, s->P, s->cand.as<unsigned long long>(), s->ccnt.as<unsigned>(), s->cand_cap, cnt + 0,
+                           ctx->p.contrast_threshold, ctx->p.edge_threshold, 1.6f, s->refined.as<Refined>(), cnt + 1, s->ref_cap, s->rhist.as<unsigned>(), bs);
+        hipLaunchKernelGGL(resp_threshold_kernel, dim3(n), dim3(1024), 0, st, s->rhist.as<unsigned>(), cnt + 1, (unsigned)nf + 256u, cnt + 8);
+    }
+    for (int pass = 0; pass < 2; pass++) {       // pass 1 (everything below the response threshold) exits at once unless top-k asked for it
+        {
+            ProfScope ps(ctx, "orient", 0.0, st);
+            hipLaunchKernelGGL(orient_kernel, dim3(ctx->num_cu * 4, n), dim3(256), 0, st, s->P, s->refined.as<Refined>(), cnt + 1, s->ref_cap,
+                               s->kps.as<KpRec>(), s->kresp.as<unsigned>(), cnt + 2, s->kp_cap, cnt + 8, pass, bs);
+        }
+        {
+            ProfScope ps(ctx, "topk", 0.0, st);
+            hipLaunchKernelGGL(topk_kernel, dim3(n), dim3(1024), 0, st, s->kps.as<KpRec>(), s->kresp.as<unsigned>(), cnt + 2, s->kp_cap, nf,
+                               outs, s->sel.as<SelRec>(), reinterpret_cast<int*>(cnt + 3), reinterpret_cast<int*>(cnt + 4), cnt + 8, pass, bs);
+        }
+    }
+    {
+        ProfScope ps(ctx, "describe", 0.0, st);
+        hipLaunchKernelGGL(describe_kernel, dim3(nf, n), dim3(256), 0, st, s->P, s->sel.as<SelRec>(), reinterpret_cast<const int*>(cnt + 3), outs, bs);
+    }
+    MI_HIP(hipGetLastError());
+    for (int k = 0; k < n; k++) {
+        Features& f = *fs[k];
+        unsigned* ck = cnt + (size_t)k * CNT_STRIDE;
+        int rc = mi_finish_features(ctx, f, reinterpret_cast<const int*>(ck + 3), st);
+        if (rc != MI355_OK) return rc;
+        int* hc = pinned_slot(ctx);
+        if (!hc) { ctx->set_error("sift: pinned alloc failed"); return MI355_ERR_NOMEM; }
+        MI_HIP(hipMemcpyAsync(hc, ck, 8 * sizeof(unsigned), hipMemcpyDeviceToHost, st));
+        f.h_cnt = hc; f.pending = true; f.n = 0;
+        f.caps[0] = 0xffffffffu; f.caps[1] = s->ref_cap; f.caps[2] = s->kp_cap;      // candidate overflow is flagged by the kernel (cnt[4])
     }
     return MI355_OK;
 }

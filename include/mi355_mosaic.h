@@ -91,9 +91,12 @@ const char* mi355_last_error(mi355_ctx* ctx);          /* ctx may be NULL: last 
 /* Run on a caller-provided hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); NULL = ctx-owned stream. */
 int  mi355_set_stream(mi355_ctx* ctx, void* hip_stream);
 int  mi355_synchronize(mi355_ctx* ctx);
-/* Tunables: "sift_slots" = frames whose detect+describe may be in flight at once (1..8, default 4; each slot owns a
- * pyramid work area, 4.7 GB at 4000x3000); "blur_stream" = 1 (default) runs pyramid levels of >= 2048x1536 through the
- * barrier-free streaming Gaussian, 0 forces the tiled kernel everywhere (same bits either way). */
+/* Tunables: "sift_batch" = frames per detect+describe batch (1..8, default 8): frames handed to mi355_sift_extract_dev
+ * collect until the batch is full (or until a call needs their features) and are then enqueued together, the small
+ * pyramid octaves and the keypoint stages of all frames of the batch in one launch each; "sift_slots" = batch work areas
+ * that may be in flight at once, each on its own stream (1..4, default 3; a work area holds sift_batch pyramids and
+ * candidate lists, 3.2 GB per frame at 4000x3000); "blur_stream" = 1 (default) runs pyramid levels of >= 2048x1536
+ * through the barrier-free streaming Gaussian, 0 forces the tiled kernel everywhere (same bits either way). */
 int  mi355_set_option(mi355_ctx* ctx, const char* name, int value);
 void mi355_free(void* p);                               /* frees host buffers returned by this library */
 
@@ -103,7 +106,9 @@ void mi355_free(void* p);                               /* frees host buffers re
  * mi355_match_pairs (the reference round-trips them through d:/feature_temp files instead). */
 int  mi355_sift_extract(mi355_ctx* ctx, int img_id, const uint8_t* bgr, int w, int h, int width_step,
                         mi355_keypoint* kp, float* desc128, int max_kp, int* n_kp);
-/* Same, image already in HBM (device pointer); nothing is copied back. */
+/* Same, image already in HBM (device pointer); nothing is copied back.  With n_kp == NULL the call returns at once and
+ * the frame joins the current batch (see "sift_batch"): d_bgr must stay valid and unchanged until a call that needs the
+ * features (match, get_features, synchronize) has returned. */
 int  mi355_sift_extract_dev(mi355_ctx* ctx, int img_id, const uint8_t* d_bgr, int w, int h, int width_step, int* n_kp);
 /* Fetch / install device-resident features (LoadSurfKeyPoints / WriteSurfKeyPoints counterparts,
  * MosaicWithoutPos.cpp:4682-4734).  desc128 holds integer-valued floats. */

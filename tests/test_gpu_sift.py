@@ -100,3 +100,31 @@ def test_sift_streaming_blur_levels(ctx, oracle):
         kp0, desc0 = c0.SiftExtract(7, img)
         c0.close()
         assert np.array_equal(kp0.view(np.uint8), kp.view(np.uint8)) and np.array_equal(desc0.astype(np.uint8), d8)
+
+
+def test_sift_batched_frames_equal_single(ctx, oracle):
+    """frames enqueued asynchronously are processed as batches (small octaves and keypoint stages of all frames in one
+    launch each, several work areas in flight): same features as one-at-a-time extraction, for ragged batch sizes, a
+    frame-size change inside a stream of frames, and a frame whose big octaves take the streaming kernels"""
+    import torch
+    import imagemosaicing_amd as im
+    from tests.synth_frames import terrain
+    sizes = [(320, 240)] * 11 + [(200, 160)] * 3 + [(1100, 780)] * 3
+    imgs = [terrain(w, h, seed=40 + k) for k, (w, h) in enumerate(sizes)]
+    ref = []
+    for k, img in enumerate(imgs):
+        ref.append(ctx.SiftExtract(900 + k, img))          # synchronous: batch of one
+    okp, odesc = oracle.sift(imgs[5])
+    assert np.array_equal(ref[5][0]["response"].view(np.uint32), okp["response"].view(np.uint32)) and np.array_equal(ref[5][1].astype(np.uint8), odesc)
+    for batch, slots in [(8, 3), (4, 1), (3, 2)]:
+        c = im.Context(0)
+        c.set_option("sift_batch", batch); c.set_option("sift_slots", slots)
+        dev = [torch.from_numpy(np.ascontiguousarray(i)).cuda() for i in imgs]
+        torch.cuda.synchronize()
+        for k, d in enumerate(dev):
+            c.SiftExtractDev(k, d.data_ptr(), sizes[k][0], sizes[k][1], sizes[k][0] * 3)
+        for k in range(len(imgs)):
+            kp, desc = c.GetFeatures(k)
+            assert np.array_equal(kp.view(np.uint8), ref[k][0].view(np.uint8)), f"batch {batch}: frame {k} keypoints differ"
+            assert np.array_equal(desc, ref[k][1]), f"batch {batch}: frame {k} descriptors differ"
+        c.close()
