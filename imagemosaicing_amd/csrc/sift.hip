@@ -435,7 +435,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     static_assert(NP % D == 0 && NP % 2 == 0 && NP >= N, "ring");
     __shared__ v4f s_buf[4][2][(BW + 64) / 4];      // + 64 floats: dump area for lanes that have no halo / fix-up work
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int unit = xcd_remap(blockIdx.x, gridDim.x) * 4 + wave;
+    int unit = xcd_remap(blockIdx.x, gridDim.x) * 4 + wave;
+    if (!UPS) {                                      // batched launch: the unit list runs over all frames
+        const int per = nstrip * nseg, fr = unit / per;
+        if (fr >= (a.nb > 1 ? a.nb : 1)) return;
+        unit -= fr * per;
+        a.src += (size_t)fr * a.fstride; a.dst += (size_t)fr * a.fstride;
+    }
     const int seg = unit / nstrip, strip = unit - seg * nstrip;
     if (seg >= nseg) return;
     const int x0 = strip * SW, y0 = seg * L;
@@ -1212,21 +1218,23 @@ int gauss_kernel_host(double sigma, float* k) {
 }
 
 constexpr int STREAM_MIN_W = 2048, STREAM_MIN_H = 1536;
+constexpr int STREAM_MIN_W_BATCH = 1000, STREAM_MIN_H_BATCH = 750;    // batched launches (several frames): smaller levels still fill the chip
 // does this level go through blur_stream?  (f32 source, 16-byte aligned rows, last strip wider than the largest radius)
 inline bool blur_streams(const BlurArgs& a, bool bgr, int R, int stream_mode) {
     const bool stream_ok = ((a.w & 3) == 0) && (((uintptr_t)a.src & 15) == 0) && (((uintptr_t)a.dst & 15) == 0) && ((a.w & 255) == 0 || (a.w & 255) > MAX_R);
     const bool has_r = R == 5 || R == 6 || R == 8 || R == 10 || R == 13;
-    return !bgr && stream_mode && stream_ok && has_r && a.w >= STREAM_MIN_W && a.h >= STREAM_MIN_H;
+    const bool big = a.nb > 1 ? (a.w >= STREAM_MIN_W_BATCH && a.h >= STREAM_MIN_H_BATCH) : (a.w >= STREAM_MIN_W && a.h >= STREAM_MIN_H);
+    return !bgr && stream_mode && stream_ok && has_r && big;
 }
 // base level (2x up-sampled gray of the frame, blurred): gray_pad_kernel + blur_stream<R, D, UPS> when the level is big
 inline bool base_streams(const BlurArgs& a, int R, int stream_mode) {
     return stream_mode && R == 5 && ((a.w & 3) == 0) && (((uintptr_t)a.dst & 15) == 0) && ((a.w & 255) == 0 || (a.w & 255) > MAX_R) && a.w >= STREAM_MIN_W && a.h >= STREAM_MIN_H;
 }
-inline void stream_grid(int w, int h, int& L, int& nstrip, int& nseg) {
+inline void stream_grid(int w, int h, int& L, int& nstrip, int& nseg, int nb = 1) {
     static const int units_target = [] { const char* e = getenv("MI355_STREAM_UNITS"); return e ? atoi(e) : 2048; }();
-    static const int stream_minl = [] { const char* e = getenv("MI355_STREAM_MINL"); return e ? atoi(e) : 32; }();
+    static const int stream_minl = [] { const char* e = getenv("MI355_STREAM_MINL"); return e ? atoi(e) : 64; }();
     nstrip = (w + 255) / 256;
-    nseg = (units_target + nstrip - 1) / nstrip;
+    nseg = (units_target + nstrip * nb - 1) / (nstrip * nb);
     L = (h + nseg - 1) / nseg;
     if (L < stream_minl) L = stream_minl;
     nseg = (h + L - 1) / L;
@@ -1251,11 +1259,11 @@ bool launch_blur(hipStream_t st, int R, const BlurArgs& a, int stream_mode = 1) 
 #else
     const bool use2 = big;
 #endif
-    if (use2 && blur_streams(a, BGR, R, stream_mode)) {
+    if (blur_streams(a, BGR, R, stream_mode)) {
         // barrier-free streaming kernel: ~2 waves per SIMD over the whole chip (2048 waves), segments of >= 32 rows
         int L, nstrip, nseg;
-        stream_grid(a.w, a.h, L, nstrip, nseg);
-        const int units = nstrip * nseg;
+        stream_grid(a.w, a.h, L, nstrip, nseg, a.nb > 1 ? a.nb : 1);
+        const int units = nstrip * nseg * (a.nb > 1 ? a.nb : 1);
         const dim3 grid((units + 3) / 4), block(256);
         switch (R) {
 #define CASE(RR, DD) case RR: hipLaunchKernelGGL((blur_stream<RR, DD, false>), grid, block, 0, st, a, L, nstrip, nseg); return true;
@@ -1575,7 +1583,7 @@ static int sift_run_batch(mi355_ctx* ctx, SiftWork* s) {
             a.bgr = nullptr; a.src = oc.lv[i - 1]; a.dst = oc.lv[i];
             memcpy(a.k, s->kern[i], sizeof(float) * (2 * s->radius[i] + 1));
             ProfScope ps(ctx, "gauss", level_bytes * 2.0, st);
-            if (!launch_blur<false>(st, s->radius[i], a, 0)) { ctx->set_error("sift: unsupported kernel radius"); return MI355_ERR_FAILED; }
+            if (!launch_blur<false>(st, s->radius[i], a, n > 1 ? ctx->blur_stream : 0)) { ctx->set_error("sift: unsupported kernel radius"); return MI355_ERR_FAILED; }
         }
         {
             ProfScope ps(ctx, "extrema", level_bytes * 6.0, st);

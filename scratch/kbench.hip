@@ -20,6 +20,7 @@ int main(int argc, char** argv) {
         BlurArgs a; memset(&a, 0, sizeof(a));
         const int R = gauss_kernel_host(std::sqrt(stt * stt - sp * sp), a.k);
         a.src = lv[i - 1]; a.dst = lv[i]; a.w = W; a.h = H; a.tiles_x = (W + TW - 1) / TW; a.tiles_y = (H + TH - 1) / TH;
+        if (getenv("KNB")) { a.nb = atoi(getenv("KNB")); a.fstride = 0; }
         launch_blur<false>(st, R, a, smode);
         CK(hipStreamSynchronize(st));
         CK(hipEventRecord(e0, st));
@@ -31,13 +32,37 @@ int main(int argc, char** argv) {
         for (size_t q = 0; q < px; q++) { unsigned u; memcpy(&u, &h[q], 4); ck = (ck ^ u) * 1099511628211ull; }
         printf("blur R=%2d: %.1f us  %.0f GB/s algorithmic  checksum %016llx\n", R, ms * 1e3, px * 8.0 / ms / 1e6, ck);
     }
+    {   // base level: u8 BGR frame (W/2 x H/2) -> gray -> 2x up-sampling -> blur
+        const int fw = W / 2, fh = H / 2, ws = fw * 3;
+        uint8_t* bgr; CK(hipMalloc(&bgr, (size_t)ws * fh));
+        std::vector<uint8_t> hb((size_t)ws * fh);
+        for (size_t i = 0; i < hb.size(); i++) { s = s * 1664525u + 1013904223u; hb[i] = (uint8_t)(s >> 24); }
+        CK(hipMemcpy(bgr, hb.data(), hb.size(), hipMemcpyHostToDevice));
+        const int gp = (fw + 8 + 15) & ~15;
+        uint8_t* gray; CK(hipMalloc(&gray, (size_t)gp * fh + 64));
+        BlurArgs a; memset(&a, 0, sizeof(a));
+        const int R = gauss_kernel_host(std::sqrt(1.6 * 1.6 - 1.0), a.k);
+        a.bgr = bgr; a.bgr_ws = ws; a.dst = lv[6]; a.w = W; a.h = H; a.tiles_x = (W + TW - 1) / TW; a.tiles_y = (H + TH - 1) / TH;
+        for (int mode = 0; mode < 2; mode++) {
+            for (int it = 0; it < 11; it++) {
+                if (it == 1) CK(hipEventRecord(e0, st));
+                if (mode && base_streams(a, R, 1)) launch_base_stream(st, a, gray, gp); else launch_blur<true>(st, R, a, 0);
+            }
+            CK(hipEventRecord(e1, st)); CK(hipStreamSynchronize(st));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= 10;
+            CK(hipMemcpy(h.data(), lv[6], px * 4, hipMemcpyDeviceToHost));
+            unsigned long long ck = 1469598103934665603ull;
+            for (size_t q = 0; q < px; q++) { unsigned u; memcpy(&u, &h[q], 4); ck = (ck ^ u) * 1099511628211ull; }
+            printf("base R=%d mode %d: %.1f us  checksum %016llx\n", R, mode, ms * 1e3, ck);
+        }
+    }
     if (argc > 1) return 0;
     OctaveDev oc; for (int i = 0; i < 6; i++) oc.lv[i] = lv[i]; oc.w = W; oc.h = H;
     unsigned long long* cand; unsigned* cnt; CK(hipMalloc(&cand, 64 << 20)); CK(hipMalloc(&cnt, 8192)); CK(hipMemset(cnt, 0, 8192));
     for (int rep = 0; rep < 2; rep++) {
         CK(hipMemset(cnt, 0, 8192));
         CK(hipEventRecord(e0, st));
-        for (int it = 0; it < 5; it++) hipLaunchKernelGGL(extrema_kernel, dim3(((W + EW - 1) / EW) * ((H + EH - 1) / EH)), dim3(256), 0, st, oc, 0, cand, cnt, (8u << 20) / 64, cnt + 2047);
+        for (int it = 0; it < 5; it++) hipLaunchKernelGGL(extrema_kernel, dim3(((W + EW - 1) / EW) * ((H + EH - 1) / EH)), dim3(256), 0, st, oc, 0, cand, cnt, (8u << 20) / 64, cnt + 2047, BatchStride{0, 0, 0, 0, 0});
         CK(hipEventRecord(e1, st)); CK(hipStreamSynchronize(st));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= 5;
         unsigned c; CK(hipMemcpy(&c, cnt, 4, hipMemcpyDeviceToHost));
