@@ -126,6 +126,7 @@ struct BlurArgs {
     float k[2 * MAX_R + 1];
     size_t fstride;          // batched launch: frame f (blockIdx.y, or the tile index / tiles for the persistent kernel) reads
     int nb;                  // src + f * fstride and writes dst + f * fstride (floats); nb = frames in the batch (0 or 1: single)
+    size_t gstride;          // blur_stream UPS: frame f reads the padded gray at bgr + f * gstride (bytes)
 };
 
 // 2x bilinear upsample of the fixed-point gray image, pixel-centre aligned, edge clamp (exact in binary32)
@@ -436,11 +437,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     __shared__ v4f s_buf[4][2][(BW + 64) / 4];      // + 64 floats: dump area for lanes that have no halo / fix-up work
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int unit = xcd_remap(blockIdx.x, gridDim.x) * 4 + wave;
-    if (!UPS) {                                      // batched launch: the unit list runs over all frames
+    {                                                // batched launch: the unit list runs over all frames
         const int per = nstrip * nseg, fr = unit / per;
         if (fr >= (a.nb > 1 ? a.nb : 1)) return;
         unit -= fr * per;
-        a.src += (size_t)fr * a.fstride; a.dst += (size_t)fr * a.fstride;
+        if (UPS) a.bgr += (size_t)fr * a.gstride; else a.src += (size_t)fr * a.fstride;
+        a.dst += (size_t)fr * a.fstride;
     }
     const int seg = unit / nstrip, strip = unit - seg * nstrip;
     if (seg >= nseg) return;
@@ -1239,14 +1241,17 @@ inline void stream_grid(int w, int h, int& L, int& nstrip, int& nseg, int nb = 1
     if (L < stream_minl) L = stream_minl;
     nseg = (h + L - 1) / L;
 }
-inline void launch_base_stream(hipStream_t st, const BlurArgs& a /* bgr frame + dst level */, uint8_t* gray, int gp) {
-    const int w = a.w >> 1, h = a.h >> 1;
-    hipLaunchKernelGGL(gray_pad_kernel, dim3((gp + 255) / 256, h), dim3(256), 0, st, a.bgr, a.bgr_ws, w, h, gray, gp);
+inline void launch_gray_pad(hipStream_t st, const uint8_t* bgr, int ws, int w, int h, uint8_t* gray, int gp) {
+    hipLaunchKernelGGL(gray_pad_kernel, dim3((gp + 255) / 256, h), dim3(256), 0, st, bgr, ws, w, h, gray, gp);
+}
+// a.dst / a.fstride / a.nb: level 0 of the batch; gray / gstride: the padded gray frames
+inline void launch_base_stream(hipStream_t st, const BlurArgs& a, const uint8_t* gray, int gp, size_t gstride) {
     BlurArgs a2 = a;
-    a2.bgr = gray; a2.bgr_ws = gp;
+    a2.bgr = gray; a2.bgr_ws = gp; a2.gstride = gstride;
+    const int nb = a.nb > 1 ? a.nb : 1;
     int L, nstrip, nseg;
-    stream_grid(a.w, a.h, L, nstrip, nseg);
-    hipLaunchKernelGGL((blur_stream<5, 8, true>), dim3((nstrip * nseg + 3) / 4), dim3(256), 0, st, a2, L, nstrip, nseg);
+    stream_grid(a.w, a.h, L, nstrip, nseg, nb);
+    hipLaunchKernelGGL((blur_stream<5, 8, true>), dim3((nstrip * nseg * nb + 3) / 4), dim3(256), 0, st, a2, L, nstrip, nseg);
 }
 template <bool BGR>
 bool launch_blur(hipStream_t st, int R, const BlurArgs& a, int stream_mode = 1) {
@@ -1524,57 +1529,32 @@ static int sift_run_batch(mi355_ctx* ctx, SiftWork* s) {
         outs.kp[k] = fs[k]->kp.as<mi355_keypoint>(); outs.d8[k] = fs[k]->d8.as<uint8_t>();
         MI_HIP(hipMemsetAsync(fs[k]->d8.p, 0, 128 * 2048, st));
     }
-    auto octave_big = [&](int o) { return s->P.oc[o].w >= STREAM_MIN_W && s->P.oc[o].h >= STREAM_MIN_H; };
-    const BatchStride bs1 = bs;                      // single-frame launches pre-offset their pointers on the host
     auto blur_args = [&](const OctaveDev& oc) {
         BlurArgs a; memset(&a, 0, sizeof(a));
         a.w = oc.w; a.h = oc.h; a.tiles_x = (oc.w + TW - 1) / TW; a.tiles_y = (oc.h + TH - 1) / TH;
         return a;
     };
-    // ---- phase 1: per frame, the octaves whose kernels fill the chip (and the base level in any case) ----
-    int first_small = s->n_oct;
-    for (int o = 0; o < s->n_oct; o++) if (!octave_big(o)) { first_small = o; break; }
-    for (int k = 0; k < n; k++) {
-        const size_t fo = (size_t)k * bs.pyr;
-        for (int o = 0; o < s->n_oct && (o < first_small || o == 0); o++) {
-            OctaveDev oc = s->P.oc[o];
-            for (int i = 0; i < N_LEVELS; i++) oc.lv[i] += fo;
-            BlurArgs a = blur_args(oc);
-            const double level_bytes = (double)oc.w * oc.h * 4.0;
-            if (o == 0) {
-                a.bgr = pend[k].d_bgr; a.bgr_ws = pend[k].ws; a.dst = oc.lv[0];
-                memcpy(a.k, s->kern0, sizeof(float) * (2 * s->radius0 + 1));
-                ProfScope ps(ctx, "gauss", level_bytes + (double)w * h * 3.0, st);      // read the u8 frame, write level 0
-                if (base_streams(a, s->radius0, ctx->blur_stream)) launch_base_stream(st, a, s->gray.as<uint8_t>() + (size_t)k * s->gray_stride, s->gray_pitch);
-                else if (!launch_blur<true>(st, s->radius0, a, ctx->blur_stream)) { ctx->set_error("sift: unsupported kernel radius"); return MI355_ERR_FAILED; }
-            } else {
-                const OctaveDev& pv = s->P.oc[o - 1];
-                ProfScope ps(ctx, "downsample", level_bytes * 2.0, st);
-                hipLaunchKernelGGL(downsample2, dim3((oc.w + 63) / 64, (oc.h + 3) / 4, 1), dim3(256), 0, st, pv.lv[N_LAYERS] + fo, pv.w, oc.lv[0], oc.w, oc.h, (size_t)0);
-            }
-            if (o >= first_small) break;                 // small frame: only its base level is per frame
-            for (int i = 1; i < N_LEVELS; i++) {
-                a.bgr = nullptr; a.src = oc.lv[i - 1]; a.dst = oc.lv[i];
-                memcpy(a.k, s->kern[i], sizeof(float) * (2 * s->radius[i] + 1));
-                ProfScope ps(ctx, blur_streams(a, false, s->radius[i], ctx->blur_stream) ? "gauss_stream" : "gauss", level_bytes * 2.0, st);   // one read + one write of the level
-                if (!launch_blur<false>(st, s->radius[i], a, ctx->blur_stream)) { ctx->set_error("sift: unsupported kernel radius"); return MI355_ERR_FAILED; }
-            }
-            {
-                ProfScope ps(ctx, "extrema", level_bytes * 6.0, st);
-                BatchStride z = bs1; (void)z;
-                hipLaunchKernelGGL(extrema_kernel, dim3(((oc.w + EW - 1) / EW) * ((oc.h + EH - 1) / EH), 1), dim3(256), 0, st,
-                                   oc, o, s->cand.as<unsigned long long>() + (size_t)k * bs.cand, s->ccnt.as<unsigned>() + (size_t)k * CCNT_STRIDE, s->cand_cap,
-                                   cnt + (size_t)k * CNT_STRIDE + 4, bs);
-            }
-        }
-    }
-    // ---- phase 2: the small octaves of all n frames, one launch per level ----
-    for (int o = first_small; o < s->n_oct; o++) {
+    // ---- phases 1+2: the pyramid, octave by octave, every launch covering all n frames of the batch ----
+    for (int o = 0; o < s->n_oct; o++) {
         const OctaveDev& oc = s->P.oc[o];
         BlurArgs a = blur_args(oc);
         a.fstride = bs.pyr; a.nb = n;
         const double level_bytes = (double)oc.w * oc.h * 4.0 * n;
-        if (o > 0) {
+        if (o == 0) {
+            a.dst = oc.lv[0];
+            memcpy(a.k, s->kern0, sizeof(float) * (2 * s->radius0 + 1));
+            ProfScope ps(ctx, "gauss", level_bytes + (double)w * h * 3.0 * n, st);      // read the u8 frames, write level 0
+            if (base_streams(a, s->radius0, ctx->blur_stream)) {
+                for (int k = 0; k < n; k++) launch_gray_pad(st, pend[k].d_bgr, pend[k].ws, w, h, s->gray.as<uint8_t>() + (size_t)k * s->gray_stride, s->gray_pitch);
+                launch_base_stream(st, a, s->gray.as<uint8_t>(), s->gray_pitch, s->gray_stride);
+            } else {
+                for (int k = 0; k < n; k++) {            // caller-owned frames: one launch each
+                    BlurArgs a1 = a;
+                    a1.bgr = pend[k].d_bgr; a1.bgr_ws = pend[k].ws; a1.dst = oc.lv[0] + (size_t)k * bs.pyr; a1.nb = 1; a1.fstride = 0;
+                    if (!launch_blur<true>(st, s->radius0, a1, 0)) { ctx->set_error("sift: unsupported kernel radius"); return MI355_ERR_FAILED; }
+                }
+            }
+        } else {
             const OctaveDev& pv = s->P.oc[o - 1];
             ProfScope ps(ctx, "downsample", level_bytes * 2.0, st);
             hipLaunchKernelGGL(downsample2, dim3((oc.w + 63) / 64, (oc.h + 3) / 4, n), dim3(256), 0, st, pv.lv[N_LAYERS], pv.w, oc.lv[0], oc.w, oc.h, bs.pyr);
@@ -1582,8 +1562,8 @@ static int sift_run_batch(mi355_ctx* ctx, SiftWork* s) {
         for (int i = 1; i < N_LEVELS; i++) {
             a.bgr = nullptr; a.src = oc.lv[i - 1]; a.dst = oc.lv[i];
             memcpy(a.k, s->kern[i], sizeof(float) * (2 * s->radius[i] + 1));
-            ProfScope ps(ctx, "gauss", level_bytes * 2.0, st);
-            if (!launch_blur<false>(st, s->radius[i], a, n > 1 ? ctx->blur_stream : 0)) { ctx->set_error("sift: unsupported kernel radius"); return MI355_ERR_FAILED; }
+            ProfScope ps(ctx, blur_streams(a, false, s->radius[i], ctx->blur_stream) ? "gauss_stream" : "gauss", level_bytes * 2.0, st);   // one read + one write of the level
+            if (!launch_blur<false>(st, s->radius[i], a, ctx->blur_stream)) { ctx->set_error("sift: unsupported kernel radius"); return MI355_ERR_FAILED; }
         }
         {
             ProfScope ps(ctx, "extrema", level_bytes * 6.0, st);

@@ -46,7 +46,7 @@ int main(int argc, char** argv) {
         for (int mode = 0; mode < 2; mode++) {
             for (int it = 0; it < 11; it++) {
                 if (it == 1) CK(hipEventRecord(e0, st));
-                if (mode && base_streams(a, R, 1)) launch_base_stream(st, a, gray, gp); else launch_blur<true>(st, R, a, 0);
+                if (mode && base_streams(a, R, 1)) { launch_gray_pad(st, a.bgr, a.bgr_ws, a.w / 2, a.h / 2, gray, gp); launch_base_stream(st, a, gray, gp, 0); } else launch_blur<true>(st, R, a, 0);
             }
             CK(hipEventRecord(e1, st)); CK(hipStreamSynchronize(st));
             float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= 10;
