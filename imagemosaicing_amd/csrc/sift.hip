@@ -415,12 +415,31 @@ template <int J, int NPP, class F> __device__ __forceinline__ bool static_rows(F
 // fixed-point gray of the frame as u8 (the values are integers 0..255), rows padded by 4 replicated pixels on each side
 // so that the 2x up-sampling below never clamps a column: gray[y * gp + 4 + x], x in [-4, w + 4)
 __global__ __launch_bounds__(256) void gray_pad_kernel(const uint8_t* bgr, int ws, int w, int h, uint8_t* gray, int gp) {
-    const int xp = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    // 4 pixels per lane: 12 source bytes (three dwords when the row and the group are 4-byte aligned), one dword store
+    const int g = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    const int xp = 4 * g;                            // first padded column of the group; gp is a multiple of 16
     if (xp >= gp) return;
-    int x = xp - 4;
-    x = x < 0 ? 0 : (x > w - 1 ? w - 1 : x);
-    const uint8_t* p = bgr + (size_t)y * ws + 3 * x;
-    gray[(size_t)y * gp + xp] = (uint8_t)((1868 * (int)p[0] + 9617 * (int)p[1] + 4899 * (int)p[2] + 8192) >> 14);
+    const uint8_t* row = bgr + (size_t)y * ws;
+    unsigned out = 0;
+    const int x0 = xp - 4;
+    if (x0 >= 0 && x0 + 3 <= w - 1 && (((uintptr_t)row | (unsigned)ws) & 3) == 0) {
+        const unsigned* q = reinterpret_cast<const unsigned*>(row + 3 * x0);     // 3 * x0 is a multiple of 12
+        const unsigned d0 = q[0], d1 = q[1], d2 = q[2];
+        const int b0 = d0 & 255, g0 = (d0 >> 8) & 255, r0 = (d0 >> 16) & 255, b1 = d0 >> 24;
+        const int g1 = d1 & 255, r1 = (d1 >> 8) & 255, b2 = (d1 >> 16) & 255, g2 = d1 >> 24;
+        const int r2 = d2 & 255, b3 = (d2 >> 8) & 255, g3 = (d2 >> 16) & 255, r3 = d2 >> 24;
+        out = (unsigned)((1868 * b0 + 9617 * g0 + 4899 * r0 + 8192) >> 14) | ((unsigned)((1868 * b1 + 9617 * g1 + 4899 * r1 + 8192) >> 14) << 8) |
+              ((unsigned)((1868 * b2 + 9617 * g2 + 4899 * r2 + 8192) >> 14) << 16) | ((unsigned)((1868 * b3 + 9617 * g3 + 4899 * r3 + 8192) >> 14) << 24);
+    } else {
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            int x = x0 + c;
+            x = x < 0 ? 0 : (x > w - 1 ? w - 1 : x);
+            const uint8_t* p = row + 3 * x;
+            out |= (unsigned)((1868 * (int)p[0] + 9617 * (int)p[1] + 4899 * (int)p[2] + 8192) >> 14) << (8 * c);
+        }
+    }
+    *reinterpret_cast<unsigned*>(gray + (size_t)y * gp + xp) = out;
 }
 
 // UPS = true: the source is the padded u8 gray of the frame and the level being blurred is its 2x bilinear up-sampling
@@ -581,6 +600,10 @@ struct OctaveDev { float* lv[N_LEVELS]; int w, h; };
 #define EXT_EH 16
 #endif
 constexpr int EW = 64, EH = EXT_EH, ECAP = 128;
+#ifndef REG_SHIFT_V
+#define REG_SHIFT_V 0
+#endif
+constexpr int REG_SHIFT = REG_SHIFT_V;      // 2^REG_SHIFT consecutive tiles append to the same region: refine_kernel then walks spatially coherent runs
 constexpr int NREG = 64, REG_STRIDE = 32;   // candidate list split into 64 regions, one counter per 128-byte line:
                                             // a single counter caps at ~1e8 returning atomics/s (one per tile = 0.5 ms)
 // batched launches: frame f = blockIdx.y (z for refine) works on its own copy of every buffer, a fixed stride apart
@@ -588,6 +611,98 @@ struct BatchStride { size_t pyr, claimed, cand, refined, kps; };   // elements o
 constexpr size_t CNT_STRIDE = 64, CCNT_STRIDE = (size_t)64 * 32, RHIST_STRIDE = 65536, SEL_STRIDE = 2048;
 constexpr int SIFT_BATCH_MAX = 8;
 struct FrameOuts { mi355_keypoint* kp[SIFT_BATCH_MAX]; uint8_t* d8[SIFT_BATCH_MAX]; };
+
+// ---------- K3b: sub-pixel refinement ---------------------------------------------------------------------------
+struct Refined { int o, layer, r, c; float xi, xr, xc, contr, scl; };
+
+struct PyrDev { OctaveDev oc[MAX_OCT]; unsigned* claimed[MAX_OCT]; int n_oct; };
+
+__device__ __forceinline__ float dogv(const OctaveDev& oc, size_t foff, int lvl, int r, int c) {
+    const size_t o = foff + (size_t)r * oc.w + c;
+    return oc.lv[lvl + 1][o] - oc.lv[lvl][o];
+}
+
+__device__ void solve3(float A[3][3], float b[3], float x[3]) {
+    int p0 = 0, p1 = 1, p2 = 2;
+    // column 0
+    {
+        float b0 = fabsf(A[0][0]), b1 = fabsf(A[1][0]), b2 = fabsf(A[2][0]);
+        int m = 0; float best = b0;
+        if (b1 > best) { best = b1; m = 1; }
+        if (b2 > best) { best = b2; m = 2; }
+        if (!(best > 1e-30f)) { x[0] = x[1] = x[2] = 0.0f; return; }
+        if (m == 1) { p0 = 1; p1 = 0; } else if (m == 2) { p0 = 2; p2 = 0; }
+    }
+    auto elim = [&](int pr, int pk, int k) {
+        const float f = A[pr][k] / A[pk][k];
+        for (int c = k + 1; c < 3; c++) A[pr][c] = A[pr][c] - f * A[pk][c];
+        b[pr] = b[pr] - f * b[pk];
+    };
+    elim(p1, p0, 0); elim(p2, p0, 0);
+    {
+        const float b1 = fabsf(A[p1][1]), b2 = fabsf(A[p2][1]);
+        float best = b1;
+        if (b2 > best) { best = b2; const int t = p1; p1 = p2; p2 = t; }
+        if (!(best > 1e-30f)) { x[0] = x[1] = x[2] = 0.0f; return; }
+    }
+    elim(p2, p1, 1);
+    if (!(fabsf(A[p2][2]) > 1e-30f)) { x[0] = x[1] = x[2] = 0.0f; return; }
+    x[2] = b[p2] / A[p2][2];
+    x[1] = (b[p1] - A[p1][2] * x[2]) / A[p1][1];
+    x[0] = ((b[p0] - A[p0][1] * x[1]) - A[p0][2] * x[2]) / A[p0][0];
+}
+
+// One Newton step of the quadratic fit at (L, R, C) and the acceptance tests, written once over an accessor dv(L, R, C)
+// so that the in-tile first step (DoG planes in LDS, extrema_kernel) and the iterative path (global memory,
+// refine_kernel) evaluate the very same expressions.
+struct FitOff { float xi, xr, xc; };
+template <class DV>
+__device__ __forceinline__ FitOff fit_step(DV dv, int L, int R, int C) {
+    const float img_scale = 1.0f / 255.0f;
+    const float deriv_scale = img_scale * 0.5f, second_scale = img_scale, cross_scale = img_scale * 0.25f;
+    float dD[3];
+    dD[0] = (dv(L, R, C + 1) - dv(L, R, C - 1)) * deriv_scale;
+    dD[1] = (dv(L, R + 1, C) - dv(L, R - 1, C)) * deriv_scale;
+    dD[2] = (dv(L + 1, R, C) - dv(L - 1, R, C)) * deriv_scale;
+    const float v2 = dv(L, R, C) * 2.0f;
+    const float dxx = (dv(L, R, C + 1) + dv(L, R, C - 1) - v2) * second_scale;
+    const float dyy = (dv(L, R + 1, C) + dv(L, R - 1, C) - v2) * second_scale;
+    const float dss = (dv(L + 1, R, C) + dv(L - 1, R, C) - v2) * second_scale;
+    const float dxy = (dv(L, R + 1, C + 1) - dv(L, R + 1, C - 1) - dv(L, R - 1, C + 1) + dv(L, R - 1, C - 1)) * cross_scale;
+    const float dxs = (dv(L + 1, R, C + 1) - dv(L + 1, R, C - 1) - dv(L - 1, R, C + 1) + dv(L - 1, R, C - 1)) * cross_scale;
+    const float dys = (dv(L + 1, R + 1, C) - dv(L + 1, R - 1, C) - dv(L - 1, R + 1, C) + dv(L - 1, R - 1, C)) * cross_scale;
+    float A[3][3] = {{dxx, dxy, dxs}, {dxy, dyy, dys}, {dxs, dys, dss}};
+    float b[3] = {dD[0], dD[1], dD[2]}, X[3];
+    solve3(A, b, X);
+    FitOff f; f.xi = -X[2]; f.xr = -X[1]; f.xc = -X[0];
+    return f;
+}
+// contrast and edge tests at the converged location; contr is the interpolated response
+template <class DV>
+__device__ __forceinline__ bool fit_accept(DV dv, int L, int R, int C, FitOff f, float contrast_thr, float edge_thr, float& contr) {
+    const float img_scale = 1.0f / 255.0f;
+    const float deriv_scale = img_scale * 0.5f, second_scale = img_scale, cross_scale = img_scale * 0.25f;
+    float dD0 = (dv(L, R, C + 1) - dv(L, R, C - 1)) * deriv_scale;
+    float dD1 = (dv(L, R + 1, C) - dv(L, R - 1, C)) * deriv_scale;
+    float dD2 = (dv(L + 1, R, C) - dv(L - 1, R, C)) * deriv_scale;
+    const float t = (dD0 * f.xc + dD1 * f.xr) + dD2 * f.xi;
+    contr = dv(L, R, C) * img_scale + t * 0.5f;
+    if (fabsf(contr) * (float)N_LAYERS < contrast_thr) return false;
+    const float v2 = dv(L, R, C) * 2.0f;
+    const float dxx = (dv(L, R, C + 1) + dv(L, R, C - 1) - v2) * second_scale;
+    const float dyy = (dv(L, R + 1, C) + dv(L, R - 1, C) - v2) * second_scale;
+    const float dxy = (dv(L, R + 1, C + 1) - dv(L, R + 1, C - 1) - dv(L, R - 1, C + 1) + dv(L, R - 1, C - 1)) * cross_scale;
+    const float tr = dxx + dyy, det = dxx * dyy - dxy * dxy;
+    if (det <= 0.0f || (tr * tr) * edge_thr >= ((edge_thr + 1.0f) * (edge_thr + 1.0f)) * det) return false;
+    return true;
+}
+// 0: converged, 1: dead (diverged / NaN), 2: keep iterating
+__device__ __forceinline__ int fit_state(FitOff f) {
+    if (fabsf(f.xi) < 0.5f && fabsf(f.xr) < 0.5f && fabsf(f.xc) < 0.5f) return 0;
+    if (fabsf(f.xi) > 7.0e8f || fabsf(f.xr) > 7.0e8f || fabsf(f.xc) > 7.0e8f) return 1;
+    if (!(f.xi == f.xi) || !(f.xr == f.xr) || !(f.xc == f.xc)) return 1;
+    return 2;
+}
 
 __global__ __launch_bounds__(256) void extrema_kernel(OctaveDev oc, int octave, unsigned long long* cand, unsigned* count, unsigned cap, unsigned* overflow, BatchStride bs) {
     {
@@ -703,7 +818,7 @@ __global__ __launch_bounds__(256) void extrema_kernel(OctaveDev oc, int octave, 
                 const unsigned slot = atomicAdd(&s_n, 1u);
                 if (slot < ECAP) s_list[slot] = rec;
                 else {                                                                           // tile with > 128 extrema (flat image)
-                    const unsigned reg = (unsigned)tile & (NREG - 1);
+                    const unsigned reg = ((unsigned)tile >> REG_SHIFT) & (NREG - 1);
                     const unsigned g = atomicAdd(&count[reg * REG_STRIDE], 1u);
                     if (g < cap) cand[(size_t)reg * cap + g] = rec; else *overflow = 1;
                 }
@@ -712,113 +827,48 @@ __global__ __launch_bounds__(256) void extrema_kernel(OctaveDev oc, int octave, 
     }
     __syncthreads();
     const unsigned nloc = s_n < ECAP ? s_n : ECAP;
-    const unsigned reg = (unsigned)tile & (NREG - 1);
+    const unsigned reg = ((unsigned)tile >> REG_SHIFT) & (NREG - 1);
     if (tid == 0 && nloc) s_base = atomicAdd(&count[reg * REG_STRIDE], nloc);
     __syncthreads();
     for (unsigned i = tid; i < nloc; i += 256) { const unsigned g = s_base + i; if (g < cap) cand[(size_t)reg * cap + g] = s_list[i]; else *overflow = 1; }
 }
 
-// ---------- K3b: sub-pixel refinement ---------------------------------------------------------------------------
-struct Refined { int o, layer, r, c; float xi, xr, xc, contr, scl; };
-
-struct PyrDev { OctaveDev oc[MAX_OCT]; unsigned* claimed[MAX_OCT]; int n_oct; };
-
-__device__ __forceinline__ float dogv(const OctaveDev& oc, size_t foff, int lvl, int r, int c) {
-    const size_t o = foff + (size_t)r * oc.w + c;
-    return oc.lv[lvl + 1][o] - oc.lv[lvl][o];
-}
-
-__device__ void solve3(float A[3][3], float b[3], float x[3]) {
-    int p0 = 0, p1 = 1, p2 = 2;
-    // column 0
-    {
-        float b0 = fabsf(A[0][0]), b1 = fabsf(A[1][0]), b2 = fabsf(A[2][0]);
-        int m = 0; float best = b0;
-        if (b1 > best) { best = b1; m = 1; }
-        if (b2 > best) { best = b2; m = 2; }
-        if (!(best > 1e-30f)) { x[0] = x[1] = x[2] = 0.0f; return; }
-        if (m == 1) { p0 = 1; p1 = 0; } else if (m == 2) { p0 = 2; p2 = 0; }
-    }
-    auto elim = [&](int pr, int pk, int k) {
-        const float f = A[pr][k] / A[pk][k];
-        for (int c = k + 1; c < 3; c++) A[pr][c] = A[pr][c] - f * A[pk][c];
-        b[pr] = b[pr] - f * b[pk];
-    };
-    elim(p1, p0, 0); elim(p2, p0, 0);
-    {
-        const float b1 = fabsf(A[p1][1]), b2 = fabsf(A[p2][1]);
-        float best = b1;
-        if (b2 > best) { best = b2; const int t = p1; p1 = p2; p2 = t; }
-        if (!(best > 1e-30f)) { x[0] = x[1] = x[2] = 0.0f; return; }
-    }
-    elim(p2, p1, 1);
-    if (!(fabsf(A[p2][2]) > 1e-30f)) { x[0] = x[1] = x[2] = 0.0f; return; }
-    x[2] = b[p2] / A[p2][2];
-    x[1] = (b[p1] - A[p1][2] * x[2]) / A[p1][1];
-    x[0] = ((b[p0] - A[p0][1] * x[1]) - A[p0][2] * x[2]) / A[p0][0];
-}
-
 __global__ __launch_bounds__(256) void refine_kernel(PyrDev P, const unsigned long long* cand_all, const unsigned* cand_counts, unsigned cand_cap, unsigned* cand_total,
                                                      float contrast_thr, float edge_thr, float sigma,
-                                                     Refined* out, unsigned* out_count, unsigned out_cap, unsigned* resp_hist, BatchStride bs) {
+                                                     Refined* out, unsigned* out_count, unsigned out_cap, unsigned* out_resp, BatchStride bs) {
     const size_t fr = blockIdx.z, foff = fr * bs.pyr;             // frame of the batch
     cand_all += fr * bs.cand; cand_counts += fr * CCNT_STRIDE; cand_total += fr * CNT_STRIDE;
-    out += fr * bs.refined; out_count += fr * CNT_STRIDE; resp_hist += fr * RHIST_STRIDE;
+    out += fr * bs.refined; out_count += fr * CNT_STRIDE; out_resp += fr * bs.refined;
     // blockIdx.y = region of the candidate list (extrema_kernel spreads its appends over NREG counters)
     const unsigned reg = blockIdx.y;
     unsigned n = cand_counts[reg * REG_STRIDE];
     if (n > cand_cap) n = cand_cap;
     const unsigned long long* cand = cand_all + (size_t)reg * cand_cap;
-    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
-        unsigned tot = 0;
-        for (int g = 0; g < NREG; g++) tot += cand_counts[g * REG_STRIDE];
-        *cand_total = tot;
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 64) {      // total for the host: one region per lane
+        unsigned tot = cand_counts[threadIdx.x * REG_STRIDE];
+        for (int off = 32; off > 0; off >>= 1) tot += __shfl_xor(tot, off);
+        if (threadIdx.x == 0) cand_total[0] = tot;
     }
-    const float img_scale = 1.0f / 255.0f;
-    const float deriv_scale = img_scale * 0.5f, second_scale = img_scale, cross_scale = img_scale * 0.25f;
     for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const unsigned long long pk = cand[i];
         const int o = (int)(pk >> 48);
         int L = (int)((pk >> 40) & 0xff), R = (int)((pk >> 20) & 0xfffff), C = (int)(pk & 0xfffff);
         const OctaveDev& oc = P.oc[o];
-        float xi = 0.0f, xr = 0.0f, xc = 0.0f;
+        auto dv = [&](int l, int r, int c) { return dogv(oc, foff, l, r, c); };
+        FitOff f = {0.0f, 0.0f, 0.0f};
         int it = 0;
         bool alive = true;
         for (; it < MAX_INTERP; it++) {
-            float dD[3];
-            dD[0] = (dogv(oc, foff, L, R, C + 1) - dogv(oc, foff, L, R, C - 1)) * deriv_scale;
-            dD[1] = (dogv(oc, foff, L, R + 1, C) - dogv(oc, foff, L, R - 1, C)) * deriv_scale;
-            dD[2] = (dogv(oc, foff, L + 1, R, C) - dogv(oc, foff, L - 1, R, C)) * deriv_scale;
-            const float v2 = dogv(oc, foff, L, R, C) * 2.0f;
-            const float dxx = (dogv(oc, foff, L, R, C + 1) + dogv(oc, foff, L, R, C - 1) - v2) * second_scale;
-            const float dyy = (dogv(oc, foff, L, R + 1, C) + dogv(oc, foff, L, R - 1, C) - v2) * second_scale;
-            const float dss = (dogv(oc, foff, L + 1, R, C) + dogv(oc, foff, L - 1, R, C) - v2) * second_scale;
-            const float dxy = (dogv(oc, foff, L, R + 1, C + 1) - dogv(oc, foff, L, R + 1, C - 1) - dogv(oc, foff, L, R - 1, C + 1) + dogv(oc, foff, L, R - 1, C - 1)) * cross_scale;
-            const float dxs = (dogv(oc, foff, L + 1, R, C + 1) - dogv(oc, foff, L + 1, R, C - 1) - dogv(oc, foff, L - 1, R, C + 1) + dogv(oc, foff, L - 1, R, C - 1)) * cross_scale;
-            const float dys = (dogv(oc, foff, L + 1, R + 1, C) - dogv(oc, foff, L + 1, R - 1, C) - dogv(oc, foff, L - 1, R + 1, C) + dogv(oc, foff, L - 1, R - 1, C)) * cross_scale;
-            float A[3][3] = {{dxx, dxy, dxs}, {dxy, dyy, dys}, {dxs, dys, dss}};
-            float b[3] = {dD[0], dD[1], dD[2]}, X[3];
-            solve3(A, b, X);
-            xi = -X[2]; xr = -X[1]; xc = -X[0];
-            if (fabsf(xi) < 0.5f && fabsf(xr) < 0.5f && fabsf(xc) < 0.5f) break;
-            if (fabsf(xi) > 7.0e8f || fabsf(xr) > 7.0e8f || fabsf(xc) > 7.0e8f) { alive = false; break; }
-            if (!(xi == xi) || !(xr == xr) || !(xc == xc)) { alive = false; break; }
-            C += (int)rintf(xc); R += (int)rintf(xr); L += (int)rintf(xi);
+            f = fit_step(dv, L, R, C);
+            const int stt = fit_state(f);
+            if (stt == 0) break;
+            if (stt == 1) { alive = false; break; }
+            C += (int)rintf(f.xc); R += (int)rintf(f.xr); L += (int)rintf(f.xi);
             if (L < 1 || L > N_LAYERS || C < IMG_BORDER || C >= oc.w - IMG_BORDER || R < IMG_BORDER || R >= oc.h - IMG_BORDER) { alive = false; break; }
         }
         if (!alive || it >= MAX_INTERP) continue;
-        float dD0 = (dogv(oc, foff, L, R, C + 1) - dogv(oc, foff, L, R, C - 1)) * deriv_scale;
-        float dD1 = (dogv(oc, foff, L, R + 1, C) - dogv(oc, foff, L, R - 1, C)) * deriv_scale;
-        float dD2 = (dogv(oc, foff, L + 1, R, C) - dogv(oc, foff, L - 1, R, C)) * deriv_scale;
-        const float t = (dD0 * xc + dD1 * xr) + dD2 * xi;
-        const float contr = dogv(oc, foff, L, R, C) * img_scale + t * 0.5f;
-        if (fabsf(contr) * (float)N_LAYERS < contrast_thr) continue;
-        const float v2 = dogv(oc, foff, L, R, C) * 2.0f;
-        const float dxx = (dogv(oc, foff, L, R, C + 1) + dogv(oc, foff, L, R, C - 1) - v2) * second_scale;
-        const float dyy = (dogv(oc, foff, L, R + 1, C) + dogv(oc, foff, L, R - 1, C) - v2) * second_scale;
-        const float dxy = (dogv(oc, foff, L, R + 1, C + 1) - dogv(oc, foff, L, R + 1, C - 1) - dogv(oc, foff, L, R - 1, C + 1) + dogv(oc, foff, L, R - 1, C - 1)) * cross_scale;
-        const float tr = dxx + dyy, det = dxx * dyy - dxy * dxy;
-        if (det <= 0.0f || (tr * tr) * edge_thr >= ((edge_thr + 1.0f) * (edge_thr + 1.0f)) * det) continue;
+        float contr;
+        if (!fit_accept(dv, L, R, C, f, contrast_thr, edge_thr, contr)) continue;
         // duplicates: several start points may converge to one location -> first claim wins (all claims carry identical values)
         const size_t bit = ((size_t)R * oc.w + C) * 4 + (size_t)L;
         const unsigned mask = 1u << (bit & 31);
@@ -827,11 +877,10 @@ __global__ __launch_bounds__(256) void refine_kernel(PyrDev P, const unsigned lo
         const unsigned slot = atomicAdd(out_count, 1u);
         if (slot < out_cap) {
             Refined rr;
-            rr.o = o; rr.layer = L; rr.r = R; rr.c = C; rr.xi = xi; rr.xr = xr; rr.xc = xc; rr.contr = contr;
-            rr.scl = sigma * det_exp2f(((float)L + xi) / (float)N_LAYERS);
+            rr.o = o; rr.layer = L; rr.r = R; rr.c = C; rr.xi = f.xi; rr.xr = f.xr; rr.xc = f.xc; rr.contr = contr;
+            rr.scl = sigma * det_exp2f(((float)L + f.xi) / (float)N_LAYERS);
             out[slot] = rr;
-            atomicAdd(&resp_hist[(__float_as_uint(fabsf(contr)) >> 15) & 0xffffu], 1u);     // 8 exponent + 8 mantissa bits, result unused
-
+            out_resp[slot] = __float_as_uint(fabsf(contr));
         }
     }
 }
@@ -847,32 +896,39 @@ struct KpRec {
 // points have response >= T.  Pass 0 orients those; if that turns out to yield fewer than nfeatures keypoints
 // (points without any histogram peak), top-k raises a flag and pass 1 orients the rest -- same final result as
 // orienting everything, ~40x less work in the common case.
-__global__ __launch_bounds__(1024) void resp_threshold_kernel(const unsigned* hist, const unsigned* ref_count, unsigned want, unsigned* ctrl /* [0]=T bits [1]=fallback flag */) {
-    hist += (size_t)blockIdx.x * RHIST_STRIDE; ref_count += (size_t)blockIdx.x * CNT_STRIDE; ctrl += (size_t)blockIdx.x * CNT_STRIDE;   // one workgroup per frame
-    __shared__ unsigned s_part[1024];
-    const int tid = threadIdx.x;
-    unsigned local[64], sum = 0;
-#pragma unroll
-    for (int u = 0; u < 64; u++) { local[u] = hist[tid * 64 + u]; sum += local[u]; }     // lane owns bins [64 tid, 64 tid + 64)
-    s_part[tid] = sum;
-    __syncthreads();
-    if (tid == 0) {
-        unsigned T = 0;
-        if (*ref_count > want) {
-            unsigned cum = 0; int b = 1023;
-            for (; b >= 0; b--) { if (cum + s_part[b] >= want) break; cum += s_part[b]; }
-            if (b < 0) b = 0;
-            s_part[0] = (unsigned)b; s_part[1] = cum;
-            T = 1;
+__global__ __launch_bounds__(1024) void resp_threshold_kernel(const unsigned* resp /* |response| bits of the refined points */, const unsigned* ref_count, unsigned ref_cap,
+                                                              unsigned want, unsigned* ctrl /* [0]=T bits [1]=fallback flag */, size_t resp_stride) {
+    // one workgroup per frame: two-pass radix select over the 16-bit key (8 exponent + 8 mantissa bits) of the responses;
+    // T = lower edge of the first key (from the top) at which the count of points with key >= it reaches `want`
+    resp += (size_t)blockIdx.x * resp_stride; ref_count += (size_t)blockIdx.x * CNT_STRIDE; ctrl += (size_t)blockIdx.x * CNT_STRIDE;
+    __shared__ unsigned s_h[16][256];               // a private histogram per wave: LDS conflicts stay inside one wave
+    __shared__ unsigned s_sel[2];
+    const int tid = threadIdx.x, wv = tid >> 6;
+    unsigned n = *ref_count;
+    if (n > ref_cap) n = ref_cap;
+    if (n <= want) { if (tid == 0) { ctrl[0] = 0; ctrl[1] = 0; } return; }
+    unsigned above = 0, hi_sel = 0;
+    for (int pass = 0; pass < 2; pass++) {
+        for (int i = tid; i < 16 * 256; i += 1024) (&s_h[0][0])[i] = 0;
+        __syncthreads();
+        for (unsigned i = tid; i < n; i += 1024) {
+            const unsigned key = (resp[i] >> 15) & 0xffffu;
+            if (pass == 0) atomicAdd(&s_h[wv][key >> 8], 1u);
+            else if ((key >> 8) == hi_sel) atomicAdd(&s_h[wv][key & 255u], 1u);
         }
-        ctrl[0] = T; ctrl[1] = 0;
-    }
-    __syncthreads();
-    if (ctrl[0] == 1 && (unsigned)tid == s_part[0]) {          // the owner of the crossing group refines to one bin
-        unsigned cum = s_part[1]; int u = 63;
-        for (; u >= 0; u--) { if (cum + local[u] >= want) break; cum += local[u]; }
-        if (u < 0) u = 0;
-        ctrl[0] = ((unsigned)(tid * 64 + u)) << 15;              // lower edge of that bin: everything >= T is oriented
+        __syncthreads();
+        if (tid < 256) { unsigned t = 0; for (int w = 0; w < 16; w++) t += s_h[w][tid]; s_h[0][tid] = t; }
+        __syncthreads();
+        if (tid == 0) {
+            unsigned cum = above; int b = 255;
+            for (; b >= 0; b--) { if (cum + s_h[0][b] >= want) break; cum += s_h[0][b]; }
+            if (b < 0) b = 0;
+            s_sel[0] = (unsigned)b; s_sel[1] = cum;
+        }
+        __syncthreads();
+        if (pass == 0) { hi_sel = s_sel[0]; above = s_sel[1]; }
+        else if (tid == 0) { ctrl[0] = ((hi_sel << 8) | s_sel[0]) << 15; ctrl[1] = 0; }
+        __syncthreads();
     }
 }
 
@@ -1242,7 +1298,7 @@ inline void stream_grid(int w, int h, int& L, int& nstrip, int& nseg, int nb = 1
     nseg = (h + L - 1) / L;
 }
 inline void launch_gray_pad(hipStream_t st, const uint8_t* bgr, int ws, int w, int h, uint8_t* gray, int gp) {
-    hipLaunchKernelGGL(gray_pad_kernel, dim3((gp + 255) / 256, h), dim3(256), 0, st, bgr, ws, w, h, gray, gp);
+    hipLaunchKernelGGL(gray_pad_kernel, dim3((gp / 4 + 255) / 256, h), dim3(256), 0, st, bgr, ws, w, h, gray, gp);
 }
 // a.dst / a.fstride / a.nb: level 0 of the batch; gray / gstride: the padded gray frames
 inline void launch_base_stream(hipStream_t st, const BlurArgs& a, const uint8_t* gray, int gp, size_t gstride) {
@@ -1423,7 +1479,7 @@ static int sift_prepare(mi355_ctx* ctx, SiftWork* s, int w, int h, int nb) {
     if (4 * px0 + 1024 > 0xfffffff0ull) { ctx->set_error("sift: image too large"); return MI355_ERR_ARG; }
     // per region: tiles hash over the regions (tile index mod 64); an octave with T tiles puts at most ceil(T/64) tiles
     // x 3*EW*EH extrema into one region, so the worst case is total/64 + one full tile per octave
-    s->cand_cap = (unsigned)((4 * px0 + 1024 + NREG - 1) / NREG + (size_t)MAX_OCT * 3 * EW * EH + 1024);
+    s->cand_cap = (unsigned)((4 * px0 + 1024 + NREG - 1) / NREG + ((size_t)MAX_OCT * 3 * EW * EH << REG_SHIFT) + 1024);   // + one full run of tiles per octave
     s->ref_cap = (unsigned)(px0 / 32 + 65536);
     s->kp_cap = (unsigned)(px0 / 32 + 65536);
     s->bs.pyr = fl; s->bs.claimed = cl; s->bs.cand = (size_t)s->cand_cap * NREG; s->bs.refined = s->ref_cap; s->bs.kps = s->kp_cap;
@@ -1438,7 +1494,7 @@ static int sift_prepare(mi355_ctx* ctx, SiftWork* s, int w, int h, int nb) {
     MI_HIP(s->kresp.reserve(B * s->bs.kps * sizeof(unsigned)));
     MI_HIP(s->sel.reserve(B * SEL_STRIDE * sizeof(SelRec)));
     MI_HIP(s->counters.reserve(B * CNT_STRIDE * sizeof(unsigned)));
-    MI_HIP(s->rhist.reserve(B * RHIST_STRIDE * sizeof(unsigned)));
+    MI_HIP(s->rhist.reserve(B * s->bs.refined * sizeof(unsigned)));      // |response| bits of the refined points (SoA next to `refined`)
     MI_HIP(s->ccnt.reserve(B * CCNT_STRIDE * sizeof(unsigned)));
     MI_HIP(s->gray.reserve(B * s->gray_stride));
     memset(&s->P, 0, sizeof(s->P));
@@ -1520,7 +1576,6 @@ static int sift_run_batch(mi355_ctx* ctx, SiftWork* s) {
     MI_HIP(hipMemsetAsync(cnt, 0, (size_t)n * CNT_STRIDE * sizeof(unsigned), st));
     MI_HIP(hipMemsetAsync(s->ccnt.p, 0, (size_t)n * CCNT_STRIDE * sizeof(unsigned), st));
     MI_HIP(hipMemsetAsync(s->claimed.p, 0, (size_t)n * bs.claimed * sizeof(unsigned), st));
-    MI_HIP(hipMemsetAsync(s->rhist.p, 0, (size_t)n * RHIST_STRIDE * sizeof(unsigned), st));
     FrameOuts outs;
     memset(&outs, 0, sizeof(outs));
     std::vector<Features*> fs(n);
@@ -1576,7 +1631,7 @@ static int sift_run_batch(mi355_ctx* ctx, SiftWork* s) {
         ProfScope ps(ctx, "refine", 0.0, st);
         hipLaunchKernelGGL(refine_kernel, dim3(32, NREG, n), dim3(256), 0, st, s->P, s->cand.as<unsigned long long>(), s->ccnt.as<unsigned>(), s->cand_cap, cnt + 0,
                            ctx->p.contrast_threshold, ctx->p.edge_threshold, 1.6f, s->refined.as<Refined>(), cnt + 1, s->ref_cap, s->rhist.as<unsigned>(), bs);
-        hipLaunchKernelGGL(resp_threshold_kernel, dim3(n), dim3(1024), 0, st, s->rhist.as<unsigned>(), cnt + 1, (unsigned)nf + 256u, cnt + 8);
+        hipLaunchKernelGGL(resp_threshold_kernel, dim3(n), dim3(1024), 0, st, s->rhist.as<unsigned>(), cnt + 1, s->ref_cap, (unsigned)nf + 256u, cnt + 8, bs.refined);
     }
     for (int pass = 0; pass < 2; pass++) {       // pass 1 (everything below the response threshold) exits at once unless top-k asked for it
         {
