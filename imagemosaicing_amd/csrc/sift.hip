@@ -607,7 +607,7 @@ constexpr int REG_SHIFT = REG_SHIFT_V;      // 2^REG_SHIFT consecutive tiles app
 constexpr int NREG = 64, REG_STRIDE = 32;   // candidate list split into 64 regions, one counter per 128-byte line:
                                             // a single counter caps at ~1e8 returning atomics/s (one per tile = 0.5 ms)
 // batched launches: frame f = blockIdx.y (z for refine) works on its own copy of every buffer, a fixed stride apart
-struct BatchStride { size_t pyr, claimed, cand, refined, kps; };   // elements of the respective type
+struct BatchStride { size_t pyr, claimed, cand, refined, kps, cube; };   // elements of the respective type
 constexpr size_t CNT_STRIDE = 64, CCNT_STRIDE = (size_t)64 * 32, RHIST_STRIDE = 65536, SEL_STRIDE = 2048;
 constexpr int SIFT_BATCH_MAX = 8;
 struct FrameOuts { mi355_keypoint* kp[SIFT_BATCH_MAX]; uint8_t* d8[SIFT_BATCH_MAX]; };
@@ -704,12 +704,13 @@ __device__ __forceinline__ int fit_state(FitOff f) {
     return 2;
 }
 
-__global__ __launch_bounds__(256) void extrema_kernel(OctaveDev oc, int octave, unsigned long long* cand, unsigned* count, unsigned cap, unsigned* overflow, BatchStride bs) {
+__global__ __launch_bounds__(256) void extrema_kernel(OctaveDev oc, int octave, unsigned long long* cand, unsigned* count, unsigned cap, unsigned* overflow, BatchStride bs,
+                                                      float* cube, unsigned cube_cap) {
     {
         const size_t f = blockIdx.y;
 #pragma unroll
         for (int l = 0; l < N_LEVELS; l++) oc.lv[l] += f * bs.pyr;
-        cand += f * bs.cand; count += f * CCNT_STRIDE; overflow += f * CNT_STRIDE;
+        cand += f * bs.cand; count += f * CCNT_STRIDE; overflow += f * CNT_STRIDE; cube += f * bs.cube;
     }
     // staged window: rows y0-1 .. y0+EH, columns x0-4 .. x0+EW+3 (16-byte aligned so that interior tiles load float4)
     constexpr int PC = EW + 8;                 // 72 columns
@@ -830,13 +831,30 @@ __global__ __launch_bounds__(256) void extrema_kernel(OctaveDev oc, int octave, 
     const unsigned reg = ((unsigned)tile >> REG_SHIFT) & (NREG - 1);
     if (tid == 0 && nloc) s_base = atomicAdd(&count[reg * REG_STRIDE], nloc);
     __syncthreads();
-    for (unsigned i = tid; i < nloc; i += 256) { const unsigned g = s_base + i; if (g < cap) cand[(size_t)reg * cap + g] = s_list[i]; else *overflow = 1; }
+    // Each candidate also leaves with its 3x3x3 DoG neighbourhood (27 floats in a 128-byte record, straight from the LDS
+    // planes): the first Newton step of refine_kernel -- the only one for two candidates out of three -- then reads one line
+    // instead of twelve cold ones scattered over four pyramid levels.  Bit 63 of the record says the cube exists.
+    for (unsigned i = tid; i < nloc; i += 256) {
+        const unsigned g = s_base + i;
+        if (g < cap) cand[(size_t)reg * cap + g] = s_list[i] | (g < cube_cap ? (1ull << 63) : 0ull); else *overflow = 1;
+    }
+    for (unsigned idx = tid; idx < nloc * 27; idx += 256) {
+        const unsigned ci = idx / 27, e = idx - ci * 27;
+        const unsigned g = s_base + ci;
+        if (g >= cube_cap) continue;
+        const unsigned long long rec = s_list[ci];
+        const int L0 = (int)((rec >> 40) & 0xff), R0 = (int)((rec >> 20) & 0xfffff), C0 = (int)(rec & 0xfffff);
+        const int dl = (int)(e / 9) - 1, dr = (int)((e / 3) % 3) - 1, dc = (int)(e % 3) - 1;
+        cube[((size_t)reg * cube_cap + g) * 32 + e] = reinterpret_cast<const float*>(s_d4[L0 + dl])[(R0 + dr - y0 + 1) * PC + (C0 + dc - x0) + 4];
+    }
 }
 
 __global__ __launch_bounds__(256) void refine_kernel(PyrDev P, const unsigned long long* cand_all, const unsigned* cand_counts, unsigned cand_cap, unsigned* cand_total,
                                                      float contrast_thr, float edge_thr, float sigma,
-                                                     Refined* out, unsigned* out_count, unsigned out_cap, unsigned* out_resp, BatchStride bs) {
+                                                     Refined* out, unsigned* out_count, unsigned out_cap, unsigned* out_resp, BatchStride bs,
+                                                     const float* cube_all, unsigned cube_cap) {
     const size_t fr = blockIdx.z, foff = fr * bs.pyr;             // frame of the batch
+    cube_all += fr * bs.cube;
     cand_all += fr * bs.cand; cand_counts += fr * CCNT_STRIDE; cand_total += fr * CNT_STRIDE;
     out += fr * bs.refined; out_count += fr * CNT_STRIDE; out_resp += fr * bs.refined;
     // blockIdx.y = region of the candidate list (extrema_kernel spreads its appends over NREG counters)
@@ -851,24 +869,43 @@ __global__ __launch_bounds__(256) void refine_kernel(PyrDev P, const unsigned lo
     }
     for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const unsigned long long pk = cand[i];
-        const int o = (int)(pk >> 48);
+        const int o = (int)((pk >> 48) & 0xff);
         int L = (int)((pk >> 40) & 0xff), R = (int)((pk >> 20) & 0xfffff), C = (int)(pk & 0xfffff);
         const OctaveDev& oc = P.oc[o];
         auto dv = [&](int l, int r, int c) { return dogv(oc, foff, l, r, c); };
         FitOff f = {0.0f, 0.0f, 0.0f};
         int it = 0;
-        bool alive = true;
-        for (; it < MAX_INTERP; it++) {
-            f = fit_step(dv, L, R, C);
+        bool alive = true, accepted = false;
+        float contr = 0.0f;
+        if (pk >> 63) {
+            // first step from the 3x3x3 neighbourhood extrema_kernel saved next to the candidate (same values as the pyramid)
+            const float* cb = cube_all + ((size_t)reg * cube_cap + i) * 32;
+            const int L0 = L, R0 = R, C0 = C;
+            auto dvc = [&](int l, int r, int c) { return cb[(l - L0 + 1) * 9 + (r - R0 + 1) * 3 + (c - C0 + 1)]; };
+            f = fit_step(dvc, L, R, C);
             const int stt = fit_state(f);
-            if (stt == 0) break;
-            if (stt == 1) { alive = false; break; }
-            C += (int)rintf(f.xc); R += (int)rintf(f.xr); L += (int)rintf(f.xi);
-            if (L < 1 || L > N_LAYERS || C < IMG_BORDER || C >= oc.w - IMG_BORDER || R < IMG_BORDER || R >= oc.h - IMG_BORDER) { alive = false; break; }
+            if (stt == 1) continue;
+            if (stt == 0) {
+                if (!fit_accept(dvc, L, R, C, f, contrast_thr, edge_thr, contr)) continue;
+                accepted = true;
+            } else {
+                C += (int)rintf(f.xc); R += (int)rintf(f.xr); L += (int)rintf(f.xi);
+                if (L < 1 || L > N_LAYERS || C < IMG_BORDER || C >= oc.w - IMG_BORDER || R < IMG_BORDER || R >= oc.h - IMG_BORDER) continue;
+                it = 1;
+            }
         }
-        if (!alive || it >= MAX_INTERP) continue;
-        float contr;
-        if (!fit_accept(dv, L, R, C, f, contrast_thr, edge_thr, contr)) continue;
+        if (!accepted) {
+            for (; it < MAX_INTERP; it++) {
+                f = fit_step(dv, L, R, C);
+                const int stt = fit_state(f);
+                if (stt == 0) break;
+                if (stt == 1) { alive = false; break; }
+                C += (int)rintf(f.xc); R += (int)rintf(f.xr); L += (int)rintf(f.xi);
+                if (L < 1 || L > N_LAYERS || C < IMG_BORDER || C >= oc.w - IMG_BORDER || R < IMG_BORDER || R >= oc.h - IMG_BORDER) { alive = false; break; }
+            }
+            if (!alive || it >= MAX_INTERP) continue;
+            if (!fit_accept(dv, L, R, C, f, contrast_thr, edge_thr, contr)) continue;
+        }
         // duplicates: several start points may converge to one location -> first claim wins (all claims carry identical values)
         const size_t bit = ((size_t)R * oc.w + C) * 4 + (size_t)L;
         const unsigned mask = 1u << (bit & 31);
@@ -1371,6 +1408,7 @@ struct SiftWork {
     DevBuf pyr;                              // all Gaussian levels
     DevBuf claimed;                          // duplicate claim bitmaps
     DevBuf cand, refined, kps, kresp, sel, counters, rhist, ccnt;
+    DevBuf cube; unsigned cube_cap = 0;       // 3x3x3 DoG neighbourhoods of the first cube_cap candidates of every region (128 B each)
     DevBuf gray; int gray_pitch = 0; size_t gray_stride = 0;   // padded u8 gray of the frame (source of the streamed base level)
     PyrDev P;                                // pointers of frame 0
     BatchStride bs;
@@ -1389,7 +1427,7 @@ void mi_sift_release(mi355_ctx* ctx) {
     for (SiftWork* s : ctx->sift_slots) {
         if (!s) continue;
         if (s->stream) { (void)hipStreamSynchronize(s->stream); (void)hipStreamDestroy(s->stream); }
-        s->pyr.release(); s->claimed.release(); s->cand.release(); s->refined.release(); s->kps.release(); s->kresp.release(); s->sel.release(); s->counters.release(); s->rhist.release(); s->ccnt.release(); s->gray.release();
+        s->pyr.release(); s->claimed.release(); s->cand.release(); s->refined.release(); s->kps.release(); s->kresp.release(); s->sel.release(); s->counters.release(); s->rhist.release(); s->ccnt.release(); s->gray.release(); s->cube.release();
         delete s;
     }
     ctx->sift_slots.clear();
@@ -1482,6 +1520,9 @@ static int sift_prepare(mi355_ctx* ctx, SiftWork* s, int w, int h, int nb) {
     s->cand_cap = (unsigned)((4 * px0 + 1024 + NREG - 1) / NREG + ((size_t)MAX_OCT * 3 * EW * EH << REG_SHIFT) + 1024);   // + one full run of tiles per octave
     s->ref_cap = (unsigned)(px0 / 32 + 65536);
     s->kp_cap = (unsigned)(px0 / 32 + 65536);
+    s->cube_cap = (unsigned)(px0 / 16 / NREG + 4096);
+    if (s->cube_cap > s->cand_cap) s->cube_cap = s->cand_cap;
+    s->bs.cube = (size_t)s->cube_cap * NREG * 32;
     s->bs.pyr = fl; s->bs.claimed = cl; s->bs.cand = (size_t)s->cand_cap * NREG; s->bs.refined = s->ref_cap; s->bs.kps = s->kp_cap;
     s->gray_pitch = (w + 8 + 15) & ~15;
     s->gray_stride = up64((size_t)s->gray_pitch * h + 64);
@@ -1496,6 +1537,7 @@ static int sift_prepare(mi355_ctx* ctx, SiftWork* s, int w, int h, int nb) {
     MI_HIP(s->counters.reserve(B * CNT_STRIDE * sizeof(unsigned)));
     MI_HIP(s->rhist.reserve(B * s->bs.refined * sizeof(unsigned)));      // |response| bits of the refined points (SoA next to `refined`)
     MI_HIP(s->ccnt.reserve(B * CCNT_STRIDE * sizeof(unsigned)));
+    MI_HIP(s->cube.reserve(B * s->bs.cube * sizeof(float)));
     MI_HIP(s->gray.reserve(B * s->gray_stride));
     memset(&s->P, 0, sizeof(s->P));
     size_t fo = 0, co = 0;
@@ -1623,14 +1665,14 @@ static int sift_run_batch(mi355_ctx* ctx, SiftWork* s) {
         {
             ProfScope ps(ctx, "extrema", level_bytes * 6.0, st);
             hipLaunchKernelGGL(extrema_kernel, dim3(((oc.w + EW - 1) / EW) * ((oc.h + EH - 1) / EH), n), dim3(256), 0, st,
-                               oc, o, s->cand.as<unsigned long long>(), s->ccnt.as<unsigned>(), s->cand_cap, cnt + 4, bs);
+                               oc, o, s->cand.as<unsigned long long>(), s->ccnt.as<unsigned>(), s->cand_cap, cnt + 4, bs, s->cube.as<float>(), s->cube_cap);
         }
     }
     // ---- phase 3: keypoint stages of all n frames ----
     {
         ProfScope ps(ctx, "refine", 0.0, st);
         hipLaunchKernelGGL(refine_kernel, dim3(32, NREG, n), dim3(256), 0, st, s->P, s->cand.as<unsigned long long>(), s->ccnt.as<unsigned>(), s->cand_cap, cnt + 0,
-                           ctx->p.contrast_threshold, ctx->p.edge_threshold, 1.6f, s->refined.as<Refined>(), cnt + 1, s->ref_cap, s->rhist.as<unsigned>(), bs);
+                           ctx->p.contrast_threshold, ctx->p.edge_threshold, 1.6f, s->refined.as<Refined>(), cnt + 1, s->ref_cap, s->rhist.as<unsigned>(), bs, s->cube.as<float>(), s->cube_cap);
         hipLaunchKernelGGL(resp_threshold_kernel, dim3(n), dim3(1024), 0, st, s->rhist.as<unsigned>(), cnt + 1, s->ref_cap, (unsigned)nf + 256u, cnt + 8, bs.refined);
     }
     for (int pass = 0; pass < 2; pass++) {       // pass 1 (everything below the response threshold) exits at once unless top-k asked for it
