@@ -127,6 +127,7 @@ struct BlurArgs {
     size_t fstride;          // batched launch: frame f (blockIdx.y, or the tile index / tiles for the persistent kernel) reads
     int nb;                  // src + f * fstride and writes dst + f * fstride (floats); nb = frames in the batch (0 or 1: single)
     size_t gstride;          // blur_stream UPS: frame f reads the padded gray at bgr + f * gstride (bytes)
+    float* ds;               // blur_stream: also write the 2x decimated level (even rows, even columns) here: the next octave's base
 };
 
 // 2x bilinear upsample of the fixed-point gray image, pixel-centre aligned, edge clamp (exact in binary32)
@@ -462,6 +463,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         unit -= fr * per;
         if (UPS) a.bgr += (size_t)fr * a.gstride; else a.src += (size_t)fr * a.fstride;
         a.dst += (size_t)fr * a.fstride;
+        if (a.ds) a.ds += (size_t)fr * a.fstride;
     }
     const int seg = unit / nstrip, strip = unit - seg * nstrip;
     if (seg >= nseg) return;
@@ -578,7 +580,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             if (i >= 2 * R) {
                 const int slot = ((j - 2 * R) % NP + NP) % NP;
                 const v4f o = {acc01[slot].x, acc01[slot].y, acc23[slot].x, acc23[slot].y};
-                if (xm < a.w) *reinterpret_cast<v4f*>(a.dst + (size_t)(y0 + i - 2 * R) * a.w + xm) = o;
+                const int gy = y0 + i - 2 * R;
+                if (xm < a.w) *reinterpret_cast<v4f*>(a.dst + (size_t)gy * a.w + xm) = o;
+                if (!UPS && a.ds && !(gy & 1) && xm < a.w && (gy >> 1) < (a.h >> 1)) {
+                    const v2f d2 = {o.x, o.z};
+                    *reinterpret_cast<v2f*>(a.ds + (size_t)(gy >> 1) * (a.w >> 1) + (xm >> 1)) = d2;
+                }
             }
             __builtin_amdgcn_sched_barrier(0);       // keep the rows apart: the scheduler otherwise interleaves them and spills
             return true;
@@ -1632,6 +1639,7 @@ static int sift_run_batch(mi355_ctx* ctx, SiftWork* s) {
         return a;
     };
     // ---- phases 1+2: the pyramid, octave by octave, every launch covering all n frames of the batch ----
+    bool ds_fused = false;
     for (int o = 0; o < s->n_oct; o++) {
         const OctaveDev& oc = s->P.oc[o];
         BlurArgs a = blur_args(oc);
@@ -1651,15 +1659,20 @@ static int sift_run_batch(mi355_ctx* ctx, SiftWork* s) {
                     if (!launch_blur<true>(st, s->radius0, a1, 0)) { ctx->set_error("sift: unsupported kernel radius"); return MI355_ERR_FAILED; }
                 }
             }
-        } else {
+        } else if (!ds_fused) {
             const OctaveDev& pv = s->P.oc[o - 1];
             ProfScope ps(ctx, "downsample", level_bytes * 2.0, st);
             hipLaunchKernelGGL(downsample2, dim3((oc.w + 63) / 64, (oc.h + 3) / 4, n), dim3(256), 0, st, pv.lv[N_LAYERS], pv.w, oc.lv[0], oc.w, oc.h, bs.pyr);
         }
+        ds_fused = false;
         for (int i = 1; i < N_LEVELS; i++) {
             a.bgr = nullptr; a.src = oc.lv[i - 1]; a.dst = oc.lv[i];
             memcpy(a.k, s->kern[i], sizeof(float) * (2 * s->radius[i] + 1));
-            ProfScope ps(ctx, blur_streams(a, false, s->radius[i], ctx->blur_stream) ? "gauss_stream" : "gauss", level_bytes * 2.0, st);   // one read + one write of the level
+            const bool streams = blur_streams(a, false, s->radius[i], ctx->blur_stream);
+            // the streamed level that seeds the next octave writes its decimation on the way out (saves re-reading it)
+            a.ds = nullptr;
+            if (streams && i == N_LAYERS && o + 1 < s->n_oct && (oc.w & 1) == 0 && (s->P.oc[o + 1].w == (oc.w >> 1)) && (s->P.oc[o + 1].h == (oc.h >> 1))) { a.ds = s->P.oc[o + 1].lv[0]; ds_fused = true; }
+            ProfScope ps(ctx, streams ? "gauss_stream" : "gauss", level_bytes * 2.0, st);   // one read + one write of the level
             if (!launch_blur<false>(st, s->radius[i], a, ctx->blur_stream)) { ctx->set_error("sift: unsupported kernel radius"); return MI355_ERR_FAILED; }
         }
         {
