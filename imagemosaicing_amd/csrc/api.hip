@@ -293,6 +293,8 @@ extern "C" int mi355_set_option(mi355_ctx* ctx, const char* name, int value) {
         return MI355_OK;
     }
     if (std::string(name) == "blur_stream") { ctx->blur_stream = value ? 1 : 0; return MI355_OK; }
+    if (std::string(name) == "xstream_min_w") { ctx->xstream_min_w = value < 256 ? 256 : value; return MI355_OK; }
+    if (std::string(name) == "xstream_min_frames") { ctx->xstream_min_frames = value < 1 ? 1 : value; return MI355_OK; }
     ctx->set_error(std::string("set_option: unknown option ") + name);
     return MI355_ERR_ARG;
 }

@@ -128,3 +128,28 @@ def test_sift_batched_frames_equal_single(ctx, oracle):
             assert np.array_equal(kp.view(np.uint8), ref[k][0].view(np.uint8)), f"batch {batch}: frame {k} keypoints differ"
             assert np.array_equal(desc, ref[k][1]), f"batch {batch}: frame {k} descriptors differ"
         c.close()
+
+
+def test_sift_streamed_extrema(ctx, oracle):
+    """extrema_stream (wave-per-strip DoG extrema with the 3x3x3 neighbourhood taken from registers) against the tiled
+    kernel and the oracle: thresholds lowered so that 1100x780 frames take it; includes a flat frame, where every pixel
+    is a (tied) extremum and the per-wave candidate list overflows row after row"""
+    import torch
+    import imagemosaicing_amd as im
+    from tests.synth_frames import terrain
+    imgs = [terrain(1100, 780, seed=60 + k) for k in range(3)] + [np.full((780, 1100, 3), 77, np.uint8)]
+    ref = [ctx.SiftExtract(800 + k, img) for k, img in enumerate(imgs)]      # tiled extrema (one frame per batch)
+    okp, odesc = oracle.sift(imgs[0])
+    assert np.array_equal(ref[0][0].view(np.uint8), okp.view(np.uint8)) and np.array_equal(ref[0][1].astype(np.uint8), odesc)
+    assert len(ref[3][0]) == 0
+    c = im.Context(0)
+    c.set_option("xstream_min_w", 1000); c.set_option("xstream_min_frames", 1); c.set_option("sift_batch", 4)
+    dev = [torch.from_numpy(np.ascontiguousarray(i)).cuda() for i in imgs]
+    torch.cuda.synchronize()
+    for k, d in enumerate(dev):
+        c.SiftExtractDev(k, d.data_ptr(), 1100, 780, 3300)
+    for k in range(len(imgs)):
+        kp, desc = c.GetFeatures(k)
+        assert np.array_equal(kp.view(np.uint8), ref[k][0].view(np.uint8)), f"frame {k} keypoints differ"
+        assert np.array_equal(desc, ref[k][1]), f"frame {k} descriptors differ"
+    c.close()
