@@ -228,12 +228,11 @@ def main():
     # event durations include the contention.  One extra UNTIMED pass over a few frames with a single frame in
     # flight gives the same kernel's stand-alone figures (reported separately, never as `achieved`).
     iso = None
-    if world == 1 or rank == 0:
+    if (world == 1 or rank == 0) and not os.environ.get("MI355_BENCH_NO_STANDALONE"):
         ctx.synchronize()
-        ctx.set_option("sift_slots", 1)
-        ctx.set_option("sift_batch", 1)
+        ctx.set_option("sift_slots", 1)                    # same launches (full batches), but nothing else on the chip
         ctx.profile_enable(True); ctx.profile_only(DOM); ctx.profile_reset()
-        nf_iso = min(F, 24)
+        nf_iso = min(F, 3 * BATCH)
         for k in range(nf_iso):
             ctx.SiftExtractDev(k, fptr[k], w, h, ws)
         i_ms, i_n, i_bytes = ctx.profile_get(DOM)
@@ -242,7 +241,7 @@ def main():
         ctx.set_option("sift_batch", BATCH)
         if i_ms > 0:
             iso = {"achieved": (i_bytes / 1e9) / (i_ms / 1e3), "frac": (i_bytes / 1e9) / (i_ms / 1e3) / HBM_PEAK_GBS, "frames": nf_iso,
-                   "avg_launch_us": i_ms * 1e3 / max(i_n, 1), "note": "same kernel, one frame in flight (no overlap with other kernels), untimed extra pass"}
+                   "avg_launch_us": i_ms * 1e3 / max(i_n, 1), "note": "same launches with one batch work area in flight (no overlap with other batches' kernels), untimed extra pass"}
 
     # quality of the last step against ground truth (accepted pairs): corner transfer error in pixels
     r = state["r"]
@@ -259,6 +258,15 @@ def main():
     accepted = int(r["accepted"].sum()) if n_pairs else 0
 
     out = None
+    # HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes of this same command
+    # (profiles/pmc_traffic.py; counters cannot be read from inside the process): reported only when the workload matches
+    traffic, traffic_src = None, None
+    try:
+        pj = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_blur_stream.json")))
+        if pj.get("frames") == str(F) and pj.get("frame") == "%dx%d" % (w, h) and pj.get("batch") == str(BATCH):
+            traffic, traffic_src = float(pj["bytes_per_launch"]), "profiles/r01_pmc_blur_stream.json (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes)"
+    except Exception:
+        pass
     if rank == 0:
         total_pairs = n_pairs * world * args.steps
         value = total_pairs / dt
@@ -273,8 +281,8 @@ def main():
                                    % (F, w, h, args.window, n_pairs),
                        "frames_per_gpu": F, "pairs_per_gpu": n_pairs, "frame": [w, h], "canvas": [state["cw"], state["ch"]],
                        "sharding": "frames+pairs per rank, RCCL all-gather of pair records" if world > 1 else "single GPU"},
-            "roofline": {"bound": "hbm", "kernel": "blur_stream<R,D> (streaming separable Gaussian: the 10 launches per frame that produce pyramid octaves 0 and 1)", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            "roofline": {"bound": "hbm", "kernel": "blur_stream<R,D,false> (streaming separable Gaussian: the 20 launches per batch of 8 frames that produce levels 1..5 of pyramid octaves 0..3)", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "launches": int(g_n), "avg_launch_us": (g_ms * 1e3 / g_n) if g_n else None,
                          "algorithmic_bytes_per_launch": (g_bytes / g_n) if g_n else None,
                          "algorithmic_bytes_per_frame": g_bytes / max(args.steps * F, 1),
