@@ -287,6 +287,10 @@ def main():
                          "algorithmic_bytes_per_launch": (g_bytes / g_n) if g_n else None,
                          "algorithmic_bytes_per_frame": g_bytes / max(args.steps * F, 1),
                          "frames_per_batch": BATCH, "batches_in_flight": SLOTS, "standalone": iso},
+            # the whole path against the fixed algorithmic figure 262*P + 1.04 MB per adjacent pair (3.145 GB at 12 MP)
+            "path_roofline": {"algorithmic_bytes_per_pair": 262.0 * w * h + 1.04e6, "achieved": value / max(world, 1) * (262.0 * w * h + 1.04e6) / 1e9,
+                              "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": value / max(world, 1) * (262.0 * w * h + 1.04e6) / 1e9 / HBM_PEAK_GBS,
+                              "note": "per GPU; SURVEY 8(d) formula (reads+writes of all 6 Gaussian levels, match operands, warp); this build moves fewer bytes than the formula assumes in places"},
             "quality": {"pairs_accepted": accepted, "pairs": n_pairs, "images_aligned": state["n_valid"],
                         "h_corner_err_px_median": float(np.median(errs)) if errs else None,
                         "h_corner_err_px_max": float(np.max(errs)) if errs else None},
