@@ -173,15 +173,22 @@ def main():
     wv, hv, wsv = [w] * F, [h] * F, [ws] * F
     state = {}
 
+    phases = os.environ.get("MI355_BENCH_PHASES")
+
     def step(seed):
+        t0 = time.perf_counter()
         for k in range(F):
             ctx.SiftExtractDev(k, fptr[k], w, h, ws)
+        if phases:
+            ctx.synchronize(); t1 = time.perf_counter()
         ctx.MatchPairsDev(pairs, results.data_ptr(), 2.5, seed)
         if world > 1:
             # RCCL over xGMI: H + inlier lists of every pair of the survey, the only exchange of the path
             state["gathered"], state["counts"] = md.allgather_pair_results(results[:max(n_pairs, 1)])
         res_host.copy_(results, non_blocking=True)
         stream.synchronize()
+        if phases:
+            t2 = time.perf_counter()
         r = res_host.numpy().view(im.PAIR_RESULT).reshape(-1)[:n_pairs]
         mp = im.results_to_match_pairs(r)
         label = im.select_connected(mp, F) if len(mp) else np.zeros(F, np.int32)
@@ -193,7 +200,12 @@ def main():
         cw, ch, cws, _ = im.mosaic_layout(wv, hv, h9)
         if cws * ch > canvas_cap:
             raise RuntimeError("canvas larger than provisioned (%d x %d)" % (cw, ch))
+        if phases:
+            t3 = time.perf_counter()
         ctx.MosaicImagesRefinedDev(fptr, wv, hv, wsv, h9, canvas.data_ptr(), cw, ch, cws)
+        if phases:
+            ctx.synchronize(); t4 = time.perf_counter()
+            print("[phases ms] sift %.1f  match+D2H %.1f  host align %.1f  warp %.1f" % ((t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3, (t4 - t3) * 1e3), file=sys.stderr)
         state.update(r=r, cw=cw, ch=ch, n_valid=int(label.sum()))
 
     def barrier():

@@ -294,6 +294,41 @@ struct GlibcRand {
         return (int)(v >> 1);
     }
 };
+// The rand() stream depends only on the seed; what depends on n is how it is consumed (% n, redraw of all four until
+// pairwise distinct).  For the all-n tables the host therefore generates the raw stream once and one device thread per n
+// walks it -- 8 M host rand() calls (25 ms per new seed) become 0.4 M + a sub-millisecond kernel.
+constexpr int RAW_STREAM = 400000;               // n = 4 consumes ~213 k values for 4999 draws (9.4 % of the groups are distinct)
+__global__ __launch_bounds__(256) void draw_tables_kernel(const int* raw, int nraw, uint16_t* tables, int n_lo, int* overflow) {
+    // one workgroup per n: groups of four stream values are tested in parallel, the accepted ones (pairwise distinct
+    // after % n) are compacted in stream order with a block-wide prefix count
+    const int n = n_lo + blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    uint16_t* out4 = tables + (size_t)blockIdx.x * MAX_DRAWS * 4;
+    __shared__ int s_w[4];
+    const int ngroups = nraw / 4;
+    int done = 0;
+    for (int g0 = 0; done < MAX_DRAWS; g0 += 256) {
+        if (g0 >= ngroups) { if (tid == 0) *overflow = 1; return; }
+        const int gi = g0 + tid;
+        int s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+        bool ok = false;
+        if (gi < ngroups) {
+            const int4 v = reinterpret_cast<const int4*>(raw)[gi];
+            s0 = v.x % n; s1 = v.y % n; s2 = v.z % n; s3 = v.w % n;
+            ok = !(s0 == s1 || s0 == s2 || s0 == s3 || s1 == s2 || s1 == s3 || s2 == s3);
+        }
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(ok);
+        const int before = __builtin_popcountll(m & ((1ull << lane) - 1ull));
+        if (lane == 0) s_w[wv] = __builtin_popcountll(m);
+        __syncthreads();
+        int woff = 0;
+        for (int q = 0; q < wv; q++) woff += s_w[q];
+        const int total = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+        const int pos = done + woff + before;
+        if (ok && pos < MAX_DRAWS) { out4[4 * pos] = (uint16_t)s0; out4[4 * pos + 1] = (uint16_t)s1; out4[4 * pos + 2] = (uint16_t)s2; out4[4 * pos + 3] = (uint16_t)s3; }
+        done += total;
+        __syncthreads();
+    }
+}
 }  // namespace
 
 // mosaicimage.h:1777-1813: srand(seed); per draw: four rand()%n, all four redrawn until pairwise distinct
@@ -349,12 +384,25 @@ int mi_ransac_batch(mi355_ctx* ctx, const mi355_sfpoint* d_p1, const mi355_sfpoi
                 ctx->draw_tables.clear();
             }
             const int ntab = MI355_MAX_SELECTED - 4 + 1;
-            std::vector<uint16_t> tabs(one * ntab);
-            for (int n = 4; n <= MI355_MAX_SELECTED; n++) mi_glibc_draw_table(seed, n, MAX_DRAWS, tabs.data() + one * (n - 4));
+            std::vector<int> raw(RAW_STREAM);
+            { GlibcRand g; g.seed(seed); for (int i = 0; i < RAW_STREAM; i++) raw[i] = g.next(); }
+            DevBuf& draw = ctx->buf("ransac_raw_stream");
+            MI_HIP(draw.reserve((size_t)RAW_STREAM * sizeof(int) + 64));
+            int* d_flag = draw.as<int>() + RAW_STREAM;
             DevBuf& b = ctx->draw_tables[key];
-            MI_HIP(b.reserve(tabs.size() * sizeof(uint16_t)));
-            MI_HIP(hipMemcpyAsync(b.p, tabs.data(), tabs.size() * sizeof(uint16_t), hipMemcpyHostToDevice, ctx->stream));
-            MI_HIP(hipStreamSynchronize(ctx->stream));
+            MI_HIP(b.reserve(one * ntab * sizeof(uint16_t)));
+            MI_HIP(hipMemcpyAsync(draw.p, raw.data(), (size_t)RAW_STREAM * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+            MI_HIP(hipMemsetAsync(d_flag, 0, sizeof(int), ctx->stream));
+            hipLaunchKernelGGL(draw_tables_kernel, dim3(ntab), dim3(256), 0, ctx->stream, draw.as<int>(), RAW_STREAM, b.as<uint16_t>(), 4, d_flag);
+            int flag = 0;
+            MI_HIP(hipMemcpyAsync(&flag, d_flag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+            MI_HIP(hipStreamSynchronize(ctx->stream));          // `raw` goes out of scope
+            if (flag) {                                        // raw stream too short for some n (never seen): per-n host generation
+                std::vector<uint16_t> tabs(one * ntab);
+                for (int n = 4; n <= MI355_MAX_SELECTED; n++) mi_glibc_draw_table(seed, n, MAX_DRAWS, tabs.data() + one * (n - 4));
+                MI_HIP(hipMemcpyAsync(b.p, tabs.data(), tabs.size() * sizeof(uint16_t), hipMemcpyHostToDevice, ctx->stream));
+                MI_HIP(hipStreamSynchronize(ctx->stream));
+            }
             it = ctx->draw_tables.find(key);
         }
         d_tables = it->second.as<uint16_t>();
