@@ -6,28 +6,28 @@
 // one stated at the top of oracle/oracle_sift.c -- this file implements the same definition, independently,
 // for the GPU, and the parity tests compare keypoints and descriptors bit for bit.
 //
-// Kernels (all on the ctx stream; no host synchronisation inside one image):
-//   blur_tile<R,LOADER>   fused separable Gaussian: 64x64 output tile, halo tile staged in LDS, row pass into
-//                         LDS, column pass to HBM; each lane produces 4 adjacent outputs from a sliding register
-//                         window so an input sample is read from LDS once per 4 taps.  LOADER=BGR computes the
-//                         2x-upsampled gray base image on the fly from the u8 frame (the upsampled image is never
-//                         materialised).  HBM-bound: one read (+halo) and one write of the level.  Blocks are
-//                         remapped so that each XCD owns a contiguous band of tiles (halo rows hit its own L2).
-//   downsample2           next octave seed = every second pixel of level 3
-//   extrema               DoG never materialised in HBM: the 6 Gaussian levels of a 64x16 tile (+1 halo) are read
-//                         once, the 5 DoG planes live in LDS, 26-neighbour test, candidates appended (wave-
-//                         aggregated atomic)
+// Host side: frames collect into batches of 8 (SiftWork, sift_run_batch at the end of this file); every launch below
+// covers all frames of a batch.  Kernels:
+//   gray_pad + blur_stream<5,8,true>   base level: fixed-point gray, 2x up-sampling and first blur, the up-sampled image
+//                         is never stored
+//   blur_stream<R,D,false> separable Gaussian of one level (>= 1000x750): a wave walks down a strip of 256 columns, rows
+//                         arrive once from HBM, the 2R+1 column accumulators live in registers, no workgroup barrier;
+//                         level 3 also writes the decimated base of the next octave
+//   blur_tile2 / blur_tile the same filter for small levels: 64x64 tile + halo in LDS, row pass then column pass
+//   downsample2           next octave seed = every second pixel of level 3 (octaves whose level 3 is not streamed)
+//   extrema_stream / extrema_kernel   DoG never materialised in HBM: the 6 Gaussian levels are read once, 26-neighbour
+//                         test on the 5 DoG planes (registers / LDS), candidates leave with their 3x3x3 neighbourhood
 //   refine                one lane per candidate: quadratic fit, contrast / edge tests, duplicate claim bitmap
-//   orient                one wave per refined point: samples into LDS, 36 lanes accumulate their bin in raster
-//                         order, smoothing + peaks via lane shuffles
-//   topk                  one workgroup: radix select of the nfeatures-th response, bitonic sort of the survivors
-//                         by the total order (response desc, octave, layer, row, col, bin)
+//   resp_threshold        response threshold above which nfeatures + 256 refined points lie (radix select)
+//   orient                one wave per refined point above the threshold: 36-bin histogram in order-free fixed point,
+//                         smoothing + peaks via lane shuffles
+//   topk                  one workgroup per frame: radix select of the nfeatures-th response, bitonic sort of the
+//                         survivors by the total order (response desc, octave, layer, row, col, bin)
 //   describe              one workgroup per keypoint: trilinear contributions quantised to 2^-20 and added with
 //                         64-bit LDS atomics (order-free by definition), normalise / clip / renormalise -> u8
 #include "common.h"
 #include <cmath>
 #include <type_traits>
-#include <chrono>
 
 namespace {
 
@@ -106,14 +106,8 @@ __host__ __device__ __forceinline__ int reflect101(int p, int n) {
 
 typedef float v2f __attribute__((ext_vector_type(2)));
 typedef float v4f __attribute__((ext_vector_type(4)));
-#ifdef BLUR_SCALAR_FMA
-__device__ __forceinline__ float nopack(float x) { asm volatile("" : "+v"(x)); return x; }
-__device__ __forceinline__ v2f vfma(v2f a, v2f b, v2f c) { v2f r; r.x = nopack(fmaf(a.x, b.x, c.x)); r.y = nopack(fmaf(a.y, b.y, c.y)); return r; }
-__device__ __forceinline__ v4f vfma(v4f a, v4f b, v4f c) { v4f r; r.x = nopack(fmaf(a.x, b.x, c.x)); r.y = nopack(fmaf(a.y, b.y, c.y)); r.z = nopack(fmaf(a.z, b.z, c.z)); r.w = nopack(fmaf(a.w, b.w, c.w)); return r; }
-#else
 __device__ __forceinline__ v2f vfma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ v4f vfma(v4f a, v4f b, v4f c) { return __builtin_elementwise_fma(a, b, c); }
-#endif
 
 // ---------- K1/K2: fused separable Gaussian blur ------------------------------------------------------------------
 struct BlurArgs {
@@ -777,10 +771,6 @@ __global__ __launch_bounds__(256) void extrema_kernel(OctaveDev oc, int octave, 
         }
     }
     __syncthreads();
-#ifdef EXT_NO_COMPUTE
-    if (reinterpret_cast<const float*>(s_d4[2])[tid] == 12345.678f) cand[0] = 1;
-    return;
-#endif
     // one item per lane: 4 adjacent pixels of one row.  All 5 DoG planes' 3x6 windows go to registers (one 128-bit and two
     // 32-bit LDS reads per row), column-wise 3-row max/min are shared by the 4 pixels, and the 26-neighbour test becomes
     // "val >= max of the neighbours" / "val <= min of the neighbours" without data-dependent branches.
@@ -1554,11 +1544,7 @@ bool launch_blur(hipStream_t st, int R, const BlurArgs& a, int stream_mode = 1) 
     // Large f32 levels: persistent 128-bit/packed-FMA variant with register prefetch (interior tiles dominate).
     // Small levels (every tile touches the border) and the BGR base level: the 512-thread per-tile kernel.
     const bool big = !BGR && a.w >= 1024 && a.h >= 768;
-#ifdef BLUR_LEGACY
-    const bool use2 = false;
-#else
     const bool use2 = big;
-#endif
     if (blur_streams(a, BGR, R, stream_mode)) {
         // barrier-free streaming kernel: ~2 waves per SIMD over the whole chip (2048 waves), segments of >= 32 rows
         int L, nstrip, nseg;
