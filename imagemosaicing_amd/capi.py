@@ -304,6 +304,21 @@ class Context:
         self.L.mi355_free(C.cast(masks, C.c_void_p))
         return dict(cw=cw.value, ch=ch.value, chips=info, chip_imgs=out_c, masks=out_m)
 
+    def MultiBandBlend(self, chips, chip_imgs, masks, cw, ch, band=5):
+        """detail::MultiBandBlender(false, band) over the chips of ChipsAndMasks (MosaicImage.cpp:2296-2299, 2451-2486)."""
+        n = len(chip_imgs)
+        ci = [np.ascontiguousarray(c, np.uint8) for c in chip_imgs]
+        mi = [np.ascontiguousarray(m, np.uint8) for m in masks]
+        cp = (C.c_void_p * max(n, 1))(*[c.ctypes.data for c in ci])
+        mp = (C.c_void_p * max(n, 1))(*[m.ctypes.data for m in mi])
+        info = np.ascontiguousarray(chips, CHIPINFO)
+        out = C.c_void_p()
+        ow, oh, ows = C.c_int(), C.c_int(), C.c_int()
+        self._chk(self.L.mi355_multiband_blend(self._h, cp, mp, _p(info), n, int(cw), int(ch), int(band), C.byref(out), C.byref(ow), C.byref(oh), C.byref(ows)))
+        buf = _copy_out(out, ows.value * oh.value, np.uint8).reshape(oh.value, ows.value)
+        self.L.mi355_free(out)
+        return buf, ow.value, oh.value, ows.value
+
 
 # ---- host-only helpers (no ctx) ---------------------------------------------------------------------------
 def mosaic_layout(w, h, h9s):

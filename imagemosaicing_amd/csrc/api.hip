@@ -265,6 +265,12 @@ extern "C" int mi355_chips_and_masks(mi355_ctx* ctx, const uint8_t* const* imgs,
     return mi_chips_and_masks(ctx, imgs, w, h, ws, n, h9s, keep, find_masks, n_chips, chips, chip_imgs, masks, canvas_w, canvas_h);
 }
 
+extern "C" int mi355_multiband_blend(mi355_ctx* ctx, const uint8_t* const* chips, const uint8_t* const* masks, const mi355_chip_info* info, int n,
+                                     int canvas_w, int canvas_h, int band, uint8_t** out, int* out_w, int* out_h, int* out_ws) {
+    LOCKED_PROLOGUE
+    return mi_multiband_blend(ctx, chips, masks, info, n, canvas_w, canvas_h, band, out, out_w, out_h, out_ws);
+}
+
 // ---- measurement hooks --------------------------------------------------------------------------------------------
 extern "C" int mi355_profile_enable(mi355_ctx* ctx, int on) {
     LOCKED_PROLOGUE

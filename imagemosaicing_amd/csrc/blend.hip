@@ -1,0 +1,217 @@
+// csrc/blend.hip -- multiband blend of the warped chips, replacing
+//   detail::MultiBandBlender blender(false, band); prepare / feed per chip / blend; convertTo(CV_8U)
+//   (MosaicImage.cpp:2296-2299, 2451-2486).
+// The arithmetic is OpenCV 2.4.0's (absent): PARITY UNPINNED.  The definition implemented here -- 16-bit Laplacian
+// pyramids, float weight pyramids, [1 4 6 4 1] REDUCE / EXPAND in integer arithmetic, every rounding and border --
+// is the one stated at the top of oracle/oracle_blend.c; the parity test compares the output bytes.
+// All kernels are streaming stencils over at most a few hundred MB: HBM-bound, one thread per output pixel.
+#include "common.h"
+#include <cmath>
+
+namespace {
+
+__device__ __forceinline__ int reflect101d(int p, int n) { if (n == 1) return 0; while (p < 0 || p >= n) { if (p < 0) p = -p; else p = 2 * n - 2 - p; } return p; }
+__device__ __forceinline__ int reflectd(int p, int n) { while (p < 0 || p >= n) { if (p < 0) p = -p - 1; else p = 2 * n - 1 - p; } return p; }
+__device__ __forceinline__ short sat16d(int v) { return (short)(v < -32768 ? -32768 : (v > 32767 ? 32767 : v)); }
+
+// level 0 of one chip's region: chip extended by reflection (edge pixel included), weight = mask / 255 extended by zeros
+__global__ __launch_bounds__(256) void blend_prep_kernel(const uint8_t* chip, int cws, const uint8_t* mask, int mws, int cw, int ch,
+                                                         int left, int top, int rw, int rh, short* g0, float* w0) {
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= rw) return;
+    const int sx = reflectd(x - left, cw), sy = reflectd(y - top, ch);
+    const uint8_t* p = chip + (size_t)sy * cws + 3 * sx;
+    short* g = g0 + ((size_t)y * rw + x) * 3;
+    g[0] = (short)p[0]; g[1] = (short)p[1]; g[2] = (short)p[2];
+    float w = 0.0f;
+    if (y - top >= 0 && y - top < ch && x - left >= 0 && x - left < cw) w = (float)mask[(size_t)(y - top) * mws + (x - left)] * (float)(1.0 / 255.0);
+    w0[(size_t)y * rw + x] = w;
+}
+
+// REDUCE i16 x 3: integer, so the 5x5 product form equals the oracle's rows-then-columns form
+__global__ __launch_bounds__(256) void pyr_down16_kernel(const short* src, int w, int h, short* dst) {
+    const int dw = w >> 1, x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= dw) return;
+    const int wt[5] = {1, 4, 6, 4, 1};
+    int xs[5];
+#pragma unroll
+    for (int j = 0; j < 5; j++) xs[j] = reflect101d(2 * x - 2 + j, w);
+    int acc[3] = {0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        const short* s = src + (size_t)reflect101d(2 * y - 2 + k, h) * w * 3;
+        int r[3] = {0, 0, 0};
+#pragma unroll
+        for (int j = 0; j < 5; j++) { r[0] += wt[j] * s[3 * xs[j]]; r[1] += wt[j] * s[3 * xs[j] + 1]; r[2] += wt[j] * s[3 * xs[j] + 2]; }
+        acc[0] += wt[k] * r[0]; acc[1] += wt[k] * r[1]; acc[2] += wt[k] * r[2];
+    }
+    short* d = dst + ((size_t)y * dw + x) * 3;
+    d[0] = sat16d((acc[0] + 128) >> 8); d[1] = sat16d((acc[1] + 128) >> 8); d[2] = sat16d((acc[2] + 128) >> 8);
+}
+
+// REDUCE f32: the order of the float operations is the oracle's
+__global__ __launch_bounds__(256) void pyr_down_f_kernel(const float* src, int w, int h, float* dst) {
+    const int dw = w >> 1, x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= dw) return;
+    const int x0 = reflect101d(2 * x - 2, w), x1 = reflect101d(2 * x - 1, w), x2 = 2 * x, x3 = reflect101d(2 * x + 1, w), x4 = reflect101d(2 * x + 2, w);
+    float r[5];
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        const float* s = src + (size_t)reflect101d(2 * y - 2 + k, h) * w;
+        r[k] = s[x2] * 6.0f + (s[x1] + s[x3]) * 4.0f + s[x0] + s[x4];
+    }
+    const float v = r[2] * 6.0f + (r[1] + r[3]) * 4.0f + r[0] + r[4];
+    dst[(size_t)y * dw + x] = v * (1.0f / 256.0f);
+}
+
+// horizontal EXPAND value (before the vertical combination) at fine column X of coarse row s (3 channels, channel c)
+__device__ __forceinline__ int up_h(const short* s, int w, int X, int c) {
+    const int x = X >> 1;
+    if (w == 1) return s[c] * 8;
+    if (!(X & 1)) {
+        if (x == 0) return s[c] * 6 + s[3 + c] * 2;
+        if (x == w - 1) return s[3 * (w - 2) + c] + s[3 * (w - 1) + c] * 7;
+        return s[3 * (x - 1) + c] + s[3 * x + c] * 6 + s[3 * (x + 1) + c];
+    }
+    if (x == w - 1) return s[3 * (w - 1) + c] * 8;
+    return (s[3 * x + c] + s[3 * (x + 1) + c]) * 4;
+}
+
+// fine = sat16(fine - EXPAND(coarse)) (SUB) or sat16(EXPAND(coarse) + fine); coarse is w x h, fine 2w x 2h
+template <bool SUB>
+__global__ __launch_bounds__(256) void pyr_up16_combine_kernel(const short* coarse, int w, int h, short* fine) {
+    const int X = blockIdx.x * 256 + threadIdx.x, Y = blockIdx.y;
+    if (X >= 2 * w) return;
+    const int y = Y >> 1;
+    const int ym = (y == 0) ? (h > 1 ? 1 : 0) : y - 1, yp = (y == h - 1) ? h - 1 : y + 1;
+    const short* rm = coarse + (size_t)ym * w * 3;
+    const short* r0 = coarse + (size_t)y * w * 3;
+    const short* rp = coarse + (size_t)yp * w * 3;
+    short* f = fine + ((size_t)Y * 2 * w + X) * 3;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        int v;
+        if (!(Y & 1)) v = up_h(rm, w, X, c) + up_h(r0, w, X, c) * 6 + up_h(rp, w, X, c);
+        else v = (up_h(r0, w, X, c) + up_h(rp, w, X, c)) * 4;
+        const int up = sat16d((v + 32) >> 6);
+        f[c] = SUB ? sat16d((int)f[c] - up) : sat16d(up + (int)f[c]);
+    }
+}
+
+// canvas Laplacian += (short)(chip Laplacian * weight), canvas weight += weight, over the chip's region at this level
+__global__ __launch_bounds__(256) void blend_accumulate_kernel(const short* g, const float* wgt, int lw, int lh, int ox, int oy, short* dl, float* dw, int DW) {
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= lw) return;
+    const float wv = wgt[(size_t)y * lw + x];
+    const size_t di = (size_t)(oy + y) * DW + (ox + x);
+    const short* s = g + ((size_t)y * lw + x) * 3;
+#pragma unroll
+    for (int c = 0; c < 3; c++) dl[di * 3 + c] = (short)(dl[di * 3 + c] + (short)((float)s[c] * wv));
+    dw[di] += wv;
+}
+
+__global__ __launch_bounds__(256) void blend_normalize_kernel(short* dl, const float* dw, size_t n) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float d = dw[i] + 1e-5f;
+#pragma unroll
+    for (int c = 0; c < 3; c++) dl[i * 3 + c] = (short)((float)dl[i * 3 + c] / d);
+}
+
+__global__ __launch_bounds__(256) void blend_finalize_kernel(const short* dl, const float* dw, int Wp, int W, uint8_t* out, int ows) {
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= W) return;
+    const size_t di = (size_t)y * Wp + x;
+    uint8_t* o = out + (size_t)y * ows + 3 * x;
+    if (!(dw[di] > 1e-5f)) { o[0] = 0; o[1] = 0; o[2] = 0; return; }
+#pragma unroll
+    for (int c = 0; c < 3; c++) { const int v = dl[di * 3 + c]; o[c] = (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v)); }
+}
+
+inline dim3 grid2(int w, int h) { return dim3((unsigned)((w + 255) / 256), (unsigned)h); }
+
+}  // namespace
+
+int mi_multiband_blend(mi355_ctx* ctx, const uint8_t* const* chips, const uint8_t* const* masks, const mi355_chip_info* info, int n,
+                       int W, int H, int band, uint8_t** out, int* ow, int* oh, int* ows_out) {
+    if (n < 0 || (n > 0 && (!chips || !masks || !info)) || W <= 0 || H <= 0 || band < 0 || !out) { ctx->set_error("multiband_blend: bad arguments"); return MI355_ERR_ARG; }
+    const hipStream_t st = ctx->stream;
+    int nb = (int)std::ceil(std::log((double)(W > H ? W : H)) / std::log(2.0));
+    if (nb > band) nb = band;
+    if (nb < 0) nb = 0;
+    const int al = 1 << nb;
+    const int Wp = (W + al - 1) / al * al, Hp = (H + al - 1) / al * al;
+    std::vector<size_t> loff(nb + 2, 0);                         // level offsets in pixels inside one pyramid buffer
+    for (int l = 0; l <= nb; l++) loff[l + 1] = loff[l] + (size_t)(Wp >> l) * (Hp >> l);
+    DevBuf& dlap = ctx->buf("blend_dst_lap");
+    DevBuf& dwgt = ctx->buf("blend_dst_w");
+    MI_HIP(dlap.reserve(loff[nb + 1] * 3 * sizeof(short)));
+    MI_HIP(dwgt.reserve(loff[nb + 1] * sizeof(float)));
+    MI_HIP(hipMemsetAsync(dlap.p, 0, loff[nb + 1] * 3 * sizeof(short), st));
+    MI_HIP(hipMemsetAsync(dwgt.p, 0, loff[nb + 1] * sizeof(float), st));
+    DevBuf& dchip = ctx->buf("blend_chip");
+    DevBuf& dmask = ctx->buf("blend_mask");
+    DevBuf& glap = ctx->buf("blend_src_lap");
+    DevBuf& gwgt = ctx->buf("blend_src_w");
+    for (int k = 0; k < n; k++) {
+        const int cw = info[k].w, chh = info[k].h, x0 = info[k].x0, y0 = info[k].y0;
+        if (cw <= 0 || chh <= 0) continue;
+        const int gap = 3 * al;
+        int tlx = x0 - gap > 0 ? x0 - gap : 0, tly = y0 - gap > 0 ? y0 - gap : 0;
+        int brx = x0 + cw + gap < Wp ? x0 + cw + gap : Wp, bry = y0 + chh + gap < Hp ? y0 + chh + gap : Hp;
+        tlx = (tlx >> nb) << nb; tly = (tly >> nb) << nb;
+        int rw = brx - tlx, rh = bry - tly;
+        rw += (al - rw % al) % al;
+        rh += (al - rh % al) % al;
+        brx = tlx + rw; bry = tly + rh;
+        const int dx = brx - Wp > 0 ? brx - Wp : 0, dy = bry - Hp > 0 ? bry - Hp : 0;
+        tlx -= dx; tly -= dy;
+        if (tlx < 0 || tly < 0 || rw <= 0 || rh <= 0) { ctx->set_error("multiband_blend: chip outside the canvas"); return MI355_ERR_ARG; }
+        const int left = x0 - tlx, top = y0 - tly;
+        const int cws = (cw * 3 + 3) & ~3, mws = (cw + 3) & ~3;
+        std::vector<size_t> roff(nb + 2, 0);
+        for (int l = 0; l <= nb; l++) roff[l + 1] = roff[l] + (size_t)(rw >> l) * (rh >> l);
+        MI_HIP(dchip.reserve((size_t)cws * chh));
+        MI_HIP(dmask.reserve((size_t)mws * chh));
+        MI_HIP(glap.reserve(roff[nb + 1] * 3 * sizeof(short)));
+        MI_HIP(gwgt.reserve(roff[nb + 1] * sizeof(float)));
+        MI_HIP(hipMemcpyAsync(dchip.p, chips[k], (size_t)cws * chh, hipMemcpyHostToDevice, st));
+        MI_HIP(hipMemcpyAsync(dmask.p, masks[k], (size_t)mws * chh, hipMemcpyHostToDevice, st));
+        short* g = glap.as<short>();
+        float* wp = gwgt.as<float>();
+        hipLaunchKernelGGL(blend_prep_kernel, grid2(rw, rh), dim3(256), 0, st, dchip.as<uint8_t>(), cws, dmask.as<uint8_t>(), mws, cw, chh, left, top, rw, rh, g, wp);
+        for (int l = 0; l < nb; l++) {
+            hipLaunchKernelGGL(pyr_down16_kernel, grid2(rw >> (l + 1), rh >> (l + 1)), dim3(256), 0, st, g + roff[l] * 3, rw >> l, rh >> l, g + roff[l + 1] * 3);
+            hipLaunchKernelGGL(pyr_down_f_kernel, grid2(rw >> (l + 1), rh >> (l + 1)), dim3(256), 0, st, wp + roff[l], rw >> l, rh >> l, wp + roff[l + 1]);
+        }
+        for (int l = 0; l < nb; l++)                                // Gaussian -> Laplacian, finest first (level l+1 still Gaussian)
+            hipLaunchKernelGGL((pyr_up16_combine_kernel<true>), grid2(rw >> l, rh >> l), dim3(256), 0, st, g + roff[l + 1] * 3, rw >> (l + 1), rh >> (l + 1), g + roff[l] * 3);
+        for (int l = 0; l <= nb; l++)
+            hipLaunchKernelGGL(blend_accumulate_kernel, grid2(rw >> l, rh >> l), dim3(256), 0, st, g + roff[l] * 3, wp + roff[l], rw >> l, rh >> l, tlx >> l, tly >> l,
+                               dlap.as<short>() + loff[l] * 3, dwgt.as<float>() + loff[l], Wp >> l);
+        MI_HIP(hipGetLastError());
+        MI_HIP(hipStreamSynchronize(st));                            // the staging buffers are reused by the next chip
+    }
+    for (int l = 0; l <= nb; l++) {
+        const size_t cnt = (size_t)(Wp >> l) * (Hp >> l);
+        hipLaunchKernelGGL(blend_normalize_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st, dlap.as<short>() + loff[l] * 3, dwgt.as<float>() + loff[l], cnt);
+    }
+    for (int l = nb - 1; l >= 0; l--)
+        hipLaunchKernelGGL((pyr_up16_combine_kernel<false>), grid2(Wp >> l, Hp >> l), dim3(256), 0, st, dlap.as<short>() + loff[l + 1] * 3, Wp >> (l + 1), Hp >> (l + 1), dlap.as<short>() + loff[l] * 3);
+    const int ows = (W * 3 + 3) & ~3;
+    DevBuf& dout = ctx->buf("blend_out");
+    MI_HIP(dout.reserve((size_t)ows * H));
+    MI_HIP(hipMemsetAsync(dout.p, 0, (size_t)ows * H, st));
+    hipLaunchKernelGGL(blend_finalize_kernel, grid2(W, H), dim3(256), 0, st, dlap.as<short>(), dwgt.as<float>(), Wp, W, dout.as<uint8_t>(), ows);
+    MI_HIP(hipGetLastError());
+    uint8_t* host = (uint8_t*)malloc((size_t)ows * H);
+    if (!host) return MI355_ERR_NOMEM;
+    hipError_t e = hipMemcpyAsync(host, dout.p, (size_t)ows * H, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) { free(host); ctx->set_error(std::string("multiband_blend: ") + hipGetErrorString(e)); return MI355_ERR_DEVICE; }
+    *out = host;
+    if (ow) *ow = W;
+    if (oh) *oh = H;
+    if (ows_out) *ows_out = ows;
+    return MI355_OK;
+}

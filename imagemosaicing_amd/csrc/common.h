@@ -110,6 +110,8 @@ int mi_warp_image(mi355_ctx*, const uint8_t* src, int w, int h, int ws, int ch, 
                   uint8_t** dst, int* dw, int* dh, int* dws);
 int mi_mosaic_refined_dev(mi355_ctx*, const uint8_t* const* d_imgs, const int* w, const int* h, const int* ws, int n,
                           const float* h9s, uint8_t* d_canvas, int cw, int ch, int cws, int row0, int rows);
+int mi_multiband_blend(mi355_ctx*, const uint8_t* const* chips, const uint8_t* const* masks, const mi355_chip_info* info, int n,
+                       int W, int H, int band, uint8_t** out, int* ow, int* oh, int* ows);
 int mi_chips_and_masks(mi355_ctx*, const uint8_t* const* imgs, const int* w, const int* h, const int* ws, int n,
                        const float* h9s, const uint8_t* keep, int find_masks, int* n_chips, mi355_chip_info** chips,
                        uint8_t*** chip_imgs, uint8_t*** masks, int* cw, int* ch);

@@ -170,6 +170,15 @@ int  mi355_chips_and_masks(mi355_ctx* ctx, const uint8_t* const* imgs, const int
                            int* n_chips, mi355_chip_info** chips, uint8_t*** chip_imgs, uint8_t*** masks,
                            int* canvas_w, int* canvas_h);
 
+/* Multiband blend of those chips ("next" row f3 of SURVEY 8f): replaces detail::MultiBandBlender blender(false, band) --
+ * prepare(Rect(0,0,canvas_w,canvas_h)), feed(chip as CV_16S, mask, corner) per chip, blend, convertTo(CV_8U)
+ * (MosaicImage.cpp:2296-2299, 2451-2486; the reference passes band = 5).  chips / masks / info exactly as
+ * mi355_chips_and_masks returns them (BGR u8 rows padded to 4 bytes, masks after FindMasksByDistMap).  The arithmetic of
+ * OpenCV 2.4.0's blender is not available: the definition is the one in oracle/oracle_blend.c (parity unpinned).
+ * *out: BGR u8 canvas, rows padded to 4 bytes, library-allocated (mi355_free). */
+int  mi355_multiband_blend(mi355_ctx* ctx, const uint8_t* const* chips, const uint8_t* const* masks, const mi355_chip_info* info, int n,
+                           int canvas_w, int canvas_h, int band, uint8_t** out, int* out_w, int* out_h, int* out_ws);
+
 /* ---- callers / formats either side of the path ("next" rows f1, f2 of SURVEY 8f) ---------------------- */
 /* matchPairs.match: int32 n + n x 40-byte records (WriteMatchPairs / LoadMatchPairs, MosaicWithoutPos.cpp:4736-4797) */
 int  mi355_write_match_pairs(const char* path, const mi355_match_point_pairs* v, int n);

@@ -1,0 +1,216 @@
+/* oracle/oracle_blend.c -- TEST INFRASTRUCTURE ONLY (see oracle.h).
+ *
+ * Multiband blend of the warped chips: SURVEY 8(f) row f3, replacing
+ *   detail::MultiBandBlender blender(false, band);  blender.prepare(Rect(0,0,W,H));
+ *   blender.feed(chip converted to CV_16S, mask, corner) per chip;  blender.blend(result_s, result_mask);
+ *   result_s.convertTo(result, CV_8U)                       (MosaicImage.cpp:2296-2299, 2451-2486)
+ *
+ * PARITY UNPINNED: the arithmetic is OpenCV 2.4.0 `stitching` (blenders.cpp) + `imgproc` (pyramids.cpp), vendored in
+ * the reference as headers + Win32 binaries only.  This file restates the published algorithm (Burt & Adelson 1983
+ * multiresolution spline) in the shape OpenCV gives it -- 16-bit Laplacian pyramids, float weight pyramids, 5-tap
+ * [1 4 6 4 1] REDUCE / EXPAND in integer arithmetic -- and DEFINES every free choice:
+ *   REDUCE  (pyrDown) i16: v = sum over the 5x5 taps (rows then columns, int), out = (v + 128) >> 8; reflect-101 border
+ *           f32: row = s[2x]*6 + (s[2x-1] + s[2x+1])*4 + s[2x-2] + s[2x+2] (left to right), same vertically, times 1/256
+ *   EXPAND  (pyrUp) i16 to exactly twice the size: horizontally even = s[x-1] + 6 s[x] + s[x+1], odd = 4 (s[x] + s[x+1]),
+ *           first pair 6 s0 + 2 s1 | 4 (s0 + s1), last pair s[w-2] + 7 s[w-1] | 8 s[w-1]; vertically the same
+ *           even / odd combination of rows with row(-1) := row(1) and row(h) := row(h-1); out = (v + 32) >> 6
+ *   Laplacian level = Gaussian level - EXPAND(next level), saturated to i16; the last level is the Gaussian itself
+ *   feed:   region of interest = chip rectangle grown by 3*2^bands, clipped to the padded canvas, snapped to multiples
+ *           of 2^bands; chip extended into it by reflection including the edge pixel (fedcba|abcdefgh|hgfedcb);
+ *           weight = mask * (1/255) as float, extended by zeros, REDUCEd per level;
+ *           canvas Laplacian += (short)(chip Laplacian * weight) (truncation toward zero, 16-bit wrap-around add),
+ *           canvas weight += weight
+ *   blend:  canvas Laplacian = (short)(value / (weight + 1e-5f)); collapse by level = sat16(EXPAND(level+1) + level);
+ *           pixels whose level-0 weight is <= 1e-5 become 0; result = clamp to 0..255
+ * bands = min(band, ceil(log2(max(W, H)))); the canvas is padded to multiples of 2^bands, so every level halves exactly.
+ */
+#include "oracle.h"
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+
+static inline int reflect101i(int p, int n) { if (n == 1) return 0; while (p < 0 || p >= n) { if (p < 0) p = -p; else p = 2 * n - 2 - p; } return p; }
+static inline int reflecti(int p, int n) { while (p < 0 || p >= n) { if (p < 0) p = -p - 1; else p = 2 * n - 1 - p; } return p; }
+static inline int16_t sat16(int v) { return (int16_t)(v < -32768 ? -32768 : (v > 32767 ? 32767 : v)); }
+
+/* REDUCE, 3-channel i16: src w x h -> dst (w/2) x (h/2), w and h even */
+void orc_pyr_down16(const int16_t* src, int w, int h, int16_t* dst)
+{
+    const int dw = w / 2, dh = h / 2;
+    int* rows = (int*)malloc(sizeof(int) * 5 * dw * 3);
+    for (int y = 0; y < dh; y++) {
+        for (int k = 0; k < 5; k++) {
+            const int sy = reflect101i(2 * y - 2 + k, h);
+            const int16_t* s = src + (size_t)sy * w * 3;
+            int* r = rows + (size_t)k * dw * 3;
+            for (int x = 0; x < dw; x++)
+                for (int c = 0; c < 3; c++) {
+                    const int x0 = reflect101i(2 * x - 2, w), x1 = reflect101i(2 * x - 1, w), x2 = 2 * x, x3 = reflect101i(2 * x + 1, w), x4 = reflect101i(2 * x + 2, w);
+                    r[3 * x + c] = s[3 * x2 + c] * 6 + (s[3 * x1 + c] + s[3 * x3 + c]) * 4 + s[3 * x0 + c] + s[3 * x4 + c];
+                }
+        }
+        for (int i = 0; i < dw * 3; i++) {
+            const int v = rows[2 * dw * 3 + i] * 6 + (rows[1 * dw * 3 + i] + rows[3 * dw * 3 + i]) * 4 + rows[i] + rows[4 * dw * 3 + i];
+            dst[(size_t)y * dw * 3 + i] = sat16((v + 128) >> 8);
+        }
+    }
+    free(rows);
+}
+
+/* REDUCE, 1-channel f32 */
+void orc_pyr_down_f(const float* src, int w, int h, float* dst)
+{
+    const int dw = w / 2, dh = h / 2;
+    float* rows = (float*)malloc(sizeof(float) * 5 * dw);
+    for (int y = 0; y < dh; y++) {
+        for (int k = 0; k < 5; k++) {
+            const int sy = reflect101i(2 * y - 2 + k, h);
+            const float* s = src + (size_t)sy * w;
+            float* r = rows + (size_t)k * dw;
+            for (int x = 0; x < dw; x++) {
+                const int x0 = reflect101i(2 * x - 2, w), x1 = reflect101i(2 * x - 1, w), x2 = 2 * x, x3 = reflect101i(2 * x + 1, w), x4 = reflect101i(2 * x + 2, w);
+                r[x] = s[x2] * 6.0f + (s[x1] + s[x3]) * 4.0f + s[x0] + s[x4];
+            }
+        }
+        for (int x = 0; x < dw; x++) {
+            const float v = rows[2 * dw + x] * 6.0f + (rows[dw + x] + rows[3 * dw + x]) * 4.0f + rows[x] + rows[4 * dw + x];
+            dst[(size_t)y * dw + x] = v * (1.0f / 256.0f);
+        }
+    }
+    free(rows);
+}
+
+/* horizontal EXPAND of one source row (3 channels) into 2w int values per channel */
+static void up_row(const int16_t* s, int w, int* r)
+{
+    for (int c = 0; c < 3; c++) {
+        if (w == 1) { r[c] = s[c] * 8; r[3 + c] = s[c] * 8; continue; }
+        r[c] = s[c] * 6 + s[3 + c] * 2;
+        r[3 + c] = (s[c] + s[3 + c]) * 4;
+        for (int x = 1; x < w - 1; x++) {
+            r[3 * (2 * x) + c] = s[3 * (x - 1) + c] + s[3 * x + c] * 6 + s[3 * (x + 1) + c];
+            r[3 * (2 * x + 1) + c] = (s[3 * x + c] + s[3 * (x + 1) + c]) * 4;
+        }
+        r[3 * (2 * (w - 1)) + c] = s[3 * (w - 2) + c] + s[3 * (w - 1) + c] * 7;
+        r[3 * (2 * (w - 1) + 1) + c] = s[3 * (w - 1) + c] * 8;
+    }
+}
+
+/* EXPAND, 3-channel i16: src w x h -> dst 2w x 2h */
+void orc_pyr_up16(const int16_t* src, int w, int h, int16_t* dst)
+{
+    const int dw = 2 * w;
+    int* r0 = (int*)malloc(sizeof(int) * dw * 3);
+    int* r1 = (int*)malloc(sizeof(int) * dw * 3);
+    int* r2 = (int*)malloc(sizeof(int) * dw * 3);
+    for (int y = 0; y < h; y++) {
+        const int ym = (y == 0) ? (h > 1 ? 1 : 0) : y - 1;           /* row(-1) := row(1) */
+        const int yp = (y == h - 1) ? h - 1 : y + 1;                 /* row(h)  := row(h-1) */
+        up_row(src + (size_t)ym * w * 3, w, r0);
+        up_row(src + (size_t)y * w * 3, w, r1);
+        up_row(src + (size_t)yp * w * 3, w, r2);
+        for (int i = 0; i < dw * 3; i++) {
+            dst[(size_t)(2 * y) * dw * 3 + i] = sat16((r0[i] + r1[i] * 6 + r2[i] + 32) >> 6);
+            dst[(size_t)(2 * y + 1) * dw * 3 + i] = sat16(((r1[i] + r2[i]) * 4 + 32) >> 6);
+        }
+    }
+    free(r0); free(r1); free(r2);
+}
+
+/* chips: BGR u8, row stride (w*3+3)&~3; masks: u8, row stride (w+3)&~3; x0/y0/w/h per chip; canvas W x H.
+ * out: BGR u8, row stride (W*3+3)&~3 (caller-allocated).  Returns the number of bands used. */
+int orc_multiband_blend(const uint8_t* const* chips, const uint8_t* const* masks, const int* cx0, const int* cy0, const int* cw, const int* chh,
+                        int n, int W, int H, int band, uint8_t* out)
+{
+    int maxlen = W > H ? W : H;
+    int nb = (int)ceil(log((double)maxlen) / log(2.0));
+    if (nb > band) nb = band;
+    if (nb < 0) nb = 0;
+    const int al = 1 << nb;
+    const int Wp = (W + al - 1) / al * al, Hp = (H + al - 1) / al * al;
+    int16_t** dl = (int16_t**)calloc((size_t)nb + 1, sizeof(int16_t*));
+    float** dwt = (float**)calloc((size_t)nb + 1, sizeof(float*));
+    for (int l = 0; l <= nb; l++) {
+        dl[l] = (int16_t*)calloc((size_t)(Wp >> l) * (Hp >> l) * 3, sizeof(int16_t));
+        dwt[l] = (float*)calloc((size_t)(Wp >> l) * (Hp >> l), sizeof(float));
+    }
+    for (int k = 0; k < n; k++) {
+        const int gap = 3 * al;
+        int tlx = cx0[k] - gap > 0 ? cx0[k] - gap : 0, tly = cy0[k] - gap > 0 ? cy0[k] - gap : 0;
+        int brx = cx0[k] + cw[k] + gap < Wp ? cx0[k] + cw[k] + gap : Wp, bry = cy0[k] + chh[k] + gap < Hp ? cy0[k] + chh[k] + gap : Hp;
+        tlx = (tlx >> nb) << nb; tly = (tly >> nb) << nb;
+        int rw = brx - tlx, rh = bry - tly;
+        rw += ((1 << nb) - rw % (1 << nb)) % (1 << nb);
+        rh += ((1 << nb) - rh % (1 << nb)) % (1 << nb);
+        brx = tlx + rw; bry = tly + rh;
+        int dx = brx - Wp > 0 ? brx - Wp : 0, dy = bry - Hp > 0 ? bry - Hp : 0;
+        tlx -= dx; brx -= dx; tly -= dy; bry -= dy;
+        const int left = cx0[k] - tlx, top = cy0[k] - tly;
+        const int cws = (cw[k] * 3 + 3) & ~3, mws = (cw[k] + 3) & ~3;
+        /* level-0 Gaussian (reflect border) and weight (zero border) of the region */
+        int16_t** g = (int16_t**)calloc((size_t)nb + 1, sizeof(int16_t*));
+        float** wp = (float**)calloc((size_t)nb + 1, sizeof(float*));
+        g[0] = (int16_t*)malloc(sizeof(int16_t) * (size_t)rw * rh * 3);
+        wp[0] = (float*)calloc((size_t)rw * rh, sizeof(float));
+        for (int y = 0; y < rh; y++) {
+            const int sy = reflecti(y - top, chh[k]);
+            for (int x = 0; x < rw; x++) {
+                const int sx = reflecti(x - left, cw[k]);
+                for (int c = 0; c < 3; c++) g[0][((size_t)y * rw + x) * 3 + c] = (int16_t)chips[k][(size_t)sy * cws + 3 * sx + c];
+                if (y - top >= 0 && y - top < chh[k] && x - left >= 0 && x - left < cw[k])
+                    wp[0][(size_t)y * rw + x] = (float)masks[k][(size_t)(y - top) * mws + (x - left)] * (float)(1.0 / 255.0);
+            }
+        }
+        for (int l = 0; l < nb; l++) {
+            g[l + 1] = (int16_t*)malloc(sizeof(int16_t) * (size_t)(rw >> (l + 1)) * (rh >> (l + 1)) * 3);
+            orc_pyr_down16(g[l], rw >> l, rh >> l, g[l + 1]);
+            wp[l + 1] = (float*)malloc(sizeof(float) * (size_t)(rw >> (l + 1)) * (rh >> (l + 1)));
+            orc_pyr_down_f(wp[l], rw >> l, rh >> l, wp[l + 1]);
+        }
+        for (int l = 0; l < nb; l++) {                               /* Gaussian -> Laplacian in place */
+            const size_t cnt = (size_t)(rw >> l) * (rh >> l) * 3;
+            int16_t* up = (int16_t*)malloc(sizeof(int16_t) * cnt);
+            orc_pyr_up16(g[l + 1], rw >> (l + 1), rh >> (l + 1), up);
+            for (size_t i = 0; i < cnt; i++) g[l][i] = sat16((int)g[l][i] - (int)up[i]);
+            free(up);
+        }
+        for (int l = 0; l <= nb; l++) {
+            const int lw = rw >> l, lh = rh >> l, ox = tlx >> l, oy = tly >> l, DW = Wp >> l;
+            for (int y = 0; y < lh; y++)
+                for (int x = 0; x < lw; x++) {
+                    const float wgt = wp[l][(size_t)y * lw + x];
+                    const size_t di = (size_t)(oy + y) * DW + (ox + x);
+                    for (int c = 0; c < 3; c++) {
+                        const int16_t add = (int16_t)((float)g[l][((size_t)y * lw + x) * 3 + c] * wgt);
+                        dl[l][di * 3 + c] = (int16_t)(dl[l][di * 3 + c] + add);
+                    }
+                    dwt[l][di] += wgt;
+                }
+            free(g[l]); free(wp[l]);
+        }
+        free(g); free(wp);
+    }
+    for (int l = 0; l <= nb; l++) {
+        const size_t cnt = (size_t)(Wp >> l) * (Hp >> l);
+        for (size_t i = 0; i < cnt; i++)
+            for (int c = 0; c < 3; c++) dl[l][i * 3 + c] = (int16_t)((float)dl[l][i * 3 + c] / (dwt[l][i] + 1e-5f));
+    }
+    for (int l = nb - 1; l >= 0; l--) {
+        const size_t cnt = (size_t)(Wp >> l) * (Hp >> l) * 3;
+        int16_t* up = (int16_t*)malloc(sizeof(int16_t) * cnt);
+        orc_pyr_up16(dl[l + 1], Wp >> (l + 1), Hp >> (l + 1), up);
+        for (size_t i = 0; i < cnt; i++) dl[l][i] = sat16((int)up[i] + (int)dl[l][i]);
+        free(up);
+    }
+    const int ows = (W * 3 + 3) & ~3;
+    memset(out, 0, (size_t)ows * H);
+    for (int y = 0; y < H; y++)
+        for (int x = 0; x < W; x++) {
+            const size_t di = (size_t)y * Wp + x;
+            if (!(dwt[0][di] > 1e-5f)) continue;
+            for (int c = 0; c < 3; c++) { const int v = dl[0][di * 3 + c]; out[(size_t)y * ows + 3 * x + c] = (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v)); }
+        }
+    for (int l = 0; l <= nb; l++) { free(dl[l]); free(dwt[l]); }
+    free(dl); free(dwt);
+    return nb;
+}

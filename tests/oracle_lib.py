@@ -172,6 +172,20 @@ class Oracle:
         rc = self.L.orc_mosaic_images_refined(ptrs, _p(w), _p(h), _p(ws), n, _p(h9s), _p(canvas), C.byref(cw), C.byref(ch), C.byref(cws))
         return rc, (canvas, cw.value, ch.value, cws.value)
 
+    def multiband_blend(self, chips, chip_imgs, masks, cw, ch, band=5):
+        n = len(chip_imgs)
+        ci = [np.ascontiguousarray(c, np.uint8) for c in chip_imgs]
+        mi = [np.ascontiguousarray(m, np.uint8) for m in masks]
+        cp = (C.c_void_p * max(n, 1))(*[c.ctypes.data for c in ci])
+        mp = (C.c_void_p * max(n, 1))(*[m.ctypes.data for m in mi])
+        x0 = np.array([int(c["x0"]) for c in chips], np.int32); y0 = np.array([int(c["y0"]) for c in chips], np.int32)
+        w = np.array([int(c["w"]) for c in chips], np.int32); h = np.array([int(c["h"]) for c in chips], np.int32)
+        ows = (cw * 3 + 3) & ~3
+        out = np.zeros((ch, ows), np.uint8)
+        self.L.orc_multiband_blend.restype = C.c_int
+        nb = self.L.orc_multiband_blend(cp, mp, _p(x0), _p(y0), _p(w), _p(h), n, int(cw), int(ch), int(band), _p(out))
+        return out, nb
+
     def chips_and_masks(self, imgs, h9s, keep=None, find_masks=True):
         n = len(imgs)
         imgs = [np.ascontiguousarray(i) for i in imgs]
