@@ -54,6 +54,7 @@ extern "C" int mi355_create(mi355_ctx** out, const mi355_params* params, int dev
     c->stream = c->own_stream;
     if (const char* e = getenv("MI355_BLUR_STREAM")) c->blur_stream = atoi(e) ? 1 : 0;
     if (const char* e = getenv("MI355_SIFT_SLOTS")) { const int v = atoi(e); c->sift_nslots = v < 1 ? 1 : (v > 4 ? 4 : v); }
+    if (const char* e = getenv("MI355_XSTREAM_MIN_W")) { const int v = atoi(e); c->xstream_min_w = v < 256 ? 256 : v; }
     if (const char* e = getenv("MI355_SIFT_BATCH")) { const int v = atoi(e); c->sift_batch = v < 1 ? 1 : (v > 8 ? 8 : v); }
     *out = c;
     return MI355_OK;

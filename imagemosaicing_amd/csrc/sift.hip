@@ -795,11 +795,12 @@ __global__ __launch_bounds__(256) void extrema_kernel(OctaveDev oc, int octave, 
                 cn[pl][j] = fminf(fminf(top[pl][j], mid[pl][j]), bot[pl][j]);
             }
         }
-        if (r < IMG_BORDER || r >= oc.h - IMG_BORDER) continue;
+        // all 12 tests of the item without a branch (same exact predicate as extrema_stream: |val| >= max(val > 0 ? mx : -mn, tiny));
+        // the rare hits are emitted afterwards
+        unsigned hit = 0;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            const int c = x0 + 4 * xg + k, j = k + 1;
-            if (c < IMG_BORDER || c >= oc.w - IMG_BORDER) continue;
+            const int j = k + 1;
 #pragma unroll
             for (int layer = 1; layer <= N_LAYERS; layer++) {
                 const float val = mid[layer][j];
@@ -810,16 +811,24 @@ __global__ __launch_bounds__(256) void extrema_kernel(OctaveDev oc, int octave, 
                 float mn = fminf(fminf(cn[layer - 1][j - 1], cn[layer - 1][j]), cn[layer - 1][j + 1]);
                 mn = fminf(mn, fminf(fminf(cn[layer + 1][j - 1], cn[layer + 1][j]), cn[layer + 1][j + 1]));
                 mn = fminf(mn, fminf(fminf(cn[layer][j - 1], cn[layer][j + 1]), fminf(top[layer][j], bot[layer][j])));
-                const bool is_ext = (val > 0.0f && val >= mx) || (val < 0.0f && val <= mn);
-                if (!is_ext) continue;
-                const unsigned long long rec = ((unsigned long long)octave << 48) | ((unsigned long long)layer << 40) | ((unsigned long long)r << 20) | (unsigned long long)c;
-                const unsigned slot = atomicAdd(&s_n, 1u);
-                if (slot < ECAP) s_list[slot] = rec;
-                else {                                                                           // tile with > 128 extrema (flat image)
-                    const unsigned reg = ((unsigned)tile >> REG_SHIFT) & (NREG - 1);
-                    const unsigned g = atomicAdd(&count[reg * REG_STRIDE], 1u);
-                    if (g < cap) cand[(size_t)reg * cap + g] = rec; else *overflow = 1;
-                }
+                const float q = val > 0.0f ? mx : -mn;
+                hit |= fabsf(val) >= fmaxf(q, 1.401298464324817e-45f) ? (1u << ((layer - 1) * 4 + k)) : 0u;
+            }
+        }
+        unsigned cmask = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) { const int c = x0 + 4 * xg + k; cmask |= (c >= IMG_BORDER && c < oc.w - IMG_BORDER) ? (0x111u << k) : 0u; }
+        hit = (r >= IMG_BORDER && r < oc.h - IMG_BORDER) ? (hit & cmask) : 0u;
+        while (hit) {
+            const int bb = __builtin_ctz(hit); hit &= hit - 1;
+            const int layer = bb / 4 + 1, c = x0 + 4 * xg + (bb & 3);
+            const unsigned long long rec = ((unsigned long long)octave << 48) | ((unsigned long long)layer << 40) | ((unsigned long long)r << 20) | (unsigned long long)c;
+            const unsigned slot = atomicAdd(&s_n, 1u);
+            if (slot < ECAP) s_list[slot] = rec;
+            else {                                                                           // tile with > 128 extrema (flat image)
+                const unsigned reg = ((unsigned)tile >> REG_SHIFT) & (NREG - 1);
+                const unsigned g = atomicAdd(&count[reg * REG_STRIDE], 1u);
+                if (g < cap) cand[(size_t)reg * cap + g] = rec; else *overflow = 1;
             }
         }
     }
@@ -888,12 +897,18 @@ __device__ __forceinline__ unsigned xtest_row(const XDog& A, const XDog& B, cons
             float mn = fminf(fminf(d6[layer - 1][k], d6[layer - 1][k + 1]), d6[layer - 1][k + 2]);
             mn = fminf(mn, fminf(fminf(d6[layer + 1][k], d6[layer + 1][k + 1]), d6[layer + 1][k + 2]));
             mn = fminf(mn, fminf(fminf(d6[layer][k], d6[layer][k + 2]), fminf(A.m[layer][k], C.m[layer][k])));
-            const int c = xm + k;
-            const bool is_ext = ((val > 0.0f && val >= mx) || (val < 0.0f && val <= mn)) && row_ok && c >= clo && c < chi;
-            hit |= is_ext ? (1u << ((layer - 1) * 4 + k)) : 0u;
+            // (val > 0 && val >= mx) || (val < 0 && val <= mn)  <=>  |val| >= max(val > 0 ? mx : -mn, smallest positive float):
+            // exact (no arithmetic on the values) and all in the vector unit -- the mask logic of the plain form costs more
+            // scalar instructions than the whole rest of the row
+            const float q = val > 0.0f ? mx : -mn;
+            hit |= fabsf(val) >= fmaxf(q, 1.401298464324817e-45f) ? (1u << ((layer - 1) * 4 + k)) : 0u;
         }
     }
-    return hit;
+    // validity of the row and of the lane's four columns, applied once
+    unsigned cmask = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) cmask |= (xm + k >= clo && xm + k < chi) ? (0x111u << k) : 0u;
+    return row_ok ? (hit & cmask) : 0u;
 }
 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))

@@ -7,11 +7,12 @@ int main(int argc, char** argv) {
     const int W = getenv("KW") ? atoi(getenv("KW")) : 8000, H = getenv("KH") ? atoi(getenv("KH")) : 6000;
     const size_t px = (size_t)W * H;
     float* lv[7];
-    for (int i = 0; i < 7; i++) CK(hipMalloc(&lv[i], px * 4));
+    const int NB = getenv("KNB") ? atoi(getenv("KNB")) : 1;
+    for (int i = 0; i < 7; i++) CK(hipMalloc(&lv[i], px * 4 * NB));
     std::vector<float> h(px);
     unsigned s = 12345;
     for (size_t i = 0; i < px; i++) { s = s * 1664525u + 1013904223u; h[i] = (float)(s >> 24); }
-    CK(hipMemcpy(lv[0], h.data(), px * 4, hipMemcpyHostToDevice));
+    for (int f = 0; f < NB; f++) CK(hipMemcpy(lv[0] + (size_t)f * px, h.data(), px * 4, hipMemcpyHostToDevice));
     hipStream_t st; CK(hipStreamCreate(&st));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     const double sigma = 1.6, k = std::pow(2.0, 1.0 / 3);
@@ -20,7 +21,7 @@ int main(int argc, char** argv) {
         BlurArgs a; memset(&a, 0, sizeof(a));
         const int R = gauss_kernel_host(std::sqrt(stt * stt - sp * sp), a.k);
         a.src = lv[i - 1]; a.dst = lv[i]; a.w = W; a.h = H; a.tiles_x = (W + TW - 1) / TW; a.tiles_y = (H + TH - 1) / TH;
-        if (getenv("KNB")) { a.nb = atoi(getenv("KNB")); a.fstride = 0; }
+        a.nb = NB; a.fstride = px;
         launch_blur<false>(st, R, a, smode);
         CK(hipStreamSynchronize(st));
         CK(hipEventRecord(e0, st));
@@ -30,7 +31,7 @@ int main(int argc, char** argv) {
         CK(hipMemcpy(h.data(), lv[i], px * 4, hipMemcpyDeviceToHost));
         unsigned long long ck = 1469598103934665603ull;
         for (size_t q = 0; q < px; q++) { unsigned u; memcpy(&u, &h[q], 4); ck = (ck ^ u) * 1099511628211ull; }
-        printf("blur R=%2d: %.1f us  %.0f GB/s algorithmic  checksum %016llx\n", R, ms * 1e3, px * 8.0 / ms / 1e6, ck);
+        printf("blur R=%2d: %.1f us/frame  %.0f GB/s algorithmic  checksum %016llx\n", R, ms * 1e3 / NB, NB * px * 8.0 / ms / 1e6, ck);
     }
     {   // base level: u8 BGR frame (W/2 x H/2) -> gray -> 2x up-sampling -> blur
         const int fw = W / 2, fh = H / 2, ws = fw * 3;
@@ -58,11 +59,12 @@ int main(int argc, char** argv) {
     }
     if (argc > 1) return 0;
     OctaveDev oc; for (int i = 0; i < 6; i++) oc.lv[i] = lv[i]; oc.w = W; oc.h = H;
+    float* cube; CK(hipMalloc(&cube, 1 << 20));
     unsigned long long* cand; unsigned* cnt; CK(hipMalloc(&cand, 64 << 20)); CK(hipMalloc(&cnt, 8192)); CK(hipMemset(cnt, 0, 8192));
     for (int rep = 0; rep < 2; rep++) {
         CK(hipMemset(cnt, 0, 8192));
         CK(hipEventRecord(e0, st));
-        for (int it = 0; it < 5; it++) hipLaunchKernelGGL(extrema_kernel, dim3(((W + EW - 1) / EW) * ((H + EH - 1) / EH)), dim3(256), 0, st, oc, 0, cand, cnt, (8u << 20) / 64, cnt + 2047, BatchStride{0, 0, 0, 0, 0});
+        for (int it = 0; it < 5; it++) hipLaunchKernelGGL(extrema_kernel, dim3(((W + EW - 1) / EW) * ((H + EH - 1) / EH)), dim3(256), 0, st, oc, 0, cand, cnt, (8u << 20) / 64, cnt + 2047, BatchStride{0, 0, 0, 0, 0, 0}, cube, 0u);
         CK(hipEventRecord(e1, st)); CK(hipStreamSynchronize(st));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= 5;
         unsigned c; CK(hipMemcpy(&c, cnt, 4, hipMemcpyDeviceToHost));
