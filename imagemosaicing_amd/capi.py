@@ -153,6 +153,13 @@ class Context:
         k = min(n.value, max_kp)
         return kp[:k].copy(), desc[:k].copy()
 
+    def SiftExtractHost(self, img_id, bgr):
+        """Host frame in, nothing back: the frame is copied into the library's staging ring and joins a batch like a device
+        frame (mi355_sift_extract with kp = desc = n_kp = NULL).  The array may be reused as soon as the call returns."""
+        img, w, h, ws, ch = _img_geom(bgr)
+        assert ch == 3
+        self._chk(self.L.mi355_sift_extract(self._h, int(img_id), _p(img), w, h, ws, None, None, 0, None))
+
     def SiftExtractDev(self, img_id, d_bgr, w, h, ws, want_count=False):
         """Asynchronous unless want_count: the frame is enqueued on one of the library's SIFT streams and the call
         returns; the keypoint count is adopted at the next MatchPairs / GetFeatures / synchronize."""

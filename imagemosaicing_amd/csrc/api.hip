@@ -68,6 +68,8 @@ extern "C" void mi355_destroy(mi355_ctx* ctx) {
     mi_sift_release(ctx);
     for (auto& kv : ctx->feats) kv.second.release();
     for (auto& kv : ctx->ws) kv.second.release();
+    for (auto& b : ctx->host_frames) b.release();
+    for (hipEvent_t e : ctx->host_frame_ev) if (e) (void)hipEventDestroy(e);
     for (auto& kv : ctx->draw_tables) kv.second.release();
     for (auto& kv : ctx->prof) for (auto& ev : kv.second.ev) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
@@ -117,11 +119,43 @@ extern "C" int mi355_sift_extract_dev(mi355_ctx* ctx, int img_id, const uint8_t*
 extern "C" int mi355_sift_extract(mi355_ctx* ctx, int img_id, const uint8_t* bgr, int w, int h, int width_step,
                                   mi355_keypoint* kp, float* desc128, int max_kp, int* n_kp) {
     int n = 0;
+    const bool deferred = !kp && !desc128 && !n_kp;           // nothing asked back: the frame may join a batch
     {
         LOCKED_PROLOGUE
         if (!bgr || w < 16 || h < 16 || width_step < 3 * w) { ctx->set_error("sift_extract: bad image geometry"); return MI355_ERR_ARG; }
-        DevBuf& dimg = ctx->buf("sift_host_img");
         const size_t bytes = (size_t)width_step * h;
+        if (deferred) {
+            // staging ring in HBM: a slot is reused only after the batch that read it has finished (event of its work area)
+            const size_t ring = (size_t)(ctx->sift_nslots + 1) * (size_t)(ctx->sift_batch < 1 ? 1 : ctx->sift_batch);
+            if (ctx->host_frames.size() != ring) {
+                int rc = mi_resolve_features(ctx);
+                if (rc != MI355_OK) return rc;
+                for (auto& b : ctx->host_frames) b.release();
+                for (hipEvent_t e : ctx->host_frame_ev) if (e) (void)hipEventDestroy(e);
+                ctx->host_frames.assign(ring, DevBuf());
+                ctx->host_frame_ev.assign(ring, nullptr);
+                ctx->host_frame_used.assign(ring, 0);
+                ctx->host_frame_next = 0;
+            }
+            const size_t slot = ctx->host_frame_next;
+            ctx->host_frame_next = (ctx->host_frame_next + 1) % ring;
+            DevBuf& dimg = ctx->host_frames[slot];
+            if (!ctx->host_frame_ev[slot]) MI_HIP(hipEventCreateWithFlags(&ctx->host_frame_ev[slot], hipEventDisableTiming));
+            if (ctx->host_frame_used[slot]) {
+                // the batch that read this slot was launched at least `batch` frames ago; its event orders the overwrite
+                int rc = mi_sift_flush_if_parked(ctx, ctx->host_frame_ev[slot]);
+                if (rc != MI355_OK) return rc;
+                MI_HIP(hipStreamWaitEvent(ctx->stream, ctx->host_frame_ev[slot], 0));
+            }
+            ctx->host_frame_used[slot] = 1;
+            MI_HIP(dimg.reserve(bytes + 16));
+            MI_HIP(hipMemcpyAsync(dimg.p, bgr, bytes, hipMemcpyHostToDevice, ctx->stream));
+            ctx->pend_event = ctx->host_frame_ev[slot];      // recorded by the batch this frame ends up in
+            const int rc = mi_sift_extract_dev(ctx, img_id, dimg.as<uint8_t>(), w, h, width_step, nullptr);
+            ctx->pend_event = nullptr;
+            return rc;
+        }
+        DevBuf& dimg = ctx->buf("sift_host_img");
         MI_HIP(dimg.reserve(bytes + 16));
         MI_HIP(hipMemcpyAsync(dimg.p, bgr, bytes, hipMemcpyHostToDevice, ctx->stream));
         int rc = mi_sift_extract_dev(ctx, img_id, dimg.as<uint8_t>(), w, h, width_step, &n);

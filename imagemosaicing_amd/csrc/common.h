@@ -78,6 +78,11 @@ struct mi355_ctx {
     std::map<std::string, ProfClass> prof;
     std::vector<SiftWork*> sift_slots;                 // batch work areas, each with its own stream (sift.hip)
     int sift_next = 0;
+    std::vector<DevBuf> host_frames;                   // staging ring of mi355_sift_extract's deferred mode (host frames joining batches)
+    std::vector<hipEvent_t> host_frame_ev;             // per ring slot: recorded after the batch that read the slot
+    std::vector<char> host_frame_used;
+    size_t host_frame_next = 0;
+    hipEvent_t pend_event = nullptr;                   // handed to the frame being parked by mi_sift_extract_dev
     int blur_stream = 1;                               // big pyramid levels through blur_stream (0: tile kernel only); option "blur_stream"
     int sift_nslots = 3;                               // batch work areas in flight, each on its own stream (option "sift_slots", env MI355_SIFT_SLOTS)
     int xstream_min_w = 4096, xstream_min_frames = 4;  // extrema_stream for octaves at least this wide (and 3/4 as high) in batches of at least so many frames
@@ -110,6 +115,7 @@ int mi_warp_image(mi355_ctx*, const uint8_t* src, int w, int h, int ws, int ch, 
                   uint8_t** dst, int* dw, int* dh, int* dws);
 int mi_mosaic_refined_dev(mi355_ctx*, const uint8_t* const* d_imgs, const int* w, const int* h, const int* ws, int n,
                           const float* h9s, uint8_t* d_canvas, int cw, int ch, int cws, int row0, int rows);
+int mi_sift_flush_if_parked(mi355_ctx*, hipEvent_t ev);   // launches the batch still holding a parked frame with this event
 int mi_multiband_blend(mi355_ctx*, const uint8_t* const* chips, const uint8_t* const* masks, const mi355_chip_info* info, int n,
                        int W, int H, int band, uint8_t** out, int* ow, int* oh, int* ows);
 int mi_chips_and_masks(mi355_ctx*, const uint8_t* const* imgs, const int* w, const int* h, const int* ws, int n,

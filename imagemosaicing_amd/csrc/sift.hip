@@ -1608,6 +1608,7 @@ struct SiftWork {
     int nb = 0;                              // frames the buffers hold
     int n_oct = 0;
     hipStream_t stream = nullptr;
+    hipEvent_t done = nullptr;               // recorded after the last launch of the latest batch
     DevBuf pyr;                              // all Gaussian levels
     DevBuf claimed;                          // duplicate claim bitmaps
     DevBuf cand, refined, kps, kresp, sel, counters, rhist, ccnt;
@@ -1619,7 +1620,7 @@ struct SiftWork {
     float kern[N_LEVELS][2 * MAX_R + 1];
     int radius[N_LEVELS];
     float kern0[2 * MAX_R + 1]; int radius0 = 0;
-    struct Pend { int img_id; const uint8_t* d_bgr; int ws; };
+    struct Pend { int img_id; const uint8_t* d_bgr; int ws; hipEvent_t ev; };   // ev: recorded once the batch is enqueued (optional)
     std::vector<Pend> pend;
 };
 
@@ -1630,6 +1631,7 @@ void mi_sift_release(mi355_ctx* ctx) {
     for (SiftWork* s : ctx->sift_slots) {
         if (!s) continue;
         if (s->stream) { (void)hipStreamSynchronize(s->stream); (void)hipStreamDestroy(s->stream); }
+        if (s->done) (void)hipEventDestroy(s->done);
         s->pyr.release(); s->claimed.release(); s->cand.release(); s->refined.release(); s->kps.release(); s->kresp.release(); s->sel.release(); s->counters.release(); s->rhist.release(); s->ccnt.release(); s->gray.release(); s->cube.release();
         delete s;
     }
@@ -1772,6 +1774,7 @@ int mi_sift_extract_dev(mi355_ctx* ctx, int img_id, const uint8_t* d_bgr, int w,
     if (!ctx->sift_slots[slot]) {
         ctx->sift_slots[slot] = new SiftWork();
         MI_HIP(hipStreamCreateWithFlags(&ctx->sift_slots[slot]->stream, hipStreamNonBlocking));
+        MI_HIP(hipEventCreateWithFlags(&ctx->sift_slots[slot]->done, hipEventDisableTiming));
     }
     SiftWork* s = ctx->sift_slots[slot];
     int rc = MI355_OK;
@@ -1786,7 +1789,7 @@ int mi_sift_extract_dev(mi355_ctx* ctx, int img_id, const uint8_t* d_bgr, int w,
     MI_HIP(f.kp.reserve(sizeof(mi355_keypoint) * 2048));
     MI_HIP(f.d8.reserve(128 * 2048));
     f.pending = true; f.h_cnt = nullptr; f.n = 0;
-    s->pend.push_back({img_id, d_bgr, ws});
+    s->pend.push_back({img_id, d_bgr, ws, ctx->pend_event});
     if ((int)s->pend.size() >= nb) {
         rc = sift_run_batch(ctx, s);
         if (rc != MI355_OK) return rc;
@@ -1925,6 +1928,17 @@ static int sift_run_batch(mi355_ctx* ctx, SiftWork* s) {
         MI_HIP(hipMemcpyAsync(hc, ck, 8 * sizeof(unsigned), hipMemcpyDeviceToHost, st));
         f.h_cnt = hc; f.pending = true; f.n = 0;
         f.caps[0] = 0xffffffffu; f.caps[1] = s->ref_cap; f.caps[2] = s->kp_cap;      // candidate overflow is flagged by the kernel (cnt[4])
+    }
+    MI_HIP(hipEventRecord(s->done, st));
+    for (int k = 0; k < n; k++) if (pend[k].ev) MI_HIP(hipEventRecord(pend[k].ev, st));
+    return MI355_OK;
+}
+
+// a frame parked with event `ev` still waits for its batch to fill: enqueue that batch now (the event gets recorded)
+int mi_sift_flush_if_parked(mi355_ctx* ctx, hipEvent_t ev) {
+    for (SiftWork* s : ctx->sift_slots) {
+        if (!s) continue;
+        for (const SiftWork::Pend& p : s->pend) if (p.ev == ev) return sift_run_batch(ctx, s);
     }
     return MI355_OK;
 }

@@ -105,7 +105,9 @@ void mi355_free(void* p);                               /* frees host buffers re
 /* ---- features: replaces the body of SiftExtraction_Thread, MosaicWithoutPos.cpp:4861-4881 ----------- */
 /* BGR u8 host image in, keypoints + 128-D descriptors out (desc128: n x 128 floats holding the integers
  * 0..255 like OpenCV's SIFT; either output may be NULL).  Features stay device-resident under img_id for
- * mi355_match_pairs (the reference round-trips them through d:/feature_temp files instead). */
+ * mi355_match_pairs (the reference round-trips them through d:/feature_temp files instead).  With kp, desc128 and n_kp all
+ * NULL nothing is waited for: the frame is copied into a staging ring in HBM (bgr may be reused on return) and joins a
+ * batch like a device frame -- the fast way to feed host images. */
 int  mi355_sift_extract(mi355_ctx* ctx, int img_id, const uint8_t* bgr, int w, int h, int width_step,
                         mi355_keypoint* kp, float* desc128, int max_kp, int* n_kp);
 /* Same, image already in HBM (device pointer); nothing is copied back.  With n_kp == NULL the call returns at once and

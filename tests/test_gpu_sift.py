@@ -109,7 +109,7 @@ def test_sift_batched_frames_equal_single(ctx, oracle):
     import torch
     import imagemosaicing_amd as im
     from tests.synth_frames import terrain
-    sizes = [(320, 240)] * 11 + [(200, 160)] * 3 + [(1100, 780)] * 3
+    sizes = [(320, 240)] * 11 + [(200, 160)] * 3 + [(333, 257)] * 3 + [(1100, 780)] * 3
     imgs = [terrain(w, h, seed=40 + k) for k, (w, h) in enumerate(sizes)]
     ref = []
     for k, img in enumerate(imgs):
@@ -152,4 +152,24 @@ def test_sift_streamed_extrema(ctx, oracle):
         kp, desc = c.GetFeatures(k)
         assert np.array_equal(kp.view(np.uint8), ref[k][0].view(np.uint8)), f"frame {k} keypoints differ"
         assert np.array_equal(desc, ref[k][1]), f"frame {k} descriptors differ"
+    c.close()
+
+
+def test_sift_host_frames_deferred(ctx):
+    """mi355_sift_extract with nothing asked back: host frames go through the staging ring and join batches; the source
+    array is overwritten right after each call; more frames than the ring holds"""
+    import imagemosaicing_amd as im
+    from tests.synth_frames import terrain
+    imgs = [terrain(320, 240, seed=70 + k) for k in range(21)]
+    ref = [ctx.SiftExtract(700 + k, img) for k, img in enumerate(imgs)]
+    c = im.Context(0)
+    c.set_option("sift_batch", 4); c.set_option("sift_slots", 2)          # ring of 12 frames
+    buf = np.empty_like(imgs[0])
+    for k, img in enumerate(imgs):
+        buf[...] = img
+        c.SiftExtractHost(k, buf)
+        buf[...] = 0
+    for k in range(len(imgs)):
+        kp, desc = c.GetFeatures(k)
+        assert np.array_equal(kp.view(np.uint8), ref[k][0].view(np.uint8)) and np.array_equal(desc, ref[k][1]), f"frame {k}"
     c.close()
