@@ -217,7 +217,7 @@ def main():
     for i in range(args.warmup):
         step(1 + i)
     ctx.profile_enable(not os.environ.get("MI355_BENCH_NOPROF"))
-    ctx.profile_only(None if args.profile_all else DOM)
+    ctx.profile_only(None if args.profile_all else DOM + ",match")
     ctx.profile_reset()
     barrier()
     t0 = time.perf_counter()
@@ -230,6 +230,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     g_ms, g_n, g_bytes = ctx.profile_get(DOM)
+    m_ms, m_n, _ = ctx.profile_get("match")
     prof_all = {}
     if args.profile_all:
         for cls in ("gauss_stream", "gauss", "downsample", "extrema", "refine", "orient", "topk", "describe", "features", "match", "select", "ransac", "warp"):
@@ -303,6 +304,10 @@ def main():
             "path_roofline": {"algorithmic_bytes_per_pair": 262.0 * w * h + 1.04e6, "achieved": value / max(world, 1) * (262.0 * w * h + 1.04e6) / 1e9,
                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": value / max(world, 1) * (262.0 * w * h + 1.04e6) / 1e9 / HBM_PEAK_GBS,
                               "note": "per GPU; SURVEY 8(d) formula (reads+writes of all 6 Gaussian levels, match operands, warp); this build moves fewer bytes than the formula assumes in places"},
+            # north_star: MFMA utilisation of the only matrix kernel (exact all-pairs descriptor distances, bf16 32x32x16 MFMA)
+            "mfma": {"kernel": "bf_match_kernel", "flop_per_pair": 2.0 * 2000 * 2000 * 128, "achieved": (n_pairs * args.steps * 2.0 * 2000 * 2000 * 128 / 1e12) / (m_ms / 1e3) if m_ms > 0 else None,
+                     "peak": 2500.0, "unit": "TFLOP/s", "frac": ((n_pairs * args.steps * 2.0 * 2000 * 2000 * 128 / 1e12) / (m_ms / 1e3) / 2500.0) if m_ms > 0 else None,
+                     "ms_per_step": m_ms / max(args.steps, 1), "note": "dense bf16 peak; 0.1 % of the step time, the path is HBM-bound"},
             "quality": {"pairs_accepted": accepted, "pairs": n_pairs, "images_aligned": state["n_valid"],
                         "h_corner_err_px_median": float(np.median(errs)) if errs else None,
                         "h_corner_err_px_max": float(np.max(errs)) if errs else None},

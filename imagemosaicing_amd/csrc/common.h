@@ -74,7 +74,7 @@ struct mi355_ctx {
     std::map<std::string, DevBuf> ws;                  // named grow-only workspaces
     std::map<std::pair<uint32_t, int>, DevBuf> draw_tables;   // (seed, n) -> RANSAC draw table
     bool profiling = false;
-    std::string prof_only;                             // non-empty: bracket only this kernel class
+    std::string prof_only;                             // non-empty: bracket only these kernel classes (comma separated)
     std::map<std::string, ProfClass> prof;
     std::vector<SiftWork*> sift_slots;                 // batch work areas, each with its own stream (sift.hip)
     int sift_next = 0;
@@ -104,7 +104,7 @@ struct ProfScope {
     mi355_ctx* c; const char* cls; hipStream_t st;
     bool on;
     ProfScope(mi355_ctx* c_, const char* cls_, double bytes, hipStream_t st_ = nullptr) : c(c_), cls(cls_), st(st_ ? st_ : c_->stream) {
-        on = c->profiling && (c->prof_only.empty() || c->prof_only == cls);
+        on = c->profiling && (c->prof_only.empty() || ("," + c->prof_only + ",").find(std::string(",") + cls + ",") != std::string::npos);
         if (on) c->prof_begin(cls, bytes, st);
     }
     ~ProfScope() { if (on) c->prof_end(cls, st); }

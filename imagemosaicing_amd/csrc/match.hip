@@ -39,13 +39,13 @@ __device__ __forceinline__ void top2_update(int s, int j, int& best, int& second
 }
 
 __global__ __launch_bounds__(256) void bf_match_kernel(const PairDesc* pairs, int* nn_idx, int* nn_d2, int* nn_2nd) {
-    __shared__ int s_nrm[KSTRIDE];
+    __shared__ __attribute__((aligned(16))) float s_nrm[KSTRIDE];    // |t|^2 of the train rows, +inf for the padding rows
     const PairDesc pd = pairs[blockIdx.y];
     const int q_base = blockIdx.x * QTILE;
     if (q_base >= pd.n_i) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int hi = lane >> 5, col = lane & 31;
-    for (int i = tid; i < pd.npad_j; i += 256) s_nrm[i] = pd.nrm_j[i];
+    for (int i = tid; i < pd.npad_j; i += 256) s_nrm[i] = i < pd.n_j ? (float)pd.nrm_j[i] : __builtin_inff();
     __syncthreads();
     const int q = q_base + wave * 32 + col;              // this lane's query (rows beyond n_i are zero padding)
     const bool q_ok = q < pd.npad_i;
@@ -56,25 +56,61 @@ __global__ __launch_bounds__(256) void bf_match_kernel(const PairDesc* pairs, in
         else for (int e = 0; e < 8; e++) bq[ks][e] = (__bf16)0.0f;
     }
     const float nq = q_ok ? (float)pd.nrm_i[q] : 0.0f;
-    int best = 0x7fffffff, second = 0x7fffffff, bi = -1;
+    // |q - t|^2 = |q|^2 - (2 q.t - |t|^2): the running top-2 is kept on x = 2 q.t - |t|^2 (to be maximised), all exact
+    // integers below 2^24 in binary32.  Per element: one fma, max, med3, compare, select -- the epilogue costs about as
+    // many cycles as the 8 MFMAs of the tile, and the two overlap across the waves of a SIMD.
+    float bx = -__builtin_inff(), sx = -__builtin_inff();
+    int bi = -1;
+    // The 32 x 128 train tile (8 KB) is the A operand of all four waves: it is fetched once per workgroup into LDS (double
+    // buffered, the next tile's global loads in flight during the MFMAs) instead of once per wave from L2 -- four waves
+    // pulling every tile themselves moved 33 MB per pair through L2, which bounded the kernel, not the matrix cores.
+    constexpr int APITCH = 128 + 8;                       // bf16 per staged row: 272 B keeps the 32 rows of a read on distinct banks
+    __shared__ __attribute__((aligned(16))) uint16_t s_a[2][32 * APITCH];
+    const int ld_row = tid >> 3, ld_chunk = tid & 7;      // this thread stages 16 bf16 (32 B) of the tile
+    uint4 pf0, pf1;
+    auto fetch = [&](int t0) {
+        const uint4* g = reinterpret_cast<const uint4*>(pd.bf_j + (size_t)(t0 + ld_row) * 128 + ld_chunk * 16);
+        pf0 = g[0]; pf1 = g[1];
+    };
+    auto stage = [&](int buf) {
+        uint4* d = reinterpret_cast<uint4*>(&s_a[buf][ld_row * APITCH + ld_chunk * 16]);
+        d[0] = pf0; d[1] = pf1;
+    };
+    fetch(0);
+    stage(0);
+    __syncthreads();
+    int cur = 0;
     for (int t0 = 0; t0 < pd.npad_j; t0 += 32) {
+        const bool more = t0 + 32 < pd.npad_j;
+        if (more) fetch(t0 + 32);
         f32x16 acc;
 #pragma unroll
         for (int e = 0; e < 16; e++) acc[e] = 0.0f;
-        const uint16_t* arow = pd.bf_j + (size_t)(t0 + col) * 128 + hi * 8;
+        const uint16_t* arow = &s_a[cur][col * APITCH + hi * 8];
 #pragma unroll
         for (int ks = 0; ks < 8; ks++) {
             const bf16x8 at = *reinterpret_cast<const bf16x8*>(arow + ks * 16);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at, bq[ks], acc, 0, 0, 0);
         }
 #pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const int m = t0 + (r & 3) + 8 * (r >> 2) + 4 * hi;       // C/D layout of the 32x32 MFMA
-            const float d = (nq + (float)s_nrm[m]) - 2.0f * acc[r];   // exact integers below 2^24
-            const int s = (m < pd.n_j) ? (int)d : 0x7fffffff;
-            top2_update(s, m, best, second, bi);
+        for (int g = 0; g < 4; g++) {
+            const int m0 = t0 + 8 * g + 4 * hi;                       // C/D layout of the 32x32 MFMA: rows m0 .. m0+3 in acc[4g .. 4g+3]
+            const float4 nt = *reinterpret_cast<const float4*>(&s_nrm[m0]);
+            const float ntv[4] = {nt.x, nt.y, nt.z, nt.w};
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const float x = fmaf(2.0f, acc[4 * g + r], -ntv[r]);
+                bi = x > bx ? m0 + r : bi;                            // strict: ties keep the lowest train index (rows ascend)
+                sx = __builtin_amdgcn_fmed3f(bx, x, sx);              // second = median(best, x, second) since second <= best
+                bx = fmaxf(bx, x);
+            }
         }
+        if (more) stage(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
     }
+    const int best = bi >= 0 ? (int)(nq - bx) : 0x7fffffff;
+    const int second = sx > -__builtin_inff() ? (int)(nq - sx) : 0x7fffffff;
     // merge the two half-waves (same query, disjoint train rows); ties -> lowest train index
     const int ob = __shfl_xor(best, 32), os = __shfl_xor(second, 32), oi = __shfl_xor(bi, 32);
     const bool other_wins = (ob < best) || (ob == best && oi >= 0 && (bi < 0 || oi < bi));
