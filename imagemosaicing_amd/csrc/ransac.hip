@@ -51,7 +51,7 @@ __device__ __forceinline__ int block_exclusive_scan_flags(bool flag, int tid, in
     return off + before;
 }
 
-__global__ __launch_bounds__(RB) void ransac_kernel(RansacArgs a) {
+__global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(2, 2))) void ransac_kernel(RansacArgs a) {
     extern __shared__ float lds[];
     __shared__ int   s_sup[RB];
     __shared__ int   s_flag[RB];

@@ -173,3 +173,32 @@ def test_sift_host_frames_deferred(ctx):
         kp, desc = c.GetFeatures(k)
         assert np.array_equal(kp.view(np.uint8), ref[k][0].view(np.uint8)) and np.array_equal(desc, ref[k][1]), f"frame {k}"
     c.close()
+
+
+def test_sift_c2_strip_1920x1080(ctx, oracle):
+    """BASELINE config C2 shape: frames of a 1920x1080 strip, batched extraction (octave 0 = 3840x2160 through the streamed
+    blur, strips an exact multiple of 256 wide), features and the adjacent-pair results against the oracle pipeline"""
+    import torch
+    import imagemosaicing_amd as im
+    from tests.synth_frames import strip
+    frames, Hs = strip(3, 1920, 1080, seed=2)
+    c = im.Context(0)
+    dev = [torch.from_numpy(np.ascontiguousarray(f)).cuda() for f in frames]
+    torch.cuda.synchronize()
+    for k, d in enumerate(dev):
+        c.SiftExtractDev(k, d.data_ptr(), 1920, 1080, 1920 * 3)
+    res = c.MatchPairs([(0, 1), (1, 2)], 2.5, 5)
+    feats = []
+    for k in range(3):
+        kp, desc = c.GetFeatures(k)
+        okp, odesc = oracle.sift(frames[k])
+        assert np.array_equal(kp.view(np.uint8), okp.view(np.uint8)), f"frame {k}: keypoints differ"
+        assert np.array_equal(desc.astype(np.uint8), odesc), f"frame {k}: descriptors differ"
+        feats.append((okp, odesc))
+    for p, (i, j) in enumerate([(0, 1), (1, 2)]):
+        (k1, d1), (k2, d2) = feats[i], feats[j]
+        nin, i1, i2, Ho, ns = oracle.match_pair(np.stack([k1["x"], k1["y"]], 1), d1, np.stack([k2["x"], k2["y"]], 1), d2, 1920, 1080, 2.5, 5)
+        r = res[p]
+        assert int(r["accepted"]) == 1 and nin == int(r["n_in"]) and ns == int(r["n_selected"])
+        assert np.array_equal(r["a"][:nin], i1[:nin]) and np.array_equal(r["H"].view(np.uint32), Ho.view(np.uint32))
+    c.close()
