@@ -30,6 +30,7 @@ struct RansacArgs {
     const mi355_sfpoint* p1;       // [pair][stride]
     const mi355_sfpoint* p2;
     const int* n;                  // [pair]
+    long long* dbg;                // optional: per pair 8 cycle stamps (MI355_RANSAC_DBG)
     const uint16_t* tables;        // concatenated draw tables (MAX_DRAWS x 4 each)
     const int* table_of;           // [pair] table index, -1 = none (n < 4)
     int stride;
@@ -92,7 +93,9 @@ __global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 
     float scratch[320];
     float h[9];
+    long long T0 = wall_clock64(); int nchunk = 0; long long Tsolve = 0, Tsup = 0, Trep = 0;
     for (int base = 0; ; base += RB) {
+        nchunk++; long long c0 = wall_clock64();
         const int r = base + tid;
         int flag = 2, support = 0;                         // 2 = no such draw (stream of 4999 draws exhausted)
         if (r < MAX_DRAWS) {
@@ -113,6 +116,7 @@ __global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                     for (int i = 0; i < 9; i++) h[i] = fine[i];
                 }
             }
+            long long c1 = wall_clock64(); Tsolve += c1 - c0;
             if (h[8] > 5.0f) flag = 0;                     // :1864-1867 skipped, no slot consumed
             else {
                 flag = 1;
@@ -127,6 +131,7 @@ __global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         }
         s_flag[tid] = flag; s_sup[tid] = support;
         __syncthreads();
+        long long c2 = wall_clock64(); Tsup += c2 - c0;
         if (tid == 0) {                                    // replay of the sequential loop over this chunk
             int t = s_state[0], mx = s_state[1], best = s_state[2], first = s_state[3], fin = 0;
             int newBest = -1, newFirst = -1;
@@ -150,8 +155,10 @@ __global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         if (s_state[6] == tid) { for (int i = 0; i < 9; i++) s_firstH[i] = h[i]; }
         const int fin = s_state[4];
         __syncthreads();
+        Trep += wall_clock64() - c2;
         if (fin) break;
     }
+    long long T1 = wall_clock64();
     // winner: hyp[maxSupportIndex]; maxSupportIndex stays 0 when no support was ever positive (:1783) -> first accepted
     float W[9];
 #pragma unroll
@@ -196,6 +203,7 @@ __global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     if (tid < 64) s_T2[tid] = 0.0f;
     __syncthreads();
 
+    long long T2 = wall_clock64(); int nit = 0;
     // ---- NonlinearLeastSquareProjection2 over the inliers from the winning hypothesis (:1977-1986) ----
     const int rows = 2 * cnt;
     for (int it = 0; it < 15; it++) {
@@ -241,8 +249,10 @@ __global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             s_state[7] = done;
         }
         __syncthreads();
+        nit++;
         if (s_state[7]) break;
     }
+    if (a.dbg && tid == 0) { long long* d = a.dbg + 8 * pair; d[0] = T1 - T0; d[1] = T2 - T1; d[2] = wall_clock64() - T2; d[3] = nchunk; d[4] = Tsolve; d[5] = Tsup; d[6] = Trep; d[7] = nit; }
     // motion[8] = max residual in float (LeastSquare.h:503-519): max is order independent
     float emax = 0.0f;
     for (int i = tid; i < cnt; i += RB) {
@@ -409,6 +419,10 @@ int mi_ransac_batch(mi355_ctx* ctx, const mi355_sfpoint* d_p1, const mi355_sfpoi
     }
     RansacArgs a;
     a.p1 = d_p1; a.p2 = d_p2; a.n = d_n; a.tables = d_tables; a.table_of = d_table_of;
+    a.dbg = nullptr;
+    static const bool dbg_on = getenv("MI355_RANSAC_DBG") != nullptr;
+    DevBuf& ddbg = ctx->buf("ransac_dbg");
+    if (dbg_on) { MI_HIP(ddbg.reserve((size_t)n_pairs * 64)); MI_HIP(hipMemsetAsync(ddbg.p, 0, (size_t)n_pairs * 64, ctx->stream)); a.dbg = ddbg.as<long long>(); }
     a.stride = stride; a.dist = dist; a.sample_times = sample_times; a.out = d_out;
     const size_t lds_bytes = (size_t)38 * nmax * sizeof(float);
     if (lds_bytes > 48 * 1024) {
@@ -419,5 +433,13 @@ int mi_ransac_batch(mi355_ctx* ctx, const mi355_sfpoint* d_p1, const mi355_sfpoi
         hipLaunchKernelGGL(ransac_kernel, dim3(n_pairs), dim3(RB), lds_bytes, ctx->stream, a);
     }
     MI_HIP(hipGetLastError());
+    if (dbg_on) {
+        std::vector<long long> hd((size_t)n_pairs * 8);
+        MI_HIP(hipMemcpyAsync(hd.data(), ddbg.p, hd.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+        MI_HIP(hipStreamSynchronize(ctx->stream));
+        double acc[8] = {0};
+        for (int i = 0; i < n_pairs; i++) for (int k = 0; k < 8; k++) acc[k] += (double)hd[(size_t)i * 8 + k];
+        fprintf(stderr, "[ransac dbg, avg per pair, 100 MHz ticks] loop %.0f split %.0f nlls %.0f | chunks %.1f solve %.0f solve+support %.0f replay %.0f | nlls iters %.1f\n", acc[0] / n_pairs, acc[1] / n_pairs, acc[2] / n_pairs, acc[3] / n_pairs, acc[4] / n_pairs, acc[5] / n_pairs, acc[6] / n_pairs, acc[7] / n_pairs);
+    }
     return MI355_OK;
 }
