@@ -240,7 +240,7 @@ HD bool inverse8_fast(const float* src, float* dst, float eps) {
 
 // 4-point SolveHomographyMatrix + (when 0.01 < H[8] < 5) NonlinearLeastSquareProjection2, everything in registers.
 // Returns false when an inversion needs the generic routine (caller falls back to solve_h4 / nlls4).
-HD bool hypothesis4_fast(const float* p, float* H) {
+HD bool hypothesis4_fast(const float* p, float* H, int* polished = nullptr) {
     float A[64], M[64], inv[64], B[8];
 #pragma unroll
     for (int i = 0; i < 64; i++) A[i] = 0.0f;
@@ -290,6 +290,7 @@ HD bool hypothesis4_fast(const float* p, float* H) {
     }
     H[8] = (float)emax;
     if (!(H[8] < 5.0f && H[8] > 0.01f)) return true;             // no polish (mosaicimage.h:1864-1876)
+    if (polished) *polished = 1;
     // ---- Gauss-Newton polish, LeastSquare.h:353-531 (J is A's storage) ----
     float w[8], C[8];
 #pragma unroll

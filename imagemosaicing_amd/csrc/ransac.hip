@@ -59,6 +59,7 @@ __global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     __shared__ float s_bestH[9], s_firstH[9], s_w[8], s_dX[8], s_T1[64], s_T2[64], s_t[128];
     __shared__ int   s_state[8];      // 0 t_acc, 1 maxSupport, 2 bestDraw, 3 firstAcc, 4 finished, 5 newBest, 6 newFirst, 7 done
     __shared__ int   s_wtot[RB / 64 + 1];
+    __shared__ int   s_npol;
     __shared__ int   s_fb;            // draws that needed the generic (private-memory) solve: diagnostic, reported in _pad
 
     const int pair = blockIdx.x;
@@ -69,7 +70,7 @@ __global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     const mi355_sfpoint* P2 = a.p2 + (size_t)pair * a.stride;
 
     if (tid < 9) out->H[tid] = 0.0f;
-    if (tid == 0) { s_fb = 0; out->_pad = 0; }
+    if (tid == 0) { s_fb = 0; s_npol = 0; out->_pad = 0; }
     if (n < 4 || a.sample_times < 1) {                     // mosaicimage.h:1739-1761
         if (tid == 0) { out->n_in = 0; out->ok = 0; }
         return;
@@ -105,7 +106,9 @@ __global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             for (int i = 0; i < 4; i++) { const int k = s[i]; p[4 * i] = x1[k]; p[4 * i + 1] = y1[k]; p[4 * i + 2] = x2[k]; p[4 * i + 3] = y2[k]; }
             // register-resident solve + polish; the (rare) draws whose inversion needs the reference's general pivot
             // search re-run the generic private-memory routines, wave by wave
-            const bool fast_ok = hm::hypothesis4_fast(p, h);
+            int pol = 0;
+            const bool fast_ok = hm::hypothesis4_fast(p, h, &pol);
+            if (a.dbg && pol) atomicAdd(&s_npol, 1);
             if (!fast_ok) {
                 atomicAdd(&s_fb, 1);                        // statistics only (reported in _pad)
                 hm::solve_h4(p, h, scratch);               // :1863
@@ -252,7 +255,7 @@ __global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         nit++;
         if (s_state[7]) break;
     }
-    if (a.dbg && tid == 0) { long long* d = a.dbg + 8 * pair; d[0] = T1 - T0; d[1] = T2 - T1; d[2] = wall_clock64() - T2; d[3] = nchunk; d[4] = Tsolve; d[5] = Tsup; d[6] = Trep; d[7] = nit; }
+    if (a.dbg && tid == 0) { long long* d = a.dbg + 8 * pair; d[0] = T1 - T0; d[1] = T2 - T1; d[2] = wall_clock64() - T2; d[3] = nchunk; d[4] = Tsolve; d[5] = Tsup; d[6] = Trep; d[7] = s_npol; }
     // motion[8] = max residual in float (LeastSquare.h:503-519): max is order independent
     float emax = 0.0f;
     for (int i = tid; i < cnt; i += RB) {
@@ -439,7 +442,7 @@ int mi_ransac_batch(mi355_ctx* ctx, const mi355_sfpoint* d_p1, const mi355_sfpoi
         MI_HIP(hipStreamSynchronize(ctx->stream));
         double acc[8] = {0};
         for (int i = 0; i < n_pairs; i++) for (int k = 0; k < 8; k++) acc[k] += (double)hd[(size_t)i * 8 + k];
-        fprintf(stderr, "[ransac dbg, avg per pair, 100 MHz ticks] loop %.0f split %.0f nlls %.0f | chunks %.1f solve %.0f solve+support %.0f replay %.0f | nlls iters %.1f\n", acc[0] / n_pairs, acc[1] / n_pairs, acc[2] / n_pairs, acc[3] / n_pairs, acc[4] / n_pairs, acc[5] / n_pairs, acc[6] / n_pairs, acc[7] / n_pairs);
+        fprintf(stderr, "[ransac dbg, avg per pair, 100 MHz ticks] loop %.0f split %.0f nlls %.0f | chunks %.1f solve %.0f solve+support %.0f replay %.0f | polished draws %.1f\n", acc[0] / n_pairs, acc[1] / n_pairs, acc[2] / n_pairs, acc[3] / n_pairs, acc[4] / n_pairs, acc[5] / n_pairs, acc[6] / n_pairs, acc[7] / n_pairs);
     }
     return MI355_OK;
 }
