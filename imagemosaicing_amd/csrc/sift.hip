@@ -1778,7 +1778,18 @@ int mi_sift_extract_dev(mi355_ctx* ctx, int img_id, const uint8_t* d_bgr, int w,
     }
     SiftWork* s = ctx->sift_slots[slot];
     int rc = MI355_OK;
-    const int nb = ctx->sift_batch < 1 ? 1 : (ctx->sift_batch > SIFT_BATCH_MAX ? SIFT_BATCH_MAX : ctx->sift_batch);
+    int nb = ctx->sift_batch < 1 ? 1 : (ctx->sift_batch > SIFT_BATCH_MAX ? SIFT_BATCH_MAX : ctx->sift_batch);
+    {
+        // A frame's work area is ~75 bytes per pixel of its 2x up-sampled base (pyramid 32, worst-case candidate list 32,
+        // neighbourhood records 8, the rest 3): keep slots x batch x that under 60 % of the device memory by shortening the
+        // batch for very large frames (4000x3000 frames: 3.6 GB each, 24 in flight = 86 GB of 288 GB, no reduction).
+        static size_t total_mem = [] { size_t fr = 0, tot = 0; return hipMemGetInfo(&fr, &tot) == hipSuccess ? tot : (size_t)0; }();
+        const double per_frame = 75.0 * 4.0 * (double)w * (double)h;
+        if (total_mem) {
+            const int fit = (int)(0.6 * (double)total_mem / per_frame / (double)SIFT_SLOTS);
+            if (fit < nb) nb = fit < 1 ? 1 : fit;
+        }
+    }
     if (!s->pend.empty() && (s->w != w || s->h != h || s->nb != nb)) { rc = sift_run_batch(ctx, s); if (rc != MI355_OK) return rc; }   // size change: close the batch
     rc = sift_prepare(ctx, s, w, h, nb);
     if (rc != MI355_OK) return rc;
