@@ -326,6 +326,23 @@ class Context:
         self.L.mi355_free(out)
         return buf, ow.value, oh.value, ows.value
 
+    def MosaicBlended(self, imgs, h9s, keep=None, band=5):
+        """LaplacianPyramidBlending in one call (MosaicImage.cpp:2205-2510): chips, masks and blend stay on the device."""
+        n = len(imgs)
+        imgs = [np.ascontiguousarray(i, np.uint8) for i in imgs]
+        ptrs = (C.c_void_p * n)(*[i.ctypes.data for i in imgs])
+        w = np.array([i.shape[1] for i in imgs], np.int32)
+        h = np.array([i.shape[0] for i in imgs], np.int32)
+        ws = np.array([i.strides[0] for i in imgs], np.int32)
+        h9s = np.ascontiguousarray(h9s, np.float32)
+        keep_a = None if keep is None else np.ascontiguousarray(keep, np.uint8)
+        out = C.c_void_p()
+        ow, oh, ows = C.c_int(), C.c_int(), C.c_int()
+        self._chk(self.L.mi355_mosaic_blended(self._h, ptrs, _p(w), _p(h), _p(ws), n, _p(h9s), _p(keep_a), int(band), C.byref(out), C.byref(ow), C.byref(oh), C.byref(ows)))
+        buf = _copy_out(out, ows.value * oh.value, np.uint8).reshape(oh.value, ows.value)
+        self.L.mi355_free(out)
+        return buf, ow.value, oh.value, ows.value
+
 
 # ---- host-only helpers (no ctx) ---------------------------------------------------------------------------
 def mosaic_layout(w, h, h9s):

@@ -306,6 +306,12 @@ extern "C" int mi355_multiband_blend(mi355_ctx* ctx, const uint8_t* const* chips
     return mi_multiband_blend(ctx, chips, masks, info, n, canvas_w, canvas_h, band, out, out_w, out_h, out_ws);
 }
 
+extern "C" int mi355_mosaic_blended(mi355_ctx* ctx, const uint8_t* const* imgs, const int* w, const int* h, const int* ws, int n, const float* h9s,
+                                    const uint8_t* keep, int band, uint8_t** out, int* out_w, int* out_h, int* out_ws) {
+    LOCKED_PROLOGUE
+    return mi_mosaic_blended(ctx, imgs, w, h, ws, n, h9s, keep, band, out, out_w, out_h, out_ws);
+}
+
 // ---- measurement hooks --------------------------------------------------------------------------------------------
 extern "C" int mi355_profile_enable(mi355_ctx* ctx, int on) {
     LOCKED_PROLOGUE

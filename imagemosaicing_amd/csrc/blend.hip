@@ -132,8 +132,9 @@ inline dim3 grid2(int w, int h) { return dim3((unsigned)((w + 255) / 256), (unsi
 
 }  // namespace
 
-int mi_multiband_blend(mi355_ctx* ctx, const uint8_t* const* chips, const uint8_t* const* masks, const mi355_chip_info* info, int n,
-                       int W, int H, int band, uint8_t** out, int* ow, int* oh, int* ows_out) {
+// chips / masks: host pointers (staged one chip at a time) when on_device == 0, device pointers otherwise
+static int blend_core(mi355_ctx* ctx, const uint8_t* const* chips, const uint8_t* const* masks, int on_device, const mi355_chip_info* info, int n,
+                      int W, int H, int band, uint8_t** out, int* ow, int* oh, int* ows_out) {
     if (n < 0 || (n > 0 && (!chips || !masks || !info)) || W <= 0 || H <= 0 || band < 0 || !out) { ctx->set_error("multiband_blend: bad arguments"); return MI355_ERR_ARG; }
     const hipStream_t st = ctx->stream;
     int nb = (int)std::ceil(std::log((double)(W > H ? W : H)) / std::log(2.0));
@@ -171,15 +172,20 @@ int mi_multiband_blend(mi355_ctx* ctx, const uint8_t* const* chips, const uint8_
         const int cws = (cw * 3 + 3) & ~3, mws = (cw + 3) & ~3;
         std::vector<size_t> roff(nb + 2, 0);
         for (int l = 0; l <= nb; l++) roff[l + 1] = roff[l] + (size_t)(rw >> l) * (rh >> l);
-        MI_HIP(dchip.reserve((size_t)cws * chh));
-        MI_HIP(dmask.reserve((size_t)mws * chh));
         MI_HIP(glap.reserve(roff[nb + 1] * 3 * sizeof(short)));
         MI_HIP(gwgt.reserve(roff[nb + 1] * sizeof(float)));
-        MI_HIP(hipMemcpyAsync(dchip.p, chips[k], (size_t)cws * chh, hipMemcpyHostToDevice, st));
-        MI_HIP(hipMemcpyAsync(dmask.p, masks[k], (size_t)mws * chh, hipMemcpyHostToDevice, st));
+        const uint8_t* d_chip = chips[k];
+        const uint8_t* d_mask = masks[k];
+        if (!on_device) {
+            MI_HIP(dchip.reserve((size_t)cws * chh));
+            MI_HIP(dmask.reserve((size_t)mws * chh));
+            MI_HIP(hipMemcpyAsync(dchip.p, chips[k], (size_t)cws * chh, hipMemcpyHostToDevice, st));
+            MI_HIP(hipMemcpyAsync(dmask.p, masks[k], (size_t)mws * chh, hipMemcpyHostToDevice, st));
+            d_chip = dchip.as<uint8_t>(); d_mask = dmask.as<uint8_t>();
+        }
         short* g = glap.as<short>();
         float* wp = gwgt.as<float>();
-        hipLaunchKernelGGL(blend_prep_kernel, grid2(rw, rh), dim3(256), 0, st, dchip.as<uint8_t>(), cws, dmask.as<uint8_t>(), mws, cw, chh, left, top, rw, rh, g, wp);
+        hipLaunchKernelGGL(blend_prep_kernel, grid2(rw, rh), dim3(256), 0, st, d_chip, cws, d_mask, mws, cw, chh, left, top, rw, rh, g, wp);
         for (int l = 0; l < nb; l++) {
             hipLaunchKernelGGL(pyr_down16_kernel, grid2(rw >> (l + 1), rh >> (l + 1)), dim3(256), 0, st, g + roff[l] * 3, rw >> l, rh >> l, g + roff[l + 1] * 3);
             hipLaunchKernelGGL(pyr_down_f_kernel, grid2(rw >> (l + 1), rh >> (l + 1)), dim3(256), 0, st, wp + roff[l], rw >> l, rh >> l, wp + roff[l + 1]);
@@ -214,4 +220,25 @@ int mi_multiband_blend(mi355_ctx* ctx, const uint8_t* const* chips, const uint8_
     if (oh) *oh = H;
     if (ows_out) *ows_out = ows;
     return MI355_OK;
+}
+
+int mi_multiband_blend(mi355_ctx* ctx, const uint8_t* const* chips, const uint8_t* const* masks, const mi355_chip_info* info, int n,
+                       int W, int H, int band, uint8_t** out, int* ow, int* oh, int* ows_out) {
+    return blend_core(ctx, chips, masks, 0, info, n, W, H, band, out, ow, oh, ows_out);
+}
+
+// The whole of LaplacianPyramidBlending (MosaicImage.cpp:2205-2510) without leaving the device between its stages: chips
+// and masks (mi_chips_and_masks_dev) feed the blender straight from HBM; only the finished canvas goes back to the host.
+int mi_mosaic_blended(mi355_ctx* ctx, const uint8_t* const* imgs, const int* w, const int* h, const int* ws, int n, const float* h9s,
+                      const uint8_t* keep, int band, uint8_t** out, int* ow, int* oh, int* ows_out) {
+    std::vector<size_t> chip_off, mask_off;
+    int nv = 0, cw = 0, ch = 0;
+    mi355_chip_info* ci = nullptr;
+    int rc = mi_chips_and_masks_dev(ctx, imgs, w, h, ws, n, h9s, keep, 1, &nv, &ci, chip_off, mask_off, &cw, &ch);
+    if (rc != MI355_OK) { free(ci); return rc; }
+    std::vector<const uint8_t*> dc(nv > 0 ? nv : 1), dm(nv > 0 ? nv : 1);
+    for (int v = 0; v < nv; v++) { dc[v] = ctx->buf("chip_imgs").as<uint8_t>() + chip_off[v]; dm[v] = ctx->buf("chip_masks").as<uint8_t>() + mask_off[v]; }
+    rc = blend_core(ctx, dc.data(), dm.data(), 1, ci, nv, cw, ch, band, out, ow, oh, ows_out);
+    free(ci);
+    return rc;
 }

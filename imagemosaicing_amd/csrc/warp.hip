@@ -319,10 +319,12 @@ __global__ __launch_bounds__(256) void owner_kernel(const ChipDev* chips, int n,
 
 }  // namespace
 
-int mi_chips_and_masks(mi355_ctx* ctx, const uint8_t* const* imgs, const int* w, const int* h, const int* ws, int n,
-                       const float* h9s, const uint8_t* keep, int find_masks, int* n_chips, mi355_chip_info** chips_out,
-                       uint8_t*** chip_imgs, uint8_t*** masks_out, int* cw_out, int* ch_out) {
-    if (!imgs || !w || !h || !ws || !h9s || n <= 0 || !n_chips || !chips_out || !chip_imgs || !masks_out) return MI355_ERR_ARG;
+// Device stage of the chips: layout on the host, warps / distance maps / ownership on the device.  The chips and masks
+// stay in ctx buffers "chip_imgs" / "chip_masks" at chip_off[v] / mask_off[v]; *chips_out is malloc'd.
+int mi_chips_and_masks_dev(mi355_ctx* ctx, const uint8_t* const* imgs, const int* w, const int* h, const int* ws, int n,
+                           const float* h9s, const uint8_t* keep, int find_masks, int* n_chips, mi355_chip_info** chips_out,
+                           std::vector<size_t>& chip_off, std::vector<size_t>& mask_off, int* cw_out, int* ch_out) {
+    if (!imgs || !w || !h || !ws || !h9s || n <= 0 || !n_chips || !chips_out) return MI355_ERR_ARG;
     // ---- layout, MosaicImage.cpp:2233-2343 (host, same float ops) ----
     float maxX = 0.0f, maxY = 0.0f, minX = 0.0f, minY = 0.0f;                     // :2234 (canvas always contains the origin)
     std::vector<float> bx0(n), by0(n), bx1(n), by1(n);
@@ -343,12 +345,10 @@ int mi_chips_and_masks(mi355_ctx* ctx, const uint8_t* const* imgs, const int* w,
     const int newW = (int)(maxX - minX + 1.5f), newH = (int)(maxY - minY + 1.5f);
     const int nv = (int)kept.size();
     mi355_chip_info* ci = (mi355_chip_info*)calloc((size_t)(nv > 0 ? nv : 1), sizeof(mi355_chip_info));
-    uint8_t** cimg = (uint8_t**)calloc((size_t)(nv > 0 ? nv : 1), sizeof(uint8_t*));
-    uint8_t** cmask = (uint8_t**)calloc((size_t)(nv > 0 ? nv : 1), sizeof(uint8_t*));
-    if (!ci || !cimg || !cmask) return MI355_ERR_NOMEM;
+    if (!ci) return MI355_ERR_NOMEM;
     std::vector<ChipDev> cd(nv);
     size_t map_total = 0, chip_total = 0, mask_total = 0;
-    std::vector<size_t> chip_off(nv), mask_off(nv);
+    chip_off.assign(nv, 0); mask_off.assign(nv, 0);
     for (int v = 0; v < nv; v++) {
         const int k = kept[v];
         const float* m = h9s + 9 * k;
@@ -433,8 +433,29 @@ int mi_chips_and_masks(mi355_ctx* ctx, const uint8_t* const* imgs, const int* w,
             hipLaunchKernelGGL(owner_kernel, grid, block, 0, ctx->stream, d_cd, nv, dmaps.as<float>(), newW, newH, d_mptr);
         }
     }
+    MI_HIP(hipGetLastError());
+    *n_chips = nv; *chips_out = ci;
+    if (cw_out) *cw_out = newW;
+    if (ch_out) *ch_out = newH;
+    return MI355_OK;
+}
+
+int mi_chips_and_masks(mi355_ctx* ctx, const uint8_t* const* imgs, const int* w, const int* h, const int* ws, int n,
+                       const float* h9s, const uint8_t* keep, int find_masks, int* n_chips, mi355_chip_info** chips_out,
+                       uint8_t*** chip_imgs, uint8_t*** masks_out, int* cw_out, int* ch_out) {
+    if (!chip_imgs || !masks_out) return MI355_ERR_ARG;
+    std::vector<size_t> chip_off, mask_off;
+    int nv = 0;
+    mi355_chip_info* ci = nullptr;
+    int rc = mi_chips_and_masks_dev(ctx, imgs, w, h, ws, n, h9s, keep, find_masks, &nv, &ci, chip_off, mask_off, cw_out, ch_out);
+    if (rc != MI355_OK) { free(ci); return rc; }
+    uint8_t** cimg = (uint8_t**)calloc((size_t)(nv > 0 ? nv : 1), sizeof(uint8_t*));
+    uint8_t** cmask = (uint8_t**)calloc((size_t)(nv > 0 ? nv : 1), sizeof(uint8_t*));
+    if (!cimg || !cmask) return MI355_ERR_NOMEM;
+    DevBuf& dchips = ctx->buf("chip_imgs");
+    DevBuf& dmasks = ctx->buf("chip_masks");
     for (int v = 0; v < nv; v++) {
-        const size_t cb = (size_t)((ci[v].w * 3 + 3) & ~3) * ci[v].h, mb = (size_t)cd[v].mws * ci[v].h;
+        const size_t cb = (size_t)((ci[v].w * 3 + 3) & ~3) * ci[v].h, mb = (size_t)((ci[v].w + 3) & ~3) * ci[v].h;
         cimg[v] = (uint8_t*)malloc(cb);
         cmask[v] = (uint8_t*)malloc(mb);
         if (!cimg[v] || !cmask[v]) return MI355_ERR_NOMEM;
@@ -443,7 +464,5 @@ int mi_chips_and_masks(mi355_ctx* ctx, const uint8_t* const* imgs, const int* w,
     }
     MI_HIP(hipStreamSynchronize(ctx->stream));
     *n_chips = nv; *chips_out = ci; *chip_imgs = cimg; *masks_out = cmask;
-    if (cw_out) *cw_out = newW;
-    if (ch_out) *ch_out = newH;
     return MI355_OK;
 }

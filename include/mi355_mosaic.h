@@ -181,6 +181,12 @@ int  mi355_chips_and_masks(mi355_ctx* ctx, const uint8_t* const* imgs, const int
 int  mi355_multiband_blend(mi355_ctx* ctx, const uint8_t* const* chips, const uint8_t* const* masks, const mi355_chip_info* info, int n,
                            int canvas_w, int canvas_h, int band, uint8_t** out, int* out_w, int* out_h, int* out_ws);
 
+/* Both stages in one call, chips and masks never leaving HBM: the whole of LaplacianPyramidBlending(pImages, n, pImgT, band, ...)
+ * (MosaicImage.cpp:2205-2510) except that the inputs are NOT released (the adaptor does that, :2464-2467).  Same bytes as
+ * mi355_chips_and_masks(find_masks = 1) followed by mi355_multiband_blend. */
+int  mi355_mosaic_blended(mi355_ctx* ctx, const uint8_t* const* imgs, const int* w, const int* h, const int* ws, int n, const float* h9s,
+                          const uint8_t* keep, int band, uint8_t** out, int* out_w, int* out_h, int* out_ws);
+
 /* ---- callers / formats either side of the path ("next" rows f1, f2 of SURVEY 8f) ---------------------- */
 /* matchPairs.match: int32 n + n x 40-byte records (WriteMatchPairs / LoadMatchPairs, MosaicWithoutPos.cpp:4736-4797) */
 int  mi355_write_match_pairs(const char* path, const mi355_match_point_pairs* v, int n);

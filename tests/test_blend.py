@@ -80,4 +80,13 @@ def test_gpu_blend_vs_oracle(oracle):
     ref, _ = oracle.multiband_blend(r2["chips"], r2["chip_imgs"], r2["masks"], r2["cw"], r2["ch"], band=5)
     got, _, _, _ = ctx.MultiBandBlend(r2["chips"], r2["chip_imgs"], r2["masks"], r2["cw"], r2["ch"], band=5)
     assert np.array_equal(got, ref)
+    # one-call form: chips and masks stay in HBM between the stages, same bytes
+    ref, _ = oracle.multiband_blend(r["chips"], r["chip_imgs"], r["masks"], r["cw"], r["ch"], band=5)
+    got, ow, oh, _ = ctx.MosaicBlended(imgs, h9s, band=5)
+    assert (ow, oh) == (r["cw"], r["ch"]) and np.array_equal(got, ref)
+    keep = np.array([1, 0, 1, 1], np.uint8)
+    rk = ctx.ChipsAndMasks(imgs, h9s, keep=keep, find_masks=True)
+    refk, _ = oracle.multiband_blend(rk["chips"], rk["chip_imgs"], rk["masks"], rk["cw"], rk["ch"], band=5)
+    gotk, _, _, _ = ctx.MosaicBlended(imgs, h9s, keep=keep, band=5)
+    assert np.array_equal(gotk, refk)
     ctx.close()
