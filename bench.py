@@ -184,7 +184,7 @@ def main():
         ctx.MatchPairsDev(pairs, results.data_ptr(), 2.5, seed)
         if world > 1:
             # RCCL over xGMI: H + inlier lists of every pair of the survey, the only exchange of the path
-            state["gathered"], state["counts"] = md.allgather_pair_results(results[:max(n_pairs, 1)])
+            state["gathered"], state["counts"] = md.allgather_pair_results(results[:max(n_pairs, 1)], accepted_only=True)
         res_host.copy_(results, non_blocking=True)
         stream.synchronize()
         if phases:

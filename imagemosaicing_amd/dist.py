@@ -16,16 +16,27 @@ from .capi import PAIR_RESULT
 REC = PAIR_RESULT.itemsize
 
 
-def allgather_pair_results(local, n_local_max=None):
+def compact_accepted(local):
+    """keeps the records of accepted pairs only (what the reference pushes to the driver, MosaicWithoutPos.cpp:5201-5227): with
+    the 182-frame pair window most scheduled pairs do not overlap, and the exchange shrinks by that factor (C4: 715 MB ->
+    a few tens of MB per rank)"""
+    off = PAIR_RESULT.fields["accepted"][1]
+    acc = local[:, off:off + 4].contiguous().view(torch.int32).reshape(-1) != 0
+    return local[acc]
+
+
+def allgather_pair_results(local, n_local_max=None, accepted_only=False):
     """local: uint8 tensor [n_local, 9664] (device for nccl, cpu for gloo).  Returns uint8 [world, n_max, 9664] and the
     per-rank counts; ranks may hold different numbers of pairs (counts are gathered first, payload padded)."""
+    if accepted_only:
+        local = compact_accepted(local)
     world = dist.get_world_size() if dist.is_initialized() else 1
     if world == 1:
         return local.unsqueeze(0), [local.shape[0]]
     if dist.get_backend() == "gloo" and local.is_cuda:
         # gloo has no device all_gather: stage through the host (CPU tests and single-GPU dry runs of bench.py only;
         # production uses backend "nccl" = RCCL, device to device over xGMI)
-        g, counts = allgather_pair_results(local.cpu(), n_local_max)
+        g, counts = allgather_pair_results(local.cpu(), n_local_max, False)
         return g.to(local.device), counts
     n = torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device)
     counts = [torch.zeros_like(n) for _ in range(world)]

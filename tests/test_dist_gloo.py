@@ -43,8 +43,15 @@ WORKER = textwrap.dedent("""
     T = im.global_affine_align(mp, N)
     tx = T["m"][:, 2]
     assert np.abs(tx - 10.0 * np.arange(N)).max() < 1e-2, tx[:5]
+    # accepted-only exchange: rejected pairs never leave their rank
+    rec2 = rec.copy()
+    rec2["accepted"][::3] = 0
+    local2 = torch.from_numpy(rec2.view(np.uint8).reshape(len(pairs), -1).copy())
+    g2, c2 = md.allgather_pair_results(local2, accepted_only=True)
+    all2 = md.gathered_to_records(g2, c2)
+    assert (all2["accepted"] == 1).all() and c2[rank] == int(rec2["accepted"].sum()) and len(all2) == sum(c2) < len(want)
     if rank == 0:
-        print("GLOO_OK", counts)
+        print("GLOO_OK", counts, c2)
     dist.destroy_process_group()
 """)
 
