@@ -1141,16 +1141,22 @@ struct KpRec {
 // (points without any histogram peak), top-k raises a flag and pass 1 orients the rest -- same final result as
 // orienting everything, ~40x less work in the common case.
 __global__ __launch_bounds__(1024) void resp_threshold_kernel(const unsigned* resp /* |response| bits of the refined points */, const unsigned* ref_count, unsigned ref_cap,
-                                                              unsigned want, unsigned* ctrl /* [0]=T bits [1]=fallback flag */, size_t resp_stride) {
+                                                              unsigned want, unsigned* ctrl /* [0]=T bits [1]=fallback flag [2]=points >= T */, size_t resp_stride,
+                                                              unsigned* list /* indices of the points >= T, what orientation pass 0 walks */) {
     // one workgroup per frame: two-pass radix select over the 16-bit key (8 exponent + 8 mantissa bits) of the responses;
     // T = lower edge of the first key (from the top) at which the count of points with key >= it reaches `want`
     resp += (size_t)blockIdx.x * resp_stride; ref_count += (size_t)blockIdx.x * CNT_STRIDE; ctrl += (size_t)blockIdx.x * CNT_STRIDE;
+    list += (size_t)blockIdx.x * resp_stride;
     __shared__ unsigned s_h[16][256];               // a private histogram per wave: LDS conflicts stay inside one wave
     __shared__ unsigned s_sel[2];
     const int tid = threadIdx.x, wv = tid >> 6;
     unsigned n = *ref_count;
     if (n > ref_cap) n = ref_cap;
-    if (n <= want) { if (tid == 0) { ctrl[0] = 0; ctrl[1] = 0; } return; }
+    if (n <= want) {                                  // everything is oriented
+        if (tid == 0) { ctrl[0] = 0; ctrl[1] = 0; ctrl[2] = n; }
+        for (unsigned i = tid; i < n; i += 1024) list[i] = i;
+        return;
+    }
     unsigned above = 0, hi_sel = 0;
     for (int pass = 0; pass < 2; pass++) {
         for (int i = tid; i < 16 * 256; i += 1024) (&s_h[0][0])[i] = 0;
@@ -1171,17 +1177,35 @@ __global__ __launch_bounds__(1024) void resp_threshold_kernel(const unsigned* re
         }
         __syncthreads();
         if (pass == 0) { hi_sel = s_sel[0]; above = s_sel[1]; }
-        else if (tid == 0) { ctrl[0] = ((hi_sel << 8) | s_sel[0]) << 15; ctrl[1] = 0; }
+        else if (tid == 0) { ctrl[0] = ((hi_sel << 8) | s_sel[0]) << 15; ctrl[1] = 0; ctrl[2] = 0; }
         __syncthreads();
+    }
+    // the points at or above the threshold, compacted (order free: the total order is established by top-k), so that the
+    // orientation pass hands exactly one point to each wave instead of letting 4096 waves look for ~2300 among ~94 000
+    __threadfence_block();
+    const unsigned T = ((hi_sel << 8) | s_sel[0]) << 15;
+    const int lane = tid & 63;
+    for (unsigned i0 = 0; i0 < n; i0 += 1024) {
+        const unsigned i = i0 + tid;
+        const bool take = i < n && resp[i] >= T;
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(take);
+        if (m) {
+            const int first = __builtin_ctzll(m);
+            unsigned base = 0;
+            if (lane == first) base = atomicAdd(&ctrl[2], (unsigned)__builtin_popcountll(m));
+            base = __shfl(base, first);
+            if (take) list[base + (unsigned)__builtin_popcountll(m & ((1ull << lane) - 1ull))] = i;
+        }
     }
 }
 
 constexpr int OCAP = 256;                     // emitted keypoints buffered per workgroup between flushes
 __global__ __launch_bounds__(256) void orient_kernel(PyrDev P, const Refined* ref, const unsigned* ref_count, unsigned ref_cap,
                                                      KpRec* out, unsigned* out_resp, unsigned* out_count, unsigned out_cap,
-                                                     const unsigned* ctrl, int pass, BatchStride bs) {
+                                                     const unsigned* ctrl, int pass, BatchStride bs, const unsigned* list) {
     const size_t fr = blockIdx.y, foff = fr * bs.pyr;             // frame of the batch
     ref += fr * bs.refined; ref_count += fr * CNT_STRIDE; out += fr * bs.kps; out_resp += fr * bs.kps; out_count += fr * CNT_STRIDE; ctrl += fr * CNT_STRIDE;
+    list += fr * bs.refined;
     __shared__ unsigned long long s_hq[4][ORI_BINS];
     const unsigned Tbits = ctrl[0];
     if (pass == 1 && (ctrl[1] == 0 || Tbits == 0)) return;      // fallback pass not needed
@@ -1191,14 +1215,15 @@ __global__ __launch_bounds__(256) void orient_kernel(PyrDev P, const Refined* re
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     unsigned n = *ref_count;
     if (n > ref_cap) n = ref_cap;
+    if (pass == 0) n = ctrl[2] < n ? ctrl[2] : n;               // pass 0 walks the compacted list of points >= T
     if (tid == 0) s_on = 0;
     __syncthreads();
     for (unsigned base = blockIdx.x * 4; base < n; base += gridDim.x * 4) {        // uniform trip count per workgroup
-        const unsigned k = base + wv;
+        unsigned k = base + wv;
         bool take = false;
         if (k < n) {
-            const unsigned rb = __float_as_uint(fabsf(ref[k].contr));
-            take = pass == 0 ? (rb >= Tbits) : (rb < Tbits);
+            if (pass == 0) { k = list[k]; take = true; }
+            else take = __float_as_uint(fabsf(ref[k].contr)) < Tbits;
         }
         if (take) {
             const Refined rr = ref[k];
@@ -1612,6 +1637,7 @@ struct SiftWork {
     DevBuf pyr;                              // all Gaussian levels
     DevBuf claimed;                          // duplicate claim bitmaps
     DevBuf cand, refined, kps, kresp, sel, counters, rhist, ccnt;
+    DevBuf olist;                            // per frame: indices of the refined points at or above the response threshold
     DevBuf cube; unsigned cube_cap = 0;       // 3x3x3 DoG neighbourhoods of the first cube_cap candidates of every region (128 B each)
     DevBuf gray; int gray_pitch = 0; size_t gray_stride = 0;   // padded u8 gray of the frame (source of the streamed base level)
     PyrDev P;                                // pointers of frame 0
@@ -1632,7 +1658,7 @@ void mi_sift_release(mi355_ctx* ctx) {
         if (!s) continue;
         if (s->stream) { (void)hipStreamSynchronize(s->stream); (void)hipStreamDestroy(s->stream); }
         if (s->done) (void)hipEventDestroy(s->done);
-        s->pyr.release(); s->claimed.release(); s->cand.release(); s->refined.release(); s->kps.release(); s->kresp.release(); s->sel.release(); s->counters.release(); s->rhist.release(); s->ccnt.release(); s->gray.release(); s->cube.release();
+        s->pyr.release(); s->claimed.release(); s->cand.release(); s->refined.release(); s->kps.release(); s->kresp.release(); s->sel.release(); s->counters.release(); s->rhist.release(); s->ccnt.release(); s->gray.release(); s->cube.release(); s->olist.release();
         delete s;
     }
     ctx->sift_slots.clear();
@@ -1740,7 +1766,8 @@ static int sift_prepare(mi355_ctx* ctx, SiftWork* s, int w, int h, int nb) {
     MI_HIP(s->kresp.reserve(B * s->bs.kps * sizeof(unsigned)));
     MI_HIP(s->sel.reserve(B * SEL_STRIDE * sizeof(SelRec)));
     MI_HIP(s->counters.reserve(B * CNT_STRIDE * sizeof(unsigned)));
-    MI_HIP(s->rhist.reserve(B * s->bs.refined * sizeof(unsigned)));      // |response| bits of the refined points (SoA next to `refined`)
+    MI_HIP(s->rhist.reserve(B * s->bs.refined * sizeof(unsigned)));
+    MI_HIP(s->olist.reserve(B * s->bs.refined * sizeof(unsigned)));      // |response| bits of the refined points (SoA next to `refined`)
     MI_HIP(s->ccnt.reserve(B * CCNT_STRIDE * sizeof(unsigned)));
     MI_HIP(s->cube.reserve(B * s->bs.cube * sizeof(float)));
     MI_HIP(s->gray.reserve(B * s->gray_stride));
@@ -1910,13 +1937,13 @@ static int sift_run_batch(mi355_ctx* ctx, SiftWork* s) {
         ProfScope ps(ctx, "refine", 0.0, st);
         hipLaunchKernelGGL(refine_kernel, dim3(32, NREG, n), dim3(256), 0, st, s->P, s->cand.as<unsigned long long>(), s->ccnt.as<unsigned>(), s->cand_cap, cnt + 0,
                            ctx->p.contrast_threshold, ctx->p.edge_threshold, 1.6f, s->refined.as<Refined>(), cnt + 1, s->ref_cap, s->rhist.as<unsigned>(), bs, s->cube.as<float>(), s->cube_cap);
-        hipLaunchKernelGGL(resp_threshold_kernel, dim3(n), dim3(1024), 0, st, s->rhist.as<unsigned>(), cnt + 1, s->ref_cap, (unsigned)nf + 256u, cnt + 8, bs.refined);
+        hipLaunchKernelGGL(resp_threshold_kernel, dim3(n), dim3(1024), 0, st, s->rhist.as<unsigned>(), cnt + 1, s->ref_cap, (unsigned)nf + 256u, cnt + 8, bs.refined, s->olist.as<unsigned>());
     }
     for (int pass = 0; pass < 2; pass++) {       // pass 1 (everything below the response threshold) exits at once unless top-k asked for it
         {
             ProfScope ps(ctx, "orient", 0.0, st);
             hipLaunchKernelGGL(orient_kernel, dim3(ctx->num_cu * 4, n), dim3(256), 0, st, s->P, s->refined.as<Refined>(), cnt + 1, s->ref_cap,
-                               s->kps.as<KpRec>(), s->kresp.as<unsigned>(), cnt + 2, s->kp_cap, cnt + 8, pass, bs);
+                               s->kps.as<KpRec>(), s->kresp.as<unsigned>(), cnt + 2, s->kp_cap, cnt + 8, pass, bs, s->olist.as<unsigned>());
         }
         {
             ProfScope ps(ctx, "topk", 0.0, st);
