@@ -1516,14 +1516,25 @@ __global__ __launch_bounds__(256) void describe_kernel(PyrDev P, const SelRec* s
         s_dst[tid] = v;
     }
     __syncthreads();
-    if (tid == 0) {                                          // sequential norms: the accumulation order is part of the definition
-        float nrm2 = 0.0f;
-        for (int q = 0; q < 128; q++) { const float sq = s_dst[q] * s_dst[q]; nrm2 = nrm2 + sq; }
-        const float thr = sqrtf(nrm2) * 0.2f;
-        nrm2 = 0.0f;
-        for (int q = 0; q < 128; q++) { const float v = s_dst[q] < thr ? s_dst[q] : thr; s_dst[q] = v; const float sq = v * v; nrm2 = nrm2 + sq; }
-        const float nn = sqrtf(nrm2);
-        s_fac = 512.0f / (nn > 1.1920929e-7f ? nn : 1.1920929e-7f);
+    if (tid < 64) {
+        // sequential norms: the accumulation order is part of the definition.  The squares are formed by the 64 lanes, the
+        // running sum visits them in index order through lane broadcasts (a lone thread walking LDS was ~40 % of the
+        // workgroup's life)
+        float a = s_dst[tid], b = s_dst[tid + 64];
+        auto seq_sum = [&](float va, float vb) {
+            const float sa = va * va, sb = vb * vb;
+            float acc = 0.0f;
+#pragma unroll
+            for (int q = 0; q < 64; q++) acc = acc + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sa), q));
+#pragma unroll
+            for (int q = 0; q < 64; q++) acc = acc + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sb), q));
+            return acc;
+        };
+        const float thr = sqrtf(seq_sum(a, b)) * 0.2f;
+        a = a < thr ? a : thr; b = b < thr ? b : thr;
+        s_dst[tid] = a; s_dst[tid + 64] = b;
+        const float nn = sqrtf(seq_sum(a, b));
+        if (tid == 0) s_fac = 512.0f / (nn > 1.1920929e-7f ? nn : 1.1920929e-7f);
     }
     __syncthreads();
     if (tid < 128) {
