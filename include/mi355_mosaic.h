@@ -97,7 +97,7 @@ int  mi355_synchronize(mi355_ctx* ctx);
  * that may be in flight at once, each on its own stream (1..4, default 3; a work area holds sift_batch pyramids and
  * candidate lists, 3.2 GB per frame at 4000x3000); "blur_stream" = 1 (default) runs pyramid levels of >= 2048x1536
  * through the barrier-free streaming Gaussian, 0 forces the tiled kernels everywhere (same bits either way);
- * "xstream_min_w" (4096) / "xstream_min_frames" (4): octaves at least that wide, in batches of at least that many frames,
+ * "xstream_min_w" (3000) / "xstream_min_frames" (4): octaves at least that wide, in batches of at least that many frames,
  * take the streamed extrema kernel instead of the tiled one (same candidates either way). */
 int  mi355_set_option(mi355_ctx* ctx, const char* name, int value);
 void mi355_free(void* p);                               /* frees host buffers returned by this library */
