@@ -53,14 +53,15 @@ __global__ __launch_bounds__(256) void warp_kernel(WarpArgs a) {
     const float w1 = (float)(a.w - 1), h1 = (float)(a.h - 1);
     uint8_t out[4 * CH];
     bool valid[4];
-    int nvalid = 0, ninside = 0;
+    int nvalid = 0;
+    // affine transform with m8 = 1: the denominator m6 x + m7 y + m8 is exactly 1.0f for every finite (x, y), and t / 1.0f = t,
+    // so the two divisions can be skipped without changing a bit (uniform test on the kernel arguments)
+    const bool unit_den = a.inv[6] == 0.0f && a.inv[7] == 0.0f && a.inv[8] == 1.0f;
+    // no per-pixel branches: a pixel without a sample still computes from a clamped address and is masked at the store
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const int xD = xg + k;
-        valid[k] = false;
         const bool inside = (xD >= a.x_beg) && (xD <= a.x_end);
-        if (!inside) continue;
-        ninside++;
         float xf, yf;
         if (CHIP) {
             xf = (((float)xD - a.dx) - a.sx) + (float)a.x0;
@@ -70,10 +71,12 @@ __global__ __launch_bounds__(256) void warp_kernel(WarpArgs a) {
             yf = (float)yD - a.dy;
         }
         float xs, ys;
-        hm::apply_div9(a.inv, xf, yf, xs, ys);
-        if (!(xs >= 0.0f && xs < w1 && ys >= 0.0f && ys < h1)) continue;      // also rejects NaN
-        const int xi = (int)xs, yi = (int)ys;
-        const float p = ys - (float)yi, q = xs - (float)xi;
+        if (unit_den) { xs = a.inv[0] * xf + a.inv[1] * yf + a.inv[2]; ys = a.inv[3] * xf + a.inv[4] * yf + a.inv[5]; }
+        else hm::apply_div9(a.inv, xf, yf, xs, ys);
+        const bool ok = inside && (xs >= 0.0f && xs < w1 && ys >= 0.0f && ys < h1);      // also rejects NaN
+        const float xc = ok ? xs : 0.0f, yc = ok ? ys : 0.0f;
+        const int xi = (int)xc, yi = (int)yc;
+        const float p = yc - (float)yi, q = xc - (float)xi;
         const uint8_t* s = a.src + (size_t)yi * a.ws + (size_t)CH * xi;
         if (CH == 3) {
             float b00, g00, r00, b01, g01, r01, b10, g10, r10, b11, g11, r11;
@@ -88,8 +91,8 @@ __global__ __launch_bounds__(256) void warp_kernel(WarpArgs a) {
             __builtin_memcpy(&t1, s + a.ws, 2);
             out[k] = hm::bilin((float)(t0 & 0xff), (float)(t0 >> 8), (float)(t1 & 0xff), (float)(t1 >> 8), p, q);
         }
-        valid[k] = true;
-        nvalid++;
+        valid[k] = ok;
+        nvalid += ok ? 1 : 0;
     }
     uint8_t* drow = a.dst + (size_t)yD * a.dws + (size_t)CH * xg;
     if (nvalid == 4) {
@@ -116,7 +119,6 @@ __global__ __launch_bounds__(256) void warp_kernel(WarpArgs a) {
             if (!valid[k]) for (int c = 0; c < CH; c++) drow[CH * k + c] = 0;
         }
     }
-    (void)ninside;
 }
 
 template <int CH, bool CHIP>
