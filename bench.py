@@ -33,7 +33,6 @@ sys.path.insert(0, ROOT)
 DOM = "gauss_stream"       # profile class of the dominant kernel (blur_stream): the only launches bracketed with events in the timed region
 SLOTS = int(os.environ.get("MI355_BENCH_SLOTS", "3"))   # batch work areas in flight (library default 3)
 BATCH = int(os.environ.get("MI355_BENCH_BATCH", "8"))   # frames per batch (library default 8)
-#                  # frames in flight during the timed region (library default)
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md (6.29 TB/s measured copy)
 
 
@@ -237,9 +236,9 @@ def main():
             ms, n, b = ctx.profile_get(cls)
             prof_all[cls] = {"ms_per_step": ms / max(args.steps, 1), "launches_per_step": n / max(args.steps, 1)}
     ctx.profile_enable(False)
-    # The timed region keeps several frames in flight, so the gauss launches above overlap other kernels and their
-    # event durations include the contention.  One extra UNTIMED pass over a few frames with a single frame in
-    # flight gives the same kernel's stand-alone figures (reported separately, never as `achieved`).
+    # The timed region keeps three batches in flight, so the blur_stream launches above overlap other batches' kernels and
+    # their event durations include the contention.  One extra UNTIMED pass over three batches with a single batch in
+    # flight gives the same launches' stand-alone figures (reported separately, never as `achieved`).
     iso = None
     if (world == 1 or rank == 0) and not os.environ.get("MI355_BENCH_NO_STANDALONE"):
         ctx.synchronize()

@@ -1597,7 +1597,7 @@ bool launch_blur(hipStream_t st, int R, const BlurArgs& a, int stream_mode = 1) 
     const bool big = !BGR && a.w >= 1024 && a.h >= 768;
     const bool use2 = big;
     if (blur_streams(a, BGR, R, stream_mode)) {
-        // barrier-free streaming kernel: ~2 waves per SIMD over the whole chip (2048 waves), segments of >= 32 rows
+        // barrier-free streaming kernel: ~2 waves per SIMD over the whole chip (2048 waves), segments of >= 64 rows, all frames of a batch in one launch
         int L, nstrip, nseg;
         stream_grid(a.w, a.h, L, nstrip, nseg, a.nb > 1 ? a.nb : 1);
         const int units = nstrip * nseg * (a.nb > 1 ? a.nb : 1);
