@@ -913,7 +913,7 @@ __device__ __forceinline__ unsigned xtest_row(const XDog& A, const XDog& B, cons
 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void extrema_stream(OctaveDev oc, int octave, unsigned long long* cand, unsigned* count, unsigned cap, unsigned* overflow, BatchStride bs,
-                    float* cube, unsigned cube_cap, int L, int nstrip, int nseg, int nb) {
+                    float* cube, unsigned cube_cap, int L, int nstrip, int nseg, int nb, int xsw /* columns per strip: multiple of 4, <= XSW */) {
     __shared__ float s_ent[4][XCAP][32];           // per wave: parked candidates, 27 floats of DoG neighbourhood + the record in [30..31]
     __shared__ unsigned s_cnt[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -928,12 +928,12 @@ void extrema_stream(OctaveDev oc, int octave, unsigned long long* cand, unsigned
         cand += f * bs.cand; count += f * CCNT_STRIDE; overflow += f * CNT_STRIDE; cube += f * bs.cube;
     }
     const int seg = unit / nstrip, strip = unit - seg * nstrip;
-    const int xs = strip * XSW, y0 = seg * L;       // the strip's own columns are [xs, xs + XSW)
+    const int xs = strip * xsw, y0 = seg * L;       // the strip's own columns are [xs, xs + xsw)
     const int lact = (oc.h - y0 < L) ? oc.h - y0 : L;
     const unsigned reg = (unsigned)unit & (NREG - 1);
     const int xm = xs - 4 + 4 * lane;               // lane 0: the four columns left of the strip, lane 63: the four right of it
     const int xl = xm < 0 ? 0 : (xm < oc.w - 4 ? xm : oc.w - 4);
-    int clo = xs > IMG_BORDER ? xs : IMG_BORDER, chi = xs + XSW < oc.w - IMG_BORDER ? xs + XSW : oc.w - IMG_BORDER;
+    int clo = xs > IMG_BORDER ? xs : IMG_BORDER, chi = xs + xsw < oc.w - IMG_BORDER ? xs + xsw : oc.w - IMG_BORDER;
     if (lane == 0 || lane == 63) { clo = 0; chi = 0; }
     const int hm1 = oc.h - 1;
     if (lane == 0) s_cnt[wave] = 0;
@@ -1931,12 +1931,18 @@ static int sift_run_batch(mi355_ctx* ctx, SiftWork* s) {
             if (xs) {
                 // no row halo to amortise here (3 + XD rows to prime a segment): many short segments balance the 2048 wave slots
                 const int nstrip = (oc.w + XSW - 1) / XSW;
-                int nseg = (8192 + nstrip * n - 1) / (nstrip * n);
-                int L = (oc.h + nseg - 1) / nseg;
-                if (L < 96) L = 96;
+                const int xsw = ((oc.w + nstrip - 1) / nstrip + 3) & ~3;      // equal strips (<= 248 columns) instead of a nearly empty last one
+                // whole rounds of the 2048 wave slots (2 waves per SIMD): the largest k <= 4 whose segments stay >= 64 rows
+                int nseg = 1, L = oc.h;
+                for (int k = 4; k >= 1; k--) {
+                    const int ns = (2048 * k) / (nstrip * n);
+                    if (ns < 1) continue;
+                    const int l = (oc.h + ns - 1) / ns;
+                    if (l >= 64 || k == 1) { L = l < 64 ? 64 : l; break; }
+                }
                 nseg = (oc.h + L - 1) / L;
                 hipLaunchKernelGGL(extrema_stream, dim3((nstrip * nseg * n + 3) / 4), dim3(256), 0, st,
-                                   oc, o, s->cand.as<unsigned long long>(), s->ccnt.as<unsigned>(), s->cand_cap, cnt + 4, bs, s->cube.as<float>(), s->cube_cap, L, nstrip, nseg, n);
+                                   oc, o, s->cand.as<unsigned long long>(), s->ccnt.as<unsigned>(), s->cand_cap, cnt + 4, bs, s->cube.as<float>(), s->cube_cap, L, nstrip, nseg, n, xsw);
             } else {
                 hipLaunchKernelGGL(extrema_kernel, dim3(((oc.w + EW - 1) / EW) * ((oc.h + EH - 1) / EH), n), dim3(256), 0, st,
                                    oc, o, s->cand.as<unsigned long long>(), s->ccnt.as<unsigned>(), s->cand_cap, cnt + 4, bs, s->cube.as<float>(), s->cube_cap);
