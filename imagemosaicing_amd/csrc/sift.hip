@@ -1125,7 +1125,21 @@ __global__ __launch_bounds__(256) void refine_kernel(PyrDev P, const unsigned lo
             rr.scl = sigma * det_exp2f(((float)L + f.xi) / (float)N_LAYERS);
             out[slot] = rr;
             out_resp[slot] = __float_as_uint(fabsf(contr));
-        }
+        } else atomicAnd(&P.claimed[o][fr * bs.claimed + (bit >> 5)], ~mask);      // list full (the frame fails): keep "bit set <=> record stored"
+    }
+}
+
+// The claim bitmaps (4 bits per pixel of every octave: 32 MB per 12 MP frame) are zero between batches: instead of clearing
+// them wholesale per batch, the bits this batch set -- exactly one per stored refined record -- are taken back.
+__global__ __launch_bounds__(256) void unclaim_kernel(PyrDev P, const Refined* ref, const unsigned* ref_count, unsigned ref_cap, BatchStride bs) {
+    const size_t fr = blockIdx.y;
+    ref += fr * bs.refined; ref_count += fr * CNT_STRIDE;
+    unsigned n = *ref_count;
+    if (n > ref_cap) n = ref_cap;
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const Refined rr = ref[i];
+        const size_t bit = ((size_t)rr.r * P.oc[rr.o].w + rr.c) * 4 + (size_t)rr.layer;
+        atomicAnd(&P.claimed[rr.o][fr * bs.claimed + (bit >> 5)], ~(1u << (bit & 31)));
     }
 }
 
@@ -1771,6 +1785,7 @@ static int sift_prepare(mi355_ctx* ctx, SiftWork* s, int w, int h, int nb) {
     const size_t B = (size_t)nb;
     MI_HIP(s->pyr.reserve(B * fl * sizeof(float)));
     MI_HIP(s->claimed.reserve(B * cl * sizeof(unsigned)));
+    MI_HIP(hipMemsetAsync(s->claimed.p, 0, B * cl * sizeof(unsigned), s->stream));      // kept zero between batches by unclaim_kernel
     MI_HIP(s->cand.reserve(B * s->bs.cand * sizeof(unsigned long long)));
     MI_HIP(s->refined.reserve(B * s->bs.refined * sizeof(Refined)));
     MI_HIP(s->kps.reserve(B * s->bs.kps * sizeof(KpRec)));
@@ -1872,7 +1887,6 @@ static int sift_run_batch(mi355_ctx* ctx, SiftWork* s) {
     unsigned* cnt = s->counters.as<unsigned>();      // per frame: [0] candidates [1] refined [2] keypoints [3] n_sel [4] overflow [8,9] ctrl
     MI_HIP(hipMemsetAsync(cnt, 0, (size_t)n * CNT_STRIDE * sizeof(unsigned), st));
     MI_HIP(hipMemsetAsync(s->ccnt.p, 0, (size_t)n * CCNT_STRIDE * sizeof(unsigned), st));
-    MI_HIP(hipMemsetAsync(s->claimed.p, 0, (size_t)n * bs.claimed * sizeof(unsigned), st));
     FrameOuts outs;
     memset(&outs, 0, sizeof(outs));
     std::vector<Features*> fs(n);
@@ -1954,6 +1968,7 @@ static int sift_run_batch(mi355_ctx* ctx, SiftWork* s) {
         ProfScope ps(ctx, "refine", 0.0, st);
         hipLaunchKernelGGL(refine_kernel, dim3(32, NREG, n), dim3(256), 0, st, s->P, s->cand.as<unsigned long long>(), s->ccnt.as<unsigned>(), s->cand_cap, cnt + 0,
                            ctx->p.contrast_threshold, ctx->p.edge_threshold, 1.6f, s->refined.as<Refined>(), cnt + 1, s->ref_cap, s->rhist.as<unsigned>(), bs, s->cube.as<float>(), s->cube_cap);
+        hipLaunchKernelGGL(unclaim_kernel, dim3(128, n), dim3(256), 0, st, s->P, s->refined.as<Refined>(), cnt + 1, s->ref_cap, bs);
         hipLaunchKernelGGL(resp_threshold_kernel, dim3(n), dim3(1024), 0, st, s->rhist.as<unsigned>(), cnt + 1, s->ref_cap, (unsigned)nf + 256u, cnt + 8, bs.refined, s->olist.as<unsigned>());
     }
     for (int pass = 0; pass < 2; pass++) {       // pass 1 (everything below the response threshold) exits at once unless top-k asked for it
