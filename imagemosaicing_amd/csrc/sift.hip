@@ -1893,7 +1893,6 @@ static int sift_run_batch(mi355_ctx* ctx, SiftWork* s) {
     for (int k = 0; k < n; k++) {
         fs[k] = &ctx->feats[pend[k].img_id];
         outs.kp[k] = fs[k]->kp.as<mi355_keypoint>(); outs.d8[k] = fs[k]->d8.as<uint8_t>();
-        MI_HIP(hipMemsetAsync(fs[k]->d8.p, 0, 128 * 2048, st));
     }
     auto blur_args = [&](const OctaveDev& oc) {
         BlurArgs a; memset(&a, 0, sizeof(a));
