@@ -172,9 +172,10 @@ def main():
     wv, hv, wsv = [w] * F, [h] * F, [ws] * F
     state = {}
 
-    phases = os.environ.get("MI355_BENCH_PHASES")
+    phases = bool(os.environ.get("MI355_BENCH_PHASES"))     # also switched on for one untimed step after the timed region
 
     def step(seed):
+        nonlocal phases
         t0 = time.perf_counter()
         for k in range(F):
             ctx.SiftExtractDev(k, fptr[k], w, h, ws)
@@ -204,7 +205,9 @@ def main():
         ctx.MosaicImagesRefinedDev(fptr, wv, hv, wsv, h9, canvas.data_ptr(), cw, ch, cws)
         if phases:
             ctx.synchronize(); t4 = time.perf_counter()
-            print("[phases ms] sift %.1f  match+D2H %.1f  host align %.1f  warp %.1f" % ((t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3, (t4 - t3) * 1e3), file=sys.stderr)
+            state["phase_ms"] = {"detect_describe": (t1 - t0) * 1e3, "match_select_ransac_d2h": (t2 - t1) * 1e3, "host_global_alignment": (t3 - t2) * 1e3, "warp": (t4 - t3) * 1e3}
+            if os.environ.get("MI355_BENCH_PHASES"):
+                print("[phases ms] sift %.1f  match+D2H %.1f  host align %.1f  warp %.1f" % ((t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3, (t4 - t3) * 1e3), file=sys.stderr)
         state.update(r=r, cw=cw, ch=ch, n_valid=int(label.sum()))
 
     def barrier():
@@ -230,6 +233,12 @@ def main():
         dt = float(t.item())
     g_ms, g_n, g_bytes = ctx.profile_get(DOM)
     m_ms, m_n, _ = ctx.profile_get("match")
+    if world == 1:                       # one extra UNTIMED step with a synchronisation after every phase: where a step's time goes
+        ctx.profile_enable(False)
+        phases = True
+        step(999)
+        phases = bool(os.environ.get("MI355_BENCH_PHASES"))
+        ctx.profile_enable(not os.environ.get("MI355_BENCH_NOPROF"))
     prof_all = {}
     if args.profile_all:
         for cls in ("gauss_stream", "gauss", "downsample", "extrema", "refine", "orient", "topk", "describe", "features", "match", "select", "ransac", "warp"):
@@ -307,6 +316,7 @@ def main():
             "mfma": {"kernel": "bf_match_kernel", "flop_per_pair": 2.0 * 2000 * 2000 * 128, "achieved": (n_pairs * args.steps * 2.0 * 2000 * 2000 * 128 / 1e12) / (m_ms / 1e3) if m_ms > 0 else None,
                      "peak": 2500.0, "unit": "TFLOP/s", "frac": ((n_pairs * args.steps * 2.0 * 2000 * 2000 * 128 / 1e12) / (m_ms / 1e3) / 2500.0) if m_ms > 0 else None,
                      "ms_per_step": m_ms / max(args.steps, 1), "note": "dense bf16 peak; 0.1 % of the step time, the path is HBM-bound"},
+            "phase_ms": state.get("phase_ms"),
             "quality": {"pairs_accepted": accepted, "pairs": n_pairs, "images_aligned": state["n_valid"],
                         "h_corner_err_px_median": float(np.median(errs)) if errs else None,
                         "h_corner_err_px_max": float(np.max(errs)) if errs else None},
