@@ -1,0 +1,41 @@
+"""randomised parity soak: GPU SIFT vs the oracle over random sizes / contents, single and batched extraction"""
+import sys, time, numpy as np, torch
+sys.path.insert(0, '/root/repo')
+import imagemosaicing_amd as im
+from tests import oracle_lib
+from tests.synth_frames import terrain
+o = oracle_lib.load_oracle()
+rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 1)
+budget = float(sys.argv[2]) if len(sys.argv) > 2 else 240.0
+t0 = time.time(); n = 0; bad = 0
+def content(w, h, kind, seed):
+    if kind == 0: return terrain(w, h, seed=seed)
+    r = np.random.default_rng(seed)
+    if kind == 1: return r.integers(0, 256, (h, w, 3), dtype=np.uint8)                       # white noise: very many extrema
+    if kind == 2:
+        g = (np.add.outer(np.arange(h), np.arange(w)) * 255 // (w + h)).astype(np.uint8)     # smooth ramp + sparse dots
+        img = np.repeat(g[..., None], 3, 2).copy(); ys = r.integers(0, h, 200); xs = r.integers(0, w, 200); img[ys, xs] = 255 - img[ys, xs]; return img
+    img = terrain(w, h, seed=seed); img[: h // 2] = 90; return img                           # half flat
+while time.time() - t0 < budget:
+    big = rng.random() < 0.25
+    w = int(rng.integers(1000, 1500)) if big else int(rng.integers(64, 700))
+    h = int(rng.integers(760, 1000)) if big else int(rng.integers(64, 500))
+    if rng.random() < 0.5: w &= ~3
+    nb = int(rng.integers(1, 6))
+    kinds = [int(rng.integers(0, 4)) for _ in range(nb)]
+    imgs = [content(w, h, k, int(rng.integers(1 << 30))) for k in kinds]
+    c = im.Context(0)
+    c.set_option("sift_batch", int(rng.integers(1, 9))); c.set_option("sift_slots", int(rng.integers(1, 4)))
+    if rng.random() < 0.5: c.set_option("xstream_min_w", 1000); c.set_option("xstream_min_frames", 1)
+    dev = [torch.from_numpy(np.ascontiguousarray(i)).cuda() for i in imgs]
+    torch.cuda.synchronize()
+    for k, d in enumerate(dev): c.SiftExtractDev(k, d.data_ptr(), w, h, w * 3)
+    for k, img in enumerate(imgs):
+        kp, desc = c.GetFeatures(k)
+        okp, od = o.sift(img)
+        ok = len(kp) == len(okp) and np.array_equal(kp.view(np.uint8), okp.view(np.uint8)) and np.array_equal(desc.astype(np.uint8), od)
+        n += 1
+        if not ok:
+            bad += 1; print("MISMATCH", w, h, kinds[k], len(kp), len(okp), flush=True)
+    c.close()
+print("soak: %d frames, %d mismatches, %.0f s" % (n, bad, time.time() - t0))
