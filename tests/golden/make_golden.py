@@ -86,7 +86,7 @@ def main():
     assert len(rec) == n_rec
     pairs = sorted(set(zip(rec["ai"].tolist(), rec["bi"].tolist())))
     rng = np.random.default_rng(5)
-    for k, (i, j) in enumerate(pairs[:12]):
+    for k, (i, j) in enumerate(pairs):            # every image pair of the reference's committed run
         sel = rec[(rec["ai"] == i) & (rec["bi"] == j)]
         n_out = 100 if k % 2 == 0 else 30
         p1 = np.zeros(len(sel) + n_out, ol.SFPOINT)
