@@ -1901,6 +1901,8 @@ static int sift_run_batch(mi355_ctx* ctx, SiftWork* s) {
     };
     // ---- phases 1+2: the pyramid, octave by octave, every launch covering all n frames of the batch ----
     bool ds_fused = false;
+    static const bool serial_heavy = getenv("MI355_SERIAL_HEAVY") != nullptr;
+    if (serial_heavy && ctx->heavy_ev_valid) MI_HIP(hipStreamWaitEvent(st, ctx->heavy_ev, 0));   // the previous batch's pyramid + extrema first
     for (int o = 0; o < s->n_oct; o++) {
         const OctaveDev& oc = s->P.oc[o];
         BlurArgs a = blur_args(oc);
@@ -1961,6 +1963,10 @@ static int sift_run_batch(mi355_ctx* ctx, SiftWork* s) {
                                    oc, o, s->cand.as<unsigned long long>(), s->ccnt.as<unsigned>(), s->cand_cap, cnt + 4, bs, s->cube.as<float>(), s->cube_cap);
             }
         }
+    }
+    if (serial_heavy) {
+        if (!ctx->heavy_ev) MI_HIP(hipEventCreateWithFlags(&ctx->heavy_ev, hipEventDisableTiming));
+        MI_HIP(hipEventRecord(ctx->heavy_ev, st)); ctx->heavy_ev_valid = true;
     }
     // ---- phase 3: keypoint stages of all n frames ----
     {
