@@ -52,29 +52,7 @@ def parse():
     return ap.parse_args()
 
 
-def frame_layout(n, w, h, rank, seed=0xC0FFEE):
-    """serpentine strip: 25 frames per row, 60 % forward / 30 % side overlap, +-3 deg yaw, +-2 % scale, +-5 % gain"""
-    rng = np.random.default_rng(seed + 7919 * rank)
-    per_row = 25
-    sx, sy = 0.4 * w, 0.7 * h
-    A, gains = [], []
-    for k in range(n):
-        row, col = divmod(k, per_row)
-        if row & 1:
-            col = per_row - 1 - col
-        cx = w / 2 + col * sx + rng.uniform(-0.01, 0.01) * w
-        cy = h / 2 + row * sy + rng.uniform(-0.01, 0.01) * h      # every rank's strip uses its own terrain seed (below), same extent
-        yaw = np.deg2rad(rng.uniform(-3, 3))
-        s = 1 + rng.uniform(-0.02, 0.02)
-        R = s * np.array([[np.cos(yaw), -np.sin(yaw)], [np.sin(yaw), np.cos(yaw)]])
-        t = np.array([cx, cy]) - R @ np.array([w / 2.0, h / 2.0])
-        A.append([R[0, 0], R[0, 1], t[0], R[1, 0], R[1, 1], t[1]])
-        gains.append(1 + rng.uniform(-0.05, 0.05))
-    return np.array(A, np.float64), np.array(gains)
-
-
-def affine3(a6):
-    return np.array([[a6[0], a6[1], a6[2]], [a6[3], a6[4], a6[5]], [0, 0, 1.0]])
+from tests.synth_survey import frame_layout, affine3  # noqa: E402  (ground-truth geometry shared with tests/test_gpu_configs.py)
 
 
 def cpu_has_v3():
@@ -85,40 +63,69 @@ def cpu_has_v3():
         return False
 
 
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_run(frames_host, A, w, h, ws, T, lib):
+    """One pass of the oracle pipeline over the sample on T host threads, image-strided in two barrier phases like the
+    reference (MosaicWithoutPos.cpp:5246-5247 T = min(8, ncpu-1); :4861 / :5066 thread k takes images k mod T):
+    phase A SIFT of every frame, phase B per frame i: match + select + Ransac2D of pair (i, i+1) and the warp of frame i."""
+    from tests import oracle_lib as ol
+    n = len(frames_host)
+    orcs = [ol.Oracle(os.path.join(ROOT, "oracle", lib)) for _ in range(T)]
+    feats = [None] * n
+    done = [None] * n
+
+    def phase_a(t):
+        for k in range(t, n, T):
+            img = frames_host[k].reshape(h, ws)[:, :3 * w].reshape(h, w, 3)
+            feats[k] = orcs[t].sift(np.ascontiguousarray(img))
+
+    def phase_b(t):
+        for k in range(t, n, T):
+            if k + 1 < n:
+                (k0, d0), (k1, d1) = feats[k], feats[k + 1]
+                done[k] = orcs[t].match_pair(np.stack([k0["x"], k0["y"]], 1), d0, np.stack([k1["x"], k1["y"]], 1), d1, w, h, 2.5, 1)
+            img = np.ascontiguousarray(frames_host[k].reshape(h, ws)[:, :3 * w].reshape(h, w, 3))
+            Hk = np.linalg.inv(affine3(A[0])) @ affine3(A[k])
+            orcs[t].image_projection_transform(img, Hk.reshape(9).astype(np.float32))
+
+    t0 = time.perf_counter()
+    for fn in (phase_a, phase_b):
+        th = [threading.Thread(target=fn, args=(t,)) for t in range(T)]
+        [t.start() for t in th]
+        [t.join() for t in th]
+    return time.perf_counter() - t0, [d for d in done if d is not None]
+
+
 def cpu_baseline(frames_host, A, w, h, ws):
-    """The oracle (CPU port of the same pipeline) on the GPU box's host cores: T = min(8, nproc-1) threads,
-    image-strided like the reference (MosaicWithoutPos.cpp:5246-5247, 4861).  Sample: T frames, T-1 adjacent pairs."""
+    """The oracle (CPU port of the same pipeline) on the GPU box's host cores: (i) T = min(8, nproc-1)
+    threads over the 20-frame / 19-adjacent-pair subset, (ii) 1 thread over its first 4 frames / 3 pairs (a 1-thread pass
+    over all 20 would take ~2 min).  `value` is (i), the reference's own threading rule."""
     from tests import oracle_lib as ol
     ol.build_oracle()
     lib = "liboracle_v3.so" if cpu_has_v3() and os.path.exists(os.path.join(ROOT, "oracle", "liboracle_v3.so")) else "liboracle.so"
-    T = len(frames_host)
-    orcs = [ol.Oracle(os.path.join(ROOT, "oracle", lib)) for _ in range(T)]
-    feats = [None] * T
-    done = [None] * T
-
-    def work_sift(k):
-        img = frames_host[k].reshape(h, ws)[:, :3 * w].reshape(h, w, 3)
-        feats[k] = orcs[k].sift(np.ascontiguousarray(img))
-
-    def work_pair(k):
-        img = np.ascontiguousarray(frames_host[k].reshape(h, ws)[:, :3 * w].reshape(h, w, 3))
-        if k + 1 < T:
-            (k0, d0), (k1, d1) = feats[k], feats[k + 1]
-            done[k] = orcs[k].match_pair(np.stack([k0["x"], k0["y"]], 1), d0, np.stack([k1["x"], k1["y"]], 1), d1, w, h, 2.5, 1)[0]
-        Hk = np.linalg.inv(affine3(A[0])) @ affine3(A[k])
-        orcs[k].image_projection_transform(img, Hk.reshape(9).astype(np.float32))
-
-    t0 = time.perf_counter()
-    for fn in (work_sift, work_pair):
-        th = [threading.Thread(target=fn, args=(k,)) for k in range(T)]
-        [t.start() for t in th]
-        [t.join() for t in th]
-    dt = time.perf_counter() - t0
-    pairs = max(T - 1, 1)
-    return {"value": pairs / dt, "unit": "image-pairs/s", "cores": T, "kind": "port",
-            "sample": "%d frames %dx%d / %d adjacent pairs of the same synthetic workload, %d threads image-strided, oracle/%s, %.1f s"
-                      % (T, w, h, pairs, T, lib, dt),
-            "inliers": [int(x) for x in done if x is not None]}
+    nproc = os.cpu_count() or 2
+    T = max(1, min(8, nproc - 1))
+    n = len(frames_host)
+    dt, done = cpu_run(frames_host, A, w, h, ws, T, lib)
+    pairs = max(n - 1, 1)
+    n1 = min(4, n)
+    dt1, _ = cpu_run(frames_host[:n1], A, w, h, ws, 1, lib)
+    out = {"value": pairs / dt, "unit": "image-pairs/s", "cores": T, "kind": "port", "nproc": nproc, "cpu_model": cpu_model(),
+           "sample": "%d frames %dx%d / %d adjacent pairs of the same synthetic workload (BASELINE.md section 2 subset), %d threads image-strided in two phases like the reference, oracle/%s, %.1f s"
+                     % (n, w, h, pairs, T, lib, dt),
+           "one_thread": {"value": max(n1 - 1, 1) / dt1, "unit": "image-pairs/s", "cores": 1,
+                          "sample": "first %d frames / %d pairs of the same subset, 1 thread, %.1f s" % (n1, max(n1 - 1, 1), dt1)},
+           "inliers": [int(d[0]) for d in done]}
+    return out, done
 
 
 def main():
@@ -323,16 +330,30 @@ def main():
         }
         if prof_all:
             out["kernel_ms_per_step"] = prof_all
-    # ---- CPU baseline: rank 0 at N=1 only, bounded sample ----
+    # ---- CPU baseline: rank 0 at N=1 only, bounded sample; its pairs double as a parity sample for the GPU records ----
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        T = max(1, min(8, (os.cpu_count() or 2) - 1))
-        T = min(T, F)
-        fh = frames[:T].cpu().numpy()
+        ns = min(20, F)
+        fh = frames[:ns].cpu().numpy()
         try:
-            out["cpu_baseline"] = cpu_baseline([fh[k] for k in range(T)], A, w, h, ws)
-            out["cpu_baseline"]["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+            cb, done = cpu_baseline([fh[k] for k in range(ns)], A, w, h, ws)
+            out["cpu_baseline"] = cb
+            cb["gpu_over_cpu"] = out["value"] / cb["value"]
+            # the same pairs on the GPU with the oracle's seed: n_selected, n_in, inlier ids and H bits must be equal
+            spairs = np.array([(k, k + 1) for k in range(ns - 1)], np.int32)
+            g = ctx.MatchPairs(spairs, 2.5, 1)
+            bad = []
+            for p, (nin, i1, i2, Ho, nsel) in enumerate(done):
+                r = g[p]
+                ok = int(r["n_selected"]) == nsel and int(r["accepted"]) == int(nin > 30)
+                if ok and nin > 30:
+                    ok = int(r["n_in"]) == nin and np.array_equal(r["a"][:nin], i1[:nin]) and np.array_equal(r["b"][:nin], i2[:nin]) and \
+                        np.array_equal(r["H"].view(np.uint32), Ho.view(np.uint32))
+                if not ok:
+                    bad.append(p)
+            out["parity_sample"] = "equal" if not bad else "DIFFERS at sample pairs %s" % bad
+            out["parity_sample_note"] = "%d adjacent pairs of the cpu_baseline sample: GPU records (features from the timed steps, seed 1) vs the oracle's n_selected / n_in / inlier lists / H bit patterns" % len(done)
         except Exception as e:       # the baseline must never take the GPU number down with it
-            out["cpu_baseline"] = {"value": None, "unit": "image-pairs/s", "cores": T, "kind": "port", "sample": "failed: %r" % (e,)}
+            out["cpu_baseline"] = {"value": None, "unit": "image-pairs/s", "cores": None, "kind": "port", "sample": "failed: %r" % (e,)}
     elif rank == 0:
         out["cpu_baseline"] = None
     if rank == 0:

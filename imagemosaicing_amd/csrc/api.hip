@@ -4,7 +4,7 @@
 #include "common.h"
 #include <new>
 
-static std::string g_create_error;
+static thread_local std::string g_create_error;   // mi355_last_error(NULL): the calling thread's last creation error
 
 extern "C" void mi355_default_params(mi355_params* p) {
     if (!p) return;
@@ -42,6 +42,9 @@ extern "C" int mi355_create(mi355_ctx** out, const mi355_params* params, int dev
         g_create_error = std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only";
         return MI355_ERR_DEVICE;
     }
+    // the caller's current device is left as it was (every entry point selects ctx->device itself)
+    struct DeviceRestore { int prev = -1; ~DeviceRestore() { if (prev >= 0) (void)hipSetDevice(prev); } } restore;
+    if (hipGetDevice(&restore.prev) != hipSuccess) restore.prev = -1;
     e = hipSetDevice(device_ordinal);
     if (e != hipSuccess) { g_create_error = hipGetErrorString(e); return MI355_ERR_DEVICE; }
     mi355_ctx* c = new (std::nothrow) mi355_ctx();
@@ -62,6 +65,9 @@ extern "C" int mi355_create(mi355_ctx** out, const mi355_params* params, int dev
 
 extern "C" void mi355_destroy(mi355_ctx* ctx) {
     if (!ctx) return;
+    struct DeviceRestore { int prev = -1; ~DeviceRestore() { if (prev >= 0) (void)hipSetDevice(prev); } } restore;
+    if (hipGetDevice(&restore.prev) != hipSuccess) restore.prev = -1;
+    { std::lock_guard<std::mutex> lk(ctx->mu); }       // a call still inside the ctx finishes first (the caller must not start new ones)
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     (void)mi_resolve_features(ctx);
@@ -80,8 +86,8 @@ extern "C" void mi355_destroy(mi355_ctx* ctx) {
 extern "C" const char* mi355_last_error(mi355_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 
 extern "C" int mi355_set_stream(mi355_ctx* ctx, void* hip_stream) {
-    if (!ctx) return MI355_ERR_ARG;
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    LOCKED_PROLOGUE
+    { int rc = mi_resolve_features(ctx); if (rc != MI355_OK) return rc; }      // parked frames were produced on the old stream
     (void)hipStreamSynchronize(ctx->stream);
     if (hip_stream) {
         // the context's own stream would only occupy a hardware queue from here on
@@ -95,8 +101,7 @@ extern "C" int mi355_set_stream(mi355_ctx* ctx, void* hip_stream) {
 }
 
 extern "C" int mi355_synchronize(mi355_ctx* ctx) {
-    if (!ctx) return MI355_ERR_ARG;
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    LOCKED_PROLOGUE
     int rc = mi_resolve_features(ctx);
     if (rc != MI355_OK) return rc;
     MI_HIP(hipStreamSynchronize(ctx->stream));
@@ -104,11 +109,6 @@ extern "C" int mi355_synchronize(mi355_ctx* ctx) {
 }
 
 extern "C" void mi355_free(void* p) { free(p); }
-
-#define LOCKED_PROLOGUE                                  \
-    if (!ctx) return MI355_ERR_ARG;                      \
-    std::lock_guard<std::mutex> lk(ctx->mu);             \
-    if (hipSetDevice(ctx->device) != hipSuccess) { ctx->set_error("hipSetDevice failed"); return MI355_ERR_DEVICE; }
 
 // ---- features --------------------------------------------------------------------------------------------------
 extern "C" int mi355_sift_extract_dev(mi355_ctx* ctx, int img_id, const uint8_t* d_bgr, int w, int h, int width_step, int* n_kp) {

@@ -21,6 +21,13 @@
         }                                                                                  \
     } while (0)
 
+// every ctx entry point: argument check, the ctx lock, and the ctx's device made current for the calling thread
+// (several contexts / devices in one process: allocations and launches must land on ctx->device)
+#define LOCKED_PROLOGUE                                  \
+    if (!ctx) return MI355_ERR_ARG;                      \
+    std::lock_guard<std::mutex> lk(ctx->mu);             \
+    if (hipSetDevice(ctx->device) != hipSuccess) { ctx->set_error("hipSetDevice failed"); return MI355_ERR_DEVICE; }
+
 // grow-only device buffer (workspaces live as long as the ctx: no hipMalloc in steady state)
 struct DevBuf {
     void*  p = nullptr;

@@ -305,8 +305,7 @@ int mi_set_features(mi355_ctx* ctx, int img_id, const mi355_keypoint* kp, const 
 }
 
 extern "C" int mi355_get_features(mi355_ctx* ctx, int img_id, mi355_keypoint* kp, float* desc128, int max_kp, int* n_kp) {
-    if (!ctx) return MI355_ERR_ARG;
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    LOCKED_PROLOGUE
     { int rc = mi_resolve_features(ctx); if (rc != MI355_OK) return rc; }
     auto it = ctx->feats.find(img_id);
     if (it == ctx->feats.end()) { ctx->set_error("get_features: unknown image id"); return MI355_ERR_ARG; }

@@ -1561,11 +1561,12 @@ __global__ __launch_bounds__(256) void describe_kernel(PyrDev P, const SelRec* s
 int gauss_kernel_host(double sigma, float* k) {
     const int ksize = ((int)lrint(sigma * 8.0 + 1.0)) | 1;
     const int r = ksize / 2;
-    double tmp[128], sum = 0.0;
+    // cv::getGaussianKernel(ksize, sigma, CV_32F): each exp() rounded to float, the floats summed in double, taps (float)(tap / sum)
+    double sum = 0.0;
     const double scale2x = -0.5 / (sigma * sigma);
-    for (int i = 0; i < ksize; i++) { const double x = (double)i - (double)(ksize - 1) * 0.5; tmp[i] = std::exp(scale2x * x * x); sum += tmp[i]; }
+    for (int i = 0; i < ksize; i++) { const double x = (double)i - (double)(ksize - 1) * 0.5; k[i] = (float)std::exp(scale2x * x * x); sum += (double)k[i]; }
     sum = 1.0 / sum;
-    for (int i = 0; i < ksize; i++) k[i] = (float)(tmp[i] * sum);
+    for (int i = 0; i < ksize; i++) k[i] = (float)((double)k[i] * sum);
     return r;
 }
 

@@ -18,6 +18,7 @@
 // contiguous run of the source row pair, so the 6-byte neighbourhood loads hit the same cache lines.
 #include "common.h"
 #include "hmath.h"
+#include <memory>
 
 namespace {
 
@@ -346,7 +347,9 @@ int mi_chips_and_masks_dev(mi355_ctx* ctx, const uint8_t* const* imgs, const int
     const float dGx = -minX, dGy = -minY;
     const int newW = (int)(maxX - minX + 1.5f), newH = (int)(maxY - minY + 1.5f);
     const int nv = (int)kept.size();
-    mi355_chip_info* ci = (mi355_chip_info*)calloc((size_t)(nv > 0 ? nv : 1), sizeof(mi355_chip_info));
+    // released on every failure path below; handed to the caller only on success
+    std::unique_ptr<mi355_chip_info, void (*)(void*)> ci_hold((mi355_chip_info*)calloc((size_t)(nv > 0 ? nv : 1), sizeof(mi355_chip_info)), free);
+    mi355_chip_info* ci = ci_hold.get();
     if (!ci) return MI355_ERR_NOMEM;
     std::vector<ChipDev> cd(nv);
     size_t map_total = 0, chip_total = 0, mask_total = 0;
@@ -383,6 +386,16 @@ int mi_chips_and_masks_dev(mi355_ctx* ctx, const uint8_t* const* imgs, const int
     MI_HIP(dmasks.reserve(mask_total + 16));
     MI_HIP(hipMemsetAsync(dchips.p, 0, chip_total, ctx->stream));
     MI_HIP(hipMemsetAsync(dmasks.p, 0, mask_total, ctx->stream));
+    // every kept source is staged in HBM up front (frames stay resident: 288 GB), so uploads and warps of consecutive chips
+    // overlap on the stream instead of synchronising per chip
+    std::vector<size_t> src_off(nv, 0);
+    size_t src_total = 0;
+    for (int v = 0; v < nv; v++) {
+        const int k = kept[v];
+        if (!imgs[k] || w[k] < 2 || h[k] < 2 || ws[k] < 3 * w[k]) { ctx->set_error("chips: bad image geometry"); return MI355_ERR_ARG; }
+        src_off[v] = src_total; src_total += ((size_t)ws[k] * h[k] + 255) & ~(size_t)255;
+    }
+    MI_HIP(dsrc.reserve(src_total + 16));
     for (int v = 0; v < nv; v++) {
         const int k = kept[v];
         const mi355_chip_info& c = ci[v];
@@ -390,10 +403,8 @@ int mi_chips_and_masks_dev(mi355_ctx* ctx, const uint8_t* const* imgs, const int
         memset(&a, 0, sizeof(a));
         if (mi_inverse_matrix_host(h9s + 9 * k, 3, a.inv, 1e-12f) != 1) { ctx->set_error("chips: homography not invertible"); return MI355_ERR_SINGULAR; }  // :2348
         const size_t src_bytes = (size_t)ws[k] * h[k];
-        MI_HIP(hipStreamSynchronize(ctx->stream));               // previous chip may still read warp_src
-        MI_HIP(dsrc.reserve(src_bytes + 16));
-        MI_HIP(hipMemcpyAsync(dsrc.p, imgs[k], src_bytes, hipMemcpyHostToDevice, ctx->stream));
-        a.src = dsrc.as<uint8_t>(); a.w = w[k]; a.h = h[k]; a.ws = ws[k];
+        MI_HIP(hipMemcpyAsync(dsrc.as<uint8_t>() + src_off[v], imgs[k], src_bytes, hipMemcpyHostToDevice, ctx->stream));
+        a.src = dsrc.as<uint8_t>() + src_off[v]; a.w = w[k]; a.h = h[k]; a.ws = ws[k];
         a.dst = dchips.as<uint8_t>() + chip_off[v]; a.dws = (c.w * 3 + 3) & ~3;
         a.mask = dmasks.as<uint8_t>() + mask_off[v]; a.mws = cd[v].mws;
         a.x_beg = 0; a.x_end = c.w - 1; a.y_beg = 0; a.y_end = c.h - 1;
@@ -436,7 +447,7 @@ int mi_chips_and_masks_dev(mi355_ctx* ctx, const uint8_t* const* imgs, const int
         }
     }
     MI_HIP(hipGetLastError());
-    *n_chips = nv; *chips_out = ci;
+    *n_chips = nv; *chips_out = ci_hold.release();
     if (cw_out) *cw_out = newW;
     if (ch_out) *ch_out = newH;
     return MI355_OK;
@@ -450,21 +461,31 @@ int mi_chips_and_masks(mi355_ctx* ctx, const uint8_t* const* imgs, const int* w,
     int nv = 0;
     mi355_chip_info* ci = nullptr;
     int rc = mi_chips_and_masks_dev(ctx, imgs, w, h, ws, n, h9s, keep, find_masks, &nv, &ci, chip_off, mask_off, cw_out, ch_out);
-    if (rc != MI355_OK) { free(ci); return rc; }
-    uint8_t** cimg = (uint8_t**)calloc((size_t)(nv > 0 ? nv : 1), sizeof(uint8_t*));
-    uint8_t** cmask = (uint8_t**)calloc((size_t)(nv > 0 ? nv : 1), sizeof(uint8_t*));
-    if (!cimg || !cmask) return MI355_ERR_NOMEM;
+    if (rc != MI355_OK) return rc;                     // nothing was handed out
+    // host results: owned here until the last copy has landed, then handed to the caller
+    struct HostArrays {
+        mi355_chip_info* ci; uint8_t** a = nullptr; uint8_t** b = nullptr; int n;
+        ~HostArrays() {
+            if (a) for (int v = 0; v < n; v++) free(a[v]);
+            if (b) for (int v = 0; v < n; v++) free(b[v]);
+            free(a); free(b); free(ci);
+        }
+    } hold{ci, nullptr, nullptr, nv};
+    hold.a = (uint8_t**)calloc((size_t)(nv > 0 ? nv : 1), sizeof(uint8_t*));
+    hold.b = (uint8_t**)calloc((size_t)(nv > 0 ? nv : 1), sizeof(uint8_t*));
+    if (!hold.a || !hold.b) return MI355_ERR_NOMEM;
     DevBuf& dchips = ctx->buf("chip_imgs");
     DevBuf& dmasks = ctx->buf("chip_masks");
     for (int v = 0; v < nv; v++) {
         const size_t cb = (size_t)((ci[v].w * 3 + 3) & ~3) * ci[v].h, mb = (size_t)((ci[v].w + 3) & ~3) * ci[v].h;
-        cimg[v] = (uint8_t*)malloc(cb);
-        cmask[v] = (uint8_t*)malloc(mb);
-        if (!cimg[v] || !cmask[v]) return MI355_ERR_NOMEM;
-        MI_HIP(hipMemcpyAsync(cimg[v], dchips.as<uint8_t>() + chip_off[v], cb, hipMemcpyDeviceToHost, ctx->stream));
-        MI_HIP(hipMemcpyAsync(cmask[v], dmasks.as<uint8_t>() + mask_off[v], mb, hipMemcpyDeviceToHost, ctx->stream));
+        hold.a[v] = (uint8_t*)malloc(cb);
+        hold.b[v] = (uint8_t*)malloc(mb);
+        if (!hold.a[v] || !hold.b[v]) return MI355_ERR_NOMEM;
+        MI_HIP(hipMemcpyAsync(hold.a[v], dchips.as<uint8_t>() + chip_off[v], cb, hipMemcpyDeviceToHost, ctx->stream));
+        MI_HIP(hipMemcpyAsync(hold.b[v], dmasks.as<uint8_t>() + mask_off[v], mb, hipMemcpyDeviceToHost, ctx->stream));
     }
     MI_HIP(hipStreamSynchronize(ctx->stream));
-    *n_chips = nv; *chips_out = ci; *chip_imgs = cimg; *masks_out = cmask;
+    *n_chips = nv; *chips_out = hold.ci; *chip_imgs = hold.a; *masks_out = hold.b;
+    hold.ci = nullptr; hold.a = nullptr; hold.b = nullptr;
     return MI355_OK;
 }

@@ -15,7 +15,8 @@
  *   2. base = 2x bilinear upsample (pixel centres, edge clamp), Gaussian blur with
  *      sqrt(sigma^2 - (2*0.5)^2)                                               (first octave = -1)
  *   3. per octave 6 Gaussian levels built incrementally, sigma_i = sqrt((s k^i)^2 - (s k^(i-1))^2),
- *      k = 2^(1/3); kernel width round(8 sigma + 1) | 1, taps exp(-x^2 / 2 sigma^2) normalised in double,
+ *      k = 2^(1/3); kernel width round(8 sigma + 1) | 1, taps (float)exp(-x^2 / 2 sigma^2) summed in double and normalised
+ *      tap by tap like cv::getGaussianKernel(.., CV_32F),
  *      border reflect-101; next octave = every second pixel of level 3
  *   4. DoG extrema over 26 neighbours (>= / <=), |D| > floor(0.5*0.01/3*255) = 0, 5 px border
  *   5. sub-pixel quadratic fit (<= 5 steps), contrast |D(x^)|*3 >= 0.01 and edge tr^2/det < 21^2/20
@@ -122,11 +123,13 @@ static int gauss_kernel(double sigma, float* k)      /* returns radius */
 {
     int ksize = ((int)lrint(sigma * 8.0 + 1.0)) | 1;
     int r = ksize / 2;
-    double tmp[64], sum = 0.0;
+    /* rounding points of cv::getGaussianKernel(ksize, sigma, CV_32F) (declared core/imgproc.hpp of the vendored 2.4.0 headers): every
+       exp() is rounded to float first, the FLOATS are summed in double, each tap is (float)(tap * (1 / sum)) */
+    double sum = 0.0;
     double scale2x = -0.5 / (sigma * sigma);
-    for (int i = 0; i < ksize; i++) { double x = (double)i - (double)(ksize - 1) * 0.5; tmp[i] = exp(scale2x * x * x); sum += tmp[i]; }
+    for (int i = 0; i < ksize; i++) { double x = (double)i - (double)(ksize - 1) * 0.5; k[i] = (float)exp(scale2x * x * x); sum += (double)k[i]; }
     sum = 1.0 / sum;
-    for (int i = 0; i < ksize; i++) k[i] = (float)(tmp[i] * sum);
+    for (int i = 0; i < ksize; i++) k[i] = (float)((double)k[i] * sum);
     return r;
 }
 

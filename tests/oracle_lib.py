@@ -311,7 +311,35 @@ class Ref:
 
 
 _ORC = None
+_ORC_FAST = None
 _REF = None
+
+
+def cpu_has_v3():
+    try:
+        flags = open("/proc/cpuinfo").read()
+        return all(f in flags for f in (" avx2", " fma", " bmi2"))
+    except OSError:
+        return False
+
+
+def load_oracle_fast():
+    """liboracle_v3.so where the host CPU has AVX2+FMA (same sources, same arithmetic: contraction stays off and fmaf()
+    is fused by definition either way), else the portable build.  For the config-sized tests (12 MP frames)."""
+    global _ORC_FAST
+    if _ORC_FAST is None:
+        build_oracle()
+        so = os.path.join(ORC_DIR, "liboracle_v3.so")
+        _ORC_FAST = Oracle(so) if cpu_has_v3() and os.path.exists(so) else load_oracle()
+    return _ORC_FAST
+
+
+def parallel_map(fn, items, threads=None):
+    """runs fn over items on host threads (ctypes releases the GIL; the oracle's C code is reentrant)"""
+    import concurrent.futures as cf
+    threads = threads or max(1, min(8, (os.cpu_count() or 2) - 1))
+    with cf.ThreadPoolExecutor(max_workers=threads) as ex:
+        return list(ex.map(fn, items))
 
 
 def load_oracle():

@@ -1,0 +1,139 @@
+"""GPU: the BASELINE.json configurations at their OWN sizes against the oracle (VERDICT r01 "next" #1).
+
+  C3  500 x 4000x3000 on the default route (sift_batch 8 / sift_slots 3, streamed base level, blur_stream, extrema_stream
+      with the default thresholds, 8000-wide strips with a 64-column last strip): a 12-frame sample -- one full batch of 8
+      and one ragged batch of 4 -- every keypoint field, every descriptor byte, and the adjacent pairs' n_selected / n_in /
+      inlier ids / H bits.
+  C2  the whole 50-frame 1920x1080 strip: features, the 49 adjacent pairs, and the MosaicImagesRefined canvas bytes.
+  C4  mini: 40 frames, reference pair window 182 => all 780 pairs; accepted / rejected sets and every accepted record.
+
+Frames come from mi355_synth_frame_dev (the bench's generator); the oracle sees the same bytes copied back to the host.
+Everything is bit-exact (floats compared by bit pattern)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _feats_equal(ctx, orc, imgs_host, ids, tag):
+    """GPU features of image ids[k] vs oracle.sift(imgs_host[k]); returns the oracle features"""
+    from tests import oracle_lib as ol
+    ofe = ol.parallel_map(lambda im: orc.sift(im), imgs_host)
+    for k, img_id in enumerate(ids):
+        kp, desc = ctx.GetFeatures(img_id)
+        okp, odesc = ofe[k]
+        assert len(kp) == len(okp), f"{tag} frame {img_id}: {len(kp)} vs {len(okp)} keypoints"
+        assert np.array_equal(kp.view(np.uint8), okp.view(np.uint8)), f"{tag} frame {img_id}: keypoint records differ"
+        assert np.array_equal(desc.astype(np.uint8), odesc), f"{tag} frame {img_id}: {int((desc.astype(np.uint8) != odesc).any(1).sum())} descriptors differ"
+    return ofe
+
+
+def _pairs_equal(res, orc, ofe, pairs, w, h, dist, seed, tag, min_inliers=30):
+    """GPU pair records vs oracle.match_pair on the oracle's features; returns the oracle's inlier counts"""
+    from tests import oracle_lib as ol
+
+    def one(p):
+        i, j = int(p[0]), int(p[1])
+        (k1, d1), (k2, d2) = ofe[i], ofe[j]
+        return orc.match_pair(np.stack([k1["x"], k1["y"]], 1), d1, np.stack([k2["x"], k2["y"]], 1), d2, w, h, dist, seed)
+
+    out = ol.parallel_map(one, list(pairs))
+    nins = []
+    for p, (nin, i1, i2, Ho, ns) in enumerate(out):
+        r = res[p]
+        i, j = int(pairs[p][0]), int(pairs[p][1])
+        assert (int(r["i"]), int(r["j"])) == (i, j)
+        assert ns == int(r["n_selected"]), f"{tag} pair ({i},{j}): n_selected {int(r['n_selected'])} vs {ns}"
+        # orc_match_pair returns 0 inliers for a rejected pair (MosaicWithoutPos.cpp:5201: appended only when > 30)
+        acc = nin > min_inliers
+        assert int(r["accepted"]) == int(acc), f"{tag} pair ({i},{j}): accepted {int(r['accepted'])} vs oracle n_in {nin}"
+        if acc:
+            assert nin == int(r["n_in"]), f"{tag} pair ({i},{j}): n_in {int(r['n_in'])} vs {nin}"
+            assert np.array_equal(r["a"][:nin], i1[:nin]) and np.array_equal(r["b"][:nin], i2[:nin]), f"{tag} pair ({i},{j}): inliers differ"
+            assert np.array_equal(r["H"].view(np.uint32), Ho.view(np.uint32)), f"{tag} pair ({i},{j}): H bits differ"
+        nins.append(nin)
+    return nins
+
+
+def test_c3_default_route_12mp():
+    import torch
+    import imagemosaicing_amd as im
+    from tests import oracle_lib as ol
+    from tests.synth_survey import render_frames, host_image
+    orc = ol.load_oracle_fast()
+    ctx = im.Context(0)                     # library defaults: sift_batch 8, sift_slots 3, xstream_min_w 3000, xstream_min_frames 4
+    w, h, F = 4000, 3000, 12
+    frames, A, gains, ws = render_frames(ctx, torch, F, w, h)
+    for k in range(F):
+        ctx.SiftExtractDev(k, frames[k].data_ptr(), w, h, ws)
+    pairs = im.pair_schedule(F, 2)
+    res = ctx.MatchPairs(pairs, 2.5, 3)
+    imgs = [host_image(frames, k, w, h, ws) for k in range(F)]
+    ofe = _feats_equal(ctx, orc, imgs, list(range(F)), "C3")
+    assert all(len(f[0]) == 2000 for f in ofe)
+    nins = _pairs_equal(res, orc, ofe, pairs, w, h, 2.5, 3, "C3")
+    assert min(nins) > 100, nins
+    ctx.close()
+
+
+def test_c2_full_strip_50_frames_with_canvas():
+    import torch
+    import imagemosaicing_amd as im
+    from tests import oracle_lib as ol
+    from tests.synth_survey import render_frames, host_image
+    orc = ol.load_oracle_fast()
+    ctx = im.Context(0)
+    w, h, F = 1920, 1080, 50
+    frames, A, gains, ws = render_frames(ctx, torch, F, w, h, per_row=F)
+    for k in range(F):
+        ctx.SiftExtractDev(k, frames[k].data_ptr(), w, h, ws)
+    pairs = im.pair_schedule(F, 2)
+    assert len(pairs) == 49
+    res = ctx.MatchPairs(pairs, 2.5, 11)
+    imgs = [host_image(frames, k, w, h, ws) for k in range(F)]
+    ofe = _feats_equal(ctx, orc, imgs, list(range(F)), "C2")
+    _pairs_equal(res, orc, ofe, pairs, w, h, 2.5, 11, "C2")
+    assert int(res["accepted"].sum()) == 49
+    # the driver steps between match and warp (connected component, global affine alignment), then the canvas
+    mp = im.results_to_match_pairs(res)
+    label = im.select_connected(mp, F)
+    assert label.sum() == F
+    T = im.global_affine_align(mp, F, fixed=[1] + [0] * (F - 1))
+    h9 = T["m"].copy()
+    fptr = [frames[k].data_ptr() for k in range(F)]
+    cw, ch, cws, _ = im.mosaic_layout([w] * F, [h] * F, h9)
+    canvas = torch.empty(ch * cws, dtype=torch.uint8, device="cuda")
+    ctx.MosaicImagesRefinedDev(fptr, [w] * F, [h] * F, [ws] * F, h9, canvas.data_ptr(), cw, ch, cws)
+    ctx.synchronize()
+    rc, (ref, rw, rh, rws) = orc.mosaic_images_refined(imgs, h9)
+    assert rc == 0 and (rw, rh, rws) == (cw, ch, cws)
+    got = canvas.cpu().numpy().reshape(ch, cws)
+    assert np.array_equal(got, ref), f"{int((got != ref).sum())} canvas bytes differ"
+    # host-image entry point (the literal drop-in form): same bytes
+    got2, cw2, ch2, cws2 = ctx.MosaicImagesRefined(imgs, h9)
+    assert (cw2, ch2, cws2) == (cw, ch, cws) and np.array_equal(got2, ref)
+    ctx.close()
+
+
+def test_c4_mini_window_182_all_pairs():
+    import torch
+    import imagemosaicing_amd as im
+    from tests import oracle_lib as ol
+    from tests.synth_survey import render_frames, host_image
+    orc = ol.load_oracle_fast()
+    ctx = im.Context(0)
+    w, h, F = 800, 600, 40
+    frames, A, gains, ws = render_frames(ctx, torch, F, w, h, per_row=8)
+    for k in range(F):
+        ctx.SiftExtractDev(k, frames[k].data_ptr(), w, h, ws)
+    pairs = im.pair_schedule(F, 182)                     # MosaicWithoutPos.cpp:5083-5084
+    assert len(pairs) == F * (F - 1) // 2
+    res = ctx.MatchPairs(pairs, 2.5, 5)
+    imgs = [host_image(frames, k, w, h, ws) for k in range(F)]
+    ofe = _feats_equal(ctx, orc, imgs, list(range(F)), "C4mini")
+    nins = _pairs_equal(res, orc, ofe, pairs, w, h, 2.5, 5, "C4mini")
+    acc = int(res["accepted"].sum())
+    # adjacent frames, frames two apart in a row, and the rows above / below overlap: both outcomes must be present
+    assert F - 1 <= acc < len(pairs) // 2, acc
+    assert sum(1 for n in nins if n > 30) == acc
+    ctx.close()
