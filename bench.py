@@ -45,6 +45,11 @@ def parse():
     ap.add_argument("--width", type=int, default=4000)
     ap.add_argument("--height", type=int, default=3000)
     ap.add_argument("--window", type=int, default=2, help="pair window: j in (i, i+window); 2 = adjacent pairs (C3), 182 = reference window (C4)")
+    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
+                    help="N>1: strong = ONE survey of --frames frames, detect+describe / pairs / canvas stripes sharded over the ranks with the two RCCL "
+                         "all-gathers (features, pair records); weak = an independent --frames strip per rank")
+    ap.add_argument("--transport", choices=["rccl", "torch"], default=None,
+                    help="exchange transport: rccl = the C ABI's own ncclAllGather calls (default with backend nccl), torch = torch.distributed (gloo dry runs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-all", action="store_true", help="bracket every kernel class with events (extra JSON field)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for single-GPU dry runs of the N>1 path)")
@@ -160,14 +165,30 @@ def main():
 
     w, h, F = args.width, args.height, args.frames
     ws = (3 * w + 3) & ~3
-    A, gains = frame_layout(F, w, h, rank)
+    strong = args.scaling == "strong"
+    exchange = world > 1 or bool(os.environ.get("MI355_BENCH_FORCE_EXCHANGE"))      # the env switch runs the collectives on one rank (dry run of the calls)
+    transport = args.transport or ("rccl" if (args.backend == "nccl" or world == 1) else "torch")
+    ex = md.Exchange(ctx, transport) if exchange else None
+    # strong: ONE survey, the same F frames on every rank (replicated in HBM: a rank renders every frame that crosses its canvas
+    # stripe, SURVEY 8e "replicas of frames + stripes"), detect+describe and pairs sharded; weak: an independent strip per rank
+    lay_rank = 0 if strong else rank
+    A, gains = frame_layout(F, w, h, lay_rank)
     # ---- synthetic frames, generated straight into HBM (never timed) ----
     frames = torch.empty((F, h * ws), dtype=torch.uint8, device=dev)
     for k in range(F):
-        ctx.SynthFrameDev(frames[k].data_ptr(), w, h, ws, A[k], (0xC0FFEE + 977 * rank) & 0xffffffff, (rank * 1000003 + k) & 0xffffffff, gains[k], 2.0)
+        ctx.SynthFrameDev(frames[k].data_ptr(), w, h, ws, A[k], (0xC0FFEE + 977 * lay_rank) & 0xffffffff, (lay_rank * 1000003 + k) & 0xffffffff, gains[k], 2.0)
     ctx.synchronize()
     fptr = [frames[k].data_ptr() for k in range(F)]
-    pairs = im.pair_schedule(F, args.window)
+    if strong:
+        own = md.owned_frames(F, rank, world)                              # k mod G == rank (MosaicWithoutPos.cpp:4861)
+        pairs = im.pair_schedule(F, args.window, rank, world)              # i mod G == rank (:5066), j in (i, i+window) (:5083)
+        survey_pairs = len(im.pair_schedule(F, args.window))
+        n_max_frames = (F + world - 1) // world
+    else:
+        own = list(range(F))
+        pairs = im.pair_schedule(F, args.window)
+        survey_pairs = len(pairs) * world
+        n_max_frames = F
     n_pairs = len(pairs)
     results = torch.zeros((max(n_pairs, 1), im.PAIR_RESULT.itemsize), dtype=torch.uint8, device=dev)
     res_host = torch.empty((max(n_pairs, 1), im.PAIR_RESULT.itemsize), dtype=torch.uint8).pin_memory()
@@ -184,19 +205,30 @@ def main():
     def step(seed):
         nonlocal phases
         t0 = time.perf_counter()
-        for k in range(F):
+        for k in own:
             ctx.SiftExtractDev(k, fptr[k], w, h, ws)
+        if exchange and strong:
+            # RCCL over xGMI: every rank receives every frame's keypoints + descriptors (the d:/feature_temp hand-off of the reference)
+            ex.allgather_features(own, n_max_frames, dev)
         if phases:
             ctx.synchronize(); t1 = time.perf_counter()
         ctx.MatchPairsDev(pairs, results.data_ptr(), 2.5, seed)
-        if world > 1:
-            # RCCL over xGMI: H + inlier lists of every pair of the survey, the only exchange of the path
-            state["gathered"], state["counts"] = md.allgather_pair_results(results[:max(n_pairs, 1)], accepted_only=True)
-        res_host.copy_(results, non_blocking=True)
-        stream.synchronize()
+        if exchange:
+            # RCCL over xGMI: H + inlier lists of every accepted pair of the survey, on every rank's host
+            r = ex.allgather_results(results, n_pairs, accepted_only=True)
+            if strong:
+                r = r[np.lexsort((r["j"], r["i"]))]      # pair order independent of the rank count
+            else:
+                # weak: the exchange is paid for, but every strip is its own survey -- this rank aligns and renders its own records
+                res_host.copy_(results, non_blocking=True)
+                stream.synchronize()
+                r = res_host.numpy().view(im.PAIR_RESULT).reshape(-1)[:n_pairs]
+        else:
+            res_host.copy_(results, non_blocking=True)
+            stream.synchronize()
+            r = res_host.numpy().view(im.PAIR_RESULT).reshape(-1)[:n_pairs]
         if phases:
             t2 = time.perf_counter()
-        r = res_host.numpy().view(im.PAIR_RESULT).reshape(-1)[:n_pairs]
         mp = im.results_to_match_pairs(r)
         label = im.select_connected(mp, F) if len(mp) else np.zeros(F, np.int32)
         label[0] = 1
@@ -209,10 +241,16 @@ def main():
             raise RuntimeError("canvas larger than provisioned (%d x %d)" % (cw, ch))
         if phases:
             t3 = time.perf_counter()
-        ctx.MosaicImagesRefinedDev(fptr, wv, hv, wsv, h9, canvas.data_ptr(), cw, ch, cws)
+        if strong and world > 1:
+            row0 = (ch * rank) // world                             # canvas stripes: every image in index order per stripe
+            ctx.MosaicImagesRefinedDev(fptr, wv, hv, wsv, h9, canvas.data_ptr(), cw, ch, cws, row0, (ch * (rank + 1)) // world - row0)
+        else:
+            ctx.MosaicImagesRefinedDev(fptr, wv, hv, wsv, h9, canvas.data_ptr(), cw, ch, cws)
         if phases:
             ctx.synchronize(); t4 = time.perf_counter()
-            state["phase_ms"] = {"detect_describe": (t1 - t0) * 1e3, "match_select_ransac_d2h": (t2 - t1) * 1e3, "host_global_alignment": (t3 - t2) * 1e3, "warp": (t4 - t3) * 1e3}
+            state["phase_ms"] = {"detect_describe" + ("+feature_allgather" if exchange and strong else ""): (t1 - t0) * 1e3,
+                                 "match_select_ransac" + ("+result_allgather" if exchange else "_d2h"): (t2 - t1) * 1e3,
+                                 "host_global_alignment": (t3 - t2) * 1e3, "warp": (t4 - t3) * 1e3}
             if os.environ.get("MI355_BENCH_PHASES"):
                 print("[phases ms] sift %.1f  match+D2H %.1f  host align %.1f  warp %.1f" % ((t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3, (t4 - t3) * 1e3), file=sys.stderr)
         state.update(r=r, cw=cw, ch=ch, n_valid=int(label.sum()))
@@ -235,7 +273,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=dev) if args.backend == "nccl" else torch.tensor([dt], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     g_ms, g_n, g_bytes = ctx.profile_get(DOM)
@@ -256,12 +294,12 @@ def main():
     # their event durations include the contention.  One extra UNTIMED pass over three batches with a single batch in
     # flight gives the same launches' stand-alone figures (reported separately, never as `achieved`).
     iso = None
-    if (world == 1 or rank == 0) and not os.environ.get("MI355_BENCH_NO_STANDALONE"):
+    if world == 1 and not os.environ.get("MI355_BENCH_NO_STANDALONE"):
         ctx.synchronize()
         ctx.set_option("sift_slots", 1)                    # same launches (full batches), but nothing else on the chip
         ctx.profile_enable(True); ctx.profile_only(DOM); ctx.profile_reset()
-        nf_iso = min(F, 3 * BATCH)
-        for k in range(nf_iso):
+        nf_iso = min(len(own), 3 * BATCH)
+        for k in own[:nf_iso]:
             ctx.SiftExtractDev(k, fptr[k], w, h, ws)
         i_ms, i_n, i_bytes = ctx.profile_get(DOM)
         ctx.profile_enable(False)
@@ -296,19 +334,26 @@ def main():
     except Exception:
         pass
     if rank == 0:
-        total_pairs = n_pairs * world * args.steps
+        total_pairs = survey_pairs * args.steps
         value = total_pairs / dt
+        n_frames_total = F if strong else F * world
+        path_bytes_per_pair = (n_frames_total * 262.0 * w * h + survey_pairs * 1.04e6) / max(survey_pairs, 1)
         achieved = (g_bytes / 1e9) / (g_ms / 1e3) if g_ms > 0 else 0.0
         out = {
             "metric": "image-pairs/sec (detect+match+H+warp), 4000x3000 UAV frames",
             "value": value, "unit": "image-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / max(args.steps, 1) * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": dt / max(args.steps, 1) * 1e3, "higher_is_better": True, "scaling": "strong" if strong else "weak",
             "vs_baseline": None, "dtype": "f32 (pyramid/RANSAC/warp coordinates), bf16 MFMA exact-integer (descriptor distances), u8 (pixels)",
             "data": "synthetic",
-            "config": {"workload": "C3: %d-frame %dx%d UAV strip per GPU, pair window %d (%d pairs per GPU), SIFT(2000,3,0.01,20) + exact BF match + 3x3 grid select + Ransac2D + MosaicImagesRefined warp"
-                                   % (F, w, h, args.window, n_pairs),
-                       "frames_per_gpu": F, "pairs_per_gpu": n_pairs, "frame": [w, h], "canvas": [state["cw"], state["ch"]],
-                       "sharding": "frames+pairs per rank, RCCL all-gather of pair records" if world > 1 else "single GPU"},
+            "config": {"workload": "%s: %s, pair window %d (%d pairs), SIFT(2000,3,0.01,20) + exact BF match + 3x3 grid select + Ransac2D + MosaicImagesRefined warp"
+                                   % ("C3" if args.window == 2 else ("C4" if args.window == 182 else "window-%d" % args.window),
+                                      ("ONE %d-frame %dx%d UAV survey" % (F, w, h)) if strong else ("%d-frame %dx%d UAV strip per GPU" % (F, w, h)),
+                                      args.window, survey_pairs),
+                       "frames": F if strong else F * world, "pairs": survey_pairs, "frames_per_gpu": len(own), "pairs_per_gpu": n_pairs,
+                       "frame": [w, h], "canvas": [state["cw"], state["ch"]],
+                       "sharding": ("single GPU" if world == 1 else
+                                    ("frames k mod G, pairs i mod G, canvas stripes; %s all-gather of feature records and accepted pair records" % transport) if strong else
+                                    ("independent strip per rank; %s all-gather of accepted pair records" % transport))},
             "roofline": {"bound": "hbm", "kernel": "blur_stream<R,D,false> (streaming separable Gaussian: the 20 launches per batch of 8 frames that produce levels 1..5 of pyramid octaves 0..3)", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "launches": int(g_n), "avg_launch_us": (g_ms * 1e3 / g_n) if g_n else None,
@@ -316,15 +361,17 @@ def main():
                          "algorithmic_bytes_per_frame": g_bytes / max(args.steps * F, 1),
                          "frames_per_batch": BATCH, "batches_in_flight": SLOTS, "standalone": iso},
             # the whole path against the fixed algorithmic figure 262*P + 1.04 MB per adjacent pair (3.145 GB at 12 MP)
-            "path_roofline": {"algorithmic_bytes_per_pair": 262.0 * w * h + 1.04e6, "achieved": value / max(world, 1) * (262.0 * w * h + 1.04e6) / 1e9,
-                              "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": value / max(world, 1) * (262.0 * w * h + 1.04e6) / 1e9 / HBM_PEAK_GBS,
+            # the whole path against the fixed algorithmic figure: (frames x (256 P + 6 P) + pairs x 1.04 MB) / pairs
+            # (= 262 P + 1.04 MB = 3.145 GB per adjacent pair at 12 MP; 22.3 MB per window pair at C4)
+            "path_roofline": {"algorithmic_bytes_per_pair": path_bytes_per_pair, "achieved": value / max(world, 1) * path_bytes_per_pair / 1e9,
+                              "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": value / max(world, 1) * path_bytes_per_pair / 1e9 / HBM_PEAK_GBS,
                               "note": "per GPU; SURVEY 8(d) formula (reads+writes of all 6 Gaussian levels, match operands, warp); this build moves fewer bytes than the formula assumes in places"},
             # north_star: MFMA utilisation of the only matrix kernel (exact all-pairs descriptor distances, bf16 32x32x16 MFMA)
             "mfma": {"kernel": "bf_match_kernel", "flop_per_pair": 2.0 * 2000 * 2000 * 128, "achieved": (n_pairs * args.steps * 2.0 * 2000 * 2000 * 128 / 1e12) / (m_ms / 1e3) if m_ms > 0 else None,
                      "peak": 2500.0, "unit": "TFLOP/s", "frac": ((n_pairs * args.steps * 2.0 * 2000 * 2000 * 128 / 1e12) / (m_ms / 1e3) / 2500.0) if m_ms > 0 else None,
                      "ms_per_step": m_ms / max(args.steps, 1), "note": "dense bf16 peak; 0.1 % of the step time, the path is HBM-bound"},
             "phase_ms": state.get("phase_ms"),
-            "quality": {"pairs_accepted": accepted, "pairs": n_pairs, "images_aligned": state["n_valid"],
+            "quality": {"pairs_accepted": accepted, "pairs": survey_pairs if strong else n_pairs, "images_aligned": state["n_valid"],
                         "h_corner_err_px_median": float(np.median(errs)) if errs else None,
                         "h_corner_err_px_max": float(np.max(errs)) if errs else None},
         }
@@ -358,6 +405,8 @@ def main():
         out["cpu_baseline"] = None
     if rank == 0:
         print(json.dumps(out))
+    if ex is not None:
+        ex.close()
     ctx.set_stream(None)
     ctx.close()
     if world > 1:

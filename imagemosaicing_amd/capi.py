@@ -19,6 +19,8 @@ PAIR_RESULT = np.dtype([("i", "<i4"), ("j", "<i4"), ("n_in", "<i4"), ("n_selecte
 CHIPINFO = np.dtype([("x0", "<i4"), ("y0", "<i4"), ("w", "<i4"), ("h", "<i4"), ("img", "<i4"),
                      ("sx", "<f4"), ("sy", "<f4"), ("quad", "<f4", (8,))])
 IMAGE_TRANSFORM = np.dtype([("m", "<f4", (9,)), ("fixed", "<i4")])
+FEATURE_HEADER = np.dtype([("img_id", "<i4"), ("n_kp", "<i4"), ("w", "<i4"), ("h", "<i4")])
+FEATURE_RECORD_BYTES = 319488
 assert SFPOINT.itemsize == 12 and KEYPOINT.itemsize == 28 and MATCHPAIR.itemsize == 40 and PAIR_RESULT.itemsize == 9664
 
 
@@ -274,6 +276,41 @@ class Context:
         self._chk(self.L.mi355_mosaic_refined_dev(self._h, ptrs, _p(w), _p(h), _p(ws), n, _p(h9s), C.c_void_p(int(d_canvas)),
                                                   int(cw), int(ch), int(cws), int(row0), int(rows if rows >= 0 else ch)))
 
+    # ---- multi-GPU exchanges -------------------------------------------------------------
+    def PackFeaturesDev(self, img_ids, d_payload):
+        """resident features of img_ids -> fixed-size records at d_payload (device, len x FEATURE_RECORD_BYTES); returns the headers"""
+        ids = np.ascontiguousarray(img_ids, np.int32)
+        hdr = np.zeros(len(ids), FEATURE_HEADER)
+        self._chk(self.L.mi355_pack_features_dev(self._h, _p(ids), len(ids), _p(hdr), C.c_void_p(int(d_payload))))
+        return hdr
+
+    def InstallFeaturesDev(self, hdr, d_payload):
+        hdr = np.ascontiguousarray(hdr, FEATURE_HEADER)
+        self._chk(self.L.mi355_install_features_dev(self._h, _p(hdr), C.c_void_p(int(d_payload)), len(hdr)))
+
+    def CompactAcceptedDev(self, d_in, n, d_out):
+        k = C.c_int(0)
+        self._chk(self.L.mi355_compact_accepted_dev(self._h, C.c_void_p(int(d_in)), int(n), C.c_void_p(int(d_out)), C.byref(k)))
+        return k.value
+
+    def CommInit(self, id128, rank, world):
+        buf = (C.c_uint8 * 128).from_buffer_copy(bytes(id128))
+        self._chk(self.L.mi355_comm_init(self._h, buf, int(rank), int(world)))
+
+    def CommDestroy(self):
+        self._chk(self.L.mi355_comm_destroy(self._h))
+
+    def AllGatherFeatures(self, img_ids, n_max_per_rank):
+        ids = np.ascontiguousarray(img_ids, np.int32)
+        self._chk(self.L.mi355_allgather_features(self._h, _p(ids), len(ids), int(n_max_per_rank)))
+
+    def AllGatherResults(self, d_local, n_local, accepted_only=True):
+        ptr, n = C.c_void_p(), C.c_int(0)
+        self._chk(self.L.mi355_allgather_results(self._h, C.c_void_p(int(d_local)), int(n_local), int(bool(accepted_only)), C.byref(ptr), C.byref(n)))
+        out = _copy_out(ptr, n.value * PAIR_RESULT.itemsize, PAIR_RESULT)
+        self.L.mi355_free(ptr)
+        return out
+
     def SynthFrameDev(self, d_dst, w, h, ws, A6, seed, frame_seed, gain=1.0, noise=2.0):
         A6 = np.ascontiguousarray(A6, np.float32)
         self._chk(self.L.mi355_synth_frame_dev(self._h, C.c_void_p(int(d_dst)), int(w), int(h), int(ws), _p(A6), C.c_uint32(seed),
@@ -345,6 +382,16 @@ class Context:
 
 
 # ---- host-only helpers (no ctx) ---------------------------------------------------------------------------
+def comm_unique_id():
+    """128-byte RCCL id for mi355_comm_init (rank 0 creates it, every rank receives it by any transport)"""
+    L = load_library()
+    buf = (C.c_uint8 * 128)()
+    rc = L.mi355_comm_unique_id(buf)
+    if rc != 0:
+        raise Mi355Error(rc, "comm_unique_id: librccl not usable")
+    return bytes(buf)
+
+
 def mosaic_layout(w, h, h9s):
     L = load_library()
     w = np.ascontiguousarray(w, np.int32)

@@ -1,0 +1,374 @@
+// csrc/comm.hip -- the multi-GPU exchanges of the path, inside the C ABI: one process per GPU, RCCL over xGMI.
+//
+// The reference shards its i-loop over threads of ONE process (thread k takes images k mod T, MosaicWithoutPos.cpp:4861 /
+// :5066); every thread can read every image's features because they sit in d:/feature_temp files (:5073-5076, 5100-5103),
+// and results meet in m_vecMatchPairs under a mutex (PushMatchPairs, :10137-10145).  With one process per GPU the same two
+// hand-offs become collectives:
+//   mi355_allgather_features   after detect+describe of the rank's own frames (k mod G == rank): every rank receives every
+//                              frame's keypoints + descriptors (fixed-size records, 312 KB per frame), so that rank r can match
+//                              (i, j) for any j of the reference's window j in (i, i+182) (:5083-5084)
+//   mi355_allgather_results    after match+select+RANSAC of the rank's own pairs: the accepted pair records (H + inlier lists)
+//                              of all ranks land on every rank's host for Select_Connected_Matched_Images / global alignment
+// Both are ncclAllGather calls on the ctx stream; nothing else of the data path crosses ranks.
+//
+// librccl is bound at run time (dlopen / dlsym) the first time a communicator is created: a process that already holds an RCCL
+// (PyTorch-ROCm bundles its own librccl.so.1 next to its own HIP runtime) must use THAT copy -- a second one from /opt/rocm
+// would bring a second HIP runtime into the process -- and a single-GPU user of the library does not need RCCL installed.
+// The pack / install halves are separate entry points so that a caller with its own transport (the gloo CPU tests, MPI)
+// moves the same records.
+#include "common.h"
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+namespace {
+
+struct RcclApi {
+    void* so = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    std::string err;
+};
+
+RcclApi* rccl_api() {
+    static RcclApi api;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        const char* names[] = {"librccl.so.1", "librccl.so"};
+        for (const char* n : names) { api.so = dlopen(n, RTLD_NOW | RTLD_NOLOAD); if (api.so) break; }      // the copy the process already uses
+        if (!api.so) for (const char* n : names) { api.so = dlopen(n, RTLD_NOW | RTLD_LOCAL); if (api.so) break; }
+        if (!api.so) api.so = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+        if (!api.so) { api.err = std::string("librccl not found: ") + (dlerror() ? dlerror() : ""); return; }
+        api.GetUniqueId = reinterpret_cast<decltype(api.GetUniqueId)>(dlsym(api.so, "ncclGetUniqueId"));
+        api.CommInitRank = reinterpret_cast<decltype(api.CommInitRank)>(dlsym(api.so, "ncclCommInitRank"));
+        api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(dlsym(api.so, "ncclCommDestroy"));
+        api.AllGather = reinterpret_cast<decltype(api.AllGather)>(dlsym(api.so, "ncclAllGather"));
+        api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(dlsym(api.so, "ncclGetErrorString"));
+        if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.AllGather || !api.GetErrorString) api.err = "librccl lacks a required symbol";
+    });
+    return &api;
+}
+
+#define MI_NCCL(call)                                                                                          \
+    do {                                                                                                       \
+        ncclResult_t r_ = (call);                                                                              \
+        if (r_ != ncclSuccess) { ctx->set_error(std::string(#call) + ": " + rccl_api()->GetErrorString(r_)); return MI355_ERR_DEVICE; } \
+    } while (0)
+
+static_assert(sizeof(mi355_feature_header) == 16, "feature header");
+static_assert(MI355_FEATURE_RECORD_BYTES >= 2048 * 28 + 2048 * 128 && MI355_FEATURE_RECORD_BYTES % 256 == 0, "feature record");
+
+// record layout: [0, 57344) keypoints (2048 x 28 B), [57344, 319488) descriptors u8 (2048 x 128); rows beyond n_kp are zero
+constexpr size_t REC_KP_BYTES = (size_t)2048 * sizeof(mi355_keypoint), REC_D8_OFF = REC_KP_BYTES, REC_D8_BYTES = (size_t)2048 * 128;
+
+struct PackSrc { const uint8_t* kp; const uint8_t* d8; int n; };
+
+// one workgroup column per record: 16-byte moves, zero fill beyond the frame's n keypoints
+__global__ __launch_bounds__(256) void pack_features_kernel(const PackSrc* src, uint8_t* payload) {
+    const PackSrc s = src[blockIdx.y];
+    uint4* dst = reinterpret_cast<uint4*>(payload + (size_t)blockIdx.y * MI355_FEATURE_RECORD_BYTES);
+    const size_t kp_bytes = (size_t)s.n * sizeof(mi355_keypoint), d8_bytes = (size_t)s.n * 128;
+    const size_t total16 = MI355_FEATURE_RECORD_BYTES / 16;
+    for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < total16; q += (size_t)gridDim.x * 256) {
+        const size_t b = q * 16;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (b < REC_KP_BYTES) {
+            if (b + 16 <= kp_bytes) v = *reinterpret_cast<const uint4*>(s.kp + b);
+            else if (b < kp_bytes) { uint8_t t[16] = {0}; for (size_t i = 0; b + i < kp_bytes; i++) t[i] = s.kp[b + i]; v = *reinterpret_cast<uint4*>(t); }
+        } else if (b < REC_D8_OFF + REC_D8_BYTES) {
+            const size_t o = b - REC_D8_OFF;
+            if (o + 16 <= d8_bytes) v = *reinterpret_cast<const uint4*>(s.d8 + o);      // d8_bytes is a multiple of 128
+        }
+        dst[q] = v;
+    }
+}
+
+// accepted pair records to the front, order kept (what the reference pushes to the driver, MosaicWithoutPos.cpp:5201-5227)
+__global__ __launch_bounds__(256) void compact_results_kernel(const mi355_pair_result* in, int n, mi355_pair_result* out, int* n_out) {
+    // one workgroup: n is a rank's pair count (<= a few 10^4); records move 16 bytes per lane
+    __shared__ int s_base, s_w[4];
+    if (threadIdx.x == 0) s_base = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int i0 = 0; i0 < n; i0 += 256) {
+        const int i = i0 + threadIdx.x;
+        const bool acc = i < n && in[i].accepted != 0;
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(acc);
+        if (lane == 0) s_w[wv] = __builtin_popcountll(m);
+        __syncthreads();
+        int off = s_base;
+        for (int q = 0; q < wv; q++) off += s_w[q];
+        const int pos = off + __builtin_popcountll(m & ((1ull << lane) - 1ull));
+        const int tot = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+        // every lane of the wave helps moving the wave's accepted records (604 x 16 B each)
+        for (int l = 0; l < 64; l++) {
+            if (!((m >> l) & 1ull)) continue;
+            const int src_i = i0 + wv * 64 + l;
+            const int dst_i = off + __builtin_popcountll(m & ((1ull << l) - 1ull));
+            const uint4* s = reinterpret_cast<const uint4*>(in + src_i);
+            uint4* d = reinterpret_cast<uint4*>(out + dst_i);
+            for (int q = lane; q < (int)(sizeof(mi355_pair_result) / 16); q += 64) d[q] = s[q];
+        }
+        (void)pos;
+        __syncthreads();
+        if (threadIdx.x == 0) s_base += tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *n_out = s_base;
+}
+static_assert(sizeof(mi355_pair_result) % 16 == 0, "pair record moves in 16-byte pieces");
+
+}  // namespace
+
+struct mi355_comm {
+    ncclComm_t comm = nullptr;
+    int rank = 0, world = 1;
+};
+
+// ---- pack / install (transport-agnostic halves) ---------------------------------------------------------------------------
+extern "C" int mi355_pack_features_dev(mi355_ctx* ctx, const int32_t* img_ids, int n, mi355_feature_header* hdr, void* d_payload) {
+    LOCKED_PROLOGUE
+    if (n < 0 || (n > 0 && (!img_ids || !hdr || !d_payload))) return MI355_ERR_ARG;
+    if (n == 0) return MI355_OK;
+    { int rc = mi_resolve_features(ctx); if (rc != MI355_OK) return rc; }
+    std::vector<PackSrc> src(n);
+    for (int k = 0; k < n; k++) {
+        auto it = ctx->feats.find(img_ids[k]);
+        if (it == ctx->feats.end()) { ctx->set_error("pack_features: no resident features for image " + std::to_string(img_ids[k])); return MI355_ERR_ARG; }
+        const Features& f = it->second;
+        if (f.n > 2048) { ctx->set_error("pack_features: more than 2048 keypoints"); return MI355_ERR_ARG; }
+        hdr[k].img_id = img_ids[k]; hdr[k].n_kp = f.n; hdr[k].w = f.w; hdr[k].h = f.h;
+        src[k] = PackSrc{f.kp.as<uint8_t>(), f.d8.as<uint8_t>(), f.n};
+    }
+    DevBuf& dsrc = ctx->buf("pack_src");
+    MI_HIP(dsrc.reserve(sizeof(PackSrc) * n));
+    MI_HIP(hipMemcpyAsync(dsrc.p, src.data(), sizeof(PackSrc) * n, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(pack_features_kernel, dim3(16, n), dim3(256), 0, ctx->stream, dsrc.as<PackSrc>(), reinterpret_cast<uint8_t*>(d_payload));
+    MI_HIP(hipGetLastError());
+    MI_HIP(hipStreamSynchronize(ctx->stream));           // `src` goes out of scope
+    return MI355_OK;
+}
+
+// One launch installs every received record: keypoints and descriptors move into the image's resident buffers and the matcher's
+// operands (xy, bf16 rows, squared norms) are derived on the way -- the per-frame form (two copies + finish_features per frame)
+// costs ~1500 API calls per step at C4.
+struct InstallDst { const uint8_t* rec; mi355_keypoint* kp; uint8_t* d8; float2* xy; uint16_t* bf; int* nrm; int n, npad; };
+
+__global__ __launch_bounds__(128) void install_features_kernel(const InstallDst* tab) {
+    const InstallDst t = tab[blockIdx.y];
+    const int row = blockIdx.x, k = threadIdx.x;            // one descriptor row per workgroup, 128 lanes = 128 dims
+    if (row >= t.npad) return;
+    unsigned v = 0;
+    if (row < t.n) v = t.rec[REC_D8_OFF + (size_t)row * 128 + k];
+    if (row < t.n) t.d8[(size_t)row * 128 + k] = (uint8_t)v;
+    t.bf[(size_t)row * 128 + k] = (uint16_t)(__float_as_uint((float)v) >> 16);      // integer 0..255 -> bf16 bits (exact)
+    int s = (int)(v * v);
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    __shared__ int part[2];
+    if ((k & 63) == 0) part[k >> 6] = s;
+    __syncthreads();
+    if (k == 0) t.nrm[row] = part[0] + part[1];
+    if (row < t.n && k < 7) {
+        const unsigned w = reinterpret_cast<const unsigned*>(t.rec + (size_t)row * sizeof(mi355_keypoint))[k];
+        reinterpret_cast<unsigned*>(t.kp + row)[k] = w;
+        if (k < 2) reinterpret_cast<unsigned*>(t.xy + row)[k] = w;                  // x, y are the first two fields
+    }
+}
+
+static int install_features(mi355_ctx* ctx, const mi355_feature_header* hdr, const void* d_payload, int n, const int32_t* skip_ids, int n_skip) {
+    std::vector<InstallDst> tab;
+    tab.reserve(n);
+    bool resolved = false;
+    for (int k = 0; k < n; k++) {
+        const mi355_feature_header& hk = hdr[k];
+        if (hk.img_id < 0) continue;                     // padding record of a rank with fewer frames
+        bool skip = false;
+        for (int q = 0; q < n_skip; q++) if (skip_ids[q] == hk.img_id) { skip = true; break; }
+        if (skip) continue;
+        if (hk.n_kp < 0 || hk.n_kp > 2048 || hk.w <= 0 || hk.h <= 0) { ctx->set_error("install_features: bad record header"); return MI355_ERR_ARG; }
+        auto it = ctx->feats.find(hk.img_id);
+        if (it != ctx->feats.end() && it->second.pending && !resolved) { int rc = mi_resolve_features(ctx); if (rc != MI355_OK) return rc; resolved = true; }
+        Features& f = ctx->feats[hk.img_id];
+        f.n = hk.n_kp; f.w = hk.w; f.h = hk.h; f.pending = false; f.h_cnt = nullptr;
+        f.npad = ((f.n + 127) / 128) * 128;
+        if (f.npad == 0) f.npad = 128;
+        // sized for 2048 keypoints once: no allocation in steady state when the counts change from step to step
+        MI_HIP(f.kp.reserve(sizeof(mi355_keypoint) * 2048));
+        MI_HIP(f.d8.reserve((size_t)128 * 2048));
+        MI_HIP(f.xy.reserve(sizeof(float2) * 2048));
+        MI_HIP(f.bf.reserve(sizeof(uint16_t) * 128 * 2048));
+        MI_HIP(f.nrm.reserve(sizeof(int) * 2048));
+        InstallDst t;
+        t.rec = reinterpret_cast<const uint8_t*>(d_payload) + (size_t)k * MI355_FEATURE_RECORD_BYTES;
+        t.kp = f.kp.as<mi355_keypoint>(); t.d8 = f.d8.as<uint8_t>(); t.xy = f.xy.as<float2>(); t.bf = f.bf.as<uint16_t>(); t.nrm = f.nrm.as<int>();
+        t.n = f.n; t.npad = f.npad;
+        tab.push_back(t);
+    }
+    if (tab.empty()) return MI355_OK;
+    DevBuf& dtab = ctx->buf("install_tab");
+    MI_HIP(dtab.reserve(sizeof(InstallDst) * tab.size()));
+    MI_HIP(hipMemcpyAsync(dtab.p, tab.data(), sizeof(InstallDst) * tab.size(), hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(install_features_kernel, dim3(2048, (unsigned)tab.size()), dim3(128), 0, ctx->stream, dtab.as<InstallDst>());
+    MI_HIP(hipGetLastError());
+    MI_HIP(hipStreamSynchronize(ctx->stream));           // `tab` goes out of scope; the caller may reuse d_payload
+    return MI355_OK;
+}
+
+extern "C" int mi355_install_features_dev(mi355_ctx* ctx, const mi355_feature_header* hdr, const void* d_payload, int n) {
+    LOCKED_PROLOGUE
+    if (n < 0 || (n > 0 && (!hdr || !d_payload))) return MI355_ERR_ARG;
+    return install_features(ctx, hdr, d_payload, n, nullptr, 0);
+}
+
+// ---- communicator ------------------------------------------------------------------------------------------------------------
+extern "C" int mi355_comm_unique_id(uint8_t id128[128]) {
+    if (!id128) return MI355_ERR_ARG;
+    RcclApi* api = rccl_api();
+    if (!api->err.empty()) return MI355_ERR_DEVICE;
+    ncclUniqueId id;
+    static_assert(sizeof(id) == 128, "ncclUniqueId");
+    if (api->GetUniqueId(&id) != ncclSuccess) return MI355_ERR_DEVICE;
+    memcpy(id128, &id, 128);
+    return MI355_OK;
+}
+
+extern "C" int mi355_comm_init(mi355_ctx* ctx, const uint8_t id128[128], int rank, int world) {
+    LOCKED_PROLOGUE
+    if (!id128 || world < 1 || rank < 0 || rank >= world) return MI355_ERR_ARG;
+    RcclApi* api = rccl_api();
+    if (!api->err.empty()) { ctx->set_error(api->err); return MI355_ERR_DEVICE; }
+    if (ctx->comm) { ctx->set_error("comm_init: the ctx already has a communicator"); return MI355_ERR_ARG; }
+    ncclUniqueId id;
+    memcpy(&id, id128, 128);
+    mi355_comm* c = new (std::nothrow) mi355_comm();
+    if (!c) return MI355_ERR_NOMEM;
+    c->rank = rank; c->world = world;
+    const ncclResult_t r = api->CommInitRank(&c->comm, world, id, rank);
+    if (r != ncclSuccess) { ctx->set_error(std::string("ncclCommInitRank: ") + api->GetErrorString(r)); delete c; return MI355_ERR_DEVICE; }
+    ctx->comm = c;
+    return MI355_OK;
+}
+
+void mi_comm_release(mi355_ctx* ctx) {
+    if (!ctx->comm) return;
+    if (ctx->comm->comm) (void)rccl_api()->CommDestroy(ctx->comm->comm);
+    delete ctx->comm;
+    ctx->comm = nullptr;
+}
+
+extern "C" int mi355_comm_destroy(mi355_ctx* ctx) {
+    LOCKED_PROLOGUE
+    (void)hipStreamSynchronize(ctx->stream);
+    mi_comm_release(ctx);
+    return MI355_OK;
+}
+
+// ---- collectives ---------------------------------------------------------------------------------------------------------------
+extern "C" int mi355_allgather_features(mi355_ctx* ctx, const int32_t* img_ids, int n_local, int n_max_per_rank) {
+    LOCKED_PROLOGUE
+    if (!ctx->comm) { ctx->set_error("allgather_features: no communicator (mi355_comm_init)"); return MI355_ERR_ARG; }
+    if (n_local < 0 || n_max_per_rank < n_local || n_max_per_rank < 1 || (n_local > 0 && !img_ids)) return MI355_ERR_ARG;
+    RcclApi* api = rccl_api();
+    const int world = ctx->comm->world, rank = ctx->comm->rank;
+    { int rc = mi_resolve_features(ctx); if (rc != MI355_OK) return rc; }
+    const size_t nm = (size_t)n_max_per_rank;
+    DevBuf& dhdr = ctx->buf("ag_feat_hdr");              // [world][n_max] headers, [world][n_max] records; this rank's block is the send buffer
+    DevBuf& dpay = ctx->buf("ag_feat_payload");
+    MI_HIP(dhdr.reserve(sizeof(mi355_feature_header) * nm * world));
+    MI_HIP(dpay.reserve((size_t)MI355_FEATURE_RECORD_BYTES * nm * world));
+    std::vector<mi355_feature_header> hdr(nm * world);
+    for (auto& hk : hdr) { hk.img_id = -1; hk.n_kp = 0; hk.w = 0; hk.h = 0; }
+    mi355_feature_header* my_hdr = hdr.data() + nm * rank;
+    uint8_t* my_pay = dpay.as<uint8_t>() + (size_t)MI355_FEATURE_RECORD_BYTES * nm * rank;
+    if (n_local > 0) {
+        std::vector<PackSrc> src(n_local);
+        for (int k = 0; k < n_local; k++) {
+            auto it = ctx->feats.find(img_ids[k]);
+            if (it == ctx->feats.end()) { ctx->set_error("allgather_features: no resident features for image " + std::to_string(img_ids[k])); return MI355_ERR_ARG; }
+            const Features& f = it->second;
+            my_hdr[k].img_id = img_ids[k]; my_hdr[k].n_kp = f.n; my_hdr[k].w = f.w; my_hdr[k].h = f.h;
+            src[k] = PackSrc{f.kp.as<uint8_t>(), f.d8.as<uint8_t>(), f.n};
+        }
+        DevBuf& dsrc = ctx->buf("pack_src");
+        MI_HIP(dsrc.reserve(sizeof(PackSrc) * n_local));
+        MI_HIP(hipMemcpyAsync(dsrc.p, src.data(), sizeof(PackSrc) * n_local, hipMemcpyHostToDevice, ctx->stream));
+        hipLaunchKernelGGL(pack_features_kernel, dim3(16, n_local), dim3(256), 0, ctx->stream, dsrc.as<PackSrc>(), my_pay);
+        MI_HIP(hipGetLastError());
+        MI_HIP(hipStreamSynchronize(ctx->stream));       // `src` goes out of scope
+    }
+    MI_HIP(hipMemcpyAsync(dhdr.as<mi355_feature_header>() + nm * rank, my_hdr, sizeof(mi355_feature_header) * nm, hipMemcpyHostToDevice, ctx->stream));
+    // in-place all-gathers (send buffer = this rank's block of the receive buffer)
+    MI_NCCL(api->AllGather(dhdr.as<mi355_feature_header>() + nm * rank, dhdr.p, sizeof(mi355_feature_header) * nm, ncclChar, ctx->comm->comm, ctx->stream));
+    MI_NCCL(api->AllGather(my_pay, dpay.p, (size_t)MI355_FEATURE_RECORD_BYTES * nm, ncclChar, ctx->comm->comm, ctx->stream));
+    MI_HIP(hipMemcpyAsync(hdr.data(), dhdr.p, sizeof(mi355_feature_header) * nm * world, hipMemcpyDeviceToHost, ctx->stream));
+    MI_HIP(hipStreamSynchronize(ctx->stream));
+    return install_features(ctx, hdr.data(), dpay.p, (int)(nm * world), img_ids, n_local);      // own frames are resident already
+}
+
+extern "C" int mi355_allgather_results(mi355_ctx* ctx, const mi355_pair_result* d_local, int n_local, int accepted_only,
+                                       mi355_pair_result** all, int* n_all) {
+    LOCKED_PROLOGUE
+    if (!ctx->comm) { ctx->set_error("allgather_results: no communicator (mi355_comm_init)"); return MI355_ERR_ARG; }
+    if (n_local < 0 || (n_local > 0 && !d_local) || !all || !n_all) return MI355_ERR_ARG;
+    *all = nullptr; *n_all = 0;
+    RcclApi* api = rccl_api();
+    const int world = ctx->comm->world, rank = ctx->comm->rank;
+    // 1. counts (after the optional compaction)
+    DevBuf& dcnt = ctx->buf("ag_res_counts");
+    MI_HIP(dcnt.reserve(sizeof(int) * (size_t)(world + 1)));
+    int* d_counts = dcnt.as<int>();
+    DevBuf& dcomp = ctx->buf("ag_res_compact");
+    const mi355_pair_result* d_send = d_local;
+    int n_send = n_local;
+    if (accepted_only && n_local > 0) {
+        MI_HIP(dcomp.reserve(sizeof(mi355_pair_result) * (size_t)n_local));
+        hipLaunchKernelGGL(compact_results_kernel, dim3(1), dim3(256), 0, ctx->stream, d_local, n_local, dcomp.as<mi355_pair_result>(), d_counts + rank);
+        MI_HIP(hipGetLastError());
+        d_send = dcomp.as<mi355_pair_result>();
+    } else {
+        MI_HIP(hipMemcpyAsync(d_counts + rank, &n_send, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    }
+    MI_NCCL(api->AllGather(d_counts + rank, d_counts, sizeof(int), ncclChar, ctx->comm->comm, ctx->stream));
+    std::vector<int> counts(world);
+    MI_HIP(hipMemcpyAsync(counts.data(), d_counts, sizeof(int) * world, hipMemcpyDeviceToHost, ctx->stream));
+    MI_HIP(hipStreamSynchronize(ctx->stream));
+    int n_max = 1; size_t total = 0;
+    for (int r = 0; r < world; r++) { if (counts[r] < 0) { ctx->set_error("allgather_results: bad count"); return MI355_ERR_FAILED; } if (counts[r] > n_max) n_max = counts[r]; total += (size_t)counts[r]; }
+    n_send = counts[rank];
+    // 2. payload, padded to the largest rank's count
+    DevBuf& dall = ctx->buf("ag_res_all");
+    MI_HIP(dall.reserve(sizeof(mi355_pair_result) * (size_t)n_max * world));
+    mi355_pair_result* my = dall.as<mi355_pair_result>() + (size_t)n_max * rank;
+    if (n_send > 0) MI_HIP(hipMemcpyAsync(my, d_send, sizeof(mi355_pair_result) * (size_t)n_send, hipMemcpyDeviceToDevice, ctx->stream));
+    MI_NCCL(api->AllGather(my, dall.p, sizeof(mi355_pair_result) * (size_t)n_max, ncclChar, ctx->comm->comm, ctx->stream));
+    // 3. to the host, rank-major, padding dropped
+    mi355_pair_result* out = (mi355_pair_result*)malloc(sizeof(mi355_pair_result) * (total > 0 ? total : 1));
+    if (!out) return MI355_ERR_NOMEM;
+    size_t o = 0;
+    hipError_t e = hipSuccess;
+    for (int r = 0; r < world && e == hipSuccess; r++) {
+        if (counts[r] > 0) e = hipMemcpyAsync(out + o, dall.as<mi355_pair_result>() + (size_t)n_max * r, sizeof(mi355_pair_result) * (size_t)counts[r], hipMemcpyDeviceToHost, ctx->stream);
+        o += (size_t)counts[r];
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) { free(out); ctx->set_error(hipGetErrorString(e)); return MI355_ERR_DEVICE; }
+    *all = out; *n_all = (int)total;
+    return MI355_OK;
+}
+
+// device-side compaction alone (callers with their own transport): accepted records to the front of d_out, count to the host
+extern "C" int mi355_compact_accepted_dev(mi355_ctx* ctx, const mi355_pair_result* d_in, int n, mi355_pair_result* d_out, int* n_out) {
+    LOCKED_PROLOGUE
+    if (n < 0 || !n_out || (n > 0 && (!d_in || !d_out))) return MI355_ERR_ARG;
+    *n_out = 0;
+    if (n == 0) return MI355_OK;
+    DevBuf& dcnt = ctx->buf("ag_res_counts");
+    MI_HIP(dcnt.reserve(sizeof(int) * 64));
+    hipLaunchKernelGGL(compact_results_kernel, dim3(1), dim3(256), 0, ctx->stream, d_in, n, d_out, dcnt.as<int>());
+    MI_HIP(hipGetLastError());
+    MI_HIP(hipMemcpyAsync(n_out, dcnt.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    MI_HIP(hipStreamSynchronize(ctx->stream));
+    return MI355_OK;
+}

@@ -1,19 +1,68 @@
-"""Multi-GPU plumbing of the hot path: one process per GPU, torch.distributed (backend "nccl" = RCCL
-over xGMI on ROCm; "gloo" in the CPU tests).
+"""Multi-GPU plumbing of the hot path: one process per GPU.
 
-The path shards embarrassingly: rank r owns frames and pairs of its own block (mi355_pair_schedule strides the
-reference's i-loop by rank exactly like its threads, MosaicWithoutPos.cpp:5066).  There is no data-path
-collective; the ONLY exchange is one all-gather of the fixed-size per-pair result records (H + inlier lists,
-9664 B each) that feed global alignment -- what the reference's threads do through PushMatchPairs under a mutex
-(MosaicWithoutPos.cpp:5236, 10137-10145).
+Sharding (the reference's own rule, MosaicWithoutPos.cpp:4861 / :5066, threads -> ranks): rank r extracts the frames
+k mod G == r and matches the pairs (i, j) whose i it owns (mi355_pair_schedule); j runs over the reference's window
+j in (i, i+182) (:5083-5084), so every rank needs every frame's features before matching.  Two exchanges, nothing else of the
+data path crosses ranks:
+
+  features   after detect+describe: all-gather of the fixed-size feature records (keypoints + u8 descriptors, 312 KB per
+             frame) -- the reference hands features from the extraction threads to the matcher threads through
+             d:/feature_temp files (:4874-4880 -> :5100-5103)
+  results    after match + select + RANSAC: all-gather of the accepted pair records (H + inlier lists, 9664 B each) that
+             feed Select_Connected_Matched_Images / global alignment -- PushMatchPairs under a mutex in the reference
+             (:5236, :10137-10145)
+
+Transports: "rccl" = the C ABI's own collectives (mi355_allgather_features / mi355_allgather_results: ncclAllGather over
+xGMI on the ctx stream; the product path, what bench.py runs with backend nccl); "torch" = the same packed records moved by
+torch.distributed.all_gather (gloo in the CPU tests and in single-GPU dry runs, where RCCL cannot place two ranks on one
+device).  Both go through the same pack / install entry points of the library.
 """
 import numpy as np
 import torch
 import torch.distributed as dist
 
-from .capi import PAIR_RESULT
+from .capi import PAIR_RESULT, FEATURE_HEADER, FEATURE_RECORD_BYTES, comm_unique_id
 
 REC = PAIR_RESULT.itemsize
+
+
+def owned_frames(n_images, rank, world):
+    """frames rank `rank` extracts: k mod world == rank (MosaicWithoutPos.cpp:4861)"""
+    return list(range(rank, n_images, world))
+
+
+def init_comm(ctx, group=None):
+    """creates the ctx's RCCL communicator: rank 0 makes the 128-byte id, torch.distributed carries it to the other ranks"""
+    if not dist.is_initialized():                      # single process: a communicator of one rank (exercises the same calls)
+        ctx.CommInit(comm_unique_id(), 0, 1)
+        return
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    box = [comm_unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0, group=group)
+    ctx.CommInit(box[0], rank, world)
+
+
+def _allgather_rows(local, n_max):
+    """local: uint8 tensor [n_local, row_bytes] -> (uint8 [world, n_max, row_bytes], counts).  Ragged counts: the counts are
+    gathered first and the payload is padded to n_max rows (None: the largest count)."""
+    world = dist.get_world_size()
+    if dist.get_backend() == "gloo" and local.is_cuda:
+        # gloo has no device collectives: stage through the host (CPU tests and single-GPU dry runs only)
+        g, counts = _allgather_rows(local.cpu(), n_max)
+        return g.to(local.device), counts
+    n = torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device)
+    counts = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(counts, n)
+    counts = [int(c.item()) for c in counts]
+    n_max = max(max(counts), 1) if n_max is None else n_max
+    row = local.shape[1]
+    padded = local
+    if local.shape[0] != n_max:
+        padded = torch.zeros((n_max, row), dtype=torch.uint8, device=local.device)
+        padded[:local.shape[0]] = local
+    out = torch.empty((world * n_max, row), dtype=torch.uint8, device=local.device)
+    dist.all_gather_into_tensor(out, padded.contiguous())
+    return out.view(world, n_max, row), counts
 
 
 def compact_accepted(local):
@@ -26,30 +75,14 @@ def compact_accepted(local):
 
 
 def allgather_pair_results(local, n_local_max=None, accepted_only=False):
-    """local: uint8 tensor [n_local, 9664] (device for nccl, cpu for gloo).  Returns uint8 [world, n_max, 9664] and the
-    per-rank counts; ranks may hold different numbers of pairs (counts are gathered first, payload padded)."""
+    """torch transport of the result exchange.  local: uint8 tensor [n_local, 9664] (device for nccl, cpu for gloo).
+    Returns uint8 [world, n_max, 9664] and the per-rank counts."""
     if accepted_only:
         local = compact_accepted(local)
     world = dist.get_world_size() if dist.is_initialized() else 1
     if world == 1:
         return local.unsqueeze(0), [local.shape[0]]
-    if dist.get_backend() == "gloo" and local.is_cuda:
-        # gloo has no device all_gather: stage through the host (CPU tests and single-GPU dry runs of bench.py only;
-        # production uses backend "nccl" = RCCL, device to device over xGMI)
-        g, counts = allgather_pair_results(local.cpu(), n_local_max, False)
-        return g.to(local.device), counts
-    n = torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device)
-    counts = [torch.zeros_like(n) for _ in range(world)]
-    dist.all_gather(counts, n)
-    counts = [int(c.item()) for c in counts]
-    n_max = max(max(counts), 1) if n_local_max is None else n_local_max
-    padded = local
-    if local.shape[0] != n_max:
-        padded = torch.zeros((n_max, REC), dtype=torch.uint8, device=local.device)
-        padded[:local.shape[0]] = local
-    out = torch.empty((world * n_max, REC), dtype=torch.uint8, device=local.device)
-    dist.all_gather_into_tensor(out, padded.contiguous())
-    return out.view(world, n_max, REC), counts
+    return _allgather_rows(local, n_local_max)
 
 
 def gathered_to_records(gathered, counts):
@@ -57,3 +90,57 @@ def gathered_to_records(gathered, counts):
     g = gathered.cpu().numpy()
     parts = [g[r, :c].reshape(-1).view(PAIR_RESULT) for r, c in enumerate(counts)]
     return np.concatenate(parts) if parts else np.zeros(0, PAIR_RESULT)
+
+
+def allgather_feature_records(hdr, payload, n_max=None):
+    """torch transport of the feature exchange.  hdr: FEATURE_HEADER array [n_local]; payload: uint8 tensor
+    [n_local, FEATURE_RECORD_BYTES].  Returns (headers [world][count_r], payload uint8 [world, n_max, REC], counts)."""
+    h = torch.from_numpy(np.ascontiguousarray(hdr, FEATURE_HEADER).view(np.uint8).reshape(len(hdr), FEATURE_HEADER.itemsize).copy())
+    gh, counts = _allgather_rows(h, n_max)
+    gp, counts2 = _allgather_rows(payload, n_max)
+    assert counts == counts2
+    hdrs = [gh[r, :c].contiguous().numpy().reshape(-1).view(FEATURE_HEADER) for r, c in enumerate(counts)]
+    return hdrs, gp, counts
+
+
+class Exchange:
+    """The two exchanges of one rank's ctx.  transport "rccl": mi355_comm_init was done (init_comm) and the library's own
+    collectives run; "torch": torch.distributed moves the same records."""
+
+    def __init__(self, ctx, transport="rccl"):
+        assert transport in ("rccl", "torch")
+        self.ctx, self.transport = ctx, transport
+        self.rank = dist.get_rank() if dist.is_initialized() else 0
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self._payload = None
+        if transport == "rccl":
+            init_comm(ctx)
+
+    def allgather_features(self, own_ids, n_max, device):
+        """afterwards every frame of every rank is resident in this rank's ctx"""
+        if self.transport == "rccl":
+            self.ctx.AllGatherFeatures(own_ids, n_max)
+            return
+        if self.world == 1:
+            return
+        n = len(own_ids)
+        if self._payload is None or self._payload.shape[0] < max(n, 1):
+            self._payload = torch.empty((max(n, 1), FEATURE_RECORD_BYTES), dtype=torch.uint8, device=device)
+        hdr = self.ctx.PackFeaturesDev(own_ids, self._payload.data_ptr()) if n else np.zeros(0, FEATURE_HEADER)
+        hdrs, gp, counts = allgather_feature_records(hdr, self._payload[:n], n_max)
+        for r in range(self.world):
+            if r == self.rank or counts[r] == 0:
+                continue
+            block = gp[r].contiguous()
+            self.ctx.InstallFeaturesDev(hdrs[r], block.data_ptr())
+
+    def allgather_results(self, results, n_local, accepted_only=True):
+        """results: uint8 device tensor [>= n_local, 9664] written by MatchPairsDev.  Returns all ranks' records (numpy, rank-major)."""
+        if self.transport == "rccl":
+            return self.ctx.AllGatherResults(results.data_ptr(), n_local, accepted_only)
+        g, counts = allgather_pair_results(results[:n_local], accepted_only=accepted_only)
+        return gathered_to_records(g, counts)
+
+    def close(self):
+        if self.transport == "rccl":
+            self.ctx.CommDestroy()

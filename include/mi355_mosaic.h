@@ -212,10 +212,41 @@ int  mi355_global_affine_align(const mi355_match_point_pairs* v, int n, int n_im
  * and flags those images invalid, h.m[8]=0, :4512-4523, 4646-4652).  Ties -> the group holding the lowest index. */
 int  mi355_select_connected(const mi355_match_point_pairs* v, int n, int n_images, int32_t* label);
 
-/* ---- multi-GPU ------------------------------------------------------------------------------------------ */
+/* ---- multi-GPU: one process per GPU ------------------------------------------------------- */
 /* Deterministic shard of the reference's pair schedule (i strided by rank like the threads at
- * MosaicWithoutPos.cpp:5066, j in (i, min(N, i+window))): writes pairs of rank `rank` of `world`. */
+ * MosaicWithoutPos.cpp:5066, j in (i, min(N, i+window))): writes pairs of rank `rank` of `world`.
+ * Rank r extracts the frames k mod world == r (:4861) and matches the pairs whose i it owns; j may be any frame
+ * of the window, so every rank needs every frame's features before matching: mi355_allgather_features. */
 int  mi355_pair_schedule(int n_images, int window, int rank, int world, int32_t* pairs_ij, int max_pairs, int* n_pairs);
+
+/* Fixed-size feature record of one frame (what the reference keeps in keypoint_%d.key + discriptor_%d.xml,
+ * MosaicWithoutPos.cpp:4682-4734): bytes [0, 57344) 2048 x cv::KeyPoint, [57344, 319488) 2048 x 128 u8 descriptors,
+ * zero beyond the frame's n_kp.  The header travels separately (host-readable). */
+#define MI355_FEATURE_RECORD_BYTES 319488
+typedef struct { int32_t img_id /* < 0: padding record */, n_kp, w, h; } mi355_feature_header;
+/* Transport-agnostic halves: pack resident features into records at d_payload (device, n x MI355_FEATURE_RECORD_BYTES; headers to
+ * the HOST array hdr) / install records as resident features (as if extracted here).  Used by callers that bring their own
+ * transport (MPI, the gloo CPU tests); mi355_allgather_features does both around one RCCL all-gather. */
+int  mi355_pack_features_dev(mi355_ctx* ctx, const int32_t* img_ids, int n, mi355_feature_header* hdr, void* d_payload);
+int  mi355_install_features_dev(mi355_ctx* ctx, const mi355_feature_header* hdr, const void* d_payload, int n);
+/* Accepted pair records to the front of d_out (order kept): what the reference pushes to the driver (:5201-5227). */
+int  mi355_compact_accepted_dev(mi355_ctx* ctx, const mi355_pair_result* d_in, int n, mi355_pair_result* d_out, int* n_out);
+
+/* RCCL communicator of the ctx (librccl is bound at run time; a process that already holds one -- PyTorch -- shares it).
+ * Rank 0 obtains the id and hands the 128 bytes to the other ranks by any means (the reference has none: file, socket,
+ * torch.distributed store); then every rank calls mi355_comm_init.  Collective calls, like every RCCL collective. */
+int  mi355_comm_unique_id(uint8_t id128[128]);
+int  mi355_comm_init(mi355_ctx* ctx, const uint8_t id128[128], int rank, int world);
+int  mi355_comm_destroy(mi355_ctx* ctx);
+/* ncclAllGather over xGMI of the feature records of this rank's frames (img_ids, n_local <= n_max_per_rank, the same
+ * n_max_per_rank on every rank): afterwards the features of every rank's frames are resident on every rank
+ * (replaces the d:/feature_temp hand-off between SiftExtraction_Thread and the matcher threads, :4874-4880 / :5100-5103). */
+int  mi355_allgather_features(mi355_ctx* ctx, const int32_t* img_ids, int n_local, int n_max_per_rank);
+/* ncclAllGather of the pair records (PushMatchPairs, :10137-10145): d_local = this rank's n_local device records
+ * (mi355_match_pairs_dev); accepted_only != 0 sends the accepted pairs only (C4: 96 % of the window pairs do not overlap).
+ * *all: host array, rank-major, every rank receives the same -> mi355_free. */
+int  mi355_allgather_results(mi355_ctx* ctx, const mi355_pair_result* d_local, int n_local, int accepted_only,
+                             mi355_pair_result** all, int* n_all);
 
 /* ---- measurement hooks (bench.py) ----------------------------------------------------------------------- */
 /* When enabled, every launch of the named kernel class is bracketed by hipEvents on the ctx stream. */

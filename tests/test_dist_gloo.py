@@ -1,5 +1,6 @@
-"""CPU, world_size 2 over gloo: the N>1 path of the hot path -- pair sharding and the single all-gather of the
-fixed-size pair records (the same code bench.py runs over RCCL)."""
+"""CPU, world_size 2 over gloo: the N>1 path of the hot path -- frame / pair sharding and the two all-gathers (feature records,
+pair records) with the "torch" transport of imagemosaicing_amd/dist.py (the same records the C ABI moves over RCCL; the
+kernels around them are covered on the GPU by tests/test_gpu_dist.py)."""
 import os
 import socket
 import subprocess
@@ -50,6 +51,31 @@ WORKER = textwrap.dedent("""
     g2, c2 = md.allgather_pair_results(local2, accepted_only=True)
     all2 = md.gathered_to_records(g2, c2)
     assert (all2["accepted"] == 1).all() and c2[rank] == int(rec2["accepted"].sum()) and len(all2) == sum(c2) < len(want)
+    # feature exchange, torch transport: ragged per-rank frame counts (19 frames over 2 ranks: 10 + 9), padded to n_max
+    F = 19
+    own = md.owned_frames(F, rank, world)
+    assert own == list(range(rank, F, world))
+    hdr = np.zeros(len(own), im.FEATURE_HEADER)
+    hdr["img_id"] = own; hdr["n_kp"] = [100 + k for k in own]; hdr["w"] = 640; hdr["h"] = 480
+    payload = torch.empty((len(own), im.FEATURE_RECORD_BYTES), dtype=torch.uint8)
+    for q, k in enumerate(own):
+        payload[q] = k %% 251
+    hdrs, gp, cnts = md.allgather_feature_records(hdr, payload, (F + world - 1) // world)
+    assert cnts == [10, 9] and gp.shape == (2, 10, im.FEATURE_RECORD_BYTES)
+    seen = []
+    for r in range(world):
+        assert hdrs[r]["img_id"].tolist() == list(range(r, F, world))
+        for q, k in enumerate(hdrs[r]["img_id"]):
+            assert int(hdrs[r]["n_kp"][q]) == 100 + k and bool((gp[r, q] == k %% 251).all())
+            seen.append(int(k))
+    assert sorted(seen) == list(range(F))
+    # every pair of the reference's window is owned by exactly one rank, and its i-frame by the same rank
+    for win in (2, 5, 182):
+        allp = {(int(a), int(b)) for a, b in im.pair_schedule(F, win)}
+        mine = {(int(a), int(b)) for a, b in im.pair_schedule(F, win, rank, world)}
+        sizes = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+        dist.all_gather(sizes, torch.tensor([len(mine)], dtype=torch.int64))
+        assert mine <= allp and sum(int(x) for x in sizes) == len(allp) and all(a %% world == rank for a, b in mine)
     if rank == 0:
         print("GLOO_OK", counts, c2)
     dist.destroy_process_group()

@@ -1,0 +1,138 @@
+"""GPU: the N>1 path on real kernels.
+
+  * world 2 on ONE device over gloo ("torch" transport: RCCL cannot place two ranks on one GPU): ONE survey, frames k mod 2 and
+    pairs i mod 2 per rank, feature records exchanged, results gathered -- the union equals what a single rank computes
+    alone, record for record, bit for bit (C4-mini: window 182 => all pairs).
+  * world 1 through the C ABI's own RCCL collectives (mi355_comm_init / mi355_allgather_features / mi355_allgather_results):
+    the calls the 8-GPU run makes, on a communicator of one rank.
+"""
+import os
+import socket
+import subprocess
+import sys
+import textwrap
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = textwrap.dedent("""
+    import os, sys
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, %r)
+    import imagemosaicing_amd as im
+    from imagemosaicing_amd import dist as md
+    from tests.synth_survey import render_frames
+
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    torch.cuda.set_device(0)
+    ctx = im.Context(0)
+    w, h, F, window = 800, 600, 13, 182
+    frames, A, gains, ws = render_frames(ctx, torch, F, w, h, per_row=5)      # the same survey on every rank
+    own = md.owned_frames(F, rank, world)
+    pairs = im.pair_schedule(F, window, rank, world)
+    assert (pairs[:, 0] %% world == rank).all()
+    ex = md.Exchange(ctx, "torch")
+    for k in own:
+        ctx.SiftExtractDev(k, frames[k].data_ptr(), w, h, ws)
+    ex.allgather_features(own, (F + world - 1) // world, "cuda")
+    # a frame owned by the other rank is resident now, with the same bytes the owner holds
+    other = (rank + 1) %% world
+    kp_o, d_o = ctx.GetFeatures(other)
+    results = torch.zeros((len(pairs), im.PAIR_RESULT.itemsize), dtype=torch.uint8, device="cuda")
+    ctx.MatchPairsDev(pairs, results.data_ptr(), 2.5, 9)
+    acc = ex.allgather_results(results, len(pairs), accepted_only=True)
+    full = ex.allgather_results(results, len(pairs), accepted_only=False)
+    acc = acc[np.lexsort((acc["j"], acc["i"]))]
+    full = full[np.lexsort((full["j"], full["i"]))]
+    if rank == 0:
+        # the whole survey on one rank
+        c1 = im.Context(0)
+        for k in range(F):
+            c1.SiftExtractDev(k, frames[k].data_ptr(), w, h, ws)
+        allp = im.pair_schedule(F, window)
+        ref = c1.MatchPairs(allp, 2.5, 9)
+        kp_r, d_r = c1.GetFeatures(other)
+        assert np.array_equal(kp_o.view(np.uint8), kp_r.view(np.uint8)) and np.array_equal(d_o, d_r), "installed features differ from the owner's"
+        assert len(full) == len(ref) == F * (F - 1) // 2
+        assert np.array_equal(full.view(np.uint8), ref.view(np.uint8)), "union of the ranks' records differs from the single-rank records"
+        racc = ref[ref["accepted"] == 1]
+        assert len(acc) == len(racc) and np.array_equal(acc.view(np.uint8), racc.view(np.uint8))
+        assert 0 < len(racc) < len(ref)
+        # the driver step on the gathered records gives the same transforms on every rank count
+        T1 = im.global_affine_align(im.results_to_match_pairs(racc), F)
+        T2 = im.global_affine_align(im.results_to_match_pairs(acc), F)
+        assert np.array_equal(T1["m"].view(np.uint32), T2["m"].view(np.uint32))
+        c1.close()
+        print("DIST_GPU_OK", len(ref), len(racc))
+    dist.barrier()
+    ctx.close()
+    dist.destroy_process_group()
+""")
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_two_ranks_one_survey_equals_single_rank(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER % ROOT)
+    env = dict(os.environ)
+    env.pop("RANK", None); env.pop("WORLD_SIZE", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), str(script)]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "DIST_GPU_OK" in r.stdout
+
+
+def test_rccl_collectives_world1():
+    import torch
+    import imagemosaicing_amd as im
+    from imagemosaicing_amd import dist as md
+    from tests.synth_survey import render_frames
+    ctx = im.Context(0)
+    w, h, F = 640, 480, 5
+    frames, A, gains, ws = render_frames(ctx, torch, F, w, h, per_row=5)
+    ex = md.Exchange(ctx, "rccl")                      # mi355_comm_unique_id + mi355_comm_init(rank 0 of 1)
+    for k in range(F):
+        ctx.SiftExtractDev(k, frames[k].data_ptr(), w, h, ws)
+    before = [ctx.GetFeatures(k) for k in range(F)]
+    ctx.AllGatherFeatures(list(range(F)), F)           # ncclAllGather of headers + records; own frames stay as they are
+    ctx.AllGatherFeatures([0, 2, 4], F)                # fewer frames than n_max: padding records are skipped
+    for k in range(F):
+        kp, d = ctx.GetFeatures(k)
+        assert np.array_equal(kp.view(np.uint8), before[k][0].view(np.uint8)) and np.array_equal(d, before[k][1])
+    pairs = im.pair_schedule(F, 182)
+    results = torch.zeros((len(pairs), im.PAIR_RESULT.itemsize), dtype=torch.uint8, device="cuda")
+    ctx.MatchPairsDev(pairs, results.data_ptr(), 2.5, 4)
+    ctx.synchronize()
+    loc = results.cpu().numpy().reshape(-1).view(im.PAIR_RESULT)
+    allr = ex.allgather_results(results, len(pairs), accepted_only=False)
+    assert np.array_equal(allr.view(np.uint8), loc.view(np.uint8))
+    acc = ex.allgather_results(results, len(pairs), accepted_only=True)
+    want = loc[loc["accepted"] == 1]
+    assert len(acc) == len(want) > 0 and np.array_equal(acc.view(np.uint8), want.view(np.uint8))
+    # pack -> install round trip under another id space (the transport-agnostic halves)
+    payload = torch.empty((2, im.FEATURE_RECORD_BYTES), dtype=torch.uint8, device="cuda")
+    hdr = ctx.PackFeaturesDev([1, 3], payload.data_ptr())
+    assert hdr["n_kp"].tolist() == [len(before[1][0]), len(before[3][0])]
+    hdr["img_id"] = [101, 103]
+    ctx.InstallFeaturesDev(hdr, payload.data_ptr())
+    for a, b in ((101, 1), (103, 3)):
+        kp, d = ctx.GetFeatures(a)
+        assert np.array_equal(kp.view(np.uint8), before[b][0].view(np.uint8)) and np.array_equal(d, before[b][1])
+    r1 = ctx.MatchPairs([(101, 103), (1, 3)], 2.5, 4)
+    assert np.array_equal(r1[0]["a"].view(np.uint8), r1[1]["a"].view(np.uint8)) and np.array_equal(r1[0]["H"].view(np.uint32), r1[1]["H"].view(np.uint32))
+    ex.close()
+    ctx.close()
