@@ -404,7 +404,13 @@ def main():
     elif rank == 0:
         out["cpu_baseline"] = None
     if rank == 0:
-        print(json.dumps(out))
+        # RCCL prints a version banner through C stdio at communicator creation: flush it first so that the JSON line is the last line
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)
     if ex is not None:
         ex.close()
     ctx.set_stream(None)
