@@ -179,6 +179,157 @@ extern "C" int mi355_mosaic_layout(const int* w, const int* h, int n, const floa
     return MI355_OK;
 }
 
+// ---- MosaicImagesRefined as ONE launch: every canvas tile is produced once -------------------------------------------------------
+// The reference composites image after image, each overwriting the canvas wherever it has a valid sample
+// (MosaicWithoutPos.cpp:2254-2348), so a canvas pixel ends up with the sample of the HIGHEST-index image that covers it.  A
+// workgroup here owns a 128 x 8 tile of the canvas, walks the images whose canvas bounding box meets the tile in DESCENDING
+// index, and takes for every pixel the first valid sample it meets: the same bytes, with one read of the winning image's
+// footprint and one write per canvas pixel instead of one read + one write per covering image (3.1 covering images per
+// pixel in the C3 survey, ~60 at C5) and no clearing pass (pixels nobody covers are stored as zeros).  All images go through
+// one launch; the result does not depend on any execution order.
+// The footprint of the tile in the image being tried is staged in LDS with aligned dword loads (rows of ~400 contiguous
+// bytes) and the 2x2 bilinear neighbourhoods are read from there; a pixel whose neighbourhood falls outside the staged window
+// (strong scale / rotation, float rounding at the rim) reads global memory instead -- staging is never a correctness matter.
+struct FrameDev {
+    const uint8_t* src; int w, h, ws;
+    int begX, endX, begY, endY;                 // clipped canvas bounding box the reference visits for this image (:2276-2306)
+    float inv[9];
+    int unit_den;                               // affine with m8 = 1: the two divisions are by exactly 1.0f
+};
+constexpr int MT_W = 128, MT_H = 8;             // canvas tile of one workgroup (256 threads x 4 pixels)
+constexpr int MT_COARSE = 256;                  // candidate lists are kept per 256 x 256 block of the canvas
+constexpr int MT_LDS = 24 * 1024;               // staged footprint, bytes
+
+// one thread per coarse block: the images whose box meets the block, highest index first
+__global__ __launch_bounds__(256) void mosaic_lists_kernel(const FrameDev* fr, int n, int bx_n, int by_n, int row0, uint16_t* lists, int* counts) {
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= bx_n * by_n) return;
+    const int by = b / bx_n, bx = b - by * bx_n;
+    const int x0 = bx * MT_COARSE, x1 = x0 + MT_COARSE - 1, y0 = row0 + by * MT_COARSE, y1 = y0 + MT_COARSE - 1;
+    uint16_t* l = lists + (size_t)b * n;
+    int cnt = 0;
+    for (int k = n - 1; k >= 0; k--) {
+        const FrameDev& f = fr[k];
+        if (f.begX <= x1 && f.endX >= x0 && f.begY <= y1 && f.endY >= y0) l[cnt++] = (uint16_t)k;
+    }
+    counts[b] = cnt;
+}
+
+__global__ __launch_bounds__(256) void mosaic_tile_kernel(const FrameDev* fr, int n, const uint16_t* lists, const int* counts, int bx_n,
+                                                          uint8_t* canvas, int cw, int cws, int row0, int row_end, float dGx, float dGy) {
+    __shared__ __attribute__((aligned(16))) uint8_t s_img[MT_LDS];
+    __shared__ int s_open;
+    const int tid = threadIdx.x;
+    const int tx0 = blockIdx.x * MT_W, ty0 = row0 + blockIdx.y * MT_H;
+    const int xg = tx0 + 4 * (tid & 31), yD = ty0 + (tid >> 5);
+    const int cb = ((ty0 - row0) / MT_COARSE) * bx_n + tx0 / MT_COARSE;
+    const uint16_t* list = lists + (size_t)cb * n;
+    const int cnt = counts[cb];
+    const bool row_ok = yD < row_end;
+    unsigned open = 0;                                   // pixels of this lane still without a sample
+#pragma unroll
+    for (int k = 0; k < 4; k++) if (row_ok && xg + k < cw) open |= 1u << k;
+    uint8_t out[12];
+#pragma unroll
+    for (int i = 0; i < 12; i++) out[i] = 0;
+    const int tx1 = tx0 + MT_W - 1 < cw - 1 ? tx0 + MT_W - 1 : cw - 1;
+    const int ty1 = ty0 + MT_H - 1 < row_end - 1 ? ty0 + MT_H - 1 : row_end - 1;
+    for (int e = 0; e < cnt; e++) {
+        const FrameDev& f = fr[list[e]];                 // uniform over the workgroup: scalar loads
+        if (f.begX > tx1 || f.endX < tx0 || f.begY > ty1 || f.endY < ty0) continue;
+        if (tid == 0) s_open = 0;
+        __syncthreads();
+        if (open) s_open = 1;                            // benign race: everybody writes 1
+        __syncthreads();
+        if (!s_open) break;                              // every pixel of the tile has its sample
+        const float w1 = (float)(f.w - 1), h1 = (float)(f.h - 1);
+        // ---- footprint of the tile in this image: bounding box of the four tile corners, one pixel of margin ----
+        float fx0 = 3.0e38f, fx1 = -3.0e38f, fy0 = 3.0e38f, fy1 = -3.0e38f;
+        bool fin = true;
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            const float xf = (float)((c & 1) ? tx1 : tx0) - dGx, yf = (float)((c & 2) ? ty1 : ty0) - dGy;
+            float xs, ys;
+            if (f.unit_den) { xs = f.inv[0] * xf + f.inv[1] * yf + f.inv[2]; ys = f.inv[3] * xf + f.inv[4] * yf + f.inv[5]; }
+            else hm::apply_div9(f.inv, xf, yf, xs, ys);
+            fin = fin && (xs == xs) && (ys == ys) && fabsf(xs) < 1.0e7f && fabsf(ys) < 1.0e7f;
+            fx0 = fminf(fx0, xs); fx1 = fmaxf(fx1, xs); fy0 = fminf(fy0, ys); fy1 = fmaxf(fy1, ys);
+        }
+        int sx0 = 0, sy0 = 0, srows = 0, pitch = 0, sb0 = 0;     // staged window: rows sy0.., bytes sb0.. (4-byte aligned) of each row
+        if (fin) {
+            sx0 = (int)floorf(fx0) - 1; int sx1 = (int)floorf(fx1) + 2;
+            sy0 = (int)floorf(fy0) - 1; int sy1 = (int)floorf(fy1) + 2;
+            sx0 = sx0 < 0 ? 0 : sx0; sy0 = sy0 < 0 ? 0 : sy0;
+            sx1 = sx1 > f.w - 1 ? f.w - 1 : sx1; sy1 = sy1 > f.h - 1 ? f.h - 1 : sy1;
+            if (sx1 >= sx0 && sy1 >= sy0) {
+                const uintptr_t base = reinterpret_cast<uintptr_t>(f.src);
+                sb0 = 3 * sx0;
+                // rows start 4-byte aligned in global memory when the image base and stride are; otherwise no staging
+                if (((base | (unsigned)f.ws) & 3) == 0) {
+                    sb0 &= ~3;
+                    const int sb1 = (3 * sx1 + 3 + 3) & ~3;                // one past the last byte, rounded up
+                    pitch = sb1 - sb0;
+                    const int sb1c = sb1 > f.ws ? f.ws : sb1;              // never read past the row stride
+                    pitch = ((sb1c - sb0) + 3) & ~3;
+                    srows = sy1 - sy0 + 1;
+                    if (pitch <= 0 || (size_t)pitch * srows > MT_LDS) srows = 0;
+                    if (sb0 + pitch > f.ws) srows = 0;
+                }
+            }
+        }
+        if (srows > 0) {
+            const int dw = pitch >> 2;
+            for (int i = tid; i < dw * srows; i += 256) {
+                const int r = i / dw, c = i - r * dw;
+                reinterpret_cast<unsigned*>(s_img)[i] = *reinterpret_cast<const unsigned*>(f.src + (size_t)(sy0 + r) * f.ws + sb0 + 4 * c);
+            }
+        }
+        __syncthreads();
+        if (open) {
+            const bool yin = yD >= f.begY && yD <= f.endY;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int xD = xg + k;
+                const bool want = ((open >> k) & 1u) && yin && xD >= f.begX && xD <= f.endX;
+                const float xf = (float)xD - dGx, yf = (float)yD - dGy;
+                float xs, ys;
+                if (f.unit_den) { xs = f.inv[0] * xf + f.inv[1] * yf + f.inv[2]; ys = f.inv[3] * xf + f.inv[4] * yf + f.inv[5]; }
+                else hm::apply_div9(f.inv, xf, yf, xs, ys);
+                const bool ok = want && (xs >= 0.0f && xs < w1 && ys >= 0.0f && ys < h1);      // also rejects NaN
+                if (!ok) continue;
+                const int xi = (int)xs, yi = (int)ys;
+                const float p = ys - (float)yi, q = xs - (float)xi;
+                float b00, g00, r00, b01, g01, r01, b10, g10, r10, b11, g11, r11;
+                const int lr = yi - sy0, lb = 3 * xi - sb0;
+                if (srows > 0 && lr >= 0 && lr + 1 < srows && lb >= 0 && lb + 6 <= pitch) {
+                    const uint8_t* l0 = s_img + lr * pitch + lb;
+                    load_pair<3>(l0, b00, g00, r00, b01, g01, r01);
+                    load_pair<3>(l0 + pitch, b10, g10, r10, b11, g11, r11);
+                } else {
+                    const uint8_t* g0 = f.src + (size_t)yi * f.ws + 3 * (size_t)xi;
+                    load_pair<3>(g0, b00, g00, r00, b01, g01, r01);
+                    load_pair<3>(g0 + f.ws, b10, g10, r10, b11, g11, r11);
+                }
+                out[3 * k + 0] = hm::bilin(b00, b01, b10, b11, p, q);
+                out[3 * k + 1] = hm::bilin(g00, g01, g10, g11, p, q);
+                out[3 * k + 2] = hm::bilin(r00, r01, r10, r11, p, q);
+                open &= ~(1u << k);
+            }
+        }
+        __syncthreads();                                 // s_img is restaged by the next image
+    }
+    if (!row_ok || xg >= cw) return;
+    uint8_t* drow = canvas + (size_t)yD * cws + 3 * (size_t)xg;
+    if (xg + 3 < cw) {
+        uint32_t* d32 = reinterpret_cast<uint32_t*>(drow);
+        const uint32_t* o32 = reinterpret_cast<const uint32_t*>(out);
+        d32[0] = o32[0]; d32[1] = o32[1]; d32[2] = o32[2];
+    } else {
+        for (int k = 0; xg + k < cw; k++) { drow[3 * k] = out[3 * k]; drow[3 * k + 1] = out[3 * k + 1]; drow[3 * k + 2] = out[3 * k + 2]; }
+        for (int b = 3 * cw; b < cws; b++) canvas[(size_t)yD * cws + b] = 0;       // row padding (cvZero'd in the reference, :2248)
+    }
+}
+
 int mi_mosaic_refined_dev(mi355_ctx* ctx, const uint8_t* const* d_imgs, const int* w, const int* h, const int* ws, int n,
                           const float* h9s, uint8_t* d_canvas, int cw, int ch, int cws, int row0, int rows) {
     int lw, lh, lws; float dG[2];
@@ -187,13 +338,16 @@ int mi_mosaic_refined_dev(mi355_ctx* ctx, const uint8_t* const* d_imgs, const in
     if (lw != cw || lh != ch || cws < cw * 3 || (cws & 3)) { ctx->set_error("mosaic_refined: canvas geometry does not match mi355_mosaic_layout"); return MI355_ERR_ARG; }
     if (row0 < 0) row0 = 0;
     if (rows < 0 || row0 + rows > ch) rows = ch - row0;
-    MI_HIP(hipMemsetAsync(d_canvas + (size_t)row0 * cws, 0, (size_t)rows * cws, ctx->stream));
+    if (rows <= 0) return MI355_OK;
+    if (n > 65535) { ctx->set_error("mosaic_refined: at most 65535 images"); return MI355_ERR_ARG; }
+    std::vector<FrameDev> fr;
+    fr.reserve(n);
     for (int k = 0; k < n; k++) {                  // ascending image order = overwrite order (MosaicWithoutPos.cpp:2254)
         const float* m = h9s + 9 * k;
         if (m[8] == 0.0f) continue;
-        WarpArgs a;
-        memset(&a, 0, sizeof(a));
-        if (mi_inverse_matrix_host(m, 3, a.inv, 1e-12f) != 1) continue;   // MosaicWithoutPos.cpp:2275 (reference: garbage invH)
+        FrameDev f;
+        memset(&f, 0, sizeof(f));
+        if (mi_inverse_matrix_host(m, 3, f.inv, 1e-12f) != 1) continue;   // MosaicWithoutPos.cpp:2275 (reference: garbage invH)
         float bminX = big(), bminY = big(), bmaxX = -big(), bmaxY = -big();
         {
             const float cx[4] = {0.0f, (float)(w[k] - 1), (float)(w[k] - 1), 0.0f};
@@ -216,13 +370,33 @@ int mi_mosaic_refined_dev(mi355_ctx* ctx, const uint8_t* const* d_imgs, const in
         if (endY > ch - 1) endY = ch - 1;
         if (begY < row0) begY = row0;                                   // canvas stripe
         if (endY > row0 + rows - 1) endY = row0 + rows - 1;
-        a.src = d_imgs[k]; a.w = w[k]; a.h = h[k]; a.ws = ws[k];
-        a.dst = d_canvas; a.dws = cws; a.mask = nullptr; a.mws = 0;
-        a.x_beg = begX; a.x_end = endX; a.y_beg = begY; a.y_end = endY;
-        a.dx = dG[0]; a.dy = dG[1];
-        launch_warp<3, false>(ctx, a);
+        if (endX < begX || endY < begY) continue;
+        if (!d_imgs[k] || w[k] < 2 || h[k] < 2 || ws[k] < 3 * w[k]) { ctx->set_error("mosaic_refined: bad image geometry"); return MI355_ERR_ARG; }
+        f.src = d_imgs[k]; f.w = w[k]; f.h = h[k]; f.ws = ws[k];
+        f.begX = begX; f.endX = endX; f.begY = begY; f.endY = endY;
+        f.unit_den = (f.inv[6] == 0.0f && f.inv[7] == 0.0f && f.inv[8] == 1.0f) ? 1 : 0;
+        fr.push_back(f);
+    }
+    const int nf = (int)fr.size();
+    const int bx_n = (cw + MT_COARSE - 1) / MT_COARSE, by_n = (rows + MT_COARSE - 1) / MT_COARSE;
+    DevBuf& dfr = ctx->buf("mosaic_frames");
+    DevBuf& dl = ctx->buf("mosaic_lists");
+    DevBuf& dc = ctx->buf("mosaic_counts");
+    MI_HIP(dfr.reserve(sizeof(FrameDev) * (size_t)(nf > 0 ? nf : 1)));
+    MI_HIP(dl.reserve(sizeof(uint16_t) * (size_t)bx_n * by_n * (size_t)(nf > 0 ? nf : 1)));
+    MI_HIP(dc.reserve(sizeof(int) * (size_t)bx_n * by_n));
+    if (nf > 0) MI_HIP(hipMemcpyAsync(dfr.p, fr.data(), sizeof(FrameDev) * (size_t)nf, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(mosaic_lists_kernel, dim3((bx_n * by_n + 255) / 256), dim3(256), 0, ctx->stream, dfr.as<FrameDev>(), nf, bx_n, by_n, row0, dl.as<uint16_t>(), dc.as<int>());
+    {
+        // SURVEY 8(d) algorithmic figure: every image read once and written once (6 P per image)
+        double bytes = 0.0;
+        for (const FrameDev& f : fr) bytes += 6.0 * (double)f.w * f.h;
+        ProfScope ps(ctx, "warp", bytes);
+        hipLaunchKernelGGL(mosaic_tile_kernel, dim3((cw + MT_W - 1) / MT_W, (rows + MT_H - 1) / MT_H), dim3(256), 0, ctx->stream,
+                           dfr.as<FrameDev>(), nf, dl.as<uint16_t>(), dc.as<int>(), bx_n, d_canvas, cw, cws, row0, row0 + rows, dG[0], dG[1]);
     }
     MI_HIP(hipGetLastError());
+    MI_HIP(hipStreamSynchronize(ctx->stream));           // `fr` goes out of scope
     return MI355_OK;
 }
 

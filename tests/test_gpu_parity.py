@@ -82,6 +82,41 @@ def test_mosaic_stripes_equal_whole(ctx):
     assert np.array_equal(canvas.cpu().numpy(), whole)
 
 
+def test_mosaic_many_overlapping_images_vs_oracle(ctx, oracle):
+    """the one-launch canvas (every tile walks its covering images in descending index and keeps the first valid sample) against the
+    oracle's image-after-image overwrite: heavy overlap, projective maps, skipped images (m8 = 0), canvas widths that are not
+    multiples of 4 or of the tile, images larger than the staging window's reach (strong scale), and odd stripes"""
+    import torch
+    import imagemosaicing_amd as im
+    rng = np.random.default_rng(5)
+    for trial, (n, w, h, spread, sc) in enumerate([(14, 200, 150, 160, 0.05), (9, 333, 257, 500, 0.3), (5, 640, 480, 300, 0.02), (40, 96, 64, 150, 0.1)]):
+        imgs = [texture(w, h, seed=100 * trial + k) for k in range(n)]
+        h9s = np.zeros((n, 9), np.float32)
+        for k in range(n):
+            H = np.eye(3) + rng.normal(0, sc, (3, 3))
+            H[0, 2] = rng.uniform(-spread, spread); H[1, 2] = rng.uniform(-spread, spread)
+            H[2, 0] = rng.normal(0, 2e-4) if k % 3 else 0.0; H[2, 1] = rng.normal(0, 2e-4) if k % 3 else 0.0; H[2, 2] = 1
+            h9s[k] = H.reshape(9)
+        h9s[0] = np.eye(3).reshape(9)
+        if n > 6:
+            h9s[3, 8] = 0; h9s[n - 1, 8] = 0          # invalid images are skipped (MosaicWithoutPos.cpp:2256)
+        rc, (ref, rw, rh, rws) = oracle.mosaic_images_refined(imgs, h9s)
+        assert rc == 0
+        got, cw, ch, cws = ctx.MosaicImagesRefined(imgs, h9s)
+        assert (cw, ch, cws) == (rw, rh, rws)
+        assert np.array_equal(got, ref), f"trial {trial}: {int((got != ref).sum())} bytes differ"
+        d_imgs = [torch.from_numpy(np.ascontiguousarray(i)).cuda() for i in imgs]
+        ws_ = [i.strides[0] for i in imgs]
+        canvas = torch.full((ch, cws), 201, dtype=torch.uint8, device="cuda")
+        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        cuts = sorted(set([0, ch] + [int(x) for x in rng.integers(1, ch, 4)]))
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            ctx.MosaicImagesRefinedDev([t.data_ptr() for t in d_imgs], [w] * n, [h] * n, ws_, h9s, canvas.data_ptr(), cw, ch, cws, a, b - a)
+        ctx.synchronize()
+        ctx.set_stream(None)
+        assert np.array_equal(canvas.cpu().numpy(), ref), f"trial {trial}: stripes differ"
+
+
 def test_chips_and_masks_vs_oracle(ctx, oracle):
     imgs, h9s = mosaic_case()
     ref = oracle.chips_and_masks(imgs, h9s, find_masks=True)
