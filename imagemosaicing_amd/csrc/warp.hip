@@ -182,7 +182,7 @@ extern "C" int mi355_mosaic_layout(const int* w, const int* h, int n, const floa
 // ---- MosaicImagesRefined as ONE launch: every canvas tile is produced once -------------------------------------------------------
 // The reference composites image after image, each overwriting the canvas wherever it has a valid sample
 // (MosaicWithoutPos.cpp:2254-2348), so a canvas pixel ends up with the sample of the HIGHEST-index image that covers it.  A
-// workgroup here owns a 128 x 8 tile of the canvas, walks the images whose canvas bounding box meets the tile in DESCENDING
+// workgroup here owns a 128 x 32 tile of the canvas, walks the images whose canvas bounding box meets the tile in DESCENDING
 // index, and takes for every pixel the first valid sample it meets: the same bytes, with one read of the winning image's
 // footprint and one write per canvas pixel instead of one read + one write per covering image (3.1 covering images per
 // pixel in the C3 survey, ~60 at C5) and no clearing pass (pixels nobody covers are stored as zeros).  All images go through
@@ -196,7 +196,7 @@ struct FrameDev {
     float inv[9];
     int unit_den;                               // affine with m8 = 1: the two divisions are by exactly 1.0f
 };
-constexpr int MT_W = 128, MT_H = 8;             // canvas tile of one workgroup (256 threads x 4 pixels)
+constexpr int MT_W = 128, MT_RPL = 4, MT_H = 8 * MT_RPL;   // canvas tile of one workgroup: 256 threads x 4 pixels x MT_RPL rows
 constexpr int MT_COARSE = 256;                  // candidate lists are kept per 256 x 256 block of the canvas
 constexpr int MT_LDS = 24 * 1024;               // staged footprint, bytes
 
@@ -221,17 +221,20 @@ __global__ __launch_bounds__(256) void mosaic_tile_kernel(const FrameDev* fr, in
     __shared__ int s_open;
     const int tid = threadIdx.x;
     const int tx0 = blockIdx.x * MT_W, ty0 = row0 + blockIdx.y * MT_H;
-    const int xg = tx0 + 4 * (tid & 31), yD = ty0 + (tid >> 5);
+    // a lane owns 4 adjacent pixels in each of MT_RPL rows (rows ty0 + (tid >> 5) + 8 j): the tile's list / image / staging
+    // latencies are paid once per 16 pixels of a lane
+    const int xg = tx0 + 4 * (tid & 31), yB = ty0 + (tid >> 5);
     const int cb = ((ty0 - row0) / MT_COARSE) * bx_n + tx0 / MT_COARSE;
     const uint16_t* list = lists + (size_t)cb * n;
     const int cnt = counts[cb];
-    const bool row_ok = yD < row_end;
-    unsigned open = 0;                                   // pixels of this lane still without a sample
+    unsigned open = 0;                                   // bit 4 j + k: pixel k of row j still without a sample
 #pragma unroll
-    for (int k = 0; k < 4; k++) if (row_ok && xg + k < cw) open |= 1u << k;
-    uint8_t out[12];
+    for (int j = 0; j < MT_RPL; j++)
 #pragma unroll
-    for (int i = 0; i < 12; i++) out[i] = 0;
+        for (int k = 0; k < 4; k++) if (yB + 8 * j < row_end && xg + k < cw) open |= 1u << (4 * j + k);
+    uint32_t out[MT_RPL][3];                             // 12 bytes per row: B G R of the 4 pixels
+#pragma unroll
+    for (int j = 0; j < MT_RPL; j++) { out[j][0] = 0; out[j][1] = 0; out[j][2] = 0; }
     const int tx1 = tx0 + MT_W - 1 < cw - 1 ? tx0 + MT_W - 1 : cw - 1;
     const int ty1 = ty0 + MT_H - 1 < row_end - 1 ? ty0 + MT_H - 1 : row_end - 1;
     for (int e = 0; e < cnt; e++) {
@@ -255,78 +258,88 @@ __global__ __launch_bounds__(256) void mosaic_tile_kernel(const FrameDev* fr, in
             fin = fin && (xs == xs) && (ys == ys) && fabsf(xs) < 1.0e7f && fabsf(ys) < 1.0e7f;
             fx0 = fminf(fx0, xs); fx1 = fmaxf(fx1, xs); fy0 = fminf(fy0, ys); fy1 = fmaxf(fy1, ys);
         }
-        int sx0 = 0, sy0 = 0, srows = 0, pitch = 0, sb0 = 0;     // staged window: rows sy0.., bytes sb0.. (4-byte aligned) of each row
+        int sy0 = 0, srows = 0, pitch = 0, sb0 = 0;      // staged window: rows sy0.., bytes sb0.. (4-byte aligned) of each row
         if (fin) {
-            sx0 = (int)floorf(fx0) - 1; int sx1 = (int)floorf(fx1) + 2;
+            int sx0 = (int)floorf(fx0) - 1, sx1 = (int)floorf(fx1) + 2;
             sy0 = (int)floorf(fy0) - 1; int sy1 = (int)floorf(fy1) + 2;
             sx0 = sx0 < 0 ? 0 : sx0; sy0 = sy0 < 0 ? 0 : sy0;
             sx1 = sx1 > f.w - 1 ? f.w - 1 : sx1; sy1 = sy1 > f.h - 1 ? f.h - 1 : sy1;
-            if (sx1 >= sx0 && sy1 >= sy0) {
-                const uintptr_t base = reinterpret_cast<uintptr_t>(f.src);
-                sb0 = 3 * sx0;
-                // rows start 4-byte aligned in global memory when the image base and stride are; otherwise no staging
-                if (((base | (unsigned)f.ws) & 3) == 0) {
-                    sb0 &= ~3;
-                    const int sb1 = (3 * sx1 + 3 + 3) & ~3;                // one past the last byte, rounded up
-                    pitch = sb1 - sb0;
-                    const int sb1c = sb1 > f.ws ? f.ws : sb1;              // never read past the row stride
-                    pitch = ((sb1c - sb0) + 3) & ~3;
-                    srows = sy1 - sy0 + 1;
-                    if (pitch <= 0 || (size_t)pitch * srows > MT_LDS) srows = 0;
-                    if (sb0 + pitch > f.ws) srows = 0;
-                }
+            // rows start 4-byte aligned in global memory when the image base and stride are; otherwise no staging
+            if (sx1 >= sx0 && sy1 >= sy0 && ((reinterpret_cast<uintptr_t>(f.src) | (unsigned)f.ws) & 3) == 0) {
+                sb0 = (3 * sx0) & ~3;
+                int sb1 = (3 * sx1 + 3 + 3) & ~3;                         // one past the last byte, rounded up
+                sb1 = sb1 > f.ws ? f.ws : sb1;                             // never past the row stride (a multiple of 4)
+                pitch = sb1 - sb0;
+                srows = sy1 - sy0 + 1;
+                if (pitch <= 0 || (size_t)pitch * srows > MT_LDS) srows = 0;
             }
         }
         if (srows > 0) {
-            const int dw = pitch >> 2;
-            for (int i = tid; i < dw * srows; i += 256) {
-                const int r = i / dw, c = i - r * dw;
+            const int dw = pitch >> 2, total = dw * srows;
+            const float inv_dw = 1.0f / (float)dw;
+            for (int i = tid; i < total; i += 256) {
+                int r = (int)((float)i * inv_dw);                          // i / dw without the integer division (i < 2^13: exact after the fix-up)
+                r -= (r * dw > i); r += ((r + 1) * dw <= i);
+                const int c = i - r * dw;
                 reinterpret_cast<unsigned*>(s_img)[i] = *reinterpret_cast<const unsigned*>(f.src + (size_t)(sy0 + r) * f.ws + sb0 + 4 * c);
             }
         }
         __syncthreads();
         if (open) {
-            const bool yin = yD >= f.begY && yD <= f.endY;
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const int xD = xg + k;
-                const bool want = ((open >> k) & 1u) && yin && xD >= f.begX && xD <= f.endX;
-                const float xf = (float)xD - dGx, yf = (float)yD - dGy;
-                float xs, ys;
-                if (f.unit_den) { xs = f.inv[0] * xf + f.inv[1] * yf + f.inv[2]; ys = f.inv[3] * xf + f.inv[4] * yf + f.inv[5]; }
-                else hm::apply_div9(f.inv, xf, yf, xs, ys);
-                const bool ok = want && (xs >= 0.0f && xs < w1 && ys >= 0.0f && ys < h1);      // also rejects NaN
-                if (!ok) continue;
-                const int xi = (int)xs, yi = (int)ys;
-                const float p = ys - (float)yi, q = xs - (float)xi;
-                float b00, g00, r00, b01, g01, r01, b10, g10, r10, b11, g11, r11;
-                const int lr = yi - sy0, lb = 3 * xi - sb0;
-                if (srows > 0 && lr >= 0 && lr + 1 < srows && lb >= 0 && lb + 6 <= pitch) {
-                    const uint8_t* l0 = s_img + lr * pitch + lb;
-                    load_pair<3>(l0, b00, g00, r00, b01, g01, r01);
-                    load_pair<3>(l0 + pitch, b10, g10, r10, b11, g11, r11);
-                } else {
-                    const uint8_t* g0 = f.src + (size_t)yi * f.ws + 3 * (size_t)xi;
-                    load_pair<3>(g0, b00, g00, r00, b01, g01, r01);
-                    load_pair<3>(g0 + f.ws, b10, g10, r10, b11, g11, r11);
+            for (int j = 0; j < MT_RPL; j++) {
+                const int yD = yB + 8 * j;
+                const bool yin = yD >= f.begY && yD <= f.endY;
+                const float yf = (float)yD - dGy;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int xD = xg + k;
+                    const bool want = ((open >> (4 * j + k)) & 1u) && yin && xD >= f.begX && xD <= f.endX;
+                    const float xf = (float)xD - dGx;
+                    float xs, ys;
+                    if (f.unit_den) { xs = f.inv[0] * xf + f.inv[1] * yf + f.inv[2]; ys = f.inv[3] * xf + f.inv[4] * yf + f.inv[5]; }
+                    else hm::apply_div9(f.inv, xf, yf, xs, ys);
+                    const bool ok = want && (xs >= 0.0f && xs < w1 && ys >= 0.0f && ys < h1);      // also rejects NaN
+                    if (!ok) continue;
+                    const int xi = (int)xs, yi = (int)ys;
+                    const float p = ys - (float)yi, q = xs - (float)xi;
+                    float b00, g00, r00, b01, g01, r01, b10, g10, r10, b11, g11, r11;
+                    const int lr = yi - sy0, lb = 3 * xi - sb0;
+                    if (srows > 0 && lr >= 0 && lr + 1 < srows && lb >= 0 && lb + 6 <= pitch) {
+                        const uint8_t* l0 = s_img + lr * pitch + lb;
+                        load_pair<3>(l0, b00, g00, r00, b01, g01, r01);
+                        load_pair<3>(l0 + pitch, b10, g10, r10, b11, g11, r11);
+                    } else {
+                        const uint8_t* g0 = f.src + (size_t)yi * f.ws + 3 * (size_t)xi;
+                        load_pair<3>(g0, b00, g00, r00, b01, g01, r01);
+                        load_pair<3>(g0 + f.ws, b10, g10, r10, b11, g11, r11);
+                    }
+                    const unsigned vb = hm::bilin(b00, b01, b10, b11, p, q), vg = hm::bilin(g00, g01, g10, g11, p, q), vr = hm::bilin(r00, r01, r10, r11, p, q);
+                    // bytes 3k, 3k+1, 3k+2 of the row's 12: static positions
+                    out[j][(3 * k) >> 2] |= vb << (8 * ((3 * k) & 3));
+                    out[j][(3 * k + 1) >> 2] |= vg << (8 * ((3 * k + 1) & 3));
+                    out[j][(3 * k + 2) >> 2] |= vr << (8 * ((3 * k + 2) & 3));
+                    open &= ~(1u << (4 * j + k));
                 }
-                out[3 * k + 0] = hm::bilin(b00, b01, b10, b11, p, q);
-                out[3 * k + 1] = hm::bilin(g00, g01, g10, g11, p, q);
-                out[3 * k + 2] = hm::bilin(r00, r01, r10, r11, p, q);
-                open &= ~(1u << k);
             }
         }
         __syncthreads();                                 // s_img is restaged by the next image
     }
-    if (!row_ok || xg >= cw) return;
-    uint8_t* drow = canvas + (size_t)yD * cws + 3 * (size_t)xg;
-    if (xg + 3 < cw) {
-        uint32_t* d32 = reinterpret_cast<uint32_t*>(drow);
-        const uint32_t* o32 = reinterpret_cast<const uint32_t*>(out);
-        d32[0] = o32[0]; d32[1] = o32[1]; d32[2] = o32[2];
-    } else {
-        for (int k = 0; xg + k < cw; k++) { drow[3 * k] = out[3 * k]; drow[3 * k + 1] = out[3 * k + 1]; drow[3 * k + 2] = out[3 * k + 2]; }
-        for (int b = 3 * cw; b < cws; b++) canvas[(size_t)yD * cws + b] = 0;       // row padding (cvZero'd in the reference, :2248)
+    if (xg >= cw) return;
+#pragma unroll
+    for (int j = 0; j < MT_RPL; j++) {
+        const int yD = yB + 8 * j;
+        if (yD >= row_end) continue;
+        uint8_t* drow = canvas + (size_t)yD * cws + 3 * (size_t)xg;
+        if (xg + 3 < cw) {
+            uint32_t* d32 = reinterpret_cast<uint32_t*>(drow);
+            d32[0] = out[j][0]; d32[1] = out[j][1]; d32[2] = out[j][2];
+        } else {
+#pragma unroll
+            for (int b = 0; b < 9; b++)                  // at most 3 pixels; static indices keep out[] in registers
+                if (xg + b / 3 < cw) drow[b] = (uint8_t)(out[j][b >> 2] >> (8 * (b & 3)));
+            for (int b = 3 * cw; b < cws; b++) canvas[(size_t)yD * cws + b] = 0;       // row padding (cvZero'd in the reference, :2248)
+        }
     }
 }
 
