@@ -405,6 +405,19 @@ def mosaic_layout(w, h, h9s):
     return cw.value, ch.value, cws.value, dG
 
 
+def resample_by_overlap(w, h, h9s, overlapT=0.7):
+    """ResampleByOverlap (MosaicImage.cpp:2069-2201): keep[k] = vecAbandonInd[k]"""
+    L = load_library()
+    w = np.ascontiguousarray(w, np.int32)
+    h = np.ascontiguousarray(h, np.int32)
+    h9s = np.ascontiguousarray(h9s, np.float32)
+    keep = np.zeros(len(w), np.uint8)
+    rc = L.mi355_resample_by_overlap(_p(w), _p(h), len(w), _p(h9s), C.c_float(overlapT), _p(keep))
+    if rc != 0:
+        raise Mi355Error(rc, "resample_by_overlap")
+    return keep
+
+
 def pair_schedule(n_images, window, rank=0, world=1):
     L = load_library()
     n = C.c_int(0)

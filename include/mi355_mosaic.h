@@ -172,6 +172,12 @@ int  mi355_chips_and_masks(mi355_ctx* ctx, const uint8_t* const* imgs, const int
                            int* n_chips, mi355_chip_info** chips, uint8_t*** chip_imgs, uint8_t*** masks,
                            int* canvas_w, int* canvas_h);
 
+/* ResampleByOverlap(pImages, n, overlapT, pImgT, vecAbandonInd), MosaicImage.cpp:2069-2201 (LaplacianPyramidBlending calls it with
+ * overlapT = 0.7f, :2227-2230): keep[k] = vecAbandonInd[k] -- image k is dropped (0) when the quadrilateral it covers overlaps an
+ * earlier KEPT image's by more than overlapT of its own area; image 0 and image n-1 are always kept.  Host geometry (no ctx): the
+ * result is the keep[] argument of the two calls around it.  h9s must already carry the resScale multiplication (:2216-2223). */
+int  mi355_resample_by_overlap(const int* w, const int* h, int n, const float* h9s, float overlapT, uint8_t* keep);
+
 /* Multiband blend of those chips ("next" row f3 of SURVEY 8f): replaces detail::MultiBandBlender blender(false, band) --
  * prepare(Rect(0,0,canvas_w,canvas_h)), feed(chip as CV_16S, mask, corner) per chip, blend, convertTo(CV_8U)
  * (MosaicImage.cpp:2296-2299, 2451-2486; the reference passes band = 5).  chips / masks / info exactly as

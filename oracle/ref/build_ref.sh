@@ -1,6 +1,6 @@
 #!/bin/bash
 # Build recipe for oracle/_ref/libref_oracle.so : the REFERENCE'S OWN arithmetic
-# (RANSAC, homography solve, NLLS, grid selection, warps) compiled with g++ from
+# (RANSAC, homography solve, NLLS, grid selection, warps, chips + distance-map masks, ResampleByOverlap) compiled with g++ from
 # the sources where they lie under /root/reference.  Test infrastructure only.
 #
 #  * No reference source is copied into the repo: line ranges are extracted at
@@ -44,6 +44,28 @@ u8 MosaicWithoutPos.h   | sed -n '135,153p'   > "$G/matchpointpairs.inc"  # Matc
 # MosaicImagesRefined (float): bbox part and registration loop, without the cv* allocation lines 2245-2248
 u8 MosaicWithoutPos.cpp | sed -n '2199,2244p' > "$G/mir_bbox.inc"
 u8 MosaicWithoutPos.cpp | sed -n '2250,2349p' | sed 's/unsigned char(/(unsigned char)(/g' > "$G/mir_loop.inc"
+# ResampleByOverlap and its quadrilateral geometry (MosaicImage.cpp:1884-2201) with the helpers it calls
+u8 Bitmap.h        | sed -n '17p;54p'     > "$G/in_pi.inc"                # #define _IN ; const float pi
+u8 mosaicimage.h   | sed -n '19,22p'      > "$G/rect4.inc"                # Rectangle4Points
+u8 imageMath.h     | sed -n '26,88p'      > "$G/angleofpoint.inc"         # template AngleofPoint
+u8 ImageMath.cpp   | sed -n '9,54p'       > "$G/angle360.inc"             # AngleofPoint360
+u8 ImageMath.cpp   | sed -n '88,103p'     > "$G/lineof2.inc"              # LineOf2Points1
+u8 ImageMath.cpp   | sed -n '144,176p'    > "$G/abctopolar.inc"           # ABCToPolar
+u8 ImageMath.cpp   | sed -n '399,413p'    > "$G/intersec.inc"             # IntersectionPointOf2PolarLines
+u8 MosaicImage.cpp | sed -n '1884,2067p'  > "$G/quad_geom.inc"            # AreaOfQuadrangle .. GetPointsInOverlapRegion
+u8 MosaicImage.cpp | sed -n '2069,2201p'  > "$G/resample.inc"             # ResampleByOverlap
+# FindMasksByDistMap (MosaicImage.cpp:1761-1881) without its cvZero loop (:1837-1841: the harness zeroes the masks there)
+u8 MosaicImage.cpp | sed -n '1761,1836p'  > "$G/fm_head.inc"
+u8 MosaicImage.cpp | sed -n '1842,1881p'  > "$G/fm_tail.inc"
+# LaplacianPyramidBlending, warp stage (MosaicImage.cpp:2216-2460) without the OpenCV object lines: scale (:2216-2223), canvas
+# box (:2233-2294), per-image head (:2302-2340), pixel loop (:2344-2448), bookkeeping (:2454-2456, :2459-2460).  Skipped:
+# :2296-2301 (MultiBandBlender / cv::Mat vectors), :2342-2343 (cvCreateImage: the harness allocates the two IplImages),
+# :2450-2453 (cv::Mat convertTo), :2458 (cvReleaseImage).
+u8 MosaicImage.cpp | sed -n '2216,2223p'  > "$G/lpb_scale.inc"
+u8 MosaicImage.cpp | sed -n '2233,2294p'  > "$G/lpb_bbox.inc"
+u8 MosaicImage.cpp | sed -n '2302,2340p'  > "$G/lpb_head.inc"
+u8 MosaicImage.cpp | sed -n '2344,2448p' | sed 's/unsigned char(/(unsigned char)(/g' > "$G/lpb_loop.inc"
+u8 MosaicImage.cpp | sed -n '2454,2456p;2459,2460p' > "$G/lpb_tail.inc"
 # --- compile ---------------------------------------------------------------------
 g++ -std=c++11 -O2 -ffp-contract=off -fpermissive -w -fPIC -shared \
     -I "$G" -I "$R" -I "$CVI" "$HERE/ref_oracle.cpp" -o "$OUT/libref_oracle.so"

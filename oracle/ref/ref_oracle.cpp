@@ -49,6 +49,23 @@ using namespace cv;
 
 struct RefImagePose { IplImage* pImg; };  // harness-side holder: the extract only reads .pImg
 
+// ---- quadrilateral geometry + ResampleByOverlap, FindMasksByDistMap, LaplacianPyramidBlending warp stage -------------------
+namespace pool {
+#include "in_pi.inc"                     // Bitmap.h:17 (#define _IN), :54 (const float pi)
+}
+#include "rect4.inc"                     // mosaicimage.h:19-22
+#include "angleofpoint.inc"              // imageMath.h:26-88
+#include "angle360.inc"                  // ImageMath.cpp:9-54
+#include "lineof2.inc"                   // ImageMath.cpp:88-103
+#include "abctopolar.inc"                // ImageMath.cpp:144-176
+#include "intersec.inc"                  // ImageMath.cpp:399-413
+#include "quad_geom.inc"                 // MosaicImage.cpp:1884-2067
+#include "resample.inc"                  // MosaicImage.cpp:2069-2201
+#include "fm_head.inc"                   // MosaicImage.cpp:1761-1836  FindMasksByDistMap: header + distance maps
+    for (int n = 0; n < nImages; n++)    // :1837-1841 cvZero(pMasks[n]) -- zeroing done by the harness (no OpenCV library here)
+        memset(pMasks[n]->imageData, 0, (size_t)pMasks[n]->widthStep * pMasks[n]->height);
+#include "fm_tail.inc"                   // MosaicImage.cpp:1842-1881  ownership loop, frees, return
+
 static void quiet() {
     static bool done = false;
     if (!done) { std::cout.setstate(std::ios_base::failbit); done = true; }
@@ -150,6 +167,87 @@ int ref_mosaic_images_refined(unsigned char** imgs, const int* ws_, const int* h
     {
 #include "mir_loop.inc"
     }
+    return 0;
+}
+
+// ResampleByOverlap(pImages, n, overlapT, pImgT, vecAbandonInd), MosaicImage.cpp:2069-2201: only width / height of the images are read
+int ref_resample_by_overlap(const int* ws_, const int* hs_, int imagesNum, const float* h9s, float overlapT, int* keep) {
+    quiet();
+    vector<IplImage> hdr(imagesNum); vector<IplImage*> pv(imagesNum); vector<ProjectMat> T(imagesNum);
+    for (int i = 0; i < imagesNum; i++) {
+        memset(&hdr[i], 0, sizeof(IplImage));
+        hdr[i].nSize = sizeof(IplImage); hdr[i].nChannels = 3; hdr[i].depth = 8; hdr[i].width = ws_[i]; hdr[i].height = hs_[i];
+        pv[i] = &hdr[i];
+        memcpy(T[i].m, h9s + 9 * i, 9 * sizeof(float));
+    }
+    vector<int> v;
+    int rc = ResampleByOverlap(&pv[0], imagesNum, overlapT, &T[0], v);
+    for (int i = 0; i < imagesNum; i++) keep[i] = v[i];
+    return rc;
+}
+
+// LaplacianPyramidBlending's warp stage (MosaicImage.cpp:2216-2460) + FindMasksByDistMap (:2471-2472): results are parked in
+// g_lpb and fetched chip by chip.  keep_in == NULL runs the reference's own ResampleByOverlap(.., 0.7f, ..) (:2227-2230).
+struct LpbChip { int x0, y0, w, h, img; float quad[8]; IplImage* chip; IplImage* mask; };
+static vector<LpbChip> g_lpb;
+static int g_lpb_w = 0, g_lpb_h = 0;
+static IplImage* harness_image(int w, int h, int ch) {      // stands where cvCreateImage(cvSize(w, h), 8, ch) stood: rows aligned to 4 bytes
+    IplImage* im = (IplImage*)calloc(1, sizeof(IplImage));
+    im->nSize = sizeof(IplImage); im->nChannels = ch; im->depth = 8; im->width = w; im->height = h;
+    im->widthStep = (w * ch + 3) & ~3;
+    im->imageData = (char*)calloc((size_t)im->widthStep * (h > 0 ? h : 1), 1);   // zeroed: pixels without a sample are left untouched by the reference
+    return im;
+}
+static void harness_free(IplImage* im) { if (im) { free(im->imageData); free(im); } }
+
+int ref_lpb_run(unsigned char** imgs, const int* ws_, const int* hs_, const int* wss_, int imagesNum, const float* h9s, float resScale,
+                const unsigned char* keep_in, int find_masks, int* canvas_w, int* canvas_h) {
+    quiet();
+    for (size_t k = 0; k < g_lpb.size(); k++) { harness_free(g_lpb[k].chip); harness_free(g_lpb[k].mask); }
+    g_lpb.clear();
+    vector<IplImage> hdr(imagesNum); vector<IplImage*> pv(imagesNum); vector<ProjectMat> T(imagesNum);
+    for (int i = 0; i < imagesNum; i++) {
+        memset(&hdr[i], 0, sizeof(IplImage));
+        hdr[i].nSize = sizeof(IplImage); hdr[i].nChannels = 3; hdr[i].depth = 8;
+        hdr[i].width = ws_[i]; hdr[i].height = hs_[i]; hdr[i].widthStep = wss_[i]; hdr[i].imageData = (char*)imgs[i];
+        pv[i] = &hdr[i];
+        memcpy(T[i].m, h9s + 9 * i, 9 * sizeof(float));
+    }
+    IplImage** pImages = &pv[0];
+    ProjectMat* pImgT = &T[0];
+#include "lpb_scale.inc"                 // :2216-2223
+    vector<int> vecAbandonInd;
+    if (keep_in) { for (int i = 0; i < imagesNum; i++) vecAbandonInd.push_back(keep_in[i] ? 1 : 0); }
+    else ResampleByOverlap(pImages, imagesNum, 0.7f, pImgT, vecAbandonInd);      // :2227-2230
+#include "lpb_bbox.inc"                  // :2233-2294
+    vector<IplImage*> harness_chips; vector<int> harness_img;
+#include "lpb_head.inc"                  // :2302-2340  (opens the per-image loop)
+        IplImage* pChipImage = harness_image(wChip, hChip, pImages[0]->nChannels);   // :2342
+        IplImage* pMask = harness_image(wChip, hChip, 1);                            // :2343
+#include "lpb_loop.inc"                  // :2344-2448
+        harness_chips.push_back(pChipImage); harness_img.push_back(n);               // instead of the cv::Mat conversion, :2450-2453
+#include "lpb_tail.inc"                  // :2454-2456, :2459-2460 (closes the loop)
+    if (find_masks && !vecMask.empty())
+        FindMasksByDistMap(&vecMask[0], (int)vecMask.size(), &vecRectPoints[0], &vecCorners[0], newWidth, newHeight);   // :2471-2472
+    for (int k = 0; k < nValid; k++) {
+        LpbChip c; c.x0 = vecCorners[k].x; c.y0 = vecCorners[k].y; c.w = harness_chips[k]->width; c.h = harness_chips[k]->height; c.img = harness_img[k];
+        for (int i = 0; i < 4; i++) { c.quad[2 * i] = vecRectPoints[k].pt[i].x; c.quad[2 * i + 1] = vecRectPoints[k].pt[i].y; }
+        c.chip = harness_chips[k]; c.mask = vecMask[k];
+        g_lpb.push_back(c);
+    }
+    delete[] pBegBox; delete[] pEndBox; delete[] pQuadrangleCorners;
+    g_lpb_w = newWidth; g_lpb_h = newHeight;
+    *canvas_w = newWidth; *canvas_h = newHeight;
+    return nValid;
+}
+// geometry of chip k: x0 y0 w h img (5 ints) + quad (8 floats); chip / mask rows are (w*3+3)&~3 and (w+3)&~3 bytes
+int ref_lpb_chip(int k, int* geom5, float* quad8, unsigned char* chip, unsigned char* mask) {
+    if (k < 0 || k >= (int)g_lpb.size()) return -1;
+    const LpbChip& c = g_lpb[k];
+    geom5[0] = c.x0; geom5[1] = c.y0; geom5[2] = c.w; geom5[3] = c.h; geom5[4] = c.img;
+    memcpy(quad8, c.quad, sizeof(c.quad));
+    if (chip) memcpy(chip, c.chip->imageData, (size_t)c.chip->widthStep * c.h);
+    if (mask) memcpy(mask, c.mask->imageData, (size_t)c.mask->widthStep * c.h);
     return 0;
 }
 

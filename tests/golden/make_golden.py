@@ -3,6 +3,8 @@
 oracle/ref/build_ref.sh from /root/reference) and copies the reference's committed run artefacts
 (data files, not source): Release/feature_temp/matchPairs.{match,txt} and Release/tran0.txt.
 
+blend_golden.npz: ResampleByOverlap keep flags and the chips / masks of LaplacianPyramidBlending's warp stage + FindMasksByDistMap.
+
 Run in the build container (needs /root/reference):   python tests/golden/make_golden.py
 Every array pair below is (seeded input, output of the reference's own code compiled with
 g++ -O2 -ffp-contract=off, x86-64 SSE2).  The tests compare the oracle restatement and the HIP
@@ -147,6 +149,20 @@ def main():
     w_out["mosaic_skip"] = canvas
     w_out["mosaic_skip_dims"] = np.array([cw, ch, cws], np.int32)
     np.savez_compressed(os.path.join(HERE, "warp_golden.npz"), **w_out)
+    # ---- blend path pieces the reference's own code produces: ResampleByOverlap decisions, chips + distance-map masks ----
+    from tests.test_overlap import overlap_layouts, blend_cases
+    b_out = {}
+    for k, (w, h, h9) in enumerate(overlap_layouts(7)):
+        b_out[f"keep{k}"] = R.resample_by_overlap(w, h, h9, 0.7)
+    for tag, imgs, h9s in blend_cases():
+        r = R.chips_and_masks(imgs, h9s, keep=np.ones(len(imgs), np.uint8), find_masks=True)
+        b_out[f"{tag}_dims"] = np.array([r["cw"], r["ch"], len(r["chips"])], np.int32)
+        for i in range(len(r["chips"])):
+            b_out[f"{tag}_chip{i}"] = r["chip_imgs"][i]
+            b_out[f"{tag}_mask{i}"] = r["masks"][i]
+            b_out[f"{tag}_quad{i}"] = r["chips"][i]["quad"].view(np.uint32)
+            b_out[f"{tag}_geom{i}"] = np.array([r["chips"][i][f] for f in ("x0", "y0", "w", "h", "img")], np.int32)
+    np.savez_compressed(os.path.join(HERE, "blend_golden.npz"), **b_out)
     print("golden vectors written to", HERE)
 
 

@@ -12,6 +12,10 @@ def warp_golden():
     return np.load(os.path.join(GOLD, "warp_golden.npz"))
 
 
+def blend_golden():
+    return np.load(os.path.join(GOLD, "blend_golden.npz"))
+
+
 def bits(a):
     return np.ascontiguousarray(a, np.float32).view(np.uint32)
 

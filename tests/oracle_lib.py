@@ -310,6 +310,42 @@ class Ref:
         return rc, (canvas, cw.value, ch.value, cws.value)
 
 
+    def resample_by_overlap(self, w, h, h9s, overlapT=0.7):
+        """the reference's ResampleByOverlap (MosaicImage.cpp:2069-2201)"""
+        w = np.ascontiguousarray(w, np.int32); h = np.ascontiguousarray(h, np.int32)
+        h9s = np.ascontiguousarray(h9s, np.float32)
+        keep = np.zeros(len(w), np.int32)
+        self.L.ref_resample_by_overlap(_p(w), _p(h), len(w), _p(h9s), C.c_float(overlapT), _p(keep))
+        return keep.astype(np.uint8)
+
+    def chips_and_masks(self, imgs, h9s, keep=None, find_masks=True, res_scale=1.0):
+        """the reference's LaplacianPyramidBlending warp stage (MosaicImage.cpp:2216-2460) + FindMasksByDistMap (:1761-1881);
+        keep=None runs the reference's own ResampleByOverlap(0.7)"""
+        n = len(imgs)
+        imgs = [np.ascontiguousarray(i) for i in imgs]
+        ptrs = (C.c_void_p * n)(*[i.ctypes.data for i in imgs])
+        w = np.array([i.shape[1] for i in imgs], np.int32)
+        h = np.array([i.shape[0] for i in imgs], np.int32)
+        ws = np.array([i.strides[0] for i in imgs], np.int32)
+        h9s = np.ascontiguousarray(h9s, np.float32)
+        keep_a = None if keep is None else np.ascontiguousarray(keep, np.uint8)
+        cw, ch = C.c_int(), C.c_int()
+        nv = self.L.ref_lpb_run(ptrs, _p(w), _p(h), _p(ws), n, _p(h9s), C.c_float(res_scale),
+                                _p(keep_a) if keep_a is not None else None, int(bool(find_masks)), C.byref(cw), C.byref(ch))
+        chips = np.zeros(nv, CHIPINFO)
+        cimgs, masks = [], []
+        for k in range(nv):
+            g = np.zeros(5, np.int32); q = np.zeros(8, np.float32)
+            self.L.ref_lpb_chip(k, _p(g), _p(q), None, None)
+            cws, mws = (int(g[2]) * 3 + 3) & ~3, (int(g[2]) + 3) & ~3
+            chip = np.zeros((int(g[3]), cws), np.uint8); mask = np.zeros((int(g[3]), mws), np.uint8)
+            self.L.ref_lpb_chip(k, _p(g), _p(q), _p(chip), _p(mask))
+            chips[k]["x0"], chips[k]["y0"], chips[k]["w"], chips[k]["h"], chips[k]["img"] = g
+            chips[k]["quad"] = q
+            cimgs.append(chip); masks.append(mask)
+        return dict(cw=cw.value, ch=ch.value, chips=chips, chip_imgs=cimgs, masks=masks)
+
+
 _ORC = None
 _ORC_FAST = None
 _REF = None

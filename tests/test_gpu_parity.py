@@ -134,6 +134,25 @@ def test_chips_and_masks_vs_oracle(ctx, oracle):
         assert np.array_equal(got_v["masks"][k], ref["valid"][k])
 
 
+def test_chips_and_masks_golden_from_reference(ctx, lib):
+    """chips, validity and distance-map ownership masks against the vectors the reference's OWN code produced
+    (LaplacianPyramidBlending warp stage MosaicImage.cpp:2216-2460 + FindMasksByDistMap :1761-1881 through oracle/_ref)"""
+    from tests.golden_util import blend_golden
+    from tests.test_overlap import blend_cases, overlap_layouts
+    g = blend_golden()
+    for tag, imgs, h9s in blend_cases():
+        got = ctx.ChipsAndMasks(imgs, h9s, find_masks=True)
+        assert [got["cw"], got["ch"], len(got["chips"])] == g[f"{tag}_dims"].tolist()
+        for k in range(len(got["chips"])):
+            assert [int(got["chips"][k][f]) for f in ("x0", "y0", "w", "h", "img")] == g[f"{tag}_geom{k}"].tolist()
+            assert np.array_equal(bits(got["chips"][k]["quad"]), g[f"{tag}_quad{k}"])
+            assert np.array_equal(got["chip_imgs"][k], g[f"{tag}_chip{k}"]), (tag, k)
+            assert np.array_equal(got["masks"][k], g[f"{tag}_mask{k}"]), (tag, k)
+    # ResampleByOverlap's decision feeds the same call as keep[]
+    for k, (w, h, h9) in enumerate(overlap_layouts(7)):
+        assert np.array_equal(lib.resample_by_overlap(w, h, h9, 0.7), g[f"keep{k}"])
+
+
 # ---------------------------------------------------------------------------------------------- RANSAC
 def test_ransac2d_golden(ctx):
     g = math_golden()
