@@ -461,6 +461,18 @@ def write_transforms(path, t):
         raise Mi355Error(rc, "write_transforms")
 
 
+def load_transforms(path, tran0=False):
+    """ImportTransform's format (count + 9 floats each), or with tran0=True the rows OutTransform writes (tran0.txt)"""
+    L = load_library()
+    ptr, n = C.c_void_p(), C.c_int(0)
+    rc = (L.mi355_load_tran0 if tran0 else L.mi355_load_transforms)(path.encode(), C.byref(ptr), C.byref(n))
+    if rc != 0:
+        raise Mi355Error(rc, "load_transforms")
+    out = _copy_out(ptr, n.value * IMAGE_TRANSFORM.itemsize, IMAGE_TRANSFORM)
+    L.mi355_free(ptr)
+    return out
+
+
 def write_keypoints(path, kp):
     kp = np.ascontiguousarray(kp, KEYPOINT)
     rc = load_library().mi355_write_keypoints(path.encode(), _p(kp), len(kp))

@@ -71,6 +71,52 @@ extern "C" int mi355_write_transforms(const char* path, const mi355_image_transf
     return out.fail() ? MI355_ERR_FAILED : MI355_OK;
 }
 
+// ImportTransform (MosaicWithoutPos.cpp:2820-2843): a count, then 9 floats per transform; fixed = 1 for the first, 0 for the rest.
+extern "C" int mi355_load_transforms(const char* path, mi355_image_transform** t, int* n) {
+    if (!path || !t || !n) return MI355_ERR_ARG;
+    *t = nullptr; *n = 0;
+    std::ifstream in(path);
+    if (!in) return MI355_ERR_FAILED;
+    int cnt = 0;
+    in >> cnt;
+    if (!in || cnt < 0 || cnt > 10000000) return MI355_ERR_FAILED;
+    mi355_image_transform* v = (mi355_image_transform*)malloc(sizeof(mi355_image_transform) * (size_t)(cnt > 0 ? cnt : 1));
+    if (!v) return MI355_ERR_NOMEM;
+    for (int i = 0; i < cnt; i++) {
+        for (int j = 0; j < 9; j++) in >> v[i].m[j];
+        v[i].fixed = (i == 0) ? 1 : 0;
+    }
+    if (!in && cnt > 0) { free(v); return MI355_ERR_FAILED; }
+    *t = v; *n = cnt;
+    return MI355_OK;
+}
+
+// The file OutTransform writes (tran0.txt, :2798-2818): one row per image 1..n-1, "m0 .. m7 fixed".  Image 0 (the fixed reference,
+// identity) is not in the file and is put back in front, so that n_images transforms come out; m8 = 1.
+extern "C" int mi355_load_tran0(const char* path, mi355_image_transform** t, int* n) {
+    if (!path || !t || !n) return MI355_ERR_ARG;
+    *t = nullptr; *n = 0;
+    std::ifstream in(path);
+    if (!in) return MI355_ERR_FAILED;
+    std::vector<mi355_image_transform> v(1);
+    for (int j = 0; j < 9; j++) v[0].m[j] = (j % 4 == 0) ? 1.0f : 0.0f;
+    v[0].fixed = 1;
+    for (;;) {
+        mi355_image_transform r;
+        bool ok = true;
+        for (int j = 0; j < 8 && ok; j++) ok = (bool)(in >> r.m[j]);
+        if (!ok) break;
+        if (!(in >> r.fixed)) return MI355_ERR_FAILED;               // a torn row
+        r.m[8] = 1.0f;
+        v.push_back(r);
+    }
+    mi355_image_transform* out = (mi355_image_transform*)malloc(sizeof(mi355_image_transform) * v.size());
+    if (!out) return MI355_ERR_NOMEM;
+    memcpy(out, v.data(), sizeof(mi355_image_transform) * v.size());
+    *t = out; *n = (int)v.size();
+    return MI355_OK;
+}
+
 extern "C" int mi355_write_keypoints(const char* path, const mi355_keypoint* kp, int n) {
     if (!path || n < 0 || (n > 0 && !kp)) return MI355_ERR_ARG;
     if (n == 0) return MI355_OK;                    // :4691 only written when non-empty

@@ -206,7 +206,7 @@ __global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     if (tid < 64) s_T2[tid] = 0.0f;
     __syncthreads();
 
-    long long T2 = wall_clock64(); int nit = 0;
+    long long T2 = wall_clock64();
     // ---- NonlinearLeastSquareProjection2 over the inliers from the winning hypothesis (:1977-1986) ----
     const int rows = 2 * cnt;
     for (int it = 0; it < 15; it++) {
@@ -252,7 +252,6 @@ __global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             s_state[7] = done;
         }
         __syncthreads();
-        nit++;
         if (s_state[7]) break;
     }
     if (a.dbg && tid == 0) { long long* d = a.dbg + 8 * pair; d[0] = T1 - T0; d[1] = T2 - T1; d[2] = wall_clock64() - T2; d[3] = nchunk; d[4] = Tsolve; d[5] = Tsup; d[6] = Trep; d[7] = s_npol; }

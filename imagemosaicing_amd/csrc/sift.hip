@@ -609,7 +609,7 @@ constexpr int NREG = 64, REG_STRIDE = 32;   // candidate list split into 64 regi
                                             // a single counter caps at ~1e8 returning atomics/s (one per tile = 0.5 ms)
 // batched launches: frame f = blockIdx.y (z for refine) works on its own copy of every buffer, a fixed stride apart
 struct BatchStride { size_t pyr, claimed, cand, refined, kps, cube; };   // elements of the respective type
-constexpr size_t CNT_STRIDE = 64, CCNT_STRIDE = (size_t)64 * 32, RHIST_STRIDE = 65536, SEL_STRIDE = 2048;
+constexpr size_t CNT_STRIDE = 64, CCNT_STRIDE = (size_t)64 * 32, SEL_STRIDE = 2048;
 constexpr int SIFT_BATCH_MAX = 8;
 struct FrameOuts { mi355_keypoint* kp[SIFT_BATCH_MAX]; uint8_t* d8[SIFT_BATCH_MAX]; };
 

@@ -11,8 +11,10 @@
 #pragma once
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <vector>
 #include "mi355_mosaic.h"
+// Needs a C++11 compiler (std::call_once guards the process-wide context; the reference's VS2008 project moves to VS2012+).
 
 #ifndef MI355_ADAPTOR_USE_REFERENCE_TYPES
 namespace mi355ref {
@@ -24,10 +26,29 @@ struct BitmapImage {                                                            
 };
 struct MatchPointPairs { SfPoint ptA; int ptA_i, ptA_Fixed; SfPoint ptB; int ptB_i, ptB_Fixed; };            // MosaicWithoutPos.h:135-153
 struct ImageTransform { ProjectMat h; int fixed; };                                                          // MosaicWithoutPos.h:224-228
+// IplImage, OpenCV 2.4.0 core/types_c.h (field for field); stand-alone images own imageData through malloc
+struct IplImage {
+    int nSize, ID, nChannels, alphaChannel, depth; char colorModel[4], channelSeq[4];
+    int dataOrder, origin, align, width, height; void* roi; void* maskROI; void* imageId; void* tileInfo;
+    int imageSize; char* imageData; int widthStep; int BorderMode[4], BorderConst[4]; char* imageDataOrigin;
+};
+inline IplImage* cvCreateImage8U(int w, int h, int ch) {              // cvCreateImage(cvSize(w, h), 8, ch): rows aligned to 4 bytes
+    IplImage* im = (IplImage*)std::calloc(1, sizeof(IplImage));
+    if (!im) return NULL;
+    im->nSize = (int)sizeof(IplImage); im->nChannels = ch; im->depth = 8; im->width = w; im->height = h; im->align = 4;
+    im->widthStep = (w * ch + 3) & ~3; im->imageSize = im->widthStep * h;
+    im->imageData = im->imageDataOrigin = (char*)std::malloc((size_t)im->imageSize > 0 ? (size_t)im->imageSize : 1);
+    if (!im->imageData) { std::free(im); return NULL; }
+    return im;
+}
+inline void cvReleaseImage(IplImage** p) { if (p && *p) { std::free((*p)->imageDataOrigin); std::free(*p); *p = NULL; } }
+struct ImagePoseInfo { IplImage* pImg; int fixed; ImagePoseInfo() : pImg(NULL), fixed(0) {} };              // MosaicWithoutPos.h:283-297 (camPose omitted)
 }  // namespace mi355ref
 #define MI355_NS mi355ref::
+#define MI355_CREATE_IMAGE_8U(w, h, ch) mi355ref::cvCreateImage8U((w), (h), (ch))
 #else
 #define MI355_NS
+#define MI355_CREATE_IMAGE_8U(w, h, ch) cvCreateImage(cvSize((w), (h)), 8, (ch))
 #endif
 
 namespace mi355 {
@@ -36,17 +57,22 @@ static_assert(sizeof(MI355_NS SfPoint) == sizeof(mi355_sfpoint), "SfPoint layout
 static_assert(sizeof(MI355_NS MatchPointPairs) == sizeof(mi355_match_point_pairs), "MatchPointPairs layout");
 static_assert(sizeof(MI355_NS ImageTransform) == sizeof(mi355_image_transform), "ImageTransform layout");
 
-// One process-wide context per device (the reference is a single-process program); thread-safe per the C ABI.
+// One process-wide context per device (the reference is a single-process program).  Creation is guarded: the reference calls the
+// per-pair code from up to 8 worker threads at once (MosaicWithoutPos.cpp:5246-5292); the ctx itself is thread-safe per the C ABI.
 inline mi355_ctx* context(int device = 0) {
-    static mi355_ctx* ctx[16] = {0};
+    struct Slot { std::once_flag once; mi355_ctx* ctx; Slot() : ctx(NULL) {} };
+    static Slot slots[16];
     if (device < 0 || device >= 16) return NULL;
-    if (!ctx[device]) { if (mi355_create(&ctx[device], NULL, device) != MI355_OK) ctx[device] = NULL; }
-    return ctx[device];
+    Slot& s = slots[device];
+    std::call_once(s.once, [&s, device]() { if (mi355_create(&s.ctx, NULL, device) != MI355_OK) s.ctx = NULL; });
+    return s.ctx;
 }
 
 // bool Ransac2D(const vector<PointType>&, const vector<PointType>&, vector<PointType>&, vector<PointType>&,
 //               float aProjectMat[9], float fRansacDist = 1, int sampleTimes = 1000)          mosaicimage.h:1729-1735
-// `seed` stands for the reference's srand((unsigned)time(0)) (mosaicimage.h:1777).
+// `seed` stands for the reference's srand((unsigned)time(0)) (mosaicimage.h:1777).  Limit: at most 400 correspondences (maxNum of
+// the live path, MosaicWithoutPos.cpp:5146 -- the only caller passes <= 396); larger inputs return false with aProjectMat zeroed,
+// where the reference would run on any n.
 inline bool Ransac2D(const std::vector<MI355_NS SfPoint>& p1, const std::vector<MI355_NS SfPoint>& p2,
                      std::vector<MI355_NS SfPoint>& in1, std::vector<MI355_NS SfPoint>& in2, float aProjectMat[9],
                      float fRansacDist = 1.0f, int sampleTimes = 1000, unsigned seed = 1) {
@@ -127,6 +153,78 @@ inline int GetMatchedPairsOneToAllSIFT(int nImages, float ransacDist, unsigned s
     }
     std::free(res);
     return rc;
+}
+
+// int CMosaicByPose::MosaicImagesRefined(const ImagePoseInfo* pImgPoses, const int nImages, const ImageTransform* pRectified)
+//                                                                                              MosaicWithoutPos.cpp:2194-2352
+// The member writes m_pMosaicResult; here it is the last argument (released first when not NULL, like a second call would leak in
+// the reference).  PoseT is the reference's ImagePoseInfo (only .pImg is read).  Returns 0 / -1 / -2 like the reference.
+template <class PoseT>
+inline int MosaicImagesRefined(const PoseT* pImgPoses, const int nImages, const MI355_NS ImageTransform* pRectified, MI355_NS IplImage*& pMosaicResult) {
+    if (NULL == pImgPoses || NULL == pRectified || nImages <= 0) return -1;
+    mi355_ctx* c = context();
+    if (!c) return -2;
+    std::vector<const uint8_t*> imgs(nImages); std::vector<int> w(nImages), h(nImages), ws(nImages); std::vector<float> h9((size_t)9 * nImages);
+    for (int n = 0; n < nImages; n++) {
+        const MI355_NS IplImage* im = pImgPoses[n].pImg;
+        std::memcpy(&h9[(size_t)9 * n], pRectified[n].h.m, 9 * sizeof(float));
+        if (!im) { imgs[n] = NULL; w[n] = h[n] = ws[n] = 0; h9[(size_t)9 * n + 8] = 0.0f; continue; }     // no image: skipped like h.m[8] == 0 (:2256)
+        imgs[n] = (const uint8_t*)im->imageData; w[n] = im->width; h[n] = im->height; ws[n] = im->widthStep;
+    }
+    uint8_t* canvas = NULL; int cw = 0, ch = 0, cws = 0;
+    const int rc = mi355_mosaic_refined(c, &imgs[0], &w[0], &h[0], &ws[0], nImages, &h9[0], &canvas, &cw, &ch, &cws);
+    if (rc != MI355_OK) return rc == MI355_ERR_ARG ? -1 : -2;
+    MI355_NS IplImage* out = MI355_CREATE_IMAGE_8U(cw, ch, 3);          // :2246-2248
+    if (!out) { mi355_free(canvas); return -2; }
+    for (int y = 0; y < ch; y++) std::memcpy(out->imageData + (size_t)y * out->widthStep, canvas + (size_t)y * cws, (size_t)3 * cw);
+    mi355_free(canvas);
+    if (pMosaicResult) cvReleaseImage(&pMosaicResult);
+    pMosaicResult = out;
+    return 0;
+}
+
+// IplImage* LaplacianPyramidBlending(IplImage** pImages, int imagesNum, ProjectMat* pImgT, int band, float resScale)
+//                                                                                              MosaicImage.cpp:2205-2510
+// Same contract as the reference: pImgT[i].m[0..5] are multiplied by resScale IN PLACE (:2216-2223), images overlapping a kept
+// earlier one by more than 0.7 are dropped (ResampleByOverlap, :2227-2230), EVERY input image is released and its pointer set
+// to NULL (:2464-2467) -- ownership passes to this function -- and the returned image belongs to the caller (cvReleaseImage).
+inline MI355_NS IplImage* LaplacianPyramidBlending(MI355_NS IplImage** pImages, int imagesNum, MI355_NS ProjectMat* pImgT, int band, float resScale) {
+    if (NULL == pImages || NULL == pImgT || imagesNum <= 0) return NULL;
+    mi355_ctx* c = context();
+    if (!c) return NULL;
+    for (int i = 0; i < imagesNum; i++) for (int j = 0; j < 6; j++) pImgT[i].m[j] *= resScale;
+    std::vector<const uint8_t*> imgs(imagesNum); std::vector<int> w(imagesNum), h(imagesNum), ws(imagesNum); std::vector<float> h9((size_t)9 * imagesNum);
+    for (int n = 0; n < imagesNum; n++) {
+        std::memcpy(&h9[(size_t)9 * n], pImgT[n].m, 9 * sizeof(float));
+        if (!pImages[n]) { imgs[n] = NULL; w[n] = h[n] = 2; ws[n] = 8; h9[(size_t)9 * n + 8] = 0.0f; continue; }
+        imgs[n] = (const uint8_t*)pImages[n]->imageData; w[n] = pImages[n]->width; h[n] = pImages[n]->height; ws[n] = pImages[n]->widthStep;
+    }
+    std::vector<uint8_t> keep(imagesNum, 1);
+    MI355_NS IplImage* result = NULL;
+    if (mi355_resample_by_overlap(&w[0], &h[0], imagesNum, &h9[0], 0.7f, &keep[0]) == MI355_OK) {
+        uint8_t* out = NULL; int ow = 0, oh = 0, ows = 0;
+        if (mi355_mosaic_blended(c, &imgs[0], &w[0], &h[0], &ws[0], imagesNum, &h9[0], &keep[0], band, &out, &ow, &oh, &ows) == MI355_OK) {
+            result = MI355_CREATE_IMAGE_8U(ow, oh, 3);
+            if (result) for (int y = 0; y < oh; y++) std::memcpy(result->imageData + (size_t)y * result->widthStep, out + (size_t)y * ows, (size_t)3 * ow);
+            mi355_free(out);
+        }
+    }
+    for (int n = 0; n < imagesNum; n++) cvReleaseImage(&pImages[n]);     // :2464-2467: the sources are gone whatever happened
+    return result;
+}
+
+// int CMosaicByPose::MergeImagesRefined(ImagePoseInfo* pImgPoses, const int nImages, const ImageTransform* pRectified)
+//                                                                                              MosaicWithoutPos.cpp:2161-2188
+// (m_scale and m_pMosaicResult are members there.)  The images are consumed: pImgPoses[i].pImg = NULL on return (:2182-2185).
+template <class PoseT>
+inline int MergeImagesRefined(PoseT* pImgPoses, const int nImages, const MI355_NS ImageTransform* pRectified, float m_scale, MI355_NS IplImage*& pMosaicResult) {
+    if (nImages <= 1) return -2;                                         // :2164-2167
+    std::vector<MI355_NS IplImage*> vecImages(nImages); std::vector<MI355_NS ProjectMat> vecHomo(nImages);
+    for (int i = 0; i < nImages; i++) { vecImages[i] = pImgPoses[i].pImg; vecHomo[i] = pRectified[i].h; }
+    const int band = 5;                                                  // :2179
+    pMosaicResult = LaplacianPyramidBlending(&vecImages[0], nImages, &vecHomo[0], band, m_scale);
+    for (int i = 0; i < nImages; i++) pImgPoses[i].pImg = NULL;           // :2182-2185
+    return 0;
 }
 
 }  // namespace mi355

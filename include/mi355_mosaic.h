@@ -201,6 +201,11 @@ int  mi355_load_match_pairs(const char* path, mi355_match_point_pairs** v, int* 
 int  mi355_write_match_pairs_txt(const char* path, const mi355_match_point_pairs* v, int n);
 /* tran0.txt (OutTransform, MosaicWithoutPos.cpp:2798-2818): rows for images 1..n-1: m0..m7 fixed */
 int  mi355_write_transforms(const char* path, const mi355_image_transform* t, int n);
+/* ImportTransform (MosaicWithoutPos.cpp:2820-2843): "n" then n x 9 floats; fixed = 1 for the first transform.  *t -> mi355_free. */
+int  mi355_load_transforms(const char* path, mi355_image_transform** t, int* n);
+/* Reads back what OutTransform / mi355_write_transforms wrote (rows "m0..m7 fixed" for images 1..n-1): returns n transforms with the
+ * identity of image 0 in front and m8 = 1.  *t -> mi355_free. */
+int  mi355_load_tran0(const char* path, mi355_image_transform** t, int* n);
 /* keypoint_%d.key (WriteSurfKeyPoints, MosaicWithoutPos.cpp:4691-4700): int32 n + n x 28-byte cv::KeyPoint */
 int  mi355_write_keypoints(const char* path, const mi355_keypoint* kp, int n);
 int  mi355_load_keypoints(const char* path, mi355_keypoint** kp, int* n);

@@ -115,6 +115,33 @@ def test_results_to_match_pairs(im):
     assert np.array_equal(v["ax"][:40], np.arange(40, dtype=np.float32)) and np.array_equal(v["bid"][40:], np.arange(35))
 
 
+def test_transform_files_roundtrip(im, tmp_path):
+    """tran0.txt as OutTransform writes it (MosaicWithoutPos.cpp:2798-2818) reads back, and ImportTransform's own format (:2820-2843)"""
+    T = im.load_transforms(os.path.join(GOLD, "tran0.txt"), tran0=True)
+    want = np.loadtxt(os.path.join(GOLD, "tran0.txt"))
+    assert len(T) == 20 and T["fixed"][0] == 1 and np.array_equal(T["m"][0], np.eye(3, dtype=np.float32).reshape(9))
+    assert np.array_equal(T["m"][1:, :8], want[:, :8].astype(np.float32)) and (T["m"][:, 8] == 1).all()
+    assert np.array_equal(T["fixed"][1:], want[:, 8].astype(np.int32))
+    out = str(tmp_path / "t.txt")
+    im.write_transforms(out, T)
+    assert np.array_equal(np.loadtxt(out), want)
+    p = str(tmp_path / "refine.txt")
+    vals = np.arange(27, dtype=np.float32).reshape(3, 9) * 0.5
+    open(p, "w").write("3\n" + "\n".join(" ".join(repr(float(x)) for x in row) for row in vals) + "\n")
+    R = im.load_transforms(p)
+    assert len(R) == 3 and R["fixed"].tolist() == [1, 0, 0] and np.array_equal(R["m"], vals)
+
+
+def test_adaptor_driver_compiles_and_links(tmp_path):
+    """tests/cxx/adaptor_driver.cpp (a C++ caller of every adaptor entry point) builds and links against the library here; it is RUN
+    on the GPU box by tests/test_gpu_cxx.py"""
+    from tests.test_gpu_cxx import build_driver
+    exe = build_driver(str(tmp_path))
+    import subprocess
+    r = subprocess.run([exe, str(tmp_path), "ransac"], capture_output=True, text=True)
+    assert r.returncode == 5 and "no context" in r.stderr          # no GPU here: fails loudly, no CPU path
+
+
 def test_adaptor_header_compiles_as_cxx(tmp_path):
     """include/mi355_adaptor.h (the reference's own signatures over the C ABI) is valid stand-alone C++"""
     import subprocess
