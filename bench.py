@@ -33,6 +33,7 @@ sys.path.insert(0, ROOT)
 DOM = "gauss_stream"       # profile class of the dominant kernel (blur_stream): the only launches bracketed with events in the timed region
 SLOTS = int(os.environ.get("MI355_BENCH_SLOTS", "3"))   # batch work areas in flight (library default 3)
 BATCH = int(os.environ.get("MI355_BENCH_BATCH", "8"))   # frames per batch (library default 8)
+PMC_JSON = "r02_pmc_blur_stream.json"   # committed rocprofv3 --pmc passes of this command (profiles/pmc_traffic.py)
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md (6.29 TB/s measured copy)
 
 
@@ -290,13 +291,32 @@ def main():
             ms, n, b = ctx.profile_get(cls)
             prof_all[cls] = {"ms_per_step": ms / max(args.steps, 1), "launches_per_step": n / max(args.steps, 1)}
     ctx.profile_enable(False)
-    # The timed region keeps three batches in flight, so the blur_stream launches above overlap other batches' kernels and
-    # their event durations include the contention.  One extra UNTIMED pass over three batches with a single batch in
-    # flight gives the same launches' stand-alone figures (reported separately, never as `achieved`).
-    iso = None
-    if world == 1 and not os.environ.get("MI355_BENCH_NO_STANDALONE"):
+    # The timed region keeps three batches in flight: the bracketed blur_stream launches overlap other batches' kernels, so their event
+    # durations double-count wall time.  `roofline.achieved` therefore comes from an extra UNTIMED pass over the same
+    # frames with the library option "serial_heavy": the pyramid + extrema phase of a batch waits for the previous batch's, no two
+    # chip-filling kernels overlap, and the bracketed durations are exclusive -- checked right here: the durations of ALL chip-filling
+    # classes of that pass sum to less than its wall time.  The in-situ figure of the timed region stays as a side field.
+    excl, iso = None, None
+    HEAVY = ("gauss_stream", "gauss", "downsample", "extrema")
+    if not os.environ.get("MI355_BENCH_NO_STANDALONE"):
         ctx.synchronize()
-        ctx.set_option("sift_slots", 1)                    # same launches (full batches), but nothing else on the chip
+        ctx.set_option("serial_heavy", 1)
+        ctx.profile_enable(True); ctx.profile_only(",".join(HEAVY)); ctx.profile_reset()
+        t_e = time.perf_counter()
+        for k in own:
+            ctx.SiftExtractDev(k, fptr[k], w, h, ws)
+        ctx.synchronize()
+        wall_ms = (time.perf_counter() - t_e) * 1e3
+        e_ms, e_n, e_bytes = ctx.profile_get(DOM)
+        heavy_ms = sum(ctx.profile_get(c)[0] for c in HEAVY)
+        ctx.profile_enable(False)
+        ctx.set_option("serial_heavy", 0)
+        if e_ms > 0:
+            excl = {"achieved": (e_bytes / 1e9) / (e_ms / 1e3), "launches": int(e_n), "avg_launch_us": e_ms * 1e3 / max(e_n, 1), "frames": len(own),
+                    "dominant_kernel_ms": e_ms, "all_chip_filling_kernels_ms": heavy_ms, "pass_wall_ms": wall_ms,
+                    "durations_are_exclusive": bool(heavy_ms <= wall_ms)}
+        # the same launches with ONE batch in flight (nothing else on the chip at all): the kernel's ceiling in this pipeline
+        ctx.set_option("sift_slots", 1)
         ctx.profile_enable(True); ctx.profile_only(DOM); ctx.profile_reset()
         nf_iso = min(len(own), 3 * BATCH)
         for k in own[:nf_iso]:
@@ -307,7 +327,7 @@ def main():
         ctx.set_option("sift_batch", BATCH)
         if i_ms > 0:
             iso = {"achieved": (i_bytes / 1e9) / (i_ms / 1e3), "frac": (i_bytes / 1e9) / (i_ms / 1e3) / HBM_PEAK_GBS, "frames": nf_iso,
-                   "avg_launch_us": i_ms * 1e3 / max(i_n, 1), "note": "same launches with one batch work area in flight (no overlap with other batches' kernels), untimed extra pass"}
+                   "avg_launch_us": i_ms * 1e3 / max(i_n, 1), "note": "same launches with one batch work area in flight (no other kernel on the chip), untimed extra pass"}
 
     # quality of the last step against ground truth (accepted pairs): corner transfer error in pixels
     r = state["r"]
@@ -328,9 +348,9 @@ def main():
     # (profiles/pmc_traffic.py; counters cannot be read from inside the process): reported only when the workload matches
     traffic, traffic_src = None, None
     try:
-        pj = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_blur_stream.json")))
+        pj = json.load(open(os.path.join(ROOT, "profiles", PMC_JSON)))
         if pj.get("frames") == str(F) and pj.get("frame") == "%dx%d" % (w, h) and pj.get("batch") == str(BATCH):
-            traffic, traffic_src = float(pj["bytes_per_launch"]), "profiles/r01_pmc_blur_stream.json (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes)"
+            traffic, traffic_src = float(pj["bytes_per_launch"]), "profiles/%s (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes)" % PMC_JSON
     except Exception:
         pass
     if rank == 0:
@@ -338,7 +358,7 @@ def main():
         value = total_pairs / dt
         n_frames_total = F if strong else F * world
         path_bytes_per_pair = (n_frames_total * 262.0 * w * h + survey_pairs * 1.04e6) / max(survey_pairs, 1)
-        achieved = (g_bytes / 1e9) / (g_ms / 1e3) if g_ms > 0 else 0.0
+        in_situ = (g_bytes / 1e9) / (g_ms / 1e3) if g_ms > 0 else 0.0
         out = {
             "metric": "image-pairs/sec (detect+match+H+warp), 4000x3000 UAV frames",
             "value": value, "unit": "image-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -354,11 +374,16 @@ def main():
                        "sharding": ("single GPU" if world == 1 else
                                     ("frames k mod G, pairs i mod G, canvas stripes; %s all-gather of feature records and accepted pair records" % transport) if strong else
                                     ("independent strip per rank; %s all-gather of accepted pair records" % transport))},
-            "roofline": {"bound": "hbm", "kernel": "blur_stream<R,D,false> (streaming separable Gaussian: the 20 launches per batch of 8 frames that produce levels 1..5 of pyramid octaves 0..3)", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         "launches": int(g_n), "avg_launch_us": (g_ms * 1e3 / g_n) if g_n else None,
+            "roofline": {"bound": "hbm", "kernel": "blur_stream<R,D,false> (streaming separable Gaussian: the 20 launches per batch of 8 frames that produce levels 1..5 of pyramid octaves 0..3)",
+                         "achieved": excl["achieved"] if excl else in_situ, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": (excl["achieved"] if excl else in_situ) / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "measurement": ("HIP events around every launch of the kernel in an untimed extra pass over the same frames with option serial_heavy (chip-filling kernels of different "
+                                         "batches never overlap: durations are exclusive, see exclusive_pass)") if excl else "HIP events in the timed region (launches overlap other batches' kernels)",
+                         "exclusive_pass": excl,
+                         "in_situ": {"achieved": in_situ, "frac": in_situ / HBM_PEAK_GBS, "launches": int(g_n), "avg_launch_us": (g_ms * 1e3 / g_n) if g_n else None,
+                                     "note": "the same launches bracketed inside the timed region, three batches in flight: durations include other batches' kernels (sum > step time); rocprofv3 --kernel-trace of this command reports this average"},
                          "algorithmic_bytes_per_launch": (g_bytes / g_n) if g_n else None,
-                         "algorithmic_bytes_per_frame": g_bytes / max(args.steps * F, 1),
+                         "algorithmic_bytes_per_frame": g_bytes / max(args.steps * len(own), 1),
                          "frames_per_batch": BATCH, "batches_in_flight": SLOTS, "standalone": iso},
             # the whole path against the fixed algorithmic figure 262*P + 1.04 MB per adjacent pair (3.145 GB at 12 MP)
             # the whole path against the fixed algorithmic figure: (frames x (256 P + 6 P) + pairs x 1.04 MB) / pairs

@@ -86,7 +86,8 @@ struct mi355_ctx {
     std::map<std::string, ProfClass> prof;
     std::vector<SiftWork*> sift_slots;                 // batch work areas, each with its own stream (sift.hip)
     int sift_next = 0;
-    hipEvent_t heavy_ev = nullptr; bool heavy_ev_valid = false;   // MI355_SERIAL_HEAVY=1 (diagnostic): the chip-filling phases of consecutive batches do not overlap
+    hipEvent_t heavy_ev = nullptr; bool heavy_ev_valid = false;   // option "serial_heavy" (measurement): the chip-filling phases of consecutive batches do not overlap
+    int serial_heavy = 0;
     std::vector<DevBuf> host_frames;                   // staging ring of mi355_sift_extract's deferred mode (host frames joining batches)
     std::vector<hipEvent_t> host_frame_ev;             // per ring slot: recorded after the batch that read the slot
     std::vector<char> host_frame_used;

@@ -1902,7 +1902,7 @@ static int sift_run_batch(mi355_ctx* ctx, SiftWork* s) {
     };
     // ---- phases 1+2: the pyramid, octave by octave, every launch covering all n frames of the batch ----
     bool ds_fused = false;
-    static const bool serial_heavy = getenv("MI355_SERIAL_HEAVY") != nullptr;
+    const bool serial_heavy = ctx->serial_heavy != 0;
     if (serial_heavy && ctx->heavy_ev_valid) MI_HIP(hipStreamWaitEvent(st, ctx->heavy_ev, 0));   // the previous batch's pyramid + extrema first
     for (int o = 0; o < s->n_oct; o++) {
         const OctaveDev& oc = s->P.oc[o];

@@ -98,7 +98,9 @@ int  mi355_synchronize(mi355_ctx* ctx);
  * candidate lists, 3.2 GB per frame at 4000x3000); "blur_stream" = 1 (default) runs pyramid levels of >= 2048x1536
  * through the barrier-free streaming Gaussian, 0 forces the tiled kernels everywhere (same bits either way);
  * "xstream_min_w" (3000) / "xstream_min_frames" (4): octaves at least that wide, in batches of at least that many frames,
- * take the streamed extrema kernel instead of the tiled one (same candidates either way). */
+ * take the streamed extrema kernel instead of the tiled one (same candidates either way); "serial_heavy" = 1 (measurement only,
+ * default 0): the pyramid + extrema phase of a batch waits for the previous batch's, so that the chip-filling kernels of different
+ * batches never overlap and their event-bracketed durations are exclusive (the whole job loses ~10 %). */
 int  mi355_set_option(mi355_ctx* ctx, const char* name, int value);
 void mi355_free(void* p);                               /* frees host buffers returned by this library */
 
