@@ -137,3 +137,46 @@ def test_c4_mini_window_182_all_pairs():
     assert F - 1 <= acc < len(pairs) // 2, acc
     assert sum(1 for n in nins if n > 30) == acc
     ctx.close()
+
+
+def test_c5_mini_dense_canvas_eight_stripes():
+    """C5 shape, scaled down: many frames piled onto a small canvas (C5: 2000 frames of 12 MP on 20000 x 20000 = ~60 covering images per
+    canvas pixel; here 240 frames of 320x240 on ~1000 x 800 = ~20 per pixel), global transforms with small projective terms, the canvas
+    rendered as 8 stripes (one per GPU of the node) -- equal to the whole render and to the oracle's image-after-image
+    overwrite; a few images flagged invalid (m8 = 0)"""
+    import torch
+    import imagemosaicing_amd as im
+    from tests import oracle_lib as ol
+    from tests.synth import texture
+    orc = ol.load_oracle_fast()
+    ctx = im.Context(0)
+    rng = np.random.default_rng(55)
+    n, w, h = 240, 320, 240
+    imgs = [texture(w, h, seed=1000 + (k % 12)) + np.uint8(k % 7) for k in range(n)]
+    h9s = np.zeros((n, 9), np.float32)
+    for k in range(n):
+        a = np.deg2rad(rng.uniform(-15, 15)); sc = 1 + rng.uniform(-0.1, 0.1)
+        H = np.array([[sc * np.cos(a), -sc * np.sin(a), rng.uniform(0, 700)], [sc * np.sin(a), sc * np.cos(a), rng.uniform(0, 560)],
+                      [rng.normal(0, 3e-5), rng.normal(0, 3e-5), 1.0]])
+        h9s[k] = H.reshape(9)
+    h9s[0] = np.eye(3).reshape(9)
+    h9s[[17, 100, 239], 8] = 0
+    rc, (ref, rw, rh, rws) = orc.mosaic_images_refined(imgs, h9s)
+    assert rc == 0
+    d_imgs = [torch.from_numpy(np.ascontiguousarray(i)).cuda() for i in imgs]
+    ptrs = [t.data_ptr() for t in d_imgs]
+    cw, ch, cws, _ = im.mosaic_layout([w] * n, [h] * n, h9s)
+    assert (cw, ch, cws) == (rw, rh, rws)
+    whole = torch.full((ch, cws), 9, dtype=torch.uint8, device="cuda")
+    stripes = torch.full((ch, cws), 9, dtype=torch.uint8, device="cuda")
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    ctx.MosaicImagesRefinedDev(ptrs, [w] * n, [h] * n, [w * 3] * n, h9s, whole.data_ptr(), cw, ch, cws)
+    G = 8
+    for r in range(G):
+        row0 = (ch * r) // G
+        ctx.MosaicImagesRefinedDev(ptrs, [w] * n, [h] * n, [w * 3] * n, h9s, stripes.data_ptr(), cw, ch, cws, row0, (ch * (r + 1)) // G - row0)
+    ctx.synchronize()
+    ctx.set_stream(None)
+    assert np.array_equal(whole.cpu().numpy(), ref), "whole canvas differs from the oracle"
+    assert np.array_equal(stripes.cpu().numpy(), ref), "8 stripes differ from the oracle"
+    ctx.close()
