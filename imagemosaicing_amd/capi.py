@@ -276,6 +276,23 @@ class Context:
         self._chk(self.L.mi355_mosaic_refined_dev(self._h, ptrs, _p(w), _p(h), _p(ws), n, _p(h9s), C.c_void_p(int(d_canvas)),
                                                   int(cw), int(ch), int(cws), int(row0), int(rows if rows >= 0 else ch)))
 
+    # ---- SURF variant (GetMatchedPairsOneToAllSurf, MosaicWithoutPos.cpp:5300-5533) ---------------------
+    def SurfExtract(self, img_id, bgr, hessian=50.0, max_kp=4096):
+        img, w, h, ws, ch = _img_geom(bgr)
+        assert ch == 3
+        kp = np.zeros(max_kp, KEYPOINT)
+        desc = np.zeros((max_kp, 128), np.float32)
+        n = C.c_int(0)
+        self._chk(self.L.mi355_surf_extract(self._h, int(img_id), _p(img), w, h, ws, C.c_float(hessian), int(max_kp), _p(kp), _p(desc), C.byref(n)))
+        return kp[:n.value].copy(), desc[:n.value].copy()
+
+    def SurfMatchPairs(self, pairs, ransac_dist=2.5, seed=1, match_dist=0.5, max_features=200, min_inliers=18):
+        pairs = np.ascontiguousarray(pairs, np.int32).reshape(-1, 2)
+        out = np.zeros(len(pairs), PAIR_RESULT)
+        self._chk(self.L.mi355_surf_match_pairs(self._h, _p(pairs), len(pairs), C.c_float(ransac_dist), C.c_uint32(seed), C.c_float(match_dist),
+                                                int(max_features), int(min_inliers), _p(out)))
+        return out
+
     # ---- multi-GPU exchanges -------------------------------------------------------------
     def PackFeaturesDev(self, img_ids, d_payload):
         """resident features of img_ids -> fixed-size records at d_payload (device, len x FEATURE_RECORD_BYTES); returns the headers"""
@@ -416,6 +433,15 @@ def resample_by_overlap(w, h, h9s, overlapT=0.7):
     if rc != 0:
         raise Mi355Error(rc, "resample_by_overlap")
     return keep
+
+
+def surf_pair_schedule(n_images):
+    L = load_library()
+    n = C.c_int(0)
+    L.mi355_surf_pair_schedule(int(n_images), None, 0, C.byref(n))
+    out = np.zeros((max(n.value, 1), 2), np.int32)
+    L.mi355_surf_pair_schedule(int(n_images), _p(out), n.value, C.byref(n))
+    return out[:n.value]
 
 
 def pair_schedule(n_images, window, rank=0, world=1):

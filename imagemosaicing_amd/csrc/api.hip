@@ -74,6 +74,7 @@ extern "C" void mi355_destroy(mi355_ctx* ctx) {
     (void)mi_resolve_features(ctx);
     mi_sift_release(ctx);
     mi_comm_release(ctx);
+    mi_surf_release(ctx);
     for (auto& kv : ctx->feats) kv.second.release();
     for (auto& kv : ctx->ws) kv.second.release();
     for (auto& b : ctx->host_frames) b.release();

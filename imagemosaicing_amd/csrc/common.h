@@ -70,6 +70,7 @@ struct ProfClass {
 
 struct SiftWork;   // sift.hip
 struct mi355_comm; // comm.hip (RCCL communicator)
+struct SurfState;  // surf.hip (device-resident SURF features)
 
 struct mi355_ctx {
     int device = 0;
@@ -102,6 +103,7 @@ struct mi355_ctx {
     size_t pinned_used = 0;
     int num_cu = 256;
     mi355_comm* comm = nullptr;                        // RCCL communicator (mi355_comm_init), comm.hip
+    SurfState* surf = nullptr;                         // SURF variant of the path (surf.hip)
     int last_counts[8] = {0};                          // SIFT counters of the last frame: candidates, refined, keypoints, selected, overflow
 
     void set_error(const std::string& s) { err = s; }
@@ -149,6 +151,7 @@ int mi_resolve_features(mi355_ctx*);               // waits for in-flight SIFT f
 int mi_sift_extract_dev(mi355_ctx*, int img_id, const uint8_t* d_bgr, int w, int h, int ws, int* n_kp);
 void mi_sift_release(mi355_ctx*);
 void mi_comm_release(mi355_ctx*);
+void mi_surf_release(mi355_ctx*);
 
 // host helpers
 int  mi_inverse_matrix_host(const float* src, int order, float* dst, float eps);   // matrix.h:147-296 (host side of the warps)

@@ -225,6 +225,27 @@ int  mi355_global_affine_align(const mi355_match_point_pairs* v, int n, int n_im
  * and flags those images invalid, h.m[8]=0, :4512-4523, 4646-4652).  Ties -> the group holding the lowest index. */
 int  mi355_select_connected(const mi355_match_point_pairs* v, int n, int n_images, int32_t* label);
 
+/* ---- SURF variant of the path ("next" row f4 of SURVEY 8f): GetMatchedPairsOneToAllSurf, MosaicWithoutPos.cpp:5300-5533 ----------
+ * (every call site of it in the reference is commented out, :4461-4499; named in north_star).  cv::SURF's arithmetic is not
+ * available: the definition is oracle/oracle_surf.c (parity unpinned).  SURF features live in their own id space of the ctx. */
+/* SurfFeatureDetector detector(minHessian).detect + SurfDescriptorExtractor.compute (:5313-5335): SURF(hessianThreshold, 4 octaves,
+ * 2 layers, extended 128-float descriptors, oriented).  The reference keeps every keypoint; here the max_kp (<= 8192) strongest
+ * by Hessian response are kept, ordered by (response descending, octave, layer, row, column).  desc128: n x 128 floats, unit norm;
+ * kp[].class_id = sign of the Laplacian.  Synchronous. */
+int  mi355_surf_extract(mi355_ctx* ctx, int img_id, const uint8_t* bgr, int w, int h, int width_step, float hessian_threshold, int max_kp,
+                        mi355_keypoint* kp, float* desc128, int* n_kp);
+int  mi355_surf_extract_dev(mi355_ctx* ctx, int img_id, const uint8_t* d_bgr, int w, int h, int width_step, float hessian_threshold, int max_kp, int* n_kp);
+int  mi355_surf_get_features(mi355_ctx* ctx, int img_id, mi355_keypoint* kp, float* desc128, int max_kp, int* n_kp);
+int  mi355_surf_drop_features(mi355_ctx* ctx, int img_id);   /* img_id < 0: all */
+/* the ring schedule of that function: ext = min(15, n/2 - 1), j0 in (i, i + ext] wrapped modulo n (:5370-5377) */
+int  mi355_surf_pair_schedule(int n_images, int32_t* pairs_ij, int max_pairs, int* n_pairs);
+/* the j-loop body :5379-5527 for a batch of pairs: exact float 1-NN (what FlannBasedMatcher approximates, :5389-5391), sort by
+ * (distance, queryIdx) (:5392), every match below matchDist with matchDist lowered by 0.05 until at most max_features remain
+ * (:5400-5424; UavMatchParam: matchDist 0.5, maxFeatruesNum 200), CMosaicHarris::Ransac (:5459 -- Ransac2D's arithmetic with the
+ * pool allocator, see tests/test_surf.py), accepted when more than min_inliers (18, :5306) inliers. */
+int  mi355_surf_match_pairs(mi355_ctx* ctx, const int32_t* pairs_ij, int n_pairs, float ransac_dist, uint32_t seed, float match_dist, int max_features,
+                            int min_inliers, mi355_pair_result* out);
+
 /* ---- multi-GPU: one process per GPU ------------------------------------------------------- */
 /* Deterministic shard of the reference's pair schedule (i strided by rank like the threads at
  * MosaicWithoutPos.cpp:5066, j in (i, min(N, i+window))): writes pairs of rank `rank` of `world`.

@@ -96,6 +96,16 @@ typedef struct { float x, y, size, angle, response; int32_t octave, class_id; } 
  * desc: n x 128 u8 (OpenCV stores the same integers in a float Mat). returns n */
 int  orc_sift(const uint8_t* bgr, int w, int h, int ws, int nfeatures, orc_keypoint* kp, uint8_t* desc, int max_kp);
 
+/* ---- oracle_surf.c: the SURF variant of the path (MosaicWithoutPos.cpp:5300-5533); PARITY UNPINNED ---- */
+/* SURF(hessianThreshold, 4 octaves, 2 layers, extended, oriented) detect + compute (:5313-5335): the strongest max_kp keypoints,
+ * ordered by (response descending, octave, layer, row, column); desc: n x 128 floats of unit norm.  returns n */
+int  orc_surf(const uint8_t* bgr, int w, int h, int ws, float hessian_threshold, orc_keypoint* kp, float* desc, int max_kp);
+/* exact 1-NN in L2 on float descriptors (what FlannBasedMatcher approximates, :5389-5391); distance = sqrt(sum of squares) */
+void orc_bf_match_f32(const float* d1, int n1, const float* d2, int n2, int32_t* nn_idx, float* nn_dist);
+/* the distance-threshold selection :5400-5424 on matches sorted by (distance, queryIdx) (:5392) */
+int  orc_select_by_distance(const int32_t* nn_idx, const float* nn_dist, int n1, const float* kp1xy, const float* kp2xy,
+                            float match_dist, int max_features, orc_sfpoint* out1, orc_sfpoint* out2);
+
 #ifdef __cplusplus
 }
 #endif

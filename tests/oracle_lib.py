@@ -230,6 +230,40 @@ class Oracle:
         return kp[:n].copy(), desc[:n].copy()
 
 
+    # ---- SURF variant (row f4) ---------------------------------------------------------------------
+    def surf(self, bgr, hessian=50.0, max_kp=4096):
+        bgr = np.ascontiguousarray(bgr, np.uint8)
+        h, w = bgr.shape[:2]
+        kp = np.zeros(max_kp, KEYPOINT)
+        desc = np.zeros((max_kp, 128), np.float32)
+        self.L.orc_surf.restype = C.c_int
+        n = self.L.orc_surf(_p(bgr), w, h, bgr.strides[0], C.c_float(hessian), _p(kp), _p(desc), max_kp)
+        return kp[:n].copy(), desc[:n].copy()
+
+    def bf_match_f32(self, d1, d2):
+        d1 = np.ascontiguousarray(d1, np.float32); d2 = np.ascontiguousarray(d2, np.float32)
+        idx = np.zeros(len(d1), np.int32); dist = np.zeros(len(d1), np.float32)
+        self.L.orc_bf_match_f32(_p(d1), len(d1), _p(d2), len(d2), _p(idx), _p(dist))
+        return idx, dist
+
+    def select_by_distance(self, idx, dist, kp1xy, kp2xy, match_dist=0.5, max_features=200):
+        idx = np.ascontiguousarray(idx, np.int32); dist = np.ascontiguousarray(dist, np.float32)
+        kp1xy = np.ascontiguousarray(kp1xy, np.float32); kp2xy = np.ascontiguousarray(kp2xy, np.float32)
+        o1 = np.zeros(max(len(idx), 1), SFPOINT); o2 = np.zeros(max(len(idx), 1), SFPOINT)
+        self.L.orc_select_by_distance.restype = C.c_int
+        n = self.L.orc_select_by_distance(_p(idx), _p(dist), len(idx), _p(kp1xy), _p(kp2xy), C.c_float(match_dist), int(max_features), _p(o1), _p(o2))
+        return o1[:n].copy(), o2[:n].copy()
+
+    def surf_match_pair(self, f1, f2, ransac_dist=2.5, seed=1, match_dist=0.5, max_features=200, min_inliers=18):
+        """the j-loop body of GetMatchedPairsOneToAllSurf (MosaicWithoutPos.cpp:5389-5517): returns (n_in or 0, in1, in2, H, n_selected)"""
+        (k1, d1), (k2, d2) = f1, f2
+        idx, dist = self.bf_match_f32(d1, d2)
+        s1, s2 = self.select_by_distance(idx, dist, np.stack([k1["x"], k1["y"]], 1), np.stack([k2["x"], k2["y"]], 1), match_dist, max_features)
+        ok, i1, i2, H = self.ransac2d(s1, s2, ransac_dist, 1000, seed)          # CMosaicHarris::Ransac == Ransac2D arithmetic (tests/test_surf.py)
+        nin = len(i1)
+        return (nin if nin > min_inliers else 0), i1, i2, H, len(s1)
+
+
 class Ref:
     """The reference's own code (oracle/_ref)."""
 

@@ -1,0 +1,127 @@
+"""The SURF variant of the path (GetMatchedPairsOneToAllSurf, MosaicWithoutPos.cpp:5300-5533).
+
+CPU part: (1) CMosaicHarris::Ransac (mosaicimage.h:96-402), the RANSAC that path calls, is Ransac2D (:1729-2035) with the pool
+allocator: shown on the reference's own text where /root/reference exists -- the two function bodies and the solvers they call
+(SolveProjectMatrix2 / SolveHomographyMatrix, SolveLinearLeastSquare / ...2, NonlinearLeastSquareProjection / ...2) are equal once
+allocation lines and names are normalised -- so the 88 golden Ransac2D cases pin it; (2) the ring pair schedule; (3) sanity of the
+SURF oracle (unit descriptors, ordering, determinism).  GPU part: the HIP path against the oracle, bit for bit."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+R = "/root/reference/code/MosaicingCode/mosaicing"
+
+
+def _body(path, a, b):
+    txt = subprocess.run(["iconv", "-f", "GB18030", "-t", "UTF-8", os.path.join(R, path)], capture_output=True, text=True).stdout.splitlines()[a - 1:b]
+    out = []
+    for line in txt:
+        line = re.sub(r"//.*", "", line)
+        line = re.sub(r"\s+", "", line)
+        if line:
+            out.append(line)
+    return out
+
+
+def _normalise(lines, drop=()):
+    """one string: comments / whitespace / line structure removed, pool allocation rewritten as new[] / delete[], names unified"""
+    lines = [l for l in lines if not any(t in l for t in drop)]
+    s = "\n".join(lines)
+    s = re.sub(r"CMemoryPoolmemPool;\n", "", s)
+    s = re.sub(r"T1\*(\w+)=NULL;\n\1=\(T1\*\)memPool\.Operate\(NULL,([^;]*?)\*sizeof\(T1\)\);", r"T1*\1=newT1[\2];", s)
+    s = re.sub(r"\(T1\*\)memPool\.Operate\(NULL,([^;]*?)\*sizeof\(T1\)\)", r"newT1[\1]", s)
+    s = re.sub(r"memPool\.Operate\((\w+)\);(\1=NULL;)?", r"delete[]\1;", s)
+    for a, b in (("SolveProjectMatrix2", "SolveHomographyMatrix"), ("NonlinearLeastSquareProjection2", "NLLS"), ("NonlinearLeastSquareProjection", "NLLS"),
+                 ("SolveLinearLeastSquare2", "SLLS"), ("SolveLinearLeastSquare", "SLLS"), ("m_vecInnerPoints", "vecInnerPoints"), ("m_transformType", "transformType"),
+                 ("Ransac2D(", "Ransac(")):
+        s = s.replace(a, b)
+    s = s.replace("\n", "").replace("{", "").replace("}", "")
+    return re.sub(r"template<[^>]*>", "", s)
+
+
+@pytest.mark.skipif(not os.path.isdir(R), reason="needs /root/reference")
+def test_cmosaicharris_ransac_is_ransac2d_arithmetic():
+    pairs = [("matrix.h", (882, 980), (783, 877)),                 # SolveProjectMatrix2 vs SolveHomographyMatrix
+             ("matrix.h", (456, 503), (334, 404)),                 # SolveLinearLeastSquare vs SolveLinearLeastSquare2
+             ("LeastSquare.h", (534, 714), (353, 531))]            # NonlinearLeastSquareProjection vs ...2
+    for path, (a0, a1), (b0, b1) in pairs:
+        A, B = _normalise(_body(path, a0, a1)), _normalise(_body(path, b0, b1))
+        assert A == B, (path, next((A[max(0, i - 40):i + 40], B[max(0, i - 40):i + 40]) for i in range(min(len(A), len(B))) if A[i] != B[i]))
+    # the two RANSAC bodies: what legitimately differs is the signature / member plumbing (the images are passed but only
+    # NULL-checked), a debug print and the local transformType the free function declares
+    H = _normalise(_body("mosaicimage.h", 96, 402), drop=("cout<<vecMatchedPoints1.size()",))
+    D = _normalise(_body("mosaicimage.h", 1729, 2035))
+    H = H.replace("boolRansac(BitmapImage*pSrc1,BitmapImage*pSrc2,conststd::vector<PointType>&vecMatchedPoints1,", "boolRansac(conststd::vector<PointType>&vecMatchedPoints1,")
+    H = H.replace("if((pSrc1==NULL)||(pSrc2==NULL))returnfalse;", "")
+    D = D.replace("std::vector<PointType>&vecInnerPoints1,std::vector<PointType>&vecInnerPoints2,", "").replace("inttransformType=PROJECT_MODEL;", "")
+    assert H == D, next((H[max(0, i - 60):i + 60], D[max(0, i - 60):i + 60]) for i in range(min(len(H), len(D))) if H[i] != D[i])
+
+
+def test_surf_pair_schedule(lib):
+    """MosaicWithoutPos.cpp:5370-5377: ext = min(15, n/2 - 1); j0 in (i, i + ext], wrapped modulo n"""
+    for n in (3, 4, 10, 40):
+        ext = min(15, n // 2 - 1)
+        want = [(i, j0 if j0 < n else j0 - n) for i in range(n) for j0 in range(i + 1, n + ext) if j0 - i <= ext]
+        got = [tuple(int(v) for v in p) for p in lib.surf_pair_schedule(n)]
+        assert got == want and len(got) == n * max(ext, 0)
+
+
+def test_surf_oracle_sanity(oracle):
+    from tests.synth_frames import strip
+    frames, Hs = strip(2, 640, 480, seed=3)
+    kp, d = oracle.surf(frames[0], 50.0, 3000)
+    kp2, d2 = oracle.surf(frames[0], 50.0, 3000)
+    assert 500 < len(kp) <= 3000 and np.array_equal(kp.view(np.uint8), kp2.view(np.uint8)) and np.array_equal(d, d2)
+    assert np.all(np.diff(kp["response"]) <= 0) and kp["response"][-1] > 50.0
+    assert np.abs(np.linalg.norm(d.astype(np.float64), axis=1) - 1).max() < 1e-5
+    assert set(np.unique(kp["class_id"])) <= {-1, 0, 1} and kp["octave"].min() == 0 and kp["octave"].max() <= 3
+    # the pair stage finds the ground-truth motion
+    f2 = oracle.surf(frames[1], 50.0, 3000)
+    nin, i1, i2, H, ns = oracle.surf_match_pair((kp, d), f2, 2.5, 1)
+    assert ns <= 200 and nin > 18
+    Hgt = np.linalg.inv(Hs[0]) @ Hs[1]
+    Hm = H.astype(np.float64).copy(); Hm[8] = 1; Hm = Hm.reshape(3, 3)
+    p = np.array([320.0, 240.0, 1.0]); a, b = Hm @ p, Hgt @ p
+    assert np.hypot(*(a[:2] / a[2] - b[:2] / b[2])) < 1.5
+
+
+@pytest.mark.gpu
+def test_surf_gpu_vs_oracle():
+    import imagemosaicing_amd as im
+    from tests import oracle_lib as ol
+    from tests.synth_frames import strip, terrain
+    orc = ol.load_oracle_fast()
+    ctx = im.Context(0)
+    cases = [(strip(3, 640, 480, seed=3)[0], 50.0, 3000), ([terrain(333, 257, seed=5), terrain(200, 160, seed=6)], 50.0, 8192),
+             ([terrain(1100, 780, seed=7)], 400.0, 2000), ([np.full((120, 160, 3), 90, np.uint8)], 50.0, 100)]
+    for frames, thr, mk in cases:
+        for k, img in enumerate(frames):
+            kp, d = ctx.SurfExtract(k, img, thr, mk)
+            okp, od = orc.surf(img, thr, mk)
+            assert len(kp) == len(okp), (img.shape, len(kp), len(okp))
+            for f in ("x", "y", "size", "angle", "response", "octave", "class_id"):
+                a, b = kp[f], okp[f]
+                same = a.view(np.uint32) == b.view(np.uint32) if a.dtype.kind == "f" else a == b
+                assert same.all(), (img.shape, f, np.where(~same)[0][:5], a[~same][:3], b[~same][:3])
+            assert np.array_equal(d.view(np.uint32), od.view(np.uint32)), (img.shape, int((d != od).any(1).sum()))
+    # the pair stage on the strip: ring schedule, records against the oracle's pair pipeline
+    frames = cases[0][0]
+    feats = []
+    for k, img in enumerate(frames):
+        ctx.SurfExtract(k, img, 50.0, 3000)
+        feats.append(orc.surf(img, 50.0, 3000))
+    pairs = im.surf_pair_schedule(len(frames))
+    res = ctx.SurfMatchPairs(pairs, 2.5, 4)
+    for p, (i, j) in enumerate(pairs):
+        nin, i1, i2, Ho, ns = orc.surf_match_pair(feats[i], feats[j], 2.5, 4)
+        r = res[p]
+        assert (int(r["i"]), int(r["j"])) == (i, j) and int(r["n_selected"]) == ns, (i, j, int(r["n_selected"]), ns)
+        assert int(r["accepted"]) == int(nin > 18)
+        if nin > 18:
+            assert int(r["n_in"]) == nin and np.array_equal(r["a"][:nin], i1[:nin]) and np.array_equal(r["b"][:nin], i2[:nin])
+            assert np.array_equal(r["H"].view(np.uint32), Ho.view(np.uint32))
+    assert int(res["accepted"].sum()) >= 2
+    ctx.close()
