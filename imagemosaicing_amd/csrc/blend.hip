@@ -154,6 +154,24 @@ static int blend_core(mi355_ctx* ctx, const uint8_t* const* chips, const uint8_t
     DevBuf& dmask = ctx->buf("blend_mask");
     DevBuf& glap = ctx->buf("blend_src_lap");
     DevBuf& gwgt = ctx->buf("blend_src_w");
+    // every staging buffer is sized for the largest chip up front: the per-chip work below is then pure stream-ordered launches
+    // (no allocation, no synchronisation between chips; the next chip's upload / pyramid simply queues behind this chip's kernels)
+    {
+        size_t max_px = 0, max_chip = 0, max_mask = 0;
+        for (int k = 0; k < n; k++) {
+            if (info[k].w <= 0 || info[k].h <= 0) continue;
+            const size_t rw = (size_t)info[k].w + 8 * (size_t)al, rh = (size_t)info[k].h + 8 * (size_t)al;     // region <= chip + 2 x (3 al gap + al rounding)
+            size_t px = 0;
+            for (int l = 0; l <= nb; l++) px += (rw >> l) * (rh >> l);
+            if (px > max_px) max_px = px;
+            const size_t cb = (size_t)((info[k].w * 3 + 3) & ~3) * info[k].h, mb = (size_t)((info[k].w + 3) & ~3) * info[k].h;
+            if (cb > max_chip) max_chip = cb;
+            if (mb > max_mask) max_mask = mb;
+        }
+        MI_HIP(glap.reserve(max_px * 3 * sizeof(short)));
+        MI_HIP(gwgt.reserve(max_px * sizeof(float)));
+        if (!on_device) { MI_HIP(dchip.reserve(max_chip + 16)); MI_HIP(dmask.reserve(max_mask + 16)); }
+    }
     for (int k = 0; k < n; k++) {
         const int cw = info[k].w, chh = info[k].h, x0 = info[k].x0, y0 = info[k].y0;
         if (cw <= 0 || chh <= 0) continue;
@@ -196,7 +214,6 @@ static int blend_core(mi355_ctx* ctx, const uint8_t* const* chips, const uint8_t
             hipLaunchKernelGGL(blend_accumulate_kernel, grid2(rw >> l, rh >> l), dim3(256), 0, st, g + roff[l] * 3, wp + roff[l], rw >> l, rh >> l, tlx >> l, tly >> l,
                                dlap.as<short>() + loff[l] * 3, dwgt.as<float>() + loff[l], Wp >> l);
         MI_HIP(hipGetLastError());
-        MI_HIP(hipStreamSynchronize(st));                            // the staging buffers are reused by the next chip
     }
     for (int l = 0; l <= nb; l++) {
         const size_t cnt = (size_t)(Wp >> l) * (Hp >> l);
