@@ -32,19 +32,35 @@ def test_bench_contract_small():
     assert d["value"] > 0
 
 
-def test_bench_two_ranks_dry_run_on_one_gpu():
-    """the N>1 code path of bench.py (per-rank strips, all-gather of the pair records, max-over-ranks timing, rank-0 JSON)
-    with two processes sharing GPU 0 and gloo standing in for RCCL (RCCL refuses two ranks on one device)"""
+def _two_ranks(extra):
     import socket
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
-           "--frames", "5", "--width", "1000", "--height", "750", "--backend", "gloo", "--all-ranks-on-device0"]
+           "--width", "1000", "--height", "750", "--backend", "gloo", "--all-ranks-on-device0"] + extra
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, "exactly one JSON line (rank 0)"
-    d = json.loads(lines[0])
+    assert r.stdout.strip().splitlines()[-1] == lines[0], "the JSON line is the last line of stdout"
+    return json.loads(lines[0])
+
+
+def test_bench_two_ranks_strong_dry_run_on_one_gpu():
+    """the default N>1 path of bench.py: ONE survey, frames k mod 2 / pairs i mod 2 per rank, feature + result exchanges, canvas
+    stripes, max-over-ranks timing, rank-0 JSON -- two processes sharing GPU 0, gloo standing in for RCCL (RCCL refuses two ranks on
+    one device; the transport moves the same records through the same pack / install entry points)"""
+    d = _two_ranks(["--frames", "9"])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["cpu_baseline"] is None
+    assert d["config"]["frames"] == 9 and d["config"]["pairs"] == 8 and d["config"]["frames_per_gpu"] == 5 and d["config"]["pairs_per_gpu"] == 4
+    assert d["quality"]["pairs_accepted"] == 8 and d["quality"]["images_aligned"] == 9 and d["quality"]["h_corner_err_px_median"] < 0.5
+    # whole-job aggregate: the survey's 8 pairs per step
+    assert abs(d["value"] - 8 / (d["ms_per_step"] / 1e3)) / d["value"] < 1e-6
+
+
+def test_bench_two_ranks_weak_dry_run_on_one_gpu():
+    """--scaling weak: an independent strip per rank, the result all-gather only"""
+    d = _two_ranks(["--frames", "5", "--scaling", "weak"])
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["cpu_baseline"] is None
     assert d["config"]["pairs_per_gpu"] == 4 and d["quality"]["pairs_accepted"] == 4
     # whole-job aggregate: 2 ranks x 4 pairs per step
