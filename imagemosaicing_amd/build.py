@@ -17,7 +17,7 @@ OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libmi355mosaic.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
-         "-Wall", "-Wno-unused-function", "-Wno-unused-result"]
+         "-Wall", "-Wno-unused-function", "-Wno-unused-result"] + os.environ.get("MI355_EXTRA_HIPCC_FLAGS", "").split()   # kernel A/B builds (scratch/)
 
 
 def sources():

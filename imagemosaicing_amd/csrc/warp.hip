@@ -182,23 +182,22 @@ extern "C" int mi355_mosaic_layout(const int* w, const int* h, int n, const floa
 // ---- MosaicImagesRefined as ONE launch: every canvas tile is produced once -------------------------------------------------------
 // The reference composites image after image, each overwriting the canvas wherever it has a valid sample
 // (MosaicWithoutPos.cpp:2254-2348), so a canvas pixel ends up with the sample of the HIGHEST-index image that covers it.  A
-// workgroup here owns a 128 x 32 tile of the canvas, walks the images whose canvas bounding box meets the tile in DESCENDING
+// workgroup here owns a 128 x 16 tile of the canvas, walks the images whose canvas bounding box meets the tile in DESCENDING
 // index, and takes for every pixel the first valid sample it meets: the same bytes, with one read of the winning image's
-// footprint and one write per canvas pixel instead of one read + one write per covering image (3.1 covering images per
+// 2 x 2 neighbourhoods and one write per canvas pixel instead of one read + one write per covering image (3.1 covering images per
 // pixel in the C3 survey, ~60 at C5) and no clearing pass (pixels nobody covers are stored as zeros).  All images go through
 // one launch; the result does not depend on any execution order.
-// The footprint of the tile in the image being tried is staged in LDS with aligned dword loads (rows of ~400 contiguous
-// bytes) and the 2x2 bilinear neighbourhoods are read from there; a pixel whose neighbourhood falls outside the staged window
-// (strong scale / rotation, float rounding at the rim) reads global memory instead -- staging is never a correctness matter.
 struct FrameDev {
     const uint8_t* src; int w, h, ws;
     int begX, endX, begY, endY;                 // clipped canvas bounding box the reference visits for this image (:2276-2306)
     float inv[9];
     int unit_den;                               // affine with m8 = 1: the two divisions are by exactly 1.0f
 };
-constexpr int MT_W = 128, MT_RPL = 4, MT_H = 8 * MT_RPL;   // canvas tile of one workgroup: 256 threads x 4 pixels x MT_RPL rows
+#ifndef MT_RPL_V
+#define MT_RPL_V 2
+#endif
+constexpr int MT_W = 128, MT_RPL = MT_RPL_V, MT_H = 8 * MT_RPL;   // canvas tile of one workgroup: 256 threads x 4 pixels x MT_RPL rows
 constexpr int MT_COARSE = 256;                  // candidate lists are kept per 256 x 256 block of the canvas
-constexpr int MT_LDS = 24 * 1024;               // staged footprint, bytes
 
 // one thread per coarse block: the images whose box meets the block, highest index first
 __global__ __launch_bounds__(256) void mosaic_lists_kernel(const FrameDev* fr, int n, int bx_n, int by_n, int row0, uint16_t* lists, int* counts) {
@@ -217,12 +216,10 @@ __global__ __launch_bounds__(256) void mosaic_lists_kernel(const FrameDev* fr, i
 
 __global__ __launch_bounds__(256) void mosaic_tile_kernel(const FrameDev* fr, int n, const uint16_t* lists, const int* counts, int bx_n,
                                                           uint8_t* canvas, int cw, int cws, int row0, int row_end, float dGx, float dGy) {
-    __shared__ __attribute__((aligned(16))) uint8_t s_img[MT_LDS];
-    __shared__ int s_open;
     const int tid = threadIdx.x;
     const int tx0 = blockIdx.x * MT_W, ty0 = row0 + blockIdx.y * MT_H;
-    // a lane owns 4 adjacent pixels in each of MT_RPL rows (rows ty0 + (tid >> 5) + 8 j): the tile's list / image / staging
-    // latencies are paid once per 16 pixels of a lane
+    // a lane owns 4 adjacent pixels in each of MT_RPL rows (rows ty0 + (tid >> 5) + 8 j): the tile's list / image loads are paid
+    // once per 4 MT_RPL pixels of a lane.  No workgroup-level coupling: a wave leaves as soon as its own pixels are resolved.
     const int xg = tx0 + 4 * (tid & 31), yB = ty0 + (tid >> 5);
     const int cb = ((ty0 - row0) / MT_COARSE) * bx_n + tx0 / MT_COARSE;
     const uint16_t* list = lists + (size_t)cb * n;
@@ -238,92 +235,44 @@ __global__ __launch_bounds__(256) void mosaic_tile_kernel(const FrameDev* fr, in
     const int tx1 = tx0 + MT_W - 1 < cw - 1 ? tx0 + MT_W - 1 : cw - 1;
     const int ty1 = ty0 + MT_H - 1 < row_end - 1 ? ty0 + MT_H - 1 : row_end - 1;
     for (int e = 0; e < cnt; e++) {
+        if (__builtin_amdgcn_ballot_w64(open != 0) == 0) break;          // every pixel of this wave has its sample
         const FrameDev& f = fr[list[e]];                 // uniform over the workgroup: scalar loads
         if (f.begX > tx1 || f.endX < tx0 || f.begY > ty1 || f.endY < ty0) continue;
-        if (tid == 0) s_open = 0;
-        __syncthreads();
-        if (open) s_open = 1;                            // benign race: everybody writes 1
-        __syncthreads();
-        if (!s_open) break;                              // every pixel of the tile has its sample
+        if (!open) continue;
         const float w1 = (float)(f.w - 1), h1 = (float)(f.h - 1);
-        // ---- footprint of the tile in this image: bounding box of the four tile corners, one pixel of margin ----
-        float fx0 = 3.0e38f, fx1 = -3.0e38f, fy0 = 3.0e38f, fy1 = -3.0e38f;
-        bool fin = true;
 #pragma unroll
-        for (int c = 0; c < 4; c++) {
-            const float xf = (float)((c & 1) ? tx1 : tx0) - dGx, yf = (float)((c & 2) ? ty1 : ty0) - dGy;
-            float xs, ys;
-            if (f.unit_den) { xs = f.inv[0] * xf + f.inv[1] * yf + f.inv[2]; ys = f.inv[3] * xf + f.inv[4] * yf + f.inv[5]; }
-            else hm::apply_div9(f.inv, xf, yf, xs, ys);
-            fin = fin && (xs == xs) && (ys == ys) && fabsf(xs) < 1.0e7f && fabsf(ys) < 1.0e7f;
-            fx0 = fminf(fx0, xs); fx1 = fmaxf(fx1, xs); fy0 = fminf(fy0, ys); fy1 = fmaxf(fy1, ys);
-        }
-        int sy0 = 0, srows = 0, pitch = 0, sb0 = 0;      // staged window: rows sy0.., bytes sb0.. (4-byte aligned) of each row
-        if (fin) {
-            int sx0 = (int)floorf(fx0) - 1, sx1 = (int)floorf(fx1) + 2;
-            sy0 = (int)floorf(fy0) - 1; int sy1 = (int)floorf(fy1) + 2;
-            sx0 = sx0 < 0 ? 0 : sx0; sy0 = sy0 < 0 ? 0 : sy0;
-            sx1 = sx1 > f.w - 1 ? f.w - 1 : sx1; sy1 = sy1 > f.h - 1 ? f.h - 1 : sy1;
-            // rows start 4-byte aligned in global memory when the image base and stride are; otherwise no staging
-            if (sx1 >= sx0 && sy1 >= sy0 && ((reinterpret_cast<uintptr_t>(f.src) | (unsigned)f.ws) & 3) == 0) {
-                sb0 = (3 * sx0) & ~3;
-                int sb1 = (3 * sx1 + 3 + 3) & ~3;                         // one past the last byte, rounded up
-                sb1 = sb1 > f.ws ? f.ws : sb1;                             // never past the row stride (a multiple of 4)
-                pitch = sb1 - sb0;
-                srows = sy1 - sy0 + 1;
-                if (pitch <= 0 || (size_t)pitch * srows > MT_LDS) srows = 0;
+        for (int j = 0; j < MT_RPL; j++) {
+            const int yD = yB + 8 * j;
+            const bool yin = yD >= f.begY && yD <= f.endY;
+            const float yf = (float)yD - dGy;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int xD = xg + k;
+                const bool want = ((open >> (4 * j + k)) & 1u) && yin && xD >= f.begX && xD <= f.endX;
+                const float xf = (float)xD - dGx;
+                float xs, ys;
+                if (f.unit_den) { xs = f.inv[0] * xf + f.inv[1] * yf + f.inv[2]; ys = f.inv[3] * xf + f.inv[4] * yf + f.inv[5]; }
+                else hm::apply_div9(f.inv, xf, yf, xs, ys);
+                const bool ok = want && (xs >= 0.0f && xs < w1 && ys >= 0.0f && ys < h1);      // also rejects NaN
+                if (!ok) continue;
+                const int xi = (int)xs, yi = (int)ys;
+                const float p = ys - (float)yi, q = xs - (float)xi;
+                float b00, g00, r00, b01, g01, r01, b10, g10, r10, b11, g11, r11;
+                // the 2 x 2 neighbourhood straight from the image: the lanes of a wave walk two nearly contiguous runs of the two
+                // source rows, so the 6-byte loads share their cache lines (staging the tile's footprint in LDS first was measured
+                // slower: 11.4 ms against 8.5 ms for the C3 canvas -- its barriers and 24 KB per workgroup cost more than the
+                // L1 / L2 hits they replace)
+                const uint8_t* g0 = f.src + (size_t)yi * f.ws + 3 * (size_t)xi;
+                load_pair<3>(g0, b00, g00, r00, b01, g01, r01);
+                load_pair<3>(g0 + f.ws, b10, g10, r10, b11, g11, r11);
+                const unsigned vb = hm::bilin(b00, b01, b10, b11, p, q), vg = hm::bilin(g00, g01, g10, g11, p, q), vr = hm::bilin(r00, r01, r10, r11, p, q);
+                // bytes 3k, 3k+1, 3k+2 of the row's 12: static positions
+                out[j][(3 * k) >> 2] |= vb << (8 * ((3 * k) & 3));
+                out[j][(3 * k + 1) >> 2] |= vg << (8 * ((3 * k + 1) & 3));
+                out[j][(3 * k + 2) >> 2] |= vr << (8 * ((3 * k + 2) & 3));
+                open &= ~(1u << (4 * j + k));
             }
         }
-        if (srows > 0) {
-            const int dw = pitch >> 2, total = dw * srows;
-            const float inv_dw = 1.0f / (float)dw;
-            for (int i = tid; i < total; i += 256) {
-                int r = (int)((float)i * inv_dw);                          // i / dw without the integer division (i < 2^13: exact after the fix-up)
-                r -= (r * dw > i); r += ((r + 1) * dw <= i);
-                const int c = i - r * dw;
-                reinterpret_cast<unsigned*>(s_img)[i] = *reinterpret_cast<const unsigned*>(f.src + (size_t)(sy0 + r) * f.ws + sb0 + 4 * c);
-            }
-        }
-        __syncthreads();
-        if (open) {
-#pragma unroll
-            for (int j = 0; j < MT_RPL; j++) {
-                const int yD = yB + 8 * j;
-                const bool yin = yD >= f.begY && yD <= f.endY;
-                const float yf = (float)yD - dGy;
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    const int xD = xg + k;
-                    const bool want = ((open >> (4 * j + k)) & 1u) && yin && xD >= f.begX && xD <= f.endX;
-                    const float xf = (float)xD - dGx;
-                    float xs, ys;
-                    if (f.unit_den) { xs = f.inv[0] * xf + f.inv[1] * yf + f.inv[2]; ys = f.inv[3] * xf + f.inv[4] * yf + f.inv[5]; }
-                    else hm::apply_div9(f.inv, xf, yf, xs, ys);
-                    const bool ok = want && (xs >= 0.0f && xs < w1 && ys >= 0.0f && ys < h1);      // also rejects NaN
-                    if (!ok) continue;
-                    const int xi = (int)xs, yi = (int)ys;
-                    const float p = ys - (float)yi, q = xs - (float)xi;
-                    float b00, g00, r00, b01, g01, r01, b10, g10, r10, b11, g11, r11;
-                    const int lr = yi - sy0, lb = 3 * xi - sb0;
-                    if (srows > 0 && lr >= 0 && lr + 1 < srows && lb >= 0 && lb + 6 <= pitch) {
-                        const uint8_t* l0 = s_img + lr * pitch + lb;
-                        load_pair<3>(l0, b00, g00, r00, b01, g01, r01);
-                        load_pair<3>(l0 + pitch, b10, g10, r10, b11, g11, r11);
-                    } else {
-                        const uint8_t* g0 = f.src + (size_t)yi * f.ws + 3 * (size_t)xi;
-                        load_pair<3>(g0, b00, g00, r00, b01, g01, r01);
-                        load_pair<3>(g0 + f.ws, b10, g10, r10, b11, g11, r11);
-                    }
-                    const unsigned vb = hm::bilin(b00, b01, b10, b11, p, q), vg = hm::bilin(g00, g01, g10, g11, p, q), vr = hm::bilin(r00, r01, r10, r11, p, q);
-                    // bytes 3k, 3k+1, 3k+2 of the row's 12: static positions
-                    out[j][(3 * k) >> 2] |= vb << (8 * ((3 * k) & 3));
-                    out[j][(3 * k + 1) >> 2] |= vg << (8 * ((3 * k + 1) & 3));
-                    out[j][(3 * k + 2) >> 2] |= vr << (8 * ((3 * k + 2) & 3));
-                    open &= ~(1u << (4 * j + k));
-                }
-            }
-        }
-        __syncthreads();                                 // s_img is restaged by the next image
     }
     if (xg >= cw) return;
 #pragma unroll
