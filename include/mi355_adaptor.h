@@ -155,6 +155,49 @@ inline int GetMatchedPairsOneToAllSIFT(int nImages, float ransacDist, unsigned s
     return rc;
 }
 
+// int CMosaicByPose::GetMatchedPairsOneToAllSurf(const ImagePoseInfo* pImgPoses, const int nImages, vector<MatchPointPairs>& vecMatchPairs,
+//                                                int& nSuccess)                                  MosaicWithoutPos.cpp:5300-5533
+// (m_minHessian, m_matchDist, m_maxFeatureNum, m_ransacDist are members there: UavMatchParam defaults 50 / 0.5 / 200 / 2.5.)
+// SURF features of every image, the ring schedule, exact float matching + distance selection + RANSAC; MatchPointPairs appended
+// like :5497-5517; nSuccess = 1 + accepted pairs (:5320, :5516).  `seed` stands for srand((unsigned)time(0)).
+template <class PoseT>
+inline int GetMatchedPairsOneToAllSurf(const PoseT* pImgPoses, const int nImages, std::vector<MI355_NS MatchPointPairs>& vecMatchPairs, int& nSuccess,
+                                       int minHessian = 50, float matchDist = 0.5f, int maxFeatureNum = 200, float ransacDist = 2.5f, unsigned seed = 1) {
+    nSuccess = 1;
+    mi355_ctx* c = context();
+    if (!c || !pImgPoses) return -1;
+    std::vector<int32_t> fixed(nImages > 0 ? nImages : 1, 0);
+    for (int i = 0; i < nImages; i++) {
+        const MI355_NS IplImage* im = pImgPoses[i].pImg;
+        if (!im) return -1;
+        fixed[i] = pImgPoses[i].fixed;
+        int n = 0;
+        const int rc = mi355_surf_extract(c, i, (const uint8_t*)im->imageData, im->width, im->height, im->widthStep, (float)minHessian, 8192, NULL, NULL, &n);
+        if (rc != MI355_OK) return rc;
+    }
+    int np = 0;
+    mi355_surf_pair_schedule(nImages, NULL, 0, &np);
+    if (np == 0) return 0;
+    std::vector<int32_t> pairs((size_t)2 * np);
+    mi355_surf_pair_schedule(nImages, &pairs[0], np, &np);
+    mi355_pair_result* res = (mi355_pair_result*)std::malloc(sizeof(mi355_pair_result) * (size_t)np);
+    if (!res) return -1;
+    int rc = mi355_surf_match_pairs(c, &pairs[0], np, ransacDist, seed, matchDist, maxFeatureNum, 18, res);
+    if (rc == MI355_OK) {
+        for (int p = 0; p < np; p++) nSuccess += res[p].accepted ? 1 : 0;
+        mi355_match_point_pairs* v = NULL; int n = 0;
+        rc = mi355_results_to_match_pairs(res, np, &fixed[0], &v, &n);
+        if (rc == MI355_OK) {
+            const size_t old = vecMatchPairs.size();
+            vecMatchPairs.resize(old + n);
+            if (n) std::memcpy(&vecMatchPairs[old], v, sizeof(mi355_match_point_pairs) * n);
+            mi355_free(v);
+        }
+    }
+    std::free(res);
+    return rc;
+}
+
 // int CMosaicByPose::MosaicImagesRefined(const ImagePoseInfo* pImgPoses, const int nImages, const ImageTransform* pRectified)
 //                                                                                              MosaicWithoutPos.cpp:2194-2352
 // The member writes m_pMosaicResult; here it is the last argument (released first when not NULL, like a second call would leak in

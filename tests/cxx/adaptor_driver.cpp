@@ -3,7 +3,7 @@
 // LaplacianPyramidBlending / MergeImagesRefined).  tests/test_gpu_cxx.py writes the inputs as raw binary files, runs this
 // program on the GPU box and compares what it writes with the golden vectors / the Python-side results.
 //
-//   adaptor_driver <dir> ransac | warp | mosaic | blend | threads
+//   adaptor_driver <dir> ransac | warp | mosaic | blend | threads | surf
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -154,6 +154,20 @@ int main(int argc, char** argv) {
         }
         write_ipl(dir + "/" + mode + ".out", result);
         cvReleaseImage(&result);
+    } else if (mode == "surf") {
+        // GetMatchedPairsOneToAllSurf through the adaptor: MatchPointPairs out (40-byte records) + nSuccess
+        std::vector<Img> imgs = read_images(dir + "/images.bin");
+        const int n = (int)imgs.size();
+        std::vector<ImagePoseInfo> poses(n);
+        for (int k = 0; k < n; k++) { poses[k].pImg = to_ipl(imgs[k]); poses[k].fixed = (k == 0); }
+        std::vector<MatchPointPairs> v; int nSuccess = 0;
+        if (mi355::GetMatchedPairsOneToAllSurf(&poses[0], n, v, nSuccess, 50, 0.5f, 200, 2.5f, 4u) != 0) return 6;
+        std::vector<unsigned char> out(8 + v.size() * sizeof(MatchPointPairs));
+        const int hd[2] = {nSuccess, (int)v.size()};
+        std::memcpy(&out[0], hd, 8);
+        if (!v.empty()) std::memcpy(&out[8], &v[0], v.size() * sizeof(MatchPointPairs));
+        spit(dir + "/surf.out", &out[0], out.size());
+        for (int k = 0; k < n; k++) cvReleaseImage(&poses[k].pImg);
     } else return 2;
     std::printf("DONE %s\n", mode.c_str());
     return 0;

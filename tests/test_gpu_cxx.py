@@ -119,3 +119,26 @@ def test_cxx_adaptor_eight_host_threads(tmp_path):
         assert ok == gok and nin == gnin
         if nin >= 4:
             assert np.array_equal(bits(H), bits(gH))
+
+
+def test_cxx_adaptor_surf_variant(tmp_path):
+    """mi355::GetMatchedPairsOneToAllSurf (MosaicWithoutPos.cpp:5300-5533) from C++: the appended MatchPointPairs equal the flattened
+    records of the Python-side call on the same frames (same seed), nSuccess = 1 + accepted pairs"""
+    import imagemosaicing_amd as im
+    from tests.synth_frames import strip
+    exe = build_driver(str(tmp_path))
+    frames = strip(6, 640, 480, seed=3)[0]
+    write_images(tmp_path / "images.bin", frames, [np.eye(3).reshape(9)] * len(frames))
+    run(exe, tmp_path, "surf")
+    raw = open(tmp_path / "surf.out", "rb").read()
+    n_success, n = np.frombuffer(raw[:8], np.int32)
+    got = np.frombuffer(raw[8:], im.MATCHPAIR)
+    assert len(got) == n
+    ctx = im.Context(0)
+    for k, f in enumerate(frames):
+        ctx.SurfExtract(k, f, 50.0, 8192)
+    res = ctx.SurfMatchPairs(im.surf_pair_schedule(len(frames)), 2.5, 4)
+    ctx.close()
+    want = im.results_to_match_pairs(res, fixed_flags=[1] + [0] * (len(frames) - 1))
+    assert n_success == 1 + int(res["accepted"].sum()) and n_success > 5
+    assert np.array_equal(got.view(np.uint8), want.view(np.uint8))
