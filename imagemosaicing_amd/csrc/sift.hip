@@ -71,22 +71,21 @@ struct BlurArgs {
     float* ds;               // blur_stream: also write the 2x decimated level (even rows, even columns) here: the next octave's base
 };
 
-// 2x bilinear upsample of the fixed-point gray image, pixel-centre aligned, edge clamp (exact in binary32)
+// 2x linear doubling of the fixed-point gray image, grids aligned at pixel (0, 0): up(2x, 2y) = gray(x, y), odd positions are the
+// mean of their neighbours, last column / row replicated (oracle_sift.c orc_sift says why this alignment: the reference's committed
+// keypoints).  Every sum is exact in binary32, so the order of evaluation is free.
 __device__ __forceinline__ float load_base(const uint8_t* bgr, int ws, int w, int h, int X, int Y) {
-    int x0 = (X & 1) ? (X >> 1) : (X >> 1) - 1, y0 = (Y & 1) ? (Y >> 1) : (Y >> 1) - 1;
-    const float wx1 = (X & 1) ? 0.25f : 0.75f, wy1 = (Y & 1) ? 0.25f : 0.75f;
-    int x1 = x0 + 1, y1 = y0 + 1;
-    if (x0 < 0) x0 = 0;
-    if (y0 < 0) y0 = 0;
+    const int x0 = X >> 1, y0 = Y >> 1;
+    int x1 = (X & 1) ? x0 + 1 : x0, y1 = (Y & 1) ? y0 + 1 : y0;
     if (x1 > w - 1) x1 = w - 1;
     if (y1 > h - 1) y1 = h - 1;
     auto gray = [&](int x, int y) {
         const uint8_t* p = bgr + (size_t)y * ws + 3 * x;
         return (float)((1868 * (int)p[0] + 9617 * (int)p[1] + 4899 * (int)p[2] + 8192) >> 14);
     };
-    const float a = fmaf(gray(x1, y0), wx1, gray(x0, y0) * (1.0f - wx1));
-    const float b = fmaf(gray(x1, y1), wx1, gray(x0, y1) * (1.0f - wx1));
-    return fmaf(b, wy1, a * (1.0f - wy1));
+    const float a = (gray(x0, y0) + gray(x1, y0)) * 0.5f;
+    const float b = (gray(x0, y1) + gray(x1, y1)) * 0.5f;
+    return (a + b) * 0.5f;
 }
 
 // XCD-aware remap: hardware places block b on XCD b % 8; give every XCD a contiguous run of tiles
@@ -123,14 +122,13 @@ __global__ __launch_bounds__(BT) void blur_tile(BlurArgs a) {
             const int ry = idx / COLS, rx = idx - ry * COLS;
             s_in[ry * PIN + rx] = base[(size_t)ry * a.w + rx];
         }
-    } else if (BGR && interior && ((x0 - R) >> 1) >= 1 && ((y0 - R) >> 1) >= 1 &&
-               ((x0 + TW - 1 + R) >> 1) + 1 <= (a.w >> 1) - 1 && ((y0 + TH - 1 + R) >> 1) + 1 <= (a.h >> 1) - 1) {
+    } else if (BGR && interior && ((x0 + TW - 1 + R) >> 1) + 1 <= (a.w >> 1) - 1 && ((y0 + TH - 1 + R) >> 1) + 1 <= (a.h >> 1) - 1) {
         // interior tile of the base level: the fixed-point gray of the low-resolution patch is computed ONCE into LDS
-        // (each frame byte is read once per tile instead of ~4x per staged sample), then up-sampled from there with the
-        // same two fmaf per axis as load_base.
+        // (each frame byte is read once per tile instead of ~4x per staged sample), then doubled from there with the same
+        // exact sums as load_base.
         constexpr int GW = (TW + 2 * R) / 2 + 3, GH = (TH + 2 * R) / 2 + 3;
         __shared__ float s_gray[GH * GW];
-        const int lxa = ((x0 - R) >> 1) - 1, lya = ((y0 - R) >> 1) - 1;
+        const int lxa = (x0 - R) >> 1, lya = (y0 - R) >> 1;
         for (int idx = tid; idx < GH * GW; idx += BT) {
             const int gy = idx / GW, gx = idx - gy * GW;
             const int ly = lya + gy, lx = lxa + gx;
@@ -145,13 +143,12 @@ __global__ __launch_bounds__(BT) void blur_tile(BlurArgs a) {
         for (int idx = tid; idx < ROWS * COLS; idx += BT) {
             const int ry = idx / COLS, rx = idx - ry * COLS;
             const int X = x0 - R + rx, Y = y0 - R + ry;
-            const int xl0 = ((X & 1) ? (X >> 1) : (X >> 1) - 1) - lxa, yl0 = ((Y & 1) ? (Y >> 1) : (Y >> 1) - 1) - lya;
-            const float wx1 = (X & 1) ? 0.25f : 0.75f, wy1 = (Y & 1) ? 0.25f : 0.75f;
-            const float* g0 = s_gray + yl0 * GW + xl0;
-            const float* g1 = g0 + GW;
-            const float aa = fmaf(g0[1], wx1, g0[0] * (1.0f - wx1));
-            const float bb = fmaf(g1[1], wx1, g1[0] * (1.0f - wx1));
-            s_in[ry * PIN + rx] = fmaf(bb, wy1, aa * (1.0f - wy1));
+            const float* g0 = s_gray + ((Y >> 1) - lya) * GW + ((X >> 1) - lxa);
+            const float* g1 = g0 + ((Y & 1) ? GW : 0);
+            const int dx = X & 1;
+            const float aa = (g0[0] + g0[dx]) * 0.5f;
+            const float bb = (g1[0] + g1[dx]) * 0.5f;
+            s_in[ry * PIN + rx] = (aa + bb) * 0.5f;
         }
     } else {
         for (int idx = tid; idx < ROWS * COLS; idx += BT) {
@@ -384,9 +381,9 @@ __global__ __launch_bounds__(256) void gray_pad_kernel(const uint8_t* bgr, int w
     *reinterpret_cast<unsigned*>(gray + (size_t)y * gp + xp) = out;
 }
 
-// UPS = true: the source is the padded u8 gray of the frame and the level being blurred is its 2x bilinear up-sampling
-// (pixel-centre aligned, weights 1/4 and 3/4, edge clamp: load_base above), formed on the fly -- every product and sum
-// is exact in binary32, so the order of evaluation is free.
+// UPS = true: the source is the padded u8 gray of the frame and the level being blurred is its 2x linear doubling (grids
+// aligned at pixel (0, 0), edge replicated: load_base above), formed on the fly -- every sum is exact in binary32, so the
+// order of evaluation is free.
 template <int R, int D, bool UPS>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void blur_stream(BlurArgs a, int L, int nstrip, int nseg) {
     constexpr int N = 2 * R + 1;
@@ -429,16 +426,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     };
     // ---- prefetch ring: raw source data of the next D steps ----
     struct Raw { v4f m; float h; unsigned ma, mb, ha, hb; };
-    const int gmain = 4 + (xl >> 1) - 1;                                   // UPS: byte column of the 4 gray pixels c-1..c+2
-    const int ghalo = 4 + ((chalo & 1) ? (chalo >> 1) : (chalo >> 1) - 1); // UPS: byte column of the halo pixel pair
-    const float hwx1 = (chalo & 1) ? 0.25f : 0.75f;
+    const int gmain = 4 + (xl >> 1) - 1;                                   // UPS: byte column of the 4 gray pixels c-1..c+2 (c = xl / 2)
+    const int ghalo = 4 + (chalo >> 1);                                    // UPS: byte column of the halo pixel pair
+    const bool hodd = (chalo & 1) != 0;
     const int hl1 = (a.h >> 1) - 1;
     auto load_raw = [&](int i, Raw& r) {
         const int gy = src_row(i);
         if constexpr (UPS) {
-            int ya = (gy & 1) ? (gy >> 1) : (gy >> 1) - 1;
-            int yb = ya + 1;
-            ya = ya < 0 ? 0 : ya;
+            const int ya = gy >> 1;                          // doubled row gy: gray row gy / 2, odd rows the mean with the next one
+            int yb = (gy & 1) ? ya + 1 : ya;
             yb = yb > hl1 ? hl1 : yb;
             const uint8_t* ra = a.bgr + (size_t)ya * a.bgr_ws;
             const uint8_t* rb = a.bgr + (size_t)yb * a.bgr_ws;
@@ -453,20 +449,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     };
     auto row_values = [&](int i, const Raw& r, v4f& m, float& hv) {
         if constexpr (UPS) {
-            const int gy = src_row(i);
-            const float wy1 = (gy & 1) ? 0.25f : 0.75f, wy0 = 1.0f - wy1;
+            // grids aligned at pixel (0, 0): doubled column 2c is gray column c, 2c + 1 the mean of c and c + 1 (load_base); rows
+            // likewise through ya / yb (ya == yb on even rows: (x + x) / 2 = x).  All sums exact in binary32.
             auto hrow = [&](unsigned q, v4f& o) {
-                const float b0 = (float)(q & 255u), b1 = (float)((q >> 8) & 255u), b2 = (float)((q >> 16) & 255u), b3 = (float)(q >> 24);
-                o.x = fmaf(b1, 0.75f, b0 * 0.25f); o.y = fmaf(b2, 0.25f, b1 * 0.75f);
-                o.z = fmaf(b2, 0.75f, b1 * 0.25f); o.w = fmaf(b3, 0.25f, b2 * 0.75f);
+                const float b1 = (float)((q >> 8) & 255u), b2 = (float)((q >> 16) & 255u), b3 = (float)(q >> 24);
+                o.x = b1; o.y = (b1 + b2) * 0.5f; o.z = b2; o.w = (b2 + b3) * 0.5f;
             };
             v4f ha4, hb4;
             hrow(r.ma, ha4); hrow(r.mb, hb4);
-            m.x = fmaf(hb4.x, wy1, ha4.x * wy0); m.y = fmaf(hb4.y, wy1, ha4.y * wy0);
-            m.z = fmaf(hb4.z, wy1, ha4.z * wy0); m.w = fmaf(hb4.w, wy1, ha4.w * wy0);
+            m.x = (ha4.x + hb4.x) * 0.5f; m.y = (ha4.y + hb4.y) * 0.5f; m.z = (ha4.z + hb4.z) * 0.5f; m.w = (ha4.w + hb4.w) * 0.5f;
             const float a0 = (float)(r.ha & 255u), a1 = (float)(r.ha >> 8), c0 = (float)(r.hb & 255u), c1 = (float)(r.hb >> 8);
-            const float qa = fmaf(a1, hwx1, a0 * (1.0f - hwx1)), qb = fmaf(c1, hwx1, c0 * (1.0f - hwx1));
-            hv = fmaf(qb, wy1, qa * wy0);
+            const float qa = hodd ? (a0 + a1) * 0.5f : a0, qb = hodd ? (c0 + c1) * 0.5f : c0;
+            hv = (qa + qb) * 0.5f;
         } else { m = r.m; hv = r.h; }
     };
     Raw pf[D];

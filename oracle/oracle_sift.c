@@ -12,7 +12,8 @@
  * the cv::SIFT class the reference instantiates (class declaration: nonfree/features2d.hpp:58-100;
  * parameters nfeatures=2000, nOctaveLayers=3, contrastThreshold=0.01, edgeThreshold=20, sigma=1.6):
  *   1. gray = (1868 B + 9617 G + 4899 R + 8192) >> 14, as float              (8-bit BGR2GRAY fixed point)
- *   2. base = 2x bilinear upsample (pixel centres, edge clamp), Gaussian blur with
+ *   2. base = 2x linear doubling (grids aligned at pixel (0,0), edge replicated; the alignment is chosen by the reference's
+ *      committed keypoints, see orc_sift), Gaussian blur with
  *      sqrt(sigma^2 - (2*0.5)^2)                                               (first octave = -1)
  *   3. per octave 6 Gaussian levels built incrementally, sigma_i = sqrt((s k^i)^2 - (s k^(i-1))^2),
  *      k = 2^(1/3); kernel width round(8 sigma + 1) | 1, taps (float)exp(-x^2 / 2 sigma^2) summed in double and normalised
@@ -330,7 +331,15 @@ int orc_sift(const uint8_t* bgr, int w, int h, int ws, int nfeatures, orc_keypoi
     const double sigma = 1.6;
     const float contrast_thr = 0.01f, edge_thr = 20.0f;
     const int W = 2 * w, H = 2 * h;
-    /* 1-2: gray, 2x upsample (weights 0.75/0.25, edge clamp) -- exact in binary32 */
+    /* 1-2: gray, 2x linear doubling with the sample grids aligned at pixel (0, 0): up(2x, 2y) = gray(x, y), odd positions are the
+     * mean of their two (four) neighbours, last column / row replicated -- every value exact in binary32, any order.
+     * WHY this alignment: the reference's committed run (Release/feature_temp/matchPairs.match: 8220 distinct keypoints that
+     * OpenCV 2.4.0's SIFT produced on Release/test_data/DSC00004..23.JPG) decides between the candidates
+     *     pixel-centre aligned doubling (weights 1/4, 3/4; what cv::resize INTER_LINEAR does today): keypoints systematically
+     *         (+0.25, +0.25) px off the reference's, all octaves alike; with that offset removed 52 % within 0.1 px
+     *     [1 4 6 4 1]/8 pyrUp-style doubling: 62 % within 0.1 px
+     *     this one: 71 % within 0.1 px (18 % within 0.02 px), residual mean (0.000, -0.001), std 0.07 px
+     * (tests/test_sift_reference_run.py keeps the measurement alive on the two frames committed under tests/golden/). */
     float* gray = (float*)malloc(sizeof(float) * (size_t)w * h);
     for (int y = 0; y < h; y++)
         for (int x = 0; x < w; x++) {
@@ -339,18 +348,14 @@ int orc_sift(const uint8_t* bgr, int w, int h, int ws, int nfeatures, orc_keypoi
         }
     float* up = (float*)malloc(sizeof(float) * (size_t)W * H);
     for (int Y = 0; Y < H; Y++) {
-        int y0 = (Y & 1) ? (Y >> 1) : (Y >> 1) - 1; float wy1 = (Y & 1) ? 0.25f : 0.75f;
-        int y1 = y0 + 1;
-        if (y0 < 0) y0 = 0;
+        int y0 = Y >> 1, y1 = (Y & 1) ? y0 + 1 : y0;
         if (y1 > h - 1) y1 = h - 1;
         for (int X = 0; X < W; X++) {
-            int x0 = (X & 1) ? (X >> 1) : (X >> 1) - 1; float wx1 = (X & 1) ? 0.25f : 0.75f;
-            int x1 = x0 + 1;
-            if (x0 < 0) x0 = 0;
+            int x0 = X >> 1, x1 = (X & 1) ? x0 + 1 : x0;
             if (x1 > w - 1) x1 = w - 1;
-            float a = fmaf(gray[(size_t)y0 * w + x1], wx1, gray[(size_t)y0 * w + x0] * (1.0f - wx1));
-            float b = fmaf(gray[(size_t)y1 * w + x1], wx1, gray[(size_t)y1 * w + x0] * (1.0f - wx1));
-            up[(size_t)Y * W + X] = fmaf(b, wy1, a * (1.0f - wy1));
+            float a = (gray[(size_t)y0 * w + x0] + gray[(size_t)y0 * w + x1]) * 0.5f;
+            float b = (gray[(size_t)y1 * w + x0] + gray[(size_t)y1 * w + x1]) * 0.5f;
+            up[(size_t)Y * W + X] = (a + b) * 0.5f;
         }
     }
     free(gray);
