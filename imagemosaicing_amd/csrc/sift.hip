@@ -69,6 +69,7 @@ struct BlurArgs {
     int nb;                  // src + f * fstride and writes dst + f * fstride (floats); nb = frames in the batch (0 or 1: single)
     size_t gstride;          // blur_stream UPS: frame f reads the padded gray at bgr + f * gstride (bytes)
     float* ds;               // blur_stream: also write the 2x decimated level (even rows, even columns) here: the next octave's base
+    int band;                // blur_stream: > 0 = only the first and the last `band` rows of the level (two segments; the cascade did the rest)
 };
 
 // 2x linear doubling of the fixed-point gray image, grids aligned at pixel (0, 0): up(2x, 2y) = gray(x, y), odd positions are the
@@ -351,8 +352,12 @@ template <int J, int NPP, class F> __device__ __forceinline__ bool static_rows(F
     else return true;
 }
 
-// fixed-point gray of the frame as u8 (the values are integers 0..255), rows padded by 4 replicated pixels on each side
-// so that the 2x up-sampling below never clamps a column: gray[y * gp + 4 + x], x in [-4, w + 4)
+// fixed-point gray of the frame as u8 (the values are integers 0..255): gray[y * gp + GPAD + x], x in [-GPAD, w + GPAD).
+// The padding continues the row so that the 2x doubling of the PADDED row is the reflect-101 continuation of the doubled
+// row: gray[-k] = gray[k] on the left, gray[w + i] = gray[w - 1 - i] on the right (the doubled row ends with a replicated
+// column, so its mirror axis sits on gray column w - 1/2).  Kernels that form doubled columns on the fly therefore never
+// test for the image border.
+constexpr int GPAD = 32;
 __global__ __launch_bounds__(256) void gray_pad_kernel(const uint8_t* bgr, int ws, int w, int h, uint8_t* gray, int gp) {
     // 4 pixels per lane: 12 source bytes (three dwords when the row and the group are 4-byte aligned), one dword store
     const int g = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
@@ -360,7 +365,7 @@ __global__ __launch_bounds__(256) void gray_pad_kernel(const uint8_t* bgr, int w
     if (xp >= gp) return;
     const uint8_t* row = bgr + (size_t)y * ws;
     unsigned out = 0;
-    const int x0 = xp - 4;
+    const int x0 = xp - GPAD;
     if (x0 >= 0 && x0 + 3 <= w - 1 && (((uintptr_t)row | (unsigned)ws) & 3) == 0) {
         const unsigned* q = reinterpret_cast<const unsigned*>(row + 3 * x0);     // 3 * x0 is a multiple of 12
         const unsigned d0 = q[0], d1 = q[1], d2 = q[2];
@@ -373,6 +378,7 @@ __global__ __launch_bounds__(256) void gray_pad_kernel(const uint8_t* bgr, int w
 #pragma unroll
         for (int c = 0; c < 4; c++) {
             int x = x0 + c;
+            x = x < 0 ? -x : (x > w - 1 ? 2 * w - 1 - x : x);
             x = x < 0 ? 0 : (x > w - 1 ? w - 1 : x);
             const uint8_t* p = row + 3 * x;
             out |= (unsigned)((1868 * (int)p[0] + 9617 * (int)p[1] + 4899 * (int)p[2] + 8192) >> 14) << (8 * c);
@@ -405,8 +411,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
     const int seg = unit / nstrip, strip = unit - seg * nstrip;
     if (seg >= nseg) return;
-    const int x0 = strip * SW, y0 = seg * L;
-    const int lact = (a.h - y0 < L) ? a.h - y0 : L;
+    const int x0 = strip * SW, y0 = a.band ? (seg ? a.h - a.band : 0) : seg * L;
+    const int lact = a.band ? a.band : ((a.h - y0 < L) ? a.h - y0 : L);
     const int nin = lact + 2 * R;
     // columns: main float4 (clamped into the row for a partial last strip), one halo dword per lane (reflect-101),
     // and for a partial last strip the reflected columns right of the image are patched inside LDS
@@ -426,8 +432,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     };
     // ---- prefetch ring: raw source data of the next D steps ----
     struct Raw { v4f m; float h; unsigned ma, mb, ha, hb; };
-    const int gmain = 4 + (xl >> 1) - 1;                                   // UPS: byte column of the 4 gray pixels c-1..c+2 (c = xl / 2)
-    const int ghalo = 4 + (chalo >> 1);                                    // UPS: byte column of the halo pixel pair
+    const int gmain = GPAD + (xl >> 1) - 1;                                // UPS: byte column of the 4 gray pixels c-1..c+2 (c = xl / 2)
+    const int ghalo = GPAD + (chalo >> 1);                                 // UPS: byte column of the halo pixel pair
     const bool hodd = (chalo & 1) != 0;
     const int hl1 = (a.h >> 1) - 1;
     auto load_raw = [&](int i, Raw& r) {
@@ -526,6 +532,300 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             return true;
         };
         if (!static_rows<0, NP>(step)) return;
+    }
+}
+
+// ---- pyr_cascade: ALL Gaussian levels of one octave in one pass (option "sift_cascade", default off) ----------------------
+// The per-level kernels above move every level through HBM twice (written by one launch, read by the next).  Here a
+// workgroup keeps a 512-column strip of ALL levels of the octave in flight and walks down the rows once: every level row is
+// written to HBM once and handed to the next level through LDS, never read back (6 level writes per octave instead of
+// 6 writes + 5 reads).  Same arithmetic as everywhere else (acc = 0; acc = fmaf(k[i], x[i], acc), ascending i, rows then
+// columns), so the bits do not change (tests/test_gpu_configs.py runs the 12 MP parity check with the option on).
+//   * one WAVE = one level of one pipeline (256 columns, 4 per lane): its column accumulators live in registers exactly like
+//     blur_stream's.  Octave 0: 12 waves = 2 pipelines x {doubling + L0, L1 .. L5}; other octaves: 10 waves = 2 x {L0 load + L1,
+//     L2 .. L5}.  Waves w, w + 4, w + 8 share a SIMD (measured); the role table gives every SIMD the same number of packed
+//     FMAs per row (211 / 204 / 211 / 204 resp. 180 / 180 / 176 / 176).
+//   * one s_barrier per row step: at step t a level reads the row its producer completed at step t - 1 (double-buffered LDS
+//     rows of the whole strip: the halo columns come from the neighbour pipeline's wave) and completes its own row t - lag.
+//     Inside a wave the window load of step t is issued first and hides behind the column pass of step t - 1's row.
+//   * the accumulator ring is 2R + U slots; the row loop is unrolled U = 8 times (compile-time slots) and the 2R live slots
+//     move down once per U rows, which keeps each loop at ~10 KB of code instead of a full ring period.
+//   * columns: the strip origin is 48 columns left of the 416 columns it stores (sum of the radii = 47); the computed columns
+//     outside that are the shrinking halo.  At the image's left / right edge the lanes owning columns 1..16 / w-17..w-2 also
+//     write their reflect-101 mirror positions into the LDS row, the out-of-image lanes write nothing: every level sees
+//     exactly BORDER_REFLECT_101 of the previous one.
+//   * rows: only rows [48, h - 48) are produced here (no vertical reflection inside the pipeline: the order in which a
+//     reflected row enters an accumulator matters for the bits); the 48 rows at the top and bottom of every level are done
+//     afterwards by blur_stream in band mode, level by level.
+// MEASURED (MI355X, 8 frames 4000x3000 per launch, scratch/casc_time.py): the three cascade launches (octaves 0-2) take 5.6 ms
+// against 5.45 ms for the 26 per-level launches they replace (+0.5 ms for the band launches): the pass is VALU-bound where
+// the per-level kernels are HBM-bound.  v_pk_fma_f32 issues at 4 cycles per wave64 (scratch/pkfma_bench.hip: same FMA rate as
+// v_fma_f32 at 2), the 400 packed FMAs per 256-pixel row of a pipeline need 146 us per 12 MP frame at full issue rate, the
+// strip / segment overlap costs x1.45 (416 of 512 columns, 738 of 844 rows), the non-FMA instructions (window shuffles, ring
+// moves, stores) another x1.5; rocprofv3 --pmc: VALU busy 47 %, waves parked (barrier / lgkmcnt) 41 % of their cycles for the
+// 4-stage variant, ~68 % VALU busy for this one.  End to end (bench.py C3) 951 pairs/s with the option on against 969 off,
+// so it stays off; variants tried: 2 and 3 pipelines x 4 two-level stages (5.9 / 5.3 ms), U = 2 / 4 / 8 (no difference: not
+// instruction-cache bound), mirror writes behind a wave-uniform flag (1.5x slower).
+namespace casc {
+constexpr int NPIPE = 2, WGW = 256 * NPIPE, HC = 48, SV = WGW - 2 * HC, BUFO = 16, BUFW = WGW + 2 * BUFO, VB = 48;
+struct Args {
+    const uint8_t* gray; int gp; size_t gstride; int gh;   // octave 0: padded gray frames (gray_pad_kernel), pitch, frame stride (bytes), rows
+    const float* src0;                                       // other octaves: level 0 (read)
+    float* lv[N_LEVELS];                                     // levels written (octave 0: 0..5, others 1..5)
+    float* ds;                                               // 2x decimated level 3 = the next octave's level 0, or null
+    size_t fstride; int nb;                                  // frame f at + f * fstride (floats)
+    int w, h;                                                // level size
+    int nstrip, nseg, lseg;
+    float k[N_LEVELS][2 * MAX_R + 2];                        // taps of level i (k[0] = the base blur; unused for the other octaves)
+};
+
+// one level, one row step, in three pieces so that the LDS latency of this step's window hides behind the column pass of the
+// PREVIOUS step's row (software pipelining inside the wave; costs one more step of lag per level):
+//   win_load : the lane's window of the incoming row (LDS -> registers), issued first
+//   col_pass : scatter the row-filtered previous row into the column accumulators; returns the completed row.
+//              Slot of output row o at local step J: tap t goes to slot J + 2R - t (tap 0 opens slot J + 2R, tap 2R closes slot J).
+//   row_pass : row filter of the window -> (r01, r23), consumed by the next step's col_pass
+template <int R> struct Win { static constexpr int RA = (R + 3) & ~3, S = RA - R, NG = (S + 2 * R + 4 + 3) / 4; float e[NG * 4]; };
+template <int R> __device__ __forceinline__ void win_load(const float* row, int c, Win<R>& w) {
+    const v4f* w4 = reinterpret_cast<const v4f*>(row + (c - Win<R>::RA + BUFO));
+#pragma unroll
+    for (int g = 0; g < Win<R>::NG; g++) { const v4f tt = w4[g]; w.e[4 * g] = tt.x; w.e[4 * g + 1] = tt.y; w.e[4 * g + 2] = tt.z; w.e[4 * g + 3] = tt.w; }
+}
+template <int R> __device__ __forceinline__ void row_pass(const Win<R>& w, const v2f (&kp)[R + 1], v2f& r01, v2f& r23) {
+    constexpr int S = Win<R>::S;
+#pragma unroll
+    for (int t = 0; t <= 2 * R; t++) {
+        const v2f e01 = {w.e[S + t], w.e[S + t + 1]}, e23 = {w.e[S + t + 2], w.e[S + t + 3]};
+        if (t == 0) { r01 = pkfma_klo0(kp[0], e01); r23 = pkfma_klo0(kp[0], e23); }
+        else if (t & 1) { pkfma_khi(kp[t >> 1], e01, r01); pkfma_khi(kp[t >> 1], e23, r23); }
+        else { pkfma_klo(kp[t >> 1], e01, r01); pkfma_klo(kp[t >> 1], e23, r23); }
+    }
+}
+template <int R, int U, int J>
+__device__ __forceinline__ v4f col_pass(const v2f r01, const v2f r23, v2f (&a01)[2 * R + U], v2f (&a23)[2 * R + U], const v2f (&kp)[R + 1]) {
+#pragma unroll
+    for (int t = 0; t <= 2 * R; t++) {
+        const int slot = J + 2 * R - t;
+        if (t == 0) { a01[slot] = pkfma_klo0(kp[0], r01); a23[slot] = pkfma_klo0(kp[0], r23); }
+        else if (t & 1) { pkfma_khi(kp[t >> 1], r01, a01[slot]); pkfma_khi(kp[t >> 1], r23, a23[slot]); }
+        else { pkfma_klo(kp[t >> 1], r01, a01[slot]); pkfma_klo(kp[t >> 1], r23, a23[slot]); }
+    }
+    return (v4f){a01[J].x, a01[J].y, a23[J].x, a23[J].y};
+}
+template <int R, int U> __device__ __forceinline__ void ring_shift(v2f (&a01)[2 * R + U], v2f (&a23)[2 * R + U]) {
+#pragma unroll
+    for (int q = 0; q < 2 * R; q++) { a01[q] = a01[q + U]; a23[q] = a23[q + U]; }
+}
+template <int R, int U> __device__ __forceinline__ void ring_zero(v2f (&a01)[2 * R + U], v2f (&a23)[2 * R + U]) {
+#pragma unroll
+    for (int q = 0; q < 2 * R + U; q++) { a01[q] = (v2f){0.0f, 0.0f}; a23[q] = (v2f){0.0f, 0.0f}; }
+}
+template <int R> __device__ __forceinline__ void load_taps(const float* k, v2f (&kp)[R + 1]) {
+#pragma unroll
+    for (int m = 0; m <= R; m++) { kp[m].x = k[2 * m]; kp[m].y = (2 * m + 1 <= 2 * R) ? k[2 * m + 1] : 0.0f; }
+}
+// a level row into its LDS row buffer: own columns (in-image lanes only) plus the reflect-101 copies beyond the image's left /
+// right edge (lanes owning columns 1..16 / w-17..w-2).  The predicates are loop invariant lane masks; a wave without such a
+// lane skips the block with one branch.  (A variant that hid the index arithmetic behind a wave-uniform flag ran 1.5x slower.)
+__device__ __forceinline__ void put_row(float* buf, int c, int x, int w, v4f o) {
+    if (x >= 0 && x < w) {
+        *reinterpret_cast<v4f*>(buf + BUFO + c) = o;
+        if (x <= 16 || x + 3 >= w - 17) {
+            const float v[4] = {o.x, o.y, o.z, o.w};
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int xx = x + q;
+                if (xx >= 1 && xx <= 16 && BUFO + c + q - 2 * xx >= 0) buf[BUFO + c + q - 2 * xx] = v[q];
+                if (xx >= w - 17 && xx <= w - 2) { const int idx = BUFO + c + q + 2 * (w - 1 - xx); if (idx < BUFW) buf[idx] = v[q]; }
+            }
+        }
+    }
+}
+__device__ __forceinline__ void step_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+}  // namespace casc
+
+// one wave = one level of one pipeline (octave 0: wave 0 of a pipeline also forms the doubled gray rows; other octaves: the
+// wave of level 1 also moves level 0 from HBM into LDS).  NW waves per workgroup: 12 (octave 0: 6 levels x 2 pipelines) / 10.
+template <bool OCT0>
+__global__ __launch_bounds__(OCT0 ? 768 : 640) __attribute__((amdgpu_waves_per_eu(3, 3))) void pyr_cascade(casc::Args a) {
+    using namespace casc;
+    constexpr int RR[N_LEVELS] = {5, 5, 6, 8, 10, 13};
+    // lag of level i: step t completes row ys + t - G[i]   (a level's column pass runs one step behind its row pass, and a
+    // level reads the row its producer completed in the previous step: + 2 + R per level)
+    constexpr int G0 = OCT0 ? RR[0] + 1 : -1, G1 = OCT0 ? G0 + 2 + RR[1] : RR[1] + 1, G2 = G1 + 2 + RR[2], G3 = G2 + 2 + RR[3], G4 = G3 + 2 + RR[4], G5 = G4 + 2 + RR[5];
+    __shared__ __attribute__((aligned(16))) float s_row[6][2][BUFW];          // [0] = the doubled gray (octave 0), [1 + i] = level i
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // role table: waves w, w + 4, w + 8 share a SIMD (measured: scratch/hwid.hip).  Packed FMAs per row and level:
+    // 59 (doubling + level 0) 44 52 68 84 108.   octave 0: {L5 F0 L1} {L5 L2 L1} {L4 L3 F0} {L4 L3 L2} = 211 / 204 / 211 / 204
+    //                                            others:   {L4 L2 L1} {L4 L2 L1} {L5 L3} {L5 L3}       = 180 / 180 / 176 / 176
+    static_assert(NPIPE == 2, "role tables");
+    int level = 0, pipe = 0;
+    {
+        constexpr int lv0[12] = {5, 5, 4, 4, 0, 2, 3, 3, 1, 1, 0, 2}, pp0[12] = {0, 1, 0, 1, 1, 0, 1, 0, 0, 1, 0, 1};
+        constexpr int lvx[10] = {4, 4, 5, 5, 2, 2, 3, 3, 1, 1}, ppx[10] = {0, 1, 0, 1, 0, 1, 0, 1, 0, 1};
+#pragma unroll
+        for (int i = 0; i < (OCT0 ? 12 : 10); i++) if (wave == i) { level = OCT0 ? lv0[i] : lvx[i]; pipe = OCT0 ? pp0[i] : ppx[i]; }
+        level = __builtin_amdgcn_readfirstlane(level); pipe = __builtin_amdgcn_readfirstlane(pipe);
+    }
+    int unit = xcd_remap(blockIdx.x, gridDim.x);
+    {
+        const int per = a.nstrip * a.nseg, fr = unit / per;
+        if (fr >= (a.nb > 1 ? a.nb : 1)) return;
+        unit -= fr * per;
+        if (OCT0) a.gray += (size_t)fr * a.gstride; else a.src0 += (size_t)fr * a.fstride;
+#pragma unroll
+        for (int i = 0; i < N_LEVELS; i++) a.lv[i] += (size_t)fr * a.fstride;
+        if (a.ds) a.ds += (size_t)fr * a.fstride;
+    }
+    const int seg = unit / a.nstrip, strip = unit - seg * a.nstrip;
+    const int X0 = strip * SV - HC;
+    const int c = 256 * pipe + 4 * lane, x = X0 + c;
+    const int s0 = VB + seg * a.lseg;
+    const int s1 = (s0 + a.lseg < a.h - VB) ? s0 + a.lseg : a.h - VB;
+    const int ys = s0 - VB;                                                   // first input row
+    const int T = (s1 - s0) + VB + G5 + 1;                                    // steps until the last level's row s1 - 1 is complete
+    const int TP = ((T + 7) / 8) * 8;                                         // every wave runs the same number of barriers
+    const bool colst = c >= HC && c < HC + SV && x < a.w;                    // this lane's columns are stored (x >= 0 follows)
+    const int hm1 = a.h - 1;
+    float* const bU = &s_row[0][0][0];
+    auto rowbuf = [&](int i, int par) { return bU + ((1 + i) * 2 + (par & 1)) * BUFW; };
+    auto store = [&](float* lvl, int r, v4f o) {
+        if (colst && r >= s0 && r < s1) *reinterpret_cast<v4f*>(lvl + (size_t)r * a.w + x) = o;
+    };
+    // the generic level: reads the rows of level LV - 1 its producer completed one step earlier, writes level LV
+    auto run_level = [&](auto lvc, auto gc) {
+        constexpr int LV = decltype(lvc)::value, G = decltype(gc)::value, R = RR[LV], U = 8;
+        v2f kp[R + 1];
+        load_taps<R>(a.k[LV], kp);
+        v2f q01[2 * R + U], q23[2 * R + U];
+        ring_zero<R, U>(q01, q23);
+        v2f r01 = {0.0f, 0.0f}, r23 = r01;
+        step_barrier();                                                       // the producers' priming barrier
+        for (int tb = 0; tb < TP; tb += U) {
+            auto step = [&](auto jc) -> bool {
+                constexpr int j = decltype(jc)::value;
+                const int t = tb + j;
+                Win<R> w;
+                win_load<R>(rowbuf(LV - 1, t - 1), c, w);
+                const v4f o = col_pass<R, U, j>(r01, r23, q01, q23, kp);
+                if constexpr (LV < N_LEVELS - 1) put_row(rowbuf(LV, t), c, x, a.w, o);
+                const int r = ys + t - G;
+                store(a.lv[LV], r, o);
+                if constexpr (LV == N_LAYERS) {                               // level 3 also seeds the next octave
+                    if (a.ds && colst && r >= s0 && r < s1 && !(r & 1) && (r >> 1) < (a.h >> 1)) {
+                        const v2f d2 = {o.x, o.z};
+                        *reinterpret_cast<v2f*>(a.ds + (size_t)(r >> 1) * (a.w >> 1) + (x >> 1)) = d2;
+                    }
+                }
+                row_pass<R>(w, kp, r01, r23);
+                step_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                return true;
+            };
+            static_rows<0, U>(step);
+            ring_shift<R, U>(q01, q23);
+        }
+    };
+    using std::integral_constant;
+    if (level == 5) { run_level(integral_constant<int, 5>{}, integral_constant<int, G5>{}); return; }
+    if (level == 4) { run_level(integral_constant<int, 4>{}, integral_constant<int, G4>{}); return; }
+    if (level == 3) { run_level(integral_constant<int, 3>{}, integral_constant<int, G3>{}); return; }
+    if (level == 2) { run_level(integral_constant<int, 2>{}, integral_constant<int, G2>{}); return; }
+    if constexpr (OCT0) {
+        if (level == 1) { run_level(integral_constant<int, 1>{}, integral_constant<int, G1>{}); return; }
+        // doubling + level 0
+        constexpr int U = 8, D = 4, R = RR[0];
+        v2f kp[R + 1];
+        load_taps<R>(a.k[0], kp);
+        v2f q01[2 * R + U], q23[2 * R + U];
+        ring_zero<R, U>(q01, q23);
+        v2f r01 = {0.0f, 0.0f}, r23 = r01;
+        int gx = GPAD + (x >> 1);                                             // byte column of gray pixel x / 2 (x is a multiple of 4, may be negative)
+        gx = gx < 0 ? 0 : (gx > a.gp - 4 ? a.gp - 4 : gx);
+        const int gh1 = a.gh - 1;
+        struct Raw { unsigned a, b; };
+        auto load_raw = [&](int t, Raw& r) {                                  // doubled row ys + t
+            int gy = ys + t;
+            gy = gy > hm1 ? hm1 : gy;
+            const int ya = gy >> 1;
+            int yb = (gy & 1) ? ya + 1 : ya;
+            yb = yb > gh1 ? gh1 : yb;
+            __builtin_memcpy(&r.a, a.gray + (size_t)ya * a.gp + gx, 4);
+            __builtin_memcpy(&r.b, a.gray + (size_t)yb * a.gp + gx, 4);
+        };
+        auto form = [&](const Raw& r) {
+            auto hrow = [&](unsigned q, v4f& o) {
+                const float b0 = (float)(q & 255u), b1 = (float)((q >> 8) & 255u), b2 = (float)((q >> 16) & 255u);
+                o.x = b0; o.y = (b0 + b1) * 0.5f; o.z = b1; o.w = (b1 + b2) * 0.5f;
+            };
+            v4f ha, hb;
+            hrow(r.a, ha); hrow(r.b, hb);
+            return (v4f){(ha.x + hb.x) * 0.5f, (ha.y + hb.y) * 0.5f, (ha.z + hb.z) * 0.5f, (ha.w + hb.w) * 0.5f};
+        };
+        Raw pf[D];
+#pragma unroll
+        for (int d = 0; d < D; d++) load_raw(d, pf[d]);
+        *reinterpret_cast<v4f*>(bU + 0 * BUFW + BUFO + c) = form(pf[0]);      // doubled row of step 0
+        load_raw(D, pf[0]);
+        step_barrier();
+        for (int tb = 0; tb < TP; tb += U) {
+            auto step = [&](auto jc) -> bool {
+                constexpr int j = decltype(jc)::value;
+                const int t = tb + j;
+                Win<R> w;
+                win_load<R>(bU + (t & 1) * BUFW, c, w);
+                *reinterpret_cast<v4f*>(bU + ((t + 1) & 1) * BUFW + BUFO + c) = form(pf[(j + 1) % D]);
+                load_raw(t + 1 + D, pf[(j + 1) % D]);
+                const v4f o = col_pass<R, U, j>(r01, r23, q01, q23, kp);
+                put_row(rowbuf(0, t), c, x, a.w, o);
+                store(a.lv[0], ys + t - G0, o);
+                row_pass<R>(w, kp, r01, r23);
+                step_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                return true;
+            };
+            static_rows<0, U>(step);
+            ring_shift<R, U>(q01, q23);
+        }
+    } else {
+        // level 0 from HBM into LDS + level 1
+        constexpr int U = 8, D = 4, R = RR[1];
+        v2f kp[R + 1];
+        load_taps<R>(a.k[1], kp);
+        v2f q01[2 * R + U], q23[2 * R + U];
+        ring_zero<R, U>(q01, q23);
+        v2f r01 = {0.0f, 0.0f}, r23 = r01;
+        const int xl = x < 0 ? 0 : (x > a.w - 4 ? a.w - 4 : x);
+        auto load_raw = [&](int t, v4f& r) {
+            int gy = ys + t;
+            gy = gy > hm1 ? hm1 : gy;
+            r = *reinterpret_cast<const v4f*>(a.src0 + (size_t)gy * a.w + xl);
+        };
+        v4f pf[D];
+#pragma unroll
+        for (int d = 0; d < D; d++) load_raw(d, pf[d]);
+        put_row(rowbuf(0, 0), c, x, a.w, pf[0]);
+        load_raw(D, pf[0]);
+        step_barrier();
+        for (int tb = 0; tb < TP; tb += U) {
+            auto step = [&](auto jc) -> bool {
+                constexpr int j = decltype(jc)::value;
+                const int t = tb + j;
+                Win<R> w;
+                win_load<R>(rowbuf(0, t), c, w);
+                put_row(rowbuf(0, t + 1), c, x, a.w, pf[(j + 1) % D]);
+                load_raw(t + 1 + D, pf[(j + 1) % D]);
+                const v4f o = col_pass<R, U, j>(r01, r23, q01, q23, kp);
+                put_row(rowbuf(1, t), c, x, a.w, o);
+                store(a.lv[1], ys + t - G1, o);
+                row_pass<R>(w, kp, r01, r23);
+                step_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                return true;
+            };
+            static_rows<0, U>(step);
+            ring_shift<R, U>(q01, q23);
+        }
     }
 }
 
@@ -1545,6 +1845,31 @@ inline void launch_base_stream(hipStream_t st, const BlurArgs& a, const uint8_t*
     stream_grid(a.w, a.h, L, nstrip, nseg, nb);
     hipLaunchKernelGGL((blur_stream<5, 8, true>), dim3((nstrip * nseg * nb + 3) / 4), dim3(256), 0, st, a2, L, nstrip, nseg);
 }
+// the 48 rows at the top and at the bottom of a level the cascade left out (blur_stream in band mode; R as in launch_blur)
+inline bool launch_band(hipStream_t st, int R, BlurArgs a, bool base) {
+    a.band = casc::VB;
+    const int nb = a.nb > 1 ? a.nb : 1, nstrip = (a.w + 255) / 256, nseg = 2;
+    const dim3 grid((nstrip * nseg * nb + 3) / 4), block(256);
+    if (base) { hipLaunchKernelGGL((blur_stream<5, 8, true>), grid, block, 0, st, a, casc::VB, nstrip, nseg); return true; }
+    switch (R) {
+#define CASE(RR, DD) case RR: hipLaunchKernelGGL((blur_stream<RR, DD, false>), grid, block, 0, st, a, casc::VB, nstrip, nseg); return true;
+        CASE(5, 6) CASE(6, 8) CASE(8, 6) CASE(10, 6) CASE(13, 4)
+#undef CASE
+        default: return false;
+    }
+}
+// segments of the cascade: whole rounds of one workgroup per CU, the row overlap (~100 steps per segment) against the tail
+inline void cascade_grid(int w, int h, int nb, int num_cu, int& nstrip, int& nseg, int& lseg) {
+    nstrip = (w + casc::SV - 1) / casc::SV;
+    const int rows = h - 2 * casc::VB, per = nstrip * nb;
+    long best = -1; nseg = 1;
+    for (int n = 1; n <= rows / 256 || n == 1; n++) {
+        const long rounds = ((long)per * n + num_cu - 1) / num_cu;
+        const long cost = rounds * ((rows + n - 1) / n + 100);
+        if (best < 0 || cost < best) { best = cost; nseg = n; }
+    }
+    lseg = (rows + nseg - 1) / nseg;
+}
 template <bool BGR>
 bool launch_blur(hipStream_t st, int R, const BlurArgs& a, int stream_mode = 1) {
     const int ntile = a.tiles_x * a.tiles_y;
@@ -1722,7 +2047,7 @@ static int sift_prepare(mi355_ctx* ctx, SiftWork* s, int w, int h, int nb) {
     if (s->cube_cap > s->cand_cap) s->cube_cap = s->cand_cap;
     s->bs.cube = (size_t)s->cube_cap * NREG * 32;
     s->bs.pyr = fl; s->bs.claimed = cl; s->bs.cand = (size_t)s->cand_cap * NREG; s->bs.refined = s->ref_cap; s->bs.kps = s->kp_cap;
-    s->gray_pitch = (w + 8 + 15) & ~15;
+    s->gray_pitch = (w + 2 * GPAD + 15) & ~15;
     s->gray_stride = up64((size_t)s->gray_pitch * h + 64);
     const size_t B = (size_t)nb;
     MI_HIP(s->pyr.reserve(B * fl * sizeof(float)));
@@ -1850,7 +2175,45 @@ static int sift_run_batch(mi355_ctx* ctx, SiftWork* s) {
         BlurArgs a = blur_args(oc);
         a.fstride = bs.pyr; a.nb = n;
         const double level_bytes = (double)oc.w * oc.h * 4.0 * n;
-        if (o == 0) {
+        // all levels of a big octave in one pass; the first and last 48 rows of every level by the per-level kernel afterwards
+        const bool radii_ok = s->radius0 == 5 && s->radius[1] == 5 && s->radius[2] == 6 && s->radius[3] == 8 && s->radius[4] == 10 && s->radius[5] == 13;
+        const bool cascade = ctx->cascade && ctx->blur_stream && radii_ok && (oc.w & 15) == 0 && oc.w >= 2000 && oc.h >= 1500 &&
+                             ((oc.w & 255) == 0 || (oc.w & 255) > MAX_R) && (o > 0 || base_streams(blur_args(oc), s->radius0, ctx->blur_stream));
+        if (cascade) {
+            casc::Args ca; memset(&ca, 0, sizeof(ca));
+            ca.w = oc.w; ca.h = oc.h; ca.fstride = bs.pyr; ca.nb = n;
+            for (int i = 0; i < N_LEVELS; i++) ca.lv[i] = oc.lv[i];
+            memcpy(ca.k[0], s->kern0, sizeof(float) * (2 * s->radius0 + 1));
+            for (int i = 1; i < N_LEVELS; i++) memcpy(ca.k[i], s->kern[i], sizeof(float) * (2 * s->radius[i] + 1));
+            const bool seeds_next = o + 1 < s->n_oct && (oc.w & 1) == 0 && s->P.oc[o + 1].w == (oc.w >> 1) && s->P.oc[o + 1].h == (oc.h >> 1);
+            ca.ds = seeds_next ? s->P.oc[o + 1].lv[0] : nullptr;
+            cascade_grid(oc.w, oc.h, n, ctx->num_cu, ca.nstrip, ca.nseg, ca.lseg);
+            const dim3 grid(ca.nstrip * ca.nseg * n), block(o == 0 ? 768 : 640);
+            if (o == 0) {
+                for (int k = 0; k < n; k++) launch_gray_pad(st, pend[k].d_bgr, pend[k].ws, w, h, s->gray.as<uint8_t>() + (size_t)k * s->gray_stride, s->gray_pitch);
+                ca.gray = s->gray.as<uint8_t>(); ca.gp = s->gray_pitch; ca.gstride = s->gray_stride; ca.gh = h;
+                ProfScope ps(ctx, "cascade", level_bytes * 6.0 + (double)w * h * 3.0 * n, st);
+                hipLaunchKernelGGL((pyr_cascade<true>), grid, block, 0, st, ca);
+            } else {
+                if (!ds_fused) {
+                    const OctaveDev& pv = s->P.oc[o - 1];
+                    hipLaunchKernelGGL(downsample2, dim3((oc.w + 63) / 64, (oc.h + 3) / 4, n), dim3(256), 0, st, pv.lv[N_LAYERS], pv.w, oc.lv[0], oc.w, oc.h, bs.pyr);
+                }
+                ca.src0 = oc.lv[0];
+                ProfScope ps(ctx, "cascade", level_bytes * 6.0, st);
+                hipLaunchKernelGGL((pyr_cascade<false>), grid, block, 0, st, ca);
+            }
+            ProfScope ps(ctx, "gauss_band", 0.0, st);
+            for (int i = (o == 0 ? 0 : 1); i < N_LEVELS; i++) {
+                BlurArgs a = blur_args(oc);
+                a.fstride = bs.pyr; a.nb = n; a.dst = oc.lv[i];
+                if (i == 0) { memcpy(a.k, s->kern0, sizeof(float) * (2 * s->radius0 + 1)); a.bgr = s->gray.as<uint8_t>(); a.bgr_ws = s->gray_pitch; a.gstride = s->gray_stride; }
+                else { memcpy(a.k, s->kern[i], sizeof(float) * (2 * s->radius[i] + 1)); a.src = oc.lv[i - 1]; }
+                a.ds = (i == N_LAYERS) ? ca.ds : nullptr;
+                if (!launch_band(st, i == 0 ? s->radius0 : s->radius[i], a, i == 0)) { ctx->set_error("sift: unsupported kernel radius"); return MI355_ERR_FAILED; }
+            }
+            ds_fused = seeds_next;
+        } else if (o == 0) {
             a.dst = oc.lv[0];
             memcpy(a.k, s->kern0, sizeof(float) * (2 * s->radius0 + 1));
             ProfScope ps(ctx, "gauss", level_bytes + (double)w * h * 3.0 * n, st);      // read the u8 frames, write level 0
@@ -1869,8 +2232,8 @@ static int sift_run_batch(mi355_ctx* ctx, SiftWork* s) {
             ProfScope ps(ctx, "downsample", level_bytes * 2.0, st);
             hipLaunchKernelGGL(downsample2, dim3((oc.w + 63) / 64, (oc.h + 3) / 4, n), dim3(256), 0, st, pv.lv[N_LAYERS], pv.w, oc.lv[0], oc.w, oc.h, bs.pyr);
         }
-        ds_fused = false;
-        for (int i = 1; i < N_LEVELS; i++) {
+        if (!cascade) ds_fused = false;
+        for (int i = 1; i < N_LEVELS && !cascade; i++) {
             a.bgr = nullptr; a.src = oc.lv[i - 1]; a.dst = oc.lv[i];
             memcpy(a.k, s->kern[i], sizeof(float) * (2 * s->radius[i] + 1));
             const bool streams = blur_streams(a, false, s->radius[i], ctx->blur_stream);

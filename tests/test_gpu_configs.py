@@ -180,3 +180,29 @@ def test_c5_mini_dense_canvas_eight_stripes():
     assert np.array_equal(whole.cpu().numpy(), ref), "whole canvas differs from the oracle"
     assert np.array_equal(stripes.cpu().numpy(), ref), "8 stripes differ from the oracle"
     ctx.close()
+
+
+def test_cascade_route_equals_per_level_route():
+    """option "sift_cascade": all Gaussian levels of a big octave in one pass (pyr_cascade + band launches) must give the
+    bits of the per-level route, which the tests above pin to the oracle: 9 frames of 12 MP (a full batch of 8 + a batch of
+    1; octaves 8000 / 4000 / 2000 wide go through the cascade), 3 frames whose doubled width is not a multiple of the 416
+    stored columns of a strip nor of 256 (2512 x 1900 -> 5024 wide), 2 frames of 1920 x 1080"""
+    import torch
+    import imagemosaicing_amd as im
+    from tests.synth_survey import render_frames
+    for (w, h, F) in ((4000, 3000, 9), (2512, 1900, 3), (1920, 1080, 2)):
+        feats = []
+        for casc in (0, 1):
+            ctx = im.Context(0)
+            ctx.set_option("sift_cascade", casc)
+            frames, A, gains, ws = render_frames(ctx, torch, F, w, h, per_row=F)
+            for k in range(F):
+                ctx.SiftExtractDev(k, frames[k].data_ptr(), w, h, ws)
+            ctx.synchronize()
+            feats.append([ctx.GetFeatures(k) for k in range(F)])
+            ctx.close()
+        for k in range(F):
+            (k0, d0), (k1, d1) = feats[0][k], feats[1][k]
+            assert len(k0) == len(k1) == 2000, (w, h, k, len(k0), len(k1))
+            assert np.array_equal(k0.view(np.uint8), k1.view(np.uint8)), f"{w}x{h} frame {k}: keypoints differ between the routes"
+            assert np.array_equal(d0, d1), f"{w}x{h} frame {k}: descriptors differ between the routes"
