@@ -13,6 +13,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include <type_traits>
 
 #define HD __host__ __device__ __forceinline__
 
@@ -193,49 +194,169 @@ HD void nlls4(const float* p, const float* H0, float* Hout, float* scratch) {
 }
 
 // ---- register-resident fast path of the 4-point solve / NLLS ---------------------------------------------------------------
-// InverseMatrix for order 8 with every index static (fully unrolled): valid when the reference's pivot search picks row i
-// for column i (the first not-yet-used row whose entry exceeds eps -- rows 0..i-1 are used by then, so this is the case
-// iff |t[i][i]| > eps) and its final "row holding an exact 1 in column r" permutation is the identity.  Both are checked;
-// when either fails the function returns false and the caller re-runs the generic routine, so the result is always the
-// reference's.  The arithmetic (including the operations on structural zeros) is the generic routine's.
-HD bool inverse8_fast(const float* src, float* dst, float eps) {
-    float t[8][16];
-#pragma unroll
-    for (int i = 0; i < 8; i++)
-#pragma unroll
-        for (int j = 0; j < 16; j++) t[i][j] = j < 8 ? src[i * 8 + j] : (j - 8 == i ? 1.0f : 0.0f);
-    bool ok = true;
-#pragma unroll
+// ---- the 4-point systems exploit their structural zeros ------------------------------------------------------------------
+// The design matrix of a 4-point solve and the Jacobian of its Gauss-Newton polish have the same fixed pattern
+//     even rows [a b c 0 0 0 g h]      odd rows [0 0 0 d e f g h]
+// so that J^T J = [[P 0 u] [0 Q v] [u^T v^T s]] (3 + 3 + 2) and InverseMatrix meets exact zeros in known places: it skips the
+// rows whose entry in the pivot column is zero (|e| < eps, matrix.h:231) and, where it does operate on a zero, produces a zero
+// again (0 / e, 0 + e * 0) or the first value of an entry (0 + x = x).  The plan below is that elimination run symbolically at
+// compile time; the code generated from it performs exactly the reference's operations whose operands are not structural zeros,
+// in the reference's order: 46 divisions, 176 multiply-adds, 56 first values instead of 128 / 896 / 0, and J^T J from 120
+// products (upper triangle, mirrored: a*b = b*a) instead of 512, (J^T J)^-1 J^T from 320 instead of 512.
+// A dropped operation is x + (+-0) = x, (+0) + (+-0) = +0 (an accumulator that starts at +0 never turns -0 by adding zeros),
+// or works on a column that is never read again, PROVIDED no operand is infinite / NaN (0 * inf = NaN in the reference), no
+// first value underflows to zero (then the sign of the zero it replaces would show), every pivot is the diagonal one and every
+// expected row update really happens (|e| >= eps).  All of that is checked; a draw that fails a check is redone by the generic
+// routines (caller), so the result is always the reference's.
+namespace sp {
+constexpr bool anz(int r, int c) { return (r & 1) ? (c >= 3) : (c <= 2 || c >= 6); }
+struct Plan {
+    bool m[8][8];                 // J^T J entry is not a structural zero
+    bool div[8][16];              // step i divides t[i][c] by the pivot
+    bool upd[8][8];               // step i updates row j
+    unsigned char op[8][8][16];   // step i, row j, column c: 0 nothing, 1 t[j][c] += ne * t[i][c], 2 t[j][c] = ne * t[i][c]
+};
+constexpr Plan make_plan() {
+    Plan P{};
+    bool nz[8][16] = {};
+    for (int r = 0; r < 8; r++)
+        for (int c = 0; c < 8; c++) {
+            bool any = false;
+            for (int k = 0; k < 8; k++) any = any || (anz(k, r) && anz(k, c));
+            P.m[r][c] = any; nz[r][c] = any; nz[r][8 + c] = (r == c);
+        }
     for (int i = 0; i < 8; i++) {
-        const float ei = t[i][i];
-        if (!(fabsf(ei) > eps)) ok = false;
-#pragma unroll
-        for (int c = 0; c < 16; c++) t[i][c] = t[i][c] / ei;
-#pragma unroll
+        for (int c = i + 1; c < 16; c++) P.div[i][c] = nz[i][c];
         for (int j = 0; j < 8; j++) {
-            if (j == i) continue;
-            const float e2 = t[j][i];
-            if (!(fabsf(e2) < eps)) {
-                const float ne = -e2;
-#pragma unroll
-                for (int c = 0; c < 16; c++) { const float prod = ne * t[i][c]; t[j][c] = t[j][c] + prod; }
+            if (j == i || !nz[j][i]) continue;
+            P.upd[i][j] = true;
+            for (int c = i + 1; c < 16; c++)
+                if (nz[i][c]) { P.op[i][j][c] = nz[j][c] ? 1 : 2; nz[j][c] = true; }
+        }
+        for (int j = 0; j < 8; j++) nz[j][i] = false;          // column i is never read again
+    }
+    return P;
+}
+inline constexpr Plan PLAN = make_plan();
+template <int I, int N, class F> HD void sfor(F&& f) {
+    if constexpr (I < N) { f(std::integral_constant<int, I>{}); sfor<I + 1, N>(f); }
+}
+constexpr float FMAXV = 3.402823466e+38f;
+}  // namespace sp
+
+// J^T J of a matrix with the pattern above (MulMatrix order: ascending k); false when an entry of A or of the product is not finite
+HD bool jtj_sparse(const float* A, float* M) {
+    float s = 0.0f;
+    sp::sfor<0, 8>([&](auto rc) {
+        constexpr int r = decltype(rc)::value;
+        sp::sfor<0, 8>([&](auto cc) {
+            constexpr int c = decltype(cc)::value;
+            if constexpr (sp::anz(r, c)) s = s + fabsf(A[r * 8 + c]);
+        });
+    });
+    bool ok = s <= sp::FMAXV;
+    float sm = 0.0f;
+    sp::sfor<0, 8>([&](auto rc) {
+        constexpr int r = decltype(rc)::value;
+        sp::sfor<r, 8>([&](auto cc) {
+            constexpr int c = decltype(cc)::value;
+            float acc = 0.0f;
+            if constexpr (sp::PLAN.m[r][c]) {
+                sp::sfor<0, 8>([&](auto kc) {
+                    constexpr int k = decltype(kc)::value;
+                    if constexpr (sp::anz(k, r) && sp::anz(k, c)) { const float pr = A[k * 8 + r] * A[k * 8 + c]; acc = acc + pr; }
+                });
+                sm = sm + fabsf(acc);
             }
+            M[r * 8 + c] = acc; M[c * 8 + r] = acc;
+        });
+    });
+    return ok && sm <= sp::FMAXV;
+}
+
+// InverseMatrix of such a J^T J (see above).  Returns 0 = inverted (dst written), 1 = the reference's routine fails here (no
+// unused row has an entry above eps in some pivot column, matrix.h:206-222: dst is left as it was -- duplicated points among the
+// four make this common), 2 = not the fast case (a pivot below the diagonal, a zero or non-finite entry in the result): use the
+// generic routine.
+// Structural zeros are kept as +0 and never operated on; a row update the reference skips because its pivot-column entry is
+// tiny (|e| < eps, data dependent) is skipped here too -- the entries it would have given their first value then stay +0 until
+// a later planned operation (0 + x = x) reaches them.  The reference's zeros may be -0 where these are +0, which can only show
+// in an entry of the inverse that is itself zero: checked at the end.
+HD int inverse8_sparse(const float* src, float* dst, float eps) {
+    float t[8][16];
+    sp::sfor<0, 8>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        sp::sfor<0, 16>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            if constexpr (j < 8) t[i][j] = sp::PLAN.m[i][j] ? src[i * 8 + j] : 0.0f;
+            else t[i][j] = (j - 8 == i) ? 1.0f : 0.0f;
+        });
+    });
+    int state = 0;
+    sp::sfor<0, 8>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        const float ei = t[i][i];
+        if (state == 0 && !(fabsf(ei) > eps)) {          // the pivot search goes on below the diagonal
+            bool other = false;
+            sp::sfor<i + 1, 8>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                if constexpr (sp::PLAN.upd[i][j]) other = other || (fabsf(t[j][i]) > eps);
+            });
+            state = other ? 2 : 1;
         }
-    }
-    // identity permutation check: the first row with an exact 1 in column r must be r (or there is none)
-#pragma unroll
-    for (int r = 0; r < 8; r++) {
-#pragma unroll
-        for (int i = 0; i < 8; i++) {
-            if (i < r && t[i][r] == 1.0f) ok = false;
-            if (i > r && t[i][r] == 1.0f && !(t[r][r] == 1.0f)) ok = false;
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < 8; i++)
-#pragma unroll
-        for (int j = 0; j < 8; j++) dst[i * 8 + j] = t[i][8 + j];
-    return ok;
+        sp::sfor<i + 1, 16>([&](auto cc) {
+            constexpr int c = decltype(cc)::value;
+            if constexpr (sp::PLAN.div[i][c]) t[i][c] = t[i][c] / ei;
+        });
+        sp::sfor<0, 8>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            if constexpr (sp::PLAN.upd[i][j]) {
+                const float e2 = t[j][i];
+                if (!(fabsf(e2) < eps)) {
+                    const float ne = -e2;
+                    sp::sfor<i + 1, 16>([&](auto cc) {
+                        constexpr int c = decltype(cc)::value;
+                        if constexpr (sp::PLAN.op[i][j][c] != 0) { const float prod = ne * t[i][c]; t[j][c] = t[j][c] + prod; }
+                    });
+                }
+            }
+        });
+    });
+    if (state != 0) return state;
+    float s = 0.0f, mn = sp::FMAXV;
+    sp::sfor<0, 8>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        sp::sfor<0, 8>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            const float v = t[i][8 + j];
+            s = s + fabsf(v); mn = fminf(mn, fabsf(v));
+        });
+    });
+    if (!((mn > 0.0f) && (s <= sp::FMAXV))) return 2;
+    sp::sfor<0, 8>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        sp::sfor<0, 8>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            dst[i * 8 + j] = t[i][8 + j];
+        });
+    });
+    return 0;
+}
+
+// (J^T J)^-1 J^T with J's pattern (MulMatrix order: ascending k over the entries that are not structural zeros)
+HD void invjt_sparse(const float* inv, const float* A, float* M) {
+    sp::sfor<0, 8>([&](auto rc) {
+        constexpr int r = decltype(rc)::value;
+        sp::sfor<0, 8>([&](auto cc) {
+            constexpr int c = decltype(cc)::value;
+            float acc = 0.0f;
+            sp::sfor<0, 8>([&](auto kc) {
+                constexpr int k = decltype(kc)::value;
+                if constexpr (sp::anz(c, k)) { const float pr = inv[r * 8 + k] * A[c * 8 + k]; acc = acc + pr; }
+            });
+            M[r * 8 + c] = acc;
+        });
+    });
 }
 
 // 4-point SolveHomographyMatrix + (when 0.01 < H[8] < 5) NonlinearLeastSquareProjection2, everything in registers.
@@ -251,27 +372,13 @@ HD bool hypothesis4_fast(const float* p, float* H, int* polished = nullptr) {
         A[(2 * r + 1) * 8 + 3] = x2; A[(2 * r + 1) * 8 + 4] = y2; A[(2 * r + 1) * 8 + 5] = 1.0f; A[(2 * r + 1) * 8 + 6] = (-y1) * x2; A[(2 * r + 1) * 8 + 7] = (-y1) * y2;
         B[2 * r] = x1; B[2 * r + 1] = y1;
     }
-#pragma unroll
-    for (int r = 0; r < 8; r++)
-#pragma unroll
-        for (int c = 0; c < 8; c++) {
-            float acc = 0.0f;
-#pragma unroll
-            for (int k = 0; k < 8; k++) { const float pr = A[k * 8 + r] * A[k * 8 + c]; acc = acc + pr; }
-            M[r * 8 + c] = acc;
-        }
     // matrix.h:377: on failure the reference multiplies with an all-zero inverse.  A missing pivot (|.| <= 1e-20) is the
     // generic routine's business.
-    if (!inverse8_fast(M, inv, 1e-20f)) return false;
+    if (!jtj_sparse(A, M)) return false;
 #pragma unroll
-    for (int r = 0; r < 8; r++)
-#pragma unroll
-        for (int c = 0; c < 8; c++) {
-            float acc = 0.0f;
-#pragma unroll
-            for (int k = 0; k < 8; k++) { const float pr = inv[r * 8 + k] * A[c * 8 + k]; acc = acc + pr; }
-            M[r * 8 + c] = acc;
-        }
+    for (int i = 0; i < 64; i++) inv[i] = 0.0f;                   // a failed inversion leaves the zeros (matrix.h:377)
+    if (inverse8_sparse(M, inv, 1e-20f) == 2) return false;
+    invjt_sparse(inv, A, M);
 #pragma unroll
     for (int r = 0; r < 8; r++) {
         float acc = 0.0f;
@@ -296,6 +403,8 @@ HD bool hypothesis4_fast(const float* p, float* H, int* polished = nullptr) {
 #pragma unroll
     for (int i = 0; i < 8; i++) w[i] = H[i];
     bool finished = false;
+#pragma unroll
+    for (int i = 0; i < 64; i++) inv[i] = 0.0f;
     for (int it = 0; it < 15 && !finished; it++) {
 #pragma unroll
         for (int i = 0; i < 4; i++) {
@@ -310,25 +419,9 @@ HD bool hypothesis4_fast(const float* p, float* H, int* polished = nullptr) {
             j[14] = ((-x1) * ny) / (d * d); j[15] = ((-y1) * ny) / (d * d);
             C[2 * i] = x2 - nx / d; C[2 * i + 1] = y2 - ny / d;
         }
-#pragma unroll
-        for (int r = 0; r < 8; r++)
-#pragma unroll
-            for (int c = 0; c < 8; c++) {
-                float acc = 0.0f;
-#pragma unroll
-                for (int k = 0; k < 8; k++) { const float pr = A[k * 8 + r] * A[k * 8 + c]; acc = acc + pr; }
-                M[r * 8 + c] = acc;
-            }
-        if (!inverse8_fast(M, inv, 1e-6f)) return false;
-#pragma unroll
-        for (int r = 0; r < 8; r++)
-#pragma unroll
-            for (int c = 0; c < 8; c++) {
-                float acc = 0.0f;
-#pragma unroll
-                for (int k = 0; k < 8; k++) { const float pr = inv[r * 8 + k] * A[c * 8 + k]; acc = acc + pr; }
-                M[r * 8 + c] = acc;
-            }
+        if (!jtj_sparse(A, M)) return false;
+        if (inverse8_sparse(M, inv, 1e-6f) == 2) return false;    // 1: the previous iteration's inverse stays (zeros before the first)
+        invjt_sparse(inv, A, M);
         bool done = true;
 #pragma unroll
         for (int r = 0; r < 8; r++) {

@@ -17,5 +17,6 @@ ctx.profile_enable(True); ctx.profile_only(None); ctx.profile_reset()
 ctx.MatchPairsDev(pairs, res.data_ptr(), 2.5, 7)
 ms = {c: round(ctx.profile_get(c)[0], 2) for c in ("match", "select", "ransac")}
 r = res.cpu().numpy().view(im.PAIR_RESULT).reshape(-1)
+print("fallback draws per pair: mean %.2f max %d" % (r["_pad"].mean(), r["_pad"].max()))
 print("pairs", len(pairs), "wall %.1f ms" % (dt * 1e3), ms, "accepted", int(r["accepted"].sum()), "us/pair ransac %.2f" % (ms["ransac"] * 1e3 / len(pairs)),
       "=> C4 (74029 pairs) ransac %.3f s" % (ms["ransac"] * 74029 / len(pairs) / 1e3))
