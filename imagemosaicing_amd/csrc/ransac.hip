@@ -52,7 +52,10 @@ __device__ __forceinline__ int block_exclusive_scan_flags(bool flag, int tid, in
     return off + before;
 }
 
-__global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(2, 2))) void ransac_kernel(RansacArgs a) {
+#ifndef RANSAC_WPE
+#define RANSAC_WPE 2
+#endif
+__global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(RANSAC_WPE, RANSAC_WPE))) void ransac_kernel(RansacArgs a) {
     extern __shared__ float lds[];
     __shared__ int   s_sup[RB];
     __shared__ int   s_flag[RB];
