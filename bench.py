@@ -373,7 +373,7 @@ def main():
             "vs_baseline": None, "dtype": "f32 (pyramid/RANSAC/warp coordinates), bf16 MFMA exact-integer (descriptor distances), u8 (pixels)",
             "data": "synthetic",
             "config": {"workload": "%s: %s, pair window %d (%d pairs), SIFT(2000,3,0.01,20) + exact BF match + 3x3 grid select + Ransac2D + MosaicImagesRefined warp"
-                                   % ("C3" if args.window == 2 else ("C4" if args.window == 182 else "window-%d" % args.window),
+                                   % ("C3" if args.window == 2 else (("C5" if F >= 2000 else "C4") if args.window == 182 else "window-%d" % args.window),
                                       ("ONE %d-frame %dx%d UAV survey" % (F, w, h)) if strong else ("%d-frame %dx%d UAV strip per GPU" % (F, w, h)),
                                       args.window, survey_pairs),
                        "frames": F if strong else F * world, "pairs": survey_pairs, "frames_per_gpu": len(own), "pairs_per_gpu": n_pairs,
