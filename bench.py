@@ -170,6 +170,8 @@ def main():
     exchange = world > 1 or bool(os.environ.get("MI355_BENCH_FORCE_EXCHANGE"))      # the env switch runs the collectives on one rank (dry run of the calls)
     transport = args.transport or ("rccl" if (args.backend == "nccl" or world == 1) else "torch")
     ex = md.Exchange(ctx, transport) if exchange else None
+    if ex is not None:
+        transport = ex.transport                      # "torch" if the C ABI's communicator could not be set up on every rank
     # strong: ONE survey, the same F frames on every rank (replicated in HBM: a rank renders every frame that crosses its canvas
     # stripe, SURVEY 8e "replicas of frames + stripes"), detect+describe and pairs sharded; weak: an independent strip per rank
     lay_rank = 0 if strong else rank

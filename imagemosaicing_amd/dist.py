@@ -17,6 +17,8 @@ xGMI on the ctx stream; the product path, what bench.py runs with backend nccl);
 torch.distributed.all_gather (gloo in the CPU tests and in single-GPU dry runs, where RCCL cannot place two ranks on one
 device).  Both go through the same pack / install entry points of the library.
 """
+import sys
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -32,13 +34,22 @@ def owned_frames(n_images, rank, world):
 
 
 def init_comm(ctx, group=None):
-    """creates the ctx's RCCL communicator: rank 0 makes the 128-byte id, torch.distributed carries it to the other ranks"""
+    """creates the ctx's RCCL communicator: rank 0 makes the 128-byte id, torch.distributed carries it to the other ranks.
+    Raises on every rank alike when the library cannot reach librccl (rank 0 then broadcasts None instead of an id)."""
     if not dist.is_initialized():                      # single process: a communicator of one rank (exercises the same calls)
         ctx.CommInit(comm_unique_id(), 0, 1)
         return
     rank, world = dist.get_rank(group), dist.get_world_size(group)
-    box = [comm_unique_id() if rank == 0 else None]
+    box = [None]
+    if rank == 0:
+        try:
+            box = [comm_unique_id()]
+        except Exception as e:                         # noqa: BLE001 -- reported below, on every rank
+            box = [None]
+            sys.stderr.write("mi355 dist: no RCCL unique id (%s)\n" % e)
     dist.broadcast_object_list(box, src=0, group=group)
+    if box[0] is None:
+        raise RuntimeError("rank 0 could not create an RCCL unique id")
     ctx.CommInit(box[0], rank, world)
 
 
@@ -114,7 +125,23 @@ class Exchange:
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self._payload = None
         if transport == "rccl":
-            init_comm(ctx)
+            # the library's own collectives; if any rank cannot set them up (librccl not reachable from the C ABI), ALL ranks
+            # move the same records through torch.distributed instead -- said loudly, and visible in `self.transport`
+            ok, err = 1, None
+            try:
+                init_comm(ctx)
+            except Exception as e:                     # noqa: BLE001
+                ok, err = 0, e
+            if self.world > 1:
+                flag = torch.tensor([ok], dtype=torch.int32, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                if int(flag.item()) == 0:
+                    if ok:
+                        ctx.CommDestroy()
+                    sys.stderr.write("mi355 dist: rank %d: RCCL communicator of the C ABI unavailable (%s): exchanges go through torch.distributed\n" % (self.rank, err))
+                    self.transport = "torch"
+            elif not ok:
+                raise err
 
     def allgather_features(self, own_ids, n_max, device):
         """afterwards every frame of every rank is resident in this rank's ctx"""
