@@ -57,8 +57,8 @@ __device__ __forceinline__ int block_exclusive_scan_flags(bool flag, int tid, in
 #endif
 __global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(RANSAC_WPE, RANSAC_WPE))) void ransac_kernel(RansacArgs a) {
     extern __shared__ float lds[];
-    __shared__ int   s_sup[RB];
-    __shared__ int   s_flag[RB];
+    __shared__ unsigned long long s_mask[5][RB / 64];
+    __shared__ unsigned s_wkey[RB / 64];
     __shared__ float s_bestH[9], s_firstH[9], s_w[8], s_dX[8], s_T1[64], s_T2[64], s_t[128];
     __shared__ int   s_state[8];      // 0 t_acc, 1 maxSupport, 2 bestDraw, 3 firstAcc, 4 finished, 5 newBest, 6 newFirst, 7 done
     __shared__ int   s_wtot[RB / 64 + 1];
@@ -112,6 +112,9 @@ __global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(RANSAC_WPE, 
             int pol = 0;
             const bool fast_ok = hm::hypothesis4_fast(p, h, &pol);
             if (a.dbg && pol) atomicAdd(&s_npol, 1);
+            // :1864-1867 the skip test looks at the 4-point solve's residual; a polished hypothesis is never skipped, whatever the
+            // residual after the polish (a polish that diverges past 5 px still consumes its slot)
+            bool skip = !pol && h[8] > 5.0f;
             // one lane of the wave at a time, its work arrays in the wave's LDS slot: a private array for these index-driven
             // routines costs the whole kernel registers and scratch set-up (measured 5.3 us per pair against 4.9 this way)
             for (unsigned long long need = __ballot(!fast_ok); need; need &= need - 1ull) {
@@ -119,6 +122,7 @@ __global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(RANSAC_WPE, 
                     atomicAdd(&s_fb, 1);                    // statistics only (reported in _pad)
                     float* const scr = s_fbk[tid >> 6];
                     hm::solve_h4(p, h, scr);               // :1863
+                    skip = h[8] > 5.0f;
                     if (!(h[8] > 5.0f) && h[8] < 5.0f && h[8] > 0.01f) {   // :1868-1876
                         float fine[9];
                         hm::nlls4(p, h, fine, scr);
@@ -128,7 +132,7 @@ __global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(RANSAC_WPE, 
                 }
             }
             long long c1 = wall_clock64(); Tsolve += c1 - c0;
-            if (h[8] > 5.0f) flag = 0;                     // :1864-1867 skipped, no slot consumed
+            if (skip) flag = 0;                            // :1864-1867 skipped, no slot consumed
             else {
                 flag = 1;
                 for (int i = 0; i < n; i++) {              // :1890-1904
@@ -140,31 +144,60 @@ __global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(RANSAC_WPE, 
                 }
             }
         }
-        s_flag[tid] = flag; s_sup[tid] = support;
+        // ---- replay of the sequential loop over this chunk (mosaicimage.h:1864-1918), in parallel ----
+        // In draw order: a draw with flag 2 ends the loop before it is looked at; flag 0 is skipped; an accepted draw (flag 1)
+        // becomes the first hypothesis if there was none, replaces the best one when its support is strictly larger (and ends
+        // the loop at once when that support exceeds 0.99 n, before the counter moves), then counts; the loop ends when the
+        // counter reaches sample_times.  So the chunk is cut at E = min(first flag 2 - 1, first accepted draw with support > mx
+        // and ratio > 0.99, the accepted draw that makes the counter reach sample_times); the best of the chunk is the first
+        // accepted draw <= E holding the maximum support, if that exceeds the running maximum.
+        const int lane = tid & 63, wv = tid >> 6;
+        const int t0 = s_state[0], mx0 = s_state[1], first0 = s_state[3];
+        const bool acc = flag == 1;
+        const unsigned long long m_acc = __ballot(acc), m_f2 = __ballot(flag == 2),
+                                 m_r = __ballot(acc && support > mx0 && (float)support * invn > 0.99f);
+        if (lane == 0) { s_mask[0][wv] = m_acc; s_mask[1][wv] = m_f2; s_mask[2][wv] = m_r; }
         __syncthreads();
         long long c2 = wall_clock64(); Tsup += c2 - c0;
-        if (tid == 0) {                                    // replay of the sequential loop over this chunk
-            int t = s_state[0], mx = s_state[1], best = s_state[2], first = s_state[3], fin = 0;
-            int newBest = -1, newFirst = -1;
-            for (int k = 0; k < RB; k++) {
-                const int f = s_flag[k];
-                if (f == 2) { fin = 1; break; }
-                if (f == 0) continue;
-                if (first < 0) { first = base + k; newFirst = k; }
-                if (s_sup[k] > mx) {                       // :1905
-                    mx = s_sup[k]; best = base + k; newBest = k;
-                    if ((float)mx * invn > 0.99f) { fin = 1; break; }      // :1913
-                }
-                t++;
-                if (t >= sample_times) { fin = 1; break; }
-            }
-            s_state[0] = t; s_state[1] = mx; s_state[2] = best; s_state[3] = first; s_state[4] = fin;
-            s_state[5] = newBest; s_state[6] = newFirst;
-        }
+        int before = 0;                                    // accepted draws of the chunk before this wave
+        for (int i = 0; i < RB / 64; i++) if (i < wv) before += __popcll(s_mask[0][i]);
+        const int cnt_incl = before + __popcll(m_acc & ((2ull << lane) - 1ull));
+        const unsigned long long m_t = __ballot(acc && t0 + cnt_incl == sample_times);
+        if (lane == 0) s_mask[3][wv] = m_t;
         __syncthreads();
-        if (s_state[5] == tid) { for (int i = 0; i < 9; i++) s_bestH[i] = h[i]; }
-        if (s_state[6] == tid) { for (int i = 0; i < 9; i++) s_firstH[i] = h[i]; }
-        const int fin = s_state[4];
+        auto first_of = [&](int which) { for (int i = 0; i < RB / 64; i++) { const unsigned long long m = s_mask[which][i]; if (m) return 64 * i + (int)__builtin_ctzll(m); } return RB; };
+        const int k2 = first_of(1), kr = first_of(2), kt = first_of(3);
+        int E = k2 - 1;
+        E = kr < E ? kr : E; E = kt < E ? kt : E;          // last draw of the chunk the loop looks at (RB - 1 when nothing ends it)
+        const int fin = (k2 < RB || kr < RB || kt < RB) ? 1 : 0;
+        const bool inc = acc && tid <= E;
+        // first accepted draw, and the first holder of the maximum support among the included ones
+        unsigned key = inc ? (((unsigned)support << 8) | (unsigned)(RB - 1 - tid)) : 0u;      // support <= 400 < 2^23
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) { const unsigned v = __shfl_xor(key, o, 64); key = v > key ? v : key; }
+        const unsigned long long m_inc = __ballot(inc);
+        if (lane == 0) { s_wkey[wv] = key; s_mask[4][wv] = m_inc; }
+        __syncthreads();
+        unsigned kb = 0; int kfirst = RB, nacc = 0;
+        for (int i = 0; i < RB / 64; i++) {
+            kb = s_wkey[i] > kb ? s_wkey[i] : kb;
+            const unsigned long long m = s_mask[4][i];
+            if (m && kfirst == RB) kfirst = 64 * i + (int)__builtin_ctzll(m);
+            nacc += __popcll(m);
+        }
+        const bool any_inc = kfirst < RB;
+        const int bsup = (int)(kb >> 8), bidx = RB - 1 - (int)(kb & 255u);
+        const bool new_best = any_inc && bsup > mx0;
+        const bool new_first = any_inc && first0 < 0;
+        if (new_best && tid == bidx) { for (int i = 0; i < 9; i++) s_bestH[i] = h[i]; }
+        if (new_first && tid == kfirst) { for (int i = 0; i < 9; i++) s_firstH[i] = h[i]; }
+        __syncthreads();                                   // everyone has read s_state / the masks
+        if (tid == 0) {
+            s_state[0] = t0 + nacc - ((kr < RB && kr == E) ? 1 : 0);     // the draw that ends the loop by its ratio is not counted
+            if (new_best) { s_state[1] = bsup; s_state[2] = base + bidx; }
+            if (new_first) s_state[3] = base + kfirst;
+            s_state[4] = fin;
+        }
         __syncthreads();
         Trep += wall_clock64() - c2;
         if (fin) break;

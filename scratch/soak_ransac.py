@@ -33,5 +33,7 @@ while time.time() - t0 < budget:
     ok2, j1, j2, H2 = o.ransac2d(p1, p2, dist, st, seed)
     good = (ok == ok2) and len(i1) == len(j1) and np.array_equal(i1.view(np.uint8), j1.view(np.uint8)) and np.array_equal(i2.view(np.uint8), j2.view(np.uint8)) and np.array_equal(H.view(np.uint32), H2.view(np.uint32))
     n += 1; acc += int(ok2 != 0)
+    if not good:
+        import os; os.makedirs("gpurun_out/soak", exist_ok=True); np.savez("gpurun_out/soak/ransac_case_%d.npz" % n, p1=p1, p2=p2, dist=dist, st=st, seed=seed, gi1=i1, gi2=i2, gH=H, ok=ok)
     if not good: bad += 1; print("MISMATCH kind", kind, "m", m, "seed", seed, dist, st, ok, ok2, len(i1), len(j1), flush=True)
 print("ransac soak: %d cases (%d ok), %d mismatches, %.0f s" % (n, acc, bad, time.time() - t0))

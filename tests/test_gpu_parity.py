@@ -322,3 +322,20 @@ def test_chips_keep_and_invalid_flags(ctx, oracle):
     assert [int(c["img"]) for c in got["chips"]] == [int(c["img"]) for c in ref["chips"]] == [0, 3]
     for k in range(2):
         assert np.array_equal(got["chip_imgs"][k], ref["chip_imgs"][k]) and np.array_equal(got["masks"][k], ref["masks"][k])
+
+
+def test_ransac2d_polish_that_diverges_keeps_its_slot(ctx, oracle):
+    """A hypothesis whose 4-point residual is below 5 px is polished and then ALWAYS consumes a slot of the sample_times
+    budget, even when the polish drives its residual past 5 (mosaicimage.h:1864-1876 tests the residual of the solve only).
+    Found by scratch/soak_ransac.py: 359 garbage correspondences, where the winner changes between sample_times 200 and 201.
+    Expected values: the reference's own code (tests/golden/ransac_polish_diverges.npz, made with oracle/_ref)."""
+    import os
+    from tests.golden_util import GOLD
+    g = np.load(os.path.join(GOLD, "ransac_polish_diverges.npz"))
+    for st in (200, 201):
+        ok, i1, i2, H = ctx.Ransac2D(g["p1"], g["p2"], float(g["dist"]), st, int(g["seed"]))
+        assert ok == int(g[f"ok{st}"]) and np.array_equal(i1, g[f"i1_{st}"]) and np.array_equal(i2, g[f"i2_{st}"]), st
+        assert np.array_equal(bits(H), bits(g[f"H{st}"])), st
+        a = oracle.ransac2d(g["p1"], g["p2"], float(g["dist"]), st, int(g["seed"]))
+        assert a[0] == ok and np.array_equal(a[1], i1) and np.array_equal(bits(a[3]), bits(H))
+    assert not np.array_equal(g["H200"], g["H201"])

@@ -78,3 +78,15 @@ def test_ransac_rejects_small_inputs(oracle):
     p = ol.sfpoints(np.zeros((3, 2)))
     ok, i1, i2, H = oracle.ransac2d(p, p, 2.5, 1000, 1)
     assert ok == 0 and len(i1) == 0
+
+
+def test_ransac2d_polish_that_diverges_keeps_its_slot(oracle):
+    """tests/golden/ransac_polish_diverges.npz (expected values from oracle/_ref): the winner changes between sample_times
+    200 and 201 only if a polished hypothesis whose residual ends above 5 px still counts (mosaicimage.h:1864-1876)"""
+    import os
+    from tests.golden_util import GOLD, bits
+    g = np.load(os.path.join(GOLD, "ransac_polish_diverges.npz"))
+    for st in (200, 201):
+        ok, i1, i2, H = oracle.ransac2d(g["p1"], g["p2"], float(g["dist"]), st, int(g["seed"]))
+        assert ok == int(g[f"ok{st}"]) and np.array_equal(i1, g[f"i1_{st}"]) and np.array_equal(i2, g[f"i2_{st}"])
+        assert np.array_equal(bits(H), bits(g[f"H{st}"]))
