@@ -343,6 +343,95 @@ HD int inverse8_sparse(const float* src, float* dst, float eps) {
     return 0;
 }
 
+// InverseMatrix of order 8 with the reference's pivot search, every array index static: the pivot row is picked with selects
+// (first not-yet-used row, in row order, whose entry in column i exceeds eps), all 16 columns of every row take part as in the
+// reference (no structural shortcuts), and the closing "row that holds an exact 1 in column r goes to position r" pass
+// (matrix.h:262-288) is replayed with predicated swaps.  ~4x the work of inverse8_sparse, ~1/20 of the index-driven generic
+// routine; used for the inversions inverse8_sparse hands back.  Returns 0 = inverted (dst written), 1 = no pivot (dst untouched).
+// Deliberately NOT inlined: inlined into the draw loop its 128 + 16 live values push the common path into scratch (measured
+// 5.7 against 4.4 us per pair); the caller passes copies so that its own arrays stay in registers.
+__host__ __device__ __attribute__((noinline)) inline int inverse8_pivot(const float* src, float* dst, float eps) {
+    float t[8][16];
+    bool used[8];
+    sp::sfor<0, 8>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        used[i] = false;
+        sp::sfor<0, 16>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            if constexpr (j < 8) t[i][j] = src[i * 8 + j]; else t[i][j] = (j - 8 == i) ? 1.0f : 0.0f;
+        });
+    });
+    bool failed = false;
+    sp::sfor<0, 8>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        int rowI = -1;
+        sp::sfor<0, 8>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            if (rowI < 0 && !used[j] && fabsf(t[j][i]) > eps) rowI = j;
+        });
+        if (rowI < 0) failed = true;
+        float pr[16];
+        float ei = 1.0f;
+        sp::sfor<0, 8>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            if (j == rowI) { used[j] = true; ei = t[j][i]; }
+        });
+        sp::sfor<0, 16>([&](auto cc) {
+            constexpr int c = decltype(cc)::value;
+            float v = 0.0f;
+            sp::sfor<0, 8>([&](auto jc) { constexpr int j = decltype(jc)::value; v = (j == rowI) ? t[j][c] : v; });
+            pr[c] = v / ei;
+        });
+        sp::sfor<0, 8>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            const float e2 = t[j][i];
+            const bool is_p = (j == rowI);
+            const bool upd = !is_p && !(fabsf(e2) < eps);
+            const float ne = -e2;
+            sp::sfor<0, 16>([&](auto cc) {
+                constexpr int c = decltype(cc)::value;
+                const float prod = ne * pr[c];
+                const float sum = t[j][c] + prod;
+                t[j][c] = is_p ? pr[c] : (upd ? sum : t[j][c]);
+            });
+        });
+    });
+    if (failed) return 1;
+    sp::sfor<0, 8>([&](auto rc) {
+        constexpr int r = decltype(rc)::value;
+        int target = -1;
+        sp::sfor<0, 8>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            if (target < 0 && t[i][r] == 1.0f) target = i;
+        });
+        sp::sfor<0, 8>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            if constexpr (i != r) {
+                const bool sw = (target == i);
+                sp::sfor<0, 16>([&](auto cc) {
+                    constexpr int c = decltype(cc)::value;
+                    const float a = t[r][c], b = t[i][c];
+                    t[r][c] = sw ? b : a; t[i][c] = sw ? a : b;
+                });
+            }
+        });
+    });
+    sp::sfor<0, 8>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        sp::sfor<0, 8>([&](auto jc) { constexpr int j = decltype(jc)::value; dst[i * 8 + j] = t[i][8 + j]; });
+    });
+    return 0;
+}
+
+HD void pivot_call(const float* M, float* inv, float eps) {
+    float in[64], out[64];
+#pragma unroll
+    for (int i = 0; i < 64; i++) { in[i] = M[i]; out[i] = inv[i]; }
+    inverse8_pivot(in, out, eps);
+#pragma unroll
+    for (int i = 0; i < 64; i++) inv[i] = out[i];
+}
+
 // (J^T J)^-1 J^T with J's pattern (MulMatrix order: ascending k over the entries that are not structural zeros)
 HD void invjt_sparse(const float* inv, const float* A, float* M) {
     sp::sfor<0, 8>([&](auto rc) {
@@ -377,7 +466,7 @@ HD bool hypothesis4_fast(const float* p, float* H, int* polished = nullptr) {
     if (!jtj_sparse(A, M)) return false;
 #pragma unroll
     for (int i = 0; i < 64; i++) inv[i] = 0.0f;                   // a failed inversion leaves the zeros (matrix.h:377)
-    if (inverse8_sparse(M, inv, 1e-20f) == 2) return false;
+    if (inverse8_sparse(M, inv, 1e-20f) == 2) pivot_call(M, inv, 1e-20f);
     invjt_sparse(inv, A, M);
 #pragma unroll
     for (int r = 0; r < 8; r++) {
@@ -420,7 +509,7 @@ HD bool hypothesis4_fast(const float* p, float* H, int* polished = nullptr) {
             C[2 * i] = x2 - nx / d; C[2 * i + 1] = y2 - ny / d;
         }
         if (!jtj_sparse(A, M)) return false;
-        if (inverse8_sparse(M, inv, 1e-6f) == 2) return false;    // 1: the previous iteration's inverse stays (zeros before the first)
+        if (inverse8_sparse(M, inv, 1e-6f) == 2) pivot_call(M, inv, 1e-6f);    // failure: the previous iteration's inverse stays (zeros before the first)
         invjt_sparse(inv, A, M);
         bool done = true;
 #pragma unroll

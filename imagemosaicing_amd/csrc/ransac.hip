@@ -39,6 +39,19 @@ struct RansacArgs {
     mi355_pair_result* out;        // [pair]
 };
 
+// the index-driven generic routines (hmath.h solve_h4 / nlls4) for the draws the register path hands back (a non-finite entry
+// in the design matrix): a call, not inlined, so that the draw loop's registers are not shared with it.  Returns the skip flag.
+__device__ __attribute__((noinline)) bool generic_hypothesis(const float* p, float* h, float* scr) {
+    hm::solve_h4(p, h, scr);                               // mosaicimage.h:1863
+    const bool skip = h[8] > 5.0f;                         // :1864-1867
+    if (!skip && h[8] < 5.0f && h[8] > 0.01f) {            // :1868-1876
+        float fine[9];
+        hm::nlls4(p, h, fine, scr);
+        for (int i = 0; i < 9; i++) h[i] = fine[i];
+    }
+    return skip;
+}
+
 __device__ __forceinline__ int block_exclusive_scan_flags(bool flag, int tid, int* wave_tot /*LDS[RB/64+1]*/, int& total) {
     const unsigned long long m = __ballot(flag);
     const int lane = tid & 63, wv = tid >> 6;
@@ -120,15 +133,12 @@ __global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(RANSAC_WPE, 
             for (unsigned long long need = __ballot(!fast_ok); need; need &= need - 1ull) {
                 if ((tid & 63) == __builtin_ctzll(need)) {
                     atomicAdd(&s_fb, 1);                    // statistics only (reported in _pad)
-                    float* const scr = s_fbk[tid >> 6];
-                    hm::solve_h4(p, h, scr);               // :1863
-                    skip = h[8] > 5.0f;
-                    if (!(h[8] > 5.0f) && h[8] < 5.0f && h[8] > 0.01f) {   // :1868-1876
-                        float fine[9];
-                        hm::nlls4(p, h, fine, scr);
+                    float pin[16], hout[9];
 #pragma unroll
-                        for (int i = 0; i < 9; i++) h[i] = fine[i];
-                    }
+                    for (int i = 0; i < 16; i++) pin[i] = p[i];
+                    skip = generic_hypothesis(pin, hout, s_fbk[tid >> 6]);
+#pragma unroll
+                    for (int i = 0; i < 9; i++) h[i] = hout[i];
                 }
             }
             long long c1 = wall_clock64(); Tsolve += c1 - c0;

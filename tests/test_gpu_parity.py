@@ -339,3 +339,41 @@ def test_ransac2d_polish_that_diverges_keeps_its_slot(ctx, oracle):
         a = oracle.ransac2d(g["p1"], g["p2"], float(g["dist"]), st, int(g["seed"]))
         assert a[0] == ok and np.array_equal(a[1], i1) and np.array_equal(bits(a[3]), bits(H))
     assert not np.array_equal(g["H200"], g["H201"])
+
+
+def _degenerate_case(rng, kind, m):
+    from tests.oracle_lib import SFPOINT
+    w, h = 4000.0, 3000.0
+    p1 = np.zeros(m, SFPOINT); p2 = np.zeros(m, SFPOINT)
+    p2["x"] = rng.uniform(0, w, m); p2["y"] = rng.uniform(0, h, m)
+    A = np.array([[1 + rng.normal(0, .02), rng.normal(0, .02), rng.uniform(-800, 800)], [rng.normal(0, .02), 1 + rng.normal(0, .02), rng.uniform(-600, 600)], [0, 0, 1]])
+    q = A @ np.stack([p2["x"], p2["y"], np.ones(m)])
+    p1["x"] = q[0] + rng.normal(0, 0.4, m); p1["y"] = q[1] + rng.normal(0, 0.4, m)
+    out = rng.random(m) < 0.5
+    p1["x"][out] = rng.uniform(0, w, out.sum()); p1["y"][out] = rng.uniform(0, h, out.sum())
+    if kind == 0:      # one source point matched by several targets: singular 4-point systems, failed inversions
+        k = rng.integers(0, m, m // 2); p2["x"][: m // 2] = p2["x"][k]; p2["y"][: m // 2] = p2["y"][k]
+    elif kind == 1:    # duplicated pairs
+        k = rng.integers(0, m, m // 3); p2[: m // 3] = p2[k]; p1[: m // 3] = p1[k]
+    elif kind == 2:    # integer lattice: collinear quadruples, exact zeros in the eliminations (pivot search below the diagonal)
+        p2["x"] = np.round(p2["x"] / 50) * 50; p2["y"] = np.round(p2["y"] / 50) * 50; p1["x"] = np.round(p1["x"]); p1["y"] = np.round(p1["y"])
+    elif kind == 3:    # every source point on one line
+        p2["y"] = 0.5 * p2["x"] + 10
+    elif kind == 4:    # coordinates whose products overflow binary32: non-finite design matrices (the generic routines)
+        p1["x"] *= 1e18; p1["y"] *= 1e18; p2["x"] *= 1e18; p2["y"] *= 1e18
+    return p1, p2
+
+
+def test_ransac2d_degenerate_inputs_vs_oracle(ctx, oracle):
+    """duplicated, collinear, lattice and overflowing correspondences drive the 4-point solve through its three tiers (sparse
+    register elimination, register elimination with the reference's pivot search, generic routines); every outcome -- also
+    'no homography' -- must be the oracle's (= the reference's: tests/test_oracle_vs_ref.py runs the same inputs on CPU)"""
+    rng = np.random.default_rng(77)
+    for kind in range(5):
+        for m in (4, 9, 60, 250, 400):
+            p1, p2 = _degenerate_case(rng, kind, m)
+            seed = int(rng.integers(1, 1 << 31)); st = int(rng.choice([1000, 200]))
+            a = oracle.ransac2d(p1, p2, 2.5, st, seed)
+            b = ctx.Ransac2D(p1, p2, 2.5, st, seed)
+            assert a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]), (kind, m, a[0], b[0], len(a[1]), len(b[1]))
+            assert np.array_equal(bits(a[3]), bits(b[3])), (kind, m)

@@ -41,3 +41,19 @@ def test_warp_random(oracle, ref):
         r1, a = oracle.image_projection_transform(img, h9)
         r2, b = ref.image_projection_transform(img, h9)
         assert r1 == r2 and a[1:] == b[1:] and np.array_equal(a[0], b[0])
+
+
+def test_ransac_degenerate_inputs(oracle, ref):
+    """the degenerate correspondences of tests/test_gpu_parity.py::test_ransac2d_degenerate_inputs_vs_oracle, oracle vs the
+    reference's own code"""
+    import numpy as np
+    from tests.test_gpu_parity import _degenerate_case
+    rng = np.random.default_rng(77)
+    for kind in range(5):
+        for m in (4, 9, 60, 250, 400):
+            p1, p2 = _degenerate_case(rng, kind, m)
+            seed = int(rng.integers(1, 1 << 31)); st = int(rng.choice([1000, 200]))
+            a = oracle.ransac2d(p1, p2, 2.5, st, seed)
+            b = ref.ransac2d(p1, p2, 2.5, st, seed)
+            assert a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]), (kind, m)
+            assert np.array_equal(bits(a[3]), bits(b[3])), (kind, m)
