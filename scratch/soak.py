@@ -5,6 +5,8 @@ import imagemosaicing_amd as im
 from tests import oracle_lib
 from tests.synth_frames import terrain
 o = oracle_lib.load_oracle()
+large = len(sys.argv) > 3 and sys.argv[3] == 'large'     # 1500..4100 px wide frames: streamed / cascade routes, odd strip remainders
+if large: o = oracle_lib.load_oracle_fast()
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 1)
 budget = float(sys.argv[2]) if len(sys.argv) > 2 else 240.0
 t0 = time.time(); n = 0; bad = 0
@@ -20,22 +22,27 @@ while time.time() - t0 < budget:
     big = rng.random() < 0.25
     w = int(rng.integers(1000, 1500)) if big else int(rng.integers(64, 700))
     h = int(rng.integers(760, 1000)) if big else int(rng.integers(64, 500))
-    if rng.random() < 0.5: w &= ~3
+    if large:
+        w = int(rng.integers(1500, 4101)); h = int(rng.integers(1100, 3101))
+        if rng.random() < 0.7: w &= ~7
+    elif rng.random() < 0.5: w &= ~3
     nb = int(rng.integers(1, 6))
     kinds = [int(rng.integers(0, 4)) for _ in range(nb)]
     imgs = [content(w, h, k, int(rng.integers(1 << 30))) for k in kinds]
     c = im.Context(0)
     c.set_option("sift_batch", int(rng.integers(1, 9))); c.set_option("sift_slots", int(rng.integers(1, 4)))
     if rng.random() < 0.5: c.set_option("xstream_min_w", 1000); c.set_option("xstream_min_frames", 1)
+    casc = int(rng.random() < 0.5); c.set_option("sift_cascade", casc)
     dev = [torch.from_numpy(np.ascontiguousarray(i)).cuda() for i in imgs]
     torch.cuda.synchronize()
     for k, d in enumerate(dev): c.SiftExtractDev(k, d.data_ptr(), w, h, w * 3)
+    oracle_out = oracle_lib.parallel_map(o.sift, imgs) if large else None
     for k, img in enumerate(imgs):
         kp, desc = c.GetFeatures(k)
-        okp, od = o.sift(img)
+        okp, od = oracle_out[k] if large else o.sift(img)
         ok = len(kp) == len(okp) and np.array_equal(kp.view(np.uint8), okp.view(np.uint8)) and np.array_equal(desc.astype(np.uint8), od)
         n += 1
         if not ok:
-            bad += 1; print("MISMATCH", w, h, kinds[k], len(kp), len(okp), flush=True)
+            bad += 1; print("MISMATCH", w, h, kinds[k], "cascade", casc, len(kp), len(okp), flush=True)
     c.close()
 print("soak: %d frames, %d mismatches, %.0f s" % (n, bad, time.time() - t0))
