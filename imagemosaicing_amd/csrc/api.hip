@@ -83,6 +83,7 @@ extern "C" void mi355_destroy(mi355_ctx* ctx) {
     for (auto& kv : ctx->draw_tables) kv.second.release();
     for (auto& kv : ctx->prof) for (auto& ev : kv.second.ev) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     if (ctx->heavy_ev) (void)hipEventDestroy(ctx->heavy_ev);
+    for (hipEvent_t e : ctx->batch_events) if (e) (void)hipEventDestroy(e);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }

@@ -58,6 +58,7 @@ struct Features {
     // adopted by mi_resolve_features() the first time the host needs it (match, get_features)
     bool pending = false;
     volatile int* h_cnt = nullptr;   // 8 ints: extrema, refined, keypoints, kept, overflow, ...
+    hipEvent_t ready = nullptr;      // recorded after the frame's batch (owned by ctx->batch_events): lets a match wait for ITS frames only
     unsigned caps[3] = {0, 0, 0};
     void release() { kp.release(); xy.release(); d8.release(); bf.release(); nrm.release(); }
 };
@@ -87,6 +88,7 @@ struct mi355_ctx {
     std::map<std::string, ProfClass> prof;
     std::vector<SiftWork*> sift_slots;                 // batch work areas, each with its own stream (sift.hip)
     int sift_next = 0;
+    std::vector<hipEvent_t> batch_events; size_t batch_events_used = 0;   // one event per enqueued batch, recycled when nothing is pending
     hipEvent_t heavy_ev = nullptr; bool heavy_ev_valid = false;   // option "serial_heavy" (measurement): the chip-filling phases of consecutive batches do not overlap
     int serial_heavy = 0;
     std::vector<DevBuf> host_frames;                   // staging ring of mi355_sift_extract's deferred mode (host frames joining batches)
@@ -149,6 +151,7 @@ int mi_select_grid(mi355_ctx*, const mi355_dmatch* sorted, int n, const float* k
 int mi_set_features(mi355_ctx*, int img_id, const mi355_keypoint* kp, const float* desc, int n, int w, int h);
 int mi_finish_features(mi355_ctx*, Features& f, const int* d_n = nullptr, hipStream_t st = nullptr);   // builds xy / bf16 / norms from kp + d8 on device
 int mi_resolve_features(mi355_ctx*);               // waits for in-flight SIFT frames and adopts their keypoint counts
+int mi_resolve_features_of(mi355_ctx*, const int* ids, int n);   // the same for the given frames only (waits for their batches' events)
 int mi_sift_extract_dev(mi355_ctx*, int img_id, const uint8_t* d_bgr, int w, int h, int ws, int* n_kp);
 void mi_sift_release(mi355_ctx*);
 void mi_comm_release(mi355_ctx*);

@@ -18,6 +18,7 @@
 // operand (columns), so after the MFMA lane l holds 16 train rows of ONE query (column l&31): the running
 // top-2 is lane-local (no cross-lane traffic in the loop) and the two half-waves are merged once at the end.
 #include "common.h"
+#include <algorithm>
 
 namespace {
 
@@ -250,7 +251,13 @@ __global__ void desc_u8_to_f32_kernel(const uint8_t* d8, float* f, size_t count)
 }
 
 int build_pair_table(mi355_ctx* ctx, const int32_t* pairs, int n_pairs, std::vector<PairDesc>& pd) {
-    { int rc = mi_resolve_features(ctx); if (rc != MI355_OK) return rc; }
+    {                                                       // wait for the frames of THESE pairs only: later batches keep running
+        std::vector<int> ids(pairs, pairs + 2 * (size_t)n_pairs);
+        std::sort(ids.begin(), ids.end());
+        ids.erase(std::unique(ids.begin(), ids.end()), ids.end());
+        int rc = mi_resolve_features_of(ctx, ids.data(), (int)ids.size());
+        if (rc != MI355_OK) return rc;
+    }
     pd.resize(n_pairs);
     for (int p = 0; p < n_pairs; p++) {
         const int i = pairs[2 * p], j = pairs[2 * p + 1];

@@ -1969,26 +1969,55 @@ int mi_sift_flush(mi355_ctx* ctx) {
     return rc;
 }
 
+// adopts the keypoint count of a finished frame from pinned memory
+static int adopt_counts(mi355_ctx* ctx, int img_id, Features& f) {
+    f.pending = false;
+    if (!f.h_cnt) { f.n = 0; return MI355_OK; }               // its batch failed to launch
+    const volatile int* c = f.h_cnt;
+    for (int i = 0; i < 8; i++) ctx->last_counts[i] = c[i];
+    if ((unsigned)c[0] > f.caps[0] || (unsigned)c[1] > f.caps[1] || (unsigned)c[2] > f.caps[2] || c[4]) {
+        ctx->set_error("sift: candidate buffer overflow (image " + std::to_string(img_id) + " has more extrema than the buffers assume)");
+        f.n = 0;
+        return MI355_ERR_FAILED;
+    }
+    f.n = c[3];
+    return MI355_OK;
+}
+
 // waits for every in-flight frame and adopts the keypoint counts that landed in pinned memory
 int mi_resolve_features(mi355_ctx* ctx) {
     int rc = mi_sift_flush(ctx);
     bool any = false;
     for (auto& kv : ctx->feats) if (kv.second.pending) { any = true; break; }
-    if (!any) return rc;
+    if (!any) { ctx->batch_events_used = 0; return rc; }
     for (SiftWork* s : ctx->sift_slots) if (s && s->stream) MI_HIP(hipStreamSynchronize(s->stream));
     for (auto& kv : ctx->feats) {
-        Features& f = kv.second;
-        if (!f.pending) continue;
-        f.pending = false;
-        if (!f.h_cnt) { f.n = 0; continue; }                   // its batch failed to launch
-        const volatile int* c = f.h_cnt;
-        for (int i = 0; i < 8; i++) ctx->last_counts[i] = c[i];
-        if ((unsigned)c[0] > f.caps[0] || (unsigned)c[1] > f.caps[1] || (unsigned)c[2] > f.caps[2] || c[4]) {
-            ctx->set_error("sift: candidate buffer overflow (image " + std::to_string(kv.first) + " has more extrema than the buffers assume)");
-            f.n = 0; rc = MI355_ERR_FAILED;
-            continue;
-        }
-        f.n = c[3];
+        if (!kv.second.pending) continue;
+        const int r = adopt_counts(ctx, kv.first, kv.second);
+        if (r != MI355_OK) rc = r;
+    }
+    ctx->batch_events_used = 0;
+    return rc;
+}
+
+// the same for the given frames only: the host waits for THEIR batches (batch events), later batches keep running -- a caller
+// that matches pairs while the rest of the survey is still in detect+describe overlaps the two (bench.py, window surveys)
+int mi_resolve_features_of(mi355_ctx* ctx, const int* ids, int n) {
+    int rc = MI355_OK;
+    bool parked = false;
+    for (int k = 0; k < n && !parked; k++) {
+        auto it = ctx->feats.find(ids[k]);
+        if (it != ctx->feats.end() && it->second.pending && !it->second.h_cnt && !it->second.ready) parked = true;
+    }
+    if (parked) rc = mi_sift_flush(ctx);                      // some of them still wait for their batch to fill: enqueue it
+    for (int k = 0; k < n; k++) {
+        auto it = ctx->feats.find(ids[k]);
+        if (it == ctx->feats.end() || !it->second.pending) continue;
+        Features& f = it->second;
+        if (f.ready) MI_HIP(hipEventSynchronize(f.ready));
+        else { const int r = mi_resolve_features(ctx); if (r != MI355_OK) rc = r; continue; }
+        const int r = adopt_counts(ctx, it->first, f);
+        if (r != MI355_OK) rc = r;
     }
     return rc;
 }
@@ -2119,7 +2148,7 @@ int mi_sift_extract_dev(mi355_ctx* ctx, int img_id, const uint8_t* d_bgr, int w,
     f.w = w; f.h = h;
     MI_HIP(f.kp.reserve(sizeof(mi355_keypoint) * 2048));
     MI_HIP(f.d8.reserve(128 * 2048));
-    f.pending = true; f.h_cnt = nullptr; f.n = 0;
+    f.pending = true; f.h_cnt = nullptr; f.ready = nullptr; f.n = 0;
     s->pend.push_back({img_id, d_bgr, ws, ctx->pend_event});
     if ((int)s->pend.size() >= nb) {
         rc = sift_run_batch(ctx, s);
@@ -2310,6 +2339,16 @@ static int sift_run_batch(mi355_ctx* ctx, SiftWork* s) {
         f.caps[0] = 0xffffffffu; f.caps[1] = s->ref_cap; f.caps[2] = s->kp_cap;      // candidate overflow is flagged by the kernel (cnt[4])
     }
     MI_HIP(hipEventRecord(s->done, st));
+    {                                                       // the batch's own event: mi_resolve_features_of() waits for it, not for the streams
+        if (ctx->batch_events_used >= ctx->batch_events.size()) {
+            hipEvent_t e = nullptr;
+            MI_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            ctx->batch_events.push_back(e);
+        }
+        hipEvent_t e = ctx->batch_events[ctx->batch_events_used++];
+        MI_HIP(hipEventRecord(e, st));
+        for (int k = 0; k < n; k++) fs[k]->ready = e;
+    }
     for (int k = 0; k < n; k++) if (pend[k].ev) MI_HIP(hipEventRecord(pend[k].ev, st));
     return MI355_OK;
 }
