@@ -123,8 +123,8 @@ __global__ __launch_bounds__(256) void surf_cols(uint32_t* S, int sw, int sh) {
 }
 
 // ---- fast Hessian -----------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void surf_det(const uint32_t* S, int sw, const SurfLayers* L, float* det, float* trace) {
-    const LayerDesc& q = L->l[blockIdx.z];
+__global__ __launch_bounds__(256) void surf_det(const uint32_t* S, int sw, const SurfLayers* L, float* det, float* trace, int z0) {
+    const LayerDesc& q = L->l[z0 + blockIdx.z];
     const int j = blockIdx.x * 64 + (threadIdx.x & 63), i = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (i >= q.si || j >= q.sj) return;
     const float vx = haar<3>(S, sw, j * q.step, i * q.step, q.dx);
@@ -133,6 +133,49 @@ __global__ __launch_bounds__(256) void surf_det(const uint32_t* S, int sw, const
     const size_t idx = q.off + (size_t)(i + q.margin) * q.cols + (j + q.margin);
     det[idx] = vx * vy - (0.81f * vxy) * vxy;
     trace[idx] = vx + vy;
+}
+
+// octave 0 (sampling step 1, sizes 9 / 15 / 21 / 27): the four layers of a 64 x 16 block of samples read the same 92 x 44 window of
+// the integral image 160 times per sample -- staged in LDS once (16 KB) instead of 160 gathers through L1 per sample.  Same boxes,
+// same double accumulation as surf_det.
+constexpr int DT_W = 64, DT_H = 16, DT_HALO = 28, DT_TW = DT_W + DT_HALO, DT_TH = DT_H + DT_HALO;
+template <int N>
+__device__ __forceinline__ float haar_tile(const uint32_t* t, int x, int y, const SBox* f) {
+    double d = 0.0;
+#pragma unroll
+    for (int k = 0; k < N; k++) {
+        const uint32_t a = t[(y + f[k].y1) * DT_TW + x + f[k].x1], b = t[(y + f[k].y1) * DT_TW + x + f[k].x2];
+        const uint32_t c = t[(y + f[k].y2) * DT_TW + x + f[k].x1], e = t[(y + f[k].y2) * DT_TW + x + f[k].x2];
+        const int box = (int)(a + e - b - c);
+        d += (double)box * (double)f[k].w;
+    }
+    return (float)d;
+}
+__global__ __launch_bounds__(256) void surf_det_tile(const uint32_t* S, int sw, int sh, const SurfLayers* L, float* det, float* trace) {
+    __shared__ uint32_t t[DT_TH * DT_TW];
+    const int x0 = blockIdx.x * DT_W, y0 = blockIdx.y * DT_H;
+    for (int e = threadIdx.x; e < DT_TH * DT_TW; e += 256) {
+        const int r = e / DT_TW, c = e - r * DT_TW;
+        const int y = y0 + r, x = x0 + c;
+        t[e] = (y < sh && x < sw) ? S[(size_t)y * sw + x] : 0u;
+    }
+    __syncthreads();
+    const int lj = threadIdx.x & 63, j = x0 + lj;
+#pragma unroll
+    for (int l = 0; l < S_LAY + 2; l++) {
+        const LayerDesc& q = L->l[l];                      // octave 0: step 1, size <= 27
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int li = (threadIdx.x >> 6) * 4 + k, i = y0 + li;
+            if (i >= q.si || j >= q.sj) continue;
+            const float vx = haar_tile<3>(t, lj, li, q.dx);
+            const float vy = haar_tile<3>(t, lj, li, q.dy);
+            const float vxy = haar_tile<4>(t, lj, li, q.dxy);
+            const size_t idx = q.off + (size_t)(i + q.margin) * q.cols + (j + q.margin);
+            det[idx] = vx * vy - (0.81f * vxy) * vxy;
+            trace[idx] = vx + vy;
+        }
+    }
 }
 
 __device__ void solve3(float A[3][3], float b[3], float x[3]) {        // oracle_surf.c surf_solve3
@@ -205,30 +248,44 @@ __device__ __forceinline__ unsigned long long surf_key(float v0, int o, int l, i
            ((unsigned long long)i << 14) | (unsigned long long)j;
 }
 
-__global__ __launch_bounds__(256) void surf_maxima(const SurfLayers* L, const float* det, float thr, unsigned long long* keys, unsigned* count, unsigned cap) {
-    const int m = blockIdx.z, o = m / S_LAY, l = 1 + m % S_LAY;
+__global__ __launch_bounds__(256) void surf_maxima(const SurfLayers* L, const float* det, float thr, unsigned long long* keys, unsigned* count, unsigned cap, int m0) {
+    // the candidates of a workgroup reserve their slots with ONE global atomic (a single address takes ~1e8 atomics/s; one per
+    // candidate cost 0.4-0.8 ms per 12 MP frame); the list is sorted afterwards, so the order inside it is free
+    __shared__ unsigned s_n, s_base;
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    const int m = m0 + blockIdx.z, o = m / S_LAY, l = 1 + m % S_LAY;
     const LayerDesc& b = L->l[o * (S_LAY + 2) + l];
     const LayerDesc& c = L->l[o * (S_LAY + 2) + l + 1];
     const LayerDesc& a = L->l[o * (S_LAY + 2) + l - 1];
     const int margin = (c.size / 2) / b.step + 1;
     const int j = margin + blockIdx.x * 64 + (threadIdx.x & 63), i = margin + blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (i >= b.rows - margin || j >= b.cols - margin) return;
-    const float v0 = det[b.off + (size_t)i * b.cols + j];
-    if (!(v0 > thr)) return;
-    const size_t offs[3] = {a.off, b.off, c.off};
-    bool is_max = true;
+    bool cand = false;
+    float v0 = 0.0f;
+    if (i < b.rows - margin && j < b.cols - margin) {
+        v0 = det[b.off + (size_t)i * b.cols + j];
+        if (v0 > thr) {
+            const size_t offs[3] = {a.off, b.off, c.off};
+            bool is_max = true;
 #pragma unroll
-    for (int q = 0; q < 3; q++)
+            for (int q = 0; q < 3; q++)
 #pragma unroll
-        for (int di = -1; di <= 1; di++)
+                for (int di = -1; di <= 1; di++)
 #pragma unroll
-            for (int dj = -1; dj <= 1; dj++)
-                if (!(q == 1 && di == 0 && dj == 0)) { if (!(v0 > det[offs[q] + (size_t)(i + di) * b.cols + (j + dj)])) is_max = false; }
-    if (!is_max) return;
-    float cx, cy, ksz;
-    if (!surf_interp(L, det, o, l, i, j, cx, cy, ksz)) return;
-    const unsigned slot = atomicAdd(count, 1u);
-    if (slot < cap) keys[slot] = surf_key(v0, o, l, i, j);
+                    for (int dj = -1; dj <= 1; dj++)
+                        if (!(q == 1 && di == 0 && dj == 0)) { if (!(v0 > det[offs[q] + (size_t)(i + di) * b.cols + (j + dj)])) is_max = false; }
+            if (is_max) {
+                float cx, cy, ksz;
+                cand = surf_interp(L, det, o, l, i, j, cx, cy, ksz);
+            }
+        }
+    }
+    unsigned local = 0;
+    if (cand) local = atomicAdd(&s_n, 1u);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_n) s_base = atomicAdd(count, s_n);
+    __syncthreads();
+    if (cand) { const unsigned slot = s_base + local; if (slot < cap) keys[slot] = surf_key(v0, o, l, i, j); }
 }
 
 // ---- bitonic sort of the keys (ascending), N a power of two, padding keys are all ones -----------------------------------------------
@@ -421,7 +478,7 @@ __global__ __launch_bounds__(256) void surf_describe(const uint8_t* gray, int w,
 }
 
 // keypoints without an orientation sample are dropped: order-preserving compaction of keypoints + descriptors (one workgroup)
-__global__ __launch_bounds__(1024) void surf_compact(const SurfKp* kps, const float* desc, const int* n_in, mi355_keypoint* kp_out, float* desc_out, float2* xy, int* n_out) {
+__global__ __launch_bounds__(1024) void surf_compact(const SurfKp* kps, const int* n_in, mi355_keypoint* kp_out, float2* xy, int* pos_out, int* n_out) {
     __shared__ int s_base, s_w[16];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, n = *n_in;
     if (tid == 0) s_base = 0;
@@ -439,13 +496,22 @@ __global__ __launch_bounds__(1024) void surf_compact(const SurfKp* kps, const fl
             const SurfKp k = kps[i];
             mi355_keypoint o; o.x = k.x; o.y = k.y; o.size = k.size; o.angle = k.angle; o.response = k.response; o.octave = k.octave; o.class_id = k.lap;
             kp_out[pos] = o; xy[pos] = make_float2(k.x, k.y);
-            for (int q = 0; q < 128; q++) desc_out[(size_t)pos * 128 + q] = desc[(size_t)i * 128 + q];
-        }
+            pos_out[i] = pos;
+        } else if (i < n) pos_out[i] = -1;
         __syncthreads();
         if (tid == 0) s_base += tot;
         __syncthreads();
     }
     if (tid == 0) *n_out = s_base;
+}
+
+// the 512-byte descriptor rows move with one workgroup per two keypoints, coalesced (a single workgroup copying them row by row
+// per lane took 1.35 ms for 8192 keypoints -- the largest kernel of the extraction)
+__global__ __launch_bounds__(256) void surf_move_desc(const float* desc, const int* pos, const int* n_in, float* desc_out) {
+    const int i = blockIdx.x * 2 + (threadIdx.x >> 7), t = threadIdx.x & 127;
+    if (i >= *n_in) return;
+    const int p = pos[i];
+    if (p >= 0) desc_out[(size_t)p * 128 + t] = desc[(size_t)i * 128 + t];
 }
 
 // ---- pair stage ---------------------------------------------------------------------------------------------------------------------
@@ -625,9 +691,28 @@ static int surf_extract_dev(mi355_ctx* ctx, int img_id, const uint8_t* d_bgr, in
     }
     if (max_si > 0) {
         ProfScope ps(ctx, "surf_det", 0.0, st);
-        hipLaunchKernelGGL(surf_det, dim3((max_sj + 63) / 64, (max_si + 3) / 4, S_NL), dim3(256), 0, st, dS.as<uint32_t>(), sw, dL.as<SurfLayers>(), ddet.as<float>(), dtr.as<float>());
-        hipLaunchKernelGGL(surf_maxima, dim3((max_cols + 63) / 64, (max_rows + 3) / 4, S_OCT * S_LAY), dim3(256), 0, st, dL.as<SurfLayers>(), ddet.as<float>(), thr,
-                           dkeys.as<unsigned long long>(), d_count, CAND_CAP);
+        // one launch per octave, sized for that octave (a common grid of the largest layer spent more time dispatching empty
+        // workgroups than computing); octave 0 (step 1, boxes <= 27) from an LDS tile, the others straight from the integral image
+        for (int o = 0; o < S_OCT; o++) {
+            int si = 0, sj = 0, rows = 0, cols = 0;
+            bool tile_ok = (o == 0);
+            for (int l = 0; l < S_LAY + 2; l++) {
+                const LayerDesc& q = L.l[o * (S_LAY + 2) + l];
+                si = std::max(si, q.si); sj = std::max(sj, q.sj); rows = std::max(rows, q.rows); cols = std::max(cols, q.cols);
+                tile_ok = tile_ok && q.step == 1 && q.size < DT_HALO;
+            }
+            if (si <= 0 || sj <= 0) continue;
+            if (tile_ok)
+                hipLaunchKernelGGL(surf_det_tile, dim3((sj + DT_W - 1) / DT_W, (si + DT_H - 1) / DT_H), dim3(256), 0, st, dS.as<uint32_t>(), sw, sh, dL.as<SurfLayers>(), ddet.as<float>(), dtr.as<float>());
+            else
+                hipLaunchKernelGGL(surf_det, dim3((sj + 63) / 64, (si + 3) / 4, S_LAY + 2), dim3(256), 0, st, dS.as<uint32_t>(), sw, dL.as<SurfLayers>(), ddet.as<float>(), dtr.as<float>(), o * (S_LAY + 2));
+        }
+        for (int o = 0; o < S_OCT; o++) {
+            const LayerDesc& q = L.l[o * (S_LAY + 2) + 1];
+            if (q.rows <= 0 || q.cols <= 0) continue;
+            hipLaunchKernelGGL(surf_maxima, dim3((q.cols + 63) / 64, (q.rows + 3) / 4, S_LAY), dim3(256), 0, st, dL.as<SurfLayers>(), ddet.as<float>(), thr,
+                               dkeys.as<unsigned long long>(), d_count, CAND_CAP, o * S_LAY);
+        }
     }
     // the number of candidates decides the sort size: one small synchronous read (the extraction is synchronous anyway)
     unsigned cnt = 0;
@@ -656,7 +741,10 @@ static int surf_extract_dev(mi355_ctx* ctx, int img_id, const uint8_t* d_bgr, in
                            d_count, CAND_CAP, max_kp, dkps.as<SurfKp>(), d_nkeep);
         hipLaunchKernelGGL(surf_orient, dim3((max_kp + 3) / 4), dim3(256), 0, st, dS.as<uint32_t>(), w, h, d_tab, dkps.as<SurfKp>(), d_nkeep);
         hipLaunchKernelGGL(surf_describe, dim3(max_kp), dim3(256), 0, st, dgray.as<uint8_t>(), w, h, d_dw, dkps.as<SurfKp>(), d_nkeep, ddesc.as<float>());
-        hipLaunchKernelGGL(surf_compact, dim3(1), dim3(1024), 0, st, dkps.as<SurfKp>(), ddesc.as<float>(), d_nkeep, f.kp.as<mi355_keypoint>(), f.desc.as<float>(), f.xy.as<float2>(), d_nout);
+        DevBuf& dpos = ctx->buf("surf_pos");
+        MI_HIP(dpos.reserve(sizeof(int) * SURF_MAX_KP));
+        hipLaunchKernelGGL(surf_compact, dim3(1), dim3(1024), 0, st, dkps.as<SurfKp>(), d_nkeep, f.kp.as<mi355_keypoint>(), f.xy.as<float2>(), dpos.as<int>(), d_nout);
+        hipLaunchKernelGGL(surf_move_desc, dim3((max_kp + 1) / 2), dim3(256), 0, st, ddesc.as<float>(), dpos.as<int>(), d_nkeep, f.desc.as<float>());
     }
     MI_HIP(hipGetLastError());
     int n = 0;
