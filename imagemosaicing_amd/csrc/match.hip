@@ -375,7 +375,7 @@ int mi_match_pairs_dev(mi355_ctx* ctx, const int32_t* pairs, int n_pairs, float 
     if (n_pairs <= 0) return MI355_OK;
     if (!pairs || !d_out) return MI355_ERR_ARG;
     if (ctx->p.grid_x * ctx->p.grid_y > 64 || ctx->p.grid_x < 1 || ctx->p.grid_y < 1 || ctx->p.max_selected > MI355_MAX_SELECTED) { ctx->set_error("match_pairs: grid > 64 cells or max_selected > 400"); return MI355_ERR_ARG; }
-    const int BATCH = 8192;                                   // bounds the nn workspaces (8192 x 2048 x 12 B = 192 MiB)
+    const int BATCH = 32768;                                  // bounds the nn workspaces (32768 x 2048 x 12 B = 768 MiB of the 288 GB); every batch boundary drains the stream
     std::vector<PairDesc> pd;
     for (int b0 = 0; b0 < n_pairs; b0 += BATCH) {
         const int nb = (n_pairs - b0) < BATCH ? (n_pairs - b0) : BATCH;
@@ -384,7 +384,7 @@ int mi_match_pairs_dev(mi355_ctx* ctx, const int32_t* pairs, int n_pairs, float 
         rc = run_match_select(ctx, pd, nb, false);
         if (rc != MI355_OK) return rc;
         rc = mi_ransac_batch(ctx, ctx->buf("sel1").as<mi355_sfpoint>(), ctx->buf("sel2").as<mi355_sfpoint>(), ctx->buf("nsel").as<int>(), nullptr,
-                             nb, MI355_MAX_SELECTED, dist, ctx->p.sample_times, seed, d_out + b0);
+                             nb, MI355_MAX_SELECTED, dist, ctx->p.sample_times, seed, d_out + b0, ctx->p.min_inliers);
         if (rc != MI355_OK) return rc;
         hipLaunchKernelGGL(finalize_kernel, dim3((nb + 255) / 256), dim3(256), 0, ctx->stream, ctx->buf("pair_desc").as<PairDesc>(), ctx->buf("nsel").as<int>(),
                            nb, ctx->p.min_inliers, d_out + b0);

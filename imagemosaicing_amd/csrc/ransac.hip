@@ -36,6 +36,7 @@ struct RansacArgs {
     int stride;
     float dist;
     int sample_times;
+    int min_keep;                  // pairs with at most this many inliers skip the closing refinement (-1: never): the caller rejects them anyway
     mi355_pair_result* out;        // [pair]
 };
 
@@ -241,6 +242,10 @@ __global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(RANSAC_WPE, 
         if (tid == 0) { out->n_in = cnt; out->ok = 0; }
         return;
     }
+    if (cnt <= a.min_keep) {                                // match_pairs: MosaicWithoutPos.cpp:5201 drops the pair (n_in <= 30), its H is never looked at
+        if (tid == 0) { out->n_in = cnt; out->ok = 0; }
+        return;
+    }
     // inlier coordinates, compacted in place into the head of the LDS arrays: read (<= 2 per lane since
     // cnt <= 400), barrier, write
     float ix1[2], iy1[2], ix2[2], iy2[2];
@@ -407,7 +412,7 @@ void mi_glibc_draw_table(uint32_t seed, int n, int max_draws, uint16_t* out4) {
 }
 
 int mi_ransac_batch(mi355_ctx* ctx, const mi355_sfpoint* d_p1, const mi355_sfpoint* d_p2, const int* d_n, const int* h_n,
-                    int n_pairs, int stride, float dist, int sample_times, uint32_t seed, mi355_pair_result* d_out) {
+                    int n_pairs, int stride, float dist, int sample_times, uint32_t seed, mi355_pair_result* d_out, int min_keep) {
     if (n_pairs <= 0) return MI355_OK;
     const size_t one = (size_t)MAX_DRAWS * 4;
     const uint16_t* d_tables = nullptr;
@@ -472,7 +477,7 @@ int mi_ransac_batch(mi355_ctx* ctx, const mi355_sfpoint* d_p1, const mi355_sfpoi
     }
     RansacArgs a;
     a.p1 = d_p1; a.p2 = d_p2; a.n = d_n; a.tables = d_tables; a.table_of = d_table_of;
-    a.dbg = nullptr;
+    a.dbg = nullptr; a.min_keep = min_keep;
     static const bool dbg_on = getenv("MI355_RANSAC_DBG") != nullptr;
     DevBuf& ddbg = ctx->buf("ransac_dbg");
     if (dbg_on) { MI_HIP(ddbg.reserve((size_t)n_pairs * 64)); MI_HIP(hipMemsetAsync(ddbg.p, 0, (size_t)n_pairs * 64, ctx->stream)); a.dbg = ddbg.as<long long>(); }

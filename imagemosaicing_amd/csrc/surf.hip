@@ -855,7 +855,7 @@ extern "C" int mi355_surf_match_pairs(mi355_ctx* ctx, const int32_t* pairs_ij, i
         }
         MI_HIP(hipGetLastError());
         int rc = mi_ransac_batch(ctx, ds1.as<mi355_sfpoint>(), ds2.as<mi355_sfpoint>(), dns.as<int>(), nullptr, nb, MI355_MAX_SELECTED, ransac_dist, ctx->p.sample_times, seed,
-                                 dres.as<mi355_pair_result>());
+                                 dres.as<mi355_pair_result>(), min_inliers);
         if (rc != MI355_OK) return rc;
         hipLaunchKernelGGL(surf_finalize_pairs, dim3((nb + 255) / 256), dim3(256), 0, ctx->stream, dpd.as<SPair>(), dns.as<int>(), nb, min_inliers, dres.as<mi355_pair_result>());
         MI_HIP(hipGetLastError());

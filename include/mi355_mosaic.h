@@ -56,9 +56,9 @@ typedef struct {
     int32_t i, j;            /* image indices (ptA_i, ptB_i) */
     int32_t n_in;            /* inlier count; the reference accepts the pair iff n_in > min_inliers (30) */
     int32_t n_selected;      /* correspondences after grid selection (<= 396) */
-    int32_t ok;              /* Ransac2D's bool */
+    int32_t ok;              /* Ransac2D's bool; 0 for a pair that is not accepted: match_pairs skips Ransac2D's closing refinement for it */
     int32_t accepted;        /* n_in > min_inliers */
-    float   H[9];            /* image j -> image i, H[8] = max residual */
+    float   H[9];            /* image j -> image i, H[8] = max residual (accepted pairs; zero otherwise) */
     int32_t _pad;            /* diagnostic: RANSAC draws that took the generic solve path (0 in the common case) */
     mi355_sfpoint a[MI355_MAX_SELECTED];   /* inliers in image i (id = keypoint index) */
     mi355_sfpoint b[MI355_MAX_SELECTED];   /* inliers in image j */
