@@ -26,7 +26,10 @@ typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 bf16x8;
 typedef __attribute__((__vector_size__(16 * sizeof(float)))) float f32x16;
 
 constexpr int KSTRIDE = 2048;        // per-pair stride of the nn arrays (>= nfeatures rounded up)
-constexpr int QTILE = 128;           // queries per workgroup (4 waves x 32)
+constexpr int QTILE = 256;           // queries per workgroup (8 waves x 32): every staged train tile serves 256 queries (128: 5 % slower).
+                                     // rocprofv3 --pmc (scratch/pmc_match.sh): matrix pipe busy 45 % of the time, 13.9 VALU instructions per
+                                     // MFMA -- the running top-2 + index epilogue (5 per element) bounds the kernel, not the matrix cores
+constexpr int BF_NT = QTILE * 2;     // threads per workgroup
 
 struct PairDesc {
     const uint16_t* bf_i; const int* nrm_i; const float2* xy_i; int n_i; int npad_i;
@@ -39,14 +42,14 @@ __device__ __forceinline__ void top2_update(int s, int j, int& best, int& second
     else if (s < second) second = s;
 }
 
-__global__ __launch_bounds__(256) void bf_match_kernel(const PairDesc* pairs, int* nn_idx, int* nn_d2, int* nn_2nd) {
+__global__ __launch_bounds__(BF_NT) void bf_match_kernel(const PairDesc* pairs, int* nn_idx, int* nn_d2, int* nn_2nd) {
     __shared__ __attribute__((aligned(16))) float s_nrm[KSTRIDE];    // |t|^2 of the train rows, +inf for the padding rows
     const PairDesc pd = pairs[blockIdx.y];
     const int q_base = blockIdx.x * QTILE;
     if (q_base >= pd.n_i) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int hi = lane >> 5, col = lane & 31;
-    for (int i = tid; i < pd.npad_j; i += 256) s_nrm[i] = i < pd.n_j ? (float)pd.nrm_j[i] : __builtin_inff();
+    for (int i = tid; i < pd.npad_j; i += BF_NT) s_nrm[i] = i < pd.n_j ? (float)pd.nrm_j[i] : __builtin_inff();
     __syncthreads();
     const int q = q_base + wave * 32 + col;              // this lane's query (rows beyond n_i are zero padding)
     const bool q_ok = q < pd.npad_i;
@@ -68,12 +71,15 @@ __global__ __launch_bounds__(256) void bf_match_kernel(const PairDesc* pairs, in
     constexpr int APITCH = 128 + 8;                       // bf16 per staged row: 272 B keeps the 32 rows of a read on distinct banks
     __shared__ __attribute__((aligned(16))) uint16_t s_a[2][32 * APITCH];
     const int ld_row = tid >> 3, ld_chunk = tid & 7;      // this thread stages 16 bf16 (32 B) of the tile
-    uint4 pf0, pf1;
+    uint4 pf0 = {0, 0, 0, 0}, pf1 = {0, 0, 0, 0};
+    const bool stager = tid < 256;                        // 32 rows x 8 chunks of 32 B: the first four waves stage
     auto fetch = [&](int t0) {
+        if (!stager) return;
         const uint4* g = reinterpret_cast<const uint4*>(pd.bf_j + (size_t)(t0 + ld_row) * 128 + ld_chunk * 16);
         pf0 = g[0]; pf1 = g[1];
     };
     auto stage = [&](int buf) {
+        if (!stager) return;
         uint4* d = reinterpret_cast<uint4*>(&s_a[buf][ld_row * APITCH + ld_chunk * 16]);
         d[0] = pf0; d[1] = pf1;
     };
@@ -355,7 +361,7 @@ static int run_match_select(mi355_ctx* ctx, const std::vector<PairDesc>& pd, int
     for (int p = 0; p < n_pairs; p++) { if (pd[p].n_i > max_ni) max_ni = pd[p].n_i; flops_bytes += (double)(pd[p].npad_i + pd[p].npad_j) * 256.0 + 8.0 * pd[p].n_i; }
     {
         ProfScope ps(ctx, "match", flops_bytes);
-        hipLaunchKernelGGL(bf_match_kernel, dim3((max_ni + QTILE - 1) / QTILE, n_pairs), dim3(256), 0, ctx->stream,
+        hipLaunchKernelGGL(bf_match_kernel, dim3((max_ni + QTILE - 1) / QTILE, n_pairs), dim3(BF_NT), 0, ctx->stream,
                            dpd.as<PairDesc>(), didx.as<int>(), dd2.as<int>(), d2nd.as<int>());
     }
     SelectParams sp;
