@@ -27,8 +27,10 @@ typedef __attribute__((__vector_size__(16 * sizeof(float)))) float f32x16;
 
 constexpr int KSTRIDE = 2048;        // per-pair stride of the nn arrays (>= nfeatures rounded up)
 constexpr int QTILE = 256;           // queries per workgroup (8 waves x 32): every staged train tile serves 256 queries (128: 5 % slower).
-                                     // rocprofv3 --pmc (scratch/pmc_match.sh): matrix pipe busy 45 % of the time, 13.9 VALU instructions per
-                                     // MFMA -- the running top-2 + index epilogue (5 per element) bounds the kernel, not the matrix cores
+                                     // rocprofv3 --pmc (scratch/pmc_match.sh): matrix pipe busy 45 % of the time, 13.9 VALU instructions per MFMA,
+                                     // waves parked 42 % of their cycles.  Tried without gain (23-24 ms for 19 729 pairs either way): the index
+                                     // of the best row tracked per 4-row group and recovered afterwards (-40 % epilogue instructions), two B
+                                     // operands per wave so that an A fragment read from LDS feeds two MFMAs (half the LDS reads)
 constexpr int BF_NT = QTILE * 2;     // threads per workgroup
 
 struct PairDesc {
