@@ -486,6 +486,9 @@ int mi_ransac_batch(mi355_ctx* ctx, const mi355_sfpoint* d_p1, const mi355_sfpoi
     if (lds_bytes > 48 * 1024) {
         MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ransac_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     }
+    // records start from zero: the inlier slots beyond n_in, H / ok of pairs that stop early and the padding are then the same bytes
+    // on every run and every rank (records are compared and all-gathered as bytes)
+    MI_HIP(hipMemsetAsync(d_out, 0, sizeof(mi355_pair_result) * (size_t)n_pairs, ctx->stream));
     {
         ProfScope ps(ctx, "ransac", (double)n_pairs * (24.0 * nmax + sizeof(mi355_pair_result)));
         hipLaunchKernelGGL(ransac_kernel, dim3(n_pairs), dim3(RB), lds_bytes, ctx->stream, a);
