@@ -18,13 +18,16 @@ for (w, h) in sizes:
         pool.append((img, kp, d))
 t0 = time.time(); checks = 0; bad = 0; ops = 0
 while time.time() - t0 < budget:
-    c = im.Context(0)
-    c.set_option("sift_batch", int(rng.integers(1, 9))); c.set_option("sift_slots", int(rng.integers(1, 5)))
-    if rng.random() < 0.3: c.set_option("sift_cascade", 1)
-    cur = {}                                  # id -> pool index
+    ctxs = []
+    for _ in range(2):                        # two contexts alive at once, operations alternate between them at random
+        c = im.Context(0)
+        c.set_option("sift_batch", int(rng.integers(1, 9))); c.set_option("sift_slots", int(rng.integers(1, 5)))
+        if rng.random() < 0.3: c.set_option("sift_cascade", 1)
+        ctxs.append((c, {}))
     keep = []                                 # device tensors must stay alive until their batch ran
-    for step in range(int(rng.integers(5, 60))):
+    for step in range(int(rng.integers(5, 80))):
         ops += 1
+        c, cur = ctxs[int(rng.integers(0, 2))]   # cur: id -> pool index
         op = rng.random()
         if op < 0.55:
             k = int(rng.integers(0, 12)); pi = int(rng.integers(0, len(pool))); img = pool[pi][0]
@@ -55,11 +58,13 @@ while time.time() - t0 < budget:
             if not ok: bad += 1; print("MISMATCH pair", i, j, cur[i], cur[j], int(r["n_selected"]), ns, int(r["n_in"]), nin, flush=True)
         else:
             c.synchronize()
-    for k, pi in cur.items():
-        kp, desc = c.GetFeatures(k)
-        _, okp, od = pool[pi]
-        ok = len(kp) == len(okp) and np.array_equal(kp.view(np.uint8), okp.view(np.uint8)) and np.array_equal(desc.astype(np.uint8), od)
-        checks += 1
-        if not ok: bad += 1; print("MISMATCH final", k, pi, len(kp), len(okp), flush=True)
-    c.close(); keep.clear()
+    for c, cur in ctxs:
+        for k, pi in cur.items():
+            kp, desc = c.GetFeatures(k)
+            _, okp, od = pool[pi]
+            ok = len(kp) == len(okp) and np.array_equal(kp.view(np.uint8), okp.view(np.uint8)) and np.array_equal(desc.astype(np.uint8), od)
+            checks += 1
+            if not ok: bad += 1; print("MISMATCH final", k, pi, len(kp), len(okp), flush=True)
+    for c, _ in ctxs: c.close()
+    keep.clear()
 print("api soak: %d operations, %d checks, %d mismatches, %.0f s" % (ops, checks, bad, time.time() - t0))
