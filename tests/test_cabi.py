@@ -150,3 +150,37 @@ def test_adaptor_header_compiles_as_cxx(tmp_path):
                    ' return mi355::Ransac2D(a, b, c, d, H, 2.5f) ? 1 : 0; }\n')
     r = subprocess.run(["g++", "-std=c++11", "-fsyntax-only", "-I", os.path.join(ROOT, "include"), str(src)], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
+
+
+def test_global_affine_align_recovers_synthetic_surveys(im):
+    """exact correspondences of randomly placed images (affine maps into a common plane, random overlap graph, some images
+    isolated and therefore fixed): the solver must return the ground-truth maps relative to image 0"""
+    rng = np.random.default_rng(12)
+    for trial in range(6):
+        N = int(rng.integers(3, 60))
+        A = []
+        for k in range(N):
+            th = rng.normal(0, 0.05); s = 1 + rng.normal(0, 0.03)
+            A.append(np.array([[s * np.cos(th), -s * np.sin(th) + rng.normal(0, 0.01), rng.uniform(-3000, 3000)],
+                               [s * np.sin(th), s * np.cos(th), rng.uniform(-3000, 3000)], [0, 0, 1]]))
+        A[0] = np.eye(3)
+        edges = [(i, i + 1) for i in range(N - 2)] + [tuple(sorted(rng.choice(N - 1, 2, replace=False))) for _ in range(N)]     # image N-1 stays isolated
+        rows = []
+        for (i, j) in edges:
+            if i == j:
+                continue
+            m = int(rng.integers(4, 40))
+            world = np.stack([rng.uniform(-4000, 4000, m), rng.uniform(-4000, 4000, m), np.ones(m)])
+            pa = np.linalg.inv(A[i]) @ world; pb = np.linalg.inv(A[j]) @ world
+            for q in range(m):
+                rows.append((pa[0, q], pa[1, q], q, i, 0, pb[0, q], pb[1, q], q, j, 0))
+        mp = np.array(rows, dtype=im.MATCHPAIR)
+        label = im.select_connected(mp, N)
+        assert label[N - 1] == 0 and label[:N - 1].all()
+        keep = (label[mp["ai"]] > 0) & (label[mp["bi"]] > 0)
+        fixed = [1 if (k == 0 or label[k] == 0) else 0 for k in range(N)]
+        T = im.global_affine_align(mp[keep], N, fixed=fixed)
+        got = T["m"][:, :6].astype(np.float64).reshape(N, 2, 3)
+        for k in range(N - 1):
+            assert np.abs(got[k] - A[k][:2]).max() < 2e-2 * max(1.0, np.abs(A[k][:2]).max() / 1000), (trial, k, got[k], A[k][:2])
+        assert np.array_equal(T["m"][N - 1], np.eye(3, dtype=np.float32).reshape(9))      # a fixed (isolated) image stays at identity
