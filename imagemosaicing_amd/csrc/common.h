@@ -96,7 +96,7 @@ struct mi355_ctx {
     std::vector<char> host_frame_used;
     size_t host_frame_next = 0;
     hipEvent_t pend_event = nullptr;                   // handed to the frame being parked by mi_sift_extract_dev
-    int cascade = 0;                                   // 1: octaves >= 2000 px wide run all Gaussian levels in one pass (pyr_cascade; same bits, VALU- instead of HBM-bound, measured 3 % slower end to end); option "sift_cascade"
+    int cascade = 0;                                   // octaves >= 2000 px wide: 1 = all Gaussian levels in one pass (pyr_cascade), 2 = in two passes of 2-3 levels (pyr_chain); same bits, not faster end to end (see sift.hip); option "sift_cascade"
     int blur_stream = 1;                               // big pyramid levels through blur_stream (0: tile kernel only); option "blur_stream"
     int sift_nslots = 3;                               // batch work areas in flight, each on its own stream (option "sift_slots", env MI355_SIFT_SLOTS)
     int xstream_min_w = 3000, xstream_min_frames = 4;  // extrema_stream for octaves at least this wide (and 3/4 as high) in batches of at least so many frames

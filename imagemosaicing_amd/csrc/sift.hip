@@ -627,7 +627,7 @@ template <int R> __device__ __forceinline__ void load_taps(const float* k, v2f (
 // a level row into its LDS row buffer: own columns (in-image lanes only) plus the reflect-101 copies beyond the image's left /
 // right edge (lanes owning columns 1..16 / w-17..w-2).  The predicates are loop invariant lane masks; a wave without such a
 // lane skips the block with one branch.  (A variant that hid the index arithmetic behind a wave-uniform flag ran 1.5x slower.)
-__device__ __forceinline__ void put_row(float* buf, int c, int x, int w, v4f o) {
+__device__ __forceinline__ void put_row(float* buf, int c, int x, int w, v4f o, int bufw = BUFW) {
     if (x >= 0 && x < w) {
         *reinterpret_cast<v4f*>(buf + BUFO + c) = o;
         if (x <= 16 || x + 3 >= w - 17) {
@@ -636,7 +636,7 @@ __device__ __forceinline__ void put_row(float* buf, int c, int x, int w, v4f o) 
             for (int q = 0; q < 4; q++) {
                 const int xx = x + q;
                 if (xx >= 1 && xx <= 16 && BUFO + c + q - 2 * xx >= 0) buf[BUFO + c + q - 2 * xx] = v[q];
-                if (xx >= w - 17 && xx <= w - 2) { const int idx = BUFO + c + q + 2 * (w - 1 - xx); if (idx < BUFW) buf[idx] = v[q]; }
+                if (xx >= w - 17 && xx <= w - 2) { const int idx = BUFO + c + q + 2 * (w - 1 - xx); if (idx < bufw) buf[idx] = v[q]; }
             }
         }
     }
@@ -818,6 +818,197 @@ __global__ __launch_bounds__(OCT0 ? 768 : 640) __attribute__((amdgpu_waves_per_e
                 const v4f o = col_pass<R, U, j>(r01, r23, q01, q23, kp);
                 put_row(rowbuf(1, t), c, x, a.w, o);
                 store(a.lv[1], ys + t - G1, o);
+                row_pass<R>(w, kp, r01, r23);
+                step_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                return true;
+            };
+            static_rows<0, U>(step);
+            ring_shift<R, U>(q01, q23);
+        }
+    }
+}
+
+// ---- pyr_chain: two or three consecutive Gaussian levels in one pass (option "sift_cascade" = 2) -----------------------------------
+// The same machinery as pyr_cascade cut into pieces that stay HBM-bound: octave 0 = {gray -> L0 L1 L2} + {L2 -> L3 L4 L5}, the other
+// octaves {L0 -> L1 L2} + {L2 -> L3 L4 L5}: 7 level transfers per octave instead of 11 (10), one wave per level and pipeline, FOUR
+// pipelines per workgroup (1024 columns, 16-32 of them halo on each side), waves w, w + 4, w + 8 (one of each level) share a SIMD.
+// The first wave of a pipeline forms the doubled gray rows (GRAY) or moves the rows of level LF - 1 from HBM into LDS, 8 rows ahead.
+// MEASURED (8 frames 4000x3000 per launch): the 7 launches of octaves 0-2 + 17 band launches take 4.9 ms against 5.45 ms for the
+// per-level route (K2 = {8, 10, 13} on octave 0: 2.1 ms = 2.9 TB/s, K1 = {gray, 5, 5, 6}: 1.25 ms), i.e. not at the HBM bound: a
+// row step costs ~170 instructions per wave (110 of them packed FMAs for R = 13) x 3 waves per SIMD x 4 cycles = the measured
+// 1.1 us.  A plain-v_fma_f32 row pass (no operand shuffles, twice the FMA instructions) was slower (5.8 ms).  End to end (three
+// batches in flight) 985 against 987-1000 pairs/s: the per-level kernels overlap across batches, these fill whole CUs.
+namespace chain {
+constexpr int NP = 4, WGW = 256 * NP, BUFO = casc::BUFO, BUFW = WGW + 2 * BUFO;
+struct Args {
+    const uint8_t* gray; int gp; size_t gstride; int gh;   // GRAY: padded gray frames
+    const float* src;                                        // else: level LF - 1 (read)
+    float* lv[3];                                            // the levels written
+    float* ds;                                               // 2x decimated copy of the level flagged by ds_of (the next octave's level 0), or null
+    int ds_of;                                               // index (0..2) of that level in lv
+    size_t fstride; int nb;
+    int w, h;
+    int vb;                                                  // rows [vb, h - vb) are produced (the rest: blur_stream in band mode)
+    int nstrip, nseg, lseg;
+    float k[3][2 * MAX_R + 2];
+};
+}  // namespace chain
+
+template <bool GRAY, int RA_, int RB_, int RC_>               // radii of the levels (RC_ = 0: two levels)
+__global__ __launch_bounds__(RC_ ? 768 : 512) __attribute__((amdgpu_waves_per_eu(RC_ ? 3 : 2, RC_ ? 3 : 2))) void pyr_chain(chain::Args a) {
+    using namespace casc;
+    constexpr int NLEV = RC_ ? 3 : 2;
+    constexpr int RR[3] = {RA_, RB_, RC_ ? RC_ : 1};
+    constexpr int SUMR = RA_ + RB_ + RC_;
+    constexpr int HC = (SUMR + 3) & ~3, SV = chain::WGW - 2 * HC, CBW = chain::BUFW;
+    constexpr int G0 = RR[0] + 1, G1 = G0 + 2 + RR[1], G2 = G1 + 2 + RR[2], GL = RC_ ? G2 : G1;
+    __shared__ __attribute__((aligned(16))) float s_row[NLEV][2][CBW];           // [0] = the input rows, [1 + i] = level i of the chain (the last level is not staged)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int level = __builtin_amdgcn_readfirstlane(wave / chain::NP), pipe = __builtin_amdgcn_readfirstlane(wave % chain::NP);
+    int unit = xcd_remap(blockIdx.x, gridDim.x);
+    {
+        const int per = a.nstrip * a.nseg, fr = unit / per;
+        if (fr >= (a.nb > 1 ? a.nb : 1)) return;
+        unit -= fr * per;
+        if (GRAY) a.gray += (size_t)fr * a.gstride; else a.src += (size_t)fr * a.fstride;
+#pragma unroll
+        for (int i = 0; i < 3; i++) if (a.lv[i]) a.lv[i] += (size_t)fr * a.fstride;
+        if (a.ds) a.ds += (size_t)fr * a.fstride;
+    }
+    const int seg = unit / a.nstrip, strip = unit - seg * a.nstrip;
+    const int X0 = strip * SV - HC;
+    const int c = 256 * pipe + 4 * lane, x = X0 + c;
+    const int s0 = a.vb + seg * a.lseg;
+    const int s1 = (s0 + a.lseg < a.h - a.vb) ? s0 + a.lseg : a.h - a.vb;
+    const int ys = s0 - SUMR;                                                 // first input row (vb >= SUMR)
+    const int T = (s1 - s0) + SUMR + GL + 1;
+    const int TP = ((T + 7) / 8) * 8;
+    const bool colst = c >= HC && c < HC + SV && x < a.w;
+    const int hm1 = a.h - 1;
+    float* const b0 = &s_row[0][0][0];
+    auto rowbuf = [&](int i, int par) { return b0 + (i * 2 + (par & 1)) * CBW; };       // i = 0: input, 1 + k: level k of the chain
+    auto store = [&](int li, int r, v4f o) {
+        if (colst && r >= s0 && r < s1) {
+            *reinterpret_cast<v4f*>(a.lv[li] + (size_t)r * a.w + x) = o;
+            if (a.ds && li == a.ds_of && !(r & 1) && (r >> 1) < (a.h >> 1)) {
+                const v2f d2 = {o.x, o.z};
+                *reinterpret_cast<v2f*>(a.ds + (size_t)(r >> 1) * (a.w >> 1) + (x >> 1)) = d2;
+            }
+        }
+    };
+    constexpr int U = 8;
+    // levels 1, 2 of the chain: read the row the producer completed one step earlier
+    auto run_level = [&](auto lic, auto gc) {
+        constexpr int LI = decltype(lic)::value, G = decltype(gc)::value, R = RR[LI];
+        v2f kp[R + 1];
+        load_taps<R>(a.k[LI], kp);
+        v2f q01[2 * R + U], q23[2 * R + U];
+        ring_zero<R, U>(q01, q23);
+        v2f r01 = {0.0f, 0.0f}, r23 = r01;
+        step_barrier();
+        for (int tb = 0; tb < TP; tb += U) {
+            auto step = [&](auto jc) -> bool {
+                constexpr int j = decltype(jc)::value;
+                const int t = tb + j;
+                Win<R> w;
+                win_load<R>(rowbuf(LI, t - 1), c, w);
+                const v4f o = col_pass<R, U, j>(r01, r23, q01, q23, kp);
+                if constexpr (LI < NLEV - 1) put_row(rowbuf(LI + 1, t), c, x, a.w, o, CBW);
+                store(LI, ys + t - G, o);
+                row_pass<R>(w, kp, r01, r23);
+                step_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                return true;
+            };
+            static_rows<0, U>(step);
+            ring_shift<R, U>(q01, q23);
+        }
+    };
+    using std::integral_constant;
+    if (level == 1) { run_level(integral_constant<int, 1>{}, integral_constant<int, G1>{}); return; }
+    if constexpr (NLEV == 3) { if (level == 2) { run_level(integral_constant<int, 2>{}, integral_constant<int, G2>{}); return; } }
+    // level 0 of the chain + the input rows
+    constexpr int R = RR[0];
+    v2f kp[R + 1];
+    load_taps<R>(a.k[0], kp);
+    v2f q01[2 * R + U], q23[2 * R + U];
+    ring_zero<R, U>(q01, q23);
+    v2f r01 = {0.0f, 0.0f}, r23 = r01;
+    if constexpr (GRAY) {
+        constexpr int D = 4;
+        int gx = GPAD + (x >> 1);
+        gx = gx < 0 ? 0 : (gx > a.gp - 4 ? a.gp - 4 : gx);
+        const int gh1 = a.gh - 1;
+        struct Raw { unsigned a, b; };
+        auto load_raw = [&](int t, Raw& r) {
+            int gy = ys + t;
+            gy = gy < 0 ? 0 : (gy > hm1 ? hm1 : gy);
+            const int ya = gy >> 1;
+            int yb = (gy & 1) ? ya + 1 : ya;
+            yb = yb > gh1 ? gh1 : yb;
+            __builtin_memcpy(&r.a, a.gray + (size_t)ya * a.gp + gx, 4);
+            __builtin_memcpy(&r.b, a.gray + (size_t)yb * a.gp + gx, 4);
+        };
+        auto form = [&](const Raw& r) {
+            auto hrow = [&](unsigned q, v4f& o) {
+                const float p0 = (float)(q & 255u), p1 = (float)((q >> 8) & 255u), p2 = (float)((q >> 16) & 255u);
+                o.x = p0; o.y = (p0 + p1) * 0.5f; o.z = p1; o.w = (p1 + p2) * 0.5f;
+            };
+            v4f ha, hb;
+            hrow(r.a, ha); hrow(r.b, hb);
+            return (v4f){(ha.x + hb.x) * 0.5f, (ha.y + hb.y) * 0.5f, (ha.z + hb.z) * 0.5f, (ha.w + hb.w) * 0.5f};
+        };
+        Raw pf[D];
+#pragma unroll
+        for (int d = 0; d < D; d++) load_raw(d, pf[d]);
+        *reinterpret_cast<v4f*>(rowbuf(0, 0) + BUFO + c) = form(pf[0]);
+        load_raw(D, pf[0]);
+        step_barrier();
+        for (int tb = 0; tb < TP; tb += U) {
+            auto step = [&](auto jc) -> bool {
+                constexpr int j = decltype(jc)::value;
+                const int t = tb + j;
+                Win<R> w;
+                win_load<R>(rowbuf(0, t), c, w);
+                *reinterpret_cast<v4f*>(rowbuf(0, t + 1) + BUFO + c) = form(pf[(j + 1) % D]);
+                load_raw(t + 1 + D, pf[(j + 1) % D]);
+                const v4f o = col_pass<R, U, j>(r01, r23, q01, q23, kp);
+                put_row(rowbuf(1, t), c, x, a.w, o, CBW);
+                store(0, ys + t - G0, o);
+                row_pass<R>(w, kp, r01, r23);
+                step_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                return true;
+            };
+            static_rows<0, U>(step);
+            ring_shift<R, U>(q01, q23);
+        }
+    } else {
+        constexpr int D = 8;                                                  // rows of the source level in flight per pipeline (registers)
+        const int xl = x < 0 ? 0 : (x > a.w - 4 ? a.w - 4 : x);
+        auto load_raw = [&](int t, v4f& r) {
+            int gy = ys + t;
+            gy = gy < 0 ? 0 : (gy > hm1 ? hm1 : gy);
+            r = *reinterpret_cast<const v4f*>(a.src + (size_t)gy * a.w + xl);
+        };
+        v4f pf[D];
+#pragma unroll
+        for (int d = 0; d < D; d++) load_raw(d, pf[d]);
+        put_row(rowbuf(0, 0), c, x, a.w, pf[0], CBW);
+        load_raw(D, pf[0]);
+        step_barrier();
+        for (int tb = 0; tb < TP; tb += U) {
+            auto step = [&](auto jc) -> bool {
+                constexpr int j = decltype(jc)::value;
+                const int t = tb + j;
+                Win<R> w;
+                win_load<R>(rowbuf(0, t), c, w);
+                put_row(rowbuf(0, t + 1), c, x, a.w, pf[(j + 1) % D], CBW);
+                load_raw(t + 1 + D, pf[(j + 1) % D]);
+                const v4f o = col_pass<R, U, j>(r01, r23, q01, q23, kp);
+                put_row(rowbuf(1, t), c, x, a.w, o, CBW);
+                store(0, ys + t - G0, o);
                 row_pass<R>(w, kp, r01, r23);
                 step_barrier();
                 __builtin_amdgcn_sched_barrier(0);
@@ -1846,17 +2037,29 @@ inline void launch_base_stream(hipStream_t st, const BlurArgs& a, const uint8_t*
     hipLaunchKernelGGL((blur_stream<5, 8, true>), dim3((nstrip * nseg * nb + 3) / 4), dim3(256), 0, st, a2, L, nstrip, nseg);
 }
 // the 48 rows at the top and at the bottom of a level the cascade left out (blur_stream in band mode; R as in launch_blur)
-inline bool launch_band(hipStream_t st, int R, BlurArgs a, bool base) {
-    a.band = casc::VB;
+inline bool launch_band(hipStream_t st, int R, BlurArgs a, bool base, int band = casc::VB) {
+    a.band = band;
     const int nb = a.nb > 1 ? a.nb : 1, nstrip = (a.w + 255) / 256, nseg = 2;
     const dim3 grid((nstrip * nseg * nb + 3) / 4), block(256);
-    if (base) { hipLaunchKernelGGL((blur_stream<5, 8, true>), grid, block, 0, st, a, casc::VB, nstrip, nseg); return true; }
+    if (base) { hipLaunchKernelGGL((blur_stream<5, 8, true>), grid, block, 0, st, a, band, nstrip, nseg); return true; }
     switch (R) {
-#define CASE(RR, DD) case RR: hipLaunchKernelGGL((blur_stream<RR, DD, false>), grid, block, 0, st, a, casc::VB, nstrip, nseg); return true;
+#define CASE(RR, DD) case RR: hipLaunchKernelGGL((blur_stream<RR, DD, false>), grid, block, 0, st, a, band, nstrip, nseg); return true;
         CASE(5, 6) CASE(6, 8) CASE(8, 6) CASE(10, 6) CASE(13, 4)
 #undef CASE
         default: return false;
     }
+}
+// segments of a chain pass: whole rounds of one workgroup per CU against the row overlap per segment
+inline void chain_grid(int w, int h, int nb, int num_cu, int sv, int vb, int overlap, int& nstrip, int& nseg, int& lseg) {
+    nstrip = (w + sv - 1) / sv;
+    const int rows = h - 2 * vb, per = nstrip * nb;
+    long best = -1; nseg = 1;
+    for (int n = 1; n <= rows / 128 || n == 1; n++) {
+        const long rounds = ((long)per * n + num_cu - 1) / num_cu;
+        const long cost = rounds * ((rows + n - 1) / n + overlap);
+        if (best < 0 || cost < best) { best = cost; nseg = n; }
+    }
+    lseg = (rows + nseg - 1) / nseg;
 }
 // segments of the cascade: whole rounds of one workgroup per CU, the row overlap (~100 steps per segment) against the tail
 inline void cascade_grid(int w, int h, int nb, int num_cu, int& nstrip, int& nseg, int& lseg) {
@@ -2208,7 +2411,47 @@ static int sift_run_batch(mi355_ctx* ctx, SiftWork* s) {
         const bool radii_ok = s->radius0 == 5 && s->radius[1] == 5 && s->radius[2] == 6 && s->radius[3] == 8 && s->radius[4] == 10 && s->radius[5] == 13;
         const bool cascade = ctx->cascade && ctx->blur_stream && radii_ok && (oc.w & 15) == 0 && oc.w >= 2000 && oc.h >= 1500 &&
                              ((oc.w & 255) == 0 || (oc.w & 255) > MAX_R) && (o > 0 || base_streams(blur_args(oc), s->radius0, ctx->blur_stream));
-        if (cascade) {
+        if (cascade && ctx->cascade == 2) {
+            // chains: {gray | L0} -> first two / three levels, then L2 -> L3 L4 L5; the top / bottom rows by blur_stream in band mode afterwards
+            const bool seeds_next = o + 1 < s->n_oct && (oc.w & 1) == 0 && s->P.oc[o + 1].w == (oc.w >> 1) && s->P.oc[o + 1].h == (oc.h >> 1);
+            const int vb1 = o == 0 ? 16 : 12, vb2 = o == 0 ? 48 : 44;
+            chain::Args c1; memset(&c1, 0, sizeof(c1));
+            c1.w = oc.w; c1.h = oc.h; c1.fstride = bs.pyr; c1.nb = n; c1.vb = vb1; c1.ds = nullptr; c1.ds_of = -1;
+            ProfScope ps(ctx, "cascade", level_bytes * 6.0, st);
+            if (o == 0) {
+                for (int k = 0; k < n; k++) launch_gray_pad(st, pend[k].d_bgr, pend[k].ws, w, h, s->gray.as<uint8_t>() + (size_t)k * s->gray_stride, s->gray_pitch);
+                c1.gray = s->gray.as<uint8_t>(); c1.gp = s->gray_pitch; c1.gstride = s->gray_stride; c1.gh = h;
+                c1.lv[0] = oc.lv[0]; c1.lv[1] = oc.lv[1]; c1.lv[2] = oc.lv[2];
+                memcpy(c1.k[0], s->kern0, sizeof(float) * 11); memcpy(c1.k[1], s->kern[1], sizeof(float) * 11); memcpy(c1.k[2], s->kern[2], sizeof(float) * 13);
+                chain_grid(oc.w, oc.h, n, ctx->num_cu, chain::WGW - 2 * 16, vb1, 16 + 25, c1.nstrip, c1.nseg, c1.lseg);
+                hipLaunchKernelGGL((pyr_chain<true, 5, 5, 6>), dim3(c1.nstrip * c1.nseg * n), dim3(768), 0, st, c1);
+            } else {
+                if (!ds_fused) {
+                    const OctaveDev& pv = s->P.oc[o - 1];
+                    hipLaunchKernelGGL(downsample2, dim3((oc.w + 63) / 64, (oc.h + 3) / 4, n), dim3(256), 0, st, pv.lv[N_LAYERS], pv.w, oc.lv[0], oc.w, oc.h, bs.pyr);
+                }
+                c1.src = oc.lv[0]; c1.lv[0] = oc.lv[1]; c1.lv[1] = oc.lv[2];
+                memcpy(c1.k[0], s->kern[1], sizeof(float) * 11); memcpy(c1.k[1], s->kern[2], sizeof(float) * 13);
+                chain_grid(oc.w, oc.h, n, ctx->num_cu, chain::WGW - 2 * 12, vb1, 11 + 15, c1.nstrip, c1.nseg, c1.lseg);
+                hipLaunchKernelGGL((pyr_chain<false, 5, 6, 0>), dim3(c1.nstrip * c1.nseg * n), dim3(512), 0, st, c1);
+            }
+            chain::Args c2; memset(&c2, 0, sizeof(c2));
+            c2.w = oc.w; c2.h = oc.h; c2.fstride = bs.pyr; c2.nb = n; c2.vb = vb2;
+            c2.src = oc.lv[2]; c2.lv[0] = oc.lv[3]; c2.lv[1] = oc.lv[4]; c2.lv[2] = oc.lv[5];
+            c2.ds = seeds_next ? s->P.oc[o + 1].lv[0] : nullptr; c2.ds_of = 0;
+            memcpy(c2.k[0], s->kern[3], sizeof(float) * 17); memcpy(c2.k[1], s->kern[4], sizeof(float) * 21); memcpy(c2.k[2], s->kern[5], sizeof(float) * 27);
+            chain_grid(oc.w, oc.h, n, ctx->num_cu, chain::WGW - 2 * 32, vb2, 31 + 37, c2.nstrip, c2.nseg, c2.lseg);
+            hipLaunchKernelGGL((pyr_chain<false, 8, 10, 13>), dim3(c2.nstrip * c2.nseg * n), dim3(768), 0, st, c2);
+            for (int i = (o == 0 ? 0 : 1); i < N_LEVELS; i++) {
+                BlurArgs a = blur_args(oc);
+                a.fstride = bs.pyr; a.nb = n; a.dst = oc.lv[i];
+                if (i == 0) { memcpy(a.k, s->kern0, sizeof(float) * (2 * s->radius0 + 1)); a.bgr = s->gray.as<uint8_t>(); a.bgr_ws = s->gray_pitch; a.gstride = s->gray_stride; }
+                else { memcpy(a.k, s->kern[i], sizeof(float) * (2 * s->radius[i] + 1)); a.src = oc.lv[i - 1]; }
+                a.ds = (i == N_LAYERS) ? c2.ds : nullptr;
+                if (!launch_band(st, i == 0 ? s->radius0 : s->radius[i], a, i == 0, i <= 2 ? vb1 : vb2)) { ctx->set_error("sift: unsupported kernel radius"); return MI355_ERR_FAILED; }
+            }
+            ds_fused = seeds_next;
+        } else if (cascade) {
             casc::Args ca; memset(&ca, 0, sizeof(ca));
             ca.w = oc.w; ca.h = oc.h; ca.fstride = bs.pyr; ca.nb = n;
             for (int i = 0; i < N_LEVELS; i++) ca.lv[i] = oc.lv[i];

@@ -9,7 +9,7 @@ base = torch.randint(0, 255, (H // 8, W // 8, 3), generator=g, dtype=torch.uint8
 img = torch.nn.functional.interpolate(base.permute(2, 0, 1)[None].float(), size=(H, W), mode="bicubic")[0].permute(1, 2, 0).clamp(0, 255).to(torch.uint8).contiguous().cuda()
 frames = [img.roll(17 * k, 1).contiguous() for k in range(N)]
 CLS = ["cascade", "gauss_band", "gauss", "gauss_stream", "downsample", "extrema"]
-for casc in ((1, 0, 1) if not os.environ.get('VARIANT') else ((0, 0) if os.environ.get('CASC') == '0' else (1, 1))):
+for casc in ((2, 0, 2, 1) if not os.environ.get('CASC') else (int(os.environ['CASC']),) * 2):
     ctx = im.Context(0)
     ctx.set_option("sift_cascade", casc); ctx.set_option("sift_slots", 1)
     for rep in range(3):

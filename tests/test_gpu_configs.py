@@ -192,7 +192,7 @@ def test_cascade_route_equals_per_level_route():
     from tests.synth_survey import render_frames
     for (w, h, F) in ((4000, 3000, 9), (2512, 1900, 3), (1920, 1080, 2)):
         feats = []
-        for casc in (0, 1):
+        for casc in (0, 1, 2):
             ctx = im.Context(0)
             ctx.set_option("sift_cascade", casc)
             frames, A, gains, ws = render_frames(ctx, torch, F, w, h, per_row=F)
@@ -201,8 +201,9 @@ def test_cascade_route_equals_per_level_route():
             ctx.synchronize()
             feats.append([ctx.GetFeatures(k) for k in range(F)])
             ctx.close()
-        for k in range(F):
-            (k0, d0), (k1, d1) = feats[0][k], feats[1][k]
-            assert len(k0) == len(k1) == 2000, (w, h, k, len(k0), len(k1))
-            assert np.array_equal(k0.view(np.uint8), k1.view(np.uint8)), f"{w}x{h} frame {k}: keypoints differ between the routes"
-            assert np.array_equal(d0, d1), f"{w}x{h} frame {k}: descriptors differ between the routes"
+        for route in (1, 2):
+            for k in range(F):
+                (k0, d0), (k1, d1) = feats[0][k], feats[route][k]
+                assert len(k0) == len(k1) == 2000, (w, h, k, len(k0), len(k1))
+                assert np.array_equal(k0.view(np.uint8), k1.view(np.uint8)), f"{w}x{h} frame {k}: keypoints differ between the routes 0 and {route}"
+                assert np.array_equal(d0, d1), f"{w}x{h} frame {k}: descriptors differ between the routes 0 and {route}"
