@@ -56,7 +56,7 @@ extern "C" int mi355_create(mi355_ctx** out, const mi355_params* params, int dev
     if (e != hipSuccess) { g_create_error = hipGetErrorString(e); delete c; return MI355_ERR_DEVICE; }
     c->stream = c->own_stream;
     if (const char* e = getenv("MI355_BLUR_STREAM")) c->blur_stream = atoi(e) ? 1 : 0;
-    if (const char* e = getenv("MI355_CASCADE")) { const int v = atoi(e); c->cascade = v < 0 ? 0 : (v > 2 ? 2 : v); }
+    if (const char* e = getenv("MI355_CASCADE")) { const int v = atoi(e); c->cascade = v < 0 ? 0 : (v > 3 ? 3 : v); }
     if (getenv("MI355_SERIAL_HEAVY")) c->serial_heavy = 1;
     if (const char* e = getenv("MI355_SIFT_SLOTS")) { const int v = atoi(e); c->sift_nslots = v < 1 ? 1 : (v > 4 ? 4 : v); }
     if (const char* e = getenv("MI355_XSTREAM_MIN_W")) { const int v = atoi(e); c->xstream_min_w = v < 256 ? 256 : v; }
@@ -346,7 +346,7 @@ extern "C" int mi355_set_option(mi355_ctx* ctx, const char* name, int value) {
         return MI355_OK;
     }
     if (std::string(name) == "blur_stream") { ctx->blur_stream = value ? 1 : 0; return MI355_OK; }
-    if (std::string(name) == "sift_cascade") { ctx->cascade = value < 0 ? 0 : (value > 2 ? 2 : value); return MI355_OK; }
+    if (std::string(name) == "sift_cascade") { ctx->cascade = value < 0 ? 0 : (value > 3 ? 3 : value); return MI355_OK; }
     if (std::string(name) == "serial_heavy") {
         int rc = mi_resolve_features(ctx);
         if (rc != MI355_OK) return rc;

@@ -2411,7 +2411,9 @@ static int sift_run_batch(mi355_ctx* ctx, SiftWork* s) {
         const bool radii_ok = s->radius0 == 5 && s->radius[1] == 5 && s->radius[2] == 6 && s->radius[3] == 8 && s->radius[4] == 10 && s->radius[5] == 13;
         const bool cascade = ctx->cascade && ctx->blur_stream && radii_ok && (oc.w & 15) == 0 && oc.w >= 2000 && oc.h >= 1500 &&
                              ((oc.w & 255) == 0 || (oc.w & 255) > MAX_R) && (o > 0 || base_streams(blur_args(oc), s->radius0, ctx->blur_stream));
-        if (cascade && ctx->cascade == 2) {
+        int first_level = 1;                               // the per-level loop below starts here (cascade value 3: the first chain did levels 0..2)
+        if (cascade && ctx->cascade >= 2) {
+            const bool first_only = ctx->cascade == 3;
             // chains: {gray | L0} -> first two / three levels, then L2 -> L3 L4 L5; the top / bottom rows by blur_stream in band mode afterwards
             const bool seeds_next = o + 1 < s->n_oct && (oc.w & 1) == 0 && s->P.oc[o + 1].w == (oc.w >> 1) && s->P.oc[o + 1].h == (oc.h >> 1);
             const int vb1 = o == 0 ? 16 : 12, vb2 = o == 0 ? 48 : 44;
@@ -2436,13 +2438,15 @@ static int sift_run_batch(mi355_ctx* ctx, SiftWork* s) {
                 hipLaunchKernelGGL((pyr_chain<false, 5, 6, 0>), dim3(c1.nstrip * c1.nseg * n), dim3(512), 0, st, c1);
             }
             chain::Args c2; memset(&c2, 0, sizeof(c2));
+            if (!first_only) {
             c2.w = oc.w; c2.h = oc.h; c2.fstride = bs.pyr; c2.nb = n; c2.vb = vb2;
             c2.src = oc.lv[2]; c2.lv[0] = oc.lv[3]; c2.lv[1] = oc.lv[4]; c2.lv[2] = oc.lv[5];
             c2.ds = seeds_next ? s->P.oc[o + 1].lv[0] : nullptr; c2.ds_of = 0;
             memcpy(c2.k[0], s->kern[3], sizeof(float) * 17); memcpy(c2.k[1], s->kern[4], sizeof(float) * 21); memcpy(c2.k[2], s->kern[5], sizeof(float) * 27);
             chain_grid(oc.w, oc.h, n, ctx->num_cu, chain::WGW - 2 * 32, vb2, 31 + 37, c2.nstrip, c2.nseg, c2.lseg);
             hipLaunchKernelGGL((pyr_chain<false, 8, 10, 13>), dim3(c2.nstrip * c2.nseg * n), dim3(768), 0, st, c2);
-            for (int i = (o == 0 ? 0 : 1); i < N_LEVELS; i++) {
+            }
+            for (int i = (o == 0 ? 0 : 1); i < (first_only ? 3 : N_LEVELS); i++) {
                 BlurArgs a = blur_args(oc);
                 a.fstride = bs.pyr; a.nb = n; a.dst = oc.lv[i];
                 if (i == 0) { memcpy(a.k, s->kern0, sizeof(float) * (2 * s->radius0 + 1)); a.bgr = s->gray.as<uint8_t>(); a.bgr_ws = s->gray_pitch; a.gstride = s->gray_stride; }
@@ -2450,7 +2454,7 @@ static int sift_run_batch(mi355_ctx* ctx, SiftWork* s) {
                 a.ds = (i == N_LAYERS) ? c2.ds : nullptr;
                 if (!launch_band(st, i == 0 ? s->radius0 : s->radius[i], a, i == 0, i <= 2 ? vb1 : vb2)) { ctx->set_error("sift: unsupported kernel radius"); return MI355_ERR_FAILED; }
             }
-            ds_fused = seeds_next;
+            if (first_only) first_level = 3; else ds_fused = seeds_next;
         } else if (cascade) {
             casc::Args ca; memset(&ca, 0, sizeof(ca));
             ca.w = oc.w; ca.h = oc.h; ca.fstride = bs.pyr; ca.nb = n;
@@ -2504,8 +2508,9 @@ static int sift_run_batch(mi355_ctx* ctx, SiftWork* s) {
             ProfScope ps(ctx, "downsample", level_bytes * 2.0, st);
             hipLaunchKernelGGL(downsample2, dim3((oc.w + 63) / 64, (oc.h + 3) / 4, n), dim3(256), 0, st, pv.lv[N_LAYERS], pv.w, oc.lv[0], oc.w, oc.h, bs.pyr);
         }
-        if (!cascade) ds_fused = false;
-        for (int i = 1; i < N_LEVELS && !cascade; i++) {
+        const bool per_level = !cascade || first_level > 1;
+        if (per_level) ds_fused = false;
+        for (int i = first_level; i < N_LEVELS && per_level; i++) {
             a.bgr = nullptr; a.src = oc.lv[i - 1]; a.dst = oc.lv[i];
             memcpy(a.k, s->kern[i], sizeof(float) * (2 * s->radius[i] + 1));
             const bool streams = blur_streams(a, false, s->radius[i], ctx->blur_stream);

@@ -32,7 +32,7 @@ while time.time() - t0 < budget:
     c = im.Context(0)
     c.set_option("sift_batch", int(rng.integers(1, 9))); c.set_option("sift_slots", int(rng.integers(1, 4)))
     if rng.random() < 0.5: c.set_option("xstream_min_w", 1000); c.set_option("xstream_min_frames", 1)
-    casc = int(rng.integers(0, 3)); c.set_option("sift_cascade", casc)
+    casc = int(rng.integers(0, 4)); c.set_option("sift_cascade", casc)
     dev = [torch.from_numpy(np.ascontiguousarray(i)).cuda() for i in imgs]
     torch.cuda.synchronize()
     for k, d in enumerate(dev): c.SiftExtractDev(k, d.data_ptr(), w, h, w * 3)

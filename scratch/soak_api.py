@@ -22,7 +22,7 @@ while time.time() - t0 < budget:
     for _ in range(2):                        # two contexts alive at once, operations alternate between them at random
         c = im.Context(0)
         c.set_option("sift_batch", int(rng.integers(1, 9))); c.set_option("sift_slots", int(rng.integers(1, 5)))
-        if rng.random() < 0.4: c.set_option("sift_cascade", int(rng.integers(1, 3)))
+        c.set_option("sift_cascade", int(rng.integers(0, 4)))
         ctxs.append((c, {}))
     keep = []                                 # device tensors must stay alive until their batch ran
     for step in range(int(rng.integers(5, 80))):

@@ -192,7 +192,7 @@ def test_cascade_route_equals_per_level_route():
     from tests.synth_survey import render_frames
     for (w, h, F) in ((4000, 3000, 9), (2512, 1900, 3), (1920, 1080, 2)):
         feats = []
-        for casc in (0, 1, 2):
+        for casc in (0, 1, 2, 3):
             ctx = im.Context(0)
             ctx.set_option("sift_cascade", casc)
             frames, A, gains, ws = render_frames(ctx, torch, F, w, h, per_row=F)
@@ -201,7 +201,7 @@ def test_cascade_route_equals_per_level_route():
             ctx.synchronize()
             feats.append([ctx.GetFeatures(k) for k in range(F)])
             ctx.close()
-        for route in (1, 2):
+        for route in (1, 2, 3):
             for k in range(F):
                 (k0, d0), (k1, d1) = feats[0][k], feats[route][k]
                 assert len(k0) == len(k1) == 2000, (w, h, k, len(k0), len(k1))
