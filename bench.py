@@ -306,7 +306,7 @@ def main():
     # chip-filling kernels overlap, and the bracketed durations are exclusive -- checked right here: the durations of ALL chip-filling
     # classes of that pass sum to less than its wall time.  The in-situ figure of the timed region stays as a side field.
     excl, iso = None, None
-    HEAVY = ("gauss_stream", "gauss", "downsample", "extrema")
+    HEAVY = ("gauss_stream", "gauss", "cascade", "gauss_band", "downsample", "extrema")     # every class of the pyramid + extrema phase
     if not os.environ.get("MI355_BENCH_NO_STANDALONE"):
         ctx.synchronize()
         ctx.set_option("serial_heavy", 1)
@@ -383,7 +383,7 @@ def main():
                        "sharding": ("single GPU" if world == 1 else
                                     ("frames k mod G, pairs i mod G, canvas stripes; %s all-gather of feature records and accepted pair records" % transport) if strong else
                                     ("independent strip per rank; %s all-gather of accepted pair records" % transport))},
-            "roofline": {"bound": "hbm", "kernel": "blur_stream<R,D,false> (streaming separable Gaussian: the 20 launches per batch of 8 frames that produce levels 1..5 of pyramid octaves 0..3)",
+            "roofline": {"bound": "hbm", "kernel": "blur_stream<R,D,false> (streaming separable Gaussian, one pyramid level of all frames of a batch per launch: levels 3..5 of the octaves whose first three levels come from pyr_chain, levels 1..5 of the smaller streamed octave)",
                          "achieved": excl["achieved"] if excl else in_situ, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": (excl["achieved"] if excl else in_situ) / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "measurement": ("HIP events around every launch of the kernel in an untimed extra pass over the same frames with option serial_heavy (chip-filling kernels of different "

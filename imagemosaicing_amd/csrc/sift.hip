@@ -26,6 +26,7 @@
 //   describe              one workgroup per keypoint: trilinear contributions quantised to 2^-20 and added with
 //                         64-bit LDS atomics (order-free by definition), normalise / clip / renormalise -> u8
 #include "common.h"
+#include <memory>
 #include "detmath.h"
 #include <cmath>
 #include <type_traits>
@@ -391,7 +392,7 @@ __global__ __launch_bounds__(256) void gray_pad_kernel(const uint8_t* bgr, int w
 // aligned at pixel (0, 0), edge replicated: load_base above), formed on the fly -- every sum is exact in binary32, so the
 // order of evaluation is free.
 template <int R, int D, bool UPS>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void blur_stream(BlurArgs a, int L, int nstrip, int nseg) {
+__device__ __forceinline__ void blur_stream_body(BlurArgs a, int L, int nstrip, int nseg) {
     constexpr int N = 2 * R + 1;
     constexpr int NP0 = ((N + D - 1) / D) * D;
     constexpr int NP = (NP0 & 1) ? NP0 + D : NP0;   // even (two LDS rows alternate) and a multiple of D
@@ -533,6 +534,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         };
         if (!static_rows<0, NP>(step)) return;
     }
+}
+
+template <int R, int D, bool UPS>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void blur_stream(BlurArgs a, int L, int nstrip, int nseg) {
+    blur_stream_body<R, D, UPS>(a, L, nstrip, nseg);
+}
+// the same code under its own name for the band launches (the first / last rows of levels a chain pass produced): traces and
+// counter collections of blur_stream then hold the full-level launches only
+template <int R, int D, bool UPS>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void blur_band(BlurArgs a, int L, int nstrip, int nseg) {
+    blur_stream_body<R, D, UPS>(a, L, nstrip, nseg);
 }
 
 // ---- pyr_cascade: ALL Gaussian levels of one octave in one pass (option "sift_cascade", default off) ----------------------
@@ -2041,9 +2053,9 @@ inline bool launch_band(hipStream_t st, int R, BlurArgs a, bool base, int band =
     a.band = band;
     const int nb = a.nb > 1 ? a.nb : 1, nstrip = (a.w + 255) / 256, nseg = 2;
     const dim3 grid((nstrip * nseg * nb + 3) / 4), block(256);
-    if (base) { hipLaunchKernelGGL((blur_stream<5, 8, true>), grid, block, 0, st, a, band, nstrip, nseg); return true; }
+    if (base) { hipLaunchKernelGGL((blur_band<5, 8, true>), grid, block, 0, st, a, band, nstrip, nseg); return true; }
     switch (R) {
-#define CASE(RR, DD) case RR: hipLaunchKernelGGL((blur_stream<RR, DD, false>), grid, block, 0, st, a, band, nstrip, nseg); return true;
+#define CASE(RR, DD) case RR: hipLaunchKernelGGL((blur_band<RR, DD, false>), grid, block, 0, st, a, band, nstrip, nseg); return true;
         CASE(5, 6) CASE(6, 8) CASE(8, 6) CASE(10, 6) CASE(13, 4)
 #undef CASE
         default: return false;
@@ -2419,7 +2431,8 @@ static int sift_run_batch(mi355_ctx* ctx, SiftWork* s) {
             const int vb1 = o == 0 ? 16 : 12, vb2 = o == 0 ? 48 : 44;
             chain::Args c1; memset(&c1, 0, sizeof(c1));
             c1.w = oc.w; c1.h = oc.h; c1.fstride = bs.pyr; c1.nb = n; c1.vb = vb1; c1.ds = nullptr; c1.ds_of = -1;
-            ProfScope ps(ctx, "cascade", level_bytes * 6.0, st);
+            // profile classes: "cascade" = the chain passes (bytes: the levels they write + the level they read), "gauss_band" = the band launches
+            std::unique_ptr<ProfScope> ps(new ProfScope(ctx, "cascade", level_bytes * (first_only ? 3.0 : 7.0), st));
             if (o == 0) {
                 for (int k = 0; k < n; k++) launch_gray_pad(st, pend[k].d_bgr, pend[k].ws, w, h, s->gray.as<uint8_t>() + (size_t)k * s->gray_stride, s->gray_pitch);
                 c1.gray = s->gray.as<uint8_t>(); c1.gp = s->gray_pitch; c1.gstride = s->gray_stride; c1.gh = h;
@@ -2446,6 +2459,8 @@ static int sift_run_batch(mi355_ctx* ctx, SiftWork* s) {
             chain_grid(oc.w, oc.h, n, ctx->num_cu, chain::WGW - 2 * 32, vb2, 31 + 37, c2.nstrip, c2.nseg, c2.lseg);
             hipLaunchKernelGGL((pyr_chain<false, 8, 10, 13>), dim3(c2.nstrip * c2.nseg * n), dim3(768), 0, st, c2);
             }
+            ps.reset();
+            ProfScope pb(ctx, "gauss_band", 0.0, st);
             for (int i = (o == 0 ? 0 : 1); i < (first_only ? 3 : N_LEVELS); i++) {
                 BlurArgs a = blur_args(oc);
                 a.fstride = bs.pyr; a.nb = n; a.dst = oc.lv[i];
