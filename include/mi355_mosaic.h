@@ -100,11 +100,11 @@ int  mi355_synchronize(mi355_ctx* ctx);
  * "xstream_min_w" (3000) / "xstream_min_frames" (4): octaves at least that wide, in batches of at least that many frames,
  * take the streamed extrema kernel instead of the tiled one (same candidates either way); "serial_heavy" = 1 (measurement only,
  * default 0): the pyramid + extrema phase of a batch waits for the previous batch's, so that the chip-filling kernels of different
- * batches never overlap and their event-bracketed durations are exclusive (the whole job loses ~10 %); "sift_cascade" = 1 / 2
- * (default 0): octaves at least 2000 x 1500 compute their Gaussian levels in one pass (1: all six) or two passes (2: three levels
- * each), the levels handed from wave to wave through LDS and written to HBM once -- the same bits; VALU-issue-bound instead of
- * HBM-bound, stand-alone 3 % slower (1) / 5 % faster (2) than the per-level kernels and no faster end to end on MI355X; kept for
- * chips with a different balance. */
+ * batches never overlap and their event-bracketed durations are exclusive (the whole job loses ~10 %); "sift_cascade" (0..3,
+ * default 3): how octaves of at least 2000 x 1500 compute their Gaussian levels -- 0: every level with its own launch; 3: the
+ * first three levels in one pass, handed from wave to wave through LDS and written to HBM once, the other levels on their own
+ * (+4 % end to end); 2: the other three in a second such pass; 1: all six in one pass.  The same bits in every mode (2 and 1 are
+ * VALU-issue-bound and no faster end to end on MI355X). */
 int  mi355_set_option(mi355_ctx* ctx, const char* name, int value);
 void mi355_free(void* p);                               /* frees host buffers returned by this library */
 
