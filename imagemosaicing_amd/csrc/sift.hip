@@ -868,7 +868,7 @@ struct Args {
 }  // namespace chain
 
 template <bool GRAY, int RA_, int RB_, int RC_>               // radii of the levels (RC_ = 0: two levels)
-__global__ __launch_bounds__(RC_ ? 768 : 512) __attribute__((amdgpu_waves_per_eu(RC_ ? 3 : 2, RC_ ? 3 : 2))) void pyr_chain(chain::Args a) {
+__global__ __launch_bounds__(RC_ ? 768 : 512) __attribute__((amdgpu_waves_per_eu(RC_ ? 3 : 4, RC_ ? 3 : 4))) void pyr_chain(chain::Args a) {
     using namespace casc;
     constexpr int NLEV = RC_ ? 3 : 2;
     constexpr int RR[3] = {RA_, RB_, RC_ ? RC_ : 1};
@@ -2447,7 +2447,7 @@ static int sift_run_batch(mi355_ctx* ctx, SiftWork* s) {
                 }
                 c1.src = oc.lv[0]; c1.lv[0] = oc.lv[1]; c1.lv[1] = oc.lv[2];
                 memcpy(c1.k[0], s->kern[1], sizeof(float) * 11); memcpy(c1.k[1], s->kern[2], sizeof(float) * 13);
-                chain_grid(oc.w, oc.h, n, ctx->num_cu, chain::WGW - 2 * 12, vb1, 11 + 15, c1.nstrip, c1.nseg, c1.lseg);
+                chain_grid(oc.w, oc.h, n, 2 * ctx->num_cu, chain::WGW - 2 * 12, vb1, 11 + 15, c1.nstrip, c1.nseg, c1.lseg);      // two workgroups of 8 waves per CU
                 hipLaunchKernelGGL((pyr_chain<false, 5, 6, 0>), dim3(c1.nstrip * c1.nseg * n), dim3(512), 0, st, c1);
             }
             chain::Args c2; memset(&c2, 0, sizeof(c2));
