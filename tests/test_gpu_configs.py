@@ -1,7 +1,8 @@
 """GPU: the BASELINE.json configurations at their OWN sizes against the oracle (VERDICT r01 "next" #1).
 
-  C3  500 x 4000x3000 on the default route (sift_batch 8 / sift_slots 3, streamed base level, blur_stream, extrema_stream
-      with the default thresholds, 8000-wide strips with a 64-column last strip): a 12-frame sample -- one full batch of 8
+  C3  500 x 4000x3000 on the default route (sift_batch 8 / sift_slots 3, the first three levels of the big octaves from pyr_chain
+      with its band launches, levels 3..5 from blur_stream, extrema_stream with the default thresholds, 8000-wide levels whose
+      last strip holds 64 columns): a 12-frame sample -- one full batch of 8
       and one ragged batch of 4 -- every keypoint field, every descriptor byte, and the adjacent pairs' n_selected / n_in /
       inlier ids / H bits.
   C2  the whole 50-frame 1920x1080 strip: features, the 49 adjacent pairs, and the MosaicImagesRefined canvas bytes.
