@@ -898,6 +898,12 @@ __global__ __launch_bounds__(RC_ ? 768 : 512) __attribute__((amdgpu_waves_per_eu
     const int TP = ((T + 7) / 8) * 8;
     const bool colst = c >= HC && c < HC + SV && x < a.w;
     const int hm1 = a.h - 1;
+    // a pipeline whose 256 columns lie beyond the image and its mirrored margin (the last strip of a level that does not fill
+    // it: 64 of 1024 columns at 8000 wide) only keeps the barrier count: nobody reads what it would write
+    if (X0 + 256 * pipe - BUFO >= a.w + BUFO) {
+        for (int t = 0; t <= TP; t++) step_barrier();
+        return;
+    }
     float* const b0 = &s_row[0][0][0];
     auto rowbuf = [&](int i, int par) { return b0 + (i * 2 + (par & 1)) * CBW; };       // i = 0: input, 1 + k: level k of the chain
     auto store = [&](int li, int r, v4f o) {
