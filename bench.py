@@ -11,9 +11,16 @@ One "step" = one pass of the hot path over the whole batch of synthetic frames r
   [N>1: RCCL all-gather of the fixed-size pair records]  ->  global affine alignment of the records on the host
   (the reference's driver step between match and warp)  ->  inverse-warp of every frame once into the canvas.
 Workload at N=1: BASELINE configs[2] "500-frame 4000x3000 UAV set, all adjacent pairs" (C3), the configuration
-the metric is quoted on (4000x3000 frames).  With N ranks every rank owns one such strip of the survey
-(weak scaling): frames and pairs shard with no data-path collective; the only exchange is the all-gather of
-per-pair homographies + inliers that feed global alignment (north_star).  Prints ONE JSON line on rank 0.
+the metric is quoted on (4000x3000 frames).  With N ranks (default --scaling strong) the SAME survey is sharded the way the
+reference's threads shard it (MosaicWithoutPos.cpp:4861 / :5066): rank r extracts the frames k mod N == r, matches the
+pairs whose i it owns and renders canvas stripe r.  Two RCCL all-gathers inside the C ABI cross ranks: the feature records
+after detect+describe and the accepted pair records (H + inliers) that feed global alignment.  value = the survey's
+pairs / max-over-ranks time.  --scaling weak keeps an independent strip per rank (the result all-gather only).
+
+`python bench.py --gpus N` with N > 1 and no launcher environment (WORLD_SIZE unset) re-executes itself under
+`python -m torch.distributed.run --nproc-per-node N` on 127.0.0.1, so the plain command form measures N ranks too.
+The line carries `transport` and `rccl_ranks` (ncclCommCount of the C ABI's communicator); with the default transport a
+rank that cannot create that communicator fails the run instead of falling back.  Prints ONE JSON line on rank 0.
 """
 import argparse
 import ctypes
@@ -134,12 +141,26 @@ def cpu_baseline(frames_host, A, w, h, ws):
     return out, done
 
 
+def relaunch_under_torchrun(args):
+    """`python bench.py --gpus N` without a launcher: become `python -m torch.distributed.run ... bench.py <same args>`"""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush(); sys.stderr.flush()
+    os.execv(sys.executable, cmd)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        relaunch_under_torchrun(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != max(args.gpus, 1) and world > 1:
+    if world != max(args.gpus, 1):
         raise SystemExit("WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus))
     if args.all_ranks_on_device0:
         local_rank = 0
@@ -169,9 +190,8 @@ def main():
     strong = args.scaling == "strong"
     exchange = world > 1 or bool(os.environ.get("MI355_BENCH_FORCE_EXCHANGE"))      # the env switch runs the collectives on one rank (dry run of the calls)
     transport = args.transport or ("rccl" if (args.backend == "nccl" or world == 1) else "torch")
-    ex = md.Exchange(ctx, transport) if exchange else None
-    if ex is not None:
-        transport = ex.transport                      # "torch" if the C ABI's communicator could not be set up on every rank
+    ex = md.Exchange(ctx, transport, strict=True) if exchange else None      # no silent fallback: rccl means the C ABI's communicator or an error
+    rccl_ranks = ex.rccl_ranks if ex is not None else None
     # strong: ONE survey, the same F frames on every rank (replicated in HBM: a rank renders every frame that crosses its canvas
     # stripe, SURVEY 8e "replicas of frames + stripes"), detect+describe and pairs sharded; weak: an independent strip per rank
     lay_rank = 0 if strong else rank
@@ -374,6 +394,7 @@ def main():
             "ms_per_step": dt / max(args.steps, 1) * 1e3, "higher_is_better": True, "scaling": "strong" if strong else "weak",
             "vs_baseline": None, "dtype": "f32 (pyramid/RANSAC/warp coordinates), bf16 MFMA exact-integer (descriptor distances), u8 (pixels)",
             "data": "synthetic",
+            "transport": transport if exchange else None, "rccl_ranks": rccl_ranks,
             "config": {"workload": "%s: %s, pair window %d (%d pairs), SIFT(2000,3,0.01,20) + exact BF match + 3x3 grid select + Ransac2D + MosaicImagesRefined warp"
                                    % ("C3" if args.window == 2 else (("C5" if F >= 2000 else "C4") if args.window == 182 else "window-%d" % args.window),
                                       ("ONE %d-frame %dx%d UAV survey" % (F, w, h)) if strong else ("%d-frame %dx%d UAV strip per GPU" % (F, w, h)),

@@ -317,6 +317,12 @@ class Context:
     def CommDestroy(self):
         self._chk(self.L.mi355_comm_destroy(self._h))
 
+    def CommInfo(self):
+        """(rank, n_ranks) as the RCCL communicator itself reports them (ncclCommUserRank / ncclCommCount)"""
+        r, n = C.c_int(0), C.c_int(0)
+        self._chk(self.L.mi355_comm_info(self._h, C.byref(r), C.byref(n)))
+        return r.value, n.value
+
     def AllGatherFeatures(self, img_ids, n_max_per_rank):
         ids = np.ascontiguousarray(img_ids, np.int32)
         self._chk(self.L.mi355_allgather_features(self._h, _p(ids), len(ids), int(n_max_per_rank)))
@@ -407,6 +413,11 @@ def comm_unique_id():
     if rc != 0:
         raise Mi355Error(rc, "comm_unique_id: librccl not usable")
     return bytes(buf)
+
+
+def comm_available():
+    """True when the library can bind librccl in this process (touches no communicator)"""
+    return load_library().mi355_comm_available() == 0
 
 
 def mosaic_layout(w, h, h9s):

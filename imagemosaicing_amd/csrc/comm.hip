@@ -28,6 +28,8 @@ struct RcclApi {
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
+    ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
     std::string err;
 };
@@ -46,7 +48,9 @@ RcclApi* rccl_api() {
         api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(dlsym(api.so, "ncclCommDestroy"));
         api.AllGather = reinterpret_cast<decltype(api.AllGather)>(dlsym(api.so, "ncclAllGather"));
         api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(dlsym(api.so, "ncclGetErrorString"));
-        if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.AllGather || !api.GetErrorString) api.err = "librccl lacks a required symbol";
+        api.CommCount = reinterpret_cast<decltype(api.CommCount)>(dlsym(api.so, "ncclCommCount"));
+        api.CommUserRank = reinterpret_cast<decltype(api.CommUserRank)>(dlsym(api.so, "ncclCommUserRank"));
+        if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.AllGather || !api.GetErrorString || !api.CommCount || !api.CommUserRank) api.err = "librccl lacks a required symbol";
     });
     return &api;
 }
@@ -234,6 +238,21 @@ extern "C" int mi355_comm_unique_id(uint8_t id128[128]) {
     return MI355_OK;
 }
 
+extern "C" int mi355_comm_available(void) {
+    return rccl_api()->err.empty() ? MI355_OK : MI355_ERR_DEVICE;
+}
+
+extern "C" int mi355_comm_info(mi355_ctx* ctx, int* rank, int* n_ranks) {
+    LOCKED_PROLOGUE
+    if (!rank || !n_ranks) return MI355_ERR_ARG;
+    *rank = 0; *n_ranks = 0;
+    if (!ctx->comm) { ctx->set_error("comm_info: no communicator (mi355_comm_init)"); return MI355_ERR_ARG; }
+    RcclApi* api = rccl_api();
+    MI_NCCL(api->CommUserRank(ctx->comm->comm, rank));
+    MI_NCCL(api->CommCount(ctx->comm->comm, n_ranks));
+    return MI355_OK;
+}
+
 extern "C" int mi355_comm_init(mi355_ctx* ctx, const uint8_t id128[128], int rank, int world) {
     LOCKED_PROLOGUE
     if (!id128 || world < 1 || rank < 0 || rank >= world) return MI355_ERR_ARG;
@@ -269,10 +288,9 @@ extern "C" int mi355_comm_destroy(mi355_ctx* ctx) {
 extern "C" int mi355_allgather_features(mi355_ctx* ctx, const int32_t* img_ids, int n_local, int n_max_per_rank) {
     LOCKED_PROLOGUE
     if (!ctx->comm) { ctx->set_error("allgather_features: no communicator (mi355_comm_init)"); return MI355_ERR_ARG; }
-    if (n_local < 0 || n_max_per_rank < n_local || n_max_per_rank < 1 || (n_local > 0 && !img_ids)) return MI355_ERR_ARG;
+    if (n_max_per_rank < 1) return MI355_ERR_ARG;        // the same value on every rank: a bad one fails everywhere alike
     RcclApi* api = rccl_api();
     const int world = ctx->comm->world, rank = ctx->comm->rank;
-    { int rc = mi_resolve_features(ctx); if (rc != MI355_OK) return rc; }
     const size_t nm = (size_t)n_max_per_rank;
     DevBuf& dhdr = ctx->buf("ag_feat_hdr");              // [world][n_max] headers, [world][n_max] records; this rank's block is the send buffer
     DevBuf& dpay = ctx->buf("ag_feat_payload");
@@ -282,12 +300,18 @@ extern "C" int mi355_allgather_features(mi355_ctx* ctx, const int32_t* img_ids, 
     for (auto& hk : hdr) { hk.img_id = -1; hk.n_kp = 0; hk.w = 0; hk.h = 0; }
     mi355_feature_header* my_hdr = hdr.data() + nm * rank;
     uint8_t* my_pay = dpay.as<uint8_t>() + (size_t)MI355_FEATURE_RECORD_BYTES * nm * rank;
-    if (n_local > 0) {
+    // Everything that can fail on THIS rank alone happens in `local`; its outcome travels in the headers (img_id == -2), and the
+    // rank takes part in both collectives whatever it was -- a rank that returned early would leave the others in ncclAllGather.
+    auto local = [&]() -> int {
+        if (n_local < 0 || n_max_per_rank < n_local || (n_local > 0 && !img_ids)) { ctx->set_error("allgather_features: bad arguments"); return MI355_ERR_ARG; }
+        { int rc = mi_resolve_features(ctx); if (rc != MI355_OK) return rc; }
+        if (n_local == 0) return MI355_OK;
         std::vector<PackSrc> src(n_local);
         for (int k = 0; k < n_local; k++) {
             auto it = ctx->feats.find(img_ids[k]);
             if (it == ctx->feats.end()) { ctx->set_error("allgather_features: no resident features for image " + std::to_string(img_ids[k])); return MI355_ERR_ARG; }
             const Features& f = it->second;
+            if (f.n > 2048) { ctx->set_error("allgather_features: more than 2048 keypoints"); return MI355_ERR_ARG; }       // as mi355_pack_features_dev
             my_hdr[k].img_id = img_ids[k]; my_hdr[k].n_kp = f.n; my_hdr[k].w = f.w; my_hdr[k].h = f.h;
             src[k] = PackSrc{f.kp.as<uint8_t>(), f.d8.as<uint8_t>(), f.n};
         }
@@ -297,6 +321,13 @@ extern "C" int mi355_allgather_features(mi355_ctx* ctx, const int32_t* img_ids, 
         hipLaunchKernelGGL(pack_features_kernel, dim3(16, n_local), dim3(256), 0, ctx->stream, dsrc.as<PackSrc>(), my_pay);
         MI_HIP(hipGetLastError());
         MI_HIP(hipStreamSynchronize(ctx->stream));       // `src` goes out of scope
+        return MI355_OK;
+    };
+    const int rc_local = local();
+    std::string err_local;
+    if (rc_local != MI355_OK) {
+        err_local = ctx->err;
+        for (size_t k = 0; k < nm; k++) { my_hdr[k].img_id = -2; my_hdr[k].n_kp = 0; my_hdr[k].w = 0; my_hdr[k].h = 0; }
     }
     MI_HIP(hipMemcpyAsync(dhdr.as<mi355_feature_header>() + nm * rank, my_hdr, sizeof(mi355_feature_header) * nm, hipMemcpyHostToDevice, ctx->stream));
     // in-place all-gathers (send buffer = this rank's block of the receive buffer)
@@ -304,6 +335,9 @@ extern "C" int mi355_allgather_features(mi355_ctx* ctx, const int32_t* img_ids, 
     MI_NCCL(api->AllGather(my_pay, dpay.p, (size_t)MI355_FEATURE_RECORD_BYTES * nm, ncclChar, ctx->comm->comm, ctx->stream));
     MI_HIP(hipMemcpyAsync(hdr.data(), dhdr.p, sizeof(mi355_feature_header) * nm * world, hipMemcpyDeviceToHost, ctx->stream));
     MI_HIP(hipStreamSynchronize(ctx->stream));
+    if (rc_local != MI355_OK) { ctx->set_error(err_local); return rc_local; }
+    for (int r = 0; r < world; r++)
+        if (hdr[nm * r].img_id == -2) { ctx->set_error("allgather_features: rank " + std::to_string(r) + " failed before the exchange"); return MI355_ERR_FAILED; }
     return install_features(ctx, hdr.data(), dpay.p, (int)(nm * world), img_ids, n_local);      // own frames are resident already
 }
 
@@ -311,8 +345,11 @@ extern "C" int mi355_allgather_results(mi355_ctx* ctx, const mi355_pair_result* 
                                        mi355_pair_result** all, int* n_all) {
     LOCKED_PROLOGUE
     if (!ctx->comm) { ctx->set_error("allgather_results: no communicator (mi355_comm_init)"); return MI355_ERR_ARG; }
-    if (n_local < 0 || (n_local > 0 && !d_local) || !all || !n_all) return MI355_ERR_ARG;
-    *all = nullptr; *n_all = 0;
+    if (all) *all = nullptr;
+    if (n_all) *n_all = 0;
+    // bad arguments of ONE rank travel as a negative count: every rank then returns an error after the first collective
+    const bool bad_local = n_local < 0 || (n_local > 0 && !d_local) || !all || !n_all;
+    if (bad_local) n_local = 0;
     RcclApi* api = rccl_api();
     const int world = ctx->comm->world, rank = ctx->comm->rank;
     // 1. counts (after the optional compaction)
@@ -322,7 +359,10 @@ extern "C" int mi355_allgather_results(mi355_ctx* ctx, const mi355_pair_result* 
     DevBuf& dcomp = ctx->buf("ag_res_compact");
     const mi355_pair_result* d_send = d_local;
     int n_send = n_local;
-    if (accepted_only && n_local > 0) {
+    if (bad_local) {
+        n_send = -1;
+        MI_HIP(hipMemcpyAsync(d_counts + rank, &n_send, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    } else if (accepted_only && n_local > 0) {
         MI_HIP(dcomp.reserve(sizeof(mi355_pair_result) * (size_t)n_local));
         hipLaunchKernelGGL(compact_results_kernel, dim3(1), dim3(256), 0, ctx->stream, d_local, n_local, dcomp.as<mi355_pair_result>(), d_counts + rank);
         MI_HIP(hipGetLastError());
@@ -335,7 +375,8 @@ extern "C" int mi355_allgather_results(mi355_ctx* ctx, const mi355_pair_result* 
     MI_HIP(hipMemcpyAsync(counts.data(), d_counts, sizeof(int) * world, hipMemcpyDeviceToHost, ctx->stream));
     MI_HIP(hipStreamSynchronize(ctx->stream));
     int n_max = 1; size_t total = 0;
-    for (int r = 0; r < world; r++) { if (counts[r] < 0) { ctx->set_error("allgather_results: bad count"); return MI355_ERR_FAILED; } if (counts[r] > n_max) n_max = counts[r]; total += (size_t)counts[r]; }
+    if (bad_local) { ctx->set_error("allgather_results: bad arguments"); return MI355_ERR_ARG; }
+    for (int r = 0; r < world; r++) { if (counts[r] < 0) { ctx->set_error("allgather_results: rank " + std::to_string(r) + " failed before the exchange"); return MI355_ERR_FAILED; } if (counts[r] > n_max) n_max = counts[r]; total += (size_t)counts[r]; }
     n_send = counts[rank];
     // 2. payload, padded to the largest rank's count
     DevBuf& dall = ctx->buf("ag_res_all");

@@ -762,8 +762,8 @@ extern "C" int mi355_surf_extract_dev(mi355_ctx* ctx, int img_id, const uint8_t*
     return surf_extract_dev(ctx, img_id, d_bgr, w, h, width_step, hessian_threshold, max_kp, n_kp);
 }
 
-extern "C" int mi355_surf_get_features(mi355_ctx* ctx, int img_id, mi355_keypoint* kp, float* desc128, int max_kp, int* n_kp) {
-    LOCKED_PROLOGUE
+// caller holds the ctx lock
+static int surf_get_features_locked(mi355_ctx* ctx, int img_id, mi355_keypoint* kp, float* desc128, int max_kp, int* n_kp) {
     auto& feats = surf_state(ctx)->feats;
     auto it = feats.find(img_id);
     if (it == feats.end()) { ctx->set_error("surf_get_features: unknown image id"); return MI355_ERR_ARG; }
@@ -777,20 +777,25 @@ extern "C" int mi355_surf_get_features(mi355_ctx* ctx, int img_id, mi355_keypoin
     return MI355_OK;
 }
 
+extern "C" int mi355_surf_get_features(mi355_ctx* ctx, int img_id, mi355_keypoint* kp, float* desc128, int max_kp, int* n_kp) {
+    LOCKED_PROLOGUE
+    return surf_get_features_locked(ctx, img_id, kp, desc128, max_kp, n_kp);
+}
+
 extern "C" int mi355_surf_extract(mi355_ctx* ctx, int img_id, const uint8_t* bgr, int w, int h, int width_step, float hessian_threshold, int max_kp,
                                   mi355_keypoint* kp, float* desc128, int* n_kp) {
+    // extraction and the copy back happen under ONE hold of the ctx lock: another thread re-extracting or dropping the same id on
+    // the shared context cannot slip in between
+    LOCKED_PROLOGUE
     int n = 0;
-    {
-        LOCKED_PROLOGUE
-        if (!bgr || w < 16 || h < 16 || width_step < 3 * w) { ctx->set_error("surf_extract: bad image geometry"); return MI355_ERR_ARG; }
-        DevBuf& dimg = ctx->buf("surf_host_img");
-        MI_HIP(dimg.reserve((size_t)width_step * h + 16));
-        MI_HIP(hipMemcpyAsync(dimg.p, bgr, (size_t)width_step * h, hipMemcpyHostToDevice, ctx->stream));
-        int rc = surf_extract_dev(ctx, img_id, dimg.as<uint8_t>(), w, h, width_step, hessian_threshold, max_kp, &n);
-        if (rc != MI355_OK) return rc;
-    }
+    if (!bgr || w < 16 || h < 16 || width_step < 3 * w) { ctx->set_error("surf_extract: bad image geometry"); return MI355_ERR_ARG; }
+    DevBuf& dimg = ctx->buf("surf_host_img");
+    MI_HIP(dimg.reserve((size_t)width_step * h + 16));
+    MI_HIP(hipMemcpyAsync(dimg.p, bgr, (size_t)width_step * h, hipMemcpyHostToDevice, ctx->stream));
+    int rc = surf_extract_dev(ctx, img_id, dimg.as<uint8_t>(), w, h, width_step, hessian_threshold, max_kp, &n);
+    if (rc != MI355_OK) return rc;
     if (n_kp) *n_kp = n;
-    if (kp || desc128) return mi355_surf_get_features(ctx, img_id, kp, desc128, max_kp, nullptr);
+    if (kp || desc128) return surf_get_features_locked(ctx, img_id, kp, desc128, max_kp, nullptr);
     return MI355_OK;
 }
 

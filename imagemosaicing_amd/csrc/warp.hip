@@ -287,8 +287,11 @@ __global__ __launch_bounds__(256) void mosaic_tile_kernel(const FrameDev* fr, in
 #pragma unroll
             for (int b = 0; b < 9; b++)                  // at most 3 pixels; static indices keep out[] in registers
                 if (xg + b / 3 < cw) drow[b] = (uint8_t)(out[j][b >> 2] >> (8 * (b & 3)));
-            for (int b = 3 * cw; b < cws; b++) canvas[(size_t)yD * cws + b] = 0;       // row padding (cvZero'd in the reference, :2248)
         }
+        // row padding (cvZero'd in the reference, :2248): the lane that owns the row's last pixel group clears [3 cw, cws), also when the
+        // group is a full one and the caller chose a wider row than the layout's
+        if (xg + 4 >= cw)
+            for (int b = 3 * cw; b < cws; b++) canvas[(size_t)yD * cws + b] = 0;
     }
 }
 

@@ -23,7 +23,7 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-from .capi import PAIR_RESULT, FEATURE_HEADER, FEATURE_RECORD_BYTES, comm_unique_id
+from .capi import PAIR_RESULT, FEATURE_HEADER, FEATURE_RECORD_BYTES, comm_unique_id, comm_available
 
 REC = PAIR_RESULT.itemsize
 
@@ -107,41 +107,52 @@ def allgather_feature_records(hdr, payload, n_max=None):
     """torch transport of the feature exchange.  hdr: FEATURE_HEADER array [n_local]; payload: uint8 tensor
     [n_local, FEATURE_RECORD_BYTES].  Returns (headers [world][count_r], payload uint8 [world, n_max, REC], counts)."""
     h = torch.from_numpy(np.ascontiguousarray(hdr, FEATURE_HEADER).view(np.uint8).reshape(len(hdr), FEATURE_HEADER.itemsize).copy())
+    if dist.get_backend() == "nccl":
+        h = h.to(payload.device)                       # RCCL moves device tensors only (ADVICE r02)
     gh, counts = _allgather_rows(h, n_max)
     gp, counts2 = _allgather_rows(payload, n_max)
     assert counts == counts2
+    gh = gh.cpu()
     hdrs = [gh[r, :c].contiguous().numpy().reshape(-1).view(FEATURE_HEADER) for r, c in enumerate(counts)]
     return hdrs, gp, counts
 
 
 class Exchange:
-    """The two exchanges of one rank's ctx.  transport "rccl": mi355_comm_init was done (init_comm) and the library's own
-    collectives run; "torch": torch.distributed moves the same records."""
+    """The two exchanges of one rank's ctx.  transport "rccl": the library's own collectives on the ctx's communicator
+    (init_comm); "torch": torch.distributed moves the same records.
 
-    def __init__(self, ctx, transport="rccl"):
+    With "rccl" every rank first says whether it can bind librccl (mi355_comm_available touches no communicator) and the answers
+    are MIN-reduced BEFORE any rank enters ncclCommInitRank -- a rank that cannot must not leave the others blocked in there.
+    strict (the default): if any rank cannot, every rank raises; strict=False: every rank falls back to "torch" together, said
+    loudly and visible in `self.transport`."""
+
+    def __init__(self, ctx, transport="rccl", strict=True):
         assert transport in ("rccl", "torch")
         self.ctx, self.transport = ctx, transport
         self.rank = dist.get_rank() if dist.is_initialized() else 0
         self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self.rccl_ranks = None                         # what the communicator itself reports (ncclCommCount)
         self._payload = None
         if transport == "rccl":
-            # the library's own collectives; if any rank cannot set them up (librccl not reachable from the C ABI), ALL ranks
-            # move the same records through torch.distributed instead -- said loudly, and visible in `self.transport`
-            ok, err = 1, None
-            try:
-                init_comm(ctx)
-            except Exception as e:                     # noqa: BLE001
-                ok, err = 0, e
+            ok = 1 if comm_available() else 0
             if self.world > 1:
-                flag = torch.tensor([ok], dtype=torch.int32, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+                flag = torch.tensor([ok], dtype=torch.int32, device=torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else "cpu")
                 dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-                if int(flag.item()) == 0:
-                    if ok:
-                        ctx.CommDestroy()
-                    sys.stderr.write("mi355 dist: rank %d: RCCL communicator of the C ABI unavailable (%s): exchanges go through torch.distributed\n" % (self.rank, err))
-                    self.transport = "torch"
-            elif not ok:
-                raise err
+                all_ok = int(flag.item())
+            else:
+                all_ok = ok
+            if not all_ok:
+                msg = "rank %d: the C ABI cannot bind librccl on %s" % (self.rank, "this rank" if not ok else "another rank")
+                if strict:
+                    raise RuntimeError("mi355 dist: " + msg + " (transport 'rccl' requested; pass transport='torch' to move the records through torch.distributed)")
+                sys.stderr.write("mi355 dist: " + msg + ": exchanges go through torch.distributed\n")
+                self.transport = "torch"
+            else:
+                init_comm(ctx)                         # collective; raises on every rank alike if rank 0 has no id
+                r, n = ctx.CommInfo()
+                if (r, n) != (self.rank, self.world):
+                    raise RuntimeError("mi355 dist: communicator reports rank %d of %d, expected %d of %d" % (r, n, self.rank, self.world))
+                self.rccl_ranks = n
 
     def allgather_features(self, own_ids, n_max, device):
         """afterwards every frame of every rank is resident in this rank's ctx"""
@@ -155,6 +166,8 @@ class Exchange:
             self._payload = torch.empty((max(n, 1), FEATURE_RECORD_BYTES), dtype=torch.uint8, device=device)
         hdr = self.ctx.PackFeaturesDev(own_ids, self._payload.data_ptr()) if n else np.zeros(0, FEATURE_HEADER)
         hdrs, gp, counts = allgather_feature_records(hdr, self._payload[:n], n_max)
+        if gp.is_cuda:
+            torch.cuda.current_stream(gp.device).synchronize()     # the ctx stream may be another one: the records must have landed
         for r in range(self.world):
             if r == self.rank or counts[r] == 0:
                 continue

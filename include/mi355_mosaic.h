@@ -276,9 +276,16 @@ int  mi355_compact_accepted_dev(mi355_ctx* ctx, const mi355_pair_result* d_in, i
 int  mi355_comm_unique_id(uint8_t id128[128]);
 int  mi355_comm_init(mi355_ctx* ctx, const uint8_t id128[128], int rank, int world);
 int  mi355_comm_destroy(mi355_ctx* ctx);
+/* MI355_OK when librccl can be bound in this process (no communicator is touched): lets every rank agree on the transport
+ * BEFORE any of them blocks inside ncclCommInitRank. */
+int  mi355_comm_available(void);
+/* what the communicator itself reports: ncclCommUserRank / ncclCommCount (both 0 ranks -> MI355_ERR_ARG without a communicator) */
+int  mi355_comm_info(mi355_ctx* ctx, int* rank, int* n_ranks);
 /* ncclAllGather over xGMI of the feature records of this rank's frames (img_ids, n_local <= n_max_per_rank, the same
  * n_max_per_rank on every rank): afterwards the features of every rank's frames are resident on every rank
- * (replaces the d:/feature_temp hand-off between SiftExtraction_Thread and the matcher threads, :4874-4880 / :5100-5103). */
+ * (replaces the d:/feature_temp hand-off between SiftExtraction_Thread and the matcher threads, :4874-4880 / :5100-5103).
+ * A rank whose own arguments / features are bad still takes part in the collective (it sends records flagged img_id == -2),
+ * so that EVERY rank returns the error together instead of the others hanging in ncclAllGather. */
 int  mi355_allgather_features(mi355_ctx* ctx, const int32_t* img_ids, int n_local, int n_max_per_rank);
 /* ncclAllGather of the pair records (PushMatchPairs, :10137-10145): d_local = this rank's n_local device records
  * (mi355_match_pairs_dev); accepted_only != 0 sends the accepted pairs only (C4: 96 % of the window pairs do not overlap).

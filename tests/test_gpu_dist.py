@@ -104,12 +104,18 @@ def test_rccl_collectives_world1():
     ctx = im.Context(0)
     w, h, F = 640, 480, 5
     frames, A, gains, ws = render_frames(ctx, torch, F, w, h, per_row=5)
+    assert im.comm_available()
     ex = md.Exchange(ctx, "rccl")                      # mi355_comm_unique_id + mi355_comm_init(rank 0 of 1)
+    assert ex.rccl_ranks == 1 and ctx.CommInfo() == (0, 1)        # what ncclCommUserRank / ncclCommCount report
     for k in range(F):
         ctx.SiftExtractDev(k, frames[k].data_ptr(), w, h, ws)
     before = [ctx.GetFeatures(k) for k in range(F)]
     ctx.AllGatherFeatures(list(range(F)), F)           # ncclAllGather of headers + records; own frames stay as they are
     ctx.AllGatherFeatures([0, 2, 4], F)                # fewer frames than n_max: padding records are skipped
+    # a rank with a bad local argument still takes part in the collectives and then reports the error
+    with pytest.raises(im.Mi355Error):
+        ctx.AllGatherFeatures([0, 77], F)              # image 77 has no features
+    ctx.AllGatherFeatures([1, 3], F)                   # the communicator is still usable afterwards
     for k in range(F):
         kp, d = ctx.GetFeatures(k)
         assert np.array_equal(kp.view(np.uint8), before[k][0].view(np.uint8)) and np.array_equal(d, before[k][1])
