@@ -102,6 +102,7 @@ class Context:
         if rc != 0:
             raise Mi355Error(rc, (self.L.mi355_last_error(None) or b"").decode())
         self.params = params if params is not None else default_params()
+        self.device = int(device)
 
     def close(self):
         if self._h:
@@ -404,6 +405,22 @@ class Context:
         return buf, ow.value, oh.value, ows.value
 
 
+    def MosaicBlendedDev(self, d_ptrs, w, h, ws, h9s, keep=None, band=5):
+        """LaplacianPyramidBlending with the survey resident in HBM: device frames in, device canvas out (a torch uint8 tensor
+        [ch, cws]); chips, masks, distance maps and the blender's pyramids stay in the ctx's buffers."""
+        import torch
+        n = len(d_ptrs)
+        ptrs = (C.c_void_p * n)(*[int(p) for p in d_ptrs])
+        w = np.ascontiguousarray(w, np.int32); h = np.ascontiguousarray(h, np.int32); ws = np.ascontiguousarray(ws, np.int32)
+        h9s = np.ascontiguousarray(h9s, np.float32)
+        keep_a = None if keep is None else np.ascontiguousarray(keep, np.uint8)
+        cw, ch, cws = blend_layout(w, h, h9s, keep_a)
+        out = torch.empty((ch, cws), dtype=torch.uint8, device=torch.device("cuda", self.device))
+        self._chk(self.L.mi355_mosaic_blended_dev(self._h, ptrs, _p(w), _p(h), _p(ws), n, _p(h9s), _p(keep_a), int(band),
+                                                  C.c_void_p(out.data_ptr()), cw, ch, cws))
+        return out, cw, ch, cws
+
+
 # ---- host-only helpers (no ctx) ---------------------------------------------------------------------------
 def comm_unique_id():
     """128-byte RCCL id for mi355_comm_init (rank 0 creates it, every rank receives it by any transport)"""
@@ -413,6 +430,19 @@ def comm_unique_id():
     if rc != 0:
         raise Mi355Error(rc, "comm_unique_id: librccl not usable")
     return bytes(buf)
+
+
+def blend_layout(w, h, h9s, keep=None):
+    """canvas size (cw, ch, cws) of LaplacianPyramidBlending for these transforms (MosaicImage.cpp:2233-2292)"""
+    L = load_library()
+    w = np.ascontiguousarray(w, np.int32); h = np.ascontiguousarray(h, np.int32)
+    h9s = np.ascontiguousarray(h9s, np.float32)
+    keep_a = None if keep is None else np.ascontiguousarray(keep, np.uint8)
+    cw, ch, cws = C.c_int(), C.c_int(), C.c_int()
+    rc = L.mi355_blend_layout(_p(w), _p(h), len(w), _p(h9s), _p(keep_a), C.byref(cw), C.byref(ch), C.byref(cws))
+    if rc != 0:
+        raise Mi355Error(rc, "blend_layout")
+    return cw.value, ch.value, cws.value
 
 
 def comm_available():

@@ -318,6 +318,19 @@ extern "C" int mi355_mosaic_blended(mi355_ctx* ctx, const uint8_t* const* imgs, 
     return mi_mosaic_blended(ctx, imgs, w, h, ws, n, h9s, keep, band, out, out_w, out_h, out_ws);
 }
 
+extern "C" int mi355_mosaic_blended_dev(mi355_ctx* ctx, const uint8_t* const* d_imgs, const int* w, const int* h, const int* ws, int n, const float* h9s,
+                                        const uint8_t* keep, int band, uint8_t* d_canvas, int cw, int ch, int cws) {
+    LOCKED_PROLOGUE
+    return mi_mosaic_blended_dev(ctx, d_imgs, w, h, ws, n, h9s, keep, band, d_canvas, cw, ch, cws);
+}
+
+extern "C" int mi355_blend_layout(const int* w, const int* h, int n, const float* h9s, const uint8_t* keep, int* cw, int* ch, int* cws) {
+    if (!cw || !ch) return MI355_ERR_ARG;
+    const int rc = mi_blend_layout(w, h, n, h9s, keep, cw, ch);
+    if (rc == MI355_OK && cws) *cws = (*cw * 3 + 3) & ~3;
+    return rc;
+}
+
 // ---- measurement hooks --------------------------------------------------------------------------------------------
 extern "C" int mi355_profile_enable(mi355_ctx* ctx, int on) {
     LOCKED_PROLOGUE

@@ -134,8 +134,9 @@ inline dim3 grid2(int w, int h) { return dim3((unsigned)((w + 255) / 256), (unsi
 
 // chips / masks: host pointers (staged one chip at a time) when on_device == 0, device pointers otherwise
 static int blend_core(mi355_ctx* ctx, const uint8_t* const* chips, const uint8_t* const* masks, int on_device, const mi355_chip_info* info, int n,
-                      int W, int H, int band, uint8_t** out, int* ow, int* oh, int* ows_out) {
-    if (n < 0 || (n > 0 && (!chips || !masks || !info)) || W <= 0 || H <= 0 || band < 0 || !out) { ctx->set_error("multiband_blend: bad arguments"); return MI355_ERR_ARG; }
+                      int W, int H, int band, uint8_t** out, int* ow, int* oh, int* ows_out, uint8_t* d_user = nullptr, int user_ws = 0) {
+    // d_user != NULL: the finished canvas goes to the caller's device buffer (rows of user_ws bytes) and nothing is copied to the host
+    if (n < 0 || (n > 0 && (!chips || !masks || !info)) || W <= 0 || H <= 0 || band < 0 || (!out && !d_user)) { ctx->set_error("multiband_blend: bad arguments"); return MI355_ERR_ARG; }
     const hipStream_t st = ctx->stream;
     int nb = (int)std::ceil(std::log((double)(W > H ? W : H)) / std::log(2.0));
     if (nb > band) nb = band;
@@ -221,7 +222,16 @@ static int blend_core(mi355_ctx* ctx, const uint8_t* const* chips, const uint8_t
     }
     for (int l = nb - 1; l >= 0; l--)
         hipLaunchKernelGGL((pyr_up16_combine_kernel<false>), grid2(Wp >> l, Hp >> l), dim3(256), 0, st, dlap.as<short>() + loff[l + 1] * 3, Wp >> (l + 1), Hp >> (l + 1), dlap.as<short>() + loff[l] * 3);
-    const int ows = (W * 3 + 3) & ~3;
+    const int ows = d_user ? user_ws : (W * 3 + 3) & ~3;
+    if (d_user) {
+        MI_HIP(hipMemsetAsync(d_user, 0, (size_t)ows * H, st));
+        hipLaunchKernelGGL(blend_finalize_kernel, grid2(W, H), dim3(256), 0, st, dlap.as<short>(), dwgt.as<float>(), Wp, W, d_user, ows);
+        MI_HIP(hipGetLastError());
+        if (ow) *ow = W;
+        if (oh) *oh = H;
+        if (ows_out) *ows_out = ows;
+        return MI355_OK;
+    }
     DevBuf& dout = ctx->buf("blend_out");
     MI_HIP(dout.reserve((size_t)ows * H));
     MI_HIP(hipMemsetAsync(dout.p, 0, (size_t)ows * H, st));
@@ -256,6 +266,26 @@ int mi_mosaic_blended(mi355_ctx* ctx, const uint8_t* const* imgs, const int* w, 
     std::vector<const uint8_t*> dc(nv > 0 ? nv : 1), dm(nv > 0 ? nv : 1);
     for (int v = 0; v < nv; v++) { dc[v] = ctx->buf("chip_imgs").as<uint8_t>() + chip_off[v]; dm[v] = ctx->buf("chip_masks").as<uint8_t>() + mask_off[v]; }
     rc = blend_core(ctx, dc.data(), dm.data(), 1, ci, nv, cw, ch, band, out, ow, oh, ows_out);
+    free(ci);
+    return rc;
+}
+
+// The same with the survey resident in HBM: device frames in, device canvas out (C5: frames + chips + masks + distance maps + both
+// pyramid sets co-resident).  Enqueues on the ctx stream.
+int mi_mosaic_blended_dev(mi355_ctx* ctx, const uint8_t* const* d_imgs, const int* w, const int* h, const int* ws, int n, const float* h9s,
+                          const uint8_t* keep, int band, uint8_t* d_canvas, int cw, int ch, int cws) {
+    if (!d_canvas) return MI355_ERR_ARG;
+    int lw = 0, lh = 0;
+    { int rc = mi_blend_layout(w, h, n, h9s, keep, &lw, &lh); if (rc != MI355_OK) return rc; }
+    if (lw != cw || lh != ch || cws < 3 * cw || (cws & 3)) { ctx->set_error("mosaic_blended_dev: canvas geometry does not match mi355_blend_layout"); return MI355_ERR_ARG; }
+    std::vector<size_t> chip_off, mask_off;
+    int nv = 0, gw = 0, gh = 0;
+    mi355_chip_info* ci = nullptr;
+    int rc = mi_chips_and_masks_dev(ctx, d_imgs, w, h, ws, n, h9s, keep, 1, &nv, &ci, chip_off, mask_off, &gw, &gh, 1);
+    if (rc != MI355_OK) { free(ci); return rc; }
+    std::vector<const uint8_t*> dc(nv > 0 ? nv : 1), dm(nv > 0 ? nv : 1);
+    for (int v = 0; v < nv; v++) { dc[v] = ctx->buf("chip_imgs").as<uint8_t>() + chip_off[v]; dm[v] = ctx->buf("chip_masks").as<uint8_t>() + mask_off[v]; }
+    rc = blend_core(ctx, dc.data(), dm.data(), 1, ci, nv, gw, gh, band, nullptr, nullptr, nullptr, nullptr, d_canvas, cws);
     free(ci);
     return rc;
 }

@@ -134,9 +134,12 @@ int mi_mosaic_refined_dev(mi355_ctx*, const uint8_t* const* d_imgs, const int* w
 int mi_sift_flush_if_parked(mi355_ctx*, hipEvent_t ev);   // launches the batch still holding a parked frame with this event
 int mi_chips_and_masks_dev(mi355_ctx*, const uint8_t* const* imgs, const int* w, const int* h, const int* ws, int n,
                            const float* h9s, const uint8_t* keep, int find_masks, int* n_chips, mi355_chip_info** chips,
-                           std::vector<size_t>& chip_off, std::vector<size_t>& mask_off, int* canvas_w, int* canvas_h);
+                           std::vector<size_t>& chip_off, std::vector<size_t>& mask_off, int* canvas_w, int* canvas_h, int imgs_on_device = 0);
 int mi_mosaic_blended(mi355_ctx*, const uint8_t* const* imgs, const int* w, const int* h, const int* ws, int n, const float* h9s,
                       const uint8_t* keep, int band, uint8_t** out, int* ow, int* oh, int* ows);
+int mi_mosaic_blended_dev(mi355_ctx*, const uint8_t* const* d_imgs, const int* w, const int* h, const int* ws, int n, const float* h9s,
+                          const uint8_t* keep, int band, uint8_t* d_canvas, int cw, int ch, int cws);
+int mi_blend_layout(const int* w, const int* h, int n, const float* h9s, const uint8_t* keep, int* cw, int* ch);
 int mi_multiband_blend(mi355_ctx*, const uint8_t* const* chips, const uint8_t* const* masks, const mi355_chip_info* info, int n,
                        int W, int H, int band, uint8_t** out, int* ow, int* oh, int* ows);
 int mi_chips_and_masks(mi355_ctx*, const uint8_t* const* imgs, const int* w, const int* h, const int* ws, int n,

@@ -467,7 +467,7 @@ __global__ __launch_bounds__(256) void owner_kernel(const ChipDev* chips, int n,
 // stay in ctx buffers "chip_imgs" / "chip_masks" at chip_off[v] / mask_off[v]; *chips_out is malloc'd.
 int mi_chips_and_masks_dev(mi355_ctx* ctx, const uint8_t* const* imgs, const int* w, const int* h, const int* ws, int n,
                            const float* h9s, const uint8_t* keep, int find_masks, int* n_chips, mi355_chip_info** chips_out,
-                           std::vector<size_t>& chip_off, std::vector<size_t>& mask_off, int* cw_out, int* ch_out) {
+                           std::vector<size_t>& chip_off, std::vector<size_t>& mask_off, int* cw_out, int* ch_out, int imgs_on_device) {
     if (!imgs || !w || !h || !ws || !h9s || n <= 0 || !n_chips || !chips_out) return MI355_ERR_ARG;
     // ---- layout, MosaicImage.cpp:2233-2343 (host, same float ops) ----
     float maxX = 0.0f, maxY = 0.0f, minX = 0.0f, minY = 0.0f;                     // :2234 (canvas always contains the origin)
@@ -536,7 +536,7 @@ int mi_chips_and_masks_dev(mi355_ctx* ctx, const uint8_t* const* imgs, const int
         if (!imgs[k] || w[k] < 2 || h[k] < 2 || ws[k] < 3 * w[k]) { ctx->set_error("chips: bad image geometry"); return MI355_ERR_ARG; }
         src_off[v] = src_total; src_total += ((size_t)ws[k] * h[k] + 255) & ~(size_t)255;
     }
-    MI_HIP(dsrc.reserve(src_total + 16));
+    if (!imgs_on_device) MI_HIP(dsrc.reserve(src_total + 16));
     for (int v = 0; v < nv; v++) {
         const int k = kept[v];
         const mi355_chip_info& c = ci[v];
@@ -544,8 +544,8 @@ int mi_chips_and_masks_dev(mi355_ctx* ctx, const uint8_t* const* imgs, const int
         memset(&a, 0, sizeof(a));
         if (mi_inverse_matrix_host(h9s + 9 * k, 3, a.inv, 1e-12f) != 1) { ctx->set_error("chips: homography not invertible"); return MI355_ERR_SINGULAR; }  // :2348
         const size_t src_bytes = (size_t)ws[k] * h[k];
-        MI_HIP(hipMemcpyAsync(dsrc.as<uint8_t>() + src_off[v], imgs[k], src_bytes, hipMemcpyHostToDevice, ctx->stream));
-        a.src = dsrc.as<uint8_t>() + src_off[v]; a.w = w[k]; a.h = h[k]; a.ws = ws[k];
+        if (!imgs_on_device) MI_HIP(hipMemcpyAsync(dsrc.as<uint8_t>() + src_off[v], imgs[k], src_bytes, hipMemcpyHostToDevice, ctx->stream));
+        a.src = imgs_on_device ? imgs[k] : dsrc.as<uint8_t>() + src_off[v]; a.w = w[k]; a.h = h[k]; a.ws = ws[k];
         a.dst = dchips.as<uint8_t>() + chip_off[v]; a.dws = (c.w * 3 + 3) & ~3;
         a.mask = dmasks.as<uint8_t>() + mask_off[v]; a.mws = cd[v].mws;
         a.x_beg = 0; a.x_end = c.w - 1; a.y_beg = 0; a.y_end = c.h - 1;
@@ -591,6 +591,24 @@ int mi_chips_and_masks_dev(mi355_ctx* ctx, const uint8_t* const* imgs, const int
     *n_chips = nv; *chips_out = ci_hold.release();
     if (cw_out) *cw_out = newW;
     if (ch_out) *ch_out = newH;
+    return MI355_OK;
+}
+
+// canvas size of the chips' layout alone (MosaicImage.cpp:2233-2292): the same float operations as the head of mi_chips_and_masks_dev
+int mi_blend_layout(const int* w, const int* h, int n, const float* h9s, const uint8_t* keep, int* cw, int* ch) {
+    if (!w || !h || !h9s || n <= 0 || !cw || !ch) return MI355_ERR_ARG;
+    float maxX = 0.0f, maxY = 0.0f, minX = 0.0f, minY = 0.0f;
+    for (int k = 0; k < n; k++) {
+        const float* m = h9s + 9 * k;
+        if ((keep && !keep[k]) || m[8] == 0.0f) continue;
+        float bMinX = big(), bMinY = big(), bMaxX = -big(), bMaxY = -big();
+        corner_bbox(m, w[k], h[k], bMinX, bMinY, bMaxX, bMaxY);
+        if (bMaxX > maxX) maxX = bMaxX;
+        if (bMinX < minX) minX = bMinX;
+        if (bMaxY > maxY) maxY = bMaxY;
+        if (bMinY < minY) minY = bMinY;
+    }
+    *cw = (int)(maxX - minX + 1.5f); *ch = (int)(maxY - minY + 1.5f);
     return MI355_OK;
 }
 

@@ -199,6 +199,15 @@ int  mi355_multiband_blend(mi355_ctx* ctx, const uint8_t* const* chips, const ui
 int  mi355_mosaic_blended(mi355_ctx* ctx, const uint8_t* const* imgs, const int* w, const int* h, const int* ws, int n, const float* h9s,
                           const uint8_t* keep, int band, uint8_t** out, int* out_w, int* out_h, int* out_ws);
 
+/* Device form for surveys that live in HBM (C5: 2000 frames + chips + masks + distance maps + the blender's pyramids co-resident):
+ * d_imgs are DEVICE pointers (no staging copy), the finished canvas is written to the caller's DEVICE buffer d_canvas whose
+ * geometry (cw, ch, cws = rows padded to 4 bytes) must be what mi355_blend_layout returns for the same arguments.  Same bytes as
+ * mi355_mosaic_blended.  Returns when the work is enqueued on the ctx stream (mi355_synchronize). */
+int  mi355_mosaic_blended_dev(mi355_ctx* ctx, const uint8_t* const* d_imgs, const int* w, const int* h, const int* ws, int n, const float* h9s,
+                              const uint8_t* keep, int band, uint8_t* d_canvas, int cw, int ch, int cws);
+/* canvas size of LaplacianPyramidBlending for these transforms (MosaicImage.cpp:2233-2292; host geometry, no ctx) */
+int  mi355_blend_layout(const int* w, const int* h, int n, const float* h9s, const uint8_t* keep, int* cw, int* ch, int* cws);
+
 /* ---- callers / formats either side of the path ("next" rows f1, f2 of SURVEY 8f) ---------------------- */
 /* matchPairs.match: int32 n + n x 40-byte records (WriteMatchPairs / LoadMatchPairs, MosaicWithoutPos.cpp:4736-4797) */
 int  mi355_write_match_pairs(const char* path, const mi355_match_point_pairs* v, int n);

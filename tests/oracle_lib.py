@@ -186,11 +186,10 @@ class Oracle:
         nb = self.L.orc_multiband_blend(cp, mp, _p(x0), _p(y0), _p(w), _p(h), n, int(cw), int(ch), int(band), _p(out))
         return out, nb
 
-    def chips_and_masks(self, imgs, h9s, keep=None, find_masks=True):
-        n = len(imgs)
-        imgs = [np.ascontiguousarray(i) for i in imgs]
-        w = np.array([i.shape[1] for i in imgs], np.int32)
-        h = np.array([i.shape[0] for i in imgs], np.int32)
+    def chip_layout(self, w, h, h9s, keep=None):
+        """geometry of the chips alone (MosaicImage.cpp:2233-2343): (chips, cw, ch, dG)"""
+        w = np.ascontiguousarray(w, np.int32); h = np.ascontiguousarray(h, np.int32)
+        n = len(w)
         h9s = np.ascontiguousarray(h9s, np.float32)
         keep = np.ones(n, np.uint8) if keep is None else np.ascontiguousarray(keep, np.uint8)
         chips = np.zeros(n, CHIPINFO)
@@ -198,26 +197,46 @@ class Oracle:
         dG = np.zeros(2, np.float32)
         self.L.orc_chip_layout.restype = C.c_int
         nv = self.L.orc_chip_layout(_p(w), _p(h), n, _p(h9s), _p(keep), C.byref(cw), C.byref(ch), _p(dG), _p(chips))
-        chips = chips[:nv].copy()
+        return chips[:nv].copy(), cw.value, ch.value, dG
+
+    def chip_warp(self, img, h9, dG, c):
+        """one chip + its validity mask (MosaicImage.cpp:2343-2448)"""
+        img = np.ascontiguousarray(img)
+        cws = (int(c["w"]) * 3 + 3) & ~3
+        mws = (int(c["w"]) + 3) & ~3
+        chip = np.zeros((int(c["h"]), cws), np.uint8)
+        mask = np.zeros((int(c["h"]), mws), np.uint8)
+        ci = np.array([c], CHIPINFO)
+        h9 = np.ascontiguousarray(h9, np.float32)
+        rc = self.L.orc_chip_warp(_p(img), img.shape[1], img.shape[0], img.strides[0], _p(h9), _p(dG), _p(ci), _p(chip), cws, _p(mask), mws)
+        assert rc == 0
+        return chip, mask
+
+    def find_masks_by_distmap(self, masks, chips, rect_w, rect_h):
+        """FindMasksByDistMap (MosaicImage.cpp:1761-1881) in place on `masks`; ownership is decided for the pixels of the
+        rectangle [0, rect_w) x [0, rect_h) in the chips' coordinate system"""
+        nv = len(masks)
+        chips = np.ascontiguousarray(chips, CHIPINFO)
+        mp = (C.c_void_p * nv)(*[m.ctypes.data for m in masks])
+        mws = np.array([m.strides[0] for m in masks], np.int32)
+        self.L.orc_find_masks_by_distmap(mp, _p(mws), _p(chips), nv, int(rect_w), int(rect_h))
+
+    def chips_and_masks(self, imgs, h9s, keep=None, find_masks=True):
+        imgs = [np.ascontiguousarray(i) for i in imgs]
+        w = np.array([i.shape[1] for i in imgs], np.int32)
+        h = np.array([i.shape[0] for i in imgs], np.int32)
+        h9s = np.ascontiguousarray(h9s, np.float32)
+        chips, cw, ch, dG = self.chip_layout(w, h, h9s, keep)
         cimgs, masks = [], []
         for c in chips:
             k = int(c["img"])
-            cws = (int(c["w"]) * 3 + 3) & ~3
-            mws = (int(c["w"]) + 3) & ~3
-            chip = np.zeros((int(c["h"]), cws), np.uint8)
-            mask = np.zeros((int(c["h"]), mws), np.uint8)
-            ci = np.array([c], CHIPINFO)
-            rc = self.L.orc_chip_warp(_p(imgs[k]), int(w[k]), int(h[k]), imgs[k].strides[0], _p(h9s[k]), _p(dG), _p(ci),
-                                      _p(chip), cws, _p(mask), mws)
-            assert rc == 0
+            chip, mask = self.chip_warp(imgs[k], h9s[k], dG, c)
             cimgs.append(chip)
             masks.append(mask)
         valid = [m.copy() for m in masks]
-        if find_masks and nv:
-            mp = (C.c_void_p * nv)(*[m.ctypes.data for m in masks])
-            mws = np.array([m.strides[0] for m in masks], np.int32)
-            self.L.orc_find_masks_by_distmap(mp, _p(mws), _p(chips), nv, cw.value, ch.value)
-        return dict(cw=cw.value, ch=ch.value, dG=dG, chips=chips, chip_imgs=cimgs, valid=valid, masks=masks)
+        if find_masks and len(chips):
+            self.find_masks_by_distmap(masks, chips, cw, ch)
+        return dict(cw=cw, ch=ch, dG=dG, chips=chips, chip_imgs=cimgs, valid=valid, masks=masks)
 
     def sift(self, bgr, nfeatures=2000, max_kp=None):
         bgr = np.ascontiguousarray(bgr, np.uint8)

@@ -64,6 +64,52 @@ def test_blend_two_chips_seam(oracle):
     assert (np.diff(row) >= -1).all() and row[127] < row[128] + 1 and 60 < row[128] < 200
 
 
+def test_blend_window_from_a_crop_equals_the_full_blend(oracle):
+    """the property tests/test_gpu_full_size.py leans on at the C5 size: a window of the 5-band result is reproduced exactly by
+    blending only the chips that reach it, cut to the window grown by 256 px on a 32 px grid (REDUCE / EXPAND reach: a 64 px
+    margin is NOT enough, 128 is), with FindMasksByDistMap's ownership decided inside the crop only"""
+    from tests import oracle_lib as ol
+    rng = np.random.default_rng(1)
+    n, w, h, S, AL = 8, 700, 500, 128, 32
+    imgs = [texture(w, h, seed=10 + k) for k in range(n)]
+    h9 = np.zeros((n, 9), np.float32)
+    for k in range(n):
+        a = np.deg2rad(rng.uniform(-10, 10)); sc = 1 + rng.uniform(-0.05, 0.05)
+        h9[k] = np.array([[sc * np.cos(a), -sc * np.sin(a), rng.uniform(0, 1100)], [sc * np.sin(a), sc * np.cos(a), rng.uniform(0, 900)],
+                          [rng.normal(0, 1e-6), rng.normal(0, 1e-6), 1]]).reshape(9)
+    h9[0] = np.eye(3).reshape(9)
+    r = oracle.chips_and_masks(imgs, h9, find_masks=True)
+    full, nb = oracle.multiband_blend(r["chips"], r["chip_imgs"], r["masks"], r["cw"], r["ch"], band=5)
+    bw, bh = r["cw"], r["ch"]
+    chips, lw, lh, dG = oracle.chip_layout([w] * n, [h] * n, h9)
+    assert (lw, lh) == (bw, bh) and nb == 5
+
+    def window(x0, y0, M):
+        cx0, cy0 = max(0, (x0 - M) // AL * AL), max(0, (y0 - M) // AL * AL)
+        cx1, cy1 = min(bw, x0 + S + M), min(bh, y0 + S + M)
+        sub = [c for c in chips if c["x0"] < cx1 and c["x0"] + c["w"] > cx0 and c["y0"] < cy1 and c["y0"] + c["h"] > cy0]
+        cm = [oracle.chip_warp(imgs[int(c["img"])], h9[int(c["img"])], dG, c) for c in sub]
+        masks = [m for _, m in cm]
+        sh = np.array(sub, ol.CHIPINFO); sh["x0"] -= cx0; sh["y0"] -= cy0
+        oracle.find_masks_by_distmap(masks, sh, cx1 - cx0, cy1 - cy0)
+        info = np.zeros(len(sub), ol.CHIPINFO); cc_, mm_ = [], []
+        for q, (c, (chip, _), mask) in enumerate(zip(sh, cm, masks)):
+            ax0, ay0 = max(0, -int(c["x0"])), max(0, -int(c["y0"]))
+            ax1, ay1 = min(int(c["w"]), cx1 - cx0 - int(c["x0"])), min(int(c["h"]), cy1 - cy0 - int(c["y0"]))
+            cw_, ch_ = ax1 - ax0, ay1 - ay0
+            cc = np.zeros((ch_, (cw_ * 3 + 3) & ~3), np.uint8); cc[:, :cw_ * 3] = chip[ay0:ay1, 3 * ax0:3 * ax1]
+            mm = np.zeros((ch_, (cw_ + 3) & ~3), np.uint8); mm[:, :cw_] = mask[ay0:ay1, ax0:ax1]
+            info[q]["x0"], info[q]["y0"], info[q]["w"], info[q]["h"], info[q]["img"] = int(c["x0"]) + ax0, int(c["y0"]) + ay0, cw_, ch_, q
+            cc_.append(cc); mm_.append(mm)
+        ref, _ = oracle.multiband_blend(info, cc_, mm_, cx1 - cx0, cy1 - cy0, band=5)
+        a = ref[y0 - cy0:y0 - cy0 + S, 3 * (x0 - cx0):3 * (x0 - cx0 + S)]
+        return int((a != full[y0:y0 + S, 3 * x0:3 * (x0 + S)]).sum())
+
+    for (x0, y0) in ((300, 250), (700, 500), (40, 30), (bw - S - 12, bh - S - 12)):
+        assert window(x0, y0, 256) == 0
+    assert window(700, 500, 32) > 0          # the check can fail: too small a margin changes the window
+
+
 @pytest.mark.gpu
 def test_gpu_blend_vs_oracle(oracle):
     import imagemosaicing_amd as im
