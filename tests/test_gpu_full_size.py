@@ -42,6 +42,7 @@ def test_c4_full_size_one_gpu():
     assert len(pairs) == 74029                                                 # C4
     results = torch.zeros((len(pairs), im.PAIR_RESULT.itemsize), dtype=torch.uint8, device="cuda")
     seed = 17
+    torch.cuda.synchronize()                                                   # the zero fill runs on torch's stream, the library on the ctx's own
     ctx.MatchPairsDev(pairs, results.data_ptr(), 2.5, seed)
     ctx.synchronize()
     res = results.cpu().numpy().reshape(-1).view(im.PAIR_RESULT)
@@ -147,7 +148,7 @@ def test_c5_full_size_canvas_and_blend():
     assert 19000 < cw < 22000 and 19000 < ch < 22000, (cw, ch)
     whole = torch.full((ch * cws,), 7, dtype=torch.uint8, device="cuda")
     stripes = torch.full((ch * cws,), 9, dtype=torch.uint8, device="cuda")
-    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()                                                   # the fills run on torch's stream, the library on the ctx's own
     ctx.MosaicImagesRefinedDev(fptr, wv, hv, wsv, h9, whole.data_ptr(), cw, ch, cws)
     G = 8
     for r in range(G):
@@ -181,12 +182,19 @@ def test_c5_full_size_canvas_and_blend():
     del whole, whole2d
 
     # ---- LaplacianPyramidBlending, everything co-resident --------------------------------------------------------------------
-    keep = im.resample_by_overlap(wv, hv, h9, 0.7)                              # MosaicImage.cpp:2069-2201 (host; == reference in tests/test_overlap.py)
-    assert keep[0] == 1 and keep[F - 1] == 1 and 50 < int(keep.sum()) < F // 2, int(keep.sum())
+    # vecAbandonInd: the reference's ResampleByOverlap(0.7) (MosaicImage.cpp:2069-2201; host function, == the reference's own code in
+    # tests/test_overlap.py) keeps ALL 2000 images of this survey -- it only measures overlaps whose polygon has 3 or 4 corners, and
+    # rectangles that differ by a small yaw intersect in 6 to 8.  All 2000 chips with their masks and distance maps (8 B per chip
+    # pixel = 202 GB) do not fit beside the 72 GB of frames, so the caller thins the list further, which the interface allows
+    # (keep[] is an input of LaplacianPyramidBlending's warp stage): every 5th image and the last = 401 chips, ~17 deep per pixel.
+    keep = im.resample_by_overlap(wv, hv, h9, 0.7)
+    assert keep[0] == 1 and keep[F - 1] == 1
+    keep[np.arange(F) % 5 != 0] = 0
+    keep[F - 1] = 1
+    assert int(keep.sum()) == 401
     band = 5
     out, bw, bh, bws = ctx.MosaicBlendedDev(fptr, wv, hv, wsv, h9, keep=keep, band=band)     # torch uint8 [bh, bws] in HBM
     ctx.synchronize()
-    ctx.set_stream(None)
     # oracle geometry of ALL chips (transforms only), pixels of the chips that reach the window only
     w_a, h_a = np.array(wv, np.int32), np.array(hv, np.int32)
     chips, lw, lh, ldG = orc.chip_layout(w_a, h_a, h9, keep)
