@@ -1,45 +1,45 @@
-/* oracle/oracle_sift.c -- TEST INFRASTRUCTURE ONLY (see oracle.h).   PARITY UNPINNED.
+/* oracle/oracle_sift.c -- TEST INFRASTRUCTURE ONLY (see oracle.h).
  *
  * CPU restatement of the SIFT detect+describe step the reference runs through OpenCV 2.4.0:
  *     SiftFeatureDetector detector(2000, 3, 0.01, 20); detector.detect(img, kp);
  *     SiftDescriptorExtractor extractor;               extractor.compute(img, kp, desc);
  *                                                      (MosaicWithoutPos.cpp:4852-4872)
- * The arithmetic lives in OpenCV 2.4.0's nonfree module (pinned by the vendored headers
- * 3rdparty/opencv240/.../core/version.hpp:50-52), of which the reference tree holds only headers and
- * Win32 binaries: it can neither be compiled nor run here, and the reference has no test or golden
- * vector at this boundary.  This file therefore restates the PUBLISHED algorithm (D. Lowe, "Distinctive
- * image features from scale-invariant keypoints", IJCV 2004) in the structure and with the constants of
- * the cv::SIFT class the reference instantiates (class declaration: nonfree/features2d.hpp:58-100;
- * parameters nfeatures=2000, nOctaveLayers=3, contrastThreshold=0.01, edgeThreshold=20, sigma=1.6):
- *   1. gray = (1868 B + 9617 G + 4899 R + 8192) >> 14, as float              (8-bit BGR2GRAY fixed point)
- *   2. base = 2x linear doubling (grids aligned at pixel (0,0), edge replicated; the alignment is chosen by the reference's
- *      committed keypoints, see orc_sift), Gaussian blur with
- *      sqrt(sigma^2 - (2*0.5)^2)                                               (first octave = -1)
- *   3. per octave 6 Gaussian levels built incrementally, sigma_i = sqrt((s k^i)^2 - (s k^(i-1))^2),
- *      k = 2^(1/3); kernel width round(8 sigma + 1) | 1, taps (float)exp(-x^2 / 2 sigma^2) summed in double and normalised
- *      tap by tap like cv::getGaussianKernel(.., CV_32F),
- *      border reflect-101; next octave = every second pixel of level 3
- *   4. DoG extrema over 26 neighbours (>= / <=), |D| > floor(0.5*0.01/3*255) = 0, 5 px border
- *   5. sub-pixel quadratic fit (<= 5 steps), contrast |D(x^)|*3 >= 0.01 and edge tr^2/det < 21^2/20
- *   6. 36-bin orientation histogram (radius round(4.5 s), weight sigma 1.5 s), [1 4 6 4 1]/16
- *      smoothing, every peak >= 0.8 max becomes a keypoint with parabolic bin interpolation
- *   7. duplicates removed, the nfeatures strongest responses kept
- *   8. 4x4x8 descriptor (bin width 3 s, window sigma 2 bins, trilinear), unit norm, clip 0.2, renorm,
- *      x512 -> u8 (the integers OpenCV stores in its float descriptor Mat)
  *
- * DEFINED HERE (where the publication leaves freedom), so that the HIP implementation can be compared
- * bit for bit instead of "approximately":
- *   - all image arithmetic is IEEE binary32; convolutions accumulate tap by tap in ascending tap order
- *     with one fused multiply-add per tap (fmaf), row pass then column pass;
- *   - exp / atan2 / sin / cos are the fixed polynomial approximations below (OpenCV also uses
- *     approximations there: cv::exp, fastAtan2), evaluated with fmaf in a fixed order;
- *   - both histograms (36-bin orientation, 4x4x8 descriptor) are accumulated ORDER-FREE: every contribution
- *     v is quantised to q = rint(v * 2^20) and summed as a 64-bit integer; the bin value is
- *     (float)sum * 2^-20 (resolution ~1e-6 of a grey level, far below the u8 quantisation of the
- *     descriptor and the 0.8 peak ratio of the orientation histogram);
- *   - the 3x3 solve is Gaussian elimination with partial pivoting (first largest pivot);
- *   - keypoints are ordered by (response descending, octave, layer, row, column, orientation bin) and
- *     that is also the output order; duplicates = same (octave, layer, row, column, bin).
+ * PIN STATUS.  The arithmetic lives in OpenCV 2.4.0 (`nonfree` sift.cpp, `imgproc` resize / filter engine, `core` Matx), which
+ * the reference vendors as headers + Win32 binaries only (3rdparty/opencv240, Release/opencv_*240.dll): no source, nothing that
+ * compiles or runs here, and the reference has no test or golden vector at this boundary -- so this file cannot be checked bit
+ * for bit against the reference and stays "parity unpinned at the bit level".  What it restates is nevertheless not a guess
+ * from the paper: the STRUCTURE and every constant below were read off the reference's own binary
+ * (Release/opencv_nonfree240.dll, disassembled with llvm-objdump; DESIGN.md section 2 lists the addresses) and off the vendored
+ * headers, and the result is measured against the reference's one committed run (tests/test_sift_reference_run.py):
+ *   - the pyramids are 16-BIT FIXED POINT: createInitialImage calls gray.convertTo(gray_fpt, CV_16S, 48) (10016112: 48.0 pushed
+ *     with type 3), buildDoGPyramid calls cv::subtract(.., dtype = 3 = CV_16S) (10019ea6), findScaleSpaceExtrema's threshold is
+ *     floor(0.5 * contrastThreshold / nOctaveLayers * 12240) with 12240 = 255 * 48 (10019f4b-10019f5b) and adjustLocalExtrema
+ *     scales by 1/12240, 1/24480, 1/48960 (10018675-10018751): OpenCV 2.4.0 is built with `typedef short sift_wt;
+ *     SIFT_FIXPT_SCALE = 48`.  Round 1-2 of this oracle used float pyramids; that was wrong for this OpenCV version;
+ *   - createInitialImage: cvtColor(BGR2GRAY = 6) -> convertTo(16S, x48) -> resize(2x, INTER_LINEAR = 1) ->
+ *     GaussianBlur(sigma = sqrtf(max(1.6^2 - 4 * 0.5^2, 0.01)), BORDER_DEFAULT = 4) (100160f3-100162a0);
+ *     cv::resize samples at src = (dst + 0.5) * scale - 0.5 (opencv_imgproc240.dll 100ce038-100ce040);
+ *   - keypoint angle = (360 / 36) * bin (1001a6ef), no "360 - angle" anywhere; descriptor constants 3, sqrt(2) / 2, 1 / 360,
+ *     pi / 180, 0.2, 512, FLT_EPSILON (10017833-10018159); orientation constants 4.5 (radius), 1.5 (sigma), 0.8 (peak ratio),
+ *     1/16 - 4/16 - 6/16 smoothing (1001a5bc-1001a643, 100174fa-10017511);
+ *   - Matx33f::solve(DECOMP_LU) is Cramer's rule in float, the expression of core/operations.hpp:882-903 (vendored header).
+ * The separable filter follows OpenCV's filter engine for 16S -> 32F -> 16S with a float kernel (recollection of
+ * imgproc/filter.cpp of the 2.4 line, consistent with the exports of the DLL: getLinearRowFilter / getLinearColumnFilter):
+ *   row pass     RowFilter<short, float>: s = k[0] * S[0]; s += k[i] * S[i] for ascending i -- product and sum rounded SEPARATELY
+ *                (SSE2 scalar code, no fused multiply-add on that target);
+ *   column pass  SymmColumnFilter<Cast<float, short>>: s = k[r] * C; s += k[r + j] * (S[+j] + S[-j]) for j = 1..r;
+ *                result = saturate_cast<short>(s) = round half to even.
+ *
+ * STILL DEFINED HERE (third-party approximations that cannot be read off cheaply; each is an open parity risk of a few ulp):
+ *   - exp / atan2 / sin / cos are the fixed polynomial forms below (OpenCV: table-driven cv::exp, fastAtan2 whose polynomial
+ *     coefficients are the ones used here, MSVCR90 cosf / sinf), evaluated with fmaf in a fixed order;
+ *   - both histograms (36-bin orientation, 4x4x8 descriptor) are accumulated ORDER-FREE: every contribution v is quantised to
+ *     q = rint(v * 2^10) and summed as a 64-bit integer; the bin value is (float)sum * 2^-10 (gradients are in 1/48 grey
+ *     levels, so the resolution is 2e-5 grey levels; OpenCV adds floats in pixel order);
+ *   - keypoints are ordered by (response descending, octave, layer, row, column, orientation bin) and that is also the output
+ *     order (OpenCV: removeDuplicated + retainBest leave an nth_element order); duplicates = same (octave, layer, row, column,
+ *     bin); ties at the nfeatures boundary are cut (retainBest keeps them all).
  */
 #include "oracle.h"
 #include <math.h>
@@ -53,6 +53,7 @@
 #define MAX_INTERP 5
 #define ORI_BINS 36
 #define MAX_OCT 16
+#define FIXPT_SCALE 48
 
 /* ---------- fixed transcendental approximations (part of the definition) ----------------------- */
 static inline float det_exp2f(float x)
@@ -74,7 +75,7 @@ static inline float det_exp2f(float x)
 }
 static inline float det_expf(float x) { return det_exp2f(x * 1.4426950408889634f); }
 
-/* angle of (x, y) in degrees, [0, 360]; 7th order odd polynomial on the smaller/larger ratio */
+/* angle of (x, y) in degrees, [0, 360]; 7th order odd polynomial on the smaller/larger ratio (cv::fastAtan2's coefficients) */
 static inline float det_atan2deg(float y, float x)
 {
     const float p1 = 57.283627f, p3 = -18.667446f, p5 = 8.9140005f, p7 = -2.5397246f;
@@ -112,7 +113,7 @@ static inline void det_sincosdeg(float deg, float* sn, float* cs)
     else { *sn = -c; *cs = s; }
 }
 
-/* ---------- Gaussian pyramid -------------------------------------------------------------------- */
+/* ---------- Gaussian pyramid, 16-bit fixed point -------------------------------------------------- */
 static inline int reflect101(int p, int n)
 {
     if (n == 1) return 0;
@@ -120,12 +121,19 @@ static inline int reflect101(int p, int n)
     return p;
 }
 
+/* saturate_cast<short>(float): round half to even (cvRound), clamp */
+static inline int16_t sat_short(float v)
+{
+    long q = lrintf(v);
+    return (int16_t)(q < -32768 ? -32768 : (q > 32767 ? 32767 : q));
+}
+
 static int gauss_kernel(double sigma, float* k)      /* returns radius */
 {
-    int ksize = ((int)lrint(sigma * 8.0 + 1.0)) | 1;
+    int ksize = ((int)lrint(sigma * 8.0 + 1.0)) | 1;       /* cvRound(sigma * 4 * 2 + 1) | 1 for every depth but 8U */
     int r = ksize / 2;
-    /* rounding points of cv::getGaussianKernel(ksize, sigma, CV_32F) (declared core/imgproc.hpp of the vendored 2.4.0 headers): every
-       exp() is rounded to float first, the FLOATS are summed in double, each tap is (float)(tap * (1 / sum)) */
+    /* rounding points of cv::getGaussianKernel(ksize, sigma, CV_32F): every exp() is rounded to float first, the FLOATS are summed in
+       double, each tap is (float)(tap * (1 / sum)) */
     double sum = 0.0;
     double scale2x = -0.5 / (sigma * sigma);
     for (int i = 0; i < ksize; i++) { double x = (double)i - (double)(ksize - 1) * 0.5; k[i] = (float)exp(scale2x * x * x); sum += (double)k[i]; }
@@ -134,33 +142,39 @@ static int gauss_kernel(double sigma, float* k)      /* returns radius */
     return r;
 }
 
-static void gauss_blur(const float* src, float* dst, float* tmp, int w, int h, double sigma)
+/* volatile-free way to keep gcc from contracting a * b + c: the oracle is compiled with -ffp-contract=off (Makefile) */
+static void gauss_blur16(const int16_t* src, int16_t* dst, float* tmp, int w, int h, double sigma)
 {
     float k[64];
     int r = gauss_kernel(sigma, k);
-    /* row pass: tmp(y,x) = sum_i k[i] * src(y, reflect(x + i - r)), ascending i, one fmaf per tap */
+    /* row pass: tmp(y, x) = k[0] * S(x - r) + k[1] * S(x - r + 1) + ... (ascending taps, product and sum rounded separately) */
     float* ext = (float*)malloc(sizeof(float) * (size_t)(w + 2 * r));
     for (int y = 0; y < h; y++) {
-        const float* s = src + (size_t)y * w;
-        for (int x = -r; x < w + r; x++) ext[x + r] = s[reflect101(x, w)];
+        const int16_t* s = src + (size_t)y * w;
+        for (int x = -r; x < w + r; x++) ext[x + r] = (float)s[reflect101(x, w)];
         float* t = tmp + (size_t)y * w;
-        for (int x = 0; x < w; x++) t[x] = 0.0f;
-        for (int i = 0; i <= 2 * r; i++) { const float ki = k[i]; const float* e = ext + i; for (int x = 0; x < w; x++) t[x] = fmaf(ki, e[x], t[x]); }
+        { const float k0 = k[0]; for (int x = 0; x < w; x++) t[x] = k0 * ext[x]; }
+        for (int i = 1; i <= 2 * r; i++) { const float ki = k[i]; const float* e = ext + i; for (int x = 0; x < w; x++) { float p = ki * e[x]; t[x] = t[x] + p; } }
     }
     free(ext);
-    /* column pass */
+    /* column pass: centre tap first, then the symmetric pairs outwards; round half to even into 16 bits */
+    float* acc = (float*)malloc(sizeof(float) * (size_t)w);
     for (int y = 0; y < h; y++) {
-        float* d = dst + (size_t)y * w;
-        for (int x = 0; x < w; x++) d[x] = 0.0f;
-        for (int i = 0; i <= 2 * r; i++) {
-            const float ki = k[i];
-            const float* t = tmp + (size_t)reflect101(y + i - r, h) * w;
-            for (int x = 0; x < w; x++) d[x] = fmaf(ki, t[x], d[x]);
+        const float* c = tmp + (size_t)y * w;
+        { const float k0 = k[r]; for (int x = 0; x < w; x++) acc[x] = k0 * c[x]; }
+        for (int j = 1; j <= r; j++) {
+            const float kj = k[r + j];
+            const float* a = tmp + (size_t)reflect101(y + j, h) * w;
+            const float* b = tmp + (size_t)reflect101(y - j, h) * w;
+            for (int x = 0; x < w; x++) { float sm = a[x] + b[x]; float p = kj * sm; acc[x] = acc[x] + p; }
         }
+        int16_t* d = dst + (size_t)y * w;
+        for (int x = 0; x < w; x++) d[x] = sat_short(acc[x]);
     }
+    free(acc);
 }
 
-typedef struct { int w, h; float* lv[N_LEVELS]; } octave_t;
+typedef struct { int w, h; int16_t* lv[N_LEVELS]; } octave_t;
 
 typedef struct {
     uint32_t resp_bits; int o, layer, r, c, bin;
@@ -168,55 +182,48 @@ typedef struct {
     float ptx, pty;      /* octave coordinates c + xc, r + xr */
 } cand_t;
 
-static inline float dogv(const octave_t* oc, int lvl, int r, int c)      /* DoG[lvl] = G[lvl+1] - G[lvl] */
+static inline int dogv(const octave_t* oc, int lvl, int r, int c)      /* DoG[lvl] = G[lvl+1] - G[lvl], saturated 16-bit subtract */
 {
     size_t o = (size_t)r * oc->w + c;
-    return oc->lv[lvl + 1][o] - oc->lv[lvl][o];
+    int v = (int)oc->lv[lvl + 1][o] - (int)oc->lv[lvl][o];
+    return v < -32768 ? -32768 : (v > 32767 ? 32767 : v);
 }
 
-/* x = A^-1 b, Gaussian elimination with partial pivoting; singular -> x = 0 */
-static void solve3(float A[3][3], float b[3], float x[3])
+/* Matx33f::solve(b, DECOMP_LU) = Matx_FastSolveOp<float, 3, 1>: Cramer's rule, core/operations.hpp:742-750, 882-903.  0 if det == 0 */
+static int solve3_cramer(const float a[3][3], const float b[3], float x[3])
 {
-    int p[3] = {0, 1, 2};
-    for (int k = 0; k < 3; k++) {
-        int m = k; float best = fabsf(A[p[k]][k]);
-        for (int r = k + 1; r < 3; r++) { float v = fabsf(A[p[r]][k]); if (v > best) { best = v; m = r; } }
-        if (!(best > 1e-30f)) { x[0] = x[1] = x[2] = 0.0f; return; }
-        int t = p[k]; p[k] = p[m]; p[m] = t;
-        for (int r = k + 1; r < 3; r++) {
-            float f = A[p[r]][k] / A[p[k]][k];
-            for (int c = k + 1; c < 3; c++) A[p[r]][c] = A[p[r]][c] - f * A[p[k]][c];
-            b[p[r]] = b[p[r]] - f * b[p[k]];
-        }
-    }
-    x[2] = b[p[2]] / A[p[2]][2];
-    x[1] = (b[p[1]] - A[p[1]][2] * x[2]) / A[p[1]][1];
-    x[0] = ((b[p[0]] - A[p[0]][1] * x[1]) - A[p[0]][2] * x[2]) / A[p[0]][0];
+    float det = (a[0][0] * (a[1][1] * a[2][2] - a[2][1] * a[1][2]) - a[0][1] * (a[1][0] * a[2][2] - a[2][0] * a[1][2])) + a[0][2] * (a[1][0] * a[2][1] - a[2][0] * a[1][1]);
+    if (det == 0.0f) { x[0] = x[1] = x[2] = 0.0f; return 0; }
+    float d = 1.0f / det;
+    x[0] = d * ((b[0] * (a[1][1] * a[2][2] - a[1][2] * a[2][1]) - a[0][1] * (b[1] * a[2][2] - a[1][2] * b[2])) + a[0][2] * (b[1] * a[2][1] - a[1][1] * b[2]));
+    x[1] = d * ((a[0][0] * (b[1] * a[2][2] - a[1][2] * b[2]) - b[0] * (a[1][0] * a[2][2] - a[1][2] * a[2][0])) + a[0][2] * (a[1][0] * b[2] - b[1] * a[2][0]));
+    x[2] = d * ((a[0][0] * (a[1][1] * b[2] - b[1] * a[2][1]) - a[0][1] * (a[1][0] * b[2] - b[1] * a[2][0])) + b[0] * (a[1][0] * a[2][1] - a[1][1] * a[2][0]));
+    return 1;
 }
 
 /* sub-pixel refinement + contrast / edge rejection. returns 1 and fills (layer,r,c,xi,xr,xc,contr) */
 static int adjust_extremum(const octave_t* oc, int* layer, int* r, int* c, float* xi, float* xr, float* xc, float* contr,
                            float contrast_thr, float edge_thr)
 {
-    const float img_scale = 1.0f / 255.0f;
+    const float img_scale = 1.0f / (float)(255 * FIXPT_SCALE);
     const float deriv_scale = img_scale * 0.5f, second_scale = img_scale, cross_scale = img_scale * 0.25f;
     int it = 0;
     float dD[3], X[3] = {0, 0, 0};
     for (; it < MAX_INTERP; it++) {
         int L = *layer, R = *r, Cc = *c;
-        dD[0] = (dogv(oc, L, R, Cc + 1) - dogv(oc, L, R, Cc - 1)) * deriv_scale;
-        dD[1] = (dogv(oc, L, R + 1, Cc) - dogv(oc, L, R - 1, Cc)) * deriv_scale;
-        dD[2] = (dogv(oc, L + 1, R, Cc) - dogv(oc, L - 1, R, Cc)) * deriv_scale;
-        float v2 = dogv(oc, L, R, Cc) * 2.0f;
-        float dxx = (dogv(oc, L, R, Cc + 1) + dogv(oc, L, R, Cc - 1) - v2) * second_scale;
-        float dyy = (dogv(oc, L, R + 1, Cc) + dogv(oc, L, R - 1, Cc) - v2) * second_scale;
-        float dss = (dogv(oc, L + 1, R, Cc) + dogv(oc, L - 1, R, Cc) - v2) * second_scale;
-        float dxy = (dogv(oc, L, R + 1, Cc + 1) - dogv(oc, L, R + 1, Cc - 1) - dogv(oc, L, R - 1, Cc + 1) + dogv(oc, L, R - 1, Cc - 1)) * cross_scale;
-        float dxs = (dogv(oc, L + 1, R, Cc + 1) - dogv(oc, L + 1, R, Cc - 1) - dogv(oc, L - 1, R, Cc + 1) + dogv(oc, L - 1, R, Cc - 1)) * cross_scale;
-        float dys = (dogv(oc, L + 1, R + 1, Cc) - dogv(oc, L + 1, R - 1, Cc) - dogv(oc, L - 1, R + 1, Cc) + dogv(oc, L - 1, R - 1, Cc)) * cross_scale;
-        float A[3][3] = {{dxx, dxy, dxs}, {dxy, dyy, dys}, {dxs, dys, dss}};
-        float b[3] = {dD[0], dD[1], dD[2]};
-        solve3(A, b, X);
+        /* integer differences of 16-bit samples (exact), one float product each */
+        dD[0] = (float)(dogv(oc, L, R, Cc + 1) - dogv(oc, L, R, Cc - 1)) * deriv_scale;
+        dD[1] = (float)(dogv(oc, L, R + 1, Cc) - dogv(oc, L, R - 1, Cc)) * deriv_scale;
+        dD[2] = (float)(dogv(oc, L + 1, R, Cc) - dogv(oc, L - 1, R, Cc)) * deriv_scale;
+        float v2 = (float)dogv(oc, L, R, Cc) * 2.0f;
+        float dxx = ((float)(dogv(oc, L, R, Cc + 1) + dogv(oc, L, R, Cc - 1)) - v2) * second_scale;
+        float dyy = ((float)(dogv(oc, L, R + 1, Cc) + dogv(oc, L, R - 1, Cc)) - v2) * second_scale;
+        float dss = ((float)(dogv(oc, L + 1, R, Cc) + dogv(oc, L - 1, R, Cc)) - v2) * second_scale;
+        float dxy = (float)(dogv(oc, L, R + 1, Cc + 1) - dogv(oc, L, R + 1, Cc - 1) - dogv(oc, L, R - 1, Cc + 1) + dogv(oc, L, R - 1, Cc - 1)) * cross_scale;
+        float dxs = (float)(dogv(oc, L + 1, R, Cc + 1) - dogv(oc, L + 1, R, Cc - 1) - dogv(oc, L - 1, R, Cc + 1) + dogv(oc, L - 1, R, Cc - 1)) * cross_scale;
+        float dys = (float)(dogv(oc, L + 1, R + 1, Cc) - dogv(oc, L + 1, R - 1, Cc) - dogv(oc, L - 1, R + 1, Cc) + dogv(oc, L - 1, R - 1, Cc)) * cross_scale;
+        const float A[3][3] = {{dxx, dxy, dxs}, {dxy, dyy, dys}, {dxs, dys, dss}};
+        solve3_cramer(A, dD, X);
         *xi = -X[2]; *xr = -X[1]; *xc = -X[0];
         if (fabsf(*xi) < 0.5f && fabsf(*xr) < 0.5f && fabsf(*xc) < 0.5f) break;
         if (fabsf(*xi) > 7.0e8f || fabsf(*xr) > 7.0e8f || fabsf(*xc) > 7.0e8f) return 0;      /* INT_MAX/3 */
@@ -227,16 +234,17 @@ static int adjust_extremum(const octave_t* oc, int* layer, int* r, int* c, float
     if (it >= MAX_INTERP) return 0;
     {
         int L = *layer, R = *r, Cc = *c;
-        dD[0] = (dogv(oc, L, R, Cc + 1) - dogv(oc, L, R, Cc - 1)) * deriv_scale;
-        dD[1] = (dogv(oc, L, R + 1, Cc) - dogv(oc, L, R - 1, Cc)) * deriv_scale;
-        dD[2] = (dogv(oc, L + 1, R, Cc) - dogv(oc, L - 1, R, Cc)) * deriv_scale;
-        float t = (dD[0] * (*xc) + dD[1] * (*xr)) + dD[2] * (*xi);
-        *contr = dogv(oc, L, R, Cc) * img_scale + t * 0.5f;
+        dD[0] = (float)(dogv(oc, L, R, Cc + 1) - dogv(oc, L, R, Cc - 1)) * deriv_scale;
+        dD[1] = (float)(dogv(oc, L, R + 1, Cc) - dogv(oc, L, R - 1, Cc)) * deriv_scale;
+        dD[2] = (float)(dogv(oc, L + 1, R, Cc) - dogv(oc, L - 1, R, Cc)) * deriv_scale;
+        float t = (0.0f + dD[0] * (*xc)) + dD[1] * (*xr);                               /* Matx::dot: s = 0; s += v[i] * m[i] */
+        t = t + dD[2] * (*xi);
+        *contr = (float)dogv(oc, L, R, Cc) * img_scale + t * 0.5f;
         if (fabsf(*contr) * (float)N_LAYERS < contrast_thr) return 0;
-        float v2 = dogv(oc, L, R, Cc) * 2.0f;
-        float dxx = (dogv(oc, L, R, Cc + 1) + dogv(oc, L, R, Cc - 1) - v2) * second_scale;
-        float dyy = (dogv(oc, L, R + 1, Cc) + dogv(oc, L, R - 1, Cc) - v2) * second_scale;
-        float dxy = (dogv(oc, L, R + 1, Cc + 1) - dogv(oc, L, R + 1, Cc - 1) - dogv(oc, L, R - 1, Cc + 1) + dogv(oc, L, R - 1, Cc - 1)) * cross_scale;
+        float v2 = (float)dogv(oc, L, R, Cc) * 2.0f;
+        float dxx = ((float)(dogv(oc, L, R, Cc + 1) + dogv(oc, L, R, Cc - 1)) - v2) * second_scale;
+        float dyy = ((float)(dogv(oc, L, R + 1, Cc) + dogv(oc, L, R - 1, Cc)) - v2) * second_scale;
+        float dxy = (float)(dogv(oc, L, R + 1, Cc + 1) - dogv(oc, L, R + 1, Cc - 1) - dogv(oc, L, R - 1, Cc + 1) + dogv(oc, L, R - 1, Cc - 1)) * cross_scale;
         float tr = dxx + dyy, det = dxx * dyy - dxy * dxy;
         if (det <= 0.0f || (tr * tr) * edge_thr >= ((edge_thr + 1.0f) * (edge_thr + 1.0f)) * det) return 0;
     }
@@ -255,10 +263,13 @@ static int cand_cmp(const void* a, const void* b)
     return 0;
 }
 
+#define HIST_Q 1024.0f                       /* order-free accumulation: contributions quantised to 2^-10 (gradients are x48 already) */
+#define FIXQ(v) ((int64_t)llrintf((v) * HIST_Q))
+
 static void describe(const octave_t* oc, const cand_t* k, uint8_t* out)
 {
     const int d = 4, n = 8;
-    const float* img = oc->lv[k->layer];
+    const int16_t* img = oc->lv[k->layer];
     const int rows = oc->h, cols = oc->w;
     const float scl = k->scl;
     const int px = (int)rintf(k->ptx), py = (int)rintf(k->pty);
@@ -280,8 +291,8 @@ static void describe(const octave_t* oc, const cand_t* k, uint8_t* out)
             float cbin = c_rot + (float)(d / 2) - 0.5f;
             int r = py + i, c = px + j;
             if (!(rbin > -1.0f && rbin < (float)d && cbin > -1.0f && cbin < (float)d && r > 0 && r < rows - 1 && c > 0 && c < cols - 1)) continue;
-            float dx = img[(size_t)r * cols + c + 1] - img[(size_t)r * cols + c - 1];
-            float dy = img[(size_t)(r - 1) * cols + c] - img[(size_t)(r + 1) * cols + c];
+            float dx = (float)((int)img[(size_t)r * cols + c + 1] - (int)img[(size_t)r * cols + c - 1]);
+            float dy = (float)((int)img[(size_t)(r - 1) * cols + c] - (int)img[(size_t)(r + 1) * cols + c]);
             float ori = det_atan2deg(dy, dx);
             float mag = sqrtf(dx * dx + dy * dy) * det_expf((c_rot * c_rot + r_rot * r_rot) * exp_scale);
             float obin = (ori - k->angle) * bins_per_deg;
@@ -298,13 +309,12 @@ static void describe(const octave_t* oc, const cand_t* k, uint8_t* out)
             float v_rco011 = v_rc01 * obin, v_rco010 = v_rc01 - v_rco011;
             float v_rco001 = v_rc00 * obin, v_rco000 = v_rc00 - v_rco001;
             int idx = ((r0 + 1) * (d + 2) + c0 + 1) * (n + 2) + o0;
-#define FIXQ(v) ((int64_t)llrintf((v) * 1048576.0f))
             hq[idx] += FIXQ(v_rco000); hq[idx + 1] += FIXQ(v_rco001);
             hq[idx + (n + 2)] += FIXQ(v_rco010); hq[idx + (n + 3)] += FIXQ(v_rco011);
             hq[idx + (d + 2) * (n + 2)] += FIXQ(v_rco100); hq[idx + (d + 2) * (n + 2) + 1] += FIXQ(v_rco101);
             hq[idx + (d + 3) * (n + 2)] += FIXQ(v_rco110); hq[idx + (d + 3) * (n + 2) + 1] += FIXQ(v_rco111);
         }
-    for (int i = 0; i < (d + 2) * (d + 2) * (n + 2); i++) hist[i] = (float)hq[i] * (1.0f / 1048576.0f);
+    for (int i = 0; i < (d + 2) * (d + 2) * (n + 2); i++) hist[i] = (float)hq[i] * (1.0f / HIST_Q);
     float dst[128];
     for (int i = 0; i < d; i++)
         for (int j = 0; j < d; j++) {
@@ -326,41 +336,73 @@ static void describe(const octave_t* oc, const cand_t* k, uint8_t* out)
     }
 }
 
+/* experiment switch (tests/test_sift_reference_run.py measures both): 0 = cv::resize INTER_LINEAR (pixel centres aligned, what the
+ * binary calls), 1 = sample grids aligned at pixel (0, 0) (round 2's choice) */
+int orc_sift_doubling_mode = 0;
+
+/* 2x INTER_LINEAR of a 16-bit image, cv::resize: src = (dst + 0.5) * 0.5 - 0.5, floor, clamp to the border with weight 0 on the far
+ * sample; horizontal pass in float (S0 * (1 - fx) + S1 * fx), vertical pass the same, saturate_cast<short> at the end.  With fx in
+ * {0.25, 0.75} every intermediate is exact in binary32, so the value is round-half-even((9 a + 3 b + 3 c + d) / 16) */
+static void double_linear16(const int16_t* g, int w, int h, int16_t* up)
+{
+    const int W = 2 * w, H = 2 * h;
+    float* row0 = (float*)malloc(sizeof(float) * (size_t)W * 2);
+    float* row1 = row0 + W;
+    for (int Y = 0; Y < H; Y++) {
+        int y0, y1; float fy;
+        if (orc_sift_doubling_mode == 0) {
+            float f = ((float)Y + 0.5f) * 0.5f - 0.5f;
+            y0 = (int)floorf(f); fy = f - (float)y0;
+            if (y0 < 0) { y0 = 0; fy = 0.0f; }
+            if (y0 >= h - 1) { y0 = h - 1; fy = 0.0f; }
+            y1 = y0 + 1 < h ? y0 + 1 : h - 1;
+        } else {
+            y0 = Y >> 1; y1 = (Y & 1) ? y0 + 1 : y0; fy = (Y & 1) ? 0.5f : 0.0f;
+            if (y1 > h - 1) { y1 = h - 1; }
+        }
+        for (int pass = 0; pass < 2; pass++) {
+            const int16_t* s = g + (size_t)(pass ? y1 : y0) * w;
+            float* d = pass ? row1 : row0;
+            for (int X = 0; X < W; X++) {
+                int x0, x1; float fx;
+                if (orc_sift_doubling_mode == 0) {
+                    float f = ((float)X + 0.5f) * 0.5f - 0.5f;
+                    x0 = (int)floorf(f); fx = f - (float)x0;
+                    if (x0 < 0) { x0 = 0; fx = 0.0f; }
+                    if (x0 >= w - 1) { x0 = w - 1; fx = 0.0f; }
+                    x1 = x0 + 1 < w ? x0 + 1 : w - 1;
+                } else {
+                    x0 = X >> 1; x1 = (X & 1) ? x0 + 1 : x0; fx = (X & 1) ? 0.5f : 0.0f;
+                    if (x1 > w - 1) x1 = w - 1;
+                }
+                d[X] = (float)s[x0] * (1.0f - fx) + (float)s[x1] * fx;
+            }
+        }
+        for (int X = 0; X < W; X++) up[(size_t)Y * W + X] = sat_short(row0[X] * (1.0f - fy) + row1[X] * fy);
+    }
+    free(row0);
+}
+
 int orc_sift(const uint8_t* bgr, int w, int h, int ws, int nfeatures, orc_keypoint* kp_out, uint8_t* desc_out, int max_kp)
 {
     const double sigma = 1.6;
     const float contrast_thr = 0.01f, edge_thr = 20.0f;
-    const int W = 2 * w, H = 2 * h;
-    /* 1-2: gray, 2x linear doubling with the sample grids aligned at pixel (0, 0): up(2x, 2y) = gray(x, y), odd positions are the
-     * mean of their two (four) neighbours, last column / row replicated -- every value exact in binary32, any order.
-     * WHY this alignment: the reference's committed run (Release/feature_temp/matchPairs.match: 8220 distinct keypoints that
-     * OpenCV 2.4.0's SIFT produced on Release/test_data/DSC00004..23.JPG) decides between the candidates
-     *     pixel-centre aligned doubling (weights 1/4, 3/4; what cv::resize INTER_LINEAR does today): keypoints systematically
-     *         (+0.25, +0.25) px off the reference's, all octaves alike; with that offset removed 52 % within 0.1 px
-     *     [1 4 6 4 1]/8 pyrUp-style doubling: 62 % within 0.1 px
-     *     this one: 71 % within 0.1 px (18 % within 0.02 px), residual mean (0.000, -0.001), std 0.07 px
-     * (tests/test_sift_reference_run.py keeps the measurement alive on the two frames committed under tests/golden/). */
-    float* gray = (float*)malloc(sizeof(float) * (size_t)w * h);
+    const int dbl = orc_sift_doubling_mode != 2;
+    const int W = dbl ? 2 * w : w, H = dbl ? 2 * h : h;
+    /* 1: gray (8-bit BGR2GRAY fixed point), x48 into 16 bits */
+    int16_t* gray = (int16_t*)malloc(sizeof(int16_t) * (size_t)w * h);
     for (int y = 0; y < h; y++)
         for (int x = 0; x < w; x++) {
             const uint8_t* p = bgr + (size_t)y * ws + 3 * x;
-            gray[(size_t)y * w + x] = (float)((1868 * p[0] + 9617 * p[1] + 4899 * p[2] + 8192) >> 14);
+            gray[(size_t)y * w + x] = (int16_t)(((1868 * p[0] + 9617 * p[1] + 4899 * p[2] + 8192) >> 14) * FIXPT_SCALE);
         }
-    float* up = (float*)malloc(sizeof(float) * (size_t)W * H);
-    for (int Y = 0; Y < H; Y++) {
-        int y0 = Y >> 1, y1 = (Y & 1) ? y0 + 1 : y0;
-        if (y1 > h - 1) y1 = h - 1;
-        for (int X = 0; X < W; X++) {
-            int x0 = X >> 1, x1 = (X & 1) ? x0 + 1 : x0;
-            if (x1 > w - 1) x1 = w - 1;
-            float a = (gray[(size_t)y0 * w + x0] + gray[(size_t)y0 * w + x1]) * 0.5f;
-            float b = (gray[(size_t)y1 * w + x0] + gray[(size_t)y1 * w + x1]) * 0.5f;
-            up[(size_t)Y * W + X] = (a + b) * 0.5f;
-        }
-    }
-    free(gray);
-    /* 3: pyramid */
-    int nOct = (int)lrint(log((double)(W < H ? W : H)) / log(2.0) - 2.0) + 1;
+    /* 2: base = 2x linear doubling, Gaussian blur with sqrt(sigma^2 - (2 * 0.5)^2) (first octave = -1) */
+    int16_t* up;
+    if (dbl) { up = (int16_t*)malloc(sizeof(int16_t) * (size_t)W * H); double_linear16(gray, w, h, up); free(gray); }
+    else up = gray;
+    /* 3: pyramid: 6 Gaussian levels per octave built incrementally, sigma_i = sqrt((s k^i)^2 - (s k^(i-1))^2), k = 2^(1/3); next
+     * octave = every second pixel of level 3 (resize INTER_NEAREST to half size) */
+    int nOct = (int)lrint(log((double)(W < H ? W : H)) / log(2.0) - 2.0) + (dbl ? 1 : 0);
     if (nOct > MAX_OCT) nOct = MAX_OCT;
     double sig[N_LEVELS];
     {
@@ -376,20 +418,21 @@ int orc_sift(const uint8_t* bgr, int w, int h, int ws, int nfeatures, orc_keypoi
         int ow = W >> o, oh = H >> o;
         if (ow < 2 * IMG_BORDER + 2 || oh < 2 * IMG_BORDER + 2) break;      /* no keypoint can exist in smaller octaves */
         oc[o].w = ow; oc[o].h = oh;
-        for (int i = 0; i < N_LEVELS; i++) oc[o].lv[i] = (float*)malloc(sizeof(float) * (size_t)ow * oh);
+        for (int i = 0; i < N_LEVELS; i++) oc[o].lv[i] = (int16_t*)malloc(sizeof(int16_t) * (size_t)ow * oh);
         if (o == 0) {
-            double sd = sqrt(sigma * sigma - 1.0 > 0.01 ? sigma * sigma - 1.0 : 0.01);
-            gauss_blur(up, oc[0].lv[0], tmp, ow, oh, sd);
+            float sd = sqrtf(fmaxf((float)sigma * (float)sigma - (dbl ? 1.0f : 0.25f), 0.01f));            /* float, as the binary computes it */
+            gauss_blur16(up, oc[0].lv[0], tmp, ow, oh, (double)sd);
         } else {
-            const float* s = oc[o - 1].lv[N_LAYERS];
+            const int16_t* s = oc[o - 1].lv[N_LAYERS];
             int pw = oc[o - 1].w;
             for (int y = 0; y < oh; y++) for (int x = 0; x < ow; x++) oc[o].lv[0][(size_t)y * ow + x] = s[(size_t)(2 * y) * pw + 2 * x];
         }
-        for (int i = 1; i < N_LEVELS; i++) gauss_blur(oc[o].lv[i - 1], oc[o].lv[i], tmp, ow, oh, sig[i]);
+        for (int i = 1; i < N_LEVELS; i++) gauss_blur16(oc[o].lv[i - 1], oc[o].lv[i], tmp, ow, oh, sig[i]);
         no = o + 1;
     }
     free(up); free(tmp);
     /* 4-6: extrema -> refined keypoints with orientations */
+    const int threshold = (int)floor(0.5 * 0.01 / N_LAYERS * 255 * FIXPT_SCALE);          /* 20 */
     size_t cap = 1 << 16, ncand = 0;
     cand_t* cand = (cand_t*)malloc(sizeof(cand_t) * cap);
     for (int o = 0; o < no; o++) {
@@ -399,14 +442,14 @@ int orc_sift(const uint8_t* bgr, int w, int h, int ws, int nfeatures, orc_keypoi
         for (int layer = 1; layer <= N_LAYERS; layer++)
             for (int r = IMG_BORDER; r < O->h - IMG_BORDER; r++)
                 for (int c = IMG_BORDER; c < O->w - IMG_BORDER; c++) {
-                    float val = dogv(O, layer, r, c);
-                    if (!(fabsf(val) > 0.0f)) continue;
-                    int ismax = val > 0.0f, ok = 1;
+                    int val = dogv(O, layer, r, c);
+                    if (!(abs(val) > threshold)) continue;
+                    int ismax = val > 0, ok = 1;
                     for (int dl = -1; dl <= 1 && ok; dl++)
                         for (int dr = -1; dr <= 1 && ok; dr++)
                             for (int dc = -1; dc <= 1; dc++) {
                                 if (!dl && !dr && !dc) continue;
-                                float v = dogv(O, layer + dl, r + dr, c + dc);
+                                int v = dogv(O, layer + dl, r + dr, c + dc);
                                 if (ismax ? !(val >= v) : !(val <= v)) { ok = 0; break; }
                             }
                     if (!ok) continue;
@@ -417,7 +460,7 @@ int orc_sift(const uint8_t* bgr, int w, int h, int ws, int nfeatures, orc_keypoi
                     claimed[(size_t)R * O->w + Cc] |= bit;
                     float scl = (float)sigma * det_exp2f(((float)L + xi) / (float)N_LAYERS);
                     /* orientation histogram on the Gaussian level L of this octave */
-                    const float* img = O->lv[L];
+                    const int16_t* img = O->lv[L];
                     int radius = (int)rintf(4.5f * scl);
                     float osig = 1.5f * scl;
                     float expf_scale = -1.0f / (2.0f * osig * osig);
@@ -430,8 +473,8 @@ int orc_sift(const uint8_t* bgr, int w, int h, int ws, int nfeatures, orc_keypoi
                         for (int j = -radius; j <= radius; j++) {
                             int x = Cc + j;
                             if (x <= 0 || x >= O->w - 1) continue;
-                            float dx = img[(size_t)y * O->w + x + 1] - img[(size_t)y * O->w + x - 1];
-                            float dy = img[(size_t)(y - 1) * O->w + x] - img[(size_t)(y + 1) * O->w + x];
+                            float dx = (float)((int)img[(size_t)y * O->w + x + 1] - (int)img[(size_t)y * O->w + x - 1]);
+                            float dy = (float)((int)img[(size_t)(y - 1) * O->w + x] - (int)img[(size_t)(y + 1) * O->w + x]);
                             float wgt = det_expf((float)(i * i + j * j) * expf_scale);
                             float ang = det_atan2deg(dy, dx);
                             float mag = sqrtf(dx * dx + dy * dy);
@@ -439,10 +482,10 @@ int orc_sift(const uint8_t* bgr, int w, int h, int ws, int nfeatures, orc_keypoi
                             if (bin >= ORI_BINS) bin -= ORI_BINS;
                             if (bin < 0) bin += ORI_BINS;
                             float t = wgt * mag;
-                            tq[bin] += (int64_t)llrintf(t * 1048576.0f);
+                            tq[bin] += FIXQ(t);
                         }
                     }
-                    for (int b = 0; b < ORI_BINS; b++) th[b] = (float)tq[b] * (1.0f / 1048576.0f);
+                    for (int b = 0; b < ORI_BINS; b++) th[b] = (float)tq[b] * (1.0f / HIST_Q);
                     float omax = 0.0f;
                     for (int b = 0; b < ORI_BINS; b++) {
                         float m2 = th[(b + ORI_BINS - 2) % ORI_BINS], m1 = th[(b + ORI_BINS - 1) % ORI_BINS];
@@ -463,7 +506,7 @@ int orc_sift(const uint8_t* bgr, int w, int h, int ws, int nfeatures, orc_keypoi
                             k->o = o; k->layer = L; k->r = R; k->c = Cc; k->bin = b;
                             k->ptx = (float)Cc + xc; k->pty = (float)R + xr;
                             /* image coordinates: octave o is scaled by 2^(o-1) relative to the input image */
-                            float s2 = o == 0 ? 0.5f : (float)(1 << (o - 1));
+                            float s2 = dbl ? (o == 0 ? 0.5f : (float)(1 << (o - 1))) : (float)(1 << o);
                             k->x = k->ptx * s2; k->y = k->pty * s2;
                             k->size = (scl * s2) * 2.0f;
                             k->angle = (360.0f / (float)ORI_BINS) * bf;
@@ -481,7 +524,7 @@ int orc_sift(const uint8_t* bgr, int w, int h, int ws, int nfeatures, orc_keypoi
         const cand_t* k = &cand[i];
         kp_out[i].x = k->x; kp_out[i].y = k->y; kp_out[i].size = k->size; kp_out[i].angle = k->angle; kp_out[i].response = k->response;
         /* OpenCV packing: octave (first octave = -1) | layer << 8 | round((xi + 0.5) * 255) << 16 */
-        kp_out[i].octave = ((k->o - 1) & 255) | (k->layer << 8) | (((int)rintf((k->xi + 0.5f) * 255.0f)) << 16);
+        kp_out[i].octave = ((k->o - (dbl ? 1 : 0)) & 255) | (k->layer << 8) | (((int)rintf((k->xi + 0.5f) * 255.0f)) << 16);
         kp_out[i].class_id = -1;
         if (desc_out) describe(&oc[k->o], k, desc_out + 128 * i);      /* 8 */
     }
