@@ -1,20 +1,21 @@
 // csrc/sift.hip -- K1..K5: SIFT detect + describe on gfx950, replacing the body of SiftExtraction_Thread
 // (MosaicWithoutPos.cpp:4832-4887: SiftFeatureDetector(2000,3,0.01,20).detect + SiftDescriptorExtractor.compute).
 //
-// The algorithm is Lowe's SIFT with the constants of the cv::SIFT object the reference builds; the exact
-// arithmetic (fmaf tap order, polynomial exp/atan2/sincos, histogram accumulation, keypoint order) is the
-// one stated at the top of oracle/oracle_sift.c -- this file implements the same definition, independently,
-// for the GPU, and the parity tests compare keypoints and descriptors bit for bit.
+// The algorithm is OpenCV 2.4.0's cv::SIFT as the reference's own binary runs it (oracle/oracle_sift.c says how that was
+// established and how the reference's committed run pins it): NO image doubling, 16-BIT FIXED-POINT pyramids (gray x 48), Gaussian
+// levels filtered 16S -> 32F -> 16S with separately rounded products and sums in the filter engine's tap order, integer DoG,
+// |DoG| > 20, Cramer's rule for the 3x3 fit.  This file implements that definition, independently, for the GPU, and the parity
+// tests compare keypoints and descriptors bit for bit with the oracle.
 //
-// Host side: frames collect into batches of 8 (SiftWork, sift_run_batch at the end of this file); every launch below
-// covers all frames of a batch.  Kernels:
-//   gray_pad + blur_stream<5,8,true>   base level: fixed-point gray, 2x up-sampling and first blur, the up-sampled image
-//                         is never stored
-//   blur_stream<R,D,false> separable Gaussian of one level (>= 1000x750): a wave walks down a strip of 256 columns, rows
-//                         arrive once from HBM, the 2R+1 column accumulators live in registers, no workgroup barrier;
-//                         level 3 also writes the decimated base of the next octave
-//   blur_tile2 / blur_tile the same filter for small levels: 64x64 tile + halo in LDS, row pass then column pass
-//   downsample2           next octave seed = every second pixel of level 3 (octaves whose level 3 is not streamed)
+// Host side: frames collect into batches (SiftWork, sift_run_batch at the end of this file); every launch below covers all frames
+// of a batch.  Kernels:
+//   blur16_stream<R,BGR>  separable Gaussian of one level (>= 512 columns): a wave walks down a strip of 256 columns, rows arrive
+//                         once from HBM (8 bytes per lane: four 16-bit samples), the row-filtered rows of the last 2R+1 steps live in
+//                         registers (the column pass needs its taps centre first, then symmetric pairs: a gather, not a scatter),
+//                         no workgroup barrier; BGR = true forms gray x 48 of the caller's frame on the fly (base level, no gray
+//                         image is ever stored); level 3 also writes the decimated base of the next octave
+//   blur16_tile<R,BGR>    the same filter for small levels: 64x32 tile + halo in LDS, row pass then column pass
+//   downsample16          next octave seed = every second pixel of level 3 (when the blur did not write it on the way out)
 //   extrema_stream / extrema_kernel   DoG never materialised in HBM: the 6 Gaussian levels are read once, 26-neighbour
 //                         test on the 5 DoG planes (registers / LDS), candidates leave with their 3x3x3 neighbourhood
 //   refine                one lane per candidate: quadratic fit, contrast / edge tests, duplicate claim bitmap
@@ -23,7 +24,7 @@
 //                         smoothing + peaks via lane shuffles
 //   topk                  one workgroup per frame: radix select of the nfeatures-th response, bitonic sort of the
 //                         survivors by the total order (response desc, octave, layer, row, col, bin)
-//   describe              one workgroup per keypoint: trilinear contributions quantised to 2^-20 and added with
+//   describe              one workgroup per keypoint: trilinear contributions quantised to 2^-10 and added with
 //                         64-bit LDS atomics (order-free by definition), normalise / clip / renormalise -> u8
 #include "common.h"
 #include <memory>
@@ -34,17 +35,12 @@
 namespace {
 
 constexpr int N_LAYERS = 3, N_LEVELS = 6, IMG_BORDER = 5, MAX_INTERP = 5, ORI_BINS = 36, MAX_OCT = 16;
-#ifndef BLUR_TW
-#define BLUR_TW 64
-#endif
-#ifndef BLUR_TH
-#define BLUR_TH 64
-#endif
-#ifndef BLUR_BT
-#define BLUR_BT 512
-#endif
-constexpr int TW = BLUR_TW, TH = BLUR_TH;       // blur tile
+constexpr int FIXPT_SCALE = 48;                 // SIFT_FIXPT_SCALE of the reference's OpenCV build: pyramid samples are gray x 48 in 16 bits
+constexpr float DOG_THRESHOLD_P1 = 21.0f;       // |DoG| > floor(0.5 * 0.01 / 3 * 255 * 48) = 20, on integers: |DoG| >= 21
+constexpr float HIST_Q = 1024.0f;               // order-free histogram accumulation: contributions quantised to 2^-10 (oracle_sift.c)
 constexpr int MAX_R = 16;
+constexpr int SIFT_BATCH_MAX = 16;
+typedef int16_t lvl_t;                          // one pyramid sample
 
 __host__ __device__ __forceinline__ int reflect101(int p, int n) {
     if (n == 1) return 0;
@@ -54,40 +50,24 @@ __host__ __device__ __forceinline__ int reflect101(int p, int n) {
 
 typedef float v2f __attribute__((ext_vector_type(2)));
 typedef float v4f __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ v2f vfma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
-__device__ __forceinline__ v4f vfma(v4f a, v4f b, v4f c) { return __builtin_elementwise_fma(a, b, c); }
 
-// ---------- K1/K2: fused separable Gaussian blur ------------------------------------------------------------------
-struct BlurArgs {
-    const float* src;        // LOADER f32: source level (w x h)
-    const uint8_t* bgr;      // LOADER BGR: frame (w/2 x h/2), row stride bgr_ws
-    int bgr_ws;
-    float* dst;
-    int w, h;                // size of the level being produced
-    int tiles_x, tiles_y;
-    float k[2 * MAX_R + 1];
-    size_t fstride;          // batched launch: frame f (blockIdx.y, or the tile index / tiles for the persistent kernel) reads
-    int nb;                  // src + f * fstride and writes dst + f * fstride (floats); nb = frames in the batch (0 or 1: single)
-    size_t gstride;          // blur_stream UPS: frame f reads the padded gray at bgr + f * gstride (bytes)
-    float* ds;               // blur_stream: also write the 2x decimated level (even rows, even columns) here: the next octave's base
-    int band;                // blur_stream: > 0 = only the first and the last `band` rows of the level (two segments; the cascade did the rest)
-};
-
-// 2x linear doubling of the fixed-point gray image, grids aligned at pixel (0, 0): up(2x, 2y) = gray(x, y), odd positions are the
-// mean of their neighbours, last column / row replicated (oracle_sift.c orc_sift says why this alignment: the reference's committed
-// keypoints).  Every sum is exact in binary32, so the order of evaluation is free.
-__device__ __forceinline__ float load_base(const uint8_t* bgr, int ws, int w, int h, int X, int Y) {
-    const int x0 = X >> 1, y0 = Y >> 1;
-    int x1 = (X & 1) ? x0 + 1 : x0, y1 = (Y & 1) ? y0 + 1 : y0;
-    if (x1 > w - 1) x1 = w - 1;
-    if (y1 > h - 1) y1 = h - 1;
-    auto gray = [&](int x, int y) {
-        const uint8_t* p = bgr + (size_t)y * ws + 3 * x;
-        return (float)((1868 * (int)p[0] + 9617 * (int)p[1] + 4899 * (int)p[2] + 8192) >> 14);
-    };
-    const float a = (gray(x0, y0) + gray(x1, y0)) * 0.5f;
-    const float b = (gray(x0, y1) + gray(x1, y1)) * 0.5f;
-    return (a + b) * 0.5f;
+// four / one 16-bit samples as floats (exact)
+__device__ __forceinline__ v4f ld4(const lvl_t* p) {              // p 8-byte aligned
+    const uint2 q = *reinterpret_cast<const uint2*>(p);
+    v4f o;
+    o.x = (float)(int)(short)(q.x & 0xffffu); o.y = (float)((int)q.x >> 16);
+    o.z = (float)(int)(short)(q.y & 0xffffu); o.w = (float)((int)q.y >> 16);
+    return o;
+}
+__device__ __forceinline__ float ld1(const lvl_t* p) { return (float)(int)*p; }
+// saturate_cast<short>(float): round half to even, clamp
+__device__ __forceinline__ int sat16(float v) {
+    int q = (int)rintf(v);
+    q = q < -32768 ? -32768 : (q > 32767 ? 32767 : q);
+    return q;
+}
+__device__ __forceinline__ float gray48(const uint8_t* p) {       // 8-bit BGR2GRAY fixed point, x 48 (convertTo(CV_16S, 48))
+    return (float)(((1868 * (int)p[0] + 9617 * (int)p[1] + 4899 * (int)p[2] + 8192) >> 14) * FIXPT_SCALE);
 }
 
 // XCD-aware remap: hardware places block b on XCD b % 8; give every XCD a contiguous run of tiles
@@ -97,326 +77,140 @@ __device__ __forceinline__ int xcd_remap(int bid, int nb) {
     return base + local;
 }
 
-#ifndef BLUR_PERSIST_BLOCKS
-#define BLUR_PERSIST_BLOCKS 512
-#endif
-constexpr int BT = BLUR_BT;                    // threads per blur workgroup (8 waves share one staged tile)
-template <int R, bool BGR>
-__global__ __launch_bounds__(BT) void blur_tile(BlurArgs a) {
-    constexpr int ROWS = TH + 2 * R;           // rows of the staged tile
-    constexpr int COLS = TW + 2 * R;
-    constexpr int PIN = COLS | 1;              // odd pitches: lanes walking rows hit distinct banks
-    constexpr int PMID = TW + 1;
-    __shared__ float s_in[ROWS * PIN];
-    __shared__ float s_mid[ROWS * PMID];
-    const int tid = threadIdx.x;
-    const int tile = xcd_remap(blockIdx.x, a.tiles_x * a.tiles_y);
-    const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
-    const int x0 = tx * TW, y0 = ty * TH;
-    if (!BGR) { a.src += (size_t)blockIdx.y * a.fstride; }
-    a.dst += (size_t)blockIdx.y * a.fstride;
-    // phase 1: stage the halo tile (reflect-101 at the image border; interior tiles skip the reflection)
-    const bool interior = (x0 - R >= 0) && (y0 - R >= 0) && (x0 + TW + R <= a.w) && (y0 + TH + R <= a.h);
-    if (interior && !BGR) {
-        const float* base = a.src + (size_t)(y0 - R) * a.w + (x0 - R);
-#pragma unroll 6
-        for (int idx = tid; idx < ROWS * COLS; idx += BT) {
-            const int ry = idx / COLS, rx = idx - ry * COLS;
-            s_in[ry * PIN + rx] = base[(size_t)ry * a.w + rx];
-        }
-    } else if (BGR && interior && ((x0 + TW - 1 + R) >> 1) + 1 <= (a.w >> 1) - 1 && ((y0 + TH - 1 + R) >> 1) + 1 <= (a.h >> 1) - 1) {
-        // interior tile of the base level: the fixed-point gray of the low-resolution patch is computed ONCE into LDS
-        // (each frame byte is read once per tile instead of ~4x per staged sample), then doubled from there with the same
-        // exact sums as load_base.
-        constexpr int GW = (TW + 2 * R) / 2 + 3, GH = (TH + 2 * R) / 2 + 3;
-        __shared__ float s_gray[GH * GW];
-        const int lxa = (x0 - R) >> 1, lya = (y0 - R) >> 1;
-        for (int idx = tid; idx < GH * GW; idx += BT) {
-            const int gy = idx / GW, gx = idx - gy * GW;
-            const int ly = lya + gy, lx = lxa + gx;
-            float v = 0.0f;
-            if (lx < (a.w >> 1) && ly < (a.h >> 1)) {
-                const uint8_t* p = a.bgr + (size_t)ly * a.bgr_ws + 3 * lx;
-                v = (float)((1868 * (int)p[0] + 9617 * (int)p[1] + 4899 * (int)p[2] + 8192) >> 14);
-            }
-            s_gray[idx] = v;
-        }
-        __syncthreads();
-        for (int idx = tid; idx < ROWS * COLS; idx += BT) {
-            const int ry = idx / COLS, rx = idx - ry * COLS;
-            const int X = x0 - R + rx, Y = y0 - R + ry;
-            const float* g0 = s_gray + ((Y >> 1) - lya) * GW + ((X >> 1) - lxa);
-            const float* g1 = g0 + ((Y & 1) ? GW : 0);
-            const int dx = X & 1;
-            const float aa = (g0[0] + g0[dx]) * 0.5f;
-            const float bb = (g1[0] + g1[dx]) * 0.5f;
-            s_in[ry * PIN + rx] = (aa + bb) * 0.5f;
-        }
-    } else {
-        for (int idx = tid; idx < ROWS * COLS; idx += BT) {
-            const int ry = idx / COLS, rx = idx - ry * COLS;
-            const int gy = reflect101(y0 - R + ry, a.h), gx = reflect101(x0 - R + rx, a.w);
-            float v;
-            if (BGR) v = load_base(a.bgr, a.bgr_ws, a.w >> 1, a.h >> 1, gx, gy);
-            else v = a.src[(size_t)gy * a.w + gx];
-            s_in[ry * PIN + rx] = v;
-        }
-    }
-    __syncthreads();
-    // phase 2: row pass, 4 adjacent outputs per item from a sliding window (tap order ascending, fmaf)
-    for (int item = tid; item < ROWS * (TW / 4); item += BT) {
-        const int xg = item / ROWS, row = item - xg * ROWS;
-        const float* in = s_in + row * PIN + 4 * xg;
-        float acc0 = 0.0f, acc1 = 0.0f, acc2 = 0.0f, acc3 = 0.0f;
-#pragma unroll
-        for (int m = 0; m < 2 * R + 4; m++) {
-            const float e = in[m];
-            if (m <= 2 * R) acc0 = fmaf(a.k[m], e, acc0);
-            if (m >= 1 && m - 1 <= 2 * R) acc1 = fmaf(a.k[m - 1], e, acc1);
-            if (m >= 2 && m - 2 <= 2 * R) acc2 = fmaf(a.k[m - 2], e, acc2);
-            if (m >= 3) acc3 = fmaf(a.k[m - 3], e, acc3);
-        }
-        float* mid = s_mid + row * PMID + 4 * xg;
-        mid[0] = acc0; mid[1] = acc1; mid[2] = acc2; mid[3] = acc3;
-    }
-    __syncthreads();
-    // phase 3: column pass, 4 vertically adjacent outputs per item
-    for (int item = tid; item < TW * (TH / 4); item += BT) {
-        const int yg = item / TW, x = item - yg * TW;
-        const float* mid = s_mid + (4 * yg) * PMID + x;
-        float acc0 = 0.0f, acc1 = 0.0f, acc2 = 0.0f, acc3 = 0.0f;
-#pragma unroll
-        for (int m = 0; m < 2 * R + 4; m++) {
-            const float e = mid[m * PMID];
-            if (m <= 2 * R) acc0 = fmaf(a.k[m], e, acc0);
-            if (m >= 1 && m - 1 <= 2 * R) acc1 = fmaf(a.k[m - 1], e, acc1);
-            if (m >= 2 && m - 2 <= 2 * R) acc2 = fmaf(a.k[m - 2], e, acc2);
-            if (m >= 3) acc3 = fmaf(a.k[m - 3], e, acc3);
-        }
-        const int gx = x0 + x, gy = y0 + 4 * yg;
-        if (gx < a.w) {
-            float* d = a.dst + (size_t)gy * a.w + gx;
-            if (gy < a.h) d[0] = acc0;
-            if (gy + 1 < a.h) d[(size_t)a.w] = acc1;
-            if (gy + 2 < a.h) d[2 * (size_t)a.w] = acc2;
-            if (gy + 3 < a.h) d[3 * (size_t)a.w] = acc3;
-        }
-    }
-}
-
-// ---- blur_tile2: the production variant -------------------------------------------------------------------------
-// Same arithmetic as blur_tile (per output: acc = 0; acc = fmaf(k[i], x[i], acc) for ascending i), restructured for
-// the CDNA4 issue limits: 128-bit LDS reads/writes, two FMAs per instruction (v_pk_fma_f32 through 2-wide vector
-// fma), and a 4x4 output block per lane in the column pass.  The staged tile starts at a 4-float aligned column
-// (halo RA = R rounded up to 4) so that global loads, LDS rows and the sliding windows are all 16-byte aligned.
-
-#ifndef BLUR2_NT
-#define BLUR2_NT 512
-#endif
-#ifndef BLUR2_TH
-#define BLUR2_TH 64
-#endif
-template <int R, bool BGR>
-__global__ __launch_bounds__(BLUR2_NT) void blur_tile2(BlurArgs a) {
-    constexpr int NT = BLUR2_NT;                // threads per workgroup
-    constexpr int TH2 = BLUR2_TH;               // tile height (width is 64)
-    constexpr int CR = TH2 * 16 / NT;           // output rows per column-pass item (4 columns x CR rows per lane)
-    constexpr int RA = (R + 3) & ~3;            // aligned halo
-    constexpr int S = RA - R;                   // first tap of output 0 inside the aligned window
-    constexpr int ROWS = TH2 + 2 * R;
-    constexpr int COLS = 64 + 2 * RA;           // multiple of 4
-    constexpr int C4 = COLS / 4;                // float4 per staged row
-    constexpr int P4 = (C4 + 15) & ~15;         // LDS row pitch in float4: multiple of 256 B => the 16-lane groups of a
-                                                // ds_read_b128 (two rows of 16-byte slots) never share a bank
-    constexpr int NG = (S + 2 * R + 4 + 3) / 4; // float4 groups read per row-pass item
-    constexpr int PMID = 64;                    // mid pitch (floats): 256 B rows, conflict-free for the same reason
-    constexpr int NPF = (ROWS * C4 + NT - 1) / NT; // float4 loads per lane to stage one tile
-    __shared__ v4f s_in4[ROWS * P4];
-    __shared__ v4f s_mid4[ROWS * (PMID / 4)];
-    float* s_in = reinterpret_cast<float*>(s_in4);
-    const int tid = threadIdx.x;
-    const int ntiles1 = a.tiles_x * a.tiles_y;            // tiles of one frame
-    const int ntiles = ntiles1 * (a.nb > 1 ? a.nb : 1);   // batched launch: the tile list runs over all frames
-    const bool vec_ok = !BGR && ((a.w & 3) == 0) && ((reinterpret_cast<uintptr_t>(a.src) & 15) == 0);
-    const bool vec_st = ((a.w & 3) == 0) && ((reinterpret_cast<uintptr_t>(a.dst) & 15) == 0);
-
-    // Persistent workgroups walk the tile list; the global loads of tile t+1 are issued into registers before the two
-    // passes of tile t run (their latency hides under ~1000 VALU instructions), and land in LDS after the passes.
-    v4f pf[NPF];
-    auto tile_origin = [&](int t, int& x0, int& y0, int& fr) {
-        const int tile = xcd_remap(t, ntiles);
-        fr = tile / ntiles1;
-        const int t1 = tile - fr * ntiles1;
-        const int ty = t1 / a.tiles_x, tx = t1 - ty * a.tiles_x;
-        x0 = tx * 64; y0 = ty * TH2;
-    };
-    auto is_interior = [&](int x0, int y0) { return vec_ok && (x0 - RA >= 0) && (y0 - R >= 0) && (x0 + 64 + RA <= a.w) && (y0 + TH2 + R <= a.h); };
-    auto prefetch = [&](int x0, int y0, int fr) {
-        const float* base = a.src + (size_t)fr * a.fstride + (size_t)(y0 - R) * a.w + (x0 - RA);
-#pragma unroll
-        for (int u = 0; u < NPF; u++) {
-            const int idx = tid + NT * u;
-            if (idx < ROWS * C4) { const int ry = idx / C4, c4 = idx - ry * C4; pf[u] = *reinterpret_cast<const v4f*>(base + (size_t)ry * a.w + 4 * c4); }
-        }
-    };
-    int t = blockIdx.x;
-    int x0 = 0, y0 = 0, fr = 0;
-    bool cur_pf = false;
-    if (t < ntiles) { tile_origin(t, x0, y0, fr); cur_pf = is_interior(x0, y0); if (cur_pf) prefetch(x0, y0, fr); }
-    for (; t < ntiles; t += gridDim.x) {
-        // stage the current tile
-        if (cur_pf) {
-#pragma unroll
-            for (int u = 0; u < NPF; u++) { const int idx = tid + NT * u; if (idx < ROWS * C4) { const int ry = idx / C4, c4 = idx - ry * C4; s_in4[ry * P4 + c4] = pf[u]; } }
-        } else {
-            for (int idx = tid; idx < ROWS * COLS; idx += NT) {
-                const int ry = idx / COLS, rx = idx - ry * COLS;
-                const int gy = reflect101(y0 - R + ry, a.h), gx = reflect101(x0 - RA + rx, a.w);
-                float v;
-                if (BGR) v = load_base(a.bgr, a.bgr_ws, a.w >> 1, a.h >> 1, gx, gy);
-                else v = a.src[(size_t)fr * a.fstride + (size_t)gy * a.w + gx];
-                s_in[ry * (P4 * 4) + rx] = v;
-            }
-        }
-        __syncthreads();
-        // issue the next tile's loads
-        const int tn = t + gridDim.x;
-        int nx0 = 0, ny0 = 0, nfr = 0; bool next_pf = false;
-        if (tn < ntiles) { tile_origin(tn, nx0, ny0, nfr); next_pf = is_interior(nx0, ny0); if (next_pf) prefetch(nx0, ny0, nfr); }
-        // row pass: item = 4 adjacent outputs of one staged row; lanes walk the 16 groups of a row (contiguous 16 B slots)
-        for (int item = tid; item < ROWS * 16; item += NT) {
-            const int row = item >> 4, xg = item & 15;
-            const v4f* in4 = s_in4 + row * P4 + xg;
-            float e[NG * 4];
-#pragma unroll
-            for (int g = 0; g < NG; g++) { const v4f tt = in4[g]; e[4 * g] = tt.x; e[4 * g + 1] = tt.y; e[4 * g + 2] = tt.z; e[4 * g + 3] = tt.w; }
-            v2f acc01 = {0.0f, 0.0f}, acc23 = {0.0f, 0.0f};
-#pragma unroll
-            for (int i = 0; i <= 2 * R; i++) {
-                const v2f kk = {a.k[i], a.k[i]};
-                const v2f e01 = {e[S + i], e[S + i + 1]}, e23 = {e[S + i + 2], e[S + i + 3]};
-                acc01 = vfma(kk, e01, acc01);
-                acc23 = vfma(kk, e23, acc23);
-            }
-            v4f o; o.x = acc01.x; o.y = acc01.y; o.z = acc23.x; o.w = acc23.y;
-            s_mid4[row * (PMID / 4) + xg] = o;
-        }
-        __syncthreads();
-        // column pass: one item per lane = 4 columns x CR rows of outputs
-        {
-            const int xg = tid & 15, yg = tid >> 4;
-            const v4f* mid4 = s_mid4 + (CR * yg) * (PMID / 4) + xg;
-            v4f acc[CR];
-#pragma unroll
-            for (int q = 0; q < CR; q++) acc[q] = (v4f){0, 0, 0, 0};
-#pragma unroll
-            for (int m = 0; m < 2 * R + CR; m++) {
-                const v4f e = mid4[m * (PMID / 4)];
-#pragma unroll
-                for (int q = 0; q < CR; q++)
-                    if (m - q >= 0 && m - q <= 2 * R) { const float kq = a.k[m - q]; const v4f kk = {kq, kq, kq, kq}; acc[q] = vfma(kk, e, acc[q]); }
-            }
-            const int gx = x0 + 4 * xg, gy = y0 + CR * yg;
-            if (gx + 3 < a.w && vec_st) {
-                float* d = a.dst + (size_t)fr * a.fstride + (size_t)gy * a.w + gx;
-#pragma unroll
-                for (int q = 0; q < CR; q++) if (gy + q < a.h) *reinterpret_cast<v4f*>(d + (size_t)q * a.w) = acc[q];
-            } else {
-                for (int r = 0; r < CR; r++)
-                    for (int c = 0; c < 4; c++)
-                        if (gy + r < a.h && gx + c < a.w) a.dst[(size_t)fr * a.fstride + (size_t)(gy + r) * a.w + gx + c] = acc[r][c];
-            }
-        }
-        __syncthreads();                        // s_in / s_mid are rewritten by the next trip
-        x0 = nx0; y0 = ny0; fr = nfr; cur_pf = next_pf;
-    }
-}
-
-// ---- blur_stream: barrier-free streaming variant for the big levels ------------------------------------------------
-// Same arithmetic again (acc = 0; acc = fmaf(k[i], x[i], acc), ascending i, rows then columns).  One WAVE owns a strip
-// of 256 columns (4 per lane) and walks down L output rows of it: every input row is read once from HBM (prefetched D
-// rows ahead into registers), exchanged with the neighbour lanes through a wave-private LDS row (no workgroup barrier
-// anywhere: LDS operations of one wave execute in order), filtered horizontally from a sliding register window, and
-// scattered into the 2R+1 column accumulators that live in registers -- output row o receives its taps in ascending
-// order because the input rows arrive in ascending order.  The accumulator ring is NP >= 2R+1 slots and the row loop is
-// unrolled NP times, so every ring / prefetch index is a compile-time constant.
-// d = (k,k) * x + c with k the low / high float of an SGPR pair: op_sel broadcasts one half of the scalar operand, so the
-// 2R+1 taps cost R+1 SGPR pairs (the compiler's own lowering materialises a (k,k) pair per tap and runs out of SGPRs)
-__device__ __forceinline__ void pkfma_klo(v2f kp, v2f x, v2f& c) { asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(c) : "s"(kp), "v"(x)); }
-__device__ __forceinline__ void pkfma_khi(v2f kp, v2f x, v2f& c) { asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(c) : "s"(kp), "v"(x)); }
-// first tap of a chain: d = (k,k) * x + 0 (low half of the pair: tap 0)
-__device__ __forceinline__ v2f pkfma_klo0(v2f kp, v2f x) { v2f d; asm("v_pk_fma_f32 %0, %1, %2, 0 op_sel_hi:[0,1,0]" : "=v"(d) : "s"(kp), "v"(x)); return d; }
-
 // compile-time row loop (the unrolled body must see its ring slot as a constant; #pragma unroll gives up on bodies this large)
 template <int J, int NPP, class F> __device__ __forceinline__ bool static_rows(F& f) {
     if constexpr (J < NPP) { if (!f(std::integral_constant<int, J>{})) return false; return static_rows<J + 1, NPP>(f); }
     else return true;
 }
 
-// fixed-point gray of the frame as u8 (the values are integers 0..255): gray[y * gp + GPAD + x], x in [-GPAD, w + GPAD).
-// The padding continues the row so that the 2x doubling of the PADDED row is the reflect-101 continuation of the doubled
-// row: gray[-k] = gray[k] on the left, gray[w + i] = gray[w - 1 - i] on the right (the doubled row ends with a replicated
-// column, so its mirror axis sits on gray column w - 1/2).  Kernels that form doubled columns on the fly therefore never
-// test for the image border.
-constexpr int GPAD = 32;
-__global__ __launch_bounds__(256) void gray_pad_kernel(const uint8_t* bgr, int ws, int w, int h, uint8_t* gray, int gp) {
-    // 4 pixels per lane: 12 source bytes (three dwords when the row and the group are 4-byte aligned), one dword store
-    const int g = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
-    const int xp = 4 * g;                            // first padded column of the group; gp is a multiple of 16
-    if (xp >= gp) return;
-    const uint8_t* row = bgr + (size_t)y * ws;
-    unsigned out = 0;
-    const int x0 = xp - GPAD;
-    if (x0 >= 0 && x0 + 3 <= w - 1 && (((uintptr_t)row | (unsigned)ws) & 3) == 0) {
-        const unsigned* q = reinterpret_cast<const unsigned*>(row + 3 * x0);     // 3 * x0 is a multiple of 12
-        const unsigned d0 = q[0], d1 = q[1], d2 = q[2];
-        const int b0 = d0 & 255, g0 = (d0 >> 8) & 255, r0 = (d0 >> 16) & 255, b1 = d0 >> 24;
-        const int g1 = d1 & 255, r1 = (d1 >> 8) & 255, b2 = (d1 >> 16) & 255, g2 = d1 >> 24;
-        const int r2 = d2 & 255, b3 = (d2 >> 8) & 255, g3 = (d2 >> 16) & 255, r3 = d2 >> 24;
-        out = (unsigned)((1868 * b0 + 9617 * g0 + 4899 * r0 + 8192) >> 14) | ((unsigned)((1868 * b1 + 9617 * g1 + 4899 * r1 + 8192) >> 14) << 8) |
-              ((unsigned)((1868 * b2 + 9617 * g2 + 4899 * r2 + 8192) >> 14) << 16) | ((unsigned)((1868 * b3 + 9617 * g3 + 4899 * r3 + 8192) >> 14) << 24);
-    } else {
+// ---------- K1/K2: separable Gaussian, 16S -> 32F -> 16S ------------------------------------------------------------------------
+// Arithmetic (oracle_sift.c gauss_blur16; OpenCV's RowFilter<short,float> + SymmColumnFilter<Cast<float,short>>), products and sums
+// rounded separately (this translation unit is compiled with -ffp-contract=off; nothing below may become an fma):
+//   row     t(x) = k[0] * S(x - R);  t(x) += k[i] * S(x - R + i)            for i = 1 .. 2R
+//   column  s    = k[R] * t(y);      s    += k[R + j] * (t(y + j) + t(y - j)) for j = 1 .. R;   out = round-half-even(s) in 16 bits
+// borders reflect-101.
+struct Blur16Args {
+    const lvl_t* src;                        // source level (w x h), frame f at src + f * fstride
+    const uint8_t* bgr[SIFT_BATCH_MAX];      // BGR = true: the caller's frames (w x h, row stride bgr_ws[f] bytes)
+    int bgr_ws[SIFT_BATCH_MAX];
+    lvl_t* dst;                              // frame f at dst + f * fstride
+    lvl_t* ds;                               // not NULL: also write the 2x decimated level (even rows, even columns): the next octave's base
+    int w, h;
+    int tiles_x, tiles_y;
+    float k[2 * MAX_R + 1];
+    size_t fstride;                          // samples between the frames of a batch
+    int nb;                                  // frames in the launch
+};
+
+constexpr int T16W = 64, T16H = 32;
+template <int R, bool BGR>
+__global__ __launch_bounds__(256) void blur16_tile(Blur16Args a) {
+    constexpr int ROWS = T16H + 2 * R, COLS = T16W + 2 * R, PIN = COLS | 1, PMID = T16W + 4;
+    __shared__ float s_in[ROWS * PIN];
+    __shared__ __attribute__((aligned(16))) float s_mid[ROWS * PMID];
+    const int tid = threadIdx.x, fr = blockIdx.y;
+    const int tile = xcd_remap(blockIdx.x, a.tiles_x * a.tiles_y);
+    const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
+    const int x0 = tx * T16W, y0 = ty * T16H;
+    const lvl_t* src = BGR ? nullptr : a.src + (size_t)fr * a.fstride;
+    const uint8_t* bgr = a.bgr[0]; int bws = a.bgr_ws[0];
+    if (BGR) {
 #pragma unroll
-        for (int c = 0; c < 4; c++) {
-            int x = x0 + c;
-            x = x < 0 ? -x : (x > w - 1 ? 2 * w - 1 - x : x);
-            x = x < 0 ? 0 : (x > w - 1 ? w - 1 : x);
-            const uint8_t* p = row + 3 * x;
-            out |= (unsigned)((1868 * (int)p[0] + 9617 * (int)p[1] + 4899 * (int)p[2] + 8192) >> 14) << (8 * c);
+        for (int q = 1; q < SIFT_BATCH_MAX; q++) if (fr == q) { bgr = a.bgr[q]; bws = a.bgr_ws[q]; }
+    }
+    lvl_t* dst = a.dst + (size_t)fr * a.fstride;
+    for (int idx = tid; idx < ROWS * COLS; idx += 256) {
+        const int ry = idx / COLS, rx = idx - ry * COLS;
+        const int gy = reflect101(y0 - R + ry, a.h), gx = reflect101(x0 - R + rx, a.w);
+        s_in[ry * PIN + rx] = BGR ? gray48(bgr + (size_t)gy * bws + 3 * gx) : ld1(src + (size_t)gy * a.w + gx);
+    }
+    __syncthreads();
+    // row pass: 4 adjacent outputs per item from a sliding window
+    for (int item = tid; item < ROWS * (T16W / 4); item += 256) {
+        const int xg = item / ROWS, row = item - xg * ROWS;
+        const float* in = s_in + row * PIN + 4 * xg;
+        float e[2 * R + 4];
+#pragma unroll
+        for (int m = 0; m < 2 * R + 4; m++) e[m] = in[m];
+        float acc[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) acc[q] = a.k[0] * e[q];
+#pragma unroll
+        for (int i = 1; i <= 2 * R; i++) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) { const float p = a.k[i] * e[q + i]; acc[q] = acc[q] + p; }
+        }
+        *reinterpret_cast<v4f*>(s_mid + row * PMID + 4 * xg) = (v4f){acc[0], acc[1], acc[2], acc[3]};
+    }
+    __syncthreads();
+    // column pass: centre tap, then the symmetric pairs outwards; one output row x 4 columns per item
+    for (int item = tid; item < T16H * (T16W / 4); item += 256) {
+        const int yy = item / (T16W / 4), xg = item - yy * (T16W / 4);
+        const float* mid = s_mid + (yy + R) * PMID + 4 * xg;
+        v4f acc = *reinterpret_cast<const v4f*>(mid) * a.k[R];
+#pragma unroll
+        for (int j = 1; j <= R; j++) {
+            const v4f sm = *reinterpret_cast<const v4f*>(mid + j * PMID) + *reinterpret_cast<const v4f*>(mid - j * PMID);
+            const v4f p = sm * a.k[R + j];
+            acc = acc + p;
+        }
+        const int gx = x0 + 4 * xg, gy = y0 + yy;
+        if (gy >= a.h) continue;
+        const int o0 = sat16(acc.x), o1 = sat16(acc.y), o2 = sat16(acc.z), o3 = sat16(acc.w);
+        lvl_t* d = dst + (size_t)gy * a.w + gx;
+        if (gx + 3 < a.w && (a.w & 3) == 0) {
+            *reinterpret_cast<uint2*>(d) = make_uint2((unsigned)(o0 & 0xffff) | ((unsigned)o1 << 16), (unsigned)(o2 & 0xffff) | ((unsigned)o3 << 16));
+        } else {
+            if (gx < a.w) d[0] = (lvl_t)o0;
+            if (gx + 1 < a.w) d[1] = (lvl_t)o1;
+            if (gx + 2 < a.w) d[2] = (lvl_t)o2;
+            if (gx + 3 < a.w) d[3] = (lvl_t)o3;
+        }
+        if (a.ds && !(gy & 1) && (gy >> 1) < (a.h >> 1)) {
+            lvl_t* q = a.ds + (size_t)fr * a.fstride + (size_t)(gy >> 1) * (a.w >> 1);
+            if ((gx >> 1) < (a.w >> 1)) q[gx >> 1] = (lvl_t)o0;
+            if (((gx + 2) >> 1) < (a.w >> 1)) q[(gx + 2) >> 1] = (lvl_t)o2;
         }
     }
-    *reinterpret_cast<unsigned*>(gray + (size_t)y * gp + xp) = out;
 }
 
-// UPS = true: the source is the padded u8 gray of the frame and the level being blurred is its 2x linear doubling (grids
-// aligned at pixel (0, 0), edge replicated: load_base above), formed on the fly -- every sum is exact in binary32, so the
-// order of evaluation is free.
-template <int R, int D, bool UPS>
-__device__ __forceinline__ void blur_stream_body(BlurArgs a, int L, int nstrip, int nseg) {
+// ---- blur16_stream: barrier-free streaming variant for the big levels ---------------------------------------------------------------
+// Same arithmetic.  One WAVE owns a strip of 256 columns (4 per lane) and walks down L output rows of it: every input row is read
+// once from HBM (prefetched D rows ahead into registers), exchanged with the neighbour lanes through a wave-private LDS row (no
+// workgroup barrier anywhere: LDS operations of one wave execute in order), filtered horizontally from a sliding register window,
+// and kept in a register ring of the last NP >= 2R+1 row results; output row y leaves when row y + R has arrived, its taps taken
+// from the ring centre first, then the pairs (y + j, y - j).  The row loop is unrolled NP times, so every ring / prefetch index is a
+// compile-time constant.
+template <int R, int D, bool BGR>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void blur16_stream(Blur16Args a, int L, int nstrip, int nseg) {
     constexpr int N = 2 * R + 1;
     constexpr int NP0 = ((N + D - 1) / D) * D;
     constexpr int NP = (NP0 & 1) ? NP0 + D : NP0;   // even (two LDS rows alternate) and a multiple of D
     constexpr int RA = (R + 3) & ~3, S = RA - R, SW = 256, BW = SW + 2 * RA;
     constexpr int NG = (S + 2 * R + 4 + 3) / 4;
     static_assert(NP % D == 0 && NP % 2 == 0 && NP >= N, "ring");
+    static_assert((D % 2 == 0) || true, "prefetch depth");
     __shared__ v4f s_buf[4][2][(BW + 64) / 4];      // + 64 floats: dump area for lanes that have no halo / fix-up work
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int unit = xcd_remap(blockIdx.x, gridDim.x) * 4 + wave;
-    {                                                // batched launch: the unit list runs over all frames
-        const int per = nstrip * nseg, fr = unit / per;
-        if (fr >= (a.nb > 1 ? a.nb : 1)) return;
-        unit -= fr * per;
-        if (UPS) a.bgr += (size_t)fr * a.gstride; else a.src += (size_t)fr * a.fstride;
-        a.dst += (size_t)fr * a.fstride;
-        if (a.ds) a.ds += (size_t)fr * a.fstride;
+    const int per = nstrip * nseg, fr = unit / per;
+    if (fr >= a.nb) return;
+    unit -= fr * per;
+    const lvl_t* src = BGR ? nullptr : a.src + (size_t)fr * a.fstride;
+    const uint8_t* bgr = a.bgr[0]; int bws = a.bgr_ws[0];
+    if (BGR) {
+#pragma unroll
+        for (int q = 1; q < SIFT_BATCH_MAX; q++) if (fr == q) { bgr = a.bgr[q]; bws = a.bgr_ws[q]; }
     }
+    lvl_t* dst = a.dst + (size_t)fr * a.fstride;
+    lvl_t* ds = a.ds ? a.ds + (size_t)fr * a.fstride : nullptr;
     const int seg = unit / nstrip, strip = unit - seg * nstrip;
     if (seg >= nseg) return;
-    const int x0 = strip * SW, y0 = a.band ? (seg ? a.h - a.band : 0) : seg * L;
-    const int lact = a.band ? a.band : ((a.h - y0 < L) ? a.h - y0 : L);
+    const int x0 = strip * SW, y0 = seg * L;
+    const int lact = (a.h - y0 < L) ? a.h - y0 : L;
     const int nin = lact + 2 * R;
-    // columns: main float4 (clamped into the row for a partial last strip), one halo dword per lane (reflect-101),
-    // and for a partial last strip the reflected columns right of the image are patched inside LDS
+    // columns: the lane's own four (clamped into the row for a partial last strip), one halo sample per lane (reflect-101), and for a
+    // partial last strip the reflected columns right of the image are patched inside LDS
     const int xm = x0 + 4 * lane;
     const int xl = xm < a.w - 4 ? xm : a.w - 4;
     const int chalo = reflect101((lane < RA) ? x0 - RA + lane : (lane < 2 * RA ? x0 + SW + (lane - RA) : x0), a.w);
@@ -431,54 +225,42 @@ __device__ __forceinline__ void blur_stream_body(BlurArgs a, int L, int nstrip, 
         gy = gy > hm1 ? 2 * hm1 - gy : gy;
         return gy < 0 ? 0 : gy;
     };
-    // ---- prefetch ring: raw source data of the next D steps ----
-    struct Raw { v4f m; float h; unsigned ma, mb, ha, hb; };
-    const int gmain = GPAD + (xl >> 1) - 1;                                // UPS: byte column of the 4 gray pixels c-1..c+2 (c = xl / 2)
-    const int ghalo = GPAD + (chalo >> 1);                                 // UPS: byte column of the halo pixel pair
-    const bool hodd = (chalo & 1) != 0;
-    const int hl1 = (a.h >> 1) - 1;
+    struct Raw { unsigned m0, m1, m2; unsigned h; };          // level: m0 m1 = four samples, h = one; BGR: m0 m1 m2 = 12 bytes, h = 3 bytes
     auto load_raw = [&](int i, Raw& r) {
         const int gy = src_row(i);
-        if constexpr (UPS) {
-            const int ya = gy >> 1;                          // doubled row gy: gray row gy / 2, odd rows the mean with the next one
-            int yb = (gy & 1) ? ya + 1 : ya;
-            yb = yb > hl1 ? hl1 : yb;
-            const uint8_t* ra = a.bgr + (size_t)ya * a.bgr_ws;
-            const uint8_t* rb = a.bgr + (size_t)yb * a.bgr_ws;
-            unsigned short ta, tb;
-            __builtin_memcpy(&r.ma, ra + gmain, 4); __builtin_memcpy(&r.mb, rb + gmain, 4);
-            __builtin_memcpy(&ta, ra + ghalo, 2); __builtin_memcpy(&tb, rb + ghalo, 2);
-            r.ha = ta; r.hb = tb;
+        if constexpr (BGR) {
+            const uint8_t* rp = bgr + (size_t)gy * bws;
+            const unsigned* q = reinterpret_cast<const unsigned*>(rp + 3 * xl);       // 3 * xl is a multiple of 12; rows are 4-byte aligned (launcher)
+            r.m0 = q[0]; r.m1 = q[1]; r.m2 = q[2];
+            const uint8_t* hp = rp + 3 * chalo;
+            r.h = (unsigned)hp[0] | ((unsigned)hp[1] << 8) | ((unsigned)hp[2] << 16);
         } else {
-            const float* rp = a.src + (size_t)gy * a.w;
-            r.m = *reinterpret_cast<const v4f*>(rp + xl); r.h = rp[chalo];
+            const lvl_t* rp = src + (size_t)gy * a.w;
+            const uint2 q = *reinterpret_cast<const uint2*>(rp + xl);
+            r.m0 = q.x; r.m1 = q.y; r.m2 = 0;
+            r.h = (unsigned)(unsigned short)rp[chalo];
         }
     };
-    auto row_values = [&](int i, const Raw& r, v4f& m, float& hv) {
-        if constexpr (UPS) {
-            // grids aligned at pixel (0, 0): doubled column 2c is gray column c, 2c + 1 the mean of c and c + 1 (load_base); rows
-            // likewise through ya / yb (ya == yb on even rows: (x + x) / 2 = x).  All sums exact in binary32.
-            auto hrow = [&](unsigned q, v4f& o) {
-                const float b1 = (float)((q >> 8) & 255u), b2 = (float)((q >> 16) & 255u), b3 = (float)(q >> 24);
-                o.x = b1; o.y = (b1 + b2) * 0.5f; o.z = b2; o.w = (b2 + b3) * 0.5f;
-            };
-            v4f ha4, hb4;
-            hrow(r.ma, ha4); hrow(r.mb, hb4);
-            m.x = (ha4.x + hb4.x) * 0.5f; m.y = (ha4.y + hb4.y) * 0.5f; m.z = (ha4.z + hb4.z) * 0.5f; m.w = (ha4.w + hb4.w) * 0.5f;
-            const float a0 = (float)(r.ha & 255u), a1 = (float)(r.ha >> 8), c0 = (float)(r.hb & 255u), c1 = (float)(r.hb >> 8);
-            const float qa = hodd ? (a0 + a1) * 0.5f : a0, qb = hodd ? (c0 + c1) * 0.5f : c0;
-            hv = (qa + qb) * 0.5f;
-        } else { m = r.m; hv = r.h; }
+    auto row_values = [&](const Raw& r, v4f& m, float& hv) {
+        if constexpr (BGR) {
+            auto g = [](unsigned b, unsigned gg, unsigned rr) { return (float)((int)((1868u * b + 9617u * gg + 4899u * rr + 8192u) >> 14) * FIXPT_SCALE); };
+            m.x = g(r.m0 & 255u, (r.m0 >> 8) & 255u, (r.m0 >> 16) & 255u);
+            m.y = g(r.m0 >> 24, r.m1 & 255u, (r.m1 >> 8) & 255u);
+            m.z = g((r.m1 >> 16) & 255u, r.m1 >> 24, r.m2 & 255u);
+            m.w = g((r.m2 >> 8) & 255u, (r.m2 >> 16) & 255u, r.m2 >> 24);
+            hv = g(r.h & 255u, (r.h >> 8) & 255u, (r.h >> 16) & 255u);
+        } else {
+            m.x = (float)(int)(short)(r.m0 & 0xffffu); m.y = (float)((int)r.m0 >> 16);
+            m.z = (float)(int)(short)(r.m1 & 0xffffu); m.w = (float)((int)r.m1 >> 16);
+            hv = (float)(int)(short)(r.h & 0xffffu);
+        }
     };
     Raw pf[D];
 #pragma unroll
     for (int d = 0; d < D; d++) load_raw(d < nin ? d : nin - 1, pf[d]);
-    v2f acc01[NP], acc23[NP];
+    v2f ring01[NP], ring23[NP];
 #pragma unroll
-    for (int q = 0; q < NP; q++) { acc01[q] = (v2f){0.0f, 0.0f}; acc23[q] = (v2f){0.0f, 0.0f}; }
-    v2f kp[R + 1];
-#pragma unroll
-    for (int m = 0; m <= R; m++) { kp[m].x = a.k[2 * m]; kp[m].y = (2 * m + 1 <= 2 * R) ? a.k[2 * m + 1] : 0.0f; }
+    for (int q = 0; q < NP; q++) { ring01[q] = (v2f){0.0f, 0.0f}; ring23[q] = (v2f){0.0f, 0.0f}; }
     float* const bufs = reinterpret_cast<float*>(&s_buf[wave][0][0]);
     for (int base = 0; base < nin; base += NP) {
         auto step = [&](auto jc) -> bool {
@@ -488,7 +270,7 @@ __device__ __forceinline__ void blur_stream_body(BlurArgs a, int L, int nstrip, 
             float* buf = bufs + (j & 1) * (BW + 64);
             {
                 v4f m; float hv;
-                row_values(i, pf[j % D], m, hv);
+                row_values(pf[j % D], m, hv);
                 *reinterpret_cast<v4f*>(buf + RA + 4 * lane) = m;
                 buf[hpos] = hv;
             }
@@ -504,29 +286,39 @@ __device__ __forceinline__ void blur_stream_body(BlurArgs a, int L, int nstrip, 
             float e[NG * 4];
 #pragma unroll
             for (int g = 0; g < NG; g++) { const v4f tt = w4[g]; e[4 * g] = tt.x; e[4 * g + 1] = tt.y; e[4 * g + 2] = tt.z; e[4 * g + 3] = tt.w; }
+            // row pass: ascending taps, product and sum rounded separately
             v2f r01, r23;
-#pragma unroll
-            for (int t = 0; t <= 2 * R; t++) {
-                const v2f e01 = {e[S + t], e[S + t + 1]}, e23 = {e[S + t + 2], e[S + t + 3]};
-                if (t == 0) { r01 = pkfma_klo0(kp[0], e01); r23 = pkfma_klo0(kp[0], e23); }
-                else if (t & 1) { pkfma_khi(kp[t >> 1], e01, r01); pkfma_khi(kp[t >> 1], e23, r23); }
-                else { pkfma_klo(kp[t >> 1], e01, r01); pkfma_klo(kp[t >> 1], e23, r23); }
+            {
+                const v2f kk = {a.k[0], a.k[0]};
+                r01 = kk * (v2f){e[S], e[S + 1]}; r23 = kk * (v2f){e[S + 2], e[S + 3]};
             }
 #pragma unroll
-            for (int t = 0; t <= 2 * R; t++) {
-                const int slot = ((j - t) % NP + NP) % NP;
-                if (t == 0) { acc01[slot] = pkfma_klo0(kp[0], r01); acc23[slot] = pkfma_klo0(kp[0], r23); }
-                else if (t & 1) { pkfma_khi(kp[t >> 1], r01, acc01[slot]); pkfma_khi(kp[t >> 1], r23, acc23[slot]); }
-                else { pkfma_klo(kp[t >> 1], r01, acc01[slot]); pkfma_klo(kp[t >> 1], r23, acc23[slot]); }
+            for (int t = 1; t <= 2 * R; t++) {
+                const v2f kk = {a.k[t], a.k[t]};
+                const v2f p01 = kk * (v2f){e[S + t], e[S + t + 1]}, p23 = kk * (v2f){e[S + t + 2], e[S + t + 3]};
+                r01 = r01 + p01; r23 = r23 + p23;
             }
+            ring01[j % NP] = r01; ring23[j % NP] = r23;
             if (i >= 2 * R) {
-                const int slot = ((j - 2 * R) % NP + NP) % NP;
-                const v4f o = {acc01[slot].x, acc01[slot].y, acc23[slot].x, acc23[slot].y};
+                // column pass of output row i - 2R: ring slots of rows (i - R) +- jj
+                constexpr int c = ((j - R) % NP + NP) % NP;
+                v2f s01, s23;
+                { const v2f kk = {a.k[R], a.k[R]}; s01 = kk * ring01[c]; s23 = kk * ring23[c]; }
+#pragma unroll
+                for (int jj = 1; jj <= R; jj++) {
+                    const int up = ((j - R + jj) % NP + NP) % NP, dn = ((j - R - jj) % NP + NP) % NP;
+                    const v2f kk = {a.k[R + jj], a.k[R + jj]};
+                    const v2f a01 = ring01[up] + ring01[dn], a23 = ring23[up] + ring23[dn];
+                    const v2f p01 = kk * a01, p23 = kk * a23;
+                    s01 = s01 + p01; s23 = s23 + p23;
+                }
+                const int o0 = sat16(s01.x), o1 = sat16(s01.y), o2 = sat16(s23.x), o3 = sat16(s23.y);
                 const int gy = y0 + i - 2 * R;
-                if (xm < a.w) *reinterpret_cast<v4f*>(a.dst + (size_t)gy * a.w + xm) = o;
-                if (!UPS && a.ds && !(gy & 1) && xm < a.w && (gy >> 1) < (a.h >> 1)) {
-                    const v2f d2 = {o.x, o.z};
-                    *reinterpret_cast<v2f*>(a.ds + (size_t)(gy >> 1) * (a.w >> 1) + (xm >> 1)) = d2;
+                if (xm < a.w) {
+                    *reinterpret_cast<uint2*>(dst + (size_t)gy * a.w + xm) =
+                        make_uint2((unsigned)(o0 & 0xffff) | ((unsigned)o1 << 16), (unsigned)(o2 & 0xffff) | ((unsigned)o3 << 16));
+                    if (ds && !(gy & 1) && (gy >> 1) < (a.h >> 1))
+                        *reinterpret_cast<unsigned*>(ds + (size_t)(gy >> 1) * (a.w >> 1) + (xm >> 1)) = (unsigned)(o0 & 0xffff) | ((unsigned)o2 << 16);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);       // keep the rows apart: the scheduler otherwise interleaves them and spills
@@ -536,516 +328,15 @@ __device__ __forceinline__ void blur_stream_body(BlurArgs a, int L, int nstrip, 
     }
 }
 
-template <int R, int D, bool UPS>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void blur_stream(BlurArgs a, int L, int nstrip, int nseg) {
-    blur_stream_body<R, D, UPS>(a, L, nstrip, nseg);
-}
-// the same code under its own name for the band launches (the first / last rows of levels a chain pass produced): traces and
-// counter collections of blur_stream then hold the full-level launches only
-template <int R, int D, bool UPS>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void blur_band(BlurArgs a, int L, int nstrip, int nseg) {
-    blur_stream_body<R, D, UPS>(a, L, nstrip, nseg);
-}
-
-// ---- pyr_cascade: ALL Gaussian levels of one octave in one pass (option "sift_cascade", default off) ----------------------
-// The per-level kernels above move every level through HBM twice (written by one launch, read by the next).  Here a
-// workgroup keeps a 512-column strip of ALL levels of the octave in flight and walks down the rows once: every level row is
-// written to HBM once and handed to the next level through LDS, never read back (6 level writes per octave instead of
-// 6 writes + 5 reads).  Same arithmetic as everywhere else (acc = 0; acc = fmaf(k[i], x[i], acc), ascending i, rows then
-// columns), so the bits do not change (tests/test_gpu_configs.py runs the 12 MP parity check with the option on).
-//   * one WAVE = one level of one pipeline (256 columns, 4 per lane): its column accumulators live in registers exactly like
-//     blur_stream's.  Octave 0: 12 waves = 2 pipelines x {doubling + L0, L1 .. L5}; other octaves: 10 waves = 2 x {L0 load + L1,
-//     L2 .. L5}.  Waves w, w + 4, w + 8 share a SIMD (measured); the role table gives every SIMD the same number of packed
-//     FMAs per row (211 / 204 / 211 / 204 resp. 180 / 180 / 176 / 176).
-//   * one s_barrier per row step: at step t a level reads the row its producer completed at step t - 1 (double-buffered LDS
-//     rows of the whole strip: the halo columns come from the neighbour pipeline's wave) and completes its own row t - lag.
-//     Inside a wave the window load of step t is issued first and hides behind the column pass of step t - 1's row.
-//   * the accumulator ring is 2R + U slots; the row loop is unrolled U = 8 times (compile-time slots) and the 2R live slots
-//     move down once per U rows, which keeps each loop at ~10 KB of code instead of a full ring period.
-//   * columns: the strip origin is 48 columns left of the 416 columns it stores (sum of the radii = 47); the computed columns
-//     outside that are the shrinking halo.  At the image's left / right edge the lanes owning columns 1..16 / w-17..w-2 also
-//     write their reflect-101 mirror positions into the LDS row, the out-of-image lanes write nothing: every level sees
-//     exactly BORDER_REFLECT_101 of the previous one.
-//   * rows: only rows [48, h - 48) are produced here (no vertical reflection inside the pipeline: the order in which a
-//     reflected row enters an accumulator matters for the bits); the 48 rows at the top and bottom of every level are done
-//     afterwards by blur_stream in band mode, level by level.
-// MEASURED (MI355X, 8 frames 4000x3000 per launch, scratch/casc_time.py): the three cascade launches (octaves 0-2) take 5.6 ms
-// against 5.45 ms for the 26 per-level launches they replace (+0.5 ms for the band launches): the pass is VALU-bound where
-// the per-level kernels are HBM-bound.  v_pk_fma_f32 issues at 4 cycles per wave64 (scratch/pkfma_bench.hip: same FMA rate as
-// v_fma_f32 at 2), the 400 packed FMAs per 256-pixel row of a pipeline need 146 us per 12 MP frame at full issue rate, the
-// strip / segment overlap costs x1.45 (416 of 512 columns, 738 of 844 rows), the non-FMA instructions (window shuffles, ring
-// moves, stores) another x1.5; rocprofv3 --pmc: VALU busy 47 %, waves parked (barrier / lgkmcnt) 41 % of their cycles for the
-// 4-stage variant, ~68 % VALU busy for this one.  End to end (bench.py C3) 951 pairs/s with the option on against 969 off,
-// so it stays off; variants tried: 2 and 3 pipelines x 4 two-level stages (5.9 / 5.3 ms), U = 2 / 4 / 8 (no difference: not
-// instruction-cache bound), mirror writes behind a wave-uniform flag (1.5x slower).
-namespace casc {
-constexpr int NPIPE = 2, WGW = 256 * NPIPE, HC = 48, SV = WGW - 2 * HC, BUFO = 16, BUFW = WGW + 2 * BUFO, VB = 48;
-struct Args {
-    const uint8_t* gray; int gp; size_t gstride; int gh;   // octave 0: padded gray frames (gray_pad_kernel), pitch, frame stride (bytes), rows
-    const float* src0;                                       // other octaves: level 0 (read)
-    float* lv[N_LEVELS];                                     // levels written (octave 0: 0..5, others 1..5)
-    float* ds;                                               // 2x decimated level 3 = the next octave's level 0, or null
-    size_t fstride; int nb;                                  // frame f at + f * fstride (floats)
-    int w, h;                                                // level size
-    int nstrip, nseg, lseg;
-    float k[N_LEVELS][2 * MAX_R + 2];                        // taps of level i (k[0] = the base blur; unused for the other octaves)
-};
-
-// one level, one row step, in three pieces so that the LDS latency of this step's window hides behind the column pass of the
-// PREVIOUS step's row (software pipelining inside the wave; costs one more step of lag per level):
-//   win_load : the lane's window of the incoming row (LDS -> registers), issued first
-//   col_pass : scatter the row-filtered previous row into the column accumulators; returns the completed row.
-//              Slot of output row o at local step J: tap t goes to slot J + 2R - t (tap 0 opens slot J + 2R, tap 2R closes slot J).
-//   row_pass : row filter of the window -> (r01, r23), consumed by the next step's col_pass
-template <int R> struct Win { static constexpr int RA = (R + 3) & ~3, S = RA - R, NG = (S + 2 * R + 4 + 3) / 4; float e[NG * 4]; };
-template <int R> __device__ __forceinline__ void win_load(const float* row, int c, Win<R>& w) {
-    const v4f* w4 = reinterpret_cast<const v4f*>(row + (c - Win<R>::RA + BUFO));
-#pragma unroll
-    for (int g = 0; g < Win<R>::NG; g++) { const v4f tt = w4[g]; w.e[4 * g] = tt.x; w.e[4 * g + 1] = tt.y; w.e[4 * g + 2] = tt.z; w.e[4 * g + 3] = tt.w; }
-}
-template <int R> __device__ __forceinline__ void row_pass(const Win<R>& w, const v2f (&kp)[R + 1], v2f& r01, v2f& r23) {
-    constexpr int S = Win<R>::S;
-#pragma unroll
-    for (int t = 0; t <= 2 * R; t++) {
-        const v2f e01 = {w.e[S + t], w.e[S + t + 1]}, e23 = {w.e[S + t + 2], w.e[S + t + 3]};
-        if (t == 0) { r01 = pkfma_klo0(kp[0], e01); r23 = pkfma_klo0(kp[0], e23); }
-        else if (t & 1) { pkfma_khi(kp[t >> 1], e01, r01); pkfma_khi(kp[t >> 1], e23, r23); }
-        else { pkfma_klo(kp[t >> 1], e01, r01); pkfma_klo(kp[t >> 1], e23, r23); }
-    }
-}
-template <int R, int U, int J>
-__device__ __forceinline__ v4f col_pass(const v2f r01, const v2f r23, v2f (&a01)[2 * R + U], v2f (&a23)[2 * R + U], const v2f (&kp)[R + 1]) {
-#pragma unroll
-    for (int t = 0; t <= 2 * R; t++) {
-        const int slot = J + 2 * R - t;
-        if (t == 0) { a01[slot] = pkfma_klo0(kp[0], r01); a23[slot] = pkfma_klo0(kp[0], r23); }
-        else if (t & 1) { pkfma_khi(kp[t >> 1], r01, a01[slot]); pkfma_khi(kp[t >> 1], r23, a23[slot]); }
-        else { pkfma_klo(kp[t >> 1], r01, a01[slot]); pkfma_klo(kp[t >> 1], r23, a23[slot]); }
-    }
-    return (v4f){a01[J].x, a01[J].y, a23[J].x, a23[J].y};
-}
-template <int R, int U> __device__ __forceinline__ void ring_shift(v2f (&a01)[2 * R + U], v2f (&a23)[2 * R + U]) {
-#pragma unroll
-    for (int q = 0; q < 2 * R; q++) { a01[q] = a01[q + U]; a23[q] = a23[q + U]; }
-}
-template <int R, int U> __device__ __forceinline__ void ring_zero(v2f (&a01)[2 * R + U], v2f (&a23)[2 * R + U]) {
-#pragma unroll
-    for (int q = 0; q < 2 * R + U; q++) { a01[q] = (v2f){0.0f, 0.0f}; a23[q] = (v2f){0.0f, 0.0f}; }
-}
-template <int R> __device__ __forceinline__ void load_taps(const float* k, v2f (&kp)[R + 1]) {
-#pragma unroll
-    for (int m = 0; m <= R; m++) { kp[m].x = k[2 * m]; kp[m].y = (2 * m + 1 <= 2 * R) ? k[2 * m + 1] : 0.0f; }
-}
-// a level row into its LDS row buffer: own columns (in-image lanes only) plus the reflect-101 copies beyond the image's left /
-// right edge (lanes owning columns 1..16 / w-17..w-2).  The predicates are loop invariant lane masks; a wave without such a
-// lane skips the block with one branch.  (A variant that hid the index arithmetic behind a wave-uniform flag ran 1.5x slower.)
-__device__ __forceinline__ void put_row(float* buf, int c, int x, int w, v4f o, int bufw = BUFW) {
-    if (x >= 0 && x < w) {
-        *reinterpret_cast<v4f*>(buf + BUFO + c) = o;
-        if (x <= 16 || x + 3 >= w - 17) {
-            const float v[4] = {o.x, o.y, o.z, o.w};
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const int xx = x + q;
-                if (xx >= 1 && xx <= 16 && BUFO + c + q - 2 * xx >= 0) buf[BUFO + c + q - 2 * xx] = v[q];
-                if (xx >= w - 17 && xx <= w - 2) { const int idx = BUFO + c + q + 2 * (w - 1 - xx); if (idx < bufw) buf[idx] = v[q]; }
-            }
-        }
-    }
-}
-__device__ __forceinline__ void step_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-}  // namespace casc
-
-// one wave = one level of one pipeline (octave 0: wave 0 of a pipeline also forms the doubled gray rows; other octaves: the
-// wave of level 1 also moves level 0 from HBM into LDS).  NW waves per workgroup: 12 (octave 0: 6 levels x 2 pipelines) / 10.
-template <bool OCT0>
-__global__ __launch_bounds__(OCT0 ? 768 : 640) __attribute__((amdgpu_waves_per_eu(3, 3))) void pyr_cascade(casc::Args a) {
-    using namespace casc;
-    constexpr int RR[N_LEVELS] = {5, 5, 6, 8, 10, 13};
-    // lag of level i: step t completes row ys + t - G[i]   (a level's column pass runs one step behind its row pass, and a
-    // level reads the row its producer completed in the previous step: + 2 + R per level)
-    constexpr int G0 = OCT0 ? RR[0] + 1 : -1, G1 = OCT0 ? G0 + 2 + RR[1] : RR[1] + 1, G2 = G1 + 2 + RR[2], G3 = G2 + 2 + RR[3], G4 = G3 + 2 + RR[4], G5 = G4 + 2 + RR[5];
-    __shared__ __attribute__((aligned(16))) float s_row[6][2][BUFW];          // [0] = the doubled gray (octave 0), [1 + i] = level i
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    // role table: waves w, w + 4, w + 8 share a SIMD (measured: scratch/hwid.hip).  Packed FMAs per row and level:
-    // 59 (doubling + level 0) 44 52 68 84 108.   octave 0: {L5 F0 L1} {L5 L2 L1} {L4 L3 F0} {L4 L3 L2} = 211 / 204 / 211 / 204
-    //                                            others:   {L4 L2 L1} {L4 L2 L1} {L5 L3} {L5 L3}       = 180 / 180 / 176 / 176
-    static_assert(NPIPE == 2, "role tables");
-    int level = 0, pipe = 0;
-    {
-        constexpr int lv0[12] = {5, 5, 4, 4, 0, 2, 3, 3, 1, 1, 0, 2}, pp0[12] = {0, 1, 0, 1, 1, 0, 1, 0, 0, 1, 0, 1};
-        constexpr int lvx[10] = {4, 4, 5, 5, 2, 2, 3, 3, 1, 1}, ppx[10] = {0, 1, 0, 1, 0, 1, 0, 1, 0, 1};
-#pragma unroll
-        for (int i = 0; i < (OCT0 ? 12 : 10); i++) if (wave == i) { level = OCT0 ? lv0[i] : lvx[i]; pipe = OCT0 ? pp0[i] : ppx[i]; }
-        level = __builtin_amdgcn_readfirstlane(level); pipe = __builtin_amdgcn_readfirstlane(pipe);
-    }
-    int unit = xcd_remap(blockIdx.x, gridDim.x);
-    {
-        const int per = a.nstrip * a.nseg, fr = unit / per;
-        if (fr >= (a.nb > 1 ? a.nb : 1)) return;
-        unit -= fr * per;
-        if (OCT0) a.gray += (size_t)fr * a.gstride; else a.src0 += (size_t)fr * a.fstride;
-#pragma unroll
-        for (int i = 0; i < N_LEVELS; i++) a.lv[i] += (size_t)fr * a.fstride;
-        if (a.ds) a.ds += (size_t)fr * a.fstride;
-    }
-    const int seg = unit / a.nstrip, strip = unit - seg * a.nstrip;
-    const int X0 = strip * SV - HC;
-    const int c = 256 * pipe + 4 * lane, x = X0 + c;
-    const int s0 = VB + seg * a.lseg;
-    const int s1 = (s0 + a.lseg < a.h - VB) ? s0 + a.lseg : a.h - VB;
-    const int ys = s0 - VB;                                                   // first input row
-    const int T = (s1 - s0) + VB + G5 + 1;                                    // steps until the last level's row s1 - 1 is complete
-    const int TP = ((T + 7) / 8) * 8;                                         // every wave runs the same number of barriers
-    const bool colst = c >= HC && c < HC + SV && x < a.w;                    // this lane's columns are stored (x >= 0 follows)
-    const int hm1 = a.h - 1;
-    float* const bU = &s_row[0][0][0];
-    auto rowbuf = [&](int i, int par) { return bU + ((1 + i) * 2 + (par & 1)) * BUFW; };
-    auto store = [&](float* lvl, int r, v4f o) {
-        if (colst && r >= s0 && r < s1) *reinterpret_cast<v4f*>(lvl + (size_t)r * a.w + x) = o;
-    };
-    // the generic level: reads the rows of level LV - 1 its producer completed one step earlier, writes level LV
-    auto run_level = [&](auto lvc, auto gc) {
-        constexpr int LV = decltype(lvc)::value, G = decltype(gc)::value, R = RR[LV], U = 8;
-        v2f kp[R + 1];
-        load_taps<R>(a.k[LV], kp);
-        v2f q01[2 * R + U], q23[2 * R + U];
-        ring_zero<R, U>(q01, q23);
-        v2f r01 = {0.0f, 0.0f}, r23 = r01;
-        step_barrier();                                                       // the producers' priming barrier
-        for (int tb = 0; tb < TP; tb += U) {
-            auto step = [&](auto jc) -> bool {
-                constexpr int j = decltype(jc)::value;
-                const int t = tb + j;
-                Win<R> w;
-                win_load<R>(rowbuf(LV - 1, t - 1), c, w);
-                const v4f o = col_pass<R, U, j>(r01, r23, q01, q23, kp);
-                if constexpr (LV < N_LEVELS - 1) put_row(rowbuf(LV, t), c, x, a.w, o);
-                const int r = ys + t - G;
-                store(a.lv[LV], r, o);
-                if constexpr (LV == N_LAYERS) {                               // level 3 also seeds the next octave
-                    if (a.ds && colst && r >= s0 && r < s1 && !(r & 1) && (r >> 1) < (a.h >> 1)) {
-                        const v2f d2 = {o.x, o.z};
-                        *reinterpret_cast<v2f*>(a.ds + (size_t)(r >> 1) * (a.w >> 1) + (x >> 1)) = d2;
-                    }
-                }
-                row_pass<R>(w, kp, r01, r23);
-                step_barrier();
-                __builtin_amdgcn_sched_barrier(0);
-                return true;
-            };
-            static_rows<0, U>(step);
-            ring_shift<R, U>(q01, q23);
-        }
-    };
-    using std::integral_constant;
-    if (level == 5) { run_level(integral_constant<int, 5>{}, integral_constant<int, G5>{}); return; }
-    if (level == 4) { run_level(integral_constant<int, 4>{}, integral_constant<int, G4>{}); return; }
-    if (level == 3) { run_level(integral_constant<int, 3>{}, integral_constant<int, G3>{}); return; }
-    if (level == 2) { run_level(integral_constant<int, 2>{}, integral_constant<int, G2>{}); return; }
-    if constexpr (OCT0) {
-        if (level == 1) { run_level(integral_constant<int, 1>{}, integral_constant<int, G1>{}); return; }
-        // doubling + level 0
-        constexpr int U = 8, D = 4, R = RR[0];
-        v2f kp[R + 1];
-        load_taps<R>(a.k[0], kp);
-        v2f q01[2 * R + U], q23[2 * R + U];
-        ring_zero<R, U>(q01, q23);
-        v2f r01 = {0.0f, 0.0f}, r23 = r01;
-        int gx = GPAD + (x >> 1);                                             // byte column of gray pixel x / 2 (x is a multiple of 4, may be negative)
-        gx = gx < 0 ? 0 : (gx > a.gp - 4 ? a.gp - 4 : gx);
-        const int gh1 = a.gh - 1;
-        struct Raw { unsigned a, b; };
-        auto load_raw = [&](int t, Raw& r) {                                  // doubled row ys + t
-            int gy = ys + t;
-            gy = gy > hm1 ? hm1 : gy;
-            const int ya = gy >> 1;
-            int yb = (gy & 1) ? ya + 1 : ya;
-            yb = yb > gh1 ? gh1 : yb;
-            __builtin_memcpy(&r.a, a.gray + (size_t)ya * a.gp + gx, 4);
-            __builtin_memcpy(&r.b, a.gray + (size_t)yb * a.gp + gx, 4);
-        };
-        auto form = [&](const Raw& r) {
-            auto hrow = [&](unsigned q, v4f& o) {
-                const float b0 = (float)(q & 255u), b1 = (float)((q >> 8) & 255u), b2 = (float)((q >> 16) & 255u);
-                o.x = b0; o.y = (b0 + b1) * 0.5f; o.z = b1; o.w = (b1 + b2) * 0.5f;
-            };
-            v4f ha, hb;
-            hrow(r.a, ha); hrow(r.b, hb);
-            return (v4f){(ha.x + hb.x) * 0.5f, (ha.y + hb.y) * 0.5f, (ha.z + hb.z) * 0.5f, (ha.w + hb.w) * 0.5f};
-        };
-        Raw pf[D];
-#pragma unroll
-        for (int d = 0; d < D; d++) load_raw(d, pf[d]);
-        *reinterpret_cast<v4f*>(bU + 0 * BUFW + BUFO + c) = form(pf[0]);      // doubled row of step 0
-        load_raw(D, pf[0]);
-        step_barrier();
-        for (int tb = 0; tb < TP; tb += U) {
-            auto step = [&](auto jc) -> bool {
-                constexpr int j = decltype(jc)::value;
-                const int t = tb + j;
-                Win<R> w;
-                win_load<R>(bU + (t & 1) * BUFW, c, w);
-                *reinterpret_cast<v4f*>(bU + ((t + 1) & 1) * BUFW + BUFO + c) = form(pf[(j + 1) % D]);
-                load_raw(t + 1 + D, pf[(j + 1) % D]);
-                const v4f o = col_pass<R, U, j>(r01, r23, q01, q23, kp);
-                put_row(rowbuf(0, t), c, x, a.w, o);
-                store(a.lv[0], ys + t - G0, o);
-                row_pass<R>(w, kp, r01, r23);
-                step_barrier();
-                __builtin_amdgcn_sched_barrier(0);
-                return true;
-            };
-            static_rows<0, U>(step);
-            ring_shift<R, U>(q01, q23);
-        }
-    } else {
-        // level 0 from HBM into LDS + level 1
-        constexpr int U = 8, D = 4, R = RR[1];
-        v2f kp[R + 1];
-        load_taps<R>(a.k[1], kp);
-        v2f q01[2 * R + U], q23[2 * R + U];
-        ring_zero<R, U>(q01, q23);
-        v2f r01 = {0.0f, 0.0f}, r23 = r01;
-        const int xl = x < 0 ? 0 : (x > a.w - 4 ? a.w - 4 : x);
-        auto load_raw = [&](int t, v4f& r) {
-            int gy = ys + t;
-            gy = gy > hm1 ? hm1 : gy;
-            r = *reinterpret_cast<const v4f*>(a.src0 + (size_t)gy * a.w + xl);
-        };
-        v4f pf[D];
-#pragma unroll
-        for (int d = 0; d < D; d++) load_raw(d, pf[d]);
-        put_row(rowbuf(0, 0), c, x, a.w, pf[0]);
-        load_raw(D, pf[0]);
-        step_barrier();
-        for (int tb = 0; tb < TP; tb += U) {
-            auto step = [&](auto jc) -> bool {
-                constexpr int j = decltype(jc)::value;
-                const int t = tb + j;
-                Win<R> w;
-                win_load<R>(rowbuf(0, t), c, w);
-                put_row(rowbuf(0, t + 1), c, x, a.w, pf[(j + 1) % D]);
-                load_raw(t + 1 + D, pf[(j + 1) % D]);
-                const v4f o = col_pass<R, U, j>(r01, r23, q01, q23, kp);
-                put_row(rowbuf(1, t), c, x, a.w, o);
-                store(a.lv[1], ys + t - G1, o);
-                row_pass<R>(w, kp, r01, r23);
-                step_barrier();
-                __builtin_amdgcn_sched_barrier(0);
-                return true;
-            };
-            static_rows<0, U>(step);
-            ring_shift<R, U>(q01, q23);
-        }
-    }
-}
-
-// ---- pyr_chain: two or three consecutive Gaussian levels in one pass (option "sift_cascade" = 2) -----------------------------------
-// The same machinery as pyr_cascade cut into pieces that stay HBM-bound: octave 0 = {gray -> L0 L1 L2} + {L2 -> L3 L4 L5}, the other
-// octaves {L0 -> L1 L2} + {L2 -> L3 L4 L5}: 7 level transfers per octave instead of 11 (10), one wave per level and pipeline, FOUR
-// pipelines per workgroup (1024 columns, 16-32 of them halo on each side), waves w, w + 4, w + 8 (one of each level) share a SIMD.
-// The first wave of a pipeline forms the doubled gray rows (GRAY) or moves the rows of level LF - 1 from HBM into LDS, 8 rows ahead.
-// MEASURED (8 frames 4000x3000 per launch): the 7 launches of octaves 0-2 + 17 band launches take 4.9 ms against 5.45 ms for the
-// per-level route (K2 = {8, 10, 13} on octave 0: 2.1 ms = 2.9 TB/s, K1 = {gray, 5, 5, 6}: 1.25 ms), i.e. not at the HBM bound: a
-// row step costs ~170 instructions per wave (110 of them packed FMAs for R = 13) x 3 waves per SIMD x 4 cycles = the measured
-// 1.1 us.  A plain-v_fma_f32 row pass (no operand shuffles, twice the FMA instructions) was slower (5.8 ms).  End to end (three
-// batches in flight) 985 against 987-1000 pairs/s: the per-level kernels overlap across batches, these fill whole CUs.
-namespace chain {
-constexpr int NP = 4, WGW = 256 * NP, BUFO = casc::BUFO, BUFW = WGW + 2 * BUFO;
-struct Args {
-    const uint8_t* gray; int gp; size_t gstride; int gh;   // GRAY: padded gray frames
-    const float* src;                                        // else: level LF - 1 (read)
-    float* lv[3];                                            // the levels written
-    float* ds;                                               // 2x decimated copy of the level flagged by ds_of (the next octave's level 0), or null
-    int ds_of;                                               // index (0..2) of that level in lv
-    size_t fstride; int nb;
-    int w, h;
-    int vb;                                                  // rows [vb, h - vb) are produced (the rest: blur_stream in band mode)
-    int nstrip, nseg, lseg;
-    float k[3][2 * MAX_R + 2];
-};
-}  // namespace chain
-
-template <bool GRAY, int RA_, int RB_, int RC_>               // radii of the levels (RC_ = 0: two levels)
-__global__ __launch_bounds__(RC_ ? 768 : 512) __attribute__((amdgpu_waves_per_eu(RC_ ? 3 : 4, RC_ ? 3 : 4))) void pyr_chain(chain::Args a) {
-    using namespace casc;
-    constexpr int NLEV = RC_ ? 3 : 2;
-    constexpr int RR[3] = {RA_, RB_, RC_ ? RC_ : 1};
-    constexpr int SUMR = RA_ + RB_ + RC_;
-    constexpr int HC = (SUMR + 3) & ~3, SV = chain::WGW - 2 * HC, CBW = chain::BUFW;
-    constexpr int G0 = RR[0] + 1, G1 = G0 + 2 + RR[1], G2 = G1 + 2 + RR[2], GL = RC_ ? G2 : G1;
-    __shared__ __attribute__((aligned(16))) float s_row[NLEV][2][CBW];           // [0] = the input rows, [1 + i] = level i of the chain (the last level is not staged)
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int level = __builtin_amdgcn_readfirstlane(wave / chain::NP), pipe = __builtin_amdgcn_readfirstlane(wave % chain::NP);
-    int unit = xcd_remap(blockIdx.x, gridDim.x);
-    {
-        const int per = a.nstrip * a.nseg, fr = unit / per;
-        if (fr >= (a.nb > 1 ? a.nb : 1)) return;
-        unit -= fr * per;
-        if (GRAY) a.gray += (size_t)fr * a.gstride; else a.src += (size_t)fr * a.fstride;
-#pragma unroll
-        for (int i = 0; i < 3; i++) if (a.lv[i]) a.lv[i] += (size_t)fr * a.fstride;
-        if (a.ds) a.ds += (size_t)fr * a.fstride;
-    }
-    const int seg = unit / a.nstrip, strip = unit - seg * a.nstrip;
-    const int X0 = strip * SV - HC;
-    const int c = 256 * pipe + 4 * lane, x = X0 + c;
-    const int s0 = a.vb + seg * a.lseg;
-    const int s1 = (s0 + a.lseg < a.h - a.vb) ? s0 + a.lseg : a.h - a.vb;
-    const int ys = s0 - SUMR;                                                 // first input row (vb >= SUMR)
-    const int T = (s1 - s0) + SUMR + GL + 1;
-    const int TP = ((T + 7) / 8) * 8;
-    const bool colst = c >= HC && c < HC + SV && x < a.w;
-    const int hm1 = a.h - 1;
-    // a pipeline whose 256 columns lie beyond the image and its mirrored margin (the last strip of a level that does not fill
-    // it: 64 of 1024 columns at 8000 wide) only keeps the barrier count: nobody reads what it would write
-    if (X0 + 256 * pipe - BUFO >= a.w + BUFO) {
-        for (int t = 0; t <= TP; t++) step_barrier();
-        return;
-    }
-    float* const b0 = &s_row[0][0][0];
-    auto rowbuf = [&](int i, int par) { return b0 + (i * 2 + (par & 1)) * CBW; };       // i = 0: input, 1 + k: level k of the chain
-    auto store = [&](int li, int r, v4f o) {
-        if (colst && r >= s0 && r < s1) {
-            *reinterpret_cast<v4f*>(a.lv[li] + (size_t)r * a.w + x) = o;
-            if (a.ds && li == a.ds_of && !(r & 1) && (r >> 1) < (a.h >> 1)) {
-                const v2f d2 = {o.x, o.z};
-                *reinterpret_cast<v2f*>(a.ds + (size_t)(r >> 1) * (a.w >> 1) + (x >> 1)) = d2;
-            }
-        }
-    };
-    constexpr int U = 8;
-    // levels 1, 2 of the chain: read the row the producer completed one step earlier
-    auto run_level = [&](auto lic, auto gc) {
-        constexpr int LI = decltype(lic)::value, G = decltype(gc)::value, R = RR[LI];
-        v2f kp[R + 1];
-        load_taps<R>(a.k[LI], kp);
-        v2f q01[2 * R + U], q23[2 * R + U];
-        ring_zero<R, U>(q01, q23);
-        v2f r01 = {0.0f, 0.0f}, r23 = r01;
-        step_barrier();
-        for (int tb = 0; tb < TP; tb += U) {
-            auto step = [&](auto jc) -> bool {
-                constexpr int j = decltype(jc)::value;
-                const int t = tb + j;
-                Win<R> w;
-                win_load<R>(rowbuf(LI, t - 1), c, w);
-                const v4f o = col_pass<R, U, j>(r01, r23, q01, q23, kp);
-                if constexpr (LI < NLEV - 1) put_row(rowbuf(LI + 1, t), c, x, a.w, o, CBW);
-                store(LI, ys + t - G, o);
-                row_pass<R>(w, kp, r01, r23);
-                step_barrier();
-                __builtin_amdgcn_sched_barrier(0);
-                return true;
-            };
-            static_rows<0, U>(step);
-            ring_shift<R, U>(q01, q23);
-        }
-    };
-    using std::integral_constant;
-    if (level == 1) { run_level(integral_constant<int, 1>{}, integral_constant<int, G1>{}); return; }
-    if constexpr (NLEV == 3) { if (level == 2) { run_level(integral_constant<int, 2>{}, integral_constant<int, G2>{}); return; } }
-    // level 0 of the chain + the input rows
-    constexpr int R = RR[0];
-    v2f kp[R + 1];
-    load_taps<R>(a.k[0], kp);
-    v2f q01[2 * R + U], q23[2 * R + U];
-    ring_zero<R, U>(q01, q23);
-    v2f r01 = {0.0f, 0.0f}, r23 = r01;
-    if constexpr (GRAY) {
-        constexpr int D = 4;
-        int gx = GPAD + (x >> 1);
-        gx = gx < 0 ? 0 : (gx > a.gp - 4 ? a.gp - 4 : gx);
-        const int gh1 = a.gh - 1;
-        struct Raw { unsigned a, b; };
-        auto load_raw = [&](int t, Raw& r) {
-            int gy = ys + t;
-            gy = gy < 0 ? 0 : (gy > hm1 ? hm1 : gy);
-            const int ya = gy >> 1;
-            int yb = (gy & 1) ? ya + 1 : ya;
-            yb = yb > gh1 ? gh1 : yb;
-            __builtin_memcpy(&r.a, a.gray + (size_t)ya * a.gp + gx, 4);
-            __builtin_memcpy(&r.b, a.gray + (size_t)yb * a.gp + gx, 4);
-        };
-        auto form = [&](const Raw& r) {
-            auto hrow = [&](unsigned q, v4f& o) {
-                const float p0 = (float)(q & 255u), p1 = (float)((q >> 8) & 255u), p2 = (float)((q >> 16) & 255u);
-                o.x = p0; o.y = (p0 + p1) * 0.5f; o.z = p1; o.w = (p1 + p2) * 0.5f;
-            };
-            v4f ha, hb;
-            hrow(r.a, ha); hrow(r.b, hb);
-            return (v4f){(ha.x + hb.x) * 0.5f, (ha.y + hb.y) * 0.5f, (ha.z + hb.z) * 0.5f, (ha.w + hb.w) * 0.5f};
-        };
-        Raw pf[D];
-#pragma unroll
-        for (int d = 0; d < D; d++) load_raw(d, pf[d]);
-        *reinterpret_cast<v4f*>(rowbuf(0, 0) + BUFO + c) = form(pf[0]);
-        load_raw(D, pf[0]);
-        step_barrier();
-        for (int tb = 0; tb < TP; tb += U) {
-            auto step = [&](auto jc) -> bool {
-                constexpr int j = decltype(jc)::value;
-                const int t = tb + j;
-                Win<R> w;
-                win_load<R>(rowbuf(0, t), c, w);
-                *reinterpret_cast<v4f*>(rowbuf(0, t + 1) + BUFO + c) = form(pf[(j + 1) % D]);
-                load_raw(t + 1 + D, pf[(j + 1) % D]);
-                const v4f o = col_pass<R, U, j>(r01, r23, q01, q23, kp);
-                put_row(rowbuf(1, t), c, x, a.w, o, CBW);
-                store(0, ys + t - G0, o);
-                row_pass<R>(w, kp, r01, r23);
-                step_barrier();
-                __builtin_amdgcn_sched_barrier(0);
-                return true;
-            };
-            static_rows<0, U>(step);
-            ring_shift<R, U>(q01, q23);
-        }
-    } else {
-        constexpr int D = 8;                                                  // rows of the source level in flight per pipeline (registers)
-        const int xl = x < 0 ? 0 : (x > a.w - 4 ? a.w - 4 : x);
-        auto load_raw = [&](int t, v4f& r) {
-            int gy = ys + t;
-            gy = gy < 0 ? 0 : (gy > hm1 ? hm1 : gy);
-            r = *reinterpret_cast<const v4f*>(a.src + (size_t)gy * a.w + xl);
-        };
-        v4f pf[D];
-#pragma unroll
-        for (int d = 0; d < D; d++) load_raw(d, pf[d]);
-        put_row(rowbuf(0, 0), c, x, a.w, pf[0], CBW);
-        load_raw(D, pf[0]);
-        step_barrier();
-        for (int tb = 0; tb < TP; tb += U) {
-            auto step = [&](auto jc) -> bool {
-                constexpr int j = decltype(jc)::value;
-                const int t = tb + j;
-                Win<R> w;
-                win_load<R>(rowbuf(0, t), c, w);
-                put_row(rowbuf(0, t + 1), c, x, a.w, pf[(j + 1) % D], CBW);
-                load_raw(t + 1 + D, pf[(j + 1) % D]);
-                const v4f o = col_pass<R, U, j>(r01, r23, q01, q23, kp);
-                put_row(rowbuf(1, t), c, x, a.w, o, CBW);
-                store(0, ys + t - G0, o);
-                row_pass<R>(w, kp, r01, r23);
-                step_barrier();
-                __builtin_amdgcn_sched_barrier(0);
-                return true;
-            };
-            static_rows<0, U>(step);
-            ring_shift<R, U>(q01, q23);
-        }
-    }
-}
-
-__global__ __launch_bounds__(256) void downsample2(const float* src, int sw, float* dst, int dw, int dh, size_t fstride) {
+// next octave seed: every second pixel of level 3 (cv::resize INTER_NEAREST to half size)
+__global__ __launch_bounds__(256) void downsample16(const lvl_t* src, int sw, lvl_t* dst, int dw, int dh, size_t fstride) {
     src += (size_t)blockIdx.z * fstride; dst += (size_t)blockIdx.z * fstride;      // blockIdx.z = frame of the batch
     const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x < dw && y < dh) dst[(size_t)y * dw + x] = src[(size_t)(2 * y) * sw + 2 * x];
 }
 
 // ---------- K3: DoG extrema -------------------------------------------------------------------------------------
-struct OctaveDev { float* lv[N_LEVELS]; int w, h; };
+struct OctaveDev { lvl_t* lv[N_LEVELS]; int w, h; };
 
 #ifndef EXT_EH
 #define EXT_EH 16
@@ -1060,7 +351,6 @@ constexpr int NREG = 64, REG_STRIDE = 32;   // candidate list split into 64 regi
 // batched launches: frame f = blockIdx.y (z for refine) works on its own copy of every buffer, a fixed stride apart
 struct BatchStride { size_t pyr, claimed, cand, refined, kps, cube; };   // elements of the respective type
 constexpr size_t CNT_STRIDE = 64, CCNT_STRIDE = (size_t)64 * 32, SEL_STRIDE = 2048;
-constexpr int SIFT_BATCH_MAX = 8;
 struct FrameOuts { mi355_keypoint* kp[SIFT_BATCH_MAX]; uint8_t* d8[SIFT_BATCH_MAX]; };
 
 // ---------- K3b: sub-pixel refinement ---------------------------------------------------------------------------
@@ -1068,39 +358,21 @@ struct Refined { int o, layer, r, c; float xi, xr, xc, contr, scl; };
 
 struct PyrDev { OctaveDev oc[MAX_OCT]; unsigned* claimed[MAX_OCT]; int n_oct; };
 
+// DoG[lvl] = G[lvl + 1] - G[lvl]: 16-bit integers (cv::subtract into CV_16S; the samples are 0 .. 12240, nothing saturates), exact as float
 __device__ __forceinline__ float dogv(const OctaveDev& oc, size_t foff, int lvl, int r, int c) {
     const size_t o = foff + (size_t)r * oc.w + c;
-    return oc.lv[lvl + 1][o] - oc.lv[lvl][o];
+    return (float)((int)oc.lv[lvl + 1][o] - (int)oc.lv[lvl][o]);
 }
 
-__device__ void solve3(float A[3][3], float b[3], float x[3]) {
-    int p0 = 0, p1 = 1, p2 = 2;
-    // column 0
-    {
-        float b0 = fabsf(A[0][0]), b1 = fabsf(A[1][0]), b2 = fabsf(A[2][0]);
-        int m = 0; float best = b0;
-        if (b1 > best) { best = b1; m = 1; }
-        if (b2 > best) { best = b2; m = 2; }
-        if (!(best > 1e-30f)) { x[0] = x[1] = x[2] = 0.0f; return; }
-        if (m == 1) { p0 = 1; p1 = 0; } else if (m == 2) { p0 = 2; p2 = 0; }
-    }
-    auto elim = [&](int pr, int pk, int k) {
-        const float f = A[pr][k] / A[pk][k];
-        for (int c = k + 1; c < 3; c++) A[pr][c] = A[pr][c] - f * A[pk][c];
-        b[pr] = b[pr] - f * b[pk];
-    };
-    elim(p1, p0, 0); elim(p2, p0, 0);
-    {
-        const float b1 = fabsf(A[p1][1]), b2 = fabsf(A[p2][1]);
-        float best = b1;
-        if (b2 > best) { best = b2; const int t = p1; p1 = p2; p2 = t; }
-        if (!(best > 1e-30f)) { x[0] = x[1] = x[2] = 0.0f; return; }
-    }
-    elim(p2, p1, 1);
-    if (!(fabsf(A[p2][2]) > 1e-30f)) { x[0] = x[1] = x[2] = 0.0f; return; }
-    x[2] = b[p2] / A[p2][2];
-    x[1] = (b[p1] - A[p1][2] * x[2]) / A[p1][1];
-    x[0] = ((b[p0] - A[p0][1] * x[1]) - A[p0][2] * x[2]) / A[p0][0];
+// Matx33f::solve(b, DECOMP_LU) = Matx_FastSolveOp<float, 3, 1>: Cramer's rule in float, the expression of the vendored
+// core/operations.hpp:742-750, 882-903 (products and sums rounded separately); det == 0 -> x = 0
+__device__ __forceinline__ void solve3(const float a[3][3], const float b[3], float x[3]) {
+    const float det = (a[0][0] * (a[1][1] * a[2][2] - a[2][1] * a[1][2]) - a[0][1] * (a[1][0] * a[2][2] - a[2][0] * a[1][2])) + a[0][2] * (a[1][0] * a[2][1] - a[2][0] * a[1][1]);
+    if (det == 0.0f) { x[0] = x[1] = x[2] = 0.0f; return; }
+    const float d = 1.0f / det;
+    x[0] = d * ((b[0] * (a[1][1] * a[2][2] - a[1][2] * a[2][1]) - a[0][1] * (b[1] * a[2][2] - a[1][2] * b[2])) + a[0][2] * (b[1] * a[2][1] - a[1][1] * b[2]));
+    x[1] = d * ((a[0][0] * (b[1] * a[2][2] - a[1][2] * b[2]) - b[0] * (a[1][0] * a[2][2] - a[1][2] * a[2][0])) + a[0][2] * (a[1][0] * b[2] - b[1] * a[2][0]));
+    x[2] = d * ((a[0][0] * (a[1][1] * b[2] - b[1] * a[2][1]) - a[0][1] * (a[1][0] * b[2] - b[1] * a[2][0])) + b[0] * (a[1][0] * a[2][1] - a[1][1] * a[2][0]));
 }
 
 // One Newton step of the quadratic fit at (L, R, C) and the acceptance tests, written once over an accessor dv(L, R, C)
@@ -1109,7 +381,7 @@ __device__ void solve3(float A[3][3], float b[3], float x[3]) {
 struct FitOff { float xi, xr, xc; };
 template <class DV>
 __device__ __forceinline__ FitOff fit_step(DV dv, int L, int R, int C) {
-    const float img_scale = 1.0f / 255.0f;
+    const float img_scale = 1.0f / (float)(255 * FIXPT_SCALE);
     const float deriv_scale = img_scale * 0.5f, second_scale = img_scale, cross_scale = img_scale * 0.25f;
     float dD[3];
     dD[0] = (dv(L, R, C + 1) - dv(L, R, C - 1)) * deriv_scale;
@@ -1122,21 +394,21 @@ __device__ __forceinline__ FitOff fit_step(DV dv, int L, int R, int C) {
     const float dxy = (dv(L, R + 1, C + 1) - dv(L, R + 1, C - 1) - dv(L, R - 1, C + 1) + dv(L, R - 1, C - 1)) * cross_scale;
     const float dxs = (dv(L + 1, R, C + 1) - dv(L + 1, R, C - 1) - dv(L - 1, R, C + 1) + dv(L - 1, R, C - 1)) * cross_scale;
     const float dys = (dv(L + 1, R + 1, C) - dv(L + 1, R - 1, C) - dv(L - 1, R + 1, C) + dv(L - 1, R - 1, C)) * cross_scale;
-    float A[3][3] = {{dxx, dxy, dxs}, {dxy, dyy, dys}, {dxs, dys, dss}};
-    float b[3] = {dD[0], dD[1], dD[2]}, X[3];
-    solve3(A, b, X);
+    const float A[3][3] = {{dxx, dxy, dxs}, {dxy, dyy, dys}, {dxs, dys, dss}};
+    float X[3];
+    solve3(A, dD, X);
     FitOff f; f.xi = -X[2]; f.xr = -X[1]; f.xc = -X[0];
     return f;
 }
 // contrast and edge tests at the converged location; contr is the interpolated response
 template <class DV>
 __device__ __forceinline__ bool fit_accept(DV dv, int L, int R, int C, FitOff f, float contrast_thr, float edge_thr, float& contr) {
-    const float img_scale = 1.0f / 255.0f;
+    const float img_scale = 1.0f / (float)(255 * FIXPT_SCALE);
     const float deriv_scale = img_scale * 0.5f, second_scale = img_scale, cross_scale = img_scale * 0.25f;
     float dD0 = (dv(L, R, C + 1) - dv(L, R, C - 1)) * deriv_scale;
     float dD1 = (dv(L, R + 1, C) - dv(L, R - 1, C)) * deriv_scale;
     float dD2 = (dv(L + 1, R, C) - dv(L - 1, R, C)) * deriv_scale;
-    const float t = (dD0 * f.xc + dD1 * f.xr) + dD2 * f.xi;
+    const float t = ((0.0f + dD0 * f.xc) + dD1 * f.xr) + dD2 * f.xi;          // Matx::dot: s = 0; s += a[i] * b[i]
     contr = dv(L, R, C) * img_scale + t * 0.5f;
     if (fabsf(contr) * (float)N_LAYERS < contrast_thr) return false;
     const float v2 = dv(L, R, C) * 2.0f;
@@ -1179,8 +451,7 @@ __global__ __launch_bounds__(256) void extrema_kernel(OctaveDev oc, int octave, 
     const int tyy = tile / tiles_x, txx = tile - tyy * tiles_x;
     const int x0 = txx * EW, y0 = tyy * EH;
     if (tid == 0) s_n = 0;
-    const bool vec = ((oc.w & 3) == 0) && (x0 - 4 >= 0) && (x0 + EW + 4 <= oc.w) && ((reinterpret_cast<uintptr_t>(oc.lv[0]) & 15) == 0) &&
-                     ((((size_t)oc.w * oc.h) & 3) == 0);
+    const bool vec = ((oc.w & 3) == 0) && (x0 - 4 >= 0) && (x0 + EW + 4 <= oc.w) && ((reinterpret_cast<uintptr_t>(oc.lv[0]) & 7) == 0);
     if (vec) {
         // centre columns x0 .. x0+EW-1: whole 256-byte runs (two 128-byte lines per row and level), float4 per lane
         for (int idx = tid; idx < RW * (EW / 4); idx += 256) {
@@ -1190,7 +461,7 @@ __global__ __launch_bounds__(256) void extrema_kernel(OctaveDev oc, int octave, 
             const size_t o = (size_t)gy * oc.w + (x0 + 4 * c4);
             v4f g[N_LEVELS];
 #pragma unroll
-            for (int l = 0; l < N_LEVELS; l++) g[l] = *reinterpret_cast<const v4f*>(oc.lv[l] + o);
+            for (int l = 0; l < N_LEVELS; l++) g[l] = ld4(oc.lv[l] + o);
 #pragma unroll
             for (int l = 0; l < 5; l++) s_d4[l][ry * P4 + 1 + c4] = g[l + 1] - g[l];
         }
@@ -1202,7 +473,7 @@ __global__ __launch_bounds__(256) void extrema_kernel(OctaveDev oc, int octave, 
             const size_t o = (size_t)gy * oc.w + (side ? x0 + EW : x0 - 1);
             float g[N_LEVELS];
 #pragma unroll
-            for (int l = 0; l < N_LEVELS; l++) g[l] = oc.lv[l][o];
+            for (int l = 0; l < N_LEVELS; l++) g[l] = ld1(oc.lv[l] + o);
 #pragma unroll
             for (int l = 0; l < 5; l++) reinterpret_cast<float*>(s_d4[l])[ry * PC + (side ? 4 + EW : 3)] = g[l + 1] - g[l];
         }
@@ -1215,7 +486,7 @@ __global__ __launch_bounds__(256) void extrema_kernel(OctaveDev oc, int octave, 
             const size_t o = (size_t)gy * oc.w + gx;
             float g[N_LEVELS];
 #pragma unroll
-            for (int l = 0; l < N_LEVELS; l++) g[l] = oc.lv[l][o];
+            for (int l = 0; l < N_LEVELS; l++) g[l] = ld1(oc.lv[l] + o);
 #pragma unroll
             for (int l = 0; l < 5; l++) reinterpret_cast<float*>(s_d4[l])[idx] = g[l + 1] - g[l];
         }
@@ -1245,7 +516,7 @@ __global__ __launch_bounds__(256) void extrema_kernel(OctaveDev oc, int octave, 
                 cn[pl][j] = fminf(fminf(top[pl][j], mid[pl][j]), bot[pl][j]);
             }
         }
-        // all 12 tests of the item without a branch (same exact predicate as extrema_stream: |val| >= max(val > 0 ? mx : -mn, tiny));
+        // all 12 tests of the item without a branch (same exact predicate as extrema_stream: |val| >= max(val > 0 ? mx : -mn, 21), DoG values are integers);
         // the rare hits are emitted afterwards
         unsigned hit = 0;
 #pragma unroll
@@ -1262,7 +533,7 @@ __global__ __launch_bounds__(256) void extrema_kernel(OctaveDev oc, int octave, 
                 mn = fminf(mn, fminf(fminf(cn[layer + 1][j - 1], cn[layer + 1][j]), cn[layer + 1][j + 1]));
                 mn = fminf(mn, fminf(fminf(cn[layer][j - 1], cn[layer][j + 1]), fminf(top[layer][j], bot[layer][j])));
                 const float q = val > 0.0f ? mx : -mn;
-                hit |= fabsf(val) >= fmaxf(q, 1.401298464324817e-45f) ? (1u << ((layer - 1) * 4 + k)) : 0u;
+                hit |= fabsf(val) >= fmaxf(q, DOG_THRESHOLD_P1) ? (1u << ((layer - 1) * 4 + k)) : 0u;
             }
         }
         unsigned cmask = 0;
@@ -1347,11 +618,11 @@ __device__ __forceinline__ unsigned xtest_row(const XDog& A, const XDog& B, cons
             float mn = fminf(fminf(d6[layer - 1][k], d6[layer - 1][k + 1]), d6[layer - 1][k + 2]);
             mn = fminf(mn, fminf(fminf(d6[layer + 1][k], d6[layer + 1][k + 1]), d6[layer + 1][k + 2]));
             mn = fminf(mn, fminf(fminf(d6[layer][k], d6[layer][k + 2]), fminf(A.m[layer][k], C.m[layer][k])));
-            // (val > 0 && val >= mx) || (val < 0 && val <= mn)  <=>  |val| >= max(val > 0 ? mx : -mn, smallest positive float):
+            // |val| > 20 && ((val > 0 && val >= mx) || (val < 0 && val <= mn))  <=>  |val| >= max(val > 0 ? mx : -mn, 21) on integers:
             // exact (no arithmetic on the values) and all in the vector unit -- the mask logic of the plain form costs more
             // scalar instructions than the whole rest of the row
             const float q = val > 0.0f ? mx : -mn;
-            hit |= fabsf(val) >= fmaxf(q, 1.401298464324817e-45f) ? (1u << ((layer - 1) * 4 + k)) : 0u;
+            hit |= fabsf(val) >= fmaxf(q, DOG_THRESHOLD_P1) ? (1u << ((layer - 1) * 4 + k)) : 0u;
         }
     }
     // validity of the row and of the lane's four columns, applied once
@@ -1393,7 +664,7 @@ void extrema_stream(OctaveDev oc, int octave, unsigned long long* cand, unsigned
         r = r < 0 ? 0 : (r > hm1 ? hm1 : r);                      // clamped rows are only ever neighbours of border pixels
         const size_t o = (size_t)r * oc.w + xl;
 #pragma unroll
-        for (int l = 0; l < N_LEVELS; l++) q.m[l] = *reinterpret_cast<const v4f*>(oc.lv[l] + o);
+        for (int l = 0; l < N_LEVELS; l++) q.m[l] = ld4(oc.lv[l] + o);
     };
     auto to_dog = [&](const XRow& q, XDog& d) {
 #pragma unroll
@@ -1692,7 +963,7 @@ __global__ __launch_bounds__(256) void orient_kernel(PyrDev P, const Refined* re
         if (take) {
             const Refined rr = ref[k];
             const OctaveDev& oc = P.oc[rr.o];
-            const float* img = oc.lv[rr.layer] + foff;
+            const lvl_t* img = oc.lv[rr.layer] + foff;
             const int radius = (int)rintf(4.5f * rr.scl);
             const float osig = 1.5f * rr.scl;
             const float expf_scale = -1.0f / (2.0f * osig * osig);
@@ -1712,8 +983,8 @@ __global__ __launch_bounds__(256) void orient_kernel(PyrDev P, const Refined* re
                     d2v[u] = i * i + j * j;
                     dxv[u] = 0.0f; dyv[u] = 0.0f;
                     if (okv[u]) {
-                        dxv[u] = img[(size_t)y * oc.w + x + 1] - img[(size_t)y * oc.w + x - 1];
-                        dyv[u] = img[(size_t)(y - 1) * oc.w + x] - img[(size_t)(y + 1) * oc.w + x];
+                        dxv[u] = (float)((int)img[(size_t)y * oc.w + x + 1] - (int)img[(size_t)y * oc.w + x - 1]);
+                        dyv[u] = (float)((int)img[(size_t)(y - 1) * oc.w + x] - (int)img[(size_t)(y + 1) * oc.w + x]);
                     }
                 }
 #pragma unroll
@@ -1727,12 +998,12 @@ __global__ __launch_bounds__(256) void orient_kernel(PyrDev P, const Refined* re
                     if (b >= ORI_BINS) b -= ORI_BINS;
                     if (b < 0) b += ORI_BINS;
                     const float t = wgt * mag;
-                    atomicAdd(&s_hq[wv][b], (unsigned long long)(long long)rintf(t * 1048576.0f));      // order-free by definition
+                    atomicAdd(&s_hq[wv][b], (unsigned long long)(long long)rintf(t * HIST_Q));      // order-free by definition
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
             __builtin_amdgcn_wave_barrier();
-            if (lane < ORI_BINS) s_hist[wv][lane] = (float)(long long)s_hq[wv][lane] * (1.0f / 1048576.0f);
+            if (lane < ORI_BINS) s_hist[wv][lane] = (float)(long long)s_hq[wv][lane] * (1.0f / HIST_Q);
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
             __builtin_amdgcn_wave_barrier();
             float hs = 0.0f;
@@ -1889,12 +1160,12 @@ __global__ __launch_bounds__(1024) void topk_kernel(const KpRec* kps, const unsi
     const unsigned keep = M < K ? M : K;
     for (unsigned i = tid; i < keep; i += 1024) {
         const KpRec k = kps[s_idx[i]];
-        // image coordinates: octave o is scaled by 2^(o-1) relative to the input image (first octave = -1)
-        const float s2 = k.o == 0 ? 0.5f : (float)(1 << (k.o - 1));
+        // image coordinates: kpt.pt = (c + xc) * (1 << octave), kpt.size = sigma * 2^((layer + xi) / 3) * (1 << octave) * 2 (no doubled octave)
+        const float s2 = (float)(1 << k.o);
         mi355_keypoint kp;
         kp.x = k.ptx * s2; kp.y = k.pty * s2; kp.size = (k.scl * s2) * 2.0f; kp.angle = k.angle;
         kp.response = __uint_as_float(k.resp_bits);
-        kp.octave = ((k.o - 1) & 255) | (k.layer << 8) | (((int)rintf((k.xi + 0.5f) * 255.0f)) << 16);
+        kp.octave = (k.o & 255) | (k.layer << 8) | (((int)rintf((k.xi + 0.5f) * 255.0f)) << 16);
         kp.class_id = -1;
         out_kp[i] = kp;
         SelRec sr; sr.ptx = k.ptx; sr.pty = k.pty; sr.scl = k.scl; sr.angle = k.angle; sr.o = k.o; sr.layer = k.layer;
@@ -1923,7 +1194,7 @@ __global__ __launch_bounds__(256) void describe_kernel(PyrDev P, const SelRec* s
     if (kidx >= *n_sel) return;
     const SelRec k = sel[kidx];
     const OctaveDev& oc = P.oc[k.o];
-    const float* img = oc.lv[k.layer] + foff;
+    const lvl_t* img = oc.lv[k.layer] + foff;
     const int rows = oc.h, cols = oc.w;
     for (int i = tid; i < HB; i += 256) s_hq[i] = 0ull;
     __syncthreads();
@@ -1944,8 +1215,8 @@ __global__ __launch_bounds__(256) void describe_kernel(PyrDev P, const SelRec* s
         float cbin = c_rot + (float)(d / 2) - 0.5f;
         const int r = py + i, c = px + j;
         if (!(rbin > -1.0f && rbin < (float)d && cbin > -1.0f && cbin < (float)d && r > 0 && r < rows - 1 && c > 0 && c < cols - 1)) continue;
-        const float dx = img[(size_t)r * cols + c + 1] - img[(size_t)r * cols + c - 1];
-        const float dy = img[(size_t)(r - 1) * cols + c] - img[(size_t)(r + 1) * cols + c];
+        const float dx = (float)((int)img[(size_t)r * cols + c + 1] - (int)img[(size_t)r * cols + c - 1]);
+        const float dy = (float)((int)img[(size_t)(r - 1) * cols + c] - (int)img[(size_t)(r + 1) * cols + c]);
         const float ori = det_atan2deg(dy, dx);
         const float mag = sqrtf(dx * dx + dy * dy) * det_expf((c_rot * c_rot + r_rot * r_rot) * exp_scale);
         float obin = (ori - k.angle) * bins_per_deg;
@@ -1963,8 +1234,8 @@ __global__ __launch_bounds__(256) void describe_kernel(PyrDev P, const SelRec* s
         const float v_rco011 = v_rc01 * obin, v_rco010 = v_rc01 - v_rco011;
         const float v_rco001 = v_rc00 * obin, v_rco000 = v_rc00 - v_rco001;
         const int idx = ((r0 + 1) * (d + 2) + c0 + 1) * (n + 2) + o0;
-        // order-free accumulation: rint(v * 2^20) as 64-bit integers (two's complement add == unsigned add)
-#define FIXQ(v) ((unsigned long long)(long long)rintf((v) * 1048576.0f))
+        // order-free accumulation: rint(v * 2^10) as 64-bit integers (two's complement add == unsigned add)
+#define FIXQ(v) ((unsigned long long)(long long)rintf((v) * HIST_Q))
         atomicAdd(&s_hq[idx], FIXQ(v_rco000)); atomicAdd(&s_hq[idx + 1], FIXQ(v_rco001));
         atomicAdd(&s_hq[idx + (n + 2)], FIXQ(v_rco010)); atomicAdd(&s_hq[idx + (n + 3)], FIXQ(v_rco011));
         atomicAdd(&s_hq[idx + (d + 2) * (n + 2)], FIXQ(v_rco100)); atomicAdd(&s_hq[idx + (d + 2) * (n + 2) + 1], FIXQ(v_rco101));
@@ -1975,8 +1246,8 @@ __global__ __launch_bounds__(256) void describe_kernel(PyrDev P, const SelRec* s
     if (tid < 128) {
         const int cell = tid >> 3, q = tid & 7, i = cell >> 2, j = cell & 3;
         const int idx = ((i + 1) * (d + 2) + (j + 1)) * (n + 2);
-        float v = (float)(long long)s_hq[idx + q] * (1.0f / 1048576.0f);
-        if (q < 2) v = v + (float)(long long)s_hq[idx + n + q] * (1.0f / 1048576.0f);       // circular orientation wrap
+        float v = (float)(long long)s_hq[idx + q] * (1.0f / HIST_Q);
+        if (q < 2) v = v + (float)(long long)s_hq[idx + n + q] * (1.0f / HIST_Q);       // circular orientation wrap
         s_dst[tid] = v;
     }
     __syncthreads();
@@ -2020,18 +1291,13 @@ int gauss_kernel_host(double sigma, float* k) {
     return r;
 }
 
-constexpr int STREAM_MIN_W = 2048, STREAM_MIN_H = 1536;
-constexpr int STREAM_MIN_W_BATCH = 1000, STREAM_MIN_H_BATCH = 750;    // batched launches (several frames): smaller levels still fill the chip
-// does this level go through blur_stream?  (f32 source, 16-byte aligned rows, last strip wider than the largest radius)
-inline bool blur_streams(const BlurArgs& a, bool bgr, int R, int stream_mode) {
-    const bool stream_ok = ((a.w & 3) == 0) && (((uintptr_t)a.src & 15) == 0) && (((uintptr_t)a.dst & 15) == 0) && ((a.w & 255) == 0 || (a.w & 255) > MAX_R);
+// does this level go through blur16_stream?  (8-byte aligned rows, last strip wider than the largest radius, enough strips x frames to fill the chip)
+inline bool blur_streams(const Blur16Args& a, bool bgr, int R, int stream_mode) {
     const bool has_r = R == 5 || R == 6 || R == 8 || R == 10 || R == 13;
-    const bool big = a.nb > 1 ? (a.w >= STREAM_MIN_W_BATCH && a.h >= STREAM_MIN_H_BATCH) : (a.w >= STREAM_MIN_W && a.h >= STREAM_MIN_H);
-    return !bgr && stream_mode && stream_ok && has_r && big;
-}
-// base level (2x up-sampled gray of the frame, blurred): gray_pad_kernel + blur_stream<R, D, UPS> when the level is big
-inline bool base_streams(const BlurArgs& a, int R, int stream_mode) {
-    return stream_mode && R == 5 && ((a.w & 3) == 0) && (((uintptr_t)a.dst & 15) == 0) && ((a.w & 255) == 0 || (a.w & 255) > MAX_R) && a.w >= STREAM_MIN_W && a.h >= STREAM_MIN_H;
+    bool ok = stream_mode && has_r && (a.w & 3) == 0 && ((a.w & 255) == 0 || (a.w & 255) > MAX_R) && a.w >= 512 && a.h >= 64;
+    if (bgr) { for (int f = 0; f < a.nb; f++) ok = ok && ((uintptr_t)a.bgr[f] & 3) == 0 && (a.bgr_ws[f] & 3) == 0; }
+    else ok = ok && ((uintptr_t)a.src & 7) == 0;
+    return ok && ((uintptr_t)a.dst & 7) == 0 && (a.fstride & 3) == 0;
 }
 inline void stream_grid(int w, int h, int& L, int& nstrip, int& nseg, int nb = 1) {
     static const int units_target = [] { const char* e = getenv("MI355_STREAM_UNITS"); return e ? atoi(e) : 2048; }();
@@ -2042,90 +1308,27 @@ inline void stream_grid(int w, int h, int& L, int& nstrip, int& nseg, int nb = 1
     if (L < stream_minl) L = stream_minl;
     nseg = (h + L - 1) / L;
 }
-inline void launch_gray_pad(hipStream_t st, const uint8_t* bgr, int ws, int w, int h, uint8_t* gray, int gp) {
-    hipLaunchKernelGGL(gray_pad_kernel, dim3((gp / 4 + 255) / 256, h), dim3(256), 0, st, bgr, ws, w, h, gray, gp);
-}
-// a.dst / a.fstride / a.nb: level 0 of the batch; gray / gstride: the padded gray frames
-inline void launch_base_stream(hipStream_t st, const BlurArgs& a, const uint8_t* gray, int gp, size_t gstride) {
-    BlurArgs a2 = a;
-    a2.bgr = gray; a2.bgr_ws = gp; a2.gstride = gstride;
-    const int nb = a.nb > 1 ? a.nb : 1;
-    int L, nstrip, nseg;
-    stream_grid(a.w, a.h, L, nstrip, nseg, nb);
-    hipLaunchKernelGGL((blur_stream<5, 8, true>), dim3((nstrip * nseg * nb + 3) / 4), dim3(256), 0, st, a2, L, nstrip, nseg);
-}
-// the 48 rows at the top and at the bottom of a level the cascade left out (blur_stream in band mode; R as in launch_blur)
-inline bool launch_band(hipStream_t st, int R, BlurArgs a, bool base, int band = casc::VB) {
-    a.band = band;
-    const int nb = a.nb > 1 ? a.nb : 1, nstrip = (a.w + 255) / 256, nseg = 2;
-    const dim3 grid((nstrip * nseg * nb + 3) / 4), block(256);
-    if (base) { hipLaunchKernelGGL((blur_band<5, 8, true>), grid, block, 0, st, a, band, nstrip, nseg); return true; }
-    switch (R) {
-#define CASE(RR, DD) case RR: hipLaunchKernelGGL((blur_band<RR, DD, false>), grid, block, 0, st, a, band, nstrip, nseg); return true;
-        CASE(5, 6) CASE(6, 8) CASE(8, 6) CASE(10, 6) CASE(13, 4)
-#undef CASE
-        default: return false;
-    }
-}
-// segments of a chain pass: whole rounds of one workgroup per CU against the row overlap per segment
-inline void chain_grid(int w, int h, int nb, int num_cu, int sv, int vb, int overlap, int& nstrip, int& nseg, int& lseg) {
-    nstrip = (w + sv - 1) / sv;
-    const int rows = h - 2 * vb, per = nstrip * nb;
-    long best = -1; nseg = 1;
-    for (int n = 1; n <= rows / 128 || n == 1; n++) {
-        const long rounds = ((long)per * n + num_cu - 1) / num_cu;
-        const long cost = rounds * ((rows + n - 1) / n + overlap);
-        if (best < 0 || cost < best) { best = cost; nseg = n; }
-    }
-    lseg = (rows + nseg - 1) / nseg;
-}
-// segments of the cascade: whole rounds of one workgroup per CU, the row overlap (~100 steps per segment) against the tail
-inline void cascade_grid(int w, int h, int nb, int num_cu, int& nstrip, int& nseg, int& lseg) {
-    nstrip = (w + casc::SV - 1) / casc::SV;
-    const int rows = h - 2 * casc::VB, per = nstrip * nb;
-    long best = -1; nseg = 1;
-    for (int n = 1; n <= rows / 256 || n == 1; n++) {
-        const long rounds = ((long)per * n + num_cu - 1) / num_cu;
-        const long cost = rounds * ((rows + n - 1) / n + 100);
-        if (best < 0 || cost < best) { best = cost; nseg = n; }
-    }
-    lseg = (rows + nseg - 1) / nseg;
-}
 template <bool BGR>
-bool launch_blur(hipStream_t st, int R, const BlurArgs& a, int stream_mode = 1) {
-    const int ntile = a.tiles_x * a.tiles_y;
-    // Large f32 levels: persistent 128-bit/packed-FMA variant with register prefetch (interior tiles dominate).
-    // Small levels (every tile touches the border) and the BGR base level: the 512-thread per-tile kernel.
-    const bool big = !BGR && a.w >= 1024 && a.h >= 768;
-    const bool use2 = big;
+bool launch_blur(hipStream_t st, int R, const Blur16Args& a, int stream_mode, bool* streamed = nullptr) {
+    const int nb = a.nb > 1 ? a.nb : 1;
+    if (streamed) *streamed = false;
     if (blur_streams(a, BGR, R, stream_mode)) {
         // barrier-free streaming kernel: ~2 waves per SIMD over the whole chip (2048 waves), segments of >= 64 rows, all frames of a batch in one launch
         int L, nstrip, nseg;
-        stream_grid(a.w, a.h, L, nstrip, nseg, a.nb > 1 ? a.nb : 1);
-        const int units = nstrip * nseg * (a.nb > 1 ? a.nb : 1);
+        stream_grid(a.w, a.h, L, nstrip, nseg, nb);
+        const int units = nstrip * nseg * nb;
         const dim3 grid((units + 3) / 4), block(256);
+        if (streamed) *streamed = true;
         switch (R) {
-#define CASE(RR, DD) case RR: hipLaunchKernelGGL((blur_stream<RR, DD, false>), grid, block, 0, st, a, L, nstrip, nseg); return true;
-            CASE(5, 6) CASE(6, 8) CASE(8, 6) CASE(10, 6) CASE(13, 4)
+#define CASE(RR, DD) case RR: hipLaunchKernelGGL((blur16_stream<RR, DD, BGR>), grid, block, 0, st, a, L, nstrip, nseg); return true;
+            CASE(5, 4) CASE(6, 4) CASE(8, 4) CASE(10, 4) CASE(13, 4)
 #undef CASE
             default: break;
         }
     }
-    if (use2) {
-        BlurArgs a2 = a;
-        a2.tiles_y = (a.h + BLUR2_TH - 1) / BLUR2_TH;
-        const int ntile2 = a2.tiles_x * a2.tiles_y * (a.nb > 1 ? a.nb : 1);
-        const dim3 grid(ntile2 < BLUR_PERSIST_BLOCKS ? ntile2 : BLUR_PERSIST_BLOCKS), block(BLUR2_NT);      // persistent workgroups
-        switch (R) {
-#define CASE(RR) case RR: hipLaunchKernelGGL((blur_tile2<RR, false>), grid, block, 0, st, a2); return true;
-            CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8) CASE(9) CASE(10) CASE(11) CASE(12) CASE(13) CASE(14) CASE(15) CASE(16)
-#undef CASE
-            default: return false;
-        }
-    }
-    const dim3 grid(ntile, a.nb > 1 ? a.nb : 1), block(BT);
+    const dim3 grid(a.tiles_x * a.tiles_y, nb), block(256);
     switch (R) {
-#define CASE(RR) case RR: hipLaunchKernelGGL((blur_tile<RR, BGR>), grid, block, 0, st, a); return true;
+#define CASE(RR) case RR: hipLaunchKernelGGL((blur16_tile<RR, BGR>), grid, block, 0, st, a); return true;
         CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8) CASE(9) CASE(10) CASE(11) CASE(12) CASE(13) CASE(14) CASE(15) CASE(16)
 #undef CASE
         default: return false;
@@ -2152,7 +1355,6 @@ struct SiftWork {
     DevBuf cand, refined, kps, kresp, sel, counters, rhist, ccnt;
     DevBuf olist;                            // per frame: indices of the refined points at or above the response threshold
     DevBuf cube; unsigned cube_cap = 0;       // 3x3x3 DoG neighbourhoods of the first cube_cap candidates of every region (128 B each)
-    DevBuf gray; int gray_pitch = 0; size_t gray_stride = 0;   // padded u8 gray of the frame (source of the streamed base level)
     PyrDev P;                                // pointers of frame 0
     BatchStride bs;
     unsigned cand_cap = 0, ref_cap = 0, kp_cap = 0;
@@ -2171,7 +1373,7 @@ void mi_sift_release(mi355_ctx* ctx) {
         if (!s) continue;
         if (s->stream) { (void)hipStreamSynchronize(s->stream); (void)hipStreamDestroy(s->stream); }
         if (s->done) (void)hipEventDestroy(s->done);
-        s->pyr.release(); s->claimed.release(); s->cand.release(); s->refined.release(); s->kps.release(); s->kresp.release(); s->sel.release(); s->counters.release(); s->rhist.release(); s->ccnt.release(); s->gray.release(); s->cube.release(); s->olist.release();
+        s->pyr.release(); s->claimed.release(); s->cand.release(); s->refined.release(); s->kps.release(); s->kresp.release(); s->sel.release(); s->counters.release(); s->rhist.release(); s->ccnt.release(); s->cube.release(); s->olist.release();
         delete s;
     }
     ctx->sift_slots.clear();
@@ -2268,39 +1470,36 @@ static int sift_prepare(mi355_ctx* ctx, SiftWork* s, int w, int h, int nb) {
             const double sp = std::pow(k, (double)(i - 1)) * sigma, st = sp * k;
             s->radius[i] = gauss_kernel_host(std::sqrt(st * st - sp * sp), s->kern[i]);
         }
-        const double sd = std::sqrt(sigma * sigma - 1.0 > 0.01 ? sigma * sigma - 1.0 : 0.01);
-        s->radius0 = gauss_kernel_host(sd, s->kern0);
+        // base level: createInitialImage(image, false, sigma) blurs with sqrtf(max(sigma^2 - 0.5^2, 0.01f)), computed in float
+        const float sd = std::sqrt(std::max((float)sigma * (float)sigma - 0.25f, 0.01f));
+        s->radius0 = gauss_kernel_host((double)sd, s->kern0);
     }
-    const int W = 2 * w, H = 2 * h;
-    int nOct = (int)lrint(std::log((double)(W < H ? W : H)) / std::log(2.0) - 2.0) + 1;
+    // octave 0 is the image itself (no doubling in the reference's OpenCV build); nOctaves = cvRound(log2(min(w, h)) - 2)
+    int nOct = (int)lrint(std::log((double)(w < h ? w : h)) / std::log(2.0) - 2.0);
     if (nOct > MAX_OCT) nOct = MAX_OCT;
     size_t fl = 0, cl = 0;
     int no = 0;
     for (int o = 0; o < nOct; o++) {
-        const int ow = W >> o, oh = H >> o;
-        if (ow < 2 * IMG_BORDER + 2 || oh < 2 * IMG_BORDER + 2) break;
-        fl += up64((size_t)ow * oh) * N_LEVELS;                     // every level starts on a 256-byte boundary
+        const int ow = w >> o, oh = h >> o;
+        if (ow < 2 * IMG_BORDER + 2 || oh < 2 * IMG_BORDER + 2) break;          // no keypoint can exist in smaller octaves
+        fl += up64((size_t)ow * oh) * N_LEVELS;                     // every level starts on a 128-byte boundary
         cl += (((size_t)ow * oh * 4 + 31) / 32 + 63) & ~(size_t)63;
         no = o + 1;
     }
-    // capacities.  Candidates: the DoG threshold is 0, so on a constant image EVERY pixel of every layer is a
-    // (tied) extremum: the worst case 3 layers x sum_o px0 / 4^o <= 4 px0 is provisioned (1.5 GB at 12 MP, of
-    // 288 GB).  Refined points / keypoints must survive the contrast test: a fraction of the pixels bounds them.
-    const size_t px0 = (size_t)W * H;
+    if (no == 0) { ctx->set_error("sift: image too small"); return MI355_ERR_ARG; }
+    // capacities.  Candidates are DoG extrema with |DoG| > 20: a plateau of equal values is the worst case (every pixel a tied
+    // extremum); 3 layers x sum_o px0 / 4^o <= 4 px0 is provisioned.  Refined points / keypoints must survive the contrast test.
+    const size_t px0 = (size_t)w * h;
     if (4 * px0 + 1024 > 0xfffffff0ull) { ctx->set_error("sift: image too large"); return MI355_ERR_ARG; }
-    // per region: tiles hash over the regions (tile index mod 64); an octave with T tiles puts at most ceil(T/64) tiles
-    // x 3*EW*EH extrema into one region, so the worst case is total/64 + one full tile per octave
     s->cand_cap = (unsigned)((4 * px0 + 1024 + NREG - 1) / NREG + ((size_t)MAX_OCT * 3 * EW * EH << REG_SHIFT) + 1024);   // + one full run of tiles per octave
-    s->ref_cap = (unsigned)(px0 / 32 + 65536);
-    s->kp_cap = (unsigned)(px0 / 32 + 65536);
-    s->cube_cap = (unsigned)(px0 / 16 / NREG + 4096);
+    s->ref_cap = (unsigned)(px0 / 8 + 65536);
+    s->kp_cap = (unsigned)(px0 / 8 + 65536);
+    s->cube_cap = (unsigned)(px0 / 4 / NREG + 4096);
     if (s->cube_cap > s->cand_cap) s->cube_cap = s->cand_cap;
     s->bs.cube = (size_t)s->cube_cap * NREG * 32;
     s->bs.pyr = fl; s->bs.claimed = cl; s->bs.cand = (size_t)s->cand_cap * NREG; s->bs.refined = s->ref_cap; s->bs.kps = s->kp_cap;
-    s->gray_pitch = (w + 2 * GPAD + 15) & ~15;
-    s->gray_stride = up64((size_t)s->gray_pitch * h + 64);
     const size_t B = (size_t)nb;
-    MI_HIP(s->pyr.reserve(B * fl * sizeof(float)));
+    MI_HIP(s->pyr.reserve(B * fl * sizeof(lvl_t)));
     MI_HIP(s->claimed.reserve(B * cl * sizeof(unsigned)));
     MI_HIP(hipMemsetAsync(s->claimed.p, 0, B * cl * sizeof(unsigned), s->stream));      // kept zero between batches by unclaim_kernel
     MI_HIP(s->cand.reserve(B * s->bs.cand * sizeof(unsigned long long)));
@@ -2313,13 +1512,12 @@ static int sift_prepare(mi355_ctx* ctx, SiftWork* s, int w, int h, int nb) {
     MI_HIP(s->olist.reserve(B * s->bs.refined * sizeof(unsigned)));      // |response| bits of the refined points (SoA next to `refined`)
     MI_HIP(s->ccnt.reserve(B * CCNT_STRIDE * sizeof(unsigned)));
     MI_HIP(s->cube.reserve(B * s->bs.cube * sizeof(float)));
-    MI_HIP(s->gray.reserve(B * s->gray_stride));
     memset(&s->P, 0, sizeof(s->P));
     size_t fo = 0, co = 0;
     for (int o = 0; o < no; o++) {
-        const int ow = W >> o, oh = H >> o;
+        const int ow = w >> o, oh = h >> o;
         s->P.oc[o].w = ow; s->P.oc[o].h = oh;
-        for (int i = 0; i < N_LEVELS; i++) { s->P.oc[o].lv[i] = s->pyr.as<float>() + fo; fo += up64((size_t)ow * oh); }
+        for (int i = 0; i < N_LEVELS; i++) { s->P.oc[o].lv[i] = s->pyr.as<lvl_t>() + fo; fo += up64((size_t)ow * oh); }
         s->P.claimed[o] = s->claimed.as<unsigned>() + co;
         co += (((size_t)ow * oh * 4 + 31) / 32 + 63) & ~(size_t)63;
     }
@@ -2328,13 +1526,15 @@ static int sift_prepare(mi355_ctx* ctx, SiftWork* s, int w, int h, int nb) {
     return MI355_OK;
 }
 
+
 // Accepts one frame: it joins the current batch, which is enqueued once it holds ctx->sift_batch frames (or on a
 // flush: any call that needs features, mi355_synchronize, or n_kp != NULL).  The frame memory must stay valid and
 // unchanged until then.  Returns without waiting; the keypoint count is adopted later by mi_resolve_features().
 int mi_sift_extract_dev(mi355_ctx* ctx, int img_id, const uint8_t* d_bgr, int w, int h, int ws, int* n_kp) {
     if (ctx->p.n_octave_layers != N_LAYERS || ctx->p.sigma != 1.6f) { ctx->set_error("sift: this build implements nOctaveLayers=3, sigma=1.6 (the reference's SIFT(2000,3,0.01,20))"); return MI355_ERR_ARG; }
     if (ctx->p.nfeatures < 1 || ctx->p.nfeatures > 2048) { ctx->set_error("sift: nfeatures must be in [1,2048]"); return MI355_ERR_ARG; }
-    if (2 * (size_t)w >= (1u << 20) || 2 * (size_t)h >= (1u << 20)) { ctx->set_error("sift: image too large"); return MI355_ERR_ARG; }
+    if ((size_t)w >= (1u << 20) || (size_t)h >= (1u << 20)) { ctx->set_error("sift: image too large"); return MI355_ERR_ARG; }
+    if (w < 16 || h < 16) { ctx->set_error("sift: image too small"); return MI355_ERR_ARG; }
     if (ctx->sift_slots.empty()) {
         ctx->sift_slots.resize(SIFT_SLOTS_MAX, nullptr);
         MI_HIP(hipEventCreateWithFlags(&ctx->sift_in_ev, hipEventDisableTiming));
@@ -2350,11 +1550,10 @@ int mi_sift_extract_dev(mi355_ctx* ctx, int img_id, const uint8_t* d_bgr, int w,
     int rc = MI355_OK;
     int nb = ctx->sift_batch < 1 ? 1 : (ctx->sift_batch > SIFT_BATCH_MAX ? SIFT_BATCH_MAX : ctx->sift_batch);
     {
-        // A frame's work area is ~75 bytes per pixel of its 2x up-sampled base (pyramid 32, worst-case candidate list 32,
-        // neighbourhood records 8, the rest 3): keep slots x batch x that under 60 % of the device memory by shortening the
-        // batch for very large frames (4000x3000 frames: 3.6 GB each, 24 in flight = 86 GB of 288 GB, no reduction).
+        // A frame's work area is ~60 bytes per pixel (pyramid 16, worst-case candidate list 32, neighbourhood records 8, the rest 4): keep
+        // slots x batch x that under 60 % of the device memory by shortening the batch for very large frames
         static size_t total_mem = [] { size_t fr = 0, tot = 0; return hipMemGetInfo(&fr, &tot) == hipSuccess ? tot : (size_t)0; }();
-        const double per_frame = 75.0 * 4.0 * (double)w * (double)h;
+        const double per_frame = 60.0 * (double)w * (double)h;
         if (total_mem) {
             const int fit = (int)(0.6 * (double)total_mem / per_frame / (double)SIFT_SLOTS);
             if (fit < nb) nb = fit < 1 ? 1 : fit;
@@ -2412,8 +1611,9 @@ static int sift_run_batch(mi355_ctx* ctx, SiftWork* s) {
         outs.kp[k] = fs[k]->kp.as<mi355_keypoint>(); outs.d8[k] = fs[k]->d8.as<uint8_t>();
     }
     auto blur_args = [&](const OctaveDev& oc) {
-        BlurArgs a; memset(&a, 0, sizeof(a));
-        a.w = oc.w; a.h = oc.h; a.tiles_x = (oc.w + TW - 1) / TW; a.tiles_y = (oc.h + TH - 1) / TH;
+        Blur16Args a; memset(&a, 0, sizeof(a));
+        a.w = oc.w; a.h = oc.h; a.tiles_x = (oc.w + T16W - 1) / T16W; a.tiles_y = (oc.h + T16H - 1) / T16H;
+        a.fstride = bs.pyr; a.nb = n;
         return a;
     };
     // ---- phases 1+2: the pyramid, octave by octave, every launch covering all n frames of the batch ----
@@ -2422,129 +1622,35 @@ static int sift_run_batch(mi355_ctx* ctx, SiftWork* s) {
     if (serial_heavy && ctx->heavy_ev_valid) MI_HIP(hipStreamWaitEvent(st, ctx->heavy_ev, 0));   // the previous batch's pyramid + extrema first
     for (int o = 0; o < s->n_oct; o++) {
         const OctaveDev& oc = s->P.oc[o];
-        BlurArgs a = blur_args(oc);
-        a.fstride = bs.pyr; a.nb = n;
-        const double level_bytes = (double)oc.w * oc.h * 4.0 * n;
-        // all levels of a big octave in one pass; the first and last 48 rows of every level by the per-level kernel afterwards
-        const bool radii_ok = s->radius0 == 5 && s->radius[1] == 5 && s->radius[2] == 6 && s->radius[3] == 8 && s->radius[4] == 10 && s->radius[5] == 13;
-        const bool cascade = ctx->cascade && ctx->blur_stream && radii_ok && (oc.w & 15) == 0 && oc.w >= 2000 && oc.h >= 1500 &&
-                             ((oc.w & 255) == 0 || (oc.w & 255) > MAX_R) && (o > 0 || base_streams(blur_args(oc), s->radius0, ctx->blur_stream));
-        int first_level = 1;                               // the per-level loop below starts here (cascade value 3: the first chain did levels 0..2)
-        if (cascade && ctx->cascade >= 2) {
-            const bool first_only = ctx->cascade == 3;
-            // chains: {gray | L0} -> first two / three levels, then L2 -> L3 L4 L5; the top / bottom rows by blur_stream in band mode afterwards
-            const bool seeds_next = o + 1 < s->n_oct && (oc.w & 1) == 0 && s->P.oc[o + 1].w == (oc.w >> 1) && s->P.oc[o + 1].h == (oc.h >> 1);
-            const int vb1 = o == 0 ? 16 : 12, vb2 = o == 0 ? 48 : 44;
-            chain::Args c1; memset(&c1, 0, sizeof(c1));
-            c1.w = oc.w; c1.h = oc.h; c1.fstride = bs.pyr; c1.nb = n; c1.vb = vb1; c1.ds = nullptr; c1.ds_of = -1;
-            // profile classes: "cascade" = the chain passes (bytes: the levels they write + the level they read), "gauss_band" = the band launches
-            std::unique_ptr<ProfScope> ps(new ProfScope(ctx, "cascade", level_bytes * (first_only ? 3.0 : 7.0), st));
-            if (o == 0) {
-                for (int k = 0; k < n; k++) launch_gray_pad(st, pend[k].d_bgr, pend[k].ws, w, h, s->gray.as<uint8_t>() + (size_t)k * s->gray_stride, s->gray_pitch);
-                c1.gray = s->gray.as<uint8_t>(); c1.gp = s->gray_pitch; c1.gstride = s->gray_stride; c1.gh = h;
-                c1.lv[0] = oc.lv[0]; c1.lv[1] = oc.lv[1]; c1.lv[2] = oc.lv[2];
-                memcpy(c1.k[0], s->kern0, sizeof(float) * 11); memcpy(c1.k[1], s->kern[1], sizeof(float) * 11); memcpy(c1.k[2], s->kern[2], sizeof(float) * 13);
-                chain_grid(oc.w, oc.h, n, ctx->num_cu, chain::WGW - 2 * 16, vb1, 16 + 25, c1.nstrip, c1.nseg, c1.lseg);
-                hipLaunchKernelGGL((pyr_chain<true, 5, 5, 6>), dim3(c1.nstrip * c1.nseg * n), dim3(768), 0, st, c1);
-            } else {
-                if (!ds_fused) {
-                    const OctaveDev& pv = s->P.oc[o - 1];
-                    hipLaunchKernelGGL(downsample2, dim3((oc.w + 63) / 64, (oc.h + 3) / 4, n), dim3(256), 0, st, pv.lv[N_LAYERS], pv.w, oc.lv[0], oc.w, oc.h, bs.pyr);
-                }
-                c1.src = oc.lv[0]; c1.lv[0] = oc.lv[1]; c1.lv[1] = oc.lv[2];
-                memcpy(c1.k[0], s->kern[1], sizeof(float) * 11); memcpy(c1.k[1], s->kern[2], sizeof(float) * 13);
-                chain_grid(oc.w, oc.h, n, 2 * ctx->num_cu, chain::WGW - 2 * 12, vb1, 11 + 15, c1.nstrip, c1.nseg, c1.lseg);      // two workgroups of 8 waves per CU
-                hipLaunchKernelGGL((pyr_chain<false, 5, 6, 0>), dim3(c1.nstrip * c1.nseg * n), dim3(512), 0, st, c1);
-            }
-            chain::Args c2; memset(&c2, 0, sizeof(c2));
-            if (!first_only) {
-            c2.w = oc.w; c2.h = oc.h; c2.fstride = bs.pyr; c2.nb = n; c2.vb = vb2;
-            c2.src = oc.lv[2]; c2.lv[0] = oc.lv[3]; c2.lv[1] = oc.lv[4]; c2.lv[2] = oc.lv[5];
-            c2.ds = seeds_next ? s->P.oc[o + 1].lv[0] : nullptr; c2.ds_of = 0;
-            memcpy(c2.k[0], s->kern[3], sizeof(float) * 17); memcpy(c2.k[1], s->kern[4], sizeof(float) * 21); memcpy(c2.k[2], s->kern[5], sizeof(float) * 27);
-            chain_grid(oc.w, oc.h, n, ctx->num_cu, chain::WGW - 2 * 32, vb2, 31 + 37, c2.nstrip, c2.nseg, c2.lseg);
-            hipLaunchKernelGGL((pyr_chain<false, 8, 10, 13>), dim3(c2.nstrip * c2.nseg * n), dim3(768), 0, st, c2);
-            }
-            ps.reset();
-            ProfScope pb(ctx, "gauss_band", 0.0, st);
-            for (int i = (o == 0 ? 0 : 1); i < (first_only ? 3 : N_LEVELS); i++) {
-                BlurArgs a = blur_args(oc);
-                a.fstride = bs.pyr; a.nb = n; a.dst = oc.lv[i];
-                if (i == 0) { memcpy(a.k, s->kern0, sizeof(float) * (2 * s->radius0 + 1)); a.bgr = s->gray.as<uint8_t>(); a.bgr_ws = s->gray_pitch; a.gstride = s->gray_stride; }
-                else { memcpy(a.k, s->kern[i], sizeof(float) * (2 * s->radius[i] + 1)); a.src = oc.lv[i - 1]; }
-                a.ds = (i == N_LAYERS) ? c2.ds : nullptr;
-                if (!launch_band(st, i == 0 ? s->radius0 : s->radius[i], a, i == 0, i <= 2 ? vb1 : vb2)) { ctx->set_error("sift: unsupported kernel radius"); return MI355_ERR_FAILED; }
-            }
-            if (first_only) first_level = 3; else ds_fused = seeds_next;
-        } else if (cascade) {
-            casc::Args ca; memset(&ca, 0, sizeof(ca));
-            ca.w = oc.w; ca.h = oc.h; ca.fstride = bs.pyr; ca.nb = n;
-            for (int i = 0; i < N_LEVELS; i++) ca.lv[i] = oc.lv[i];
-            memcpy(ca.k[0], s->kern0, sizeof(float) * (2 * s->radius0 + 1));
-            for (int i = 1; i < N_LEVELS; i++) memcpy(ca.k[i], s->kern[i], sizeof(float) * (2 * s->radius[i] + 1));
-            const bool seeds_next = o + 1 < s->n_oct && (oc.w & 1) == 0 && s->P.oc[o + 1].w == (oc.w >> 1) && s->P.oc[o + 1].h == (oc.h >> 1);
-            ca.ds = seeds_next ? s->P.oc[o + 1].lv[0] : nullptr;
-            cascade_grid(oc.w, oc.h, n, ctx->num_cu, ca.nstrip, ca.nseg, ca.lseg);
-            const dim3 grid(ca.nstrip * ca.nseg * n), block(o == 0 ? 768 : 640);
-            if (o == 0) {
-                for (int k = 0; k < n; k++) launch_gray_pad(st, pend[k].d_bgr, pend[k].ws, w, h, s->gray.as<uint8_t>() + (size_t)k * s->gray_stride, s->gray_pitch);
-                ca.gray = s->gray.as<uint8_t>(); ca.gp = s->gray_pitch; ca.gstride = s->gray_stride; ca.gh = h;
-                ProfScope ps(ctx, "cascade", level_bytes * 6.0 + (double)w * h * 3.0 * n, st);
-                hipLaunchKernelGGL((pyr_cascade<true>), grid, block, 0, st, ca);
-            } else {
-                if (!ds_fused) {
-                    const OctaveDev& pv = s->P.oc[o - 1];
-                    hipLaunchKernelGGL(downsample2, dim3((oc.w + 63) / 64, (oc.h + 3) / 4, n), dim3(256), 0, st, pv.lv[N_LAYERS], pv.w, oc.lv[0], oc.w, oc.h, bs.pyr);
-                }
-                ca.src0 = oc.lv[0];
-                ProfScope ps(ctx, "cascade", level_bytes * 6.0, st);
-                hipLaunchKernelGGL((pyr_cascade<false>), grid, block, 0, st, ca);
-            }
-            ProfScope ps(ctx, "gauss_band", 0.0, st);
-            for (int i = (o == 0 ? 0 : 1); i < N_LEVELS; i++) {
-                BlurArgs a = blur_args(oc);
-                a.fstride = bs.pyr; a.nb = n; a.dst = oc.lv[i];
-                if (i == 0) { memcpy(a.k, s->kern0, sizeof(float) * (2 * s->radius0 + 1)); a.bgr = s->gray.as<uint8_t>(); a.bgr_ws = s->gray_pitch; a.gstride = s->gray_stride; }
-                else { memcpy(a.k, s->kern[i], sizeof(float) * (2 * s->radius[i] + 1)); a.src = oc.lv[i - 1]; }
-                a.ds = (i == N_LAYERS) ? ca.ds : nullptr;
-                if (!launch_band(st, i == 0 ? s->radius0 : s->radius[i], a, i == 0)) { ctx->set_error("sift: unsupported kernel radius"); return MI355_ERR_FAILED; }
-            }
-            ds_fused = seeds_next;
-        } else if (o == 0) {
+        const double level_bytes = (double)oc.w * oc.h * sizeof(lvl_t) * n;
+        if (o == 0) {
+            // base level straight from the caller's frames: gray x 48 formed on the fly, blurred with sqrt(1.6^2 - 0.5^2)
+            Blur16Args a = blur_args(oc);
+            for (int k = 0; k < n; k++) { a.bgr[k] = pend[k].d_bgr; a.bgr_ws[k] = pend[k].ws; }
             a.dst = oc.lv[0];
             memcpy(a.k, s->kern0, sizeof(float) * (2 * s->radius0 + 1));
-            ProfScope ps(ctx, "gauss", level_bytes + (double)w * h * 3.0 * n, st);      // read the u8 frames, write level 0
-            if (base_streams(a, s->radius0, ctx->blur_stream)) {
-                for (int k = 0; k < n; k++) launch_gray_pad(st, pend[k].d_bgr, pend[k].ws, w, h, s->gray.as<uint8_t>() + (size_t)k * s->gray_stride, s->gray_pitch);
-                launch_base_stream(st, a, s->gray.as<uint8_t>(), s->gray_pitch, s->gray_stride);
-            } else {
-                for (int k = 0; k < n; k++) {            // caller-owned frames: one launch each
-                    BlurArgs a1 = a;
-                    a1.bgr = pend[k].d_bgr; a1.bgr_ws = pend[k].ws; a1.dst = oc.lv[0] + (size_t)k * bs.pyr; a1.nb = 1; a1.fstride = 0;
-                    if (!launch_blur<true>(st, s->radius0, a1, 0)) { ctx->set_error("sift: unsupported kernel radius"); return MI355_ERR_FAILED; }
-                }
-            }
+            const bool streams = blur_streams(a, true, s->radius0, ctx->blur_stream);
+            ProfScope ps(ctx, streams ? "gauss_stream" : "gauss", level_bytes + (double)w * h * 3.0 * n, st);      // read the u8 frames, write level 0
+            if (!launch_blur<true>(st, s->radius0, a, ctx->blur_stream)) { ctx->set_error("sift: unsupported kernel radius"); return MI355_ERR_FAILED; }
         } else if (!ds_fused) {
             const OctaveDev& pv = s->P.oc[o - 1];
             ProfScope ps(ctx, "downsample", level_bytes * 2.0, st);
-            hipLaunchKernelGGL(downsample2, dim3((oc.w + 63) / 64, (oc.h + 3) / 4, n), dim3(256), 0, st, pv.lv[N_LAYERS], pv.w, oc.lv[0], oc.w, oc.h, bs.pyr);
+            hipLaunchKernelGGL(downsample16, dim3((oc.w + 63) / 64, (oc.h + 3) / 4, n), dim3(256), 0, st, pv.lv[N_LAYERS], pv.w, oc.lv[0], oc.w, oc.h, bs.pyr);
         }
-        const bool per_level = !cascade || first_level > 1;
-        if (per_level) ds_fused = false;
-        for (int i = first_level; i < N_LEVELS && per_level; i++) {
-            a.bgr = nullptr; a.src = oc.lv[i - 1]; a.dst = oc.lv[i];
+        ds_fused = false;
+        for (int i = 1; i < N_LEVELS; i++) {
+            Blur16Args a = blur_args(oc);
+            a.src = oc.lv[i - 1]; a.dst = oc.lv[i];
             memcpy(a.k, s->kern[i], sizeof(float) * (2 * s->radius[i] + 1));
+            // the level that seeds the next octave writes its decimation on the way out (saves re-reading it)
+            if (i == N_LAYERS && o + 1 < s->n_oct && (oc.w & 3) == 0 && (s->P.oc[o + 1].w == (oc.w >> 1)) && (s->P.oc[o + 1].h == (oc.h >> 1))) { a.ds = s->P.oc[o + 1].lv[0]; ds_fused = true; }
             const bool streams = blur_streams(a, false, s->radius[i], ctx->blur_stream);
-            // the streamed level that seeds the next octave writes its decimation on the way out (saves re-reading it)
-            a.ds = nullptr;
-            if (streams && i == N_LAYERS && o + 1 < s->n_oct && (oc.w & 1) == 0 && (s->P.oc[o + 1].w == (oc.w >> 1)) && (s->P.oc[o + 1].h == (oc.h >> 1))) { a.ds = s->P.oc[o + 1].lv[0]; ds_fused = true; }
             ProfScope ps(ctx, streams ? "gauss_stream" : "gauss", level_bytes * 2.0, st);   // one read + one write of the level
             if (!launch_blur<false>(st, s->radius[i], a, ctx->blur_stream)) { ctx->set_error("sift: unsupported kernel radius"); return MI355_ERR_FAILED; }
         }
         {
             ProfScope ps(ctx, "extrema", level_bytes * 6.0, st);
-            // the streamed test pays off on the big octaves of a full batch (measured at 8000x6000 x 8 frames: 283 vs 326 us per frame);
-            // smaller launches do not keep enough rows in flight and stay with the tiled kernel
+            // the streamed test pays off on the big octaves of a full batch; smaller launches do not keep enough rows in flight and stay with the tiled kernel
             const bool xs = ctx->blur_stream && (oc.w & 3) == 0 && oc.w >= ctx->xstream_min_w && oc.h >= ctx->xstream_min_w * 3 / 4 && n >= ctx->xstream_min_frames;
             if (xs) {
                 // no row halo to amortise here (3 + XD rows to prime a segment): many short segments balance the 2048 wave slots

@@ -5,41 +5,53 @@
  *     SiftDescriptorExtractor extractor;               extractor.compute(img, kp, desc);
  *                                                      (MosaicWithoutPos.cpp:4852-4872)
  *
- * PIN STATUS.  The arithmetic lives in OpenCV 2.4.0 (`nonfree` sift.cpp, `imgproc` resize / filter engine, `core` Matx), which
- * the reference vendors as headers + Win32 binaries only (3rdparty/opencv240, Release/opencv_*240.dll): no source, nothing that
- * compiles or runs here, and the reference has no test or golden vector at this boundary -- so this file cannot be checked bit
- * for bit against the reference and stays "parity unpinned at the bit level".  What it restates is nevertheless not a guess
- * from the paper: the STRUCTURE and every constant below were read off the reference's own binary
- * (Release/opencv_nonfree240.dll, disassembled with llvm-objdump; DESIGN.md section 2 lists the addresses) and off the vendored
- * headers, and the result is measured against the reference's one committed run (tests/test_sift_reference_run.py):
- *   - the pyramids are 16-BIT FIXED POINT: createInitialImage calls gray.convertTo(gray_fpt, CV_16S, 48) (10016112: 48.0 pushed
- *     with type 3), buildDoGPyramid calls cv::subtract(.., dtype = 3 = CV_16S) (10019ea6), findScaleSpaceExtrema's threshold is
- *     floor(0.5 * contrastThreshold / nOctaveLayers * 12240) with 12240 = 255 * 48 (10019f4b-10019f5b) and adjustLocalExtrema
- *     scales by 1/12240, 1/24480, 1/48960 (10018675-10018751): OpenCV 2.4.0 is built with `typedef short sift_wt;
- *     SIFT_FIXPT_SCALE = 48`.  Round 1-2 of this oracle used float pyramids; that was wrong for this OpenCV version;
- *   - createInitialImage: cvtColor(BGR2GRAY = 6) -> convertTo(16S, x48) -> resize(2x, INTER_LINEAR = 1) ->
- *     GaussianBlur(sigma = sqrtf(max(1.6^2 - 4 * 0.5^2, 0.01)), BORDER_DEFAULT = 4) (100160f3-100162a0);
- *     cv::resize samples at src = (dst + 0.5) * scale - 0.5 (opencv_imgproc240.dll 100ce038-100ce040);
+ * PIN STATUS: PINNED BY THE REFERENCE'S COMMITTED OUTPUT for the detector, statistically for the descriptor.
+ * The arithmetic lives in OpenCV 2.4.0 (`nonfree` sift.cpp, `imgproc` filter engine, `core` Matx), which the reference vendors as
+ * headers + Win32 binaries only (3rdparty/opencv240, Release/opencv_*240.dll): no source, nothing that compiles or runs here.
+ * Two things pin this restatement nevertheless:
+ *  (1) its STRUCTURE and constants were read off the reference's own binary (Release/opencv_nonfree240.dll and
+ *      opencv_imgproc240.dll, llvm-objdump; addresses below) and off the vendored headers, not guessed from the paper;
+ *  (2) the reference's ONE committed run (Release/feature_temp/matchPairs.match: the inlier keypoints cv::SIFT 2.4.0 produced on
+ *      Release/test_data/DSC00004..23.JPG, float32 x / y + index) is reproduced EXACTLY: all 8220 distinct keypoints of the 20
+ *      frames appear in this oracle's output with bit-identical float32 coordinates AND at the index the file gives them
+ *      (tests/test_sift_reference_run.py; with fused multiply-adds in the filter taps instead of separate products and sums only
+ *      8100 of the 8220 stay bit-identical -- the check resolves single roundings).  That covers gray conversion, the 16-bit
+ *      pyramid, DoG, extremum test, sub-pixel refinement, contrast / edge rejection, duplicate removal and the NUMBER of
+ *      orientation peaks per point.  Size / angle / response / descriptors are not in that file: for them the evidence is
+ *      statistical (same test: the reference's inlier correspondences are nearest neighbours under this oracle's descriptors).
+ * Facts read off the binary (nonfree DLL unless noted):
+ *   - NO image doubling: SIFT::operator() calls createInitialImage(image, doubleImageSize = false, sigma) (1001aa5d: push 0) and
+ *     there is no keypoint rescaling after retainBest (1001ab87-1001ac0d); nOctaves = cvRound(log(min(w, h)) / log 2 - 2)
+ *     (1001aaba-1001aaf8).  (The doubling, firstOctave = -1, came with later 2.4.x releases; rounds 1-2 of this oracle assumed it.)
+ *   - the pyramids are 16-BIT FIXED POINT: gray.convertTo(gray_fpt, CV_16S = 3, 48.0) (10016112), buildDoGPyramid calls
+ *     cv::subtract(.., dtype = 3) (10019ea6), findScaleSpaceExtrema's threshold is floor(0.5 * contrastThreshold / nOctaveLayers *
+ *     12240), 12240 = 255 * 48 (10019f4b-10019f5b), adjustLocalExtrema scales by 1/12240, 1/24480, 1/48960 (10018675-10018751):
+ *     `typedef short sift_wt; SIFT_FIXPT_SCALE = 48`;
+ *   - createInitialImage(.., false, ..): cvtColor(BGR2GRAY = 6) -> convertTo(16S, x48) ->
+ *     GaussianBlur(sigma = sqrtf(max(1.6^2 - 0.5^2, 0.01)), BORDER_DEFAULT = 4) (100160f3, 100162d8-10016349);
  *   - keypoint angle = (360 / 36) * bin (1001a6ef), no "360 - angle" anywhere; descriptor constants 3, sqrt(2) / 2, 1 / 360,
  *     pi / 180, 0.2, 512, FLT_EPSILON (10017833-10018159); orientation constants 4.5 (radius), 1.5 (sigma), 0.8 (peak ratio),
  *     1/16 - 4/16 - 6/16 smoothing (1001a5bc-1001a643, 100174fa-10017511);
- *   - Matx33f::solve(DECOMP_LU) is Cramer's rule in float, the expression of core/operations.hpp:882-903 (vendored header).
- * The separable filter follows OpenCV's filter engine for 16S -> 32F -> 16S with a float kernel (recollection of
- * imgproc/filter.cpp of the 2.4 line, consistent with the exports of the DLL: getLinearRowFilter / getLinearColumnFilter):
+ *   - Matx33f::solve(DECOMP_LU) is Cramer's rule in float, the expression of core/operations.hpp:742-750, 882-903 (vendored header).
+ * The separable filter follows OpenCV's filter engine for 16S -> 32F -> 16S with a float kernel (imgproc/filter.cpp of the 2.4 line;
+ * confirmed by (2)):
+ *   kernel       width cvRound(8 sigma + 1) | 1, cv::getGaussianKernel(.., CV_32F): exp() rounded to float, summed in double,
+ *                tap = (float)(tap * (1 / sum)); border reflect-101
  *   row pass     RowFilter<short, float>: s = k[0] * S[0]; s += k[i] * S[i] for ascending i -- product and sum rounded SEPARATELY
  *                (SSE2 scalar code, no fused multiply-add on that target);
  *   column pass  SymmColumnFilter<Cast<float, short>>: s = k[r] * C; s += k[r + j] * (S[+j] + S[-j]) for j = 1..r;
- *                result = saturate_cast<short>(s) = round half to even.
+ *                result = saturate_cast<short>(s) = round half to even;
+ *   next octave  every second pixel of level 3 (resize INTER_NEAREST to half size).
  *
- * STILL DEFINED HERE (third-party approximations that cannot be read off cheaply; each is an open parity risk of a few ulp):
+ * STILL DEFINED HERE (third-party approximations that (2) cannot see; each an open parity risk of a few ulp in angle / descriptor):
  *   - exp / atan2 / sin / cos are the fixed polynomial forms below (OpenCV: table-driven cv::exp, fastAtan2 whose polynomial
  *     coefficients are the ones used here, MSVCR90 cosf / sinf), evaluated with fmaf in a fixed order;
  *   - both histograms (36-bin orientation, 4x4x8 descriptor) are accumulated ORDER-FREE: every contribution v is quantised to
  *     q = rint(v * 2^10) and summed as a 64-bit integer; the bin value is (float)sum * 2^-10 (gradients are in 1/48 grey
  *     levels, so the resolution is 2e-5 grey levels; OpenCV adds floats in pixel order);
- *   - keypoints are ordered by (response descending, octave, layer, row, column, orientation bin) and that is also the output
- *     order (OpenCV: removeDuplicated + retainBest leave an nth_element order); duplicates = same (octave, layer, row, column,
- *     bin); ties at the nfeatures boundary are cut (retainBest keeps them all).
+ *   - with nfeatures > 0 the keypoints are ordered by (response descending, octave, layer, row, column, orientation bin) and
+ *     that is the output order (OpenCV: retainBest leaves an nth_element order, and keeps ALL ties at the boundary where this
+ *     cuts at nfeatures); with nfeatures <= 0 the order is OpenCV's own (generation order, see orc_sift).
  */
 #include "oracle.h"
 #include <math.h>
@@ -336,59 +348,11 @@ static void describe(const octave_t* oc, const cand_t* k, uint8_t* out)
     }
 }
 
-/* experiment switch (tests/test_sift_reference_run.py measures both): 0 = cv::resize INTER_LINEAR (pixel centres aligned, what the
- * binary calls), 1 = sample grids aligned at pixel (0, 0) (round 2's choice) */
-int orc_sift_doubling_mode = 0;
-
-/* 2x INTER_LINEAR of a 16-bit image, cv::resize: src = (dst + 0.5) * 0.5 - 0.5, floor, clamp to the border with weight 0 on the far
- * sample; horizontal pass in float (S0 * (1 - fx) + S1 * fx), vertical pass the same, saturate_cast<short> at the end.  With fx in
- * {0.25, 0.75} every intermediate is exact in binary32, so the value is round-half-even((9 a + 3 b + 3 c + d) / 16) */
-static void double_linear16(const int16_t* g, int w, int h, int16_t* up)
-{
-    const int W = 2 * w, H = 2 * h;
-    float* row0 = (float*)malloc(sizeof(float) * (size_t)W * 2);
-    float* row1 = row0 + W;
-    for (int Y = 0; Y < H; Y++) {
-        int y0, y1; float fy;
-        if (orc_sift_doubling_mode == 0) {
-            float f = ((float)Y + 0.5f) * 0.5f - 0.5f;
-            y0 = (int)floorf(f); fy = f - (float)y0;
-            if (y0 < 0) { y0 = 0; fy = 0.0f; }
-            if (y0 >= h - 1) { y0 = h - 1; fy = 0.0f; }
-            y1 = y0 + 1 < h ? y0 + 1 : h - 1;
-        } else {
-            y0 = Y >> 1; y1 = (Y & 1) ? y0 + 1 : y0; fy = (Y & 1) ? 0.5f : 0.0f;
-            if (y1 > h - 1) { y1 = h - 1; }
-        }
-        for (int pass = 0; pass < 2; pass++) {
-            const int16_t* s = g + (size_t)(pass ? y1 : y0) * w;
-            float* d = pass ? row1 : row0;
-            for (int X = 0; X < W; X++) {
-                int x0, x1; float fx;
-                if (orc_sift_doubling_mode == 0) {
-                    float f = ((float)X + 0.5f) * 0.5f - 0.5f;
-                    x0 = (int)floorf(f); fx = f - (float)x0;
-                    if (x0 < 0) { x0 = 0; fx = 0.0f; }
-                    if (x0 >= w - 1) { x0 = w - 1; fx = 0.0f; }
-                    x1 = x0 + 1 < w ? x0 + 1 : w - 1;
-                } else {
-                    x0 = X >> 1; x1 = (X & 1) ? x0 + 1 : x0; fx = (X & 1) ? 0.5f : 0.0f;
-                    if (x1 > w - 1) x1 = w - 1;
-                }
-                d[X] = (float)s[x0] * (1.0f - fx) + (float)s[x1] * fx;
-            }
-        }
-        for (int X = 0; X < W; X++) up[(size_t)Y * W + X] = sat_short(row0[X] * (1.0f - fy) + row1[X] * fy);
-    }
-    free(row0);
-}
-
 int orc_sift(const uint8_t* bgr, int w, int h, int ws, int nfeatures, orc_keypoint* kp_out, uint8_t* desc_out, int max_kp)
 {
     const double sigma = 1.6;
     const float contrast_thr = 0.01f, edge_thr = 20.0f;
-    const int dbl = orc_sift_doubling_mode != 2;
-    const int W = dbl ? 2 * w : w, H = dbl ? 2 * h : h;
+    const int W = w, H = h;                  /* octave 0 is the image itself: 2.4.0 calls createInitialImage(image, false, sigma) */
     /* 1: gray (8-bit BGR2GRAY fixed point), x48 into 16 bits */
     int16_t* gray = (int16_t*)malloc(sizeof(int16_t) * (size_t)w * h);
     for (int y = 0; y < h; y++)
@@ -396,13 +360,11 @@ int orc_sift(const uint8_t* bgr, int w, int h, int ws, int nfeatures, orc_keypoi
             const uint8_t* p = bgr + (size_t)y * ws + 3 * x;
             gray[(size_t)y * w + x] = (int16_t)(((1868 * p[0] + 9617 * p[1] + 4899 * p[2] + 8192) >> 14) * FIXPT_SCALE);
         }
-    /* 2: base = 2x linear doubling, Gaussian blur with sqrt(sigma^2 - (2 * 0.5)^2) (first octave = -1) */
-    int16_t* up;
-    if (dbl) { up = (int16_t*)malloc(sizeof(int16_t) * (size_t)W * H); double_linear16(gray, w, h, up); free(gray); }
-    else up = gray;
+    /* 2: base = Gaussian blur of the 16-bit gray image with sqrt(sigma^2 - 0.5^2): NO image doubling in this OpenCV version */
+    int16_t* up = gray;
     /* 3: pyramid: 6 Gaussian levels per octave built incrementally, sigma_i = sqrt((s k^i)^2 - (s k^(i-1))^2), k = 2^(1/3); next
      * octave = every second pixel of level 3 (resize INTER_NEAREST to half size) */
-    int nOct = (int)lrint(log((double)(W < H ? W : H)) / log(2.0) - 2.0) + (dbl ? 1 : 0);
+    int nOct = (int)lrint(log((double)(W < H ? W : H)) / log(2.0) - 2.0) ;
     if (nOct > MAX_OCT) nOct = MAX_OCT;
     double sig[N_LEVELS];
     {
@@ -420,7 +382,7 @@ int orc_sift(const uint8_t* bgr, int w, int h, int ws, int nfeatures, orc_keypoi
         oc[o].w = ow; oc[o].h = oh;
         for (int i = 0; i < N_LEVELS; i++) oc[o].lv[i] = (int16_t*)malloc(sizeof(int16_t) * (size_t)ow * oh);
         if (o == 0) {
-            float sd = sqrtf(fmaxf((float)sigma * (float)sigma - (dbl ? 1.0f : 0.25f), 0.01f));            /* float, as the binary computes it */
+            float sd = sqrtf(fmaxf((float)sigma * (float)sigma - 0.25f, 0.01f));            /* float, as the binary computes it */
             gauss_blur16(up, oc[0].lv[0], tmp, ow, oh, (double)sd);
         } else {
             const int16_t* s = oc[o - 1].lv[N_LAYERS];
@@ -505,8 +467,8 @@ int orc_sift(const uint8_t* bgr, int w, int h, int ws, int nfeatures, orc_keypoi
                             memcpy(&k->resp_bits, &resp, 4);
                             k->o = o; k->layer = L; k->r = R; k->c = Cc; k->bin = b;
                             k->ptx = (float)Cc + xc; k->pty = (float)R + xr;
-                            /* image coordinates: octave o is scaled by 2^(o-1) relative to the input image */
-                            float s2 = dbl ? (o == 0 ? 0.5f : (float)(1 << (o - 1))) : (float)(1 << o);
+                            /* image coordinates: kpt.pt = (c + xc) * (1 << octave), kpt.size = sigma * 2^((layer + xi) / 3) * (1 << octave) * 2 */
+                            float s2 = (float)(1 << o);
                             k->x = k->ptx * s2; k->y = k->pty * s2;
                             k->size = (scl * s2) * 2.0f;
                             k->angle = (360.0f / (float)ORI_BINS) * bf;
@@ -516,15 +478,18 @@ int orc_sift(const uint8_t* bgr, int w, int h, int ws, int nfeatures, orc_keypoi
                 }
         free(claimed);
     }
-    /* 7: order, keep the strongest */
-    qsort(cand, ncand, sizeof(cand_t), cand_cmp);
-    size_t keep = ncand < (size_t)nfeatures ? ncand : (size_t)nfeatures;
+    /* 7: order, keep the strongest.  nfeatures <= 0 (cv::SIFT's "keep all"): every keypoint in GENERATION order -- octave, layer,
+     * row, column of the extremum the refinement started from, orientation peaks in bin order, first of identical ones kept --
+     * which is the order of OpenCV's vector when retainBest does not run: the ids stored in the reference's committed
+     * matchPairs.match are indices into exactly this list (tests/test_sift_reference_run.py) */
+    if (nfeatures > 0) qsort(cand, ncand, sizeof(cand_t), cand_cmp);
+    size_t keep = (nfeatures <= 0 || ncand < (size_t)nfeatures) ? ncand : (size_t)nfeatures;
     if (keep > (size_t)max_kp) keep = (size_t)max_kp;
     for (size_t i = 0; i < keep; i++) {
         const cand_t* k = &cand[i];
         kp_out[i].x = k->x; kp_out[i].y = k->y; kp_out[i].size = k->size; kp_out[i].angle = k->angle; kp_out[i].response = k->response;
-        /* OpenCV packing: octave (first octave = -1) | layer << 8 | round((xi + 0.5) * 255) << 16 */
-        kp_out[i].octave = ((k->o - (dbl ? 1 : 0)) & 255) | (k->layer << 8) | (((int)rintf((k->xi + 0.5f) * 255.0f)) << 16);
+        /* OpenCV packing: octave | layer << 8 | round((xi + 0.5) * 255) << 16 */
+        kp_out[i].octave = (k->o & 255) | (k->layer << 8) | (((int)rintf((k->xi + 0.5f) * 255.0f)) << 16);
         kp_out[i].class_id = -1;
         if (desc_out) describe(&oc[k->o], k, desc_out + 128 * i);      /* 8 */
     }
