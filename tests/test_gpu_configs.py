@@ -1,8 +1,8 @@
 """GPU: the BASELINE.json configurations at their OWN sizes against the oracle (VERDICT r01 "next" #1).
 
-  C3  500 x 4000x3000 on the default route (sift_batch 8 / sift_slots 3, the first three levels of the big octaves from pyr_chain
-      with its band launches, levels 3..5 from blur_stream, extrema_stream with the default thresholds, 8000-wide levels whose
-      last strip holds 64 columns): a 12-frame sample -- one full batch of 8
+  C3  500 x 4000x3000 on the default route (sift_batch 8 / sift_slots 3, blur16_stream for the levels >= 512 columns, the base level
+      straight from the BGR frames, extrema_stream on octave 0, 4000-wide levels whose last strip holds 160 columns): a 12-frame
+      sample -- one full batch of 8
       and one ragged batch of 4 -- every keypoint field, every descriptor byte, and the adjacent pairs' n_selected / n_in /
       inlier ids / H bits.
   C2  the whole 50-frame 1920x1080 strip: features, the 49 adjacent pairs, and the MosaicImagesRefined canvas bytes.
@@ -183,28 +183,26 @@ def test_c5_mini_dense_canvas_eight_stripes():
     ctx.close()
 
 
-def test_cascade_route_equals_per_level_route():
-    """option "sift_cascade": all Gaussian levels of a big octave in one pass (pyr_cascade + band launches) must give the
-    bits of the per-level route, which the tests above pin to the oracle: 9 frames of 12 MP (a full batch of 8 + a batch of
-    1; octaves 8000 / 4000 / 2000 wide go through the cascade), 3 frames whose doubled width is not a multiple of the 416
-    stored columns of a strip nor of 256 (2512 x 1900 -> 5024 wide), 2 frames of 1920 x 1080"""
+def test_tile_route_equals_stream_route():
+    """option "blur_stream" 0: every pyramid level through the LDS-tile kernel and every octave through the tiled extrema kernel must
+    give the bits of the streaming kernels, which the tests above pin to the oracle: 9 frames of 12 MP (a full batch of 8 + a batch
+    of 1), 3 frames whose width is not a multiple of 256 (2512 x 1900), 2 frames of 1920 x 1080"""
     import torch
     import imagemosaicing_amd as im
     from tests.synth_survey import render_frames
     for (w, h, F) in ((4000, 3000, 9), (2512, 1900, 3), (1920, 1080, 2)):
         feats = []
-        for casc in (0, 1, 2, 3):
+        for mode in (1, 0):
             ctx = im.Context(0)
-            ctx.set_option("sift_cascade", casc)
+            ctx.set_option("blur_stream", mode)
             frames, A, gains, ws = render_frames(ctx, torch, F, w, h, per_row=F)
             for k in range(F):
                 ctx.SiftExtractDev(k, frames[k].data_ptr(), w, h, ws)
             ctx.synchronize()
             feats.append([ctx.GetFeatures(k) for k in range(F)])
             ctx.close()
-        for route in (1, 2, 3):
-            for k in range(F):
-                (k0, d0), (k1, d1) = feats[0][k], feats[route][k]
-                assert len(k0) == len(k1) == 2000, (w, h, k, len(k0), len(k1))
-                assert np.array_equal(k0.view(np.uint8), k1.view(np.uint8)), f"{w}x{h} frame {k}: keypoints differ between the routes 0 and {route}"
-                assert np.array_equal(d0, d1), f"{w}x{h} frame {k}: descriptors differ between the routes 0 and {route}"
+        for k in range(F):
+            (k0, d0), (k1, d1) = feats[0][k], feats[1][k]
+            assert len(k0) == len(k1) == 2000, (w, h, k, len(k0), len(k1))
+            assert np.array_equal(k0.view(np.uint8), k1.view(np.uint8)), f"{w}x{h} frame {k}: keypoints differ between the stream and the tile route"
+            assert np.array_equal(d0, d1), f"{w}x{h} frame {k}: descriptors differ between the stream and the tile route"

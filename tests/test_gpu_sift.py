@@ -35,7 +35,7 @@ def test_sift_two_overlapping_tiles_c1(ctx, oracle):
     from tests.synth_frames import strip
     frames, Hs = strip(2, 640, 480, seed=1)
     k0, d0 = _check(ctx, oracle, frames[0], "tile0")
-    assert len(k0) == 2000
+    assert len(k0) > 1500                        # a 640x480 tile holds fewer than nfeatures = 2000 keypoints without the doubled octave
     ctx.SiftExtract(0, frames[0]); ctx.SiftExtract(1, frames[1])
     res = ctx.MatchPairs([(0, 1)], 2.5, 1)[0]
     assert int(res["accepted"]) == 1 and int(res["n_in"]) > 100
@@ -87,11 +87,12 @@ def test_sift_row_padding_is_ignored(ctx, oracle):
 
 
 def test_sift_streaming_blur_levels(ctx, oracle):
-    """frames whose octave 0 is >= 2048x1536 go through blur_stream (wave-per-strip streaming Gaussian): partial last
-    strip (2200 = 8*256 + 152), several row segments with reflected top/bottom rows, and an exact multiple of 256"""
+    """levels at least 512 columns wide go through blur16_stream (wave-per-strip streaming Gaussian): partial last strip
+    (2200 = 8*256 + 152; 1100 = 4*256 + 76; the octaves below halve them), several row segments with reflected top / bottom rows, an
+    exact multiple of 256, a width that is no multiple of 4 (tile kernel on every level)"""
     import imagemosaicing_amd as im
     from tests.synth_frames import terrain
-    for (w, h, seed) in [(1100, 780, 21), (1024, 768, 22)]:
+    for (w, h, seed) in [(2200, 1604, 20), (1100, 780, 21), (1024, 768, 22), (1101, 700, 23)]:
         img = terrain(w, h, seed=seed)
         kp, d8 = _check(ctx, oracle, img, f"{w}x{h}")
         assert len(kp) == 2000
