@@ -37,11 +37,29 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-DOM = "gauss_stream"       # profile class of the dominant kernel (blur_stream): the only launches bracketed with events in the timed region
+DOM = "gauss_stream"       # profile class of the dominant kernel (blur16_stream): the only launches bracketed with events in the timed region
 SLOTS = int(os.environ.get("MI355_BENCH_SLOTS", "3"))   # batch work areas in flight (library default 3)
-BATCH = int(os.environ.get("MI355_BENCH_BATCH", "8"))   # frames per batch (library default 8)
-PMC_JSON = "r02_pmc_blur_stream.json"   # committed rocprofv3 --pmc passes of this command (profiles/pmc_traffic.py)
+BATCH = int(os.environ.get("MI355_BENCH_BATCH", "16"))  # frames per batch (library default 16)
+PMC_JSON = "r03_pmc_blur16_stream.json"   # committed rocprofv3 --pmc passes of this command (profiles/pmc_traffic.py)
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md (6.29 TB/s measured copy)
+VALU_PEAK_TOPS = 78.65     # f32 vector multiplies OR adds per second (T lane-operations/s): the 157.3 TFLOP/s vector peak counts an fma as two
+
+
+def streamed_lane_ops(w, h):
+    """f32 lane-operations (separately rounded products and sums, oracle_sift.c gauss_blur16) of the levels of ONE w x h frame that go
+    through blur16_stream: per output pixel of a level with radius R the row pass is 2R+1 products + 2R sums, the column pass R+1
+    products + 2R sums (pairs) = 7R + 2.  Same level selection as sift.hip blur_streams(): >= 512 columns, width a multiple of 4."""
+    radii = {0: 6, 1: 5, 2: 6, 3: 8, 4: 10, 5: 13}          # base level sigma sqrt(1.6^2 - 0.5^2), then the five incremental blurs
+    total, o = 0.0, 0
+    while (w >> o) >= 12 and (h >> o) >= 12:
+        ow, oh = w >> o, h >> o
+        if ow >= 512 and oh >= 64 and ow % 4 == 0 and ((ow & 255) == 0 or (ow & 255) > 16):
+            for lv, R in radii.items():
+                if lv == 0 and o > 0:
+                    continue
+                total += float(ow) * oh * (7 * R + 2)
+        o += 1
+    return total
 
 
 def parse():
@@ -278,6 +296,7 @@ def main():
             ctx.MosaicImagesRefinedDev(fptr, wv, hv, wsv, h9, canvas.data_ptr(), cw, ch, cws)
         if phases:
             ctx.synchronize(); t4 = time.perf_counter()
+            state["warp_ms"] = (t4 - t3) * 1e3
             state["phase_ms"] = {"detect_describe" + ("+feature_allgather" if exchange and strong else ""): (t1 - t0) * 1e3,
                                  "match_select_ransac" + ("+result_allgather" if exchange else "_d2h"): (t2 - t1) * 1e3,
                                  "host_global_alignment": (t3 - t2) * 1e3, "warp": (t4 - t3) * 1e3}
@@ -316,7 +335,7 @@ def main():
         ctx.profile_enable(not os.environ.get("MI355_BENCH_NOPROF"))
     prof_all = {}
     if args.profile_all:
-        for cls in ("gauss_stream", "gauss", "downsample", "extrema", "refine", "orient", "topk", "describe", "features", "match", "select", "ransac", "warp"):
+        for cls in ("gauss_stream", "gauss", "downsample", "extrema", "refine", "kp_select", "orient", "topk", "describe", "features", "match", "select", "ransac", "warp"):
             ms, n, b = ctx.profile_get(cls)
             prof_all[cls] = {"ms_per_step": ms / max(args.steps, 1), "launches_per_step": n / max(args.steps, 1)}
     ctx.profile_enable(False)
@@ -326,7 +345,7 @@ def main():
     # chip-filling kernels overlap, and the bracketed durations are exclusive -- checked right here: the durations of ALL chip-filling
     # classes of that pass sum to less than its wall time.  The in-situ figure of the timed region stays as a side field.
     excl, iso = None, None
-    HEAVY = ("gauss_stream", "gauss", "cascade", "gauss_band", "downsample", "extrema")     # every class of the pyramid + extrema phase
+    HEAVY = ("gauss_stream", "gauss", "downsample", "extrema")     # every class of the pyramid + extrema phase
     if not os.environ.get("MI355_BENCH_NO_STANDALONE"):
         ctx.synchronize()
         ctx.set_option("serial_heavy", 1)
@@ -337,13 +356,15 @@ def main():
         ctx.synchronize()
         wall_ms = (time.perf_counter() - t_e) * 1e3
         e_ms, e_n, e_bytes = ctx.profile_get(DOM)
+        x_ms, x_n, x_bytes = ctx.profile_get("extrema")
         heavy_ms = sum(ctx.profile_get(c)[0] for c in HEAVY)
         ctx.profile_enable(False)
         ctx.set_option("serial_heavy", 0)
         if e_ms > 0:
             excl = {"achieved": (e_bytes / 1e9) / (e_ms / 1e3), "launches": int(e_n), "avg_launch_us": e_ms * 1e3 / max(e_n, 1), "frames": len(own),
                     "dominant_kernel_ms": e_ms, "all_chip_filling_kernels_ms": heavy_ms, "pass_wall_ms": wall_ms,
-                    "durations_are_exclusive": bool(heavy_ms <= wall_ms)}
+                    "durations_are_exclusive": bool(heavy_ms <= wall_ms),
+                    "extrema": {"ms": x_ms, "launches": int(x_n), "bytes": x_bytes}}
         # the same launches with ONE batch in flight (nothing else on the chip at all): the kernel's ceiling in this pipeline
         ctx.set_option("sift_slots", 1)
         ctx.profile_enable(True); ctx.profile_only(DOM); ctx.profile_reset()
@@ -392,7 +413,7 @@ def main():
             "metric": "image-pairs/sec (detect+match+H+warp), 4000x3000 UAV frames",
             "value": value, "unit": "image-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / max(args.steps, 1) * 1e3, "higher_is_better": True, "scaling": "strong" if strong else "weak",
-            "vs_baseline": None, "dtype": "f32 (pyramid/RANSAC/warp coordinates), bf16 MFMA exact-integer (descriptor distances), u8 (pixels)",
+            "vs_baseline": None, "dtype": "i16 fixed-point pyramid filtered in f32 (as the reference's OpenCV), f32 (RANSAC / warp coordinates), bf16 MFMA exact-integer (descriptor distances), u8 (pixels)",
             "data": "synthetic",
             "transport": transport if exchange else None, "rccl_ranks": rccl_ranks,
             "config": {"workload": "%s: %s, pair window %d (%d pairs), SIFT(2000,3,0.01,20) + exact BF match + 3x3 grid select + Ransac2D + MosaicImagesRefined warp"
@@ -404,9 +425,13 @@ def main():
                        "sharding": ("single GPU" if world == 1 else
                                     ("frames k mod G, pairs i mod G, canvas stripes; %s all-gather of feature records and accepted pair records" % transport) if strong else
                                     ("independent strip per rank; %s all-gather of accepted pair records" % transport))},
-            "roofline": {"bound": "hbm", "kernel": "blur_stream<R,D,false> (streaming separable Gaussian, one pyramid level of all frames of a batch per launch: levels 3..5 of the octaves whose first three levels come from pyr_chain, levels 1..5 of the smaller streamed octave)",
+            "roofline": {"bound": "hbm", "kernel": "blur16_stream<R,D,BGR> (streaming separable Gaussian 16S -> 32F -> 16S, one pyramid level of all frames of a batch per launch: every level at least 512 columns wide, the base level straight from the BGR frames)",
                          "achieved": excl["achieved"] if excl else in_situ, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": (excl["achieved"] if excl else in_situ) / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "note": "algorithmic bytes = 2 B read + 2 B written per pixel of a level (the reference's pyramid is 16-bit fixed point; base level: 3 B BGR read); the kernel is bound by f32 vector instruction issue, not by HBM: see valu",
+                         "valu": ({"lane_ops_per_frame": streamed_lane_ops(w, h), "achieved": streamed_lane_ops(w, h) * excl["frames"] / (excl["dominant_kernel_ms"] / 1e3) / 1e12,
+                                   "peak": VALU_PEAK_TOPS, "unit": "T f32 lane-operations/s", "frac": streamed_lane_ops(w, h) * excl["frames"] / (excl["dominant_kernel_ms"] / 1e3) / 1e12 / VALU_PEAK_TOPS,
+                                   "note": "separately rounded f32 products and sums the definition requires (7R + 2 per output pixel; an fma would count once but changes the reference's bits); peak = 256 CU x 128 lanes x 2.4 GHz"} if excl else None),
                          "measurement": ("HIP events around every launch of the kernel in an untimed extra pass over the same frames with option serial_heavy (chip-filling kernels of different "
                                          "batches never overlap: durations are exclusive, see exclusive_pass)") if excl else "HIP events in the timed region (launches overlap other batches' kernels)",
                          "exclusive_pass": excl,
@@ -415,16 +440,28 @@ def main():
                          "algorithmic_bytes_per_launch": (g_bytes / g_n) if g_n else None,
                          "algorithmic_bytes_per_frame": g_bytes / max(args.steps * len(own), 1),
                          "frames_per_batch": BATCH, "batches_in_flight": SLOTS, "standalone": iso},
+            # the other chip-filling kernels: exclusive durations of the same serial_heavy pass / the single warp launch of the last step
+            "roofline_by_kernel": {
+                "extrema_stream+extrema_kernel": ({"bound": "hbm", "algorithmic_bytes": "6 level reads x 2 B per pixel", "achieved": (excl["extrema"]["bytes"] / 1e9) / (excl["extrema"]["ms"] / 1e3),
+                                                   "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (excl["extrema"]["bytes"] / 1e9) / (excl["extrema"]["ms"] / 1e3) / HBM_PEAK_GBS,
+                                                   "us_per_frame": excl["extrema"]["ms"] * 1e3 / excl["frames"]} if excl and excl["extrema"]["ms"] > 0 else None),
+                "mosaic_tile_kernel": ({"bound": "hbm", "algorithmic_bytes": "6 B per frame pixel (SURVEY 8d B_W)", "achieved": 6.0 * w * h * len(own) / 1e9 / (state["warp_ms"] / 1e3),
+                                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": 6.0 * w * h * len(own) / 1e9 / (state["warp_ms"] / 1e3) / HBM_PEAK_GBS,
+                                        "ms": state["warp_ms"]} if state.get("warp_ms") else None)},
             # the whole path against the fixed algorithmic figure 262*P + 1.04 MB per adjacent pair (3.145 GB at 12 MP)
             # the whole path against the fixed algorithmic figure: (frames x (256 P + 6 P) + pairs x 1.04 MB) / pairs
             # (= 262 P + 1.04 MB = 3.145 GB per adjacent pair at 12 MP; 22.3 MB per window pair at C4)
             "path_roofline": {"algorithmic_bytes_per_pair": path_bytes_per_pair, "achieved": value / max(world, 1) * path_bytes_per_pair / 1e9,
                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": value / max(world, 1) * path_bytes_per_pair / 1e9 / HBM_PEAK_GBS,
-                              "note": "per GPU; SURVEY 8(d) formula (reads+writes of all 6 Gaussian levels, match operands, warp); this build moves fewer bytes than the formula assumes in places"},
+                              "note": "per GPU; SURVEY 8(d) formula, written for a 2x doubled f32 pyramid (256 P per frame).  The reference's OpenCV 2.4.0 builds NO doubled octave and keeps 16-bit levels (oracle/oracle_sift.c), which this build now follows: the formula over-counts its traffic 8x, so this fraction no longer bounds anything -- see path_roofline_16bit"},
+            "path_roofline_16bit": (lambda b: {"algorithmic_bytes_per_pair": b, "achieved": value / max(world, 1) * b / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                               "frac": value / max(world, 1) * b / 1e9 / HBM_PEAK_GBS,
+                                               "note": "the same formula with the pyramid the reference really builds: 3 P BGR read + (4/3) P x 6 levels x 2 B x (1 write + 1 read) = 35 P per frame, + 6 P warp, + 1.04 MB per pair"})(
+                                       (n_frames_total * 41.0 * w * h + survey_pairs * 1.04e6) / max(survey_pairs, 1)),
             # north_star: MFMA utilisation of the only matrix kernel (exact all-pairs descriptor distances, bf16 32x32x16 MFMA)
             "mfma": {"kernel": "bf_match_kernel", "flop_per_pair": 2.0 * 2000 * 2000 * 128, "achieved": (n_pairs * args.steps * 2.0 * 2000 * 2000 * 128 / 1e12) / (m_ms / 1e3) if m_ms > 0 else None,
                      "peak": 2500.0, "unit": "TFLOP/s", "frac": ((n_pairs * args.steps * 2.0 * 2000 * 2000 * 128 / 1e12) / (m_ms / 1e3) / 2500.0) if m_ms > 0 else None,
-                     "ms_per_step": m_ms / max(args.steps, 1), "note": "dense bf16 peak; 0.1 % of the step time, the path is HBM-bound"},
+                     "ms_per_step": m_ms / max(args.steps, 1), "note": "dense bf16 peak; 0.3 % of the step time"},
             "phase_ms": state.get("phase_ms"),
             "quality": {"pairs_accepted": accepted, "pairs": survey_pairs if strong else n_pairs, "images_aligned": state["n_valid"],
                         "h_corner_err_px_median": float(np.median(errs)) if errs else None,

@@ -38,7 +38,8 @@ class Mi355Error(RuntimeError):
 
 
 def lib_path():
-    return os.path.join(_HERE, "libmi355mosaic.so")
+    # MI355_LIB: a kernel A/B build of the same library (scratch/build_variant.sh); measurement only
+    return os.environ.get("MI355_LIB") or os.path.join(_HERE, "libmi355mosaic.so")
 
 
 def load_library():
@@ -310,6 +311,12 @@ class Context:
         k = C.c_int(0)
         self._chk(self.L.mi355_compact_accepted_dev(self._h, C.c_void_p(int(d_in)), int(n), C.c_void_p(int(d_out)), C.byref(k)))
         return k.value
+
+    def last_sift_counters(self):
+        """SIFT stage populations of the last extracted frame: DoG extrema, refined points, oriented keypoints, kept, overflow flag"""
+        out = (C.c_int32 * 8)()
+        self._chk(self.L.mi355_last_sift_counters(self._h, out))
+        return list(out)
 
     def CommInit(self, id128, rank, world):
         buf = (C.c_uint8 * 128).from_buffer_copy(bytes(id128))

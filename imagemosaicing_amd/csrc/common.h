@@ -100,7 +100,7 @@ struct mi355_ctx {
     int blur_stream = 1;                               // big pyramid levels through blur_stream (0: tile kernel only); option "blur_stream"
     int sift_nslots = 3;                               // batch work areas in flight, each on its own stream (option "sift_slots", env MI355_SIFT_SLOTS)
     int xstream_min_w = 3000, xstream_min_frames = 4;  // extrema_stream for octaves at least this wide (and 3/4 as high) in batches of at least so many frames
-    int sift_batch = 8;                                // frames per batch (option "sift_batch", env MI355_SIFT_BATCH)
+    int sift_batch = 16;                               // frames per batch (option "sift_batch", env MI355_SIFT_BATCH)
     hipEvent_t sift_in_ev = nullptr;                   // orders the SIFT streams after the caller's stream
     std::vector<int*> pinned_chunks;                   // pinned count slots, 8 ints per frame
     size_t pinned_used = 0;

@@ -182,7 +182,7 @@ __global__ __launch_bounds__(256) void blur16_tile(Blur16Args a) {
 // from the ring centre first, then the pairs (y + j, y - j).  The row loop is unrolled NP times, so every ring / prefetch index is a
 // compile-time constant.
 template <int R, int D, bool BGR>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void blur16_stream(Blur16Args a, int L, int nstrip, int nseg) {
+__device__ __forceinline__ void blur16_stream_body(const Blur16Args a, int L, int nstrip, int nseg) {
     constexpr int N = 2 * R + 1;
     constexpr int NP0 = ((N + D - 1) / D) * D;
     constexpr int NP = (NP0 & 1) ? NP0 + D : NP0;   // even (two LDS rows alternate) and a multiple of D
@@ -262,30 +262,43 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
     for (int q = 0; q < NP; q++) { ring01[q] = (v2f){0.0f, 0.0f}; ring23[q] = (v2f){0.0f, 0.0f}; }
     float* const bufs = reinterpret_cast<float*>(&s_buf[wave][0][0]);
+    // The exchange of a row through LDS is software-pipelined: row i + 1 is written to LDS before row i is filtered and patched (its
+    // reflected columns at the right image border) after the row pass, so that a step waits for ONE LDS round trip (the window read
+    // at its start) instead of four in a row (write, patch read, patch write, window read).
+    auto put_row = [&](const Raw& r, float* buf) {
+        v4f m; float hv;
+        row_values(r, m, hv);
+        *reinterpret_cast<v4f*>(buf + RA + 4 * lane) = m;
+        buf[hpos] = hv;
+    };
+    auto patch_row = [&](float* buf) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        { const float t = buf[p_src]; buf[p_dst] = t; }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    put_row(pf[0], bufs);
+    load_raw(D < nin ? D : nin - 1, pf[0]);
+    patch_row(bufs);
     for (int base = 0; base < nin; base += NP) {
         auto step = [&](auto jc) -> bool {
             constexpr int j = decltype(jc)::value;
             const int i = base + j;
             if (i >= nin) return false;
-            float* buf = bufs + (j & 1) * (BW + 64);
-            {
-                v4f m; float hv;
-                row_values(pf[j % D], m, hv);
-                *reinterpret_cast<v4f*>(buf + RA + 4 * lane) = m;
-                buf[hpos] = hv;
-            }
-            load_raw(i + D < nin ? i + D : nin - 1, pf[j % D]);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            { const float t = buf[p_src]; buf[p_dst] = t; }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            float* const buf = bufs + (j & 1) * (BW + 64);
+            float* const nbuf = bufs + ((j + 1) & 1) * (BW + 64);
             const v4f* w4 = reinterpret_cast<const v4f*>(buf) + lane;
             float e[NG * 4];
 #pragma unroll
             for (int g = 0; g < NG; g++) { const v4f tt = w4[g]; e[4 * g] = tt.x; e[4 * g + 1] = tt.y; e[4 * g + 2] = tt.z; e[4 * g + 3] = tt.w; }
+            const bool more = i + 1 < nin;
+            if (more) {
+                put_row(pf[(j + 1) % D], nbuf);
+                load_raw(i + 1 + D < nin ? i + 1 + D : nin - 1, pf[(j + 1) % D]);
+            }
             // row pass: ascending taps, product and sum rounded separately
             v2f r01, r23;
             {
@@ -299,6 +312,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 r01 = r01 + p01; r23 = r23 + p23;
             }
             ring01[j % NP] = r01; ring23[j % NP] = r23;
+            if (more) patch_row(nbuf);
             if (i >= 2 * R) {
                 // column pass of output row i - 2R: ring slots of rows (i - R) +- jj
                 constexpr int c = ((j - R) % NP + NP) % NP;
@@ -326,6 +340,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         };
         if (!static_rows<0, NP>(step)) return;
     }
+}
+
+// two waves per SIMD (256 registers each) for the long kernels, three (168 registers) for the short ones whose ring is small
+template <int R, int D, bool BGR>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void blur16_stream(Blur16Args a, int L, int nstrip, int nseg) {
+    blur16_stream_body<R, D, BGR>(a, L, nstrip, nseg);
+}
+template <int R, int D, bool BGR>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void blur16_stream3(Blur16Args a, int L, int nstrip, int nseg) {
+    blur16_stream_body<R, D, BGR>(a, L, nstrip, nseg);
 }
 
 // next octave seed: every second pixel of level 3 (cv::resize INTER_NEAREST to half size)
@@ -822,6 +846,9 @@ __global__ __launch_bounds__(256) void refine_kernel(PyrDev P, const unsigned lo
                 it = 1;
             }
         }
+#ifdef REFINE_EXP_NOSLOW
+        if (!accepted) continue;
+#endif
         if (!accepted) {
             for (; it < MAX_INTERP; it++) {
                 f = fit_step(dv, L, R, C);
@@ -837,9 +864,18 @@ __global__ __launch_bounds__(256) void refine_kernel(PyrDev P, const unsigned lo
         // duplicates: several start points may converge to one location -> first claim wins (all claims carry identical values)
         const size_t bit = ((size_t)R * oc.w + C) * 4 + (size_t)L;
         const unsigned mask = 1u << (bit & 31);
+#ifdef REFINE_EXP_NOCLAIM
+        const unsigned old = 0;
+#else
         const unsigned old = atomicOr(&P.claimed[o][fr * bs.claimed + (bit >> 5)], mask);
+#endif
         if (old & mask) continue;
-        const unsigned slot = atomicAdd(out_count, 1u);
+        // one atomic per wave, not per point: ~67 000 points of a 12 MP frame on ONE counter serialise in the L2 (0.65 ms per batch measured)
+        const unsigned long long act = __ballot(1);
+        const int leader = __builtin_ctzll(act), lane_id = (int)(threadIdx.x & 63);
+        unsigned slot = 0;
+        if (lane_id == leader) slot = atomicAdd(out_count, (unsigned)__builtin_popcountll(act));
+        slot = __shfl(slot, leader) + (unsigned)__builtin_popcountll(act & ((1ull << lane_id) - 1ull));
         if (slot < out_cap) {
             Refined rr;
             rr.o = o; rr.layer = L; rr.r = R; rr.c = C; rr.xi = f.xi; rr.xr = f.xr; rr.xc = f.xc; rr.contr = contr;
@@ -1299,8 +1335,9 @@ inline bool blur_streams(const Blur16Args& a, bool bgr, int R, int stream_mode) 
     else ok = ok && ((uintptr_t)a.src & 7) == 0;
     return ok && ((uintptr_t)a.dst & 7) == 0 && (a.fstride & 3) == 0;
 }
-inline void stream_grid(int w, int h, int& L, int& nstrip, int& nseg, int nb = 1) {
-    static const int units_target = [] { const char* e = getenv("MI355_STREAM_UNITS"); return e ? atoi(e) : 2048; }();
+inline void stream_grid(int w, int h, int& L, int& nstrip, int& nseg, int nb = 1, int waves = 2) {
+    static const int units_env = [] { const char* e = getenv("MI355_STREAM_UNITS"); return e ? atoi(e) : 0; }();
+    const int units_target = units_env ? units_env : 1024 * waves;
     static const int stream_minl = [] { const char* e = getenv("MI355_STREAM_MINL"); return e ? atoi(e) : 64; }();
     nstrip = (w + 255) / 256;
     nseg = (units_target + nstrip * nb - 1) / (nstrip * nb);
@@ -1314,15 +1351,19 @@ bool launch_blur(hipStream_t st, int R, const Blur16Args& a, int stream_mode, bo
     if (streamed) *streamed = false;
     if (blur_streams(a, BGR, R, stream_mode)) {
         // barrier-free streaming kernel: ~2 waves per SIMD over the whole chip (2048 waves), segments of >= 64 rows, all frames of a batch in one launch
+        static const int w3 = [] { const char* e = getenv("MI355_STREAM_W3"); return e ? atoi(e) : 10; }();     // largest radius run with 3 waves per SIMD
+        const bool three = R <= w3 && R <= 10;
         int L, nstrip, nseg;
-        stream_grid(a.w, a.h, L, nstrip, nseg, nb);
+        stream_grid(a.w, a.h, L, nstrip, nseg, nb, three ? 3 : 2);
         const int units = nstrip * nseg * nb;
         const dim3 grid((units + 3) / 4), block(256);
         if (streamed) *streamed = true;
         switch (R) {
-#define CASE(RR, DD) case RR: hipLaunchKernelGGL((blur16_stream<RR, DD, BGR>), grid, block, 0, st, a, L, nstrip, nseg); return true;
-            CASE(5, 4) CASE(6, 4) CASE(8, 4) CASE(10, 4) CASE(13, 4)
+#define CASE(RR, DD) case RR: if (three) hipLaunchKernelGGL((blur16_stream3<RR, DD, BGR>), grid, block, 0, st, a, L, nstrip, nseg); \
+                              else hipLaunchKernelGGL((blur16_stream<RR, DD, BGR>), grid, block, 0, st, a, L, nstrip, nseg); return true;
+            CASE(5, 4) CASE(6, 4) CASE(8, 4) CASE(10, 4)
 #undef CASE
+            case 13: hipLaunchKernelGGL((blur16_stream<13, 4, BGR>), grid, block, 0, st, a, L, nstrip, nseg); return true;
             default: break;
         }
     }
@@ -1680,8 +1721,12 @@ static int sift_run_batch(mi355_ctx* ctx, SiftWork* s) {
     // ---- phase 3: keypoint stages of all n frames ----
     {
         ProfScope ps(ctx, "refine", 0.0, st);
-        hipLaunchKernelGGL(refine_kernel, dim3(32, NREG, n), dim3(256), 0, st, s->P, s->cand.as<unsigned long long>(), s->ccnt.as<unsigned>(), s->cand_cap, cnt + 0,
+        static const int refine_gx = [] { const char* e = getenv("MI355_REFINE_GX"); return e ? atoi(e) : 2; }();      // workgroups per candidate region: 32 x 64 regions x frames of mostly empty workgroups cost more to dispatch than the fits
+        hipLaunchKernelGGL(refine_kernel, dim3(refine_gx, NREG, n), dim3(256), 0, st, s->P, s->cand.as<unsigned long long>(), s->ccnt.as<unsigned>(), s->cand_cap, cnt + 0,
                            ctx->p.contrast_threshold, ctx->p.edge_threshold, 1.6f, s->refined.as<Refined>(), cnt + 1, s->ref_cap, s->rhist.as<unsigned>(), bs, s->cube.as<float>(), s->cube_cap);
+    }
+    {
+        ProfScope ps(ctx, "kp_select", 0.0, st);
         hipLaunchKernelGGL(unclaim_kernel, dim3(128, n), dim3(256), 0, st, s->P, s->refined.as<Refined>(), cnt + 1, s->ref_cap, bs);
         hipLaunchKernelGGL(resp_threshold_kernel, dim3(n), dim3(1024), 0, st, s->rhist.as<unsigned>(), cnt + 1, s->ref_cap, (unsigned)nf + 256u, cnt + 8, bs.refined, s->olist.as<unsigned>());
     }

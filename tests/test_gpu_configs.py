@@ -1,8 +1,8 @@
 """GPU: the BASELINE.json configurations at their OWN sizes against the oracle (VERDICT r01 "next" #1).
 
-  C3  500 x 4000x3000 on the default route (sift_batch 8 / sift_slots 3, blur16_stream for the levels >= 512 columns, the base level
-      straight from the BGR frames, extrema_stream on octave 0, 4000-wide levels whose last strip holds 160 columns): a 12-frame
-      sample -- one full batch of 8
+  C3  500 x 4000x3000 on the default route (sift_batch 16 / sift_slots 3, blur16_stream for the levels >= 512 columns, the base level
+      straight from the BGR frames, extrema_stream on octave 0, 4000-wide levels whose last strip holds 160 columns): a 20-frame
+      sample -- one full batch of 16
       and one ragged batch of 4 -- every keypoint field, every descriptor byte, and the adjacent pairs' n_selected / n_in /
       inlier ids / H bits.
   C2  the whole 50-frame 1920x1080 strip: features, the 49 adjacent pairs, and the MosaicImagesRefined canvas bytes.
@@ -62,8 +62,8 @@ def test_c3_default_route_12mp():
     from tests import oracle_lib as ol
     from tests.synth_survey import render_frames, host_image
     orc = ol.load_oracle_fast()
-    ctx = im.Context(0)                     # library defaults: sift_batch 8, sift_slots 3, xstream_min_w 3000, xstream_min_frames 4
-    w, h, F = 4000, 3000, 12
+    ctx = im.Context(0)                     # library defaults: sift_batch 16, sift_slots 3, xstream_min_w 3000, xstream_min_frames 4
+    w, h, F = 4000, 3000, 20
     frames, A, gains, ws = render_frames(ctx, torch, F, w, h)
     for k in range(F):
         ctx.SiftExtractDev(k, frames[k].data_ptr(), w, h, ws)
@@ -185,8 +185,7 @@ def test_c5_mini_dense_canvas_eight_stripes():
 
 def test_tile_route_equals_stream_route():
     """option "blur_stream" 0: every pyramid level through the LDS-tile kernel and every octave through the tiled extrema kernel must
-    give the bits of the streaming kernels, which the tests above pin to the oracle: 9 frames of 12 MP (a full batch of 8 + a batch
-    of 1), 3 frames whose width is not a multiple of 256 (2512 x 1900), 2 frames of 1920 x 1080"""
+    give the bits of the streaming kernels, which the tests above pin to the oracle: 9 frames of 12 MP (a batch of 9), 3 frames whose width is not a multiple of 256 (2512 x 1900), 2 frames of 1920 x 1080"""
     import torch
     import imagemosaicing_amd as im
     from tests.synth_survey import render_frames
