@@ -1,9 +1,10 @@
 import sys, time, numpy as np, torch
 sys.path.insert(0, '/root/repo')
-import bench, imagemosaicing_amd as im
+import imagemosaicing_amd as im
+from tests.synth_survey import frame_layout
 w, h, F = 4000, 3000, 96
 ws = 3 * w
-A, g = bench.frame_layout(F, w, h, 0)
+A, g = frame_layout(F, w, h, 0)
 ctx = im.Context(0)
 st = torch.cuda.Stream(); torch.cuda.set_stream(st); ctx.set_stream(st.cuda_stream)
 frames = torch.empty((8, h * ws), dtype=torch.uint8, device='cuda')
