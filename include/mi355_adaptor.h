@@ -155,6 +155,51 @@ inline int GetMatchedPairsOneToAllSIFT(int nImages, float ransacDist, unsigned s
     return rc;
 }
 
+// int CMosaicByPose::GetMatchedPairsOneToAllSIFT_MultiThread()                                 MosaicWithoutPos.cpp:5244-5295
+// The reference's member reads m_pImgPoses / m_nImages / m_ransacDist and fills m_vecMatchPairs / m_nSuccess through its threads
+// (extraction :4832-4887, matching :5031-5241, results pushed under a mutex :10137-10145; the caller sets
+// m_pImgPoses / m_nImages at :4484-4486).  This is that whole call in one: SIFT(2000,3,0.01,20) of every image (parked as batches,
+// no keypoint_%d.key / discriptor_%d.xml round trip), then every pair of the window j in (i, i + 182) (:5083-5084), MatchPointPairs
+// appended like :5201-5221, nSuccess = accepted pairs.  PoseT is the reference's ImagePoseInfo (.pImg and .fixed are read; the images
+// must stay valid until the call returns).  `seed` stands for srand((unsigned)time(0)) (:5061).  Returns 0 like the reference, < 0 on error.
+template <class PoseT>
+inline int GetMatchedPairsOneToAllSIFT_MultiThread(const PoseT* pImgPoses, const int nImages, std::vector<MI355_NS MatchPointPairs>& vecMatchPairs,
+                                                   int& nSuccess, float ransacDist = 2.5f, unsigned seed = 1, int window = 182) {
+    nSuccess = 0;
+    mi355_ctx* c = context();
+    if (!c || !pImgPoses || nImages < 0) return -1;
+    std::vector<int32_t> fixed(nImages > 0 ? nImages : 1, 0);
+    for (int i = 0; i < nImages; i++) {
+        const MI355_NS IplImage* im = pImgPoses[i].pImg;
+        if (!im) return -1;
+        fixed[i] = pImgPoses[i].fixed;
+        // deferred form (no output pointers): the frame is staged in HBM and joins a batch; the match call below waits for the features
+        const int rc = mi355_sift_extract(c, i, (const uint8_t*)im->imageData, im->width, im->height, im->widthStep, NULL, NULL, 0, NULL);
+        if (rc != MI355_OK) return rc;
+    }
+    int n_pairs = 0;
+    mi355_pair_schedule(nImages, window, 0, 1, NULL, 0, &n_pairs);
+    if (n_pairs == 0) return 0;
+    std::vector<int32_t> pairs((size_t)n_pairs * 2);
+    mi355_pair_schedule(nImages, window, 0, 1, &pairs[0], n_pairs, &n_pairs);
+    mi355_pair_result* res = (mi355_pair_result*)std::malloc(sizeof(mi355_pair_result) * (size_t)n_pairs);
+    if (!res) return -1;
+    int rc = mi355_match_pairs(c, &pairs[0], n_pairs, ransacDist, seed, res);
+    if (rc == MI355_OK) {
+        for (int p = 0; p < n_pairs; p++) nSuccess += res[p].accepted ? 1 : 0;
+        mi355_match_point_pairs* v = NULL; int n = 0;
+        rc = mi355_results_to_match_pairs(res, n_pairs, &fixed[0], &v, &n);
+        if (rc == MI355_OK) {
+            const size_t old = vecMatchPairs.size();
+            vecMatchPairs.resize(old + n);
+            if (n) std::memcpy(&vecMatchPairs[old], v, sizeof(mi355_match_point_pairs) * n);
+            mi355_free(v);
+        }
+    }
+    std::free(res);
+    return rc;
+}
+
 // int CMosaicByPose::GetMatchedPairsOneToAllSurf(const ImagePoseInfo* pImgPoses, const int nImages, vector<MatchPointPairs>& vecMatchPairs,
 //                                                int& nSuccess)                                  MosaicWithoutPos.cpp:5300-5533
 // (m_minHessian, m_matchDist, m_maxFeatureNum, m_ransacDist are members there: UavMatchParam defaults 50 / 0.5 / 200 / 2.5.)

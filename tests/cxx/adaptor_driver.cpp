@@ -168,6 +168,20 @@ int main(int argc, char** argv) {
         if (!v.empty()) std::memcpy(&out[8], &v[0], v.size() * sizeof(MatchPointPairs));
         spit(dir + "/surf.out", &out[0], out.size());
         for (int k = 0; k < n; k++) cvReleaseImage(&poses[k].pImg);
+    } else if (mode == "sift") {
+        // GetMatchedPairsOneToAllSIFT_MultiThread through the adaptor: extraction + window matching in ONE call
+        std::vector<Img> imgs = read_images(dir + "/images.bin");
+        const int n = (int)imgs.size();
+        std::vector<ImagePoseInfo> poses(n);
+        for (int k = 0; k < n; k++) { poses[k].pImg = to_ipl(imgs[k]); poses[k].fixed = (k == 0); }
+        std::vector<MatchPointPairs> v; int nSuccess = -1;
+        if (mi355::GetMatchedPairsOneToAllSIFT_MultiThread(&poses[0], n, v, nSuccess, 2.5f, 9u) != 0) return 6;
+        std::vector<unsigned char> out(8 + v.size() * sizeof(MatchPointPairs));
+        const int hd[2] = {nSuccess, (int)v.size()};
+        std::memcpy(&out[0], hd, 8);
+        if (!v.empty()) std::memcpy(&out[8], &v[0], v.size() * sizeof(MatchPointPairs));
+        spit(dir + "/sift.out", &out[0], out.size());
+        for (int k = 0; k < n; k++) cvReleaseImage(&poses[k].pImg);
     } else return 2;
     std::printf("DONE %s\n", mode.c_str());
     return 0;

@@ -142,3 +142,27 @@ def test_cxx_adaptor_surf_variant(tmp_path):
     want = im.results_to_match_pairs(res, fixed_flags=[1] + [0] * (len(frames) - 1))
     assert n_success == 1 + int(res["accepted"].sum()) and n_success > 5
     assert np.array_equal(got.view(np.uint8), want.view(np.uint8))
+
+
+def test_cxx_adaptor_sift_one_call(tmp_path):
+    """mi355::GetMatchedPairsOneToAllSIFT_MultiThread (MosaicWithoutPos.cpp:5244-5295 with its extraction threads :4832-4887) from C++:
+    host frames in, MatchPointPairs + nSuccess out, equal to the flattened records of the Python-side extract + match on the same frames
+    (same seed, window 182 = every pair of the 7 frames)"""
+    import imagemosaicing_amd as im
+    from tests.synth_frames import strip
+    exe = build_driver(str(tmp_path))
+    frames = strip(7, 640, 480, seed=5)[0]
+    write_images(tmp_path / "images.bin", frames, [np.eye(3).reshape(9)] * len(frames))
+    run(exe, tmp_path, "sift")
+    raw = open(tmp_path / "sift.out", "rb").read()
+    n_success, n = np.frombuffer(raw[:8], np.int32)
+    got = np.frombuffer(raw[8:], im.MATCHPAIR)
+    assert len(got) == n
+    ctx = im.Context(0)
+    for k, f in enumerate(frames):
+        ctx.SiftExtract(k, f)
+    res = ctx.MatchPairs(im.pair_schedule(len(frames), 182), 2.5, 9)
+    ctx.close()
+    want = im.results_to_match_pairs(res, fixed_flags=[1] + [0] * (len(frames) - 1))
+    assert n_success == int(res["accepted"].sum()) and n_success >= 6
+    assert np.array_equal(got.view(np.uint8), want.view(np.uint8))
