@@ -99,7 +99,7 @@ struct mi355_ctx {
     int cascade = 3;                                   // octaves >= 2000 px wide: 3 (default) = the first three levels ({gray | L0} -> L0/L1 L2) in one pass (pyr_chain), the rest per level; 2 = also L3..L5 in one pass; 1 = all six in one pass (pyr_cascade); 0 = every level on its own. Same bits; option "sift_cascade"
     int blur_stream = 1;                               // big pyramid levels through blur_stream (0: tile kernel only); option "blur_stream"
     int sift_nslots = 3;                               // batch work areas in flight, each on its own stream (option "sift_slots", env MI355_SIFT_SLOTS)
-    int xstream_min_w = 3000, xstream_min_frames = 4;  // extrema_stream for octaves at least this wide (and 3/4 as high) in batches of at least so many frames
+    int xstream_min_w = 1500, xstream_min_frames = 4;  // extrema_stream for octaves at least this wide (and 3/4 as high) in batches of at least so many frames
     int sift_batch = 16;                               // frames per batch (option "sift_batch", env MI355_SIFT_BATCH)
     hipEvent_t sift_in_ev = nullptr;                   // orders the SIFT streams after the caller's stream
     std::vector<int*> pinned_chunks;                   // pinned count slots, 8 ints per frame

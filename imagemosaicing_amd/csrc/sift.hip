@@ -607,46 +607,60 @@ __global__ __launch_bounds__(256) void extrema_kernel(OctaveDev oc, int octave, 
 // loop issues no memory operation besides those row loads: a candidate (rare) is parked in a wave-private LDS list
 // together with its 3x3x3 DoG neighbourhood, taken from the registers of the lane and of its two neighbours; the list
 // goes to global memory when it is full and at the end of the segment.
-constexpr int XCAP = 64;                        // candidates buffered per wave between flushes
+constexpr int XCAP = 128;                       // candidate records buffered per wave between flushes (a trip of the emit loop adds at most 64)
 constexpr int XD = 2;                           // rows in flight per wave
-__device__ __forceinline__ float dpp_from_lower_lane(float own_if_lane0, float v) {      // lane l gets v of lane l-1; lane 0 keeps own_if_lane0
-    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(own_if_lane0), __float_as_int(v), 0x138 /* wave_shr:1 */, 0xf, 0xf, false));
+__device__ __forceinline__ int dpp_from_lower_lane(int own_if_lane0, int v) {      // lane l gets v of lane l-1; lane 0 keeps own_if_lane0
+    return __builtin_amdgcn_update_dpp(own_if_lane0, v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
 }
-__device__ __forceinline__ float dpp_from_upper_lane(float own_if_lane63, float v) {     // lane l gets v of lane l+1; lane 63 keeps own_if_lane63
-    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(own_if_lane63), __float_as_int(v), 0x130 /* wave_shl:1 */, 0xf, 0xf, false));
+__device__ __forceinline__ int dpp_from_upper_lane(int own_if_lane63, int v) {     // lane l gets v of lane l+1; lane 63 keeps own_if_lane63
+    return __builtin_amdgcn_update_dpp(own_if_lane63, v, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
 }
 constexpr int XSW = 248;                        // columns a wave is responsible for: lanes 1..62; lanes 0 and 63 carry the neighbours' columns
-struct XRow { v4f m[N_LEVELS]; };               // one row of the six levels: 4 pixels per lane
-struct XDog { v4f m[5]; };
+// the DoG values are 16-bit integers, held as exact floats: v_max3_f32 / v_min3_f32 issue at twice the rate of their integer twins
+// (measured: 72 against 76 us per 12 MP frame for the whole test)
+typedef float xv; typedef v4f v4x;
+struct XRow { uint2 m[N_LEVELS]; };             // one row of the six levels: 4 packed 16-bit pixels per lane
+struct XDog { v4x m[5]; };
+__device__ __forceinline__ xv imax3(xv a, xv b, xv c) { return fmaxf(fmaxf(a, b), c); }
+__device__ __forceinline__ xv imin3(xv a, xv b, xv c) { return fminf(fminf(a, b), c); }
+__device__ __forceinline__ xv xmax(xv a, xv b) { return fmaxf(a, b); }
+__device__ __forceinline__ xv xmin(xv a, xv b) { return fminf(a, b); }
+__device__ __forceinline__ xv xabs(xv a) { return fabsf(a); }
+__device__ __forceinline__ xv dppl(xv o, xv v) { return __int_as_float(dpp_from_lower_lane(__float_as_int(o), __float_as_int(v))); }
+__device__ __forceinline__ xv dppu(xv o, xv v) { return __int_as_float(dpp_from_upper_lane(__float_as_int(o), __float_as_int(v))); }
 
 // 26-neighbour test of the centre row B (rows A above, C below): bit (layer-1)*4 + k set for an extremum at column k.
-// The 3-wide horizontal extremes of a plane are formed right before the layers that need them (register pressure).
 __device__ __forceinline__ unsigned xtest_row(const XDog& A, const XDog& B, const XDog& C, int xm, int clo, int chi, bool row_ok) {
-    float c6[5][6], d6[5][6];                       // column-wise max / min over the three rows, with the neighbours' columns
+    // 3-wide horizontal extremes of the column-wise extremes of every plane: the 3x3 blocks of the planes above / below a layer
+    xv h3x[5][4], h3n[5][4];
+    xv c6m[3][6], c6n[3][6];                       // column-wise extremes of the three layer planes, with the neighbours' columns (in-plane test)
 #pragma unroll
     for (int p = 0; p < 5; p++) {
-        const v4f cm = __builtin_elementwise_max(__builtin_elementwise_max(A.m[p], B.m[p]), C.m[p]);
-        const v4f cn = __builtin_elementwise_min(__builtin_elementwise_min(A.m[p], B.m[p]), C.m[p]);
-        c6[p][0] = dpp_from_lower_lane(cm.w, cm.w); c6[p][1] = cm.x; c6[p][2] = cm.y; c6[p][3] = cm.z; c6[p][4] = cm.w; c6[p][5] = dpp_from_upper_lane(cm.x, cm.x);
-        d6[p][0] = dpp_from_lower_lane(cn.w, cn.w); d6[p][1] = cn.x; d6[p][2] = cn.y; d6[p][3] = cn.z; d6[p][4] = cn.w; d6[p][5] = dpp_from_upper_lane(cn.x, cn.x);
+        const v4x cm = __builtin_elementwise_max(__builtin_elementwise_max(A.m[p], B.m[p]), C.m[p]);
+        const v4x cn = __builtin_elementwise_min(__builtin_elementwise_min(A.m[p], B.m[p]), C.m[p]);
+        const xv x6[6] = {dppl(cm.w, cm.w), cm.x, cm.y, cm.z, cm.w, dppu(cm.x, cm.x)};
+        const xv n6[6] = {dppl(cn.w, cn.w), cn.x, cn.y, cn.z, cn.w, dppu(cn.x, cn.x)};
+#pragma unroll
+        for (int k = 0; k < 4; k++) { h3x[p][k] = imax3(x6[k], x6[k + 1], x6[k + 2]); h3n[p][k] = imin3(n6[k], n6[k + 1], n6[k + 2]); }
+        if (p >= 1 && p <= 3) {
+#pragma unroll
+            for (int j = 0; j < 6; j++) { c6m[p - 1][j] = x6[j]; c6n[p - 1][j] = n6[j]; }
+        }
     }
     unsigned hit = 0;
 #pragma unroll
     for (int layer = 1; layer <= N_LAYERS; layer++) {
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            const float val = B.m[layer][k];
-            float mx = fmaxf(fmaxf(c6[layer - 1][k], c6[layer - 1][k + 1]), c6[layer - 1][k + 2]);
-            mx = fmaxf(mx, fmaxf(fmaxf(c6[layer + 1][k], c6[layer + 1][k + 1]), c6[layer + 1][k + 2]));
-            mx = fmaxf(mx, fmaxf(fmaxf(c6[layer][k], c6[layer][k + 2]), fmaxf(A.m[layer][k], C.m[layer][k])));
-            float mn = fminf(fminf(d6[layer - 1][k], d6[layer - 1][k + 1]), d6[layer - 1][k + 2]);
-            mn = fminf(mn, fminf(fminf(d6[layer + 1][k], d6[layer + 1][k + 1]), d6[layer + 1][k + 2]));
-            mn = fminf(mn, fminf(fminf(d6[layer][k], d6[layer][k + 2]), fminf(A.m[layer][k], C.m[layer][k])));
-            // |val| > 20 && ((val > 0 && val >= mx) || (val < 0 && val <= mn))  <=>  |val| >= max(val > 0 ? mx : -mn, 21) on integers:
-            // exact (no arithmetic on the values) and all in the vector unit -- the mask logic of the plain form costs more
-            // scalar instructions than the whole rest of the row
-            const float q = val > 0.0f ? mx : -mn;
-            hit |= fabsf(val) >= fmaxf(q, DOG_THRESHOLD_P1) ? (1u << ((layer - 1) * 4 + k)) : 0u;
+            const xv val = B.m[layer][k];
+            // in-plane 8 neighbours: the two side columns' 3-row extremes and the pixels above / below
+            const xv ipx = imax3(c6m[layer - 1][k], c6m[layer - 1][k + 2], xmax(A.m[layer][k], C.m[layer][k]));
+            const xv ipn = imin3(c6n[layer - 1][k], c6n[layer - 1][k + 2], xmin(A.m[layer][k], C.m[layer][k]));
+            const xv mx = imax3(h3x[layer - 1][k], h3x[layer + 1][k], ipx);
+            const xv mn = imin3(h3n[layer - 1][k], h3n[layer + 1][k], ipn);
+            // |val| > 20 && ((val > 0 && val >= mx) || (val < 0 && val <= mn))  <=>  |val| >= max(val > 0 ? mx : -mn, 21) on integers
+            const xv q = val > (xv)0 ? mx : -mn;
+            hit |= xabs(val) >= xmax(q, (xv)21) ? (1u << ((layer - 1) * 4 + k)) : 0u;
         }
     }
     // validity of the row and of the lane's four columns, applied once
@@ -659,8 +673,6 @@ __device__ __forceinline__ unsigned xtest_row(const XDog& A, const XDog& B, cons
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void extrema_stream(OctaveDev oc, int octave, unsigned long long* cand, unsigned* count, unsigned cap, unsigned* overflow, BatchStride bs,
                     float* cube, unsigned cube_cap, int L, int nstrip, int nseg, int nb, int xsw /* columns per strip: multiple of 4, <= XSW */) {
-    __shared__ float s_ent[4][XCAP][32];           // per wave: parked candidates, 27 floats of DoG neighbourhood + the record in [30..31]
-    __shared__ unsigned s_cnt[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int unit = xcd_remap(blockIdx.x, gridDim.x) * 4 + wave;
     const int per = nstrip * nseg, fr = unit / per;
@@ -681,124 +693,101 @@ void extrema_stream(OctaveDev oc, int octave, unsigned long long* cand, unsigned
     int clo = xs > IMG_BORDER ? xs : IMG_BORDER, chi = xs + xsw < oc.w - IMG_BORDER ? xs + xsw : oc.w - IMG_BORDER;
     if (lane == 0 || lane == 63) { clo = 0; chi = 0; }
     const int hm1 = oc.h - 1;
-    if (lane == 0) s_cnt[wave] = 0;
-    auto wave_sync = [&]() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); };
-    wave_sync();
     auto load_row = [&](int r, XRow& q) {
         r = r < 0 ? 0 : (r > hm1 ? hm1 : r);                      // clamped rows are only ever neighbours of border pixels
         const size_t o = (size_t)r * oc.w + xl;
 #pragma unroll
-        for (int l = 0; l < N_LEVELS; l++) q.m[l] = ld4(oc.lv[l] + o);
+        for (int l = 0; l < N_LEVELS; l++) q.m[l] = *reinterpret_cast<const uint2*>(oc.lv[l] + o);
     };
+    auto unpack = [](uint2 q) { return (v4x){(xv)(int)(short)(q.x & 0xffffu), (xv)((int)q.x >> 16), (xv)(int)(short)(q.y & 0xffffu), (xv)((int)q.y >> 16)}; };
     auto to_dog = [&](const XRow& q, XDog& d) {
 #pragma unroll
-        for (int p = 0; p < 5; p++) d.m[p] = q.m[p + 1] - q.m[p];
+        for (int p = 0; p < 5; p++) d.m[p] = unpack(q.m[p + 1]) - unpack(q.m[p]);
     };
-    auto pack = [&](int layer, int rc, int c) {
-        return ((unsigned long long)octave << 48) | ((unsigned long long)layer << 40) | ((unsigned long long)rc << 20) | (unsigned long long)c;
-    };
+    // Candidates are rare per lane but not per wave (a 12 MP frame has ~2 per wave-row): a hit only appends its 8-byte record to a
+    // wave-private LDS list (slots from a ballot, the list length is wave-uniform and lives in a scalar); when the list is full, and at
+    // the end of the segment, every lane takes one record, re-reads the 3x3x3 DoG neighbourhood from the four levels (36 16-bit loads
+    // that hit lines this wave fetched a few rows ago -- ONE memory round trip per 64 candidates) and writes record + neighbourhood
+    // behind one region-counter atomic per flush.  Round 2 extracted the neighbourhood from the neighbour lanes' registers at once,
+    // code that ran on nearly every row and cost twice the test itself.
+    __shared__ unsigned long long s_rec[4][XCAP];
+    int nq = 0;                                      // wave-uniform
+    auto wave_sync = [&]() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); };
     auto flush = [&]() {
+        if (nq == 0) return;
         wave_sync();
-        unsigned n = s_cnt[wave];
-        if (n > XCAP) n = XCAP;
-        if (n) {
-            unsigned base = 0;
-            if (lane == 0) base = atomicAdd(&count[reg * REG_STRIDE], n);
-            base = __shfl(base, 0);
-            if ((unsigned)lane < n) {
-                const unsigned g = base + lane;
-                const unsigned long long rec = *reinterpret_cast<const unsigned long long*>(&s_ent[wave][lane][30]);
-                if (g < cap) cand[(size_t)reg * cap + g] = rec | (g < cube_cap ? (1ull << 63) : 0ull); else *overflow = 1;
+        unsigned base = 0;
+        if (lane == 0) base = atomicAdd(&count[reg * REG_STRIDE], (unsigned)nq);
+        base = __shfl(base, 0);
+        for (int idx = lane; idx < nq; idx += 64) {
+            const unsigned long long rec = s_rec[wave][idx];
+            const unsigned g = base + (unsigned)idx;
+            if (g >= cap) { *overflow = 1; continue; }
+            cand[(size_t)reg * cap + g] = rec | (g < cube_cap ? (1ull << 63) : 0ull);
+            if (g >= cube_cap) continue;
+            const int layer = (int)((rec >> 40) & 0xff), rc = (int)((rec >> 20) & 0xfffff), c = (int)(rec & 0xfffff);
+            float* cb = cube + ((size_t)reg * cube_cap + g) * 32;
+            int v[4][9];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const lvl_t* lp = oc.lv[0];
+#pragma unroll
+                for (int l = 1; l < N_LEVELS; l++) if (layer - 1 + q == l) lp = oc.lv[l];      // levels layer-1 .. layer+2 (layer in 1..3)
+#pragma unroll
+                for (int dr = 0; dr < 3; dr++)
+#pragma unroll
+                    for (int dc = 0; dc < 3; dc++) v[q][dr * 3 + dc] = (int)lp[(size_t)(rc - 1 + dr) * oc.w + (c - 1 + dc)];
             }
-            for (unsigned idx = lane; idx < n * 32; idx += 64) {
-                const unsigned g = base + (idx >> 5);
-                if (g < cube_cap) cube[((size_t)reg * cube_cap + g) * 32 + (idx & 31)] = (&s_ent[wave][0][0])[idx];
-            }
+#pragma unroll
+            for (int dl = 0; dl < 3; dl++)
+#pragma unroll
+                for (int e = 0; e < 9; e++) cb[dl * 9 + e] = (float)(v[dl + 1][e] - v[dl][e]);
         }
         wave_sync();
-        if (lane == 0) s_cnt[wave] = 0;
-        wave_sync();
+        nq = 0;
     };
-    int t = 0;                                       // next centre row, relative to y0
-    while (t < lact) {
-        // ---- (re)prime: rows t-1 and t as DoG, rows t+1 .. t+XD in flight ----
-        XDog win[3];
-        XRow nxt[XD];
-        {
-            XRow q;
-            load_row(y0 + t - 1, q); to_dog(q, win[0]);
-            load_row(y0 + t, q); to_dog(q, win[1]);
-#pragma unroll
-            for (int d = 0; d < XD; d++) load_row(y0 + t + 1 + d, nxt[d]);
-        }
-        int stop = 0;                                // 1: list full (resume at row t)   2: one row alone exceeds the list (slow row)
-        for (int tb = t; stop == 0 && tb < lact; tb += 3 * XD) {
-            auto step = [&](auto jc) -> bool {
-                constexpr int j = decltype(jc)::value;
-                const int tt = tb + j;
-                if (tt >= lact) { t = lact; return false; }
-                const int rc = y0 + tt;
-                XDog& A = win[j % 3]; XDog& B = win[(j + 1) % 3]; XDog& Cc = win[(j + 2) % 3];
-                to_dog(nxt[j % XD], Cc);
-                load_row(rc + 1 + XD, nxt[j % XD]);           // the bottom row of XD steps ahead, in flight meanwhile
-                const unsigned hit = xtest_row(A, B, Cc, xm, clo, chi, rc >= IMG_BORDER && rc < oc.h - IMG_BORDER);
-                if (__builtin_amdgcn_ballot_w64(hit != 0)) {      // rare: LDS only in here
-                    unsigned row_total = 0;
-#pragma unroll
-                    for (int b = 0; b < 12; b++) row_total += (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64((hit >> b) & 1u));
-                    const unsigned have = s_cnt[wave];
-                    if (have + row_total > XCAP) { t = tt; stop = (have == 0) ? 2 : 1; return false; }
-#pragma unroll
-                    for (int layer = 1; layer <= N_LAYERS; layer++)
-#pragma unroll
-                        for (int k = 0; k < 4; k++) {
-                            const bool mine = (hit >> ((layer - 1) * 4 + k)) & 1u;
-                            if (__builtin_amdgcn_ballot_w64(mine) == 0) continue;
-                            // the 3x3x3 neighbourhood: own registers, plus one column of the lane below / above for k = 0 / 3
-                            unsigned slot = 0;
-                            if (mine) slot = atomicAdd(&s_cnt[wave], 1u);
-                            float* e = &s_ent[wave][slot & (XCAP - 1)][0];
-#pragma unroll
-                            for (int dl = -1; dl <= 1; dl++) {
-                                const int p = layer + dl;
-                                const XDog* rows[3] = {&A, &B, &Cc};
-#pragma unroll
-                                for (int dr = 0; dr < 3; dr++) {
-                                    const v4f v = rows[dr]->m[p];
-                                    float x6[6] = {0.0f, v.x, v.y, v.z, v.w, 0.0f};
-                                    if (k == 0) x6[0] = dpp_from_lower_lane(v.w, v.w);
-                                    if (k == 3) x6[5] = dpp_from_upper_lane(v.x, v.x);
-                                    if (mine) {
-#pragma unroll
-                                        for (int dc = 0; dc < 3; dc++) e[(dl + 1) * 9 + dr * 3 + dc] = x6[k + dc];
-                                    }
-                                }
-                            }
-                            if (mine) *reinterpret_cast<unsigned long long*>(e + 30) = pack(layer, rc, xm + k);
-                        }
-                }
-                return true;
-            };
-            if (!static_rows<0, 3 * XD>(step)) break;
-        }
-        if (stop == 0) t = lact;
-        flush();
-        if (stop == 2) {
-            // pathological row (flat image): append its extrema one by one, without neighbourhoods
-            XRow q; XDog A, B, Cc;
-            load_row(y0 + t - 1, q); to_dog(q, A);
-            load_row(y0 + t, q); to_dog(q, B);
-            load_row(y0 + t + 1, q); to_dog(q, Cc);
-            const int rc = y0 + t;
-            unsigned hit = xtest_row(A, B, Cc, xm, clo, chi, rc >= IMG_BORDER && rc < oc.h - IMG_BORDER);
-            while (hit) {
-                const int b = __builtin_ctz(hit); hit &= hit - 1;
-                const unsigned g = atomicAdd(&count[reg * REG_STRIDE], 1u);
-                if (g < cap) cand[(size_t)reg * cap + g] = pack(b / 4 + 1, rc, xm + (b & 3)); else *overflow = 1;
+    auto emit = [&](unsigned hit, int rc) {
+        while (__builtin_amdgcn_ballot_w64(hit != 0)) {
+            const bool mine = hit != 0;
+            const int bb = mine ? __builtin_ctz(hit) : 0;
+            hit &= hit - 1;
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(mine);
+            const int add = __builtin_popcountll(m);
+            if (nq + add > XCAP) flush();
+            if (mine) {
+                const int layer = bb / 4 + 1, c = xm + (bb & 3);
+                s_rec[wave][nq + __builtin_popcountll(m & ((1ull << lane) - 1ull))] =
+                    ((unsigned long long)octave << 48) | ((unsigned long long)layer << 40) | ((unsigned long long)rc << 20) | (unsigned long long)c;
             }
-            t++;
+            nq += add;
         }
+    };
+    // rows t-1 and t as DoG, rows t+1 .. t+XD in flight
+    XDog win[3];
+    XRow nxt[XD];
+    {
+        XRow q;
+        load_row(y0 - 1, q); to_dog(q, win[0]);
+        load_row(y0, q); to_dog(q, win[1]);
+#pragma unroll
+        for (int d = 0; d < XD; d++) load_row(y0 + 1 + d, nxt[d]);
     }
+    for (int tb = 0; tb < lact; tb += 3 * XD) {
+        auto step = [&](auto jc) -> bool {
+            constexpr int j = decltype(jc)::value;
+            const int tt = tb + j;
+            if (tt >= lact) return false;
+            const int rc = y0 + tt;
+            XDog& A = win[j % 3]; XDog& B = win[(j + 1) % 3]; XDog& Cc = win[(j + 2) % 3];
+            to_dog(nxt[j % XD], Cc);
+            load_row(rc + 1 + XD, nxt[j % XD]);           // the bottom row of XD steps ahead, in flight meanwhile
+            const unsigned hit = xtest_row(A, B, Cc, xm, clo, chi, rc >= IMG_BORDER && rc < oc.h - IMG_BORDER);
+            emit(hit, rc);
+            return true;
+        };
+        if (!static_rows<0, 3 * XD>(step)) break;
+    }
+    flush();
 }
 
 __global__ __launch_bounds__(256) void refine_kernel(PyrDev P, const unsigned long long* cand_all, const unsigned* cand_counts, unsigned cand_cap, unsigned* cand_total,
@@ -1216,6 +1205,9 @@ __global__ __launch_bounds__(1024) void topk_kernel(const KpRec* kps, const unsi
 }
 
 // ---------- K5: descriptors -----------------------------------------------------------------------------------------
+// One WAVE per keypoint, four keypoints per workgroup (16 frames x 2000 keypoints as 256-thread workgroups of their own were
+// dispatch- and latency-bound: each lane looped over ~20 samples with four dependent 2-byte loads each).  A lane takes four
+// samples per trip and issues their 16 gradient loads before any is consumed; the histogram lives in wave-private LDS.
 __global__ __launch_bounds__(256) void describe_kernel(PyrDev P, const SelRec* sel, const int* n_sel, FrameOuts outs, BatchStride bs) {
     const size_t fr = blockIdx.y, foff = fr * bs.pyr;             // frame of the batch
     sel += fr * SEL_STRIDE; n_sel += fr * CNT_STRIDE;
@@ -1223,17 +1215,20 @@ __global__ __launch_bounds__(256) void describe_kernel(PyrDev P, const SelRec* s
 #pragma unroll
     for (int q = 1; q < SIFT_BATCH_MAX; q++) if ((int)fr == q) desc = outs.d8[q];
     constexpr int d = 4, n = 8, HB = (d + 2) * (d + 2) * (n + 2);
-    __shared__ unsigned long long s_hq[HB];
-    __shared__ float s_dst[128];
-    __shared__ float s_fac;
-    const int kidx = blockIdx.x, tid = threadIdx.x;
+    __shared__ unsigned long long s_hq4[4][HB];
+    __shared__ float s_dst4[4][128];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int kidx = blockIdx.x * 4 + wv;
     if (kidx >= *n_sel) return;
+    unsigned long long* s_hq = s_hq4[wv];
+    float* s_dst = s_dst4[wv];
+    auto wave_sync = [&]() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier(); };
     const SelRec k = sel[kidx];
     const OctaveDev& oc = P.oc[k.o];
     const lvl_t* img = oc.lv[k.layer] + foff;
     const int rows = oc.h, cols = oc.w;
-    for (int i = tid; i < HB; i += 256) s_hq[i] = 0ull;
-    __syncthreads();
+    for (int i = lane; i < HB; i += 64) s_hq[i] = 0ull;
+    wave_sync();
     const int px = (int)rintf(k.ptx), py = (int)rintf(k.pty);
     float sin_t, cos_t;
     det_sincosdeg(k.angle, sin_t, cos_t);
@@ -1243,75 +1238,86 @@ __global__ __launch_bounds__(256) void describe_kernel(PyrDev P, const SelRec* s
     const int radius = (int)rintf(hist_width * 1.4142135623730951f * (float)(d + 1) * 0.5f);
     cos_t = cos_t / hist_width; sin_t = sin_t / hist_width;
     const int side = 2 * radius + 1, S = side * side;
-    for (int s = tid; s < S; s += 256) {
-        const int ii = s / side, i = ii - radius, j = s - ii * side - radius;
-        const float c_rot = (float)j * cos_t - (float)i * sin_t;
-        const float r_rot = (float)j * sin_t + (float)i * cos_t;
-        float rbin = r_rot + (float)(d / 2) - 0.5f;
-        float cbin = c_rot + (float)(d / 2) - 0.5f;
-        const int r = py + i, c = px + j;
-        if (!(rbin > -1.0f && rbin < (float)d && cbin > -1.0f && cbin < (float)d && r > 0 && r < rows - 1 && c > 0 && c < cols - 1)) continue;
-        const float dx = (float)((int)img[(size_t)r * cols + c + 1] - (int)img[(size_t)r * cols + c - 1]);
-        const float dy = (float)((int)img[(size_t)(r - 1) * cols + c] - (int)img[(size_t)(r + 1) * cols + c]);
-        const float ori = det_atan2deg(dy, dx);
-        const float mag = sqrtf(dx * dx + dy * dy) * det_expf((c_rot * c_rot + r_rot * r_rot) * exp_scale);
-        float obin = (ori - k.angle) * bins_per_deg;
-        const float r0f = floorf(rbin), c0f = floorf(cbin), o0f = floorf(obin);
-        rbin -= r0f; cbin -= c0f; obin -= o0f;
-        const int r0 = (int)r0f, c0 = (int)c0f;
-        int o0 = (int)o0f;
-        if (o0 < 0) o0 += n;
-        if (o0 >= n) o0 -= n;
-        const float v_r1 = mag * rbin, v_r0 = mag - v_r1;
-        const float v_rc11 = v_r1 * cbin, v_rc10 = v_r1 - v_rc11;
-        const float v_rc01 = v_r0 * cbin, v_rc00 = v_r0 - v_rc01;
-        const float v_rco111 = v_rc11 * obin, v_rco110 = v_rc11 - v_rco111;
-        const float v_rco101 = v_rc10 * obin, v_rco100 = v_rc10 - v_rco101;
-        const float v_rco011 = v_rc01 * obin, v_rco010 = v_rc01 - v_rco011;
-        const float v_rco001 = v_rc00 * obin, v_rco000 = v_rc00 - v_rco001;
-        const int idx = ((r0 + 1) * (d + 2) + c0 + 1) * (n + 2) + o0;
-        // order-free accumulation: rint(v * 2^10) as 64-bit integers (two's complement add == unsigned add)
+    for (int s0 = lane; s0 < S; s0 += 256) {
+        float c_rotv[4], r_rotv[4], rbinv[4], cbinv[4], dxv[4], dyv[4]; bool okv[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int s = s0 + 64 * u;
+            const int ii = s / side, i = ii - radius, j = s - ii * side - radius;
+            const float c_rot = (float)j * cos_t - (float)i * sin_t;
+            const float r_rot = (float)j * sin_t + (float)i * cos_t;
+            const float rbin = r_rot + (float)(d / 2) - 0.5f;
+            const float cbin = c_rot + (float)(d / 2) - 0.5f;
+            const int r = py + i, c = px + j;
+            okv[u] = s < S && (rbin > -1.0f && rbin < (float)d && cbin > -1.0f && cbin < (float)d && r > 0 && r < rows - 1 && c > 0 && c < cols - 1);
+            c_rotv[u] = c_rot; r_rotv[u] = r_rot; rbinv[u] = rbin; cbinv[u] = cbin;
+            dxv[u] = 0.0f; dyv[u] = 0.0f;
+            if (okv[u]) {
+                dxv[u] = (float)((int)img[(size_t)r * cols + c + 1] - (int)img[(size_t)r * cols + c - 1]);
+                dyv[u] = (float)((int)img[(size_t)(r - 1) * cols + c] - (int)img[(size_t)(r + 1) * cols + c]);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            if (!okv[u]) continue;
+            const float dx = dxv[u], dy = dyv[u], c_rot = c_rotv[u], r_rot = r_rotv[u];
+            float rbin = rbinv[u], cbin = cbinv[u];
+            const float ori = det_atan2deg(dy, dx);
+            const float mag = sqrtf(dx * dx + dy * dy) * det_expf((c_rot * c_rot + r_rot * r_rot) * exp_scale);
+            float obin = (ori - k.angle) * bins_per_deg;
+            const float r0f = floorf(rbin), c0f = floorf(cbin), o0f = floorf(obin);
+            rbin -= r0f; cbin -= c0f; obin -= o0f;
+            const int r0 = (int)r0f, c0 = (int)c0f;
+            int o0 = (int)o0f;
+            if (o0 < 0) o0 += n;
+            if (o0 >= n) o0 -= n;
+            const float v_r1 = mag * rbin, v_r0 = mag - v_r1;
+            const float v_rc11 = v_r1 * cbin, v_rc10 = v_r1 - v_rc11;
+            const float v_rc01 = v_r0 * cbin, v_rc00 = v_r0 - v_rc01;
+            const float v_rco111 = v_rc11 * obin, v_rco110 = v_rc11 - v_rco111;
+            const float v_rco101 = v_rc10 * obin, v_rco100 = v_rc10 - v_rco101;
+            const float v_rco011 = v_rc01 * obin, v_rco010 = v_rc01 - v_rco011;
+            const float v_rco001 = v_rc00 * obin, v_rco000 = v_rc00 - v_rco001;
+            const int idx = ((r0 + 1) * (d + 2) + c0 + 1) * (n + 2) + o0;
+            // order-free accumulation: rint(v * 2^10) as 64-bit integers (two's complement add == unsigned add)
 #define FIXQ(v) ((unsigned long long)(long long)rintf((v) * HIST_Q))
-        atomicAdd(&s_hq[idx], FIXQ(v_rco000)); atomicAdd(&s_hq[idx + 1], FIXQ(v_rco001));
-        atomicAdd(&s_hq[idx + (n + 2)], FIXQ(v_rco010)); atomicAdd(&s_hq[idx + (n + 3)], FIXQ(v_rco011));
-        atomicAdd(&s_hq[idx + (d + 2) * (n + 2)], FIXQ(v_rco100)); atomicAdd(&s_hq[idx + (d + 2) * (n + 2) + 1], FIXQ(v_rco101));
-        atomicAdd(&s_hq[idx + (d + 3) * (n + 2)], FIXQ(v_rco110)); atomicAdd(&s_hq[idx + (d + 3) * (n + 2) + 1], FIXQ(v_rco111));
+            atomicAdd(&s_hq[idx], FIXQ(v_rco000)); atomicAdd(&s_hq[idx + 1], FIXQ(v_rco001));
+            atomicAdd(&s_hq[idx + (n + 2)], FIXQ(v_rco010)); atomicAdd(&s_hq[idx + (n + 3)], FIXQ(v_rco011));
+            atomicAdd(&s_hq[idx + (d + 2) * (n + 2)], FIXQ(v_rco100)); atomicAdd(&s_hq[idx + (d + 2) * (n + 2) + 1], FIXQ(v_rco101));
+            atomicAdd(&s_hq[idx + (d + 3) * (n + 2)], FIXQ(v_rco110)); atomicAdd(&s_hq[idx + (d + 3) * (n + 2) + 1], FIXQ(v_rco111));
 #undef FIXQ
+        }
     }
-    __syncthreads();
-    if (tid < 128) {
-        const int cell = tid >> 3, q = tid & 7, i = cell >> 2, j = cell & 3;
+    wave_sync();
+#pragma unroll
+    for (int half = 0; half < 2; half++) {
+        const int t = lane + 64 * half;
+        const int cell = t >> 3, q = t & 7, i = cell >> 2, j = cell & 3;
         const int idx = ((i + 1) * (d + 2) + (j + 1)) * (n + 2);
         float v = (float)(long long)s_hq[idx + q] * (1.0f / HIST_Q);
         if (q < 2) v = v + (float)(long long)s_hq[idx + n + q] * (1.0f / HIST_Q);       // circular orientation wrap
-        s_dst[tid] = v;
+        s_dst[t] = v;
     }
-    __syncthreads();
-    if (tid < 64) {
-        // sequential norms: the accumulation order is part of the definition.  The squares are formed by the 64 lanes, the
-        // running sum visits them in index order through lane broadcasts (a lone thread walking LDS was ~40 % of the
-        // workgroup's life)
-        float a = s_dst[tid], b = s_dst[tid + 64];
-        auto seq_sum = [&](float va, float vb) {
-            const float sa = va * va, sb = vb * vb;
-            float acc = 0.0f;
+    wave_sync();
+    // sequential norms: the accumulation order is part of the definition.  The squares are formed by the 64 lanes, the
+    // running sum visits them in index order through lane broadcasts
+    float a = s_dst[lane], b = s_dst[lane + 64];
+    auto seq_sum = [&](float va, float vb) {
+        const float sa = va * va, sb = vb * vb;
+        float acc = 0.0f;
 #pragma unroll
-            for (int q = 0; q < 64; q++) acc = acc + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sa), q));
+        for (int q = 0; q < 64; q++) acc = acc + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sa), q));
 #pragma unroll
-            for (int q = 0; q < 64; q++) acc = acc + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sb), q));
-            return acc;
-        };
-        const float thr = sqrtf(seq_sum(a, b)) * 0.2f;
-        a = a < thr ? a : thr; b = b < thr ? b : thr;
-        s_dst[tid] = a; s_dst[tid + 64] = b;
-        const float nn = sqrtf(seq_sum(a, b));
-        if (tid == 0) s_fac = 512.0f / (nn > 1.1920929e-7f ? nn : 1.1920929e-7f);
-    }
-    __syncthreads();
-    if (tid < 128) {
-        const float v = rintf(s_dst[tid] * s_fac);
-        desc[(size_t)kidx * 128 + tid] = (uint8_t)(v < 0.0f ? 0 : (v > 255.0f ? 255 : (int)v));
-    }
+        for (int q = 0; q < 64; q++) acc = acc + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sb), q));
+        return acc;
+    };
+    const float thr = sqrtf(seq_sum(a, b)) * 0.2f;
+    a = a < thr ? a : thr; b = b < thr ? b : thr;
+    const float nn = sqrtf(seq_sum(a, b));
+    const float fac = 512.0f / (nn > 1.1920929e-7f ? nn : 1.1920929e-7f);
+    const float va = rintf(a * fac), vb = rintf(b * fac);
+    desc[(size_t)kidx * 128 + lane] = (uint8_t)(va < 0.0f ? 0 : (va > 255.0f ? 255 : (int)va));
+    desc[(size_t)kidx * 128 + lane + 64] = (uint8_t)(vb < 0.0f ? 0 : (vb > 255.0f ? 255 : (int)vb));
 }
 
 // ---------- host ---------------------------------------------------------------------------------------------------
@@ -1744,7 +1750,7 @@ static int sift_run_batch(mi355_ctx* ctx, SiftWork* s) {
     }
     {
         ProfScope ps(ctx, "describe", 0.0, st);
-        hipLaunchKernelGGL(describe_kernel, dim3(nf, n), dim3(256), 0, st, s->P, s->sel.as<SelRec>(), reinterpret_cast<const int*>(cnt + 3), outs, bs);
+        hipLaunchKernelGGL(describe_kernel, dim3((nf + 3) / 4, n), dim3(256), 0, st, s->P, s->sel.as<SelRec>(), reinterpret_cast<const int*>(cnt + 3), outs, bs);
     }
     MI_HIP(hipGetLastError());
     for (int k = 0; k < n; k++) {
