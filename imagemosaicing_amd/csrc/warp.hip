@@ -412,23 +412,25 @@ void line_of_2_points(float& a, float& b, float& c, float x1, float y1, float x2
 
 struct LineSet { float A[4], B[4], C[4], inv[4]; };
 
-// per chip: min distance to the 4 quad edges for valid pixels, and the chip-wide max (float bits, all >= 0)
-__global__ __launch_bounds__(256) void distmap_kernel(const uint8_t* mask, int mws, int w, int h, LineSet L, float* map, unsigned* maxbits) {
+// distance of chip pixel (c, r) to the nearest of the 4 quad edges (MosaicImage.cpp:1790-1826); ONE expression for both kernels below:
+// the ownership kernel recomputes what the maximum kernel saw, so the values must be the same bits
+__device__ __forceinline__ float quad_min_dist(const LineSet& L, int c, int r) {
+    float minDist = (float)(1 << 29);
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const float d = fabsf(L.A[i] * (float)c + L.B[i] * (float)r + L.C[i]) * L.inv[i];
+        if (d < minDist) minDist = d;
+    }
+    return minDist;
+}
+
+// per chip: the chip-wide maximum of that distance over the valid pixels (float bits, all >= 0).  The distances themselves are NOT
+// stored (round 2 kept a float map per chip pixel: 4 of the 8 bytes per chip pixel, 101 GB for the 2000 chips of C5)
+__global__ __launch_bounds__(256) void distmax_kernel(const uint8_t* mask, int mws, int w, int h, LineSet L, unsigned* maxbits) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     const int r = blockIdx.y * blockDim.y + threadIdx.y;
     float v = 0.0f;
-    if (c < w && r < h) {
-        if (mask[(size_t)r * mws + c] != 0) {
-            float minDist = (float)(1 << 29);
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                float d = fabsf(L.A[i] * (float)c + L.B[i] * (float)r + L.C[i]) * L.inv[i];
-                if (d < minDist) minDist = d;
-            }
-            v = minDist;
-        }
-        map[(size_t)r * mws + c] = v;
-    }
+    if (c < w && r < h && mask[(size_t)r * mws + c] != 0) v = quad_min_dist(L, c, r);
     // wave max via shuffles, then one atomic per wave
     unsigned bits = __float_as_uint(v);
     for (int off = 32; off > 0; off >>= 1) { unsigned o = __shfl_xor(bits, off); bits = o > bits ? o : bits; }
@@ -437,28 +439,35 @@ __global__ __launch_bounds__(256) void distmap_kernel(const uint8_t* mask, int m
     if (((threadIdx.y * blockDim.x + threadIdx.x) & 63) == 0 && bits > *reinterpret_cast<volatile unsigned*>(maxbits)) atomicMax(maxbits, bits);
 }
 
-__global__ __launch_bounds__(256) void distmap_norm_kernel(float* map, int mws, int w, int h, const unsigned* maxbits) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    const int r = blockIdx.y * blockDim.y + threadIdx.y;
-    if (c >= w || r >= h) return;
-    const float mx = __uint_as_float(*maxbits);
-    map[(size_t)r * mws + c] = map[(size_t)r * mws + c] / mx;               // MosaicImage.cpp:1828
-}
-
-// per canvas pixel: chip with the strictly largest normalised distance (first wins, start 0) -> owner index
-__global__ __launch_bounds__(256) void owner_kernel(const ChipDev* chips, int n, const float* maps, int rectW, int rectH, uint8_t* const* masks) {
+// per canvas pixel: the chip with the strictly largest normalised distance (first wins, start 0) owns it (MosaicImage.cpp:1842-1872).
+// The candidates of a pixel come from the chip list of its 256 x 256 canvas block (ascending chip index = the reference's order);
+// validity is read from the masks (255 = sample exists), the distance is recomputed and divided by the chip's maximum (:1828), then
+// every covering chip's mask byte is rewritten: 255 for the owner, 0 for the others.  A mask byte belongs to exactly one canvas
+// pixel, so the thread of that pixel is the only one that touches it.
+constexpr int OWN_BLK = 256;
+__global__ __launch_bounds__(256) void owner_kernel(const ChipDev* chips, const LineSet* lines, const unsigned* maxbits, const int* list_off, const int* list,
+                                                    int bx_n, int rectW, int rectH, uint8_t* const* masks) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     const int r = blockIdx.y * blockDim.y + threadIdx.y;
     if (c >= rectW || r >= rectH) return;
+    const int blk = (r / OWN_BLK) * bx_n + (c / OWN_BLK);         // uniform over the workgroup (64 x 4 threads inside one block)
+    const int l0 = list_off[blk], l1 = list_off[blk + 1];
     int best = -1; float bd = 0.0f;
-    for (int k = 0; k < n; k++) {
+    for (int q = l0; q < l1; q++) {
+        const int k = list[q];
         const int yC = r - chips[k].y0, xC = c - chips[k].x0;
         if (yC >= 0 && yC < chips[k].h && xC >= 0 && xC < chips[k].w) {
-            const float d = maps[chips[k].map_off + (size_t)yC * chips[k].mws + xC];
+            float v = 0.0f;
+            if (masks[k][(size_t)yC * chips[k].mws + xC] != 0) v = quad_min_dist(lines[k], xC, yC);
+            const float d = v / __uint_as_float(maxbits[k]);
             if (d > bd) { bd = d; best = k; }
         }
     }
-    if (best >= 0) masks[best][(size_t)(r - chips[best].y0) * chips[best].mws + (c - chips[best].x0)] = 255;
+    for (int q = l0; q < l1; q++) {
+        const int k = list[q];
+        const int yC = r - chips[k].y0, xC = c - chips[k].x0;
+        if (yC >= 0 && yC < chips[k].h && xC >= 0 && xC < chips[k].w) masks[k][(size_t)yC * chips[k].mws + xC] = (k == best) ? 255 : 0;
+    }
 }
 
 }  // namespace
@@ -520,7 +529,6 @@ int mi_chips_and_masks_dev(mi355_ctx* ctx, const uint8_t* const* imgs, const int
     }
     DevBuf& dchips = ctx->buf("chip_imgs");
     DevBuf& dmasks = ctx->buf("chip_masks");
-    DevBuf& dmaps = ctx->buf("chip_maps");
     DevBuf& dsrc = ctx->buf("warp_src");
     DevBuf& dmeta = ctx->buf("chip_meta");
     MI_HIP(dchips.reserve(chip_total + 16));
@@ -554,38 +562,64 @@ int mi_chips_and_masks_dev(mi355_ctx* ctx, const uint8_t* const* imgs, const int
     }
     // validity masks are final here unless the distance-map ownership is requested
     if (find_masks && nv > 0) {
-        MI_HIP(dmaps.reserve(map_total * sizeof(float) + 16));
-        const size_t meta_bytes = sizeof(ChipDev) * nv + sizeof(uint8_t*) * nv + sizeof(unsigned) * nv;
-        MI_HIP(dmeta.reserve(meta_bytes + 64));
-        ChipDev* d_cd = dmeta.as<ChipDev>();
-        uint8_t** d_mptr = reinterpret_cast<uint8_t**>(dmeta.as<uint8_t>() + sizeof(ChipDev) * nv);
-        unsigned* d_max = reinterpret_cast<unsigned*>(dmeta.as<uint8_t>() + sizeof(ChipDev) * nv + sizeof(uint8_t*) * nv);
-        std::vector<uint8_t*> mptr(nv);
-        for (int v = 0; v < nv; v++) mptr[v] = dmasks.as<uint8_t>() + mask_off[v];
-        MI_HIP(hipMemcpyAsync(d_cd, cd.data(), sizeof(ChipDev) * nv, hipMemcpyHostToDevice, ctx->stream));
-        MI_HIP(hipMemcpyAsync(d_mptr, mptr.data(), sizeof(uint8_t*) * nv, hipMemcpyHostToDevice, ctx->stream));
-        MI_HIP(hipMemsetAsync(d_max, 0, sizeof(unsigned) * nv, ctx->stream));
-        dim3 block(64, 4);
+        // chip lists per 256 x 256 canvas block (host: the chips' rectangles are known), ascending chip index inside a block
+        const int bx_n = (newW + OWN_BLK - 1) / OWN_BLK, by_n = (newH + OWN_BLK - 1) / OWN_BLK;
+        std::vector<int> loff((size_t)bx_n * by_n + 1, 0);
+        for (int v = 0; v < nv; v++) {
+            const int bx0 = std::max(0, ci[v].x0 / OWN_BLK), bx1 = std::min(bx_n - 1, (ci[v].x0 + ci[v].w - 1) / OWN_BLK);
+            const int by0 = std::max(0, ci[v].y0 / OWN_BLK), by1 = std::min(by_n - 1, (ci[v].y0 + ci[v].h - 1) / OWN_BLK);
+            for (int by = by0; by <= by1; by++) for (int bx = bx0; bx <= bx1; bx++) loff[(size_t)by * bx_n + bx + 1]++;
+        }
+        for (size_t q = 1; q < loff.size(); q++) loff[q] += loff[q - 1];
+        std::vector<int> lst((size_t)loff.back() > 0 ? loff.back() : 1), fill(loff.begin(), loff.end() - 1);
+        for (int v = 0; v < nv; v++) {
+            const int bx0 = std::max(0, ci[v].x0 / OWN_BLK), bx1 = std::min(bx_n - 1, (ci[v].x0 + ci[v].w - 1) / OWN_BLK);
+            const int by0 = std::max(0, ci[v].y0 / OWN_BLK), by1 = std::min(by_n - 1, (ci[v].y0 + ci[v].h - 1) / OWN_BLK);
+            for (int by = by0; by <= by1; by++) for (int bx = bx0; bx <= bx1; bx++) lst[fill[(size_t)by * bx_n + bx]++] = v;
+        }
+        std::vector<LineSet> lines(nv);
         for (int v = 0; v < nv; v++) {
             const float* q = ci[v].quad;
-            LineSet L;
+            LineSet& L = lines[v];
             line_of_2_points(L.A[0], L.B[0], L.C[0], q[0], q[1], q[2], q[3]);
             line_of_2_points(L.A[1], L.B[1], L.C[1], q[2], q[3], q[4], q[5]);
             line_of_2_points(L.A[2], L.B[2], L.C[2], q[4], q[5], q[6], q[7]);
             line_of_2_points(L.A[3], L.B[3], L.C[3], q[6], q[7], q[0], q[1]);
             for (int i = 0; i < 4; i++) L.inv[i] = 1.0f / sqrtf(L.A[i] * L.A[i] + L.B[i] * L.B[i]);       // :1786
-            dim3 grid((ci[v].w + 63) / 64, (ci[v].h + 3) / 4);
-            float* map = dmaps.as<float>() + cd[v].map_off;
-            ProfScope ps(ctx, "distmap", (double)ci[v].w * ci[v].h * 9.0);
-            hipLaunchKernelGGL(distmap_kernel, grid, block, 0, ctx->stream, mptr[v], cd[v].mws, ci[v].w, ci[v].h, L, map, d_max + v);
-            hipLaunchKernelGGL(distmap_norm_kernel, grid, block, 0, ctx->stream, map, cd[v].mws, ci[v].w, ci[v].h, d_max + v);
         }
-        MI_HIP(hipMemsetAsync(dmasks.p, 0, mask_total, ctx->stream));                                      // cvZero, :1836-1839
+        auto up16 = [](size_t b) { return (b + 15) & ~(size_t)15; };
+        const size_t o_cd = 0, o_mp = up16(o_cd + sizeof(ChipDev) * nv), o_mx = up16(o_mp + sizeof(uint8_t*) * nv), o_ln = up16(o_mx + sizeof(unsigned) * nv),
+                     o_lo = up16(o_ln + sizeof(LineSet) * nv), o_ls = up16(o_lo + sizeof(int) * loff.size()), meta_bytes = o_ls + sizeof(int) * lst.size();
+        MI_HIP(dmeta.reserve(meta_bytes + 64));
+        uint8_t* mb = dmeta.as<uint8_t>();
+        ChipDev* d_cd = reinterpret_cast<ChipDev*>(mb + o_cd);
+        uint8_t** d_mptr = reinterpret_cast<uint8_t**>(mb + o_mp);
+        unsigned* d_max = reinterpret_cast<unsigned*>(mb + o_mx);
+        LineSet* d_lines = reinterpret_cast<LineSet*>(mb + o_ln);
+        int* d_loff = reinterpret_cast<int*>(mb + o_lo);
+        int* d_list = reinterpret_cast<int*>(mb + o_ls);
+        std::vector<uint8_t*> mptr(nv);
+        for (int v = 0; v < nv; v++) mptr[v] = dmasks.as<uint8_t>() + mask_off[v];
+        MI_HIP(hipMemcpyAsync(d_cd, cd.data(), sizeof(ChipDev) * nv, hipMemcpyHostToDevice, ctx->stream));
+        MI_HIP(hipMemcpyAsync(d_mptr, mptr.data(), sizeof(uint8_t*) * nv, hipMemcpyHostToDevice, ctx->stream));
+        MI_HIP(hipMemcpyAsync(d_lines, lines.data(), sizeof(LineSet) * nv, hipMemcpyHostToDevice, ctx->stream));
+        MI_HIP(hipMemcpyAsync(d_loff, loff.data(), sizeof(int) * loff.size(), hipMemcpyHostToDevice, ctx->stream));
+        MI_HIP(hipMemcpyAsync(d_list, lst.data(), sizeof(int) * lst.size(), hipMemcpyHostToDevice, ctx->stream));
+        MI_HIP(hipMemsetAsync(d_max, 0, sizeof(unsigned) * nv, ctx->stream));
+        dim3 block(64, 4);
+        {
+            ProfScope ps(ctx, "distmap", (double)chip_total / 3.0);
+            for (int v = 0; v < nv; v++) {
+                dim3 grid((ci[v].w + 63) / 64, (ci[v].h + 3) / 4);
+                hipLaunchKernelGGL(distmax_kernel, grid, block, 0, ctx->stream, mptr[v], cd[v].mws, ci[v].w, ci[v].h, lines[v], d_max + v);
+            }
+        }
         dim3 grid((newW + 63) / 64, (newH + 3) / 4);
         {
-            ProfScope ps(ctx, "owner", (double)newW * newH * (4.0 * nv + 1.0));
-            hipLaunchKernelGGL(owner_kernel, grid, block, 0, ctx->stream, d_cd, nv, dmaps.as<float>(), newW, newH, d_mptr);
+            ProfScope ps(ctx, "owner", (double)newW * newH);
+            hipLaunchKernelGGL(owner_kernel, grid, block, 0, ctx->stream, d_cd, d_lines, d_max, d_loff, d_list, bx_n, newW, newH, d_mptr);
         }
+        MI_HIP(hipStreamSynchronize(ctx->stream));        // the host vectors above were sources of asynchronous copies
     }
     MI_HIP(hipGetLastError());
     *n_chips = nv; *chips_out = ci_hold.release();

@@ -7,7 +7,7 @@
   C5  2000 frames of 4000x3000 resident in HBM (72 GB), global transforms whose bounding box is a 20000 x 20000-class canvas
       (SURVEY 8d).  MosaicImagesRefined: 8 stripes (one per GPU of the node) == the whole canvas, byte for byte, and
       4 random 1024^2 windows == the oracle's image-after-image overwrite.  LaplacianPyramidBlending (MosaicImage.cpp:2205-2510)
-      through mi355_mosaic_blended_dev with chips, masks, distance maps and the blender's pyramids co-resident with the frames:
+      through mi355_mosaic_blended_dev with ALL chips, their masks and the blender's pyramids co-resident with the frames (180 GB):
       4 random 1024^2 windows == oracle chips -> FindMasksByDistMap -> multiband blend (oracle_blend.c).
 
 The window checks render with the oracle only what can reach the window: the images (chips) that intersect it, in image order,
@@ -184,14 +184,10 @@ def test_c5_full_size_canvas_and_blend():
     # ---- LaplacianPyramidBlending, everything co-resident --------------------------------------------------------------------
     # vecAbandonInd: the reference's ResampleByOverlap(0.7) (MosaicImage.cpp:2069-2201; host function, == the reference's own code in
     # tests/test_overlap.py) keeps ALL 2000 images of this survey -- it only measures overlaps whose polygon has 3 or 4 corners, and
-    # rectangles that differ by a small yaw intersect in 6 to 8.  All 2000 chips with their masks and distance maps (8 B per chip
-    # pixel = 202 GB) do not fit beside the 72 GB of frames, so the caller thins the list further, which the interface allows
-    # (keep[] is an input of LaplacianPyramidBlending's warp stage): every 5th image and the last = 401 chips, ~17 deep per pixel.
+    # rectangles that differ by a small yaw intersect in 6 to 8.  So all ~1998 valid chips (3 B) and masks (1 B per chip pixel: 101 GB)
+    # sit beside the 72 GB of frames and the blender's pyramids; the distance maps are not stored any more (warp.hip owner_kernel).
     keep = im.resample_by_overlap(wv, hv, h9, 0.7)
-    assert keep[0] == 1 and keep[F - 1] == 1
-    keep[np.arange(F) % 5 != 0] = 0
-    keep[F - 1] = 1
-    assert int(keep.sum()) == 401
+    assert keep[0] == 1 and keep[F - 1] == 1 and int(keep.sum()) == F
     band = 5
     out, bw, bh, bws = ctx.MosaicBlendedDev(fptr, wv, hv, wsv, h9, keep=keep, band=band)     # torch uint8 [bh, bws] in HBM
     ctx.synchronize()
@@ -206,11 +202,8 @@ def test_c5_full_size_canvas_and_blend():
         cx0, cy0 = max(0, (x0 - M) // AL * AL), max(0, (y0 - M) // AL * AL)
         cx1, cy1 = min(bw, x0 + 1024 + M), min(bh, y0 + 1024 + M)
         sub = [c for c in chips if c["x0"] < cx1 and c["x0"] + c["w"] > cx0 and c["y0"] < cy1 and c["y0"] + c["h"] > cy0]
-        cimgs, masks = [], []
-        for c in sub:
-            k = int(c["img"])
-            chip, mask = orc.chip_warp(host_image(frames, k, w, h, ws), h9[k], ldG, c)
-            cimgs.append(chip); masks.append(mask)
+        cm = ol.parallel_map(lambda c: orc.chip_warp(host_image(frames, int(c["img"]), w, h, ws), h9[int(c["img"])], ldG, c), sub, threads=min(48, _threads()))
+        cimgs, masks = [c_ for c_, _ in cm], [m_ for _, m_ in cm]
         # ownership inside the crop only: chip origins relative to the crop, rect = the crop (pixels outside stay 0 = not owned)
         shifted = np.array(sub, ol.CHIPINFO)
         shifted["x0"] -= cx0; shifted["y0"] -= cy0
@@ -232,7 +225,7 @@ def test_c5_full_size_canvas_and_blend():
         return ref[y0 - cy0:y0 - cy0 + 1024, 3 * (x0 - cx0):3 * (x0 - cx0 + 1024)].copy(), len(sub)
 
     bwins = [(int(rng.integers(0, bw - 1024)), int(rng.integers(0, bh - 1024))) for _ in range(4)]
-    for win, (ref, nsub) in zip(bwins, ol.parallel_map(blended_window, bwins, threads=4)):
+    for win, (ref, nsub) in zip(bwins, [blended_window(bw_) for bw_ in bwins]):
         x0, y0 = win
         got = out[y0:y0 + 1024, 3 * x0:3 * (x0 + 1024)].cpu().numpy()
         assert nsub >= 2 and np.array_equal(got, ref), f"C5 blend window {win}: {int((got != ref).sum())} bytes differ ({nsub} chips)"
