@@ -76,6 +76,11 @@ def parse():
                          "all-gathers (features, pair records); weak = an independent --frames strip per rank")
     ap.add_argument("--transport", choices=["rccl", "torch"], default=None,
                     help="exchange transport: rccl = the C ABI's own ncclAllGather calls (default with backend nccl), torch = torch.distributed (gloo dry runs)")
+    ap.add_argument("--layout", choices=["strip", "block"], default="strip",
+                    help="strip = serpentine survey, 60 %% forward / 30 %% side overlap (SURVEY 8d; C3 / C4); block = the frames piled onto a ~20000 x 20000 canvas (C5's canvas)")
+    ap.add_argument("--blend", action="store_true",
+                    help="after the timed steps also render the survey with LaplacianPyramidBlending (mi355_mosaic_blended_dev: frames, chips, masks and the blender's "
+                         "pyramids co-resident in HBM) and report its time and the resident memory; not part of `value` (the metric's warp is the last-write-wins canvas)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-all", action="store_true", help="bracket every kernel class with events (extra JSON field)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for single-GPU dry runs of the N>1 path)")
@@ -83,7 +88,7 @@ def parse():
     return ap.parse_args()
 
 
-from tests.synth_survey import frame_layout, affine3  # noqa: E402  (ground-truth geometry shared with tests/test_gpu_configs.py)
+from tests.synth_survey import frame_layout, block_layout, affine3  # noqa: E402  (ground-truth geometry shared with tests/test_gpu_configs.py)
 
 
 def cpu_has_v3():
@@ -214,6 +219,8 @@ def main():
     # stripe, SURVEY 8e "replicas of frames + stripes"), detect+describe and pairs sharded; weak: an independent strip per rank
     lay_rank = 0 if strong else rank
     A, gains = frame_layout(F, w, h, lay_rank)
+    if args.layout == "block":
+        A = block_layout(F, w, h, seed=5 + lay_rank)
     # ---- synthetic frames, generated straight into HBM (never timed) ----
     frames = torch.empty((F, h * ws), dtype=torch.uint8, device=dev)
     for k in range(F):
@@ -302,7 +309,7 @@ def main():
                                  "host_global_alignment": (t3 - t2) * 1e3, "warp": (t4 - t3) * 1e3}
             if os.environ.get("MI355_BENCH_PHASES"):
                 print("[phases ms] sift %.1f  match+D2H %.1f  host align %.1f  warp %.1f" % ((t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3, (t4 - t3) * 1e3), file=sys.stderr)
-        state.update(r=r, cw=cw, ch=ch, n_valid=int(label.sum()))
+        state.update(r=r, cw=cw, ch=ch, n_valid=int(label.sum()), h9=h9)
 
     def barrier():
         torch.cuda.synchronize()
@@ -393,6 +400,26 @@ def main():
         errs.append(float(np.abs(a[:2] / a[2] - b[:2] / b[2]).max()))
     accepted = int(r["accepted"].sum()) if n_pairs else 0
 
+    blend = None
+    if args.blend and world == 1:
+        # LaplacianPyramidBlending of the survey as aligned by the last step: everything stays in HBM (device frames in, device canvas out)
+        h9b = state["h9"]
+        keep = im.resample_by_overlap(wv, hv, h9b, 0.7)                 # MosaicImage.cpp:2227-2230
+        torch.cuda.synchronize()
+        free0 = torch.cuda.mem_get_info()[0]
+        tb = []
+        for rep in range(2):
+            t_b = time.perf_counter()
+            outb, bw_, bh_, bws_ = ctx.MosaicBlendedDev(fptr, wv, hv, wsv, h9b, keep=keep, band=5)
+            ctx.synchronize()
+            tb.append((time.perf_counter() - t_b) * 1e3)
+        free1 = torch.cuda.mem_get_info()[0]
+        tot = torch.cuda.mem_get_info()[1]
+        blend = {"ms": min(tb), "ms_first_call": tb[0], "chips": int(keep.sum()), "canvas": [bw_, bh_], "bands": 5,
+                 "resident_gb": (tot - free1) / 1e9, "blend_buffers_gb": (free0 - free1) / 1e9, "frames_gb": F * h * ws / 1e9,
+                 "note": "mi355_mosaic_blended_dev: chips (3 B) + masks (1 B per chip pixel) + canvas Laplacian / weight pyramids next to the frames; device in, device out (no PCIe); second call (buffers allocated)"}
+        del outb
+
     out = None
     # HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes of this same command
     # (profiles/pmc_traffic.py; counters cannot be read from inside the process): reported only when the workload matches
@@ -417,7 +444,7 @@ def main():
             "data": "synthetic",
             "transport": transport if exchange else None, "rccl_ranks": rccl_ranks,
             "config": {"workload": "%s: %s, pair window %d (%d pairs), SIFT(2000,3,0.01,20) + exact BF match + 3x3 grid select + Ransac2D + MosaicImagesRefined warp"
-                                   % ("C3" if args.window == 2 else (("C5" if F >= 2000 else "C4") if args.window == 182 else "window-%d" % args.window),
+                                   % (("C3" if args.window == 2 else (("C5" if F >= 2000 else "C4") if args.window == 182 else "window-%d" % args.window)) + (" (block layout)" if args.layout == "block" else ""),
                                       ("ONE %d-frame %dx%d UAV survey" % (F, w, h)) if strong else ("%d-frame %dx%d UAV strip per GPU" % (F, w, h)),
                                       args.window, survey_pairs),
                        "frames": F if strong else F * world, "pairs": survey_pairs, "frames_per_gpu": len(own), "pairs_per_gpu": n_pairs,
@@ -463,6 +490,7 @@ def main():
                      "peak": 2500.0, "unit": "TFLOP/s", "frac": ((n_pairs * args.steps * 2.0 * 2000 * 2000 * 128 / 1e12) / (m_ms / 1e3) / 2500.0) if m_ms > 0 else None,
                      "ms_per_step": m_ms / max(args.steps, 1), "note": "dense bf16 peak; 0.3 % of the step time"},
             "phase_ms": state.get("phase_ms"),
+            "blend": blend,
             "quality": {"pairs_accepted": accepted, "pairs": survey_pairs if strong else n_pairs, "images_aligned": state["n_valid"],
                         "h_corner_err_px_median": float(np.median(errs)) if errs else None,
                         "h_corner_err_px_max": float(np.max(errs)) if errs else None},

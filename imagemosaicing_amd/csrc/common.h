@@ -35,7 +35,9 @@ struct DevBuf {
     hipError_t reserve(size_t bytes) {
         if (bytes <= cap) return hipSuccess;
         if (p) { hipError_t e = hipFree(p); if (e != hipSuccess) return e; p = nullptr; cap = 0; }
-        size_t want = bytes + bytes / 4 + 256;
+        size_t slack = bytes / 4;                     // growth room for small workspaces; bounded: a 100 GB chip buffer must not take 125
+        if (slack > ((size_t)256 << 20)) slack = (size_t)256 << 20;
+        size_t want = bytes + slack + 256;
         hipError_t e = hipMalloc(&p, want);
         if (e == hipSuccess) cap = want;
         return e;

@@ -25,6 +25,27 @@ def frame_layout(n, w, h, rank=0, seed=0xC0FFEE, per_row=25):
     return np.array(A, np.float64), np.array(gains)
 
 
+def block_layout(n, w, h, cols=50, seed=5, extent=20000.0):
+    """frame -> ground affine maps of a dense block survey whose bounding box is ~20000 x 20000 (C5), +-3 deg yaw,
+    +-2 % scale; returns A [n, 6]"""
+    rng = np.random.default_rng(seed)
+    rows = (n + cols - 1) // cols
+    sx = (extent - w) / (cols - 1)
+    sy = (extent - h) / (rows - 1)
+    A = []
+    for k in range(n):
+        r, c = divmod(k, cols)
+        if r & 1:
+            c = cols - 1 - c
+        cx, cy = w / 2 + c * sx + rng.uniform(-20, 20), h / 2 + r * sy + rng.uniform(-20, 20)
+        yaw = np.deg2rad(rng.uniform(-3, 3)); s = 1 + rng.uniform(-0.02, 0.02)
+        R = s * np.array([[np.cos(yaw), -np.sin(yaw)], [np.sin(yaw), np.cos(yaw)]])
+        t = np.array([cx, cy]) - R @ np.array([w / 2.0, h / 2.0])
+        A.append([R[0, 0], R[0, 1], t[0], R[1, 0], R[1, 1], t[1]])
+    return np.array(A, np.float64)
+
+
+
 def affine3(a6):
     return np.array([[a6[0], a6[1], a6[2]], [a6[3], a6[4], a6[5]], [0, 0, 1.0]])
 

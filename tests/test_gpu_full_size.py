@@ -89,26 +89,6 @@ def test_c4_full_size_one_gpu():
 
 
 # ---------------------------------------------------------------------------------------------------------------------------------
-def _c5_layout(n, w, h, cols=50, seed=5):
-    """frame -> ground affine maps of a dense block survey whose bounding box is ~20000 x 20000 (C5), +-3 deg yaw,
-    +-2 % scale; returns A [n, 6]"""
-    rng = np.random.default_rng(seed)
-    rows = (n + cols - 1) // cols
-    sx = (20000.0 - w) / (cols - 1)
-    sy = (20000.0 - h) / (rows - 1)
-    A = []
-    for k in range(n):
-        r, c = divmod(k, cols)
-        if r & 1:
-            c = cols - 1 - c
-        cx, cy = w / 2 + c * sx + rng.uniform(-20, 20), h / 2 + r * sy + rng.uniform(-20, 20)
-        yaw = np.deg2rad(rng.uniform(-3, 3)); s = 1 + rng.uniform(-0.02, 0.02)
-        R = s * np.array([[np.cos(yaw), -np.sin(yaw)], [np.sin(yaw), np.cos(yaw)]])
-        t = np.array([cx, cy]) - R @ np.array([w / 2.0, h / 2.0])
-        A.append([R[0, 0], R[0, 1], t[0], R[1, 0], R[1, 1], t[1]])
-    return np.array(A, np.float64)
-
-
 def _bbox(h9, w, h):
     c = np.array([[0, 0, 1], [w - 1, 0, 1], [w - 1, h - 1, 1], [0, h - 1, 1]], np.float64).T
     p = h9.reshape(3, 3).astype(np.float64) @ c
@@ -120,12 +100,12 @@ def test_c5_full_size_canvas_and_blend():
     import torch
     import imagemosaicing_amd as im
     from tests import oracle_lib as ol
-    from tests.synth_survey import affine3, host_image
+    from tests.synth_survey import affine3, host_image, block_layout
     orc = ol.load_oracle_fast()
     ctx = im.Context(0)
     w, h, F = 4000, 3000, 2000
     ws = (3 * w + 3) & ~3
-    A = _c5_layout(F, w, h)
+    A = block_layout(F, w, h)
     rng = np.random.default_rng(8)
     frames = torch.empty((F, h * ws), dtype=torch.uint8, device="cuda")        # 72 GB resident
     for k in range(F):
