@@ -5,10 +5,19 @@
  *   blender.feed(chip converted to CV_16S, mask, corner) per chip;  blender.blend(result_s, result_mask);
  *   result_s.convertTo(result, CV_8U)                       (MosaicImage.cpp:2296-2299, 2451-2486)
  *
- * PARITY UNPINNED: the arithmetic is OpenCV 2.4.0 `stitching` (blenders.cpp) + `imgproc` (pyramids.cpp), vendored in
- * the reference as headers + Win32 binaries only.  This file restates the published algorithm (Burt & Adelson 1983
- * multiresolution spline) in the shape OpenCV gives it -- 16-bit Laplacian pyramids, float weight pyramids, 5-tap
- * [1 4 6 4 1] REDUCE / EXPAND in integer arithmetic -- and DEFINES every free choice:
+ * PARITY UNPINNED AT THE BIT LEVEL: the arithmetic is OpenCV 2.4.0 `stitching` (blenders.cpp) + `imgproc` (pyramids.cpp), vendored
+ * in the reference as headers + Win32 binaries only, and the reference commits no blended output to compare with.  The STRUCTURE
+ * below was checked this round against the reference's own binary (Release/opencv_stitching240.dll, llvm-objdump):
+ *   MultiBandBlender::feed (1000b190): gap = 3 << num_bands (1000b3c0-1000b3cb), corners snapped by >> / << num_bands (1000b486-1000b48c),
+ *     copyMakeBorder(img, .., BORDER_REFLECT = 2) (1000b61d-1000b657), createLaplacePyr (1000b6c0), weight = mask.convertTo(CV_32F, 1/255)
+ *     (1000b776-1000b782; the CV_16S weight branch exists and is not taken: the reference constructs MultiBandBlender(false, band)),
+ *     copyMakeBorder of the weight with a constant border, pyrDown(.., BORDER_DEFAULT = 4) per level (1000b9bb), accumulation through
+ *     sign-extended 16-bit loads and truncating float -> int conversions;
+ *   createLaplacePyr (1000a440): pyrDown chain, pyrUp to the finer size, cv::subtract(.., dtype CV_16S = 3) (1000a59f-1000a797);
+ *   normalizeUsingWeightMap (10006710): (short)(value / (weight + 1e-5f)) with cvttss2si = truncation toward zero (1000684d-100068ce).
+ * The per-pixel arithmetic of cv::pyrDown / cv::pyrUp for CV_16SC3 and CV_32F (opencv_imgproc240.dll) was NOT read from the binary;
+ * it is restated from the published algorithm (Burt & Adelson 1983 multiresolution spline) in the shape OpenCV gives it -- 16-bit
+ * Laplacian pyramids, float weight pyramids, 5-tap [1 4 6 4 1] REDUCE / EXPAND in integer arithmetic -- with these choices:
  *   REDUCE  (pyrDown) i16: v = sum over the 5x5 taps (rows then columns, int), out = (v + 128) >> 8; reflect-101 border
  *           f32: row = s[2x]*6 + (s[2x-1] + s[2x+1])*4 + s[2x-2] + s[2x+2] (left to right), same vertically, times 1/256
  *   EXPAND  (pyrUp) i16 to exactly twice the size: horizontally even = s[x-1] + 6 s[x] + s[x+1], odd = 4 (s[x] + s[x+1]),
