@@ -192,7 +192,8 @@ __device__ __forceinline__ void blur16_stream_body(const Blur16Args a, int L, in
     static_assert((D % 2 == 0) || true, "prefetch depth");
     __shared__ v4f s_buf[4][2][(BW + 64) / 4];      // + 64 floats: dump area for lanes that have no halo / fix-up work
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    int unit = xcd_remap(blockIdx.x, gridDim.x) * 4 + wave;
+    // wave-uniform by construction; readfirstlane tells the compiler, so that rows, segments and their branches live in scalar registers
+    int unit = __builtin_amdgcn_readfirstlane(xcd_remap(blockIdx.x, gridDim.x) * 4 + wave);
     const int per = nstrip * nseg, fr = unit / per;
     if (fr >= a.nb) return;
     unit -= fr * per;
@@ -349,6 +350,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 }
 template <int R, int D, bool BGR>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void blur16_stream3(Blur16Args a, int L, int nstrip, int nseg) {
+    blur16_stream_body<R, D, BGR>(a, L, nstrip, nseg);
+}
+template <int R, int D, bool BGR>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void blur16_stream4(Blur16Args a, int L, int nstrip, int nseg) {
     blur16_stream_body<R, D, BGR>(a, L, nstrip, nseg);
 }
 
@@ -674,7 +679,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void extrema_stream(OctaveDev oc, int octave, unsigned long long* cand, unsigned* count, unsigned cap, unsigned* overflow, BatchStride bs,
                     float* cube, unsigned cube_cap, int L, int nstrip, int nseg, int nb, int xsw /* columns per strip: multiple of 4, <= XSW */) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    int unit = xcd_remap(blockIdx.x, gridDim.x) * 4 + wave;
+    // wave-uniform by construction; readfirstlane tells the compiler, so that rows, segments and their branches live in scalar registers
+    int unit = __builtin_amdgcn_readfirstlane(xcd_remap(blockIdx.x, gridDim.x) * 4 + wave);
     const int per = nstrip * nseg, fr = unit / per;
     if (fr >= nb) return;
     unit -= fr * per;
@@ -1357,18 +1363,25 @@ bool launch_blur(hipStream_t st, int R, const Blur16Args& a, int stream_mode, bo
     if (streamed) *streamed = false;
     if (blur_streams(a, BGR, R, stream_mode)) {
         // barrier-free streaming kernel: ~2 waves per SIMD over the whole chip (2048 waves), segments of >= 64 rows, all frames of a batch in one launch
-        static const int w3 = [] { const char* e = getenv("MI355_STREAM_W3"); return e ? atoi(e) : 10; }();     // largest radius run with 3 waves per SIMD
-        const bool three = R <= w3 && R <= 10;
+        // waves per SIMD: the register ring of the row results (4 x (2R + 2) registers) decides: R <= 8 fits 128 registers (4 waves),
+        // R = 10 fits 168 (3 waves), R = 13 needs 176 (2 waves)
+        static const int w4 = [] { const char* e = getenv("MI355_STREAM_W4"); return e ? atoi(e) : 8; }();
+        static const int w3 = [] { const char* e = getenv("MI355_STREAM_W3"); return e ? atoi(e) : 10; }();
+        const int waves = (R <= w4 && R <= 8) ? 4 : ((R <= w3 && R <= 10) ? 3 : 2);
         int L, nstrip, nseg;
-        stream_grid(a.w, a.h, L, nstrip, nseg, nb, three ? 3 : 2);
+        stream_grid(a.w, a.h, L, nstrip, nseg, nb, waves);
         const int units = nstrip * nseg * nb;
         const dim3 grid((units + 3) / 4), block(256);
         if (streamed) *streamed = true;
         switch (R) {
-#define CASE(RR, DD) case RR: if (three) hipLaunchKernelGGL((blur16_stream3<RR, DD, BGR>), grid, block, 0, st, a, L, nstrip, nseg); \
+#define CASE(RR, DD) case RR: if (waves == 4) hipLaunchKernelGGL((blur16_stream4<RR, DD, BGR>), grid, block, 0, st, a, L, nstrip, nseg); \
+                              else if (waves == 3) hipLaunchKernelGGL((blur16_stream3<RR, DD, BGR>), grid, block, 0, st, a, L, nstrip, nseg); \
                               else hipLaunchKernelGGL((blur16_stream<RR, DD, BGR>), grid, block, 0, st, a, L, nstrip, nseg); return true;
-            CASE(5, 4) CASE(6, 4) CASE(8, 4) CASE(10, 4)
+            CASE(5, 4) CASE(6, 4) CASE(8, 4)
 #undef CASE
+            case 10: if (waves == 3) hipLaunchKernelGGL((blur16_stream3<10, 4, BGR>), grid, block, 0, st, a, L, nstrip, nseg);
+                     else hipLaunchKernelGGL((blur16_stream<10, 4, BGR>), grid, block, 0, st, a, L, nstrip, nseg);
+                     return true;
             case 13: hipLaunchKernelGGL((blur16_stream<13, 4, BGR>), grid, block, 0, st, a, L, nstrip, nseg); return true;
             default: break;
         }
