@@ -30,7 +30,8 @@ constexpr int QTILE = 256;           // queries per workgroup (8 waves x 32): ev
                                      // rocprofv3 --pmc (scratch/pmc_match.sh): matrix pipe busy 45 % of the time, 13.9 VALU instructions per MFMA,
                                      // waves parked 42 % of their cycles.  Tried without gain (23-24 ms for 19 729 pairs either way): the index
                                      // of the best row tracked per 4-row group and recovered afterwards (-40 % epilogue instructions), two B
-                                     // operands per wave so that an A fragment read from LDS feeds two MFMAs (half the LDS reads)
+                                     // operands per wave so that an A fragment read from LDS feeds two MFMAs (half the LDS reads); round 3: 128 train
+                                     // rows per stage (one workgroup barrier per 128 rows, 70 KB LDS): 163 ms against 92 ms per 74 029 pairs
 constexpr int BF_NT = QTILE * 2;     // threads per workgroup
 
 struct PairDesc {
@@ -71,61 +72,47 @@ __global__ __launch_bounds__(BF_NT) void bf_match_kernel(const PairDesc* pairs, 
     // buffered, the next tile's global loads in flight during the MFMAs) instead of once per wave from L2 -- four waves
     // pulling every tile themselves moved 33 MB per pair through L2, which bounded the kernel, not the matrix cores.
     constexpr int APITCH = 128 + 8;                       // bf16 per staged row: 272 B keeps the 32 rows of a read on distinct banks
-    // TR train rows per stage.  128 rows per stage (one workgroup barrier per 128 rows instead of one per 32; 70 KB of LDS, two
-    // workgroups per CU) was measured on C4: 163 ms against 92 ms per 74 029 pairs -- the barrier is not what parks the waves
-#ifndef BF_TR
-#define BF_TR 32
-#endif
-    constexpr int TR = BF_TR, CH = TR * 8 / BF_NT;        // 32-byte chunks per thread and stage
-    static_assert(TR % 32 == 0 && (TR * 8) % BF_NT == 0 && CH >= 1, "stage shape");
-    __shared__ __attribute__((aligned(16))) uint16_t s_a[2][TR * APITCH];
-    uint4 pf[CH][2];
+    __shared__ __attribute__((aligned(16))) uint16_t s_a[2][32 * APITCH];
+    const int ld_row = tid >> 3, ld_chunk = tid & 7;      // this thread stages 16 bf16 (32 B) of the tile
+    uint4 pf0 = {0, 0, 0, 0}, pf1 = {0, 0, 0, 0};
+    const bool stager = tid < 256;                        // 32 rows x 8 chunks of 32 B: the first four waves stage
     auto fetch = [&](int t0) {
-#pragma unroll
-        for (int c = 0; c < CH; c++) {
-            const int id = tid + BF_NT * c, row = id >> 3, chunk = id & 7;
-            const uint4* g = reinterpret_cast<const uint4*>(pd.bf_j + (size_t)(t0 + row) * 128 + chunk * 16);
-            pf[c][0] = g[0]; pf[c][1] = g[1];
-        }
+        if (!stager) return;
+        const uint4* g = reinterpret_cast<const uint4*>(pd.bf_j + (size_t)(t0 + ld_row) * 128 + ld_chunk * 16);
+        pf0 = g[0]; pf1 = g[1];
     };
     auto stage = [&](int buf) {
-#pragma unroll
-        for (int c = 0; c < CH; c++) {
-            const int id = tid + BF_NT * c, row = id >> 3, chunk = id & 7;
-            uint4* d = reinterpret_cast<uint4*>(&s_a[buf][row * APITCH + chunk * 16]);
-            d[0] = pf[c][0]; d[1] = pf[c][1];
-        }
+        if (!stager) return;
+        uint4* d = reinterpret_cast<uint4*>(&s_a[buf][ld_row * APITCH + ld_chunk * 16]);
+        d[0] = pf0; d[1] = pf1;
     };
     fetch(0);
     stage(0);
     __syncthreads();
     int cur = 0;
-    for (int t0 = 0; t0 < pd.npad_j; t0 += TR) {
-        const bool more = t0 + TR < pd.npad_j;
-        if (more) fetch(t0 + TR);
+    for (int t0 = 0; t0 < pd.npad_j; t0 += 32) {
+        const bool more = t0 + 32 < pd.npad_j;
+        if (more) fetch(t0 + 32);
+        f32x16 acc;
 #pragma unroll
-        for (int sub = 0; sub < TR / 32; sub++) {
-            f32x16 acc;
+        for (int e = 0; e < 16; e++) acc[e] = 0.0f;
+        const uint16_t* arow = &s_a[cur][col * APITCH + hi * 8];
 #pragma unroll
-            for (int e = 0; e < 16; e++) acc[e] = 0.0f;
-            const uint16_t* arow = &s_a[cur][(sub * 32 + col) * APITCH + hi * 8];
+        for (int ks = 0; ks < 8; ks++) {
+            const bf16x8 at = *reinterpret_cast<const bf16x8*>(arow + ks * 16);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at, bq[ks], acc, 0, 0, 0);
+        }
 #pragma unroll
-            for (int ks = 0; ks < 8; ks++) {
-                const bf16x8 at = *reinterpret_cast<const bf16x8*>(arow + ks * 16);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at, bq[ks], acc, 0, 0, 0);
-            }
+        for (int g = 0; g < 4; g++) {
+            const int m0 = t0 + 8 * g + 4 * hi;                       // C/D layout of the 32x32 MFMA: rows m0 .. m0+3 in acc[4g .. 4g+3]
+            const float4 nt = *reinterpret_cast<const float4*>(&s_nrm[m0]);
+            const float ntv[4] = {nt.x, nt.y, nt.z, nt.w};
 #pragma unroll
-            for (int g = 0; g < 4; g++) {
-                const int m0 = t0 + sub * 32 + 8 * g + 4 * hi;            // C/D layout of the 32x32 MFMA: rows m0 .. m0+3 in acc[4g .. 4g+3]
-                const float4 nt = *reinterpret_cast<const float4*>(&s_nrm[m0]);
-                const float ntv[4] = {nt.x, nt.y, nt.z, nt.w};
-#pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    const float x = fmaf(2.0f, acc[4 * g + r], -ntv[r]);
-                    bi = x > bx ? m0 + r : bi;                            // strict: ties keep the lowest train index (rows ascend)
-                    sx = __builtin_amdgcn_fmed3f(bx, x, sx);              // second = median(best, x, second) since second <= best
-                    bx = fmaxf(bx, x);
-                }
+            for (int r = 0; r < 4; r++) {
+                const float x = fmaf(2.0f, acc[4 * g + r], -ntv[r]);
+                bi = x > bx ? m0 + r : bi;                            // strict: ties keep the lowest train index (rows ascend)
+                sx = __builtin_amdgcn_fmed3f(bx, x, sx);              // second = median(best, x, second) since second <= best
+                bx = fmaxf(bx, x);
             }
         }
         if (more) stage(cur ^ 1);
