@@ -187,69 +187,83 @@ extern "C" int mi355_global_affine_align(const mi355_match_point_pairs* v, int n
     }
     if (nf == 0) return MI355_OK;
     const int D = 3 * nf;
-    std::vector<double> N((size_t)D * D, 0.0), bx(D, 0.0), by(D, 0.0);
+    // The normal matrix is banded: with the free images in index order, N(i,j) != 0 only for |block(i) - block(j)| <= max |a - b| over
+    // the pairs (adjacent-pair strips: 1 block; the reference's window: 181 blocks), and the Cholesky factor keeps that band.  Only the
+    // lower band is stored: entry (i, j), i - bw <= j <= i, at Nb[i * W + (j - i + bw)] (a dense D x D matrix was 18 MB to clear per
+    // call at 500 images, 288 MB at 2000).
+    int bwb = 0;
     for (int p = 0; p < n; p++) {
         const int a = v[p].ptA_i, b = v[p].ptB_i;
         if (a < 0 || a >= n_images || b < 0 || b >= n_images) return MI355_ERR_ARG;
-        // row: coefficients [xa ya 1] on image a's columns, -[xb yb 1] on image b's columns
-        double ca[3] = {v[p].ptA.x, v[p].ptA.y, 1.0}, cb[3] = {-(double)v[p].ptB.x, -(double)v[p].ptB.y, -1.0};
-        double rx = 0.0, ry = 0.0;                     // right-hand sides after moving the fixed image's identity terms
         const int oa = col[a], ob = col[b];
-        if (oa < 0) { rx -= v[p].ptA.x; ry -= v[p].ptA.y; }
-        if (ob < 0) { rx += v[p].ptB.x; ry += v[p].ptB.y; }
-        if (oa < 0 && ob < 0) continue;
-        for (int s = 0; s < 2; s++) {
-            const int os = s == 0 ? oa : ob;
-            if (os < 0) continue;
-            const double* cs = s == 0 ? ca : cb;
+        if (oa >= 0 && ob >= 0) { const int d = oa > ob ? oa - ob : ob - oa; if (d > bwb) bwb = d; }
+    }
+    const int bw = 3 * bwb + 2;                      // half bandwidth in scalar rows
+    const size_t W = (size_t)bw + 1;
+    std::vector<double> Nb((size_t)D * W, 0.0), bx(D, 0.0), by(D, 0.0);
+    auto NL = [&](int i, int j) -> double& { return Nb[(size_t)i * W + (size_t)(j - i + bw)]; };     // i >= j >= i - bw
+    // rows: coefficients [xa ya 1] on image a's columns, -[xb yb 1] on image b's columns.  The records of one image pair are consecutive
+    // (mi355_results_to_match_pairs): their second moments are summed first (21 products per point), then added to the blocks once
+    for (int p = 0; p < n;) {
+        const int a = v[p].ptA_i, b = v[p].ptB_i;
+        const int oa = col[a], ob = col[b];
+        int q = p;
+        while (q < n && v[q].ptA_i == a && v[q].ptB_i == b) q++;
+        if (oa < 0 && ob < 0) { p = q; continue; }
+        double Maa[3][3] = {{0}}, Mab[3][3] = {{0}}, Mbb[3][3] = {{0}}, Vax[3] = {0}, Vay[3] = {0}, Vbx[3] = {0}, Vby[3] = {0};
+        for (int k = p; k < q; k++) {
+            const double ca[3] = {v[k].ptA.x, v[k].ptA.y, 1.0}, cb[3] = {v[k].ptB.x, v[k].ptB.y, 1.0};
+            double rx = 0.0, ry = 0.0;                 // right-hand sides after moving the fixed image's identity terms
+            if (oa < 0) { rx -= v[k].ptA.x; ry -= v[k].ptA.y; }
+            if (ob < 0) { rx += v[k].ptB.x; ry += v[k].ptB.y; }
             for (int i = 0; i < 3; i++) {
-                bx[3 * os + i] += cs[i] * rx; by[3 * os + i] += cs[i] * ry;
-                for (int t = 0; t < 2; t++) {
-                    const int ot = t == 0 ? oa : ob;
-                    if (ot < 0) continue;
-                    const double* ct = t == 0 ? ca : cb;
-                    for (int j = 0; j < 3; j++) N[(size_t)(3 * os + i) * D + 3 * ot + j] += cs[i] * ct[j];
-                }
+                for (int j = 0; j <= i; j++) { Maa[i][j] += ca[i] * ca[j]; Mbb[i][j] += cb[i] * cb[j]; }
+                for (int j = 0; j < 3; j++) Mab[i][j] += ca[i] * cb[j];
+                Vax[i] += ca[i] * rx; Vay[i] += ca[i] * ry; Vbx[i] += cb[i] * rx; Vby[i] += cb[i] * ry;
             }
         }
+        if (oa >= 0) for (int i = 0; i < 3; i++) { bx[3 * oa + i] += Vax[i]; by[3 * oa + i] += Vay[i]; for (int j = 0; j <= i; j++) NL(3 * oa + i, 3 * oa + j) += Maa[i][j]; }
+        if (ob >= 0) for (int i = 0; i < 3; i++) { bx[3 * ob + i] -= Vbx[i]; by[3 * ob + i] -= Vby[i]; for (int j = 0; j <= i; j++) NL(3 * ob + i, 3 * ob + j) += Mbb[i][j]; }
+        if (oa >= 0 && ob >= 0 && oa != ob) {
+            for (int i = 0; i < 3; i++)
+                for (int j = 0; j < 3; j++) {
+                    // N(a_i, b_j) = -Mab[i][j] = N(b_j, a_i): store the entry of the lower triangle
+                    if (oa > ob) NL(3 * oa + i, 3 * ob + j) -= Mab[i][j]; else NL(3 * ob + j, 3 * oa + i) -= Mab[i][j];
+                }
+        }
+        p = q;
     }
     // images without any correspondence would make N singular: pin them to identity (the driver flags them
     // invalid through Select_Connected_Matched_Images before calling, MosaicWithoutPos.cpp:4503-4523)
     for (int k = 0; k < n_images; k++) {
         const int o = col[k];
         if (o < 0) continue;
-        if (N[(size_t)(3 * o + 2) * D + 3 * o + 2] == 0.0) {
-            for (int i = 0; i < 3; i++) N[(size_t)(3 * o + i) * D + 3 * o + i] = 1.0;
+        if (NL(3 * o + 2, 3 * o + 2) == 0.0) {
+            for (int i = 0; i < 3; i++) NL(3 * o + i, 3 * o + i) = 1.0;
             bx[3 * o + 0] = 1.0; by[3 * o + 1] = 1.0;
         }
     }
-    // Cholesky N = L L^T (lower), in place, restricted to the band of the image graph: with the free images in index
-    // order, N(i,j) != 0 only for |block(i) - block(j)| <= max |a - b| over the pairs (adjacent-pair strips: 1 block;
-    // the reference's window: 181 blocks), and the factor keeps that band.
-    int bwb = 0;
-    for (int p = 0; p < n; p++) {
-        const int oa = col[v[p].ptA_i], ob = col[v[p].ptB_i];
-        if (oa >= 0 && ob >= 0) { const int d = oa > ob ? oa - ob : ob - oa; if (d > bwb) bwb = d; }
-    }
-    const int bw = 3 * bwb + 2;                      // half bandwidth in scalar rows
+    // Cholesky N = L L^T (lower), in place, inside the band
     for (int j = 0; j < D; j++) {
         const int k0 = j - bw > 0 ? j - bw : 0;
-        double d = N[(size_t)j * D + j];
-        for (int k = k0; k < j; k++) d -= N[(size_t)j * D + k] * N[(size_t)j * D + k];
+        double d = NL(j, j);
+        for (int k = k0; k < j; k++) d -= NL(j, k) * NL(j, k);
         if (!(d > 0.0)) return MI355_ERR_FAILED;
         d = std::sqrt(d);
-        N[(size_t)j * D + j] = d;
+        NL(j, j) = d;
         const int i1 = j + bw < D - 1 ? j + bw : D - 1;
         for (int i = j + 1; i <= i1; i++) {
             const int kk0 = i - bw > k0 ? i - bw : k0;
-            double s = N[(size_t)i * D + j];
-            for (int k = kk0; k < j; k++) s -= N[(size_t)i * D + k] * N[(size_t)j * D + k];
-            N[(size_t)i * D + j] = s / d;
+            double s = NL(i, j);
+            const double* ri = &Nb[(size_t)i * W + (size_t)(kk0 - i + bw)];
+            const double* rj = &Nb[(size_t)j * W + (size_t)(kk0 - j + bw)];
+            for (int k = 0; k < j - kk0; k++) s -= ri[k] * rj[k];
+            NL(i, j) = s / d;
         }
     }
     auto solve = [&](std::vector<double>& b) {
-        for (int i = 0; i < D; i++) { const int k0 = i - bw > 0 ? i - bw : 0; double s = b[i]; for (int k = k0; k < i; k++) s -= N[(size_t)i * D + k] * b[k]; b[i] = s / N[(size_t)i * D + i]; }
-        for (int i = D - 1; i >= 0; i--) { const int k1 = i + bw < D - 1 ? i + bw : D - 1; double s = b[i]; for (int k = i + 1; k <= k1; k++) s -= N[(size_t)k * D + i] * b[k]; b[i] = s / N[(size_t)i * D + i]; }
+        for (int i = 0; i < D; i++) { const int k0 = i - bw > 0 ? i - bw : 0; double s = b[i]; for (int k = k0; k < i; k++) s -= NL(i, k) * b[k]; b[i] = s / NL(i, i); }
+        for (int i = D - 1; i >= 0; i--) { const int k1 = i + bw < D - 1 ? i + bw : D - 1; double s = b[i]; for (int k = i + 1; k <= k1; k++) s -= NL(k, i) * b[k]; b[i] = s / NL(i, i); }
     };
     solve(bx); solve(by);
     for (int k = 0; k < n_images; k++) {
