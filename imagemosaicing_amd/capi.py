@@ -233,8 +233,8 @@ class Context:
         p1 = np.ascontiguousarray(p1, SFPOINT)
         p2 = np.ascontiguousarray(p2, SFPOINT)
         n = len(p1)
-        i1 = np.zeros(400, SFPOINT)
-        i2 = np.zeros(400, SFPOINT)
+        i1 = np.zeros(max(400, n), SFPOINT)
+        i2 = np.zeros(max(400, n), SFPOINT)
         nin = C.c_int(0)
         H = np.zeros(9, np.float32)
         ok = self._chk(self.L.mi355_ransac2d(self._h, _p(p1), _p(p2), n, C.c_float(fRansacDist), int(sampleTimes), C.c_uint32(seed),

@@ -149,6 +149,8 @@ int mi_chips_and_masks(mi355_ctx*, const uint8_t* const* imgs, const int* w, con
                        uint8_t*** chip_imgs, uint8_t*** masks, int* cw, int* ch);
 int mi_ransac_batch(mi355_ctx*, const mi355_sfpoint* d_p1, const mi355_sfpoint* d_p2, const int* d_n, const int* h_n,
                     int n_pairs, int stride, float dist, int sample_times, uint32_t seed, mi355_pair_result* d_out, int min_keep = -1);
+int mi_ransac_big(mi355_ctx*, const mi355_sfpoint* p1, const mi355_sfpoint* p2, int n, float dist, int sample_times, uint32_t seed,
+                  mi355_sfpoint* in1, mi355_sfpoint* in2, int* n_in, float* H, int* ok);
 int mi_match_pairs_dev(mi355_ctx*, const int32_t* pairs, int n_pairs, float dist, uint32_t seed, mi355_pair_result* d_out);
 int mi_bf_match(mi355_ctx*, int img_i, int img_j, int sorted, mi355_dmatch* matches, int32_t* d2, int32_t* second, int maxm, int* nm);
 int mi_select_grid(mi355_ctx*, const mi355_dmatch* sorted, int n, const float* kp1, int nk1, const float* kp2, int nk2,

@@ -38,6 +38,10 @@ struct RansacArgs {
     int sample_times;
     int min_keep;                  // pairs with at most this many inliers skip the closing refinement (-1: never): the caller rejects them anyway
     mi355_pair_result* out;        // [pair]
+    // BIG variant (one pair with 400 < n <= 4096, mi355_ransac2d only): work arrays of the closing Gauss-Newton and the inlier lists in HBM
+    float* big_ws;                 // 38 n floats: J (16 n), J* (16 n), C (2 n), compaction scratch (4 n)
+    mi355_sfpoint* big_a;          // [n] inliers of image i
+    mi355_sfpoint* big_b;          // [n] inliers of image j
 };
 
 // the index-driven generic routines (hmath.h solve_h4 / nlls4) for the draws the register path hands back (a non-finite entry
@@ -66,8 +70,8 @@ __device__ __forceinline__ int block_exclusive_scan_flags(bool flag, int tid, in
     return off + before;
 }
 
-// 2 waves per SIMD (256 registers each): with 1 (512 registers, spills in AGPRs instead of scratch) the kernel measured 30 % slower
-__global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(2, 2))) void ransac_kernel(RansacArgs a) {
+template <bool BIG>
+__device__ __forceinline__ void ransac_body(const RansacArgs& a) {
     extern __shared__ float lds[];
     __shared__ unsigned long long s_mask[5][RB / 64];
     __shared__ unsigned s_wkey[RB / 64];
@@ -95,9 +99,10 @@ __global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     float* y1 = x1 + n;
     float* x2 = y1 + n;         // sources (image j)
     float* y2 = x2 + n;
-    float* J  = y2 + n;         // 2n x 8
+    float* J  = BIG ? a.big_ws : y2 + n;         // 2n x 8   (BIG: in HBM, the points alone fill the LDS)
     float* JL = J + 16 * n;     // 8 x 2n
     float* C  = JL + 16 * n;    // 2n
+    float* CS = C + 2 * n;      // BIG: 4n floats of compaction scratch
     for (int i = tid; i < n; i += RB) { x1[i] = P1[i].x; y1[i] = P1[i].y; x2[i] = P2[i].x; y2[i] = P2[i].y; }
     if (tid < 8) s_state[tid] = (tid == 2 || tid == 3) ? -1 : 0;
     if (tid < 9) { s_bestH[tid] = 0.0f; s_firstH[tid] = 0.0f; }
@@ -231,7 +236,8 @@ __global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         }
         int tot;
         const int pos = cnt + block_exclusive_scan_flags(in, tid, s_wtot, tot);
-        if (in && pos < MI355_MAX_SELECTED) { out->a[pos] = P1[i]; out->b[pos] = P2[i]; }
+        if constexpr (BIG) { if (in) { a.big_a[pos] = P1[i]; a.big_b[pos] = P2[i]; } }
+        else if (in && pos < MI355_MAX_SELECTED) { out->a[pos] = P1[i]; out->b[pos] = P2[i]; }
         if (in) { C[pos] = (float)i; }                      // remember source index (C reused later)
         cnt += tot;
     }
@@ -246,15 +252,21 @@ __global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     }
     // inlier coordinates, compacted in place into the head of the LDS arrays: read (<= 2 per lane since
     // cnt <= 400), barrier, write
-    float ix1[2], iy1[2], ix2[2], iy2[2];
-    {
-        int m = 0;
-        for (int i = tid; i < cnt; i += RB) { const int s = (int)C[i]; ix1[m] = x1[s]; iy1[m] = y1[s]; ix2[m] = x2[s]; iy2[m] = y2[s]; m++; }
-    }
-    __syncthreads();
-    {
-        int m = 0;
-        for (int i = tid; i < cnt; i += RB) { x1[i] = ix1[m]; y1[i] = iy1[m]; x2[i] = ix2[m]; y2[i] = iy2[m]; m++; }
+    if constexpr (BIG) {                                    // more than 2 per lane: through the HBM scratch
+        for (int i = tid; i < cnt; i += RB) { const int s = (int)C[i]; CS[4 * i] = x1[s]; CS[4 * i + 1] = y1[s]; CS[4 * i + 2] = x2[s]; CS[4 * i + 3] = y2[s]; }
+        __syncthreads();
+        for (int i = tid; i < cnt; i += RB) { x1[i] = CS[4 * i]; y1[i] = CS[4 * i + 1]; x2[i] = CS[4 * i + 2]; y2[i] = CS[4 * i + 3]; }
+    } else {
+        float ix1[2], iy1[2], ix2[2], iy2[2];
+        {
+            int m = 0;
+            for (int i = tid; i < cnt; i += RB) { const int s = (int)C[i]; ix1[m] = x1[s]; iy1[m] = y1[s]; ix2[m] = x2[s]; iy2[m] = y2[s]; m++; }
+        }
+        __syncthreads();
+        {
+            int m = 0;
+            for (int i = tid; i < cnt; i += RB) { x1[i] = ix1[m]; y1[i] = iy1[m]; x2[i] = ix2[m]; y2[i] = iy2[m]; m++; }
+        }
     }
     if (tid < 8) s_w[tid] = W[tid];
     if (tid < 64) s_T2[tid] = 0.0f;
@@ -334,6 +346,11 @@ __global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     }
 }
 
+// 2 waves per SIMD (256 registers each): with 1 (512 registers, spills in AGPRs instead of scratch) the kernel measured 30 % slower
+__global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(2, 2))) void ransac_kernel(RansacArgs a) { ransac_body<false>(a); }
+// Ransac2D accepts any n (mosaicimage.h:1729-1761); the live path never exceeds 396, stand-alone callers may: up to 4096 points in LDS
+__global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(2, 2))) void ransac_big_kernel(RansacArgs a) { ransac_body<true>(a); }
+
 }  // namespace
 
 // ---- host: glibc rand() (TYPE_3 additive feedback, stdlib/random_r.c) and the draw table ------------------
@@ -409,6 +426,45 @@ void mi_glibc_draw_table(uint32_t seed, int n, int max_draws, uint16_t* out4) {
     }
 }
 
+// one pair with 400 < n <= MI355_RANSAC_BIG_MAX correspondences (host arrays in, host arrays out): mi355_ransac2d's large-n path
+int mi_ransac_big(mi355_ctx* ctx, const mi355_sfpoint* p1, const mi355_sfpoint* p2, int n, float dist, int sample_times, uint32_t seed,
+                  mi355_sfpoint* in1, mi355_sfpoint* in2, int* n_in, float* H, int* ok) {
+    DevBuf& d1 = ctx->buf("rbig_p1"); DevBuf& d2 = ctx->buf("rbig_p2"); DevBuf& da = ctx->buf("rbig_a"); DevBuf& db = ctx->buf("rbig_b");
+    DevBuf& dn = ctx->buf("r1_n"); DevBuf& dres = ctx->buf("pair_results"); DevBuf& dws = ctx->buf("rbig_ws"); DevBuf& dtab = ctx->buf("ransac_tables");
+    const size_t pb = sizeof(mi355_sfpoint) * (size_t)n, one = (size_t)MAX_DRAWS * 4;
+    MI_HIP(d1.reserve(pb)); MI_HIP(d2.reserve(pb)); MI_HIP(da.reserve(pb)); MI_HIP(db.reserve(pb));
+    MI_HIP(dn.reserve(sizeof(int))); MI_HIP(dres.reserve(sizeof(mi355_pair_result))); MI_HIP(dws.reserve(sizeof(float) * 38 * (size_t)n));
+    MI_HIP(dtab.reserve(one * sizeof(uint16_t)));
+    std::vector<uint16_t> tab(one);
+    mi_glibc_draw_table(seed, n, MAX_DRAWS, tab.data());
+    MI_HIP(hipMemcpyAsync(d1.p, p1, pb, hipMemcpyHostToDevice, ctx->stream));
+    MI_HIP(hipMemcpyAsync(d2.p, p2, pb, hipMemcpyHostToDevice, ctx->stream));
+    MI_HIP(hipMemcpyAsync(dn.p, &n, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    MI_HIP(hipMemcpyAsync(dtab.p, tab.data(), one * sizeof(uint16_t), hipMemcpyHostToDevice, ctx->stream));
+    MI_HIP(hipMemsetAsync(dres.p, 0, sizeof(mi355_pair_result), ctx->stream));
+    RansacArgs a;
+    memset(&a, 0, sizeof(a));
+    a.p1 = d1.as<mi355_sfpoint>(); a.p2 = d2.as<mi355_sfpoint>(); a.n = dn.as<int>(); a.tables = dtab.as<uint16_t>(); a.table_of = nullptr;
+    a.stride = n; a.dist = dist; a.sample_times = sample_times; a.min_keep = -1; a.out = dres.as<mi355_pair_result>();
+    a.big_ws = dws.as<float>(); a.big_a = da.as<mi355_sfpoint>(); a.big_b = db.as<mi355_sfpoint>();
+    a.tables -= (size_t)(n - 4) * one;                    // the kernel indexes tables by n - 4 when there is no per-pair index
+    const size_t lds_bytes = (size_t)4 * n * sizeof(float);
+    MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ransac_big_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    hipLaunchKernelGGL(ransac_big_kernel, dim3(1), dim3(RB), lds_bytes, ctx->stream, a);
+    MI_HIP(hipGetLastError());
+    mi355_pair_result r;
+    MI_HIP(hipMemcpyAsync(&r, dres.p, sizeof(r), hipMemcpyDeviceToHost, ctx->stream));
+    MI_HIP(hipStreamSynchronize(ctx->stream));            // `tab` goes out of scope; r has landed
+    *n_in = r.n_in; *ok = r.ok;
+    memcpy(H, r.H, sizeof(float) * 9);
+    if (r.n_in > 0) {
+        if (in1) MI_HIP(hipMemcpyAsync(in1, da.p, sizeof(mi355_sfpoint) * (size_t)r.n_in, hipMemcpyDeviceToHost, ctx->stream));
+        if (in2) MI_HIP(hipMemcpyAsync(in2, db.p, sizeof(mi355_sfpoint) * (size_t)r.n_in, hipMemcpyDeviceToHost, ctx->stream));
+        MI_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    return MI355_OK;
+}
+
 int mi_ransac_batch(mi355_ctx* ctx, const mi355_sfpoint* d_p1, const mi355_sfpoint* d_p2, const int* d_n, const int* h_n,
                     int n_pairs, int stride, float dist, int sample_times, uint32_t seed, mi355_pair_result* d_out, int min_keep) {
     if (n_pairs <= 0) return MI355_OK;
@@ -474,6 +530,7 @@ int mi_ransac_batch(mi355_ctx* ctx, const mi355_sfpoint* d_p1, const mi355_sfpoi
         d_tables = it->second.as<uint16_t>();
     }
     RansacArgs a;
+    memset(&a, 0, sizeof(a));
     a.p1 = d_p1; a.p2 = d_p2; a.n = d_n; a.tables = d_tables; a.table_of = d_table_of;
     a.dbg = nullptr; a.min_keep = min_keep;
     static const bool dbg_on = getenv("MI355_RANSAC_DBG") != nullptr;

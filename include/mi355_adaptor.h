@@ -70,9 +70,9 @@ inline mi355_ctx* context(int device = 0) {
 
 // bool Ransac2D(const vector<PointType>&, const vector<PointType>&, vector<PointType>&, vector<PointType>&,
 //               float aProjectMat[9], float fRansacDist = 1, int sampleTimes = 1000)          mosaicimage.h:1729-1735
-// `seed` stands for the reference's srand((unsigned)time(0)) (mosaicimage.h:1777).  Limit: at most 400 correspondences (maxNum of
-// the live path, MosaicWithoutPos.cpp:5146 -- the only caller passes <= 396); larger inputs return false with aProjectMat zeroed,
-// where the reference would run on any n.
+// `seed` stands for the reference's srand((unsigned)time(0)) (mosaicimage.h:1777).  Up to 4096 correspondences (the live path passes
+// <= 396: maxNum, MosaicWithoutPos.cpp:5146; above 400 a second kernel keeps the work arrays in HBM); larger inputs return false
+// with aProjectMat zeroed, where the reference would run on any n.
 inline bool Ransac2D(const std::vector<MI355_NS SfPoint>& p1, const std::vector<MI355_NS SfPoint>& p2,
                      std::vector<MI355_NS SfPoint>& in1, std::vector<MI355_NS SfPoint>& in2, float aProjectMat[9],
                      float fRansacDist = 1.0f, int sampleTimes = 1000, unsigned seed = 1) {
@@ -80,7 +80,8 @@ inline bool Ransac2D(const std::vector<MI355_NS SfPoint>& p1, const std::vector<
     if (p1.empty() || p1.size() != p2.size()) return false;
     mi355_ctx* c = context();
     if (!c) return false;
-    std::vector<mi355_sfpoint> a(MI355_MAX_SELECTED), b(MI355_MAX_SELECTED);
+    const size_t cap = p1.size() > MI355_MAX_SELECTED ? p1.size() : MI355_MAX_SELECTED;
+    std::vector<mi355_sfpoint> a(cap), b(cap);
     int n_in = 0;
     const int ok = mi355_ransac2d(c, reinterpret_cast<const mi355_sfpoint*>(&p1[0]), reinterpret_cast<const mi355_sfpoint*>(&p2[0]), (int)p1.size(),
                                   fRansacDist, sampleTimes, seed, &a[0], &b[0], &n_in, aProjectMat);
