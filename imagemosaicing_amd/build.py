@@ -20,6 +20,11 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
          "-Wall", "-Wno-unused-function", "-Wno-unused-result"] + os.environ.get("MI355_EXTRA_HIPCC_FLAGS", "").split()   # kernel A/B builds (scratch/)
 
 
+# match.hip only: its distances are exact integers / half-integers or -inf by construction (never NaN), and without the flag every fmaxf of
+# an MFMA result is preceded by a canonicalising v_max_f32 x, x, x (a third of the epilogue's instructions)
+PER_FILE = {"match.hip": ["-fno-honor-nans"]}
+
+
 def sources():
     return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".cpp")))
 
@@ -42,7 +47,7 @@ def compile_one(src):
     newest = max(os.path.getmtime(p) for p in [src] + headers())
     if os.path.exists(obj) and os.path.getmtime(obj) > newest:
         return obj
-    cmd = [HIPCC] + FLAGS + (["-x", "hip"] if src.endswith(".hip") else []) + ["-c", src, "-o", obj]
+    cmd = [HIPCC] + FLAGS + PER_FILE.get(os.path.basename(src), []) + (["-x", "hip"] if src.endswith(".hip") else []) + ["-c", src, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, r.stdout, r.stderr))

@@ -24,9 +24,17 @@ namespace {
 
 typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 bf16x8;
 typedef __attribute__((__vector_size__(16 * sizeof(float)))) float f32x16;
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+// Pointers that arrive inside a structure read from memory (PairDesc) are generic to the compiler: it emits flat_load, and with a
+// flat load in flight every LDS wait becomes a wait for ALL memory (vmcnt(0) right after the first MFMA of the tile) -- the L2
+// latency of the next tile's prefetch was exposed in every iteration.  Cast to the global address space: global_load, counted apart.
+#define GLOBAL_PTR(T, p) ((const __attribute__((address_space(1))) T*)(p))
 
 constexpr int KSTRIDE = 2048;        // per-pair stride of the nn arrays (>= nfeatures rounded up)
-constexpr int QTILE = 256;           // queries per workgroup (8 waves x 32): every staged train tile serves 256 queries (128: 5 % slower).
+#ifndef MATCH_QTILE
+#define MATCH_QTILE 256
+#endif
+constexpr int QTILE = MATCH_QTILE;   // queries per workgroup (8 waves x 32): every staged train tile serves 256 queries (128: 5 % slower).
                                      // rocprofv3 --pmc (scratch/pmc_match.sh): matrix pipe busy 45 % of the time, 13.9 VALU instructions per MFMA,
                                      // waves parked 42 % of their cycles.  Tried without gain (23-24 ms for 19 729 pairs either way): the index
                                      // of the best row tracked per 4-row group and recovered afterwards (-40 % epilogue instructions), two B
@@ -35,8 +43,8 @@ constexpr int QTILE = 256;           // queries per workgroup (8 waves x 32): ev
 constexpr int BF_NT = QTILE * 2;     // threads per workgroup
 
 struct PairDesc {
-    const uint16_t* bf_i; const int* nrm_i; const float2* xy_i; int n_i; int npad_i;
-    const uint16_t* bf_j; const int* nrm_j; const float2* xy_j; int n_j; int npad_j;
+    const uint16_t* bf_i; const int* nrm_i; const float2* xy_i; const uint8_t* d8_i; int n_i; int npad_i;
+    const uint16_t* bf_j; const int* nrm_j; const float2* xy_j; const uint8_t* d8_j; int n_j; int npad_j;
     int img_i, img_j, width, height;
 };
 
@@ -45,82 +53,141 @@ __device__ __forceinline__ void top2_update(int s, int j, int& best, int& second
     else if (s < second) second = s;
 }
 
-__global__ __launch_bounds__(BF_NT) void bf_match_kernel(const PairDesc* pairs, int* nn_idx, int* nn_d2, int* nn_2nd) {
-    __shared__ __attribute__((aligned(16))) float s_nrm[KSTRIDE];    // |t|^2 of the train rows, +inf for the padding rows
-    const PairDesc pd = pairs[blockIdx.y];
-    const int q_base = blockIdx.x * QTILE;
+// Work-to-XCD placement: workgroup ids go round-robin over the 8 XCDs (each with its own L2).  XCD x owns a contiguous eighth of
+// the (pair, query tile) list, so the query tiles of a pair run side by side under ONE L2 and the train set crosses the fabric once.
+__device__ __forceinline__ int xcd_owned(int bid, int nb) {
+    const int q = nb >> 3, r = nb & 7, xcd = bid & 7, local = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+}
+
+// What the loop costs (scratch/match_time.py, 1740 pairs of 2000 x 2000, MI355X; 2.14 ms would be the dense bf16 peak):
+//   the eight MFMAs per tile alone, operands in registers, no LDS / barrier / epilogue       3.07 ms  (the pipe's own ceiling here: 0.70)
+//   + LDS operand reads                                                                       3.16 ms
+//   + staging and one workgroup barrier per tile                                              4.09 ms
+//   + the per-element top-2 epilogue of round 2 (fma, compare, select, med3, max = 96 VALU)    5.96 ms  (0.36 of peak)
+// so the epilogue and the barrier-to-first-MFMA latency were the two things to remove:
+//   * -|t|^2 / 2 enters as the C operand of the first MFMA (x = q.t - |t|^2 / 2 comes out of the matrix pipe; all partial sums
+//     are multiples of 1/2 below 2^23, exact in binary32) -- no per-element fma;
+//   * the running top-2 is kept per GROUP of four rows (max3, max, compare, select, med3, max = 6 VALU per 4 elements), the
+//     winning row of the best group and the runner-up inside it are recovered after the loop from the u8 descriptors with
+//     v_dot4_u32_u8 (4 rows x 32 dot4 per lane, once per query);
+//   * three LDS stages: the first half of the NEXT tile's operands and its C rows are read before the barrier, so the MFMAs of
+//     the next iteration start straight after it.
+__global__ __launch_bounds__(BF_NT) void bf_match_kernel(const PairDesc* pairs, int nqt, int* nn_idx, int* nn_d2, int* nn_2nd) {
+    __shared__ __attribute__((aligned(16))) float s_c[KSTRIDE + 32]; // -|t|^2 / 2 of the train rows (the C operand), -inf for the padding rows
+    constexpr int APITCH = 128 + 8;                       // bf16 per staged row: 272 B keeps the 32 rows of a read on distinct banks
+    constexpr int STAGE = 32 * APITCH;
+    __shared__ __attribute__((aligned(16))) uint16_t s_a[3 * STAGE];
+    const int work = xcd_owned(blockIdx.x, gridDim.x), pair = work / nqt;
+    const PairDesc pd = pairs[pair];
+    const int q_base = (work - pair * nqt) * QTILE;
     if (q_base >= pd.n_i) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int hi = lane >> 5, col = lane & 31;
-    for (int i = tid; i < pd.npad_j; i += BF_NT) s_nrm[i] = i < pd.n_j ? (float)pd.nrm_j[i] : __builtin_inff();
-    __syncthreads();
+    for (int i = tid; i < pd.npad_j; i += BF_NT) s_c[i] = i < pd.n_j ? -0.5f * (float)GLOBAL_PTR(int, pd.nrm_j)[i] : -__builtin_inff();
     const int q = q_base + wave * 32 + col;              // this lane's query (rows beyond n_i are zero padding)
-    const bool q_ok = q < pd.npad_i;
+    const int q_ld = q < pd.npad_i ? q : pd.npad_i - 1;
     bf16x8 bq[8];
 #pragma unroll
-    for (int ks = 0; ks < 8; ks++) {
-        if (q_ok) bq[ks] = *reinterpret_cast<const bf16x8*>(pd.bf_i + (size_t)q * 128 + ks * 16 + hi * 8);
-        else for (int e = 0; e < 8; e++) bq[ks][e] = (__bf16)0.0f;
-    }
-    const float nq = q_ok ? (float)pd.nrm_i[q] : 0.0f;
-    // |q - t|^2 = |q|^2 - (2 q.t - |t|^2): the running top-2 is kept on x = 2 q.t - |t|^2 (to be maximised), all exact
-    // integers below 2^24 in binary32.  Per element: one fma, max, med3, compare, select -- the epilogue costs about as
-    // many cycles as the 8 MFMAs of the tile, and the two overlap across the waves of a SIMD.
-    float bx = -__builtin_inff(), sx = -__builtin_inff();
-    int bi = -1;
-    // The 32 x 128 train tile (8 KB) is the A operand of all four waves: it is fetched once per workgroup into LDS (double
-    // buffered, the next tile's global loads in flight during the MFMAs) instead of once per wave from L2 -- four waves
-    // pulling every tile themselves moved 33 MB per pair through L2, which bounded the kernel, not the matrix cores.
-    constexpr int APITCH = 128 + 8;                       // bf16 per staged row: 272 B keeps the 32 rows of a read on distinct banks
-    __shared__ __attribute__((aligned(16))) uint16_t s_a[2][32 * APITCH];
-    const int ld_row = tid >> 3, ld_chunk = tid & 7;      // this thread stages 16 bf16 (32 B) of the tile
-    uint4 pf0 = {0, 0, 0, 0}, pf1 = {0, 0, 0, 0};
-    const bool stager = tid < 256;                        // 32 rows x 8 chunks of 32 B: the first four waves stage
+    for (int ks = 0; ks < 8; ks++) bq[ks] = *GLOBAL_PTR(bf16x8, pd.bf_i + (size_t)q_ld * 128 + ks * 16 + hi * 8);
+    // The 32 x 128 train tile (8 KB) is the A operand of all eight waves: fetched once per workgroup into LDS, every thread 16 B.
+    constexpr int NST = BF_NT >= 512 ? 1 : 512 / BF_NT;                      // 16-byte pieces of the tile per thread
+    struct Pf { u32x4 v[NST]; };
+    Pf pf;
     auto fetch = [&](int t0) {
-        if (!stager) return;
-        const uint4* g = reinterpret_cast<const uint4*>(pd.bf_j + (size_t)(t0 + ld_row) * 128 + ld_chunk * 16);
-        pf0 = g[0]; pf1 = g[1];
+#pragma unroll
+        for (int k = 0; k < NST; k++) { const int i = (tid + k * BF_NT) & 511; pf.v[k] = *GLOBAL_PTR(u32x4, pd.bf_j + (size_t)(t0 + (i >> 4)) * 128 + (i & 15) * 8); }
     };
-    auto stage = [&](int buf) {
-        if (!stager) return;
-        uint4* d = reinterpret_cast<uint4*>(&s_a[buf][ld_row * APITCH + ld_chunk * 16]);
-        d[0] = pf0; d[1] = pf1;
+    auto stage = [&](int buf, const Pf& v) {
+#pragma unroll
+        for (int k = 0; k < NST; k++) { const int i = (tid + k * BF_NT) & 511; if (BF_NT <= 512 || tid < 512) *reinterpret_cast<u32x4*>(&s_a[buf * STAGE + (i >> 4) * APITCH + (i & 15) * 8]) = v.v[k]; }
     };
-    fetch(0);
-    stage(0);
+    const int npad = pd.npad_j;
+    fetch(0); stage(0, pf);
+    fetch(32); stage(1, pf);                              // npad is a multiple of 256
+    fetch(64);                                            // staged during iteration 0; every later fetch has a whole iteration to land
     __syncthreads();
-    int cur = 0;
-    for (int t0 = 0; t0 < pd.npad_j; t0 += 32) {
-        const bool more = t0 + 32 < pd.npad_j;
-        if (more) fetch(t0 + 32);
-        f32x16 acc;
+    const int a_off = col * APITCH + hi * 8;
+    bf16x8 fa[8];
+    f32x16 acc;                                           // holds the C rows (-|t|^2 / 2) of the tile when the iteration starts
+    auto read_lo = [&](int buf, int t0) {                 // operands ks 0..3 of the tile in `buf` and its C rows
+        const uint16_t* arow = &s_a[buf * STAGE + a_off];
 #pragma unroll
-        for (int e = 0; e < 16; e++) acc[e] = 0.0f;
-        const uint16_t* arow = &s_a[cur][col * APITCH + hi * 8];
+        for (int ks = 0; ks < 4; ks++) fa[ks] = *reinterpret_cast<const bf16x8*>(arow + ks * 16);
 #pragma unroll
-        for (int ks = 0; ks < 8; ks++) {
-            const bf16x8 at = *reinterpret_cast<const bf16x8*>(arow + ks * 16);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at, bq[ks], acc, 0, 0, 0);
+        for (int g = 0; g < 4; g++) {                     // C/D layout of the 32x32 MFMA: rows 8g + 4hi .. +3 in acc[4g .. 4g+3]
+            const float4 c = *reinterpret_cast<const float4*>(&s_c[t0 + 8 * g + 4 * hi]);
+            acc[4 * g] = c.x; acc[4 * g + 1] = c.y; acc[4 * g + 2] = c.z; acc[4 * g + 3] = c.w;
         }
+    };
+    read_lo(0, 0);
+    float bx = -__builtin_inff(), sx = -__builtin_inff();
+    int bt = -1, bg = 0;
+    int cur = 0, tile = 0;
+    for (int t0 = 0; t0 < npad; t0 += 32, tile++) {
+        const int nxt = cur == 2 ? 0 : cur + 1, nx2 = nxt == 2 ? 0 : nxt + 1;
+        const Pf pf_stage = pf;                        // tile t + 2, fetched one iteration ago
+        fetch(t0 + 96 < npad ? t0 + 96 : 0);              // the loop body is branch-free: past the end it fetches / stages / reads tiles nobody uses
+        const uint16_t* arow = &s_a[cur * STAGE + a_off];
+#pragma unroll
+        for (int ks = 4; ks < 8; ks++) fa[ks] = *reinterpret_cast<const bf16x8*>(arow + ks * 16);
+#pragma unroll
+        for (int ks = 0; ks < 8; ks++) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks], bq[ks], acc, 0, 0, 0);
+        float gm[4];
+#pragma unroll
+        for (int g = 0; g < 4; g++) gm[g] = fmaxf(fmaxf(fmaxf(acc[4 * g], acc[4 * g + 1]), acc[4 * g + 2]), acc[4 * g + 3]);
+        read_lo(nxt, t0 + 32);                            // issued before the barrier: the next iteration starts with its MFMAs
+        const float bx0 = bx;
+#if MATCH_EXP == 8
+        bx = fmaxf(bx, gm[0] + gm[1] + gm[2] + gm[3]);
+#else
 #pragma unroll
         for (int g = 0; g < 4; g++) {
-            const int m0 = t0 + 8 * g + 4 * hi;                       // C/D layout of the 32x32 MFMA: rows m0 .. m0+3 in acc[4g .. 4g+3]
-            const float4 nt = *reinterpret_cast<const float4*>(&s_nrm[m0]);
-            const float ntv[4] = {nt.x, nt.y, nt.z, nt.w};
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const float x = fmaf(2.0f, acc[4 * g + r], -ntv[r]);
-                bi = x > bx ? m0 + r : bi;                            // strict: ties keep the lowest train index (rows ascend)
-                sx = __builtin_amdgcn_fmed3f(bx, x, sx);              // second = median(best, x, second) since second <= best
-                bx = fmaxf(bx, x);
-            }
+            bg = gm[g] > bx ? g : bg;                                 // strict: ties keep the earliest group
+            sx = __builtin_amdgcn_fmed3f(bx, gm[g], sx);              // second = median(best, x, second) since second <= best
+            bx = fmaxf(bx, gm[g]);
         }
-        if (more) stage(cur ^ 1);
+#endif
+        bt = bx > bx0 ? tile : bt;
+        stage(nx2, pf_stage);
         __syncthreads();
-        cur ^= 1;
+        cur = nxt;
     }
-    const int best = bi >= 0 ? (int)(nq - bx) : 0x7fffffff;
-    const int second = sx > -__builtin_inff() ? (int)(nq - sx) : 0x7fffffff;
+    // ---- recovery: the rows of the best group again, in integers (x2 = 2 q.t - |t|^2), from the u8 descriptors
+    int best = 0x7fffffff, second = 0x7fffffff, bi = -1;
+#ifndef MATCH_EXP
+#define MATCH_EXP 0
+#endif
+#if MATCH_EXP == 7 || MATCH_EXP == 8
+    if (q < pd.n_i && bt >= 0) { best = (int)bx; second = (int)sx; bi = bt * 32 + bg; }
+    if (false) {
+#else
+    if (q < pd.n_i && bt >= 0) {
+#endif
+        const int nq = GLOBAL_PTR(int, pd.nrm_i)[q];
+        const int m0 = bt * 32 + 8 * bg + 4 * hi;
+        const int x2_best = (int)(2.0f * bx);
+        u32x4 qd[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) qd[k] = GLOBAL_PTR(u32x4, pd.d8_i + (size_t)q * 128)[k];
+        int s2 = sx > -__builtin_inff() ? (int)(2.0f * sx) : (int)0x80000000;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            if (m0 + r >= pd.n_j) continue;
+            unsigned dot = 0;
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const u32x4 t = GLOBAL_PTR(u32x4, pd.d8_j + (size_t)(m0 + r) * 128)[k];
+                dot = __builtin_amdgcn_udot4(qd[k].x, t.x, dot, false); dot = __builtin_amdgcn_udot4(qd[k].y, t.y, dot, false);
+                dot = __builtin_amdgcn_udot4(qd[k].z, t.z, dot, false); dot = __builtin_amdgcn_udot4(qd[k].w, t.w, dot, false);
+            }
+            const int x2 = 2 * (int)dot - GLOBAL_PTR(int, pd.nrm_j)[m0 + r];
+            if (x2 == x2_best && bi < 0) bi = m0 + r;                 // lowest row of the group that reaches the maximum
+            else s2 = x2 > s2 ? x2 : s2;
+        }
+        best = nq - x2_best;
+        second = s2 == (int)0x80000000 ? 0x7fffffff : nq - s2;
+    }
     // merge the two half-waves (same query, disjoint train rows); ties -> lowest train index
     const int ob = __shfl_xor(best, 32), os = __shfl_xor(second, 32), oi = __shfl_xor(bi, 32);
     const bool other_wins = (ob < best) || (ob == best && oi >= 0 && (bi < 0 || oi < bi));
@@ -129,7 +196,7 @@ __global__ __launch_bounds__(BF_NT) void bf_match_kernel(const PairDesc* pairs, 
     const int min_sec = os < second ? os : second;
     const int ns = loser_best < min_sec ? loser_best : min_sec;
     if (hi == 0 && q < pd.n_i) {
-        const size_t o = (size_t)blockIdx.y * KSTRIDE + q;
+        const size_t o = (size_t)pair * KSTRIDE + q;
         nn_idx[o] = ni; nn_d2[o] = nb; nn_2nd[o] = ns;
     }
 }
@@ -275,8 +342,8 @@ int build_pair_table(mi355_ctx* ctx, const int32_t* pairs, int n_pairs, std::vec
         const Features &a = fi->second, &b = fj->second;
         if (a.n > KSTRIDE || b.n > KSTRIDE) { ctx->set_error("match_pairs: more than 2048 keypoints per image"); return MI355_ERR_ARG; }
         PairDesc& d = pd[p];
-        d.bf_i = a.bf.as<uint16_t>(); d.nrm_i = a.nrm.as<int>(); d.xy_i = a.xy.as<float2>(); d.n_i = a.n; d.npad_i = a.npad;
-        d.bf_j = b.bf.as<uint16_t>(); d.nrm_j = b.nrm.as<int>(); d.xy_j = b.xy.as<float2>(); d.n_j = b.n; d.npad_j = b.npad;
+        d.bf_i = a.bf.as<uint16_t>(); d.nrm_i = a.nrm.as<int>(); d.xy_i = a.xy.as<float2>(); d.d8_i = a.d8.as<uint8_t>(); d.n_i = a.n; d.npad_i = a.npad;
+        d.bf_j = b.bf.as<uint16_t>(); d.nrm_j = b.nrm.as<int>(); d.xy_j = b.xy.as<float2>(); d.d8_j = b.d8.as<uint8_t>(); d.n_j = b.n; d.npad_j = b.npad;
         d.img_i = i; d.img_j = j; d.width = a.w; d.height = a.h;        // the cell comes from the image-i point (:5002-5009)
     }
     return MI355_OK;
@@ -287,8 +354,8 @@ int build_pair_table(mi355_ctx* ctx, const int32_t* pairs, int n_pairs, std::vec
 int mi_finish_features(mi355_ctx* ctx, Features& f, const int* d_n, hipStream_t st) {
     if (!st) st = ctx->stream;
     const int nmax = d_n ? KSTRIDE : f.n;
-    f.npad = ((nmax + QTILE - 1) / QTILE) * QTILE;
-    if (f.npad == 0) f.npad = QTILE;
+    f.npad = ((nmax + 255) / 256) * 256;
+    if (f.npad == 0) f.npad = 256;
     MI_HIP(f.xy.reserve(sizeof(float2) * (size_t)(nmax > 0 ? nmax : 1)));
     MI_HIP(f.bf.reserve(sizeof(uint16_t) * 128 * (size_t)f.npad));
     MI_HIP(f.nrm.reserve(sizeof(int) * (size_t)f.npad));
@@ -364,8 +431,9 @@ static int run_match_select(mi355_ctx* ctx, const std::vector<PairDesc>& pd, int
     for (int p = 0; p < n_pairs; p++) { if (pd[p].n_i > max_ni) max_ni = pd[p].n_i; flops_bytes += (double)(pd[p].npad_i + pd[p].npad_j) * 256.0 + 8.0 * pd[p].n_i; }
     {
         ProfScope ps(ctx, "match", flops_bytes);
-        hipLaunchKernelGGL(bf_match_kernel, dim3((max_ni + QTILE - 1) / QTILE, n_pairs), dim3(BF_NT), 0, ctx->stream,
-                           dpd.as<PairDesc>(), didx.as<int>(), dd2.as<int>(), d2nd.as<int>());
+        const int nqt = (max_ni + QTILE - 1) / QTILE;
+        hipLaunchKernelGGL(bf_match_kernel, dim3((unsigned)nqt * (unsigned)n_pairs), dim3(BF_NT), 0, ctx->stream,
+                           dpd.as<PairDesc>(), nqt, didx.as<int>(), dd2.as<int>(), d2nd.as<int>());
     }
     SelectParams sp;
     sp.max_selected = ctx->p.max_selected; sp.fraction = ctx->p.select_fraction; sp.gx = ctx->p.grid_x; sp.gy = ctx->p.grid_y;
@@ -477,4 +545,11 @@ int mi_select_grid(mi355_ctx* ctx, const mi355_dmatch* sorted, int n, const floa
     }
     *n_out = cnt;
     return MI355_OK;
+}
+
+// diagnostic (scratch/match_time.py): workgroups of bf_match_kernel the runtime keeps resident per CU
+extern "C" int mi355_debug_match_occupancy() {
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, bf_match_kernel, BF_NT, 0) != hipSuccess) return -1;
+    return nb;
 }
