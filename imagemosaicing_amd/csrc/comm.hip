@@ -156,24 +156,23 @@ extern "C" int mi355_pack_features_dev(mi355_ctx* ctx, const int32_t* img_ids, i
 }
 
 // One launch installs every received record: keypoints and descriptors move into the image's resident buffers and the matcher's
-// operands (xy, bf16 rows, squared norms) are derived on the way -- the per-frame form (two copies + finish_features per frame)
+// operands (xy, int8 rows, squared norms) are derived on the way -- the per-frame form (two copies + finish_features per frame)
 // costs ~1500 API calls per step at C4.
-struct InstallDst { const uint8_t* rec; mi355_keypoint* kp; uint8_t* d8; float2* xy; uint16_t* bf; int* nrm; int n, npad; };
+struct InstallDst { const uint8_t* rec; mi355_keypoint* kp; uint8_t* d8; float2* xy; int8_t* s8; int* n8; int n, npad; };
 
 __global__ __launch_bounds__(128) void install_features_kernel(const InstallDst* tab) {
     const InstallDst t = tab[blockIdx.y];
     const int row = blockIdx.x, k = threadIdx.x;            // one descriptor row per workgroup, 128 lanes = 128 dims
     if (row >= t.npad) return;
-    unsigned v = 0;
-    if (row < t.n) v = t.rec[REC_D8_OFF + (size_t)row * 128 + k];
-    if (row < t.n) t.d8[(size_t)row * 128 + k] = (uint8_t)v;
-    t.bf[(size_t)row * 128 + k] = (uint16_t)(__float_as_uint((float)v) >> 16);      // integer 0..255 -> bf16 bits (exact)
-    int s = (int)(v * v);
+    int v = 0;
+    if (row < t.n) { const unsigned u = t.rec[REC_D8_OFF + (size_t)row * 128 + k]; t.d8[(size_t)row * 128 + k] = (uint8_t)u; v = (int)u - 128; }
+    t.s8[(size_t)row * 128 + k] = (int8_t)v;              // the matcher's int8 operand (match.hip), zeros in the padding rows
+    int s = v * v;
     for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
     __shared__ int part[2];
     if ((k & 63) == 0) part[k >> 6] = s;
     __syncthreads();
-    if (k == 0) t.nrm[row] = part[0] + part[1];
+    if (k == 0) t.n8[row] = part[0] + part[1];
     if (row < t.n && k < 7) {
         const unsigned w = reinterpret_cast<const unsigned*>(t.rec + (size_t)row * sizeof(mi355_keypoint))[k];
         reinterpret_cast<unsigned*>(t.kp + row)[k] = w;
@@ -196,17 +195,17 @@ static int install_features(mi355_ctx* ctx, const mi355_feature_header* hdr, con
         if (it != ctx->feats.end() && it->second.pending && !resolved) { int rc = mi_resolve_features(ctx); if (rc != MI355_OK) return rc; resolved = true; }
         Features& f = ctx->feats[hk.img_id];
         f.n = hk.n_kp; f.w = hk.w; f.h = hk.h; f.pending = false; f.h_cnt = nullptr;
-        f.npad = ((f.n + 127) / 128) * 128;
-        if (f.npad == 0) f.npad = 128;
+        f.npad = ((f.n + 255) / 256) * 256;
+        if (f.npad == 0) f.npad = 256;
         // sized for 2048 keypoints once: no allocation in steady state when the counts change from step to step
         MI_HIP(f.kp.reserve(sizeof(mi355_keypoint) * 2048));
         MI_HIP(f.d8.reserve((size_t)128 * 2048));
         MI_HIP(f.xy.reserve(sizeof(float2) * 2048));
-        MI_HIP(f.bf.reserve(sizeof(uint16_t) * 128 * 2048));
-        MI_HIP(f.nrm.reserve(sizeof(int) * 2048));
+        MI_HIP(f.s8.reserve((size_t)128 * 2048));
+        MI_HIP(f.n8.reserve(sizeof(int) * 2048));
         InstallDst t;
         t.rec = reinterpret_cast<const uint8_t*>(d_payload) + (size_t)k * MI355_FEATURE_RECORD_BYTES;
-        t.kp = f.kp.as<mi355_keypoint>(); t.d8 = f.d8.as<uint8_t>(); t.xy = f.xy.as<float2>(); t.bf = f.bf.as<uint16_t>(); t.nrm = f.nrm.as<int>();
+        t.kp = f.kp.as<mi355_keypoint>(); t.d8 = f.d8.as<uint8_t>(); t.xy = f.xy.as<float2>(); t.s8 = f.s8.as<int8_t>(); t.n8 = f.n8.as<int>();
         t.n = f.n; t.npad = f.npad;
         tab.push_back(t);
     }

@@ -49,20 +49,20 @@ struct DevBuf {
 // device-resident features of one image (what the reference keeps in d:/feature_temp files)
 struct Features {
     int n = 0;          // keypoints
-    int npad = 0;       // rows of the bf16 matrix (multiple of 64, zero padded)
+    int npad = 0;       // rows of the matcher's int8 matrix (multiple of 256, zero padded)
     int w = 0, h = 0;   // image size (grid selection needs it)
     DevBuf kp;          // n x mi355_keypoint
     DevBuf xy;          // n x float2
     DevBuf d8;          // n x 128 u8   (the integers OpenCV's SIFT stores in its float Mat)
-    DevBuf bf;          // npad x 128 bf16 (same integers, exact in bf16)
-    DevBuf nrm;         // npad x int32  squared norms
+    DevBuf s8;          // npad x 128 int8 (the same integers minus 128: the MFMA operands)
+    DevBuf n8;          // npad x int32  squared norms of the shifted rows
     // asynchronous SIFT: the keypoint count is produced on the device; it lands in pinned host memory and is
     // adopted by mi_resolve_features() the first time the host needs it (match, get_features)
     bool pending = false;
     volatile int* h_cnt = nullptr;   // 8 ints: extrema, refined, keypoints, kept, overflow, ...
     hipEvent_t ready = nullptr;      // recorded after the frame's batch (owned by ctx->batch_events): lets a match wait for ITS frames only
     unsigned caps[3] = {0, 0, 0};
-    void release() { kp.release(); xy.release(); d8.release(); bf.release(); nrm.release(); }
+    void release() { kp.release(); xy.release(); d8.release(); s8.release(); n8.release(); }
 };
 
 struct ProfClass {

@@ -8,50 +8,40 @@
 //   Ransac2D (:5169)                                              -> csrc/ransac.hip
 //   accept when inliers > 30 (:5049, :5201)
 //
-// Why bf16 MFMA is EXACT here: SIFT descriptors are the integers 0..255 (OpenCV stores saturate_cast<uchar>
-// values in a float Mat).  bf16 has 8 significand bits, so 0..255 are exact; every product <= 65025 and every
-// 128-term dot product <= 8.33e6 < 2^24 is exact in the f32 accumulator in any summation order; the squared
-// norms are exact integers too.  d2 = |a|^2 + |b|^2 - 2 a.b is therefore the exact integer squared distance
-// and the arg-min (ties -> lowest train index) equals a CPU integer brute force bit for bit.
+// The distances are exact integers on the matrix cores: SIFT descriptors are the integers 0..255 (OpenCV stores
+// saturate_cast<uchar> values in a float Mat); moved to v - 128 they are int8, and v_mfma_i32_32x32x32_i8 accumulates
+// S = sum (q - 128)(t - 128) in int32 without rounding.  |q - t|^2 = |q'|^2 - (2 S - |t'|^2) for the shifted vectors q', t', so
+// the nearest train row maximises x2 = 2 S - |t'|^2 and the arg-max (ties -> lowest train index) equals a CPU integer brute force.
+// Round 2 did the same sum in bf16 (exact too, 8 significand bits); the int8 pipe is twice as fast (scratch/mfma_bench.hip, MI355X,
+// descriptor-like operands: bf16 32x32x16 1.95 PFLOP/s, i8 32x32x32 3.9 POP/s -- both clock lower on toggling data than the
+// 2.4 / 4.9 they reach on zeros) and its operands are half the bytes in HBM, L2 and LDS.
 //
-// Kernel shape (v_mfma_f32_32x32x16_bf16): the TRAIN tile is the A operand (rows) and the QUERY tile the B
-// operand (columns), so after the MFMA lane l holds 16 train rows of ONE query (column l&31): the running
-// top-2 is lane-local (no cross-lane traffic in the loop) and the two half-waves are merged once at the end.
+// Kernel shape (v_mfma_i32_32x32x32_i8): the TRAIN tile is the A operand (rows) and the QUERY tile the B operand (columns), so
+// after the MFMA lane l holds 16 train rows of ONE query (column l & 31): the running best is lane-local (no cross-lane traffic
+// in the loop) and the two half-waves are merged once at the end.  A wave owns 64 queries (two B operands): every A fragment and
+// every row constant read from LDS feeds two MFMAs.
 #include "common.h"
 #include <algorithm>
 
 namespace {
 
-typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 bf16x8;
-typedef __attribute__((__vector_size__(16 * sizeof(float)))) float f32x16;
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-// Pointers that arrive inside a structure read from memory (PairDesc) are generic to the compiler: it emits flat_load, and with a
-// flat load in flight every LDS wait becomes a wait for ALL memory (vmcnt(0) right after the first MFMA of the tile) -- the L2
-// latency of the next tile's prefetch was exposed in every iteration.  Cast to the global address space: global_load, counted apart.
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x16 __attribute__((ext_vector_type(16)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+// Pointers that arrive inside a structure read from memory (PairDesc) are generic to the compiler: it emits flat_load, and a flat
+// load in flight turns every LDS wait into a wait for ALL memory.  Cast to the global address space: global_load, counted apart.
 #define GLOBAL_PTR(T, p) ((const __attribute__((address_space(1))) T*)(p))
 
 constexpr int KSTRIDE = 2048;        // per-pair stride of the nn arrays (>= nfeatures rounded up)
-#ifndef MATCH_QTILE
-#define MATCH_QTILE 256
-#endif
-constexpr int QTILE = MATCH_QTILE;   // queries per workgroup (8 waves x 32): every staged train tile serves 256 queries (128: 5 % slower).
-                                     // rocprofv3 --pmc (scratch/pmc_match.sh): matrix pipe busy 45 % of the time, 13.9 VALU instructions per MFMA,
-                                     // waves parked 42 % of their cycles.  Tried without gain (23-24 ms for 19 729 pairs either way): the index
-                                     // of the best row tracked per 4-row group and recovered afterwards (-40 % epilogue instructions), two B
-                                     // operands per wave so that an A fragment read from LDS feeds two MFMAs (half the LDS reads); round 3: 128 train
-                                     // rows per stage (one workgroup barrier per 128 rows, 70 KB LDS): 163 ms against 92 ms per 74 029 pairs
-constexpr int BF_NT = QTILE * 2;     // threads per workgroup
+constexpr int QTILE = 512;           // queries per workgroup (8 waves x 64): every staged train tile serves 512 queries
+constexpr int BF_NT = 512;           // threads per workgroup
+constexpr int ROWPAD = 256;          // descriptor matrices are padded to a multiple of this many rows (zeros)
 
 struct PairDesc {
-    const uint16_t* bf_i; const int* nrm_i; const float2* xy_i; const uint8_t* d8_i; int n_i; int npad_i;
-    const uint16_t* bf_j; const int* nrm_j; const float2* xy_j; const uint8_t* d8_j; int n_j; int npad_j;
+    const int8_t* s8_i; const int* n8_i; const float2* xy_i; int n_i; int npad_i;
+    const int8_t* s8_j; const int* n8_j; const float2* xy_j; int n_j; int npad_j;
     int img_i, img_j, width, height;
 };
-
-__device__ __forceinline__ void top2_update(int s, int j, int& best, int& second, int& bi) {
-    if (s < best) { second = best; best = s; bi = j; }
-    else if (s < second) second = s;
-}
 
 // Work-to-XCD placement: workgroup ids go round-robin over the 8 XCDs (each with its own L2).  XCD x owns a contiguous eighth of
 // the (pair, query tile) list, so the query tiles of a pair run side by side under ONE L2 and the train set crosses the fabric once.
@@ -60,144 +50,142 @@ __device__ __forceinline__ int xcd_owned(int bid, int nb) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
 }
 
-// What the loop costs (scratch/match_time.py, 1740 pairs of 2000 x 2000, MI355X; 2.14 ms would be the dense bf16 peak):
-//   the eight MFMAs per tile alone, operands in registers, no LDS / barrier / epilogue       3.07 ms  (the pipe's own ceiling here: 0.70)
-//   + LDS operand reads                                                                       3.16 ms
-//   + staging and one workgroup barrier per tile                                              4.09 ms
-//   + the per-element top-2 epilogue of round 2 (fma, compare, select, med3, max = 96 VALU)    5.96 ms  (0.36 of peak)
-// so the epilogue and the barrier-to-first-MFMA latency were the two things to remove:
-//   * -|t|^2 / 2 enters as the C operand of the first MFMA (x = q.t - |t|^2 / 2 comes out of the matrix pipe; all partial sums
-//     are multiples of 1/2 below 2^23, exact in binary32) -- no per-element fma;
-//   * the running top-2 is kept per GROUP of four rows (max3, max, compare, select, med3, max = 6 VALU per 4 elements), the
-//     winning row of the best group and the runner-up inside it are recovered after the loop from the u8 descriptors with
-//     v_dot4_u32_u8 (4 rows x 32 dot4 per lane, once per query);
-//   * three LDS stages: the first half of the NEXT tile's operands and its C rows are read before the barrier, so the MFMAs of
-//     the next iteration start straight after it.
+__device__ __forceinline__ int med3_i32(int a, int b, int c) { int r; asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+
+// Where the time of the round-2 kernel went (scratch/match_time.py, 1740 pairs of 2000 x 2000; bf16, 32 queries per wave):
+//   the eight MFMAs per tile alone, operands in registers       3.07 ms   (the pipe on these operands: 94 % of what mfma_bench gets)
+//   + LDS operand reads                                         3.16 ms
+//   + staging and one workgroup barrier per tile                4.09 ms
+//   + per-element top-2 (fma, compare, select, med3, max)       5.96 ms   (0.36 of the nominal bf16 peak)
+// and re-reading the rows of the best group after the loop to find the row costs more L2 traffic than the loop itself (tried:
+// +1.2 ms).  Hence:
+//   * the row position rides in the low bits of the compared value: z = 16 x2 + (15 - e) for slot e of the lane's 16 rows of the
+//     tile (|x2| < 2^23, so z fits int32); ONE v_lshl_add_u32 per element builds it from the accumulator and a per-row constant
+//     k = -16 |t'|^2 + 15 - e kept in LDS, a v_max3 tree finds the tile's maximum with its slot, and the running best needs four
+//     more instructions per TILE (compare against best | 15 so that an equal distance in a later tile does not replace an earlier
+//     row): 28 VALU per 16 elements instead of 96;
+//   * the second-best distance is only needed by the optional ratio test and by mi355_bf_match: template parameter (two more
+//     instructions per element, a multiset top-2 of z, whose order statistics map onto those of x2);
+//   * three LDS stages: the first half of the NEXT tile's operands and its row constants are read before the barrier, so the
+//     MFMAs of the next iteration start straight after it; the loop body has no branches.
+template <bool SECOND>
 __global__ __launch_bounds__(BF_NT) void bf_match_kernel(const PairDesc* pairs, int nqt, int* nn_idx, int* nn_d2, int* nn_2nd) {
-    __shared__ __attribute__((aligned(16))) float s_c[KSTRIDE + 32]; // -|t|^2 / 2 of the train rows (the C operand), -inf for the padding rows
-    constexpr int APITCH = 128 + 8;                       // bf16 per staged row: 272 B keeps the 32 rows of a read on distinct banks
+    constexpr int NOROW = -(1 << 30);
+    __shared__ __attribute__((aligned(16))) int s_k[KSTRIDE + 32];   // k of the train rows, NOROW for the padding rows
+    constexpr int APITCH = 128 + 16;                      // bytes per staged row: 36 dwords keep the 16 lanes of a b128 group on distinct banks
     constexpr int STAGE = 32 * APITCH;
-    __shared__ __attribute__((aligned(16))) uint16_t s_a[3 * STAGE];
+    __shared__ __attribute__((aligned(16))) int8_t s_a[3 * STAGE];
     const int work = xcd_owned(blockIdx.x, gridDim.x), pair = work / nqt;
     const PairDesc pd = pairs[pair];
     const int q_base = (work - pair * nqt) * QTILE;
     if (q_base >= pd.n_i) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int hi = lane >> 5, col = lane & 31;
-    for (int i = tid; i < pd.npad_j; i += BF_NT) s_c[i] = i < pd.n_j ? -0.5f * (float)GLOBAL_PTR(int, pd.nrm_j)[i] : -__builtin_inff();
-    const int q = q_base + wave * 32 + col;              // this lane's query (rows beyond n_i are zero padding)
-    const int q_ld = q < pd.npad_i ? q : pd.npad_i - 1;
-    bf16x8 bq[8];
-#pragma unroll
-    for (int ks = 0; ks < 8; ks++) bq[ks] = *GLOBAL_PTR(bf16x8, pd.bf_i + (size_t)q_ld * 128 + ks * 16 + hi * 8);
-    // The 32 x 128 train tile (8 KB) is the A operand of all eight waves: fetched once per workgroup into LDS, every thread 16 B.
-    constexpr int NST = BF_NT >= 512 ? 1 : 512 / BF_NT;                      // 16-byte pieces of the tile per thread
-    struct Pf { u32x4 v[NST]; };
-    Pf pf;
-    auto fetch = [&](int t0) {
-#pragma unroll
-        for (int k = 0; k < NST; k++) { const int i = (tid + k * BF_NT) & 511; pf.v[k] = *GLOBAL_PTR(u32x4, pd.bf_j + (size_t)(t0 + (i >> 4)) * 128 + (i & 15) * 8); }
-    };
-    auto stage = [&](int buf, const Pf& v) {
-#pragma unroll
-        for (int k = 0; k < NST; k++) { const int i = (tid + k * BF_NT) & 511; if (BF_NT <= 512 || tid < 512) *reinterpret_cast<u32x4*>(&s_a[buf * STAGE + (i >> 4) * APITCH + (i & 15) * 8]) = v.v[k]; }
-    };
     const int npad = pd.npad_j;
+    for (int i = tid; i < npad + 32; i += BF_NT) {
+        const int e = 4 * ((i & 31) >> 3) + (i & 3);      // slot of row i in its lane: C/D layout of the 32x32 MFMA, rows 8g + 4hi + r in acc[4g + r]
+        s_k[i] = i < pd.n_j ? -16 * GLOBAL_PTR(int, pd.n8_j)[i] + 15 - e : NOROW;
+    }
+    int q[2];
+    i32x4 bq[2][4];
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+        q[c] = q_base + wave * 64 + c * 32 + col;         // this lane's queries (rows beyond n_i are zero padding)
+        const int q_ld = q[c] < pd.npad_i ? q[c] : pd.npad_i - 1;
+#pragma unroll
+        for (int ks = 0; ks < 4; ks++) bq[c][ks] = *GLOBAL_PTR(i32x4, pd.s8_i + (size_t)q_ld * 128 + ks * 32 + hi * 16);
+    }
+    // The 32 x 128 train tile (4 KB) is the A operand of all eight waves: fetched once per workgroup into LDS, every thread 8 B.
+    const int ld_off = (tid >> 4) * APITCH + (tid & 15) * 8;
+    const int8_t* gsrc = pd.s8_j + (size_t)(tid >> 4) * 128 + (tid & 15) * 8;
+    u32x2 pf;
+    auto fetch = [&](int t0) { pf = *GLOBAL_PTR(u32x2, gsrc + (size_t)t0 * 128); };
+    auto stage = [&](int buf, const u32x2& v) { *reinterpret_cast<u32x2*>(&s_a[buf * STAGE + ld_off]) = v; };
     fetch(0); stage(0, pf);
     fetch(32); stage(1, pf);                              // npad is a multiple of 256
     fetch(64);                                            // staged during iteration 0; every later fetch has a whole iteration to land
     __syncthreads();
-    const int a_off = col * APITCH + hi * 8;
-    bf16x8 fa[8];
-    f32x16 acc;                                           // holds the C rows (-|t|^2 / 2) of the tile when the iteration starts
-    auto read_lo = [&](int buf, int t0) {                 // operands ks 0..3 of the tile in `buf` and its C rows
-        const uint16_t* arow = &s_a[buf * STAGE + a_off];
+    const int a_off = col * APITCH + hi * 16;
+    i32x4 fa[4];
+    i32x16 kk;
+    auto read_lo = [&](int buf, int t0) {                 // operands ks 0..1 of the tile in `buf` and its row constants
 #pragma unroll
-        for (int ks = 0; ks < 4; ks++) fa[ks] = *reinterpret_cast<const bf16x8*>(arow + ks * 16);
+        for (int ks = 0; ks < 2; ks++) fa[ks] = *reinterpret_cast<const i32x4*>(&s_a[buf * STAGE + a_off + ks * 32]);
 #pragma unroll
-        for (int g = 0; g < 4; g++) {                     // C/D layout of the 32x32 MFMA: rows 8g + 4hi .. +3 in acc[4g .. 4g+3]
-            const float4 c = *reinterpret_cast<const float4*>(&s_c[t0 + 8 * g + 4 * hi]);
-            acc[4 * g] = c.x; acc[4 * g + 1] = c.y; acc[4 * g + 2] = c.z; acc[4 * g + 3] = c.w;
+        for (int g = 0; g < 4; g++) {
+            const i32x4 c = *reinterpret_cast<const i32x4*>(&s_k[t0 + 8 * g + 4 * hi]);
+            kk[4 * g] = c.x; kk[4 * g + 1] = c.y; kk[4 * g + 2] = c.z; kk[4 * g + 3] = c.w;
         }
     };
     read_lo(0, 0);
-    float bx = -__builtin_inff(), sx = -__builtin_inff();
-    int bt = -1, bg = 0;
+    constexpr int IMIN = (int)0x80000000;
+    int bz[2] = {IMIN, IMIN}, bthr[2] = {IMIN | 15, IMIN | 15}, bt[2] = {0, 0};
+    int b2[2] = {IMIN, IMIN}, s2[2] = {IMIN, IMIN};       // SECOND: multiset top-2 of z
     int cur = 0, tile = 0;
     for (int t0 = 0; t0 < npad; t0 += 32, tile++) {
         const int nxt = cur == 2 ? 0 : cur + 1, nx2 = nxt == 2 ? 0 : nxt + 1;
-        const Pf pf_stage = pf;                        // tile t + 2, fetched one iteration ago
-        fetch(t0 + 96 < npad ? t0 + 96 : 0);              // the loop body is branch-free: past the end it fetches / stages / reads tiles nobody uses
-        const uint16_t* arow = &s_a[cur * STAGE + a_off];
+        const u32x2 pf_stage = pf;                        // tile t + 2, fetched one iteration ago
+        fetch(t0 + 96 < npad ? t0 + 96 : 0);              // past the end the loop fetches / stages / reads tiles nobody uses
 #pragma unroll
-        for (int ks = 4; ks < 8; ks++) fa[ks] = *reinterpret_cast<const bf16x8*>(arow + ks * 16);
+        for (int ks = 2; ks < 4; ks++) fa[ks] = *reinterpret_cast<const i32x4*>(&s_a[cur * STAGE + a_off + ks * 32]);
+        i32x16 acc[2];
 #pragma unroll
-        for (int ks = 0; ks < 8; ks++) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks], bq[ks], acc, 0, 0, 0);
-        float gm[4];
-#pragma unroll
-        for (int g = 0; g < 4; g++) gm[g] = fmaxf(fmaxf(fmaxf(acc[4 * g], acc[4 * g + 1]), acc[4 * g + 2]), acc[4 * g + 3]);
-        read_lo(nxt, t0 + 32);                            // issued before the barrier: the next iteration starts with its MFMAs
-        const float bx0 = bx;
-#if MATCH_EXP == 8
-        bx = fmaxf(bx, gm[0] + gm[1] + gm[2] + gm[3]);
-#else
-#pragma unroll
-        for (int g = 0; g < 4; g++) {
-            bg = gm[g] > bx ? g : bg;                                 // strict: ties keep the earliest group
-            sx = __builtin_amdgcn_fmed3f(bx, gm[g], sx);              // second = median(best, x, second) since second <= best
-            bx = fmaxf(bx, gm[g]);
+        for (int c = 0; c < 2; c++) {
+            acc[c] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[0], bq[c][0], i32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, 0, 0, 0);
         }
-#endif
-        bt = bx > bx0 ? tile : bt;
+#pragma unroll
+        for (int ks = 1; ks < 4; ks++) {
+#pragma unroll
+            for (int c = 0; c < 2; c++) acc[c] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[ks], bq[c][ks], acc[c], 0, 0, 0);
+        }
+        int tm[2];
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            int z[16];
+#pragma unroll
+            for (int e = 0; e < 16; e++) z[e] = (acc[c][e] << 5) + kk[e];
+            if (SECOND) {
+#pragma unroll
+                for (int e = 0; e < 16; e++) { s2[c] = med3_i32(b2[c], z[e], s2[c]); b2[c] = max(b2[c], z[e]); }
+            }
+            int m4[4];
+#pragma unroll
+            for (int g = 0; g < 4; g++) m4[g] = max(max(max(z[4 * g], z[4 * g + 1]), z[4 * g + 2]), z[4 * g + 3]);
+            tm[c] = max(max(max(m4[0], m4[1]), m4[2]), m4[3]);
+        }
+        read_lo(nxt, t0 + 32);                            // issued before the barrier: the next iteration starts with its MFMAs
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            const bool win = tm[c] > bthr[c];             // strictly nearer than the best so far (the position bits masked out)
+            bz[c] = win ? tm[c] : bz[c];
+            bt[c] = win ? tile : bt[c];
+            bthr[c] = bz[c] | 15;
+        }
         stage(nx2, pf_stage);
         __syncthreads();
         cur = nxt;
     }
-    // ---- recovery: the rows of the best group again, in integers (x2 = 2 q.t - |t|^2), from the u8 descriptors
-    int best = 0x7fffffff, second = 0x7fffffff, bi = -1;
-#ifndef MATCH_EXP
-#define MATCH_EXP 0
-#endif
-#if MATCH_EXP == 7 || MATCH_EXP == 8
-    if (q < pd.n_i && bt >= 0) { best = (int)bx; second = (int)sx; bi = bt * 32 + bg; }
-    if (false) {
-#else
-    if (q < pd.n_i && bt >= 0) {
-#endif
-        const int nq = GLOBAL_PTR(int, pd.nrm_i)[q];
-        const int m0 = bt * 32 + 8 * bg + 4 * hi;
-        const int x2_best = (int)(2.0f * bx);
-        u32x4 qd[8];
 #pragma unroll
-        for (int k = 0; k < 8; k++) qd[k] = GLOBAL_PTR(u32x4, pd.d8_i + (size_t)q * 128)[k];
-        int s2 = sx > -__builtin_inff() ? (int)(2.0f * sx) : (int)0x80000000;
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            if (m0 + r >= pd.n_j) continue;
-            unsigned dot = 0;
-#pragma unroll
-            for (int k = 0; k < 8; k++) {
-                const u32x4 t = GLOBAL_PTR(u32x4, pd.d8_j + (size_t)(m0 + r) * 128)[k];
-                dot = __builtin_amdgcn_udot4(qd[k].x, t.x, dot, false); dot = __builtin_amdgcn_udot4(qd[k].y, t.y, dot, false);
-                dot = __builtin_amdgcn_udot4(qd[k].z, t.z, dot, false); dot = __builtin_amdgcn_udot4(qd[k].w, t.w, dot, false);
+    for (int c = 0; c < 2; c++) {
+        int best = 0x7fffffff, second = 0x7fffffff, bi = -1;
+        const int e = 15 - (bz[c] & 15), row = bt[c] * 32 + 8 * (e >> 2) + 4 * hi + (e & 3);
+        const bool q_ok = q[c] < pd.n_i;
+        const int nq = q_ok ? GLOBAL_PTR(int, pd.n8_i)[q[c]] : 0;
+        if (q_ok && bz[c] != IMIN && row < pd.n_j) { bi = row; best = nq - (bz[c] >> 4); }
+        if (SECOND && q_ok && s2[c] > NOROW / 2) second = nq - (s2[c] >> 4);
+        // merge the two half-waves (same query, disjoint train rows); ties -> lowest train index
+        const int ob = __shfl_xor(best, 32), os = __shfl_xor(second, 32), oi = __shfl_xor(bi, 32);
+        const bool other_wins = (ob < best) || (ob == best && oi >= 0 && (bi < 0 || oi < bi));
+        const int nb = other_wins ? ob : best, ni = other_wins ? oi : bi;
+        if (hi == 0 && q_ok) {
+            const size_t o = (size_t)pair * KSTRIDE + q[c];
+            nn_idx[o] = ni; nn_d2[o] = nb;
+            if (SECOND) {
+                const int loser_best = other_wins ? best : ob;
+                const int min_sec = os < second ? os : second;
+                nn_2nd[o] = loser_best < min_sec ? loser_best : min_sec;
             }
-            const int x2 = 2 * (int)dot - GLOBAL_PTR(int, pd.nrm_j)[m0 + r];
-            if (x2 == x2_best && bi < 0) bi = m0 + r;                 // lowest row of the group that reaches the maximum
-            else s2 = x2 > s2 ? x2 : s2;
         }
-        best = nq - x2_best;
-        second = s2 == (int)0x80000000 ? 0x7fffffff : nq - s2;
-    }
-    // merge the two half-waves (same query, disjoint train rows); ties -> lowest train index
-    const int ob = __shfl_xor(best, 32), os = __shfl_xor(second, 32), oi = __shfl_xor(bi, 32);
-    const bool other_wins = (ob < best) || (ob == best && oi >= 0 && (bi < 0 || oi < bi));
-    const int nb = other_wins ? ob : best, ni = other_wins ? oi : bi;
-    const int loser_best = other_wins ? best : ob;
-    const int min_sec = os < second ? os : second;
-    const int ns = loser_best < min_sec ? loser_best : min_sec;
-    if (hi == 0 && q < pd.n_i) {
-        const size_t o = (size_t)pair * KSTRIDE + q;
-        nn_idx[o] = ni; nn_d2[o] = nb; nn_2nd[o] = ns;
     }
 }
 
@@ -295,20 +283,19 @@ __global__ void finalize_kernel(const PairDesc* pairs, const int* nsel, int n_pa
 
 // ---- features ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(128) void finish_features_kernel(const mi355_keypoint* kp, const uint8_t* d8, int n, const int* d_n, int npad,
-                                                              float2* xy, uint16_t* bf, int* nrm) {
+                                                              float2* xy, int8_t* s8, int* n8) {
     const int row = blockIdx.x, k = threadIdx.x;            // one row per block, 128 lanes = 128 dims
     if (d_n) n = *d_n;                                       // count still on the device (asynchronous SIFT)
-    unsigned v = 0;
-    if (row < n) v = d8[(size_t)row * 128 + k];
-    // integer 0..255 -> bf16 bits (exact): f32 bits >> 16
-    bf[(size_t)row * 128 + k] = (uint16_t)(__float_as_uint((float)v) >> 16);
-    int s = (int)(v * v);
+    int v = 0;
+    if (row < n) v = (int)d8[(size_t)row * 128 + k] - 128;   // the matcher's operand: the descriptor moved to int8 (padding rows: zeros)
+    s8[(size_t)row * 128 + k] = (int8_t)v;
+    int s = v * v;
     for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
     __shared__ int part[2];
     if ((k & 63) == 0) part[k >> 6] = s;
     __syncthreads();
     if (k == 0) {
-        nrm[row] = part[0] + part[1];
+        n8[row] = part[0] + part[1];
         if (row < n) xy[row] = make_float2(kp[row].x, kp[row].y);
     }
 }
@@ -342,8 +329,8 @@ int build_pair_table(mi355_ctx* ctx, const int32_t* pairs, int n_pairs, std::vec
         const Features &a = fi->second, &b = fj->second;
         if (a.n > KSTRIDE || b.n > KSTRIDE) { ctx->set_error("match_pairs: more than 2048 keypoints per image"); return MI355_ERR_ARG; }
         PairDesc& d = pd[p];
-        d.bf_i = a.bf.as<uint16_t>(); d.nrm_i = a.nrm.as<int>(); d.xy_i = a.xy.as<float2>(); d.d8_i = a.d8.as<uint8_t>(); d.n_i = a.n; d.npad_i = a.npad;
-        d.bf_j = b.bf.as<uint16_t>(); d.nrm_j = b.nrm.as<int>(); d.xy_j = b.xy.as<float2>(); d.d8_j = b.d8.as<uint8_t>(); d.n_j = b.n; d.npad_j = b.npad;
+        d.s8_i = a.s8.as<int8_t>(); d.n8_i = a.n8.as<int>(); d.xy_i = a.xy.as<float2>(); d.n_i = a.n; d.npad_i = a.npad;
+        d.s8_j = b.s8.as<int8_t>(); d.n8_j = b.n8.as<int>(); d.xy_j = b.xy.as<float2>(); d.n_j = b.n; d.npad_j = b.npad;
         d.img_i = i; d.img_j = j; d.width = a.w; d.height = a.h;        // the cell comes from the image-i point (:5002-5009)
     }
     return MI355_OK;
@@ -354,14 +341,14 @@ int build_pair_table(mi355_ctx* ctx, const int32_t* pairs, int n_pairs, std::vec
 int mi_finish_features(mi355_ctx* ctx, Features& f, const int* d_n, hipStream_t st) {
     if (!st) st = ctx->stream;
     const int nmax = d_n ? KSTRIDE : f.n;
-    f.npad = ((nmax + 255) / 256) * 256;
-    if (f.npad == 0) f.npad = 256;
+    f.npad = ((nmax + ROWPAD - 1) / ROWPAD) * ROWPAD;
+    if (f.npad == 0) f.npad = ROWPAD;
     MI_HIP(f.xy.reserve(sizeof(float2) * (size_t)(nmax > 0 ? nmax : 1)));
-    MI_HIP(f.bf.reserve(sizeof(uint16_t) * 128 * (size_t)f.npad));
-    MI_HIP(f.nrm.reserve(sizeof(int) * (size_t)f.npad));
-    ProfScope ps(ctx, "features", (double)f.npad * 128 * 3, st);
+    MI_HIP(f.s8.reserve((size_t)128 * (size_t)f.npad));
+    MI_HIP(f.n8.reserve(sizeof(int) * (size_t)f.npad));
+    ProfScope ps(ctx, "features", (double)f.npad * 128 * 2, st);
     hipLaunchKernelGGL(finish_features_kernel, dim3(f.npad), dim3(128), 0, st,
-                       f.kp.as<mi355_keypoint>(), f.d8.as<uint8_t>(), f.n, d_n, f.npad, f.xy.as<float2>(), f.bf.as<uint16_t>(), f.nrm.as<int>());
+                       f.kp.as<mi355_keypoint>(), f.d8.as<uint8_t>(), f.n, d_n, f.npad, f.xy.as<float2>(), f.s8.as<int8_t>(), f.n8.as<int>());
     MI_HIP(hipGetLastError());
     return MI355_OK;
 }
@@ -428,12 +415,15 @@ static int run_match_select(mi355_ctx* ctx, const std::vector<PairDesc>& pd, int
     MI_HIP(hipStreamSynchronize(ctx->stream));
     int max_ni = 1;
     double flops_bytes = 0.0;
-    for (int p = 0; p < n_pairs; p++) { if (pd[p].n_i > max_ni) max_ni = pd[p].n_i; flops_bytes += (double)(pd[p].npad_i + pd[p].npad_j) * 256.0 + 8.0 * pd[p].n_i; }
+    for (int p = 0; p < n_pairs; p++) { if (pd[p].n_i > max_ni) max_ni = pd[p].n_i; flops_bytes += (double)(pd[p].npad_i + pd[p].npad_j) * 128.0 + 8.0 * pd[p].n_i; }
     {
         ProfScope ps(ctx, "match", flops_bytes);
         const int nqt = (max_ni + QTILE - 1) / QTILE;
-        hipLaunchKernelGGL(bf_match_kernel, dim3((unsigned)nqt * (unsigned)n_pairs), dim3(BF_NT), 0, ctx->stream,
-                           dpd.as<PairDesc>(), nqt, didx.as<int>(), dd2.as<int>(), d2nd.as<int>());
+        const bool second = want_sorted_keys || ctx->p.ratio > 0.0f;      // mi355_bf_match reports it, the ratio test reads it
+        if (second) hipLaunchKernelGGL(bf_match_kernel<true>, dim3((unsigned)nqt * (unsigned)n_pairs), dim3(BF_NT), 0, ctx->stream,
+                                       dpd.as<PairDesc>(), nqt, didx.as<int>(), dd2.as<int>(), d2nd.as<int>());
+        else hipLaunchKernelGGL(bf_match_kernel<false>, dim3((unsigned)nqt * (unsigned)n_pairs), dim3(BF_NT), 0, ctx->stream,
+                                dpd.as<PairDesc>(), nqt, didx.as<int>(), dd2.as<int>(), d2nd.as<int>());
     }
     SelectParams sp;
     sp.max_selected = ctx->p.max_selected; sp.fraction = ctx->p.select_fraction; sp.gx = ctx->p.grid_x; sp.gy = ctx->p.grid_y;
@@ -550,6 +540,6 @@ int mi_select_grid(mi355_ctx* ctx, const mi355_dmatch* sorted, int n, const floa
 // diagnostic (scratch/match_time.py): workgroups of bf_match_kernel the runtime keeps resident per CU
 extern "C" int mi355_debug_match_occupancy() {
     int nb = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, bf_match_kernel, BF_NT, 0) != hipSuccess) return -1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, bf_match_kernel<false>, BF_NT, 0) != hipSuccess) return -1;
     return nb;
 }
