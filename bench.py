@@ -440,7 +440,7 @@ def main():
             "metric": "image-pairs/sec (detect+match+H+warp), 4000x3000 UAV frames",
             "value": value, "unit": "image-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / max(args.steps, 1) * 1e3, "higher_is_better": True, "scaling": "strong" if strong else "weak",
-            "vs_baseline": None, "dtype": "i16 fixed-point pyramid filtered in f32 (as the reference's OpenCV), f32 (RANSAC / warp coordinates), bf16 MFMA exact-integer (descriptor distances), u8 (pixels)",
+            "vs_baseline": None, "dtype": "i16 fixed-point pyramid filtered in f32 (as the reference's OpenCV), f32 (RANSAC / warp coordinates), int8 MFMA with int32 accumulation (descriptor distances, exact), u8 (pixels)",
             "data": "synthetic",
             "transport": transport if exchange else None, "rccl_ranks": rccl_ranks,
             "config": {"workload": "%s: %s, pair window %d (%d pairs), SIFT(2000,3,0.01,20) + exact BF match + 3x3 grid select + Ransac2D + MosaicImagesRefined warp"
@@ -485,10 +485,16 @@ def main():
                                                "frac": value / max(world, 1) * b / 1e9 / HBM_PEAK_GBS,
                                                "note": "the same formula with the pyramid the reference really builds: 3 P BGR read + (4/3) P x 6 levels x 2 B x (1 write + 1 read) = 35 P per frame, + 6 P warp, + 1.04 MB per pair"})(
                                        (n_frames_total * 41.0 * w * h + survey_pairs * 1.04e6) / max(survey_pairs, 1)),
-            # north_star: MFMA utilisation of the only matrix kernel (exact all-pairs descriptor distances, bf16 32x32x16 MFMA)
-            "mfma": {"kernel": "bf_match_kernel", "flop_per_pair": 2.0 * 2000 * 2000 * 128, "achieved": (n_pairs * args.steps * 2.0 * 2000 * 2000 * 128 / 1e12) / (m_ms / 1e3) if m_ms > 0 else None,
-                     "peak": 2500.0, "unit": "TFLOP/s", "frac": ((n_pairs * args.steps * 2.0 * 2000 * 2000 * 128 / 1e12) / (m_ms / 1e3) / 2500.0) if m_ms > 0 else None,
-                     "ms_per_step": m_ms / max(args.steps, 1), "note": "dense bf16 peak; 0.3 % of the step time"},
+            # north_star: MFMA utilisation of the only matrix kernel (exact all-pairs descriptor distances, v_mfma_i32_32x32x32_i8).
+            # peak: MI355X_MICROARCH.md lists I8 at ~2x the bf16 rate (>= 3944 TOP/s measured there, 2 x 2500 nominal); on descriptor-like
+            # operands scratch/mfma_bench.hip sustains 3.9 POP/s (4.9 on zeros: the pipe clocks lower on toggling data)
+            "mfma": (lambda ops: {"kernel": "bf_match_kernel", "dtype": "i8 x i8 -> i32 (exact)", "op_per_pair": 2.0 * 2000 * 2000 * 128,
+                                  "achieved": ops / (m_ms / 1e3) if m_ms > 0 else None, "peak": 5000.0, "unit": "TOP/s",
+                                  "frac": (ops / (m_ms / 1e3) / 5000.0) if m_ms > 0 else None,
+                                  "sustained_on_descriptor_operands": 3900.0, "frac_of_sustained": (ops / (m_ms / 1e3) / 3900.0) if m_ms > 0 else None,
+                                  "ms_per_step": m_ms / max(args.steps, 1),
+                                  "note": "nominal dense int8 rate (2 x the 2.5 PFLOP/s bf16 figure); round 2 ran this product in bf16 at 0.33 of 2500"})(
+                         n_pairs * args.steps * 2.0 * 2000 * 2000 * 128 / 1e12),
             "phase_ms": state.get("phase_ms"),
             "blend": blend,
             "quality": {"pairs_accepted": accepted, "pairs": survey_pairs if strong else n_pairs, "images_aligned": state["n_valid"],

@@ -68,8 +68,13 @@ __device__ __forceinline__ int med3_i32(int a, int b, int c) { int r; asm("v_med
 //     instructions per element, a multiset top-2 of z, whose order statistics map onto those of x2);
 //   * three LDS stages: the first half of the NEXT tile's operands and its row constants are read before the barrier, so the
 //     MFMAs of the next iteration start straight after it; the loop body has no branches.
+// This kernel, same job: 2.50 ms = 2.1 POP/s (0.55 of the 3.9 the pipe sustains on these operands).  Its parts: MFMAs + LDS reads
+// alone 1.72 ms, + staging and barrier 1.89, + epilogue 2.64, epilogues issued under the other query block's MFMAs 2.50.  What is
+// left is VALU issue: scratch/valu_bench.hip puts v_lshl_add_u32, v_max3_i32 / _f32, v_med3, v_cmp and v_cvt at 4.3 cycles per
+// wave64 instruction (half rate; only fma / add / or / mul run at 2.5), so the 58 epilogue instructions of a wave's tile take as
+// long (250 cycles) as its eight MFMAs (256), and the four waves of a SIMD share both pipes.
 template <bool SECOND>
-__global__ __launch_bounds__(BF_NT) void bf_match_kernel(const PairDesc* pairs, int nqt, int* nn_idx, int* nn_d2, int* nn_2nd) {
+__global__ __launch_bounds__(BF_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void bf_match_kernel(const PairDesc* pairs, int nqt, int* nn_idx, int* nn_d2, int* nn_2nd) {
     constexpr int NOROW = -(1 << 30);
     __shared__ __attribute__((aligned(16))) int s_k[KSTRIDE + 32];   // k of the train rows, NOROW for the padding rows
     constexpr int APITCH = 128 + 16;                      // bytes per staged row: 36 dwords keep the 16 lanes of a b128 group on distinct banks
@@ -107,8 +112,8 @@ __global__ __launch_bounds__(BF_NT) void bf_match_kernel(const PairDesc* pairs, 
     __syncthreads();
     const int a_off = col * APITCH + hi * 16;
     i32x4 fa[4];
-    i32x16 kk;
-    auto read_lo = [&](int buf, int t0) {                 // operands ks 0..1 of the tile in `buf` and its row constants
+    i32x16 kA, kB;                                        // row constants of the even / odd tiles
+    auto read_lo = [&](int buf, int t0, i32x16& kk) {     // operands ks 0..1 of the tile in `buf` and its row constants
 #pragma unroll
         for (int ks = 0; ks < 2; ks++) fa[ks] = *reinterpret_cast<const i32x4*>(&s_a[buf * STAGE + a_off + ks * 32]);
 #pragma unroll
@@ -117,54 +122,60 @@ __global__ __launch_bounds__(BF_NT) void bf_match_kernel(const PairDesc* pairs, 
             kk[4 * g] = c.x; kk[4 * g + 1] = c.y; kk[4 * g + 2] = c.z; kk[4 * g + 3] = c.w;
         }
     };
-    read_lo(0, 0);
     constexpr int IMIN = (int)0x80000000;
     int bz[2] = {IMIN, IMIN}, bthr[2] = {IMIN | 15, IMIN | 15}, bt[2] = {0, 0};
     int b2[2] = {IMIN, IMIN}, s2[2] = {IMIN, IMIN};       // SECOND: multiset top-2 of z
-    int cur = 0, tile = 0;
-    for (int t0 = 0; t0 < npad; t0 += 32, tile++) {
+    i32x16 acc[2];
+    // epilogue of one 32 x 32 block: z = 32 S + k, the tile's maximum with its slot, the running best
+    auto epilogue = [&](int c, const i32x16& kk, int tile) {
+        int z[16];
+#pragma unroll
+        for (int e = 0; e < 16; e++) z[e] = (acc[c][e] << 5) + kk[e];
+        if (SECOND) {
+#pragma unroll
+            for (int e = 0; e < 16; e++) { s2[c] = med3_i32(b2[c], z[e], s2[c]); b2[c] = max(b2[c], z[e]); }
+        }
+        int m4[4];
+#pragma unroll
+        for (int g = 0; g < 4; g++) m4[g] = max(max(max(z[4 * g], z[4 * g + 1]), z[4 * g + 2]), z[4 * g + 3]);
+        const int tm = max(max(max(m4[0], m4[1]), m4[2]), m4[3]);
+        const bool win = tm > bthr[c];                    // strictly nearer than the best so far (the position bits masked out)
+        bz[c] = win ? tm : bz[c];
+        bt[c] = win ? tile : bt[c];
+        bthr[c] = bz[c] | 15;
+    };
+    auto chain = [&](int c) {
+        acc[c] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[0], bq[c][0], i32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, 0, 0, 0);
+#pragma unroll
+        for (int ks = 1; ks < 4; ks++) acc[c] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[ks], bq[c][ks], acc[c], 0, 0, 0);
+    };
+    // Within a wave the matrix pipe and the VALU work side by side: the epilogue of query block 1 of the PREVIOUS tile is issued among the
+    // MFMAs of block 0, the epilogue of block 0 among the MFMAs of block 1 (each needs only the other block's accumulator to be busy).
+    int cur = 0;
+    auto iteration = [&](int t0, int tile, i32x16& kcur, i32x16& kother) {   // kother: constants of tile - 1 on entry, of tile + 1 on exit
         const int nxt = cur == 2 ? 0 : cur + 1, nx2 = nxt == 2 ? 0 : nxt + 1;
         const u32x2 pf_stage = pf;                        // tile t + 2, fetched one iteration ago
         fetch(t0 + 96 < npad ? t0 + 96 : 0);              // past the end the loop fetches / stages / reads tiles nobody uses
 #pragma unroll
         for (int ks = 2; ks < 4; ks++) fa[ks] = *reinterpret_cast<const i32x4*>(&s_a[cur * STAGE + a_off + ks * 32]);
-        i32x16 acc[2];
-#pragma unroll
-        for (int c = 0; c < 2; c++) {
-            acc[c] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[0], bq[c][0], i32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, 0, 0, 0);
-        }
-#pragma unroll
-        for (int ks = 1; ks < 4; ks++) {
-#pragma unroll
-            for (int c = 0; c < 2; c++) acc[c] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[ks], bq[c][ks], acc[c], 0, 0, 0);
-        }
-        int tm[2];
-#pragma unroll
-        for (int c = 0; c < 2; c++) {
-            int z[16];
-#pragma unroll
-            for (int e = 0; e < 16; e++) z[e] = (acc[c][e] << 5) + kk[e];
-            if (SECOND) {
-#pragma unroll
-                for (int e = 0; e < 16; e++) { s2[c] = med3_i32(b2[c], z[e], s2[c]); b2[c] = max(b2[c], z[e]); }
-            }
-            int m4[4];
-#pragma unroll
-            for (int g = 0; g < 4; g++) m4[g] = max(max(max(z[4 * g], z[4 * g + 1]), z[4 * g + 2]), z[4 * g + 3]);
-            tm[c] = max(max(max(m4[0], m4[1]), m4[2]), m4[3]);
-        }
-        read_lo(nxt, t0 + 32);                            // issued before the barrier: the next iteration starts with its MFMAs
-#pragma unroll
-        for (int c = 0; c < 2; c++) {
-            const bool win = tm[c] > bthr[c];             // strictly nearer than the best so far (the position bits masked out)
-            bz[c] = win ? tm[c] : bz[c];
-            bt[c] = win ? tile : bt[c];
-            bthr[c] = bz[c] | 15;
-        }
+        chain(0);
+        epilogue(1, kother, tile - 1);
+        chain(1);
+        read_lo(nxt, t0 + 32, kother);                    // issued before the barrier: the next iteration starts with its MFMAs
+        epilogue(0, kcur, tile);
         stage(nx2, pf_stage);
         __syncthreads();
         cur = nxt;
+    };
+    read_lo(0, 0, kA);
+#pragma unroll
+    for (int e = 0; e < 16; e++) { acc[1][e] = 0; kB[e] = NOROW; }     // the "previous tile" of the first iteration: nothing
+    int tile = 0;
+    for (int t0 = 0; t0 < npad; t0 += 64, tile += 2) {    // npad is a multiple of 256
+        iteration(t0, tile, kA, kB);
+        iteration(t0 + 32, tile + 1, kB, kA);
     }
+    epilogue(1, kB, tile - 1);
 #pragma unroll
     for (int c = 0; c < 2; c++) {
         int best = 0x7fffffff, second = 0x7fffffff, bi = -1;

@@ -213,15 +213,20 @@ def test_select_match_pairs_golden(ctx):
 
 # ---------------------------------------------------------------------------------------------- matching
 def test_bf_match_exact(ctx, oracle):
-    """bf16 MFMA distances are exact integers: indices, 1-NN and 2-NN squared distances equal the CPU
+    """int8 MFMA distances (int32 accumulation) are exact integers: indices, 1-NN and 2-NN squared distances equal the CPU
     integer brute force bit for bit, including ties (duplicated descriptors) and ragged sizes."""
     rng = np.random.default_rng(5)
     from imagemosaicing_amd import KEYPOINT
-    for (n1, n2) in [(2000, 2000), (1999, 1531), (130, 70), (1, 5), (64, 64)]:
+    for (n1, n2) in [(2000, 2000), (1999, 1531), (130, 70), (1, 5), (64, 64), (2048, 2048), (513, 33)]:
         d1, d2 = _rand_desc(rng, n1), _rand_desc(rng, n2)
         if n2 > 40:
             d2[37] = d2[3]              # exact tie -> lowest train index must win
             d1[0] = d2[3]
+        if n2 > 1200 and n1 > 8:
+            d2[1000] = d2[3]            # the same row again, 31 tiles later: still the lowest index
+            d2[5] = d2[4]; d1[1] = d2[4]                    # a tie inside one group of four rows
+            d2[10] = 255; d2[11] = 0; d1[2] = 255; d1[3] = 0; d1[4] = 0; d1[4, ::2] = 255     # the ends of the int8 range, the largest norms and products
+            d2[1999 if n2 > 1999 else n2 - 1] = d2[40]; d1[5] = d2[40]                        # a tie between the two half-waves' rows
         kp1 = np.zeros(n1, KEYPOINT); kp2 = np.zeros(n2, KEYPOINT)
         kp1["x"] = rng.uniform(5, 995, n1); kp1["y"] = rng.uniform(5, 745, n1)
         kp2["x"] = rng.uniform(5, 995, n2); kp2["y"] = rng.uniform(5, 745, n2)
