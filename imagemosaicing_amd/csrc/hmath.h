@@ -450,6 +450,9 @@ HD void invjt_sparse(const float* inv, const float* A, float* M) {
 
 // 4-point SolveHomographyMatrix + (when 0.01 < H[8] < 5) NonlinearLeastSquareProjection2, everything in registers.
 // Returns false when an inversion needs the generic routine (caller falls back to solve_h4 / nlls4).
+// POLISH = false stops after the 4-point solve: H[8] is its residual and *polished tells whether the polish WOULD run (the draw
+// classification pass of csrc/ransac.hip; the arithmetic up to that point is the same instruction for instruction).
+template <bool POLISH = true>
 HD bool hypothesis4_fast(const float* p, float* H, int* polished = nullptr) {
     float A[64], M[64], inv[64], B[8];
 #pragma unroll
@@ -487,6 +490,7 @@ HD bool hypothesis4_fast(const float* p, float* H, int* polished = nullptr) {
     H[8] = (float)emax;
     if (!(H[8] < 5.0f && H[8] > 0.01f)) return true;             // no polish (mosaicimage.h:1864-1876)
     if (polished) *polished = 1;
+    if constexpr (!POLISH) return true;
     // ---- Gauss-Newton polish, LeastSquare.h:353-531 (J is A's storage) ----
     float w[8], C[8];
 #pragma unroll

@@ -36,6 +36,7 @@ struct RansacArgs {
     int stride;
     float dist;
     int sample_times;
+    int list_floats;               // floats of dynamic LDS in front of the point arrays: the list of accepted draws (uint16 x min(sample_times, 4999))
     int min_keep;                  // pairs with at most this many inliers skip the closing refinement (-1: never): the caller rejects them anyway
     mi355_pair_result* out;        // [pair]
     // BIG variant (one pair with 400 < n <= 4096, mi355_ransac2d only): work arrays of the closing Gauss-Newton and the inlier lists in HBM
@@ -95,7 +96,8 @@ __device__ __forceinline__ void ransac_body(const RansacArgs& a) {
         if (tid == 0) { out->n_in = 0; out->ok = 0; }
         return;
     }
-    float* x1 = lds;            // targets (image i)
+    uint16_t* list = reinterpret_cast<uint16_t*>(lds);   // draws that hold a hypothesis slot, in draw order
+    float* x1 = lds + a.list_floats;                     // targets (image i)
     float* y1 = x1 + n;
     float* x2 = y1 + n;         // sources (image j)
     float* y2 = x2 + n;
@@ -115,11 +117,49 @@ __device__ __forceinline__ void ransac_body(const RansacArgs& a) {
 
     float h[9];
     long long T0 = wall_clock64(); int nchunk = 0; long long Tsolve = 0, Tsup = 0, Trep = 0;
+    // ---- pass 1: which draws hold a hypothesis slot ------------------------------------------------------------------------
+    // A draw whose 4-point solve leaves a residual above 5 px is skipped without consuming a slot (:1864-1867): on unrelated image
+    // pairs that is 42 % of the draws, and 6.8 chunks of 256 draws were walked for the 1000 slots with those lanes idle through
+    // the 15 Gauss-Newton iterations of their neighbours' polish (80 % of the kernel's time).  The solve alone is 1 / 60 of a
+    // polished draw: run it for every draw first, keep the accepted ones in draw order, then evaluate them densely packed.
+    int nlist = 0;
+    const int list_cap = sample_times < MAX_DRAWS ? sample_times : MAX_DRAWS;
+    for (int base = 0; base < MAX_DRAWS && nlist < list_cap; base += RB) {
+        const int r = base + tid;
+        bool accepted = false;
+        if (r < MAX_DRAWS) {
+            float p[16];
+            const uint16_t* s = table + 4 * r;
+#pragma unroll
+            for (int i = 0; i < 4; i++) { const int k = s[i]; p[4 * i] = x1[k]; p[4 * i + 1] = y1[k]; p[4 * i + 2] = x2[k]; p[4 * i + 3] = y2[k]; }
+            int pol = 0;
+            const bool fast_ok = hm::hypothesis4_fast<false>(p, h, &pol);
+            bool skip = !pol && h[8] > 5.0f;
+            for (unsigned long long need = __ballot(!fast_ok); need; need &= need - 1ull) {
+                if ((tid & 63) == __builtin_ctzll(need)) {
+                    float pin[16], hout[9];
+#pragma unroll
+                    for (int i = 0; i < 16; i++) pin[i] = p[i];
+                    skip = generic_hypothesis(pin, hout, s_fbk[tid >> 6]);
+                }
+            }
+            accepted = !skip;
+        }
+        int tot;
+        const int pos = nlist + block_exclusive_scan_flags(accepted, tid, s_wtot, tot);
+        if (accepted && pos < list_cap) list[pos] = (uint16_t)r;
+        nlist += tot;
+    }
+    nlist = nlist < list_cap ? nlist : list_cap;
+    __syncthreads();
+    long long Tclass = wall_clock64() - T0;
+    // ---- pass 2: hypotheses + supports of the accepted draws, 256 at a time; the sequential loop replayed over each chunk ----
     for (int base = 0; ; base += RB) {
         nchunk++; long long c0 = wall_clock64();
-        const int r = base + tid;
-        int flag = 2, support = 0;                         // 2 = no such draw (stream of 4999 draws exhausted)
-        if (r < MAX_DRAWS) {
+        const int li = base + tid;
+        int flag = 2, support = 0;                         // 2 = no such draw (stream of 4999 draws exhausted before sample_times slots were filled)
+        if (li < nlist) {
+            const int r = list[li];
             float p[16];
             const uint16_t* s = table + 4 * r;
 #pragma unroll
@@ -129,9 +169,6 @@ __device__ __forceinline__ void ransac_body(const RansacArgs& a) {
             int pol = 0;
             const bool fast_ok = hm::hypothesis4_fast(p, h, &pol);
             if (a.dbg && pol) atomicAdd(&s_npol, 1);
-            // :1864-1867 the skip test looks at the 4-point solve's residual; a polished hypothesis is never skipped, whatever the
-            // residual after the polish (a polish that diverges past 5 px still consumes its slot)
-            bool skip = !pol && h[8] > 5.0f;
             // one lane of the wave at a time, its work arrays in the wave's LDS slot: a private array for these index-driven
             // routines costs the whole kernel registers and scratch set-up (measured 5.3 us per pair against 4.9 this way)
             for (unsigned long long need = __ballot(!fast_ok); need; need &= need - 1ull) {
@@ -140,26 +177,24 @@ __device__ __forceinline__ void ransac_body(const RansacArgs& a) {
                     float pin[16], hout[9];
 #pragma unroll
                     for (int i = 0; i < 16; i++) pin[i] = p[i];
-                    skip = generic_hypothesis(pin, hout, s_fbk[tid >> 6]);
+                    (void)generic_hypothesis(pin, hout, s_fbk[tid >> 6]);
 #pragma unroll
                     for (int i = 0; i < 9; i++) h[i] = hout[i];
                 }
             }
             long long c1 = wall_clock64(); Tsolve += c1 - c0;
-            if (skip) flag = 0;                            // :1864-1867 skipped, no slot consumed
-            else {
-                flag = 1;
-                for (int i = 0; i < n; i++) {              // :1890-1904
-                    float bx, by;
-                    hm::apply_recip1(h, x2[i], y2[i], bx, by);
-                    const float dx = bx - x1[i], dy = by - y1[i];
-                    const float dd = dx * dx + dy * dy;
-                    if (dd < d2) support++;
-                }
+            flag = 1;                                      // a polished hypothesis is never skipped, whatever its residual after the polish (:1868-1876)
+            for (int i = 0; i < n; i++) {                  // :1890-1904
+                float bx, by;
+                hm::apply_recip1(h, x2[i], y2[i], bx, by);
+                const float dx = bx - x1[i], dy = by - y1[i];
+                const float dd = dx * dx + dy * dy;
+                if (dd < d2) support++;
             }
         }
         // ---- replay of the sequential loop over this chunk (mosaicimage.h:1864-1918), in parallel ----
-        // In draw order: a draw with flag 2 ends the loop before it is looked at; flag 0 is skipped; an accepted draw (flag 1)
+        // In draw order (the chunk holds accepted draws only; the skipped ones were left out by pass 1): a draw with flag 2 ends the
+        // loop before it is looked at; an accepted draw (flag 1)
         // becomes the first hypothesis if there was none, replaces the best one when its support is strictly larger (and ends
         // the loop at once when that support exceeds 0.99 n, before the counter moves), then counts; the loop ends when the
         // counter reaches sample_times.  So the chunk is cut at E = min(first flag 2 - 1, first accepted draw with support > mx
@@ -208,7 +243,7 @@ __device__ __forceinline__ void ransac_body(const RansacArgs& a) {
         __syncthreads();                                   // everyone has read s_state / the masks
         if (tid == 0) {
             s_state[0] = t0 + nacc - ((kr < RB && kr == E) ? 1 : 0);     // the draw that ends the loop by its ratio is not counted
-            if (new_best) { s_state[1] = bsup; s_state[2] = base + bidx; }
+            if (new_best) { s_state[1] = bsup; s_state[2] = base + bidx; }       // position in the accepted list: only its sign is used
             if (new_first) s_state[3] = base + kfirst;
             s_state[4] = fin;
         }
@@ -248,6 +283,7 @@ __device__ __forceinline__ void ransac_body(const RansacArgs& a) {
     }
     if (cnt <= a.min_keep) {                                // match_pairs: MosaicWithoutPos.cpp:5201 drops the pair (n_in <= 30), its H is never looked at
         if (tid == 0) { out->n_in = cnt; out->ok = 0; }
+        if (a.dbg && tid == 0) { long long* d = a.dbg + 8 * pair; d[0] = T1 - T0; d[3] = nchunk; d[4] = Tsolve; d[5] = Tsup; d[6] = Tclass; d[7] = s_npol; }
         return;
     }
     // inlier coordinates, compacted in place into the head of the LDS arrays: read (<= 2 per lane since
@@ -320,7 +356,7 @@ __device__ __forceinline__ void ransac_body(const RansacArgs& a) {
         __syncthreads();
         if (s_state[7]) break;
     }
-    if (a.dbg && tid == 0) { long long* d = a.dbg + 8 * pair; d[0] = T1 - T0; d[1] = T2 - T1; d[2] = wall_clock64() - T2; d[3] = nchunk; d[4] = Tsolve; d[5] = Tsup; d[6] = Trep; d[7] = s_npol; }
+    if (a.dbg && tid == 0) { long long* d = a.dbg + 8 * pair; d[0] = T1 - T0; d[1] = T2 - T1; d[2] = wall_clock64() - T2; d[3] = nchunk; d[4] = Tsolve; d[5] = Tsup; d[6] = Tclass; d[7] = s_npol; }
     // motion[8] = max residual in float (LeastSquare.h:503-519): max is order independent
     float emax = 0.0f;
     for (int i = tid; i < cnt; i += RB) {
@@ -448,7 +484,8 @@ int mi_ransac_big(mi355_ctx* ctx, const mi355_sfpoint* p1, const mi355_sfpoint* 
     a.stride = n; a.dist = dist; a.sample_times = sample_times; a.min_keep = -1; a.out = dres.as<mi355_pair_result>();
     a.big_ws = dws.as<float>(); a.big_a = da.as<mi355_sfpoint>(); a.big_b = db.as<mi355_sfpoint>();
     a.tables -= (size_t)(n - 4) * one;                    // the kernel indexes tables by n - 4 when there is no per-pair index
-    const size_t lds_bytes = (size_t)4 * n * sizeof(float);
+    a.list_floats = ((((sample_times < MAX_DRAWS ? (sample_times > 0 ? sample_times : 1) : MAX_DRAWS) * 2 + 15) / 16) * 16) / 4;
+    const size_t lds_bytes = ((size_t)4 * n + a.list_floats) * sizeof(float);
     MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ransac_big_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     hipLaunchKernelGGL(ransac_big_kernel, dim3(1), dim3(RB), lds_bytes, ctx->stream, a);
     MI_HIP(hipGetLastError());
@@ -537,7 +574,8 @@ int mi_ransac_batch(mi355_ctx* ctx, const mi355_sfpoint* d_p1, const mi355_sfpoi
     DevBuf& ddbg = ctx->buf("ransac_dbg");
     if (dbg_on) { MI_HIP(ddbg.reserve((size_t)n_pairs * 64)); MI_HIP(hipMemsetAsync(ddbg.p, 0, (size_t)n_pairs * 64, ctx->stream)); a.dbg = ddbg.as<long long>(); }
     a.stride = stride; a.dist = dist; a.sample_times = sample_times; a.out = d_out;
-    const size_t lds_bytes = (size_t)38 * nmax * sizeof(float);
+    a.list_floats = ((((sample_times < MAX_DRAWS ? (sample_times > 0 ? sample_times : 1) : MAX_DRAWS) * 2 + 15) / 16) * 16) / 4;
+    const size_t lds_bytes = ((size_t)38 * nmax + a.list_floats) * sizeof(float);
     if (lds_bytes > 48 * 1024) {
         MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ransac_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     }
@@ -555,7 +593,7 @@ int mi_ransac_batch(mi355_ctx* ctx, const mi355_sfpoint* d_p1, const mi355_sfpoi
         MI_HIP(hipStreamSynchronize(ctx->stream));
         double acc[8] = {0};
         for (int i = 0; i < n_pairs; i++) for (int k = 0; k < 8; k++) acc[k] += (double)hd[(size_t)i * 8 + k];
-        fprintf(stderr, "[ransac dbg, avg per pair, 100 MHz ticks] loop %.0f split %.0f nlls %.0f | chunks %.1f solve %.0f solve+support %.0f replay %.0f | polished draws %.1f\n", acc[0] / n_pairs, acc[1] / n_pairs, acc[2] / n_pairs, acc[3] / n_pairs, acc[4] / n_pairs, acc[5] / n_pairs, acc[6] / n_pairs, acc[7] / n_pairs);
+        fprintf(stderr, "[ransac dbg, avg per pair, 100 MHz ticks] loop %.0f split %.0f nlls %.0f | chunks %.1f solve %.0f solve+support %.0f classify %.0f | polished draws %.1f\n", acc[0] / n_pairs, acc[1] / n_pairs, acc[2] / n_pairs, acc[3] / n_pairs, acc[4] / n_pairs, acc[5] / n_pairs, acc[6] / n_pairs, acc[7] / n_pairs);
     }
     return MI355_OK;
 }
