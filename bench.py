@@ -321,6 +321,11 @@ def main():
         step(1 + i)
     ctx.profile_enable(not os.environ.get("MI355_BENCH_NOPROF"))
     ctx.profile_only(None if args.profile_all else DOM + ",match")
+    # the dominant class is launched 16 times per batch of frames (one launch per pyramid level of the wide octaves): bracket every 5th
+    # launch (5 and 16 are coprime: every level is sampled equally often) -- two event records around each of ~500 launches per step
+    # cost up to 15 % of the step on some boxes
+    PROF_EVERY = 1 if args.profile_all else 5
+    ctx.set_option("profile_every:" + DOM, PROF_EVERY)
     ctx.profile_reset()
     barrier()
     t0 = time.perf_counter()
@@ -334,6 +339,7 @@ def main():
         dt = float(t.item())
     g_ms, g_n, g_bytes = ctx.profile_get(DOM)
     m_ms, m_n, _ = ctx.profile_get("match")
+    ctx.set_option("profile_every:" + DOM, 1)
     if world == 1:                       # one extra UNTIMED step with a synchronisation after every phase: where a step's time goes
         ctx.profile_enable(False)
         phases = True
@@ -463,9 +469,10 @@ def main():
                                          "batches never overlap: durations are exclusive, see exclusive_pass)") if excl else "HIP events in the timed region (launches overlap other batches' kernels)",
                          "exclusive_pass": excl,
                          "in_situ": {"achieved": in_situ, "frac": in_situ / HBM_PEAK_GBS, "launches": int(g_n), "avg_launch_us": (g_ms * 1e3 / g_n) if g_n else None,
-                                     "note": "the same launches bracketed inside the timed region, three batches in flight: durations include other batches' kernels (sum > step time); rocprofv3 --kernel-trace of this command reports this average"},
+                                     "sampled": "every %d-th launch of the class" % PROF_EVERY,
+                                     "note": "launches bracketed inside the timed region, three batches in flight: durations include other batches' kernels (sum > step time); rocprofv3 --kernel-trace of this command reports this average"},
                          "algorithmic_bytes_per_launch": (g_bytes / g_n) if g_n else None,
-                         "algorithmic_bytes_per_frame": g_bytes / max(args.steps * len(own), 1),
+                         "algorithmic_bytes_per_frame": g_bytes * PROF_EVERY / max(args.steps * len(own), 1),
                          "frames_per_batch": BATCH, "batches_in_flight": SLOTS, "standalone": iso},
             # the other chip-filling kernels: exclusive durations of the same serial_heavy pass / the single warp launch of the last step
             "roofline_by_kernel": {

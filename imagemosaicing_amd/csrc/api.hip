@@ -371,6 +371,7 @@ extern "C" int mi355_set_option(mi355_ctx* ctx, const char* name, int value) {
         ctx->serial_heavy = value ? 1 : 0; ctx->heavy_ev_valid = false;
         return MI355_OK;
     }
+    if (std::string(name).rfind("profile_every:", 0) == 0) { ctx->prof[std::string(name).substr(14)].every = value < 1 ? 1 : value; return MI355_OK; }
     if (std::string(name) == "xstream_min_w") { ctx->xstream_min_w = value < 256 ? 256 : value; return MI355_OK; }
     if (std::string(name) == "xstream_min_frames") { ctx->xstream_min_frames = value < 1 ? 1 : value; return MI355_OK; }
     ctx->set_error(std::string("set_option: unknown option ") + name);
@@ -385,7 +386,7 @@ extern "C" int mi355_profile_reset(mi355_ctx* ctx) {
     LOCKED_PROLOGUE
     (void)mi_resolve_features(ctx);
     MI_HIP(hipStreamSynchronize(ctx->stream));
-    for (auto& kv : ctx->prof) { kv.second.used = 0; kv.second.bytes = 0.0; }
+    for (auto& kv : ctx->prof) { kv.second.used = 0; kv.second.bytes = 0.0; kv.second.seen = 0; }
     return MI355_OK;
 }
 extern "C" int mi355_profile_get(mi355_ctx* ctx, const char* kernel_class, double* total_ms, int64_t* launches, double* alg_bytes) {

@@ -69,6 +69,8 @@ struct ProfClass {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
     size_t used = 0;
     double bytes = 0.0;
+    size_t seen = 0;     // launches of the class since the last reset (bracketed or not)
+    int every = 1;       // bracket every n-th launch only (set_option "profile_every:<class>")
 };
 
 struct SiftWork;   // sift.hip
@@ -123,6 +125,7 @@ struct ProfScope {
     bool on;
     ProfScope(mi355_ctx* c_, const char* cls_, double bytes, hipStream_t st_ = nullptr) : c(c_), cls(cls_), st(st_ ? st_ : c_->stream) {
         on = c->profiling && (c->prof_only.empty() || ("," + c->prof_only + ",").find(std::string(",") + cls + ",") != std::string::npos);
+        if (on) { ProfClass& pc = c->prof[cls]; if (pc.every > 1) on = (pc.seen++ % (size_t)pc.every) == 0; }
         if (on) c->prof_begin(cls, bytes, st);
     }
     ~ProfScope() { if (on) c->prof_end(cls, st); }

@@ -105,7 +105,8 @@ int  mi355_synchronize(mi355_ctx* ctx);
  * default 3): how octaves of at least 2000 x 1500 compute their Gaussian levels -- 0: every level with its own launch; 3: the
  * first three levels in one pass, handed from wave to wave through LDS and written to HBM once, the other levels on their own
  * (+4 % end to end); 2: the other three in a second such pass; 1: all six in one pass.  The same bits in every mode (2 and 1 are
- * VALU-issue-bound and no faster end to end on MI355X). */
+ * VALU-issue-bound and no faster end to end on MI355X); "profile_every:<class>" = n (measurement only, default 1): with
+ * mi355_profile_enable only every n-th launch of that kernel class is bracketed by events (the average duration is then a sample). */
 int  mi355_set_option(mi355_ctx* ctx, const char* name, int value);
 void mi355_free(void* p);                               /* frees host buffers returned by this library */
 
