@@ -284,14 +284,19 @@ def main():
             r = local_accepted()
         if phases:
             t2 = time.perf_counter()
-        mp = im.results_to_match_pairs(r)
-        label = im.select_connected(mp, F) if len(mp) else np.zeros(F, np.int32)
+        # Select_Connected_Matched_Images + the global alignment straight from the pair records (the m_vecMatchPairs copy of the adaptor
+        # path is 28 M correspondences = 1.1 GB at C5; same sums in the same order, tests/test_cabi.py)
+        label = im.select_connected_results(r, F) if len(r) else np.zeros(F, np.int32)
         label[0] = 1
-        keep = (label[mp["ai"]] > 0) & (label[mp["bi"]] > 0) if len(mp) else np.zeros(0, bool)
-        T = im.global_affine_align(mp[keep], F, fixed=[1 if (k == 0 or label[k] == 0) else 0 for k in range(F)])
+        ta = time.perf_counter()
+        T = im.global_affine_align_results(r, F, fixed=[1 if (k == 0 or label[k] == 0) else 0 for k in range(F)], label=label)
+        td = time.perf_counter()
         h9 = T["m"].copy()
         h9[label == 0, 8] = 0.0                                     # invalid images are skipped by the warp (MWP.cpp:4646-4652)
         cw, ch, cws, _ = im.mosaic_layout(wv, hv, h9)
+        if phases:
+            state["host_parts_ms"] = {"select_connected": (ta - t2) * 1e3, "global_affine_align": (td - ta) * 1e3, "layout": (time.perf_counter() - td) * 1e3,
+                                      "correspondences": int(r["n_in"].astype(np.int64).sum())}
         if cws * ch > canvas_cap:
             raise RuntimeError("canvas larger than provisioned (%d x %d)" % (cw, ch))
         if phases:
@@ -502,7 +507,7 @@ def main():
                                   "ms_per_step": m_ms / max(args.steps, 1),
                                   "note": "nominal dense int8 rate (2 x the 2.5 PFLOP/s bf16 figure); round 2 ran this product in bf16 at 0.33 of 2500"})(
                          n_pairs * args.steps * 2.0 * 2000 * 2000 * 128 / 1e12),
-            "phase_ms": state.get("phase_ms"),
+            "phase_ms": state.get("phase_ms"), "host_parts_ms": state.get("host_parts_ms"),
             "blend": blend,
             "quality": {"pairs_accepted": accepted, "pairs": survey_pairs if strong else n_pairs, "images_aligned": state["n_valid"],
                         "h_corner_err_px_median": float(np.median(errs)) if errs else None,

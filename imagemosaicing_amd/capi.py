@@ -588,6 +588,28 @@ def global_affine_align(match_pairs, n_images, fixed=None):
     return out
 
 
+def select_connected_results(results, n_images):
+    """Select_Connected_Matched_Images straight from PAIR_RESULT records (accepted pairs with inliers are the edges)"""
+    r = np.ascontiguousarray(results, PAIR_RESULT)
+    label = np.zeros(n_images, np.int32)
+    rc = load_library().mi355_select_connected_results(_p(r), len(r), int(n_images), _p(label))
+    if rc != 0:
+        raise Mi355Error(rc, "select_connected_results")
+    return label
+
+
+def global_affine_align_results(results, n_images, fixed=None, label=None):
+    """global_affine_align straight from PAIR_RESULT records; label: use only the pairs whose two images are labelled"""
+    r = np.ascontiguousarray(results, PAIR_RESULT)
+    ff = None if fixed is None else np.ascontiguousarray(fixed, np.int32)
+    lb = None if label is None else np.ascontiguousarray(label, np.int32)
+    out = np.zeros(n_images, IMAGE_TRANSFORM)
+    rc = load_library().mi355_global_affine_align_results(_p(r), len(r), int(n_images), _p(ff), _p(lb), _p(out))
+    if rc != 0:
+        raise Mi355Error(rc, "global_affine_align_results")
+    return out
+
+
 def select_connected(match_pairs, n_images):
     v = np.ascontiguousarray(match_pairs, MATCHPAIR)
     label = np.zeros(n_images, np.int32)

@@ -13,6 +13,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
+#include <atomic>
+#include <thread>
 #include <vector>
 
 static_assert(sizeof(mi355_match_point_pairs) == 40, "MatchPointPairs must be 40 bytes (matchPairs.match record)");
@@ -171,9 +173,35 @@ extern "C" int mi355_results_to_match_pairs(const mi355_pair_result* r, int n_pa
 // equations (MosaicWithoutPos.cpp:6971-7202, test_cholmod.cpp:180-262).  Here the 6(N-F) normal matrix
 // is accumulated directly in double (x- and y-rows decouple into two identical 3(N-F) systems) and
 // factorised by dense Cholesky.  Known answer: tests/golden/matchPairs.txt -> tran0.txt.
-extern "C" int mi355_global_affine_align(const mi355_match_point_pairs* v, int n, int n_images, const int32_t* fixed,
-                                         mi355_image_transform* out) {
-    if (n < 0 || n_images <= 0 || (n > 0 && !v) || !out) return MI355_ERR_ARG;
+// The work is in two places: the second moments of the correspondences (21 products per point; C5: 28 M points) and the banded
+// Cholesky factorisation (C5: 6000 rows x half bandwidth 545).  Both run on a few host threads in a way that keeps every sum's
+// order: a thread owns whole image pairs (their moments are summed per pair first, then added to the blocks in pair order by one
+// thread, as the serial code did) and whole matrix entries (one dot product, ascending k) -- the result does not depend on the
+// number of threads.
+namespace {
+int host_threads() {
+    static const int n = [] {
+        const char* e = getenv("MI355_HOST_THREADS");
+        int v = e ? atoi(e) : (int)std::thread::hardware_concurrency();
+        if (v > 16) v = 16;
+        return v < 1 ? 1 : v;
+    }();
+    return n;
+}
+template <class F> void parallel_chunks(size_t n, int threads, F&& f) {          // f(begin, end) on contiguous chunks
+    if (threads <= 1 || n < 2) { f((size_t)0, n); return; }
+    std::vector<std::thread> th;
+    const size_t per = (n + (size_t)threads - 1) / (size_t)threads;
+    for (int t = 1; t < threads; t++) { const size_t lo = per * t, hi = lo + per < n ? lo + per : n; if (lo < hi) th.emplace_back([&f, lo, hi] { f(lo, hi); }); }
+    f((size_t)0, per < n ? per : n);
+    for (auto& x : th) x.join();
+}
+struct PairGroup { int a, b; size_t first; int count; };                          // correspondences `first .. first + count` belong to images (a, b)
+struct Moments { double aa[6], ab[9], bb[6], vax[3], vay[3], vbx[3], vby[3]; };
+
+// xy(k, xa, ya, xb, yb): the k-th correspondence
+template <class XY>
+int align_core(const std::vector<PairGroup>& groups, XY&& xy, int n_images, const int32_t* fixed, mi355_image_transform* out) {
     std::vector<int> col(n_images, -1);
     int nf = 0;
     for (int k = 0; k < n_images; k++) {
@@ -192,46 +220,62 @@ extern "C" int mi355_global_affine_align(const mi355_match_point_pairs* v, int n
     // lower band is stored: entry (i, j), i - bw <= j <= i, at Nb[i * W + (j - i + bw)] (a dense D x D matrix was 18 MB to clear per
     // call at 500 images, 288 MB at 2000).
     int bwb = 0;
-    for (int p = 0; p < n; p++) {
-        const int a = v[p].ptA_i, b = v[p].ptB_i;
-        if (a < 0 || a >= n_images || b < 0 || b >= n_images) return MI355_ERR_ARG;
-        const int oa = col[a], ob = col[b];
+    size_t npoints = 0;
+    for (const PairGroup& g : groups) {
+        if (g.a < 0 || g.a >= n_images || g.b < 0 || g.b >= n_images) return MI355_ERR_ARG;
+        const int oa = col[g.a], ob = col[g.b];
         if (oa >= 0 && ob >= 0) { const int d = oa > ob ? oa - ob : ob - oa; if (d > bwb) bwb = d; }
+        npoints += (size_t)g.count;
     }
     const int bw = 3 * bwb + 2;                      // half bandwidth in scalar rows
     const size_t W = (size_t)bw + 1;
     std::vector<double> Nb((size_t)D * W, 0.0), bx(D, 0.0), by(D, 0.0);
     auto NL = [&](int i, int j) -> double& { return Nb[(size_t)i * W + (size_t)(j - i + bw)]; };     // i >= j >= i - bw
-    // rows: coefficients [xa ya 1] on image a's columns, -[xb yb 1] on image b's columns.  The records of one image pair are consecutive
-    // (mi355_results_to_match_pairs): their second moments are summed first (21 products per point), then added to the blocks once
-    for (int p = 0; p < n;) {
-        const int a = v[p].ptA_i, b = v[p].ptB_i;
-        const int oa = col[a], ob = col[b];
-        int q = p;
-        while (q < n && v[q].ptA_i == a && v[q].ptB_i == b) q++;
-        if (oa < 0 && ob < 0) { p = q; continue; }
-        double Maa[3][3] = {{0}}, Mab[3][3] = {{0}}, Mbb[3][3] = {{0}}, Vax[3] = {0}, Vay[3] = {0}, Vbx[3] = {0}, Vby[3] = {0};
-        for (int k = p; k < q; k++) {
-            const double ca[3] = {v[k].ptA.x, v[k].ptA.y, 1.0}, cb[3] = {v[k].ptB.x, v[k].ptB.y, 1.0};
-            double rx = 0.0, ry = 0.0;                 // right-hand sides after moving the fixed image's identity terms
-            if (oa < 0) { rx -= v[k].ptA.x; ry -= v[k].ptA.y; }
-            if (ob < 0) { rx += v[k].ptB.x; ry += v[k].ptB.y; }
-            for (int i = 0; i < 3; i++) {
-                for (int j = 0; j <= i; j++) { Maa[i][j] += ca[i] * ca[j]; Mbb[i][j] += cb[i] * cb[j]; }
-                for (int j = 0; j < 3; j++) Mab[i][j] += ca[i] * cb[j];
-                Vax[i] += ca[i] * rx; Vay[i] += ca[i] * ry; Vbx[i] += cb[i] * rx; Vby[i] += cb[i] * ry;
+    // rows: coefficients [xa ya 1] on image a's columns, -[xb yb 1] on image b's columns.  The second moments of one image pair are
+    // summed first (21 products per point), then added to the blocks once
+    std::vector<Moments> mom(groups.size());
+    parallel_chunks(groups.size(), npoints > 200000 ? host_threads() : 1, [&](size_t g0, size_t g1) {
+        for (size_t gi = g0; gi < g1; gi++) {
+            const PairGroup& g = groups[gi];
+            const int oa = col[g.a], ob = col[g.b];
+            Moments& m = mom[gi];
+            memset(&m, 0, sizeof(m));
+            if (oa < 0 && ob < 0) continue;
+            double Maa[3][3] = {{0}}, Mab[3][3] = {{0}}, Mbb[3][3] = {{0}}, Vax[3] = {0}, Vay[3] = {0}, Vbx[3] = {0}, Vby[3] = {0};
+            for (int k = 0; k < g.count; k++) {
+                float fxa, fya, fxb, fyb;
+                xy(g.first + (size_t)k, fxa, fya, fxb, fyb);
+                const double ca[3] = {fxa, fya, 1.0}, cb[3] = {fxb, fyb, 1.0};
+                double rx = 0.0, ry = 0.0;                 // right-hand sides after moving the fixed image's identity terms
+                if (oa < 0) { rx -= fxa; ry -= fya; }
+                if (ob < 0) { rx += fxb; ry += fyb; }
+                for (int i = 0; i < 3; i++) {
+                    for (int j = 0; j <= i; j++) { Maa[i][j] += ca[i] * ca[j]; Mbb[i][j] += cb[i] * cb[j]; }
+                    for (int j = 0; j < 3; j++) Mab[i][j] += ca[i] * cb[j];
+                    Vax[i] += ca[i] * rx; Vay[i] += ca[i] * ry; Vbx[i] += cb[i] * rx; Vby[i] += cb[i] * ry;
+                }
             }
+            int t = 0;
+            for (int i = 0; i < 3; i++) for (int j = 0; j <= i; j++, t++) { m.aa[t] = Maa[i][j]; m.bb[t] = Mbb[i][j]; }
+            for (int i = 0; i < 3; i++) { for (int j = 0; j < 3; j++) m.ab[3 * i + j] = Mab[i][j]; m.vax[i] = Vax[i]; m.vay[i] = Vay[i]; m.vbx[i] = Vbx[i]; m.vby[i] = Vby[i]; }
         }
-        if (oa >= 0) for (int i = 0; i < 3; i++) { bx[3 * oa + i] += Vax[i]; by[3 * oa + i] += Vay[i]; for (int j = 0; j <= i; j++) NL(3 * oa + i, 3 * oa + j) += Maa[i][j]; }
-        if (ob >= 0) for (int i = 0; i < 3; i++) { bx[3 * ob + i] -= Vbx[i]; by[3 * ob + i] -= Vby[i]; for (int j = 0; j <= i; j++) NL(3 * ob + i, 3 * ob + j) += Mbb[i][j]; }
+    });
+    for (size_t gi = 0; gi < groups.size(); gi++) {
+        const PairGroup& g = groups[gi];
+        const int oa = col[g.a], ob = col[g.b];
+        if (oa < 0 && ob < 0) continue;
+        const Moments& m = mom[gi];
+        int t = 0;
+        if (oa >= 0) for (int i = 0; i < 3; i++) { bx[3 * oa + i] += m.vax[i]; by[3 * oa + i] += m.vay[i]; for (int j = 0; j <= i; j++) NL(3 * oa + i, 3 * oa + j) += m.aa[t++]; }
+        t = 0;
+        if (ob >= 0) for (int i = 0; i < 3; i++) { bx[3 * ob + i] -= m.vbx[i]; by[3 * ob + i] -= m.vby[i]; for (int j = 0; j <= i; j++) NL(3 * ob + i, 3 * ob + j) += m.bb[t++]; }
         if (oa >= 0 && ob >= 0 && oa != ob) {
             for (int i = 0; i < 3; i++)
                 for (int j = 0; j < 3; j++) {
                     // N(a_i, b_j) = -Mab[i][j] = N(b_j, a_i): store the entry of the lower triangle
-                    if (oa > ob) NL(3 * oa + i, 3 * ob + j) -= Mab[i][j]; else NL(3 * ob + j, 3 * oa + i) -= Mab[i][j];
+                    if (oa > ob) NL(3 * oa + i, 3 * ob + j) -= m.ab[3 * i + j]; else NL(3 * ob + j, 3 * oa + i) -= m.ab[3 * i + j];
                 }
         }
-        p = q;
     }
     // images without any correspondence would make N singular: pin them to identity (the driver flags them
     // invalid through Select_Connected_Matched_Images before calling, MosaicWithoutPos.cpp:4503-4523)
@@ -243,29 +287,46 @@ extern "C" int mi355_global_affine_align(const mi355_match_point_pairs* v, int n
             bx[3 * o + 0] = 1.0; by[3 * o + 1] = 1.0;
         }
     }
-    // Cholesky N = L L^T (lower), in place, inside the band
-    for (int j = 0; j < D; j++) {
-        const int k0 = j - bw > 0 ? j - bw : 0;
-        double d = NL(j, j);
-        for (int k = k0; k < j; k++) d -= NL(j, k) * NL(j, k);
-        if (!(d > 0.0)) return MI355_ERR_FAILED;
-        d = std::sqrt(d);
-        NL(j, j) = d;
-        const int i1 = j + bw < D - 1 ? j + bw : D - 1;
-        for (int i = j + 1; i <= i1; i++) {
-            const int kk0 = i - bw > k0 ? i - bw : k0;
-            double s = NL(i, j);
-            const double* ri = &Nb[(size_t)i * W + (size_t)(kk0 - i + bw)];
-            const double* rj = &Nb[(size_t)j * W + (size_t)(kk0 - j + bw)];
-            for (int k = 0; k < j - kk0; k++) s -= ri[k] * rj[k];
-            NL(i, j) = s / d;
+    // Cholesky N = L L^T (lower), in place, inside the band: column by column, the entries of a column are independent dot products.
+    // A team of threads walks the columns together (one spin barrier per column); every thread computes the pivot itself.
+    const int team = ((double)D * bw * bw > 5e7) ? host_threads() : 1;
+    std::atomic<int> arrived{0}, generation{0}, failed{0};
+    auto column_worker = [&](int tid) {
+        int gen = 0;
+        for (int j = 0; j < D; j++) {
+            const int k0 = j - bw > 0 ? j - bw : 0;
+            double d = NL(j, j);
+            for (int k = k0; k < j; k++) d -= NL(j, k) * NL(j, k);
+            if (!(d > 0.0)) { failed.store(1); d = 1.0; }         // keep walking so that the team stays in step; the caller sees `failed`
+            d = std::sqrt(d);
+            const int i1 = j + bw < D - 1 ? j + bw : D - 1;
+            for (int i = j + 1 + tid; i <= i1; i += team) {
+                const int kk0 = i - bw > k0 ? i - bw : k0;
+                double s = NL(i, j);
+                const double* ri = &Nb[(size_t)i * W + (size_t)(kk0 - i + bw)];
+                const double* rj = &Nb[(size_t)j * W + (size_t)(kk0 - j + bw)];
+                for (int k = 0; k < j - kk0; k++) s -= ri[k] * rj[k];
+                NL(i, j) = s / d;
+            }
+            if (team > 1) {                                        // everyone has read row j's old diagonal and written its rows
+                gen++;
+                if (arrived.fetch_add(1) + 1 == team) { NL(j, j) = d; arrived.store(0); generation.store(gen); }
+                else while (generation.load() < gen) { }
+            } else NL(j, j) = d;
         }
-    }
+    };
+    if (team > 1) {
+        std::vector<std::thread> th;
+        for (int t = 1; t < team; t++) th.emplace_back(column_worker, t);
+        column_worker(0);
+        for (auto& x : th) x.join();
+    } else column_worker(0);
+    if (failed.load()) return MI355_ERR_FAILED;
     auto solve = [&](std::vector<double>& b) {
         for (int i = 0; i < D; i++) { const int k0 = i - bw > 0 ? i - bw : 0; double s = b[i]; for (int k = k0; k < i; k++) s -= NL(i, k) * b[k]; b[i] = s / NL(i, i); }
         for (int i = D - 1; i >= 0; i--) { const int k1 = i + bw < D - 1 ? i + bw : D - 1; double s = b[i]; for (int k = i + 1; k <= k1; k++) s -= NL(k, i) * b[k]; b[i] = s / NL(i, i); }
     };
-    solve(bx); solve(by);
+    if (team > 1) { std::thread t2([&] { solve(by); }); solve(bx); t2.join(); } else { solve(bx); solve(by); }
     for (int k = 0; k < n_images; k++) {
         const int o = col[k];
         if (o < 0) continue;
@@ -274,17 +335,51 @@ extern "C" int mi355_global_affine_align(const mi355_match_point_pairs* v, int n
     }
     return MI355_OK;
 }
+}  // namespace
+
+extern "C" int mi355_global_affine_align(const mi355_match_point_pairs* v, int n, int n_images, const int32_t* fixed,
+                                         mi355_image_transform* out) {
+    if (n < 0 || n_images <= 0 || (n > 0 && !v) || !out) return MI355_ERR_ARG;
+    std::vector<PairGroup> groups;                      // the records of one image pair are consecutive (mi355_results_to_match_pairs)
+    for (int p = 0; p < n;) {
+        int q = p;
+        while (q < n && v[q].ptA_i == v[p].ptA_i && v[q].ptB_i == v[p].ptB_i) q++;
+        groups.push_back(PairGroup{v[p].ptA_i, v[p].ptB_i, (size_t)p, q - p});
+        p = q;
+    }
+    return align_core(groups, [v](size_t k, float& xa, float& ya, float& xb, float& yb) { xa = v[k].ptA.x; ya = v[k].ptA.y; xb = v[k].ptB.x; yb = v[k].ptB.y; },
+                      n_images, fixed, out);
+}
+
+// The same system straight from the pair records (no m_vecMatchPairs copy: at C5 that vector is 28 M records = 1.1 GB): accepted pairs
+// only, and with `label` only the pairs whose two images carry a non-zero label (the driver drops the others, :4512-4523).
+extern "C" int mi355_global_affine_align_results(const mi355_pair_result* r, int n_pairs, int n_images, const int32_t* fixed,
+                                                 const int32_t* label, mi355_image_transform* out) {
+    if (n_pairs < 0 || n_images <= 0 || (n_pairs > 0 && !r) || !out) return MI355_ERR_ARG;
+    std::vector<PairGroup> groups;
+    for (int p = 0; p < n_pairs; p++) {
+        if (!r[p].accepted || r[p].n_in <= 0) continue;
+        if (r[p].i < 0 || r[p].i >= n_images || r[p].j < 0 || r[p].j >= n_images || r[p].n_in > MI355_MAX_SELECTED) return MI355_ERR_ARG;
+        if (label && !(label[r[p].i] && label[r[p].j])) continue;
+        groups.push_back(PairGroup{r[p].i, r[p].j, (size_t)p * MI355_MAX_SELECTED, r[p].n_in});
+    }
+    return align_core(groups, [r](size_t k, float& xa, float& ya, float& xb, float& yb) {
+                          const mi355_pair_result& e = r[k / MI355_MAX_SELECTED]; const size_t q = k % MI355_MAX_SELECTED;
+                          xa = e.a[q].x; ya = e.a[q].y; xb = e.b[q].x; yb = e.b[q].y; },
+                      n_images, fixed, out);
+}
 
 // Select_Connected_Matched_Images, MosaicWithoutPos.cpp:2754-2796: images are nodes, every image pair that has at
 // least one correspondence is an edge; label the largest connected group (union-find here instead of the
 // reference's O(E^2) cluster merge, same partition).
-extern "C" int mi355_select_connected(const mi355_match_point_pairs* v, int n, int n_images, int32_t* label) {
-    if (n < 0 || n_images <= 0 || (n > 0 && !v) || !label) return MI355_ERR_ARG;
+namespace {
+template <class Edge> int select_connected_core(int n, Edge&& edge, int n_images, int32_t* label) {
     std::vector<int> parent(n_images), size(n_images, 1), touched(n_images, 0);
     for (int i = 0; i < n_images; i++) parent[i] = i;
     auto find = [&](int x) { while (parent[x] != x) { parent[x] = parent[parent[x]]; x = parent[x]; } return x; };
     for (int p = 0; p < n; p++) {
-        const int a = v[p].ptA_i, b = v[p].ptB_i;
+        int a, b;
+        if (!edge(p, a, b)) continue;
         if (a < 0 || a >= n_images || b < 0 || b >= n_images) return MI355_ERR_ARG;
         touched[a] = touched[b] = 1;
         int ra = find(a), rb = find(b);
@@ -296,4 +391,16 @@ extern "C" int mi355_select_connected(const mi355_match_point_pairs* v, int n, i
     for (int i = 0; i < n_images; i++) if (touched[i] && find(i) == i && size[i] > best_size) { best = i; best_size = size[i]; }
     for (int i = 0; i < n_images; i++) label[i] = (best >= 0 && touched[i] && find(i) == best) ? 1 : 0;
     return MI355_OK;
+}
+}  // namespace
+
+extern "C" int mi355_select_connected(const mi355_match_point_pairs* v, int n, int n_images, int32_t* label) {
+    if (n < 0 || n_images <= 0 || (n > 0 && !v) || !label) return MI355_ERR_ARG;
+    return select_connected_core(n, [v](int p, int& a, int& b) { a = v[p].ptA_i; b = v[p].ptB_i; return true; }, n_images, label);
+}
+
+// the same labelling straight from the pair records: an accepted pair with at least one inlier is an edge
+extern "C" int mi355_select_connected_results(const mi355_pair_result* r, int n_pairs, int n_images, int32_t* label) {
+    if (n_pairs < 0 || n_images <= 0 || (n_pairs > 0 && !r) || !label) return MI355_ERR_ARG;
+    return select_connected_core(n_pairs, [r](int p, int& a, int& b) { a = r[p].i; b = r[p].j; return r[p].accepted && r[p].n_in > 0; }, n_images, label);
 }

@@ -239,6 +239,13 @@ int  mi355_global_affine_align(const mi355_match_point_pairs* v, int n, int n_im
  * the images of the largest group connected through match pairs, else 0 (the driver then drops the other pairs
  * and flags those images invalid, h.m[8]=0, :4512-4523, 4646-4652).  Ties -> the group holding the lowest index. */
 int  mi355_select_connected(const mi355_match_point_pairs* v, int n, int n_images, int32_t* label);
+/* The two driver steps above straight from the pair records of mi355_match_pairs (no m_vecMatchPairs copy: at C5 that vector holds
+ * 28 M correspondences, 1.1 GB): accepted pairs with at least one inlier are the edges / the equations; with label != NULL the
+ * alignment uses only the pairs whose two images carry a non-zero label (the driver drops the others, :4512-4523).  Same sums in
+ * the same order as the m_vecMatchPairs forms: the transforms are the same bits. */
+int  mi355_select_connected_results(const mi355_pair_result* r, int n_pairs, int n_images, int32_t* label);
+int  mi355_global_affine_align_results(const mi355_pair_result* r, int n_pairs, int n_images, const int32_t* fixed,
+                                       const int32_t* label, mi355_image_transform* out);
 
 /* ---- SURF variant of the path ("next" row f4 of SURVEY 8f): GetMatchedPairsOneToAllSurf, MosaicWithoutPos.cpp:5300-5533 ----------
  * (every call site of it in the reference is commented out, :4461-4499; named in north_star).  cv::SURF's arithmetic is not

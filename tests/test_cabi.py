@@ -184,3 +184,33 @@ def test_global_affine_align_recovers_synthetic_surveys(im):
         for k in range(N - 1):
             assert np.abs(got[k] - A[k][:2]).max() < 2e-2 * max(1.0, np.abs(A[k][:2]).max() / 1000), (trial, k, got[k], A[k][:2])
         assert np.array_equal(T["m"][N - 1], np.eye(3, dtype=np.float32).reshape(9))      # a fixed (isolated) image stays at identity
+
+
+def test_alignment_from_pair_records_equals_the_match_pairs_form(im):
+    """mi355_select_connected_results / mi355_global_affine_align_results (straight from PAIR_RESULT records, host threads) give the
+    labels and the transforms of the m_vecMatchPairs forms bit for bit: rejected records and a second, smaller component included; a
+    survey large enough for the threaded moments and the threaded banded Cholesky (2000 images, band of 90 image blocks)"""
+    rng = np.random.default_rng(3)
+    for (N, per, K) in [(40, 7, 60), (2000, 45, 110)]:
+        pos = np.stack([(np.arange(N) % per) * 400.0, (np.arange(N) // per) * 300.0], 1)
+        pairs = [(i, i + d) for i in range(N - 3) for d in (1, per - 1, per, per + 1, 2 * per) if i + d < N - 3 and abs(pos[i, 0] - pos[i + d, 0]) < 1500]
+        pairs.append((N - 2, N - 1))                                  # a component of two images: labelled 0, its pair dropped
+        r = np.zeros(len(pairs) + 5, im.PAIR_RESULT)
+        for p, (a, b) in enumerate(pairs):
+            n = int(rng.integers(31, K))
+            r["i"][p] = a; r["j"][p] = b; r["accepted"][p] = 1; r["n_in"][p] = n
+            xa = rng.uniform(0, 4000, n).astype(np.float32); ya = rng.uniform(0, 3000, n).astype(np.float32)
+            r["a"]["x"][p, :n] = xa; r["a"]["y"][p, :n] = ya
+            r["b"]["x"][p, :n] = xa + np.float32(pos[a, 0] - pos[b, 0]) + rng.normal(0, 0.3, n).astype(np.float32)
+            r["b"]["y"][p, :n] = ya + np.float32(pos[a, 1] - pos[b, 1]) + rng.normal(0, 0.3, n).astype(np.float32)
+        r["i"][len(pairs):] = 0; r["j"][len(pairs):] = N - 1; r["n_in"][len(pairs):] = 12          # rejected records: no edge, no equations
+        mp = im.results_to_match_pairs(r)
+        label = im.select_connected(mp, N)
+        assert label[N - 1] == 0 and label[N - 2] == 0 and label[:N - 3].all()
+        assert np.array_equal(im.select_connected_results(r, N), label)
+        keep = (label[mp["ai"]] > 0) & (label[mp["bi"]] > 0)
+        fixed = [1 if (k == 0 or label[k] == 0) else 0 for k in range(N)]
+        T = im.global_affine_align(mp[keep], N, fixed=fixed)
+        T2 = im.global_affine_align_results(r, N, fixed=fixed, label=label)
+        assert np.array_equal(T.view(np.uint8), T2.view(np.uint8))
+        assert np.abs(T["m"][N // 2, [2, 5]] - pos[N // 2]).max() < 5.0          # noisy correspondences, a chain of ~20 rows of images
