@@ -28,7 +28,7 @@ while time.time() - t0 < budget:
         p2['y'] = 0.5 * p2['x'] + 10
     elif kind == 5:    # pure garbage
         p1['x'] = rng.uniform(0, w, m); p1['y'] = rng.uniform(0, h, m)
-    seed = int(rng.integers(1, 1 << 31)); dist = float(rng.choice([1.0, 2.5, 4.0])); st = int(rng.choice([1000, 1000, 200, 37]))
+    seed = int(rng.integers(1, 1 << 31)); dist = float(rng.choice([1.0, 2.5, 4.0])); st = int(rng.choice([1000, 1000, 200, 37, 1, 5, 256, 257, 1700, 4999]))
     ok, i1, i2, H = c.Ransac2D(p1, p2, dist, st, seed)
     ok2, j1, j2, H2 = o.ransac2d(p1, p2, dist, st, seed)
     good = (ok == ok2) and len(i1) == len(j1) and np.array_equal(i1.view(np.uint8), j1.view(np.uint8)) and np.array_equal(i2.view(np.uint8), j2.view(np.uint8)) and np.array_equal(H.view(np.uint32), H2.view(np.uint32))
