@@ -98,6 +98,33 @@ __global__ __launch_bounds__(256) void pyr_up16_combine_kernel(const short* coar
     }
 }
 
+// Laplacian level of a chip and its accumulation in one pass: lap = sat16(fine - EXPAND(coarse)) is formed in registers and added to the
+// canvas, never stored (the separate in-place pyr_up16_combine<true> + blend_accumulate pair moved 12 more bytes per pixel and was a
+// third of the blend's kernel time).  Both levels stay Gaussian, so the levels can be taken in any order.
+__global__ __launch_bounds__(256) void blend_lap_accumulate_kernel(const short* coarse, int w, int h, const short* fine, const float* wgt, int ox, int oy,
+                                                                   short* dl, float* dw, int DW) {
+    const int X = blockIdx.x * 256 + threadIdx.x, Y = blockIdx.y;
+    if (X >= 2 * w) return;
+    const int y = Y >> 1;
+    const int ym = (y == 0) ? (h > 1 ? 1 : 0) : y - 1, yp = (y == h - 1) ? h - 1 : y + 1;
+    const short* rm = coarse + (size_t)ym * w * 3;
+    const short* r0 = coarse + (size_t)y * w * 3;
+    const short* rp = coarse + (size_t)yp * w * 3;
+    const size_t fi = (size_t)Y * 2 * w + X;
+    const float wv = wgt[fi];
+    const size_t di = (size_t)(oy + Y) * DW + (ox + X);
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        int v;
+        if (!(Y & 1)) v = up_h(rm, w, X, c) + up_h(r0, w, X, c) * 6 + up_h(rp, w, X, c);
+        else v = (up_h(r0, w, X, c) + up_h(rp, w, X, c)) * 4;
+        const int up = sat16d((v + 32) >> 6);
+        const short lap = sat16d((int)fine[fi * 3 + c] - up);
+        dl[di * 3 + c] = (short)(dl[di * 3 + c] + (short)((float)lap * wv));
+    }
+    dw[di] += wv;
+}
+
 // canvas Laplacian += (short)(chip Laplacian * weight), canvas weight += weight, over the chip's region at this level
 __global__ __launch_bounds__(256) void blend_accumulate_kernel(const short* g, const float* wgt, int lw, int lh, int ox, int oy, short* dl, float* dw, int DW) {
     const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
@@ -209,11 +236,11 @@ static int blend_core(mi355_ctx* ctx, const uint8_t* const* chips, const uint8_t
             hipLaunchKernelGGL(pyr_down16_kernel, grid2(rw >> (l + 1), rh >> (l + 1)), dim3(256), 0, st, g + roff[l] * 3, rw >> l, rh >> l, g + roff[l + 1] * 3);
             hipLaunchKernelGGL(pyr_down_f_kernel, grid2(rw >> (l + 1), rh >> (l + 1)), dim3(256), 0, st, wp + roff[l], rw >> l, rh >> l, wp + roff[l + 1]);
         }
-        for (int l = 0; l < nb; l++)                                // Gaussian -> Laplacian, finest first (level l+1 still Gaussian)
-            hipLaunchKernelGGL((pyr_up16_combine_kernel<true>), grid2(rw >> l, rh >> l), dim3(256), 0, st, g + roff[l + 1] * 3, rw >> (l + 1), rh >> (l + 1), g + roff[l] * 3);
-        for (int l = 0; l <= nb; l++)
-            hipLaunchKernelGGL(blend_accumulate_kernel, grid2(rw >> l, rh >> l), dim3(256), 0, st, g + roff[l] * 3, wp + roff[l], rw >> l, rh >> l, tlx >> l, tly >> l,
-                               dlap.as<short>() + loff[l] * 3, dwgt.as<float>() + loff[l], Wp >> l);
+        for (int l = 0; l < nb; l++)                                // Laplacian level l = Gaussian l - EXPAND(Gaussian l + 1), accumulated as it is formed
+            hipLaunchKernelGGL(blend_lap_accumulate_kernel, grid2(rw >> l, rh >> l), dim3(256), 0, st, g + roff[l + 1] * 3, rw >> (l + 1), rh >> (l + 1),
+                               g + roff[l] * 3, wp + roff[l], tlx >> l, tly >> l, dlap.as<short>() + loff[l] * 3, dwgt.as<float>() + loff[l], Wp >> l);
+        hipLaunchKernelGGL(blend_accumulate_kernel, grid2(rw >> nb, rh >> nb), dim3(256), 0, st, g + roff[nb] * 3, wp + roff[nb], rw >> nb, rh >> nb, tlx >> nb, tly >> nb,
+                           dlap.as<short>() + loff[nb] * 3, dwgt.as<float>() + loff[nb], Wp >> nb);
         MI_HIP(hipGetLastError());
     }
     for (int l = 0; l <= nb; l++) {

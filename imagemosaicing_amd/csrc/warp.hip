@@ -426,17 +426,33 @@ __device__ __forceinline__ float quad_min_dist(const LineSet& L, int c, int r) {
 
 // per chip: the chip-wide maximum of that distance over the valid pixels (float bits, all >= 0).  The distances themselves are NOT
 // stored (round 2 kept a float map per chip pixel: 4 of the 8 bytes per chip pixel, 101 GB for the 2000 chips of C5)
-__global__ __launch_bounds__(256) void distmax_kernel(const uint8_t* mask, int mws, int w, int h, LineSet L, unsigned* maxbits) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    const int r = blockIdx.y * blockDim.y + threadIdx.y;
-    float v = 0.0f;
-    if (c < w && r < h && mask[(size_t)r * mws + c] != 0) v = quad_min_dist(L, c, r);
-    // wave max via shuffles, then one atomic per wave
-    unsigned bits = __float_as_uint(v);
+// One launch for all chips (blockIdx.z = chip): a workgroup walks a 256 x 64 pixel block (4 pixels per lane from one 32-bit mask
+// load, 16 row steps) and ends with ONE atomic -- a thread per pixel with an atomic per wave took 290 us per 12 MP chip, 25 % of a blend.
+__global__ __launch_bounds__(256) void distmax_kernel(const ChipDev* chips, uint8_t* const* masks, const LineSet* lines, unsigned* maxbits) {
+    const ChipDev cd = chips[blockIdx.z];
+    const int c0 = (blockIdx.x * 64 + threadIdx.x) * 4, r0 = blockIdx.y * 64;
+    if (blockIdx.x * 256 >= cd.w || r0 >= cd.h) return;
+    const LineSet L = lines[blockIdx.z];
+    const uint8_t* mask = masks[blockIdx.z];
+    unsigned bits = 0;                                                  // all distances >= 0: float order = bit order (a NaN would win, as it did per pixel)
+    if (c0 < cd.w) {
+        for (int r = r0 + threadIdx.y; r < r0 + 64 && r < cd.h; r += 4) {
+            const uint8_t* m = mask + (size_t)r * cd.mws + c0;          // mws is a multiple of 4 and c0 too: the 4 bytes are inside the row's storage
+            const unsigned mm = *reinterpret_cast<const unsigned*>(m);
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                if (c0 + k < cd.w && ((mm >> (8 * k)) & 0xffu) != 0) { const unsigned b = __float_as_uint(quad_min_dist(L, c0 + k, r)); bits = b > bits ? b : bits; }
+        }
+    }
     for (int off = 32; off > 0; off >>= 1) { unsigned o = __shfl_xor(bits, off); bits = o > bits ? o : bits; }
-    // one atomic per wave at most, and only while the wave still raises the maximum (a single address takes ~1e8 atomics/s:
-    // 187 000 waves of a 12 MP chip cost 1.9 ms without the test)
-    if (((threadIdx.y * blockDim.x + threadIdx.x) & 63) == 0 && bits > *reinterpret_cast<volatile unsigned*>(maxbits)) atomicMax(maxbits, bits);
+    __shared__ unsigned s_m[4];
+    const int tid = threadIdx.y * 64 + threadIdx.x;
+    if ((tid & 63) == 0) s_m[tid >> 6] = bits;
+    __syncthreads();
+    if (tid == 0) {
+        unsigned m = s_m[0]; m = s_m[1] > m ? s_m[1] : m; m = s_m[2] > m ? s_m[2] : m; m = s_m[3] > m ? s_m[3] : m;
+        if (m > *reinterpret_cast<volatile unsigned*>(maxbits + blockIdx.z)) atomicMax(maxbits + blockIdx.z, m);
+    }
 }
 
 // per canvas pixel: the chip with the strictly largest normalised distance (first wins, start 0) owns it (MosaicImage.cpp:1842-1872).
@@ -609,10 +625,11 @@ int mi_chips_and_masks_dev(mi355_ctx* ctx, const uint8_t* const* imgs, const int
         dim3 block(64, 4);
         {
             ProfScope ps(ctx, "distmap", (double)chip_total / 3.0);
-            for (int v = 0; v < nv; v++) {
-                dim3 grid((ci[v].w + 63) / 64, (ci[v].h + 3) / 4);
-                hipLaunchKernelGGL(distmax_kernel, grid, block, 0, ctx->stream, mptr[v], cd[v].mws, ci[v].w, ci[v].h, lines[v], d_max + v);
-            }
+            int mw = 1, mh = 1;
+            for (int v = 0; v < nv; v++) { if (ci[v].w > mw) mw = ci[v].w; if (ci[v].h > mh) mh = ci[v].h; }
+            for (int v0 = 0; v0 < nv; v0 += 65535)      // gridDim.z limit
+                hipLaunchKernelGGL(distmax_kernel, dim3((mw + 255) / 256, (mh + 63) / 64, nv - v0 < 65535 ? nv - v0 : 65535), block, 0, ctx->stream,
+                                   d_cd + v0, d_mptr + v0, d_lines + v0, d_max + v0);
         }
         dim3 grid((newW + 63) / 64, (newH + 3) / 4);
         {
