@@ -101,28 +101,52 @@ __global__ __launch_bounds__(256) void pyr_up16_combine_kernel(const short* coar
 // Laplacian level of a chip and its accumulation in one pass: lap = sat16(fine - EXPAND(coarse)) is formed in registers and added to the
 // canvas, never stored (the separate in-place pyr_up16_combine<true> + blend_accumulate pair moved 12 more bytes per pixel and was a
 // third of the blend's kernel time).  Both levels stay Gaussian, so the levels can be taken in any order.
+// One thread per COARSE pixel = a 2 x 2 block of fine pixels: the 3 x 3 coarse neighbourhood is read once for the four of them (a thread
+// per fine pixel issued 27 two-byte loads each and ran at a quarter of the bandwidth the bytes need).
 __global__ __launch_bounds__(256) void blend_lap_accumulate_kernel(const short* coarse, int w, int h, const short* fine, const float* wgt, int ox, int oy,
                                                                    short* dl, float* dw, int DW) {
-    const int X = blockIdx.x * 256 + threadIdx.x, Y = blockIdx.y;
-    if (X >= 2 * w) return;
-    const int y = Y >> 1;
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= w) return;
     const int ym = (y == 0) ? (h > 1 ? 1 : 0) : y - 1, yp = (y == h - 1) ? h - 1 : y + 1;
-    const short* rm = coarse + (size_t)ym * w * 3;
-    const short* r0 = coarse + (size_t)y * w * 3;
-    const short* rp = coarse + (size_t)yp * w * 3;
-    const size_t fi = (size_t)Y * 2 * w + X;
-    const float wv = wgt[fi];
-    const size_t di = (size_t)(oy + Y) * DW + (ox + X);
+    const short* rows[3] = {coarse + (size_t)ym * w * 3, coarse + (size_t)y * w * 3, coarse + (size_t)yp * w * 3};
+    int he[3][3], ho[3][3];                               // horizontal EXPAND values at fine columns 2x (even) and 2x + 1 (odd), per row and channel
 #pragma unroll
-    for (int c = 0; c < 3; c++) {
-        int v;
-        if (!(Y & 1)) v = up_h(rm, w, X, c) + up_h(r0, w, X, c) * 6 + up_h(rp, w, X, c);
-        else v = (up_h(r0, w, X, c) + up_h(rp, w, X, c)) * 4;
-        const int up = sat16d((v + 32) >> 6);
-        const short lap = sat16d((int)fine[fi * 3 + c] - up);
-        dl[di * 3 + c] = (short)(dl[di * 3 + c] + (short)((float)lap * wv));
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) { he[r][c] = up_h(rows[r], w, 2 * x, c); ho[r][c] = up_h(rows[r], w, 2 * x + 1, c); }
+    const int FW = 2 * w;
+    // the two fine pixels of a row are 12 contiguous bytes (4-byte aligned: the fine column 2x, the region offset ox and the row pitches are
+    // even): three 32-bit loads / stores instead of six 16-bit ones, the weights as one 64-bit access
+#pragma unroll
+    for (int dy = 0; dy < 2; dy++) {
+        const int Y = 2 * y + dy;
+        const size_t fi = (size_t)Y * FW + 2 * x;
+        const size_t di = (size_t)(oy + Y) * DW + (ox + 2 * x);
+        const float2 wv2 = *reinterpret_cast<const float2*>(wgt + fi);
+        const unsigned* fp = reinterpret_cast<const unsigned*>(fine + fi * 3);
+        unsigned* dp = reinterpret_cast<unsigned*>(dl + di * 3);
+        const unsigned f0 = fp[0], f1 = fp[1], f2 = fp[2];
+        unsigned d0 = dp[0], d1 = dp[1], d2 = dp[2];
+        const short fv[6] = {(short)(f0 & 0xffff), (short)(f0 >> 16), (short)(f1 & 0xffff), (short)(f1 >> 16), (short)(f2 & 0xffff), (short)(f2 >> 16)};
+        short dv[6] = {(short)(d0 & 0xffff), (short)(d0 >> 16), (short)(d1 & 0xffff), (short)(d1 >> 16), (short)(d2 & 0xffff), (short)(d2 >> 16)};
+#pragma unroll
+        for (int dx = 0; dx < 2; dx++) {
+            const float wv = dx ? wv2.y : wv2.x;
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                const int hm = dx ? ho[0][c] : he[0][c], h0 = dx ? ho[1][c] : he[1][c], hp = dx ? ho[2][c] : he[2][c];
+                const int v = dy ? (h0 + hp) * 4 : hm + h0 * 6 + hp;
+                const int up = sat16d((v + 32) >> 6);
+                const short lap = sat16d((int)fv[3 * dx + c] - up);
+                dv[3 * dx + c] = (short)(dv[3 * dx + c] + (short)((float)lap * wv));
+            }
+        }
+        dp[0] = (unsigned)(unsigned short)dv[0] | ((unsigned)(unsigned short)dv[1] << 16);
+        dp[1] = (unsigned)(unsigned short)dv[2] | ((unsigned)(unsigned short)dv[3] << 16);
+        dp[2] = (unsigned)(unsigned short)dv[4] | ((unsigned)(unsigned short)dv[5] << 16);
+        float2* wp2 = reinterpret_cast<float2*>(dw + di);
+        float2 a2 = *wp2; a2.x += wv2.x; a2.y += wv2.y; *wp2 = a2;
     }
-    dw[di] += wv;
 }
 
 // canvas Laplacian += (short)(chip Laplacian * weight), canvas weight += weight, over the chip's region at this level
@@ -237,7 +261,7 @@ static int blend_core(mi355_ctx* ctx, const uint8_t* const* chips, const uint8_t
             hipLaunchKernelGGL(pyr_down_f_kernel, grid2(rw >> (l + 1), rh >> (l + 1)), dim3(256), 0, st, wp + roff[l], rw >> l, rh >> l, wp + roff[l + 1]);
         }
         for (int l = 0; l < nb; l++)                                // Laplacian level l = Gaussian l - EXPAND(Gaussian l + 1), accumulated as it is formed
-            hipLaunchKernelGGL(blend_lap_accumulate_kernel, grid2(rw >> l, rh >> l), dim3(256), 0, st, g + roff[l + 1] * 3, rw >> (l + 1), rh >> (l + 1),
+            hipLaunchKernelGGL(blend_lap_accumulate_kernel, grid2(rw >> (l + 1), rh >> (l + 1)), dim3(256), 0, st, g + roff[l + 1] * 3, rw >> (l + 1), rh >> (l + 1),
                                g + roff[l] * 3, wp + roff[l], tlx >> l, tly >> l, dlap.as<short>() + loff[l] * 3, dwgt.as<float>() + loff[l], Wp >> l);
         hipLaunchKernelGGL(blend_accumulate_kernel, grid2(rw >> nb, rh >> nb), dim3(256), 0, st, g + roff[nb] * 3, wp + roff[nb], rw >> nb, rh >> nb, tlx >> nb, tly >> nb,
                            dlap.as<short>() + loff[nb] * 3, dwgt.as<float>() + loff[nb], Wp >> nb);
