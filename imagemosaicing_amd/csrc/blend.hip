@@ -28,40 +28,62 @@ __global__ __launch_bounds__(256) void blend_prep_kernel(const uint8_t* chip, in
     w0[(size_t)y * rw + x] = w;
 }
 
-// REDUCE i16 x 3: integer, so the 5x5 product form equals the oracle's rows-then-columns form
-__global__ __launch_bounds__(256) void pyr_down16_kernel(const short* src, int w, int h, short* dst) {
-    const int dw = w >> 1, x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
-    if (x >= dw) return;
+// REDUCE: i16 x 3 in integers (so the 5x5 product form equals the oracle's rows-then-columns form: rows [1 4 6 4 1] . pixels, then
+// columns, (sum + 128) >> 8) and f32 weights in the oracle's order (6 c + 4 (l + r) + ll + rr per row, the same over the rows, / 256).
+// REDUCE of both pyramids of a chip in one launch, two horizontally adjacent outputs per thread: their 5-tap windows share three of the
+// seven source columns, and away from the left / right border those seven pixels are 42 contiguous, 4-byte aligned bytes (11 32-bit
+// loads per row instead of 30 16-bit ones).  The sums are the ones of pyr_down16_kernel / pyr_down_f_kernel, term for term.
+__global__ __launch_bounds__(256) void pyr_down_pair_kernel(const short* src, const float* srcw, int w, int h, short* dst, float* dstw) {
+    const int dw = w >> 1, x0 = (blockIdx.x * 256 + threadIdx.x) * 2, y = blockIdx.y;
+    if (x0 >= dw) return;
+    const bool two = x0 + 1 < dw;
     const int wt[5] = {1, 4, 6, 4, 1};
-    int xs[5];
+    const bool interior = 2 * x0 - 2 >= 0 && 2 * x0 + 4 < w;
+    int xs[7];
 #pragma unroll
-    for (int j = 0; j < 5; j++) xs[j] = reflect101d(2 * x - 2 + j, w);
-    int acc[3] = {0, 0, 0};
-#pragma unroll
-    for (int k = 0; k < 5; k++) {
-        const short* s = src + (size_t)reflect101d(2 * y - 2 + k, h) * w * 3;
-        int r[3] = {0, 0, 0};
-#pragma unroll
-        for (int j = 0; j < 5; j++) { r[0] += wt[j] * s[3 * xs[j]]; r[1] += wt[j] * s[3 * xs[j] + 1]; r[2] += wt[j] * s[3 * xs[j] + 2]; }
-        acc[0] += wt[k] * r[0]; acc[1] += wt[k] * r[1]; acc[2] += wt[k] * r[2];
-    }
-    short* d = dst + ((size_t)y * dw + x) * 3;
-    d[0] = sat16d((acc[0] + 128) >> 8); d[1] = sat16d((acc[1] + 128) >> 8); d[2] = sat16d((acc[2] + 128) >> 8);
-}
-
-// REDUCE f32: the order of the float operations is the oracle's
-__global__ __launch_bounds__(256) void pyr_down_f_kernel(const float* src, int w, int h, float* dst) {
-    const int dw = w >> 1, x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
-    if (x >= dw) return;
-    const int x0 = reflect101d(2 * x - 2, w), x1 = reflect101d(2 * x - 1, w), x2 = 2 * x, x3 = reflect101d(2 * x + 1, w), x4 = reflect101d(2 * x + 2, w);
-    float r[5];
+    for (int j = 0; j < 7; j++) xs[j] = reflect101d(2 * x0 - 2 + j, w);
+    int acc[2][3] = {{0, 0, 0}, {0, 0, 0}};
+    float fr[2][5];
 #pragma unroll
     for (int k = 0; k < 5; k++) {
-        const float* s = src + (size_t)reflect101d(2 * y - 2 + k, h) * w;
-        r[k] = s[x2] * 6.0f + (s[x1] + s[x3]) * 4.0f + s[x0] + s[x4];
+        const int sy = reflect101d(2 * y - 2 + k, h);
+        const short* s = src + (size_t)sy * w * 3;
+        short px[7][3];
+        if (interior) {
+            const unsigned* p = reinterpret_cast<const unsigned*>(s + 3 * (2 * x0 - 2));      // 12 (x0 - 1) bytes into a row of 6 w bytes, w even
+            unsigned u[11];
+#pragma unroll
+            for (int q = 0; q < 11; q++) u[q] = p[q];
+#pragma unroll
+            for (int j = 0; j < 7; j++)
+#pragma unroll
+                for (int c = 0; c < 3; c++) { const int e = 3 * j + c; px[j][c] = (short)((e & 1) ? (u[e >> 1] >> 16) : (u[e >> 1] & 0xffff)); }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 7; j++) { px[j][0] = s[3 * xs[j]]; px[j][1] = s[3 * xs[j] + 1]; px[j][2] = s[3 * xs[j] + 2]; }
+        }
+#pragma unroll
+        for (int o = 0; o < 2; o++) {
+            int r[3] = {0, 0, 0};
+#pragma unroll
+            for (int j = 0; j < 5; j++) { r[0] += wt[j] * px[2 * o + j][0]; r[1] += wt[j] * px[2 * o + j][1]; r[2] += wt[j] * px[2 * o + j][2]; }
+            acc[o][0] += wt[k] * r[0]; acc[o][1] += wt[k] * r[1]; acc[o][2] += wt[k] * r[2];
+        }
+        const float* sw = srcw + (size_t)sy * w;
+        float f[7];
+#pragma unroll
+        for (int j = 0; j < 7; j++) f[j] = sw[xs[j]];
+#pragma unroll
+        for (int o = 0; o < 2; o++) fr[o][k] = f[2 * o + 2] * 6.0f + (f[2 * o + 1] + f[2 * o + 3]) * 4.0f + f[2 * o] + f[2 * o + 4];
     }
-    const float v = r[2] * 6.0f + (r[1] + r[3]) * 4.0f + r[0] + r[4];
-    dst[(size_t)y * dw + x] = v * (1.0f / 256.0f);
+#pragma unroll
+    for (int o = 0; o < 2; o++) {
+        if (o == 1 && !two) break;
+        short* d = dst + ((size_t)y * dw + x0 + o) * 3;
+        d[0] = sat16d((acc[o][0] + 128) >> 8); d[1] = sat16d((acc[o][1] + 128) >> 8); d[2] = sat16d((acc[o][2] + 128) >> 8);
+        const float v = fr[o][2] * 6.0f + (fr[o][1] + fr[o][3]) * 4.0f + fr[o][0] + fr[o][4];
+        dstw[(size_t)y * dw + x0 + o] = v * (1.0f / 256.0f);
+    }
 }
 
 // horizontal EXPAND value (before the vertical combination) at fine column X of coarse row s (3 channels, channel c)
@@ -256,10 +278,9 @@ static int blend_core(mi355_ctx* ctx, const uint8_t* const* chips, const uint8_t
         short* g = glap.as<short>();
         float* wp = gwgt.as<float>();
         hipLaunchKernelGGL(blend_prep_kernel, grid2(rw, rh), dim3(256), 0, st, d_chip, cws, d_mask, mws, cw, chh, left, top, rw, rh, g, wp);
-        for (int l = 0; l < nb; l++) {
-            hipLaunchKernelGGL(pyr_down16_kernel, grid2(rw >> (l + 1), rh >> (l + 1)), dim3(256), 0, st, g + roff[l] * 3, rw >> l, rh >> l, g + roff[l + 1] * 3);
-            hipLaunchKernelGGL(pyr_down_f_kernel, grid2(rw >> (l + 1), rh >> (l + 1)), dim3(256), 0, st, wp + roff[l], rw >> l, rh >> l, wp + roff[l + 1]);
-        }
+        for (int l = 0; l < nb; l++)
+            hipLaunchKernelGGL(pyr_down_pair_kernel, grid2(((rw >> (l + 1)) + 1) / 2, rh >> (l + 1)), dim3(256), 0, st, g + roff[l] * 3, wp + roff[l], rw >> l, rh >> l,
+                               g + roff[l + 1] * 3, wp + roff[l + 1]);
         for (int l = 0; l < nb; l++)                                // Laplacian level l = Gaussian l - EXPAND(Gaussian l + 1), accumulated as it is formed
             hipLaunchKernelGGL(blend_lap_accumulate_kernel, grid2(rw >> (l + 1), rh >> (l + 1)), dim3(256), 0, st, g + roff[l + 1] * 3, rw >> (l + 1), rh >> (l + 1),
                                g + roff[l] * 3, wp + roff[l], tlx >> l, tly >> l, dlap.as<short>() + loff[l] * 3, dwgt.as<float>() + loff[l], Wp >> l);
