@@ -5,9 +5,9 @@
  *   blender.feed(chip converted to CV_16S, mask, corner) per chip;  blender.blend(result_s, result_mask);
  *   result_s.convertTo(result, CV_8U)                       (MosaicImage.cpp:2296-2299, 2451-2486)
  *
- * PARITY UNPINNED AT THE BIT LEVEL: the arithmetic is OpenCV 2.4.0 `stitching` (blenders.cpp) + `imgproc` (pyramids.cpp), vendored
+ * PARITY UNPINNED AT THE OUTPUT LEVEL: the arithmetic is OpenCV 2.4.0 `stitching` (blenders.cpp) + `imgproc` (pyramids.cpp), vendored
  * in the reference as headers + Win32 binaries only, and the reference commits no blended output to compare with.  The STRUCTURE
- * below was checked this round against the reference's own binary (Release/opencv_stitching240.dll, llvm-objdump):
+ * below was checked against the reference's own binary (Release/opencv_stitching240.dll, llvm-objdump):
  *   MultiBandBlender::feed (1000b190): gap = 3 << num_bands (1000b3c0-1000b3cb), corners snapped by >> / << num_bands (1000b486-1000b48c),
  *     copyMakeBorder(img, .., BORDER_REFLECT = 2) (1000b61d-1000b657), createLaplacePyr (1000b6c0), weight = mask.convertTo(CV_32F, 1/255)
  *     (1000b776-1000b782; the CV_16S weight branch exists and is not taken: the reference constructs MultiBandBlender(false, band)),
@@ -15,9 +15,26 @@
  *     sign-extended 16-bit loads and truncating float -> int conversions;
  *   createLaplacePyr (1000a440): pyrDown chain, pyrUp to the finer size, cv::subtract(.., dtype CV_16S = 3) (1000a59f-1000a797);
  *   normalizeUsingWeightMap (10006710): (short)(value / (weight + 1e-5f)) with cvttss2si = truncation toward zero (1000684d-100068ce).
- * The per-pixel arithmetic of cv::pyrDown / cv::pyrUp for CV_16SC3 and CV_32F (opencv_imgproc240.dll) was NOT read from the binary;
- * it is restated from the published algorithm (Burt & Adelson 1983 multiresolution spline) in the shape OpenCV gives it -- 16-bit
- * Laplacian pyramids, float weight pyramids, 5-tap [1 4 6 4 1] REDUCE / EXPAND in integer arithmetic -- with these choices:
+ * The per-pixel arithmetic of cv::pyrDown / cv::pyrUp is restated from Burt & Adelson's REDUCE / EXPAND in the shape OpenCV gives it and
+ * was then checked against the reference's opencv_imgproc240.dll (round 3, llvm-objdump; the template instantiations are identified by
+ * their load / store widths):
+ *   pyrDown, 16-bit outputs (two instantiations, short and ushort, vertical pass at 100f793c-100f7969 and 100f818c-100f81b9):
+ *     (6 r2 + 4 (r1 + r3) + r0 + r4 + 128) >> 8 on int rows, stored with a plain 16-bit move (the weights sum to 256: saturation
+ *     cannot trigger); the 8-bit instantiation at 100f70f0-100f7121 has the same shape;
+ *   pyrDown, float (the weight pyramid): scalar SSE single precision (mulss / addss, no x87 extended intermediates) -- but the binary
+ *     was compiled with reassociating float optimisation, and the association of the sum DIFFERS BY LOOP SLOT.  Horizontal pass, with
+ *     a4 = (s[2x-1] + s[2x+1]) * 4, c6 = s[2x] * 6: the 4x unrolled interior loop (100f88d0-100f897f) computes ((a4 + c6) + s[2x+2]) + s[2x-2]
+ *     in three slots and ((a4 + s[2x+2]) + c6) + s[2x-2] in the fourth, its remainder loop (100f89a0-100f89cf) ((a4 + c6) + s[2x-2]) + s[2x+2],
+ *     the border loop over the index table (100f8822-100f888a) ((a4 + s[2x-2]) + c6) + s[2x+2].  Vertical pass: an SSE routine
+ *     (call at 100f8e51 -> 100f6460, OpenCV's PyrDownVec_32f) for the bulk of a row and a scalar tail (100f8eaf-100f8ef6) with the
+ *     1/256 distributed into the constants: (r0 + r4) * (1/256) + (r1 + r3) * (4/256) + r2 * (6/256).
+ *     THE ORACLE DOES NOT FOLLOW THESE SLOT-DEPENDENT ORDERS: it keeps the single association of OpenCV's published source
+ *     (c6 + a4 + s[2x-2] + s[2x+2], the same over the rows, times 1/256).  The weights are the same real numbers; their float values
+ *     can differ from the reference's in the last bit at some pixels, which can move a (short)(laplacian * weight) truncation by one.
+ *     The 16-bit Laplacian paths are integer arithmetic and do not depend on association.
+ *   pyrUp, short: horizontal pass at 100fa54b-100fa5b3: left border 6 s0 + 2 s1 | 4 (s0 + s1), right border s[w-2] + 7 s[w-1] | 8 s[w-1];
+ *     vertical pass at 100fa6dc-100fa708: (r0 + 6 r1 + r2 + 32) >> 6 and (4 (r1 + r2) + 32) >> 6, 16-bit moves.
+ * So the choices below are the binary's:
  *   REDUCE  (pyrDown) i16: v = sum over the 5x5 taps (rows then columns, int), out = (v + 128) >> 8; reflect-101 border
  *           f32: row = s[2x]*6 + (s[2x-1] + s[2x+1])*4 + s[2x-2] + s[2x+2] (left to right), same vertically, times 1/256
  *   EXPAND  (pyrUp) i16 to exactly twice the size: horizontally even = s[x-1] + 6 s[x] + s[x+1], odd = 4 (s[x] + s[x+1]),
