@@ -1,10 +1,12 @@
 // csrc/blend.hip -- multiband blend of the warped chips, replacing
 //   detail::MultiBandBlender blender(false, band); prepare / feed per chip / blend; convertTo(CV_8U)
 //   (MosaicImage.cpp:2296-2299, 2451-2486).
-// The arithmetic is OpenCV 2.4.0's (absent): PARITY UNPINNED.  The definition implemented here -- 16-bit Laplacian
-// pyramids, float weight pyramids, [1 4 6 4 1] REDUCE / EXPAND in integer arithmetic, every rounding and border --
-// is the one stated at the top of oracle/oracle_blend.c; the parity test compares the output bytes.
-// All kernels are streaming stencils over at most a few hundred MB: HBM-bound, one thread per output pixel.
+// The arithmetic is OpenCV 2.4.0's (binaries only; the reference commits no blended output).  The definition implemented here --
+// 16-bit Laplacian pyramids, float weight pyramids, [1 4 6 4 1] REDUCE / EXPAND in integer arithmetic, every rounding and border --
+// is the one stated at the top of oracle/oracle_blend.c, which also lists what was checked against the reference's DLLs and the one
+// known divergence (the binary's reassociated float REDUCE); the parity test compares the output bytes with that oracle.
+// All kernels are streaming stencils over at most a few hundred MB.  Per chip: prep, 5 x paired REDUCE (both pyramids, two outputs per
+// thread from 32-bit loads), 5 x Laplacian + accumulate (a 2 x 2 fine block per thread, never stored), the top level's accumulate.
 #include "common.h"
 #include <cmath>
 
