@@ -160,23 +160,29 @@ extern "C" int mi355_pack_features_dev(mi355_ctx* ctx, const int32_t* img_ids, i
 // costs ~1500 API calls per step at C4.
 struct InstallDst { const uint8_t* rec; mi355_keypoint* kp; uint8_t* d8; float2* xy; int8_t* s8; int* n8; int n, npad; };
 
-__global__ __launch_bounds__(128) void install_features_kernel(const InstallDst* tab) {
+__global__ __launch_bounds__(256) void install_features_kernel(const InstallDst* tab) {
     const InstallDst t = tab[blockIdx.y];
-    const int row = blockIdx.x, k = threadIdx.x;            // one descriptor row per workgroup, 128 lanes = 128 dims
+    const int row = blockIdx.x * 32 + (threadIdx.x >> 3), part = threadIdx.x & 7;     // 8 lanes per descriptor row, 16 bytes each
     if (row >= t.npad) return;
-    int v = 0;
-    if (row < t.n) { const unsigned u = t.rec[REC_D8_OFF + (size_t)row * 128 + k]; t.d8[(size_t)row * 128 + k] = (uint8_t)u; v = (int)u - 128; }
-    t.s8[(size_t)row * 128 + k] = (int8_t)v;              // the matcher's int8 operand (match.hip), zeros in the padding rows
-    int s = v * v;
-    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
-    __shared__ int part[2];
-    if ((k & 63) == 0) part[k >> 6] = s;
-    __syncthreads();
-    if (k == 0) t.n8[row] = part[0] + part[1];
-    if (row < t.n && k < 7) {
-        const unsigned w = reinterpret_cast<const unsigned*>(t.rec + (size_t)row * sizeof(mi355_keypoint))[k];
-        reinterpret_cast<unsigned*>(t.kp + row)[k] = w;
-        if (k < 2) reinterpret_cast<unsigned*>(t.xy + row)[k] = w;                  // x, y are the first two fields
+    uint4 v = make_uint4(0x80808080u, 0x80808080u, 0x80808080u, 0x80808080u);           // padding rows: zeros after the shift
+    if (row < t.n) {
+        v = *reinterpret_cast<const uint4*>(t.rec + REC_D8_OFF + (size_t)row * 128 + part * 16);
+        *reinterpret_cast<uint4*>(t.d8 + (size_t)row * 128 + part * 16) = v;
+    }
+    const unsigned w[4] = {v.x, v.y, v.z, v.w};
+    int s = 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+#pragma unroll
+        for (int b = 0; b < 4; b++) { const int u = (int)((w[q] >> (8 * b)) & 0xffu) - 128; s += u * u; }
+    // the matcher's int8 operand (match.hip): u - 128 = u ^ 0x80 as a byte
+    *reinterpret_cast<uint4*>(t.s8 + (size_t)row * 128 + part * 16) = make_uint4(v.x ^ 0x80808080u, v.y ^ 0x80808080u, v.z ^ 0x80808080u, v.w ^ 0x80808080u);
+    s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4);
+    if (part == 0) t.n8[row] = s;
+    if (row < t.n && part < 7) {
+        const unsigned kw = reinterpret_cast<const unsigned*>(t.rec + (size_t)row * sizeof(mi355_keypoint))[part];
+        reinterpret_cast<unsigned*>(t.kp + row)[part] = kw;
+        if (part < 2) reinterpret_cast<unsigned*>(t.xy + row)[part] = kw;               // x, y are the first two fields
     }
 }
 
@@ -213,7 +219,7 @@ static int install_features(mi355_ctx* ctx, const mi355_feature_header* hdr, con
     DevBuf& dtab = ctx->buf("install_tab");
     MI_HIP(dtab.reserve(sizeof(InstallDst) * tab.size()));
     MI_HIP(hipMemcpyAsync(dtab.p, tab.data(), sizeof(InstallDst) * tab.size(), hipMemcpyHostToDevice, ctx->stream));
-    hipLaunchKernelGGL(install_features_kernel, dim3(2048, (unsigned)tab.size()), dim3(128), 0, ctx->stream, dtab.as<InstallDst>());
+    hipLaunchKernelGGL(install_features_kernel, dim3(2048 / 32, (unsigned)tab.size()), dim3(256), 0, ctx->stream, dtab.as<InstallDst>());
     MI_HIP(hipGetLastError());
     MI_HIP(hipStreamSynchronize(ctx->stream));           // `tab` goes out of scope; the caller may reuse d_payload
     return MI355_OK;
