@@ -159,7 +159,7 @@ int mi_bf_match(mi355_ctx*, int img_i, int img_j, int sorted, mi355_dmatch* matc
 int mi_select_grid(mi355_ctx*, const mi355_dmatch* sorted, int n, const float* kp1, int nk1, const float* kp2, int nk2,
                    int nMatch, int width, int height, int gx, int gy, mi355_sfpoint* v1, mi355_sfpoint* v2, int* n_out);
 int mi_set_features(mi355_ctx*, int img_id, const mi355_keypoint* kp, const float* desc, int n, int w, int h);
-int mi_finish_features(mi355_ctx*, Features& f, const int* d_n = nullptr, hipStream_t st = nullptr);   // builds xy / bf16 / norms from kp + d8 on device
+int mi_finish_features(mi355_ctx*, Features& f, const int* d_n = nullptr, hipStream_t st = nullptr);   // builds xy / int8 rows / norms from kp + d8 on device
 int mi_resolve_features(mi355_ctx*);               // waits for in-flight SIFT frames and adopts their keypoint counts
 int mi_resolve_features_of(mi355_ctx*, const int* ids, int n);   // the same for the given frames only (waits for their batches' events)
 int mi_sift_extract_dev(mi355_ctx*, int img_id, const uint8_t* d_bgr, int w, int h, int ws, int* n_kp);
