@@ -58,6 +58,48 @@ __device__ __attribute__((noinline)) bool generic_hypothesis(const float* p, flo
     return skip;
 }
 
+// InverseMatrix of order 8 (matrix.h:147-296, hm::inverse_matrix) by the whole workgroup: thread (j, c) of the first 128 owns entry (j, c) of
+// the 8 x 16 tableau in LDS and performs on it exactly the operations the sequential routine performs on that entry -- the pivot search
+// (first unused row whose entry in column i exceeds eps) is evaluated by every thread on the same LDS values, the pivot row is divided by
+// the pivot, every other row whose entry in the pivot column is not below eps takes row + (-entry) * pivot row, and the closing pass swaps
+// the row holding an exact 1 in column r into position r.  A missing pivot leaves dst untouched (the caller keeps the stale inverse).
+// One lane running the index-driven routine took ~55 us per call, 15 calls per accepted pair: as long as the whole hypothesis loop.
+// All RB threads must call; uniform control flow.
+__device__ __forceinline__ void inverse8_team(const float* src, float* dst, float eps, float* t, int tid) {
+    const int j = (tid >> 4) & 7, c = tid & 15;
+    if (tid < 128) t[tid] = c < 8 ? src[j * 8 + c] : ((c - 8 == j) ? 1.0f : 0.0f);
+    __syncthreads();
+    unsigned used = 0;
+    for (int i = 0; i < 8; i++) {
+        int rowI = -1;
+        for (int jj = 0; jj < 8; jj++) if (rowI < 0 && !((used >> jj) & 1u) && fabsf(t[jj * 16 + i]) > eps) rowI = jj;
+        if (rowI < 0) return;                                // matrix.h:206-222: no pivot, the routine gives up
+        used |= 1u << rowI;
+        const float ei = t[rowI * 16 + i];
+        const float prc = t[rowI * 16 + c] / ei;
+        const float e2 = t[j * 16 + i], old = t[j * 16 + c];
+        __syncthreads();                                      // every read of this step precedes its writes
+        if (tid < 128) {
+            float nv = old;
+            if (j == rowI) nv = prc;
+            else if (!(fabsf(e2) < eps)) { const float ne = -e2; const float prod = ne * prc; nv = old + prod; }
+            t[j * 16 + c] = nv;
+        }
+        __syncthreads();
+    }
+    for (int r = 0; r < 8; r++) {
+        int target = -1;
+        for (int ii = 0; ii < 8; ii++) if (target < 0 && t[ii * 16 + r] == 1.0f) target = ii;
+        const bool sw = target >= 0 && target != r;
+        float a = 0.0f, b = 0.0f;
+        if (sw && tid < 16) { a = t[r * 16 + tid]; b = t[target * 16 + tid]; }
+        __syncthreads();
+        if (sw && tid < 16) { t[r * 16 + tid] = b; t[target * 16 + tid] = a; }
+        __syncthreads();
+    }
+    if (tid < 64) dst[tid] = t[(tid >> 3) * 16 + 8 + (tid & 7)];
+}
+
 __device__ __forceinline__ int block_exclusive_scan_flags(bool flag, int tid, int* wave_tot /*LDS[RB/64+1]*/, int& total) {
     const unsigned long long m = __ballot(flag);
     const int lane = tid & 63, wv = tid >> 6;
@@ -328,11 +370,12 @@ __device__ __forceinline__ void ransac_body(const RansacArgs& a) {
         if (tid < 64) {                                     // J^T J, entry (r,c): k-ordered accumulation
             const int r = tid >> 3, c = tid & 7;
             float acc = 0.0f;
+#pragma unroll 8                                             // the loads of eight steps in flight; the sum stays in k order
             for (int k = 0; k < rows; k++) { const float pr = J[k * 8 + r] * J[k * 8 + c]; acc = acc + pr; }
             s_T1[tid] = acc;
         }
         __syncthreads();
-        if (tid == 0) hm::inverse_matrix<8>(s_T1, 8, s_T2, 1e-6f, s_t);      // LeastSquare.h:451 (stale T2 on failure)
+        inverse8_team(s_T1, s_T2, 1e-6f, s_t, tid);                          // LeastSquare.h:451 (stale T2 on failure)
         __syncthreads();
         for (int e = tid; e < 8 * rows; e += RB) {         // J* = (J^T J)^-1 J^T
             const int r = e / rows, k = e - r * rows;
@@ -344,6 +387,7 @@ __device__ __forceinline__ void ransac_body(const RansacArgs& a) {
         __syncthreads();
         if (tid < 8) {
             float acc = 0.0f;
+#pragma unroll 8
             for (int k = 0; k < rows; k++) { const float pr = JL[tid * rows + k] * C[k]; acc = acc + pr; }
             s_dX[tid] = acc;
         }
