@@ -458,9 +458,79 @@ struct GlibcRand {
     }
 };
 // The rand() stream depends only on the seed; what depends on n is how it is consumed (% n, redraw of all four until
-// pairwise distinct).  For the all-n tables the host therefore generates the raw stream once and one device thread per n
-// walks it -- 8 M host rand() calls (25 ms per new seed) become 0.4 M + a sub-millisecond kernel.
-constexpr int RAW_STREAM = 400000;               // n = 4 consumes ~213 k values for 4999 draws (9.4 % of the groups are distinct)
+// pairwise distinct).  For the all-n tables the raw stream is generated once and one workgroup per n walks it.
+//
+// The stream itself is produced on the device.  rand() is the lagged sum x_n = x_{n-3} + x_{n-31} (mod 2^32), output x_n >> 1: linear
+// in the 31 last values, so the state after K steps is A^K times the state before, A a fixed 31 x 31 matrix over Z / 2^32.  The host
+// seeds the generator (344 steps) and hands over the 31 values; workgroup j of the kernel jumps to the state after 992 j steps by
+// applying the precomputed powers A^(992 * 2^b) for the set bits of j (at most 9 matrix-vector products of 961 terms), then one
+// lane runs the 992 steps of its block with the 31 values in registers.  The host loop over 400 000 rand() calls plus the 1.6 MB
+// upload cost 1.4-2.2 ms per new seed (every survey has its own seed); this takes ~0.1 ms.  Same integers by construction; every
+// RANSAC golden case and soak compares results that depend on every draw.
+constexpr int RAW_BLK = 31 * 32;                 // values per workgroup: 32 trips of the 31-step ring
+constexpr int RAW_STREAM = 404 * RAW_BLK;        // 400 768 values: n = 4 consumes ~213 k for 4999 draws (9.4 % of the groups are distinct)
+constexpr int RAW_BITS = 9;                      // 404 blocks < 2^9
+struct RawSeed { uint32_t s[31]; };
+__global__ __launch_bounds__(64) void raw_stream_kernel(const uint32_t* powers /* RAW_BITS x 31 x 31 */, RawSeed seed, int* raw, int nraw) {
+    __shared__ uint32_t st[2][32];
+    __shared__ int outv[RAW_BLK];
+    const int j = blockIdx.x, l = threadIdx.x;
+    if (l < 31) st[0][l] = seed.s[l];
+    __syncthreads();
+    int cur = 0;
+    for (int b = 0; b < RAW_BITS; b++) {
+        if (!((j >> b) & 1)) continue;                    // uniform
+        if (l < 31) {
+            const uint32_t* m = powers + ((size_t)b * 31 + l) * 31;
+            uint32_t acc = 0;
+            for (int k = 0; k < 31; k++) acc += m[k] * st[cur][k];
+            st[cur ^ 1][l] = acc;
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+    if (l == 0) {
+        uint32_t x[31];
+#pragma unroll
+        for (int k = 0; k < 31; k++) x[k] = st[cur][k];   // x[k] = x_{n-31+k}: slot k is the oldest value when step k runs
+        for (int t = 0; t < RAW_BLK / 31; t++) {
+#pragma unroll
+            for (int k = 0; k < 31; k++) {
+                x[k] = x[k] + x[(k + 28) % 31];           // x_n = x_{n-31} + x_{n-3}
+                outv[t * 31 + k] = (int)(x[k] >> 1);
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = l; i < RAW_BLK; i += 64) { const int g = j * RAW_BLK + i; if (g < nraw) raw[g] = outv[i]; }
+}
+// powers of the step matrix: P[b] = A^(RAW_BLK * 2^b); S' = A S with S'[k] = S[k + 1] (k < 30), S'[30] = S[0] + S[28]
+struct Mat31 { uint32_t m[31][31]; };
+static void mat31_mul(const Mat31& a, const Mat31& b, Mat31& c) {
+    for (int i = 0; i < 31; i++)
+        for (int j = 0; j < 31; j++) { uint32_t acc = 0; for (int k = 0; k < 31; k++) acc += a.m[i][k] * b.m[k][j]; c.m[i][j] = acc; }
+}
+static const std::vector<uint32_t>& raw_stream_powers() {
+    static const std::vector<uint32_t> P = [] {
+        Mat31 A; memset(&A, 0, sizeof(A));
+        for (int k = 0; k < 30; k++) A.m[k][k + 1] = 1;
+        A.m[30][0] = 1; A.m[30][28] = 1;
+        Mat31 R; memset(&R, 0, sizeof(R));
+        for (int k = 0; k < 31; k++) R.m[k][k] = 1;
+        Mat31 B = A, T;
+        for (int e = RAW_BLK; e; e >>= 1) {               // R = A^RAW_BLK by binary powers
+            if (e & 1) { mat31_mul(R, B, T); R = T; }
+            mat31_mul(B, B, T); B = T;
+        }
+        std::vector<uint32_t> out((size_t)RAW_BITS * 31 * 31);
+        for (int b = 0; b < RAW_BITS; b++) {
+            memcpy(out.data() + (size_t)b * 961, &R, sizeof(R));
+            mat31_mul(R, R, T); R = T;
+        }
+        return out;
+    }();
+    return P;
+}
 __global__ __launch_bounds__(256) void draw_tables_kernel(const int* raw, int nraw, uint16_t* tables, int n_lo, int* overflow) {
     // one workgroup per n: groups of four stream values are tested in parallel, the accepted ones (pairwise distinct
     // after % n) are compacted in stream order with a block-wide prefix count
@@ -587,19 +657,25 @@ int mi_ransac_batch(mi355_ctx* ctx, const mi355_sfpoint* d_p1, const mi355_sfpoi
                 ctx->draw_tables.clear();
             }
             const int ntab = MI355_MAX_SELECTED - 4 + 1;
-            std::vector<int> raw(RAW_STREAM);
-            { GlibcRand g; g.seed(seed); for (int i = 0; i < RAW_STREAM; i++) raw[i] = g.next(); }
+            RawSeed rs;
+            { GlibcRand g; g.seed(seed); for (int k = 0; k < 31; k++) rs.s[k] = (uint32_t)g.r[(g.f + k) % 31]; }     // x_{-31} .. x_{-1}: slot f is overwritten next
             DevBuf& draw = ctx->buf("ransac_raw_stream");
             MI_HIP(draw.reserve((size_t)RAW_STREAM * sizeof(int) + 64));
             int* d_flag = draw.as<int>() + RAW_STREAM;
+            DevBuf& dpow = ctx->buf("ransac_raw_powers");
+            if (dpow.cap == 0) {
+                const std::vector<uint32_t>& P = raw_stream_powers();
+                MI_HIP(dpow.reserve(P.size() * sizeof(uint32_t)));
+                MI_HIP(hipMemcpyAsync(dpow.p, P.data(), P.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));      // P is static: outlives the copy
+            }
             DevBuf& b = ctx->draw_tables[key];
             MI_HIP(b.reserve(one * ntab * sizeof(uint16_t)));
-            MI_HIP(hipMemcpyAsync(draw.p, raw.data(), (size_t)RAW_STREAM * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+            hipLaunchKernelGGL(raw_stream_kernel, dim3(RAW_STREAM / RAW_BLK), dim3(64), 0, ctx->stream, dpow.as<uint32_t>(), rs, draw.as<int>(), RAW_STREAM);
             MI_HIP(hipMemsetAsync(d_flag, 0, sizeof(int), ctx->stream));
             hipLaunchKernelGGL(draw_tables_kernel, dim3(ntab), dim3(256), 0, ctx->stream, draw.as<int>(), RAW_STREAM, b.as<uint16_t>(), 4, d_flag);
             int flag = 0;
             MI_HIP(hipMemcpyAsync(&flag, d_flag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-            MI_HIP(hipStreamSynchronize(ctx->stream));          // `raw` goes out of scope
+            MI_HIP(hipStreamSynchronize(ctx->stream));          // the flag has landed
             if (flag) {                                        // raw stream too short for some n (never seen): per-n host generation
                 std::vector<uint16_t> tabs(one * ntab);
                 for (int n = 4; n <= MI355_MAX_SELECTED; n++) mi_glibc_draw_table(seed, n, MAX_DRAWS, tabs.data() + one * (n - 4));

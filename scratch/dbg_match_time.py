@@ -11,7 +11,7 @@ for k in range(F): ctx.SynthFrameDev(frames[k].data_ptr(), w, h, ws, A[k], 0xC0F
 for k in range(F): ctx.SiftExtractDev(k, frames[k].data_ptr(), w, h, ws)
 ctx.synchronize()
 pairs = [(i, j) for i in range(F) for j in range(i + 1, min(F, i + 9))]
-pairs = pairs[:499]
+pairs = pairs[:int(sys.argv[1]) if len(sys.argv) > 1 else 499]
 res = torch.zeros((len(pairs), im.PAIR_RESULT.itemsize), dtype=torch.uint8, device='cuda')
 for seed in (1, 2, 2, 3):
     t0 = time.perf_counter(); ctx.MatchPairsDev(pairs, res.data_ptr(), 2.5, seed); t1 = time.perf_counter(); ctx.synchronize(); t2 = time.perf_counter()
