@@ -717,3 +717,24 @@ int mi_ransac_batch(mi355_ctx* ctx, const mi355_sfpoint* d_p1, const mi355_sfpoi
     }
     return MI355_OK;
 }
+
+// diagnostic (tests/test_gpu_parity.py): the device-generated rand() stream of a seed, for comparison with libc's
+extern "C" int mi355_debug_rand_stream(mi355_ctx* ctx, uint32_t seed, int32_t* out, int n) {
+    if (!out || n < 0 || n > RAW_STREAM) return MI355_ERR_ARG;
+    LOCKED_PROLOGUE
+    RawSeed rs;
+    { GlibcRand g; g.seed(seed); for (int k = 0; k < 31; k++) rs.s[k] = (uint32_t)g.r[(g.f + k) % 31]; }
+    DevBuf& draw = ctx->buf("ransac_raw_stream");
+    MI_HIP(draw.reserve((size_t)RAW_STREAM * sizeof(int) + 64));
+    DevBuf& dpow = ctx->buf("ransac_raw_powers");
+    if (dpow.cap == 0) {
+        const std::vector<uint32_t>& P = raw_stream_powers();
+        MI_HIP(dpow.reserve(P.size() * sizeof(uint32_t)));
+        MI_HIP(hipMemcpyAsync(dpow.p, P.data(), P.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    }
+    hipLaunchKernelGGL(raw_stream_kernel, dim3(RAW_STREAM / RAW_BLK), dim3(64), 0, ctx->stream, dpow.as<uint32_t>(), rs, draw.as<int>(), RAW_STREAM);
+    MI_HIP(hipMemcpyAsync(out, draw.p, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+    MI_HIP(hipStreamSynchronize(ctx->stream));
+    return MI355_OK;
+}
+

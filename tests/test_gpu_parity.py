@@ -211,6 +211,21 @@ def test_select_match_pairs_golden(ctx):
         assert np.array_equal(a1, o1[:no]) and np.array_equal(a2, o2[:no])
 
 
+def test_device_rand_stream_equals_glibc(ctx, oracle):
+    """the RANSAC draw tables are built from a rand() stream generated on the device by jump-ahead of glibc's lagged sum (ransac.hip):
+    all 400 768 values of three seeds against the oracle's restatement of glibc (itself checked against libc in test_oracle_golden)"""
+    import ctypes as C
+    for seed in (1, 12345, 0xFFFFFFFF):
+        n = 404 * 992
+        out = np.zeros(n, np.int32)
+        assert ctx.L.mi355_debug_rand_stream(ctx._h, C.c_uint32(seed), out.ctypes.data_as(C.c_void_p), n) == 0
+        st = (C.c_int32 * 40)()
+        oracle.L.orc_srand(st, C.c_uint(seed))
+        rnd = oracle.L.orc_rand
+        want = np.fromiter((rnd(st) for _ in range(n)), np.int32, n)
+        assert np.array_equal(out, want), int((out != want).argmax())
+
+
 # ---------------------------------------------------------------------------------------------- matching
 def test_bf_match_exact(ctx, oracle):
     """int8 MFMA distances (int32 accumulation) are exact integers: indices, 1-NN and 2-NN squared distances equal the CPU
