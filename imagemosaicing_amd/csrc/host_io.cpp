@@ -311,7 +311,7 @@ int align_core(const std::vector<PairGroup>& groups, XY&& xy, int n_images, cons
             if (team > 1) {                                        // everyone has read row j's old diagonal and written its rows
                 gen++;
                 if (arrived.fetch_add(1) + 1 == team) { NL(j, j) = d; arrived.store(0); generation.store(gen); }
-                else while (generation.load() < gen) { }
+                else { int spins = 0; while (generation.load() < gen) { if (++spins > 4096) { std::this_thread::yield(); spins = 4000; } } }   // a column takes microseconds: spinning is right unless the host has fewer cores than threads (27 s instead of 0.09 s at 16 threads on 8 cores without the yield)
             } else NL(j, j) = d;
         }
     };
