@@ -25,6 +25,14 @@
  *      (dx and |dx| split by the sign of dy, dy and |dy| split by the sign of dx) = 128 floats, normalised to unit length
  *   6. keypoints leave ordered by (response descending, octave, layer, row, column); the strongest max_kp are kept
  *
+ * READ FROM THE REFERENCE'S BINARY (Release/opencv_nonfree240.dll, llvm-objdump; a spot check, not a pin): the constants 0.81
+ * (1001cb7f, calcLayerDetAndTrace), 1.2 / 9 (100208d5), the Gaussian sigmas 2.5 and 3.3 as doubles (100228e9, 10022aae) are the ones
+ * used below.  The same function shows what a bit-level pin would have to follow and this file does NOT: the build evaluates floating
+ * point on the x87 unit -- det = (float)(dx * dy - (dxy * dxy) * 0.81) with dx, dy rounded to float and dxy kept at the double
+ * precision calcHaarPattern accumulated it in (1001cb55-1001cb87), trace = (float)(dy + dx) -- where this restatement rounds every
+ * operation to float.  Determinants therefore differ from the reference's in their last bits, which can reorder keypoints of nearly
+ * equal response; SURF stays PARITY UNPINNED.
+ *
  * DEFINED HERE (where the publication leaves freedom) so that the HIP implementation can be compared bit for bit:
  *   - box responses accumulate (double)boxsum * (double)weight over the boxes in prototype order, then round to float once;
  *   - rounding to integers is round-half-to-even (rint); atan2 / sin / cos are the fixed polynomials of oracle_sift.c;
