@@ -29,17 +29,28 @@ def sources():
     return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".cpp")))
 
 
+GEN = os.path.join(CSRC, "gen_blur16_asm.py")          # writes blur16_asm.inc (the hand-scheduled row loop of blur16_stream)
+INC = os.path.join(CSRC, "blur16_asm.inc")
+
+
+def generate():
+    if not os.path.exists(INC) or os.path.getmtime(INC) < os.path.getmtime(GEN):
+        out = subprocess.run([sys.executable, GEN], capture_output=True, text=True, check=True).stdout
+        with open(INC, "w") as f:
+            f.write(out)
+
+
 def headers():
-    hs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    hs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".inc"))]
     hs.append(os.path.join(os.path.dirname(HERE), "include", "mi355_mosaic.h"))
     return hs
 
 
 def needs_build():
-    if not os.path.exists(LIB):
+    if not os.path.exists(LIB) or not os.path.exists(INC):
         return True
     t = os.path.getmtime(LIB)
-    return any(os.path.getmtime(p) > t for p in sources() + headers() + [os.path.abspath(__file__)])
+    return any(os.path.getmtime(p) > t for p in sources() + headers() + [GEN, os.path.abspath(__file__)])
 
 
 def compile_one(src):
@@ -64,6 +75,7 @@ def build(force=False):
             return LIB                      # GPU box without a toolchain change: use the prebuilt library
         raise RuntimeError("hipcc not found and no prebuilt libmi355mosaic.so")
     os.makedirs(OBJ, exist_ok=True)
+    generate()
     with ThreadPoolExecutor(max_workers=8) as ex:
         objs = list(ex.map(compile_one, sources()))
     cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs

@@ -98,6 +98,7 @@ struct Blur16Args {
     int w, h;
     int tiles_x, tiles_y;
     float k[2 * MAX_R + 1];
+    float kp[2 * (MAX_R + 1)];               // blur16_stream: tap pairs (k[t], k[t-1]) for t = 0 .. R, k[-1] = 0
     size_t fstride;                          // samples between the frames of a batch
     int nb;                                  // frames in the launch
 };
@@ -176,185 +177,82 @@ __global__ __launch_bounds__(256) void blur16_tile(Blur16Args a) {
 
 // ---- blur16_stream: barrier-free streaming variant for the big levels ---------------------------------------------------------------
 // Same arithmetic.  One WAVE owns a strip of 256 columns (4 per lane) and walks down L output rows of it: every input row is read
-// once from HBM (prefetched D rows ahead into registers), exchanged with the neighbour lanes through a wave-private LDS row (no
-// workgroup barrier anywhere: LDS operations of one wave execute in order), filtered horizontally from a sliding register window,
-// and kept in a register ring of the last NP >= 2R+1 row results; output row y leaves when row y + R has arrived, its taps taken
-// from the ring centre first, then the pairs (y + j, y - j).  The row loop is unrolled NP times, so every ring / prefetch index is a
-// compile-time constant.
-template <int R, int D, bool BGR>
-__device__ __forceinline__ void blur16_stream_body(const Blur16Args a, int L, int nstrip, int nseg) {
-    constexpr int N = 2 * R + 1;
-    constexpr int NP0 = ((N + D - 1) / D) * D;
-    constexpr int NP = (NP0 & 1) ? NP0 + D : NP0;   // even (two LDS rows alternate) and a multiple of D
-    constexpr int RA = (R + 3) & ~3, S = RA - R, SW = 256, BW = SW + 2 * RA;
-    constexpr int NG = (S + 2 * R + 4 + 3) / 4;
-    static_assert(NP % D == 0 && NP % 2 == 0 && NP >= N, "ring");
-    static_assert((D % 2 == 0) || true, "prefetch depth");
-    __shared__ v4f s_buf[4][2][(BW + 64) / 4];      // + 64 floats: dump area for lanes that have no halo / fix-up work
+// once from HBM (prefetched two rows ahead into registers), exchanged with the neighbour lanes through a wave-private LDS row (no
+// workgroup barrier anywhere: LDS operations of one wave execute in order), filtered horizontally from a rolling register window, and
+// kept in a register ring of the last 2R+2 row results; an output row leaves one step after its last row has arrived (its column pass
+// covers the LDS round trip of the next row's window), taps centre first, then the pairs (y + j, y - j).
+// The row loop itself is hand-scheduled gfx950 assembly (blur16_asm.inc, generated by gen_blur16_asm.py, which says what the hand
+// schedule does that hipcc's did not: counted vmcnt waits, tap-staggered packed products without register moves, ...).  The HIP code
+// below only works out the wave's geometry.
+#include "blur16_asm.inc"
+template <int R, bool BGR, bool DS>
+__device__ __forceinline__ void blur16_stream_body(const Blur16Args& a, int L, int nstrip, int nseg) {
+    constexpr int RA = (R + 3) / 4 * 4, SW = 256, BW = SW + 2 * RA;
+    constexpr int BUF = (BW + 8 + 63) & ~63;          // + 8 floats: dump area for lanes that have no halo sample to write
+    static_assert(2 * RA + R <= 64, "halo lanes");
+    __shared__ __attribute__((aligned(16))) float s_buf[4][2][BUF];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    // wave-uniform by construction; readfirstlane tells the compiler, so that rows, segments and their branches live in scalar registers
+    // wave-uniform by construction; readfirstlane tells the compiler, so that segment, strip and row pointers live in scalar registers
     int unit = __builtin_amdgcn_readfirstlane(xcd_remap(blockIdx.x, gridDim.x) * 4 + wave);
     const int per = nstrip * nseg, fr = unit / per;
     if (fr >= a.nb) return;
     unit -= fr * per;
-    const lvl_t* src = BGR ? nullptr : a.src + (size_t)fr * a.fstride;
+    const int seg = unit / nstrip, strip = unit - seg * nstrip;
+    if (seg >= nseg) return;
+    const int x0 = strip * SW, y0 = seg * L;          // L is even (launcher): the decimated rows are the even rows of a segment
+    const int lact = (a.h - y0 < L) ? a.h - y0 : L;
+    const int wv = a.w - x0;                          // valid columns of this strip (> R, checked by the launcher)
+    // columns: the lane's own four (clamped into the row for a partial last strip); one more sample for the lanes < 2 RA (the halos,
+    // reflect-101) and, in a partial last strip, for the lanes 2 RA .. 2 RA + R - 1: the reflected columns right of the image,
+    // written AFTER the main samples (LDS operations of one wave execute in order) over whatever the clamped main loads left there
+    const int xm = x0 + 4 * lane;
+    const int xl = xm < a.w - 4 ? xm : a.w - 4;
+    int hcol, hpos;
+    if (lane < RA) { hcol = x0 - RA + lane; hpos = lane; }
+    else if (lane < 2 * RA) { hcol = x0 + SW + (lane - RA); hpos = SW + lane; }
+    else if (wv < SW && lane < 2 * RA + R) { hcol = x0 + wv + (lane - 2 * RA); hpos = RA + wv + (lane - 2 * RA); }
+    else { hcol = x0; hpos = BW + (lane & 7); }
+    hcol = reflect101(hcol, a.w);
+    const size_t fro = (size_t)fr * a.fstride;
     const uint8_t* bgr = a.bgr[0]; int bws = a.bgr_ws[0];
     if (BGR) {
 #pragma unroll
         for (int q = 1; q < SIFT_BATCH_MAX; q++) if (fr == q) { bgr = a.bgr[q]; bws = a.bgr_ws[q]; }
     }
-    lvl_t* dst = a.dst + (size_t)fr * a.fstride;
-    lvl_t* ds = a.ds ? a.ds + (size_t)fr * a.fstride : nullptr;
-    const int seg = unit / nstrip, strip = unit - seg * nstrip;
-    if (seg >= nseg) return;
-    const int x0 = strip * SW, y0 = seg * L;
-    const int lact = (a.h - y0 < L) ? a.h - y0 : L;
-    const int nin = lact + 2 * R;
-    // columns: the lane's own four (clamped into the row for a partial last strip), one halo sample per lane (reflect-101), and for a
-    // partial last strip the reflected columns right of the image are patched inside LDS
-    const int xm = x0 + 4 * lane;
-    const int xl = xm < a.w - 4 ? xm : a.w - 4;
-    const int chalo = reflect101((lane < RA) ? x0 - RA + lane : (lane < 2 * RA ? x0 + SW + (lane - RA) : x0), a.w);
-    const int hpos = (lane < RA) ? lane : (lane < 2 * RA ? SW + lane : BW + lane - 2 * RA);
-    const int wv = a.w - x0;                         // valid columns of this strip (>= R + 1, checked by the launcher)
-    const bool patch = (wv < SW) && (lane < R);
-    const int p_src = patch ? RA + wv - 2 - lane : 0, p_dst = patch ? RA + wv + lane : BW + 32 + (lane & 31);
-    const int hm1 = a.h - 1;
-    auto src_row = [&](int i) {                     // source row of step i: reflect-101, clamped for the prefetch past the end
-        int gy = y0 - R + i;
-        gy = gy < 0 ? -gy : gy;
-        gy = gy > hm1 ? 2 * hm1 - gy : gy;
-        return gy < 0 ? 0 : gy;
-    };
-    struct Raw { unsigned m0, m1, m2; unsigned h; };          // level: m0 m1 = four samples, h = one; BGR: m0 m1 m2 = 12 bytes, h = 3 bytes
-    auto load_raw = [&](int i, Raw& r) {
-        const int gy = src_row(i);
-        if constexpr (BGR) {
-            const uint8_t* rp = bgr + (size_t)gy * bws;
-            const unsigned* q = reinterpret_cast<const unsigned*>(rp + 3 * xl);       // 3 * xl is a multiple of 12; rows are 4-byte aligned (launcher)
-            r.m0 = q[0]; r.m1 = q[1]; r.m2 = q[2];
-            const uint8_t* hp = rp + 3 * chalo;
-            r.h = (unsigned)hp[0] | ((unsigned)hp[1] << 8) | ((unsigned)hp[2] << 16);
-        } else {
-            const lvl_t* rp = src + (size_t)gy * a.w;
-            const uint2 q = *reinterpret_cast<const uint2*>(rp + xl);
-            r.m0 = q.x; r.m1 = q.y; r.m2 = 0;
-            r.h = (unsigned)(unsigned short)rp[chalo];
-        }
-    };
-    auto row_values = [&](const Raw& r, v4f& m, float& hv) {
-        if constexpr (BGR) {
-            auto g = [](unsigned b, unsigned gg, unsigned rr) { return (float)((int)((1868u * b + 9617u * gg + 4899u * rr + 8192u) >> 14) * FIXPT_SCALE); };
-            m.x = g(r.m0 & 255u, (r.m0 >> 8) & 255u, (r.m0 >> 16) & 255u);
-            m.y = g(r.m0 >> 24, r.m1 & 255u, (r.m1 >> 8) & 255u);
-            m.z = g((r.m1 >> 16) & 255u, r.m1 >> 24, r.m2 & 255u);
-            m.w = g((r.m2 >> 8) & 255u, (r.m2 >> 16) & 255u, r.m2 >> 24);
-            hv = g(r.h & 255u, (r.h >> 8) & 255u, (r.h >> 16) & 255u);
-        } else {
-            m.x = (float)(int)(short)(r.m0 & 0xffffu); m.y = (float)((int)r.m0 >> 16);
-            m.z = (float)(int)(short)(r.m1 & 0xffffu); m.w = (float)((int)r.m1 >> 16);
-            hv = (float)(int)(short)(r.h & 0xffffu);
-        }
-    };
-    Raw pf[D];
-#pragma unroll
-    for (int d = 0; d < D; d++) load_raw(d < nin ? d : nin - 1, pf[d]);
-    v2f ring01[NP], ring23[NP];
-#pragma unroll
-    for (int q = 0; q < NP; q++) { ring01[q] = (v2f){0.0f, 0.0f}; ring23[q] = (v2f){0.0f, 0.0f}; }
-    float* const bufs = reinterpret_cast<float*>(&s_buf[wave][0][0]);
-    // The exchange of a row through LDS is software-pipelined: row i + 1 is written to LDS before row i is filtered and patched (its
-    // reflected columns at the right image border) after the row pass, so that a step waits for ONE LDS round trip (the window read
-    // at its start) instead of four in a row (write, patch read, patch write, window read).
-    auto put_row = [&](const Raw& r, float* buf) {
-        v4f m; float hv;
-        row_values(r, m, hv);
-        *reinterpret_cast<v4f*>(buf + RA + 4 * lane) = m;
-        buf[hpos] = hv;
-    };
-    auto patch_row = [&](float* buf) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        { const float t = buf[p_src]; buf[p_dst] = t; }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    };
-    put_row(pf[0], bufs);
-    load_raw(D < nin ? D : nin - 1, pf[0]);
-    patch_row(bufs);
-    for (int base = 0; base < nin; base += NP) {
-        auto step = [&](auto jc) -> bool {
-            constexpr int j = decltype(jc)::value;
-            const int i = base + j;
-            if (i >= nin) return false;
-            float* const buf = bufs + (j & 1) * (BW + 64);
-            float* const nbuf = bufs + ((j + 1) & 1) * (BW + 64);
-            const v4f* w4 = reinterpret_cast<const v4f*>(buf) + lane;
-            float e[NG * 4];
-#pragma unroll
-            for (int g = 0; g < NG; g++) { const v4f tt = w4[g]; e[4 * g] = tt.x; e[4 * g + 1] = tt.y; e[4 * g + 2] = tt.z; e[4 * g + 3] = tt.w; }
-            const bool more = i + 1 < nin;
-            if (more) {
-                put_row(pf[(j + 1) % D], nbuf);
-                load_raw(i + 1 + D < nin ? i + 1 + D : nin - 1, pf[(j + 1) % D]);
-            }
-            // row pass: ascending taps, product and sum rounded separately
-            v2f r01, r23;
-            {
-                const v2f kk = {a.k[0], a.k[0]};
-                r01 = kk * (v2f){e[S], e[S + 1]}; r23 = kk * (v2f){e[S + 2], e[S + 3]};
-            }
-#pragma unroll
-            for (int t = 1; t <= 2 * R; t++) {
-                const v2f kk = {a.k[t], a.k[t]};
-                const v2f p01 = kk * (v2f){e[S + t], e[S + t + 1]}, p23 = kk * (v2f){e[S + t + 2], e[S + t + 3]};
-                r01 = r01 + p01; r23 = r23 + p23;
-            }
-            ring01[j % NP] = r01; ring23[j % NP] = r23;
-            if (more) patch_row(nbuf);
-            if (i >= 2 * R) {
-                // column pass of output row i - 2R: ring slots of rows (i - R) +- jj
-                constexpr int c = ((j - R) % NP + NP) % NP;
-                v2f s01, s23;
-                { const v2f kk = {a.k[R], a.k[R]}; s01 = kk * ring01[c]; s23 = kk * ring23[c]; }
-#pragma unroll
-                for (int jj = 1; jj <= R; jj++) {
-                    const int up = ((j - R + jj) % NP + NP) % NP, dn = ((j - R - jj) % NP + NP) % NP;
-                    const v2f kk = {a.k[R + jj], a.k[R + jj]};
-                    const v2f a01 = ring01[up] + ring01[dn], a23 = ring23[up] + ring23[dn];
-                    const v2f p01 = kk * a01, p23 = kk * a23;
-                    s01 = s01 + p01; s23 = s23 + p23;
-                }
-                const int o0 = sat16(s01.x), o1 = sat16(s01.y), o2 = sat16(s23.x), o3 = sat16(s23.y);
-                const int gy = y0 + i - 2 * R;
-                if (xm < a.w) {
-                    *reinterpret_cast<uint2*>(dst + (size_t)gy * a.w + xm) =
-                        make_uint2((unsigned)(o0 & 0xffff) | ((unsigned)o1 << 16), (unsigned)(o2 & 0xffff) | ((unsigned)o3 << 16));
-                    if (ds && !(gy & 1) && (gy >> 1) < (a.h >> 1))
-                        *reinterpret_cast<unsigned*>(ds + (size_t)(gy >> 1) * (a.w >> 1) + (xm >> 1)) = (unsigned)(o0 & 0xffff) | ((unsigned)o2 << 16);
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);       // keep the rows apart: the scheduler otherwise interleaves them and spills
-            return true;
-        };
-        if (!static_rows<0, NP>(step)) return;
-    }
+    const int rowb = BGR ? bws : 2 * a.w;             // bytes per source row
+    int gy = y0 - R, dir = 1;                         // first source row of the reflect-101 walk
+    if (gy < 0) { gy = -gy; dir = -1; }
+    const unsigned long long rp = (unsigned long long)(BGR ? reinterpret_cast<uintptr_t>(bgr) : reinterpret_cast<uintptr_t>(a.src + fro)) + (unsigned long long)gy * (unsigned)rowb;
+    const unsigned moff = BGR ? 3u * xl : 2u * xl;    // 3 xl is a multiple of 12; rows are 4-byte aligned (launcher)
+    unsigned hoff, hsh = 0;
+    if (BGR) {                                        // the 8 bytes inside the row that hold the halo pixel's three
+        const int b0 = 3 * hcol; int st = b0 & ~3; if (st + 8 > bws) st = bws - 8;
+        hoff = (unsigned)st; hsh = 8u * (unsigned)(b0 - st);
+    } else hoff = 2u * hcol;
+    const unsigned lds0 = (unsigned)reinterpret_cast<uintptr_t>(&s_buf[wave][0][0]);
+    const unsigned lds_win = lds0 + 16u * lane, lds_main = lds0 + 4u * (RA + 4 * lane), lds_halo = lds0 + 4u * hpos;
+    const unsigned long long dp = (unsigned long long)reinterpret_cast<uintptr_t>(a.dst + fro) + 2ull * (unsigned long long)y0 * a.w;
+    const unsigned long long dsp = DS ? (unsigned long long)reinterpret_cast<uintptr_t>(a.ds + fro) + 2ull * (unsigned long long)(y0 >> 1) * (a.w >> 1) : 0ull;
+    const unsigned doff = 2u * xm, dsoff = 2u * (xm >> 1);
+    const unsigned long long smask = __ballot(xm < a.w);                 // lanes that store (partial last strip)
+    const unsigned long long kp = (unsigned long long)reinterpret_cast<uintptr_t>(__builtin_amdgcn_kernarg_segment_ptr()) + offsetof(Blur16Args, kp);
+    const int n = lact + 2 * R + 1;                   // steps: 2R + 1 rows fill the ring, then one output row per step
+    const int hm1 = a.h - 1, dstr = 2 * a.w;
+    (void)hsh;
+#define BLUR_ASM_CALL(NAME) NAME(lds_win, lds_main, lds_halo, moff, hoff, doff, dsoff, rp, dp, dsp, kp, smask, rowb, gy, dir, hm1, dstr, n)
+    if constexpr (BGR) { static_assert(R == 6, "base level"); blur16_asm_r6_bgr(lds_win, lds_main, lds_halo, moff, hoff, doff, dsoff, hsh, rp, dp, dsp, kp, smask, rowb, gy, dir, hm1, dstr, n); }
+    else if constexpr (R == 5) BLUR_ASM_CALL(blur16_asm_r5);
+    else if constexpr (R == 6) BLUR_ASM_CALL(blur16_asm_r6);
+    else if constexpr (R == 8 && DS) BLUR_ASM_CALL(blur16_asm_r8_ds);
+    else if constexpr (R == 8) BLUR_ASM_CALL(blur16_asm_r8);
+    else if constexpr (R == 10) BLUR_ASM_CALL(blur16_asm_r10);
+    else if constexpr (R == 13) BLUR_ASM_CALL(blur16_asm_r13);
+#undef BLUR_ASM_CALL
 }
-
-// two waves per SIMD (256 registers each) for the long kernels, three (168 registers) for the short ones whose ring is small
-template <int R, int D, bool BGR>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void blur16_stream(Blur16Args a, int L, int nstrip, int nseg) {
-    blur16_stream_body<R, D, BGR>(a, L, nstrip, nseg);
-}
-template <int R, int D, bool BGR>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void blur16_stream3(Blur16Args a, int L, int nstrip, int nseg) {
-    blur16_stream_body<R, D, BGR>(a, L, nstrip, nseg);
-}
-template <int R, int D, bool BGR>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void blur16_stream4(Blur16Args a, int L, int nstrip, int nseg) {
-    blur16_stream_body<R, D, BGR>(a, L, nstrip, nseg);
+// W waves per SIMD: the launcher sizes the grid to exactly W x 1024 waves, and the cap keeps the dispatcher from stacking them unevenly
+template <int R, bool BGR, bool DS, int W>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W, W))) void blur16_stream(Blur16Args a, int L, int nstrip, int nseg) {
+    blur16_stream_body<R, BGR, DS>(a, L, nstrip, nseg);
 }
 
 // next octave seed: every second pixel of level 3 (cv::resize INTER_NEAREST to half size)
@@ -1339,12 +1237,14 @@ int gauss_kernel_host(double sigma, float* k) {
     return r;
 }
 
-// does this level go through blur16_stream?  (8-byte aligned rows, last strip wider than the largest radius, enough strips x frames to fill the chip)
+// does this level go through blur16_stream?  (8-byte aligned rows, last strip wider than the largest radius, enough strips x frames to fill the chip;
+// the decimated copy needs an even height: the even rows of every segment are then the even rows of the image)
 inline bool blur_streams(const Blur16Args& a, bool bgr, int R, int stream_mode) {
-    const bool has_r = R == 5 || R == 6 || R == 8 || R == 10 || R == 13;
+    const bool has_r = bgr ? R == 6 : (R == 5 || R == 6 || R == 8 || R == 10 || R == 13);
     bool ok = stream_mode && has_r && (a.w & 3) == 0 && ((a.w & 255) == 0 || (a.w & 255) > MAX_R) && a.w >= 512 && a.h >= 64;
-    if (bgr) { for (int f = 0; f < a.nb; f++) ok = ok && ((uintptr_t)a.bgr[f] & 3) == 0 && (a.bgr_ws[f] & 3) == 0; }
+    if (bgr) { for (int f = 0; f < a.nb; f++) ok = ok && ((uintptr_t)a.bgr[f] & 3) == 0 && (a.bgr_ws[f] & 3) == 0 && a.bgr_ws[f] >= 3 * a.w; }
     else ok = ok && ((uintptr_t)a.src & 7) == 0;
+    if (a.ds) ok = ok && R == 8 && (a.h & 1) == 0;
     return ok && ((uintptr_t)a.dst & 7) == 0 && (a.fstride & 3) == 0;
 }
 inline void stream_grid(int w, int h, int& L, int& nstrip, int& nseg, int nb = 1, int waves = 2) {
@@ -1355,37 +1255,42 @@ inline void stream_grid(int w, int h, int& L, int& nstrip, int& nseg, int nb = 1
     nseg = (units_target + nstrip * nb - 1) / (nstrip * nb);
     L = (h + nseg - 1) / nseg;
     if (L < stream_minl) L = stream_minl;
+    L = (L + 1) & ~1;
     nseg = (h + L - 1) / L;
 }
 template <bool BGR>
-bool launch_blur(hipStream_t st, int R, const Blur16Args& a, int stream_mode, bool* streamed = nullptr) {
+bool launch_blur(hipStream_t st, int R, const Blur16Args& a_in, int stream_mode, bool* streamed = nullptr) {
+    Blur16Args a = a_in;
     const int nb = a.nb > 1 ? a.nb : 1;
     if (streamed) *streamed = false;
     if (blur_streams(a, BGR, R, stream_mode)) {
-        // barrier-free streaming kernel: ~2 waves per SIMD over the whole chip (2048 waves), segments of >= 64 rows, all frames of a batch in one launch
-        // waves per SIMD: the register ring of the row results (4 x (2R + 2) registers) decides: R <= 8 fits 128 registers (4 waves),
-        // R = 10 fits 168 (3 waves), R = 13 fits 168 with two rows of prefetch instead of four (12 bytes of scratch; 5 % faster than 2 waves)
+        // barrier-free streaming kernel over the whole chip: W waves per SIMD (W x 1024 waves, one round), segments of >= 64 rows, all frames of
+        // a batch in one launch.  The register ring of the row results (4 x (2R + 2) registers) decides W: R <= 8 fits 128 registers, R = 10 / 13 168
         static const int w4 = [] { const char* e = getenv("MI355_STREAM_W4"); return e ? atoi(e) : 8; }();
-        static const int w3 = [] { const char* e = getenv("MI355_STREAM_W3"); return e ? atoi(e) : 13; }();
-        const int waves = (R <= w4 && R <= 8) ? 4 : ((R <= w3 && R <= 13) ? 3 : 2);
-        int L, nstrip, nseg;
-        stream_grid(a.w, a.h, L, nstrip, nseg, nb, waves);
-        const int units = nstrip * nseg * nb;
-        const dim3 grid((units + 3) / 4), block(256);
-        if (streamed) *streamed = true;
-        switch (R) {
-#define CASE(RR, DD) case RR: if (waves == 4) hipLaunchKernelGGL((blur16_stream4<RR, DD, BGR>), grid, block, 0, st, a, L, nstrip, nseg); \
-                              else if (waves == 3) hipLaunchKernelGGL((blur16_stream3<RR, DD, BGR>), grid, block, 0, st, a, L, nstrip, nseg); \
-                              else hipLaunchKernelGGL((blur16_stream<RR, DD, BGR>), grid, block, 0, st, a, L, nstrip, nseg); return true;
-            CASE(5, 4) CASE(6, 4) CASE(8, 4)
-#undef CASE
-            case 10: if (waves == 3) hipLaunchKernelGGL((blur16_stream3<10, 4, BGR>), grid, block, 0, st, a, L, nstrip, nseg);
-                     else hipLaunchKernelGGL((blur16_stream<10, 4, BGR>), grid, block, 0, st, a, L, nstrip, nseg);
-                     return true;
-            case 13: if (waves == 3) hipLaunchKernelGGL((blur16_stream3<13, 2, BGR>), grid, block, 0, st, a, L, nstrip, nseg);
-                     else hipLaunchKernelGGL((blur16_stream<13, 4, BGR>), grid, block, 0, st, a, L, nstrip, nseg);
-                     return true;
-            default: break;
+        const int waves = (R <= w4 && R <= 8) ? 4 : 3;
+        double ksum = 0.0;
+        for (int t = 0; t <= 2 * R; t++) ksum += std::fabs((double)a.k[t]);
+        if (ksum < 2.6) {                            // the kernel's rounding assumes results in [0, 32767]: samples <= 255 * 48, taps positive and normalised
+            for (int t = 0; t <= R; t++) { a.kp[2 * t] = a.k[t]; a.kp[2 * t + 1] = t ? a.k[t - 1] : 0.0f; }
+            int L, nstrip, nseg;
+            stream_grid(a.w, a.h, L, nstrip, nseg, nb, waves);
+            const int units = nstrip * nseg * nb;
+            const dim3 grid((units + 3) / 4), block(256);
+            if (streamed) *streamed = true;
+#define LAUNCH(RR, DS, WW) hipLaunchKernelGGL((blur16_stream<RR, BGR, DS, WW>), grid, block, 0, st, a, L, nstrip, nseg); return true
+            if constexpr (BGR) { if (waves == 4) { LAUNCH(6, false, 4); } else { LAUNCH(6, false, 3); } }
+            else {
+                switch (R) {
+                    case 5: if (waves == 4) { LAUNCH(5, false, 4); } else { LAUNCH(5, false, 3); }
+                    case 6: if (waves == 4) { LAUNCH(6, false, 4); } else { LAUNCH(6, false, 3); }
+                    case 8: if (a.ds) { if (waves == 4) { LAUNCH(8, true, 4); } else { LAUNCH(8, true, 3); } }
+                            else { if (waves == 4) { LAUNCH(8, false, 4); } else { LAUNCH(8, false, 3); } }
+                    case 10: LAUNCH(10, false, 3);
+                    case 13: LAUNCH(13, false, 3);
+                    default: break;
+                }
+            }
+#undef LAUNCH
         }
     }
     const dim3 grid(a.tiles_x * a.tiles_y, nb), block(256);
@@ -1705,7 +1610,13 @@ static int sift_run_batch(mi355_ctx* ctx, SiftWork* s) {
             a.src = oc.lv[i - 1]; a.dst = oc.lv[i];
             memcpy(a.k, s->kern[i], sizeof(float) * (2 * s->radius[i] + 1));
             // the level that seeds the next octave writes its decimation on the way out (saves re-reading it)
-            if (i == N_LAYERS && o + 1 < s->n_oct && (oc.w & 3) == 0 && (s->P.oc[o + 1].w == (oc.w >> 1)) && (s->P.oc[o + 1].h == (oc.h >> 1))) { a.ds = s->P.oc[o + 1].lv[0]; ds_fused = true; }
+            if (i == N_LAYERS && o + 1 < s->n_oct && (oc.w & 3) == 0 && (s->P.oc[o + 1].w == (oc.w >> 1)) && (s->P.oc[o + 1].h == (oc.h >> 1))) {
+                a.ds = s->P.oc[o + 1].lv[0]; ds_fused = true;
+                if (!blur_streams(a, false, s->radius[i], ctx->blur_stream)) {         // (odd height, unusual radius:) rather stream without the copy
+                    Blur16Args b = a; b.ds = nullptr;
+                    if (blur_streams(b, false, s->radius[i], ctx->blur_stream)) { a.ds = nullptr; ds_fused = false; }
+                }
+            }
             const bool streams = blur_streams(a, false, s->radius[i], ctx->blur_stream);
             ProfScope ps(ctx, streams ? "gauss_stream" : "gauss", level_bytes * 2.0, st);   // one read + one write of the level
             if (!launch_blur<false>(st, s->radius[i], a, ctx->blur_stream)) { ctx->set_error("sift: unsupported kernel radius"); return MI355_ERR_FAILED; }
