@@ -60,7 +60,7 @@ extern "C" int mi355_create(mi355_ctx** out, const mi355_params* params, int dev
     if (getenv("MI355_SERIAL_HEAVY")) c->serial_heavy = 1;
     if (const char* e = getenv("MI355_SIFT_SLOTS")) { const int v = atoi(e); c->sift_nslots = v < 1 ? 1 : (v > 4 ? 4 : v); }
     if (const char* e = getenv("MI355_XSTREAM_MIN_W")) { const int v = atoi(e); c->xstream_min_w = v < 256 ? 256 : v; }
-    if (const char* e = getenv("MI355_SIFT_BATCH")) { const int v = atoi(e); c->sift_batch = v < 1 ? 1 : (v > 16 ? 16 : v); }
+    if (const char* e = getenv("MI355_SIFT_BATCH")) { const int v = atoi(e); c->sift_batch = v < 1 ? 1 : (v > 32 ? 32 : v); }
     *out = c;
     return MI355_OK;
 }
@@ -360,7 +360,7 @@ extern "C" int mi355_set_option(mi355_ctx* ctx, const char* name, int value) {
     if (std::string(name) == "sift_batch") {
         int rc = mi_resolve_features(ctx);
         if (rc != MI355_OK) return rc;
-        ctx->sift_batch = value < 1 ? 1 : (value > 16 ? 16 : value);
+        ctx->sift_batch = value < 1 ? 1 : (value > 32 ? 32 : value);
         return MI355_OK;
     }
     if (std::string(name) == "blur_stream") { ctx->blur_stream = value ? 1 : 0; return MI355_OK; }

@@ -1,0 +1,16 @@
+#!/bin/bash
+cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+O=gpurun_out/pmc_match; rm -rf $O; mkdir -p $O
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES --kernel-include-regex "bf_match" --output-format csv -d $O/p1 -o p -- python scratch/ransac_time.py 200 > $O/log1.txt 2>&1
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE --kernel-include-regex "bf_match" --output-format csv -d $O/p2 -o p -- python scratch/ransac_time.py 200 > $O/log2.txt 2>&1
+python - <<'PY'
+import csv, glob, collections
+for d in ("p1", "p2"):
+    f = glob.glob("gpurun_out/pmc_match/%s/**/*counter_collection.csv" % d, recursive=True)
+    if not f: print(d, "no csv", open("gpurun_out/pmc_match/log%s.txt" % d[1]).read()[-500:]); continue
+    acc = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.Counter()
+    for r in csv.DictReader(open(f[0])):
+        k = r["Kernel_Name"][:30] + " grid=" + r.get("Grid_Size", "?")
+        acc[k][r["Counter_Name"]] += float(r["Counter_Value"]); cnt[(k, r["Counter_Name"])] += 1
+    for k, v in acc.items(): print(d, k, {c: "%.4g" % (x / cnt[(k, c)]) for c, x in v.items()})
+PY
