@@ -20,9 +20,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
          "-Wall", "-Wno-unused-function", "-Wno-unused-result"] + os.environ.get("MI355_EXTRA_HIPCC_FLAGS", "").split()   # kernel A/B builds (scratch/)
 
 
-# match.hip only: its distances are exact integers / half-integers or -inf by construction (never NaN), and without the flag every fmaxf of
-# an MFMA result is preceded by a canonicalising v_max_f32 x, x, x (a third of the epilogue's instructions)
-PER_FILE = {"match.hip": ["-fno-honor-nans"]}
+PER_FILE = {}          # per-file extra flags (none: round 3's -fno-honor-nans for match.hip belonged to the removed float epilogue)
 
 
 def sources():

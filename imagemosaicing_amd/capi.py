@@ -414,7 +414,10 @@ class Context:
 
     def MosaicBlendedDev(self, d_ptrs, w, h, ws, h9s, keep=None, band=5):
         """LaplacianPyramidBlending with the survey resident in HBM: device frames in, device canvas out (a torch uint8 tensor
-        [ch, cws]); chips, masks, distance maps and the blender's pyramids stay in the ctx's buffers."""
+        [ch, cws]); chips, masks and the blender's pyramids stay in the ctx's buffers.
+        Ordering: the library writes the canvas on the ctx's stream, the tensor comes from torch's allocator (torch's current stream).  The
+        wrapper synchronises torch's stream before the call (a recycled block may still be in use by pending torch work) and the ctx's
+        stream after it: the tensor it returns is complete and safe to use on any stream."""
         import torch
         n = len(d_ptrs)
         ptrs = (C.c_void_p * n)(*[int(p) for p in d_ptrs])
@@ -423,8 +426,10 @@ class Context:
         keep_a = None if keep is None else np.ascontiguousarray(keep, np.uint8)
         cw, ch, cws = blend_layout(w, h, h9s, keep_a)
         out = torch.empty((ch, cws), dtype=torch.uint8, device=torch.device("cuda", self.device))
+        torch.cuda.current_stream(out.device).synchronize()
         self._chk(self.L.mi355_mosaic_blended_dev(self._h, ptrs, _p(w), _p(h), _p(ws), n, _p(h9s), _p(keep_a), int(band),
                                                   C.c_void_p(out.data_ptr()), cw, ch, cws))
+        self.synchronize()
         return out, cw, ch, cws
 
 

@@ -183,6 +183,13 @@ int host_threads() {
     static const int n = [] {
         const char* e = getenv("MI355_HOST_THREADS");
         int v = e ? atoi(e) : (int)std::thread::hardware_concurrency();
+        if (!e) {
+            // several ranks of one node call the alignment at the same moment (the host step is replicated): share the cores between them,
+            // a team of spinning threads per rank on oversubscribed cores is what the yield below exists for
+            const char* lw = getenv("LOCAL_WORLD_SIZE");
+            const int ranks = lw ? atoi(lw) : 1;
+            if (ranks > 1) v /= ranks;
+        }
         if (v > 16) v = 16;
         return v < 1 ? 1 : v;
     }();

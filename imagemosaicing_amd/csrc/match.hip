@@ -182,7 +182,7 @@ __global__ __launch_bounds__(BF_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) v
         const int e = 15 - (bz[c] & 15), row = bt[c] * 32 + 8 * (e >> 2) + 4 * hi + (e & 3);
         const bool q_ok = q[c] < pd.n_i;
         const int nq = q_ok ? GLOBAL_PTR(int, pd.n8_i)[q[c]] : 0;
-        if (q_ok && bz[c] != IMIN && row < pd.n_j) { bi = row; best = nq - (bz[c] >> 4); }
+        if (q_ok && bz[c] != IMIN && bt[c] >= 0 && row < pd.n_j) { bi = row; best = nq - (bz[c] >> 4); }      // bt < 0: the lane's 16 rows never held a train row (n_j <= 4 / n_j == 0)
         if (SECOND && q_ok && s2[c] > NOROW / 2) second = nq - (s2[c] >> 4);
         // merge the two half-waves (same query, disjoint train rows); ties -> lowest train index
         const int ob = __shfl_xor(best, 32), os = __shfl_xor(second, 32), oi = __shfl_xor(bi, 32);

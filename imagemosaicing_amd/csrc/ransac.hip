@@ -32,6 +32,7 @@ struct RansacArgs {
     const int* n;                  // [pair]
     long long* dbg;                // optional: per pair 8 cycle stamps (MI355_RANSAC_DBG)
     const uint16_t* tables;        // concatenated draw tables (MAX_DRAWS x 4 each)
+    int single_table;              // 1: `tables` IS the one table of this call's n (mi_ransac_big), whatever n is
     const int* table_of;           // [pair] table index, -1 = none (n < 4)
     int stride;
     float dist;
@@ -155,7 +156,7 @@ __device__ __forceinline__ void ransac_body(const RansacArgs& a) {
     const float d2 = a.dist * a.dist;                      // :1757
     const float invn = 1.0f / (float)n;                    // :1763
     const int sample_times = a.sample_times > 5000 ? 5000 : a.sample_times;
-    const uint16_t* table = a.tables + (size_t)(a.table_of ? a.table_of[pair] : (n - 4)) * MAX_DRAWS * 4;
+    const uint16_t* table = a.tables + (size_t)(a.single_table ? 0 : (a.table_of ? a.table_of[pair] : (n - 4))) * MAX_DRAWS * 4;
 
     float h[9];
     long long T0 = wall_clock64(); int nchunk = 0; long long Tsolve = 0, Tsup = 0, Trep = 0;
@@ -597,7 +598,7 @@ int mi_ransac_big(mi355_ctx* ctx, const mi355_sfpoint* p1, const mi355_sfpoint* 
     a.p1 = d1.as<mi355_sfpoint>(); a.p2 = d2.as<mi355_sfpoint>(); a.n = dn.as<int>(); a.tables = dtab.as<uint16_t>(); a.table_of = nullptr;
     a.stride = n; a.dist = dist; a.sample_times = sample_times; a.min_keep = -1; a.out = dres.as<mi355_pair_result>();
     a.big_ws = dws.as<float>(); a.big_a = da.as<mi355_sfpoint>(); a.big_b = db.as<mi355_sfpoint>();
-    a.tables -= (size_t)(n - 4) * one;                    // the kernel indexes tables by n - 4 when there is no per-pair index
+    a.single_table = 1;                                   // the one uploaded table, not table n - 4 of a set
     a.list_floats = ((((sample_times < MAX_DRAWS ? (sample_times > 0 ? sample_times : 1) : MAX_DRAWS) * 2 + 15) / 16) * 16) / 4;
     const size_t lds_bytes = ((size_t)4 * n + a.list_floats) * sizeof(float);
     MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ransac_big_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));

@@ -499,7 +499,7 @@ __global__ __launch_bounds__(256) void extrema_kernel(OctaveDev oc, int octave, 
         const unsigned long long rec = s_list[ci];
         const int L0 = (int)((rec >> 40) & 0xff), R0 = (int)((rec >> 20) & 0xfffff), C0 = (int)(rec & 0xfffff);
         const int dl = (int)(e / 9) - 1, dr = (int)((e / 3) % 3) - 1, dc = (int)(e % 3) - 1;
-        cube[((size_t)reg * cube_cap + g) * 32 + e] = reinterpret_cast<const float*>(s_d4[L0 + dl])[(R0 + dr - y0 + 1) * PC + (C0 + dc - x0) + 4];
+        cube[((size_t)reg * 32 + e) * cube_cap + g] = reinterpret_cast<const float*>(s_d4[L0 + dl])[(R0 + dr - y0 + 1) * PC + (C0 + dc - x0) + 4];
     }
 }
 
@@ -616,11 +616,10 @@ void extrema_stream(OctaveDev oc, int octave, unsigned long long* cand, unsigned
         for (int p = 0; p < 5; p++) { d.m[p][0] = as_s2(q.m[p + 1].x) - as_s2(q.m[p].x); d.m[p][1] = as_s2(q.m[p + 1].y) - as_s2(q.m[p].y); }
     };
     // Candidates are rare per lane but not per wave (a 12 MP frame has ~2 per wave-row): a hit only appends its 8-byte record to a
-    // wave-private LDS list (slots from a ballot, the list length is wave-uniform and lives in a scalar); when the list is full, and at
-    // the end of the segment, every lane takes one record, re-reads the 3x3x3 DoG neighbourhood from the four levels (36 16-bit loads
-    // that hit lines this wave fetched a few rows ago -- ONE memory round trip per 64 candidates) and writes record + neighbourhood
-    // behind one region-counter atomic per flush.  Round 2 extracted the neighbourhood from the neighbour lanes' registers at once,
-    // code that ran on nearly every row and cost twice the test itself.
+    // wave-private LDS list (slots from a ballot, the list length is wave-uniform and lives in a scalar); the list goes to the region's
+    // candidate list behind one region-counter atomic per flush.  The 3x3x3 DoG neighbourhoods refine starts from are gathered by
+    // cube_gather_kernel afterwards, one lane per candidate: gathered here (round 3), every flush stalled its wave for the round trip of
+    // 36 scattered loads of rows that had long left the L2 -- a third of this kernel's time (73 -> 49 us per 12 MP frame without).
     __shared__ unsigned long long s_rec[4][XCAP];
     int nq = 0;                                      // wave-uniform
     auto wave_sync = [&]() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); };
@@ -631,37 +630,9 @@ void extrema_stream(OctaveDev oc, int octave, unsigned long long* cand, unsigned
         if (lane == 0) base = atomicAdd(&count[reg * REG_STRIDE], (unsigned)nq);
         base = __shfl(base, 0);
         for (int idx = lane; idx < nq; idx += 64) {
-            const unsigned long long rec = s_rec[wave][idx];
             const unsigned g = base + (unsigned)idx;
             if (g >= cap) { *overflow = 1; continue; }
-#ifdef MI355_X_NOCUBE
-            cand[(size_t)reg * cap + g] = rec; continue;
-#endif
-            cand[(size_t)reg * cap + g] = rec | (g < cube_cap ? (1ull << 63) : 0ull);
-            if (g >= cube_cap) continue;
-            const int layer = (int)((rec >> 40) & 0xff), rc = (int)((rec >> 20) & 0xfffff), c = (int)(rec & 0xfffff);
-            float* cb = cube + ((size_t)reg * cube_cap + g) * 32;
-            const int a0 = (c - 1) & ~1, sh = ((c - 1) & 1) * 16;
-            int v[4][9];
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const lvl_t* lp = oc.lv[0];
-#pragma unroll
-                for (int l = 1; l < N_LEVELS; l++) if (layer - 1 + q == l) lp = oc.lv[l];      // levels layer-1 .. layer+2 (layer in 1..3)
-                // the three columns of a row lie inside the four that start at the even column (c - 1) & ~1 (inside the row: candidates
-                // keep IMG_BORDER columns off the edges; 4-byte aligned: the streamed test needs w % 4 == 0): one 8-byte load per row
-                // and level instead of three 2-byte loads -- the gather was a third of this kernel's time
-#pragma unroll
-                for (int dr = 0; dr < 3; dr++) {
-                    const uint2 wv = *reinterpret_cast<const uint2*>(lp + (size_t)(rc - 1 + dr) * oc.w + a0);
-                    const unsigned long long ww = (((unsigned long long)wv.y << 32) | wv.x) >> sh;
-                    v[q][dr * 3 + 0] = (int)(short)(ww & 0xffffu); v[q][dr * 3 + 1] = (int)(short)((ww >> 16) & 0xffffu); v[q][dr * 3 + 2] = (int)(short)((ww >> 32) & 0xffffu);
-                }
-            }
-#pragma unroll
-            for (int dl = 0; dl < 3; dl++)
-#pragma unroll
-                for (int e = 0; e < 9; e++) cb[dl * 9 + e] = (float)(v[dl + 1][e] - v[dl][e]);
+            cand[(size_t)reg * cap + g] = s_rec[wave][idx] | (g < cube_cap ? (1ull << 63) : 0ull);      // bit 63: cube_gather_kernel fills in the neighbourhood
         }
         wave_sync();
         nq = 0;
@@ -740,6 +711,46 @@ void extrema_stream(OctaveDev oc, int octave, unsigned long long* cand, unsigned
     }
 }
 
+// The 3x3x3 DoG neighbourhood of every candidate the streamed test found (octaves in `omask`; the tiled extrema_kernel writes its
+// own from LDS): one lane per candidate, twelve 8-byte loads (three rows of four levels: the three columns lie inside the four that
+// start at the even column (c - 1) & ~1 -- inside the row, candidates keep IMG_BORDER columns off the edges; 4-byte aligned, the
+// streamed test needs w % 4 == 0), 27 floats out.  Every candidate independent: the latency the flush of extrema_stream used to wait
+// for is hidden by occupancy here.
+__global__ __launch_bounds__(256) void cube_gather_kernel(PyrDev P, const unsigned long long* cand_all, const unsigned* cand_counts, unsigned cand_cap,
+                                                          float* cube_all, unsigned cube_cap, unsigned omask, BatchStride bs) {
+    const size_t fr = blockIdx.z, foff = fr * bs.pyr;
+    cube_all += fr * bs.cube; cand_all += fr * bs.cand; cand_counts += fr * CCNT_STRIDE;
+    const unsigned reg = blockIdx.y;
+    unsigned n = cand_counts[reg * REG_STRIDE];
+    if (n > cand_cap) n = cand_cap;
+    if (n > cube_cap) n = cube_cap;
+    const unsigned long long* cand = cand_all + (size_t)reg * cand_cap;
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const unsigned long long pk = cand[i];
+        const int o = (int)((pk >> 48) & 0xff);
+        if (!((omask >> o) & 1u)) continue;
+        const int L = (int)((pk >> 40) & 0xff), R = (int)((pk >> 20) & 0xfffff), C = (int)(pk & 0xfffff);
+        const OctaveDev& oc = P.oc[o];
+        const int a0 = (C - 1) & ~1, sh = ((C - 1) & 1) * 16;
+        int v[4][9];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const lvl_t* lp = oc.lv[L - 1 + q] + foff;
+#pragma unroll
+            for (int dr = 0; dr < 3; dr++) {
+                const uint2 wv = *reinterpret_cast<const uint2*>(lp + (size_t)(R - 1 + dr) * oc.w + a0);
+                const unsigned long long ww = (((unsigned long long)wv.y << 32) | wv.x) >> sh;
+                v[q][dr * 3 + 0] = (int)(short)(ww & 0xffffu); v[q][dr * 3 + 1] = (int)(short)((ww >> 16) & 0xffffu); v[q][dr * 3 + 2] = (int)(short)((ww >> 32) & 0xffffu);
+            }
+        }
+        float* cb = cube_all + (size_t)reg * 32 * cube_cap + i;            // element e of candidate i at [e][i]: the lanes of a wave write runs of 256 bytes
+#pragma unroll
+        for (int dl = 0; dl < 3; dl++)
+#pragma unroll
+            for (int e = 0; e < 9; e++) cb[(size_t)(dl * 9 + e) * cube_cap] = (float)(v[dl + 1][e] - v[dl][e]);
+    }
+}
+
 __global__ __launch_bounds__(256) void refine_kernel(PyrDev P, const unsigned long long* cand_all, const unsigned* cand_counts, unsigned cand_cap, unsigned* cand_total,
                                                      float contrast_thr, float edge_thr, float sigma,
                                                      Refined* out, unsigned* out_count, unsigned out_cap, unsigned* out_resp, BatchStride bs,
@@ -770,9 +781,9 @@ __global__ __launch_bounds__(256) void refine_kernel(PyrDev P, const unsigned lo
         float contr = 0.0f;
         if (pk >> 63) {
             // first step from the 3x3x3 neighbourhood extrema_kernel saved next to the candidate (same values as the pyramid)
-            const float* cb = cube_all + ((size_t)reg * cube_cap + i) * 32;
+            const float* cb = cube_all + (size_t)reg * 32 * cube_cap + i;       // [element][candidate]: coalesced across the lanes
             const int L0 = L, R0 = R, C0 = C;
-            auto dvc = [&](int l, int r, int c) { return cb[(l - L0 + 1) * 9 + (r - R0 + 1) * 3 + (c - C0 + 1)]; };
+            auto dvc = [&](int l, int r, int c) { return cb[(size_t)((l - L0 + 1) * 9 + (r - R0 + 1) * 3 + (c - C0 + 1)) * cube_cap]; };
             f = fit_step(dvc, L, R, C);
             const int stt = fit_state(f);
             if (stt == 1) continue;
@@ -1188,11 +1199,16 @@ __global__ __launch_bounds__(256) void describe_kernel(PyrDev P, const SelRec* s
     const int radius = (int)rintf(hist_width * 1.4142135623730951f * (float)(d + 1) * 0.5f);
     cos_t = cos_t / hist_width; sin_t = sin_t / hist_width;
     const int side = 2 * radius + 1, S = side * side;
-    for (int s0 = lane; s0 < S; s0 += 256) {
+    // lane l takes the samples [l * per, (l + 1) * per) in turn: at any moment the 64 lanes sit ~per samples apart, i.e. in different
+    // rows and mostly different cells of the 4 x 4 grid, so their LDS atomics seldom meet on one bin (64 adjacent samples of a row, the
+    // obvious assignment, pile onto the same eight bins and serialise); the sums are order-free, the result is the same
+    const int per = (S + 63) / 64;
+    for (int k0 = 0; k0 < per; k0 += 4) {
         float c_rotv[4], r_rotv[4], rbinv[4], cbinv[4], dxv[4], dyv[4]; bool okv[4];
 #pragma unroll
         for (int u = 0; u < 4; u++) {
-            const int s = s0 + 64 * u;
+            const int kk = k0 + u;
+            const int s = kk < per ? lane * per + kk : S;
             const int ii = s / side, i = ii - radius, j = s - ii * side - radius;
             const float c_rot = (float)j * cos_t - (float)i * sin_t;
             const float r_rot = (float)j * sin_t + (float)i * cos_t;
@@ -1631,6 +1647,7 @@ static int sift_run_batch(mi355_ctx* ctx, SiftWork* s) {
     };
     // ---- phases 1+2: the pyramid, octave by octave, every launch covering all n frames of the batch ----
     bool ds_fused = false;
+    unsigned xs_octaves = 0;                              // octaves whose extrema came from extrema_stream (their neighbourhoods: cube_gather_kernel)
     const bool serial_heavy = ctx->serial_heavy != 0;
     if (serial_heavy && ctx->heavy_ev_valid) MI_HIP(hipStreamWaitEvent(st, ctx->heavy_ev, 0));   // the previous batch's pyramid + extrema first
     for (int o = 0; o < s->n_oct; o++) {
@@ -1672,6 +1689,7 @@ static int sift_run_batch(mi355_ctx* ctx, SiftWork* s) {
             // the streamed test pays off on the big octaves of a full batch; smaller launches do not keep enough rows in flight and stay with the tiled kernel
             const bool xs = ctx->blur_stream && (oc.w & 3) == 0 && oc.w >= ctx->xstream_min_w && oc.h >= ctx->xstream_min_w * 3 / 4 && n >= ctx->xstream_min_frames;
             if (xs) {
+                xs_octaves |= 1u << o;
                 // no row halo to amortise here (3 + XD rows to prime a segment): many short segments balance the wave slots
                 const int nstrip = (oc.w + XSW - 1) / XSW;
                 const int xsw = ((oc.w + nstrip - 1) / nstrip + 3) & ~3;      // equal strips (<= 248 columns) instead of a nearly empty last one
@@ -1697,6 +1715,12 @@ static int sift_run_batch(mi355_ctx* ctx, SiftWork* s) {
         MI_HIP(hipEventRecord(ctx->heavy_ev, st)); ctx->heavy_ev_valid = true;
     }
     // ---- phase 3: keypoint stages of all n frames ----
+    if (xs_octaves) {
+        ProfScope ps(ctx, "extrema", 0.0, st);
+        static const int gather_gx = [] { const char* e = getenv("MI355_GATHER_GX"); return e ? atoi(e) : 8; }();       // ~2000 candidates per region of a 12 MP frame
+        hipLaunchKernelGGL(cube_gather_kernel, dim3(gather_gx, NREG, n), dim3(256), 0, st, s->P, s->cand.as<unsigned long long>(), s->ccnt.as<unsigned>(), s->cand_cap,
+                           s->cube.as<float>(), s->cube_cap, xs_octaves, bs);
+    }
     {
         ProfScope ps(ctx, "refine", 0.0, st);
         static const int refine_gx = [] { const char* e = getenv("MI355_REFINE_GX"); return e ? atoi(e) : 2; }();      // workgroups per candidate region: 32 x 64 regions x frames of mostly empty workgroups cost more to dispatch than the fits
