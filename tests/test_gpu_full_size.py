@@ -14,6 +14,9 @@ The window checks render with the oracle only what can reach the window: the ima
 inside the full canvas geometry (the layout functions see all 2000 transforms).  For the blend the window is cut with a 256 px
 margin on a 32 px grid: a pixel of the 5-band result depends on chip pixels at most ~190 px away (REDUCE / EXPAND reach 2 px per
 level, summed over the levels down and up), and a crop whose origin is a multiple of 2^5 keeps every level's sampling phase.
+  C5 pair stage: the same 2000 resident frames through detect+describe and the reference's window: 345 529 pairs in the
+      32 768-pair batches of the library, ~118 000 accepted.  Checked against the oracle with the C4 test's sampling: the features of 16
+      random frames, 2 000 random accepted records + 1 000 random rejected ones (n_selected, n_in, inlier lists, H bit patterns).
 Frames come from mi355_synth_frame_dev; everything is compared bit for bit."""
 import os
 
@@ -209,4 +212,73 @@ def test_c5_full_size_canvas_and_blend():
         x0, y0 = win
         got = out[y0:y0 + 1024, 3 * x0:3 * (x0 + 1024)].cpu().numpy()
         assert nsub >= 2 and np.array_equal(got, ref), f"C5 blend window {win}: {int((got != ref).sum())} bytes differ ({nsub} chips)"
+    ctx.close()
+
+
+def test_c5_pair_stage_full_size():
+    """MosaicWithoutPos.cpp:5083-5084 on 2000 frames: j in (i, i + 182) -> 345 529 pairs, on the GPU's own features of all frames"""
+    import torch
+    import imagemosaicing_amd as im
+    from tests import oracle_lib as ol
+    from tests.synth_survey import host_image, block_layout
+    orc = ol.load_oracle_fast()
+    ctx = im.Context(0)
+    w, h, F = 4000, 3000, 2000
+    ws = (3 * w + 3) & ~3
+    A = block_layout(F, w, h)
+    rng = np.random.default_rng(8)
+    frames = torch.empty((F, h * ws), dtype=torch.uint8, device="cuda")        # 72 GB resident
+    for k in range(F):
+        ctx.SynthFrameDev(frames[k].data_ptr(), w, h, ws, A[k], 0xC5C5C5, k, 1 + rng.uniform(-0.05, 0.05), 2.0)
+    ctx.synchronize()
+    for k in range(F):
+        ctx.SiftExtractDev(k, frames[k].data_ptr(), w, h, ws)
+    pairs = im.pair_schedule(F, 182)
+    assert len(pairs) == 345529                                                # SURVEY 8: C5
+    results = torch.zeros((len(pairs), im.PAIR_RESULT.itemsize), dtype=torch.uint8, device="cuda")   # 3.3 GB
+    seed = 23
+    torch.cuda.synchronize()
+    ctx.MatchPairsDev(pairs, results.data_ptr(), 2.5, seed)
+    ctx.synchronize()
+    # the record fields that decide the sample, without pulling 3.3 GB through PCIe: i, j, accepted of every record, whole records of the sample
+    head = results[:, :16].cpu().numpy().copy()
+    offs = {n: im.PAIR_RESULT.fields[n][1] for n in ("i", "j", "accepted")}
+    col = lambda n: results[:, offs[n]:offs[n] + 4].contiguous().view(torch.int32).reshape(-1).cpu().numpy()
+    assert np.array_equal(np.stack([col("i"), col("j")], 1), pairs)
+    accepted = col("accepted")
+    acc, rej = np.flatnonzero(accepted == 1), np.flatnonzero(accepted == 0)
+    assert 80000 < len(acc) < 160000, len(acc)
+    check = np.concatenate([rng.choice(acc, 2000, replace=False), rng.choice(rej, 1000, replace=False)])
+    res = results[torch.from_numpy(check).cuda()].cpu().numpy().reshape(-1).view(im.PAIR_RESULT)
+    del head
+    used = sorted(set(pairs[check].reshape(-1).tolist()))
+    feats = {k: ctx.GetFeatures(k) for k in used}
+    assert all(len(f[0]) == 2000 for f in feats.values())
+    # (1) features of 16 random frames against oracle.sift
+    pick = sorted(rng.choice(F, 16, replace=False).tolist())
+    imgs = [host_image(frames, k, w, h, ws) for k in pick]
+    ofe = ol.parallel_map(lambda a: orc.sift(a), imgs, threads=min(16, _threads()))
+    for k, (okp, od) in zip(pick, ofe):
+        kp, d = ctx.GetFeatures(k)
+        assert len(kp) == len(okp) and np.array_equal(kp.view(np.uint8), okp.view(np.uint8)), f"C5 frame {k}: keypoints differ"
+        assert np.array_equal(d.astype(np.uint8), od), f"C5 frame {k}: descriptors differ"
+    # (2) the sampled records against oracle.match_pair on the GPU's features
+    xy = {k: np.stack([f[0]["x"], f[0]["y"]], 1) for k, f in feats.items()}
+    d8 = {k: f[1].astype(np.uint8) for k, f in feats.items()}
+
+    def one(q):
+        i, j = int(pairs[check[q]][0]), int(pairs[check[q]][1])
+        return orc.match_pair(xy[i], d8[i], xy[j], d8[j], w, h, 2.5, seed)
+
+    out = ol.parallel_map(one, list(range(len(check))), threads=_threads())
+    bad = []
+    for q, (nin, i1, i2, Ho, ns) in enumerate(out):
+        r = res[q]
+        ok = ns == int(r["n_selected"]) and int(r["accepted"]) == int(nin > 30)
+        if ok and nin > 30:
+            ok = nin == int(r["n_in"]) and np.array_equal(r["a"][:nin], i1[:nin]) and np.array_equal(r["b"][:nin], i2[:nin]) and \
+                np.array_equal(r["H"].view(np.uint32), Ho.view(np.uint32))
+        if not ok:
+            bad.append((int(r["i"]), int(r["j"])))
+    assert not bad, f"C5: {len(bad)} of {len(check)} checked records differ from the oracle, first {bad[:5]}"
     ctx.close()
