@@ -1203,13 +1203,16 @@ __global__ __launch_bounds__(256) void describe_kernel(PyrDev P, const SelRec* s
     // rows and mostly different cells of the 4 x 4 grid, so their LDS atomics seldom meet on one bin (64 adjacent samples of a row, the
     // obvious assignment, pile onto the same eight bins and serialise); the sums are order-free, the result is the same
     const int per = (S + 63) / 64;
+    int sc = lane * per, ic = sc / side, jc = sc - ic * side;       // the lane's running sample, its row and column in the window (one division per lane)
     for (int k0 = 0; k0 < per; k0 += 4) {
         float c_rotv[4], r_rotv[4], rbinv[4], cbinv[4], dxv[4], dyv[4]; bool okv[4];
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             const int kk = k0 + u;
-            const int s = kk < per ? lane * per + kk : S;
-            const int ii = s / side, i = ii - radius, j = s - ii * side - radius;
+            const int s = kk < per ? sc : S;
+            const int i = ic - radius, j = jc - radius;
+            sc++; jc++;
+            if (jc == side) { jc = 0; ic++; }
             const float c_rot = (float)j * cos_t - (float)i * sin_t;
             const float r_rot = (float)j * sin_t + (float)i * cos_t;
             const float rbin = r_rot + (float)(d / 2) - 0.5f;
