@@ -1199,64 +1199,75 @@ __global__ __launch_bounds__(256) void describe_kernel(PyrDev P, const SelRec* s
     const int radius = (int)rintf(hist_width * 1.4142135623730951f * (float)(d + 1) * 0.5f);
     cos_t = cos_t / hist_width; sin_t = sin_t / hist_width;
     const int side = 2 * radius + 1, S = side * side;
-    // lane l takes the samples [l * per, (l + 1) * per) in turn: at any moment the 64 lanes sit ~per samples apart, i.e. in different
-    // rows and mostly different cells of the 4 x 4 grid, so their LDS atomics seldom meet on one bin (64 adjacent samples of a row, the
-    // obvious assignment, pile onto the same eight bins and serialise); the sums are order-free, the result is the same
+    // Only about half of the window's samples fall inside the rotated 4 x 4 grid.  The cheap part -- the sample's grid coordinates and the
+    // test -- runs for all of them; the samples that pass are queued (window row, column packed into one word) in a wave-private LDS list
+    // and the expensive part (four loads, atan2, exp, eight fixed-point atomics) runs on full waves of queued samples: 34 -> 24 us per
+    // 12 MP frame.  The sums are order-free, so the order of the queue does not matter.
+    __shared__ int s_q4[4][64 * 5];
+    int* s_q = s_q4[wv];
+    int qn = 0;                                       // wave-uniform
+    auto heavy = [&](int packed) {
+        const int i = (int)((unsigned)packed >> 16) - 32768, j = (int)((unsigned)packed & 0xffffu) - 32768;
+        const float c_rot = (float)j * cos_t - (float)i * sin_t;
+        const float r_rot = (float)j * sin_t + (float)i * cos_t;
+        float rbin = r_rot + (float)(d / 2) - 0.5f;
+        float cbin = c_rot + (float)(d / 2) - 0.5f;
+        const int r = py + i, c = px + j;
+        const float dx = (float)((int)img[(size_t)r * cols + c + 1] - (int)img[(size_t)r * cols + c - 1]);
+        const float dy = (float)((int)img[(size_t)(r - 1) * cols + c] - (int)img[(size_t)(r + 1) * cols + c]);
+        const float ori = det_atan2deg(dy, dx);
+        const float mag = sqrtf(dx * dx + dy * dy) * det_expf((c_rot * c_rot + r_rot * r_rot) * exp_scale);
+        float obin = (ori - k.angle) * bins_per_deg;
+        const float r0f = floorf(rbin), c0f = floorf(cbin), o0f = floorf(obin);
+        rbin -= r0f; cbin -= c0f; obin -= o0f;
+        const int r0 = (int)r0f, c0 = (int)c0f;
+        int o0 = (int)o0f;
+        if (o0 < 0) o0 += n;
+        if (o0 >= n) o0 -= n;
+        const float v_r1 = mag * rbin, v_r0 = mag - v_r1;
+        const float v_rc11 = v_r1 * cbin, v_rc10 = v_r1 - v_rc11;
+        const float v_rc01 = v_r0 * cbin, v_rc00 = v_r0 - v_rc01;
+        const float v_rco111 = v_rc11 * obin, v_rco110 = v_rc11 - v_rco111;
+        const float v_rco101 = v_rc10 * obin, v_rco100 = v_rc10 - v_rco101;
+        const float v_rco011 = v_rc01 * obin, v_rco010 = v_rc01 - v_rco011;
+        const float v_rco001 = v_rc00 * obin, v_rco000 = v_rc00 - v_rco001;
+        const int idx = ((r0 + 1) * (d + 2) + c0 + 1) * (n + 2) + o0;
+        // order-free accumulation: rint(v * 2^10) as 64-bit integers (two's complement add == unsigned add)
+#define FIXQ(v) ((unsigned long long)(long long)(int)rintf((v) * HIST_Q))     /* |v| <= sqrt(2) x 255 x 48: v x 2^10 fits 32 bits (one v_cvt_i32_f32 instead of the 64-bit conversion sequence) */
+        atomicAdd(&s_hq[idx], FIXQ(v_rco000)); atomicAdd(&s_hq[idx + 1], FIXQ(v_rco001));
+        atomicAdd(&s_hq[idx + (n + 2)], FIXQ(v_rco010)); atomicAdd(&s_hq[idx + (n + 3)], FIXQ(v_rco011));
+        atomicAdd(&s_hq[idx + (d + 2) * (n + 2)], FIXQ(v_rco100)); atomicAdd(&s_hq[idx + (d + 2) * (n + 2) + 1], FIXQ(v_rco101));
+        atomicAdd(&s_hq[idx + (d + 3) * (n + 2)], FIXQ(v_rco110)); atomicAdd(&s_hq[idx + (d + 3) * (n + 2) + 1], FIXQ(v_rco111));
+#undef FIXQ
+    };
+    // lane l tests the samples [l * per, (l + 1) * per) in turn (one division per lane, then running row / column)
     const int per = (S + 63) / 64;
-    int sc = lane * per, ic = sc / side, jc = sc - ic * side;       // the lane's running sample, its row and column in the window (one division per lane)
+    int sc = lane * per, ic = sc / side, jc = sc - ic * side;
     for (int k0 = 0; k0 < per; k0 += 4) {
-        float c_rotv[4], r_rotv[4], rbinv[4], cbinv[4], dxv[4], dyv[4]; bool okv[4];
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             const int kk = k0 + u;
-            const int s = kk < per ? sc : S;
             const int i = ic - radius, j = jc - radius;
-            sc++; jc++;
-            if (jc == side) { jc = 0; ic++; }
             const float c_rot = (float)j * cos_t - (float)i * sin_t;
             const float r_rot = (float)j * sin_t + (float)i * cos_t;
             const float rbin = r_rot + (float)(d / 2) - 0.5f;
             const float cbin = c_rot + (float)(d / 2) - 0.5f;
             const int r = py + i, c = px + j;
-            okv[u] = s < S && (rbin > -1.0f && rbin < (float)d && cbin > -1.0f && cbin < (float)d && r > 0 && r < rows - 1 && c > 0 && c < cols - 1);
-            c_rotv[u] = c_rot; r_rotv[u] = r_rot; rbinv[u] = rbin; cbinv[u] = cbin;
-            dxv[u] = 0.0f; dyv[u] = 0.0f;
-            if (okv[u]) {
-                dxv[u] = (float)((int)img[(size_t)r * cols + c + 1] - (int)img[(size_t)r * cols + c - 1]);
-                dyv[u] = (float)((int)img[(size_t)(r - 1) * cols + c] - (int)img[(size_t)(r + 1) * cols + c]);
-            }
+            const bool ok = kk < per && sc < S && (rbin > -1.0f && rbin < (float)d && cbin > -1.0f && cbin < (float)d && r > 0 && r < rows - 1 && c > 0 && c < cols - 1);
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(ok);
+            if (ok) s_q[qn + __builtin_popcountll(m & ((1ull << lane) - 1ull))] = (int)(((unsigned)(i + 32768) << 16) | (unsigned)(j + 32768));
+            qn += __builtin_popcountll(m);
+            sc++; jc++;
+            if (jc == side) { jc = 0; ic++; }
         }
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            if (!okv[u]) continue;
-            const float dx = dxv[u], dy = dyv[u], c_rot = c_rotv[u], r_rot = r_rotv[u];
-            float rbin = rbinv[u], cbin = cbinv[u];
-            const float ori = det_atan2deg(dy, dx);
-            const float mag = sqrtf(dx * dx + dy * dy) * det_expf((c_rot * c_rot + r_rot * r_rot) * exp_scale);
-            float obin = (ori - k.angle) * bins_per_deg;
-            const float r0f = floorf(rbin), c0f = floorf(cbin), o0f = floorf(obin);
-            rbin -= r0f; cbin -= c0f; obin -= o0f;
-            const int r0 = (int)r0f, c0 = (int)c0f;
-            int o0 = (int)o0f;
-            if (o0 < 0) o0 += n;
-            if (o0 >= n) o0 -= n;
-            const float v_r1 = mag * rbin, v_r0 = mag - v_r1;
-            const float v_rc11 = v_r1 * cbin, v_rc10 = v_r1 - v_rc11;
-            const float v_rc01 = v_r0 * cbin, v_rc00 = v_r0 - v_rc01;
-            const float v_rco111 = v_rc11 * obin, v_rco110 = v_rc11 - v_rco111;
-            const float v_rco101 = v_rc10 * obin, v_rco100 = v_rc10 - v_rco101;
-            const float v_rco011 = v_rc01 * obin, v_rco010 = v_rc01 - v_rco011;
-            const float v_rco001 = v_rc00 * obin, v_rco000 = v_rc00 - v_rco001;
-            const int idx = ((r0 + 1) * (d + 2) + c0 + 1) * (n + 2) + o0;
-            // order-free accumulation: rint(v * 2^10) as 64-bit integers (two's complement add == unsigned add)
-#define FIXQ(v) ((unsigned long long)(long long)rintf((v) * HIST_Q))
-            atomicAdd(&s_hq[idx], FIXQ(v_rco000)); atomicAdd(&s_hq[idx + 1], FIXQ(v_rco001));
-            atomicAdd(&s_hq[idx + (n + 2)], FIXQ(v_rco010)); atomicAdd(&s_hq[idx + (n + 3)], FIXQ(v_rco011));
-            atomicAdd(&s_hq[idx + (d + 2) * (n + 2)], FIXQ(v_rco100)); atomicAdd(&s_hq[idx + (d + 2) * (n + 2) + 1], FIXQ(v_rco101));
-            atomicAdd(&s_hq[idx + (d + 3) * (n + 2)], FIXQ(v_rco110)); atomicAdd(&s_hq[idx + (d + 3) * (n + 2) + 1], FIXQ(v_rco111));
-#undef FIXQ
+        wave_sync();
+        while (qn >= 64) {
+            qn -= 64;
+            heavy(s_q[qn + lane]);
         }
+        wave_sync();
     }
+    if (lane < qn) heavy(s_q[lane]);
     wave_sync();
 #pragma unroll
     for (int half = 0; half < 2; half++) {
