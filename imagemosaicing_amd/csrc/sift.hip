@@ -958,12 +958,17 @@ __global__ __launch_bounds__(256) void orient_kernel(PyrDev P, const Refined* re
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
             __builtin_amdgcn_wave_barrier();
             // 4 samples per lane per trip: the 16 gradient loads of a trip are issued before any is consumed
-            for (int s0 = lane; s0 < S; s0 += 256) {
+            // lane l takes the samples [l * per, (l + 1) * per) in turn: one division per lane, then a running row / column
+            const int per = (S + 63) / 64;
+            int sc = lane * per, ic = sc / side, jc = sc - ic * side;
+            for (int k0 = 0; k0 < per; k0 += 4) {
                 float dxv[4], dyv[4]; int d2v[4]; bool okv[4];
 #pragma unroll
                 for (int u = 0; u < 4; u++) {
-                    const int s = s0 + 64 * u;
-                    const int ii = s / side, i = ii - radius, j = s - ii * side - radius;
+                    const int s = k0 + u < per ? sc : S;
+                    const int i = ic - radius, j = jc - radius;
+                    sc++; jc++;
+                    if (jc == side) { jc = 0; ic++; }
                     const int y = rr.r + i, x = rr.c + j;
                     okv[u] = (s < S) && !(y <= 0 || y >= oc.h - 1 || x <= 0 || x >= oc.w - 1);
                     d2v[u] = i * i + j * j;
@@ -984,7 +989,7 @@ __global__ __launch_bounds__(256) void orient_kernel(PyrDev P, const Refined* re
                     if (b >= ORI_BINS) b -= ORI_BINS;
                     if (b < 0) b += ORI_BINS;
                     const float t = wgt * mag;
-                    atomicAdd(&s_hq[wv][b], (unsigned long long)(long long)rintf(t * HIST_Q));      // order-free by definition
+                    atomicAdd(&s_hq[wv][b], (unsigned long long)(long long)(int)rintf(t * HIST_Q));      // order-free by definition; t <= sqrt(2) x 255 x 48: 32 bits hold t x 2^10
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
