@@ -39,8 +39,8 @@ sys.path.insert(0, ROOT)
 
 DOM = "gauss_stream"       # profile class of the dominant kernel (blur16_stream): the only launches bracketed with events in the timed region
 SLOTS = int(os.environ.get("MI355_BENCH_SLOTS", "3"))   # batch work areas in flight (library default 3)
-BATCH = int(os.environ.get("MI355_BENCH_BATCH", "16"))  # frames per batch (library default 16)
-PMC_JSON = "r03_pmc_blur16_stream.json"   # committed rocprofv3 --pmc passes of this command (profiles/pmc_traffic.py)
+BATCH = int(os.environ.get("MI355_BENCH_BATCH", "0"))   # frames per batch; 0 = chosen in main(): 32 (library default 16) unless the survey needs the HBM (C5, --blend)
+PMC_JSON = "r04_pmc_blur16_stream.json"   # committed rocprofv3 --pmc passes of this command (profiles/pmc_traffic.py)
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md (6.29 TB/s measured copy)
 VALU_PEAK_TOPS = 78.65     # f32 vector multiplies OR adds per second (T lane-operations/s): the 157.3 TFLOP/s vector peak counts an fma as two
 
@@ -193,6 +193,9 @@ def rank_share_proxy(args):
     ranks = [int(x) for x in str(args.as_rank).split(",")]
     torch.cuda.set_device(0)
     dev = torch.device("cuda", 0)
+    global BATCH
+    if BATCH <= 0:
+        BATCH = 16 if args.frames * args.width * args.height > 1000 * 4000 * 3000 else 32
     ctx = im.Context(0)
     ctx.set_option("sift_slots", SLOTS)
     ctx.set_option("sift_batch", BATCH)
@@ -339,6 +342,11 @@ def main():
         else:
             dist.init_process_group(args.backend)
 
+    global BATCH
+    if BATCH <= 0:
+        # 32 frames per batch: the latency-bound launches of the small octaves and the per-frame selections are paid once per 32 frames
+        # (3 x 32 frames in flight = 86 GB of work areas at 12 MP); surveys that need the HBM themselves keep the library's 16
+        BATCH = 16 if (args.blend or args.frames * args.width * args.height > 1000 * 4000 * 3000) else 32
     import imagemosaicing_amd as im
     from imagemosaicing_amd import dist as md
     ctx = im.Context(local_rank)

@@ -31,7 +31,7 @@ def main():
         t0, t1 = t0 + a * (t1 - t0), t0 + b * (t1 - t0)
     rows = [r for r in rows if r[1] >= t0 and r[2] <= t1]
     span = t1 - t0
-    heavy = lambda n: ("blur_" in n) or ("extrema" in n)
+    heavy = lambda n: ("blur" in n) or ("extrema" in n)         # blur_stream (r01-r02), blur16_stream / blur16_tile (r03+), extrema_stream / extrema_kernel
     print("window %.1f ms, %d kernels" % (span / 1e6, len(rows)))
     print("any kernel running   : %5.1f %% of the window" % (100.0 * union([(s, e) for _, s, e in rows]) / span))
     print("blur/extrema running : %5.1f %% of the window" % (100.0 * union([(s, e) for n, s, e in rows if heavy(n)]) / span))

@@ -1,44 +1,48 @@
 #!/bin/bash
-# collects the round's evidence on the GPU box into gpurun_out/r03 (copied to profiles/ afterwards)
+# collects the round's evidence on the GPU box into gpurun_out/r04 (copied to profiles/ afterwards)
 set -x
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-O=gpurun_out/r03; mkdir -p $O
+O=gpurun_out/r04; mkdir -p $O
 # counters first: bench.py reads the traffic of the dominant kernel from profiles/ (the copy on this box is refreshed here)
 for C in FETCH_SIZE WRITE_SIZE; do
   MI355_BENCH_NO_STANDALONE=1 MI355_BENCH_NOPROF=1 rocprofv3 --pmc $C --kernel-include-regex blur16_stream --output-format csv -d $O/pmc_$C -o p -- python bench.py --no-cpu-baseline --steps 1 --warmup 0 > /dev/null 2>> $O/bench.err
   F=$(find $O/pmc_$C -name "*counter_collection.csv" | head -1)
-  cp $F $O/r03_pmc_${C}_blur16_stream.csv; gzip -f $O/r03_pmc_${C}_blur16_stream.csv
+  cp $F $O/r04_pmc_${C}_blur16_stream.csv; gzip -f $O/r04_pmc_${C}_blur16_stream.csv
   rm -rf $O/pmc_$C
 done
-python profiles/pmc_traffic.py <(zcat $O/r03_pmc_FETCH_SIZE_blur16_stream.csv.gz) <(zcat $O/r03_pmc_WRITE_SIZE_blur16_stream.csv.gz) blur16_stream $O/r03_pmc_blur16_stream.json frames=500 frame=4000x3000 batch=16 "command=rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE (two passes) --kernel-include-regex blur16_stream --output-format csv -- python bench.py --no-cpu-baseline --steps 1 --warmup 0, with MI355_BENCH_NO_STANDALONE=1 MI355_BENCH_NOPROF=1"
-cp $O/r03_pmc_blur16_stream.json profiles/r03_pmc_blur16_stream.json
-python bench.py --steps 5 --warmup 2 > $O/r03_bench_n1.json 2> $O/bench.err
-rocprofv3 --kernel-trace --stats -d $O/trace -o t -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/r03_bench_n1_under_rocprofv3.json 2>> $O/bench.err
+python profiles/pmc_traffic.py <(zcat $O/r04_pmc_FETCH_SIZE_blur16_stream.csv.gz) <(zcat $O/r04_pmc_WRITE_SIZE_blur16_stream.csv.gz) blur16_stream $O/r04_pmc_blur16_stream.json frames=500 frame=4000x3000 batch=32 "command=rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE (two passes) --kernel-include-regex blur16_stream --output-format csv -- python bench.py --no-cpu-baseline --steps 1 --warmup 0, with MI355_BENCH_NO_STANDALONE=1 MI355_BENCH_NOPROF=1"
+cp $O/r04_pmc_blur16_stream.json profiles/r04_pmc_blur16_stream.json
+python bench.py --steps 5 --warmup 2 > $O/r04_bench_n1.json 2> $O/bench.err
+rocprofv3 --kernel-trace --stats -d $O/trace -o t -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/r04_bench_n1_under_rocprofv3.json 2>> $O/bench.err
 DB=$(find $O/trace -name "*.db" | head -1)
-python profiles/rocpd_summary.py $DB $O/r03_rocprofv3_kernel_stats_bench_n1.txt
-python profiles/rocpd_by_grid.py $DB > $O/r03_rocprofv3_kernel_stats_by_grid_bench_n1.txt 2>/dev/null
-python profiles/rocpd_overlap.py $DB > $O/r03_rocpd_overlap.txt 2>/dev/null
+python profiles/rocpd_summary.py $DB $O/r04_rocprofv3_kernel_stats_bench_n1.txt
+python profiles/rocpd_by_grid.py $DB > $O/r04_rocprofv3_kernel_stats_by_grid_bench_n1.txt 2>/dev/null
+python profiles/rocpd_overlap.py $DB > $O/r04_rocpd_overlap.txt 2>/dev/null
 rm -rf $O/trace
 # the serial_heavy pass alone under the tracer: exclusive kernel durations recomputable from a committed file
-rocprofv3 --kernel-trace --stats -d $O/trace2 -o t -- python scratch/sift_time.py 64 4000 3000 16 serial > $O/r03_sift_time_serial.txt 2>> $O/bench.err
+rocprofv3 --kernel-trace --stats -d $O/trace2 -o t -- python scratch/sift_time.py 96 4000 3000 32 serial > $O/r04_sift_time_serial.txt 2>> $O/bench.err
 DB=$(find $O/trace2 -name "*.db" | head -1)
-python profiles/rocpd_summary.py $DB $O/r03_rocprofv3_kernel_stats_serial_pass.txt
-python profiles/rocpd_by_grid.py $DB > $O/r03_rocprofv3_kernel_stats_by_grid_serial_pass.txt 2>/dev/null
+python profiles/rocpd_summary.py $DB $O/r04_rocprofv3_kernel_stats_serial_pass.txt
+python profiles/rocpd_by_grid.py $DB > $O/r04_rocprofv3_kernel_stats_by_grid_serial_pass.txt 2>/dev/null
 rm -rf $O/trace2
 # C4 on one GPU (74 029 window pairs) and the 2-rank dry run of the strong-scaling path on one device (gloo, torch transport)
-MI355_BENCH_NO_STANDALONE=1 python bench.py --window 182 --steps 2 --warmup 1 --no-cpu-baseline > $O/r03_bench_c4_n1.json 2>> $O/bench.err
+MI355_BENCH_NO_STANDALONE=1 python bench.py --window 182 --steps 2 --warmup 1 > $O/r04_bench_c4_n1.json 2>> $O/bench.err
 # C5: 2000 frames piled onto a 20000^2-class canvas, window 182, warp + LaplacianPyramidBlending with everything co-resident
-MI355_BENCH_NO_STANDALONE=1 python bench.py --frames 2000 --layout block --blend --window 182 --no-cpu-baseline --steps 1 --warmup 1 > $O/r03_bench_c5_blend_n1.json 2>> $O/bench.err
+MI355_BENCH_NO_STANDALONE=1 python bench.py --frames 2000 --layout block --blend --window 182 --steps 1 --warmup 1 > $O/r04_bench_c5_blend_n1.json 2>> $O/bench.err
 # C4 under the tracer: bf_match_kernel / ransac_kernel / select_kernel durations recomputable from a committed file
-MI355_BENCH_NO_STANDALONE=1 rocprofv3 --kernel-trace --stats -d $O/trace3 -o t -- python bench.py --window 182 --steps 1 --warmup 1 --no-cpu-baseline > $O/r03_bench_c4_n1_under_rocprofv3.json 2>> $O/bench.err
+MI355_BENCH_NO_STANDALONE=1 rocprofv3 --kernel-trace --stats -d $O/trace3 -o t -- python bench.py --window 182 --steps 1 --warmup 1 --no-cpu-baseline > $O/r04_bench_c4_n1_under_rocprofv3.json 2>> $O/bench.err
 DB=$(find $O/trace3 -name "*.db" | head -1)
-python profiles/rocpd_summary.py $DB $O/r03_rocprofv3_kernel_stats_bench_c4.txt
+python profiles/rocpd_summary.py $DB $O/r04_rocprofv3_kernel_stats_bench_c4.txt
 rm -rf $O/trace3
 # the pair stage alone at C4 size (74 029 pairs x 3 calls) and the pipe / issue-rate micro-benchmarks its comments quote
-python scratch/match_time.py 500 182 > $O/r03_match_time_c4.txt 2>> $O/bench.err
-./scratch/mfma_bench > $O/r03_mfma_bench.txt 2>> $O/bench.err
-./scratch/valu_bench > $O/r03_valu_bench.txt 2>> $O/bench.err
-MI355_RANSAC_DBG=1 python scratch/ransac_time.py 300 > $O/r03_ransac_time.txt 2>&1
-python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29544 bench.py --gpus 2 --backend gloo --all-ranks-on-device0 --steps 2 --warmup 1 --frames 96 --no-cpu-baseline > $O/r03_bench_dryrun_2ranks_1device.json 2>> $O/bench.err
+python scratch/match_time.py 500 182 > $O/r04_match_time_c4.txt 2>> $O/bench.err
+./scratch/mfma_bench > $O/r04_mfma_bench.txt 2>> $O/bench.err
+./scratch/valu_bench > $O/r04_valu_bench.txt 2>> $O/bench.err
+MI355_RANSAC_DBG=1 python scratch/ransac_time.py 300 > $O/r04_ransac_time.txt 2>&1
+python bench.py --as-rank 0,7 --of 8 --steps 5 --warmup 1 > $O/r04_rank_share_proxy_c3.json 2>> $O/bench.err
+python bench.py --as-rank 0,7 --of 8 --window 182 --steps 3 --warmup 1 > $O/r04_rank_share_proxy_c4.json 2>> $O/bench.err
+./scratch/pk_rate > $O/r04_pk_rate.txt 2>> $O/bench.err
+python scratch/sift_time.py 96 4000 3000 32 > $O/r04_sift_time.txt 2>> $O/bench.err
+python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29544 bench.py --gpus 2 --backend gloo --all-ranks-on-device0 --steps 2 --warmup 1 --frames 96 --no-cpu-baseline > $O/r04_bench_dryrun_2ranks_1device.json 2>> $O/bench.err
 tail -3 $O/bench.err
 ls -la $O
