@@ -149,7 +149,7 @@ class Context:
     def SiftExtract(self, img_id, bgr, max_kp=None):
         img, w, h, ws, ch = _img_geom(bgr)
         assert ch == 3
-        max_kp = max_kp or int(self.params.nfeatures)
+        max_kp = max_kp or max(int(self.params.nfeatures), 2048)      # nfeatures + ties with the last one (retainBest), up to the record's 2048
         kp = np.zeros(max_kp, KEYPOINT)
         desc = np.zeros((max_kp, 128), np.float32)
         n = C.c_int(0)

@@ -1148,7 +1148,9 @@ __global__ __launch_bounds__(1024) void topk_kernel(const KpRec* kps, const unsi
             __syncthreads();
         }
     }
-    const unsigned keep = M < K ? M : K;
+    // KeyPointsFilter::retainBest keeps everything whose response is >= the K-th strongest: the M survivors of the threshold are exactly
+    // those (ties with the K-th included), up to the feature record's capacity
+    const unsigned keep = N > K ? (M < (unsigned)SEL_STRIDE ? M : (unsigned)SEL_STRIDE) : M;
     for (unsigned i = tid; i < keep; i += 1024) {
         const KpRec k = kps[s_idx[i]];
         // image coordinates: kpt.pt = (c + xc) * (1 << octave), kpt.size = sigma * 2^((layer + xi) / 3) * (1 << octave) * 2 (no doubled octave)
@@ -1765,7 +1767,7 @@ static int sift_run_batch(mi355_ctx* ctx, SiftWork* s) {
     }
     {
         ProfScope ps(ctx, "describe", 0.0, st);
-        hipLaunchKernelGGL(describe_kernel, dim3((nf + 3) / 4, n), dim3(256), 0, st, s->P, s->sel.as<SelRec>(), reinterpret_cast<const int*>(cnt + 3), outs, bs);
+        hipLaunchKernelGGL(describe_kernel, dim3(((int)SEL_STRIDE + 3) / 4, n), dim3(256), 0, st, s->P, s->sel.as<SelRec>(), reinterpret_cast<const int*>(cnt + 3), outs, bs);
     }
     MI_HIP(hipGetLastError());
     for (int k = 0; k < n; k++) {

@@ -315,7 +315,7 @@ int  mi355_allgather_results(mi355_ctx* ctx, const mi355_pair_result* d_local, i
 /* When enabled, every launch of the named kernel class is bracketed by hipEvents on the ctx stream. */
 int  mi355_profile_enable(mi355_ctx* ctx, int on);
 /* SIFT stage populations of the last extracted frame: [0] DoG extrema, [1] refined points, [2] oriented keypoints,
- * [3] kept (<= nfeatures), [4] overflow flag */
+ * [3] kept (nfeatures + ties with the last one as KeyPointsFilter::retainBest keeps them, <= 2048), [4] overflow flag */
 int  mi355_last_sift_counters(mi355_ctx* ctx, int32_t out8[8]);
 int  mi355_profile_reset(mi355_ctx* ctx);
 int  mi355_profile_only(mi355_ctx* ctx, const char* kernel_class /* NULL or "" = every class */);

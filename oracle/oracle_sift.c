@@ -50,8 +50,8 @@
  *     q = rint(v * 2^10) and summed as a 64-bit integer; the bin value is (float)sum * 2^-10 (gradients are in 1/48 grey
  *     levels, so the resolution is 2e-5 grey levels; OpenCV adds floats in pixel order);
  *   - with nfeatures > 0 the keypoints are ordered by (response descending, octave, layer, row, column, orientation bin) and
- *     that is the output order (OpenCV: retainBest leaves an nth_element order, and keeps ALL ties at the boundary where this
- *     cuts at nfeatures); with nfeatures <= 0 the order is OpenCV's own (generation order, see orc_sift).
+ *     that is the output order (OpenCV: retainBest leaves an nth_element order); like retainBest, every keypoint whose response
+ *     ties with the nfeatures-th strongest is kept too; with nfeatures <= 0 the order is OpenCV's own (generation order, see orc_sift).
  */
 #include "oracle.h"
 #include <math.h>
@@ -484,6 +484,10 @@ int orc_sift(const uint8_t* bgr, int w, int h, int ws, int nfeatures, orc_keypoi
      * matchPairs.match are indices into exactly this list (tests/test_sift_reference_run.py) */
     if (nfeatures > 0) qsort(cand, ncand, sizeof(cand_t), cand_cmp);
     size_t keep = (nfeatures <= 0 || ncand < (size_t)nfeatures) ? ncand : (size_t)nfeatures;
+    /* KeyPointsFilter::retainBest (features2d keypoint.cpp, called by SIFT::operator() with nfeatures): nth_element, then everything
+     * whose response is >= that of the nfeatures-th strongest stays -- ties at the boundary are all kept (two orientations of one point
+     * share their response, so a tie there is an ordinary event) */
+    if (nfeatures > 0) while (keep < ncand && cand[keep].response == cand[nfeatures - 1].response) keep++;
     if (keep > (size_t)max_kp) keep = (size_t)max_kp;
     for (size_t i = 0; i < keep; i++) {
         const cand_t* k = &cand[i];

@@ -241,7 +241,7 @@ class Oracle:
     def sift(self, bgr, nfeatures=2000, max_kp=None):
         bgr = np.ascontiguousarray(bgr, np.uint8)
         h, w = bgr.shape[:2]
-        max_kp = max_kp or nfeatures
+        max_kp = max_kp or (max(nfeatures, 2048) if nfeatures > 0 else nfeatures)     # nfeatures + ties with the last one (retainBest), up to the feature record's 2048
         kp = np.zeros(max_kp, KEYPOINT)
         desc = np.zeros((max_kp, 128), np.uint8)
         self.L.orc_sift.restype = C.c_int

@@ -71,7 +71,7 @@ def test_c3_default_route_12mp():
     res = ctx.MatchPairs(pairs, 2.5, 3)
     imgs = [host_image(frames, k, w, h, ws) for k in range(F)]
     ofe = _feats_equal(ctx, orc, imgs, list(range(F)), "C3")
-    assert all(len(f[0]) == 2000 for f in ofe)
+    assert all(2000 <= len(f[0]) <= 2048 for f in ofe)          # nfeatures + ties with the last one (retainBest)
     nins = _pairs_equal(res, orc, ofe, pairs, w, h, 2.5, 3, "C3")
     assert min(nins) > 100, nins
     ctx.close()
@@ -202,6 +202,6 @@ def test_tile_route_equals_stream_route():
             ctx.close()
         for k in range(F):
             (k0, d0), (k1, d1) = feats[0][k], feats[1][k]
-            assert len(k0) == len(k1) == 2000, (w, h, k, len(k0), len(k1))
+            assert len(k0) == len(k1) and 2000 <= len(k0) <= 2048, (w, h, k, len(k0), len(k1))
             assert np.array_equal(k0.view(np.uint8), k1.view(np.uint8)), f"{w}x{h} frame {k}: keypoints differ between the stream and the tile route"
             assert np.array_equal(d0, d1), f"{w}x{h} frame {k}: descriptors differ between the stream and the tile route"

@@ -51,7 +51,7 @@ def test_c4_full_size_one_gpu():
     res = results.cpu().numpy().reshape(-1).view(im.PAIR_RESULT)
     assert np.array_equal(np.stack([res["i"], res["j"]], 1), pairs)
     feats = [ctx.GetFeatures(k) for k in range(F)]
-    assert all(len(f[0]) == 2000 for f in feats)
+    assert all(2000 <= len(f[0]) <= 2048 for f in feats)       # nfeatures + ties with the last one (retainBest)
     # (1) features of 16 random frames against oracle.sift
     rng = np.random.default_rng(4)
     pick = sorted(rng.choice(F, 16, replace=False).tolist())
@@ -253,7 +253,7 @@ def test_c5_pair_stage_full_size():
     del head
     used = sorted(set(pairs[check].reshape(-1).tolist()))
     feats = {k: ctx.GetFeatures(k) for k in used}
-    assert all(len(f[0]) == 2000 for f in feats.values())
+    assert all(2000 <= len(f[0]) <= 2048 for f in feats.values())
     # (1) features of 16 random frames against oracle.sift
     pick = sorted(rng.choice(F, 16, replace=False).tolist())
     imgs = [host_image(frames, k, w, h, ws) for k in pick]

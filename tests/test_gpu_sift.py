@@ -95,7 +95,7 @@ def test_sift_streaming_blur_levels(ctx, oracle):
     for (w, h, seed) in [(2200, 1604, 20), (1100, 780, 21), (1024, 768, 22), (1101, 700, 23)]:
         img = terrain(w, h, seed=seed)
         kp, d8 = _check(ctx, oracle, img, f"{w}x{h}")
-        assert len(kp) == 2000
+        assert 2000 <= len(kp) <= 2048                 # nfeatures + ties with the last one (retainBest)
         c0 = im.Context(0)
         c0.set_option("blur_stream", 0)
         kp0, desc0 = c0.SiftExtract(7, img)

@@ -91,7 +91,7 @@ def test_sift_gpu_equals_oracle_on_the_reference_frames():
         assert img.shape == (750, 1000, 3)
         kp, desc = ctx.SiftExtract(k, img)
         okp, odesc = orc.sift(img)
-        assert len(kp) == len(okp) == 2000
+        assert len(kp) == len(okp) and 2000 <= len(kp) <= 2048
         assert np.array_equal(kp.view(np.uint8), okp.view(np.uint8)), f"frame {k}: keypoints differ"
         assert np.array_equal(desc.astype(np.uint8), odesc), f"frame {k}: descriptors differ"
         feats.append((okp, odesc))
