@@ -1737,7 +1737,7 @@ static int sift_run_batch(mi355_ctx* ctx, SiftWork* s) {
     }
     // ---- phase 3: keypoint stages of all n frames ----
     if (xs_octaves) {
-        ProfScope ps(ctx, "extrema", 0.0, st);
+        ProfScope ps(ctx, "gather", 0.0, st);
         static const int gather_gx = [] { const char* e = getenv("MI355_GATHER_GX"); return e ? atoi(e) : 8; }();       // ~2000 candidates per region of a 12 MP frame
         hipLaunchKernelGGL(cube_gather_kernel, dim3(gather_gx, NREG, n), dim3(256), 0, st, s->P, s->cand.as<unsigned long long>(), s->ccnt.as<unsigned>(), s->cand_cap,
                            s->cube.as<float>(), s->cube_cap, xs_octaves, bs);
