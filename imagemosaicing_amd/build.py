@@ -20,7 +20,11 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
          "-Wall", "-Wno-unused-function", "-Wno-unused-result"] + os.environ.get("MI355_EXTRA_HIPCC_FLAGS", "").split()   # kernel A/B builds (scratch/)
 
 
-PER_FILE = {}          # per-file extra flags (none: round 3's -fno-honor-nans for match.hip belonged to the removed float epilogue)
+# per-file extra flags.  ransac.hip: the SLP vectoriser packs the unrolled 8 x 8 solves into v_pk_mul/add_f32 and pays for it with ~480
+# register moves and scratch traffic per Gauss-Newton step; a packed f32 instruction occupies the SIMD as long as its two halves issued
+# one by one (profiles/r04_pk_rate.txt), so the moves are pure loss: 557 -> 454 us of polish per pair.  The one loop that gains from
+# pairs (the support count) is written with explicit two-element vectors.
+PER_FILE = {"ransac.hip": ["-fno-slp-vectorize"]}
 
 
 def sources():

@@ -208,6 +208,40 @@ HD void nlls4(const float* p, const float* H0, float* Hout, float* scratch) {
 // first value underflows to zero (then the sign of the zero it replaces would show), every pivot is the diagonal one and every
 // expected row update really happens (|e| >= eps).  All of that is checked; a draw that fails a check is redone by the generic
 // routines (caller), so the result is always the reference's.
+// ---- exact division with a shared reciprocal (device) ---------------------------------------------------------------------
+// hipcc expands a correctly rounded a / b into v_div_scale x2, v_rcp, two Newton fmas for the reciprocal, q = a r and two
+// residual corrections q += (a - b q) r, v_div_fmas, v_div_fixup: 11 instructions, one of them quarter rate, and nothing is
+// shared between divisions by the same b.  v_div_scale changes its operands only when b is denormal or above 2^126, a is below
+// 2^-103, or a / b is denormal or reaches 2^96; v_div_fmas then is a plain fma, and v_div_fixup changes the result only for zero,
+// infinite or NaN operands.  Outside those cases the same roundings are reproduced by the core sequence alone: the reciprocal (3
+// instructions) once per divisor, 5 instructions per quotient.  The guard proves it per Gauss-Newton step: every divisor in
+// [2^-30, 2^62], every quotient in [2^-70, 2^38] (so every dividend in [2^-100, 2^100]: no residual a - b q is denormal), the sum of
+// the |q| catches infinite and NaN dividends.  A step whose guard fails is redone with true divisions (caller).
+struct DivGuard { float s, mn; bool bok; };
+HD void guard_init(DivGuard& g) { g.s = 0.0f; g.mn = 1.0f; g.bok = true; }
+HD bool guard_ok(const DivGuard& g) { return g.bok && g.mn >= 0x1p-70f && g.s <= 0x1p38f; }
+#if defined(__HIP_DEVICE_COMPILE__)
+HD float rcp_nr(float b, DivGuard& g) {
+    g.bok = g.bok && fabsf(b) >= 0x1p-30f && fabsf(b) <= 0x1p62f;
+    float r = __builtin_amdgcn_rcpf(b);
+    const float e = __builtin_fmaf(-b, r, 1.0f);
+    r = __builtin_fmaf(e, r, r);
+    return r;
+}
+HD float div_nr(float a, float b, float r, DivGuard& g) {
+    float q = a * r;
+    float e = __builtin_fmaf(-b, q, a);
+    q = __builtin_fmaf(e, r, q);
+    e = __builtin_fmaf(-b, q, a);
+    q = __builtin_fmaf(e, r, q);
+    g.s = g.s + fabsf(q); g.mn = fminf(g.mn, fabsf(q));
+    return q;
+}
+#else
+HD float rcp_nr(float b, DivGuard&) { return b; }
+HD float div_nr(float a, float b, float, DivGuard&) { return a / b; }
+#endif
+
 namespace sp {
 constexpr bool anz(int r, int c) { return (r & 1) ? (c >= 3) : (c <= 2 || c >= 6); }
 struct Plan {
@@ -282,8 +316,11 @@ HD bool jtj_sparse(const float* A, float* M) {
 // tiny (|e| < eps, data dependent) is skipped here too -- the entries it would have given their first value then stay +0 until
 // a later planned operation (0 + x = x) reaches them.  The reference's zeros may be -0 where these are +0, which can only show
 // in an entry of the inverse that is itself zero: checked at the end.
+template <bool FAST = false>
 HD int inverse8_sparse(const float* src, float* dst, float eps) {
     float t[8][16];
+    DivGuard g; guard_init(g);
+    bool ok_at_fail = true;
     sp::sfor<0, 8>([&](auto ic) {
         constexpr int i = decltype(ic)::value;
         sp::sfor<0, 16>([&](auto jc) {
@@ -303,11 +340,20 @@ HD int inverse8_sparse(const float* src, float* dst, float eps) {
                 if constexpr (sp::PLAN.upd[i][j]) other = other || (fabsf(t[j][i]) > eps);
             });
             state = other ? 2 : 1;
+            if constexpr (FAST) ok_at_fail = guard_ok(g);       // the verdict rests on the quotients so far; what follows is never used
         }
-        sp::sfor<i + 1, 16>([&](auto cc) {
-            constexpr int c = decltype(cc)::value;
-            if constexpr (sp::PLAN.div[i][c]) t[i][c] = t[i][c] / ei;
-        });
+        if constexpr (FAST) {
+            const float ri = rcp_nr(ei, g);
+            sp::sfor<i + 1, 16>([&](auto cc) {
+                constexpr int c = decltype(cc)::value;
+                if constexpr (sp::PLAN.div[i][c]) t[i][c] = div_nr(t[i][c], ei, ri, g);
+            });
+        } else {
+            sp::sfor<i + 1, 16>([&](auto cc) {
+                constexpr int c = decltype(cc)::value;
+                if constexpr (sp::PLAN.div[i][c]) t[i][c] = t[i][c] / ei;
+            });
+        }
         sp::sfor<0, 8>([&](auto jc) {
             constexpr int j = decltype(jc)::value;
             if constexpr (sp::PLAN.upd[i][j]) {
@@ -322,6 +368,7 @@ HD int inverse8_sparse(const float* src, float* dst, float eps) {
             }
         });
     });
+    if constexpr (FAST) { if (!(state != 0 ? ok_at_fail : guard_ok(g))) return 3; }      // 3 = a division left the guarded range: redo exactly
     if (state != 0) return state;
     float s = 0.0f, mn = sp::FMAXV;
     sp::sfor<0, 8>([&](auto ic) {
@@ -469,7 +516,11 @@ HD bool hypothesis4_fast(const float* p, float* H, int* polished = nullptr) {
     if (!jtj_sparse(A, M)) return false;
 #pragma unroll
     for (int i = 0; i < 64; i++) inv[i] = 0.0f;                   // a failed inversion leaves the zeros (matrix.h:377)
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (inverse8_sparse<true>(M, inv, 1e-20f) >= 2) pivot_call(M, inv, 1e-20f);      // 2: pivot search below the diagonal, 3: division guard
+#else
     if (inverse8_sparse(M, inv, 1e-20f) == 2) pivot_call(M, inv, 1e-20f);
+#endif
     invjt_sparse(inv, A, M);
 #pragma unroll
     for (int r = 0; r < 8; r++) {
@@ -499,21 +550,44 @@ HD bool hypothesis4_fast(const float* p, float* H, int* polished = nullptr) {
 #pragma unroll
     for (int i = 0; i < 64; i++) inv[i] = 0.0f;
     for (int it = 0; it < 15 && !finished; it++) {
+        auto jacobian = [&](auto fast) {
+            constexpr bool FAST = decltype(fast)::value;
+            DivGuard g; guard_init(g);
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const float x2 = p[4 * i], y2 = p[4 * i + 1], x1 = p[4 * i + 2], y1 = p[4 * i + 3];
-            const float d = w[6] * x1 + w[7] * y1 + 1.0f;
-            const float nx = w[0] * x1 + w[1] * y1 + w[2];
-            const float ny = w[3] * x1 + w[4] * y1 + w[5];
-            float* j = A + i * 16;
-            j[0] = x1 / d; j[1] = y1 / d; j[2] = 1.0f / d; j[3] = 0.0f; j[4] = 0.0f; j[5] = 0.0f;
-            j[6] = ((-x1) * nx) / (d * d); j[7] = ((-y1) * nx) / (d * d);
-            j[8] = 0.0f; j[9] = 0.0f; j[10] = 0.0f; j[11] = x1 / d; j[12] = y1 / d; j[13] = 1.0f / d;
-            j[14] = ((-x1) * ny) / (d * d); j[15] = ((-y1) * ny) / (d * d);
-            C[2 * i] = x2 - nx / d; C[2 * i + 1] = y2 - ny / d;
-        }
+            for (int i = 0; i < 4; i++) {
+                const float x2 = p[4 * i], y2 = p[4 * i + 1], x1 = p[4 * i + 2], y1 = p[4 * i + 3];
+                const float d = w[6] * x1 + w[7] * y1 + 1.0f;
+                const float nx = w[0] * x1 + w[1] * y1 + w[2];
+                const float ny = w[3] * x1 + w[4] * y1 + w[5];
+                float* j = A + i * 16;
+                j[3] = 0.0f; j[4] = 0.0f; j[5] = 0.0f; j[8] = 0.0f; j[9] = 0.0f; j[10] = 0.0f;
+                if constexpr (FAST) {
+                    const float dd = d * d, rd = rcp_nr(d, g), rdd = rcp_nr(dd, g);
+                    j[0] = div_nr(x1, d, rd, g); j[1] = div_nr(y1, d, rd, g); j[2] = div_nr(1.0f, d, rd, g);
+                    j[6] = div_nr((-x1) * nx, dd, rdd, g); j[7] = div_nr((-y1) * nx, dd, rdd, g);
+                    j[11] = j[0]; j[12] = j[1]; j[13] = j[2];
+                    j[14] = div_nr((-x1) * ny, dd, rdd, g); j[15] = div_nr((-y1) * ny, dd, rdd, g);
+                    C[2 * i] = x2 - div_nr(nx, d, rd, g); C[2 * i + 1] = y2 - div_nr(ny, d, rd, g);
+                } else {
+                    j[0] = x1 / d; j[1] = y1 / d; j[2] = 1.0f / d;
+                    j[6] = ((-x1) * nx) / (d * d); j[7] = ((-y1) * nx) / (d * d);
+                    j[11] = x1 / d; j[12] = y1 / d; j[13] = 1.0f / d;
+                    j[14] = ((-x1) * ny) / (d * d); j[15] = ((-y1) * ny) / (d * d);
+                    C[2 * i] = x2 - nx / d; C[2 * i + 1] = y2 - ny / d;
+                }
+            }
+            return guard_ok(g);
+        };
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (!jacobian(std::true_type{})) { jacobian(std::false_type{}); if (polished) *polished |= 2; }   // (rare) a division outside the guarded range: true divisions
+        if (!jtj_sparse(A, M)) return false;
+        const int inv_state = inverse8_sparse<true>(M, inv, 1e-6f);    // 1: no pivot, the previous iteration's inverse stays (zeros before the first)
+        if (inv_state >= 2) { pivot_call(M, inv, 1e-6f); if (polished && inv_state == 3) *polished |= 4; }      // 2: pivot search below the diagonal, 3: guard
+#else
+        jacobian(std::false_type{});
         if (!jtj_sparse(A, M)) return false;
         if (inverse8_sparse(M, inv, 1e-6f) == 2) pivot_call(M, inv, 1e-6f);    // failure: the previous iteration's inverse stays (zeros before the first)
+#endif
         invjt_sparse(inv, A, M);
         bool done = true;
 #pragma unroll

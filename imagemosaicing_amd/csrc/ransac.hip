@@ -23,6 +23,7 @@
 
 namespace {
 
+typedef float f2 __attribute__((ext_vector_type(2)));
 constexpr int RB = 256;            // threads per workgroup = draws per chunk
 constexpr int MAX_DRAWS = 4999;    // realSamTimes >= 5000 breaks before drawing (mosaicimage.h:1787-1792)
 
@@ -148,7 +149,13 @@ __device__ __forceinline__ void ransac_body(const RansacArgs& a) {
     float* JL = J + 16 * n;     // 8 x 2n
     float* C  = JL + 16 * n;    // 2n
     float* CS = C + 2 * n;      // BIG: 4n floats of compaction scratch
-    for (int i = tid; i < n; i += RB) { x1[i] = P1[i].x; y1[i] = P1[i].y; x2[i] = P2[i].x; y2[i] = P2[i].y; }
+    // The support loop reads every point once per hypothesis: (x1, y1, x2, y2) interleaved, one 16-byte broadcast read per point.  The
+    // copy lives where the closing Gauss-Newton later keeps J (unused until then; BIG keeps J in HBM and reads the four arrays).
+    float4* pts = reinterpret_cast<float4*>(y2 + n);
+    for (int i = tid; i < n; i += RB) {
+        x1[i] = P1[i].x; y1[i] = P1[i].y; x2[i] = P2[i].x; y2[i] = P2[i].y;
+        if constexpr (!BIG) pts[i] = make_float4(P1[i].x, P1[i].y, P2[i].x, P2[i].y);
+    }
     if (tid < 8) s_state[tid] = (tid == 2 || tid == 3) ? -1 : 0;
     if (tid < 9) { s_bestH[tid] = 0.0f; s_firstH[tid] = 0.0f; }
     __syncthreads();
@@ -211,7 +218,7 @@ __device__ __forceinline__ void ransac_body(const RansacArgs& a) {
             // whose inversion needs the reference's pivot search below the diagonal re-run the generic private-memory routines
             int pol = 0;
             const bool fast_ok = hm::hypothesis4_fast(p, h, &pol);
-            if (a.dbg && pol) atomicAdd(&s_npol, 1);
+            if (a.dbg && pol) atomicAdd(&s_npol, 1 + ((pol & 2) ? (1 << 12) : 0) + ((pol & 4) ? (1 << 22) : 0));      // polished draws | << 12: a Jacobian redone with true divisions | << 22: an inversion
             // one lane of the wave at a time, its work arrays in the wave's LDS slot: a private array for these index-driven
             // routines costs the whole kernel registers and scratch set-up (measured 5.3 us per pair against 4.9 this way)
             for (unsigned long long need = __ballot(!fast_ok); need; need &= need - 1ull) {
@@ -227,12 +234,31 @@ __device__ __forceinline__ void ransac_body(const RansacArgs& a) {
             }
             long long c1 = wall_clock64(); Tsolve += c1 - c0;
             flag = 1;                                      // a polished hypothesis is never skipped, whatever its residual after the polish (:1868-1876)
-            for (int i = 0; i < n; i++) {                  // :1890-1904
-                float bx, by;
-                hm::apply_recip1(h, x2[i], y2[i], bx, by);
-                const float dx = bx - x1[i], dy = by - y1[i];
-                const float dd = dx * dx + dy * dy;
-                if (dd < d2) support++;
+            if constexpr (BIG) {
+                for (int i = 0; i < n; i++) {              // :1890-1904
+                    float bx, by;
+                    hm::apply_recip1(h, x2[i], y2[i], bx, by);
+                    const float dx = bx - x1[i], dy = by - y1[i];
+                    const float dd = dx * dx + dy * dy;
+                    if (dd < d2) support++;
+                }
+            } else {
+                // the same expressions (ApplyProjectMat2, :1890-1904) with X and Y side by side in explicit pairs: every product and sum is
+                // rounded separately as before (-ffp-contract=off), the pairs are packed instructions whatever the vectoriser's settings
+                const f2 m03 = {h[0], h[3]}, m14 = {h[1], h[4]}, m25 = {h[2], h[5]};
+                const float m6 = h[6], m7 = h[7];
+#pragma unroll 4                                             // four independent points in flight: the chain of one (LDS read, 11-instruction division) is all latency
+                for (int i = 0; i < n; i++) {
+                    const float4 q = pts[i];
+                    const float inv = 1.0f / (m6 * q.z + m7 * q.w + 1.0f);
+                    const f2 num = (m03 * q.z + m14 * q.w) + m25;
+                    const f2 b = num * inv;
+                    const f2 t1 = {q.x, q.y};
+                    const f2 d = b - t1;
+                    const f2 sq = d * d;
+                    const float dd = sq.x + sq.y;
+                    if (dd < d2) support++;
+                }
             }
         }
         // ---- replay of the sequential loop over this chunk (mosaicimage.h:1864-1918), in parallel ----
@@ -713,8 +739,13 @@ int mi_ransac_batch(mi355_ctx* ctx, const mi355_sfpoint* d_p1, const mi355_sfpoi
         MI_HIP(hipMemcpyAsync(hd.data(), ddbg.p, hd.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
         MI_HIP(hipStreamSynchronize(ctx->stream));
         double acc[8] = {0};
-        for (int i = 0; i < n_pairs; i++) for (int k = 0; k < 8; k++) acc[k] += (double)hd[(size_t)i * 8 + k];
-        fprintf(stderr, "[ransac dbg, avg per pair, 100 MHz ticks] loop %.0f split %.0f nlls %.0f | chunks %.1f solve %.0f solve+support %.0f classify %.0f | polished draws %.1f\n", acc[0] / n_pairs, acc[1] / n_pairs, acc[2] / n_pairs, acc[3] / n_pairs, acc[4] / n_pairs, acc[5] / n_pairs, acc[6] / n_pairs, acc[7] / n_pairs);
+        double redo_j = 0, redo_i = 0;
+        for (int i = 0; i < n_pairs; i++) {
+            for (int k = 0; k < 7; k++) acc[k] += (double)hd[(size_t)i * 8 + k];
+            const long long v = hd[(size_t)i * 8 + 7];
+            acc[7] += (double)(v & 0xfff); redo_j += (double)((v >> 12) & 0x3ff); redo_i += (double)(v >> 22);
+        }
+        fprintf(stderr, "[ransac dbg, avg per pair, 100 MHz ticks] loop %.0f split %.0f nlls %.0f | chunks %.1f solve %.0f solve+support %.0f classify %.0f | polished draws %.1f, with a Jacobian / an inversion outside the division guard %.3f / %.3f\n", acc[0] / n_pairs, acc[1] / n_pairs, acc[2] / n_pairs, acc[3] / n_pairs, acc[4] / n_pairs, acc[5] / n_pairs, acc[6] / n_pairs, acc[7] / n_pairs, redo_j / n_pairs, redo_i / n_pairs);
     }
     return MI355_OK;
 }

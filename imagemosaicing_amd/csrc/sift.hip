@@ -1650,6 +1650,10 @@ static int sift_run_batch(mi355_ctx* ctx, SiftWork* s) {
     // the frames were produced on the caller's stream
     MI_HIP(hipEventRecord(ctx->sift_in_ev, ctx->stream));
     MI_HIP(hipStreamWaitEvent(st, ctx->sift_in_ev, 0));
+    // (measurement mode) the previous batch's pyramid + extrema first.  The wait stands BEFORE the memsets: an event recorded right
+    // after a wait takes the end of the stream's last command as its time, which would put the waiting into the first bracket
+    const bool serial_heavy = ctx->serial_heavy != 0;
+    if (serial_heavy && ctx->heavy_ev_valid) MI_HIP(hipStreamWaitEvent(st, ctx->heavy_ev, 0));
     unsigned* cnt = s->counters.as<unsigned>();      // per frame: [0] candidates [1] refined [2] keypoints [3] n_sel [4] overflow [8,9] ctrl
     MI_HIP(hipMemsetAsync(cnt, 0, (size_t)n * CNT_STRIDE * sizeof(unsigned), st));
     MI_HIP(hipMemsetAsync(s->ccnt.p, 0, (size_t)n * CCNT_STRIDE * sizeof(unsigned), st));
@@ -1669,8 +1673,6 @@ static int sift_run_batch(mi355_ctx* ctx, SiftWork* s) {
     // ---- phases 1+2: the pyramid, octave by octave, every launch covering all n frames of the batch ----
     bool ds_fused = false;
     unsigned xs_octaves = 0;                              // octaves whose extrema came from extrema_stream (their neighbourhoods: cube_gather_kernel)
-    const bool serial_heavy = ctx->serial_heavy != 0;
-    if (serial_heavy && ctx->heavy_ev_valid) MI_HIP(hipStreamWaitEvent(st, ctx->heavy_ev, 0));   // the previous batch's pyramid + extrema first
     for (int o = 0; o < s->n_oct; o++) {
         const OctaveDev& oc = s->P.oc[o];
         const double level_bytes = (double)oc.w * oc.h * sizeof(lvl_t) * n;

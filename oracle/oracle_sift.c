@@ -45,7 +45,12 @@
  *
  * STILL DEFINED HERE (third-party approximations that (2) cannot see; each an open parity risk of a few ulp in angle / descriptor):
  *   - exp / atan2 / sin / cos are the fixed polynomial forms below (OpenCV: table-driven cv::exp, fastAtan2 whose polynomial
- *     coefficients are the ones used here, MSVCR90 cosf / sinf), evaluated with fmaf in a fixed order;
+ *     coefficients are the ones used here, MSVCR90 cosf / sinf), evaluated with fmaf in a fixed order.  cv::exp of this build
+ *     (opencv_core240.dll: export 100881a0 -> Exp_32f 10085780) is POSITION DEPENDENT: blocks of eight array elements take an SSE2
+ *     single-precision path (1008598e-10085bb7: float Horner form times (float)expTab[i & 63] * 2^(i >> 6)), the last n mod 8
+ *     elements a double-precision x87 path (10085bc2-), and SIFT calls it on the compacted in-window samples -- the weight of a
+ *     sample depends on the number and order of the samples of its window.  Not restated (it would still not pin a descriptor
+ *     byte: MSVCR's cosf / sinf are not shipped, the histogram sums are float in that order, no descriptor is committed);
  *   - both histograms (36-bin orientation, 4x4x8 descriptor) are accumulated ORDER-FREE: every contribution v is quantised to
  *     q = rint(v * 2^10) and summed as a 64-bit integer; the bin value is (float)sum * 2^-10 (gradients are in 1/48 grey
  *     levels, so the resolution is 2e-5 grey levels; OpenCV adds floats in pixel order);
