@@ -5,8 +5,12 @@
 // 16-bit Laplacian pyramids, float weight pyramids, [1 4 6 4 1] REDUCE / EXPAND in integer arithmetic, every rounding and border --
 // is the one stated at the top of oracle/oracle_blend.c, which also lists what was checked against the reference's DLLs and the one
 // known divergence (the binary's reassociated float REDUCE); the parity test compares the output bytes with that oracle.
-// All kernels are streaming stencils over at most a few hundred MB.  Per chip: prep, 5 x paired REDUCE (both pyramids, two outputs per
-// thread from 32-bit loads), 5 x Laplacian + accumulate (a 2 x 2 fine block per thread, never stored), the top level's accumulate.
+// All kernels are streaming stencils over at most a few hundred MB.  Level 0 of a chip's pyramids is never stored (round 4): it IS the
+// chip (u8 -> i16, extended by reflection) and mask / 255 (extended by zeros), so the first REDUCE and the level-0 Laplacian read the
+// chip and the mask themselves (4 bytes per pixel instead of 10 written and 20 read).  The REDUCE chains of up to 32 chips run as five
+// batched launches (blockIdx.z = chip; they are independent of one another); the accumulation into the canvas pyramids stays one chip
+// after the other, in chip order, because the float weight sums make the order per pixel part of the result: per chip 5 x Laplacian +
+// accumulate (a 2 x 2 fine block per thread, never stored) and the top level's accumulate.
 #include "common.h"
 #include <cmath>
 
@@ -15,6 +19,16 @@ namespace {
 __device__ __forceinline__ int reflect101d(int p, int n) { if (n == 1) return 0; while (p < 0 || p >= n) { if (p < 0) p = -p; else p = 2 * n - 2 - p; } return p; }
 __device__ __forceinline__ int reflectd(int p, int n) { while (p < 0 || p >= n) { if (p < 0) p = -p - 1; else p = 2 * n - 1 - p; } return p; }
 __device__ __forceinline__ short sat16d(int v) { return (short)(v < -32768 ? -32768 : (v > 32767 ? 32767 : v)); }
+
+// Pointers read from a structure in memory are generic to the compiler (flat loads, and no unaligned vector loads: the 24-byte reads
+// below came out as 24 byte loads); in the global address space an unaligned run of bytes is one or two vector loads.
+#define GLOBAL_U8(p) ((const __attribute__((address_space(1))) uint8_t*)(p))
+__device__ __forceinline__ void load_run(const void* p, unsigned* out, int nbytes_const8) {      // nbytes: 8, 20 or 24
+    const __attribute__((address_space(1))) uint8_t* g = GLOBAL_U8(p);
+    if (nbytes_const8 == 8) __builtin_memcpy(out, (const void __attribute__((address_space(1)))*)g, 8);
+    else if (nbytes_const8 == 20) __builtin_memcpy(out, (const void __attribute__((address_space(1)))*)g, 20);
+    else __builtin_memcpy(out, (const void __attribute__((address_space(1)))*)g, 24);
+}
 
 // level 0 of one chip's region: chip extended by reflection (edge pixel included), weight = mask / 255 extended by zeros
 __global__ __launch_bounds__(256) void blend_prep_kernel(const uint8_t* chip, int cws, const uint8_t* mask, int mws, int cw, int ch,
@@ -30,14 +44,24 @@ __global__ __launch_bounds__(256) void blend_prep_kernel(const uint8_t* chip, in
     w0[(size_t)y * rw + x] = w;
 }
 
+// one chip of a batch: where its pixels are, how its region lies on the chip, where its pyramid levels >= 1 live
+struct ChipP {
+    const uint8_t* chip; const uint8_t* mask;
+    int cw, ch, cws, mws;             // chip size, row pitches of chip (3 B / pixel) and mask
+    int left, top, rw, rh;            // chip origin inside its region, region size (multiples of 2^bands)
+    size_t tmp;                       // pixel offset of this chip's level 1 inside the batch's pyramid buffers
+};
+// pixel offset of level l >= 1 behind tmp
+__device__ __forceinline__ size_t level_off(int rw, int rh, int l) { size_t o = 0; for (int m = 1; m < l; m++) o += (size_t)(rw >> m) * (rh >> m); return o; }
+
 // REDUCE: i16 x 3 in integers (so the 5x5 product form equals the oracle's rows-then-columns form: rows [1 4 6 4 1] . pixels, then
 // columns, (sum + 128) >> 8) and f32 weights in the oracle's order (6 c + 4 (l + r) + ll + rr per row, the same over the rows, / 256).
 // REDUCE of both pyramids of a chip in one launch, two horizontally adjacent outputs per thread: their 5-tap windows share three of the
 // seven source columns, and away from the left / right border those seven pixels are 42 contiguous, 4-byte aligned bytes (11 32-bit
 // loads per row instead of 30 16-bit ones).  The sums are the ones of pyr_down16_kernel / pyr_down_f_kernel, term for term.
-__global__ __launch_bounds__(256) void pyr_down_pair_kernel(const short* src, const float* srcw, int w, int h, short* dst, float* dstw) {
+__device__ __forceinline__ void pyr_down_pair_body(const short* src, const float* srcw, int w, int h, short* dst, float* dstw) {
     const int dw = w >> 1, x0 = (blockIdx.x * 256 + threadIdx.x) * 2, y = blockIdx.y;
-    if (x0 >= dw) return;
+    if (x0 >= dw || y >= (h >> 1)) return;
     const bool two = x0 + 1 < dw;
     const int wt[5] = {1, 4, 6, 4, 1};
     const bool interior = 2 * x0 - 2 >= 0 && 2 * x0 + 4 < w;
@@ -87,6 +111,100 @@ __global__ __launch_bounds__(256) void pyr_down_pair_kernel(const short* src, co
         dstw[(size_t)y * dw + x0 + o] = v * (1.0f / 256.0f);
     }
 }
+__global__ __launch_bounds__(256) void pyr_down_pair_kernel(const short* src, const float* srcw, int w, int h, short* dst, float* dstw) {
+    pyr_down_pair_body(src, srcw, w, h, dst, dstw);
+}
+// level l -> l + 1 (l >= 1) of every chip of a batch; the grid covers the largest chip
+__global__ __launch_bounds__(256) void pyr_down_pair_batch_kernel(const ChipP* cp, int l, short* g, float* wp) {
+    const ChipP c = cp[blockIdx.z];
+    const size_t a = c.tmp + level_off(c.rw, c.rh, l), b = c.tmp + level_off(c.rw, c.rh, l + 1);
+    pyr_down_pair_body(g + a * 3, wp + a, c.rw >> l, c.rh >> l, g + b * 3, wp + b);
+}
+
+// Level 0 -> 1 straight from the chip and its mask: the level-0 value at region pixel (x, y) is (short)chip[reflect(x - left), reflect(y - top)]
+// (the chip extended by BORDER_REFLECT, edge pixel included), the weight mask / 255 inside the chip and 0 outside -- what blend_prep_kernel
+// used to store.  Same sums as pyr_down_pair_body, term for term.  Away from the borders the seven pixels of a row are 21 contiguous
+// bytes: six unaligned 32-bit loads (three bytes of slack inside the row), the seven mask bytes two.
+__global__ __launch_bounds__(256) void pyr_down0_batch_kernel(const ChipP* cp, short* g, float* wp) {
+    const ChipP c = cp[blockIdx.z];
+    const int w = c.rw, h = c.rh;
+    const int dw = w >> 1, x0 = (blockIdx.x * 256 + threadIdx.x) * 2, y = blockIdx.y;
+    if (x0 >= dw || y >= (h >> 1)) return;
+    short* dst = g + c.tmp * 3;
+    float* dstw = wp + c.tmp;
+    const bool two = x0 + 1 < dw;
+    const int wt[5] = {1, 4, 6, 4, 1};
+    const int cx0 = 2 * x0 - 2 - c.left;                                   // chip column of the first of the seven
+    const bool interior = 2 * x0 - 2 >= 0 && 2 * x0 + 4 < w && cx0 >= 0 && cx0 + 8 < c.cw;
+    int xs[7]; bool xin[7];
+    if (!interior) {
+#pragma unroll
+        for (int j = 0; j < 7; j++) { const int xr = reflect101d(2 * x0 - 2 + j, w) - c.left; xin[j] = xr >= 0 && xr < c.cw; xs[j] = reflectd(xr, c.cw); }
+    }
+    int acc[2][3] = {{0, 0, 0}, {0, 0, 0}};
+    float fr[2][5];
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        const int yr = reflect101d(2 * y - 2 + k, h) - c.top;
+        const bool yin = yr >= 0 && yr < c.ch;
+        const int sy = reflectd(yr, c.ch);
+        const __attribute__((address_space(1))) uint8_t* s = GLOBAL_U8(c.chip) + (size_t)sy * c.cws;
+        const __attribute__((address_space(1))) uint8_t* m = GLOBAL_U8(c.mask) + (size_t)sy * c.mws;
+        short px[7][3];
+        float f[7];
+        if (interior) {
+            // the horizontal [1 4 6 4 1] of both outputs and the three channels straight on the packed bytes: pixel j, channel ch is byte
+            // 3 j + ch of the run, so a dword meets a constant vector of tap weights (zeros on the other channels' bytes) in one
+            // v_dot4_u32_u8 -- 27 of them per row instead of 21 byte extractions and 30 multiply-adds; the same integers
+            unsigned u[6];
+            load_run((const void*)(s + 3 * cx0), u, 24);
+#pragma unroll
+            for (int o = 0; o < 2; o++)
+#pragma unroll
+                for (int ch = 0; ch < 3; ch++) {
+                    unsigned r = 0;
+#pragma unroll
+                    for (int q = 0; q < 6; q++) {
+                        unsigned wq = 0;
+#pragma unroll
+                        for (int b = 0; b < 4; b++) {
+                            const int e = 4 * q + b, jj = e / 3 - 2 * o;
+                            if (e % 3 == ch && jj >= 0 && jj < 5) wq |= (unsigned)wt[jj] << (8 * b);
+                        }
+                        if (wq) r = __builtin_amdgcn_udot4(u[q], wq, r, false);
+                    }
+                    acc[o][ch] += wt[k] * (int)r;
+                }
+            unsigned mv[2];
+            load_run((const void*)(m + cx0), mv, 8);
+#pragma unroll
+            for (int j = 0; j < 7; j++) f[j] = yin ? (float)((mv[j >> 2] >> (8 * (j & 3))) & 0xffu) * (float)(1.0 / 255.0) : 0.0f;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 7; j++) {
+                px[j][0] = (short)s[3 * xs[j]]; px[j][1] = (short)s[3 * xs[j] + 1]; px[j][2] = (short)s[3 * xs[j] + 2];
+                f[j] = (yin && xin[j]) ? (float)m[xs[j]] * (float)(1.0 / 255.0) : 0.0f;
+            }
+#pragma unroll
+            for (int o = 0; o < 2; o++) {
+                int r[3] = {0, 0, 0};
+#pragma unroll
+                for (int j = 0; j < 5; j++) { r[0] += wt[j] * px[2 * o + j][0]; r[1] += wt[j] * px[2 * o + j][1]; r[2] += wt[j] * px[2 * o + j][2]; }
+                acc[o][0] += wt[k] * r[0]; acc[o][1] += wt[k] * r[1]; acc[o][2] += wt[k] * r[2];
+            }
+        }
+#pragma unroll
+        for (int o = 0; o < 2; o++) fr[o][k] = f[2 * o + 2] * 6.0f + (f[2 * o + 1] + f[2 * o + 3]) * 4.0f + f[2 * o] + f[2 * o + 4];
+    }
+#pragma unroll
+    for (int o = 0; o < 2; o++) {
+        if (o == 1 && !two) break;
+        short* d = dst + ((size_t)y * dw + x0 + o) * 3;
+        d[0] = sat16d((acc[o][0] + 128) >> 8); d[1] = sat16d((acc[o][1] + 128) >> 8); d[2] = sat16d((acc[o][2] + 128) >> 8);
+        const float v = fr[o][2] * 6.0f + (fr[o][1] + fr[o][3]) * 4.0f + fr[o][0] + fr[o][4];
+        dstw[(size_t)y * dw + x0 + o] = v * (1.0f / 256.0f);
+    }
+}
 
 // horizontal EXPAND value (before the vertical combination) at fine column X of coarse row s (3 channels, channel c)
 __device__ __forceinline__ int up_h(const short* s, int w, int X, int c) {
@@ -99,6 +217,23 @@ __device__ __forceinline__ int up_h(const short* s, int w, int X, int c) {
     }
     if (x == w - 1) return s[3 * (w - 1) + c] * 8;
     return (s[3 * x + c] + s[3 * (x + 1) + c]) * 4;
+}
+
+// up_h at the fine columns 2x and 2x + 1 for the three channels of one coarse row; away from the left / right border the three coarse
+// pixels are 18 contiguous bytes (one 20-byte run instead of nine 2-byte loads)
+__device__ __forceinline__ void up_h_pair(const short* row, int w, int x, int* he, int* ho) {
+    if (x >= 1 && x + 1 < w) {
+        unsigned u[5];
+        load_run(row + 3 * (x - 1), u, 20);
+        short v[9];
+#pragma unroll
+        for (int e = 0; e < 9; e++) v[e] = (short)((e & 1) ? (u[e >> 1] >> 16) : (u[e >> 1] & 0xffffu));
+#pragma unroll
+        for (int c = 0; c < 3; c++) { he[c] = v[c] + v[3 + c] * 6 + v[6 + c]; ho[c] = (v[3 + c] + v[6 + c]) * 4; }
+    } else {
+#pragma unroll
+        for (int c = 0; c < 3; c++) { he[c] = up_h(row, w, 2 * x, c); ho[c] = up_h(row, w, 2 * x + 1, c); }
+    }
 }
 
 // fine = sat16(fine - EXPAND(coarse)) (SUB) or sat16(EXPAND(coarse) + fine); coarse is w x h, fine 2w x 2h
@@ -135,9 +270,7 @@ __global__ __launch_bounds__(256) void blend_lap_accumulate_kernel(const short* 
     const short* rows[3] = {coarse + (size_t)ym * w * 3, coarse + (size_t)y * w * 3, coarse + (size_t)yp * w * 3};
     int he[3][3], ho[3][3];                               // horizontal EXPAND values at fine columns 2x (even) and 2x + 1 (odd), per row and channel
 #pragma unroll
-    for (int r = 0; r < 3; r++)
-#pragma unroll
-        for (int c = 0; c < 3; c++) { he[r][c] = up_h(rows[r], w, 2 * x, c); ho[r][c] = up_h(rows[r], w, 2 * x + 1, c); }
+    for (int r = 0; r < 3; r++) up_h_pair(rows[r], w, x, he[r], ho[r]);
     const int FW = 2 * w;
     // the two fine pixels of a row are 12 contiguous bytes (4-byte aligned: the fine column 2x, the region offset ox and the row pitches are
     // even): three 32-bit loads / stores instead of six 16-bit ones, the weights as one 64-bit access
@@ -170,6 +303,67 @@ __global__ __launch_bounds__(256) void blend_lap_accumulate_kernel(const short* 
         dp[2] = (unsigned)(unsigned short)dv[4] | ((unsigned)(unsigned short)dv[5] << 16);
         float2* wp2 = reinterpret_cast<float2*>(dw + di);
         float2 a2 = *wp2; a2.x += wv2.x; a2.y += wv2.y; *wp2 = a2;
+    }
+}
+
+// The same for level 0, whose Gaussian level is the chip itself (see pyr_down0_batch_kernel): fine values from the chip extended by
+// reflection, weights mask / 255 inside the chip and 0 outside.  Inside the chip the two fine pixels of a row are six contiguous bytes.
+__global__ __launch_bounds__(256) void blend_lap0_accumulate_kernel(ChipP c, const short* coarse, int ox, int oy, short* dl, float* dw, int DW) {
+    const int w = c.rw >> 1, h = c.rh >> 1;
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= w) return;
+    const int ym = (y == 0) ? (h > 1 ? 1 : 0) : y - 1, yp = (y == h - 1) ? h - 1 : y + 1;
+    const short* rows[3] = {coarse + (size_t)ym * w * 3, coarse + (size_t)y * w * 3, coarse + (size_t)yp * w * 3};
+    int he[3][3], ho[3][3];
+#pragma unroll
+    for (int r = 0; r < 3; r++) up_h_pair(rows[r], w, x, he[r], ho[r]);
+    const int cx = 2 * x - c.left;                            // chip column of the even fine pixel
+    const bool xfast = cx >= 0 && cx + 3 < c.cw;              // both columns inside the chip and the 8-byte read inside the row
+#pragma unroll
+    for (int dy = 0; dy < 2; dy++) {
+        const int Y = 2 * y + dy;
+        const int cy = Y - c.top;
+        const bool yin = cy >= 0 && cy < c.ch;
+        const int sy = reflectd(cy, c.ch);
+        const uint8_t* srow = c.chip + (size_t)sy * c.cws;
+        const uint8_t* mrow = c.mask + (size_t)sy * c.mws;
+        short fv[6]; float wv2[2];
+        if (xfast) {
+            unsigned u[2];
+            load_run(srow + 3 * cx, u, 8);
+#pragma unroll
+            for (int e = 0; e < 6; e++) fv[e] = (short)((u[e >> 2] >> (8 * (e & 3))) & 0xffu);
+            wv2[0] = yin ? (float)mrow[cx] * (float)(1.0 / 255.0) : 0.0f;
+            wv2[1] = yin ? (float)mrow[cx + 1] * (float)(1.0 / 255.0) : 0.0f;
+        } else {
+#pragma unroll
+            for (int dx = 0; dx < 2; dx++) {
+                const int xr = cx + dx, sx = reflectd(xr, c.cw);
+                fv[3 * dx] = (short)srow[3 * sx]; fv[3 * dx + 1] = (short)srow[3 * sx + 1]; fv[3 * dx + 2] = (short)srow[3 * sx + 2];
+                wv2[dx] = (yin && xr >= 0 && xr < c.cw) ? (float)mrow[sx] * (float)(1.0 / 255.0) : 0.0f;
+            }
+        }
+        const size_t di = (size_t)(oy + Y) * DW + (ox + 2 * x);
+        unsigned* dp = reinterpret_cast<unsigned*>(dl + di * 3);
+        unsigned d0 = dp[0], d1 = dp[1], d2 = dp[2];
+        short dv[6] = {(short)(d0 & 0xffff), (short)(d0 >> 16), (short)(d1 & 0xffff), (short)(d1 >> 16), (short)(d2 & 0xffff), (short)(d2 >> 16)};
+#pragma unroll
+        for (int dx = 0; dx < 2; dx++) {
+            const float wv = wv2[dx];
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++) {
+                const int hm = dx ? ho[0][ch] : he[0][ch], h0 = dx ? ho[1][ch] : he[1][ch], hp = dx ? ho[2][ch] : he[2][ch];
+                const int v = dy ? (h0 + hp) * 4 : hm + h0 * 6 + hp;
+                const int up = sat16d((v + 32) >> 6);
+                const short lap = sat16d((int)fv[3 * dx + ch] - up);
+                dv[3 * dx + ch] = (short)(dv[3 * dx + ch] + (short)((float)lap * wv));
+            }
+        }
+        dp[0] = (unsigned)(unsigned short)dv[0] | ((unsigned)(unsigned short)dv[1] << 16);
+        dp[1] = (unsigned)(unsigned short)dv[2] | ((unsigned)(unsigned short)dv[3] << 16);
+        dp[2] = (unsigned)(unsigned short)dv[4] | ((unsigned)(unsigned short)dv[5] << 16);
+        float2* wp2 = reinterpret_cast<float2*>(dw + di);
+        float2 a2 = *wp2; a2.x += wv2[0]; a2.y += wv2[1]; *wp2 = a2;
     }
 }
 
@@ -230,24 +424,11 @@ static int blend_core(mi355_ctx* ctx, const uint8_t* const* chips, const uint8_t
     DevBuf& dmask = ctx->buf("blend_mask");
     DevBuf& glap = ctx->buf("blend_src_lap");
     DevBuf& gwgt = ctx->buf("blend_src_w");
-    // every staging buffer is sized for the largest chip up front: the per-chip work below is then pure stream-ordered launches
-    // (no allocation, no synchronisation between chips; the next chip's upload / pyramid simply queues behind this chip's kernels)
-    {
-        size_t max_px = 0, max_chip = 0, max_mask = 0;
-        for (int k = 0; k < n; k++) {
-            if (info[k].w <= 0 || info[k].h <= 0) continue;
-            const size_t rw = (size_t)info[k].w + 8 * (size_t)al, rh = (size_t)info[k].h + 8 * (size_t)al;     // region <= chip + 2 x (3 al gap + al rounding)
-            size_t px = 0;
-            for (int l = 0; l <= nb; l++) px += (rw >> l) * (rh >> l);
-            if (px > max_px) max_px = px;
-            const size_t cb = (size_t)((info[k].w * 3 + 3) & ~3) * info[k].h, mb = (size_t)((info[k].w + 3) & ~3) * info[k].h;
-            if (cb > max_chip) max_chip = cb;
-            if (mb > max_mask) max_mask = mb;
-        }
-        MI_HIP(glap.reserve(max_px * 3 * sizeof(short)));
-        MI_HIP(gwgt.reserve(max_px * sizeof(float)));
-        if (!on_device) { MI_HIP(dchip.reserve(max_chip + 16)); MI_HIP(dmask.reserve(max_mask + 16)); }
-    }
+    DevBuf& dpar = ctx->buf("blend_chip_params");
+    // geometry of every chip (MultiBandBlender::feed: gap 3 * 2^bands, corners snapped to the level grid, region pulled back inside the canvas)
+    struct Geo { int k, tlx, tly; };
+    std::vector<ChipP> par; std::vector<Geo> geo;
+    par.reserve(n); geo.reserve(n);
     for (int k = 0; k < n; k++) {
         const int cw = info[k].w, chh = info[k].h, x0 = info[k].x0, y0 = info[k].y0;
         if (cw <= 0 || chh <= 0) continue;
@@ -262,32 +443,87 @@ static int blend_core(mi355_ctx* ctx, const uint8_t* const* chips, const uint8_t
         const int dx = brx - Wp > 0 ? brx - Wp : 0, dy = bry - Hp > 0 ? bry - Hp : 0;
         tlx -= dx; tly -= dy;
         if (tlx < 0 || tly < 0 || rw <= 0 || rh <= 0) { ctx->set_error("multiband_blend: chip outside the canvas"); return MI355_ERR_ARG; }
-        const int left = x0 - tlx, top = y0 - tly;
-        const int cws = (cw * 3 + 3) & ~3, mws = (cw + 3) & ~3;
-        std::vector<size_t> roff(nb + 2, 0);
-        for (int l = 0; l <= nb; l++) roff[l + 1] = roff[l] + (size_t)(rw >> l) * (rh >> l);
-        MI_HIP(glap.reserve(roff[nb + 1] * 3 * sizeof(short)));
-        MI_HIP(gwgt.reserve(roff[nb + 1] * sizeof(float)));
-        const uint8_t* d_chip = chips[k];
-        const uint8_t* d_mask = masks[k];
+        ChipP c; memset(&c, 0, sizeof(c));
+        c.chip = chips[k]; c.mask = masks[k];
+        c.cw = cw; c.ch = chh; c.cws = (cw * 3 + 3) & ~3; c.mws = (cw + 3) & ~3;
+        c.left = x0 - tlx; c.top = y0 - tly; c.rw = rw; c.rh = rh;
+        par.push_back(c); geo.push_back({k, tlx, tly});
+    }
+    const int nc = (int)par.size();
+    // batches of up to 32 chips whose levels >= 1 (10 bytes per pixel, a third of the region) fit 2 GB; host chips are staged per batch
+    constexpr int MAXB = 32;
+    const size_t tmp_budget_px = ((size_t)2 << 30) / 10;
+    auto levels_px = [&](const ChipP& c) { size_t px = 0; for (int l = 1; l <= nb; l++) px += (size_t)(c.rw >> l) * (c.rh >> l); return px; };
+    struct Batch { int b0, b1, maxw, maxh; size_t px, cbytes, mbytes; };
+    std::vector<Batch> batches;
+    size_t max_px = 0, max_cb = 0, max_mb = 0;
+    for (int b0 = 0; b0 < nc;) {
+        Batch bt = {b0, b0, 0, 0, 0, 0, 0};
+        while (bt.b1 < nc && bt.b1 - b0 < MAXB) {
+            ChipP& c = par[bt.b1];
+            const size_t p = nb > 0 ? levels_px(c) : (size_t)c.rw * c.rh;
+            if (bt.b1 > b0 && bt.px + p > tmp_budget_px) break;
+            c.tmp = bt.px; bt.px += p;
+            if (!on_device) { bt.cbytes += ((size_t)c.cws * c.ch + 15) & ~(size_t)15; bt.mbytes += ((size_t)c.mws * c.ch + 15) & ~(size_t)15; }
+            bt.maxw = c.rw > bt.maxw ? c.rw : bt.maxw; bt.maxh = c.rh > bt.maxh ? c.rh : bt.maxh;
+            bt.b1++;
+        }
+        max_px = bt.px > max_px ? bt.px : max_px; max_cb = bt.cbytes > max_cb ? bt.cbytes : max_cb; max_mb = bt.mbytes > max_mb ? bt.mbytes : max_mb;
+        batches.push_back(bt);
+        b0 = bt.b1;
+    }
+    // every buffer is sized once, up front: the work below is then pure stream-ordered copies and launches (no allocation, no
+    // synchronisation between chips or batches)
+    MI_HIP(glap.reserve(max_px * 3 * sizeof(short) + 16));
+    MI_HIP(gwgt.reserve(max_px * sizeof(float) + 16));
+    MI_HIP(dpar.reserve((size_t)(nc > 0 ? nc : 1) * sizeof(ChipP)));
+    if (!on_device) { MI_HIP(dchip.reserve(max_cb + 16)); MI_HIP(dmask.reserve(max_mb + 16)); }
+    for (const Batch& bt : batches) {
+        const int b0 = bt.b0, b1 = bt.b1, B = b1 - b0, maxw = bt.maxw, maxh = bt.maxh;
         if (!on_device) {
-            MI_HIP(dchip.reserve((size_t)cws * chh));
-            MI_HIP(dmask.reserve((size_t)mws * chh));
-            MI_HIP(hipMemcpyAsync(dchip.p, chips[k], (size_t)cws * chh, hipMemcpyHostToDevice, st));
-            MI_HIP(hipMemcpyAsync(dmask.p, masks[k], (size_t)mws * chh, hipMemcpyHostToDevice, st));
-            d_chip = dchip.as<uint8_t>(); d_mask = dmask.as<uint8_t>();
+            size_t co = 0, mo = 0;
+            for (int i = b0; i < b1; i++) {
+                const size_t cb = (size_t)par[i].cws * par[i].ch, mb = (size_t)par[i].mws * par[i].ch;
+                MI_HIP(hipMemcpyAsync(dchip.as<uint8_t>() + co, par[i].chip, cb, hipMemcpyHostToDevice, st));
+                MI_HIP(hipMemcpyAsync(dmask.as<uint8_t>() + mo, par[i].mask, mb, hipMemcpyHostToDevice, st));
+                par[i].chip = dchip.as<uint8_t>() + co; par[i].mask = dmask.as<uint8_t>() + mo;
+                co += (cb + 15) & ~(size_t)15; mo += (mb + 15) & ~(size_t)15;
+            }
         }
         short* g = glap.as<short>();
         float* wp = gwgt.as<float>();
-        hipLaunchKernelGGL(blend_prep_kernel, grid2(rw, rh), dim3(256), 0, st, d_chip, cws, d_mask, mws, cw, chh, left, top, rw, rh, g, wp);
-        for (int l = 0; l < nb; l++)
-            hipLaunchKernelGGL(pyr_down_pair_kernel, grid2(((rw >> (l + 1)) + 1) / 2, rh >> (l + 1)), dim3(256), 0, st, g + roff[l] * 3, wp + roff[l], rw >> l, rh >> l,
-                               g + roff[l + 1] * 3, wp + roff[l + 1]);
-        for (int l = 0; l < nb; l++)                                // Laplacian level l = Gaussian l - EXPAND(Gaussian l + 1), accumulated as it is formed
-            hipLaunchKernelGGL(blend_lap_accumulate_kernel, grid2(rw >> (l + 1), rh >> (l + 1)), dim3(256), 0, st, g + roff[l + 1] * 3, rw >> (l + 1), rh >> (l + 1),
-                               g + roff[l] * 3, wp + roff[l], tlx >> l, tly >> l, dlap.as<short>() + loff[l] * 3, dwgt.as<float>() + loff[l], Wp >> l);
-        hipLaunchKernelGGL(blend_accumulate_kernel, grid2(rw >> nb, rh >> nb), dim3(256), 0, st, g + roff[nb] * 3, wp + roff[nb], rw >> nb, rh >> nb, tlx >> nb, tly >> nb,
-                           dlap.as<short>() + loff[nb] * 3, dwgt.as<float>() + loff[nb], Wp >> nb);
+        if (nb == 0) {
+            // no pyramid: level 0 is the only level; it is materialised and accumulated (the path of bands = 0)
+            for (int i = b0; i < b1; i++) {
+                const ChipP& c = par[i];
+                hipLaunchKernelGGL(blend_prep_kernel, grid2(c.rw, c.rh), dim3(256), 0, st, c.chip, c.cws, c.mask, c.mws, c.cw, c.ch, c.left, c.top, c.rw, c.rh, g + c.tmp * 3, wp + c.tmp);
+                hipLaunchKernelGGL(blend_accumulate_kernel, grid2(c.rw, c.rh), dim3(256), 0, st, g + c.tmp * 3, wp + c.tmp, c.rw, c.rh, geo[i].tlx, geo[i].tly,
+                                   dlap.as<short>(), dwgt.as<float>(), Wp);
+            }
+            MI_HIP(hipGetLastError());
+            continue;
+        }
+        // the chips' parameters of this batch (the slot of the previous batch may still be read: one slot per batch, sized once)
+        const ChipP* d_par = dpar.as<ChipP>() + b0;
+        MI_HIP(hipMemcpyAsync(dpar.as<ChipP>() + b0, par.data() + b0, (size_t)B * sizeof(ChipP), hipMemcpyHostToDevice, st));
+        // REDUCE chains of the whole batch: independent of one another and of the canvas
+        hipLaunchKernelGGL(pyr_down0_batch_kernel, dim3((unsigned)((((maxw >> 1) + 1) / 2 + 255) / 256), (unsigned)(maxh >> 1), (unsigned)B), dim3(256), 0, st, d_par, g, wp);
+        for (int l = 1; l < nb; l++)
+            hipLaunchKernelGGL(pyr_down_pair_batch_kernel, dim3((unsigned)((((maxw >> (l + 1)) + 1) / 2 + 255) / 256), (unsigned)(maxh >> (l + 1)), (unsigned)B), dim3(256), 0, st, d_par, l, g, wp);
+        // accumulation, chip after chip in chip order: Laplacian level l = Gaussian l - EXPAND(Gaussian l + 1), accumulated as it is formed
+        for (int i = b0; i < b1; i++) {
+            const ChipP& c = par[i];
+            const int tlx = geo[i].tlx, tly = geo[i].tly, rw = c.rw, rh = c.rh;
+            std::vector<size_t> roff(nb + 2, 0);                      // levels >= 1 behind c.tmp
+            roff[1] = c.tmp;
+            for (int l = 1; l < nb; l++) roff[l + 1] = roff[l] + (size_t)(rw >> l) * (rh >> l);
+            hipLaunchKernelGGL(blend_lap0_accumulate_kernel, grid2(rw >> 1, rh >> 1), dim3(256), 0, st, c, g + roff[1] * 3, tlx, tly, dlap.as<short>(), dwgt.as<float>(), Wp);
+            for (int l = 1; l < nb; l++)
+                hipLaunchKernelGGL(blend_lap_accumulate_kernel, grid2(rw >> (l + 1), rh >> (l + 1)), dim3(256), 0, st, g + roff[l + 1] * 3, rw >> (l + 1), rh >> (l + 1),
+                                   g + roff[l] * 3, wp + roff[l], tlx >> l, tly >> l, dlap.as<short>() + loff[l] * 3, dwgt.as<float>() + loff[l], Wp >> l);
+            hipLaunchKernelGGL(blend_accumulate_kernel, grid2(rw >> nb, rh >> nb), dim3(256), 0, st, g + roff[nb] * 3, wp + roff[nb], rw >> nb, rh >> nb, tlx >> nb, tly >> nb,
+                               dlap.as<short>() + loff[nb] * 3, dwgt.as<float>() + loff[nb], Wp >> nb);
+        }
         MI_HIP(hipGetLastError());
     }
     for (int l = 0; l <= nb; l++) {
