@@ -29,6 +29,8 @@
     if (hipSetDevice(ctx->device) != hipSuccess) { ctx->set_error("hipSetDevice failed"); return MI355_ERR_DEVICE; }
 
 // grow-only device buffer (workspaces live as long as the ctx: no hipMalloc in steady state)
+constexpr int MI355_SIFT_BATCH_MAX = 32;      // frames per SIFT batch (per-frame pointers travel in kernel arguments)
+
 struct DevBuf {
     void*  p = nullptr;
     size_t cap = 0;
@@ -159,7 +161,8 @@ int mi_bf_match(mi355_ctx*, int img_i, int img_j, int sorted, mi355_dmatch* matc
 int mi_select_grid(mi355_ctx*, const mi355_dmatch* sorted, int n, const float* kp1, int nk1, const float* kp2, int nk2,
                    int nMatch, int width, int height, int gx, int gy, mi355_sfpoint* v1, mi355_sfpoint* v2, int* n_out);
 int mi_set_features(mi355_ctx*, int img_id, const mi355_keypoint* kp, const float* desc, int n, int w, int h);
-int mi_finish_features(mi355_ctx*, Features& f, const int* d_n = nullptr, hipStream_t st = nullptr);   // builds xy / int8 rows / norms from kp + d8 on device
+int mi_finish_features(mi355_ctx*, Features& f, const int* d_n = nullptr, hipStream_t st = nullptr);
+int mi_finish_features_batch(mi355_ctx*, Features* const* fs, int nf, const int* d_n, int n_stride, hipStream_t st);   // all frames of a SIFT batch, one launch   // builds xy / int8 rows / norms from kp + d8 on device
 int mi_resolve_features(mi355_ctx*);               // waits for in-flight SIFT frames and adopts their keypoint counts
 int mi_resolve_features_of(mi355_ctx*, const int* ids, int n);   // the same for the given frames only (waits for their batches' events)
 int mi_sift_extract_dev(mi355_ctx*, int img_id, const uint8_t* d_bgr, int w, int h, int ws, int* n_kp);

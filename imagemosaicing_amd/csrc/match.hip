@@ -317,6 +317,34 @@ __global__ __launch_bounds__(256) void finish_features_kernel(const mi355_keypoi
     }
 }
 
+// the same for all frames of a SIFT batch in one launch (blockIdx.y = frame): 32 launches of 5 us at the tail of every batch were 160 us
+// during which the batch's stream held a slot of the pipeline for nothing
+struct FinishBatch {
+    const mi355_keypoint* kp[MI355_SIFT_BATCH_MAX]; const uint8_t* d8[MI355_SIFT_BATCH_MAX];
+    float2* xy[MI355_SIFT_BATCH_MAX]; int8_t* s8[MI355_SIFT_BATCH_MAX]; int* n8[MI355_SIFT_BATCH_MAX];
+};
+__global__ __launch_bounds__(256) void finish_features_batch_kernel(FinishBatch fb, const int* d_n, int n_stride, int npad) {
+    const int k = blockIdx.y;
+    const int row = blockIdx.x * 32 + (threadIdx.x >> 3), part = threadIdx.x & 7;
+    if (row >= npad) return;
+    const int n = d_n[(size_t)k * n_stride];
+    const uint8_t* d8 = fb.d8[k];
+    uint4 v = make_uint4(0x80808080u, 0x80808080u, 0x80808080u, 0x80808080u);
+    if (row < n) v = *reinterpret_cast<const uint4*>(d8 + (size_t)row * 128 + part * 16);
+    const unsigned w[4] = {v.x, v.y, v.z, v.w};
+    int s = 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+#pragma unroll
+        for (int b = 0; b < 4; b++) { const int t = (int)((w[q] >> (8 * b)) & 0xffu) - 128; s += t * t; }
+    *reinterpret_cast<uint4*>(fb.s8[k] + (size_t)row * 128 + part * 16) = make_uint4(v.x ^ 0x80808080u, v.y ^ 0x80808080u, v.z ^ 0x80808080u, v.w ^ 0x80808080u);
+    s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4);
+    if (part == 0) {
+        fb.n8[k][row] = s;
+        if (row < n) fb.xy[k][row] = make_float2(fb.kp[k][row].x, fb.kp[k][row].y);
+    }
+}
+
 __global__ void desc_f32_to_u8_kernel(const float* f, uint8_t* d8, size_t count) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
@@ -366,6 +394,28 @@ int mi_finish_features(mi355_ctx* ctx, Features& f, const int* d_n, hipStream_t 
     ProfScope ps(ctx, "features", (double)f.npad * 128 * 2, st);
     hipLaunchKernelGGL(finish_features_kernel, dim3((f.npad + 31) / 32), dim3(256), 0, st,
                        f.kp.as<mi355_keypoint>(), f.d8.as<uint8_t>(), f.n, d_n, f.npad, f.xy.as<float2>(), f.s8.as<int8_t>(), f.n8.as<int>());
+    MI_HIP(hipGetLastError());
+    return MI355_OK;
+}
+
+// the matcher's operands of all frames of a SIFT batch; the keypoint counts are still on the device (d_n[k * n_stride])
+int mi_finish_features_batch(mi355_ctx* ctx, Features* const* fs, int nf, const int* d_n, int n_stride, hipStream_t st) {
+    if (nf <= 0) return MI355_OK;
+    if (nf > MI355_SIFT_BATCH_MAX) return MI355_ERR_ARG;
+    FinishBatch fb;
+    memset(&fb, 0, sizeof(fb));
+    const int npad = ((KSTRIDE + ROWPAD - 1) / ROWPAD) * ROWPAD;
+    for (int k = 0; k < nf; k++) {
+        Features& f = *fs[k];
+        f.npad = npad;
+        MI_HIP(f.xy.reserve(sizeof(float2) * (size_t)KSTRIDE));
+        MI_HIP(f.s8.reserve((size_t)128 * (size_t)npad));
+        MI_HIP(f.n8.reserve(sizeof(int) * (size_t)npad));
+        fb.kp[k] = f.kp.as<mi355_keypoint>(); fb.d8[k] = f.d8.as<uint8_t>();
+        fb.xy[k] = f.xy.as<float2>(); fb.s8[k] = f.s8.as<int8_t>(); fb.n8[k] = f.n8.as<int>();
+    }
+    ProfScope ps(ctx, "features", (double)npad * 128 * 2 * nf, st);
+    hipLaunchKernelGGL(finish_features_batch_kernel, dim3((npad + 31) / 32, nf), dim3(256), 0, st, fb, d_n, n_stride, npad);
     MI_HIP(hipGetLastError());
     return MI355_OK;
 }

@@ -39,7 +39,7 @@ constexpr int FIXPT_SCALE = 48;                 // SIFT_FIXPT_SCALE of the refer
 constexpr float DOG_THRESHOLD_P1 = 21.0f;       // |DoG| > floor(0.5 * 0.01 / 3 * 255 * 48) = 20, on integers: |DoG| >= 21
 constexpr float HIST_Q = 1024.0f;               // order-free histogram accumulation: contributions quantised to 2^-10 (oracle_sift.c)
 constexpr int MAX_R = 16;
-constexpr int SIFT_BATCH_MAX = 32;
+constexpr int SIFT_BATCH_MAX = MI355_SIFT_BATCH_MAX;
 typedef int16_t lvl_t;                          // one pyramid sample
 
 __host__ __device__ __forceinline__ int reflect101(int p, int n) {
@@ -1772,16 +1772,21 @@ static int sift_run_batch(mi355_ctx* ctx, SiftWork* s) {
         hipLaunchKernelGGL(describe_kernel, dim3(((int)SEL_STRIDE + 3) / 4, n), dim3(256), 0, st, s->P, s->sel.as<SelRec>(), reinterpret_cast<const int*>(cnt + 3), outs, bs);
     }
     MI_HIP(hipGetLastError());
-    for (int k = 0; k < n; k++) {
-        Features& f = *fs[k];
-        unsigned* ck = cnt + (size_t)k * CNT_STRIDE;
-        int rc = mi_finish_features(ctx, f, reinterpret_cast<const int*>(ck + 3), st);
-        if (rc != MI355_OK) return rc;
-        int* hc = pinned_slot(ctx);
-        if (!hc) { ctx->set_error("sift: pinned alloc failed"); return MI355_ERR_NOMEM; }
-        MI_HIP(hipMemcpyAsync(hc, ck, 8 * sizeof(unsigned), hipMemcpyDeviceToHost, st));
-        f.h_cnt = hc; f.pending = true; f.n = 0;
-        f.caps[0] = 0xffffffffu; f.caps[1] = s->ref_cap; f.caps[2] = s->kp_cap;      // candidate overflow is flagged by the kernel (cnt[4])
+    // the matcher's operands of all n frames in one launch, their counters in one strided copy (n launches + n copies of ~5 us each kept
+    // the batch's stream, and a pipeline slot, busy for 0.3 ms per batch of 32)
+    { int rc = mi_finish_features_batch(ctx, fs.data(), n, reinterpret_cast<const int*>(cnt + 3), (int)CNT_STRIDE, st); if (rc != MI355_OK) return rc; }
+    {
+        if (ctx->pinned_used % PINNED_CHUNK + (size_t)n > PINNED_CHUNK) ctx->pinned_used += PINNED_CHUNK - ctx->pinned_used % PINNED_CHUNK;   // n slots in one chunk
+        int* h0 = nullptr;
+        for (int k = 0; k < n; k++) {
+            int* hc = pinned_slot(ctx);
+            if (!hc) { ctx->set_error("sift: pinned alloc failed"); return MI355_ERR_NOMEM; }
+            if (k == 0) h0 = hc;
+            Features& f = *fs[k];
+            f.h_cnt = hc; f.pending = true; f.n = 0;
+            f.caps[0] = 0xffffffffu; f.caps[1] = s->ref_cap; f.caps[2] = s->kp_cap;      // candidate overflow is flagged by the kernel (cnt[4])
+        }
+        MI_HIP(hipMemcpy2DAsync(h0, 8 * sizeof(int), cnt, CNT_STRIDE * sizeof(unsigned), 8 * sizeof(unsigned), (size_t)n, hipMemcpyDeviceToHost, st));
     }
     MI_HIP(hipEventRecord(s->done, st));
     {                                                       // the batch's own event: mi_resolve_features_of() waits for it, not for the streams
