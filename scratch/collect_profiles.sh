@@ -44,5 +44,10 @@ python bench.py --as-rank 0,7 --of 8 --window 182 --steps 3 --warmup 1 > $O/r04_
 ./scratch/pk_rate > $O/r04_pk_rate.txt 2>> $O/bench.err
 python scratch/sift_time.py 96 4000 3000 32 > $O/r04_sift_time.txt 2>> $O/bench.err
 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29544 bench.py --gpus 2 --backend gloo --all-ranks-on-device0 --steps 2 --warmup 1 --frames 96 --no-cpu-baseline > $O/r04_bench_dryrun_2ranks_1device.json 2>> $O/bench.err
+# the blend's kernel breakdown (200 resident 12 MP chips) and the counters behind DESIGN's RANSAC paragraph
+bash scratch/prof_blend.sh 200 > /dev/null 2>&1; cp gpurun_out/prof_blend/blend_kernel_stats.txt $O/r04_blend_kernel_stats.txt; grep "^blend" gpurun_out/prof_blend/log.txt >> $O/r04_blend_kernel_stats.txt
+bash scratch/pmc_ransac.sh 2>/dev/null | grep "^p[123] " > $O/r04_pmc_ransac.txt
+# randomised parity soaks on this commit (GPU against the oracle): totals quoted in DESIGN.md
+( python scratch/soak.py 41 100; python scratch/soak.py 47 60 large; python scratch/soak_ransac.py 42 100; python scratch/soak_match.py 43 60; python scratch/soak_pairs.py 44 80; python scratch/soak_mosaic.py 45 60; python scratch/soak_api.py 46 60 ) 2>&1 | grep -iv "^RCCL\|^HIP\|^ROCm\|^Host\|^Librccl\|amdgpu.ids" | grep -i "mismatch\|cases\|soak" > $O/r04_soak_totals.txt
 tail -3 $O/bench.err
 ls -la $O
