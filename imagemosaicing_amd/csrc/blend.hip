@@ -262,9 +262,8 @@ __global__ __launch_bounds__(256) void pyr_up16_combine_kernel(const short* coar
 // third of the blend's kernel time).  Both levels stay Gaussian, so the levels can be taken in any order.
 // One thread per COARSE pixel = a 2 x 2 block of fine pixels: the 3 x 3 coarse neighbourhood is read once for the four of them (a thread
 // per fine pixel issued 27 two-byte loads each and ran at a quarter of the bandwidth the bytes need).
-__global__ __launch_bounds__(256) void blend_lap_accumulate_kernel(const short* coarse, int w, int h, const short* fine, const float* wgt, int ox, int oy,
-                                                                   short* dl, float* dw, int DW) {
-    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+__device__ __forceinline__ void blend_lap_accumulate_body(const short* coarse, int w, int h, const short* fine, const float* wgt, int ox, int oy,
+                                                          short* dl, float* dw, int DW, int x, int y) {
     if (x >= w) return;
     const int ym = (y == 0) ? (h > 1 ? 1 : 0) : y - 1, yp = (y == h - 1) ? h - 1 : y + 1;
     const short* rows[3] = {coarse + (size_t)ym * w * 3, coarse + (size_t)y * w * 3, coarse + (size_t)yp * w * 3};
@@ -303,6 +302,40 @@ __global__ __launch_bounds__(256) void blend_lap_accumulate_kernel(const short* 
         dp[2] = (unsigned)(unsigned short)dv[4] | ((unsigned)(unsigned short)dv[5] << 16);
         float2* wp2 = reinterpret_cast<float2*>(dw + di);
         float2 a2 = *wp2; a2.x += wv2.x; a2.y += wv2.y; *wp2 = a2;
+    }
+}
+
+__global__ __launch_bounds__(256) void blend_lap_accumulate_kernel(const short* coarse, int w, int h, const short* fine, const float* wgt, int ox, int oy,
+                                                                   short* dl, float* dw, int DW) {
+    blend_lap_accumulate_body(coarse, w, h, fine, wgt, ox, oy, dl, dw, DW, blockIdx.x * 256 + threadIdx.x, blockIdx.y);
+}
+
+// Levels 1 .. bands of one chip in ONE launch (blockIdx.y walks the rows of all of them): the Laplacian levels 1 .. bands - 1 and the top
+// (Gaussian) level.  Launched one by one the small levels cost ~8 us each whatever their size: four of the six launches per chip.
+constexpr int MAX_BANDS = 16;
+struct LapLevels {
+    int n;                                   // entries: n - 1 Laplacian levels, then the top level
+    int row0[MAX_BANDS + 1];                 // first grid row of entry i (row0[n] = grid rows)
+    int w[MAX_BANDS], h[MAX_BANDS], ox[MAX_BANDS], oy[MAX_BANDS], DW[MAX_BANDS];
+    size_t fine[MAX_BANDS], coarse[MAX_BANDS], dst[MAX_BANDS];      // pixel offsets into the chip pyramid (g / wp) and the canvas pyramids (dl / dw)
+};
+__global__ __launch_bounds__(256) void blend_lap_levels_kernel(LapLevels L, const short* g, const float* wp, short* dl, float* dw) {
+    int i = 0;
+#pragma unroll 1
+    while (i + 1 < L.n && (int)blockIdx.y >= L.row0[i + 1]) i++;
+    const int y = blockIdx.y - L.row0[i], x = blockIdx.x * 256 + threadIdx.x;
+    if (i + 1 < L.n) {
+        blend_lap_accumulate_body(g + L.coarse[i] * 3, L.w[i], L.h[i], g + L.fine[i] * 3, wp + L.fine[i], L.ox[i], L.oy[i], dl + L.dst[i] * 3, dw + L.dst[i], L.DW[i], x, y);
+    } else {
+        // top level: canvas Laplacian += (short)(Gaussian * weight), canvas weight += weight (blend_accumulate_kernel)
+        const int lw = L.w[i];
+        if (x >= lw) return;
+        const float wv = wp[L.fine[i] + (size_t)y * lw + x];
+        const size_t di = L.dst[i] + (size_t)(L.oy[i] + y) * L.DW[i] + (L.ox[i] + x);
+        const short* s = g + (L.fine[i] + (size_t)y * lw + x) * 3;
+#pragma unroll
+        for (int c = 0; c < 3; c++) dl[di * 3 + c] = (short)(dl[di * 3 + c] + (short)((float)s[c] * wv));
+        dw[di] += wv;
     }
 }
 
@@ -518,11 +551,30 @@ static int blend_core(mi355_ctx* ctx, const uint8_t* const* chips, const uint8_t
             roff[1] = c.tmp;
             for (int l = 1; l < nb; l++) roff[l + 1] = roff[l] + (size_t)(rw >> l) * (rh >> l);
             hipLaunchKernelGGL(blend_lap0_accumulate_kernel, grid2(rw >> 1, rh >> 1), dim3(256), 0, st, c, g + roff[1] * 3, tlx, tly, dlap.as<short>(), dwgt.as<float>(), Wp);
-            for (int l = 1; l < nb; l++)
-                hipLaunchKernelGGL(blend_lap_accumulate_kernel, grid2(rw >> (l + 1), rh >> (l + 1)), dim3(256), 0, st, g + roff[l + 1] * 3, rw >> (l + 1), rh >> (l + 1),
-                                   g + roff[l] * 3, wp + roff[l], tlx >> l, tly >> l, dlap.as<short>() + loff[l] * 3, dwgt.as<float>() + loff[l], Wp >> l);
-            hipLaunchKernelGGL(blend_accumulate_kernel, grid2(rw >> nb, rh >> nb), dim3(256), 0, st, g + roff[nb] * 3, wp + roff[nb], rw >> nb, rh >> nb, tlx >> nb, tly >> nb,
-                               dlap.as<short>() + loff[nb] * 3, dwgt.as<float>() + loff[nb], Wp >> nb);
+            if (nb > MAX_BANDS) {                                             // (band > 16 on a canvas that allows it:) level by level
+                for (int l = 1; l < nb; l++)
+                    hipLaunchKernelGGL(blend_lap_accumulate_kernel, grid2(rw >> (l + 1), rh >> (l + 1)), dim3(256), 0, st, g + roff[l + 1] * 3, rw >> (l + 1), rh >> (l + 1),
+                                       g + roff[l] * 3, wp + roff[l], tlx >> l, tly >> l, dlap.as<short>() + loff[l] * 3, dwgt.as<float>() + loff[l], Wp >> l);
+                hipLaunchKernelGGL(blend_accumulate_kernel, grid2(rw >> nb, rh >> nb), dim3(256), 0, st, g + roff[nb] * 3, wp + roff[nb], rw >> nb, rh >> nb, tlx >> nb, tly >> nb,
+                                   dlap.as<short>() + loff[nb] * 3, dwgt.as<float>() + loff[nb], Wp >> nb);
+                continue;
+            }
+            LapLevels L; memset(&L, 0, sizeof(L));
+            int rows = 0, maxw = 0;
+            for (int l = 1; l < nb; l++) {                                     // Laplacian level l: one thread per pixel of level l + 1
+                const int i = L.n++;
+                L.row0[i] = rows; L.w[i] = rw >> (l + 1); L.h[i] = rh >> (l + 1); L.ox[i] = tlx >> l; L.oy[i] = tly >> l; L.DW[i] = Wp >> l;
+                L.fine[i] = roff[l]; L.coarse[i] = roff[l + 1]; L.dst[i] = loff[l];
+                rows += L.h[i]; maxw = L.w[i] > maxw ? L.w[i] : maxw;
+            }
+            {
+                const int i = L.n++;
+                L.row0[i] = rows; L.w[i] = rw >> nb; L.h[i] = rh >> nb; L.ox[i] = tlx >> nb; L.oy[i] = tly >> nb; L.DW[i] = Wp >> nb;
+                L.fine[i] = roff[nb]; L.coarse[i] = 0; L.dst[i] = loff[nb];
+                rows += L.h[i]; maxw = L.w[i] > maxw ? L.w[i] : maxw;
+            }
+            L.row0[L.n] = rows;
+            hipLaunchKernelGGL(blend_lap_levels_kernel, grid2(maxw, rows), dim3(256), 0, st, L, g, wp, dlap.as<short>(), dwgt.as<float>());
         }
         MI_HIP(hipGetLastError());
     }
