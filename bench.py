@@ -504,7 +504,7 @@ def main():
         ctx.profile_enable(not os.environ.get("MI355_BENCH_NOPROF"))
     prof_all = {}
     if args.profile_all:
-        for cls in ("gauss_stream", "gauss", "downsample", "extrema", "gather", "refine", "kp_select", "orient", "topk", "describe", "features", "match", "select", "ransac", "warp"):
+        for cls in ("gauss_stream", "gauss", "downsample", "extrema", "refine", "kp_select", "orient", "topk", "describe", "features", "match", "select", "ransac", "warp"):
             ms, n, b = ctx.profile_get(cls)
             prof_all[cls] = {"ms_per_step": ms / max(args.steps, 1), "launches_per_step": n / max(args.steps, 1)}
     ctx.profile_enable(False)

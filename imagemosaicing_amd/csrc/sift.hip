@@ -618,7 +618,7 @@ void extrema_stream(OctaveDev oc, int octave, unsigned long long* cand, unsigned
     // Candidates are rare per lane but not per wave (a 12 MP frame has ~2 per wave-row): a hit only appends its 8-byte record to a
     // wave-private LDS list (slots from a ballot, the list length is wave-uniform and lives in a scalar); the list goes to the region's
     // candidate list behind one region-counter atomic per flush.  The 3x3x3 DoG neighbourhoods refine starts from are gathered by
-    // cube_gather_kernel afterwards, one lane per candidate: gathered here (round 3), every flush stalled its wave for the round trip of
+    // refine_kernel itself, one lane per candidate: gathered here (round 3), every flush stalled its wave for the round trip of
     // 36 scattered loads of rows that had long left the L2 -- a third of this kernel's time (73 -> 49 us per 12 MP frame without).
     __shared__ unsigned long long s_rec[4][XCAP];
     int nq = 0;                                      // wave-uniform
@@ -632,7 +632,7 @@ void extrema_stream(OctaveDev oc, int octave, unsigned long long* cand, unsigned
         for (int idx = lane; idx < nq; idx += 64) {
             const unsigned g = base + (unsigned)idx;
             if (g >= cap) { *overflow = 1; continue; }
-            cand[(size_t)reg * cap + g] = s_rec[wave][idx] | (g < cube_cap ? (1ull << 63) : 0ull);      // bit 63: cube_gather_kernel fills in the neighbourhood
+            cand[(size_t)reg * cap + g] = s_rec[wave][idx];                                             // bit 63 clear: refine_kernel gathers the neighbourhood itself
         }
         wave_sync();
         nq = 0;
@@ -711,46 +711,6 @@ void extrema_stream(OctaveDev oc, int octave, unsigned long long* cand, unsigned
     }
 }
 
-// The 3x3x3 DoG neighbourhood of every candidate the streamed test found (octaves in `omask`; the tiled extrema_kernel writes its
-// own from LDS): one lane per candidate, twelve 8-byte loads (three rows of four levels: the three columns lie inside the four that
-// start at the even column (c - 1) & ~1 -- inside the row, candidates keep IMG_BORDER columns off the edges; 4-byte aligned, the
-// streamed test needs w % 4 == 0), 27 floats out.  Every candidate independent: the latency the flush of extrema_stream used to wait
-// for is hidden by occupancy here.
-__global__ __launch_bounds__(256) void cube_gather_kernel(PyrDev P, const unsigned long long* cand_all, const unsigned* cand_counts, unsigned cand_cap,
-                                                          float* cube_all, unsigned cube_cap, unsigned omask, BatchStride bs) {
-    const size_t fr = blockIdx.z, foff = fr * bs.pyr;
-    cube_all += fr * bs.cube; cand_all += fr * bs.cand; cand_counts += fr * CCNT_STRIDE;
-    const unsigned reg = blockIdx.y;
-    unsigned n = cand_counts[reg * REG_STRIDE];
-    if (n > cand_cap) n = cand_cap;
-    if (n > cube_cap) n = cube_cap;
-    const unsigned long long* cand = cand_all + (size_t)reg * cand_cap;
-    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const unsigned long long pk = cand[i];
-        const int o = (int)((pk >> 48) & 0xff);
-        if (!((omask >> o) & 1u)) continue;
-        const int L = (int)((pk >> 40) & 0xff), R = (int)((pk >> 20) & 0xfffff), C = (int)(pk & 0xfffff);
-        const OctaveDev& oc = P.oc[o];
-        const int a0 = (C - 1) & ~1, sh = ((C - 1) & 1) * 16;
-        int v[4][9];
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const lvl_t* lp = oc.lv[L - 1 + q] + foff;
-#pragma unroll
-            for (int dr = 0; dr < 3; dr++) {
-                const uint2 wv = *reinterpret_cast<const uint2*>(lp + (size_t)(R - 1 + dr) * oc.w + a0);
-                const unsigned long long ww = (((unsigned long long)wv.y << 32) | wv.x) >> sh;
-                v[q][dr * 3 + 0] = (int)(short)(ww & 0xffffu); v[q][dr * 3 + 1] = (int)(short)((ww >> 16) & 0xffffu); v[q][dr * 3 + 2] = (int)(short)((ww >> 32) & 0xffffu);
-            }
-        }
-        float* cb = cube_all + (size_t)reg * 32 * cube_cap + i;            // element e of candidate i at [e][i]: the lanes of a wave write runs of 256 bytes
-#pragma unroll
-        for (int dl = 0; dl < 3; dl++)
-#pragma unroll
-            for (int e = 0; e < 9; e++) cb[(size_t)(dl * 9 + e) * cube_cap] = (float)(v[dl + 1][e] - v[dl][e]);
-    }
-}
-
 __global__ __launch_bounds__(256) void refine_kernel(PyrDev P, const unsigned long long* cand_all, const unsigned* cand_counts, unsigned cand_cap, unsigned* cand_total,
                                                      float contrast_thr, float edge_thr, float sigma,
                                                      Refined* out, unsigned* out_count, unsigned out_cap, unsigned* out_resp, BatchStride bs,
@@ -779,11 +739,39 @@ __global__ __launch_bounds__(256) void refine_kernel(PyrDev P, const unsigned lo
         int it = 0;
         bool alive = true, accepted = false;
         float contr = 0.0f;
-        if (pk >> 63) {
-            // first step from the 3x3x3 neighbourhood extrema_kernel saved next to the candidate (same values as the pyramid)
-            const float* cb = cube_all + (size_t)reg * 32 * cube_cap + i;       // [element][candidate]: coalesced across the lanes
+        // The first step -- the only one for two candidates out of three -- from the 3x3x3 neighbourhood held in registers: either the one
+        // extrema_kernel saved next to the candidate (bit 63; straight from its LDS planes), or, for the candidates of the streamed test,
+        // gathered here: three rows of four levels, the three columns inside the four that start at the even column (C - 1) & ~1 (twelve
+        // 8-byte loads instead of 54 two-byte ones).  Round 4 first gathered these in a kernel of its own and handed them over through
+        // HBM: the same twelve cold 64-byte sectors per candidate there, and a second time here for every candidate that moves on to a
+        // neighbouring pixel (one in three) -- now a mover's next step finds most of its sectors in the cache.
+        const bool from_cube = (pk >> 63) != 0;
+        if (from_cube || (oc.w & 1) == 0) {
+            float cv[27];
+            if (from_cube) {
+                const float* cb = cube_all + (size_t)reg * 32 * cube_cap + i;       // [element][candidate]: coalesced across the lanes
+#pragma unroll
+                for (int e = 0; e < 27; e++) cv[e] = cb[(size_t)e * cube_cap];
+            } else {
+                const int a0 = (C - 1) & ~1, sh = ((C - 1) & 1) * 16;
+                int v[4][9];
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const lvl_t* lp = oc.lv[L - 1 + q] + foff;
+#pragma unroll
+                    for (int dr = 0; dr < 3; dr++) {
+                        const uint2 wv = *reinterpret_cast<const uint2*>(lp + (size_t)(R - 1 + dr) * oc.w + a0);
+                        const unsigned long long ww = (((unsigned long long)wv.y << 32) | wv.x) >> sh;
+                        v[q][dr * 3 + 0] = (int)(short)(ww & 0xffffu); v[q][dr * 3 + 1] = (int)(short)((ww >> 16) & 0xffffu); v[q][dr * 3 + 2] = (int)(short)((ww >> 32) & 0xffffu);
+                    }
+                }
+#pragma unroll
+                for (int dl = 0; dl < 3; dl++)
+#pragma unroll
+                    for (int e = 0; e < 9; e++) cv[dl * 9 + e] = (float)(v[dl + 1][e] - v[dl][e]);
+            }
             const int L0 = L, R0 = R, C0 = C;
-            auto dvc = [&](int l, int r, int c) { return cb[(size_t)((l - L0 + 1) * 9 + (r - R0 + 1) * 3 + (c - C0 + 1)) * cube_cap]; };
+            auto dvc = [&](int l, int r, int c) { return cv[(l - L0 + 1) * 9 + (r - R0 + 1) * 3 + (c - C0 + 1)]; };
             f = fit_step(dvc, L, R, C);
             const int stt = fit_state(f);
             if (stt == 1) continue;
@@ -1672,7 +1660,6 @@ static int sift_run_batch(mi355_ctx* ctx, SiftWork* s) {
     };
     // ---- phases 1+2: the pyramid, octave by octave, every launch covering all n frames of the batch ----
     bool ds_fused = false;
-    unsigned xs_octaves = 0;                              // octaves whose extrema came from extrema_stream (their neighbourhoods: cube_gather_kernel)
     for (int o = 0; o < s->n_oct; o++) {
         const OctaveDev& oc = s->P.oc[o];
         const double level_bytes = (double)oc.w * oc.h * sizeof(lvl_t) * n;
@@ -1712,7 +1699,6 @@ static int sift_run_batch(mi355_ctx* ctx, SiftWork* s) {
             // the streamed test pays off on the big octaves of a full batch; smaller launches do not keep enough rows in flight and stay with the tiled kernel
             const bool xs = ctx->blur_stream && (oc.w & 3) == 0 && oc.w >= ctx->xstream_min_w && oc.h >= ctx->xstream_min_w * 3 / 4 && n >= ctx->xstream_min_frames;
             if (xs) {
-                xs_octaves |= 1u << o;
                 // no row halo to amortise here (3 + XD rows to prime a segment): many short segments balance the wave slots
                 const int nstrip = (oc.w + XSW - 1) / XSW;
                 const int xsw = ((oc.w + nstrip - 1) / nstrip + 3) & ~3;      // equal strips (<= 248 columns) instead of a nearly empty last one
@@ -1738,12 +1724,6 @@ static int sift_run_batch(mi355_ctx* ctx, SiftWork* s) {
         MI_HIP(hipEventRecord(ctx->heavy_ev, st)); ctx->heavy_ev_valid = true;
     }
     // ---- phase 3: keypoint stages of all n frames ----
-    if (xs_octaves) {
-        ProfScope ps(ctx, "gather", 0.0, st);
-        static const int gather_gx = [] { const char* e = getenv("MI355_GATHER_GX"); return e ? atoi(e) : 8; }();       // ~2000 candidates per region of a 12 MP frame
-        hipLaunchKernelGGL(cube_gather_kernel, dim3(gather_gx, NREG, n), dim3(256), 0, st, s->P, s->cand.as<unsigned long long>(), s->ccnt.as<unsigned>(), s->cand_cap,
-                           s->cube.as<float>(), s->cube_cap, xs_octaves, bs);
-    }
     {
         ProfScope ps(ctx, "refine", 0.0, st);
         static const int refine_gx = [] { const char* e = getenv("MI355_REFINE_GX"); return e ? atoi(e) : 2; }();      // workgroups per candidate region: 32 x 64 regions x frames of mostly empty workgroups cost more to dispatch than the fits

@@ -13,7 +13,7 @@ SERIAL = len(sys.argv) > 5 and sys.argv[5] == "serial"      # one slot, no event
 ctx = im.Context(0)
 ctx.set_option("sift_batch", B)
 frames, A, gains, ws = render_frames(ctx, torch, F, w, h)
-CLS = ("gauss_stream", "gauss", "downsample", "extrema", "gather", "refine", "kp_select", "orient", "topk", "describe", "features")
+CLS = ("gauss_stream", "gauss", "downsample", "extrema", "refine", "kp_select", "orient", "topk", "describe", "features")
 def run():
     for k in range(F):
         ctx.SiftExtractDev(k, frames[k].data_ptr(), w, h, ws)
