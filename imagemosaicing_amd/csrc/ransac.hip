@@ -750,6 +750,36 @@ int mi_ransac_batch(mi355_ctx* ctx, const mi355_sfpoint* d_p1, const mi355_sfpoi
     return MI355_OK;
 }
 
+// diagnostic (tests/test_gpu_parity.py): the guarded shared-reciprocal division of hmath.h against the compiler's correctly rounded a / b,
+// element by element: q_fast = hm::div_nr(a, b, hm::rcp_nr(b)), ok = the guard's verdict for this one quotient, q_true = a / b
+namespace {
+__global__ __launch_bounds__(256) void div_check_kernel(const float* a, const float* b, int n, float* q_fast, float* q_true, int* ok) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    hm::DivGuard g; hm::guard_init(g);
+    const float r = hm::rcp_nr(b[i], g);
+    q_fast[i] = hm::div_nr(a[i], b[i], r, g);
+    ok[i] = hm::guard_ok(g) ? 1 : 0;
+    q_true[i] = a[i] / b[i];
+}
+}  // namespace
+extern "C" int mi355_debug_div(mi355_ctx* ctx, const float* a, const float* b, int n, float* q_fast, float* q_true, int32_t* ok) {
+    if (!a || !b || !q_fast || !q_true || !ok || n <= 0) return MI355_ERR_ARG;
+    LOCKED_PROLOGUE
+    DevBuf& d = ctx->buf("debug_div");
+    MI_HIP(d.reserve((size_t)n * 5 * sizeof(float)));
+    float* da = d.as<float>(); float* db = da + n; float* dqf = db + n; float* dqt = dqf + n; int* dok = reinterpret_cast<int*>(dqt + n);
+    MI_HIP(hipMemcpyAsync(da, a, sizeof(float) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+    MI_HIP(hipMemcpyAsync(db, b, sizeof(float) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(div_check_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, da, db, n, dqf, dqt, dok);
+    MI_HIP(hipGetLastError());
+    MI_HIP(hipMemcpyAsync(q_fast, dqf, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+    MI_HIP(hipMemcpyAsync(q_true, dqt, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+    MI_HIP(hipMemcpyAsync(ok, dok, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+    MI_HIP(hipStreamSynchronize(ctx->stream));
+    return MI355_OK;
+}
+
 // diagnostic (tests/test_gpu_parity.py): the device-generated rand() stream of a seed, for comparison with libc's
 extern "C" int mi355_debug_rand_stream(mi355_ctx* ctx, uint32_t seed, int32_t* out, int n) {
     if (!out || n < 0 || n > RAW_STREAM) return MI355_ERR_ARG;

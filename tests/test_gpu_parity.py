@@ -226,6 +226,49 @@ def test_device_rand_stream_equals_glibc(ctx, oracle):
         assert np.array_equal(out, want), int((out != want).argmax())
 
 
+def test_guarded_division_equals_true_division(ctx):
+    """hmath.h rcp_nr / div_nr (the shared-reciprocal division of the RANSAC polish): wherever the guard accepts a quotient it has the
+    bits of the correctly rounded a / b -- 8 M random operand pairs over the whole exponent range, quotients next to rounding
+    boundaries, and the special values; and the guard does accept the magnitudes the polish works with."""
+    import ctypes as C
+    rng = np.random.default_rng(77)
+
+    def run(a, b):
+        a = np.ascontiguousarray(a, np.float32); b = np.ascontiguousarray(b, np.float32)
+        n = len(a)
+        qf = np.zeros(n, np.float32); qt = np.zeros(n, np.float32); ok = np.zeros(n, np.int32)
+        p = lambda x: x.ctypes.data_as(C.c_void_p)
+        assert ctx.L.mi355_debug_div(ctx._h, p(a), p(b), n, p(qf), p(qt), p(ok)) == 0
+        return qf.view(np.uint32), qt.view(np.uint32), ok.astype(bool)
+
+    n = 1 << 22
+    # (1) every bit pattern is fair game: random sign / exponent / mantissa
+    a = rng.integers(0, 1 << 32, n, dtype=np.uint64).astype(np.uint32).view(np.float32)
+    b = rng.integers(0, 1 << 32, n, dtype=np.uint64).astype(np.uint32).view(np.float32)
+    qf, qt, ok = run(a, b)
+    assert np.array_equal(qf[ok], qt[ok]), int((qf[ok] != qt[ok]).sum())
+    # (2) the polish's magnitudes (coordinates, their products, pivots of J^T J): all accepted, all equal
+    mag = lambda lo, hi: np.exp2(rng.uniform(lo, hi, n)).astype(np.float32) * rng.choice(np.float32([-1, 1]), n)
+    a, b = mag(-20, 52), mag(-18, 52)
+    qf, qt, ok = run(a, b)
+    inwin = (np.abs(qt.view(np.float32)) >= 2.0 ** -70) & (np.abs(qt.view(np.float32)) <= 2.0 ** 38)
+    assert ok[inwin].all() and inwin.mean() > 0.7
+    assert np.array_equal(qf[ok], qt[ok])
+    # (3) quotients that sit next to a rounding boundary: a = round(q * b) for q with few mantissa bits, +- 1 ulp
+    q = (rng.integers(1 << 23, 1 << 24, n).astype(np.float32) * np.float32(2.0 ** -23))
+    b = mag(-10, 10)
+    a = (q * b).astype(np.float32)
+    a = np.nextafter(a, np.where(rng.random(n) < 0.5, np.float32(np.inf), np.float32(-np.inf))).astype(np.float32)
+    qf, qt, ok = run(a, b)
+    assert ok.mean() > 0.99 and np.array_equal(qf[ok], qt[ok])
+    # (4) special values are never accepted with other bits
+    sp = np.float32([0.0, -0.0, np.inf, -np.inf, np.nan, 1e-45, -1e-45, 1.17549435e-38, 3.4028235e38, 1.0, -1.0, 2.0 ** -100, 2.0 ** 100, 2.0 ** -31, 2.0 ** 63])
+    a, b = np.repeat(sp, len(sp)), np.tile(sp, len(sp))
+    qf, qt, ok = run(a, b)
+    assert np.array_equal(qf[ok], qt[ok])
+    assert not ok[(a == 0) | ~np.isfinite(a) | (b == 0) | ~np.isfinite(b)].any()
+
+
 # ---------------------------------------------------------------------------------------------- matching
 def test_bf_match_exact(ctx, oracle):
     """int8 MFMA distances (int32 accumulation) are exact integers: indices, 1-NN and 2-NN squared distances equal the CPU
