@@ -62,6 +62,18 @@ def streamed_lane_ops(w, h):
     return total
 
 
+def batch_for(frames_of_rank, big):
+    """frames per SIFT batch: 32 when the rank's frames fill three batches of 32 (the latency-bound launches of the small octaves and the
+    per-frame selections are then paid once per 32 frames; 3 x 32 frames in flight = 86 GB of work areas at 12 MP), otherwise a third of
+    the rank's frames so that all three batch work areas are in flight (a rank of an 8-rank C3 / C4 run owns 62-63 frames: two batches
+    of 32 leave a slot idle -- 21.0 instead of 21.9 ms per step for the rank's share); surveys that need the HBM themselves keep 16."""
+    if big:
+        return 16
+    if frames_of_rank >= 3 * 32:
+        return 32
+    return max(8, min(32, -(-frames_of_rank // SLOTS)))
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -194,11 +206,12 @@ def rank_share_proxy(args):
     torch.cuda.set_device(0)
     dev = torch.device("cuda", 0)
     global BATCH
+    batch_one = BATCH if BATCH > 0 else batch_for(args.frames, args.frames * args.width * args.height > 1000 * 4000 * 3000)
     if BATCH <= 0:
-        BATCH = 16 if args.frames * args.width * args.height > 1000 * 4000 * 3000 else 32
+        BATCH = batch_for(-(-args.frames // G), args.frames * args.width * args.height > 1000 * 4000 * 3000)
     ctx = im.Context(0)
     ctx.set_option("sift_slots", SLOTS)
-    ctx.set_option("sift_batch", BATCH)
+    ctx.set_option("sift_batch", batch_one)                       # the one-GPU reference pass runs with the one-GPU batch size
     stream = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(stream)
     ctx.set_stream(stream.cuda_stream)
@@ -252,6 +265,7 @@ def rank_share_proxy(args):
     t_one = timed(full_step, max(args.steps, 1))
     r_all = full_step(7)                                          # every frame's features + the survey's accepted records now resident
     ctx.synchronize()
+    ctx.set_option("sift_batch", BATCH)                           # a rank's own batch size (batch_for)
     n_max_frames = (F + G - 1) // G
     shares = {}
     for rk in ranks:
@@ -300,7 +314,7 @@ def rank_share_proxy(args):
     out = {"kind": "rank_share_proxy (ONE GPU; a proxy of a rank's share, NOT a measured scaling curve)",
            "metric": "image-pairs/sec (detect+match+H+warp), 4000x3000 UAV frames", "of_ranks": G, "ranks_run": ranks,
            "workload": "%d frames %dx%d, pair window %d (%d pairs), strong scaling: frames k mod %d, pairs i mod %d, canvas stripes" % (F, w, h, args.window, survey_pairs, G, G),
-           "one_gpu_ms_per_step": t_one, "one_gpu_pairs_per_s": survey_pairs / t_one * 1e3,
+           "one_gpu_ms_per_step": t_one, "one_gpu_pairs_per_s": survey_pairs / t_one * 1e3, "frames_per_batch": {"one_gpu": batch_one, "rank": BATCH},
            "share": shares, "accepted_records": acc,
            "wire_model_ms": {"ring_one_link_153GBs": wire_ring_ms, "direct_7_links": wire_direct_ms,
                              "bytes_received_per_rank": {"features": feat_bytes, "accepted_records": res_bytes},
@@ -346,7 +360,8 @@ def main():
     if BATCH <= 0:
         # 32 frames per batch: the latency-bound launches of the small octaves and the per-frame selections are paid once per 32 frames
         # (3 x 32 frames in flight = 86 GB of work areas at 12 MP); surveys that need the HBM themselves keep the library's 16
-        BATCH = 16 if (args.blend or args.frames * args.width * args.height > 1000 * 4000 * 3000) else 32
+        per_rank = -(-args.frames // world) if (world > 1 and args.scaling == "strong") else args.frames
+        BATCH = batch_for(per_rank, args.blend or args.frames * args.width * args.height > 1000 * 4000 * 3000)
     import imagemosaicing_amd as im
     from imagemosaicing_amd import dist as md
     ctx = im.Context(local_rank)

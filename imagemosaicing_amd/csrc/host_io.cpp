@@ -176,8 +176,8 @@ extern "C" int mi355_results_to_match_pairs(const mi355_pair_result* r, int n_pa
 // The work is in two places: the second moments of the correspondences (21 products per point; C5: 28 M points) and the banded
 // Cholesky factorisation (C5: 6000 rows x half bandwidth 545).  Both run on a few host threads in a way that keeps every sum's
 // order: a thread owns whole image pairs (their moments are summed per pair first, then added to the blocks in pair order by one
-// thread, as the serial code did) and whole matrix entries (one dot product, ascending k) -- the result does not depend on the
-// number of threads.
+// thread, as the serial code did) and whole matrix entries (the products of an entry are subtracted one by one, ascending k, panel
+// after panel) -- the result does not depend on the number of threads or on the panel width.
 namespace {
 int host_threads() {
     static const int n = [] {
@@ -190,7 +190,7 @@ int host_threads() {
             const int ranks = lw ? atoi(lw) : 1;
             if (ranks > 1) v /= ranks;
         }
-        if (v > 16) v = 16;
+        if (v > 32) v = 32;
         return v < 1 ? 1 : v;
     }();
     return n;
@@ -294,40 +294,86 @@ int align_core(const std::vector<PairGroup>& groups, XY&& xy, int n_images, cons
             bx[3 * o + 0] = 1.0; by[3 * o + 1] = 1.0;
         }
     }
-    // Cholesky N = L L^T (lower), in place, inside the band: column by column, the entries of a column are independent dot products.
-    // A team of threads walks the columns together (one spin barrier per column); every thread computes the pivot itself.
+    // Cholesky N = L L^T (lower), in place, inside the band, in panels of 64 columns.  Every entry (i, j) still receives the same
+    // operations in the same order as in the column-by-column form -- N(i, j) minus L(i, k) L(j, k) for ascending k, each product
+    // subtracted on its own, then the division by the diagonal -- so the factor has the same bits whatever the panel width and the
+    // number of threads; what changes is who waits for whom: a team walking the columns together met at one barrier per column
+    // (1497 at C4, 6000 at C5: half of the time), and one dot product per entry is a single dependent chain of subtractions.  Per
+    // panel: (A) one thread factors the 64 x 64 diagonal block, (B) the rows below it are divided up between the threads, (C) the
+    // panel's products are subtracted from the trailing band, again by rows, four independent entries at a time.  Three barriers per
+    // panel.
     const int team = ((double)D * bw * bw > 5e7) ? host_threads() : 1;
+    constexpr int PW = 64;
     std::atomic<int> arrived{0}, generation{0}, failed{0};
-    auto column_worker = [&](int tid) {
+    auto rowp = [&](int i) -> double* { return Nb.data() + (ptrdiff_t)i * (ptrdiff_t)W + (ptrdiff_t)(bw - i); };     // rowp(i)[j] = N(i, j), i - bw <= j <= i
+    auto worker = [&](int tid) {
         int gen = 0;
-        for (int j = 0; j < D; j++) {
-            const int k0 = j - bw > 0 ? j - bw : 0;
-            double d = NL(j, j);
-            for (int k = k0; k < j; k++) d -= NL(j, k) * NL(j, k);
-            if (!(d > 0.0)) { failed.store(1); d = 1.0; }         // keep walking so that the team stays in step; the caller sees `failed`
-            d = std::sqrt(d);
-            const int i1 = j + bw < D - 1 ? j + bw : D - 1;
-            for (int i = j + 1 + tid; i <= i1; i += team) {
-                const int kk0 = i - bw > k0 ? i - bw : k0;
-                double s = NL(i, j);
-                const double* ri = &Nb[(size_t)i * W + (size_t)(kk0 - i + bw)];
-                const double* rj = &Nb[(size_t)j * W + (size_t)(kk0 - j + bw)];
-                for (int k = 0; k < j - kk0; k++) s -= ri[k] * rj[k];
-                NL(i, j) = s / d;
+        auto barrier = [&]() {
+            if (team <= 1) return;
+            gen++;
+            if (arrived.fetch_add(1) + 1 == team) { arrived.store(0); generation.store(gen); }
+            else { int spins = 0; while (generation.load() < gen) { if (++spins > 4096) { std::this_thread::yield(); spins = 4000; } } }   // a phase takes microseconds: spin, but yield when the host has fewer cores than threads
+        };
+        for (int p0 = 0; p0 < D; p0 += PW) {
+            const int p1 = p0 + PW < D ? p0 + PW : D;
+            if (tid == 0) {                                       // (A) the diagonal block
+                for (int j = p0; j < p1; j++) {
+                    double* rj = rowp(j);
+                    double d = rj[j];
+                    for (int k = (j - bw > p0 ? j - bw : p0); k < j; k++) d -= rj[k] * rj[k];
+                    if (!(d > 0.0)) { failed.store(1); d = 1.0; }        // keep walking so that the team stays in step; the caller sees `failed`
+                    d = std::sqrt(d);
+                    rj[j] = d;
+                    for (int i = j + 1; i < p1 && i <= j + bw; i++) {    // rows of the block that reach column j (half bandwidth below the panel width: adjacent-pair strips)
+                        double* ri = rowp(i);
+                        double sv = ri[j];
+                        for (int k = (i - bw > p0 ? i - bw : p0); k < j; k++) sv -= ri[k] * rj[k];
+                        ri[j] = sv / d;
+                    }
+                }
             }
-            if (team > 1) {                                        // everyone has read row j's old diagonal and written its rows
-                gen++;
-                if (arrived.fetch_add(1) + 1 == team) { NL(j, j) = d; arrived.store(0); generation.store(gen); }
-                else { int spins = 0; while (generation.load() < gen) { if (++spins > 4096) { std::this_thread::yield(); spins = 4000; } } }   // a column takes microseconds: spinning is right unless the host has fewer cores than threads (27 s instead of 0.09 s at 16 threads on 8 cores without the yield)
-            } else NL(j, j) = d;
+            barrier();
+            const int i_end = p1 - 1 + bw < D - 1 ? p1 - 1 + bw : D - 1;             // last row that holds an entry in a column of the panel
+            // rows dealt out one by one: row i of the trailing band has i - p1 + 1 entries to update, contiguous chunks would give the last
+            // thread twice the mean
+            for (int i = p1 + tid; i <= i_end; i += team) {       // (B) the panel's columns of the rows below the block
+                double* ri = rowp(i);
+                const int j0 = i - bw > p0 ? i - bw : p0;
+                for (int j = j0; j < p1; j++) {
+                    const double* rj = rowp(j);
+                    double sv = ri[j];
+                    for (int k = j0; k < j; k++) sv -= ri[k] * rj[k];
+                    ri[j] = sv / rj[j];
+                }
+            }
+            barrier();
+            for (int i = p1 + tid; i <= i_end; i += team) {       // (C) the panel's products leave the trailing band
+                double* ri = rowp(i);
+                const int k0 = i - bw > p0 ? i - bw : p0;
+                const int j0 = i - bw > p1 ? i - bw : p1;
+                int j = j0;
+                for (; j + 3 <= i; j += 4) {
+                    const double *a0 = rowp(j), *a1 = rowp(j + 1), *a2 = rowp(j + 2), *a3 = rowp(j + 3);
+                    double s0 = ri[j], s1 = ri[j + 1], s2 = ri[j + 2], s3 = ri[j + 3];
+                    for (int k = k0; k < p1; k++) { const double l = ri[k]; s0 -= l * a0[k]; s1 -= l * a1[k]; s2 -= l * a2[k]; s3 -= l * a3[k]; }
+                    ri[j] = s0; ri[j + 1] = s1; ri[j + 2] = s2; ri[j + 3] = s3;
+                }
+                for (; j <= i; j++) {
+                    const double* rj = rowp(j);
+                    double sv = ri[j];
+                    for (int k = k0; k < p1; k++) sv -= ri[k] * rj[k];
+                    ri[j] = sv;
+                }
+            }
+            barrier();
         }
     };
     if (team > 1) {
         std::vector<std::thread> th;
-        for (int t = 1; t < team; t++) th.emplace_back(column_worker, t);
-        column_worker(0);
+        for (int t = 1; t < team; t++) th.emplace_back(worker, t);
+        worker(0);
         for (auto& x : th) x.join();
-    } else column_worker(0);
+    } else worker(0);
     if (failed.load()) return MI355_ERR_FAILED;
     auto solve = [&](std::vector<double>& b) {
         for (int i = 0; i < D; i++) { const int k0 = i - bw > 0 ? i - bw : 0; double s = b[i]; for (int k = k0; k < i; k++) s -= NL(i, k) * b[k]; b[i] = s / NL(i, i); }
