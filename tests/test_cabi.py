@@ -214,3 +214,39 @@ def test_alignment_from_pair_records_equals_the_match_pairs_form(im):
         T2 = im.global_affine_align_results(r, N, fixed=fixed, label=label)
         assert np.array_equal(T.view(np.uint8), T2.view(np.uint8))
         assert np.abs(T["m"][N // 2, [2, 5]] - pos[N // 2]).max() < 5.0          # noisy correspondences, a chain of ~20 rows of images
+
+
+def test_alignment_bits_do_not_depend_on_the_thread_count(tmp_path):
+    """the banded Cholesky of mi355_global_affine_align_results works in panels of 64 columns on a team of host threads; every entry still
+    receives its products one by one in ascending order, so the transforms have the same bits on 1, 3 and 7 threads (fresh processes:
+    the thread count is read once).  Two systems: a window-120 survey (half bandwidth 362 > panel) and an adjacent-pair strip (5 < panel)."""
+    import hashlib
+    import subprocess
+    import sys
+    script = tmp_path / "align_threads.py"
+    script.write_text(
+        "import sys, hashlib, numpy as np\n"
+        "sys.path.insert(0, %r)\n"
+        "import imagemosaicing_amd as im\n"
+        "out = []\n"
+        "for (N, win, frac) in [(260, 120, 0.06), (300, 2, 1.0)]:\n"
+        "    rng = np.random.default_rng(N)\n"
+        "    pairs = [(i, j) for i in range(N) for j in range(i + 1, min(N, i + win)) if (j == i + 1 or rng.random() < frac)]\n"
+        "    r = np.zeros(len(pairs), im.PAIR_RESULT)\n"
+        "    pos = np.cumsum(rng.uniform(300, 900, (N, 2)), axis=0)\n"
+        "    for k, (i, j) in enumerate(pairs):\n"
+        "        n = 400 if win > 2 else 60\n"
+        "        xy = rng.uniform(0, 4000, (n, 2)).astype(np.float32)\n"
+        "        r['i'][k] = i; r['j'][k] = j; r['n_in'][k] = n; r['accepted'][k] = 1\n"
+        "        r['a']['x'][k, :n] = xy[:, 0] + (pos[j, 0] - pos[i, 0]); r['a']['y'][k, :n] = xy[:, 1] + (pos[j, 1] - pos[i, 1])\n"
+        "        r['b']['x'][k, :n] = xy[:, 0] + rng.normal(0, .3, n); r['b']['y'][k, :n] = xy[:, 1] + rng.normal(0, .3, n)\n"
+        "    T = im.global_affine_align_results(r, N)\n"
+        "    assert np.isfinite(T['m']).all() and (win == 2 or np.abs(T['m'][:, 2] - (pos[:, 0] - pos[0, 0])).max() < 2.0)   # (a 300-link chain of free affines drifts)\n"
+        "    out.append(hashlib.sha1(T['m'].tobytes()).hexdigest())\n"
+        "print(' '.join(out))\n" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    seen = set()
+    for th in ("1", "3", "7"):
+        r = subprocess.run([sys.executable, str(script)], env=dict(os.environ, MI355_HOST_THREADS=th), capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        seen.add(r.stdout.strip().splitlines()[-1])
+    assert len(seen) == 1, seen
