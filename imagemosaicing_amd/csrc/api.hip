@@ -227,7 +227,7 @@ extern "C" int mi355_ransac2d(mi355_ctx* ctx, const mi355_sfpoint* p1, const mi3
     *n_in = 0;
     for (int i = 0; i < 9; i++) H[i] = 0.0f;
     if (n <= 0 || !p1 || !p2) return 0;                                // Ransac2D: empty input -> false (mosaicimage.h:1739-1744)
-    if (n > MI355_RANSAC_BIG_MAX) { ctx->set_error("ransac2d: at most 4096 correspondences"); return MI355_ERR_ARG; }
+    if (n > MI355_RANSAC_BIG_MAX) { ctx->set_error("ransac2d: at most 65535 correspondences"); return MI355_ERR_ARG; }
     if (n > MI355_MAX_SELECTED) {                                      // beyond the live path's maxNum (MosaicWithoutPos.cpp:5146): the large-n kernel
         int ok = 0;
         const int rc = mi_ransac_big(ctx, p1, p2, n, dist, sample_times, seed, in1, in2, n_in, H, &ok);

@@ -25,6 +25,7 @@ namespace {
 
 typedef float f2 __attribute__((ext_vector_type(2)));
 constexpr int RB = 256;            // threads per workgroup = draws per chunk
+constexpr int RANSAC_LDS_POINTS = 4096;   // largest n whose points stay in LDS (64 KB)
 constexpr int MAX_DRAWS = 4999;    // realSamTimes >= 5000 breaks before drawing (mosaicimage.h:1787-1792)
 
 struct RansacArgs {
@@ -41,10 +42,11 @@ struct RansacArgs {
     int list_floats;               // floats of dynamic LDS in front of the point arrays: the list of accepted draws (uint16 x min(sample_times, 4999))
     int min_keep;                  // pairs with at most this many inliers skip the closing refinement (-1: never): the caller rejects them anyway
     mi355_pair_result* out;        // [pair]
-    // BIG variant (one pair with 400 < n <= 4096, mi355_ransac2d only): work arrays of the closing Gauss-Newton and the inlier lists in HBM
+    // BIG variants (one pair with n > 400, mi355_ransac2d only): work arrays of the closing Gauss-Newton and the inlier lists in HBM
     float* big_ws;                 // 38 n floats: J (16 n), J* (16 n), C (2 n), compaction scratch (4 n)
     mi355_sfpoint* big_a;          // [n] inliers of image i
     mi355_sfpoint* big_b;          // [n] inliers of image j
+    float* big_pts;                // MODE 2: x1, y1, x2, y2 (4 n floats) in HBM
 };
 
 // the index-driven generic routines (hmath.h solve_h4 / nlls4) for the draws the register path hands back (a non-finite entry
@@ -115,8 +117,11 @@ __device__ __forceinline__ int block_exclusive_scan_flags(bool flag, int tid, in
     return off + before;
 }
 
-template <bool BIG>
+// MODE 0: the batched live path (n <= 400, everything in LDS); 1: one pair with 400 < n <= 4096 (points in LDS, Gauss-Newton work arrays in
+// HBM); 2: one pair with more points than the LDS holds (points in HBM too: every lane of a wave reads the same point, one request)
+template <int MODE>
 __device__ __forceinline__ void ransac_body(const RansacArgs& a) {
+    constexpr bool BIG = MODE >= 1;
     extern __shared__ float lds[];
     __shared__ unsigned long long s_mask[5][RB / 64];
     __shared__ unsigned s_wkey[RB / 64];
@@ -141,7 +146,7 @@ __device__ __forceinline__ void ransac_body(const RansacArgs& a) {
         return;
     }
     uint16_t* list = reinterpret_cast<uint16_t*>(lds);   // draws that hold a hypothesis slot, in draw order
-    float* x1 = lds + a.list_floats;                     // targets (image i)
+    float* x1 = MODE == 2 ? a.big_pts : lds + a.list_floats;      // targets (image i)
     float* y1 = x1 + n;
     float* x2 = y1 + n;         // sources (image j)
     float* y2 = x2 + n;
@@ -454,9 +459,11 @@ __device__ __forceinline__ void ransac_body(const RansacArgs& a) {
 }
 
 // 2 waves per SIMD (256 registers each): with 1 (512 registers, spills in AGPRs instead of scratch) the kernel measured 30 % slower
-__global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(2, 2))) void ransac_kernel(RansacArgs a) { ransac_body<false>(a); }
+__global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(2, 2))) void ransac_kernel(RansacArgs a) { ransac_body<0>(a); }
 // Ransac2D accepts any n (mosaicimage.h:1729-1761); the live path never exceeds 396, stand-alone callers may: up to 4096 points in LDS
-__global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(2, 2))) void ransac_big_kernel(RansacArgs a) { ransac_body<true>(a); }
+__global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(2, 2))) void ransac_big_kernel(RansacArgs a) { ransac_body<1>(a); }
+// ... and beyond 4096 (up to the 65 535 a 16-bit draw table can address) with the points in HBM
+__global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(2, 2))) void ransac_huge_kernel(RansacArgs a) { ransac_body<2>(a); }
 
 }  // namespace
 
@@ -626,9 +633,17 @@ int mi_ransac_big(mi355_ctx* ctx, const mi355_sfpoint* p1, const mi355_sfpoint* 
     a.big_ws = dws.as<float>(); a.big_a = da.as<mi355_sfpoint>(); a.big_b = db.as<mi355_sfpoint>();
     a.single_table = 1;                                   // the one uploaded table, not table n - 4 of a set
     a.list_floats = ((((sample_times < MAX_DRAWS ? (sample_times > 0 ? sample_times : 1) : MAX_DRAWS) * 2 + 15) / 16) * 16) / 4;
-    const size_t lds_bytes = ((size_t)4 * n + a.list_floats) * sizeof(float);
-    MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ransac_big_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    hipLaunchKernelGGL(ransac_big_kernel, dim3(1), dim3(RB), lds_bytes, ctx->stream, a);
+    if (n > RANSAC_LDS_POINTS) {                          // the points do not fit the LDS: HBM (ransac_huge_kernel)
+        DevBuf& dpts = ctx->buf("rbig_pts");
+        MI_HIP(dpts.reserve(sizeof(float) * 4 * (size_t)n));
+        a.big_pts = dpts.as<float>();
+        const size_t lds_bytes = (size_t)a.list_floats * sizeof(float);
+        hipLaunchKernelGGL(ransac_huge_kernel, dim3(1), dim3(RB), lds_bytes, ctx->stream, a);
+    } else {
+        const size_t lds_bytes = ((size_t)4 * n + a.list_floats) * sizeof(float);
+        MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ransac_big_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        hipLaunchKernelGGL(ransac_big_kernel, dim3(1), dim3(RB), lds_bytes, ctx->stream, a);
+    }
     MI_HIP(hipGetLastError());
     mi355_pair_result r;
     MI_HIP(hipMemcpyAsync(&r, dres.p, sizeof(r), hipMemcpyDeviceToHost, ctx->stream));

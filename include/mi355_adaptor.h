@@ -70,9 +70,9 @@ inline mi355_ctx* context(int device = 0) {
 
 // bool Ransac2D(const vector<PointType>&, const vector<PointType>&, vector<PointType>&, vector<PointType>&,
 //               float aProjectMat[9], float fRansacDist = 1, int sampleTimes = 1000)          mosaicimage.h:1729-1735
-// `seed` stands for the reference's srand((unsigned)time(0)) (mosaicimage.h:1777).  Up to 4096 correspondences (the live path passes
-// <= 396: maxNum, MosaicWithoutPos.cpp:5146; above 400 a second kernel keeps the work arrays in HBM); larger inputs return false
-// with aProjectMat zeroed, where the reference would run on any n.
+// `seed` stands for the reference's srand((unsigned)time(0)) (mosaicimage.h:1777).  Up to 65535 correspondences (the live path passes
+// <= 396: maxNum, MosaicWithoutPos.cpp:5146; above 400 a second kernel keeps the work arrays in HBM, above 4096 a third the points too);
+// larger inputs return false with aProjectMat zeroed, where the reference would run on any n.
 inline bool Ransac2D(const std::vector<MI355_NS SfPoint>& p1, const std::vector<MI355_NS SfPoint>& p2,
                      std::vector<MI355_NS SfPoint>& in1, std::vector<MI355_NS SfPoint>& in2, float aProjectMat[9],
                      float fRansacDist = 1.0f, int sampleTimes = 1000, unsigned seed = 1) {

@@ -35,7 +35,7 @@ extern "C" {
 #define MI355_ERR_NOMEM    (-5)
 
 #define MI355_MAX_SELECTED 400    /* maxNum, MosaicWithoutPos.cpp:5146 */
-#define MI355_RANSAC_BIG_MAX 4096 /* largest n mi355_ransac2d accepts (Ransac2D itself accepts any n, mosaicimage.h:1729-1761) */
+#define MI355_RANSAC_BIG_MAX 65535 /* largest n mi355_ransac2d accepts: what a 16-bit draw table addresses (Ransac2D itself accepts any n, mosaicimage.h:1729-1761) */
 #define MI355_DESC_DIM     128
 
 typedef struct mi355_ctx mi355_ctx;

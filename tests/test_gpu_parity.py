@@ -177,10 +177,11 @@ def test_ransac2d_vs_oracle_random(ctx, oracle):
 
 def test_ransac2d_more_than_400_correspondences(ctx, oracle):
     """Ransac2D accepts any n (mosaicimage.h:1729-1761); the live path stops at 396, mi355_ransac2d goes on to 4096 through a second
-    kernel (work arrays of the closing Gauss-Newton in HBM).  Same bits as the oracle, which tests/test_oracle_vs_ref.py shows equal
-    to the reference's own code at these sizes; 4097 is refused."""
+    kernel (work arrays of the closing Gauss-Newton in HBM) and to 65 535 -- what a 16-bit draw table addresses -- through a third
+    (the points in HBM as well).  Same bits as the oracle, which tests/test_oracle_vs_ref.py shows equal to the reference's own code
+    at these sizes; 65 536 is refused."""
     import imagemosaicing_amd as im
-    for n, of in [(401, 0.5), (777, 0.2), (1500, 0.6), (4096, 0.7), (4096, 0.97)]:
+    for n, of in [(401, 0.5), (777, 0.2), (1500, 0.6), (4096, 0.7), (4096, 0.97), (4097, 0.5), (9001, 0.4), (30000, 0.8), (65535, 0.6)]:
         for seed in (31, 32):
             p1, p2 = synth_pairs(n, of, seed=seed * 7 + n, size=(4000, 3000))
             a = oracle.ransac2d(p1, p2, 2.5, 1000, seed)
@@ -188,7 +189,7 @@ def test_ransac2d_more_than_400_correspondences(ctx, oracle):
             assert a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]), (n, of, seed, a[0], b[0], len(a[1]), len(b[1]))
             if len(a[1]) >= 4:
                 assert np.array_equal(bits(a[3]), bits(b[3])), (n, of, seed)
-    p1, p2 = synth_pairs(4097, 0.5, seed=5, size=(4000, 3000))
+    p1, p2 = synth_pairs(65536, 0.5, seed=5, size=(4000, 3000))
     with pytest.raises(im.Mi355Error):
         ctx.Ransac2D(p1, p2, 2.5, 1000, 1)
 

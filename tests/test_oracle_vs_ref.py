@@ -20,8 +20,8 @@ def test_inverse_random(oracle, ref):
 
 
 def test_ransac_random(oracle, ref):
-    # beyond the live path's maxNum = 400 too: Ransac2D accepts any n (mosaicimage.h:1729-1761), mi355_ransac2d up to 4096
-    for n, of in [(60, 0.4), (396, 0.3), (396, 0.6), (10, 0.2), (250, 0.9), (401, 0.5), (1500, 0.6), (4096, 0.7)]:
+    # beyond the live path's maxNum = 400 too: Ransac2D accepts any n (mosaicimage.h:1729-1761), mi355_ransac2d up to 65535
+    for n, of in [(60, 0.4), (396, 0.3), (396, 0.6), (10, 0.2), (250, 0.9), (401, 0.5), (1500, 0.6), (4096, 0.7), (9001, 0.4), (30000, 0.8)]:
         for seed in (11, 12):
             p1, p2 = synth_pairs(n, of, seed=seed * 31 + n, size=(4000, 3000))
             a = oracle.ransac2d(p1, p2, 2.5, 1000, seed)
