@@ -525,9 +525,11 @@ def main():
     ctx.profile_enable(False)
     # The timed region keeps three batches in flight: the bracketed blur_stream launches overlap other batches' kernels, so their event
     # durations double-count wall time.  `roofline.achieved` therefore comes from an extra UNTIMED pass over the same
-    # frames with the library option "serial_heavy": the pyramid + extrema phase of a batch waits for the previous batch's, no two
-    # chip-filling kernels overlap, and the bracketed durations are exclusive -- checked right here: the durations of ALL chip-filling
-    # classes of that pass sum to less than its wall time.  The in-situ figure of the timed region stays as a side field.
+    # frames with ONE batch work area in flight (exclusive_pass: nothing else on the chip while a bracketed launch runs -- the pass the
+    # committed rocprofv3 serial summary traces).  Rounds 1-3 quoted a pass with the library option "serial_heavy" instead (the pyramid +
+    # extrema phase of a batch waits for the previous batch's: no two chip-filling kernels overlap, checked right here, but the previous
+    # batch's keypoint kernels share the chip with the bracketed launch): it stays in the line as shared_chip_pass, the in-situ figure
+    # of the timed region as in_situ.
     excl, iso = None, None
     HEAVY = ("gauss_stream", "gauss", "downsample", "extrema")     # every class of the pyramid + extrema phase
     if not os.environ.get("MI355_BENCH_NO_STANDALONE"):
@@ -552,7 +554,7 @@ def main():
         # the same launches with ONE batch in flight (nothing else on the chip at all): the kernel's ceiling in this pipeline
         ctx.set_option("sift_slots", 1)
         ctx.profile_enable(True); ctx.profile_only(DOM); ctx.profile_reset()
-        nf_iso = min(len(own), 3 * BATCH)
+        nf_iso = len(own)
         for k in own[:nf_iso]:
             ctx.SiftExtractDev(k, fptr[k], w, h, ws)
         i_ms, i_n, i_bytes = ctx.profile_get(DOM)
@@ -561,7 +563,8 @@ def main():
         ctx.set_option("sift_batch", BATCH)
         if i_ms > 0:
             iso = {"achieved": (i_bytes / 1e9) / (i_ms / 1e3), "frac": (i_bytes / 1e9) / (i_ms / 1e3) / HBM_PEAK_GBS, "frames": nf_iso, "dominant_kernel_ms": i_ms,
-                   "avg_launch_us": i_ms * 1e3 / max(i_n, 1), "note": "same launches with one batch work area in flight (no other kernel on the chip), untimed extra pass"}
+                   "launches": int(i_n), "avg_launch_us": i_ms * 1e3 / max(i_n, 1),
+                   "note": "one batch work area in flight: no other kernel on the chip while a bracketed launch runs (what rocprofv3 --kernel-trace of scratch/sift_time.py ... serial reports: profiles/r04_rocprofv3_kernel_stats_serial_pass.txt), untimed extra pass"}
 
     # quality of the last step against ground truth (accepted pairs): corner transfer error in pixels
     r = state["r"]
@@ -612,6 +615,8 @@ def main():
         value = total_pairs / dt
         n_frames_total = F if strong else F * world
         in_situ = (g_bytes / 1e9) / (g_ms / 1e3) if g_ms > 0 else 0.0
+        head = iso or excl                       # the kernel alone on the chip; the shared-chip pass if that one was skipped
+        valu_of = lambda p: streamed_lane_ops(w, h) * p["frames"] / (p["dominant_kernel_ms"] / 1e3) / 1e12
         out = {
             "metric": "image-pairs/sec (detect+match+H+warp), 4000x3000 UAV frames",
             "value": value, "unit": "image-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -629,24 +634,25 @@ def main():
                                     ("frames k mod G, pairs i mod G, canvas stripes; %s all-gather of feature records and accepted pair records" % transport) if strong else
                                     ("independent strip per rank; %s all-gather of accepted pair records" % transport))},
             "roofline": {"bound": "hbm", "kernel": "blur16_stream<R,D,BGR> (streaming separable Gaussian 16S -> 32F -> 16S, one pyramid level of all frames of a batch per launch: every level at least 512 columns wide, the base level straight from the BGR frames)",
-                         "achieved": excl["achieved"] if excl else in_situ, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": (excl["achieved"] if excl else in_situ) / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "achieved": head["achieved"] if head else in_situ, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": (head["achieved"] if head else in_situ) / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "note": "algorithmic bytes = 2 B read + 2 B written per pixel of a level (the reference's pyramid is 16-bit fixed point; base level: 3 B BGR read); the kernel is bound by f32 vector instruction issue, not by HBM: see valu",
-                         "valu": ({"lane_ops_per_frame": streamed_lane_ops(w, h), "achieved": streamed_lane_ops(w, h) * excl["frames"] / (excl["dominant_kernel_ms"] / 1e3) / 1e12,
-                                   "peak": VALU_PEAK_TOPS, "unit": "T f32 lane-operations/s", "frac": streamed_lane_ops(w, h) * excl["frames"] / (excl["dominant_kernel_ms"] / 1e3) / 1e12 / VALU_PEAK_TOPS,
-                                   "standalone": ({"achieved": streamed_lane_ops(w, h) * iso["frames"] / (iso["dominant_kernel_ms"] / 1e3) / 1e12,
-                                                   "frac": streamed_lane_ops(w, h) * iso["frames"] / (iso["dominant_kernel_ms"] / 1e3) / 1e12 / VALU_PEAK_TOPS,
-                                                   "note": "the same launches with one batch work area in flight (nothing else on the chip): the kernel's own rate; the figure above shares the chip with the previous batch's keypoint kernels"} if iso else None),
-                                   "note": "separately rounded f32 products and sums the definition requires (7R + 2 per output pixel; an fma would count once but changes the reference's bits); peak = 256 CU x 128 lanes x 2.4 GHz"} if excl else None),
-                         "measurement": ("HIP events around every launch of the kernel in an untimed extra pass over the same frames with option serial_heavy (chip-filling kernels of different "
-                                         "batches never overlap: durations are exclusive, see exclusive_pass)") if excl else "HIP events in the timed region (launches overlap other batches' kernels)",
-                         "exclusive_pass": excl,
+                         "valu": ({"lane_ops_per_frame": streamed_lane_ops(w, h), "achieved": valu_of(head),
+                                   "peak": VALU_PEAK_TOPS, "unit": "T f32 lane-operations/s", "frac": valu_of(head) / VALU_PEAK_TOPS,
+                                   "shared_chip": ({"achieved": valu_of(excl), "frac": valu_of(excl) / VALU_PEAK_TOPS,
+                                                    "note": "the same launches in the shared_chip_pass (the previous batch's keypoint kernels run beside them): the round-3 headline"} if excl else None),
+                                   "note": "separately rounded f32 products and sums the definition requires (7R + 2 per output pixel; an fma would count once but changes the reference's bits); peak = 256 CU x 128 lanes x 2.4 GHz"} if head else None),
+                         "measurement": ("HIP events around every launch of the kernel in an untimed extra pass over the same frames with ONE batch work area in flight: nothing else runs "
+                                         "while a bracketed launch runs, the duration is the kernel's own (exclusive_pass; the committed rocprofv3 serial-pass summary measures the same). "
+                                         "shared_chip_pass keeps the figure of rounds 1-3: option serial_heavy, the heavy phases of the batches take turns but the previous batch's "
+                                         "keypoint kernels share the chip with the bracketed launch") if head else "HIP events in the timed region (launches overlap other batches' kernels)",
+                         "exclusive_pass": iso, "shared_chip_pass": excl,
                          "in_situ": {"achieved": in_situ, "frac": in_situ / HBM_PEAK_GBS, "launches": int(g_n), "avg_launch_us": (g_ms * 1e3 / g_n) if g_n else None,
                                      "sampled": "every %d-th launch of the class" % PROF_EVERY,
                                      "note": "launches bracketed inside the timed region, three batches in flight: durations include other batches' kernels (sum > step time); rocprofv3 --kernel-trace of this command reports this average"},
                          "algorithmic_bytes_per_launch": (g_bytes / g_n) if g_n else None,
                          "algorithmic_bytes_per_frame": g_bytes * PROF_EVERY / max(args.steps * len(own), 1),
-                         "frames_per_batch": BATCH, "batches_in_flight": SLOTS, "standalone": iso},
+                         "frames_per_batch": BATCH, "batches_in_flight": SLOTS},
             # the other chip-filling kernels: exclusive durations of the same serial_heavy pass / the single warp launch of the last step
             "roofline_by_kernel": {
                 "extrema_stream+extrema_kernel": ({"bound": "hbm", "algorithmic_bytes": "6 level reads x 2 B per pixel", "achieved": (excl["extrema"]["bytes"] / 1e9) / (excl["extrema"]["ms"] / 1e3),
