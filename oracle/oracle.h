@@ -84,6 +84,7 @@ int  orc_find_masks_by_distmap(uint8_t** masks, const int* mask_ws, const orc_ch
 /* ---- oracle_blend.c: multiband blend of the chips (MosaicImage.cpp:2296-2299, 2451-2486); PARITY UNPINNED */
 void orc_pyr_down16(const int16_t* src, int w, int h, int16_t* dst);
 void orc_pyr_down_f(const float* src, int w, int h, float* dst);
+void orc_set_float_reduce_mode(int binary_order);   /* 0 (default): the published source's single order; 1: the loop-dependent associations of opencv_imgproc240.dll */
 void orc_pyr_up16(const int16_t* src, int w, int h, int16_t* dst);
 int  orc_multiband_blend(const uint8_t* const* chips, const uint8_t* const* masks, const int* cx0, const int* cy0, const int* cw, const int* chh,
                          int n, int W, int H, int band, uint8_t* out);

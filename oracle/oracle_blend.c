@@ -84,10 +84,34 @@ void orc_pyr_down16(const int16_t* src, int w, int h, int16_t* dst)
 }
 
 /* REDUCE, 1-channel f32 */
+/* REDUCE, 1-channel f32 (the weight pyramid): cv::pyrDown<float> of opencv_imgproc240.dll, association by association.
+ * The binary was compiled with reassociating float optimisation and the order of the four additions of a row value depends on the
+ * LOOP that produces it (a4 = (s[2x-1] + s[2x+1]) * 4, c6 = s[2x] * 6):
+ *   x = 0 and x >= width0 (border loop over the index table, 100f8822-100f888a)   ((a4 + s[2x-2]) + c6) + s[2x+2]
+ *   1 <= x < 1 + 4 n4, n4 = (width0 - 1) / 4 (4 x unrolled loop, 100f88d0-100f897f)
+ *         (x - 1) mod 4 in {0, 1, 2}                                                ((a4 + c6) + s[2x+2]) + s[2x-2]
+ *         (x - 1) mod 4 == 3                                                        ((a4 + s[2x+2]) + c6) + s[2x-2]
+ *   1 + 4 n4 <= x < width0 (remainder loop, 100f89a0-100f89cf)                      ((a4 + c6) + s[2x-2]) + s[2x+2]
+ * with width0 = min((w - 3) / 2 + 1, dw) (= dw - 1 for even w).  Vertical pass over the five row values r0 .. r4:
+ *   x < 8 (dw / 8) (PyrDownVec_32f, 100f6540-100f65c6)   (((r1 + r3) + r2) * 4 + ((r0 + r4) + (r2 + r2))) * (1 / 256)
+ *   the other columns (scalar tail, 100f8eaf-100f8ef6)    ((r0 + r4) * (1 / 256) + (r1 + r3) * (4 / 256)) + r2 * (6 / 256)
+ * orc_float_reduce_mode = 0 (the default, and what csrc/blend.hip computes) keeps the single association of the published source
+ * instead (c6 + a4 + s[2x-2] + s[2x+2], the same over the rows, times 1 / 256).  The binary's orders are implemented here to MEASURE
+ * what the difference does to a blended mosaic (tests/test_blend.py: weights of levels 1-3 are exact multiples of 2^-24 and do not
+ * depend on the order at all; levels 4-5 differ in the last bit near mask seams).  They are not the product's definition because they
+ * tie a pixel's weight to its column's position inside the chip's region modulo 4 and 8: a window of the canvas could then no longer
+ * be checked on a crop (the check tests/test_gpu_full_size.py runs at the C5 size), for an effect of a few output bytes by one level. */
+int orc_float_reduce_mode = 0;
+void orc_set_float_reduce_mode(int binary_order) { orc_float_reduce_mode = binary_order; }
+
 void orc_pyr_down_f(const float* src, int w, int h, float* dst)
 {
     const int dw = w / 2, dh = h / 2;
     float* rows = (float*)malloc(sizeof(float) * 5 * dw);
+    int width0 = (w - 3) / 2 + 1;
+    if (width0 > dw) width0 = dw;
+    const int n4 = width0 - 1 >= 4 ? (width0 - 1) / 4 : 0;
+    const int vec_end = dw >= 8 ? (dw / 8) * 8 : 0;
     for (int y = 0; y < dh; y++) {
         for (int k = 0; k < 5; k++) {
             const int sy = reflect101i(2 * y - 2 + k, h);
@@ -95,12 +119,32 @@ void orc_pyr_down_f(const float* src, int w, int h, float* dst)
             float* r = rows + (size_t)k * dw;
             for (int x = 0; x < dw; x++) {
                 const int x0 = reflect101i(2 * x - 2, w), x1 = reflect101i(2 * x - 1, w), x2 = 2 * x, x3 = reflect101i(2 * x + 1, w), x4 = reflect101i(2 * x + 2, w);
-                r[x] = s[x2] * 6.0f + (s[x1] + s[x3]) * 4.0f + s[x0] + s[x4];
+                if (!orc_float_reduce_mode) { r[x] = s[x2] * 6.0f + (s[x1] + s[x3]) * 4.0f + s[x0] + s[x4]; continue; }
+                const float a4 = (s[x1] + s[x3]) * 4.0f, c6 = s[x2] * 6.0f, m2 = s[x0], p2 = s[x4];
+                float v;
+                if (x == 0 || x >= width0) { v = a4 + m2; v = v + c6; v = v + p2; }
+                else if (x < 1 + 4 * n4) {
+                    if (((x - 1) & 3) == 3) { v = a4 + p2; v = v + c6; v = v + m2; }
+                    else { v = a4 + c6; v = v + p2; v = v + m2; }
+                } else { v = a4 + c6; v = v + m2; v = v + p2; }
+                r[x] = v;
             }
         }
+        const float *r0 = rows, *r1 = rows + dw, *r2 = rows + 2 * dw, *r3 = rows + 3 * dw, *r4 = rows + 4 * dw;
         for (int x = 0; x < dw; x++) {
-            const float v = rows[2 * dw + x] * 6.0f + (rows[dw + x] + rows[3 * dw + x]) * 4.0f + rows[x] + rows[4 * dw + x];
-            dst[(size_t)y * dw + x] = v * (1.0f / 256.0f);
+            float v;
+            if (!orc_float_reduce_mode) { v = r2[x] * 6.0f + (r1[x] + r3[x]) * 4.0f + r0[x] + r4[x]; v = v * (1.0f / 256.0f); }
+            else if (x < vec_end) {
+                float a = r1[x] + r3[x]; a = a + r2[x]; a = a * 4.0f;
+                float b = r0[x] + r4[x]; const float c = r2[x] + r2[x]; b = b + c;
+                v = a + b; v = v * (1.0f / 256.0f);
+            } else {
+                float a = r0[x] + r4[x]; a = a * (1.0f / 256.0f);
+                float b = r1[x] + r3[x]; b = b * (4.0f / 256.0f);
+                const float c = r2[x] * (6.0f / 256.0f);
+                v = a + b; v = v + c;
+            }
+            dst[(size_t)y * dw + x] = v;
         }
     }
     free(rows);

@@ -110,6 +110,50 @@ def test_blend_window_from_a_crop_equals_the_full_blend(oracle):
     assert window(700, 500, 32) > 0          # the check can fail: too small a margin changes the window
 
 
+def test_the_binarys_float_reduce_order_moves_bytes_by_one_level_at_most(oracle):
+    """opencv_imgproc240.dll adds the four terms of a float REDUCE value in an order that depends on the loop that produces it
+    (oracle_blend.c orc_pyr_down_f: border table / 4 x unrolled slots / remainder; SSE rows / scalar tail); oracle and product keep the
+    published source's single order.  Measured here on a 12-chip mosaic with every association of the binary: the weights of levels 1-3
+    are the same bits (their sums are exact in float whatever the order), those of levels 4-5 differ by a few ulp, and the blended image
+    differs by ONE grey level at most, in 0.3 % of its bytes (a +-1 of a level-4 / 5 Laplacian spreads over 16 / 32 pixels)."""
+    rng = np.random.default_rng(7)
+    n, w, h = 12, 640, 480
+    imgs = [texture(w, h, seed=40 + k) for k in range(n)]
+    h9 = np.zeros((n, 9), np.float32)
+    for k in range(n):
+        a = np.deg2rad(rng.uniform(-12, 12)); sc = 1 + rng.uniform(-0.05, 0.05)
+        h9[k] = np.array([[sc * np.cos(a), -sc * np.sin(a), rng.uniform(0, 1500)], [sc * np.sin(a), sc * np.cos(a), rng.uniform(0, 1100)],
+                          [rng.normal(0, 1e-6), rng.normal(0, 1e-6), 1]]).reshape(9)
+    h9[0] = np.eye(3).reshape(9)
+    r = oracle.chips_and_masks(imgs, h9, find_masks=True)
+    import ctypes as C
+    # the REDUCE alone: a 0 / 1 mask goes down five levels in both orders
+    m = (rng.random((480, 640)) < 0.5).astype(np.float32)
+    m[:, :200] = 1.0; m[300:, :] = 0.0
+    levels = {}
+    for mode in (0, 1):
+        oracle.L.orc_set_float_reduce_mode(mode)
+        cur, out = m, []
+        for _ in range(5):
+            d = np.zeros((cur.shape[0] // 2, cur.shape[1] // 2), np.float32)
+            oracle.L.orc_pyr_down_f(cur.ctypes.data_as(C.c_void_p), cur.shape[1], cur.shape[0], d.ctypes.data_as(C.c_void_p))
+            out.append(d); cur = d
+        levels[mode] = out
+    oracle.L.orc_set_float_reduce_mode(0)
+    for l in range(3):
+        assert np.array_equal(levels[0][l].view(np.uint32), levels[1][l].view(np.uint32)), l      # exact sums: any order gives the same bits
+    ulp = [int((levels[0][l].view(np.int32).astype(np.int64) - levels[1][l].view(np.int32)).__abs__().max()) for l in (3, 4)]
+    assert max(ulp) >= 1 and max(ulp) <= 4, ulp                                                   # levels 4-5: last bits
+    try:
+        a, nb = oracle.multiband_blend(r["chips"], r["chip_imgs"], r["masks"], r["cw"], r["ch"], band=5)
+        oracle.L.orc_set_float_reduce_mode(1)
+        b, _ = oracle.multiband_blend(r["chips"], r["chip_imgs"], r["masks"], r["cw"], r["ch"], band=5)
+    finally:
+        oracle.L.orc_set_float_reduce_mode(0)
+    d = np.abs(a.astype(np.int16) - b.astype(np.int16))
+    assert nb == 5 and d.max() == 1 and (d != 0).sum() <= 1e-2 * d.size, (int(d.max()), int((d != 0).sum()), d.size)      # measured: 25 381 of 9 258 880 bytes
+
+
 @pytest.mark.gpu
 def test_gpu_blend_vs_oracle(oracle):
     import imagemosaicing_amd as im
