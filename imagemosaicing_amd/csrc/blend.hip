@@ -45,11 +45,20 @@ __global__ __launch_bounds__(256) void blend_prep_kernel(const uint8_t* chip, in
 }
 
 // one chip of a batch: where its pixels are, how its region lies on the chip, where its pyramid levels >= 1 live
+constexpr int MAX_BANDS = 16;
+struct Win { int x0, y0, x1, y1; };   // inclusive
 struct ChipP {
     const uint8_t* chip; const uint8_t* mask;
     int cw, ch, cws, mws;             // chip size, row pitches of chip (3 B / pixel) and mask
     int left, top, rw, rh;            // chip origin inside its region, region size (multiples of 2^bands)
     size_t tmp;                       // pixel offset of this chip's level 1 inside the batch's pyramid buffers
+    // Active windows (round 4).  With FindMasksByDistMap's masks a chip's weights are non-zero only over the cell of the mosaic it owns (+ the
+    // reach of the REDUCE filter per level), and a pixel of weight +0 adds nothing to the canvas: only the part of the pyramids that the
+    // non-zero weights can see is ever formed.  cwin[l], l = 1 .. bands: the pixels of level l (Gaussian and weight) that are computed --
+    // everything outside is never written and never read; twin[l], l = 0 .. bands: the threads of the accumulation of level l (one per
+    // 2 x 2 block of level l below the top level, one per pixel at the top level).  See chip_windows() for the derivation.
+    Win cwin[MAX_BANDS + 1];
+    Win twin[MAX_BANDS + 1];
 };
 // pixel offset of level l >= 1 behind tmp
 __device__ __forceinline__ size_t level_off(int rw, int rh, int l) { size_t o = 0; for (int m = 1; m < l; m++) o += (size_t)(rw >> m) * (rh >> m); return o; }
@@ -59,9 +68,9 @@ __device__ __forceinline__ size_t level_off(int rw, int rh, int l) { size_t o = 
 // REDUCE of both pyramids of a chip in one launch, two horizontally adjacent outputs per thread: their 5-tap windows share three of the
 // seven source columns, and away from the left / right border those seven pixels are 42 contiguous, 4-byte aligned bytes (11 32-bit
 // loads per row instead of 30 16-bit ones).  The sums are the ones of pyr_down16_kernel / pyr_down_f_kernel, term for term.
-__device__ __forceinline__ void pyr_down_pair_body(const short* src, const float* srcw, int w, int h, short* dst, float* dstw) {
-    const int dw = w >> 1, x0 = (blockIdx.x * 256 + threadIdx.x) * 2, y = blockIdx.y;
-    if (x0 >= dw || y >= (h >> 1)) return;
+__device__ __forceinline__ void pyr_down_pair_body(const short* src, const float* srcw, int w, int h, short* dst, float* dstw, const Win win) {
+    const int dw = w >> 1, x0 = (win.x0 & ~1) + (blockIdx.x * 256 + threadIdx.x) * 2, y = win.y0 + blockIdx.y;
+    if (x0 >= dw || y >= (h >> 1) || x0 > win.x1 || y > win.y1) return;
     const bool two = x0 + 1 < dw;
     const int wt[5] = {1, 4, 6, 4, 1};
     const bool interior = 2 * x0 - 2 >= 0 && 2 * x0 + 4 < w;
@@ -112,13 +121,14 @@ __device__ __forceinline__ void pyr_down_pair_body(const short* src, const float
     }
 }
 __global__ __launch_bounds__(256) void pyr_down_pair_kernel(const short* src, const float* srcw, int w, int h, short* dst, float* dstw) {
-    pyr_down_pair_body(src, srcw, w, h, dst, dstw);
+    pyr_down_pair_body(src, srcw, w, h, dst, dstw, Win{0, 0, (w >> 1) - 1, (h >> 1) - 1});
 }
 // level l -> l + 1 (l >= 1) of every chip of a batch; the grid covers the largest chip
 __global__ __launch_bounds__(256) void pyr_down_pair_batch_kernel(const ChipP* cp, int l, short* g, float* wp) {
-    const ChipP c = cp[blockIdx.z];
+    const ChipP& c = cp[blockIdx.z];
     const size_t a = c.tmp + level_off(c.rw, c.rh, l), b = c.tmp + level_off(c.rw, c.rh, l + 1);
-    pyr_down_pair_body(g + a * 3, wp + a, c.rw >> l, c.rh >> l, g + b * 3, wp + b);
+    const Win win = l + 1 <= MAX_BANDS ? c.cwin[l + 1] : Win{0, 0, (c.rw >> (l + 1)) - 1, (c.rh >> (l + 1)) - 1};
+    pyr_down_pair_body(g + a * 3, wp + a, c.rw >> l, c.rh >> l, g + b * 3, wp + b, win);
 }
 
 // Level 0 -> 1 straight from the chip and its mask: the level-0 value at region pixel (x, y) is (short)chip[reflect(x - left), reflect(y - top)]
@@ -126,10 +136,11 @@ __global__ __launch_bounds__(256) void pyr_down_pair_batch_kernel(const ChipP* c
 // used to store.  Same sums as pyr_down_pair_body, term for term.  Away from the borders the seven pixels of a row are 21 contiguous
 // bytes: six unaligned 32-bit loads (three bytes of slack inside the row), the seven mask bytes two.
 __global__ __launch_bounds__(256) void pyr_down0_batch_kernel(const ChipP* cp, short* g, float* wp) {
-    const ChipP c = cp[blockIdx.z];
+    const ChipP& c = cp[blockIdx.z];
     const int w = c.rw, h = c.rh;
-    const int dw = w >> 1, x0 = (blockIdx.x * 256 + threadIdx.x) * 2, y = blockIdx.y;
-    if (x0 >= dw || y >= (h >> 1)) return;
+    const Win win = c.cwin[1];
+    const int dw = w >> 1, x0 = (win.x0 & ~1) + (blockIdx.x * 256 + threadIdx.x) * 2, y = win.y0 + blockIdx.y;
+    if (x0 >= dw || y >= (h >> 1) || x0 > win.x1 || y > win.y1) return;
     short* dst = g + c.tmp * 3;
     float* dstw = wp + c.tmp;
     const bool two = x0 + 1 < dw;
@@ -265,12 +276,21 @@ __global__ __launch_bounds__(256) void pyr_up16_combine_kernel(const short* coar
 __device__ __forceinline__ void blend_lap_accumulate_body(const short* coarse, int w, int h, const short* fine, const float* wgt, int ox, int oy,
                                                           short* dl, float* dw, int DW, int x, int y) {
     if (x >= w) return;
+    const int FW = 2 * w;
+    {
+        // A pixel whose weight is +0 leaves the canvas as it is: (short)((float)lap * 0.0f) = 0 and sum + 0.0f = sum (the weight sums start
+        // at +0 and only grow).  With FindMasksByDistMap's masks a chip's weights vanish outside its own cell of the mosaic (+ the reach of
+        // the REDUCE filter at this level) -- 98 % of a chip's pixels when 2000 chips share a 20000^2 canvas -- so the block is judged by its
+        // four weights before anything else is read.
+        const float2 wa = *reinterpret_cast<const float2*>(wgt + (size_t)(2 * y) * FW + 2 * x);
+        const float2 wb = *reinterpret_cast<const float2*>(wgt + (size_t)(2 * y + 1) * FW + 2 * x);
+        if (wa.x == 0.0f && wa.y == 0.0f && wb.x == 0.0f && wb.y == 0.0f && !__builtin_signbit(wa.x + wa.y + wb.x + wb.y)) return;
+    }
     const int ym = (y == 0) ? (h > 1 ? 1 : 0) : y - 1, yp = (y == h - 1) ? h - 1 : y + 1;
     const short* rows[3] = {coarse + (size_t)ym * w * 3, coarse + (size_t)y * w * 3, coarse + (size_t)yp * w * 3};
     int he[3][3], ho[3][3];                               // horizontal EXPAND values at fine columns 2x (even) and 2x + 1 (odd), per row and channel
 #pragma unroll
     for (int r = 0; r < 3; r++) up_h_pair(rows[r], w, x, he[r], ho[r]);
-    const int FW = 2 * w;
     // the two fine pixels of a row are 12 contiguous bytes (4-byte aligned: the fine column 2x, the region offset ox and the row pitches are
     // even): three 32-bit loads / stores instead of six 16-bit ones, the weights as one 64-bit access
 #pragma unroll
@@ -312,25 +332,27 @@ __global__ __launch_bounds__(256) void blend_lap_accumulate_kernel(const short* 
 
 // Levels 1 .. bands of one chip in ONE launch (blockIdx.y walks the rows of all of them): the Laplacian levels 1 .. bands - 1 and the top
 // (Gaussian) level.  Launched one by one the small levels cost ~8 us each whatever their size: four of the six launches per chip.
-constexpr int MAX_BANDS = 16;
 struct LapLevels {
     int n;                                   // entries: n - 1 Laplacian levels, then the top level
     int row0[MAX_BANDS + 1];                 // first grid row of entry i (row0[n] = grid rows)
     int w[MAX_BANDS], h[MAX_BANDS], ox[MAX_BANDS], oy[MAX_BANDS], DW[MAX_BANDS];
+    int x0[MAX_BANDS], y0[MAX_BANDS], x1[MAX_BANDS];     // first thread column / row and last thread column of the entry's active window
     size_t fine[MAX_BANDS], coarse[MAX_BANDS], dst[MAX_BANDS];      // pixel offsets into the chip pyramid (g / wp) and the canvas pyramids (dl / dw)
 };
 __global__ __launch_bounds__(256) void blend_lap_levels_kernel(LapLevels L, const short* g, const float* wp, short* dl, float* dw) {
     int i = 0;
 #pragma unroll 1
     while (i + 1 < L.n && (int)blockIdx.y >= L.row0[i + 1]) i++;
-    const int y = blockIdx.y - L.row0[i], x = blockIdx.x * 256 + threadIdx.x;
+    const int y = L.y0[i] + (blockIdx.y - L.row0[i]), x = L.x0[i] + blockIdx.x * 256 + threadIdx.x;      // the level's active window (ChipP::twin)
     if (i + 1 < L.n) {
+        if (x > L.x1[i]) return;
         blend_lap_accumulate_body(g + L.coarse[i] * 3, L.w[i], L.h[i], g + L.fine[i] * 3, wp + L.fine[i], L.ox[i], L.oy[i], dl + L.dst[i] * 3, dw + L.dst[i], L.DW[i], x, y);
     } else {
         // top level: canvas Laplacian += (short)(Gaussian * weight), canvas weight += weight (blend_accumulate_kernel)
         const int lw = L.w[i];
-        if (x >= lw) return;
+        if (x >= lw || x > L.x1[i]) return;
         const float wv = wp[L.fine[i] + (size_t)y * lw + x];
+        if (wv == 0.0f && !__builtin_signbit(wv)) return;      // adds nothing (see blend_lap_accumulate_body)
         const size_t di = L.dst[i] + (size_t)(L.oy[i] + y) * L.DW[i] + (L.ox[i] + x);
         const short* s = g + (L.fine[i] + (size_t)y * lw + x) * 3;
 #pragma unroll
@@ -343,15 +365,29 @@ __global__ __launch_bounds__(256) void blend_lap_levels_kernel(LapLevels L, cons
 // reflection, weights mask / 255 inside the chip and 0 outside.  Inside the chip the two fine pixels of a row are six contiguous bytes.
 __global__ __launch_bounds__(256) void blend_lap0_accumulate_kernel(ChipP c, const short* coarse, int ox, int oy, short* dl, float* dw, int DW) {
     const int w = c.rw >> 1, h = c.rh >> 1;
-    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
-    if (x >= w) return;
+    const int x = c.twin[0].x0 + blockIdx.x * 256 + threadIdx.x, y = c.twin[0].y0 + blockIdx.y;
+    if (x >= w || x > c.twin[0].x1) return;
+    const int cx = 2 * x - c.left;                            // chip column of the even fine pixel
+    const bool xfast = cx >= 0 && cx + 3 < c.cw;              // both columns inside the chip and the 8-byte read inside the row
+    {
+        // the block's four mask bytes first: all zero (or outside the chip) = four weights of +0, which leave the canvas as it is
+        // (blend_lap_accumulate_body); only the chip's own cell of the mosaic goes on
+        unsigned any = 0;
+#pragma unroll
+        for (int dy = 0; dy < 2; dy++) {
+            const int cy = 2 * y + dy - c.top;
+            if (cy < 0 || cy >= c.ch) continue;
+            const uint8_t* mrow = c.mask + (size_t)cy * c.mws;
+            if (cx >= 0 && cx < c.cw) any |= mrow[cx];
+            if (cx + 1 >= 0 && cx + 1 < c.cw) any |= mrow[cx + 1];
+        }
+        if (!any) return;
+    }
     const int ym = (y == 0) ? (h > 1 ? 1 : 0) : y - 1, yp = (y == h - 1) ? h - 1 : y + 1;
     const short* rows[3] = {coarse + (size_t)ym * w * 3, coarse + (size_t)y * w * 3, coarse + (size_t)yp * w * 3};
     int he[3][3], ho[3][3];
 #pragma unroll
     for (int r = 0; r < 3; r++) up_h_pair(rows[r], w, x, he[r], ho[r]);
-    const int cx = 2 * x - c.left;                            // chip column of the even fine pixel
-    const bool xfast = cx >= 0 && cx + 3 < c.cw;              // both columns inside the chip and the 8-byte read inside the row
 #pragma unroll
     for (int dy = 0; dy < 2; dy++) {
         const int Y = 2 * y + dy;
@@ -432,11 +468,89 @@ __global__ __launch_bounds__(256) void blend_finalize_kernel(const short* dl, co
 
 inline dim3 grid2(int w, int h) { return dim3((unsigned)((w + 255) / 256), (unsigned)h); }
 
+// Active windows of one chip (ChipP::cwin / twin), one axis at a time.  n_l = extent of level l, S_0 = the owned pixels' range in region
+// coordinates (bb == NULL: everything).  Every set is a superset of what is needed, so a window can only cost time, never change a value:
+//   S_l    where the weight of level l can be non-zero: REDUCE output q sees the inputs 2q - 2 .. 2q + 2 (reflected indices fall on inputs
+//          the unreflected ones already reach), so S_l+1 = [floor((a - 2) / 2) - 1, floor((b + 2) / 2) + 1], one more on each side for slack;
+//   T_l    the accumulation's threads: 2 x 2 blocks of level l below the top level ([a >> 1, b >> 1]), pixels at the top level;
+//   F_l    the pixels of level l those threads read (Gaussian + weight): the blocks themselves;
+//   E_l+1  the pixels of level l + 1 the EXPAND of those blocks reads: T_l widened by one;
+//   C_l    what is computed of level l >= 1: F_l, E_l and the inputs of the REDUCE that forms C_l+1 ([2a - 2, 2b + 2]).
+// Everything outside C_l stays unwritten in the batch's pyramid buffers and is never read (the pair kernels' second output may be formed
+// from such pixels when C_l+1 starts at an odd column; it lies outside C_l+1 and is never read either).
+void chip_windows(ChipP& c, int nb, const int* bb) {
+    const int L = nb < MAX_BANDS ? nb : MAX_BANDS;
+    if (!bb || nb > MAX_BANDS) {
+        for (int l = 0; l <= L; l++) {
+            c.cwin[l] = Win{0, 0, (c.rw >> l) - 1, (c.rh >> l) - 1};
+            c.twin[l] = l < nb ? Win{0, 0, (c.rw >> (l + 1)) - 1, (c.rh >> (l + 1)) - 1} : c.cwin[l];
+        }
+        return;
+    }
+    for (int axis = 0; axis < 2; axis++) {
+        const int dim = axis ? c.rh : c.rw, off = axis ? c.top : c.left;
+        int Sa[MAX_BANDS + 1], Sb[MAX_BANDS + 1], Ta[MAX_BANDS + 1], Tb[MAX_BANDS + 1], Fa[MAX_BANDS + 1], Fb[MAX_BANDS + 1], Ea[MAX_BANDS + 2], Eb[MAX_BANDS + 2];
+        int Ca[MAX_BANDS + 1], Cb[MAX_BANDS + 1];
+        auto clip = [](int& a, int& b, int n) { if (a < 0) a = 0; if (b > n - 1) b = n - 1; if (a > b) { a = a < n ? a : n - 1; b = a; } };
+        Sa[0] = bb[axis] + off; Sb[0] = bb[2 + axis] + off;
+        clip(Sa[0], Sb[0], dim);
+        for (int l = 0; l < nb; l++) {
+            Sa[l + 1] = ((Sa[l] - 2) >> 1) - 1; Sb[l + 1] = ((Sb[l] + 2) >> 1) + 1;
+            clip(Sa[l + 1], Sb[l + 1], dim >> (l + 1));
+        }
+        Ea[0] = 0; Eb[0] = -1;
+        for (int l = 0; l <= nb; l++) {
+            if (l < nb) {
+                Ta[l] = Sa[l] >> 1; Tb[l] = Sb[l] >> 1; Fa[l] = 2 * Ta[l]; Fb[l] = 2 * Tb[l] + 1;
+                Ea[l + 1] = Ta[l] - 1; Eb[l + 1] = Tb[l] + 1;
+                clip(Ea[l + 1], Eb[l + 1], dim >> (l + 1));
+            } else { Ta[l] = Sa[l]; Tb[l] = Sb[l]; Fa[l] = Sa[l]; Fb[l] = Sb[l]; }
+        }
+        for (int l = nb; l >= 1; l--) {
+            int a = Fa[l] < Ea[l] ? Fa[l] : Ea[l], b = Fb[l] > Eb[l] ? Fb[l] : Eb[l];
+            if (l < nb) { const int ra = 2 * Ca[l + 1] - 2, rb = 2 * Cb[l + 1] + 2; a = ra < a ? ra : a; b = rb > b ? rb : b; }
+            clip(a, b, dim >> l);
+            Ca[l] = a; Cb[l] = b;
+        }
+        Ca[0] = 0; Cb[0] = dim - 1;
+        for (int l = 0; l <= nb; l++) {
+            if (axis == 0) { c.cwin[l].x0 = Ca[l]; c.cwin[l].x1 = Cb[l]; c.twin[l].x0 = Ta[l]; c.twin[l].x1 = Tb[l]; }
+            else           { c.cwin[l].y0 = Ca[l]; c.cwin[l].y1 = Cb[l]; c.twin[l].y0 = Ta[l]; c.twin[l].y1 = Tb[l]; }
+        }
+    }
+}
+
 }  // namespace
+
+// The chip pixels a chip's windows read: the 2 x 2 blocks of the level-0 accumulation (twin[0]) and the inputs of the first REDUCE over
+// cwin[1] (both outputs of a thread, rows and columns 2q - 2 .. 2q + 2), taken through the two reflections the kernels apply (BORDER_REFLECT_101
+// at the region's border, then BORDER_REFLECT into the chip).  Chip coordinates, inclusive.
+static void chip_pixel_window(const ChipP& c, int& x0, int& y0, int& x1, int& y1) {
+    for (int axis = 0; axis < 2; axis++) {
+        const int rdim = axis ? c.rh : c.rw, cdim = axis ? c.ch : c.cw, off = axis ? c.top : c.left;
+        const int ta = axis ? c.twin[0].y0 : c.twin[0].x0, tb = axis ? c.twin[0].y1 : c.twin[0].x1;
+        int ca = axis ? c.cwin[1].y0 : (c.cwin[1].x0 & ~1), cb = axis ? c.cwin[1].y1 : (c.cwin[1].x1 | 1);
+        int a = 2 * ta < 2 * ca - 2 ? 2 * ta : 2 * ca - 2, b = 2 * tb + 1 > 2 * cb + 2 ? 2 * tb + 1 : 2 * cb + 2;
+        if (a < 0) { b = b > -a ? b : -a; a = 0; }
+        if (b > rdim - 1) { const int m = 2 * (rdim - 1) - b; a = a < m ? a : m; b = rdim - 1; }
+        if (a < 0) a = 0;
+        a -= off; b -= off;
+        if (a < 0) { b = b > -a - 1 ? b : -a - 1; a = 0; }
+        if (b > cdim - 1) { const int m = 2 * cdim - 1 - b; a = a < m ? a : m; b = cdim - 1; }
+        if (a < 0) a = 0;
+        if (b < a) b = a;
+        if (axis == 0) { x0 = a; x1 = b; } else { y0 = a; y1 = b; }
+    }
+}
 
 // chips / masks: host pointers (staged one chip at a time) when on_device == 0, device pointers otherwise
 static int blend_core(mi355_ctx* ctx, const uint8_t* const* chips, const uint8_t* const* masks, int on_device, const mi355_chip_info* info, int n,
-                      int W, int H, int band, uint8_t** out, int* ow, int* oh, int* ows_out, uint8_t* d_user = nullptr, int user_ws = 0) {
+                      int W, int H, int band, uint8_t** out, int* ow, int* oh, int* ows_out, uint8_t* d_user = nullptr, int user_ws = 0,
+                      const int* owned_bbox = nullptr, int deferred_pixels = 0) {
+    // deferred_pixels: the chips hold no pixels yet (mi_chips_and_masks_dev(.., defer_pixels)): each chip's are made here, inside the part
+    // of the chip its active windows read (chip_pixel_window)
+    // owned_bbox != NULL (the masks are FindMasksByDistMap's, made on this device): per chip the box of its non-zero mask bytes -- a chip
+    // that owns nothing is left out, the others work inside their active windows (chip_windows)
     // d_user != NULL: the finished canvas goes to the caller's device buffer (rows of user_ws bytes) and nothing is copied to the host
     if (n < 0 || (n > 0 && (!chips || !masks || !info)) || W <= 0 || H <= 0 || band < 0 || (!out && !d_user)) { ctx->set_error("multiband_blend: bad arguments"); return MI355_ERR_ARG; }
     const hipStream_t st = ctx->stream;
@@ -465,6 +579,7 @@ static int blend_core(mi355_ctx* ctx, const uint8_t* const* chips, const uint8_t
     for (int k = 0; k < n; k++) {
         const int cw = info[k].w, chh = info[k].h, x0 = info[k].x0, y0 = info[k].y0;
         if (cw <= 0 || chh <= 0) continue;
+        if (owned_bbox && (owned_bbox[4 * k + 2] < owned_bbox[4 * k] || owned_bbox[4 * k + 3] < owned_bbox[4 * k + 1])) continue;      // all weights +0: adds nothing
         const int gap = 3 * al;
         int tlx = x0 - gap > 0 ? x0 - gap : 0, tly = y0 - gap > 0 ? y0 - gap : 0;
         int brx = x0 + cw + gap < Wp ? x0 + cw + gap : Wp, bry = y0 + chh + gap < Hp ? y0 + chh + gap : Hp;
@@ -480,6 +595,7 @@ static int blend_core(mi355_ctx* ctx, const uint8_t* const* chips, const uint8_t
         c.chip = chips[k]; c.mask = masks[k];
         c.cw = cw; c.ch = chh; c.cws = (cw * 3 + 3) & ~3; c.mws = (cw + 3) & ~3;
         c.left = x0 - tlx; c.top = y0 - tly; c.rw = rw; c.rh = rh;
+        chip_windows(c, nb, owned_bbox ? owned_bbox + 4 * k : nullptr);
         par.push_back(c); geo.push_back({k, tlx, tly});
     }
     const int nc = (int)par.size();
@@ -511,6 +627,7 @@ static int blend_core(mi355_ctx* ctx, const uint8_t* const* chips, const uint8_t
     MI_HIP(gwgt.reserve(max_px * sizeof(float) + 16));
     MI_HIP(dpar.reserve((size_t)(nc > 0 ? nc : 1) * sizeof(ChipP)));
     if (!on_device) { MI_HIP(dchip.reserve(max_cb + 16)); MI_HIP(dmask.reserve(max_mb + 16)); }
+    if (on_device && nb > 0 && nc > 0) MI_HIP(hipMemcpyAsync(dpar.as<ChipP>(), par.data(), (size_t)nc * sizeof(ChipP), hipMemcpyHostToDevice, st));   // one copy, not one per batch
     for (const Batch& bt : batches) {
         const int b0 = bt.b0, b1 = bt.b1, B = b1 - b0, maxw = bt.maxw, maxh = bt.maxh;
         if (!on_device) {
@@ -521,6 +638,14 @@ static int blend_core(mi355_ctx* ctx, const uint8_t* const* chips, const uint8_t
                 MI_HIP(hipMemcpyAsync(dmask.as<uint8_t>() + mo, par[i].mask, mb, hipMemcpyHostToDevice, st));
                 par[i].chip = dchip.as<uint8_t>() + co; par[i].mask = dmask.as<uint8_t>() + mo;
                 co += (cb + 15) & ~(size_t)15; mo += (mb + 15) & ~(size_t)15;
+            }
+        }
+        if (deferred_pixels) {
+            for (int i = b0; i < b1; i++) {
+                int x0 = 0, y0 = 0, x1 = par[i].cw - 1, y1 = par[i].ch - 1;
+                if (nb >= 1 && nb <= MAX_BANDS) chip_pixel_window(par[i], x0, y0, x1, y1);
+                const int rc = mi_chip_pixels_window(ctx, geo[i].k, x0, y0, x1, y1);
+                if (rc != MI355_OK) return rc;
             }
         }
         short* g = glap.as<short>();
@@ -538,11 +663,22 @@ static int blend_core(mi355_ctx* ctx, const uint8_t* const* chips, const uint8_t
         }
         // the chips' parameters of this batch (the slot of the previous batch may still be read: one slot per batch, sized once)
         const ChipP* d_par = dpar.as<ChipP>() + b0;
-        MI_HIP(hipMemcpyAsync(dpar.as<ChipP>() + b0, par.data() + b0, (size_t)B * sizeof(ChipP), hipMemcpyHostToDevice, st));
+        if (!on_device) MI_HIP(hipMemcpyAsync(dpar.as<ChipP>() + b0, par.data() + b0, (size_t)B * sizeof(ChipP), hipMemcpyHostToDevice, st));      // (device chips: all of them at once, above)
         // REDUCE chains of the whole batch: independent of one another and of the canvas
-        hipLaunchKernelGGL(pyr_down0_batch_kernel, dim3((unsigned)((((maxw >> 1) + 1) / 2 + 255) / 256), (unsigned)(maxh >> 1), (unsigned)B), dim3(256), 0, st, d_par, g, wp);
+        // (grids: the largest active window of the batch at that level, in threads of two outputs)
+        auto red_grid = [&](int l1) {
+            int tw = 1, th = 1;
+            for (int i = b0; i < b1; i++) {
+                const Win wn = l1 <= MAX_BANDS ? par[i].cwin[l1] : Win{0, 0, (par[i].rw >> l1) - 1, (par[i].rh >> l1) - 1};
+                const int t = (wn.x1 - (wn.x0 & ~1)) / 2 + 1, hh = wn.y1 - wn.y0 + 1;
+                tw = t > tw ? t : tw; th = hh > th ? hh : th;
+            }
+            return dim3((unsigned)((tw + 255) / 256), (unsigned)th, (unsigned)B);
+        };
+        (void)maxw; (void)maxh;
+        hipLaunchKernelGGL(pyr_down0_batch_kernel, red_grid(1), dim3(256), 0, st, d_par, g, wp);
         for (int l = 1; l < nb; l++)
-            hipLaunchKernelGGL(pyr_down_pair_batch_kernel, dim3((unsigned)((((maxw >> (l + 1)) + 1) / 2 + 255) / 256), (unsigned)(maxh >> (l + 1)), (unsigned)B), dim3(256), 0, st, d_par, l, g, wp);
+            hipLaunchKernelGGL(pyr_down_pair_batch_kernel, red_grid(l + 1), dim3(256), 0, st, d_par, l, g, wp);
         // accumulation, chip after chip in chip order: Laplacian level l = Gaussian l - EXPAND(Gaussian l + 1), accumulated as it is formed
         for (int i = b0; i < b1; i++) {
             const ChipP& c = par[i];
@@ -550,7 +686,8 @@ static int blend_core(mi355_ctx* ctx, const uint8_t* const* chips, const uint8_t
             std::vector<size_t> roff(nb + 2, 0);                      // levels >= 1 behind c.tmp
             roff[1] = c.tmp;
             for (int l = 1; l < nb; l++) roff[l + 1] = roff[l] + (size_t)(rw >> l) * (rh >> l);
-            hipLaunchKernelGGL(blend_lap0_accumulate_kernel, grid2(rw >> 1, rh >> 1), dim3(256), 0, st, c, g + roff[1] * 3, tlx, tly, dlap.as<short>(), dwgt.as<float>(), Wp);
+            hipLaunchKernelGGL(blend_lap0_accumulate_kernel, grid2(c.twin[0].x1 - c.twin[0].x0 + 1, c.twin[0].y1 - c.twin[0].y0 + 1), dim3(256), 0, st, c, g + roff[1] * 3, tlx, tly,
+                               dlap.as<short>(), dwgt.as<float>(), Wp);
             if (nb > MAX_BANDS) {                                             // (band > 16 on a canvas that allows it:) level by level
                 for (int l = 1; l < nb; l++)
                     hipLaunchKernelGGL(blend_lap_accumulate_kernel, grid2(rw >> (l + 1), rh >> (l + 1)), dim3(256), 0, st, g + roff[l + 1] * 3, rw >> (l + 1), rh >> (l + 1),
@@ -565,13 +702,17 @@ static int blend_core(mi355_ctx* ctx, const uint8_t* const* chips, const uint8_t
                 const int i = L.n++;
                 L.row0[i] = rows; L.w[i] = rw >> (l + 1); L.h[i] = rh >> (l + 1); L.ox[i] = tlx >> l; L.oy[i] = tly >> l; L.DW[i] = Wp >> l;
                 L.fine[i] = roff[l]; L.coarse[i] = roff[l + 1]; L.dst[i] = loff[l];
-                rows += L.h[i]; maxw = L.w[i] > maxw ? L.w[i] : maxw;
+                const Win t = c.twin[l];
+                L.x0[i] = t.x0; L.y0[i] = t.y0; L.x1[i] = t.x1;
+                rows += t.y1 - t.y0 + 1; maxw = t.x1 - t.x0 + 1 > maxw ? t.x1 - t.x0 + 1 : maxw;
             }
             {
                 const int i = L.n++;
                 L.row0[i] = rows; L.w[i] = rw >> nb; L.h[i] = rh >> nb; L.ox[i] = tlx >> nb; L.oy[i] = tly >> nb; L.DW[i] = Wp >> nb;
                 L.fine[i] = roff[nb]; L.coarse[i] = 0; L.dst[i] = loff[nb];
-                rows += L.h[i]; maxw = L.w[i] > maxw ? L.w[i] : maxw;
+                const Win t = c.twin[nb];
+                L.x0[i] = t.x0; L.y0[i] = t.y0; L.x1[i] = t.x1;
+                rows += t.y1 - t.y0 + 1; maxw = t.x1 - t.x0 + 1 > maxw ? t.x1 - t.x0 + 1 : maxw;
             }
             L.row0[L.n] = rows;
             hipLaunchKernelGGL(blend_lap_levels_kernel, grid2(maxw, rows), dim3(256), 0, st, L, g, wp, dlap.as<short>(), dwgt.as<float>());
@@ -623,11 +764,12 @@ int mi_mosaic_blended(mi355_ctx* ctx, const uint8_t* const* imgs, const int* w, 
     std::vector<size_t> chip_off, mask_off;
     int nv = 0, cw = 0, ch = 0;
     mi355_chip_info* ci = nullptr;
-    int rc = mi_chips_and_masks_dev(ctx, imgs, w, h, ws, n, h9s, keep, 1, &nv, &ci, chip_off, mask_off, &cw, &ch);
+    std::vector<int> bbox;
+    int rc = mi_chips_and_masks_dev(ctx, imgs, w, h, ws, n, h9s, keep, 1, &nv, &ci, chip_off, mask_off, &cw, &ch, 0, &bbox, 1);
     if (rc != MI355_OK) { free(ci); return rc; }
     std::vector<const uint8_t*> dc(nv > 0 ? nv : 1), dm(nv > 0 ? nv : 1);
     for (int v = 0; v < nv; v++) { dc[v] = ctx->buf("chip_imgs").as<uint8_t>() + chip_off[v]; dm[v] = ctx->buf("chip_masks").as<uint8_t>() + mask_off[v]; }
-    rc = blend_core(ctx, dc.data(), dm.data(), 1, ci, nv, cw, ch, band, out, ow, oh, ows_out);
+    rc = blend_core(ctx, dc.data(), dm.data(), 1, ci, nv, cw, ch, band, out, ow, oh, ows_out, nullptr, 0, (int)bbox.size() == 4 * nv && nv > 0 ? bbox.data() : nullptr, 1);
     free(ci);
     return rc;
 }
@@ -643,11 +785,12 @@ int mi_mosaic_blended_dev(mi355_ctx* ctx, const uint8_t* const* d_imgs, const in
     std::vector<size_t> chip_off, mask_off;
     int nv = 0, gw = 0, gh = 0;
     mi355_chip_info* ci = nullptr;
-    int rc = mi_chips_and_masks_dev(ctx, d_imgs, w, h, ws, n, h9s, keep, 1, &nv, &ci, chip_off, mask_off, &gw, &gh, 1);
+    std::vector<int> bbox;
+    int rc = mi_chips_and_masks_dev(ctx, d_imgs, w, h, ws, n, h9s, keep, 1, &nv, &ci, chip_off, mask_off, &gw, &gh, 1, &bbox, 1);
     if (rc != MI355_OK) { free(ci); return rc; }
     std::vector<const uint8_t*> dc(nv > 0 ? nv : 1), dm(nv > 0 ? nv : 1);
     for (int v = 0; v < nv; v++) { dc[v] = ctx->buf("chip_imgs").as<uint8_t>() + chip_off[v]; dm[v] = ctx->buf("chip_masks").as<uint8_t>() + mask_off[v]; }
-    rc = blend_core(ctx, dc.data(), dm.data(), 1, ci, nv, gw, gh, band, nullptr, nullptr, nullptr, nullptr, d_canvas, cws);
+    rc = blend_core(ctx, dc.data(), dm.data(), 1, ci, nv, gw, gh, band, nullptr, nullptr, nullptr, nullptr, d_canvas, cws, (int)bbox.size() == 4 * nv && nv > 0 ? bbox.data() : nullptr, 1);
     free(ci);
     return rc;
 }

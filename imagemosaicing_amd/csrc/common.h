@@ -117,6 +117,7 @@ struct mi355_ctx {
 
     void set_error(const std::string& s) { err = s; }
     DevBuf& buf(const std::string& name) { return ws[name]; }
+    std::vector<unsigned char> deferred_warps;         // warp.hip: the chips' warp arguments when mi_chips_and_masks_dev was asked to leave the pixels to mi_chip_pixels_window
     // profiling brackets
     void prof_begin(const char* cls, double alg_bytes, hipStream_t st);
     void prof_end(const char* cls, hipStream_t st);
@@ -141,7 +142,11 @@ int mi_mosaic_refined_dev(mi355_ctx*, const uint8_t* const* d_imgs, const int* w
 int mi_sift_flush_if_parked(mi355_ctx*, hipEvent_t ev);   // launches the batch still holding a parked frame with this event
 int mi_chips_and_masks_dev(mi355_ctx*, const uint8_t* const* imgs, const int* w, const int* h, const int* ws, int n,
                            const float* h9s, const uint8_t* keep, int find_masks, int* n_chips, mi355_chip_info** chips,
-                           std::vector<size_t>& chip_off, std::vector<size_t>& mask_off, int* canvas_w, int* canvas_h, int imgs_on_device = 0);
+                           std::vector<size_t>& chip_off, std::vector<size_t>& mask_off, int* canvas_w, int* canvas_h, int imgs_on_device = 0,
+                           std::vector<int>* owned_bbox = nullptr, int defer_pixels = 0);      // find_masks: per chip {min col, min row, max col, max row} of its non-zero mask bytes (max < min: none)
+// defer_pixels: the chips' validity masks (and ownership) are made at once, their PIXELS only where asked for afterwards, chip by chip
+// (the blender needs them inside a chip's active window only); columns / rows inclusive, clipped to the chip
+int mi_chip_pixels_window(mi355_ctx*, int chip, int x0, int y0, int x1, int y1);
 int mi_mosaic_blended(mi355_ctx*, const uint8_t* const* imgs, const int* w, const int* h, const int* ws, int n, const float* h9s,
                       const uint8_t* keep, int band, uint8_t** out, int* ow, int* oh, int* ows);
 int mi_mosaic_blended_dev(mi355_ctx*, const uint8_t* const* d_imgs, const int* w, const int* h, const int* ws, int n, const float* h9s,

@@ -45,7 +45,9 @@ __device__ __forceinline__ void load_pair<3>(const uint8_t* s, float& b0, float&
     b1 = (float)(lo >> 24);  g1 = (float)(hi & 0xff);        r1 = (float)(hi >> 8);
 }
 
-template <int CH, bool CHIP>
+// PART (chips only): 0 = pixels and validity mask, 1 = the validity mask alone (no source read), 2 = the pixels alone (the mask bytes
+// hold the ownership by then and stay as they are)
+template <int CH, bool CHIP, int PART = 0>
 __global__ __launch_bounds__(256) void warp_kernel(WarpArgs a) {
     const int gx = blockIdx.x * blockDim.x + threadIdx.x;          // group of 4 pixels
     const int yD = a.y_beg + blockIdx.y * blockDim.y + threadIdx.y;
@@ -79,7 +81,8 @@ __global__ __launch_bounds__(256) void warp_kernel(WarpArgs a) {
         const int xi = (int)xc, yi = (int)yc;
         const float p = yc - (float)yi, q = xc - (float)xi;
         const uint8_t* s = a.src + (size_t)yi * a.ws + (size_t)CH * xi;
-        if (CH == 3) {
+        if (PART == 1) {
+        } else if (CH == 3) {
             float b00, g00, r00, b01, g01, r01, b10, g10, r10, b11, g11, r11;
             load_pair<3>(s, b00, g00, r00, b01, g01, r01);
             load_pair<3>(s + a.ws, b10, g10, r10, b11, g11, r11);
@@ -96,6 +99,16 @@ __global__ __launch_bounds__(256) void warp_kernel(WarpArgs a) {
         nvalid += ok ? 1 : 0;
     }
     uint8_t* drow = a.dst + (size_t)yD * a.dws + (size_t)CH * xg;
+    if (PART == 1) {
+        uint8_t* mrow = a.mask + (size_t)yD * a.mws + xg;
+        if (xg >= a.x_beg && xg + 3 <= a.x_end) {
+            *reinterpret_cast<uint32_t*>(mrow) = (valid[0] ? 0xffu : 0u) | (valid[1] ? 0xff00u : 0u) | (valid[2] ? 0xff0000u : 0u) | (valid[3] ? 0xff000000u : 0u);     // xg and mws are multiples of 4
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; k++) if (xg + k >= a.x_beg && xg + k <= a.x_end) mrow[k] = valid[k] ? 255 : 0;
+        }
+        return;
+    }
     if (nvalid == 4) {
         // whole group valid: aligned dword stores (xg % 4 == 0 and dws % 4 == 0)
         uint32_t* d32 = reinterpret_cast<uint32_t*>(drow);
@@ -116,13 +129,13 @@ __global__ __launch_bounds__(256) void warp_kernel(WarpArgs a) {
         for (int k = 0; k < 4; k++) {
             const int xD = xg + k;
             if (xD < a.x_beg || xD > a.x_end) continue;
-            mrow[k] = valid[k] ? 255 : 0;
+            if (PART == 0) mrow[k] = valid[k] ? 255 : 0;
             if (!valid[k]) for (int c = 0; c < CH; c++) drow[CH * k + c] = 0;
         }
     }
 }
 
-template <int CH, bool CHIP>
+template <int CH, bool CHIP, int PART = 0>
 void launch_warp(mi355_ctx* ctx, const WarpArgs& a) {
     if (a.x_end < a.x_beg || a.y_end < a.y_beg) return;
     const int groups = (a.x_end - (a.x_beg & ~3)) / 4 + 1;
@@ -131,7 +144,7 @@ void launch_warp(mi355_ctx* ctx, const WarpArgs& a) {
     dim3 grid((groups + 63) / 64, (rows + 3) / 4);
     const double bytes = (double)CH * ((double)(a.x_end - a.x_beg + 1) * rows) * 2.0;   // read ~P + write P
     ProfScope ps(ctx, "warp", bytes);
-    hipLaunchKernelGGL((warp_kernel<CH, CHIP>), grid, block, 0, ctx->stream, a);
+    hipLaunchKernelGGL((warp_kernel<CH, CHIP, PART>), grid, block, 0, ctx->stream, a);
 }
 
 inline float big() { return (float)(1 << 29); }
@@ -508,13 +521,62 @@ __global__ __launch_bounds__(256) void owner_kernel(const ChipDev* chips, const 
     }
 }
 
+// Per chip the box of its mask's non-zero bytes, i.e. of the pixels the chip OWNS after owner_kernel: {min column, min row} in
+// bbox_min[2k..] (start 0x7f7f7f7f), {max column, max row} in bbox_max[2k..] (start -1).  The blender works only where a chip's weights can
+// be non-zero (blend.hip chip_windows).  One launch for all chips, a workgroup per 256 x 64 mask block (one 32-bit load per lane and row);
+// only the workgroups that meet a non-zero byte -- a chip owns a few percent of its area in a dense survey -- end with atomics.
+// (Tracked inside owner_kernel instead, every wave of a cell moved the maximum row: 12 000 atomics per address, 7 -> 18 ms per canvas.)
+__global__ __launch_bounds__(256) void mask_bbox_kernel(const ChipDev* chips, uint8_t* const* masks, int* bbox_min, int* bbox_max) {
+    const ChipDev cd = chips[blockIdx.z];
+    const int c0 = (blockIdx.x * 64 + threadIdx.x) * 4, r0 = blockIdx.y * 64;
+    if (blockIdx.x * 256 >= cd.w || r0 >= cd.h) return;
+    const uint8_t* mask = masks[blockIdx.z];
+    int xa = 0x7fffffff, xb = -1, ya = 0x7fffffff, yb = -1;
+    if (c0 < cd.w) {
+#pragma unroll 4
+        for (int r = r0 + threadIdx.y; r < r0 + 64 && r < cd.h; r += 4) {
+            unsigned mm = *reinterpret_cast<const unsigned*>(mask + (size_t)r * cd.mws + c0);      // mws and c0 are multiples of 4
+            if (c0 + 3 >= cd.w) mm &= 0xffffffffu >> (8 * (c0 + 4 - cd.w));                        // row padding is not part of the chip
+            if (mm) {
+                const int lo = c0 + (__builtin_ctz(mm) >> 3), hi = c0 + 3 - (__builtin_clz(mm) >> 3);
+                xa = lo < xa ? lo : xa; xb = hi > xb ? hi : xb; ya = r < ya ? r : ya; yb = r > yb ? r : yb;
+            }
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        int o;
+        o = __shfl_xor(xa, off); xa = o < xa ? o : xa;
+        o = __shfl_xor(ya, off); ya = o < ya ? o : ya;
+        o = __shfl_xor(xb, off); xb = o > xb ? o : xb;
+        o = __shfl_xor(yb, off); yb = o > yb ? o : yb;
+    }
+    __shared__ int s_b[4][4];
+    const int tid = threadIdx.y * 64 + threadIdx.x;
+    if ((tid & 63) == 0) { s_b[tid >> 6][0] = xa; s_b[tid >> 6][1] = ya; s_b[tid >> 6][2] = xb; s_b[tid >> 6][3] = yb; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int i = 1; i < 4; i++) {
+            xa = s_b[i][0] < xa ? s_b[i][0] : xa; ya = s_b[i][1] < ya ? s_b[i][1] : ya;
+            xb = s_b[i][2] > xb ? s_b[i][2] : xb; yb = s_b[i][3] > yb ? s_b[i][3] : yb;
+        }
+        if (xb >= 0) {
+            int* mn = bbox_min + 2 * blockIdx.z; int* mx = bbox_max + 2 * blockIdx.z;
+            if (xa < *reinterpret_cast<volatile int*>(mn)) atomicMin(mn, xa);
+            if (ya < *reinterpret_cast<volatile int*>(mn + 1)) atomicMin(mn + 1, ya);
+            if (xb > *reinterpret_cast<volatile int*>(mx)) atomicMax(mx, xb);
+            if (yb > *reinterpret_cast<volatile int*>(mx + 1)) atomicMax(mx + 1, yb);
+        }
+    }
+}
+
 }  // namespace
 
 // Device stage of the chips: layout on the host, warps / distance maps / ownership on the device.  The chips and masks
 // stay in ctx buffers "chip_imgs" / "chip_masks" at chip_off[v] / mask_off[v]; *chips_out is malloc'd.
 int mi_chips_and_masks_dev(mi355_ctx* ctx, const uint8_t* const* imgs, const int* w, const int* h, const int* ws, int n,
                            const float* h9s, const uint8_t* keep, int find_masks, int* n_chips, mi355_chip_info** chips_out,
-                           std::vector<size_t>& chip_off, std::vector<size_t>& mask_off, int* cw_out, int* ch_out, int imgs_on_device) {
+                           std::vector<size_t>& chip_off, std::vector<size_t>& mask_off, int* cw_out, int* ch_out, int imgs_on_device,
+                           std::vector<int>* owned_bbox, int defer_pixels) {
     if (!imgs || !w || !h || !ws || !h9s || n <= 0 || !n_chips || !chips_out) return MI355_ERR_ARG;
     // ---- layout, MosaicImage.cpp:2233-2343 (host, same float ops) ----
     float maxX = 0.0f, maxY = 0.0f, minX = 0.0f, minY = 0.0f;                     // :2234 (canvas always contains the origin)
@@ -571,8 +633,13 @@ int mi_chips_and_masks_dev(mi355_ctx* ctx, const uint8_t* const* imgs, const int
     DevBuf& dmeta = ctx->buf("chip_meta");
     MI_HIP(dchips.reserve(chip_total + 16));
     MI_HIP(dmasks.reserve(mask_total + 16));
-    MI_HIP(hipMemsetAsync(dchips.p, 0, chip_total, ctx->stream));
-    MI_HIP(hipMemsetAsync(dmasks.p, 0, mask_total, ctx->stream));
+    // defer_pixels (the one-call blend): every mask byte of a chip's columns is written by the validity pass, the pixels later and only
+    // inside the chip's active window (mi_chip_pixels_window); row padding is never read there, so nothing is cleared
+    if (!defer_pixels) {
+        MI_HIP(hipMemsetAsync(dchips.p, 0, chip_total, ctx->stream));
+        MI_HIP(hipMemsetAsync(dmasks.p, 0, mask_total, ctx->stream));
+    }
+    if (defer_pixels) ctx->deferred_warps.resize(sizeof(WarpArgs) * (size_t)nv);
     // every kept source is staged in HBM up front (frames stay resident: 288 GB), so uploads and warps of consecutive chips
     // overlap on the stream instead of synchronising per chip
     std::vector<size_t> src_off(nv, 0);
@@ -596,7 +663,8 @@ int mi_chips_and_masks_dev(mi355_ctx* ctx, const uint8_t* const* imgs, const int
         a.mask = dmasks.as<uint8_t>() + mask_off[v]; a.mws = cd[v].mws;
         a.x_beg = 0; a.x_end = c.w - 1; a.y_beg = 0; a.y_end = c.h - 1;
         a.dx = dGx; a.dy = dGy; a.sx = c.sx; a.sy = c.sy; a.x0 = c.x0; a.y0 = c.y0;
-        launch_warp<3, true>(ctx, a);
+        if (defer_pixels) { launch_warp<3, true, 1>(ctx, a); memcpy(ctx->deferred_warps.data() + sizeof(WarpArgs) * (size_t)v, &a, sizeof(a)); }
+        else launch_warp<3, true>(ctx, a);
     }
     // validity masks are final here unless the distance-map ownership is requested
     if (find_masks && nv > 0) {
@@ -627,7 +695,8 @@ int mi_chips_and_masks_dev(mi355_ctx* ctx, const uint8_t* const* imgs, const int
         }
         auto up16 = [](size_t b) { return (b + 15) & ~(size_t)15; };
         const size_t o_cd = 0, o_mp = up16(o_cd + sizeof(ChipDev) * nv), o_mx = up16(o_mp + sizeof(uint8_t*) * nv), o_ln = up16(o_mx + sizeof(unsigned) * nv),
-                     o_lo = up16(o_ln + sizeof(LineSet) * nv), o_ls = up16(o_lo + sizeof(int) * loff.size()), meta_bytes = o_ls + sizeof(int) * lst.size();
+                     o_lo = up16(o_ln + sizeof(LineSet) * nv), o_ls = up16(o_lo + sizeof(int) * loff.size()), o_bb = up16(o_ls + sizeof(int) * lst.size()),
+                     meta_bytes = o_bb + sizeof(int) * 4 * nv;
         MI_HIP(dmeta.reserve(meta_bytes + 64));
         uint8_t* mb = dmeta.as<uint8_t>();
         ChipDev* d_cd = reinterpret_cast<ChipDev*>(mb + o_cd);
@@ -644,6 +713,12 @@ int mi_chips_and_masks_dev(mi355_ctx* ctx, const uint8_t* const* imgs, const int
         MI_HIP(hipMemcpyAsync(d_loff, loff.data(), sizeof(int) * loff.size(), hipMemcpyHostToDevice, ctx->stream));
         MI_HIP(hipMemcpyAsync(d_list, lst.data(), sizeof(int) * lst.size(), hipMemcpyHostToDevice, ctx->stream));
         MI_HIP(hipMemsetAsync(d_max, 0, sizeof(unsigned) * nv, ctx->stream));
+        int* d_bbmin = owned_bbox ? reinterpret_cast<int*>(mb + o_bb) : nullptr;      // [2 nv] minima, then [2 nv] maxima
+        int* d_bbmax = owned_bbox ? d_bbmin + 2 * nv : nullptr;
+        if (owned_bbox) {
+            MI_HIP(hipMemsetAsync(d_bbmin, 0x7f, sizeof(int) * 2 * nv, ctx->stream));
+            MI_HIP(hipMemsetAsync(d_bbmax, 0xff, sizeof(int) * 2 * nv, ctx->stream));
+        }
         dim3 block(64, 4);
         {
             ProfScope ps(ctx, "distmap", (double)chip_total / 3.0);
@@ -658,12 +733,36 @@ int mi_chips_and_masks_dev(mi355_ctx* ctx, const uint8_t* const* imgs, const int
             ProfScope ps(ctx, "owner", (double)newW * newH);
             hipLaunchKernelGGL(owner_kernel, grid, block, 0, ctx->stream, d_cd, d_lines, d_max, d_loff, d_list, bx_n, newW, newH, d_mptr);
         }
+        if (owned_bbox) {
+            ProfScope ps(ctx, "distmap", (double)chip_total / 3.0);
+            int mw = 1, mh = 1;
+            for (int v = 0; v < nv; v++) { if (ci[v].w > mw) mw = ci[v].w; if (ci[v].h > mh) mh = ci[v].h; }
+            for (int v0 = 0; v0 < nv; v0 += 65535)
+                hipLaunchKernelGGL(mask_bbox_kernel, dim3((mw + 255) / 256, (mh + 63) / 64, nv - v0 < 65535 ? nv - v0 : 65535), block, 0, ctx->stream,
+                                   d_cd + v0, d_mptr + v0, d_bbmin + 2 * v0, d_bbmax + 2 * v0);
+        }
+        std::vector<int> bb;
+        if (owned_bbox) { bb.resize((size_t)4 * nv); MI_HIP(hipMemcpyAsync(bb.data(), d_bbmin, sizeof(int) * 4 * nv, hipMemcpyDeviceToHost, ctx->stream)); }
         MI_HIP(hipStreamSynchronize(ctx->stream));        // the host vectors above were sources of asynchronous copies
+        if (owned_bbox) {
+            owned_bbox->resize((size_t)4 * nv);
+            for (int v = 0; v < nv; v++) { int* o = owned_bbox->data() + 4 * v; o[0] = bb[2 * v]; o[1] = bb[2 * v + 1]; o[2] = bb[2 * nv + 2 * v]; o[3] = bb[2 * nv + 2 * v + 1]; }
+        }
     }
     MI_HIP(hipGetLastError());
     *n_chips = nv; *chips_out = ci_hold.release();
     if (cw_out) *cw_out = newW;
     if (ch_out) *ch_out = newH;
+    return MI355_OK;
+}
+
+int mi_chip_pixels_window(mi355_ctx* ctx, int chip, int x0, int y0, int x1, int y1) {
+    if (chip < 0 || sizeof(WarpArgs) * ((size_t)chip + 1) > ctx->deferred_warps.size()) { ctx->set_error("chip_pixels_window: no such deferred chip"); return MI355_ERR_ARG; }
+    WarpArgs a;
+    memcpy(&a, ctx->deferred_warps.data() + sizeof(WarpArgs) * (size_t)chip, sizeof(a));
+    a.x_beg = x0 > a.x_beg ? x0 : a.x_beg; a.y_beg = y0 > a.y_beg ? y0 : a.y_beg;
+    a.x_end = x1 < a.x_end ? x1 : a.x_end; a.y_end = y1 < a.y_end ? y1 : a.y_end;
+    launch_warp<3, true, 2>(ctx, a);
     return MI355_OK;
 }
 

@@ -180,3 +180,34 @@ def test_gpu_blend_vs_oracle(oracle):
     gotk, _, _, _ = ctx.MosaicBlended(imgs, h9s, keep=keep, band=5)
     assert np.array_equal(gotk, refk)
     ctx.close()
+
+
+@pytest.mark.gpu
+def test_gpu_blend_active_windows_dense_survey(oracle):
+    """mi355_mosaic_blended works only inside each chip's active windows (the cell of the mosaic the chip owns + the reach of the REDUCE
+    filter per level; blend.hip chip_windows) and leaves out chips that own nothing.  A dense pile of small frames -- heavy overlap, cells of
+    a few dozen pixels, chips that own nothing at all, odd window origins -- must give the bytes of the full computation (the oracle works
+    on whole regions), for several pyramid depths."""
+    import imagemosaicing_amd as im
+    rng = np.random.default_rng(20260930)
+    ctx = im.Context(0)
+    for trial, (n, w, h, spread) in enumerate([(24, 320, 240, 260.0), (40, 200, 152, 120.0), (9, 413, 307, 500.0)]):
+        imgs, h9s = [], []
+        for k in range(n):
+            imgs.append(texture(w, h, seed=100 * trial + k))
+            yaw = np.deg2rad(rng.uniform(-8, 8)); s = 1 + rng.uniform(-0.03, 0.03)
+            tx, ty = (0.0, 0.0) if k == 0 else rng.uniform(0, spread, 2)
+            H = np.array([[s * np.cos(yaw), -s * np.sin(yaw), tx], [s * np.sin(yaw), s * np.cos(yaw), ty], [0, 0, 1]], np.float32)
+            h9s.append(H.reshape(9))
+        h9s = np.stack(h9s)
+        # one frame exactly on top of another one: the later of the two can never own a pixel (strict maximum, first wins)
+        h9s[n - 1] = h9s[n // 2]; imgs[n - 1] = imgs[n // 2].copy()
+        r = ctx.ChipsAndMasks(imgs, h9s, find_masks=True)
+        owned = [int((m != 0).sum()) for m in r["masks"]]
+        assert min(owned) == 0 and max(owned) > 0
+        for band in (5, 3, 1):
+            ref, _ = oracle.multiband_blend(r["chips"], r["chip_imgs"], r["masks"], r["cw"], r["ch"], band=band)
+            got, ow, oh, _ = ctx.MosaicBlended(imgs, h9s, band=band)
+            assert (ow, oh) == (r["cw"], r["ch"])
+            assert np.array_equal(got, ref), f"trial {trial} band {band}: {(got != ref).sum()} bytes differ"
+    ctx.close()
