@@ -52,6 +52,7 @@ struct ChipP {
     int cw, ch, cws, mws;             // chip size, row pitches of chip (3 B / pixel) and mask
     int left, top, rw, rh;            // chip origin inside its region, region size (multiples of 2^bands)
     size_t tmp;                       // pixel offset of this chip's level 1 inside the batch's pyramid buffers
+    int tlx, tly;                     // the region's origin on the canvas
     // Active windows (round 4).  With FindMasksByDistMap's masks a chip's weights are non-zero only over the cell of the mosaic it owns (+ the
     // reach of the REDUCE filter per level), and a pixel of weight +0 adds nothing to the canvas: only the part of the pyramids that the
     // non-zero weights can see is ever formed.  cwin[l], l = 1 .. bands: the pixels of level l (Gaussian and weight) that are computed --
@@ -363,7 +364,11 @@ __global__ __launch_bounds__(256) void blend_lap_levels_kernel(LapLevels L, cons
 
 // The same for level 0, whose Gaussian level is the chip itself (see pyr_down0_batch_kernel): fine values from the chip extended by
 // reflection, weights mask / 255 inside the chip and 0 outside.  Inside the chip the two fine pixels of a row are six contiguous bytes.
-__global__ __launch_bounds__(256) void blend_lap0_accumulate_kernel(ChipP c, const short* coarse, int ox, int oy, short* dl, float* dw, int DW) {
+// A row's two pixels are written as three 32-bit words only when BOTH have a weight: then both belong to this chip's cell and no other chip
+// has a weight there.  Otherwise each pixel with a weight is updated on its own (16-bit accesses) and a pixel without one is not touched --
+// so with masks that partition the canvas (FindMasksByDistMap) the chips write disjoint bytes at level 0, in any order: the batch form
+// below runs the level-0 accumulation of up to 32 chips as one launch (per chip it was ~10 us of stream time whatever the window's size).
+__device__ __forceinline__ void blend_lap0_body(const ChipP& c, const short* coarse, int ox, int oy, short* dl, float* dw, int DW) {
     const int w = c.rw >> 1, h = c.rh >> 1;
     const int x = c.twin[0].x0 + blockIdx.x * 256 + threadIdx.x, y = c.twin[0].y0 + blockIdx.y;
     if (x >= w || x > c.twin[0].x1) return;
@@ -413,9 +418,7 @@ __global__ __launch_bounds__(256) void blend_lap0_accumulate_kernel(ChipP c, con
             }
         }
         const size_t di = (size_t)(oy + Y) * DW + (ox + 2 * x);
-        unsigned* dp = reinterpret_cast<unsigned*>(dl + di * 3);
-        unsigned d0 = dp[0], d1 = dp[1], d2 = dp[2];
-        short dv[6] = {(short)(d0 & 0xffff), (short)(d0 >> 16), (short)(d1 & 0xffff), (short)(d1 >> 16), (short)(d2 & 0xffff), (short)(d2 >> 16)};
+        short add[6];
 #pragma unroll
         for (int dx = 0; dx < 2; dx++) {
             const float wv = wv2[dx];
@@ -425,15 +428,39 @@ __global__ __launch_bounds__(256) void blend_lap0_accumulate_kernel(ChipP c, con
                 const int v = dy ? (h0 + hp) * 4 : hm + h0 * 6 + hp;
                 const int up = sat16d((v + 32) >> 6);
                 const short lap = sat16d((int)fv[3 * dx + ch] - up);
-                dv[3 * dx + ch] = (short)(dv[3 * dx + ch] + (short)((float)lap * wv));
+                add[3 * dx + ch] = (short)((float)lap * wv);
             }
         }
-        dp[0] = (unsigned)(unsigned short)dv[0] | ((unsigned)(unsigned short)dv[1] << 16);
-        dp[1] = (unsigned)(unsigned short)dv[2] | ((unsigned)(unsigned short)dv[3] << 16);
-        dp[2] = (unsigned)(unsigned short)dv[4] | ((unsigned)(unsigned short)dv[5] << 16);
-        float2* wp2 = reinterpret_cast<float2*>(dw + di);
-        float2 a2 = *wp2; a2.x += wv2[0]; a2.y += wv2[1]; *wp2 = a2;
+        if (wv2[0] != 0.0f && wv2[1] != 0.0f) {
+            unsigned* dp = reinterpret_cast<unsigned*>(dl + di * 3);
+            const unsigned d0 = dp[0], d1 = dp[1], d2 = dp[2];
+            short dv[6] = {(short)(d0 & 0xffff), (short)(d0 >> 16), (short)(d1 & 0xffff), (short)(d1 >> 16), (short)(d2 & 0xffff), (short)(d2 >> 16)};
+#pragma unroll
+            for (int e = 0; e < 6; e++) dv[e] = (short)(dv[e] + add[e]);
+            dp[0] = (unsigned)(unsigned short)dv[0] | ((unsigned)(unsigned short)dv[1] << 16);
+            dp[1] = (unsigned)(unsigned short)dv[2] | ((unsigned)(unsigned short)dv[3] << 16);
+            dp[2] = (unsigned)(unsigned short)dv[4] | ((unsigned)(unsigned short)dv[5] << 16);
+            float2* wp2 = reinterpret_cast<float2*>(dw + di);
+            float2 a2 = *wp2; a2.x += wv2[0]; a2.y += wv2[1]; *wp2 = a2;
+        } else {
+#pragma unroll
+            for (int dx = 0; dx < 2; dx++) {
+                if (wv2[dx] == 0.0f) continue;                        // adds nothing (blend_lap_accumulate_body)
+                short* dp = dl + (di + dx) * 3;
+#pragma unroll
+                for (int ch = 0; ch < 3; ch++) dp[ch] = (short)(dp[ch] + add[3 * dx + ch]);
+                dw[di + dx] += wv2[dx];
+            }
+        }
     }
+}
+__global__ __launch_bounds__(256) void blend_lap0_accumulate_kernel(ChipP c, const short* coarse, int ox, int oy, short* dl, float* dw, int DW) {
+    blend_lap0_body(c, coarse, ox, oy, dl, dw, DW);
+}
+// level 0 of every chip of a batch (blockIdx.z = chip; the grid covers the largest window): only for masks that partition the canvas
+__global__ __launch_bounds__(256) void blend_lap0_accumulate_batch_kernel(const ChipP* cp, const short* g, short* dl, float* dw, int DW) {
+    const ChipP& c = cp[blockIdx.z];
+    blend_lap0_body(c, g + c.tmp * 3, c.tlx, c.tly, dl, dw, DW);
 }
 
 // canvas Laplacian += (short)(chip Laplacian * weight), canvas weight += weight, over the chip's region at this level
@@ -594,7 +621,7 @@ static int blend_core(mi355_ctx* ctx, const uint8_t* const* chips, const uint8_t
         ChipP c; memset(&c, 0, sizeof(c));
         c.chip = chips[k]; c.mask = masks[k];
         c.cw = cw; c.ch = chh; c.cws = (cw * 3 + 3) & ~3; c.mws = (cw + 3) & ~3;
-        c.left = x0 - tlx; c.top = y0 - tly; c.rw = rw; c.rh = rh;
+        c.left = x0 - tlx; c.top = y0 - tly; c.rw = rw; c.rh = rh; c.tlx = tlx; c.tly = tly;
         chip_windows(c, nb, owned_bbox ? owned_bbox + 4 * k : nullptr);
         par.push_back(c); geo.push_back({k, tlx, tly});
     }
@@ -627,6 +654,16 @@ static int blend_core(mi355_ctx* ctx, const uint8_t* const* chips, const uint8_t
     MI_HIP(gwgt.reserve(max_px * sizeof(float) + 16));
     MI_HIP(dpar.reserve((size_t)(nc > 0 ? nc : 1) * sizeof(ChipP)));
     if (!on_device) { MI_HIP(dchip.reserve(max_cb + 16)); MI_HIP(dmask.reserve(max_mb + 16)); }
+    if (deferred_pixels) {
+        std::vector<int> ids((size_t)(nc > 0 ? nc : 1)), wins((size_t)4 * (nc > 0 ? nc : 1));
+        for (int i = 0; i < nc; i++) {
+            int x0 = 0, y0 = 0, x1 = par[i].cw - 1, y1 = par[i].ch - 1;
+            if (nb >= 1 && nb <= MAX_BANDS) chip_pixel_window(par[i], x0, y0, x1, y1);
+            ids[i] = geo[i].k; wins[4 * i] = x0; wins[4 * i + 1] = y0; wins[4 * i + 2] = x1; wins[4 * i + 3] = y1;
+        }
+        const int rc = mi_chip_pixels_prepare(ctx, nc, ids.data(), wins.data());
+        if (rc != MI355_OK) return rc;
+    }
     if (on_device && nb > 0 && nc > 0) MI_HIP(hipMemcpyAsync(dpar.as<ChipP>(), par.data(), (size_t)nc * sizeof(ChipP), hipMemcpyHostToDevice, st));   // one copy, not one per batch
     for (const Batch& bt : batches) {
         const int b0 = bt.b0, b1 = bt.b1, B = b1 - b0, maxw = bt.maxw, maxh = bt.maxh;
@@ -640,14 +677,7 @@ static int blend_core(mi355_ctx* ctx, const uint8_t* const* chips, const uint8_t
                 co += (cb + 15) & ~(size_t)15; mo += (mb + 15) & ~(size_t)15;
             }
         }
-        if (deferred_pixels) {
-            for (int i = b0; i < b1; i++) {
-                int x0 = 0, y0 = 0, x1 = par[i].cw - 1, y1 = par[i].ch - 1;
-                if (nb >= 1 && nb <= MAX_BANDS) chip_pixel_window(par[i], x0, y0, x1, y1);
-                const int rc = mi_chip_pixels_window(ctx, geo[i].k, x0, y0, x1, y1);
-                if (rc != MI355_OK) return rc;
-            }
-        }
+        if (deferred_pixels) { const int rc = mi_chip_pixels_launch(ctx, b0, B); if (rc != MI355_OK) return rc; }      // the batch's chip pixels, one launch
         short* g = glap.as<short>();
         float* wp = gwgt.as<float>();
         if (nb == 0) {
@@ -679,6 +709,13 @@ static int blend_core(mi355_ctx* ctx, const uint8_t* const* chips, const uint8_t
         hipLaunchKernelGGL(pyr_down0_batch_kernel, red_grid(1), dim3(256), 0, st, d_par, g, wp);
         for (int l = 1; l < nb; l++)
             hipLaunchKernelGGL(pyr_down_pair_batch_kernel, red_grid(l + 1), dim3(256), 0, st, d_par, l, g, wp);
+        // level 0 of the whole batch at once when the masks partition the canvas (owned_bbox: they are this device's FindMasksByDistMap masks)
+        const bool lap0_batched = owned_bbox != nullptr && nb <= MAX_BANDS;
+        if (lap0_batched) {
+            int tw = 1, th = 1;
+            for (int i = b0; i < b1; i++) { const Win t = par[i].twin[0]; tw = t.x1 - t.x0 + 1 > tw ? t.x1 - t.x0 + 1 : tw; th = t.y1 - t.y0 + 1 > th ? t.y1 - t.y0 + 1 : th; }
+            hipLaunchKernelGGL(blend_lap0_accumulate_batch_kernel, dim3((unsigned)((tw + 255) / 256), (unsigned)th, (unsigned)B), dim3(256), 0, st, d_par, g, dlap.as<short>(), dwgt.as<float>(), Wp);
+        }
         // accumulation, chip after chip in chip order: Laplacian level l = Gaussian l - EXPAND(Gaussian l + 1), accumulated as it is formed
         for (int i = b0; i < b1; i++) {
             const ChipP& c = par[i];
@@ -686,8 +723,9 @@ static int blend_core(mi355_ctx* ctx, const uint8_t* const* chips, const uint8_t
             std::vector<size_t> roff(nb + 2, 0);                      // levels >= 1 behind c.tmp
             roff[1] = c.tmp;
             for (int l = 1; l < nb; l++) roff[l + 1] = roff[l] + (size_t)(rw >> l) * (rh >> l);
-            hipLaunchKernelGGL(blend_lap0_accumulate_kernel, grid2(c.twin[0].x1 - c.twin[0].x0 + 1, c.twin[0].y1 - c.twin[0].y0 + 1), dim3(256), 0, st, c, g + roff[1] * 3, tlx, tly,
-                               dlap.as<short>(), dwgt.as<float>(), Wp);
+            if (!lap0_batched)
+                hipLaunchKernelGGL(blend_lap0_accumulate_kernel, grid2(c.twin[0].x1 - c.twin[0].x0 + 1, c.twin[0].y1 - c.twin[0].y0 + 1), dim3(256), 0, st, c, g + roff[1] * 3, tlx, tly,
+                                   dlap.as<short>(), dwgt.as<float>(), Wp);
             if (nb > MAX_BANDS) {                                             // (band > 16 on a canvas that allows it:) level by level
                 for (int l = 1; l < nb; l++)
                     hipLaunchKernelGGL(blend_lap_accumulate_kernel, grid2(rw >> (l + 1), rh >> (l + 1)), dim3(256), 0, st, g + roff[l + 1] * 3, rw >> (l + 1), rh >> (l + 1),

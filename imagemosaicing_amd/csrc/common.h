@@ -117,6 +117,7 @@ struct mi355_ctx {
 
     void set_error(const std::string& s) { err = s; }
     DevBuf& buf(const std::string& name) { return ws[name]; }
+    std::vector<int> deferred_dims;                    // per prepared entry: launch extent (groups of 4 columns, rows)
     std::vector<unsigned char> deferred_warps;         // warp.hip: the chips' warp arguments when mi_chips_and_masks_dev was asked to leave the pixels to mi_chip_pixels_window
     // profiling brackets
     void prof_begin(const char* cls, double alg_bytes, hipStream_t st);
@@ -146,7 +147,8 @@ int mi_chips_and_masks_dev(mi355_ctx*, const uint8_t* const* imgs, const int* w,
                            std::vector<int>* owned_bbox = nullptr, int defer_pixels = 0);      // find_masks: per chip {min col, min row, max col, max row} of its non-zero mask bytes (max < min: none)
 // defer_pixels: the chips' validity masks (and ownership) are made at once, their PIXELS only where asked for afterwards, chip by chip
 // (the blender needs them inside a chip's active window only); columns / rows inclusive, clipped to the chip
-int mi_chip_pixels_window(mi355_ctx*, int chip, int x0, int y0, int x1, int y1);
+int mi_chip_pixels_prepare(mi355_ctx*, int n, const int* chips, const int* win4);      // entry e = chip chips[e] inside win4[4e..]: arguments to the device
+int mi_chip_pixels_launch(mi355_ctx*, int first, int count);                          // one launch for entries first .. first + count - 1
 int mi_mosaic_blended(mi355_ctx*, const uint8_t* const* imgs, const int* w, const int* h, const int* ws, int n, const float* h9s,
                       const uint8_t* keep, int band, uint8_t** out, int* ow, int* oh, int* ows);
 int mi_mosaic_blended_dev(mi355_ctx*, const uint8_t* const* d_imgs, const int* w, const int* h, const int* ws, int n, const float* h9s,

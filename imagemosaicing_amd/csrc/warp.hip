@@ -47,8 +47,8 @@ __device__ __forceinline__ void load_pair<3>(const uint8_t* s, float& b0, float&
 
 // PART (chips only): 0 = pixels and validity mask, 1 = the validity mask alone (no source read), 2 = the pixels alone (the mask bytes
 // hold the ownership by then and stay as they are)
-template <int CH, bool CHIP, int PART = 0>
-__global__ __launch_bounds__(256) void warp_kernel(WarpArgs a) {
+template <int CH, bool CHIP, int PART>
+__device__ __forceinline__ void warp_body(const WarpArgs& a) {
     const int gx = blockIdx.x * blockDim.x + threadIdx.x;          // group of 4 pixels
     const int yD = a.y_beg + blockIdx.y * blockDim.y + threadIdx.y;
     const int xg = (a.x_beg & ~3) + gx * 4;
@@ -134,6 +134,13 @@ __global__ __launch_bounds__(256) void warp_kernel(WarpArgs a) {
         }
     }
 }
+
+template <int CH, bool CHIP, int PART = 0>
+__global__ __launch_bounds__(256) void warp_kernel(WarpArgs a) { warp_body<CH, CHIP, PART>(a); }
+// the chips of a survey in one launch (blockIdx.z = chip; the grid covers the largest range): one launch per chip was ~10 us of stream time
+// each whatever its size -- 2000 chips, two passes
+template <int PART>
+__global__ __launch_bounds__(256) void warp_chips_kernel(const WarpArgs* arr) { warp_body<3, true, PART>(arr[blockIdx.z]); }
 
 template <int CH, bool CHIP, int PART = 0>
 void launch_warp(mi355_ctx* ctx, const WarpArgs& a) {
@@ -663,8 +670,19 @@ int mi_chips_and_masks_dev(mi355_ctx* ctx, const uint8_t* const* imgs, const int
         a.mask = dmasks.as<uint8_t>() + mask_off[v]; a.mws = cd[v].mws;
         a.x_beg = 0; a.x_end = c.w - 1; a.y_beg = 0; a.y_end = c.h - 1;
         a.dx = dGx; a.dy = dGy; a.sx = c.sx; a.sy = c.sy; a.x0 = c.x0; a.y0 = c.y0;
-        if (defer_pixels) { launch_warp<3, true, 1>(ctx, a); memcpy(ctx->deferred_warps.data() + sizeof(WarpArgs) * (size_t)v, &a, sizeof(a)); }
+        if (defer_pixels) memcpy(ctx->deferred_warps.data() + sizeof(WarpArgs) * (size_t)v, &a, sizeof(a));
         else launch_warp<3, true>(ctx, a);
+    }
+    if (defer_pixels && nv > 0) {                       // validity masks of all chips: one launch
+        DevBuf& dwa = ctx->buf("chip_warp_args");
+        MI_HIP(dwa.reserve(sizeof(WarpArgs) * (size_t)nv));
+        MI_HIP(hipMemcpyAsync(dwa.p, ctx->deferred_warps.data(), sizeof(WarpArgs) * (size_t)nv, hipMemcpyHostToDevice, ctx->stream));
+        int mw = 1, mh = 1;
+        for (int v = 0; v < nv; v++) { if (ci[v].w > mw) mw = ci[v].w; if (ci[v].h > mh) mh = ci[v].h; }
+        ProfScope ps(ctx, "warp", (double)mask_total);
+        for (int v0 = 0; v0 < nv; v0 += 65535)
+            hipLaunchKernelGGL((warp_chips_kernel<1>), dim3(((mw + 3) / 4 + 63) / 64, (mh + 3) / 4, nv - v0 < 65535 ? nv - v0 : 65535), dim3(64, 4), 0, ctx->stream,
+                               dwa.as<WarpArgs>() + v0);
     }
     // validity masks are final here unless the distance-map ownership is requested
     if (find_masks && nv > 0) {
@@ -705,20 +723,19 @@ int mi_chips_and_masks_dev(mi355_ctx* ctx, const uint8_t* const* imgs, const int
         LineSet* d_lines = reinterpret_cast<LineSet*>(mb + o_ln);
         int* d_loff = reinterpret_cast<int*>(mb + o_lo);
         int* d_list = reinterpret_cast<int*>(mb + o_ls);
-        std::vector<uint8_t*> mptr(nv);
-        for (int v = 0; v < nv; v++) mptr[v] = dmasks.as<uint8_t>() + mask_off[v];
-        MI_HIP(hipMemcpyAsync(d_cd, cd.data(), sizeof(ChipDev) * nv, hipMemcpyHostToDevice, ctx->stream));
-        MI_HIP(hipMemcpyAsync(d_mptr, mptr.data(), sizeof(uint8_t*) * nv, hipMemcpyHostToDevice, ctx->stream));
-        MI_HIP(hipMemcpyAsync(d_lines, lines.data(), sizeof(LineSet) * nv, hipMemcpyHostToDevice, ctx->stream));
-        MI_HIP(hipMemcpyAsync(d_loff, loff.data(), sizeof(int) * loff.size(), hipMemcpyHostToDevice, ctx->stream));
-        MI_HIP(hipMemcpyAsync(d_list, lst.data(), sizeof(int) * lst.size(), hipMemcpyHostToDevice, ctx->stream));
-        MI_HIP(hipMemsetAsync(d_max, 0, sizeof(unsigned) * nv, ctx->stream));
+        // one host image of the whole meta area, one copy (six small copies from pageable memory cost ~0.35 ms each on the stream): chip
+        // descriptors, mask pointers, the maxima (zero), the edge lines, the block lists, the owned boxes' start values
+        std::vector<uint8_t> blob(meta_bytes, 0);
+        memcpy(blob.data() + o_cd, cd.data(), sizeof(ChipDev) * nv);
+        for (int v = 0; v < nv; v++) { uint8_t* mp = dmasks.as<uint8_t>() + mask_off[v]; memcpy(blob.data() + o_mp + sizeof(uint8_t*) * v, &mp, sizeof(mp)); }
+        memcpy(blob.data() + o_ln, lines.data(), sizeof(LineSet) * nv);
+        memcpy(blob.data() + o_lo, loff.data(), sizeof(int) * loff.size());
+        memcpy(blob.data() + o_ls, lst.data(), sizeof(int) * lst.size());
+        memset(blob.data() + o_bb, 0x7f, sizeof(int) * 2 * nv);
+        memset(blob.data() + o_bb + sizeof(int) * 2 * nv, 0xff, sizeof(int) * 2 * nv);
+        MI_HIP(hipMemcpyAsync(mb, blob.data(), meta_bytes, hipMemcpyHostToDevice, ctx->stream));
         int* d_bbmin = owned_bbox ? reinterpret_cast<int*>(mb + o_bb) : nullptr;      // [2 nv] minima, then [2 nv] maxima
         int* d_bbmax = owned_bbox ? d_bbmin + 2 * nv : nullptr;
-        if (owned_bbox) {
-            MI_HIP(hipMemsetAsync(d_bbmin, 0x7f, sizeof(int) * 2 * nv, ctx->stream));
-            MI_HIP(hipMemsetAsync(d_bbmax, 0xff, sizeof(int) * 2 * nv, ctx->stream));
-        }
         dim3 block(64, 4);
         {
             ProfScope ps(ctx, "distmap", (double)chip_total / 3.0);
@@ -756,13 +773,38 @@ int mi_chips_and_masks_dev(mi355_ctx* ctx, const uint8_t* const* imgs, const int
     return MI355_OK;
 }
 
-int mi_chip_pixels_window(mi355_ctx* ctx, int chip, int x0, int y0, int x1, int y1) {
-    if (chip < 0 || sizeof(WarpArgs) * ((size_t)chip + 1) > ctx->deferred_warps.size()) { ctx->set_error("chip_pixels_window: no such deferred chip"); return MI355_ERR_ARG; }
-    WarpArgs a;
-    memcpy(&a, ctx->deferred_warps.data() + sizeof(WarpArgs) * (size_t)chip, sizeof(a));
-    a.x_beg = x0 > a.x_beg ? x0 : a.x_beg; a.y_beg = y0 > a.y_beg ? y0 : a.y_beg;
-    a.x_end = x1 < a.x_end ? x1 : a.x_end; a.y_end = y1 < a.y_end ? y1 : a.y_end;
-    launch_warp<3, true, 2>(ctx, a);
+// deferred chips: entry e of the list = chip chips[e] restricted to columns / rows win[4e .. 4e+3] (inclusive, clipped to the chip).  The
+// arguments of all entries go to the device in one copy; mi_chip_pixels_launch then renders a run of entries with one launch.
+int mi_chip_pixels_prepare(mi355_ctx* ctx, int n, const int* chips, const int* win) {
+    std::vector<WarpArgs> arr((size_t)(n > 0 ? n : 1));
+    ctx->deferred_dims.assign((size_t)2 * (n > 0 ? n : 0), 0);
+    for (int e = 0; e < n; e++) {
+        const int chip = chips[e];
+        if (chip < 0 || sizeof(WarpArgs) * ((size_t)chip + 1) > ctx->deferred_warps.size()) { ctx->set_error("chip_pixels: no such deferred chip"); return MI355_ERR_ARG; }
+        WarpArgs a;
+        memcpy(&a, ctx->deferred_warps.data() + sizeof(WarpArgs) * (size_t)chip, sizeof(a));
+        const int* w4 = win + 4 * e;
+        a.x_beg = w4[0] > a.x_beg ? w4[0] : a.x_beg; a.y_beg = w4[1] > a.y_beg ? w4[1] : a.y_beg;
+        a.x_end = w4[2] < a.x_end ? w4[2] : a.x_end; a.y_end = w4[3] < a.y_end ? w4[3] : a.y_end;
+        arr[e] = a;
+        ctx->deferred_dims[2 * e] = a.x_end < a.x_beg ? 0 : (a.x_end - (a.x_beg & ~3)) / 4 + 1;      // groups of 4 columns
+        ctx->deferred_dims[2 * e + 1] = a.y_end < a.y_beg ? 0 : a.y_end - a.y_beg + 1;
+    }
+    if (n <= 0) return MI355_OK;
+    DevBuf& d = ctx->buf("chip_warp_windows");
+    MI_HIP(d.reserve(sizeof(WarpArgs) * (size_t)n));
+    MI_HIP(hipMemcpy(d.p, arr.data(), sizeof(WarpArgs) * (size_t)n, hipMemcpyHostToDevice));      // `arr` is a local: the copy must have read it on return
+    return MI355_OK;
+}
+int mi_chip_pixels_launch(mi355_ctx* ctx, int first, int count) {
+    if (count <= 0) return MI355_OK;
+    if (first < 0 || (size_t)2 * (first + count) > ctx->deferred_dims.size()) { ctx->set_error("chip_pixels: bad range"); return MI355_ERR_ARG; }
+    int gw = 0, gh = 0;
+    for (int e = first; e < first + count; e++) { gw = ctx->deferred_dims[2 * e] > gw ? ctx->deferred_dims[2 * e] : gw; gh = ctx->deferred_dims[2 * e + 1] > gh ? ctx->deferred_dims[2 * e + 1] : gh; }
+    if (gw == 0 || gh == 0) return MI355_OK;
+    ProfScope ps(ctx, "warp", 0.0);
+    hipLaunchKernelGGL((warp_chips_kernel<2>), dim3((gw + 63) / 64, (gh + 3) / 4, count), dim3(64, 4), 0, ctx->stream, ctx->buf("chip_warp_windows").as<WarpArgs>() + first);
+    MI_HIP(hipGetLastError());
     return MI355_OK;
 }
 
