@@ -481,6 +481,7 @@ __global__ __launch_bounds__(256) void distmax_kernel(const ChipDev* chips, uint
 // every covering chip's mask byte is rewritten: 255 for the owner, 0 for the others.  A mask byte belongs to exactly one canvas
 // pixel, so the thread of that pixel is the only one that touches it.
 constexpr int OWN_BLK = 256;
+constexpr int OWN_ROWS = 4;
 // The chips of the block (uniform over the workgroup: 64 x 4 threads inside one block) are staged in LDS, 32 at a time: with the
 // descriptors read per thread and per chip from global memory every candidate was a chain of four dependent loads (list -> chip ->
 // mask pointer -> mask byte) and the kernel ran at 0.2 TB/s of its own byte traffic.
@@ -490,38 +491,57 @@ __global__ __launch_bounds__(256) void owner_kernel(const ChipDev* chips, const 
     constexpr int NE = 32;
     __shared__ OwnEntry s_e[NE];
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    const int r = blockIdx.y * blockDim.y + threadIdx.y;
+    const int r = (blockIdx.y * blockDim.y + threadIdx.y) * OWN_ROWS;                                  // first of the thread's rows
     const int tid = threadIdx.y * blockDim.x + threadIdx.x;
     const bool inside = c < rectW && r < rectH;
-    const int rb = (blockIdx.y * blockDim.y) / OWN_BLK, cb = (blockIdx.x * blockDim.x) / OWN_BLK;      // the workgroup lies inside one block
+    const int rb = (blockIdx.y * blockDim.y * OWN_ROWS) / OWN_BLK, cb = (blockIdx.x * blockDim.x) / OWN_BLK;      // the workgroup (64 x 16 pixels) lies inside one block
     const int blk = rb * bx_n + cb;
     const int l0 = list_off[blk], l1 = list_off[blk + 1];
-    int best = -1; float bd = 0.0f;
-    for (int pass = 0; pass < 2; pass++) {                       // 0: find the owner, 1: rewrite the mask bytes
-        for (int base = l0; base < l1; base += NE) {
-            const int ne = l1 - base < NE ? l1 - base : NE;
-            __syncthreads();
-            if (tid < ne) {
-                const int k = list[base + tid];
-                const ChipDev cd = chips[k];
-                OwnEntry e;
-                e.x0 = cd.x0; e.y0 = cd.y0; e.w = cd.w; e.h = cd.h; e.mws = cd.mws; e.k = k; e.maxv = __uint_as_float(maxbits[k]); e.pad = 0;
-                e.mask = masks[k]; e.L = lines[k];
-                s_e[tid] = e;
-            }
-            __syncthreads();
-            if (!inside) continue;
-            for (int q = 0; q < ne; q++) {
-                const OwnEntry& e = s_e[q];
-                const int yC = r - e.y0, xC = c - e.x0;
-                if (yC >= 0 && yC < e.h && xC >= 0 && xC < e.w) {
-                    uint8_t* m = e.mask + (size_t)yC * e.mws + xC;
-                    if (pass == 0) {
-                        float v = 0.0f;
-                        if (*m != 0) v = quad_min_dist(e.L, xC, yC);
-                        const float d = v / e.maxv;
-                        if (d > bd) { bd = d; best = e.k; }
-                    } else *m = (e.k == best) ? 255 : 0;
+    // One walk over the candidates (round 4; it was two: find the owner, then rewrite every covering chip's byte).  Afterwards the owner's
+    // byte is 255 and every other covering chip's is 0.  A byte is 255 or 0 before (sample / no sample) and the owner's is 255 necessarily
+    // (its distance is > 0, so it has a sample): it is enough to clear the byte of every candidate that has a sample and loses -- at once when
+    // it does not beat the leader (d > bd is false: smaller, equal = the earlier chip wins, or NaN), or when a later chip takes the lead.
+    // Four consecutive rows per thread (a wave = 64 columns x 4 rows, the workgroup 64 x 16): the candidate's descriptor (26 dwords of LDS),
+    // the column test and the products A[i] * column are shared by the four pixels; each row keeps its own leader.
+    float bd[OWN_ROWS];
+    uint8_t* lead[OWN_ROWS];                                      // the leader's mask byte
+#pragma unroll
+    for (int j = 0; j < OWN_ROWS; j++) { bd[j] = 0.0f; lead[j] = nullptr; }
+    for (int base = l0; base < l1; base += NE) {
+        const int ne = l1 - base < NE ? l1 - base : NE;
+        __syncthreads();
+        if (tid < ne) {
+            const int k = list[base + tid];
+            const ChipDev cd = chips[k];
+            OwnEntry e;
+            e.x0 = cd.x0; e.y0 = cd.y0; e.w = cd.w; e.h = cd.h; e.mws = cd.mws; e.k = k; e.maxv = __uint_as_float(maxbits[k]); e.pad = 0;
+            e.mask = masks[k]; e.L = lines[k];
+            s_e[tid] = e;
+        }
+        __syncthreads();
+        if (!inside) continue;
+        for (int q = 0; q < ne; q++) {
+            const OwnEntry& e = s_e[q];
+            const int xC = c - e.x0, yC0 = r - e.y0;
+            if (xC < 0 || xC >= e.w || yC0 + OWN_ROWS - 1 < 0 || yC0 >= e.h) continue;
+            float ac[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) ac[i] = e.L.A[i] * (float)xC;      // the first product of quad_min_dist's expression
+#pragma unroll
+            for (int j = 0; j < OWN_ROWS; j++) {
+                const int yC = yC0 + j;
+                if (yC < 0 || yC >= e.h || r + j >= rectH) continue;
+                uint8_t* m = e.mask + (size_t)yC * e.mws + xC;
+                if (*m != 0) {
+                    float minDist = (float)(1 << 29);                       // quad_min_dist(e.L, xC, yC), same operations
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        const float dd = fabsf(ac[i] + e.L.B[i] * (float)yC + e.L.C[i]) * e.L.inv[i];
+                        if (dd < minDist) minDist = dd;
+                    }
+                    const float d = minDist / e.maxv;
+                    if (d > bd[j]) { bd[j] = d; if (lead[j]) *lead[j] = 0; lead[j] = m; }
+                    else *m = 0;
                 }
             }
         }
@@ -745,7 +765,7 @@ int mi_chips_and_masks_dev(mi355_ctx* ctx, const uint8_t* const* imgs, const int
                 hipLaunchKernelGGL(distmax_kernel, dim3((mw + 255) / 256, (mh + 63) / 64, nv - v0 < 65535 ? nv - v0 : 65535), block, 0, ctx->stream,
                                    d_cd + v0, d_mptr + v0, d_lines + v0, d_max + v0);
         }
-        dim3 grid((newW + 63) / 64, (newH + 3) / 4);
+        dim3 grid((newW + 63) / 64, (newH + 4 * OWN_ROWS - 1) / (4 * OWN_ROWS));
         {
             ProfScope ps(ctx, "owner", (double)newW * newH);
             hipLaunchKernelGGL(owner_kernel, grid, block, 0, ctx->stream, d_cd, d_lines, d_max, d_loff, d_list, bx_n, newW, newH, d_mptr);
