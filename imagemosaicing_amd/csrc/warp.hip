@@ -520,8 +520,26 @@ __global__ __launch_bounds__(256) void owner_kernel(const ChipDev* chips, const 
         }
         __syncthreads();
         if (!inside) continue;
+        // The mask bytes of candidate q + 1 are fetched before candidate q is judged: a candidate's stores go to its own mask or to an earlier
+        // leader's, never to the next candidate's, but the compiler cannot know that and would start each load after the previous stores.
+        uint8_t nxt[OWN_ROWS];
+        auto fetch = [&](int q, uint8_t* out) {
+            const OwnEntry& e = s_e[q];
+            const int xC = c - e.x0, yC0 = r - e.y0;
+            const bool xin = xC >= 0 && xC < e.w;
+#pragma unroll
+            for (int j = 0; j < OWN_ROWS; j++) {
+                const int yC = yC0 + j;
+                out[j] = (xin && yC >= 0 && yC < e.h && r + j < rectH) ? e.mask[(size_t)yC * e.mws + xC] : (uint8_t)0;
+            }
+        };
+        fetch(0, nxt);
         for (int q = 0; q < ne; q++) {
             const OwnEntry& e = s_e[q];
+            uint8_t cur[OWN_ROWS];
+#pragma unroll
+            for (int j = 0; j < OWN_ROWS; j++) cur[j] = nxt[j];
+            if (q + 1 < ne) fetch(q + 1, nxt);
             const int xC = c - e.x0, yC0 = r - e.y0;
             if (xC < 0 || xC >= e.w || yC0 + OWN_ROWS - 1 < 0 || yC0 >= e.h) continue;
             float ac[4];
@@ -532,7 +550,7 @@ __global__ __launch_bounds__(256) void owner_kernel(const ChipDev* chips, const 
                 const int yC = yC0 + j;
                 if (yC < 0 || yC >= e.h || r + j >= rectH) continue;
                 uint8_t* m = e.mask + (size_t)yC * e.mws + xC;
-                if (*m != 0) {
+                if (cur[j] != 0) {
                     float minDist = (float)(1 << 29);                       // quad_min_dist(e.L, xC, yC), same operations
 #pragma unroll
                     for (int i = 0; i < 4; i++) {
