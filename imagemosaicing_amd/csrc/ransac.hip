@@ -39,7 +39,8 @@ struct RansacArgs {
     int stride;
     float dist;
     int sample_times;
-    int list_floats;               // floats of dynamic LDS in front of the point arrays: the list of accepted draws (uint16 x min(sample_times, 4999))
+    int list_floats;               // floats of dynamic LDS in front of the point arrays: the list of accepted draws and their supports (2 x uint16 x min(sample_times, 4999)); also the uint16 offset of the supports
+    int hb_off;                    // float offset of the lanes' best hypotheses (9 x RB floats) inside the dynamic LDS: behind the points and their float4 copy, where J* is kept later
     int min_keep;                  // pairs with at most this many inliers skip the closing refinement (-1: never): the caller rejects them anyway
     mi355_pair_result* out;        // [pair]
     // BIG variants (one pair with n > 400, mi355_ransac2d only): work arrays of the closing Gauss-Newton and the inlier lists in HBM
@@ -129,6 +130,7 @@ __device__ __forceinline__ void ransac_body(const RansacArgs& a) {
     __shared__ int   s_state[8];      // 0 t_acc, 1 maxSupport, 2 bestDraw, 3 firstAcc, 4 finished, 5 newBest, 6 newFirst, 7 done
     __shared__ int   s_wtot[RB / 64 + 1];
     __shared__ int   s_npol;
+    __shared__ int   s_next;          // next group of 64 list entries to hand to a wave
     __shared__ float s_fbk[RB / 64][320];   // work arrays of the generic solve, one slot per wave
     __shared__ int   s_fb;            // draws that needed the generic (private-memory) solve: diagnostic, reported in _pad
 
@@ -140,7 +142,7 @@ __device__ __forceinline__ void ransac_body(const RansacArgs& a) {
     const mi355_sfpoint* P2 = a.p2 + (size_t)pair * a.stride;
 
     if (tid < 9) out->H[tid] = 0.0f;
-    if (tid == 0) { s_fb = 0; s_npol = 0; out->_pad = 0; }
+    if (tid == 0) { s_fb = 0; s_npol = 0; s_next = 0; out->_pad = 0; }
     if (n < 4 || a.sample_times < 1) {                     // mosaicimage.h:1739-1761
         if (tid == 0) { out->n_in = 0; out->ok = 0; }
         return;
@@ -171,7 +173,8 @@ __device__ __forceinline__ void ransac_body(const RansacArgs& a) {
     const uint16_t* table = a.tables + (size_t)(a.single_table ? 0 : (a.table_of ? a.table_of[pair] : (n - 4))) * MAX_DRAWS * 4;
 
     float h[9];
-    long long T0 = wall_clock64(); int nchunk = 0; long long Tsolve = 0, Tsup = 0, Trep = 0;
+    int my_li = -1;
+    long long T0 = wall_clock64(); int nchunk = 0; long long Tsolve = 0, Tsup = 0;
     // ---- pass 1: which draws hold a hypothesis slot ------------------------------------------------------------------------
     // A draw whose 4-point solve leaves a residual above 5 px is skipped without consuming a slot (:1864-1867): on unrelated image
     // pairs that is 42 % of the draws, and 6.8 chunks of 256 draws were walked for the 1000 slots with those lanes idle through
@@ -208,12 +211,30 @@ __device__ __forceinline__ void ransac_body(const RansacArgs& a) {
     nlist = nlist < list_cap ? nlist : list_cap;
     __syncthreads();
     long long Tclass = wall_clock64() - T0;
-    // ---- pass 2: hypotheses + supports of the accepted draws, 256 at a time; the sequential loop replayed over each chunk ----
-    for (int base = 0; ; base += RB) {
-        nchunk++; long long c0 = wall_clock64();
-        const int li = base + tid;
-        int flag = 2, support = 0;                         // 2 = no such draw (stream of 4999 draws exhausted before sample_times slots were filled)
-        if (li < nlist) {
+    // ---- pass 2: hypotheses + supports of the accepted draws; then the sequential loop (mosaicimage.h:1864-1918) replayed once over all of them ----
+    // Round 4 (late): the waves no longer meet after every 256 draws.  A wave takes the next 64 draws of the list from a counter, solves, polishes,
+    // counts, and takes the next ones; the supports go to LDS, and a lane keeps the hypothesis of ITS OWN first maximum in LDS (a lane's draws
+    // come in list order, so the loop's winner -- the first draw holding the maximum of the draws the loop looks at -- is its lane's first
+    // maximum).  With a barrier per chunk the four waves of a workgroup, whose solve times differ by a quarter from chunk to chunk, waited for
+    // the slowest one four times per pair: 14 000 of 80 000 ticks.  The loop's two stop rules are applied afterwards on the stored supports;
+    // draws behind a stop have then been evaluated for nothing (a stop by the 0.99 ratio is rare, the slot limit is the list's length).
+    uint16_t* sup = list + a.list_floats;                      // support of list entry i (<= n <= 65535)
+    float* hb = lds + a.hb_off;                                // [9][RB]: the lane's own best hypothesis
+    {
+        const int lane = tid & 63;
+        const int nsub = (nlist + 63) >> 6;
+        int mybest = -1;
+        my_li = -1;
+        for (;;) {
+            long long c0 = wall_clock64();
+            int sc = 0;
+            if (lane == 0) sc = atomicAdd(&s_next, 1);
+            sc = __shfl(sc, 0, 64);
+            if (sc >= nsub) break;
+            nchunk++;
+            const int li = sc * 64 + lane;
+            int support = 0;
+            if (li < nlist) {
             const int r = list[li];
             float p[16];
             const uint16_t* s = table + 4 * r;
@@ -238,7 +259,7 @@ __device__ __forceinline__ void ransac_body(const RansacArgs& a) {
                 }
             }
             long long c1 = wall_clock64(); Tsolve += c1 - c0;
-            flag = 1;                                      // a polished hypothesis is never skipped, whatever its residual after the polish (:1868-1876)
+            // (a polished hypothesis is never skipped, whatever its residual after the polish: :1868-1876)
             if constexpr (BIG) {
                 for (int i = 0; i < n; i++) {              // :1890-1904
                     float bx, by;
@@ -265,65 +286,77 @@ __device__ __forceinline__ void ransac_body(const RansacArgs& a) {
                     if (dd < d2) support++;
                 }
             }
-        }
-        // ---- replay of the sequential loop over this chunk (mosaicimage.h:1864-1918), in parallel ----
-        // In draw order (the chunk holds accepted draws only; the skipped ones were left out by pass 1): a draw with flag 2 ends the
-        // loop before it is looked at; an accepted draw (flag 1)
-        // becomes the first hypothesis if there was none, replaces the best one when its support is strictly larger (and ends
-        // the loop at once when that support exceeds 0.99 n, before the counter moves), then counts; the loop ends when the
-        // counter reaches sample_times.  So the chunk is cut at E = min(first flag 2 - 1, first accepted draw with support > mx
-        // and ratio > 0.99, the accepted draw that makes the counter reach sample_times); the best of the chunk is the first
-        // accepted draw <= E holding the maximum support, if that exceeds the running maximum.
-        const int lane = tid & 63, wv = tid >> 6;
-        const int t0 = s_state[0], mx0 = s_state[1], first0 = s_state[3];
-        const bool acc = flag == 1;
-        const unsigned long long m_acc = __ballot(acc), m_f2 = __ballot(flag == 2),
-                                 m_r = __ballot(acc && support > mx0 && (float)support * invn > 0.99f);
-        if (lane == 0) { s_mask[0][wv] = m_acc; s_mask[1][wv] = m_f2; s_mask[2][wv] = m_r; }
-        __syncthreads();
-        long long c2 = wall_clock64(); Tsup += c2 - c0;
-        int before = 0;                                    // accepted draws of the chunk before this wave
-        for (int i = 0; i < RB / 64; i++) if (i < wv) before += __popcll(s_mask[0][i]);
-        const int cnt_incl = before + __popcll(m_acc & ((2ull << lane) - 1ull));
-        const unsigned long long m_t = __ballot(acc && t0 + cnt_incl == sample_times);
-        if (lane == 0) s_mask[3][wv] = m_t;
-        __syncthreads();
-        auto first_of = [&](int which) { for (int i = 0; i < RB / 64; i++) { const unsigned long long m = s_mask[which][i]; if (m) return 64 * i + (int)__builtin_ctzll(m); } return RB; };
-        const int k2 = first_of(1), kr = first_of(2), kt = first_of(3);
-        int E = k2 - 1;
-        E = kr < E ? kr : E; E = kt < E ? kt : E;          // last draw of the chunk the loop looks at (RB - 1 when nothing ends it)
-        const int fin = (k2 < RB || kr < RB || kt < RB) ? 1 : 0;
-        const bool inc = acc && tid <= E;
-        // first accepted draw, and the first holder of the maximum support among the included ones
-        unsigned key = inc ? (((unsigned)support << 8) | (unsigned)(RB - 1 - tid)) : 0u;      // support <= 400 < 2^23
+                sup[li] = (uint16_t)support;
+                if (support > mybest) {
+                    mybest = support; my_li = li;
 #pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) { const unsigned v = __shfl_xor(key, o, 64); key = v > key ? v : key; }
-        const unsigned long long m_inc = __ballot(inc);
-        if (lane == 0) { s_wkey[wv] = key; s_mask[4][wv] = m_inc; }
-        __syncthreads();
-        unsigned kb = 0; int kfirst = RB, nacc = 0;
-        for (int i = 0; i < RB / 64; i++) {
-            kb = s_wkey[i] > kb ? s_wkey[i] : kb;
-            const unsigned long long m = s_mask[4][i];
-            if (m && kfirst == RB) kfirst = 64 * i + (int)__builtin_ctzll(m);
-            nacc += __popcll(m);
+                    for (int i = 0; i < 9; i++) hb[i * RB + tid] = h[i];
+                }
+                if (li == 0) { for (int i = 0; i < 9; i++) s_firstH[i] = h[i]; }      // the first accepted draw (:1878-1884)
+            }
+            Tsup += wall_clock64() - c0;
         }
-        const bool any_inc = kfirst < RB;
-        const int bsup = (int)(kb >> 8), bidx = RB - 1 - (int)(kb & 255u);
-        const bool new_best = any_inc && bsup > mx0;
-        const bool new_first = any_inc && first0 < 0;
-        if (new_best && tid == bidx) { for (int i = 0; i < 9; i++) s_bestH[i] = h[i]; }
-        if (new_first && tid == kfirst) { for (int i = 0; i < 9; i++) s_firstH[i] = h[i]; }
-        __syncthreads();                                   // everyone has read s_state / the masks
-        if (tid == 0) {
-            s_state[0] = t0 + nacc - ((kr < RB && kr == E) ? 1 : 0);     // the draw that ends the loop by its ratio is not counted
-            if (new_best) { s_state[1] = bsup; s_state[2] = base + bidx; }       // position in the accepted list: only its sign is used
-            if (new_first) s_state[3] = base + kfirst;
-            s_state[4] = fin;
+    }
+    __syncthreads();
+    // ---- the loop's bookkeeping over the stored supports, in list order: a draw replaces the best one when its support is strictly larger
+    // (and ends the loop at once when that support exceeds 0.99 n); the slot limit is the list's length (list_cap <= sample_times).  E = the
+    // last draw the loop looks at; the winner is the first draw <= E holding the maximum, if that is positive.
+    {
+        const int lane = tid & 63, wv = tid >> 6;
+        int run = 0;                                          // maximum over the blocks before this one
+        unsigned bestkey = 0;
+        bool stopped = false;
+        for (int b0 = 0; b0 < nlist && !stopped; b0 += RB) {
+            const int i = b0 + tid;
+            const bool valid = i < nlist;
+            const int sv = valid ? (int)sup[i] : 0;
+            int v = sv;                                        // inclusive maximum scan over the wave
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(v, o, 64); if (lane >= o) v = t > v ? t : v; }
+            int ex = __shfl_up(v, 1, 64); if (lane == 0) ex = 0;
+            if (lane == 63) s_wtot[wv] = v;
+            __syncthreads();
+            int prev = run, blk = run;
+            for (int w = 0; w < RB / 64; w++) { const int t = s_wtot[w]; if (w < wv) prev = t > prev ? t : prev; blk = t > blk ? t : blk; }
+            ex = ex > prev ? ex : prev;                        // maximum of every earlier draw (0 before the first: :1783)
+            const unsigned long long m_r = __ballot(valid && sv > ex && (float)sv * invn > 0.99f);
+            if (lane == 0) s_mask[0][wv] = m_r;
+            __syncthreads();
+            int kr = RB;
+            for (int w = 0; w < RB / 64; w++) { const unsigned long long m = s_mask[0][w]; if (m && kr == RB) kr = 64 * w + (int)__builtin_ctzll(m); }
+            int E = b0 + RB - 1;
+            if (kr < RB) { E = b0 + kr; stopped = true; }
+            unsigned key = (valid && i <= E) ? (((unsigned)sv << 13) | (unsigned)(8191 - i)) : 0u;      // i <= 4998 < 2^13, support < 2^16
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) { const unsigned t = __shfl_xor(key, o, 64); key = t > key ? t : key; }
+            if (lane == 0) s_wkey[wv] = key;
+            __syncthreads();
+            for (int w = 0; w < RB / 64; w++) bestkey = s_wkey[w] > bestkey ? s_wkey[w] : bestkey;
+            run = blk;
+            __syncthreads();                                   // s_wtot / s_mask / s_wkey are rewritten by the next block
+        }
+        const int M = (int)(bestkey >> 13), win = 8191 - (int)(bestkey & 8191u);
+        if (tid == 0) { s_state[2] = M > 0 ? win : -1; s_state[5] = 0; }
+        __syncthreads();
+        if (M > 0) {
+            if (my_li == win) { for (int i = 0; i < 9; i++) s_bestH[i] = hb[i * RB + tid]; s_state[5] = 1; }
+            __syncthreads();
+            if (!s_state[5]) {
+                // the lane that evaluated the winner went on to a larger support behind a stop: the winner's hypothesis is formed again (same
+                // operations, same bits) by one lane
+                if (tid == 0) {
+                    const int r = list[win];
+                    float p[16];
+                    const uint16_t* sx = table + 4 * r;
+                    for (int i = 0; i < 4; i++) { const int k = sx[i]; p[4 * i] = x1[k]; p[4 * i + 1] = y1[k]; p[4 * i + 2] = x2[k]; p[4 * i + 3] = y2[k]; }
+                    int pol = 0;
+                    float hh[9];
+                    if (!hm::hypothesis4_fast(p, hh, &pol)) (void)generic_hypothesis(p, hh, s_fbk[0]);
+                    for (int i = 0; i < 9; i++) s_bestH[i] = hh[i];
+                }
+            }
         }
         __syncthreads();
-        Trep += wall_clock64() - c2;
-        if (fin) break;
     }
     long long T1 = wall_clock64();
     // winner: hyp[maxSupportIndex]; maxSupportIndex stays 0 when no support was ever positive (:1783) -> first accepted
@@ -632,15 +665,17 @@ int mi_ransac_big(mi355_ctx* ctx, const mi355_sfpoint* p1, const mi355_sfpoint* 
     a.stride = n; a.dist = dist; a.sample_times = sample_times; a.min_keep = -1; a.out = dres.as<mi355_pair_result>();
     a.big_ws = dws.as<float>(); a.big_a = da.as<mi355_sfpoint>(); a.big_b = db.as<mi355_sfpoint>();
     a.single_table = 1;                                   // the one uploaded table, not table n - 4 of a set
-    a.list_floats = ((((sample_times < MAX_DRAWS ? (sample_times > 0 ? sample_times : 1) : MAX_DRAWS) * 2 + 15) / 16) * 16) / 4;
+    a.list_floats = (((sample_times < MAX_DRAWS ? (sample_times > 0 ? sample_times : 1) : MAX_DRAWS) + 7) / 8) * 8;      // uint16 list + uint16 supports
     if (n > RANSAC_LDS_POINTS) {                          // the points do not fit the LDS: HBM (ransac_huge_kernel)
         DevBuf& dpts = ctx->buf("rbig_pts");
         MI_HIP(dpts.reserve(sizeof(float) * 4 * (size_t)n));
         a.big_pts = dpts.as<float>();
-        const size_t lds_bytes = (size_t)a.list_floats * sizeof(float);
+        a.hb_off = a.list_floats;
+        const size_t lds_bytes = ((size_t)a.list_floats + 9 * RB) * sizeof(float);
         hipLaunchKernelGGL(ransac_huge_kernel, dim3(1), dim3(RB), lds_bytes, ctx->stream, a);
     } else {
-        const size_t lds_bytes = ((size_t)4 * n + a.list_floats) * sizeof(float);
+        a.hb_off = a.list_floats + 4 * n;
+        const size_t lds_bytes = ((size_t)4 * n + a.list_floats + 9 * RB) * sizeof(float);
         MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ransac_big_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
         hipLaunchKernelGGL(ransac_big_kernel, dim3(1), dim3(RB), lds_bytes, ctx->stream, a);
     }
@@ -736,8 +771,12 @@ int mi_ransac_batch(mi355_ctx* ctx, const mi355_sfpoint* d_p1, const mi355_sfpoi
     DevBuf& ddbg = ctx->buf("ransac_dbg");
     if (dbg_on) { MI_HIP(ddbg.reserve((size_t)n_pairs * 64)); MI_HIP(hipMemsetAsync(ddbg.p, 0, (size_t)n_pairs * 64, ctx->stream)); a.dbg = ddbg.as<long long>(); }
     a.stride = stride; a.dist = dist; a.sample_times = sample_times; a.out = d_out;
-    a.list_floats = ((((sample_times < MAX_DRAWS ? (sample_times > 0 ? sample_times : 1) : MAX_DRAWS) * 2 + 15) / 16) * 16) / 4;
-    const size_t lds_bytes = ((size_t)38 * nmax + a.list_floats) * sizeof(float);
+    a.list_floats = (((sample_times < MAX_DRAWS ? (sample_times > 0 ? sample_times : 1) : MAX_DRAWS) + 7) / 8) * 8;      // uint16 list + uint16 supports
+    // the lanes' best hypotheses (9 x RB floats) lie at the end of the allocation, where J* and C are kept after the draw loop (points + their
+    // float4 copy take the first 8 n floats)
+    const size_t body_floats = (size_t)38 * nmax > (size_t)8 * nmax + 9 * RB ? (size_t)38 * nmax : (size_t)8 * nmax + 9 * RB;
+    a.hb_off = (int)(a.list_floats + body_floats - 9 * RB);
+    const size_t lds_bytes = (body_floats + a.list_floats) * sizeof(float);
     if (lds_bytes > 48 * 1024) {
         MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ransac_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     }
