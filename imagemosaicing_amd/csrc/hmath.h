@@ -470,6 +470,23 @@ __host__ __device__ __attribute__((noinline)) inline int inverse8_pivot(const fl
     return 0;
 }
 
+// The same sparse elimination with true divisions, out of line (its own registers): where the shared-reciprocal form leaves its guarded
+// range (state 3) the result is formed again this way -- it is the host / reference form of the very same plan -- and only a pivot below the
+// diagonal (state 2) still goes to the generic routine.  A draw that leaves the guard does so in every one of its 15 Gauss-Newton steps:
+// through inverse8_pivot (~2000 ticks per call) such a draw held its wave for 30 000 ticks, a quarter of all pairs have one.
+__host__ __device__ __attribute__((noinline)) inline int inverse8_sparse_exact(const float* src, float* dst, float eps) {
+    return inverse8_sparse<false>(src, dst, eps);
+}
+HD int exact_call(const float* M, float* inv, float eps) {
+    float in[64], out[64];
+#pragma unroll
+    for (int i = 0; i < 64; i++) { in[i] = M[i]; out[i] = inv[i]; }
+    const int st = inverse8_sparse_exact(in, out, eps);
+#pragma unroll
+    for (int i = 0; i < 64; i++) inv[i] = out[i];
+    return st;
+}
+
 HD void pivot_call(const float* M, float* inv, float eps) {
     float in[64], out[64];
 #pragma unroll
@@ -517,7 +534,11 @@ HD bool hypothesis4_fast(const float* p, float* H, int* polished = nullptr) {
 #pragma unroll
     for (int i = 0; i < 64; i++) inv[i] = 0.0f;                   // a failed inversion leaves the zeros (matrix.h:377)
 #if defined(__HIP_DEVICE_COMPILE__)
-    if (inverse8_sparse<true>(M, inv, 1e-20f) >= 2) pivot_call(M, inv, 1e-20f);      // 2: pivot search below the diagonal, 3: division guard
+    {
+        int st = inverse8_sparse<true>(M, inv, 1e-20f);
+        if (st == 3) st = exact_call(M, inv, 1e-20f);            // division guard: the same plan with true divisions
+        if (st == 2) pivot_call(M, inv, 1e-20f);                 // pivot search below the diagonal
+    }
 #else
     if (inverse8_sparse(M, inv, 1e-20f) == 2) pivot_call(M, inv, 1e-20f);
 #endif
@@ -581,8 +602,9 @@ HD bool hypothesis4_fast(const float* p, float* H, int* polished = nullptr) {
 #if defined(__HIP_DEVICE_COMPILE__)
         if (!jacobian(std::true_type{})) { jacobian(std::false_type{}); if (polished) *polished |= 2; }   // (rare) a division outside the guarded range: true divisions
         if (!jtj_sparse(A, M)) return false;
-        const int inv_state = inverse8_sparse<true>(M, inv, 1e-6f);    // 1: no pivot, the previous iteration's inverse stays (zeros before the first)
-        if (inv_state >= 2) { pivot_call(M, inv, 1e-6f); if (polished && inv_state == 3) *polished |= 4; }      // 2: pivot search below the diagonal, 3: guard
+        int inv_state = inverse8_sparse<true>(M, inv, 1e-6f);    // 1: no pivot, the previous iteration's inverse stays (zeros before the first)
+        if (inv_state == 3) { if (polished) *polished |= 4; inv_state = exact_call(M, inv, 1e-6f); }      // 3: division guard -> the same plan with true divisions
+        if (inv_state == 2) pivot_call(M, inv, 1e-6f);                                                    // 2: pivot search below the diagonal
 #else
         jacobian(std::false_type{});
         if (!jtj_sparse(A, M)) return false;
