@@ -118,7 +118,7 @@ struct mi355_ctx {
     void set_error(const std::string& s) { err = s; }
     DevBuf& buf(const std::string& name) { return ws[name]; }
     std::vector<int> deferred_dims;                    // per prepared entry: launch extent (groups of 4 columns, rows)
-    std::vector<unsigned char> deferred_warps;         // warp.hip: the chips' warp arguments when mi_chips_and_masks_dev was asked to leave the pixels to mi_chip_pixels_window
+    std::vector<unsigned char> deferred_warps;         // warp.hip: the chips' warp arguments when mi_chips_and_masks_dev was asked to leave the pixels to mi_chip_pixels_prepare / _launch
     // profiling brackets
     void prof_begin(const char* cls, double alg_bytes, hipStream_t st);
     void prof_end(const char* cls, hipStream_t st);

@@ -679,7 +679,7 @@ int mi_chips_and_masks_dev(mi355_ctx* ctx, const uint8_t* const* imgs, const int
     MI_HIP(dchips.reserve(chip_total + 16));
     MI_HIP(dmasks.reserve(mask_total + 16));
     // defer_pixels (the one-call blend): every mask byte of a chip's columns is written by the validity pass, the pixels later and only
-    // inside the chip's active window (mi_chip_pixels_window); row padding is never read there, so nothing is cleared
+    // inside the chip's active window (mi_chip_pixels_prepare / _launch); row padding is never read there, so nothing is cleared
     if (!defer_pixels) {
         MI_HIP(hipMemsetAsync(dchips.p, 0, chip_total, ctx->stream));
         MI_HIP(hipMemsetAsync(dmasks.p, 0, mask_total, ctx->stream));
