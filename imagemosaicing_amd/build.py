@@ -32,10 +32,11 @@ def sources():
 
 
 GEN = os.path.join(CSRC, "gen_blur16_asm.py")          # writes blur16_asm.inc (the hand-scheduled row loop of blur16_stream)
-INC = os.path.join(CSRC, "blur16_asm.inc")
+INC = os.path.join(OBJ, "blur16_asm.inc")              # generated text lives with the objects (the source directory stays as checked out); found through -I
 
 
 def generate():
+    os.makedirs(OBJ, exist_ok=True)
     if not os.path.exists(INC) or os.path.getmtime(INC) < os.path.getmtime(GEN):
         out = subprocess.run([sys.executable, GEN], capture_output=True, text=True, check=True).stdout
         with open(INC, "w") as f:
@@ -43,7 +44,9 @@ def generate():
 
 
 def headers():
-    hs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".inc"))]
+    hs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    if os.path.exists(INC):
+        hs.append(INC)
     hs.append(os.path.join(os.path.dirname(HERE), "include", "mi355_mosaic.h"))
     return hs
 
@@ -60,7 +63,7 @@ def compile_one(src):
     newest = max(os.path.getmtime(p) for p in [src] + headers())
     if os.path.exists(obj) and os.path.getmtime(obj) > newest:
         return obj
-    cmd = [HIPCC] + FLAGS + PER_FILE.get(os.path.basename(src), []) + (["-x", "hip"] if src.endswith(".hip") else []) + ["-c", src, "-o", obj]
+    cmd = [HIPCC] + FLAGS + ["-I", OBJ] + PER_FILE.get(os.path.basename(src), []) + (["-x", "hip"] if src.endswith(".hip") else []) + ["-c", src, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, r.stdout, r.stderr))

@@ -412,7 +412,7 @@ class Context:
         return buf, ow.value, oh.value, ows.value
 
 
-    def MosaicBlendedDev(self, d_ptrs, w, h, ws, h9s, keep=None, band=5):
+    def MosaicBlendedDev(self, d_ptrs, w, h, ws, h9s, keep=None, band=5, row0=0, rows=-1):
         """LaplacianPyramidBlending with the survey resident in HBM: device frames in, device canvas out (a torch uint8 tensor
         [ch, cws]); chips, masks and the blender's pyramids stay in the ctx's buffers.
         Ordering: the library writes the canvas on the ctx's stream, the tensor comes from torch's allocator (torch's current stream).  The
@@ -425,6 +425,14 @@ class Context:
         h9s = np.ascontiguousarray(h9s, np.float32)
         keep_a = None if keep is None else np.ascontiguousarray(keep, np.uint8)
         cw, ch, cws = blend_layout(w, h, h9s, keep_a)
+        if rows >= 0:
+            # one stripe of the canvas (a rank's share): the tensor holds the rows row0 .. row0 + rows - 1; cw, ch, cws stay the whole canvas's
+            out = torch.empty((rows, cws), dtype=torch.uint8, device=torch.device("cuda", self.device))
+            torch.cuda.current_stream(out.device).synchronize()
+            self._chk(self.L.mi355_mosaic_blended_rows_dev(self._h, ptrs, _p(w), _p(h), _p(ws), n, _p(h9s), _p(keep_a), int(band),
+                                                           C.c_void_p(out.data_ptr()), cw, ch, cws, int(row0), int(rows)))
+            self.synchronize()
+            return out, cw, ch, cws
         out = torch.empty((ch, cws), dtype=torch.uint8, device=torch.device("cuda", self.device))
         torch.cuda.current_stream(out.device).synchronize()
         self._chk(self.L.mi355_mosaic_blended_dev(self._h, ptrs, _p(w), _p(h), _p(ws), n, _p(h9s), _p(keep_a), int(band),

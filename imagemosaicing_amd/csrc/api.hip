@@ -58,6 +58,11 @@ extern "C" int mi355_create(mi355_ctx** out, const mi355_params* params, int dev
     if (const char* e = getenv("MI355_BLUR_STREAM")) c->blur_stream = atoi(e) ? 1 : 0;
     if (const char* e = getenv("MI355_CASCADE")) { const int v = atoi(e); c->cascade = v < 0 ? 0 : (v > 3 ? 3 : v); }
     if (getenv("MI355_SERIAL_HEAVY")) c->serial_heavy = 1;
+    {
+        struct { const char* n; int* p; } knobs[] = {{"MI355_SIFT_SPLIT", &c->sift_split}, {"MI355_SIFT_PRIO", &c->sift_prio}, {"MI355_SIFT_ONE_HEAVY", &c->sift_one_heavy},
+            {"MI355_TAIL_CUS", &c->tail_cus}, {"MI355_HEAVY_EXCL", &c->heavy_excl}, {"MI355_STREAM_WAVES_SMALL", &c->stream_waves_small}, {"MI355_STREAM_WAVES_BIG", &c->stream_waves_big}, {"MI355_XWAVES", &c->xwaves}, {"MI355_RANSAC_SPLIT", &c->ransac_split}};
+        for (auto& k : knobs) if (const char* e = getenv(k.n)) *k.p = atoi(e);
+    }
     if (const char* e = getenv("MI355_SIFT_SLOTS")) { const int v = atoi(e); c->sift_nslots = v < 1 ? 1 : (v > 4 ? 4 : v); }
     if (const char* e = getenv("MI355_XSTREAM_MIN_W")) { const int v = atoi(e); c->xstream_min_w = v < 256 ? 256 : v; }
     if (const char* e = getenv("MI355_SIFT_BATCH")) { const int v = atoi(e); c->sift_batch = v < 1 ? 1 : (v > 32 ? 32 : v); }
@@ -329,6 +334,13 @@ extern "C" int mi355_mosaic_blended_dev(mi355_ctx* ctx, const uint8_t* const* d_
     return mi_mosaic_blended_dev(ctx, d_imgs, w, h, ws, n, h9s, keep, band, d_canvas, cw, ch, cws);
 }
 
+extern "C" int mi355_mosaic_blended_rows_dev(mi355_ctx* ctx, const uint8_t* const* d_imgs, const int* w, const int* h, const int* ws, int n, const float* h9s,
+                                             const uint8_t* keep, int band, uint8_t* d_rows, int cw, int ch, int cws, int row0, int rows) {
+    LOCKED_PROLOGUE
+    if (rows < 1) { ctx->set_error("mosaic_blended_rows_dev: bad stripe"); return MI355_ERR_ARG; }
+    return mi_mosaic_blended_dev(ctx, d_imgs, w, h, ws, n, h9s, keep, band, d_rows, cw, ch, cws, row0, rows);
+}
+
 extern "C" int mi355_blend_layout(const int* w, const int* h, int n, const float* h9s, const uint8_t* keep, int* cw, int* ch, int* cws) {
     if (!cw || !ch) return MI355_ERR_ARG;
     const int rc = mi_blend_layout(w, h, n, h9s, keep, cw, ch);
@@ -362,6 +374,12 @@ extern "C" int mi355_set_option(mi355_ctx* ctx, const char* name, int value) {
         if (rc != MI355_OK) return rc;
         ctx->sift_batch = value < 1 ? 1 : (value > 32 ? 32 : value);
         return MI355_OK;
+    }
+    {
+        // pipeline layout knobs: take effect for work areas created afterwards (set them before the first frame)
+        struct { const char* n; int* p; } knobs[] = {{"sift_split", &ctx->sift_split}, {"sift_prio", &ctx->sift_prio}, {"sift_one_heavy", &ctx->sift_one_heavy},
+            {"tail_cus", &ctx->tail_cus}, {"heavy_excl", &ctx->heavy_excl}, {"stream_waves_small", &ctx->stream_waves_small}, {"stream_waves_big", &ctx->stream_waves_big}, {"xwaves", &ctx->xwaves}, {"ransac_split", &ctx->ransac_split}};
+        for (auto& k : knobs) if (std::string(name) == k.n) { *k.p = value; return MI355_OK; }
     }
     if (std::string(name) == "blur_stream") { ctx->blur_stream = value ? 1 : 0; return MI355_OK; }
     if (std::string(name) == "sift_cascade") { ctx->cascade = value < 0 ? 0 : (value > 3 ? 3 : value); return MI355_OK; }

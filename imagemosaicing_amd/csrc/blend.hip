@@ -250,8 +250,8 @@ __device__ __forceinline__ void up_h_pair(const short* row, int w, int x, int* h
 
 // fine = sat16(fine - EXPAND(coarse)) (SUB) or sat16(EXPAND(coarse) + fine); coarse is w x h, fine 2w x 2h
 template <bool SUB>
-__global__ __launch_bounds__(256) void pyr_up16_combine_kernel(const short* coarse, int w, int h, short* fine) {
-    const int X = blockIdx.x * 256 + threadIdx.x, Y = blockIdx.y;
+__global__ __launch_bounds__(256) void pyr_up16_combine_kernel(const short* coarse, int w, int h, short* fine, int Y0 = 0) {
+    const int X = blockIdx.x * 256 + threadIdx.x, Y = Y0 + blockIdx.y;      // fine rows Y0 .. Y0 + gridDim.y - 1
     if (X >= 2 * w) return;
     const int y = Y >> 1;
     const int ym = (y == 0) ? (h > 1 ? 1 : 0) : y - 1, yp = (y == h - 1) ? h - 1 : y + 1;
@@ -338,7 +338,8 @@ struct LapLevels {
     int row0[MAX_BANDS + 1];                 // first grid row of entry i (row0[n] = grid rows)
     int w[MAX_BANDS], h[MAX_BANDS], ox[MAX_BANDS], oy[MAX_BANDS], DW[MAX_BANDS];
     int x0[MAX_BANDS], y0[MAX_BANDS], x1[MAX_BANDS];     // first thread column / row and last thread column of the entry's active window
-    size_t fine[MAX_BANDS], coarse[MAX_BANDS], dst[MAX_BANDS];      // pixel offsets into the chip pyramid (g / wp) and the canvas pyramids (dl / dw)
+    size_t fine[MAX_BANDS], coarse[MAX_BANDS];      // pixel offsets into the chip pyramid (g / wp)
+    long long dst[MAX_BANDS];                       // ... and into the canvas pyramids (dl / dw): may be negative for a stripe (the level's rows above the stripe are not stored)
 };
 __global__ __launch_bounds__(256) void blend_lap_levels_kernel(LapLevels L, const short* g, const float* wp, short* dl, float* dw) {
     int i = 0;
@@ -354,7 +355,7 @@ __global__ __launch_bounds__(256) void blend_lap_levels_kernel(LapLevels L, cons
         if (x >= lw || x > L.x1[i]) return;
         const float wv = wp[L.fine[i] + (size_t)y * lw + x];
         if (wv == 0.0f && !__builtin_signbit(wv)) return;      // adds nothing (see blend_lap_accumulate_body)
-        const size_t di = L.dst[i] + (size_t)(L.oy[i] + y) * L.DW[i] + (L.ox[i] + x);
+        const long long di = L.dst[i] + (long long)(L.oy[i] + y) * L.DW[i] + (L.ox[i] + x);
         const short* s = g + (L.fine[i] + (size_t)y * lw + x) * 3;
 #pragma unroll
         for (int c = 0; c < 3; c++) dl[di * 3 + c] = (short)(dl[di * 3 + c] + (short)((float)s[c] * wv));
@@ -371,7 +372,7 @@ __global__ __launch_bounds__(256) void blend_lap_levels_kernel(LapLevels L, cons
 __device__ __forceinline__ void blend_lap0_body(const ChipP& c, const short* coarse, int ox, int oy, short* dl, float* dw, int DW) {
     const int w = c.rw >> 1, h = c.rh >> 1;
     const int x = c.twin[0].x0 + blockIdx.x * 256 + threadIdx.x, y = c.twin[0].y0 + blockIdx.y;
-    if (x >= w || x > c.twin[0].x1) return;
+    if (x >= w || x > c.twin[0].x1 || y > c.twin[0].y1) return;      // (the rows matter: a stripe's canvas pyramids hold the stripe's rows only)
     const int cx = 2 * x - c.left;                            // chip column of the even fine pixel
     const bool xfast = cx >= 0 && cx + 3 < c.cw;              // both columns inside the chip and the 8-byte read inside the row
     {
@@ -483,11 +484,11 @@ __global__ __launch_bounds__(256) void blend_normalize_kernel(short* dl, const f
     for (int c = 0; c < 3; c++) dl[i * 3 + c] = (short)((float)dl[i * 3 + c] / d);
 }
 
-__global__ __launch_bounds__(256) void blend_finalize_kernel(const short* dl, const float* dw, int Wp, int W, uint8_t* out, int ows) {
-    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+__global__ __launch_bounds__(256) void blend_finalize_kernel(const short* dl, const float* dw, int Wp, int W, uint8_t* out, int ows, int row0 = 0) {
+    const int x = blockIdx.x * 256 + threadIdx.x, y = row0 + blockIdx.y;      // canvas row; `out` starts at canvas row row0
     if (x >= W) return;
     const size_t di = (size_t)y * Wp + x;
-    uint8_t* o = out + (size_t)y * ows + 3 * x;
+    uint8_t* o = out + (size_t)blockIdx.y * ows + 3 * x;
     if (!(dw[di] > 1e-5f)) { o[0] = 0; o[1] = 0; o[2] = 0; return; }
 #pragma unroll
     for (int c = 0; c < 3; c++) { const int v = dl[di * 3 + c]; o[c] = (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v)); }
@@ -505,38 +506,55 @@ inline dim3 grid2(int w, int h) { return dim3((unsigned)((w + 255) / 256), (unsi
 //   C_l    what is computed of level l >= 1: F_l, E_l and the inputs of the REDUCE that forms C_l+1 ([2a - 2, 2b + 2]).
 // Everything outside C_l stays unwritten in the batch's pyramid buffers and is never read (the pair kernels' second output may be formed
 // from such pixels when C_l+1 starts at an odd column; it lies outside C_l+1 and is never read either).
-void chip_windows(ChipP& c, int nb, const int* bb) {
+// nlo / nhi (not NULL: a stripe of the canvas is blended): per level the canvas rows whose pyramid values the stripe's output depends on; the
+// accumulation windows are cut to them, a level whose window is empty then has y1 < y0 (and adds nothing to F / E / C).  Returns false when
+// no level of the chip is left: the chip adds nothing to the stripe.
+bool chip_windows(ChipP& c, int nb, const int* bb, const int* nlo = nullptr, const int* nhi = nullptr) {
     const int L = nb < MAX_BANDS ? nb : MAX_BANDS;
     if (!bb || nb > MAX_BANDS) {
         for (int l = 0; l <= L; l++) {
             c.cwin[l] = Win{0, 0, (c.rw >> l) - 1, (c.rh >> l) - 1};
             c.twin[l] = l < nb ? Win{0, 0, (c.rw >> (l + 1)) - 1, (c.rh >> (l + 1)) - 1} : c.cwin[l];
         }
-        return;
+        return true;
     }
+    bool any = false;
     for (int axis = 0; axis < 2; axis++) {
         const int dim = axis ? c.rh : c.rw, off = axis ? c.top : c.left;
         int Sa[MAX_BANDS + 1], Sb[MAX_BANDS + 1], Ta[MAX_BANDS + 1], Tb[MAX_BANDS + 1], Fa[MAX_BANDS + 1], Fb[MAX_BANDS + 1], Ea[MAX_BANDS + 2], Eb[MAX_BANDS + 2];
-        int Ca[MAX_BANDS + 1], Cb[MAX_BANDS + 1];
+        int Ca[MAX_BANDS + 2], Cb[MAX_BANDS + 2];
         auto clip = [](int& a, int& b, int n) { if (a < 0) a = 0; if (b > n - 1) b = n - 1; if (a > b) { a = a < n ? a : n - 1; b = a; } };
+        auto uni = [](int& a, int& b, int a2, int b2) { if (a2 > b2) return; if (a > b) { a = a2; b = b2; return; } a = a2 < a ? a2 : a; b = b2 > b ? b2 : b; };
         Sa[0] = bb[axis] + off; Sb[0] = bb[2 + axis] + off;
         clip(Sa[0], Sb[0], dim);
         for (int l = 0; l < nb; l++) {
             Sa[l + 1] = ((Sa[l] - 2) >> 1) - 1; Sb[l + 1] = ((Sb[l] + 2) >> 1) + 1;
             clip(Sa[l + 1], Sb[l + 1], dim >> (l + 1));
         }
-        Ea[0] = 0; Eb[0] = -1;
+        for (int l = 0; l <= nb + 1; l++) { Ea[l] = 0; Eb[l] = -1; }
         for (int l = 0; l <= nb; l++) {
+            if (l < nb) { Ta[l] = Sa[l] >> 1; Tb[l] = Sb[l] >> 1; } else { Ta[l] = Sa[l]; Tb[l] = Sb[l]; }
+            if (axis == 1 && nlo) {
+                // the threads whose canvas rows meet nlo[l] .. nhi[l]: thread t covers the level's rows 2t, 2t + 1 below the top level
+                const int oy = c.tly >> l, lo = nlo[l] - oy, hi = nhi[l] - oy;
+                const int ta = l < nb ? (lo >= 1 ? lo >> 1 : 0) : (lo > 0 ? lo : 0), tb = l < nb ? (hi >= 0 ? hi >> 1 : -1) : hi;
+                if (ta > Ta[l]) Ta[l] = ta;
+                if (tb < Tb[l]) Tb[l] = tb;
+            }
+            if (Ta[l] > Tb[l]) { Ta[l] = 0; Tb[l] = -1; Fa[l] = 0; Fb[l] = -1; continue; }
+            if (axis == 1) any = true;
             if (l < nb) {
-                Ta[l] = Sa[l] >> 1; Tb[l] = Sb[l] >> 1; Fa[l] = 2 * Ta[l]; Fb[l] = 2 * Tb[l] + 1;
+                Fa[l] = 2 * Ta[l]; Fb[l] = 2 * Tb[l] + 1;
                 Ea[l + 1] = Ta[l] - 1; Eb[l + 1] = Tb[l] + 1;
                 clip(Ea[l + 1], Eb[l + 1], dim >> (l + 1));
-            } else { Ta[l] = Sa[l]; Tb[l] = Sb[l]; Fa[l] = Sa[l]; Fb[l] = Sb[l]; }
+            } else { Fa[l] = Ta[l]; Fb[l] = Tb[l]; }
         }
+        Ca[nb + 1] = 0; Cb[nb + 1] = -1;
         for (int l = nb; l >= 1; l--) {
-            int a = Fa[l] < Ea[l] ? Fa[l] : Ea[l], b = Fb[l] > Eb[l] ? Fb[l] : Eb[l];
-            if (l < nb) { const int ra = 2 * Ca[l + 1] - 2, rb = 2 * Cb[l + 1] + 2; a = ra < a ? ra : a; b = rb > b ? rb : b; }
-            clip(a, b, dim >> l);
+            int a = 0, b = -1;
+            uni(a, b, Fa[l], Fb[l]); uni(a, b, Ea[l], Eb[l]);
+            if (l < nb && Ca[l + 1] <= Cb[l + 1]) uni(a, b, 2 * Ca[l + 1] - 2, 2 * Cb[l + 1] + 2);
+            if (a <= b) clip(a, b, dim >> l);
             Ca[l] = a; Cb[l] = b;
         }
         Ca[0] = 0; Cb[0] = dim - 1;
@@ -545,6 +563,7 @@ void chip_windows(ChipP& c, int nb, const int* bb) {
             else           { c.cwin[l].y0 = Ca[l]; c.cwin[l].y1 = Cb[l]; c.twin[l].y0 = Ta[l]; c.twin[l].y1 = Tb[l]; }
         }
     }
+    return any;
 }
 
 }  // namespace
@@ -557,7 +576,10 @@ static void chip_pixel_window(const ChipP& c, int& x0, int& y0, int& x1, int& y1
         const int rdim = axis ? c.rh : c.rw, cdim = axis ? c.ch : c.cw, off = axis ? c.top : c.left;
         const int ta = axis ? c.twin[0].y0 : c.twin[0].x0, tb = axis ? c.twin[0].y1 : c.twin[0].x1;
         int ca = axis ? c.cwin[1].y0 : (c.cwin[1].x0 & ~1), cb = axis ? c.cwin[1].y1 : (c.cwin[1].x1 | 1);
-        int a = 2 * ta < 2 * ca - 2 ? 2 * ta : 2 * ca - 2, b = 2 * tb + 1 > 2 * cb + 2 ? 2 * tb + 1 : 2 * cb + 2;
+        int a = 0, b = -1;                                    // (a stripe may leave either window empty: y1 < y0)
+        if (ta <= tb) { a = 2 * ta; b = 2 * tb + 1; }
+        if (ca <= cb) { if (a > b) { a = 2 * ca - 2; b = 2 * cb + 2; } else { a = a < 2 * ca - 2 ? a : 2 * ca - 2; b = b > 2 * cb + 2 ? b : 2 * cb + 2; } }
+        if (a > b) { if (axis == 0) { x0 = 0; x1 = -1; } else { y0 = 0; y1 = -1; } continue; }
         if (a < 0) { b = b > -a ? b : -a; a = 0; }
         if (b > rdim - 1) { const int m = 2 * (rdim - 1) - b; a = a < m ? a : m; b = rdim - 1; }
         if (a < 0) a = 0;
@@ -571,14 +593,44 @@ static void chip_pixel_window(const ChipP& c, int& x0, int& y0, int& x1, int& y1
 }
 
 // chips / masks: host pointers (staged one chip at a time) when on_device == 0, device pointers otherwise
+// The canvas rows of every pyramid level that the output rows row0 .. row0 + rows - 1 depend on (a stripe of the canvas: one rank's part of
+// LaplacianPyramidBlending).  The collapse forms level l from its Laplacian and EXPAND of level l + 1: fine row Y reads the coarse rows
+// (Y >> 1) - 1 .. (Y >> 1) + 1, so N_0 = the stripe, N_l+1 = [(a >> 1) - 1, (b >> 1) + 1]; below the top level the ranges are widened to whole
+// 2 x 2 blocks (the accumulation's threads).  Everything a rank forms is what the whole canvas holds there: the canvas geometry (padded
+// size, level count, the chips' regions) is the full canvas's, only rows are left out.
+static void stripe_levels(int row0, int rows, int nb, int Hp, std::vector<int>& nlo, std::vector<int>& nhi) {
+    nlo.assign(nb + 1, 0); nhi.assign(nb + 1, 0);
+    nlo[0] = row0; nhi[0] = row0 + rows - 1;
+    for (int l = 0; l <= nb; l++) {
+        const int hl = Hp >> l;
+        if (l > 0) { nlo[l] = (nlo[l - 1] >> 1) - 1; nhi[l] = (nhi[l - 1] >> 1) + 1; }
+        if (l < nb) { nlo[l] &= ~1; nhi[l] |= 1; }
+        if (nlo[l] < 0) nlo[l] = 0;
+        if (nhi[l] > hl - 1) nhi[l] = hl - 1;
+    }
+}
+// ... and the canvas rows whose ownership (FindMasksByDistMap) those values can depend on: a level-l value sees 2^l q -+ (2^(l+1) - 2) rows of
+// level 0 through its l REDUCE steps, its Laplacian one more level; 8 * 2^l on either side covers both with room to spare
+static void stripe_mask_rows(const std::vector<int>& nlo, const std::vector<int>& nhi, int H, int& r0, int& r1) {
+    r0 = nlo[0]; r1 = nhi[0];
+    for (size_t l = 0; l < nlo.size(); l++) {
+        const long long a = ((long long)nlo[l] << l) - (8ll << l), b = (((long long)nhi[l] + 1) << l) - 1 + (8ll << l);
+        if (a < r0) r0 = a < 0 ? 0 : (int)a;
+        if (b > r1) r1 = b > H - 1 ? H - 1 : (int)b;
+    }
+    if (r1 > H - 1) r1 = H - 1;
+}
+
+// chips / masks: host pointers (staged one chip at a time) when on_device == 0, device pointers otherwise
 static int blend_core(mi355_ctx* ctx, const uint8_t* const* chips, const uint8_t* const* masks, int on_device, const mi355_chip_info* info, int n,
                       int W, int H, int band, uint8_t** out, int* ow, int* oh, int* ows_out, uint8_t* d_user = nullptr, int user_ws = 0,
-                      const int* owned_bbox = nullptr, int deferred_pixels = 0) {
+                      const int* owned_bbox = nullptr, int deferred_pixels = 0, int row0 = 0, int rows = -1) {
     // deferred_pixels: the chips hold no pixels yet (mi_chips_and_masks_dev(.., defer_pixels)): each chip's are made here, inside the part
     // of the chip its active windows read (chip_pixel_window)
     // owned_bbox != NULL (the masks are FindMasksByDistMap's, made on this device): per chip the box of its non-zero mask bytes -- a chip
     // that owns nothing is left out, the others work inside their active windows (chip_windows)
     // d_user != NULL: the finished canvas goes to the caller's device buffer (rows of user_ws bytes) and nothing is copied to the host
+    // rows >= 0: only the canvas rows row0 .. row0 + rows - 1 are formed (d_user then starts at row row0); needs owned_bbox
     if (n < 0 || (n > 0 && (!chips || !masks || !info)) || W <= 0 || H <= 0 || band < 0 || (!out && !d_user)) { ctx->set_error("multiband_blend: bad arguments"); return MI355_ERR_ARG; }
     const hipStream_t st = ctx->stream;
     int nb = (int)std::ceil(std::log((double)(W > H ? W : H)) / std::log(2.0));
@@ -586,14 +638,26 @@ static int blend_core(mi355_ctx* ctx, const uint8_t* const* chips, const uint8_t
     if (nb < 0) nb = 0;
     const int al = 1 << nb;
     const int Wp = (W + al - 1) / al * al, Hp = (H + al - 1) / al * al;
-    std::vector<size_t> loff(nb + 2, 0);                         // level offsets in pixels inside one pyramid buffer
-    for (int l = 0; l <= nb; l++) loff[l + 1] = loff[l] + (size_t)(Wp >> l) * (Hp >> l);
+    const bool striped = rows >= 0 && !(row0 == 0 && rows == H);
+    if (striped && (row0 < 0 || rows < 1 || row0 + rows > H || !owned_bbox || !d_user || nb > MAX_BANDS || nb < 1)) { ctx->set_error("multiband_blend: bad stripe"); return MI355_ERR_ARG; }
+    if (!striped) { row0 = 0; rows = H; }
+    // rows of level l held by the canvas pyramids: all of them, or the stripe's (stripe_levels).  loff: level offsets in pixels inside one
+    // pyramid buffer; voff: the same minus the rows left out above the stripe, so that canvas coordinates index the buffers unchanged
+    std::vector<int> nlo(nb + 1, 0), nhi(nb + 1, 0);
+    for (int l = 0; l <= nb; l++) nhi[l] = (Hp >> l) - 1;
+    if (striped) stripe_levels(row0, rows, nb, Hp, nlo, nhi);
+    std::vector<size_t> loff(nb + 2, 0);
+    std::vector<long long> voff(nb + 1, 0);
+    for (int l = 0; l <= nb; l++) {
+        loff[l + 1] = loff[l] + (size_t)(Wp >> l) * (size_t)(nhi[l] - nlo[l] + 1);
+        voff[l] = (long long)loff[l] - (long long)nlo[l] * (Wp >> l);
+    }
     DevBuf& dlap = ctx->buf("blend_dst_lap");
     DevBuf& dwgt = ctx->buf("blend_dst_w");
     MI_HIP(dlap.reserve(loff[nb + 1] * 3 * sizeof(short)));
     MI_HIP(dwgt.reserve(loff[nb + 1] * sizeof(float)));
-    MI_HIP(hipMemsetAsync(dlap.p, 0, loff[nb + 1] * 3 * sizeof(short), st));
-    MI_HIP(hipMemsetAsync(dwgt.p, 0, loff[nb + 1] * sizeof(float), st));
+    auto vlap = [&](int l) { return dlap.as<short>() + voff[l] * 3; };      // level l of the canvas Laplacian / weight pyramid, addressed by canvas coordinates
+    auto vwgt = [&](int l) { return dwgt.as<float>() + voff[l]; };
     DevBuf& dchip = ctx->buf("blend_chip");
     DevBuf& dmask = ctx->buf("blend_mask");
     DevBuf& glap = ctx->buf("blend_src_lap");
@@ -622,7 +686,7 @@ static int blend_core(mi355_ctx* ctx, const uint8_t* const* chips, const uint8_t
         c.chip = chips[k]; c.mask = masks[k];
         c.cw = cw; c.ch = chh; c.cws = (cw * 3 + 3) & ~3; c.mws = (cw + 3) & ~3;
         c.left = x0 - tlx; c.top = y0 - tly; c.rw = rw; c.rh = rh; c.tlx = tlx; c.tly = tly;
-        chip_windows(c, nb, owned_bbox ? owned_bbox + 4 * k : nullptr);
+        if (!chip_windows(c, nb, owned_bbox ? owned_bbox + 4 * k : nullptr, striped ? nlo.data() : nullptr, striped ? nhi.data() : nullptr)) continue;      // nothing of it reaches the stripe
         par.push_back(c); geo.push_back({k, tlx, tly});
     }
     const int nc = (int)par.size();
@@ -664,7 +728,13 @@ static int blend_core(mi355_ctx* ctx, const uint8_t* const* chips, const uint8_t
         const int rc = mi_chip_pixels_prepare(ctx, nc, ids.data(), wins.data());
         if (rc != MI355_OK) return rc;
     }
-    if (on_device && nb > 0 && nc > 0) MI_HIP(hipMemcpyAsync(dpar.as<ChipP>(), par.data(), (size_t)nc * sizeof(ChipP), hipMemcpyHostToDevice, st));   // one copy, not one per batch
+    if (on_device && nb > 0 && nc > 0) {
+        MI_HIP(hipMemcpyAsync(dpar.as<ChipP>(), par.data(), (size_t)nc * sizeof(ChipP), hipMemcpyHostToDevice, st));   // one copy, not one per batch
+        MI_HIP(hipStreamSynchronize(st));      // `par` is a local and the device-canvas path returns without another wait: the copy must have read it (the stream holds little here: the stage before ended with a wait)
+    }
+    // the canvas pyramids start from zero (after the wait above, so that the host does not sit through them)
+    MI_HIP(hipMemsetAsync(dlap.p, 0, loff[nb + 1] * 3 * sizeof(short), st));
+    MI_HIP(hipMemsetAsync(dwgt.p, 0, loff[nb + 1] * sizeof(float), st));
     for (const Batch& bt : batches) {
         const int b0 = bt.b0, b1 = bt.b1, B = b1 - b0, maxw = bt.maxw, maxh = bt.maxh;
         if (!on_device) {
@@ -686,7 +756,7 @@ static int blend_core(mi355_ctx* ctx, const uint8_t* const* chips, const uint8_t
                 const ChipP& c = par[i];
                 hipLaunchKernelGGL(blend_prep_kernel, grid2(c.rw, c.rh), dim3(256), 0, st, c.chip, c.cws, c.mask, c.mws, c.cw, c.ch, c.left, c.top, c.rw, c.rh, g + c.tmp * 3, wp + c.tmp);
                 hipLaunchKernelGGL(blend_accumulate_kernel, grid2(c.rw, c.rh), dim3(256), 0, st, g + c.tmp * 3, wp + c.tmp, c.rw, c.rh, geo[i].tlx, geo[i].tly,
-                                   dlap.as<short>(), dwgt.as<float>(), Wp);
+                                   vlap(0), vwgt(0), Wp);
             }
             MI_HIP(hipGetLastError());
             continue;
@@ -714,7 +784,7 @@ static int blend_core(mi355_ctx* ctx, const uint8_t* const* chips, const uint8_t
         if (lap0_batched) {
             int tw = 1, th = 1;
             for (int i = b0; i < b1; i++) { const Win t = par[i].twin[0]; tw = t.x1 - t.x0 + 1 > tw ? t.x1 - t.x0 + 1 : tw; th = t.y1 - t.y0 + 1 > th ? t.y1 - t.y0 + 1 : th; }
-            hipLaunchKernelGGL(blend_lap0_accumulate_batch_kernel, dim3((unsigned)((tw + 255) / 256), (unsigned)th, (unsigned)B), dim3(256), 0, st, d_par, g, dlap.as<short>(), dwgt.as<float>(), Wp);
+            hipLaunchKernelGGL(blend_lap0_accumulate_batch_kernel, dim3((unsigned)((tw + 255) / 256), (unsigned)th, (unsigned)B), dim3(256), 0, st, d_par, g, vlap(0), vwgt(0), Wp);
         }
         // accumulation, chip after chip in chip order: Laplacian level l = Gaussian l - EXPAND(Gaussian l + 1), accumulated as it is formed
         for (int i = b0; i < b1; i++) {
@@ -723,53 +793,53 @@ static int blend_core(mi355_ctx* ctx, const uint8_t* const* chips, const uint8_t
             std::vector<size_t> roff(nb + 2, 0);                      // levels >= 1 behind c.tmp
             roff[1] = c.tmp;
             for (int l = 1; l < nb; l++) roff[l + 1] = roff[l] + (size_t)(rw >> l) * (rh >> l);
-            if (!lap0_batched)
+            if (!lap0_batched && c.twin[0].y1 >= c.twin[0].y0)
                 hipLaunchKernelGGL(blend_lap0_accumulate_kernel, grid2(c.twin[0].x1 - c.twin[0].x0 + 1, c.twin[0].y1 - c.twin[0].y0 + 1), dim3(256), 0, st, c, g + roff[1] * 3, tlx, tly,
-                                   dlap.as<short>(), dwgt.as<float>(), Wp);
+                                   vlap(0), vwgt(0), Wp);
             if (nb > MAX_BANDS) {                                             // (band > 16 on a canvas that allows it:) level by level
                 for (int l = 1; l < nb; l++)
                     hipLaunchKernelGGL(blend_lap_accumulate_kernel, grid2(rw >> (l + 1), rh >> (l + 1)), dim3(256), 0, st, g + roff[l + 1] * 3, rw >> (l + 1), rh >> (l + 1),
-                                       g + roff[l] * 3, wp + roff[l], tlx >> l, tly >> l, dlap.as<short>() + loff[l] * 3, dwgt.as<float>() + loff[l], Wp >> l);
+                                       g + roff[l] * 3, wp + roff[l], tlx >> l, tly >> l, vlap(l), vwgt(l), Wp >> l);
                 hipLaunchKernelGGL(blend_accumulate_kernel, grid2(rw >> nb, rh >> nb), dim3(256), 0, st, g + roff[nb] * 3, wp + roff[nb], rw >> nb, rh >> nb, tlx >> nb, tly >> nb,
-                                   dlap.as<short>() + loff[nb] * 3, dwgt.as<float>() + loff[nb], Wp >> nb);
+                                   vlap(nb), vwgt(nb), Wp >> nb);
                 continue;
             }
             LapLevels L; memset(&L, 0, sizeof(L));
-            int rows = 0, maxw = 0;
+            int grows = 0, maxw = 0;                                           // (an empty window -- a stripe -- has y1 = y0 - 1: no rows)
             for (int l = 1; l < nb; l++) {                                     // Laplacian level l: one thread per pixel of level l + 1
                 const int i = L.n++;
-                L.row0[i] = rows; L.w[i] = rw >> (l + 1); L.h[i] = rh >> (l + 1); L.ox[i] = tlx >> l; L.oy[i] = tly >> l; L.DW[i] = Wp >> l;
-                L.fine[i] = roff[l]; L.coarse[i] = roff[l + 1]; L.dst[i] = loff[l];
+                L.row0[i] = grows; L.w[i] = rw >> (l + 1); L.h[i] = rh >> (l + 1); L.ox[i] = tlx >> l; L.oy[i] = tly >> l; L.DW[i] = Wp >> l;
+                L.fine[i] = roff[l]; L.coarse[i] = roff[l + 1]; L.dst[i] = voff[l];
                 const Win t = c.twin[l];
                 L.x0[i] = t.x0; L.y0[i] = t.y0; L.x1[i] = t.x1;
-                rows += t.y1 - t.y0 + 1; maxw = t.x1 - t.x0 + 1 > maxw ? t.x1 - t.x0 + 1 : maxw;
+                grows += t.y1 - t.y0 + 1; maxw = t.x1 - t.x0 + 1 > maxw ? t.x1 - t.x0 + 1 : maxw;
             }
             {
                 const int i = L.n++;
-                L.row0[i] = rows; L.w[i] = rw >> nb; L.h[i] = rh >> nb; L.ox[i] = tlx >> nb; L.oy[i] = tly >> nb; L.DW[i] = Wp >> nb;
-                L.fine[i] = roff[nb]; L.coarse[i] = 0; L.dst[i] = loff[nb];
+                L.row0[i] = grows; L.w[i] = rw >> nb; L.h[i] = rh >> nb; L.ox[i] = tlx >> nb; L.oy[i] = tly >> nb; L.DW[i] = Wp >> nb;
+                L.fine[i] = roff[nb]; L.coarse[i] = 0; L.dst[i] = voff[nb];
                 const Win t = c.twin[nb];
                 L.x0[i] = t.x0; L.y0[i] = t.y0; L.x1[i] = t.x1;
-                rows += t.y1 - t.y0 + 1; maxw = t.x1 - t.x0 + 1 > maxw ? t.x1 - t.x0 + 1 : maxw;
+                grows += t.y1 - t.y0 + 1; maxw = t.x1 - t.x0 + 1 > maxw ? t.x1 - t.x0 + 1 : maxw;
             }
-            L.row0[L.n] = rows;
-            hipLaunchKernelGGL(blend_lap_levels_kernel, grid2(maxw, rows), dim3(256), 0, st, L, g, wp, dlap.as<short>(), dwgt.as<float>());
+            L.row0[L.n] = grows;
+            if (grows > 0 && maxw > 0) hipLaunchKernelGGL(blend_lap_levels_kernel, grid2(maxw, grows), dim3(256), 0, st, L, g, wp, dlap.as<short>(), dwgt.as<float>());
         }
         MI_HIP(hipGetLastError());
     }
     for (int l = 0; l <= nb; l++) {
-        const size_t cnt = (size_t)(Wp >> l) * (Hp >> l);
+        const size_t cnt = (size_t)(Wp >> l) * (size_t)(nhi[l] - nlo[l] + 1);      // the level's stored rows are contiguous from loff[l]
         hipLaunchKernelGGL(blend_normalize_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st, dlap.as<short>() + loff[l] * 3, dwgt.as<float>() + loff[l], cnt);
     }
-    for (int l = nb - 1; l >= 0; l--)
-        hipLaunchKernelGGL((pyr_up16_combine_kernel<false>), grid2(Wp >> l, Hp >> l), dim3(256), 0, st, dlap.as<short>() + loff[l + 1] * 3, Wp >> (l + 1), Hp >> (l + 1), dlap.as<short>() + loff[l] * 3);
+    for (int l = nb - 1; l >= 0; l--)       // collapse: rows nlo[l] .. nhi[l] of level l from the rows of level l + 1 they read (all stored: stripe_levels)
+        hipLaunchKernelGGL((pyr_up16_combine_kernel<false>), grid2(Wp >> l, nhi[l] - nlo[l] + 1), dim3(256), 0, st, vlap(l + 1), Wp >> (l + 1), Hp >> (l + 1), vlap(l), nlo[l]);
     const int ows = d_user ? user_ws : (W * 3 + 3) & ~3;
     if (d_user) {
-        MI_HIP(hipMemsetAsync(d_user, 0, (size_t)ows * H, st));
-        hipLaunchKernelGGL(blend_finalize_kernel, grid2(W, H), dim3(256), 0, st, dlap.as<short>(), dwgt.as<float>(), Wp, W, d_user, ows);
+        MI_HIP(hipMemsetAsync(d_user, 0, (size_t)ows * rows, st));
+        hipLaunchKernelGGL(blend_finalize_kernel, grid2(W, rows), dim3(256), 0, st, vlap(0), vwgt(0), Wp, W, d_user, ows, row0);
         MI_HIP(hipGetLastError());
         if (ow) *ow = W;
-        if (oh) *oh = H;
+        if (oh) *oh = rows;
         if (ows_out) *ows_out = ows;
         return MI355_OK;
     }
@@ -814,21 +884,48 @@ int mi_mosaic_blended(mi355_ctx* ctx, const uint8_t* const* imgs, const int* w, 
 
 // The same with the survey resident in HBM: device frames in, device canvas out (C5: frames + chips + masks + distance maps + both
 // pyramid sets co-resident).  Enqueues on the ctx stream.
+// row0, rows: one STRIPE of the canvas (rows < 0: all of it) -- a rank's part of the blended mosaic, the counterpart of mi_mosaic_refined_dev's
+// stripes.  d_canvas then holds the rows row0 .. row0 + rows - 1 only.  The canvas geometry stays the whole canvas's; the rank forms the chips
+// that reach its rows (+ the pyramids' reach: stripe_levels / stripe_mask_rows), their ownership there, and the rows of every canvas pyramid level
+// its output rows depend on -- the same values the whole canvas holds there, so stripes put side by side are the whole canvas byte for byte.
 int mi_mosaic_blended_dev(mi355_ctx* ctx, const uint8_t* const* d_imgs, const int* w, const int* h, const int* ws, int n, const float* h9s,
-                          const uint8_t* keep, int band, uint8_t* d_canvas, int cw, int ch, int cws) {
+                          const uint8_t* keep, int band, uint8_t* d_canvas, int cw, int ch, int cws, int row0, int rows) {
     if (!d_canvas) return MI355_ERR_ARG;
     int lw = 0, lh = 0;
     { int rc = mi_blend_layout(w, h, n, h9s, keep, &lw, &lh); if (rc != MI355_OK) return rc; }
     if (lw != cw || lh != ch || cws < 3 * cw || (cws & 3)) { ctx->set_error("mosaic_blended_dev: canvas geometry does not match mi355_blend_layout"); return MI355_ERR_ARG; }
+    if (rows < 0) { row0 = 0; rows = ch; }
+    if (row0 < 0 || rows < 1 || row0 + rows > ch) { ctx->set_error("mosaic_blended_dev: bad stripe"); return MI355_ERR_ARG; }
+    int nb = (int)std::ceil(std::log((double)(cw > ch ? cw : ch)) / std::log(2.0));
+    if (nb > band) nb = band;
+    if (nb < 0) nb = 0;
+    bool striped = !(row0 == 0 && rows == ch);
+    if (striped && (nb < 1 || nb > MAX_BANDS)) striped = false;      // (no pyramid, or more levels than the windows hold:) the whole canvas is formed and the stripe copied out
+    int mr0 = 0, mr1 = ch - 1;
+    if (striped) {
+        const int al = 1 << nb, Hp = (ch + al - 1) / al * al;
+        std::vector<int> nlo, nhi;
+        stripe_levels(row0, rows, nb, Hp, nlo, nhi);
+        stripe_mask_rows(nlo, nhi, ch, mr0, mr1);
+    }
     std::vector<size_t> chip_off, mask_off;
     int nv = 0, gw = 0, gh = 0;
     mi355_chip_info* ci = nullptr;
     std::vector<int> bbox;
-    int rc = mi_chips_and_masks_dev(ctx, d_imgs, w, h, ws, n, h9s, keep, 1, &nv, &ci, chip_off, mask_off, &gw, &gh, 1, &bbox, 1);
+    int rc = mi_chips_and_masks_dev(ctx, d_imgs, w, h, ws, n, h9s, keep, 1, &nv, &ci, chip_off, mask_off, &gw, &gh, 1, &bbox, 1, mr0, mr1);
     if (rc != MI355_OK) { free(ci); return rc; }
     std::vector<const uint8_t*> dc(nv > 0 ? nv : 1), dm(nv > 0 ? nv : 1);
     for (int v = 0; v < nv; v++) { dc[v] = ctx->buf("chip_imgs").as<uint8_t>() + chip_off[v]; dm[v] = ctx->buf("chip_masks").as<uint8_t>() + mask_off[v]; }
-    rc = blend_core(ctx, dc.data(), dm.data(), 1, ci, nv, gw, gh, band, nullptr, nullptr, nullptr, nullptr, d_canvas, cws, (int)bbox.size() == 4 * nv && nv > 0 ? bbox.data() : nullptr, 1);
+    const int* bb = (int)bbox.size() == 4 * nv && nv > 0 ? bbox.data() : nullptr;
+    if (striped || (row0 == 0 && rows == ch)) {
+        rc = blend_core(ctx, dc.data(), dm.data(), 1, ci, nv, gw, gh, band, nullptr, nullptr, nullptr, nullptr, d_canvas, cws, bb, 1, row0, striped ? rows : -1);
+    } else {
+        DevBuf& full = ctx->buf("blend_full_canvas");
+        hipError_t e = full.reserve((size_t)cws * ch);
+        if (e != hipSuccess) { free(ci); ctx->set_error(std::string("mosaic_blended_dev: ") + hipGetErrorString(e)); return MI355_ERR_NOMEM; }
+        rc = blend_core(ctx, dc.data(), dm.data(), 1, ci, nv, gw, gh, band, nullptr, nullptr, nullptr, nullptr, full.as<uint8_t>(), cws, bb, 1);
+        if (rc == MI355_OK && hipMemcpyAsync(d_canvas, full.as<uint8_t>() + (size_t)row0 * cws, (size_t)rows * cws, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess) rc = MI355_ERR_DEVICE;
+    }
     free(ci);
     return rc;
 }

@@ -107,6 +107,16 @@ struct mi355_ctx {
     int sift_nslots = 3;                               // batch work areas in flight, each on its own stream (option "sift_slots", env MI355_SIFT_SLOTS)
     int xstream_min_w = 1500, xstream_min_frames = 4;  // extrema_stream for octaves at least this wide (and 3/4 as high) in batches of at least so many frames
     int sift_batch = 16;                               // frames per batch (option "sift_batch", env MI355_SIFT_BATCH)
+    // the detect pipeline's streams (options of the same names; read when a batch work area is created, i.e. before the first frame):
+    int sift_split = 0;                                // 1: a batch's keypoint stages run on a second stream of its work area (so that the two kinds of work can be given different queues)
+    int sift_prio = 0;                                 // with sift_split: pyramid + extrema streams at the highest queue priority, keypoint streams at the lowest
+    int sift_one_heavy = 0;                            // with sift_split: ONE stream for the pyramid + extrema phases of all work areas (they run in batch order)
+    int tail_cus = 0;                                  // with sift_split: keypoint streams confined to this many CUs per XCD (hipExtStreamCreateWithCUMask); 0 = no mask
+    int heavy_excl = 0;                                // with tail_cus: the pyramid + extrema streams get the OTHER CUs (their grids are sized for them)
+    int stream_waves_small = 0, stream_waves_big = 0;  // waves per SIMD the streamed blur's grid is sized for (R <= 8 / R >= 10); 0 = 4 / 3
+    int xwaves = 0;                                    // the same for extrema_stream; 0 = 3
+    hipStream_t sift_heavy_stream = nullptr;           // sift_one_heavy
+    int ransac_split = -1;                             // ransac.hip: workgroups per pair when there are few pairs (-1: by the pair count, 0: never, k: k); option "ransac_split", env MI355_RANSAC_SPLIT
     hipEvent_t sift_in_ev = nullptr;                   // orders the SIFT streams after the caller's stream
     std::vector<int*> pinned_chunks;                   // pinned count slots, 8 ints per frame
     size_t pinned_used = 0;
@@ -144,7 +154,7 @@ int mi_sift_flush_if_parked(mi355_ctx*, hipEvent_t ev);   // launches the batch 
 int mi_chips_and_masks_dev(mi355_ctx*, const uint8_t* const* imgs, const int* w, const int* h, const int* ws, int n,
                            const float* h9s, const uint8_t* keep, int find_masks, int* n_chips, mi355_chip_info** chips,
                            std::vector<size_t>& chip_off, std::vector<size_t>& mask_off, int* canvas_w, int* canvas_h, int imgs_on_device = 0,
-                           std::vector<int>* owned_bbox = nullptr, int defer_pixels = 0);      // find_masks: per chip {min col, min row, max col, max row} of its non-zero mask bytes (max < min: none)
+                           std::vector<int>* owned_bbox = nullptr, int defer_pixels = 0, int row_lo = 0, int row_hi = 0x7fffffff);      // row_lo .. row_hi: a stripe of the canvas (see warp.hip); find_masks: per chip {min col, min row, max col, max row} of its non-zero mask bytes (max < min: none)
 // defer_pixels: the chips' validity masks (and ownership) are made at once, their PIXELS only where asked for afterwards, chip by chip
 // (the blender needs them inside a chip's active window only); columns / rows inclusive, clipped to the chip
 int mi_chip_pixels_prepare(mi355_ctx*, int n, const int* chips, const int* win4);      // entry e = chip chips[e] inside win4[4e..]: arguments to the device
@@ -152,7 +162,7 @@ int mi_chip_pixels_launch(mi355_ctx*, int first, int count);                    
 int mi_mosaic_blended(mi355_ctx*, const uint8_t* const* imgs, const int* w, const int* h, const int* ws, int n, const float* h9s,
                       const uint8_t* keep, int band, uint8_t** out, int* ow, int* oh, int* ows);
 int mi_mosaic_blended_dev(mi355_ctx*, const uint8_t* const* d_imgs, const int* w, const int* h, const int* ws, int n, const float* h9s,
-                          const uint8_t* keep, int band, uint8_t* d_canvas, int cw, int ch, int cws);
+                          const uint8_t* keep, int band, uint8_t* d_canvas, int cw, int ch, int cws, int row0 = 0, int rows = -1);      // rows >= 0: the stripe row0 .. row0 + rows - 1 of the canvas only
 int mi_blend_layout(const int* w, const int* h, int n, const float* h9s, const uint8_t* keep, int* cw, int* ch);
 int mi_multiband_blend(mi355_ctx*, const uint8_t* const* chips, const uint8_t* const* masks, const mi355_chip_info* info, int n,
                        int W, int H, int band, uint8_t** out, int* ow, int* oh, int* ows);

@@ -118,21 +118,365 @@ __device__ __forceinline__ int block_exclusive_scan_flags(bool flag, int tid, in
     return off + before;
 }
 
+// the small shared arrays of a pair's workgroup (one object, so that the stages below can be functions)
+struct RShared {
+    unsigned long long mask[5][RB / 64];
+    unsigned wkey[RB / 64];
+    float bestH[9], firstH[9], w[8], dX[8], T1[64], T2[64], t[128];
+    int   state[8];      // 0 t_acc, 1 maxSupport, 2 bestDraw, 3 firstAcc, 4 finished, 5 newBest, 6 newFirst, 7 done
+    int   wtot[RB / 64 + 1];
+    int   npol;
+    int   next;          // next group of 64 list entries to hand to a wave
+    int   fb;            // draws that needed the generic (private-memory) solve: diagnostic, reported in _pad
+    float fbk[RB / 64][320];   // work arrays of the generic solve, one slot per wave
+};
+
+// ---- stage 1: does draw r hold a hypothesis slot? --------------------------------------------------------------------------------------
+// A draw whose 4-point solve leaves a residual above 5 px is skipped without consuming a slot (mosaicimage.h:1864-1867): on unrelated image
+// pairs that is 42 % of the draws, and 6.8 chunks of 256 draws were walked for the 1000 slots with those lanes idle through the 15
+// Gauss-Newton iterations of their neighbours' polish (80 % of the kernel's time).  The solve alone is 1 / 60 of a polished draw: it runs
+// for every draw first, the accepted ones are kept in draw order and then evaluated densely packed.
+__device__ __forceinline__ bool classify_draw(const uint16_t* table, int r, const float* x1, const float* y1, const float* x2, const float* y2, RShared& sh, int tid) {
+    float p[16], h[9];
+    const uint16_t* s = table + 4 * r;
+#pragma unroll
+    for (int i = 0; i < 4; i++) { const int k = s[i]; p[4 * i] = x1[k]; p[4 * i + 1] = y1[k]; p[4 * i + 2] = x2[k]; p[4 * i + 3] = y2[k]; }
+    int pol = 0;
+    const bool fast_ok = hm::hypothesis4_fast<false>(p, h, &pol);
+    bool skip = !pol && h[8] > 5.0f;
+    for (unsigned long long need = __ballot(!fast_ok); need; need &= need - 1ull) {
+        if ((tid & 63) == __builtin_ctzll(need)) {
+            float pin[16], hout[9];
+#pragma unroll
+            for (int i = 0; i < 16; i++) pin[i] = p[i];
+            skip = generic_hypothesis(pin, hout, sh.fbk[tid >> 6]);
+        }
+    }
+    return !skip;
+}
+
+// ---- stage 2: hypothesis + support of draw r (mosaicimage.h:1863-1904) -------------------------------------------------------------------
+template <bool BIG>
+__device__ __forceinline__ int eval_draw(const RansacArgs& a, const uint16_t* table, int r, int n, float d2, const float* x1, const float* y1, const float* x2, const float* y2,
+                                         const float4* pts, float* h, RShared& sh, int tid, long long* t_solve) {
+    const long long c0 = wall_clock64();
+    float p[16];
+    const uint16_t* s = table + 4 * r;
+#pragma unroll
+    for (int i = 0; i < 4; i++) { const int k = s[i]; p[4 * i] = x1[k]; p[4 * i + 1] = y1[k]; p[4 * i + 2] = x2[k]; p[4 * i + 3] = y2[k]; }
+    // register-resident solve + polish (structural zeros skipped, failed inversions reproduced: hmath.h); the rare draws
+    // whose inversion needs the reference's pivot search below the diagonal re-run the generic private-memory routines
+    int pol = 0;
+    const bool fast_ok = hm::hypothesis4_fast(p, h, &pol);
+    if (a.dbg && pol) atomicAdd(&sh.npol, 1 + ((pol & 2) ? (1 << 12) : 0) + ((pol & 4) ? (1 << 22) : 0));      // polished draws | << 12: a Jacobian redone with true divisions | << 22: an inversion
+    // one lane of the wave at a time, its work arrays in the wave's LDS slot: a private array for these index-driven
+    // routines costs the whole kernel registers and scratch set-up (measured 5.3 us per pair against 4.9 this way)
+    for (unsigned long long need = __ballot(!fast_ok); need; need &= need - 1ull) {
+        if ((tid & 63) == __builtin_ctzll(need)) {
+            atomicAdd(&sh.fb, 1);                    // statistics only (reported in _pad)
+            float pin[16], hout[9];
+#pragma unroll
+            for (int i = 0; i < 16; i++) pin[i] = p[i];
+            (void)generic_hypothesis(pin, hout, sh.fbk[tid >> 6]);
+#pragma unroll
+            for (int i = 0; i < 9; i++) h[i] = hout[i];
+        }
+    }
+    *t_solve += wall_clock64() - c0;
+    // (a polished hypothesis is never skipped, whatever its residual after the polish: :1868-1876)
+    int support = 0;
+    if constexpr (BIG) {
+        for (int i = 0; i < n; i++) {              // :1890-1904
+            float bx, by;
+            hm::apply_recip1(h, x2[i], y2[i], bx, by);
+            const float dx = bx - x1[i], dy = by - y1[i];
+            const float dd = dx * dx + dy * dy;
+            if (dd < d2) support++;
+        }
+    } else {
+        // the same expressions (ApplyProjectMat2, :1890-1904) with X and Y side by side in explicit pairs: every product and sum is
+        // rounded separately as before (-ffp-contract=off), the pairs are packed instructions whatever the vectoriser's settings
+        const f2 m03 = {h[0], h[3]}, m14 = {h[1], h[4]}, m25 = {h[2], h[5]};
+        const float m6 = h[6], m7 = h[7];
+#pragma unroll 4                                             // four independent points in flight: the chain of one (LDS read, 11-instruction division) is all latency
+        for (int i = 0; i < n; i++) {
+            const float4 q = pts[i];
+            const float inv = 1.0f / (m6 * q.z + m7 * q.w + 1.0f);
+            const f2 num = (m03 * q.z + m14 * q.w) + m25;
+            const f2 b = num * inv;
+            const f2 t1 = {q.x, q.y};
+            const f2 d = b - t1;
+            const f2 sq = d * d;
+            const float dd = sq.x + sq.y;
+            if (dd < d2) support++;
+        }
+    }
+    return support;
+}
+
+// ---- stage 3: the loop's bookkeeping over the stored supports, in list order (mosaicimage.h:1864-1918) -------------------------------------
+// A draw replaces the best one when its support is strictly larger (and ends the loop at once when that support exceeds 0.99 n); the slot
+// limit is the list's length (list_cap <= sample_times).  E = the last draw the loop looks at; the winner is the first draw <= E holding the
+// maximum, if that is positive.  All RB threads call; M = the winner's support (0: none), win = its list index.
+__device__ __forceinline__ void replay_supports(const uint16_t* sup, int nlist, float invn, RShared& sh, int tid, int& M, int& win) {
+    const int lane = tid & 63, wv = tid >> 6;
+    int run = 0;                                          // maximum over the blocks before this one
+    unsigned bestkey = 0;
+    bool stopped = false;
+    for (int b0 = 0; b0 < nlist && !stopped; b0 += RB) {
+        const int i = b0 + tid;
+        const bool valid = i < nlist;
+        const int sv = valid ? (int)sup[i] : 0;
+        int v = sv;                                        // inclusive maximum scan over the wave
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(v, o, 64); if (lane >= o) v = t > v ? t : v; }
+        int ex = __shfl_up(v, 1, 64); if (lane == 0) ex = 0;
+        if (lane == 63) sh.wtot[wv] = v;
+        __syncthreads();
+        int prev = run, blk = run;
+        for (int w = 0; w < RB / 64; w++) { const int t = sh.wtot[w]; if (w < wv) prev = t > prev ? t : prev; blk = t > blk ? t : blk; }
+        ex = ex > prev ? ex : prev;                        // maximum of every earlier draw (0 before the first: :1783)
+        const unsigned long long m_r = __ballot(valid && sv > ex && (float)sv * invn > 0.99f);
+        if (lane == 0) sh.mask[0][wv] = m_r;
+        __syncthreads();
+        int kr = RB;
+        for (int w = 0; w < RB / 64; w++) { const unsigned long long m = sh.mask[0][w]; if (m && kr == RB) kr = 64 * w + (int)__builtin_ctzll(m); }
+        int E = b0 + RB - 1;
+        if (kr < RB) { E = b0 + kr; stopped = true; }
+        unsigned key = (valid && i <= E) ? (((unsigned)sv << 13) | (unsigned)(8191 - i)) : 0u;      // i <= 4998 < 2^13, support < 2^16
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) { const unsigned t = __shfl_xor(key, o, 64); key = t > key ? t : key; }
+        if (lane == 0) sh.wkey[wv] = key;
+        __syncthreads();
+        for (int w = 0; w < RB / 64; w++) bestkey = sh.wkey[w] > bestkey ? sh.wkey[w] : bestkey;
+        run = blk;
+        __syncthreads();                                   // wtot / mask / wkey are rewritten by the next block
+    }
+    M = (int)(bestkey >> 13); win = 8191 - (int)(bestkey & 8191u);
+}
+
+// the winner's hypothesis formed again by one lane (same operations, same bits): the lane that evaluated it went on to a larger support
+// behind a stop, or (split form) its record is not at hand
+__device__ __forceinline__ void recompute_hypothesis(const uint16_t* table, int r, const float* x1, const float* y1, const float* x2, const float* y2, RShared& sh) {
+    float p[16];
+    const uint16_t* sx = table + 4 * r;
+    for (int i = 0; i < 4; i++) { const int k = sx[i]; p[4 * i] = x1[k]; p[4 * i + 1] = y1[k]; p[4 * i + 2] = x2[k]; p[4 * i + 3] = y2[k]; }
+    int pol = 0;
+    float hh[9];
+    if (!hm::hypothesis4_fast(p, hh, &pol)) (void)generic_hypothesis(p, hh, sh.fbk[0]);
+    for (int i = 0; i < 9; i++) sh.bestH[i] = hh[i];
+}
+
+// ---- stage 4: inlier split, true-division form (:1922-1944), order preserving compaction; returns the inlier count --------------------
+template <bool BIG>
+__device__ __forceinline__ int split_inliers(const RansacArgs& a, mi355_pair_result* out, const mi355_sfpoint* P1, const mi355_sfpoint* P2, int n, float d2, const float* W,
+                                             const float* x1, const float* y1, const float* x2, const float* y2, float* C, RShared& sh, int tid) {
+    int cnt = 0;
+    for (int base = 0; base < n; base += RB) {
+        const int i = base + tid;
+        bool in = false;
+        if (i < n) {
+            float bx, by;
+            hm::apply_div1(W, x2[i], y2[i], bx, by);
+            const float dx = bx - x1[i], dy = by - y1[i];
+            const float dd = dx * dx + dy * dy;
+            in = dd < d2;
+        }
+        int tot;
+        const int pos = cnt + block_exclusive_scan_flags(in, tid, sh.wtot, tot);
+        if constexpr (BIG) { if (in) { a.big_a[pos] = P1[i]; a.big_b[pos] = P2[i]; } }
+        else if (in && pos < MI355_MAX_SELECTED) { out->a[pos] = P1[i]; out->b[pos] = P2[i]; }
+        if (in) { C[pos] = (float)i; }                      // remember source index (C reused later)
+        cnt += tot;
+    }
+    __syncthreads();
+    return cnt;
+}
+
+// inlier coordinates, compacted in place into the head of the point arrays (C holds the source indices)
+template <bool BIG>
+__device__ __forceinline__ void compact_inliers(int cnt, float* x1, float* y1, float* x2, float* y2, const float* C, float* CS, int tid) {
+    if constexpr (BIG) {                                    // more than 2 per lane: through the HBM scratch
+        for (int i = tid; i < cnt; i += RB) { const int s = (int)C[i]; CS[4 * i] = x1[s]; CS[4 * i + 1] = y1[s]; CS[4 * i + 2] = x2[s]; CS[4 * i + 3] = y2[s]; }
+        __syncthreads();
+        for (int i = tid; i < cnt; i += RB) { x1[i] = CS[4 * i]; y1[i] = CS[4 * i + 1]; x2[i] = CS[4 * i + 2]; y2[i] = CS[4 * i + 3]; }
+    } else {                                                // read (<= 2 per lane since cnt <= 400), barrier, write
+        float ix1[2], iy1[2], ix2[2], iy2[2];
+        {
+            int m = 0;
+            for (int i = tid; i < cnt; i += RB) { const int s = (int)C[i]; ix1[m] = x1[s]; iy1[m] = y1[s]; ix2[m] = x2[s]; iy2[m] = y2[s]; m++; }
+        }
+        __syncthreads();
+        {
+            int m = 0;
+            for (int i = tid; i < cnt; i += RB) { x1[i] = ix1[m]; y1[i] = iy1[m]; x2[i] = ix2[m]; y2[i] = iy2[m]; m++; }
+        }
+    }
+}
+
+// the Jacobian rows and residuals of the closing refinement's step (LeastSquare.h:404-432; naming there: 1 = source, 2 = target)
+__device__ __forceinline__ void nlls_jacobian(int cnt, const float* x1, const float* y1, const float* x2, const float* y2, const float* w, float* J, float* C, int tid) {
+    for (int i = tid; i < cnt; i += RB) {
+        const float X2 = x1[i], Y2 = y1[i], X1 = x2[i], Y1 = y2[i];
+        const float d = w[6] * X1 + w[7] * Y1 + 1.0f;
+        const float nx = w[0] * X1 + w[1] * Y1 + w[2];
+        const float ny = w[3] * X1 + w[4] * Y1 + w[5];
+        float* j = J + i * 16;
+        j[0] = X1 / d; j[1] = Y1 / d; j[2] = 1.0f / d; j[3] = 0.0f; j[4] = 0.0f; j[5] = 0.0f;
+        j[6] = ((-X1) * nx) / (d * d); j[7] = ((-Y1) * nx) / (d * d);
+        j[8] = 0.0f; j[9] = 0.0f; j[10] = 0.0f; j[11] = X1 / d; j[12] = Y1 / d; j[13] = 1.0f / d;
+        j[14] = ((-X1) * ny) / (d * d); j[15] = ((-Y1) * ny) / (d * d);
+        C[2 * i] = X2 - nx / d; C[2 * i + 1] = Y2 - ny / d;
+    }
+}
+
+// ---- stage 5: NonlinearLeastSquareProjection2 over the inliers from the winning hypothesis (:1977-1986); w in sh.w ------------------------
+__device__ __forceinline__ void nlls_closing(int cnt, const float* x1, const float* y1, const float* x2, const float* y2, float* J, float* JL, float* C, RShared& sh, int tid) {
+    const int rows = 2 * cnt;
+    for (int it = 0; it < 15; it++) {
+        nlls_jacobian(cnt, x1, y1, x2, y2, sh.w, J, C, tid);
+        __syncthreads();
+        if (tid < 64) {                                     // J^T J, entry (r,c): k-ordered accumulation
+            const int r = tid >> 3, c = tid & 7;
+            float acc = 0.0f;
+#pragma unroll 8                                             // the loads of eight steps in flight; the sum stays in k order
+            for (int k = 0; k < rows; k++) { const float pr = J[k * 8 + r] * J[k * 8 + c]; acc = acc + pr; }
+            sh.T1[tid] = acc;
+        }
+        __syncthreads();
+        inverse8_team(sh.T1, sh.T2, 1e-6f, sh.t, tid);                          // LeastSquare.h:451 (stale T2 on failure)
+        __syncthreads();
+        for (int e = tid; e < 8 * rows; e += RB) {         // J* = (J^T J)^-1 J^T
+            const int r = e / rows, k = e - r * rows;
+            float acc = 0.0f;
+#pragma unroll
+            for (int m = 0; m < 8; m++) { const float pr = sh.T2[r * 8 + m] * J[k * 8 + m]; acc = acc + pr; }
+            JL[e] = acc;
+        }
+        __syncthreads();
+        if (tid < 8) {
+            float acc = 0.0f;
+#pragma unroll 8
+            for (int k = 0; k < rows; k++) { const float pr = JL[tid * rows + k] * C[k]; acc = acc + pr; }
+            sh.dX[tid] = acc;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int done = 1;
+            for (int i = 0; i < 8; i++) { sh.w[i] = sh.w[i] + sh.dX[i]; if (!(fabsf(sh.dX[i]) < 1e-10f)) done = 0; }
+            sh.state[7] = done;
+        }
+        __syncthreads();
+        if (sh.state[7]) break;
+    }
+}
+
+// The same refinement for the split form (a pair's workgroup alone on its CU, LDS to spare): the two k-ordered sums of a step -- J^T J's 64
+// entries over the 2 cnt Jacobian rows, the 8 entries of the update -- are chains of 2 cnt dependent additions whatever is done, but
+// the chain's wave above also forms each product and reads its two factors (4 instructions per term, one wave issuing alone).  Here ALL
+// threads form the products first (a thread per Jacobian row: 36 distinct products of its 8 entries; J^T J is symmetric and a product does
+// not care about the order of its factors), into PQ[entry][k] with k contiguous, and the chain's wave only adds: one 16-byte LDS read per
+// four terms.  Every product and every sum is the one of nlls_closing, in the same order.  PQ: 36 x pq_stride floats (>= 2 cnt, a multiple
+// of 4 whose quarter is odd: the entries' rows then start in different banks); it also takes J* and the update's products later.
+__device__ __forceinline__ void nlls_closing_wide(int cnt, const float* x1, const float* y1, const float* x2, const float* y2, float* J, float* PQ, int pq_stride, float* C, RShared& sh, int tid) {
+    const int rows = 2 * cnt;
+    float* JL = PQ;                                         // [8][pq_stride], after the J^T J chain is done with PQ
+    float* P2 = PQ + 8 * (size_t)pq_stride;                 // [8][pq_stride]: J*[r][k] * C[k]
+    for (int it = 0; it < 15; it++) {
+        nlls_jacobian(cnt, x1, y1, x2, y2, sh.w, J, C, tid);
+        __syncthreads();
+        for (int k = tid; k < rows; k += RB) {              // products of row k: entry (r, c), r <= c, at index r * 8 - r (r - 1) / 2 + (c - r)
+            float jr[8];
+#pragma unroll
+            for (int m = 0; m < 8; m++) jr[m] = J[k * 8 + m];
+            int e = 0;
+#pragma unroll
+            for (int r = 0; r < 8; r++)
+#pragma unroll
+                for (int c = r; c < 8; c++) { PQ[(size_t)e * pq_stride + k] = jr[r] * jr[c]; e++; }
+        }
+        __syncthreads();
+        if (tid < 64) {                                     // J^T J, entry (r,c): k-ordered accumulation of the products
+            const int r = tid >> 3, c = tid & 7, lo = r < c ? r : c, hi = r < c ? c : r;
+            const float* pq = PQ + (size_t)(lo * 8 - lo * (lo - 1) / 2 + (hi - lo)) * pq_stride;
+            float acc = 0.0f;
+            int k = 0;
+#pragma unroll 4
+            for (; k + 4 <= rows; k += 4) { const float4 q = *reinterpret_cast<const float4*>(pq + k); acc = acc + q.x; acc = acc + q.y; acc = acc + q.z; acc = acc + q.w; }
+            for (; k < rows; k++) acc = acc + pq[k];
+            sh.T1[tid] = acc;
+        }
+        __syncthreads();
+        inverse8_team(sh.T1, sh.T2, 1e-6f, sh.t, tid);                          // LeastSquare.h:451 (stale T2 on failure)
+        __syncthreads();
+        for (int k = tid; k < rows; k += RB) {              // J*[r][k] = sum_m inv[r][m] J[k][m] in m order; and its product with C[k]
+            float jr[8];
+#pragma unroll
+            for (int m = 0; m < 8; m++) jr[m] = J[k * 8 + m];
+            const float ck = C[k];
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                float acc = 0.0f;
+#pragma unroll
+                for (int m = 0; m < 8; m++) { const float pr = sh.T2[r * 8 + m] * jr[m]; acc = acc + pr; }
+                JL[(size_t)r * pq_stride + k] = acc;
+                P2[(size_t)r * pq_stride + k] = acc * ck;
+            }
+        }
+        __syncthreads();
+        if (tid < 8) {
+            const float* pq = P2 + (size_t)tid * pq_stride;
+            float acc = 0.0f;
+            int k = 0;
+#pragma unroll 4
+            for (; k + 4 <= rows; k += 4) { const float4 q = *reinterpret_cast<const float4*>(pq + k); acc = acc + q.x; acc = acc + q.y; acc = acc + q.z; acc = acc + q.w; }
+            for (; k < rows; k++) acc = acc + pq[k];
+            sh.dX[tid] = acc;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int done = 1;
+            for (int i = 0; i < 8; i++) { sh.w[i] = sh.w[i] + sh.dX[i]; if (!(fabsf(sh.dX[i]) < 1e-10f)) done = 0; }
+            sh.state[7] = done;
+        }
+        __syncthreads();
+        if (sh.state[7]) break;
+    }
+}
+
+// motion[8] = max residual in float (LeastSquare.h:503-519; max is order independent), then the record's head
+__device__ __forceinline__ void write_result(mi355_pair_result* out, int cnt, const float* x1, const float* y1, const float* x2, const float* y2, RShared& sh, int tid) {
+    float emax = 0.0f;
+    for (int i = tid; i < cnt; i += RB) {
+        float fx, fy;
+        hm::apply_recip1(sh.w, x2[i], y2[i], fx, fy);
+        const float dx = x1[i] - fx, dy = y1[i] - fy;
+        const float d = sqrtf(dx * dx + dy * dy);
+        if (d > emax) emax = d;
+    }
+    unsigned bits = __float_as_uint(emax);                  // non-negative floats order like their bit patterns
+    if (emax != emax) bits = 0;                             // NaN never wins `d > max` in the reference
+    for (int off = 32; off > 0; off >>= 1) { const unsigned o = __shfl_xor(bits, off); bits = o > bits ? o : bits; }
+    if ((tid & 63) == 0) sh.wtot[tid >> 6] = (int)bits;
+    __syncthreads();
+    if (tid == 0) {
+        unsigned m = 0;
+        for (int i = 0; i < RB / 64; i++) { const unsigned v = (unsigned)sh.wtot[i]; m = v > m ? v : m; }
+        for (int i = 0; i < 8; i++) out->H[i] = sh.w[i];
+        out->H[8] = __uint_as_float(m);
+        out->n_in = cnt;
+        out->ok = 1;
+        out->_pad = sh.fb;
+    }
+}
+
 // MODE 0: the batched live path (n <= 400, everything in LDS); 1: one pair with 400 < n <= 4096 (points in LDS, Gauss-Newton work arrays in
 // HBM); 2: one pair with more points than the LDS holds (points in HBM too: every lane of a wave reads the same point, one request)
 template <int MODE>
 __device__ __forceinline__ void ransac_body(const RansacArgs& a) {
     constexpr bool BIG = MODE >= 1;
     extern __shared__ float lds[];
-    __shared__ unsigned long long s_mask[5][RB / 64];
-    __shared__ unsigned s_wkey[RB / 64];
-    __shared__ float s_bestH[9], s_firstH[9], s_w[8], s_dX[8], s_T1[64], s_T2[64], s_t[128];
-    __shared__ int   s_state[8];      // 0 t_acc, 1 maxSupport, 2 bestDraw, 3 firstAcc, 4 finished, 5 newBest, 6 newFirst, 7 done
-    __shared__ int   s_wtot[RB / 64 + 1];
-    __shared__ int   s_npol;
-    __shared__ int   s_next;          // next group of 64 list entries to hand to a wave
-    __shared__ float s_fbk[RB / 64][320];   // work arrays of the generic solve, one slot per wave
-    __shared__ int   s_fb;            // draws that needed the generic (private-memory) solve: diagnostic, reported in _pad
+    __shared__ RShared sh;
 
     const int pair = blockIdx.x;
     const int tid = threadIdx.x;
@@ -142,7 +486,7 @@ __device__ __forceinline__ void ransac_body(const RansacArgs& a) {
     const mi355_sfpoint* P2 = a.p2 + (size_t)pair * a.stride;
 
     if (tid < 9) out->H[tid] = 0.0f;
-    if (tid == 0) { s_fb = 0; s_npol = 0; s_next = 0; out->_pad = 0; }
+    if (tid == 0) { sh.fb = 0; sh.npol = 0; sh.next = 0; out->_pad = 0; }
     if (n < 4 || a.sample_times < 1) {                     // mosaicimage.h:1739-1761
         if (tid == 0) { out->n_in = 0; out->ok = 0; }
         return;
@@ -163,8 +507,8 @@ __device__ __forceinline__ void ransac_body(const RansacArgs& a) {
         x1[i] = P1[i].x; y1[i] = P1[i].y; x2[i] = P2[i].x; y2[i] = P2[i].y;
         if constexpr (!BIG) pts[i] = make_float4(P1[i].x, P1[i].y, P2[i].x, P2[i].y);
     }
-    if (tid < 8) s_state[tid] = (tid == 2 || tid == 3) ? -1 : 0;
-    if (tid < 9) { s_bestH[tid] = 0.0f; s_firstH[tid] = 0.0f; }
+    if (tid < 8) sh.state[tid] = (tid == 2 || tid == 3) ? -1 : 0;
+    if (tid < 9) { sh.bestH[tid] = 0.0f; sh.firstH[tid] = 0.0f; }
     __syncthreads();
 
     const float d2 = a.dist * a.dist;                      // :1757
@@ -175,36 +519,15 @@ __device__ __forceinline__ void ransac_body(const RansacArgs& a) {
     float h[9];
     int my_li = -1;
     long long T0 = wall_clock64(); int nchunk = 0; long long Tsolve = 0, Tsup = 0;
-    // ---- pass 1: which draws hold a hypothesis slot ------------------------------------------------------------------------
-    // A draw whose 4-point solve leaves a residual above 5 px is skipped without consuming a slot (:1864-1867): on unrelated image
-    // pairs that is 42 % of the draws, and 6.8 chunks of 256 draws were walked for the 1000 slots with those lanes idle through
-    // the 15 Gauss-Newton iterations of their neighbours' polish (80 % of the kernel's time).  The solve alone is 1 / 60 of a
-    // polished draw: run it for every draw first, keep the accepted ones in draw order, then evaluate them densely packed.
+    // ---- pass 1: which draws hold a hypothesis slot (classify_draw) ----
     int nlist = 0;
     const int list_cap = sample_times < MAX_DRAWS ? sample_times : MAX_DRAWS;
     for (int base = 0; base < MAX_DRAWS && nlist < list_cap; base += RB) {
         const int r = base + tid;
         bool accepted = false;
-        if (r < MAX_DRAWS) {
-            float p[16];
-            const uint16_t* s = table + 4 * r;
-#pragma unroll
-            for (int i = 0; i < 4; i++) { const int k = s[i]; p[4 * i] = x1[k]; p[4 * i + 1] = y1[k]; p[4 * i + 2] = x2[k]; p[4 * i + 3] = y2[k]; }
-            int pol = 0;
-            const bool fast_ok = hm::hypothesis4_fast<false>(p, h, &pol);
-            bool skip = !pol && h[8] > 5.0f;
-            for (unsigned long long need = __ballot(!fast_ok); need; need &= need - 1ull) {
-                if ((tid & 63) == __builtin_ctzll(need)) {
-                    float pin[16], hout[9];
-#pragma unroll
-                    for (int i = 0; i < 16; i++) pin[i] = p[i];
-                    skip = generic_hypothesis(pin, hout, s_fbk[tid >> 6]);
-                }
-            }
-            accepted = !skip;
-        }
+        if (r < MAX_DRAWS) accepted = classify_draw(table, r, x1, y1, x2, y2, sh, tid);
         int tot;
-        const int pos = nlist + block_exclusive_scan_flags(accepted, tid, s_wtot, tot);
+        const int pos = nlist + block_exclusive_scan_flags(accepted, tid, sh.wtot, tot);
         if (accepted && pos < list_cap) list[pos] = (uint16_t)r;
         nlist += tot;
     }
@@ -228,133 +551,35 @@ __device__ __forceinline__ void ransac_body(const RansacArgs& a) {
         for (;;) {
             long long c0 = wall_clock64();
             int sc = 0;
-            if (lane == 0) sc = atomicAdd(&s_next, 1);
+            if (lane == 0) sc = atomicAdd(&sh.next, 1);
             sc = __shfl(sc, 0, 64);
             if (sc >= nsub) break;
             nchunk++;
             const int li = sc * 64 + lane;
-            int support = 0;
             if (li < nlist) {
-            const int r = list[li];
-            float p[16];
-            const uint16_t* s = table + 4 * r;
-#pragma unroll
-            for (int i = 0; i < 4; i++) { const int k = s[i]; p[4 * i] = x1[k]; p[4 * i + 1] = y1[k]; p[4 * i + 2] = x2[k]; p[4 * i + 3] = y2[k]; }
-            // register-resident solve + polish (structural zeros skipped, failed inversions reproduced: hmath.h); the rare draws
-            // whose inversion needs the reference's pivot search below the diagonal re-run the generic private-memory routines
-            int pol = 0;
-            const bool fast_ok = hm::hypothesis4_fast(p, h, &pol);
-            if (a.dbg && pol) atomicAdd(&s_npol, 1 + ((pol & 2) ? (1 << 12) : 0) + ((pol & 4) ? (1 << 22) : 0));      // polished draws | << 12: a Jacobian redone with true divisions | << 22: an inversion
-            // one lane of the wave at a time, its work arrays in the wave's LDS slot: a private array for these index-driven
-            // routines costs the whole kernel registers and scratch set-up (measured 5.3 us per pair against 4.9 this way)
-            for (unsigned long long need = __ballot(!fast_ok); need; need &= need - 1ull) {
-                if ((tid & 63) == __builtin_ctzll(need)) {
-                    atomicAdd(&s_fb, 1);                    // statistics only (reported in _pad)
-                    float pin[16], hout[9];
-#pragma unroll
-                    for (int i = 0; i < 16; i++) pin[i] = p[i];
-                    (void)generic_hypothesis(pin, hout, s_fbk[tid >> 6]);
-#pragma unroll
-                    for (int i = 0; i < 9; i++) h[i] = hout[i];
-                }
-            }
-            long long c1 = wall_clock64(); Tsolve += c1 - c0;
-            // (a polished hypothesis is never skipped, whatever its residual after the polish: :1868-1876)
-            if constexpr (BIG) {
-                for (int i = 0; i < n; i++) {              // :1890-1904
-                    float bx, by;
-                    hm::apply_recip1(h, x2[i], y2[i], bx, by);
-                    const float dx = bx - x1[i], dy = by - y1[i];
-                    const float dd = dx * dx + dy * dy;
-                    if (dd < d2) support++;
-                }
-            } else {
-                // the same expressions (ApplyProjectMat2, :1890-1904) with X and Y side by side in explicit pairs: every product and sum is
-                // rounded separately as before (-ffp-contract=off), the pairs are packed instructions whatever the vectoriser's settings
-                const f2 m03 = {h[0], h[3]}, m14 = {h[1], h[4]}, m25 = {h[2], h[5]};
-                const float m6 = h[6], m7 = h[7];
-#pragma unroll 4                                             // four independent points in flight: the chain of one (LDS read, 11-instruction division) is all latency
-                for (int i = 0; i < n; i++) {
-                    const float4 q = pts[i];
-                    const float inv = 1.0f / (m6 * q.z + m7 * q.w + 1.0f);
-                    const f2 num = (m03 * q.z + m14 * q.w) + m25;
-                    const f2 b = num * inv;
-                    const f2 t1 = {q.x, q.y};
-                    const f2 d = b - t1;
-                    const f2 sq = d * d;
-                    const float dd = sq.x + sq.y;
-                    if (dd < d2) support++;
-                }
-            }
+                const int support = eval_draw<BIG>(a, table, list[li], n, d2, x1, y1, x2, y2, pts, h, sh, tid, &Tsolve);
                 sup[li] = (uint16_t)support;
                 if (support > mybest) {
                     mybest = support; my_li = li;
 #pragma unroll
                     for (int i = 0; i < 9; i++) hb[i * RB + tid] = h[i];
                 }
-                if (li == 0) { for (int i = 0; i < 9; i++) s_firstH[i] = h[i]; }      // the first accepted draw (:1878-1884)
+                if (li == 0) { for (int i = 0; i < 9; i++) sh.firstH[i] = h[i]; }      // the first accepted draw (:1878-1884)
             }
             Tsup += wall_clock64() - c0;
         }
     }
     __syncthreads();
-    // ---- the loop's bookkeeping over the stored supports, in list order: a draw replaces the best one when its support is strictly larger
-    // (and ends the loop at once when that support exceeds 0.99 n); the slot limit is the list's length (list_cap <= sample_times).  E = the
-    // last draw the loop looks at; the winner is the first draw <= E holding the maximum, if that is positive.
     {
-        const int lane = tid & 63, wv = tid >> 6;
-        int run = 0;                                          // maximum over the blocks before this one
-        unsigned bestkey = 0;
-        bool stopped = false;
-        for (int b0 = 0; b0 < nlist && !stopped; b0 += RB) {
-            const int i = b0 + tid;
-            const bool valid = i < nlist;
-            const int sv = valid ? (int)sup[i] : 0;
-            int v = sv;                                        // inclusive maximum scan over the wave
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(v, o, 64); if (lane >= o) v = t > v ? t : v; }
-            int ex = __shfl_up(v, 1, 64); if (lane == 0) ex = 0;
-            if (lane == 63) s_wtot[wv] = v;
-            __syncthreads();
-            int prev = run, blk = run;
-            for (int w = 0; w < RB / 64; w++) { const int t = s_wtot[w]; if (w < wv) prev = t > prev ? t : prev; blk = t > blk ? t : blk; }
-            ex = ex > prev ? ex : prev;                        // maximum of every earlier draw (0 before the first: :1783)
-            const unsigned long long m_r = __ballot(valid && sv > ex && (float)sv * invn > 0.99f);
-            if (lane == 0) s_mask[0][wv] = m_r;
-            __syncthreads();
-            int kr = RB;
-            for (int w = 0; w < RB / 64; w++) { const unsigned long long m = s_mask[0][w]; if (m && kr == RB) kr = 64 * w + (int)__builtin_ctzll(m); }
-            int E = b0 + RB - 1;
-            if (kr < RB) { E = b0 + kr; stopped = true; }
-            unsigned key = (valid && i <= E) ? (((unsigned)sv << 13) | (unsigned)(8191 - i)) : 0u;      // i <= 4998 < 2^13, support < 2^16
-#pragma unroll
-            for (int o = 32; o >= 1; o >>= 1) { const unsigned t = __shfl_xor(key, o, 64); key = t > key ? t : key; }
-            if (lane == 0) s_wkey[wv] = key;
-            __syncthreads();
-            for (int w = 0; w < RB / 64; w++) bestkey = s_wkey[w] > bestkey ? s_wkey[w] : bestkey;
-            run = blk;
-            __syncthreads();                                   // s_wtot / s_mask / s_wkey are rewritten by the next block
-        }
-        const int M = (int)(bestkey >> 13), win = 8191 - (int)(bestkey & 8191u);
-        if (tid == 0) { s_state[2] = M > 0 ? win : -1; s_state[5] = 0; }
+        int M, win;
+        replay_supports(sup, nlist, invn, sh, tid, M, win);
+        if (tid == 0) { sh.state[2] = M > 0 ? win : -1; sh.state[5] = 0; }
         __syncthreads();
         if (M > 0) {
-            if (my_li == win) { for (int i = 0; i < 9; i++) s_bestH[i] = hb[i * RB + tid]; s_state[5] = 1; }
+            if (my_li == win) { for (int i = 0; i < 9; i++) sh.bestH[i] = hb[i * RB + tid]; sh.state[5] = 1; }
             __syncthreads();
-            if (!s_state[5]) {
-                // the lane that evaluated the winner went on to a larger support behind a stop: the winner's hypothesis is formed again (same
-                // operations, same bits) by one lane
-                if (tid == 0) {
-                    const int r = list[win];
-                    float p[16];
-                    const uint16_t* sx = table + 4 * r;
-                    for (int i = 0; i < 4; i++) { const int k = sx[i]; p[4 * i] = x1[k]; p[4 * i + 1] = y1[k]; p[4 * i + 2] = x2[k]; p[4 * i + 3] = y2[k]; }
-                    int pol = 0;
-                    float hh[9];
-                    if (!hm::hypothesis4_fast(p, hh, &pol)) (void)generic_hypothesis(p, hh, s_fbk[0]);
-                    for (int i = 0; i < 9; i++) s_bestH[i] = hh[i];
-                }
-            }
+            // the lane that evaluated the winner went on to a larger support behind a stop: the winner's hypothesis is formed again
+            if (!sh.state[5] && tid == 0) recompute_hypothesis(table, list[win], x1, y1, x2, y2, sh);
         }
         __syncthreads();
     }
@@ -362,133 +587,27 @@ __device__ __forceinline__ void ransac_body(const RansacArgs& a) {
     // winner: hyp[maxSupportIndex]; maxSupportIndex stays 0 when no support was ever positive (:1783) -> first accepted
     float W[9];
 #pragma unroll
-    for (int i = 0; i < 9; i++) W[i] = (s_state[2] >= 0) ? s_bestH[i] : s_firstH[i];
+    for (int i = 0; i < 9; i++) W[i] = (sh.state[2] >= 0) ? sh.bestH[i] : sh.firstH[i];
 
-    // ---- inlier split, true-division form (:1922-1944), order preserving compaction ----
-    int cnt = 0;
-    for (int base = 0; base < n; base += RB) {
-        const int i = base + tid;
-        bool in = false;
-        if (i < n) {
-            float bx, by;
-            hm::apply_div1(W, x2[i], y2[i], bx, by);
-            const float dx = bx - x1[i], dy = by - y1[i];
-            const float dd = dx * dx + dy * dy;
-            in = dd < d2;
-        }
-        int tot;
-        const int pos = cnt + block_exclusive_scan_flags(in, tid, s_wtot, tot);
-        if constexpr (BIG) { if (in) { a.big_a[pos] = P1[i]; a.big_b[pos] = P2[i]; } }
-        else if (in && pos < MI355_MAX_SELECTED) { out->a[pos] = P1[i]; out->b[pos] = P2[i]; }
-        if (in) { C[pos] = (float)i; }                      // remember source index (C reused later)
-        cnt += tot;
-    }
-    __syncthreads();
+    const int cnt = split_inliers<BIG>(a, out, P1, P2, n, d2, W, x1, y1, x2, y2, C, sh, tid);
     if (cnt < 4) {                                          // :1953-1961 refit fails below 4 -> no H; :2024-2032
         if (tid == 0) { out->n_in = cnt; out->ok = 0; }
         return;
     }
     if (cnt <= a.min_keep) {                                // match_pairs: MosaicWithoutPos.cpp:5201 drops the pair (n_in <= 30), its H is never looked at
         if (tid == 0) { out->n_in = cnt; out->ok = 0; }
-        if (a.dbg && tid == 0) { long long* d = a.dbg + 8 * pair; d[0] = T1 - T0; d[3] = nchunk; d[4] = Tsolve; d[5] = Tsup; d[6] = Tclass; d[7] = s_npol; }
+        if (a.dbg && tid == 0) { long long* d = a.dbg + 8 * pair; d[0] = T1 - T0; d[3] = nchunk; d[4] = Tsolve; d[5] = Tsup; d[6] = Tclass; d[7] = sh.npol; }
         return;
     }
-    // inlier coordinates, compacted in place into the head of the LDS arrays: read (<= 2 per lane since
-    // cnt <= 400), barrier, write
-    if constexpr (BIG) {                                    // more than 2 per lane: through the HBM scratch
-        for (int i = tid; i < cnt; i += RB) { const int s = (int)C[i]; CS[4 * i] = x1[s]; CS[4 * i + 1] = y1[s]; CS[4 * i + 2] = x2[s]; CS[4 * i + 3] = y2[s]; }
-        __syncthreads();
-        for (int i = tid; i < cnt; i += RB) { x1[i] = CS[4 * i]; y1[i] = CS[4 * i + 1]; x2[i] = CS[4 * i + 2]; y2[i] = CS[4 * i + 3]; }
-    } else {
-        float ix1[2], iy1[2], ix2[2], iy2[2];
-        {
-            int m = 0;
-            for (int i = tid; i < cnt; i += RB) { const int s = (int)C[i]; ix1[m] = x1[s]; iy1[m] = y1[s]; ix2[m] = x2[s]; iy2[m] = y2[s]; m++; }
-        }
-        __syncthreads();
-        {
-            int m = 0;
-            for (int i = tid; i < cnt; i += RB) { x1[i] = ix1[m]; y1[i] = iy1[m]; x2[i] = ix2[m]; y2[i] = iy2[m]; m++; }
-        }
-    }
-    if (tid < 8) s_w[tid] = W[tid];
-    if (tid < 64) s_T2[tid] = 0.0f;
+    compact_inliers<BIG>(cnt, x1, y1, x2, y2, C, CS, tid);
+    if (tid < 8) sh.w[tid] = W[tid];
+    if (tid < 64) sh.T2[tid] = 0.0f;
     __syncthreads();
 
     long long T2 = wall_clock64();
-    // ---- NonlinearLeastSquareProjection2 over the inliers from the winning hypothesis (:1977-1986) ----
-    const int rows = 2 * cnt;
-    for (int it = 0; it < 15; it++) {
-        for (int i = tid; i < cnt; i += RB) {
-            const float X2 = x1[i], Y2 = y1[i], X1 = x2[i], Y1 = y2[i];      // LeastSquare.h naming: 1 = source, 2 = target
-            const float d = s_w[6] * X1 + s_w[7] * Y1 + 1.0f;
-            const float nx = s_w[0] * X1 + s_w[1] * Y1 + s_w[2];
-            const float ny = s_w[3] * X1 + s_w[4] * Y1 + s_w[5];
-            float* j = J + i * 16;
-            j[0] = X1 / d; j[1] = Y1 / d; j[2] = 1.0f / d; j[3] = 0.0f; j[4] = 0.0f; j[5] = 0.0f;
-            j[6] = ((-X1) * nx) / (d * d); j[7] = ((-Y1) * nx) / (d * d);
-            j[8] = 0.0f; j[9] = 0.0f; j[10] = 0.0f; j[11] = X1 / d; j[12] = Y1 / d; j[13] = 1.0f / d;
-            j[14] = ((-X1) * ny) / (d * d); j[15] = ((-Y1) * ny) / (d * d);
-            C[2 * i] = X2 - nx / d; C[2 * i + 1] = Y2 - ny / d;
-        }
-        __syncthreads();
-        if (tid < 64) {                                     // J^T J, entry (r,c): k-ordered accumulation
-            const int r = tid >> 3, c = tid & 7;
-            float acc = 0.0f;
-#pragma unroll 8                                             // the loads of eight steps in flight; the sum stays in k order
-            for (int k = 0; k < rows; k++) { const float pr = J[k * 8 + r] * J[k * 8 + c]; acc = acc + pr; }
-            s_T1[tid] = acc;
-        }
-        __syncthreads();
-        inverse8_team(s_T1, s_T2, 1e-6f, s_t, tid);                          // LeastSquare.h:451 (stale T2 on failure)
-        __syncthreads();
-        for (int e = tid; e < 8 * rows; e += RB) {         // J* = (J^T J)^-1 J^T
-            const int r = e / rows, k = e - r * rows;
-            float acc = 0.0f;
-#pragma unroll
-            for (int m = 0; m < 8; m++) { const float pr = s_T2[r * 8 + m] * J[k * 8 + m]; acc = acc + pr; }
-            JL[e] = acc;
-        }
-        __syncthreads();
-        if (tid < 8) {
-            float acc = 0.0f;
-#pragma unroll 8
-            for (int k = 0; k < rows; k++) { const float pr = JL[tid * rows + k] * C[k]; acc = acc + pr; }
-            s_dX[tid] = acc;
-        }
-        __syncthreads();
-        if (tid == 0) {
-            int done = 1;
-            for (int i = 0; i < 8; i++) { s_w[i] = s_w[i] + s_dX[i]; if (!(fabsf(s_dX[i]) < 1e-10f)) done = 0; }
-            s_state[7] = done;
-        }
-        __syncthreads();
-        if (s_state[7]) break;
-    }
-    if (a.dbg && tid == 0) { long long* d = a.dbg + 8 * pair; d[0] = T1 - T0; d[1] = T2 - T1; d[2] = wall_clock64() - T2; d[3] = nchunk; d[4] = Tsolve; d[5] = Tsup; d[6] = Tclass; d[7] = s_npol; }
-    // motion[8] = max residual in float (LeastSquare.h:503-519): max is order independent
-    float emax = 0.0f;
-    for (int i = tid; i < cnt; i += RB) {
-        float fx, fy;
-        hm::apply_recip1(s_w, x2[i], y2[i], fx, fy);
-        const float dx = x1[i] - fx, dy = y1[i] - fy;
-        const float d = sqrtf(dx * dx + dy * dy);
-        if (d > emax) emax = d;
-    }
-    unsigned bits = __float_as_uint(emax);                  // non-negative floats order like their bit patterns
-    if (emax != emax) bits = 0;                             // NaN never wins `d > max` in the reference
-    for (int off = 32; off > 0; off >>= 1) { const unsigned o = __shfl_xor(bits, off); bits = o > bits ? o : bits; }
-    if ((tid & 63) == 0) s_wtot[tid >> 6] = (int)bits;
-    __syncthreads();
-    if (tid == 0) {
-        unsigned m = 0;
-        for (int i = 0; i < RB / 64; i++) { const unsigned v = (unsigned)s_wtot[i]; m = v > m ? v : m; }
-        for (int i = 0; i < 8; i++) out->H[i] = s_w[i];
-        out->H[8] = __uint_as_float(m);
-        out->n_in = cnt;
-        out->ok = 1;
-        out->_pad = s_fb;
-    }
+    nlls_closing(cnt, x1, y1, x2, y2, J, JL, C, sh, tid);
+    if (a.dbg && tid == 0) { long long* d = a.dbg + 8 * pair; d[0] = T1 - T0; d[1] = T2 - T1; d[2] = wall_clock64() - T2; d[3] = nchunk; d[4] = Tsolve; d[5] = Tsup; d[6] = Tclass; d[7] = sh.npol; }
+    write_result(out, cnt, x1, y1, x2, y2, sh, tid);
 }
 
 // 2 waves per SIMD (256 registers each): with 1 (512 registers, spills in AGPRs instead of scratch) the kernel measured 30 % slower
@@ -497,6 +616,180 @@ __global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 __global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(2, 2))) void ransac_big_kernel(RansacArgs a) { ransac_body<1>(a); }
 // ... and beyond 4096 (up to the 65 535 a 16-bit draw table can address) with the points in HBM
 __global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(2, 2))) void ransac_huge_kernel(RansacArgs a) { ransac_body<2>(a); }
+
+// ---- few pairs: a pair's draws spread over several workgroups -------------------------------------------------------------------------------
+// One workgroup per pair is ~1.3 ms of latency whatever the number of pairs (0.7 ms of draws, 0.5 ms of closing refinement): a rank that owns
+// 63 pairs of a survey, or a caller of mi355_ransac2d, waits that long with most of the chip idle.  With fewer pairs than wave slots the same
+// stages run as three launches (the launch boundaries are the synchronisation):
+//   classify  S workgroups per pair classify all 20 chunks of 256 draws between them (ballot masks to HBM);
+//   evaluate  S workgroups per pair rebuild the list of accepted draws from the masks and take groups of 64 of them from ONE counter per pair
+//             (a wave's draws still come in list order), supports and the lanes' own first maxima go to HBM;
+//   finish    one workgroup per pair replays the sequential loop over the stored supports (replay_supports, the same code), fetches the
+//             winner's hypothesis from the lane that holds it, splits the inliers and runs the closing refinement in its wide form.
+// Every hypothesis, support and sum is formed by the same code as in ransac_kernel, so the records are the same bytes.
+constexpr int NCHUNK = (MAX_DRAWS + RB - 1) / RB;      // 20
+constexpr int SPLIT_MAX = 8;                           // workgroups per pair at most
+struct SplitBufs {
+    unsigned long long* masks;   // [pair][NCHUNK][RB / 64]
+    uint16_t* list;              // [pair][list_stride]
+    uint16_t* sup;               // [pair][list_stride]
+    int* nlist;                  // [pair]
+    int* next;                   // [pair]: the evaluate pass's group counter (zero before the launch)
+    float* rec;                  // [pair][S * RB][10]: list index of the lane's first maximum (int bits; -1 none), its hypothesis
+    float* firstH;               // [pair][9]
+    int* fb;                     // [pair]: draws that took the generic solve (the record's _pad)
+    int S, list_stride;
+};
+
+__global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(2, 2))) void ransac_split_classify(RansacArgs a, SplitBufs b) {
+    extern __shared__ float lds[];
+    __shared__ RShared sh;
+    const int pair = blockIdx.y, part = blockIdx.x, tid = threadIdx.x;
+    const int n = a.n[pair];
+    if (n < 4 || a.sample_times < 1) return;
+    const mi355_sfpoint* P1 = a.p1 + (size_t)pair * a.stride;
+    const mi355_sfpoint* P2 = a.p2 + (size_t)pair * a.stride;
+    float* x1 = lds; float* y1 = x1 + n; float* x2 = y1 + n; float* y2 = x2 + n;
+    for (int i = tid; i < n; i += RB) { x1[i] = P1[i].x; y1[i] = P1[i].y; x2[i] = P2[i].x; y2[i] = P2[i].y; }
+    __syncthreads();
+    const uint16_t* table = a.tables + (size_t)(a.single_table ? 0 : (a.table_of ? a.table_of[pair] : (n - 4))) * MAX_DRAWS * 4;
+    for (int chunk = part; chunk < NCHUNK; chunk += b.S) {
+        const int r = chunk * RB + tid;
+        bool accepted = false;
+        if (r < MAX_DRAWS) accepted = classify_draw(table, r, x1, y1, x2, y2, sh, tid);
+        const unsigned long long m = __ballot(accepted);
+        if ((tid & 63) == 0) b.masks[((size_t)pair * NCHUNK + chunk) * (RB / 64) + (tid >> 6)] = m;
+    }
+}
+
+__global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(2, 2))) void ransac_split_evaluate(RansacArgs a, SplitBufs b) {
+    extern __shared__ float lds[];
+    __shared__ RShared sh;
+    __shared__ int s_pref[NCHUNK * (RB / 64) + 1];
+    const int pair = blockIdx.y, part = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int n = a.n[pair];
+    if (n < 4 || a.sample_times < 1) return;
+    const mi355_sfpoint* P1 = a.p1 + (size_t)pair * a.stride;
+    const mi355_sfpoint* P2 = a.p2 + (size_t)pair * a.stride;
+    uint16_t* list = reinterpret_cast<uint16_t*>(lds);
+    float* x1 = lds + a.list_floats; float* y1 = x1 + n; float* x2 = y1 + n; float* y2 = x2 + n;
+    float4* pts = reinterpret_cast<float4*>(y2 + n);
+    float* hb = reinterpret_cast<float*>(pts + n);             // [9][RB]
+    for (int i = tid; i < n; i += RB) {
+        x1[i] = P1[i].x; y1[i] = P1[i].y; x2[i] = P2[i].x; y2[i] = P2[i].y;
+        pts[i] = make_float4(P1[i].x, P1[i].y, P2[i].x, P2[i].y);
+    }
+    if (tid == 0) { sh.fb = 0; sh.npol = 0; }
+    // the list of accepted draws from the masks: (chunk, wave) blocks in draw order
+    const unsigned long long* masks = b.masks + (size_t)pair * NCHUNK * (RB / 64);
+    if (tid == 0) {
+        int acc = 0;
+        for (int q = 0; q < NCHUNK * (RB / 64); q++) { s_pref[q] = acc; acc += __popcll(masks[q]); }
+        s_pref[NCHUNK * (RB / 64)] = acc;
+    }
+    __syncthreads();
+    const int sample_times = a.sample_times > 5000 ? 5000 : a.sample_times;
+    const int list_cap = sample_times < MAX_DRAWS ? sample_times : MAX_DRAWS;
+    int nlist = s_pref[NCHUNK * (RB / 64)];
+    nlist = nlist < list_cap ? nlist : list_cap;
+    for (int chunk = 0; chunk < NCHUNK; chunk++) {
+        const int q = chunk * (RB / 64) + (tid >> 6);
+        if (s_pref[q] >= list_cap) break;                       // (uniform enough: later blocks only start further on)
+        const unsigned long long m = masks[q];
+        if ((m >> lane) & 1ull) { const int pos = s_pref[q] + __popcll(m & ((1ull << lane) - 1ull)); if (pos < list_cap) list[pos] = (uint16_t)(chunk * RB + tid); }
+    }
+    __syncthreads();
+    if (part == 0) {
+        for (int i = tid; i < nlist; i += RB) b.list[(size_t)pair * b.list_stride + i] = list[i];
+        if (tid == 0) b.nlist[pair] = nlist;
+    }
+    const float d2 = a.dist * a.dist;
+    const uint16_t* table = a.tables + (size_t)(a.single_table ? 0 : (a.table_of ? a.table_of[pair] : (n - 4))) * MAX_DRAWS * 4;
+    const int nsub = (nlist + 63) >> 6;
+    int mybest = -1, my_li = -1;
+    long long Tsolve = 0;
+    float h[9];
+    for (;;) {
+        int sc = 0;
+        if (lane == 0) sc = atomicAdd(&b.next[pair], 1);
+        sc = __shfl(sc, 0, 64);
+        if (sc >= nsub) break;
+        const int li = sc * 64 + lane;
+        if (li < nlist) {
+            const int support = eval_draw<false>(a, table, list[li], n, d2, x1, y1, x2, y2, pts, h, sh, tid, &Tsolve);
+            b.sup[(size_t)pair * b.list_stride + li] = (uint16_t)support;
+            if (support > mybest) {
+                mybest = support; my_li = li;
+#pragma unroll
+                for (int i = 0; i < 9; i++) hb[i * RB + tid] = h[i];
+            }
+            if (li == 0) { for (int i = 0; i < 9; i++) b.firstH[(size_t)pair * 9 + i] = h[i]; }
+        }
+    }
+    float* rec = b.rec + ((size_t)pair * b.S * RB + (size_t)part * RB + tid) * 10;
+    rec[0] = __int_as_float(my_li);
+    if (my_li >= 0) { for (int i = 0; i < 9; i++) rec[1 + i] = hb[i * RB + tid]; }
+    __syncthreads();
+    if (tid == 0 && sh.fb) atomicAdd(&b.fb[pair], sh.fb);
+}
+
+__global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(2, 2))) void ransac_split_finish(RansacArgs a, SplitBufs b, int pq_stride) {
+    extern __shared__ float lds[];
+    __shared__ RShared sh;
+    const int pair = blockIdx.x, tid = threadIdx.x;
+    const int n = a.n[pair];
+    mi355_pair_result* out = a.out + pair;
+    const mi355_sfpoint* P1 = a.p1 + (size_t)pair * a.stride;
+    const mi355_sfpoint* P2 = a.p2 + (size_t)pair * a.stride;
+    if (tid < 9) out->H[tid] = 0.0f;
+    if (tid == 0) { sh.fb = b.fb[pair]; sh.npol = 0; out->_pad = 0; }
+    if (n < 4 || a.sample_times < 1) {                     // mosaicimage.h:1739-1761
+        if (tid == 0) { out->n_in = 0; out->ok = 0; }
+        return;
+    }
+    uint16_t* sup = reinterpret_cast<uint16_t*>(lds);      // list_floats floats hold the supports (2 bytes each)
+    float* x1 = lds + a.list_floats; float* y1 = x1 + n; float* x2 = y1 + n; float* y2 = x2 + n;
+    float* J = y2 + n;                                     // 2n x 8
+    float* C = J + 16 * n;                                 // 2n
+    float* PQ = lds + ((a.list_floats + 22 * n + 3) & ~3);  // 36 x pq_stride, 16-byte aligned
+    const int nlist = b.nlist[pair];
+    for (int i = tid; i < n; i += RB) { x1[i] = P1[i].x; y1[i] = P1[i].y; x2[i] = P2[i].x; y2[i] = P2[i].y; }
+    for (int i = tid; i < nlist; i += RB) sup[i] = b.sup[(size_t)pair * b.list_stride + i];
+    if (tid < 8) sh.state[tid] = (tid == 2 || tid == 3) ? -1 : 0;
+    if (tid < 9) { sh.bestH[tid] = 0.0f; sh.firstH[tid] = nlist > 0 ? b.firstH[(size_t)pair * 9 + tid] : 0.0f; }
+    __syncthreads();
+    const float d2 = a.dist * a.dist;                      // :1757
+    const float invn = 1.0f / (float)n;                    // :1763
+    const uint16_t* table = a.tables + (size_t)(a.single_table ? 0 : (a.table_of ? a.table_of[pair] : (n - 4))) * MAX_DRAWS * 4;
+    {
+        int M, win;
+        replay_supports(sup, nlist, invn, sh, tid, M, win);
+        if (tid == 0) { sh.state[2] = M > 0 ? win : -1; sh.state[5] = 0; }
+        __syncthreads();
+        if (M > 0) {
+            const float* rec = b.rec + (size_t)pair * b.S * RB * 10;
+            for (int q = tid; q < b.S * RB; q += RB)
+                if (__float_as_int(rec[(size_t)q * 10]) == win) { for (int i = 0; i < 9; i++) sh.bestH[i] = rec[(size_t)q * 10 + 1 + i]; sh.state[5] = 1; }      // at most one lane evaluated it
+            __syncthreads();
+            if (!sh.state[5] && tid == 0) recompute_hypothesis(table, b.list[(size_t)pair * b.list_stride + win], x1, y1, x2, y2, sh);
+        }
+        __syncthreads();
+    }
+    float W[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) W[i] = (sh.state[2] >= 0) ? sh.bestH[i] : sh.firstH[i];
+    const int cnt = split_inliers<false>(a, out, P1, P2, n, d2, W, x1, y1, x2, y2, C, sh, tid);
+    if (cnt < 4 || cnt <= a.min_keep) {                    // :1953-1961 / :2024-2032; MosaicWithoutPos.cpp:5201 (see ransac_body)
+        if (tid == 0) { out->n_in = cnt; out->ok = 0; }
+        return;
+    }
+    compact_inliers<false>(cnt, x1, y1, x2, y2, C, nullptr, tid);
+    if (tid < 8) sh.w[tid] = W[tid];
+    if (tid < 64) sh.T2[tid] = 0.0f;
+    __syncthreads();
+    nlls_closing_wide(cnt, x1, y1, x2, y2, J, PQ, pq_stride, C, sh, tid);
+    write_result(out, cnt, x1, y1, x2, y2, sh, tid);
+}
 
 }  // namespace
 
@@ -783,7 +1076,38 @@ int mi_ransac_batch(mi355_ctx* ctx, const mi355_sfpoint* d_p1, const mi355_sfpoi
     // records start from zero: the inlier slots beyond n_in, H / ok of pairs that stop early and the padding are then the same bytes
     // on every run and every rank (records are compared and all-gathered as bytes)
     MI_HIP(hipMemsetAsync(d_out, 0, sizeof(mi355_pair_result) * (size_t)n_pairs, ctx->stream));
-    {
+    // few pairs (a rank's share of a strip survey, a single mi355_ransac2d call): several workgroups per pair, three launches
+    int S = ctx->ransac_split;                          // option "ransac_split": -1 = by the number of pairs, 0 = never, k = k workgroups per pair
+    if (S < 0) { S = (2 * ctx->num_cu) / n_pairs; if (S < 2) S = 0; }
+    if (S > SPLIT_MAX) S = SPLIT_MAX;
+    if (S >= 1 && !dbg_on) {
+        SplitBufs b;
+        memset(&b, 0, sizeof(b));
+        b.S = S; b.list_stride = (a.list_floats + 7) & ~7;
+        const size_t o_masks = 0, o_list = o_masks + sizeof(unsigned long long) * NCHUNK * (RB / 64) * (size_t)n_pairs, o_sup = o_list + sizeof(uint16_t) * b.list_stride * (size_t)n_pairs,
+                     o_nlist = o_sup + sizeof(uint16_t) * b.list_stride * (size_t)n_pairs, o_next = o_nlist + sizeof(int) * (size_t)n_pairs, o_first = o_next + sizeof(int) * (size_t)n_pairs,
+                     o_fb = o_first + sizeof(float) * 9 * (size_t)n_pairs, o_rec = (o_fb + sizeof(int) * (size_t)n_pairs + 15) & ~(size_t)15, total = o_rec + sizeof(float) * 10 * S * RB * (size_t)n_pairs;
+        DevBuf& dsp = ctx->buf("ransac_split");
+        MI_HIP(dsp.reserve(total));
+        uint8_t* base = dsp.as<uint8_t>();
+        b.masks = reinterpret_cast<unsigned long long*>(base + o_masks); b.list = reinterpret_cast<uint16_t*>(base + o_list); b.sup = reinterpret_cast<uint16_t*>(base + o_sup);
+        b.nlist = reinterpret_cast<int*>(base + o_nlist); b.next = reinterpret_cast<int*>(base + o_next); b.firstH = reinterpret_cast<float*>(base + o_first); b.fb = reinterpret_cast<int*>(base + o_fb);
+        b.rec = reinterpret_cast<float*>(base + o_rec);
+        MI_HIP(hipMemsetAsync(base + o_nlist, 0, o_rec - o_nlist, ctx->stream));      // list lengths, group counters, first hypotheses
+        ProfScope ps(ctx, "ransac", (double)n_pairs * (24.0 * nmax + sizeof(mi355_pair_result)));
+        const size_t lds_c = sizeof(float) * 4 * (size_t)nmax;
+        const size_t lds_e = sizeof(float) * ((size_t)a.list_floats + 8 * (size_t)nmax + 9 * RB);
+        int q4 = (2 * nmax + 3) / 4; if (!(q4 & 1)) q4++;                             // rows of the product table: a multiple of 4 floats whose quarter is odd
+        const int pq_stride = 4 * q4;
+        RansacArgs af = a;
+        af.list_floats = ((a.list_floats + 1) / 2 + 3) & ~3;                          // the finish pass keeps only the supports there (2 bytes each)
+        const size_t lds_f = sizeof(float) * ((size_t)af.list_floats + 22 * (size_t)nmax + 4 + 36 * (size_t)pq_stride);
+        if (lds_e > 48 * 1024) MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ransac_split_evaluate), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_e));
+        if (lds_f > 48 * 1024) MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ransac_split_finish), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_f));
+        hipLaunchKernelGGL(ransac_split_classify, dim3(S, n_pairs), dim3(RB), lds_c, ctx->stream, a, b);
+        hipLaunchKernelGGL(ransac_split_evaluate, dim3(S, n_pairs), dim3(RB), lds_e, ctx->stream, a, b);
+        hipLaunchKernelGGL(ransac_split_finish, dim3(n_pairs), dim3(RB), lds_f, ctx->stream, af, b, pq_stride);
+    } else {
         ProfScope ps(ctx, "ransac", (double)n_pairs * (24.0 * nmax + sizeof(mi355_pair_result)));
         hipLaunchKernelGGL(ransac_kernel, dim3(n_pairs), dim3(RB), lds_bytes, ctx->stream, a);
     }

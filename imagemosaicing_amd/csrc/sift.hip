@@ -49,6 +49,7 @@ __host__ __device__ __forceinline__ int reflect101(int p, int n) {
 }
 
 typedef float v2f __attribute__((ext_vector_type(2)));
+struct __attribute__((aligned(4))) uint2_a4 { unsigned x, y; };     // two dwords at a 4-byte aligned address (global_load_dwordx2 asks for no more)
 typedef float v4f __attribute__((ext_vector_type(4)));
 
 // four / one 16-bit samples as floats (exact)
@@ -192,7 +193,8 @@ __device__ __forceinline__ void blur16_stream_body(const Blur16Args& a, int L, i
     static_assert(2 * RA + R <= 64, "halo lanes");
     __shared__ __attribute__((aligned(16))) float s_buf[4][2][BUF];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    // wave-uniform by construction; readfirstlane tells the compiler, so that segment, strip and row pointers live in scalar registers
+    // wave-uniform by construction; readfirstlane tells the compiler, so that segment, strip and row pointers live in scalar registers.
+    // Every return below is taken by whole waves (the tests are on `unit`): the assembly body runs with all 64 lanes on and leaves exec = -1
     int unit = __builtin_amdgcn_readfirstlane(xcd_remap(blockIdx.x, gridDim.x) * 4 + wave);
     const int per = nstrip * nseg, fr = unit / per;
     if (fr >= a.nb) return;
@@ -746,7 +748,7 @@ __global__ __launch_bounds__(256) void refine_kernel(PyrDev P, const unsigned lo
         // HBM: the same twelve cold 64-byte sectors per candidate there, and a second time here for every candidate that moves on to a
         // neighbouring pixel (one in three) -- now a mover's next step finds most of its sectors in the cache.
         const bool from_cube = (pk >> 63) != 0;
-        if (from_cube || (oc.w & 1) == 0) {
+        if (from_cube || ((oc.w & 1) == 0 && (foff & 1) == 0)) {
             float cv[27];
             if (from_cube) {
                 const float* cb = cube_all + (size_t)reg * 32 * cube_cap + i;       // [element][candidate]: coalesced across the lanes
@@ -760,7 +762,7 @@ __global__ __launch_bounds__(256) void refine_kernel(PyrDev P, const unsigned lo
                     const lvl_t* lp = oc.lv[L - 1 + q] + foff;
 #pragma unroll
                     for (int dr = 0; dr < 3; dr++) {
-                        const uint2 wv = *reinterpret_cast<const uint2*>(lp + (size_t)(R - 1 + dr) * oc.w + a0);
+                        const uint2_a4 wv = *reinterpret_cast<const uint2_a4*>(lp + (size_t)(R - 1 + dr) * oc.w + a0);      // 4-byte aligned: a0, the row pitch and the frame offset are even
                         const unsigned long long ww = (((unsigned long long)wv.y << 32) | wv.x) >> sh;
                         v[q][dr * 3 + 0] = (int)(short)(ww & 0xffffu); v[q][dr * 3 + 1] = (int)(short)((ww >> 16) & 0xffffu); v[q][dr * 3 + 2] = (int)(short)((ww >> 32) & 0xffffu);
                     }
@@ -784,9 +786,6 @@ __global__ __launch_bounds__(256) void refine_kernel(PyrDev P, const unsigned lo
                 it = 1;
             }
         }
-#ifdef REFINE_EXP_NOSLOW
-        if (!accepted) continue;
-#endif
         if (!accepted) {
             for (; it < MAX_INTERP; it++) {
                 f = fit_step(dv, L, R, C);
@@ -802,11 +801,7 @@ __global__ __launch_bounds__(256) void refine_kernel(PyrDev P, const unsigned lo
         // duplicates: several start points may converge to one location -> first claim wins (all claims carry identical values)
         const size_t bit = ((size_t)R * oc.w + C) * 4 + (size_t)L;
         const unsigned mask = 1u << (bit & 31);
-#ifdef REFINE_EXP_NOCLAIM
-        const unsigned old = 0;
-#else
         const unsigned old = atomicOr(&P.claimed[o][fr * bs.claimed + (bit >> 5)], mask);
-#endif
         if (old & mask) continue;
         // one atomic per wave, not per point: ~67 000 points of a 12 MP frame on ONE counter serialise in the L2 (0.65 ms per batch measured)
         const unsigned long long act = __ballot(1);
@@ -1116,6 +1111,9 @@ __global__ __launch_bounds__(1024) void topk_kernel(const KpRec* kps, const unsi
     __syncthreads();
     unsigned M = s_misc[2];
     if (M > TOPK_CAP) { M = TOPK_CAP; if (tid == 0) *overflow = 1; }
+    // retainBest keeps every keypoint tied with the nfeatures-th response; the feature record holds SEL_STRIDE: more than that (nfeatures
+    // close to 2048 and a tie at the boundary) is reported as an overflow rather than cut off silently
+    if (N > K && M > (unsigned)SEL_STRIDE && tid == 0) *overflow = 1;
     // bitonic sort by (k0, k1) of the smallest power of two >= M (padding keys are all-ones and stay last)
     int SN = 64;
     while ((unsigned)SN < M) SN <<= 1;
@@ -1318,9 +1316,9 @@ inline bool blur_streams(const Blur16Args& a, bool bgr, int R, int stream_mode) 
     if (a.ds) ok = ok && R == 8 && (a.h & 1) == 0;
     return ok && ((uintptr_t)a.dst & 7) == 0 && (a.fstride & 3) == 0;
 }
-inline void stream_grid(int w, int h, int& L, int& nstrip, int& nseg, int nb = 1, int waves = 2) {
+inline void stream_grid(int w, int h, int& L, int& nstrip, int& nseg, int nb = 1, int waves = 2, int simds = 1024) {
     static const int units_env = [] { const char* e = getenv("MI355_STREAM_UNITS"); return e ? atoi(e) : 0; }();
-    const int units_target = units_env ? units_env : 1024 * waves;
+    const int units_target = units_env ? units_env : simds * waves;
     static const int stream_minl = [] { const char* e = getenv("MI355_STREAM_MINL"); return e ? atoi(e) : 64; }();
     nstrip = (w + 255) / 256;
     nseg = (units_target + nstrip * nb - 1) / (nstrip * nb);
@@ -1329,8 +1327,9 @@ inline void stream_grid(int w, int h, int& L, int& nstrip, int& nseg, int nb = 1
     L = (L + 1) & ~1;
     nseg = (h + L - 1) / L;
 }
+struct HeavyGeom { int simds = 1024, waves_small = 0, waves_big = 0; };      // SIMDs the pyramid streams may use; waves per SIMD their grids are sized for (0: 4 / 3)
 template <bool BGR>
-bool launch_blur(hipStream_t st, int R, const Blur16Args& a_in, int stream_mode, bool* streamed = nullptr) {
+bool launch_blur(hipStream_t st, int R, const Blur16Args& a_in, int stream_mode, bool* streamed = nullptr, HeavyGeom hg = HeavyGeom()) {
     Blur16Args a = a_in;
     const int nb = a.nb > 1 ? a.nb : 1;
     if (streamed) *streamed = false;
@@ -1338,13 +1337,15 @@ bool launch_blur(hipStream_t st, int R, const Blur16Args& a_in, int stream_mode,
         // barrier-free streaming kernel over the whole chip: W waves per SIMD (W x 1024 waves, one round), segments of >= 64 rows, all frames of
         // a batch in one launch.  The register ring of the row results (4 x (2R + 2) registers) decides W: R <= 8 fits 128 registers, R = 10 / 13 168
         static const int w4 = [] { const char* e = getenv("MI355_STREAM_W4"); return e ? atoi(e) : 8; }();
-        const int waves = (R <= w4 && R <= 8) ? 4 : 3;
+        const int waves = (R <= w4 && R <= 8) ? 4 : 3;                                     // the instantiation (its register budget)
+        const int gwaves = R <= 8 ? (hg.waves_small > 0 && hg.waves_small < waves ? hg.waves_small : waves)      // what the grid fills: fewer leaves registers to other streams' waves
+                                  : (hg.waves_big > 0 && hg.waves_big < waves ? hg.waves_big : waves);
         double ksum = 0.0;
         for (int t = 0; t <= 2 * R; t++) ksum += std::fabs((double)a.k[t]);
         if (ksum < 2.6) {                            // the kernel's rounding assumes results in [0, 32767]: samples <= 255 * 48, taps positive and normalised
             for (int t = 0; t <= R; t++) { a.kp[2 * t] = a.k[t]; a.kp[2 * t + 1] = t ? a.k[t - 1] : 0.0f; }
             int L, nstrip, nseg;
-            stream_grid(a.w, a.h, L, nstrip, nseg, nb, waves);
+            stream_grid(a.w, a.h, L, nstrip, nseg, nb, gwaves, hg.simds);
             const int units = nstrip * nseg * nb;
             const dim3 grid((units + 3) / 4), block(256);
             if (streamed) *streamed = true;
@@ -1386,7 +1387,10 @@ struct SiftWork {
     int w = 0, h = 0;                        // input frame size the buffers are sized for
     int nb = 0;                              // frames the buffers hold
     int n_oct = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;             // pyramid + extrema (and everything else unless `tail` exists)
+    hipStream_t tail = nullptr;               // option sift_split: the keypoint stages of the batch
+    bool own_stream = true;                   // false: `stream` is the ctx's shared heavy stream
+    hipEvent_t heavy_done = nullptr;          // sift_split: end of the batch's pyramid + extrema phase
     hipEvent_t done = nullptr;               // recorded after the last launch of the latest batch
     DevBuf pyr;                              // all Gaussian levels
     DevBuf claimed;                          // duplicate claim bitmaps
@@ -1399,6 +1403,7 @@ struct SiftWork {
     float kern[N_LEVELS][2 * MAX_R + 1];
     int radius[N_LEVELS];
     float kern0[2 * MAX_R + 1]; int radius0 = 0;
+    size_t batches = 0;                      // batches enqueued on this work area
     struct Pend { int img_id; const uint8_t* d_bgr; int ws; hipEvent_t ev; };   // ev: recorded once the batch is enqueued (optional)
     std::vector<Pend> pend;
 };
@@ -1409,12 +1414,15 @@ constexpr int SIFT_SLOTS_MAX = 4;            // batch work areas (each with its 
 void mi_sift_release(mi355_ctx* ctx) {
     for (SiftWork* s : ctx->sift_slots) {
         if (!s) continue;
-        if (s->stream) { (void)hipStreamSynchronize(s->stream); (void)hipStreamDestroy(s->stream); }
+        if (s->stream) { (void)hipStreamSynchronize(s->stream); if (s->own_stream) (void)hipStreamDestroy(s->stream); }
+        if (s->tail) { (void)hipStreamSynchronize(s->tail); (void)hipStreamDestroy(s->tail); }
         if (s->done) (void)hipEventDestroy(s->done);
+        if (s->heavy_done) (void)hipEventDestroy(s->heavy_done);
         s->pyr.release(); s->claimed.release(); s->cand.release(); s->refined.release(); s->kps.release(); s->kresp.release(); s->sel.release(); s->counters.release(); s->rhist.release(); s->ccnt.release(); s->cube.release(); s->olist.release();
         delete s;
     }
     ctx->sift_slots.clear();
+    if (ctx->sift_heavy_stream) { (void)hipStreamDestroy(ctx->sift_heavy_stream); ctx->sift_heavy_stream = nullptr; }
     if (ctx->sift_in_ev) { (void)hipEventDestroy(ctx->sift_in_ev); ctx->sift_in_ev = nullptr; }
     for (int* p : ctx->pinned_chunks) (void)hipHostFree(p);
     ctx->pinned_chunks.clear();
@@ -1422,6 +1430,38 @@ void mi_sift_release(mi355_ctx* ctx) {
 }
 
 static int sift_run_batch(mi355_ctx* ctx, SiftWork* s);
+
+// CU masks (hipExtStreamCreateWithCUMask): bit b of the mask is CU b / 8 of XCD b % 8 on this chip (the driver deals the bits round robin
+// over the XCDs), so the low 8 k bits are k CUs of every XCD
+static void cu_mask_words(int num_cu, int per_xcd, bool complement, std::vector<uint32_t>& m) {
+    m.assign((size_t)(num_cu + 31) / 32, 0u);
+    for (int b = 0; b < num_cu; b++) { const bool in = b < 8 * per_xcd; if (in != complement) m[(size_t)b >> 5] |= 1u << (b & 31); }
+}
+// The streams of one batch work area.  Default: one in-order stream.  Option sift_split: the pyramid + extrema phase and the keypoint stages
+// on two streams (linked by events), so that the chip-filling kernels and the latency-bound ones can be given different queue priorities
+// (sift_prio) or different CUs (tail_cus / heavy_excl), or all work areas share ONE pyramid stream (sift_one_heavy).
+static int sift_make_streams(mi355_ctx* ctx, SiftWork* s) {
+    MI_HIP(hipEventCreateWithFlags(&s->done, hipEventDisableTiming));
+    if (!ctx->sift_split) { MI_HIP(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking)); return MI355_OK; }
+    MI_HIP(hipEventCreateWithFlags(&s->heavy_done, hipEventDisableTiming));
+    int least = 0, greatest = 0;
+    MI_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    std::vector<uint32_t> mask;
+    auto make = [&](hipStream_t* out, bool heavy) -> hipError_t {
+        if (ctx->tail_cus > 0 && (!heavy || ctx->heavy_excl)) {
+            cu_mask_words(ctx->num_cu, ctx->tail_cus, heavy, mask);
+            return hipExtStreamCreateWithCUMask(out, (uint32_t)mask.size(), mask.data());
+        }
+        if (ctx->sift_prio) return hipStreamCreateWithPriority(out, hipStreamNonBlocking, heavy ? greatest : least);
+        return hipStreamCreateWithFlags(out, hipStreamNonBlocking);
+    };
+    if (ctx->sift_one_heavy) {
+        if (!ctx->sift_heavy_stream) MI_HIP(make(&ctx->sift_heavy_stream, true));
+        s->stream = ctx->sift_heavy_stream; s->own_stream = false;
+    } else MI_HIP(make(&s->stream, true));
+    MI_HIP(make(&s->tail, false));
+    return MI355_OK;
+}
 
 // enqueues every partly filled batch
 int mi_sift_flush(mi355_ctx* ctx) {
@@ -1451,7 +1491,7 @@ int mi_resolve_features(mi355_ctx* ctx) {
     bool any = false;
     for (auto& kv : ctx->feats) if (kv.second.pending) { any = true; break; }
     if (!any) { ctx->batch_events_used = 0; return rc; }
-    for (SiftWork* s : ctx->sift_slots) if (s && s->stream) MI_HIP(hipStreamSynchronize(s->stream));
+    for (SiftWork* s : ctx->sift_slots) if (s && s->stream) { MI_HIP(hipStreamSynchronize(s->stream)); if (s->tail) MI_HIP(hipStreamSynchronize(s->tail)); }
     for (auto& kv : ctx->feats) {
         if (!kv.second.pending) continue;
         const int r = adopt_counts(ctx, kv.first, kv.second);
@@ -1501,6 +1541,7 @@ static inline size_t up64(size_t v) { return (v + 63) & ~(size_t)63; }
 static int sift_prepare(mi355_ctx* ctx, SiftWork* s, int w, int h, int nb) {
     if (s->w == w && s->h == h && s->nb == nb) return MI355_OK;
     MI_HIP(hipStreamSynchronize(s->stream));
+    if (s->tail) MI_HIP(hipStreamSynchronize(s->tail));
     if (s->radius0 == 0) {
         // Gaussian kernels (double math on the host, like the oracle): sigma_i = sqrt((s k^i)^2 - (s k^(i-1))^2)
         const double sigma = 1.6, k = std::pow(2.0, 1.0 / N_LAYERS);
@@ -1581,8 +1622,8 @@ int mi_sift_extract_dev(mi355_ctx* ctx, int img_id, const uint8_t* d_bgr, int w,
     const int slot = ctx->sift_next;
     if (!ctx->sift_slots[slot]) {
         ctx->sift_slots[slot] = new SiftWork();
-        MI_HIP(hipStreamCreateWithFlags(&ctx->sift_slots[slot]->stream, hipStreamNonBlocking));
-        MI_HIP(hipEventCreateWithFlags(&ctx->sift_slots[slot]->done, hipEventDisableTiming));
+        const int rc = sift_make_streams(ctx, ctx->sift_slots[slot]);
+        if (rc != MI355_OK) return rc;
     }
     SiftWork* s = ctx->sift_slots[slot];
     int rc = MI355_OK;
@@ -1631,13 +1672,20 @@ static int sift_run_batch(mi355_ctx* ctx, SiftWork* s) {
     const int n = (int)pend.size();
     if (n == 0) return MI355_OK;
     ctx->sift_next = (ctx->sift_next + 1) % SIFT_SLOTS;     // the next batch collects in the next work area
-    const hipStream_t st = s->stream;
+    const hipStream_t st = s->stream;                 // pyramid + extrema
+    const hipStream_t tt = s->tail ? s->tail : st;    // keypoint stages
+    HeavyGeom hg;
+    hg.simds = 4 * (ctx->tail_cus > 0 && ctx->heavy_excl && s->tail ? ctx->num_cu - 8 * ctx->tail_cus : ctx->num_cu);
+    hg.waves_small = ctx->stream_waves_small; hg.waves_big = ctx->stream_waves_big;
+    const int xw = ctx->xwaves > 0 && ctx->xwaves < XWAVES ? ctx->xwaves : XWAVES;
     const int w = s->w, h = s->h;
     const int nf = ctx->p.nfeatures;
     const BatchStride bs = s->bs;
     // the frames were produced on the caller's stream
     MI_HIP(hipEventRecord(ctx->sift_in_ev, ctx->stream));
     MI_HIP(hipStreamWaitEvent(st, ctx->sift_in_ev, 0));
+    if (tt != st && s->batches > 0) MI_HIP(hipStreamWaitEvent(st, s->done, 0));      // the work area's previous batch: its keypoint stages still read the pyramid
+    s->batches++;
     // (measurement mode) the previous batch's pyramid + extrema first.  The wait stands BEFORE the memsets: an event recorded right
     // after a wait takes the end of the stream's last command as its time, which would put the waiting into the first bracket
     const bool serial_heavy = ctx->serial_heavy != 0;
@@ -1671,7 +1719,7 @@ static int sift_run_batch(mi355_ctx* ctx, SiftWork* s) {
             memcpy(a.k, s->kern0, sizeof(float) * (2 * s->radius0 + 1));
             const bool streams = blur_streams(a, true, s->radius0, ctx->blur_stream);
             ProfScope ps(ctx, streams ? "gauss_stream" : "gauss", level_bytes + (double)w * h * 3.0 * n, st);      // read the u8 frames, write level 0
-            if (!launch_blur<true>(st, s->radius0, a, ctx->blur_stream)) { ctx->set_error("sift: unsupported kernel radius"); return MI355_ERR_FAILED; }
+            if (!launch_blur<true>(st, s->radius0, a, ctx->blur_stream, nullptr, hg)) { ctx->set_error("sift: unsupported kernel radius"); return MI355_ERR_FAILED; }
         } else if (!ds_fused) {
             const OctaveDev& pv = s->P.oc[o - 1];
             ProfScope ps(ctx, "downsample", level_bytes * 2.0, st);
@@ -1692,7 +1740,7 @@ static int sift_run_batch(mi355_ctx* ctx, SiftWork* s) {
             }
             const bool streams = blur_streams(a, false, s->radius[i], ctx->blur_stream);
             ProfScope ps(ctx, streams ? "gauss_stream" : "gauss", level_bytes * 2.0, st);   // one read + one write of the level
-            if (!launch_blur<false>(st, s->radius[i], a, ctx->blur_stream)) { ctx->set_error("sift: unsupported kernel radius"); return MI355_ERR_FAILED; }
+            if (!launch_blur<false>(st, s->radius[i], a, ctx->blur_stream, nullptr, hg)) { ctx->set_error("sift: unsupported kernel radius"); return MI355_ERR_FAILED; }
         }
         {
             ProfScope ps(ctx, "extrema", level_bytes * 6.0, st);
@@ -1705,7 +1753,7 @@ static int sift_run_batch(mi355_ctx* ctx, SiftWork* s) {
                 // whole rounds of the 1024 x XWAVES wave slots: the largest k <= 2 whose segments stay >= 64 rows
                 int nseg = 1, L = oc.h;
                 for (int k = 2; k >= 1; k--) {
-                    const int ns = (1024 * XWAVES * k) / (nstrip * n);
+                    const int ns = (hg.simds * xw * k) / (nstrip * n);
                     if (ns < 1) continue;
                     const int l = (oc.h + ns - 1) / ns;
                     if (l >= 64 || k == 1) { L = l < 64 ? 64 : l; break; }
@@ -1724,37 +1772,38 @@ static int sift_run_batch(mi355_ctx* ctx, SiftWork* s) {
         MI_HIP(hipEventRecord(ctx->heavy_ev, st)); ctx->heavy_ev_valid = true;
     }
     // ---- phase 3: keypoint stages of all n frames ----
+    if (tt != st) { MI_HIP(hipEventRecord(s->heavy_done, st)); MI_HIP(hipStreamWaitEvent(tt, s->heavy_done, 0)); }
     {
-        ProfScope ps(ctx, "refine", 0.0, st);
+        ProfScope ps(ctx, "refine", 0.0, tt);
         static const int refine_gx = [] { const char* e = getenv("MI355_REFINE_GX"); return e ? atoi(e) : 2; }();      // workgroups per candidate region: 32 x 64 regions x frames of mostly empty workgroups cost more to dispatch than the fits
-        hipLaunchKernelGGL(refine_kernel, dim3(refine_gx, NREG, n), dim3(256), 0, st, s->P, s->cand.as<unsigned long long>(), s->ccnt.as<unsigned>(), s->cand_cap, cnt + 0,
+        hipLaunchKernelGGL(refine_kernel, dim3(refine_gx, NREG, n), dim3(256), 0, tt, s->P, s->cand.as<unsigned long long>(), s->ccnt.as<unsigned>(), s->cand_cap, cnt + 0,
                            ctx->p.contrast_threshold, ctx->p.edge_threshold, 1.6f, s->refined.as<Refined>(), cnt + 1, s->ref_cap, s->rhist.as<unsigned>(), bs, s->cube.as<float>(), s->cube_cap);
     }
     {
-        ProfScope ps(ctx, "kp_select", 0.0, st);
-        hipLaunchKernelGGL(unclaim_kernel, dim3(128, n), dim3(256), 0, st, s->P, s->refined.as<Refined>(), cnt + 1, s->ref_cap, bs);
-        hipLaunchKernelGGL(resp_threshold_kernel, dim3(n), dim3(1024), 0, st, s->rhist.as<unsigned>(), cnt + 1, s->ref_cap, (unsigned)nf + 256u, cnt + 8, bs.refined, s->olist.as<unsigned>());
+        ProfScope ps(ctx, "kp_select", 0.0, tt);
+        hipLaunchKernelGGL(unclaim_kernel, dim3(128, n), dim3(256), 0, tt, s->P, s->refined.as<Refined>(), cnt + 1, s->ref_cap, bs);
+        hipLaunchKernelGGL(resp_threshold_kernel, dim3(n), dim3(1024), 0, tt, s->rhist.as<unsigned>(), cnt + 1, s->ref_cap, (unsigned)nf + 256u, cnt + 8, bs.refined, s->olist.as<unsigned>());
     }
     for (int pass = 0; pass < 2; pass++) {       // pass 1 (everything below the response threshold) exits at once unless top-k asked for it
         {
-            ProfScope ps(ctx, "orient", 0.0, st);
-            hipLaunchKernelGGL(orient_kernel, dim3(ctx->num_cu * 4, n), dim3(256), 0, st, s->P, s->refined.as<Refined>(), cnt + 1, s->ref_cap,
+            ProfScope ps(ctx, "orient", 0.0, tt);
+            hipLaunchKernelGGL(orient_kernel, dim3(ctx->num_cu * 4, n), dim3(256), 0, tt, s->P, s->refined.as<Refined>(), cnt + 1, s->ref_cap,
                                s->kps.as<KpRec>(), s->kresp.as<unsigned>(), cnt + 2, s->kp_cap, cnt + 8, pass, bs, s->olist.as<unsigned>());
         }
         {
-            ProfScope ps(ctx, "topk", 0.0, st);
-            hipLaunchKernelGGL(topk_kernel, dim3(n), dim3(1024), 0, st, s->kps.as<KpRec>(), s->kresp.as<unsigned>(), cnt + 2, s->kp_cap, nf,
+            ProfScope ps(ctx, "topk", 0.0, tt);
+            hipLaunchKernelGGL(topk_kernel, dim3(n), dim3(1024), 0, tt, s->kps.as<KpRec>(), s->kresp.as<unsigned>(), cnt + 2, s->kp_cap, nf,
                                outs, s->sel.as<SelRec>(), reinterpret_cast<int*>(cnt + 3), reinterpret_cast<int*>(cnt + 4), cnt + 8, pass, bs);
         }
     }
     {
-        ProfScope ps(ctx, "describe", 0.0, st);
-        hipLaunchKernelGGL(describe_kernel, dim3(((int)SEL_STRIDE + 3) / 4, n), dim3(256), 0, st, s->P, s->sel.as<SelRec>(), reinterpret_cast<const int*>(cnt + 3), outs, bs);
+        ProfScope ps(ctx, "describe", 0.0, tt);
+        hipLaunchKernelGGL(describe_kernel, dim3(((int)SEL_STRIDE + 3) / 4, n), dim3(256), 0, tt, s->P, s->sel.as<SelRec>(), reinterpret_cast<const int*>(cnt + 3), outs, bs);
     }
     MI_HIP(hipGetLastError());
     // the matcher's operands of all n frames in one launch, their counters in one strided copy (n launches + n copies of ~5 us each kept
     // the batch's stream, and a pipeline slot, busy for 0.3 ms per batch of 32)
-    { int rc = mi_finish_features_batch(ctx, fs.data(), n, reinterpret_cast<const int*>(cnt + 3), (int)CNT_STRIDE, st); if (rc != MI355_OK) return rc; }
+    { int rc = mi_finish_features_batch(ctx, fs.data(), n, reinterpret_cast<const int*>(cnt + 3), (int)CNT_STRIDE, tt); if (rc != MI355_OK) return rc; }
     {
         if (ctx->pinned_used % PINNED_CHUNK + (size_t)n > PINNED_CHUNK) ctx->pinned_used += PINNED_CHUNK - ctx->pinned_used % PINNED_CHUNK;   // n slots in one chunk
         int* h0 = nullptr;
@@ -1766,9 +1815,9 @@ static int sift_run_batch(mi355_ctx* ctx, SiftWork* s) {
             f.h_cnt = hc; f.pending = true; f.n = 0;
             f.caps[0] = 0xffffffffu; f.caps[1] = s->ref_cap; f.caps[2] = s->kp_cap;      // candidate overflow is flagged by the kernel (cnt[4])
         }
-        MI_HIP(hipMemcpy2DAsync(h0, 8 * sizeof(int), cnt, CNT_STRIDE * sizeof(unsigned), 8 * sizeof(unsigned), (size_t)n, hipMemcpyDeviceToHost, st));
+        MI_HIP(hipMemcpy2DAsync(h0, 8 * sizeof(int), cnt, CNT_STRIDE * sizeof(unsigned), 8 * sizeof(unsigned), (size_t)n, hipMemcpyDeviceToHost, tt));
     }
-    MI_HIP(hipEventRecord(s->done, st));
+    MI_HIP(hipEventRecord(s->done, tt));
     {                                                       // the batch's own event: mi_resolve_features_of() waits for it, not for the streams
         if (ctx->batch_events_used >= ctx->batch_events.size()) {
             hipEvent_t e = nullptr;
@@ -1776,10 +1825,10 @@ static int sift_run_batch(mi355_ctx* ctx, SiftWork* s) {
             ctx->batch_events.push_back(e);
         }
         hipEvent_t e = ctx->batch_events[ctx->batch_events_used++];
-        MI_HIP(hipEventRecord(e, st));
+        MI_HIP(hipEventRecord(e, tt));
         for (int k = 0; k < n; k++) fs[k]->ready = e;
     }
-    for (int k = 0; k < n; k++) if (pend[k].ev) MI_HIP(hipEventRecord(pend[k].ev, st));
+    for (int k = 0; k < n; k++) if (pend[k].ev) MI_HIP(hipEventRecord(pend[k].ev, tt));
     return MI355_OK;
 }
 

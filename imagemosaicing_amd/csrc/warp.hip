@@ -487,14 +487,15 @@ constexpr int OWN_ROWS = 4;
 // mask pointer -> mask byte) and the kernel ran at 0.2 TB/s of its own byte traffic.
 struct OwnEntry { int x0, y0, w, h, mws, k; float maxv; int pad; uint8_t* mask; LineSet L; };
 __global__ __launch_bounds__(256) void owner_kernel(const ChipDev* chips, const LineSet* lines, const unsigned* maxbits, const int* list_off, const int* list,
-                                                    int bx_n, int rectW, int rectH, uint8_t* const* masks) {
+                                                    int bx_n, int rectW, int rectH, uint8_t* const* masks, int row_beg) {
     constexpr int NE = 32;
     __shared__ OwnEntry s_e[NE];
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    const int r = (blockIdx.y * blockDim.y + threadIdx.y) * OWN_ROWS;                                  // first of the thread's rows
+    // row_beg (a multiple of the workgroup's 16 rows) .. rectH - 1: the canvas rows this launch decides (a stripe of the canvas, or all of it)
+    const int r = row_beg + (blockIdx.y * blockDim.y + threadIdx.y) * OWN_ROWS;                        // first of the thread's rows
     const int tid = threadIdx.y * blockDim.x + threadIdx.x;
     const bool inside = c < rectW && r < rectH;
-    const int rb = (blockIdx.y * blockDim.y * OWN_ROWS) / OWN_BLK, cb = (blockIdx.x * blockDim.x) / OWN_BLK;      // the workgroup (64 x 16 pixels) lies inside one block
+    const int rb = (row_beg + blockIdx.y * blockDim.y * OWN_ROWS) / OWN_BLK, cb = (blockIdx.x * blockDim.x) / OWN_BLK;      // the workgroup (64 x 16 pixels) lies inside one block
     const int blk = rb * bx_n + cb;
     const int l0 = list_off[blk], l1 = list_off[blk + 1];
     // One walk over the candidates (round 4; it was two: find the owner, then rewrite every covering chip's byte).  Afterwards the owner's
@@ -571,15 +572,19 @@ __global__ __launch_bounds__(256) void owner_kernel(const ChipDev* chips, const 
 // be non-zero (blend.hip chip_windows).  One launch for all chips, a workgroup per 256 x 64 mask block (one 32-bit load per lane and row);
 // only the workgroups that meet a non-zero byte -- a chip owns a few percent of its area in a dense survey -- end with atomics.
 // (Tracked inside owner_kernel instead, every wave of a cell moved the maximum row: 12 000 atomics per address, 7 -> 18 ms per canvas.)
-__global__ __launch_bounds__(256) void mask_bbox_kernel(const ChipDev* chips, uint8_t* const* masks, int* bbox_min, int* bbox_max) {
+__global__ __launch_bounds__(256) void mask_bbox_kernel(const ChipDev* chips, uint8_t* const* masks, int* bbox_min, int* bbox_max, int row_lo, int row_hi) {
     const ChipDev cd = chips[blockIdx.z];
     const int c0 = (blockIdx.x * 64 + threadIdx.x) * 4, r0 = blockIdx.y * 64;
     if (blockIdx.x * 256 >= cd.w || r0 >= cd.h) return;
+    // only the canvas rows row_lo .. row_hi were decided by owner_kernel (a stripe; the whole canvas otherwise): the rest of the mask still
+    // holds validity and is not part of the box
+    if (cd.y0 + r0 + 63 < row_lo || cd.y0 + r0 > row_hi) return;
     const uint8_t* mask = masks[blockIdx.z];
     int xa = 0x7fffffff, xb = -1, ya = 0x7fffffff, yb = -1;
     if (c0 < cd.w) {
 #pragma unroll 4
         for (int r = r0 + threadIdx.y; r < r0 + 64 && r < cd.h; r += 4) {
+            if (cd.y0 + r < row_lo || cd.y0 + r > row_hi) continue;
             unsigned mm = *reinterpret_cast<const unsigned*>(mask + (size_t)r * cd.mws + c0);      // mws and c0 are multiples of 4
             if (c0 + 3 >= cd.w) mm &= 0xffffffffu >> (8 * (c0 + 4 - cd.w));                        // row padding is not part of the chip
             if (mm) {
@@ -618,10 +623,14 @@ __global__ __launch_bounds__(256) void mask_bbox_kernel(const ChipDev* chips, ui
 
 // Device stage of the chips: layout on the host, warps / distance maps / ownership on the device.  The chips and masks
 // stay in ctx buffers "chip_imgs" / "chip_masks" at chip_off[v] / mask_off[v]; *chips_out is malloc'd.
+// row_lo .. row_hi (canvas rows, inclusive; the default is the whole canvas): a STRIPE of the canvas -- only the chips that reach these rows
+// (widened to whole groups of 16) get storage, validity masks, a maximum distance, and ownership is decided for these rows only; the owned
+// boxes are the boxes inside the stripe, and the chips outside it report an empty box.  What is decided is what the whole canvas gives
+// there: ownership is per canvas pixel among the chips that cover it, and a chip's maximum distance is taken over the whole chip.
 int mi_chips_and_masks_dev(mi355_ctx* ctx, const uint8_t* const* imgs, const int* w, const int* h, const int* ws, int n,
                            const float* h9s, const uint8_t* keep, int find_masks, int* n_chips, mi355_chip_info** chips_out,
                            std::vector<size_t>& chip_off, std::vector<size_t>& mask_off, int* cw_out, int* ch_out, int imgs_on_device,
-                           std::vector<int>* owned_bbox, int defer_pixels) {
+                           std::vector<int>* owned_bbox, int defer_pixels, int row_lo, int row_hi) {
     if (!imgs || !w || !h || !ws || !h9s || n <= 0 || !n_chips || !chips_out) return MI355_ERR_ARG;
     // ---- layout, MosaicImage.cpp:2233-2343 (host, same float ops) ----
     float maxX = 0.0f, maxY = 0.0f, minX = 0.0f, minY = 0.0f;                     // :2234 (canvas always contains the origin)
@@ -642,11 +651,18 @@ int mi_chips_and_masks_dev(mi355_ctx* ctx, const uint8_t* const* imgs, const int
     const float dGx = -minX, dGy = -minY;
     const int newW = (int)(maxX - minX + 1.5f), newH = (int)(maxY - minY + 1.5f);
     const int nv = (int)kept.size();
+    // the stripe in whole groups of owner_kernel's 16 rows
+    const bool striped = row_lo > 0 || row_hi < newH - 1;
+    if (striped && (!find_masks || !defer_pixels || !owned_bbox)) { ctx->set_error("chips: a row window needs the one-call blend's form"); return MI355_ERR_ARG; }
+    const int row_beg = (row_lo < 0 ? 0 : row_lo) & ~(4 * OWN_ROWS - 1);
+    int row_end = row_hi >= newH - 1 ? newH : ((row_hi + 4 * OWN_ROWS) & ~(4 * OWN_ROWS - 1));      // exclusive
+    if (row_end > newH) row_end = newH;
     // released on every failure path below; handed to the caller only on success
     std::unique_ptr<mi355_chip_info, void (*)(void*)> ci_hold((mi355_chip_info*)calloc((size_t)(nv > 0 ? nv : 1), sizeof(mi355_chip_info)), free);
     mi355_chip_info* ci = ci_hold.get();
     if (!ci) return MI355_ERR_NOMEM;
     std::vector<ChipDev> cd(nv);
+    std::vector<int> av;                                     // the chips that reach the stripe, ascending (= the reference's order)
     size_t map_total = 0, chip_total = 0, mask_total = 0;
     chip_off.assign(nv, 0); mask_off.assign(nv, 0);
     for (int v = 0; v < nv; v++) {
@@ -667,11 +683,15 @@ int mi_chips_and_masks_dev(mi355_ctx* ctx, const uint8_t* const* imgs, const int
         }
         if (c.w <= 0 || c.h <= 0) { ctx->set_error("chips: empty chip"); return MI355_ERR_FAILED; }
         const int cws = (c.w * 3 + 3) & ~3, mws = (c.w + 3) & ~3;
+        cd[v] = ChipDev{c.x0, c.y0, c.w, c.h, mws, 0};
+        if (striped && (c.y0 + c.h - 1 < row_beg || c.y0 >= row_end)) continue;                      // does not reach the stripe
         chip_off[v] = chip_total; mask_off[v] = mask_total;
         chip_total += (size_t)cws * c.h; mask_total += (size_t)mws * c.h;
-        cd[v] = ChipDev{c.x0, c.y0, c.w, c.h, mws, map_total};
+        cd[v].map_off = map_total;
         map_total += (size_t)mws * c.h;
+        av.push_back(v);
     }
+    const int na = (int)av.size();
     DevBuf& dchips = ctx->buf("chip_imgs");
     DevBuf& dmasks = ctx->buf("chip_masks");
     DevBuf& dsrc = ctx->buf("warp_src");
@@ -684,19 +704,20 @@ int mi_chips_and_masks_dev(mi355_ctx* ctx, const uint8_t* const* imgs, const int
         MI_HIP(hipMemsetAsync(dchips.p, 0, chip_total, ctx->stream));
         MI_HIP(hipMemsetAsync(dmasks.p, 0, mask_total, ctx->stream));
     }
-    if (defer_pixels) ctx->deferred_warps.resize(sizeof(WarpArgs) * (size_t)nv);
+    if (defer_pixels) ctx->deferred_warps.assign(sizeof(WarpArgs) * (size_t)nv, 0);
     // every kept source is staged in HBM up front (frames stay resident: 288 GB), so uploads and warps of consecutive chips
     // overlap on the stream instead of synchronising per chip
     std::vector<size_t> src_off(nv, 0);
     size_t src_total = 0;
-    for (int v = 0; v < nv; v++) {
+    for (int v : av) {
         const int k = kept[v];
         if (!imgs[k] || w[k] < 2 || h[k] < 2 || ws[k] < 3 * w[k]) { ctx->set_error("chips: bad image geometry"); return MI355_ERR_ARG; }
         src_off[v] = src_total; src_total += ((size_t)ws[k] * h[k] + 255) & ~(size_t)255;
     }
     if (!imgs_on_device) MI_HIP(dsrc.reserve(src_total + 16));
-    for (int v = 0; v < nv; v++) {
-        const int k = kept[v];
+    std::vector<WarpArgs> wargs((size_t)(na > 0 ? na : 1));
+    for (int q = 0; q < na; q++) {
+        const int v = av[q], k = kept[v];
         const mi355_chip_info& c = ci[v];
         WarpArgs a;
         memset(&a, 0, sizeof(a));
@@ -708,51 +729,58 @@ int mi_chips_and_masks_dev(mi355_ctx* ctx, const uint8_t* const* imgs, const int
         a.mask = dmasks.as<uint8_t>() + mask_off[v]; a.mws = cd[v].mws;
         a.x_beg = 0; a.x_end = c.w - 1; a.y_beg = 0; a.y_end = c.h - 1;
         a.dx = dGx; a.dy = dGy; a.sx = c.sx; a.sy = c.sy; a.x0 = c.x0; a.y0 = c.y0;
-        if (defer_pixels) memcpy(ctx->deferred_warps.data() + sizeof(WarpArgs) * (size_t)v, &a, sizeof(a));
+        if (defer_pixels) { memcpy(ctx->deferred_warps.data() + sizeof(WarpArgs) * (size_t)v, &a, sizeof(a)); wargs[q] = a; }
         else launch_warp<3, true>(ctx, a);
     }
-    if (defer_pixels && nv > 0) {                       // validity masks of all chips: one launch
+    if (defer_pixels && na > 0) {                       // validity masks of all chips: one launch
         DevBuf& dwa = ctx->buf("chip_warp_args");
-        MI_HIP(dwa.reserve(sizeof(WarpArgs) * (size_t)nv));
-        MI_HIP(hipMemcpyAsync(dwa.p, ctx->deferred_warps.data(), sizeof(WarpArgs) * (size_t)nv, hipMemcpyHostToDevice, ctx->stream));
+        MI_HIP(dwa.reserve(sizeof(WarpArgs) * (size_t)na));
+        MI_HIP(hipMemcpyAsync(dwa.p, wargs.data(), sizeof(WarpArgs) * (size_t)na, hipMemcpyHostToDevice, ctx->stream));
+        MI_HIP(hipStreamSynchronize(ctx->stream));      // `wargs` is a local: the copy must have read it before it goes
         int mw = 1, mh = 1;
-        for (int v = 0; v < nv; v++) { if (ci[v].w > mw) mw = ci[v].w; if (ci[v].h > mh) mh = ci[v].h; }
+        for (int v : av) { if (ci[v].w > mw) mw = ci[v].w; if (ci[v].h > mh) mh = ci[v].h; }
         ProfScope ps(ctx, "warp", (double)mask_total);
-        for (int v0 = 0; v0 < nv; v0 += 65535)
-            hipLaunchKernelGGL((warp_chips_kernel<1>), dim3(((mw + 3) / 4 + 63) / 64, (mh + 3) / 4, nv - v0 < 65535 ? nv - v0 : 65535), dim3(64, 4), 0, ctx->stream,
+        for (int v0 = 0; v0 < na; v0 += 65535)
+            hipLaunchKernelGGL((warp_chips_kernel<1>), dim3(((mw + 3) / 4 + 63) / 64, (mh + 3) / 4, na - v0 < 65535 ? na - v0 : 65535), dim3(64, 4), 0, ctx->stream,
                                dwa.as<WarpArgs>() + v0);
     }
     // validity masks are final here unless the distance-map ownership is requested
-    if (find_masks && nv > 0) {
-        // chip lists per 256 x 256 canvas block (host: the chips' rectangles are known), ascending chip index inside a block
+    if (find_masks && na > 0) {
+        // chip lists per 256 x 256 canvas block (host: the chips' rectangles are known), ascending chip index inside a block; entries are
+        // positions in `av`
         const int bx_n = (newW + OWN_BLK - 1) / OWN_BLK, by_n = (newH + OWN_BLK - 1) / OWN_BLK;
         std::vector<int> loff((size_t)bx_n * by_n + 1, 0);
-        for (int v = 0; v < nv; v++) {
+        for (int q = 0; q < na; q++) {
+            const int v = av[q];
             const int bx0 = std::max(0, ci[v].x0 / OWN_BLK), bx1 = std::min(bx_n - 1, (ci[v].x0 + ci[v].w - 1) / OWN_BLK);
             const int by0 = std::max(0, ci[v].y0 / OWN_BLK), by1 = std::min(by_n - 1, (ci[v].y0 + ci[v].h - 1) / OWN_BLK);
             for (int by = by0; by <= by1; by++) for (int bx = bx0; bx <= bx1; bx++) loff[(size_t)by * bx_n + bx + 1]++;
         }
         for (size_t q = 1; q < loff.size(); q++) loff[q] += loff[q - 1];
         std::vector<int> lst((size_t)loff.back() > 0 ? loff.back() : 1), fill(loff.begin(), loff.end() - 1);
-        for (int v = 0; v < nv; v++) {
+        for (int q = 0; q < na; q++) {
+            const int v = av[q];
             const int bx0 = std::max(0, ci[v].x0 / OWN_BLK), bx1 = std::min(bx_n - 1, (ci[v].x0 + ci[v].w - 1) / OWN_BLK);
             const int by0 = std::max(0, ci[v].y0 / OWN_BLK), by1 = std::min(by_n - 1, (ci[v].y0 + ci[v].h - 1) / OWN_BLK);
-            for (int by = by0; by <= by1; by++) for (int bx = bx0; bx <= bx1; bx++) lst[fill[(size_t)by * bx_n + bx]++] = v;
+            for (int by = by0; by <= by1; by++) for (int bx = bx0; bx <= bx1; bx++) lst[fill[(size_t)by * bx_n + bx]++] = q;
         }
-        std::vector<LineSet> lines(nv);
-        for (int v = 0; v < nv; v++) {
-            const float* q = ci[v].quad;
-            LineSet& L = lines[v];
-            line_of_2_points(L.A[0], L.B[0], L.C[0], q[0], q[1], q[2], q[3]);
-            line_of_2_points(L.A[1], L.B[1], L.C[1], q[2], q[3], q[4], q[5]);
-            line_of_2_points(L.A[2], L.B[2], L.C[2], q[4], q[5], q[6], q[7]);
-            line_of_2_points(L.A[3], L.B[3], L.C[3], q[6], q[7], q[0], q[1]);
+        std::vector<LineSet> lines(na);
+        std::vector<ChipDev> cda(na);
+        for (int q = 0; q < na; q++) {
+            const int v = av[q];
+            cda[q] = cd[v];
+            const float* qd = ci[v].quad;
+            LineSet& L = lines[q];
+            line_of_2_points(L.A[0], L.B[0], L.C[0], qd[0], qd[1], qd[2], qd[3]);
+            line_of_2_points(L.A[1], L.B[1], L.C[1], qd[2], qd[3], qd[4], qd[5]);
+            line_of_2_points(L.A[2], L.B[2], L.C[2], qd[4], qd[5], qd[6], qd[7]);
+            line_of_2_points(L.A[3], L.B[3], L.C[3], qd[6], qd[7], qd[0], qd[1]);
             for (int i = 0; i < 4; i++) L.inv[i] = 1.0f / sqrtf(L.A[i] * L.A[i] + L.B[i] * L.B[i]);       // :1786
         }
         auto up16 = [](size_t b) { return (b + 15) & ~(size_t)15; };
-        const size_t o_cd = 0, o_mp = up16(o_cd + sizeof(ChipDev) * nv), o_mx = up16(o_mp + sizeof(uint8_t*) * nv), o_ln = up16(o_mx + sizeof(unsigned) * nv),
-                     o_lo = up16(o_ln + sizeof(LineSet) * nv), o_ls = up16(o_lo + sizeof(int) * loff.size()), o_bb = up16(o_ls + sizeof(int) * lst.size()),
-                     meta_bytes = o_bb + sizeof(int) * 4 * nv;
+        const size_t o_cd = 0, o_mp = up16(o_cd + sizeof(ChipDev) * na), o_mx = up16(o_mp + sizeof(uint8_t*) * na), o_ln = up16(o_mx + sizeof(unsigned) * na),
+                     o_lo = up16(o_ln + sizeof(LineSet) * na), o_ls = up16(o_lo + sizeof(int) * loff.size()), o_bb = up16(o_ls + sizeof(int) * lst.size()),
+                     meta_bytes = o_bb + sizeof(int) * 4 * na;
         MI_HIP(dmeta.reserve(meta_bytes + 64));
         uint8_t* mb = dmeta.as<uint8_t>();
         ChipDev* d_cd = reinterpret_cast<ChipDev*>(mb + o_cd);
@@ -764,45 +792,47 @@ int mi_chips_and_masks_dev(mi355_ctx* ctx, const uint8_t* const* imgs, const int
         // one host image of the whole meta area, one copy (six small copies from pageable memory cost ~0.35 ms each on the stream): chip
         // descriptors, mask pointers, the maxima (zero), the edge lines, the block lists, the owned boxes' start values
         std::vector<uint8_t> blob(meta_bytes, 0);
-        memcpy(blob.data() + o_cd, cd.data(), sizeof(ChipDev) * nv);
-        for (int v = 0; v < nv; v++) { uint8_t* mp = dmasks.as<uint8_t>() + mask_off[v]; memcpy(blob.data() + o_mp + sizeof(uint8_t*) * v, &mp, sizeof(mp)); }
-        memcpy(blob.data() + o_ln, lines.data(), sizeof(LineSet) * nv);
+        memcpy(blob.data() + o_cd, cda.data(), sizeof(ChipDev) * na);
+        for (int q = 0; q < na; q++) { uint8_t* mp = dmasks.as<uint8_t>() + mask_off[av[q]]; memcpy(blob.data() + o_mp + sizeof(uint8_t*) * q, &mp, sizeof(mp)); }
+        memcpy(blob.data() + o_ln, lines.data(), sizeof(LineSet) * na);
         memcpy(blob.data() + o_lo, loff.data(), sizeof(int) * loff.size());
         memcpy(blob.data() + o_ls, lst.data(), sizeof(int) * lst.size());
-        memset(blob.data() + o_bb, 0x7f, sizeof(int) * 2 * nv);
-        memset(blob.data() + o_bb + sizeof(int) * 2 * nv, 0xff, sizeof(int) * 2 * nv);
+        memset(blob.data() + o_bb, 0x7f, sizeof(int) * 2 * na);
+        memset(blob.data() + o_bb + sizeof(int) * 2 * na, 0xff, sizeof(int) * 2 * na);
         MI_HIP(hipMemcpyAsync(mb, blob.data(), meta_bytes, hipMemcpyHostToDevice, ctx->stream));
-        int* d_bbmin = owned_bbox ? reinterpret_cast<int*>(mb + o_bb) : nullptr;      // [2 nv] minima, then [2 nv] maxima
-        int* d_bbmax = owned_bbox ? d_bbmin + 2 * nv : nullptr;
+        int* d_bbmin = owned_bbox ? reinterpret_cast<int*>(mb + o_bb) : nullptr;      // [2 na] minima, then [2 na] maxima
+        int* d_bbmax = owned_bbox ? d_bbmin + 2 * na : nullptr;
         dim3 block(64, 4);
+        int mw = 1, mh = 1;
+        for (int v : av) { if (ci[v].w > mw) mw = ci[v].w; if (ci[v].h > mh) mh = ci[v].h; }
         {
             ProfScope ps(ctx, "distmap", (double)chip_total / 3.0);
-            int mw = 1, mh = 1;
-            for (int v = 0; v < nv; v++) { if (ci[v].w > mw) mw = ci[v].w; if (ci[v].h > mh) mh = ci[v].h; }
-            for (int v0 = 0; v0 < nv; v0 += 65535)      // gridDim.z limit
-                hipLaunchKernelGGL(distmax_kernel, dim3((mw + 255) / 256, (mh + 63) / 64, nv - v0 < 65535 ? nv - v0 : 65535), block, 0, ctx->stream,
+            for (int v0 = 0; v0 < na; v0 += 65535)      // gridDim.z limit
+                hipLaunchKernelGGL(distmax_kernel, dim3((mw + 255) / 256, (mh + 63) / 64, na - v0 < 65535 ? na - v0 : 65535), block, 0, ctx->stream,
                                    d_cd + v0, d_mptr + v0, d_lines + v0, d_max + v0);
         }
-        dim3 grid((newW + 63) / 64, (newH + 4 * OWN_ROWS - 1) / (4 * OWN_ROWS));
+        dim3 grid((newW + 63) / 64, (row_end - row_beg + 4 * OWN_ROWS - 1) / (4 * OWN_ROWS));
         {
-            ProfScope ps(ctx, "owner", (double)newW * newH);
-            hipLaunchKernelGGL(owner_kernel, grid, block, 0, ctx->stream, d_cd, d_lines, d_max, d_loff, d_list, bx_n, newW, newH, d_mptr);
+            ProfScope ps(ctx, "owner", (double)newW * (row_end - row_beg));
+            hipLaunchKernelGGL(owner_kernel, grid, block, 0, ctx->stream, d_cd, d_lines, d_max, d_loff, d_list, bx_n, newW, row_end, d_mptr, row_beg);
         }
         if (owned_bbox) {
             ProfScope ps(ctx, "distmap", (double)chip_total / 3.0);
-            int mw = 1, mh = 1;
-            for (int v = 0; v < nv; v++) { if (ci[v].w > mw) mw = ci[v].w; if (ci[v].h > mh) mh = ci[v].h; }
-            for (int v0 = 0; v0 < nv; v0 += 65535)
-                hipLaunchKernelGGL(mask_bbox_kernel, dim3((mw + 255) / 256, (mh + 63) / 64, nv - v0 < 65535 ? nv - v0 : 65535), block, 0, ctx->stream,
-                                   d_cd + v0, d_mptr + v0, d_bbmin + 2 * v0, d_bbmax + 2 * v0);
+            for (int v0 = 0; v0 < na; v0 += 65535)
+                hipLaunchKernelGGL(mask_bbox_kernel, dim3((mw + 255) / 256, (mh + 63) / 64, na - v0 < 65535 ? na - v0 : 65535), block, 0, ctx->stream,
+                                   d_cd + v0, d_mptr + v0, d_bbmin + 2 * v0, d_bbmax + 2 * v0, row_beg, row_end - 1);
         }
         std::vector<int> bb;
-        if (owned_bbox) { bb.resize((size_t)4 * nv); MI_HIP(hipMemcpyAsync(bb.data(), d_bbmin, sizeof(int) * 4 * nv, hipMemcpyDeviceToHost, ctx->stream)); }
+        if (owned_bbox) { bb.resize((size_t)4 * na); MI_HIP(hipMemcpyAsync(bb.data(), d_bbmin, sizeof(int) * 4 * na, hipMemcpyDeviceToHost, ctx->stream)); }
         MI_HIP(hipStreamSynchronize(ctx->stream));        // the host vectors above were sources of asynchronous copies
         if (owned_bbox) {
-            owned_bbox->resize((size_t)4 * nv);
-            for (int v = 0; v < nv; v++) { int* o = owned_bbox->data() + 4 * v; o[0] = bb[2 * v]; o[1] = bb[2 * v + 1]; o[2] = bb[2 * nv + 2 * v]; o[3] = bb[2 * nv + 2 * v + 1]; }
+            owned_bbox->assign((size_t)4 * nv, 0);
+            for (int v = 0; v < nv; v++) { int* o = owned_bbox->data() + 4 * v; o[0] = 0; o[1] = 0; o[2] = -1; o[3] = -1; }      // chips outside the stripe: nothing owned
+            for (int q = 0; q < na; q++) { int* o = owned_bbox->data() + 4 * av[q]; o[0] = bb[2 * q]; o[1] = bb[2 * q + 1]; o[2] = bb[2 * na + 2 * q]; o[3] = bb[2 * na + 2 * q + 1]; }
         }
+    } else if (owned_bbox && find_masks) {
+        owned_bbox->assign((size_t)4 * nv, 0);
+        for (int v = 0; v < nv; v++) { int* o = owned_bbox->data() + 4 * v; o[2] = -1; o[3] = -1; }
     }
     MI_HIP(hipGetLastError());
     *n_chips = nv; *chips_out = ci_hold.release();

@@ -207,6 +207,15 @@ int  mi355_mosaic_blended(mi355_ctx* ctx, const uint8_t* const* imgs, const int*
  * mi355_mosaic_blended.  Returns when the work is enqueued on the ctx stream (mi355_synchronize). */
 int  mi355_mosaic_blended_dev(mi355_ctx* ctx, const uint8_t* const* d_imgs, const int* w, const int* h, const int* ws, int n, const float* h9s,
                               const uint8_t* keep, int band, uint8_t* d_canvas, int cw, int ch, int cws);
+/* One horizontal STRIPE of that canvas: rows row0 .. row0 + rows - 1 go to d_rows (rows x cws bytes; cw, ch, cws are still the WHOLE
+ * canvas's, from mi355_blend_layout).  This is a rank's share of the reference's default compositing path (blending = 2,
+ * MosaicWithoutPos.h:57-79 -> LaplacianPyramidBlending, MosaicImage.cpp:2205-2510) when the canvas is cut into G stripes like
+ * mi355_mosaic_refined_dev's: the rank forms the chips that reach its rows plus the pyramids' reach (3 * 2^band rows of feed gap, the
+ * REDUCE / EXPAND taps per level), FindMasksByDistMap's ownership there (MosaicImage.cpp:1842-1872: per canvas pixel) and the rows of
+ * every blender level its output depends on (MosaicImage.cpp:2296-2299, 2471-2486).  Stripes put side by side are the bytes of
+ * mi355_mosaic_blended_dev, whatever the cut. */
+int  mi355_mosaic_blended_rows_dev(mi355_ctx* ctx, const uint8_t* const* d_imgs, const int* w, const int* h, const int* ws, int n, const float* h9s,
+                                   const uint8_t* keep, int band, uint8_t* d_rows, int cw, int ch, int cws, int row0, int rows);
 /* canvas size of LaplacianPyramidBlending for these transforms (MosaicImage.cpp:2233-2292; host geometry, no ctx) */
 int  mi355_blend_layout(const int* w, const int* h, int n, const float* h9s, const uint8_t* keep, int* cw, int* ch, int* cws);
 

@@ -5,7 +5,9 @@ F=${3:-sift}
 cd "$(dirname "$0")/.."
 mkdir -p scratch/variants
 B=imagemosaicing_amd/csrc/build
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wno-unused-result $2 -Iinclude -x hip -c imagemosaicing_amd/csrc/$F.hip -o scratch/variants/${F}_$1.o 2>&1 | grep -E "error" || true
+python -c "from imagemosaicing_amd import build as b; b.generate()"      # blur16_asm.inc (generated, lives in $B)
+PF=""; [ "$F" = ransac ] && PF="-fno-slp-vectorize"                      # build.py PER_FILE
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wno-unused-result $PF $2 -Iinclude -I$B -x hip -c imagemosaicing_amd/csrc/$F.hip -o scratch/variants/${F}_$1.o
 OBJS=$(ls $B/*.o | grep -v $F.hip.o)
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o scratch/variants/lib_$1.so scratch/variants/${F}_$1.o $OBJS
 rm -f scratch/variants/${F}_$1.o

@@ -211,3 +211,45 @@ def test_gpu_blend_active_windows_dense_survey(oracle):
             assert (ow, oh) == (r["cw"], r["ch"])
             assert np.array_equal(got, ref), f"trial {trial} band {band}: {(got != ref).sum()} bytes differ"
     ctx.close()
+
+
+@pytest.mark.gpu
+def test_gpu_blend_stripes_equal_whole_canvas():
+    """mi355_mosaic_blended_rows_dev: a rank's stripe of LaplacianPyramidBlending (the default compositing path, blending = 2).  Stripes put
+    side by side must be the whole canvas byte for byte, whatever the cut: eight even stripes, single rows, cuts that are odd, that fall
+    inside one 2^band block, at the canvas's first and last rows -- on dense piles of small frames (cells of a few dozen pixels, chips that
+    own nothing, chips that reach several stripes) and for several pyramid depths.  (The whole canvas equals the oracle's:
+    test_gpu_blend_active_windows_dense_survey, same surveys.)"""
+    import torch
+    import imagemosaicing_amd as im
+    rng = np.random.default_rng(20261001)
+    ctx = im.Context(0)
+    dev = torch.device("cuda", 0)
+    for trial, (n, w, h, spread) in enumerate([(24, 320, 240, 260.0), (40, 200, 152, 120.0), (9, 413, 307, 500.0), (30, 256, 192, 900.0)]):
+        imgs, h9s = [], []
+        for k in range(n):
+            imgs.append(texture(w, h, seed=300 * trial + k))
+            yaw = np.deg2rad(rng.uniform(-8, 8)); s = 1 + rng.uniform(-0.03, 0.03)
+            tx, ty = (0.0, 0.0) if k == 0 else rng.uniform(0, spread, 2)
+            H = np.array([[s * np.cos(yaw), -s * np.sin(yaw), tx], [s * np.sin(yaw), s * np.cos(yaw), ty], [0, 0, 1]], np.float32)
+            h9s.append(H.reshape(9))
+        h9s = np.stack(h9s)
+        h9s[n - 1] = h9s[n // 2]; imgs[n - 1] = imgs[n // 2].copy()
+        d_imgs = [torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in imgs]
+        ptrs = [t.data_ptr() for t in d_imgs]
+        wv, hv, wsv = [w] * n, [h] * n, [imgs[0].strides[0]] * n
+        keep = None if trial != 1 else (np.arange(n) % 7 != 3).astype(np.uint8)
+        for band in (5, 3, 1):
+            whole, cw, ch, cws = ctx.MosaicBlendedDev(ptrs, wv, hv, wsv, h9s, keep=keep, band=band)
+            whole = whole.cpu().numpy()
+            cuts = [list(np.linspace(0, ch, 9).astype(int)),                                    # eight stripes
+                    [0, 1, 2, 33, 64, 65, ch // 2 - 1, ch // 2, ch - 31, ch - 1, ch],            # single rows, odd cuts, cuts inside a block
+                    sorted(set([0, ch] + [int(v) for v in rng.integers(1, ch, 5)]))]
+            for cut in cuts:
+                cut = sorted(set(int(c) for c in cut if 0 <= c <= ch))
+                for a, b in zip(cut[:-1], cut[1:]):
+                    got, cw2, ch2, cws2 = ctx.MosaicBlendedDev(ptrs, wv, hv, wsv, h9s, keep=keep, band=band, row0=a, rows=b - a)
+                    assert (cw2, ch2, cws2) == (cw, ch, cws) and tuple(got.shape) == (b - a, cws)
+                    got = got.cpu().numpy()
+                    assert np.array_equal(got, whole[a:b]), f"trial {trial} band {band} rows {a}..{b - 1}: {int((got != whole[a:b]).sum())} bytes differ"
+    ctx.close()

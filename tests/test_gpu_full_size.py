@@ -212,6 +212,13 @@ def test_c5_full_size_canvas_and_blend():
         x0, y0 = win
         got = out[y0:y0 + 1024, 3 * x0:3 * (x0 + 1024)].cpu().numpy()
         assert nsub >= 2 and np.array_equal(got, ref), f"C5 blend window {win}: {int((got != ref).sum())} bytes differ ({nsub} chips)"
+    # ---- the same canvas as the 8 stripes 8 ranks would blend (mi355_mosaic_blended_rows_dev): byte for byte the whole one ----
+    import torch
+    edges = np.linspace(0, bh, 9).astype(int)
+    for a, b in zip(edges[:-1], edges[1:]):
+        part, _, _, _ = ctx.MosaicBlendedDev(fptr, wv, hv, wsv, h9, keep=keep, band=band, row0=int(a), rows=int(b - a))
+        assert torch.equal(part, out[int(a):int(b)]), f"C5 blend stripe rows {a}..{b - 1} differs from the whole canvas"
+        del part
     ctx.close()
 
 

@@ -164,6 +164,43 @@ def test_ransac2d_golden(ctx):
             assert np.array_equal(bits(H2), bits(H)), (n, seed, H2, H)
 
 
+def test_ransac2d_one_workgroup_per_pair_and_split_forms_agree(ctx, oracle):
+    """Few pairs run as several workgroups per pair and three launches (ransac.hip "few pairs": classify / evaluate / finish with the wide
+    closing refinement), many pairs as one workgroup per pair; option ransac_split forces either.  The golden cases from the reference's own
+    code, random cases against the oracle and whole pair records (n_in, inlier lists, H bits, the padding word) must not depend on the form."""
+    g = math_golden()
+    try:
+        for S in (0, 1, 3, 8):
+            ctx.set_option("ransac_split", S)
+            for p1, p2, n, seed, ok, nin, ids, H in zip(g["r_p1"], g["r_p2"], g["r_n"], g["r_seed"], g["r_ok"], g["r_nin"], g["r_ids"], g["r_H"]):
+                ok2, i1, i2, H2 = ctx.Ransac2D(p1[:n].copy(), p2[:n].copy(), 2.5, 1000, int(seed))
+                assert ok2 == ok and len(i1) == nin and np.array_equal(i1["id"], ids[:nin]), (S, n, seed)
+                if nin >= 4:
+                    assert np.array_equal(bits(H2), bits(H)), (S, n, seed, H2, H)
+            for n, of, st in [(396, 0.35, 1000), (396, 0.8, 1000), (57, 0.5, 1000), (31, 0.2, 1000), (9, 0.0, 1000), (4, 0.0, 1000), (396, 0.5, 1), (396, 0.5, 77), (200, 0.6, 4999), (13, 0.5, 5000)]:
+                p1, p2 = synth_pairs(n, of, seed=1000 + 31 * n + st, size=(4000, 3000))
+                a = oracle.ransac2d(p1, p2, 2.5, st, 5)
+                b = ctx.Ransac2D(p1, p2, 2.5, st, 5)
+                assert a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]), (S, n, of, st)
+                if len(a[1]) >= 4:
+                    assert np.array_equal(bits(a[3]), bits(b[3])), (S, n, of, st)
+        # whole records of a batch of pairs (accepted, rejected, degenerate), byte for byte between the forms
+        rng = np.random.default_rng(4)
+        for k in range(6):
+            kp1, d1, kp2, d2 = _synthetic_feature_pair(rng, n=2000 if k % 2 == 0 else 500 + 100 * k)
+            ctx.SetFeatures(2 * k, kp1, d1.astype(np.float32), 4000, 3000)
+            ctx.SetFeatures(2 * k + 1, kp2, d2.astype(np.float32), 4000, 3000)
+        pairs = [(2 * k, 2 * k + 1) for k in range(6)] + [(0, 3), (2, 7), (1, 2)]
+        recs = []
+        for S in (0, 2, 8):
+            ctx.set_option("ransac_split", S)
+            recs.append(ctx.MatchPairs(pairs, 2.5, 99).tobytes())
+        assert recs[0] == recs[1] == recs[2]
+    finally:
+        ctx.set_option("ransac_split", -1)
+        ctx.DropFeatures(-1)
+
+
 def test_ransac2d_vs_oracle_random(ctx, oracle):
     for n, of in [(396, 0.35), (396, 0.8), (123, 0.5), (9, 0.0), (4, 0.0)]:
         for seed in (21, 22):
