@@ -304,6 +304,29 @@ def rank_share_proxy(args):
         share_step(999, sync=True)
         # restore the survey's features for the next rank's matching (share_step re-extracted this rank's own frames only: same bytes)
         shares[str(rk)] = {"ms_per_step": t_r, "frames": len(own), "pairs": int(len(pairs)), "batches": -(-len(own) // BATCH), "phase_ms_synchronised": dict(ph)}
+    blend = None
+    if args.blend:
+        # the default compositing path (LaplacianPyramidBlending) as the ranks would share it: the whole canvas on one GPU against a rank's stripe
+        h9b, _, _, _ = align_and_layout(r_all)
+        keep = im.resample_by_overlap(wv, hv, h9b, 0.7)
+        bw_, bh_, _ = im.blend_layout(wv, hv, h9b, keep)
+
+        def blend_ms(row0, rows):
+            ts = []
+            for rep in range(3):
+                torch.cuda.synchronize(); t0 = time.perf_counter()
+                o, _, _, _ = ctx.MosaicBlendedDev(fptr, wv, hv, wsv, h9b, keep=keep, band=5, row0=row0, rows=rows)
+                ctx.synchronize(); ts.append((time.perf_counter() - t0) * 1e3)
+                del o
+            return min(ts[1:])
+        whole = blend_ms(0, -1)
+        stripes = {}
+        for rk in ranks:
+            row0 = (bh_ * rk) // G
+            stripes[str(rk)] = blend_ms(row0, (bh_ * (rk + 1)) // G - row0)
+        blend = {"canvas": [bw_, bh_], "chips": int(keep.sum()), "bands": 5, "whole_canvas_ms_one_gpu": whole, "stripe_ms": stripes,
+                 "speedup_of_the_slowest_stripe": whole / max(stripes.values()),
+                 "note": "mi355_mosaic_blended_rows_dev: a rank forms the chips that reach its rows (+ the pyramids' reach), their ownership there and the rows of every blender level its output depends on; no exchange (replicas of frames + stripes)"}
     acc = int(len(r_all))
     feat_bytes = F * 319488 * (G - 1) / G                          # feature records a rank RECEIVES (2048 x (28 + 128) B per frame)
     res_bytes = acc * 9664 * (G - 1) / G
@@ -322,6 +345,7 @@ def rank_share_proxy(args):
            "predicted_ms_per_step": t_max + wire_ring_ms,
            "predicted_pairs_per_s": survey_pairs / (t_max + wire_ring_ms) * 1e3,
            "predicted_speedup_over_one_gpu": t_one / (t_max + wire_ring_ms),
+           "blend": blend,
            "note": "max over the ranks run of the measured share + the ring wire model; assumes the slowest of the ranks run is the slowest rank (rank 0 owns "
                    "ceil(F/G) frames and the reference image, rank G-1 the last stripe)"}
     try:
@@ -581,23 +605,35 @@ def main():
     accepted = int(r["accepted"].sum()) if n_pairs else 0
 
     blend = None
-    if args.blend and world == 1:
-        # LaplacianPyramidBlending of the survey as aligned by the last step: everything stays in HBM (device frames in, device canvas out)
+    if args.blend and (world == 1 or strong):
+        # LaplacianPyramidBlending of the survey as aligned by the last step: everything stays in HBM (device frames in, device canvas out).
+        # N > 1 (one survey sharded): every rank blends ITS STRIPE of the canvas (mi355_mosaic_blended_rows_dev; the stripes are the whole
+        # canvas's bytes: tests/test_blend.py, tests/test_gpu_full_size.py), the time reported is the slowest rank's
         h9b = state["h9"]
         keep = im.resample_by_overlap(wv, hv, h9b, 0.7)                 # MosaicImage.cpp:2227-2230
+        bw_, bh_, _ = im.blend_layout(wv, hv, h9b, keep)
+        row0 = (bh_ * rank) // world if world > 1 else 0
+        rows = ((bh_ * (rank + 1)) // world - row0) if world > 1 else -1
         torch.cuda.synchronize()
         free0 = torch.cuda.mem_get_info()[0]
         tb = []
         for rep in range(2):
+            if world > 1:
+                dist.barrier()
             t_b = time.perf_counter()
-            outb, bw_, bh_, bws_ = ctx.MosaicBlendedDev(fptr, wv, hv, wsv, h9b, keep=keep, band=5)
+            outb, bw_, bh_, bws_ = ctx.MosaicBlendedDev(fptr, wv, hv, wsv, h9b, keep=keep, band=5, row0=row0, rows=rows)
             ctx.synchronize()
             tb.append((time.perf_counter() - t_b) * 1e3)
+        if world > 1:
+            tt = torch.tensor(tb, dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            tb = [float(v) for v in tt.cpu()]
         free1 = torch.cuda.mem_get_info()[0]
         tot = torch.cuda.mem_get_info()[1]
         blend = {"ms": min(tb), "ms_first_call": tb[0], "chips": int(keep.sum()), "canvas": [bw_, bh_], "bands": 5,
+                 "stripes": world, "rows_of_rank0": rows if world > 1 else bh_,
                  "resident_gb": (tot - free1) / 1e9, "blend_buffers_gb": (free0 - free1) / 1e9, "frames_gb": F * h * ws / 1e9,
-                 "note": "mi355_mosaic_blended_dev: chips (3 B) + masks (1 B per chip pixel) + canvas Laplacian / weight pyramids next to the frames; device in, device out (no PCIe); second call (buffers allocated)"}
+                 "note": "mi355_mosaic_blended_dev / _rows_dev: chips (3 B) + masks (1 B per chip pixel) of the chips that reach the rank's rows + the rows of the canvas Laplacian / weight pyramids its output depends on, next to the frames; device in, device out (no PCIe); second call (buffers allocated); N > 1: max over the ranks"}
         del outb
 
     out = None
@@ -647,6 +683,7 @@ def main():
                                          "shared_chip_pass keeps the figure of rounds 1-3: option serial_heavy, the heavy phases of the batches take turns but the previous batch's "
                                          "keypoint kernels share the chip with the bracketed launch") if head else "HIP events in the timed region (launches overlap other batches' kernels)",
                          "exclusive_pass": iso, "shared_chip_pass": excl,
+                         "shared_chip_frac": (excl["achieved"] / HBM_PEAK_GBS) if excl else None,      # the pipeline's figure next to the kernel's own (`frac`)
                          "in_situ": {"achieved": in_situ, "frac": in_situ / HBM_PEAK_GBS, "launches": int(g_n), "avg_launch_us": (g_ms * 1e3 / g_n) if g_n else None,
                                      "sampled": "every %d-th launch of the class" % PROF_EVERY,
                                      "note": "launches bracketed inside the timed region, three batches in flight: durations include other batches' kernels (sum > step time); rocprofv3 --kernel-trace of this command reports this average"},
@@ -679,6 +716,7 @@ def main():
                          n_pairs * args.steps * 2.0 * 2000 * 2000 * 128 / 1e12),
             "phase_ms": state.get("phase_ms"), "host_parts_ms": state.get("host_parts_ms"),
             "blend": blend,
+            "roofline_shared_chip_frac": (excl["achieved"] / HBM_PEAK_GBS) if excl else None,      # dominant kernel with the other batches' keypoint kernels beside it (the pipeline's figure; roofline.frac is the kernel's own)
             "quality": {"pairs_accepted": accepted, "pairs": survey_pairs if strong else n_pairs, "images_aligned": state["n_valid"],
                         "h_corner_err_px_median": float(np.median(errs)) if errs else None,
                         "h_corner_err_px_max": float(np.max(errs)) if errs else None},

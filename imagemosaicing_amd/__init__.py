@@ -9,7 +9,7 @@ ImageProjectionTransform, MosaicImagesRefined ...).
 from .capi import (  # noqa: F401
     Context, Mi355Error, lib_path, load_library, default_params, Params,
     SFPOINT, KEYPOINT, DMATCH, MATCHPAIR, PAIR_RESULT, CHIPINFO, IMAGE_TRANSFORM, FEATURE_HEADER, FEATURE_RECORD_BYTES, comm_unique_id, comm_available,
-    mosaic_layout, pair_schedule, surf_pair_schedule, resample_by_overlap, write_match_pairs, load_match_pairs, write_match_pairs_txt,
+    mosaic_layout, blend_layout, pair_schedule, surf_pair_schedule, resample_by_overlap, write_match_pairs, load_match_pairs, write_match_pairs_txt,
     write_transforms, load_transforms, write_keypoints, load_keypoints, results_to_match_pairs, global_affine_align, select_connected,
     global_affine_align_results, select_connected_results,
 )

@@ -496,6 +496,90 @@ HD void pivot_call(const float* M, float* inv, float eps) {
     for (int i = 0; i < 64; i++) inv[i] = out[i];
 }
 
+#if defined(__HIP_DEVICE_COMPILE__)
+// InverseMatrix of order 8 (matrix.h:147-296) of ONE lane's matrix by the lanes of its wave that are active with it: the register form above
+// holds a lane for ~50 us per call (its 144 live values live in scratch at the draw loop's register budget), and a draw whose J^T J needs a
+// pivot below the diagonal needs one in each of its 15 Gauss-Newton steps -- one such draw kept its wave, and with it its image pair, for
+// 0.7 ms (a rank's 63 pairs then wait for that one).  Here lane `src` puts its matrix into the wave's LDS scratch (wl: 192 floats), the active
+// lanes (at least 32: the caller checks) share the 8 x 16 tableau's 128 entries and perform on each entry exactly the operations the
+// sequential routine performs on it -- the scheme of ransac.hip inverse8_team with the wave in place of the workgroup: pivot search (first
+// unused row whose entry in column i exceeds eps) by every lane on the same values, pivot row divided by the pivot, every other row whose
+// entry in the pivot column is not below eps takes row + (-entry) * pivot row, and the closing pass moves the row that holds an exact 1 in
+// column r to position r.  No pivot: inv stays as it is (the caller keeps the stale inverse).  LDS operations of one wave execute in order,
+// so the lanes only have to wait for their own reads before the writes of a step.
+// (inlined: as a call it costs the draw loop a stack frame and measured 2.7 against 1.5 us per pair)
+__device__ __forceinline__ void inverse8_wave(const float* M, float* inv, float eps, float* wl, int src, unsigned long long active) {
+    const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    const int rank = __builtin_popcountll(active & ((1ull << lane) - 1ull)), na = __builtin_popcountll(active);      // na >= 32: at most 4 entries per lane
+    auto wsync = []() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); };
+    float* t = wl + 64;
+    wsync();                                                  // earlier users of the scratch are done
+    if (lane == src) {
+#pragma unroll
+        for (int k = 0; k < 64; k++) wl[k] = M[k];
+    }
+    wsync();
+    for (int e = rank; e < 128; e += na) { const int j = e >> 4, c = e & 15; t[e] = c < 8 ? wl[j * 8 + c] : ((c - 8 == j) ? 1.0f : 0.0f); }
+    wsync();
+    unsigned used = 0;
+    bool failed = false;
+    for (int i = 0; i < 8; i++) {
+        int rowI = -1;
+        for (int jj = 0; jj < 8; jj++) if (rowI < 0 && !((used >> jj) & 1u) && fabsf(t[jj * 16 + i]) > eps) rowI = jj;
+        if (rowI < 0) { failed = true; break; }               // matrix.h:206-222: no pivot, the routine gives up (the same verdict in every lane)
+        used |= 1u << rowI;
+        const float ei = t[rowI * 16 + i];
+        float nv[4];
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+            const int e = rank + m * na;
+            nv[m] = 0.0f;
+            if (e < 128) {
+                const int j = e >> 4, c = e & 15;
+                const float prc = t[rowI * 16 + c] / ei;
+                const float e2 = t[j * 16 + i], old = t[e];
+                float v = old;
+                if (j == rowI) v = prc;
+                else if (!(fabsf(e2) < eps)) { const float ne = -e2; const float prod = ne * prc; v = old + prod; }
+                nv[m] = v;
+            }
+        }
+        wsync();                                              // every read of this step precedes its writes
+#pragma unroll
+        for (int m = 0; m < 4; m++) { const int e = rank + m * na; if (e < 128) t[e] = nv[m]; }
+        wsync();
+    }
+    if (!failed) {
+        for (int r = 0; r < 8; r++) {
+            int target = -1;
+            for (int ii = 0; ii < 8; ii++) if (target < 0 && t[ii * 16 + r] == 1.0f) target = ii;
+            const bool sw = target >= 0 && target != r && rank < 16;      // lanes of rank 0 .. 15 swap one column each
+            float x = 0.0f, y = 0.0f;
+            if (sw) { x = t[r * 16 + rank]; y = t[target * 16 + rank]; }
+            wsync();
+            if (sw) { t[r * 16 + rank] = y; t[target * 16 + rank] = x; }
+            wsync();
+        }
+        if (lane == src) {
+#pragma unroll
+            for (int k = 0; k < 64; k++) inv[k] = t[(k >> 3) * 16 + 8 + (k & 7)];
+        }
+    }
+    wsync();
+}
+// the inversions inverse8_sparse hands back for a pivot search below the diagonal: with the wave's LDS scratch at hand and at least half of
+// the wave active, one lane's matrix after the other by the wave together; else (host, or few active lanes) the register routine per lane
+__device__ __forceinline__ void pivot_dispatch(bool need, const float* M, float* inv, float eps, float* wl) {
+    if (wl) {
+        const unsigned long long active = __ballot(1);
+        unsigned long long nm = __ballot(need);
+        if (nm == 0) return;
+        if (__builtin_popcountll(active) >= 32) { for (; nm; nm &= nm - 1ull) inverse8_wave(M, inv, eps, wl, __builtin_ctzll(nm), active); return; }
+    }
+    if (need) pivot_call(M, inv, eps);
+}
+#endif
+
 // (J^T J)^-1 J^T with J's pattern (MulMatrix order: ascending k over the entries that are not structural zeros)
 HD void invjt_sparse(const float* inv, const float* A, float* M) {
     sp::sfor<0, 8>([&](auto rc) {
@@ -516,8 +600,10 @@ HD void invjt_sparse(const float* inv, const float* A, float* M) {
 // Returns false when an inversion needs the generic routine (caller falls back to solve_h4 / nlls4).
 // POLISH = false stops after the 4-point solve: H[8] is its residual and *polished tells whether the polish WOULD run (the draw
 // classification pass of csrc/ransac.hip; the arithmetic up to that point is the same instruction for instruction).
+// wave_lds (device, optional): 192 floats of LDS private to the calling wave, for the inversions that need a pivot search (pivot_dispatch)
 template <bool POLISH = true>
-HD bool hypothesis4_fast(const float* p, float* H, int* polished = nullptr) {
+HD bool hypothesis4_fast(const float* p, float* H, int* polished = nullptr, float* wave_lds = nullptr) {
+    (void)wave_lds;
     float A[64], M[64], inv[64], B[8];
 #pragma unroll
     for (int i = 0; i < 64; i++) A[i] = 0.0f;
@@ -537,7 +623,7 @@ HD bool hypothesis4_fast(const float* p, float* H, int* polished = nullptr) {
     {
         int st = inverse8_sparse<true>(M, inv, 1e-20f);
         if (st == 3) st = exact_call(M, inv, 1e-20f);            // division guard: the same plan with true divisions
-        if (st == 2) pivot_call(M, inv, 1e-20f);                 // pivot search below the diagonal
+        pivot_dispatch(st == 2, M, inv, 1e-20f, wave_lds);       // pivot search below the diagonal
     }
 #else
     if (inverse8_sparse(M, inv, 1e-20f) == 2) pivot_call(M, inv, 1e-20f);
@@ -604,7 +690,7 @@ HD bool hypothesis4_fast(const float* p, float* H, int* polished = nullptr) {
         if (!jtj_sparse(A, M)) return false;
         int inv_state = inverse8_sparse<true>(M, inv, 1e-6f);    // 1: no pivot, the previous iteration's inverse stays (zeros before the first)
         if (inv_state == 3) { if (polished) *polished |= 4; inv_state = exact_call(M, inv, 1e-6f); }      // 3: division guard -> the same plan with true divisions
-        if (inv_state == 2) pivot_call(M, inv, 1e-6f);                                                    // 2: pivot search below the diagonal
+        pivot_dispatch(inv_state == 2, M, inv, 1e-6f, wave_lds);                                          // 2: pivot search below the diagonal
 #else
         jacobian(std::false_type{});
         if (!jtj_sparse(A, M)) return false;

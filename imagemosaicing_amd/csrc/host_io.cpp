@@ -15,6 +15,7 @@
 #include <fstream>
 #include <atomic>
 #include <thread>
+#include <chrono>
 #include <vector>
 
 static_assert(sizeof(mi355_match_point_pairs) == 40, "MatchPointPairs must be 40 bytes (matchPairs.match record)");
@@ -203,12 +204,33 @@ template <class F> void parallel_chunks(size_t n, int threads, F&& f) {         
     f((size_t)0, per < n ? per : n);
     for (auto& x : th) x.join();
 }
+// Phase (C) of the banded Cholesky below for one row: s[j] -= l_k * pt_k[j] for the panel's columns k in ascending order, j over the row's
+// trailing entries.  pt_k = the panel's column k laid out along j (a transposed copy made in phase (B)), so the j loop runs over contiguous
+// doubles and the compiler vectorises it; every entry still takes its products one by one in k order, each product rounded, then the
+// difference (this file is compiled with -ffp-contract=off): the same bits as the scalar form, for any vector width.  Clones for the
+// host's vector unit are picked when the library is loaded (the build machine need not be the machine that runs).
+#if defined(__HIP_DEVICE_COMPILE__) || !defined(__x86_64__) || defined(__SANITIZE_THREAD__) || defined(__SANITIZE_ADDRESS__)      // (an ifunc resolver runs before a sanitizer's runtime is up)
+#define MI355_SIMD_CLONES
+#else
+#define MI355_SIMD_CLONES __attribute__((target_clones("avx512f", "avx2", "default")))
+#endif
+MI355_SIMD_CLONES static void chol_row_update(double* __restrict s, int n, const double* __restrict l, int nk, const double* __restrict pt, size_t pt_stride) {
+    for (int k = 0; k < nk; k++) {
+        const double lk = l[k];
+        const double* __restrict p = pt + (size_t)k * pt_stride;
+        for (int j = 0; j < n; j++) s[j] -= lk * p[j];
+    }
+}
+
 struct PairGroup { int a, b; size_t first; int count; };                          // correspondences `first .. first + count` belong to images (a, b)
 struct Moments { double aa[6], ab[9], bb[6], vax[3], vay[3], vbx[3], vby[3]; };
 
 // xy(k, xa, ya, xb, yb): the k-th correspondence
 template <class XY>
 int align_core(const std::vector<PairGroup>& groups, XY&& xy, int n_images, const int32_t* fixed, mi355_image_transform* out) {
+    static const bool align_dbg = getenv("MI355_ALIGN_DBG") != nullptr;
+    const auto tdbg0 = std::chrono::steady_clock::now();
+    auto tdbg = [&](const char* what) { if (align_dbg) fprintf(stderr, "[align] %-10s at %.3f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tdbg0).count()); };
     std::vector<int> col(n_images, -1);
     int nf = 0;
     for (int k = 0; k < n_images; k++) {
@@ -240,6 +262,7 @@ int align_core(const std::vector<PairGroup>& groups, XY&& xy, int n_images, cons
     auto NL = [&](int i, int j) -> double& { return Nb[(size_t)i * W + (size_t)(j - i + bw)]; };     // i >= j >= i - bw
     // rows: coefficients [xa ya 1] on image a's columns, -[xb yb 1] on image b's columns.  The second moments of one image pair are
     // summed first (21 products per point), then added to the blocks once
+    tdbg("setup");
     std::vector<Moments> mom(groups.size());
     parallel_chunks(groups.size(), npoints > 200000 ? host_threads() : 1, [&](size_t g0, size_t g1) {
         for (size_t gi = g0; gi < g1; gi++) {
@@ -267,6 +290,7 @@ int align_core(const std::vector<PairGroup>& groups, XY&& xy, int n_images, cons
             for (int i = 0; i < 3; i++) { for (int j = 0; j < 3; j++) m.ab[3 * i + j] = Mab[i][j]; m.vax[i] = Vax[i]; m.vay[i] = Vay[i]; m.vbx[i] = Vbx[i]; m.vby[i] = Vby[i]; }
         }
     });
+    tdbg("moments");
     for (size_t gi = 0; gi < groups.size(); gi++) {
         const PairGroup& g = groups[gi];
         const int oa = col[g.a], ob = col[g.b];
@@ -302,8 +326,11 @@ int align_core(const std::vector<PairGroup>& groups, XY&& xy, int n_images, cons
     // panel: (A) one thread factors the 64 x 64 diagonal block, (B) the rows below it are divided up between the threads, (C) the
     // panel's products are subtracted from the trailing band, again by rows, four independent entries at a time.  Three barriers per
     // panel.
-    const int team = ((double)D * bw * bw > 5e7) ? host_threads() : 1;
+    tdbg("assembled");
+    const int team = ((double)D * bw * bw > 4e6) ? host_threads() : 1;
     constexpr int PW = 64;
+    const size_t pts = ((size_t)bw + PW + 7) & ~(size_t)7;       // a panel's columns, transposed: PT[k - p0][i - p1] = L(i, k) for the rows i below the block
+    std::vector<double> PT((size_t)PW * pts, 0.0);
     std::atomic<int> arrived{0}, generation{0}, failed{0};
     auto rowp = [&](int i) -> double* { return Nb.data() + (ptrdiff_t)i * (ptrdiff_t)W + (ptrdiff_t)(bw - i); };     // rowp(i)[j] = N(i, j), i - bw <= j <= i
     auto worker = [&](int tid) {
@@ -343,7 +370,9 @@ int align_core(const std::vector<PairGroup>& groups, XY&& xy, int n_images, cons
                     const double* rj = rowp(j);
                     double sv = ri[j];
                     for (int k = j0; k < j; k++) sv -= ri[k] * rj[k];
-                    ri[j] = sv / rj[j];
+                    sv = sv / rj[j];
+                    ri[j] = sv;
+                    PT[(size_t)(j - p0) * pts + (size_t)(i - p1)] = sv;
                 }
             }
             barrier();
@@ -351,19 +380,8 @@ int align_core(const std::vector<PairGroup>& groups, XY&& xy, int n_images, cons
                 double* ri = rowp(i);
                 const int k0 = i - bw > p0 ? i - bw : p0;
                 const int j0 = i - bw > p1 ? i - bw : p1;
-                int j = j0;
-                for (; j + 3 <= i; j += 4) {
-                    const double *a0 = rowp(j), *a1 = rowp(j + 1), *a2 = rowp(j + 2), *a3 = rowp(j + 3);
-                    double s0 = ri[j], s1 = ri[j + 1], s2 = ri[j + 2], s3 = ri[j + 3];
-                    for (int k = k0; k < p1; k++) { const double l = ri[k]; s0 -= l * a0[k]; s1 -= l * a1[k]; s2 -= l * a2[k]; s3 -= l * a3[k]; }
-                    ri[j] = s0; ri[j + 1] = s1; ri[j + 2] = s2; ri[j + 3] = s3;
-                }
-                for (; j <= i; j++) {
-                    const double* rj = rowp(j);
-                    double sv = ri[j];
-                    for (int k = k0; k < p1; k++) sv -= ri[k] * rj[k];
-                    ri[j] = sv;
-                }
+                // row j <= i of the trailing band holds L(j, k) for every k >= k0 (j - bw <= i - bw <= k0): the transposed copy is complete there
+                chol_row_update(ri + j0, i - j0 + 1, ri + k0, p1 - k0, PT.data() + (size_t)(k0 - p0) * pts + (size_t)(j0 - p1), pts);
             }
             barrier();
         }
@@ -374,12 +392,24 @@ int align_core(const std::vector<PairGroup>& groups, XY&& xy, int n_images, cons
         worker(0);
         for (auto& x : th) x.join();
     } else worker(0);
+    tdbg("cholesky");
     if (failed.load()) return MI355_ERR_FAILED;
-    auto solve = [&](std::vector<double>& b) {
-        for (int i = 0; i < D; i++) { const int k0 = i - bw > 0 ? i - bw : 0; double s = b[i]; for (int k = k0; k < i; k++) s -= NL(i, k) * b[k]; b[i] = s / NL(i, i); }
-        for (int i = D - 1; i >= 0; i--) { const int k1 = i + bw < D - 1 ? i + bw : D - 1; double s = b[i]; for (int k = i + 1; k <= k1; k++) s -= NL(k, i) * b[k]; b[i] = s / NL(i, i); }
-    };
-    if (team > 1) { std::thread t2([&] { solve(by); }); solve(bx); t2.join(); } else { solve(bx); solve(by); }
+    // L y = b, L^T x = y for both right-hand sides in one walk (two independent chains of subtractions; the same operations per side as before)
+    for (int i = 0; i < D; i++) {
+        const int k0 = i - bw > 0 ? i - bw : 0;
+        const double* ri = rowp(i);
+        double sx = bx[i], sy = by[i];
+        for (int k = k0; k < i; k++) { const double l = ri[k]; sx -= l * bx[k]; sy -= l * by[k]; }
+        bx[i] = sx / ri[i]; by[i] = sy / ri[i];
+    }
+    for (int i = D - 1; i >= 0; i--) {
+        const int k1 = i + bw < D - 1 ? i + bw : D - 1;
+        double sx = bx[i], sy = by[i];
+        for (int k = i + 1; k <= k1; k++) { const double l = NL(k, i); sx -= l * bx[k]; sy -= l * by[k]; }
+        const double d = NL(i, i);
+        bx[i] = sx / d; by[i] = sy / d;
+    }
+    tdbg("solved");
     for (int k = 0; k < n_images; k++) {
         const int o = col[k];
         if (o < 0) continue;

@@ -142,7 +142,7 @@ __device__ __forceinline__ bool classify_draw(const uint16_t* table, int r, cons
 #pragma unroll
     for (int i = 0; i < 4; i++) { const int k = s[i]; p[4 * i] = x1[k]; p[4 * i + 1] = y1[k]; p[4 * i + 2] = x2[k]; p[4 * i + 3] = y2[k]; }
     int pol = 0;
-    const bool fast_ok = hm::hypothesis4_fast<false>(p, h, &pol);
+    const bool fast_ok = hm::hypothesis4_fast<false>(p, h, &pol, sh.fbk[tid >> 6]);
     bool skip = !pol && h[8] > 5.0f;
     for (unsigned long long need = __ballot(!fast_ok); need; need &= need - 1ull) {
         if ((tid & 63) == __builtin_ctzll(need)) {
@@ -167,7 +167,7 @@ __device__ __forceinline__ int eval_draw(const RansacArgs& a, const uint16_t* ta
     // register-resident solve + polish (structural zeros skipped, failed inversions reproduced: hmath.h); the rare draws
     // whose inversion needs the reference's pivot search below the diagonal re-run the generic private-memory routines
     int pol = 0;
-    const bool fast_ok = hm::hypothesis4_fast(p, h, &pol);
+    const bool fast_ok = hm::hypothesis4_fast(p, h, &pol, sh.fbk[tid >> 6]);
     if (a.dbg && pol) atomicAdd(&sh.npol, 1 + ((pol & 2) ? (1 << 12) : 0) + ((pol & 4) ? (1 << 22) : 0));      // polished draws | << 12: a Jacobian redone with true divisions | << 22: an inversion
     // one lane of the wave at a time, its work arrays in the wave's LDS slot: a private array for these index-driven
     // routines costs the whole kernel registers and scratch set-up (measured 5.3 us per pair against 4.9 this way)
@@ -638,7 +638,9 @@ struct SplitBufs {
     float* rec;                  // [pair][S * RB][10]: list index of the lane's first maximum (int bits; -1 none), its hypothesis
     float* firstH;               // [pair][9]
     int* fb;                     // [pair]: draws that took the generic solve (the record's _pad)
+    long long* dbg;              // optional (MI355_RANSAC_SPLIT_DBG): per evaluate wave {start, end, groups taken, time to the list}
     int S, list_stride;
+    int nclass;                  // chunks of 256 draws the classify pass covers (the evaluate pass classifies the rest itself in the rare case that they are needed)
 };
 
 __global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(2, 2))) void ransac_split_classify(RansacArgs a, SplitBufs b) {
@@ -653,7 +655,7 @@ __global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     for (int i = tid; i < n; i += RB) { x1[i] = P1[i].x; y1[i] = P1[i].y; x2[i] = P2[i].x; y2[i] = P2[i].y; }
     __syncthreads();
     const uint16_t* table = a.tables + (size_t)(a.single_table ? 0 : (a.table_of ? a.table_of[pair] : (n - 4))) * MAX_DRAWS * 4;
-    for (int chunk = part; chunk < NCHUNK; chunk += b.S) {
+    for (int chunk = part; chunk < b.nclass; chunk += b.S) {
         const int r = chunk * RB + tid;
         bool accepted = false;
         if (r < MAX_DRAWS) accepted = classify_draw(table, r, x1, y1, x2, y2, sh, tid);
@@ -667,6 +669,7 @@ __global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     __shared__ RShared sh;
     __shared__ int s_pref[NCHUNK * (RB / 64) + 1];
     const int pair = blockIdx.y, part = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const long long t_start = wall_clock64();
     const int n = a.n[pair];
     if (n < 4 || a.sample_times < 1) return;
     const mi355_sfpoint* P1 = a.p1 + (size_t)pair * a.stride;
@@ -680,22 +683,41 @@ __global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         pts[i] = make_float4(P1[i].x, P1[i].y, P2[i].x, P2[i].y);
     }
     if (tid == 0) { sh.fb = 0; sh.npol = 0; }
-    // the list of accepted draws from the masks: (chunk, wave) blocks in draw order
-    const unsigned long long* masks = b.masks + (size_t)pair * NCHUNK * (RB / 64);
-    if (tid == 0) {
-        int acc = 0;
-        for (int q = 0; q < NCHUNK * (RB / 64); q++) { s_pref[q] = acc; acc += __popcll(masks[q]); }
-        s_pref[NCHUNK * (RB / 64)] = acc;
-    }
-    __syncthreads();
+    // the list of accepted draws from the masks: (chunk, wave) blocks in draw order.  The classify pass covered the first nclass chunks (twice the
+    // list's length in draws: enough unless fewer than half of the draws hold a slot); if those do not fill the list, this workgroup classifies the
+    // remaining chunks itself -- every workgroup of the pair does, and arrives at the same masks
+    constexpr int NB = NCHUNK * (RB / 64);                       // 80 blocks of 64 draws
+    __shared__ unsigned long long s_masks[NB];
+    __shared__ int s_cnt[NB];
     const int sample_times = a.sample_times > 5000 ? 5000 : a.sample_times;
     const int list_cap = sample_times < MAX_DRAWS ? sample_times : MAX_DRAWS;
-    int nlist = s_pref[NCHUNK * (RB / 64)];
+    const uint16_t* table = a.tables + (size_t)(a.single_table ? 0 : (a.table_of ? a.table_of[pair] : (n - 4))) * MAX_DRAWS * 4;
+    {
+        const unsigned long long* masks = b.masks + (size_t)pair * NB;
+        const int nb1 = b.nclass * (RB / 64);
+        if (tid < NB) { const unsigned long long m = tid < nb1 ? masks[tid] : 0ull; s_masks[tid] = m; s_cnt[tid] = __popcll(m); }
+        __syncthreads();
+        int have = 0;
+        for (int q = 0; q < nb1; q++) have += s_cnt[q];          // (the same sum in every thread)
+        if (have < list_cap && b.nclass < NCHUNK) {
+            for (int chunk = b.nclass; chunk < NCHUNK; chunk++) {
+                const int r = chunk * RB + tid;
+                bool accepted = false;
+                if (r < MAX_DRAWS) accepted = classify_draw(table, r, x1, y1, x2, y2, sh, tid);
+                const unsigned long long m = __ballot(accepted);
+                if (lane == 0) { s_masks[chunk * (RB / 64) + (tid >> 6)] = m; s_cnt[chunk * (RB / 64) + (tid >> 6)] = __popcll(m); }
+            }
+            __syncthreads();
+        }
+        if (tid <= NB) { int acc = 0; for (int q = 0; q < tid; q++) acc += s_cnt[q]; s_pref[tid] = acc; }
+    }
+    __syncthreads();
+    int nlist = s_pref[NB];
     nlist = nlist < list_cap ? nlist : list_cap;
     for (int chunk = 0; chunk < NCHUNK; chunk++) {
         const int q = chunk * (RB / 64) + (tid >> 6);
-        if (s_pref[q] >= list_cap) break;                       // (uniform enough: later blocks only start further on)
-        const unsigned long long m = masks[q];
+        if (s_pref[q] >= list_cap) break;                       // (later blocks only start further on)
+        const unsigned long long m = s_masks[q];
         if ((m >> lane) & 1ull) { const int pos = s_pref[q] + __popcll(m & ((1ull << lane) - 1ull)); if (pos < list_cap) list[pos] = (uint16_t)(chunk * RB + tid); }
     }
     __syncthreads();
@@ -704,16 +726,17 @@ __global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         if (tid == 0) b.nlist[pair] = nlist;
     }
     const float d2 = a.dist * a.dist;
-    const uint16_t* table = a.tables + (size_t)(a.single_table ? 0 : (a.table_of ? a.table_of[pair] : (n - 4))) * MAX_DRAWS * 4;
     const int nsub = (nlist + 63) >> 6;
     int mybest = -1, my_li = -1;
     long long Tsolve = 0;
     float h[9];
+    int ngroups = 0;
     for (;;) {
         int sc = 0;
         if (lane == 0) sc = atomicAdd(&b.next[pair], 1);
         sc = __shfl(sc, 0, 64);
         if (sc >= nsub) break;
+        ngroups++;
         const int li = sc * 64 + lane;
         if (li < nlist) {
             const int support = eval_draw<false>(a, table, list[li], n, d2, x1, y1, x2, y2, pts, h, sh, tid, &Tsolve);
@@ -726,6 +749,7 @@ __global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             if (li == 0) { for (int i = 0; i < 9; i++) b.firstH[(size_t)pair * 9 + i] = h[i]; }
         }
     }
+    if (b.dbg && lane == 0) { long long* d = b.dbg + (((size_t)pair * b.S + part) * (RB / 64) + (tid >> 6)) * 4; d[0] = t_start; d[1] = wall_clock64(); d[2] = ngroups; unsigned hw, xc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw)); asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xc)); d[3] = (long long)(((xc & 15u) << 16) | (hw & 0xffffu)); }
     float* rec = b.rec + ((size_t)pair * b.S * RB + (size_t)part * RB + tid) * 10;
     rec[0] = __int_as_float(my_li);
     if (my_li >= 0) { for (int i = 0; i < 9; i++) rec[1 + i] = hb[i * RB + tid]; }
@@ -747,14 +771,13 @@ __global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         if (tid == 0) { out->n_in = 0; out->ok = 0; }
         return;
     }
-    uint16_t* sup = reinterpret_cast<uint16_t*>(lds);      // list_floats floats hold the supports (2 bytes each)
-    float* x1 = lds + a.list_floats; float* y1 = x1 + n; float* x2 = y1 + n; float* y2 = x2 + n;
+    const uint16_t* sup = b.sup + (size_t)pair * b.list_stride;      // read once by the replay: straight from HBM
+    float* x1 = lds; float* y1 = x1 + n; float* x2 = y1 + n; float* y2 = x2 + n;
     float* J = y2 + n;                                     // 2n x 8
     float* C = J + 16 * n;                                 // 2n
-    float* PQ = lds + ((a.list_floats + 22 * n + 3) & ~3);  // 36 x pq_stride, 16-byte aligned
+    float* PQ = lds + ((22 * n + 3) & ~3);                 // 36 x pq_stride, 16-byte aligned
     const int nlist = b.nlist[pair];
     for (int i = tid; i < n; i += RB) { x1[i] = P1[i].x; y1[i] = P1[i].y; x2[i] = P2[i].x; y2[i] = P2[i].y; }
-    for (int i = tid; i < nlist; i += RB) sup[i] = b.sup[(size_t)pair * b.list_stride + i];
     if (tid < 8) sh.state[tid] = (tid == 2 || tid == 3) ? -1 : 0;
     if (tid < 9) { sh.bestH[tid] = 0.0f; sh.firstH[tid] = nlist > 0 ? b.firstH[(size_t)pair * 9 + tid] : 0.0f; }
     __syncthreads();
@@ -1078,12 +1101,18 @@ int mi_ransac_batch(mi355_ctx* ctx, const mi355_sfpoint* d_p1, const mi355_sfpoi
     MI_HIP(hipMemsetAsync(d_out, 0, sizeof(mi355_pair_result) * (size_t)n_pairs, ctx->stream));
     // few pairs (a rank's share of a strip survey, a single mi355_ransac2d call): several workgroups per pair, three launches
     int S = ctx->ransac_split;                          // option "ransac_split": -1 = by the number of pairs, 0 = never, k = k workgroups per pair
-    if (S < 0) { S = (2 * ctx->num_cu) / n_pairs; if (S < 2) S = 0; }
+    if (S < 0) { S = (2 * ctx->num_cu) / n_pairs; if (S < 2) S = 0; if (S > 4) S = 4; }      // 4 x 4 waves take the 16 groups of a 1000-draw list at once; more only idle
     if (S > SPLIT_MAX) S = SPLIT_MAX;
     if (S >= 1 && !dbg_on) {
         SplitBufs b;
         memset(&b, 0, sizeof(b));
         b.S = S; b.list_stride = (a.list_floats + 7) & ~7;
+        {
+            const int cap = sample_times < MAX_DRAWS ? (sample_times > 0 ? sample_times : 1) : MAX_DRAWS;
+            b.nclass = (2 * cap + RB - 1) / RB;
+            if (b.nclass < S) b.nclass = S;
+            if (b.nclass > NCHUNK) b.nclass = NCHUNK;
+        }
         const size_t o_masks = 0, o_list = o_masks + sizeof(unsigned long long) * NCHUNK * (RB / 64) * (size_t)n_pairs, o_sup = o_list + sizeof(uint16_t) * b.list_stride * (size_t)n_pairs,
                      o_nlist = o_sup + sizeof(uint16_t) * b.list_stride * (size_t)n_pairs, o_next = o_nlist + sizeof(int) * (size_t)n_pairs, o_first = o_next + sizeof(int) * (size_t)n_pairs,
                      o_fb = o_first + sizeof(float) * 9 * (size_t)n_pairs, o_rec = (o_fb + sizeof(int) * (size_t)n_pairs + 15) & ~(size_t)15, total = o_rec + sizeof(float) * 10 * S * RB * (size_t)n_pairs;
@@ -1094,19 +1123,46 @@ int mi_ransac_batch(mi355_ctx* ctx, const mi355_sfpoint* d_p1, const mi355_sfpoi
         b.nlist = reinterpret_cast<int*>(base + o_nlist); b.next = reinterpret_cast<int*>(base + o_next); b.firstH = reinterpret_cast<float*>(base + o_first); b.fb = reinterpret_cast<int*>(base + o_fb);
         b.rec = reinterpret_cast<float*>(base + o_rec);
         MI_HIP(hipMemsetAsync(base + o_nlist, 0, o_rec - o_nlist, ctx->stream));      // list lengths, group counters, first hypotheses
+        static const bool split_dbg = getenv("MI355_RANSAC_SPLIT_DBG") != nullptr;
+        if (split_dbg) { DevBuf& dd = ctx->buf("ransac_split_dbg"); MI_HIP(dd.reserve((size_t)n_pairs * S * (RB / 64) * 32)); MI_HIP(hipMemsetAsync(dd.p, 0, (size_t)n_pairs * S * (RB / 64) * 32, ctx->stream)); b.dbg = dd.as<long long>(); }
         ProfScope ps(ctx, "ransac", (double)n_pairs * (24.0 * nmax + sizeof(mi355_pair_result)));
         const size_t lds_c = sizeof(float) * 4 * (size_t)nmax;
         const size_t lds_e = sizeof(float) * ((size_t)a.list_floats + 8 * (size_t)nmax + 9 * RB);
         int q4 = (2 * nmax + 3) / 4; if (!(q4 & 1)) q4++;                             // rows of the product table: a multiple of 4 floats whose quarter is odd
         const int pq_stride = 4 * q4;
-        RansacArgs af = a;
-        af.list_floats = ((a.list_floats + 1) / 2 + 3) & ~3;                          // the finish pass keeps only the supports there (2 bytes each)
-        const size_t lds_f = sizeof(float) * ((size_t)af.list_floats + 22 * (size_t)nmax + 4 + 36 * (size_t)pq_stride);
+        const size_t lds_f = sizeof(float) * (22 * (size_t)nmax + 4 + 36 * (size_t)pq_stride);      // points, J, C, the product table
         if (lds_e > 48 * 1024) MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ransac_split_evaluate), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_e));
         if (lds_f > 48 * 1024) MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ransac_split_finish), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_f));
         hipLaunchKernelGGL(ransac_split_classify, dim3(S, n_pairs), dim3(RB), lds_c, ctx->stream, a, b);
         hipLaunchKernelGGL(ransac_split_evaluate, dim3(S, n_pairs), dim3(RB), lds_e, ctx->stream, a, b);
-        hipLaunchKernelGGL(ransac_split_finish, dim3(n_pairs), dim3(RB), lds_f, ctx->stream, af, b, pq_stride);
+        hipLaunchKernelGGL(ransac_split_finish, dim3(n_pairs), dim3(RB), lds_f, ctx->stream, a, b, pq_stride);
+        if (split_dbg) {
+            std::vector<long long> hd((size_t)n_pairs * S * (RB / 64) * 4);
+            MI_HIP(hipMemcpyAsync(hd.data(), b.dbg, hd.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+            MI_HIP(hipStreamSynchronize(ctx->stream));
+            long long t0 = -1, t1 = 0;
+            for (size_t q = 0; q < hd.size(); q += 4) { if (hd[q] == 0) continue; if (t0 < 0 || hd[q] < t0) t0 = hd[q]; if (hd[q + 1] > t1) t1 = hd[q + 1]; }
+            // busy waves: duration by XCD, and by the number of busy waves that share their CU
+            std::map<int, std::pair<double, int>> byx, bycu;
+            std::map<long long, int> cu_busy;
+            for (size_t q = 0; q < hd.size(); q += 4) if (hd[q + 2] > 0) { const long long id = hd[q + 3]; cu_busy[(id >> 16) * 4096 + ((id >> 8) & 0xff)]++; }      // (xcd, se | cu)
+            for (size_t q = 0; q < hd.size(); q += 4) {
+                if (hd[q + 2] == 0) continue;
+                const long long id = hd[q + 3]; const double dur = (double)(hd[q + 1] - hd[q]);
+                auto& a1 = byx[(int)(id >> 16)]; a1.first += dur; a1.second++;
+                auto& a2 = bycu[cu_busy[(id >> 16) * 4096 + ((id >> 8) & 0xff)]]; a2.first += dur; a2.second++;
+            }
+            fprintf(stderr, "[ransac split dbg, 100 MHz ticks] %d pairs x %d workgroups, evaluate pass %lld ticks; busy waves by XCD (n, mean ticks):", n_pairs, S, t1 - t0);
+            for (auto& kv : byx) fprintf(stderr, " x%d:%d,%.0f", kv.first, kv.second.second, kv.second.first / kv.second.second);
+            fprintf(stderr, " | by busy waves on the same CU:");
+            for (auto& kv : bycu) fprintf(stderr, " %d:%d,%.0f", kv.first, kv.second.second, kv.second.first / kv.second.second);
+            int dh[16] = {0}; double dmax = 0; long long slow_id = 0; long long slow_q = 0;
+            for (size_t q = 0; q < hd.size(); q += 4) if (hd[q + 2] > 0) { const double dur = (double)(hd[q + 1] - hd[q]); int bk = (int)(dur / 10000.0); dh[bk > 15 ? 15 : bk]++; if (dur > dmax) { dmax = dur; slow_id = hd[q + 3]; slow_q = (long long)(q / 4); } }
+            fprintf(stderr, " | durations in steps of 10000 ticks:");
+            for (int i = 0; i < 16; i++) fprintf(stderr, " %d", dh[i]);
+            fprintf(stderr, " | slowest: wave %lld (pair %lld part %lld) on xcd %lld hw_id 0x%llx, %.0f ticks", slow_q, slow_q / (S * 4), (slow_q / 4) % S, slow_id >> 16, slow_id & 0xffff, dmax);
+            fprintf(stderr, "\n");
+        }
     } else {
         ProfScope ps(ctx, "ransac", (double)n_pairs * (24.0 * nmax + sizeof(mi355_pair_result)));
         hipLaunchKernelGGL(ransac_kernel, dim3(n_pairs), dim3(RB), lds_bytes, ctx->stream, a);
@@ -1154,6 +1210,45 @@ extern "C" int mi355_debug_div(mi355_ctx* ctx, const float* a, const float* b, i
     MI_HIP(hipMemcpyAsync(q_fast, dqf, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
     MI_HIP(hipMemcpyAsync(q_true, dqt, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
     MI_HIP(hipMemcpyAsync(ok, dok, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+    MI_HIP(hipStreamSynchronize(ctx->stream));
+    return MI355_OK;
+}
+
+// diagnostic (tests/test_gpu_parity.py): InverseMatrix of order 8 with the pivot search, lane per matrix: the register routine (inverse8_pivot)
+// and what the draw loop uses when a wave's LDS scratch is at hand (pivot_dispatch -> inverse8_wave for >= 32 active lanes).  Both start from
+// the caller's `init` in the output (a matrix without a pivot leaves it untouched).
+namespace {
+// (every kernel of this file that reaches the out-of-line solvers carries the same waves-per-SIMD bound: a caller without one widens the
+// callees' register budget, and with it the draw loop's kernels lose their second wave per SIMD -- 2.5 instead of 1.5 us per pair)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void inverse8_check_kernel(const float* mats, int n, float eps, const float* init, float* out_reg, float* out_wave) {
+    __shared__ float s_wl[4][192];
+    (void)s_wl;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;                                      // the last wave is partly active: what the draw loop's last group looks like
+    float M[64], a[64], b[64];
+#pragma unroll
+    for (int k = 0; k < 64; k++) { M[k] = mats[(size_t)i * 64 + k]; a[k] = init[k]; b[k] = init[k]; }
+    hm::pivot_call(M, a, eps);
+#if defined(__HIP_DEVICE_COMPILE__)
+    hm::pivot_dispatch(true, M, b, eps, s_wl[threadIdx.x >> 6]);
+#endif
+#pragma unroll
+    for (int k = 0; k < 64; k++) { out_reg[(size_t)i * 64 + k] = a[k]; out_wave[(size_t)i * 64 + k] = b[k]; }
+}
+}  // namespace
+extern "C" int mi355_debug_inverse8(mi355_ctx* ctx, const float* mats, int n, float eps, const float* init64, float* out_reg, float* out_wave) {
+    if (!mats || !init64 || !out_reg || !out_wave || n <= 0) return MI355_ERR_ARG;
+    LOCKED_PROLOGUE
+    DevBuf& d = ctx->buf("debug_inv8");
+    const size_t mb = sizeof(float) * 64 * (size_t)n;
+    MI_HIP(d.reserve(3 * mb + 256));
+    float* dm = d.as<float>(); float* da = dm + 64 * (size_t)n; float* db = da + 64 * (size_t)n; float* di = db + 64 * (size_t)n;
+    MI_HIP(hipMemcpyAsync(dm, mats, mb, hipMemcpyHostToDevice, ctx->stream));
+    MI_HIP(hipMemcpyAsync(di, init64, sizeof(float) * 64, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(inverse8_check_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, dm, n, eps, di, da, db);
+    MI_HIP(hipGetLastError());
+    MI_HIP(hipMemcpyAsync(out_reg, da, mb, hipMemcpyDeviceToHost, ctx->stream));
+    MI_HIP(hipMemcpyAsync(out_wave, db, mb, hipMemcpyDeviceToHost, ctx->stream));
     MI_HIP(hipStreamSynchronize(ctx->stream));
     return MI355_OK;
 }

@@ -96,6 +96,12 @@ typedef struct { float x, y, size, angle, response; int32_t octave, class_id; } 
 /* SIFT(nfeatures,3,0.01,20,1.6) detect + compute on a BGR u8 image (MosaicWithoutPos.cpp:4852-4872).
  * desc: n x 128 u8 (OpenCV stores the same integers in a float Mat). returns n */
 int  orc_sift(const uint8_t* bgr, int w, int h, int ws, int nfeatures, orc_keypoint* kp, uint8_t* desc, int max_kp);
+/* 0 (default): the definition the product implements; 1: orientation / descriptor arithmetic in the order the reference's binary runs it
+ * (a measuring instrument, see oracle_sift.c).  Process-wide switch: set it, call orc_sift, set it back. */
+void orc_sift_set_mode(int mode);
+int  orc_sift_get_mode(void);
+void orc_cv_exp32f(const float* x, float* y, int n);      /* OpenCV 2.4.0 cv::exp over an array, as opencv_core240.dll runs it */
+const double* orc_cv_exp_table(void);                     /* its 64-entry table 2^(k/64) * A0 */
 
 /* ---- oracle_surf.c: the SURF variant of the path (MosaicWithoutPos.cpp:5300-5533); PARITY UNPINNED ---- */
 /* SURF(hessianThreshold, 4 octaves, 2 layers, extended, oriented) detect + compute (:5313-5335): the strongest max_kp keypoints,

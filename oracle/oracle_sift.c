@@ -130,6 +130,92 @@ static inline void det_sincosdeg(float deg, float* sn, float* cs)
     else { *sn = -c; *cs = s; }
 }
 
+/* ---------- second mode: orientation / descriptor arithmetic in the order the reference's binary runs it --------------------------------
+ * orc_sift_set_mode(1) keeps everything above the orientation histogram as it is (that part is pinned bit for bit by the reference's
+ * committed run) and evaluates calcOrientationHist / calcSIFTDescriptor the way opencv_nonfree240.dll + opencv_core240.dll do, as far as
+ * they were read (llvm-objdump; file offsets / addresses of the Release/ DLLs):
+ *   - the in-window samples are COMPACTED in scan order into arrays and cv::exp / cv::fastAtan2 / cv::magnitude run over the arrays;
+ *   - cv::exp(const float*, float*, int) (core 100881a0 -> Exp_32f 10085780): blocks of eight elements through the SSE2 path -- clamp,
+ *     x * (64 / ln 2) in double, cvtpd2dq, the fraction back to float and * 1/64, Horner form (((f + A1) f + A2) f + A3) f + A4 in float
+ *     with separately rounded products and sums (A4..A1 at 1016bc98: 103.40865, 71.677414, 24.841499, 5.739531), times
+ *     (float)expTab[i & 63] * 2^(i >> 6) (expTab at 1016a7c0: 2^(k/64) * 0.0096703711395723377, 64 doubles; tests/test_sift_binary_order.py
+ *     compares the table built here with the DLL's bytes) -- and the last n mod 8 elements through the scalar path in double (x87, 53-bit
+ *     precision control), rounded to float at the end: the weight of a sample depends on its position in the compacted array;
+ *   - fastAtan2 (array form 100885a0; the same in its packed and scalar parts): the 7th order polynomial with separately rounded products
+ *     and sums, c = min / (max + (float)DBL_EPSILON), 90 - a, 180 - a, 360 - a (mode 0 evaluates the same coefficients with fmaf);
+ *   - magnitude (10088cf0): sqrt(x x + y y) in float, the same in both parts (= mode 0);
+ *   - both histograms are float sums in scan order (mode 0: order-free 2^-10 fixed point);
+ *   - cosf / sinf / powf are the C library's (the DLL calls MSVCR90's, which the reference does not ship; glibc's are used here -- both
+ *     are < 1 ulp routines, they can still differ in a last bit).
+ * Mode 1 is a MEASURING INSTRUMENT (how many angles / descriptor bytes move between the product's definition and the closest restatement
+ * of the binary that can be made here; tests/test_sift_binary_order.py), not the parity checker: the product implements mode 0. */
+static int g_sift_mode = 0;
+void orc_sift_set_mode(int mode) { g_sift_mode = mode; }
+int orc_sift_get_mode(void) { return g_sift_mode; }
+
+#define EXPPOLY_A0 .9670371139572337719125840413672004409288e-2
+static double g_exp_tab[64];
+static int g_exp_tab_ready = 0;
+const double* orc_cv_exp_table(void)
+{
+    if (!g_exp_tab_ready) { for (int k = 0; k < 64; k++) g_exp_tab[k] = exp2((double)k / 64.0) * EXPPOLY_A0; g_exp_tab_ready = 1; }
+    return g_exp_tab;
+}
+/* cv::exp over an array, OpenCV 2.4.0's Exp_32f as the binary runs it (see above) */
+void orc_cv_exp32f(const float* x, float* y, int n)
+{
+    const double* tab = orc_cv_exp_table();
+    const float A4 = (float)(1.000000000000002438532970795181890933776 / EXPPOLY_A0), A3 = (float)(.6931471805521448196800669615864773144641 / EXPPOLY_A0),
+                A2 = (float)(.2402265109513301490103372422686535526573 / EXPPOLY_A0), A1 = (float)(.5550339366753125211915322047004666939128e-1 / EXPPOLY_A0);
+    const double prescale = 1.4426950408889634073599246810019 * 64.0, postscale = 1.0 / 64.0, max_val = 3000.0 * 64.0;
+    const float maxv = (float)(max_val / prescale), minv = (float)(-max_val / prescale);
+    int i = 0;
+    if (n >= 8) {
+        for (; i <= n - 8; i += 8)
+            for (int q = 0; q < 8; q++) {
+                float xf = x[i + q];
+                xf = xf > minv ? xf : minv; xf = xf < maxv ? xf : maxv;             /* maxps, minps */
+                double xd = (double)xf * prescale;
+                int xi = (int)lrint(xd);                                           /* cvtpd2dq: round to nearest even */
+                xd = xd - (double)xi;
+                float f = (float)xd;
+                f = f * (float)postscale;
+                int xs = xi < -32768 ? -32768 : (xi > 32767 ? 32767 : xi);          /* packssdw */
+                int e = (xs >> 6) + 127; e = e < 0 ? 0 : (e > 255 ? 255 : e);
+                union { uint32_t u; float f; } sc; sc.u = (uint32_t)e << 23;
+                float yf = (float)tab[xs & 63];
+                yf = yf * sc.f;
+                float z = f + A1;
+                z = z * f; z = z + A2;
+                z = z * f; z = z + A3;
+                z = z * f; z = z + A4;
+                y[i + q] = z * yf;
+            }
+    }
+    for (; i < n; i++) {
+        union { uint32_t u; float f; } in; in.f = x[i];
+        double x0 = (double)x[i] * prescale;
+        if (((in.u >> 23) & 255) > 127 + 10) x0 = (in.u >> 31) ? -max_val : max_val;
+        int val0 = (int)lrint(x0);
+        int t = (val0 >> 6) + 127; t = !(t & ~255) ? t : (t < 0 ? 0 : 255);
+        union { uint32_t u; float f; } b; b.u = (uint32_t)t << 23;
+        x0 = (x0 - (double)val0) * postscale;
+        double poly = ((((x0 + (double)A1) * x0 + (double)A2) * x0 + (double)A3) * x0 + (double)A4);
+        y[i] = (float)(((double)b.f * tab[val0 & 63]) * poly);
+    }
+}
+/* cv::fastAtan2, degrees: every product and sum rounded on its own (the binary's mulss / addss, mulps / addps) */
+static inline float bin_atan2deg(float y, float x)
+{
+    const float p1 = 57.283627f, p3 = -18.667446f, p5 = 8.9140005f, p7 = -2.5397246f;
+    float ax = fabsf(x), ay = fabsf(y), a, c, c2;
+    if (ax >= ay) { c = ay / (ax + 2.220446e-16f); c2 = c * c; a = c2 * p7; a = a + p5; a = a * c2; a = a + p3; a = a * c2; a = a + p1; a = a * c; }
+    else { c = ax / (ay + 2.220446e-16f); c2 = c * c; a = c2 * p7; a = a + p5; a = a * c2; a = a + p3; a = a * c2; a = a + p1; a = a * c; a = 90.0f - a; }
+    if (x < 0.0f) a = 180.0f - a;
+    if (y < 0.0f) a = 360.0f - a;
+    return a;
+}
+
 /* ---------- Gaussian pyramid, 16-bit fixed point -------------------------------------------------- */
 static inline int reflect101(int p, int n)
 {
@@ -300,6 +386,57 @@ static void describe(const octave_t* oc, const cand_t* k, uint8_t* out)
     int64_t hq[(4 + 2) * (4 + 2) * (8 + 2)];
     float hist[(4 + 2) * (4 + 2) * (8 + 2)];
     for (int i = 0; i < (d + 2) * (d + 2) * (n + 2); i++) hq[i] = 0;
+    if (g_sift_mode == 1) {
+        /* the binary's order (see orc_sift_set_mode): cosf / sinf of the C library, samples compacted in scan order, fastAtan2 / magnitude /
+           cv::exp over the arrays, float sums in that order */
+        float cs = cosf(k->angle * (float)(3.14159265358979323846 / 180.0)), sn = sinf(k->angle * (float)(3.14159265358979323846 / 180.0));
+        cs = cs / hist_width; sn = sn / hist_width;
+        const int len0 = (2 * radius + 1) * (2 * radius + 1);
+        float* buf = (float*)malloc(sizeof(float) * 6 * (size_t)len0);
+        float *X = buf, *Y = X + len0, *Ori = Y + len0, *W = Ori + len0, *RB = W + len0, *CB = RB + len0;
+        int m = 0;
+        for (int i = -radius; i <= radius; i++)
+            for (int j = -radius; j <= radius; j++) {
+                float c_rot = (float)j * cs - (float)i * sn;
+                float r_rot = (float)j * sn + (float)i * cs;
+                float rbin = r_rot + (float)(d / 2) - 0.5f;
+                float cbin = c_rot + (float)(d / 2) - 0.5f;
+                int r = py + i, c = px + j;
+                if (!(rbin > -1.0f && rbin < (float)d && cbin > -1.0f && cbin < (float)d && r > 0 && r < rows - 1 && c > 0 && c < cols - 1)) continue;
+                X[m] = (float)((int)img[(size_t)r * cols + c + 1] - (int)img[(size_t)r * cols + c - 1]);
+                Y[m] = (float)((int)img[(size_t)(r - 1) * cols + c] - (int)img[(size_t)(r + 1) * cols + c]);
+                RB[m] = rbin; CB[m] = cbin;
+                W[m] = (c_rot * c_rot + r_rot * r_rot) * exp_scale;
+                m++;
+            }
+        for (int q = 0; q < m; q++) Ori[q] = bin_atan2deg(Y[q], X[q]);
+        for (int q = 0; q < m; q++) { float sq = X[q] * X[q], sq2 = Y[q] * Y[q]; Y[q] = sqrtf(sq + sq2); }      /* Mag = Y, in place */
+        orc_cv_exp32f(W, W, m);
+        for (int i = 0; i < (d + 2) * (d + 2) * (n + 2); i++) hist[i] = 0.0f;
+        for (int q = 0; q < m; q++) {
+            float rbin = RB[q], cbin = CB[q];
+            float obin = (Ori[q] - k->angle) * bins_per_deg;
+            float mag = Y[q] * W[q];
+            float r0f = floorf(rbin), c0f = floorf(cbin), o0f = floorf(obin);
+            rbin -= r0f; cbin -= c0f; obin -= o0f;
+            int r0 = (int)r0f, c0 = (int)c0f, o0 = (int)o0f;
+            if (o0 < 0) o0 += n;
+            if (o0 >= n) o0 -= n;
+            float v_r1 = mag * rbin, v_r0 = mag - v_r1;
+            float v_rc11 = v_r1 * cbin, v_rc10 = v_r1 - v_rc11;
+            float v_rc01 = v_r0 * cbin, v_rc00 = v_r0 - v_rc01;
+            float v_rco111 = v_rc11 * obin, v_rco110 = v_rc11 - v_rco111;
+            float v_rco101 = v_rc10 * obin, v_rco100 = v_rc10 - v_rco101;
+            float v_rco011 = v_rc01 * obin, v_rco010 = v_rc01 - v_rco011;
+            float v_rco001 = v_rc00 * obin, v_rco000 = v_rc00 - v_rco001;
+            int idx = ((r0 + 1) * (d + 2) + c0 + 1) * (n + 2) + o0;
+            hist[idx] += v_rco000; hist[idx + 1] += v_rco001;
+            hist[idx + (n + 2)] += v_rco010; hist[idx + (n + 3)] += v_rco011;
+            hist[idx + (d + 2) * (n + 2)] += v_rco100; hist[idx + (d + 2) * (n + 2) + 1] += v_rco101;
+            hist[idx + (d + 3) * (n + 2)] += v_rco110; hist[idx + (d + 3) * (n + 2) + 1] += v_rco111;
+        }
+        free(buf);
+    } else
     for (int i = -radius; i <= radius; i++)
         for (int j = -radius; j <= radius; j++) {
             float c_rot = (float)j * cos_t - (float)i * sin_t;
@@ -331,7 +468,7 @@ static void describe(const octave_t* oc, const cand_t* k, uint8_t* out)
             hq[idx + (d + 2) * (n + 2)] += FIXQ(v_rco100); hq[idx + (d + 2) * (n + 2) + 1] += FIXQ(v_rco101);
             hq[idx + (d + 3) * (n + 2)] += FIXQ(v_rco110); hq[idx + (d + 3) * (n + 2) + 1] += FIXQ(v_rco111);
         }
-    for (int i = 0; i < (d + 2) * (d + 2) * (n + 2); i++) hist[i] = (float)hq[i] * (1.0f / HIST_Q);
+    if (g_sift_mode != 1) for (int i = 0; i < (d + 2) * (d + 2) * (n + 2); i++) hist[i] = (float)hq[i] * (1.0f / HIST_Q);
     float dst[128];
     for (int i = 0; i < d; i++)
         for (int j = 0; j < d; j++) {
@@ -425,7 +562,8 @@ int orc_sift(const uint8_t* bgr, int w, int h, int ws, int nfeatures, orc_keypoi
                     uint8_t bit = (uint8_t)(1u << L);
                     if (claimed[(size_t)R * O->w + Cc] & bit) continue;
                     claimed[(size_t)R * O->w + Cc] |= bit;
-                    float scl = (float)sigma * det_exp2f(((float)L + xi) / (float)N_LAYERS);
+                    float scl = g_sift_mode == 1 ? (float)sigma * powf(2.0f, ((float)L + xi) / (float)N_LAYERS)      /* kpt.size = sigma * powf(2.f, ..) * (1 << o) * 2, scl_octv = size * 0.5f / (1 << o) */
+                                                 : (float)sigma * det_exp2f(((float)L + xi) / (float)N_LAYERS);
                     /* orientation histogram on the Gaussian level L of this octave */
                     const int16_t* img = O->lv[L];
                     int radius = (int)rintf(4.5f * scl);
@@ -434,6 +572,37 @@ int orc_sift(const uint8_t* bgr, int w, int h, int ws, int nfeatures, orc_keypoi
                     float th[ORI_BINS], hs[ORI_BINS];
                     int64_t tq[ORI_BINS];
                     for (int b = 0; b < ORI_BINS; b++) tq[b] = 0;
+                    if (g_sift_mode == 1) {
+                        /* calcOrientationHist as the binary runs it: compacted samples, cv::exp / fastAtan2 / magnitude over the arrays, float sums */
+                        const int len0 = (2 * radius + 1) * (2 * radius + 1);
+                        float* buf = (float*)malloc(sizeof(float) * 4 * (size_t)len0);
+                        float *X = buf, *Y = X + len0, *Ori = Y + len0, *W = Ori + len0;
+                        int m = 0;
+                        for (int i = -radius; i <= radius; i++) {
+                            int y = R + i;
+                            if (y <= 0 || y >= O->h - 1) continue;
+                            for (int j = -radius; j <= radius; j++) {
+                                int x = Cc + j;
+                                if (x <= 0 || x >= O->w - 1) continue;
+                                X[m] = (float)((int)img[(size_t)y * O->w + x + 1] - (int)img[(size_t)y * O->w + x - 1]);
+                                Y[m] = (float)((int)img[(size_t)(y - 1) * O->w + x] - (int)img[(size_t)(y + 1) * O->w + x]);
+                                W[m] = (float)(i * i + j * j) * expf_scale;
+                                m++;
+                            }
+                        }
+                        orc_cv_exp32f(W, W, m);
+                        for (int q = 0; q < m; q++) Ori[q] = bin_atan2deg(Y[q], X[q]);
+                        for (int q = 0; q < m; q++) { float sq = X[q] * X[q], sq2 = Y[q] * Y[q]; X[q] = sqrtf(sq + sq2); }      /* Mag = X, in place */
+                        for (int b = 0; b < ORI_BINS; b++) th[b] = 0.0f;
+                        for (int q = 0; q < m; q++) {
+                            int bin = (int)rintf(((float)ORI_BINS / 360.0f) * Ori[q]);
+                            if (bin >= ORI_BINS) bin -= ORI_BINS;
+                            if (bin < 0) bin += ORI_BINS;
+                            float t = W[q] * X[q];
+                            th[bin] = th[bin] + t;
+                        }
+                        free(buf);
+                    } else
                     for (int i = -radius; i <= radius; i++) {
                         int y = R + i;
                         if (y <= 0 || y >= O->h - 1) continue;
@@ -452,7 +621,7 @@ int orc_sift(const uint8_t* bgr, int w, int h, int ws, int nfeatures, orc_keypoi
                             tq[bin] += FIXQ(t);
                         }
                     }
-                    for (int b = 0; b < ORI_BINS; b++) th[b] = (float)tq[b] * (1.0f / HIST_Q);
+                    if (g_sift_mode != 1) for (int b = 0; b < ORI_BINS; b++) th[b] = (float)tq[b] * (1.0f / HIST_Q);
                     float omax = 0.0f;
                     for (int b = 0; b < ORI_BINS; b++) {
                         float m2 = th[(b + ORI_BINS - 2) % ORI_BINS], m1 = th[(b + ORI_BINS - 1) % ORI_BINS];

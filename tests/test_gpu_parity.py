@@ -264,6 +264,37 @@ def test_device_rand_stream_equals_glibc(ctx, oracle):
         assert np.array_equal(out, want), int((out != want).argmax())
 
 
+def test_pivoting_inverse_by_the_wave_equals_the_oracle(ctx, oracle):
+    """hmath.h inverse8_wave: InverseMatrix of order 8 (matrix.h:147-296) for the draws whose J^T J needs a pivot below the diagonal, by the
+    lanes of the draw's wave together (the register routine holds a lane for ~50 us per call, 15 calls per such draw).  Matrices that need row
+    swaps, that have no pivot in some column (the output stays what it was), pivots at either side of eps, whole and partly filled waves (the
+    last group of a list: 40 active lanes take the wave routine, 7 the register routine): the same bits as the oracle's InverseMatrix and as
+    the register routine."""
+    import ctypes as C
+    rng = np.random.default_rng(2026)
+    p = lambda x: x.ctypes.data_as(C.c_void_p)
+    init = rng.normal(0, 1, 64).astype(np.float32)
+    for n in (256, 64 * 3 + 40, 64 * 2 + 7, 33, 1):
+        for eps in (1e-6, 1e-20):
+            mats = rng.normal(0, 1, (n, 8, 8)).astype(np.float32)
+            kind = rng.integers(0, 6, n)
+            for i in range(n):
+                m = mats[i]
+                if kind[i] == 1: m[0, 0] = 0.0                                   # pivot below the diagonal in column 0
+                elif kind[i] == 2: m[:, 3] = 0.0                                 # no pivot in column 3: the routine gives up
+                elif kind[i] == 3: m[rng.integers(0, 8), :] = m[rng.integers(0, 8), :]      # (maybe) two equal rows
+                elif kind[i] == 4: m *= np.float32(eps) * np.float32(rng.choice([0.5, 2.0]))   # entries around eps
+                elif kind[i] == 5: m[:] = np.float32(np.diag(rng.normal(0, 1, 8)))[rng.permutation(8)]   # a permuted diagonal: the closing row pass
+            mats = np.ascontiguousarray(mats.reshape(n, 64))
+            a = np.zeros((n, 64), np.float32); b = np.zeros((n, 64), np.float32)
+            assert ctx.L.mi355_debug_inverse8(ctx._h, p(mats), n, C.c_float(eps), p(init), p(a), p(b)) == 0
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (n, eps, int((a.view(np.uint32) != b.view(np.uint32)).any(1).sum()))
+            for i in range(n):
+                rc, want = oracle.inverse_matrix(mats[i].reshape(8, 8), eps)
+                ref = want.reshape(64) if rc == 1 else init
+                assert np.array_equal(b[i].view(np.uint32), np.ascontiguousarray(ref, np.float32).view(np.uint32)), (n, eps, i, int(kind[i]), rc)
+
+
 def test_guarded_division_equals_true_division(ctx):
     """hmath.h rcp_nr / div_nr (the shared-reciprocal division of the RANSAC polish): wherever the guard accepts a quotient it has the
     bits of the correctly rounded a / b -- 8 M random operand pairs over the whole exponent range, quotients next to rounding
