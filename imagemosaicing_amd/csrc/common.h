@@ -30,6 +30,7 @@
 
 // grow-only device buffer (workspaces live as long as the ctx: no hipMalloc in steady state)
 constexpr int MI355_SIFT_BATCH_MAX = 32;      // frames per SIFT batch (per-frame pointers travel in kernel arguments)
+constexpr int MI355_SIFT_KEEPALL_MAX = 32768;  // keypoints per frame the feature record holds with nfeatures <= 0 (keep all); the matcher takes frames of <= 2048
 
 struct DevBuf {
     void*  p = nullptr;

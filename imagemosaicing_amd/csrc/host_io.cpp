@@ -264,7 +264,7 @@ int align_core(const std::vector<PairGroup>& groups, XY&& xy, int n_images, cons
     // summed first (21 products per point), then added to the blocks once
     tdbg("setup");
     std::vector<Moments> mom(groups.size());
-    parallel_chunks(groups.size(), npoints > 200000 ? host_threads() : 1, [&](size_t g0, size_t g1) {
+    parallel_chunks(groups.size(), npoints > 200000 ? (host_threads() < 8 ? host_threads() : 8) : 1, [&](size_t g0, size_t g1) {      // 3.2 ms on one thread at C4, 0.7 on eight; more threads only add their start-up
         for (size_t gi = g0; gi < g1; gi++) {
             const PairGroup& g = groups[gi];
             const int oa = col[g.a], ob = col[g.b];
@@ -327,7 +327,23 @@ int align_core(const std::vector<PairGroup>& groups, XY&& xy, int n_images, cons
     // panel's products are subtracted from the trailing band, again by rows, four independent entries at a time.  Three barriers per
     // panel.
     tdbg("assembled");
-    const int team = ((double)D * bw * bw > 4e6) ? host_threads() : 1;
+    // The band's width is set by the ONE pair with the largest index distance (a window survey accepts a few pairs up to 181 images apart
+    // among ~2000 between neighbours <= 51 apart): most rows are much shorter than the band.  fst[i] = first column of row i that can be
+    // non-zero; the factor's fill-in stays inside each row's own envelope (profile Cholesky), so everything left of fst[i] is skipped --
+    // those entries are exact zeros, skipping them changes no value -- and the work is sum (i - fst[i])^2 instead of D * bw^2 (C4: 12 x less).
+    std::vector<int> fst(D);
+    for (int o = 0; o < nf; o++) for (int t = 0; t < 3; t++) fst[3 * o + t] = 3 * o;
+    for (const PairGroup& g : groups) {
+        const int oa = col[g.a], ob = col[g.b];
+        if (oa < 0 || ob < 0 || oa == ob) continue;
+        const int hi = oa > ob ? oa : ob, lo = oa > ob ? ob : oa;
+        for (int t = 0; t < 3; t++) if (3 * lo < fst[3 * hi + t]) fst[3 * hi + t] = 3 * lo;
+    }
+    double work = 0.0;
+    for (int i = 0; i < D; i++) work += (double)(i - fst[i]) * (double)(i - fst[i]);
+    // one thread up to ~1e8 multiply-subtracts (C4: 3.6e7, 1.3 ms): measured on the GPU box's host (256 logical CPUs behind a 16-CPU quota) a team
+    // of spinning threads only pays from C5's size on (5e8: 105 -> 47 ms), at C4's it costs 5 ms
+    const int team = (work > 1.5e8) ? host_threads() : 1;
     constexpr int PW = 64;
     const size_t pts = ((size_t)bw + PW + 7) & ~(size_t)7;       // a panel's columns, transposed: PT[k - p0][i - p1] = L(i, k) for the rows i below the block
     std::vector<double> PT((size_t)PW * pts, 0.0);
@@ -347,14 +363,16 @@ int align_core(const std::vector<PairGroup>& groups, XY&& xy, int n_images, cons
                 for (int j = p0; j < p1; j++) {
                     double* rj = rowp(j);
                     double d = rj[j];
-                    for (int k = (j - bw > p0 ? j - bw : p0); k < j; k++) d -= rj[k] * rj[k];
+                    for (int k = (fst[j] > p0 ? fst[j] : p0); k < j; k++) d -= rj[k] * rj[k];
                     if (!(d > 0.0)) { failed.store(1); d = 1.0; }        // keep walking so that the team stays in step; the caller sees `failed`
                     d = std::sqrt(d);
                     rj[j] = d;
                     for (int i = j + 1; i < p1 && i <= j + bw; i++) {    // rows of the block that reach column j (half bandwidth below the panel width: adjacent-pair strips)
+                        if (fst[i] > j) continue;
                         double* ri = rowp(i);
                         double sv = ri[j];
-                        for (int k = (i - bw > p0 ? i - bw : p0); k < j; k++) sv -= ri[k] * rj[k];
+                        const int ka = fst[i] > fst[j] ? fst[i] : fst[j];
+                        for (int k = (ka > p0 ? ka : p0); k < j; k++) sv -= ri[k] * rj[k];
                         ri[j] = sv / d;
                     }
                 }
@@ -365,11 +383,12 @@ int align_core(const std::vector<PairGroup>& groups, XY&& xy, int n_images, cons
             // thread twice the mean
             for (int i = p1 + tid; i <= i_end; i += team) {       // (B) the panel's columns of the rows below the block
                 double* ri = rowp(i);
-                const int j0 = i - bw > p0 ? i - bw : p0;
+                const int j0 = fst[i] > p0 ? fst[i] : p0;
+                for (int j = p0; j < j0 && j < p1; j++) PT[(size_t)(j - p0) * pts + (size_t)(i - p1)] = 0.0;      // left of the row's envelope (or the row does not reach the panel at all)
                 for (int j = j0; j < p1; j++) {
                     const double* rj = rowp(j);
                     double sv = ri[j];
-                    for (int k = j0; k < j; k++) sv -= ri[k] * rj[k];
+                    for (int k = (fst[j] > j0 ? fst[j] : j0); k < j; k++) sv -= ri[k] * rj[k];
                     sv = sv / rj[j];
                     ri[j] = sv;
                     PT[(size_t)(j - p0) * pts + (size_t)(i - p1)] = sv;
@@ -377,10 +396,11 @@ int align_core(const std::vector<PairGroup>& groups, XY&& xy, int n_images, cons
             }
             barrier();
             for (int i = p1 + tid; i <= i_end; i += team) {       // (C) the panel's products leave the trailing band
+                if (fst[i] >= p1) continue;                        // the row holds nothing in the panel's columns
                 double* ri = rowp(i);
-                const int k0 = i - bw > p0 ? i - bw : p0;
-                const int j0 = i - bw > p1 ? i - bw : p1;
-                // row j <= i of the trailing band holds L(j, k) for every k >= k0 (j - bw <= i - bw <= k0): the transposed copy is complete there
+                const int k0 = fst[i] > p0 ? fst[i] : p0;
+                const int j0 = fst[i] > p1 ? fst[i] : p1;
+                // the transposed copy holds L(j, k) for every row j of the trailing band, zeros left of row j's envelope
                 chol_row_update(ri + j0, i - j0 + 1, ri + k0, p1 - k0, PT.data() + (size_t)(k0 - p0) * pts + (size_t)(j0 - p1), pts);
             }
             barrier();
@@ -396,7 +416,7 @@ int align_core(const std::vector<PairGroup>& groups, XY&& xy, int n_images, cons
     if (failed.load()) return MI355_ERR_FAILED;
     // L y = b, L^T x = y for both right-hand sides in one walk (two independent chains of subtractions; the same operations per side as before)
     for (int i = 0; i < D; i++) {
-        const int k0 = i - bw > 0 ? i - bw : 0;
+        const int k0 = fst[i];
         const double* ri = rowp(i);
         double sx = bx[i], sy = by[i];
         for (int k = k0; k < i; k++) { const double l = ri[k]; sx -= l * bx[k]; sy -= l * by[k]; }
@@ -405,7 +425,7 @@ int align_core(const std::vector<PairGroup>& groups, XY&& xy, int n_images, cons
     for (int i = D - 1; i >= 0; i--) {
         const int k1 = i + bw < D - 1 ? i + bw : D - 1;
         double sx = bx[i], sy = by[i];
-        for (int k = i + 1; k <= k1; k++) { const double l = NL(k, i); sx -= l * bx[k]; sy -= l * by[k]; }
+        for (int k = i + 1; k <= k1; k++) { if (fst[k] > i) continue; const double l = NL(k, i); sx -= l * bx[k]; sy -= l * by[k]; }
         const double d = NL(i, i);
         bx[i] = sx / d; by[i] = sy / d;
     }

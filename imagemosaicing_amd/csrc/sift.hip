@@ -278,14 +278,15 @@ constexpr int REG_SHIFT = REG_SHIFT_V;      // 2^REG_SHIFT consecutive tiles app
 constexpr int NREG = 64, REG_STRIDE = 32;   // candidate list split into 64 regions, one counter per 128-byte line:
                                             // a single counter caps at ~1e8 returning atomics/s (one per tile = 0.5 ms)
 // batched launches: frame f = blockIdx.y (z for refine) works on its own copy of every buffer, a fixed stride apart
-struct BatchStride { size_t pyr, claimed, cand, refined, kps, cube; };   // elements of the respective type
+struct BatchStride { size_t pyr, claimed, cand, refined, kps, cube, sel, mins; };   // elements of the respective type (sel: selected keypoints per frame; mins: keep-all's start-key table)
 constexpr size_t CNT_STRIDE = 64, CCNT_STRIDE = (size_t)64 * 32, SEL_STRIDE = 2048;
+constexpr int KEEPALL_MAX = MI355_SIFT_KEEPALL_MAX;      // keypoints per frame with nfeatures <= 0 (cv::SIFT's "keep all")
 struct FrameOuts { mi355_keypoint* kp[SIFT_BATCH_MAX]; uint8_t* d8[SIFT_BATCH_MAX]; };
 
 // ---------- K3b: sub-pixel refinement ---------------------------------------------------------------------------
-struct Refined { int o, layer, r, c; float xi, xr, xc, contr, scl; };
+struct Refined { int o, layer, r, c; float xi, xr, xc, contr, scl; unsigned start; };      // start: keep-all: (layer, row, column) of the extremum the fit started from, packed 2 + 14 + 14 bits
 
-struct PyrDev { OctaveDev oc[MAX_OCT]; unsigned* claimed[MAX_OCT]; int n_oct; };
+struct PyrDev { OctaveDev oc[MAX_OCT]; unsigned* claimed[MAX_OCT]; unsigned* mins[MAX_OCT]; int n_oct; };      // mins: keep-all only (one word per claim bit)
 
 // DoG[lvl] = G[lvl + 1] - G[lvl]: 16-bit integers (cv::subtract into CV_16S; the samples are 0 .. 12240, nothing saturates), exact as float
 __device__ __forceinline__ float dogv(const OctaveDev& oc, size_t foff, int lvl, int r, int c) {
@@ -735,6 +736,7 @@ __global__ __launch_bounds__(256) void refine_kernel(PyrDev P, const unsigned lo
         const unsigned long long pk = cand[i];
         const int o = (int)((pk >> 48) & 0xff);
         int L = (int)((pk >> 40) & 0xff), R = (int)((pk >> 20) & 0xfffff), C = (int)(pk & 0xfffff);
+        const unsigned start = ((unsigned)L << 28) | ((unsigned)R << 14) | (unsigned)C;      // generation order inside the octave: layer, row, column of the extremum
         const OctaveDev& oc = P.oc[o];
         auto dv = [&](int l, int r, int c) { return dogv(oc, foff, l, r, c); };
         FitOff f = {0.0f, 0.0f, 0.0f};
@@ -801,8 +803,15 @@ __global__ __launch_bounds__(256) void refine_kernel(PyrDev P, const unsigned lo
         // duplicates: several start points may converge to one location -> first claim wins (all claims carry identical values)
         const size_t bit = ((size_t)R * oc.w + C) * 4 + (size_t)L;
         const unsigned mask = 1u << (bit & 31);
-        const unsigned old = atomicOr(&P.claimed[o][fr * bs.claimed + (bit >> 5)], mask);
-        if (old & mask) continue;
+        if (P.mins[o]) {
+            // keep-all (nfeatures <= 0): OpenCV's list is in generation order and of several start points that converge to one location the
+            // FIRST in that order keeps it -- every start point is stored, the location remembers its smallest start key, keepall_live_kernel
+            // keeps the record that holds it
+            atomicMin(&P.mins[o][fr * bs.mins + bit], start);
+        } else {
+            const unsigned old = atomicOr(&P.claimed[o][fr * bs.claimed + (bit >> 5)], mask);
+            if (old & mask) continue;
+        }
         // one atomic per wave, not per point: ~67 000 points of a 12 MP frame on ONE counter serialise in the L2 (0.65 ms per batch measured)
         const unsigned long long act = __ballot(1);
         const int leader = __builtin_ctzll(act), lane_id = (int)(threadIdx.x & 63);
@@ -813,9 +822,10 @@ __global__ __launch_bounds__(256) void refine_kernel(PyrDev P, const unsigned lo
             Refined rr;
             rr.o = o; rr.layer = L; rr.r = R; rr.c = C; rr.xi = f.xi; rr.xr = f.xr; rr.xc = f.xc; rr.contr = contr;
             rr.scl = sigma * det_exp2f(((float)L + f.xi) / (float)N_LAYERS);
+            rr.start = start;
             out[slot] = rr;
             out_resp[slot] = __float_as_uint(fabsf(contr));
-        } else atomicAnd(&P.claimed[o][fr * bs.claimed + (bit >> 5)], ~mask);      // list full (the frame fails): keep "bit set <=> record stored"
+        } else if (!P.mins[o]) atomicAnd(&P.claimed[o][fr * bs.claimed + (bit >> 5)], ~mask);      // list full (the frame fails): keep "bit set <=> record stored"
     }
 }
 
@@ -833,10 +843,51 @@ __global__ __launch_bounds__(256) void unclaim_kernel(PyrDev P, const Refined* r
     }
 }
 
+// ---- keep-all (nfeatures <= 0, cv::SIFT's default of its own: every keypoint, in OpenCV's generation order) ------------------------------
+// The reference's one committed run was made this way (tests/test_sift_reference_run.py).  No response threshold, no top-k: every refined
+// point that holds its location's smallest start key is oriented, and the keypoints leave in the order (octave, start layer / row / column,
+// orientation bin) -- the order of OpenCV's vector when retainBest does not run.  Not a hot path: the ranks are counted by brute force.
+__global__ __launch_bounds__(256) void keepall_live_kernel(PyrDev P, const Refined* ref, const unsigned* ref_count, unsigned ref_cap, unsigned* ctrl, unsigned* list, BatchStride bs) {
+    const size_t fr = blockIdx.y;
+    ref += fr * bs.refined; ref_count += fr * CNT_STRIDE; ctrl += fr * CNT_STRIDE; list += fr * bs.refined;
+    unsigned n = *ref_count;
+    if (n > ref_cap) n = ref_cap;
+    const int lane = threadIdx.x & 63;
+    for (unsigned i0 = blockIdx.x * blockDim.x; i0 < n; i0 += gridDim.x * blockDim.x) {      // uniform trip count per wave
+        const unsigned i = i0 + threadIdx.x;
+        bool take = false;
+        if (i < n) {
+            const Refined rr = ref[i];
+            const size_t bit = ((size_t)rr.r * P.oc[rr.o].w + rr.c) * 4 + (size_t)rr.layer;
+            take = P.mins[rr.o][fr * bs.mins + bit] == rr.start;
+        }
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(take);
+        if (m) {
+            const int first = __builtin_ctzll(m);
+            unsigned base = 0;
+            if (lane == first) base = atomicAdd(&ctrl[2], (unsigned)__builtin_popcountll(m));
+            base = __shfl(base, first);
+            if (take) list[base + (unsigned)__builtin_popcountll(m & ((1ull << lane) - 1ull))] = i;
+        }
+    }
+}
+// the start-key table is all ones between batches: the locations this batch touched are put back
+__global__ __launch_bounds__(256) void keepall_reset_kernel(PyrDev P, const Refined* ref, const unsigned* ref_count, unsigned ref_cap, BatchStride bs) {
+    const size_t fr = blockIdx.y;
+    ref += fr * bs.refined; ref_count += fr * CNT_STRIDE;
+    unsigned n = *ref_count;
+    if (n > ref_cap) n = ref_cap;
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const Refined rr = ref[i];
+        P.mins[rr.o][fr * bs.mins + ((size_t)rr.r * P.oc[rr.o].w + rr.c) * 4 + (size_t)rr.layer] = 0xffffffffu;
+    }
+}
+
 // ---------- K4: orientation ---------------------------------------------------------------------------------------
 struct KpRec {
     unsigned resp_bits; int o, layer, r, c, bin;
     float ptx, pty, scl, angle, xi;
+    unsigned start;                     // keep-all: the refined point's start key
 };
 
 // Only the nfeatures strongest keypoints survive, and the response is known before the orientation: a 65536-bin
@@ -997,7 +1048,7 @@ __global__ __launch_bounds__(256) void orient_kernel(PyrDev P, const Refined* re
                 KpRec kr;
                 kr.resp_bits = __float_as_uint(fabsf(rr.contr));
                 kr.o = rr.o; kr.layer = rr.layer; kr.r = rr.r; kr.c = rr.c; kr.bin = lane;
-                kr.ptx = (float)rr.c + rr.xc; kr.pty = (float)rr.r + rr.xr; kr.scl = rr.scl; kr.xi = rr.xi;
+                kr.ptx = (float)rr.c + rr.xc; kr.pty = (float)rr.r + rr.xr; kr.scl = rr.scl; kr.xi = rr.xi; kr.start = rr.start;
                 kr.angle = (360.0f / (float)ORI_BINS) * bf;
                 const unsigned slot = atomicAdd(&s_on, 1u);            // LDS counter; <= 18 peaks x 4 waves per trip
                 if (slot < OCAP) s_out[slot] = kr;
@@ -1033,7 +1084,7 @@ __device__ __forceinline__ unsigned long long tie_key(const KpRec& k) {
 __global__ __launch_bounds__(1024) void topk_kernel(const KpRec* kps, const unsigned* resp, const unsigned* kp_count, unsigned kp_cap, int nfeatures,
                                                     FrameOuts outs, SelRec* out_sel, int* out_n, int* overflow, unsigned* ctrl, int pass, BatchStride bs) {
     const size_t fr = blockIdx.x;                                 // one workgroup per frame of the batch
-    kps += fr * bs.kps; resp += fr * bs.kps; kp_count += fr * CNT_STRIDE; out_sel += fr * SEL_STRIDE; out_n += fr * CNT_STRIDE; overflow += fr * CNT_STRIDE; ctrl += fr * CNT_STRIDE;
+    kps += fr * bs.kps; resp += fr * bs.kps; kp_count += fr * CNT_STRIDE; out_sel += fr * bs.sel; out_n += fr * CNT_STRIDE; overflow += fr * CNT_STRIDE; ctrl += fr * CNT_STRIDE;
     mi355_keypoint* out_kp = outs.kp[0];
 #pragma unroll
     for (int q = 1; q < SIFT_BATCH_MAX; q++) if ((int)fr == q) out_kp = outs.kp[q];
@@ -1158,13 +1209,55 @@ __global__ __launch_bounds__(1024) void topk_kernel(const KpRec* kps, const unsi
     }
 }
 
+// keep-all: a keypoint's place in the output = the number of keypoints with a smaller (octave, start key, orientation bin); the keys are
+// distinct (one refined record per start point, one keypoint per bin).  Every workgroup walks all keys of its frame in tiles through LDS.
+__global__ __launch_bounds__(256) void keepall_output_kernel(const KpRec* kps, const unsigned* kp_count, unsigned kp_cap, FrameOuts outs, SelRec* out_sel, int* out_n, int* overflow, BatchStride bs) {
+    const size_t fr = blockIdx.y;
+    kps += fr * bs.kps; kp_count += fr * CNT_STRIDE; out_sel += fr * bs.sel; out_n += fr * CNT_STRIDE; overflow += fr * CNT_STRIDE;
+    mi355_keypoint* out_kp = outs.kp[0];
+#pragma unroll
+    for (int q = 1; q < SIFT_BATCH_MAX; q++) if ((int)fr == q) out_kp = outs.kp[q];
+    unsigned N = *kp_count;
+    if (N > kp_cap || N > (unsigned)KEEPALL_MAX) {                     // more keypoints than the record holds: the frame fails (OpenCV would keep them all)
+        if (blockIdx.x == 0 && threadIdx.x == 0) { *overflow = 1; *out_n = 0; }
+        return;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) *out_n = (int)N;
+    auto key_of = [](const KpRec& k) { return ((unsigned long long)k.o << 40) | ((unsigned long long)k.start << 6) | (unsigned long long)k.bin; };
+    __shared__ unsigned long long s_key[1024];
+    const unsigned i = blockIdx.x * 256 + threadIdx.x;
+    if (blockIdx.x * 256 >= N) return;
+    KpRec mine;
+    unsigned long long mk = ~0ull;
+    if (i < N) { mine = kps[i]; mk = key_of(mine); }
+    unsigned rank = 0;
+    for (unsigned t0 = 0; t0 < N; t0 += 1024) {
+        __syncthreads();
+        for (unsigned q = threadIdx.x; q < 1024; q += 256) s_key[q] = t0 + q < N ? key_of(kps[t0 + q]) : ~0ull;
+        __syncthreads();
+        const unsigned cntq = N - t0 < 1024 ? N - t0 : 1024;
+        for (unsigned q = 0; q < cntq; q++) rank += s_key[q] < mk ? 1u : 0u;
+    }
+    if (i >= N) return;
+    const KpRec& k = mine;
+    const float s2 = (float)(1 << k.o);
+    mi355_keypoint kp;
+    kp.x = k.ptx * s2; kp.y = k.pty * s2; kp.size = (k.scl * s2) * 2.0f; kp.angle = k.angle;
+    kp.response = __uint_as_float(k.resp_bits);
+    kp.octave = (k.o & 255) | (k.layer << 8) | (((int)rintf((k.xi + 0.5f) * 255.0f)) << 16);
+    kp.class_id = -1;
+    out_kp[rank] = kp;
+    SelRec sr; sr.ptx = k.ptx; sr.pty = k.pty; sr.scl = k.scl; sr.angle = k.angle; sr.o = k.o; sr.layer = k.layer;
+    out_sel[rank] = sr;
+}
+
 // ---------- K5: descriptors -----------------------------------------------------------------------------------------
 // One WAVE per keypoint, four keypoints per workgroup (16 frames x 2000 keypoints as 256-thread workgroups of their own were
 // dispatch- and latency-bound: each lane looped over ~20 samples with four dependent 2-byte loads each).  A lane takes four
 // samples per trip and issues their 16 gradient loads before any is consumed; the histogram lives in wave-private LDS.
 __global__ __launch_bounds__(256) void describe_kernel(PyrDev P, const SelRec* sel, const int* n_sel, FrameOuts outs, BatchStride bs) {
     const size_t fr = blockIdx.y, foff = fr * bs.pyr;             // frame of the batch
-    sel += fr * SEL_STRIDE; n_sel += fr * CNT_STRIDE;
+    sel += fr * bs.sel; n_sel += fr * CNT_STRIDE;
     uint8_t* desc = outs.d8[0];
 #pragma unroll
     for (int q = 1; q < SIFT_BATCH_MAX; q++) if ((int)fr == q) desc = outs.d8[q];
@@ -1396,6 +1489,7 @@ struct SiftWork {
     DevBuf claimed;                          // duplicate claim bitmaps
     DevBuf cand, refined, kps, kresp, sel, counters, rhist, ccnt;
     DevBuf olist;                            // per frame: indices of the refined points at or above the response threshold
+    DevBuf mins; bool keepall = false;       // keep-all (nfeatures <= 0): smallest start key per refined location, all ones between batches
     DevBuf cube; unsigned cube_cap = 0;       // 3x3x3 DoG neighbourhoods of the first cube_cap candidates of every region (128 B each)
     PyrDev P;                                // pointers of frame 0
     BatchStride bs;
@@ -1418,7 +1512,7 @@ void mi_sift_release(mi355_ctx* ctx) {
         if (s->tail) { (void)hipStreamSynchronize(s->tail); (void)hipStreamDestroy(s->tail); }
         if (s->done) (void)hipEventDestroy(s->done);
         if (s->heavy_done) (void)hipEventDestroy(s->heavy_done);
-        s->pyr.release(); s->claimed.release(); s->cand.release(); s->refined.release(); s->kps.release(); s->kresp.release(); s->sel.release(); s->counters.release(); s->rhist.release(); s->ccnt.release(); s->cube.release(); s->olist.release();
+        s->pyr.release(); s->claimed.release(); s->cand.release(); s->refined.release(); s->kps.release(); s->kresp.release(); s->sel.release(); s->counters.release(); s->rhist.release(); s->ccnt.release(); s->cube.release(); s->olist.release(); s->mins.release();
         delete s;
     }
     ctx->sift_slots.clear();
@@ -1538,8 +1632,8 @@ static int* pinned_slot(mi355_ctx* ctx) {
 
 static inline size_t up64(size_t v) { return (v + 63) & ~(size_t)63; }
 
-static int sift_prepare(mi355_ctx* ctx, SiftWork* s, int w, int h, int nb) {
-    if (s->w == w && s->h == h && s->nb == nb) return MI355_OK;
+static int sift_prepare(mi355_ctx* ctx, SiftWork* s, int w, int h, int nb, bool keepall) {
+    if (s->w == w && s->h == h && s->nb == nb && s->keepall == keepall) return MI355_OK;
     MI_HIP(hipStreamSynchronize(s->stream));
     if (s->tail) MI_HIP(hipStreamSynchronize(s->tail));
     if (s->radius0 == 0) {
@@ -1577,6 +1671,10 @@ static int sift_prepare(mi355_ctx* ctx, SiftWork* s, int w, int h, int nb) {
     if (s->cube_cap > s->cand_cap) s->cube_cap = s->cand_cap;
     s->bs.cube = (size_t)s->cube_cap * NREG * 32;
     s->bs.pyr = fl; s->bs.claimed = cl; s->bs.cand = (size_t)s->cand_cap * NREG; s->bs.refined = s->ref_cap; s->bs.kps = s->kp_cap;
+    s->bs.sel = keepall ? (size_t)KEEPALL_MAX : SEL_STRIDE;
+    size_t ml = 0;                                              // keep-all: one word per claim bit (4 per pixel of every octave)
+    if (keepall) for (int o = 0; o < no; o++) ml += (size_t)(w >> o) * (h >> o) * 4;
+    s->bs.mins = ml;
     const size_t B = (size_t)nb;
     MI_HIP(s->pyr.reserve(B * fl * sizeof(lvl_t)));
     MI_HIP(s->claimed.reserve(B * cl * sizeof(unsigned)));
@@ -1585,23 +1683,27 @@ static int sift_prepare(mi355_ctx* ctx, SiftWork* s, int w, int h, int nb) {
     MI_HIP(s->refined.reserve(B * s->bs.refined * sizeof(Refined)));
     MI_HIP(s->kps.reserve(B * s->bs.kps * sizeof(KpRec)));
     MI_HIP(s->kresp.reserve(B * s->bs.kps * sizeof(unsigned)));
-    MI_HIP(s->sel.reserve(B * SEL_STRIDE * sizeof(SelRec)));
+    MI_HIP(s->sel.reserve(B * s->bs.sel * sizeof(SelRec)));
+    if (keepall) { MI_HIP(s->mins.reserve(B * ml * sizeof(unsigned))); MI_HIP(hipMemsetAsync(s->mins.p, 0xff, B * ml * sizeof(unsigned), s->stream)); }      // kept all ones between batches by keepall_reset_kernel
+    else s->mins.release();
     MI_HIP(s->counters.reserve(B * CNT_STRIDE * sizeof(unsigned)));
     MI_HIP(s->rhist.reserve(B * s->bs.refined * sizeof(unsigned)));
     MI_HIP(s->olist.reserve(B * s->bs.refined * sizeof(unsigned)));      // |response| bits of the refined points (SoA next to `refined`)
     MI_HIP(s->ccnt.reserve(B * CCNT_STRIDE * sizeof(unsigned)));
     MI_HIP(s->cube.reserve(B * s->bs.cube * sizeof(float)));
     memset(&s->P, 0, sizeof(s->P));
-    size_t fo = 0, co = 0;
+    size_t fo = 0, co = 0, mo = 0;
     for (int o = 0; o < no; o++) {
         const int ow = w >> o, oh = h >> o;
         s->P.oc[o].w = ow; s->P.oc[o].h = oh;
         for (int i = 0; i < N_LEVELS; i++) { s->P.oc[o].lv[i] = s->pyr.as<lvl_t>() + fo; fo += up64((size_t)ow * oh); }
         s->P.claimed[o] = s->claimed.as<unsigned>() + co;
         co += (((size_t)ow * oh * 4 + 31) / 32 + 63) & ~(size_t)63;
+        s->P.mins[o] = keepall ? s->mins.as<unsigned>() + mo : nullptr;
+        mo += (size_t)ow * oh * 4;
     }
     s->P.n_oct = no; s->n_oct = no;
-    s->w = w; s->h = h; s->nb = nb;
+    s->w = w; s->h = h; s->nb = nb; s->keepall = keepall;
     return MI355_OK;
 }
 
@@ -1611,7 +1713,9 @@ static int sift_prepare(mi355_ctx* ctx, SiftWork* s, int w, int h, int nb) {
 // unchanged until then.  Returns without waiting; the keypoint count is adopted later by mi_resolve_features().
 int mi_sift_extract_dev(mi355_ctx* ctx, int img_id, const uint8_t* d_bgr, int w, int h, int ws, int* n_kp) {
     if (ctx->p.n_octave_layers != N_LAYERS || ctx->p.sigma != 1.6f) { ctx->set_error("sift: this build implements nOctaveLayers=3, sigma=1.6 (the reference's SIFT(2000,3,0.01,20))"); return MI355_ERR_ARG; }
-    if (ctx->p.nfeatures < 1 || ctx->p.nfeatures > 2048) { ctx->set_error("sift: nfeatures must be in [1,2048]"); return MI355_ERR_ARG; }
+    if (ctx->p.nfeatures > 2048) { ctx->set_error("sift: nfeatures must be in [1,2048], or <= 0 for cv::SIFT's keep-all (up to 32768 keypoints per frame)"); return MI355_ERR_ARG; }
+    const bool keepall = ctx->p.nfeatures <= 0;
+    if (keepall && (w > 16384 || h > 16384)) { ctx->set_error("sift: keep-all frames are at most 16384 x 16384"); return MI355_ERR_ARG; }
     if ((size_t)w >= (1u << 20) || (size_t)h >= (1u << 20)) { ctx->set_error("sift: image too large"); return MI355_ERR_ARG; }
     if (w < 16 || h < 16) { ctx->set_error("sift: image too small"); return MI355_ERR_ARG; }
     if (ctx->sift_slots.empty()) {
@@ -1634,19 +1738,20 @@ int mi_sift_extract_dev(mi355_ctx* ctx, int img_id, const uint8_t* d_bgr, int w,
         static size_t total_mem = [] { size_t fr = 0, tot = 0; return hipMemGetInfo(&fr, &tot) == hipSuccess ? tot : (size_t)0; }();
         const double per_frame = 60.0 * (double)w * (double)h;
         if (total_mem) {
-            const int fit = (int)(0.6 * (double)total_mem / per_frame / (double)SIFT_SLOTS);
+            const int fit = (int)(0.6 * (double)total_mem / ((keepall ? 1.4 : 1.0) * per_frame) / (double)SIFT_SLOTS);      // keep-all: + 21 B per pixel of start keys
             if (fit < nb) nb = fit < 1 ? 1 : fit;
         }
+        if (keepall && nb > 8) nb = 8;
     }
-    if (!s->pend.empty() && (s->w != w || s->h != h || s->nb != nb)) { rc = sift_run_batch(ctx, s); if (rc != MI355_OK) return rc; }   // size change: close the batch
-    rc = sift_prepare(ctx, s, w, h, nb);
+    if (!s->pend.empty() && (s->w != w || s->h != h || s->nb != nb || s->keepall != keepall)) { rc = sift_run_batch(ctx, s); if (rc != MI355_OK) return rc; }   // size change: close the batch
+    rc = sift_prepare(ctx, s, w, h, nb, keepall);
     if (rc != MI355_OK) return rc;
     auto fit = ctx->feats.find(img_id);
     if (fit != ctx->feats.end() && fit->second.pending) { rc = mi_resolve_features(ctx); if (rc != MI355_OK) return rc; }   // same id re-extracted while in flight
     Features& f = ctx->feats[img_id];
     f.w = w; f.h = h;
-    MI_HIP(f.kp.reserve(sizeof(mi355_keypoint) * 2048));
-    MI_HIP(f.d8.reserve(128 * 2048));
+    MI_HIP(f.kp.reserve(sizeof(mi355_keypoint) * (size_t)(keepall ? KEEPALL_MAX : 2048)));
+    MI_HIP(f.d8.reserve((size_t)128 * (size_t)(keepall ? KEEPALL_MAX : 2048)));
     f.pending = true; f.h_cnt = nullptr; f.ready = nullptr; f.n = 0;
     s->pend.push_back({img_id, d_bgr, ws, ctx->pend_event});
     if ((int)s->pend.size() >= nb) {
@@ -1779,6 +1884,24 @@ static int sift_run_batch(mi355_ctx* ctx, SiftWork* s) {
         hipLaunchKernelGGL(refine_kernel, dim3(refine_gx, NREG, n), dim3(256), 0, tt, s->P, s->cand.as<unsigned long long>(), s->ccnt.as<unsigned>(), s->cand_cap, cnt + 0,
                            ctx->p.contrast_threshold, ctx->p.edge_threshold, 1.6f, s->refined.as<Refined>(), cnt + 1, s->ref_cap, s->rhist.as<unsigned>(), bs, s->cube.as<float>(), s->cube_cap);
     }
+    if (s->keepall) {
+        // keep-all: every refined point that holds its location's smallest start key is oriented; the keypoints leave in generation order
+        {
+            ProfScope ps(ctx, "kp_select", 0.0, tt);
+            hipLaunchKernelGGL(keepall_live_kernel, dim3(256, n), dim3(256), 0, tt, s->P, s->refined.as<Refined>(), cnt + 1, s->ref_cap, cnt + 8, s->olist.as<unsigned>(), bs);
+            hipLaunchKernelGGL(keepall_reset_kernel, dim3(256, n), dim3(256), 0, tt, s->P, s->refined.as<Refined>(), cnt + 1, s->ref_cap, bs);
+        }
+        {
+            ProfScope ps(ctx, "orient", 0.0, tt);
+            hipLaunchKernelGGL(orient_kernel, dim3(ctx->num_cu * 4, n), dim3(256), 0, tt, s->P, s->refined.as<Refined>(), cnt + 1, s->ref_cap,
+                               s->kps.as<KpRec>(), s->kresp.as<unsigned>(), cnt + 2, s->kp_cap, cnt + 8, 0, bs, s->olist.as<unsigned>());
+        }
+        {
+            ProfScope ps(ctx, "topk", 0.0, tt);
+            hipLaunchKernelGGL(keepall_output_kernel, dim3((KEEPALL_MAX + 255) / 256, n), dim3(256), 0, tt, s->kps.as<KpRec>(), cnt + 2, s->kp_cap, outs, s->sel.as<SelRec>(),
+                               reinterpret_cast<int*>(cnt + 3), reinterpret_cast<int*>(cnt + 4), bs);
+        }
+    } else {
     {
         ProfScope ps(ctx, "kp_select", 0.0, tt);
         hipLaunchKernelGGL(unclaim_kernel, dim3(128, n), dim3(256), 0, tt, s->P, s->refined.as<Refined>(), cnt + 1, s->ref_cap, bs);
@@ -1796,9 +1919,10 @@ static int sift_run_batch(mi355_ctx* ctx, SiftWork* s) {
                                outs, s->sel.as<SelRec>(), reinterpret_cast<int*>(cnt + 3), reinterpret_cast<int*>(cnt + 4), cnt + 8, pass, bs);
         }
     }
+    }
     {
         ProfScope ps(ctx, "describe", 0.0, tt);
-        hipLaunchKernelGGL(describe_kernel, dim3(((int)SEL_STRIDE + 3) / 4, n), dim3(256), 0, tt, s->P, s->sel.as<SelRec>(), reinterpret_cast<const int*>(cnt + 3), outs, bs);
+        hipLaunchKernelGGL(describe_kernel, dim3(((int)bs.sel + 3) / 4, n), dim3(256), 0, tt, s->P, s->sel.as<SelRec>(), reinterpret_cast<const int*>(cnt + 3), outs, bs);
     }
     MI_HIP(hipGetLastError());
     // the matcher's operands of all n frames in one launch, their counters in one strided copy (n launches + n copies of ~5 us each kept

@@ -67,7 +67,9 @@ typedef struct {
 
 /* Literals of the live path; mi355_default_params() fills the reference's values. */
 typedef struct {
-    int32_t nfeatures;         /* 2000   SIFT(2000,3,0.01,20)            MosaicWithoutPos.cpp:4852 */
+    int32_t nfeatures;         /* 2000   SIFT(2000,3,0.01,20)            MosaicWithoutPos.cpp:4852; 1 .. 2048, or <= 0 = cv::SIFT's keep-all
+                                  (CVI/nonfree/features2d.hpp:61: every keypoint, OpenCV's generation order, <= 32768 per frame; what the
+                                  reference's committed run used; such frames can be read back but the matcher takes <= 2048 keypoints) */
     int32_t n_octave_layers;   /* 3 */
     float   contrast_threshold;/* 0.01 */
     float   edge_threshold;    /* 20 */

@@ -107,6 +107,7 @@ const double* orc_cv_exp_table(void);                     /* its 64-entry table 
 /* SURF(hessianThreshold, 4 octaves, 2 layers, extended, oriented) detect + compute (:5313-5335): the strongest max_kp keypoints,
  * ordered by (response descending, octave, layer, row, column); desc: n x 128 floats of unit norm.  returns n */
 int  orc_surf(const uint8_t* bgr, int w, int h, int ws, float hessian_threshold, orc_keypoint* kp, float* desc, int max_kp);
+void orc_surf_set_mode(int mode);      /* 1: det / trace evaluated as the reference's binary does on the x87 unit (measuring instrument, oracle_surf.c) */
 /* exact 1-NN in L2 on float descriptors (what FlannBasedMatcher approximates, :5389-5391); distance = sqrt(sum of squares) */
 void orc_bf_match_f32(const float* d1, int n1, const float* d2, int n2, int32_t* nn_idx, float* nn_dist);
 /* the distance-threshold selection :5400-5424 on matches sorted by (distance, queryIdx) (:5392) */

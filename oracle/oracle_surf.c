@@ -111,6 +111,22 @@ static void stretch(const int proto[][5], int n, int old_size, int size, surf_bo
         out[k].w = (float)proto[k][4] / ((float)(out[k].x2 - out[k].x1) * (float)(out[k].y2 - out[k].y1));
     }
 }
+/* orc_surf_set_mode(1): det / trace as the reference's binary forms them on the x87 unit (see the header: dx, dy rounded to float, dxy
+ * kept at the double precision it was accumulated in, the whole expression in double, rounded to float once) -- a measuring instrument
+ * for tests/test_surf.py, not the definition the product implements (mode 0: every operation rounded to float) */
+static int g_surf_mode = 0;
+void orc_surf_set_mode(int mode) { g_surf_mode = mode; }
+static inline double haar_d(const uint32_t* S, int sw, int x, int y, const surf_box* f, int n)
+{
+    double d = 0.0;
+    for (int k = 0; k < n; k++) {
+        const uint32_t a = S[(size_t)(y + f[k].y1) * sw + x + f[k].x1], b = S[(size_t)(y + f[k].y1) * sw + x + f[k].x2];
+        const uint32_t c = S[(size_t)(y + f[k].y2) * sw + x + f[k].x1], e = S[(size_t)(y + f[k].y2) * sw + x + f[k].x2];
+        const int32_t box = (int32_t)(a + e - b - c);
+        d += (double)box * (double)f[k].w;
+    }
+    return d;
+}
 static inline float haar(const uint32_t* S, int sw, int x, int y, const surf_box* f, int n)
 {
     double d = 0.0;
@@ -286,6 +302,7 @@ int orc_surf(const uint8_t* bgr, int w, int h, int ws, float hessian_threshold, 
             if (q->size > sh - 1 || q->size > sw - 1) continue;
             surf_box dx[3], dy[3], dxy[4];
             stretch(DX_P, 3, 9, q->size, dx); stretch(DY_P, 3, 9, q->size, dy); stretch(DXY_P, 4, 9, q->size, dxy);
+            const surf_box* dxy_boxes = dxy;
             const int si = 1 + (sh - 1 - q->size) / q->step, sj = 1 + (sw - 1 - q->size) / q->step;
             const int margin = (q->size / 2) / q->step;
             for (int i = 0; i < si; i++)
@@ -296,6 +313,11 @@ int orc_surf(const uint8_t* bgr, int w, int h, int ws, float hessian_threshold, 
                     const size_t idx = (size_t)(i + margin) * q->cols + (j + margin);
                     q->det[idx] = vx * vy - (0.81f * vxy) * vxy;
                     q->trace[idx] = vx + vy;
+                    if (g_surf_mode == 1) {
+                        const double dxy = haar_d(S, sw, j * q->step, i * q->step, dxy_boxes, 4);
+                        q->det[idx] = (float)((double)vx * (double)vy - (dxy * dxy) * 0.81);
+                        q->trace[idx] = (float)((double)vy + (double)vx);
+                    }
                 }
         }
     /* ---- maxima over (x, y, layer) + interpolation ---- */

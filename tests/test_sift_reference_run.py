@@ -105,6 +105,42 @@ def test_sift_gpu_equals_oracle_on_the_reference_frames():
     ctx.close()
 
 
+@pytest.mark.gpu
+def test_gpu_keep_all_meets_the_reference_records_directly():
+    """The reference's committed run kept every keypoint (cv::SIFT's nfeatures = 0).  With mi355_params.nfeatures = 0 the HIP path does the
+    same -- up to 32 768 keypoints per frame, in OpenCV's generation order (octave, layer / row / column of the start extremum, orientation
+    bin; of several start points that converge to one location the first keeps it) -- so the file is met WITHOUT the oracle in between:
+    every record of matchPairs.match that names one of the frames at hand is found at its stored index, with its float32 x and y, in the
+    GPU's own output.  (And the whole output equals the oracle's keep-all list: every field, every descriptor byte.)"""
+    import imagemosaicing_amd as im
+    from tests import oracle_lib as ol
+    orc = ol.load_oracle_fast()
+    mp = load_match_pairs()
+    prm = im.default_params()
+    prm.nfeatures = 0
+    ctx = im.Context(0, prm)
+    ks = available_frames()
+    tot = ok = 0
+    for k in ks:
+        img = frame(k)
+        kp, desc = ctx.SiftExtract(k, img, max_kp=32768)
+        assert 2500 < len(kp) < 32768
+        for side in ("a", "b"):
+            m = mp[side + "i"] == k
+            for i, x, y in zip(mp[side + "id"][m], mp[side + "x"][m], mp[side + "y"][m]):
+                tot += 1
+                ok += int(int(i) < len(kp) and kp["x"][int(i)] == np.float32(x) and kp["y"][int(i)] == np.float32(y))
+        okp, odesc = orc.sift(img, nfeatures=0, max_kp=32768)
+        assert len(kp) == len(okp) and np.array_equal(kp.view(np.uint8), okp.view(np.uint8)), f"frame {k}: keep-all keypoints differ from the oracle's"
+        assert np.array_equal(desc.astype(np.uint8), odesc), f"frame {k}: keep-all descriptors differ from the oracle's"
+    assert tot >= (11836 if len(ks) == 20 else 1100), tot      # frames 0 and 1 alone appear in 1154 records
+    assert ok == tot, f"{tot - ok} of {tot} records of the reference run are not in the GPU's keep-all output (index + float32 bits)"
+    # such frames hold more keypoints than the matcher takes: the pair stage says so
+    with pytest.raises(im.Mi355Error):
+        ctx.MatchPairs([(ks[0], ks[1])], 2.5, 1)
+    ctx.close()
+
+
 @pytest.mark.skipif(not os.path.isdir(REF_DATA), reason="needs the reference's 20 test frames (build container only)")
 def test_the_reference_run_end_to_end_from_the_oracles_own_features():
     """the whole pair stage on the reference's 20 frames -- oracle SIFT (nfeatures = 0 as that run), exact 1-NN, grid

@@ -125,3 +125,32 @@ def test_surf_gpu_vs_oracle():
             assert np.array_equal(r["H"].view(np.uint32), Ho.view(np.uint32))
     assert len(pairs) == 12 and 5 <= int(res["accepted"].sum()) < 12
     ctx.close()
+
+
+def test_surf_x87_determinant_moves_a_handful_of_keypoints():
+    """What the one known divergence of the SURF oracle from the reference's binary amounts to: the DLL forms
+    det = (float)(dx dy - 0.81 dxy^2) on the x87 unit, with dxy at the double precision it was accumulated in and one rounding at the end;
+    the oracle (and the product) round every operation to float.  Measured on a frame of the reference's own run with oracle_surf.c's
+    second mode: the same keypoints come out -- the maxima test and the threshold see determinants that differ in their last bits, which can
+    only flip near-ties -- and the responses differ by a few ulp."""
+    PIL = pytest.importorskip("PIL.Image")
+    from tests import oracle_lib as ol
+    from tests.golden_util import GOLD
+    orc = ol.load_oracle_fast()
+    img = np.ascontiguousarray(np.array(PIL.open(os.path.join(GOLD, "DSC00004.JPG")).convert("RGB"))[:, :, ::-1])
+    ka, da = orc.surf(img, 50.0, max_kp=20000)
+    orc.L.orc_surf_set_mode(1)
+    try:
+        kb, db = orc.surf(img, 50.0, max_kp=20000)
+    finally:
+        orc.L.orc_surf_set_mode(0)
+    key = lambda k: set(zip(k["octave"].tolist(), np.round(k["x"], 2).tolist(), np.round(k["y"], 2).tolist()))
+    sa, sb = key(ka), key(kb)
+    common = len(sa & sb)
+    print("\nSURF float-rounded vs x87-style determinant: %d / %d keypoints, %d common" % (len(ka), len(kb), common))
+    assert len(ka) > 1500 and abs(len(ka) - len(kb)) <= max(3, len(ka) // 500) and common >= 0.995 * min(len(ka), len(kb))
+    # responses of the common keypoints: relative difference of a few float ulp
+    ia = {t: i for i, t in enumerate(zip(ka["octave"].tolist(), np.round(ka["x"], 2).tolist(), np.round(ka["y"], 2).tolist()))}
+    ib = {t: i for i, t in enumerate(zip(kb["octave"].tolist(), np.round(kb["x"], 2).tolist(), np.round(kb["y"], 2).tolist()))}
+    rel = np.array([abs(float(ka["response"][ia[t]]) - float(kb["response"][ib[t]])) / float(ka["response"][ia[t]]) for t in sa & sb])
+    assert rel.max() < 1e-4, rel.max()
