@@ -59,8 +59,7 @@ extern "C" int mi355_create(mi355_ctx** out, const mi355_params* params, int dev
     if (const char* e = getenv("MI355_CASCADE")) { const int v = atoi(e); c->cascade = v < 0 ? 0 : (v > 3 ? 3 : v); }
     if (getenv("MI355_SERIAL_HEAVY")) c->serial_heavy = 1;
     {
-        struct { const char* n; int* p; } knobs[] = {{"MI355_SIFT_SPLIT", &c->sift_split}, {"MI355_SIFT_PRIO", &c->sift_prio}, {"MI355_SIFT_ONE_HEAVY", &c->sift_one_heavy},
-            {"MI355_TAIL_CUS", &c->tail_cus}, {"MI355_HEAVY_EXCL", &c->heavy_excl}, {"MI355_STREAM_WAVES_SMALL", &c->stream_waves_small}, {"MI355_STREAM_WAVES_BIG", &c->stream_waves_big}, {"MI355_XWAVES", &c->xwaves}, {"MI355_RANSAC_SPLIT", &c->ransac_split}};
+        struct { const char* n; int* p; } knobs[] = {{"MI355_RANSAC_SPLIT", &c->ransac_split}};
         for (auto& k : knobs) if (const char* e = getenv(k.n)) *k.p = atoi(e);
     }
     if (const char* e = getenv("MI355_SIFT_SLOTS")) { const int v = atoi(e); c->sift_nslots = v < 1 ? 1 : (v > 4 ? 4 : v); }
@@ -85,7 +84,10 @@ extern "C" void mi355_destroy(mi355_ctx* ctx) {
     for (auto& kv : ctx->ws) kv.second.release();
     for (auto& b : ctx->host_frames) b.release();
     for (hipEvent_t e : ctx->host_frame_ev) if (e) (void)hipEventDestroy(e);
-    for (auto& kv : ctx->draw_tables) kv.second.release();
+    for (auto& t : ctx->draw_tables) { t.buf.release(); t.raw.release(); if (t.ready) (void)hipEventDestroy(t.ready); }
+    if (ctx->aux_ev) (void)hipEventDestroy(ctx->aux_ev);
+    if (ctx->aux_stream) (void)hipStreamDestroy(ctx->aux_stream);
+    if (ctx->draw_flags) (void)hipHostFree(ctx->draw_flags);
     for (auto& kv : ctx->prof) for (auto& ev : kv.second.ev) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     if (ctx->heavy_ev) (void)hipEventDestroy(ctx->heavy_ev);
     for (hipEvent_t e : ctx->batch_events) if (e) (void)hipEventDestroy(e);
@@ -376,11 +378,10 @@ extern "C" int mi355_set_option(mi355_ctx* ctx, const char* name, int value) {
         return MI355_OK;
     }
     {
-        // pipeline layout knobs: take effect for work areas created afterwards (set them before the first frame)
-        struct { const char* n; int* p; } knobs[] = {{"sift_split", &ctx->sift_split}, {"sift_prio", &ctx->sift_prio}, {"sift_one_heavy", &ctx->sift_one_heavy},
-            {"tail_cus", &ctx->tail_cus}, {"heavy_excl", &ctx->heavy_excl}, {"stream_waves_small", &ctx->stream_waves_small}, {"stream_waves_big", &ctx->stream_waves_big}, {"xwaves", &ctx->xwaves}, {"ransac_split", &ctx->ransac_split}};
+        struct { const char* n; int* p; } knobs[] = {{"ransac_split", &ctx->ransac_split}};
         for (auto& k : knobs) if (std::string(name) == k.n) { *k.p = value; return MI355_OK; }
     }
+    if (std::string(name) == "sift_flush") return mi_sift_flush(ctx);      // close the batch that is collecting frames now (no wait): the caller shapes the batches of a short survey
     if (std::string(name) == "blur_stream") { ctx->blur_stream = value ? 1 : 0; return MI355_OK; }
     if (std::string(name) == "sift_cascade") { ctx->cascade = value < 0 ? 0 : (value > 3 ? 3 : value); return MI355_OK; }
     if (std::string(name) == "serial_heavy") {

@@ -89,7 +89,14 @@ struct mi355_ctx {
     std::string err;
     std::unordered_map<int, Features> feats;
     std::map<std::string, DevBuf> ws;                  // named grow-only workspaces
-    std::map<std::pair<uint32_t, int>, DevBuf> draw_tables;   // (seed, n) -> RANSAC draw table
+    // RANSAC draw tables of every n in [4, 400] for the last seeds used (ransac.hip mi_ransac_tables): four slots, reused in turn (15.9 MB each;
+    // built on a side stream so that a survey's new seed costs its pair stage nothing: the build runs beside the matcher)
+    struct DrawTables { uint32_t seed = 0; bool valid = false; DevBuf buf, raw; hipEvent_t ready = nullptr; unsigned long long used = 0; };
+    DrawTables draw_tables[4];
+    unsigned long long draw_clock = 0;
+    hipStream_t aux_stream = nullptr;                  // side stream of the table builds
+    hipEvent_t aux_ev = nullptr;
+    int* draw_flags = nullptr;                         // pinned, one word per slot: the raw rand() stream was too short for some n (never seen; checked at the slot's next use)
     bool profiling = false;
     std::string prof_only;                             // non-empty: bracket only these kernel classes (comma separated)
     std::map<std::string, ProfClass> prof;
@@ -108,15 +115,6 @@ struct mi355_ctx {
     int sift_nslots = 3;                               // batch work areas in flight, each on its own stream (option "sift_slots", env MI355_SIFT_SLOTS)
     int xstream_min_w = 1500, xstream_min_frames = 4;  // extrema_stream for octaves at least this wide (and 3/4 as high) in batches of at least so many frames
     int sift_batch = 16;                               // frames per batch (option "sift_batch", env MI355_SIFT_BATCH)
-    // the detect pipeline's streams (options of the same names; read when a batch work area is created, i.e. before the first frame):
-    int sift_split = 0;                                // 1: a batch's keypoint stages run on a second stream of its work area (so that the two kinds of work can be given different queues)
-    int sift_prio = 0;                                 // with sift_split: pyramid + extrema streams at the highest queue priority, keypoint streams at the lowest
-    int sift_one_heavy = 0;                            // with sift_split: ONE stream for the pyramid + extrema phases of all work areas (they run in batch order)
-    int tail_cus = 0;                                  // with sift_split: keypoint streams confined to this many CUs per XCD (hipExtStreamCreateWithCUMask); 0 = no mask
-    int heavy_excl = 0;                                // with tail_cus: the pyramid + extrema streams get the OTHER CUs (their grids are sized for them)
-    int stream_waves_small = 0, stream_waves_big = 0;  // waves per SIMD the streamed blur's grid is sized for (R <= 8 / R >= 10); 0 = 4 / 3
-    int xwaves = 0;                                    // the same for extrema_stream; 0 = 3
-    hipStream_t sift_heavy_stream = nullptr;           // sift_one_heavy
     int ransac_split = -1;                             // ransac.hip: workgroups per pair when there are few pairs (-1: by the pair count, 0: never, k: k); option "ransac_split", env MI355_RANSAC_SPLIT
     hipEvent_t sift_in_ev = nullptr;                   // orders the SIFT streams after the caller's stream
     std::vector<int*> pinned_chunks;                   // pinned count slots, 8 ints per frame
@@ -151,6 +149,7 @@ int mi_warp_image(mi355_ctx*, const uint8_t* src, int w, int h, int ws, int ch, 
                   uint8_t** dst, int* dw, int* dh, int* dws);
 int mi_mosaic_refined_dev(mi355_ctx*, const uint8_t* const* d_imgs, const int* w, const int* h, const int* ws, int n,
                           const float* h9s, uint8_t* d_canvas, int cw, int ch, int cws, int row0, int rows);
+int mi_sift_flush(mi355_ctx*);                               // enqueues every partly filled batch (no wait)
 int mi_sift_flush_if_parked(mi355_ctx*, hipEvent_t ev);   // launches the batch still holding a parked frame with this event
 int mi_chips_and_masks_dev(mi355_ctx*, const uint8_t* const* imgs, const int* w, const int* h, const int* ws, int n,
                            const float* h9s, const uint8_t* keep, int find_masks, int* n_chips, mi355_chip_info** chips,
@@ -170,6 +169,7 @@ int mi_multiband_blend(mi355_ctx*, const uint8_t* const* chips, const uint8_t* c
 int mi_chips_and_masks(mi355_ctx*, const uint8_t* const* imgs, const int* w, const int* h, const int* ws, int n,
                        const float* h9s, const uint8_t* keep, int find_masks, int* n_chips, mi355_chip_info** chips,
                        uint8_t*** chip_imgs, uint8_t*** masks, int* cw, int* ch);
+int mi_ransac_tables(mi355_ctx*, uint32_t seed, const uint16_t** d_tables);      // the draw tables of a seed (built on a side stream; NULL: prefetch)
 int mi_ransac_batch(mi355_ctx*, const mi355_sfpoint* d_p1, const mi355_sfpoint* d_p2, const int* d_n, const int* h_n,
                     int n_pairs, int stride, float dist, int sample_times, uint32_t seed, mi355_pair_result* d_out, int min_keep = -1);
 int mi_ransac_big(mi355_ctx*, const mi355_sfpoint* p1, const mi355_sfpoint* p2, int n, float dist, int sample_times, uint32_t seed,

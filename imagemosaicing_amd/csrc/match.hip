@@ -511,6 +511,7 @@ int mi_match_pairs_dev(mi355_ctx* ctx, const int32_t* pairs, int n_pairs, float 
     if (ctx->p.grid_x * ctx->p.grid_y > 64 || ctx->p.grid_x < 1 || ctx->p.grid_y < 1 || ctx->p.max_selected > MI355_MAX_SELECTED) { ctx->set_error("match_pairs: grid > 64 cells or max_selected > 400"); return MI355_ERR_ARG; }
     const int BATCH = 32768;                                  // bounds the nn workspaces (32768 x 2048 x 12 B = 768 MiB of the 288 GB); every batch boundary drains the stream
     std::vector<PairDesc> pd;
+    { const int rc = mi_ransac_tables(ctx, seed, nullptr); if (rc != MI355_OK) return rc; }      // a new seed's draw tables are built beside the matcher
     for (int b0 = 0; b0 < n_pairs; b0 += BATCH) {
         const int nb = (n_pairs - b0) < BATCH ? (n_pairs - b0) : BATCH;
         int rc = build_pair_table(ctx, pairs + 2 * b0, nb, pd);

@@ -1009,6 +1009,66 @@ int mi_ransac_big(mi355_ctx* ctx, const mi355_sfpoint* p1, const mi355_sfpoint* 
     return MI355_OK;
 }
 
+// Draw tables of every n in [4, 400] for `seed`, indexed by n - 4 (397 x 40 KB = 15.9 MB): built once per seed on the ctx's side stream
+// -- the device generates the rand() stream itself (raw_stream_kernel) -- and kept in one of four slots that are reused in turn, so that a
+// caller whose every survey has its own seed (the reference seeds from the clock) neither allocates nor waits: mi_match_pairs_dev asks for the
+// tables BEFORE it enqueues the matcher, the build runs beside it, and the RANSAC launch only waits for the slot's event on the device.  The
+// "stream too short" flag of a build (never seen: the stream is twice what n = 4 needs) lands in pinned memory and is looked at when the slot is
+// used again.  d_tables == NULL: prefetch only; otherwise the ctx stream is made to wait for the slot's event.
+int mi_ransac_tables(mi355_ctx* ctx, uint32_t seed, const uint16_t** d_tables) {
+    const size_t one = (size_t)MAX_DRAWS * 4;
+    const int ntab = MI355_MAX_SELECTED - 4 + 1;
+    if (!ctx->aux_stream) {
+        MI_HIP(hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking));
+        MI_HIP(hipEventCreateWithFlags(&ctx->aux_ev, hipEventDisableTiming));
+        MI_HIP(hipHostMalloc((void**)&ctx->draw_flags, 4 * sizeof(int), hipHostMallocDefault));
+        for (int i = 0; i < 4; i++) ctx->draw_flags[i] = 0;
+    }
+    mi355_ctx::DrawTables* slot = nullptr;
+    for (auto& t : ctx->draw_tables) if (t.valid && t.seed == seed) slot = &t;
+    if (slot) {
+        const int si = (int)(slot - ctx->draw_tables);
+        if (hipEventQuery(slot->ready) == hipSuccess && ctx->draw_flags[si]) {      // (never seen) the stream was too short for some n: per-n host generation
+            MI_HIP(hipStreamSynchronize(ctx->stream));
+            std::vector<uint16_t> tabs(one * ntab);
+            for (int n = 4; n <= MI355_MAX_SELECTED; n++) mi_glibc_draw_table(seed, n, MAX_DRAWS, tabs.data() + one * (n - 4));
+            MI_HIP(hipMemcpy(slot->buf.p, tabs.data(), tabs.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+            ctx->draw_flags[si] = 0;
+            ctx->set_error("ransac: the draw tables of an earlier call were incomplete (rand() stream too short); they have been rebuilt, results of that call are void");
+            return MI355_ERR_FAILED;
+        }
+    } else {
+        for (auto& t : ctx->draw_tables) if (!t.valid) { slot = &t; break; }
+        if (!slot) { slot = &ctx->draw_tables[0]; for (auto& t : ctx->draw_tables) if (t.used < slot->used) slot = &t; }      // the slot used longest ago
+        const int si = (int)(slot - ctx->draw_tables);
+        if (!slot->ready) MI_HIP(hipEventCreateWithFlags(&slot->ready, hipEventDisableTiming));
+        MI_HIP(slot->buf.reserve(one * ntab * sizeof(uint16_t)));
+        MI_HIP(slot->raw.reserve((size_t)RAW_STREAM * sizeof(int) + 64));
+        // launches that still read the slot's old tables were enqueued on the ctx stream: the build starts behind them
+        MI_HIP(hipEventRecord(ctx->aux_ev, ctx->stream));
+        MI_HIP(hipStreamWaitEvent(ctx->aux_stream, ctx->aux_ev, 0));
+        RawSeed rs;
+        { GlibcRand g; g.seed(seed); for (int k = 0; k < 31; k++) rs.s[k] = (uint32_t)g.r[(g.f + k) % 31]; }     // x_{-31} .. x_{-1}: slot f is overwritten next
+        int* d_flag = slot->raw.as<int>() + RAW_STREAM;
+        DevBuf& dpow = ctx->buf("ransac_raw_powers");
+        if (dpow.cap == 0) {
+            const std::vector<uint32_t>& P = raw_stream_powers();
+            MI_HIP(dpow.reserve(P.size() * sizeof(uint32_t)));
+            MI_HIP(hipMemcpyAsync(dpow.p, P.data(), P.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->aux_stream));      // P is static: outlives the copy
+        }
+        hipLaunchKernelGGL(raw_stream_kernel, dim3(RAW_STREAM / RAW_BLK), dim3(64), 0, ctx->aux_stream, dpow.as<uint32_t>(), rs, slot->raw.as<int>(), RAW_STREAM);
+        MI_HIP(hipMemsetAsync(d_flag, 0, sizeof(int), ctx->aux_stream));
+        hipLaunchKernelGGL(draw_tables_kernel, dim3(ntab), dim3(256), 0, ctx->aux_stream, slot->raw.as<int>(), RAW_STREAM, slot->buf.as<uint16_t>(), 4, d_flag);
+        MI_HIP(hipGetLastError());
+        MI_HIP(hipMemcpyAsync(&ctx->draw_flags[si], d_flag, sizeof(int), hipMemcpyDeviceToHost, ctx->aux_stream));
+        MI_HIP(hipEventRecord(slot->ready, ctx->aux_stream));
+        slot->seed = seed; slot->valid = true;
+    }
+    slot->used = ++ctx->draw_clock;
+    if (d_tables) { MI_HIP(hipStreamWaitEvent(ctx->stream, slot->ready, 0)); *d_tables = slot->buf.as<uint16_t>(); }      // (a prefetch does not make the ctx stream wait)
+    return MI355_OK;
+}
+
 int mi_ransac_batch(mi355_ctx* ctx, const mi355_sfpoint* d_p1, const mi355_sfpoint* d_p2, const int* d_n, const int* h_n,
                     int n_pairs, int stride, float dist, int sample_times, uint32_t seed, mi355_pair_result* d_out, int min_keep) {
     if (n_pairs <= 0) return MI355_OK;
@@ -1039,45 +1099,9 @@ int mi_ransac_batch(mi355_ctx* ctx, const mi355_sfpoint* d_p1, const mi355_sfpoi
         MI_HIP(hipStreamSynchronize(ctx->stream));              // host vectors go out of scope
         d_tables = dtab.as<uint16_t>(); d_table_of = dof.as<int>();
     } else {
-        // n is only known on the device (output of the selection kernel): tables for every n in [4, 400],
-        // indexed by n - 4, built once per seed and cached in HBM (397 x 40 KB = 15.9 MB)
-        auto key = std::make_pair(seed, 0);
-        auto it = ctx->draw_tables.find(key);
-        if (it == ctx->draw_tables.end()) {
-            if (ctx->draw_tables.size() >= 4) {             // keep at most 4 seeds resident
-                MI_HIP(hipStreamSynchronize(ctx->stream));
-                for (auto& kv : ctx->draw_tables) kv.second.release();
-                ctx->draw_tables.clear();
-            }
-            const int ntab = MI355_MAX_SELECTED - 4 + 1;
-            RawSeed rs;
-            { GlibcRand g; g.seed(seed); for (int k = 0; k < 31; k++) rs.s[k] = (uint32_t)g.r[(g.f + k) % 31]; }     // x_{-31} .. x_{-1}: slot f is overwritten next
-            DevBuf& draw = ctx->buf("ransac_raw_stream");
-            MI_HIP(draw.reserve((size_t)RAW_STREAM * sizeof(int) + 64));
-            int* d_flag = draw.as<int>() + RAW_STREAM;
-            DevBuf& dpow = ctx->buf("ransac_raw_powers");
-            if (dpow.cap == 0) {
-                const std::vector<uint32_t>& P = raw_stream_powers();
-                MI_HIP(dpow.reserve(P.size() * sizeof(uint32_t)));
-                MI_HIP(hipMemcpyAsync(dpow.p, P.data(), P.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));      // P is static: outlives the copy
-            }
-            DevBuf& b = ctx->draw_tables[key];
-            MI_HIP(b.reserve(one * ntab * sizeof(uint16_t)));
-            hipLaunchKernelGGL(raw_stream_kernel, dim3(RAW_STREAM / RAW_BLK), dim3(64), 0, ctx->stream, dpow.as<uint32_t>(), rs, draw.as<int>(), RAW_STREAM);
-            MI_HIP(hipMemsetAsync(d_flag, 0, sizeof(int), ctx->stream));
-            hipLaunchKernelGGL(draw_tables_kernel, dim3(ntab), dim3(256), 0, ctx->stream, draw.as<int>(), RAW_STREAM, b.as<uint16_t>(), 4, d_flag);
-            int flag = 0;
-            MI_HIP(hipMemcpyAsync(&flag, d_flag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-            MI_HIP(hipStreamSynchronize(ctx->stream));          // the flag has landed
-            if (flag) {                                        // raw stream too short for some n (never seen): per-n host generation
-                std::vector<uint16_t> tabs(one * ntab);
-                for (int n = 4; n <= MI355_MAX_SELECTED; n++) mi_glibc_draw_table(seed, n, MAX_DRAWS, tabs.data() + one * (n - 4));
-                MI_HIP(hipMemcpyAsync(b.p, tabs.data(), tabs.size() * sizeof(uint16_t), hipMemcpyHostToDevice, ctx->stream));
-                MI_HIP(hipStreamSynchronize(ctx->stream));
-            }
-            it = ctx->draw_tables.find(key);
-        }
-        d_tables = it->second.as<uint16_t>();
+        // n is only known on the device (output of the selection kernel): the tables of every n in [4, 400] for this seed
+        const int rc = mi_ransac_tables(ctx, seed, &d_tables);
+        if (rc != MI355_OK) return rc;
     }
     RansacArgs a;
     memset(&a, 0, sizeof(a));

@@ -743,50 +743,51 @@ __global__ __launch_bounds__(256) void refine_kernel(PyrDev P, const unsigned lo
         int it = 0;
         bool alive = true, accepted = false;
         float contr = 0.0f;
-        // The first step -- the only one for two candidates out of three -- from the 3x3x3 neighbourhood held in registers: either the one
-        // extrema_kernel saved next to the candidate (bit 63; straight from its LDS planes), or, for the candidates of the streamed test,
-        // gathered here: three rows of four levels, the three columns inside the four that start at the even column (C - 1) & ~1 (twelve
-        // 8-byte loads instead of 54 two-byte ones).  Round 4 first gathered these in a kernel of its own and handed them over through
-        // HBM: the same twelve cold 64-byte sectors per candidate there, and a second time here for every candidate that moves on to a
-        // neighbouring pixel (one in three) -- now a mover's next step finds most of its sectors in the cache.
+        // Every Newton step works on the 3x3x3 DoG neighbourhood of its location held in registers: the one extrema_kernel saved next to the
+        // candidate (bit 63; straight from its LDS planes; first step only), or gathered here -- three rows of four levels, the three columns
+        // inside the four that start at the even column (C - 1) & ~1: twelve 8-byte loads instead of the ~50 two-byte ones the fit and the
+        // acceptance tests read through dogv().  Round 4 gathered for the first step only and sent the candidates that move on (one in three)
+        // through dogv() for their later steps; a mover's next location shares most of its 64-byte sectors with the last one, so gathering
+        // again costs little memory and a quarter of the load instructions.  (Odd level widths: dogv() throughout.)
         const bool from_cube = (pk >> 63) != 0;
-        if (from_cube || ((oc.w & 1) == 0 && (foff & 1) == 0)) {
-            float cv[27];
-            if (from_cube) {
-                const float* cb = cube_all + (size_t)reg * 32 * cube_cap + i;       // [element][candidate]: coalesced across the lanes
+        const bool can_gather = (oc.w & 1) == 0 && (foff & 1) == 0;
+        float cv[27];
+        auto gather = [&](int l, int r, int c) {
+            const int a0 = (c - 1) & ~1, sh = ((c - 1) & 1) * 16;
+            int v[4][9];
 #pragma unroll
-                for (int e = 0; e < 27; e++) cv[e] = cb[(size_t)e * cube_cap];
-            } else {
-                const int a0 = (C - 1) & ~1, sh = ((C - 1) & 1) * 16;
-                int v[4][9];
+            for (int q = 0; q < 4; q++) {
+                const lvl_t* lp = oc.lv[l - 1 + q] + foff;
 #pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    const lvl_t* lp = oc.lv[L - 1 + q] + foff;
-#pragma unroll
-                    for (int dr = 0; dr < 3; dr++) {
-                        const uint2_a4 wv = *reinterpret_cast<const uint2_a4*>(lp + (size_t)(R - 1 + dr) * oc.w + a0);      // 4-byte aligned: a0, the row pitch and the frame offset are even
-                        const unsigned long long ww = (((unsigned long long)wv.y << 32) | wv.x) >> sh;
-                        v[q][dr * 3 + 0] = (int)(short)(ww & 0xffffu); v[q][dr * 3 + 1] = (int)(short)((ww >> 16) & 0xffffu); v[q][dr * 3 + 2] = (int)(short)((ww >> 32) & 0xffffu);
-                    }
+                for (int dr = 0; dr < 3; dr++) {
+                    const uint2_a4 wv = *reinterpret_cast<const uint2_a4*>(lp + (size_t)(r - 1 + dr) * oc.w + a0);      // 4-byte aligned: a0, the row pitch and the frame offset are even
+                    const unsigned long long ww = (((unsigned long long)wv.y << 32) | wv.x) >> sh;
+                    v[q][dr * 3 + 0] = (int)(short)(ww & 0xffffu); v[q][dr * 3 + 1] = (int)(short)((ww >> 16) & 0xffffu); v[q][dr * 3 + 2] = (int)(short)((ww >> 32) & 0xffffu);
                 }
-#pragma unroll
-                for (int dl = 0; dl < 3; dl++)
-#pragma unroll
-                    for (int e = 0; e < 9; e++) cv[dl * 9 + e] = (float)(v[dl + 1][e] - v[dl][e]);
             }
-            const int L0 = L, R0 = R, C0 = C;
-            auto dvc = [&](int l, int r, int c) { return cv[(l - L0 + 1) * 9 + (r - R0 + 1) * 3 + (c - C0 + 1)]; };
-            f = fit_step(dvc, L, R, C);
-            const int stt = fit_state(f);
-            if (stt == 1) continue;
-            if (stt == 0) {
-                if (!fit_accept(dvc, L, R, C, f, contrast_thr, edge_thr, contr)) continue;
-                accepted = true;
-            } else {
+#pragma unroll
+            for (int dl = 0; dl < 3; dl++)
+#pragma unroll
+                for (int e = 0; e < 9; e++) cv[dl * 9 + e] = (float)(v[dl + 1][e] - v[dl][e]);
+        };
+        if (from_cube || can_gather) {
+            for (; it < MAX_INTERP; it++) {
+                if (it == 0 && from_cube) {
+                    const float* cb = cube_all + (size_t)reg * 32 * cube_cap + i;       // [element][candidate]: coalesced across the lanes
+#pragma unroll
+                    for (int e = 0; e < 27; e++) cv[e] = cb[(size_t)e * cube_cap];
+                } else if (can_gather) gather(L, R, C);
+                else break;                                                            // (a saved cube on an odd-width level: the later steps through dogv())
+                const int L0 = L, R0 = R, C0 = C;
+                auto dvc = [&](int l, int r, int c) { return cv[(l - L0 + 1) * 9 + (r - R0 + 1) * 3 + (c - C0 + 1)]; };
+                f = fit_step(dvc, L, R, C);
+                const int stt = fit_state(f);
+                if (stt == 1) { alive = false; break; }
+                if (stt == 0) { accepted = fit_accept(dvc, L, R, C, f, contrast_thr, edge_thr, contr); alive = accepted; break; }
                 C += (int)rintf(f.xc); R += (int)rintf(f.xr); L += (int)rintf(f.xi);
-                if (L < 1 || L > N_LAYERS || C < IMG_BORDER || C >= oc.w - IMG_BORDER || R < IMG_BORDER || R >= oc.h - IMG_BORDER) continue;
-                it = 1;
+                if (L < 1 || L > N_LAYERS || C < IMG_BORDER || C >= oc.w - IMG_BORDER || R < IMG_BORDER || R >= oc.h - IMG_BORDER) { alive = false; break; }
             }
+            if (!alive || (can_gather && !accepted)) continue;                       // dead, rejected, or still moving after MAX_INTERP steps
         }
         if (!accepted) {
             for (; it < MAX_INTERP; it++) {
@@ -1409,9 +1410,9 @@ inline bool blur_streams(const Blur16Args& a, bool bgr, int R, int stream_mode) 
     if (a.ds) ok = ok && R == 8 && (a.h & 1) == 0;
     return ok && ((uintptr_t)a.dst & 7) == 0 && (a.fstride & 3) == 0;
 }
-inline void stream_grid(int w, int h, int& L, int& nstrip, int& nseg, int nb = 1, int waves = 2, int simds = 1024) {
+inline void stream_grid(int w, int h, int& L, int& nstrip, int& nseg, int nb = 1, int waves = 2) {
     static const int units_env = [] { const char* e = getenv("MI355_STREAM_UNITS"); return e ? atoi(e) : 0; }();
-    const int units_target = units_env ? units_env : simds * waves;
+    const int units_target = units_env ? units_env : 1024 * waves;
     static const int stream_minl = [] { const char* e = getenv("MI355_STREAM_MINL"); return e ? atoi(e) : 64; }();
     nstrip = (w + 255) / 256;
     nseg = (units_target + nstrip * nb - 1) / (nstrip * nb);
@@ -1420,9 +1421,8 @@ inline void stream_grid(int w, int h, int& L, int& nstrip, int& nseg, int nb = 1
     L = (L + 1) & ~1;
     nseg = (h + L - 1) / L;
 }
-struct HeavyGeom { int simds = 1024, waves_small = 0, waves_big = 0; };      // SIMDs the pyramid streams may use; waves per SIMD their grids are sized for (0: 4 / 3)
 template <bool BGR>
-bool launch_blur(hipStream_t st, int R, const Blur16Args& a_in, int stream_mode, bool* streamed = nullptr, HeavyGeom hg = HeavyGeom()) {
+bool launch_blur(hipStream_t st, int R, const Blur16Args& a_in, int stream_mode, bool* streamed = nullptr) {
     Blur16Args a = a_in;
     const int nb = a.nb > 1 ? a.nb : 1;
     if (streamed) *streamed = false;
@@ -1430,15 +1430,13 @@ bool launch_blur(hipStream_t st, int R, const Blur16Args& a_in, int stream_mode,
         // barrier-free streaming kernel over the whole chip: W waves per SIMD (W x 1024 waves, one round), segments of >= 64 rows, all frames of
         // a batch in one launch.  The register ring of the row results (4 x (2R + 2) registers) decides W: R <= 8 fits 128 registers, R = 10 / 13 168
         static const int w4 = [] { const char* e = getenv("MI355_STREAM_W4"); return e ? atoi(e) : 8; }();
-        const int waves = (R <= w4 && R <= 8) ? 4 : 3;                                     // the instantiation (its register budget)
-        const int gwaves = R <= 8 ? (hg.waves_small > 0 && hg.waves_small < waves ? hg.waves_small : waves)      // what the grid fills: fewer leaves registers to other streams' waves
-                                  : (hg.waves_big > 0 && hg.waves_big < waves ? hg.waves_big : waves);
+        const int waves = (R <= w4 && R <= 8) ? 4 : 3;      // (grids sized for one wave per SIMD fewer, to leave registers to the other batches' keypoint kernels, measured the same: profiles/r05_pipeline_layouts.txt)
         double ksum = 0.0;
         for (int t = 0; t <= 2 * R; t++) ksum += std::fabs((double)a.k[t]);
         if (ksum < 2.6) {                            // the kernel's rounding assumes results in [0, 32767]: samples <= 255 * 48, taps positive and normalised
             for (int t = 0; t <= R; t++) { a.kp[2 * t] = a.k[t]; a.kp[2 * t + 1] = t ? a.k[t - 1] : 0.0f; }
             int L, nstrip, nseg;
-            stream_grid(a.w, a.h, L, nstrip, nseg, nb, gwaves, hg.simds);
+            stream_grid(a.w, a.h, L, nstrip, nseg, nb, waves);
             const int units = nstrip * nseg * nb;
             const dim3 grid((units + 3) / 4), block(256);
             if (streamed) *streamed = true;
@@ -1480,10 +1478,7 @@ struct SiftWork {
     int w = 0, h = 0;                        // input frame size the buffers are sized for
     int nb = 0;                              // frames the buffers hold
     int n_oct = 0;
-    hipStream_t stream = nullptr;             // pyramid + extrema (and everything else unless `tail` exists)
-    hipStream_t tail = nullptr;               // option sift_split: the keypoint stages of the batch
-    bool own_stream = true;                   // false: `stream` is the ctx's shared heavy stream
-    hipEvent_t heavy_done = nullptr;          // sift_split: end of the batch's pyramid + extrema phase
+    hipStream_t stream = nullptr;
     hipEvent_t done = nullptr;               // recorded after the last launch of the latest batch
     DevBuf pyr;                              // all Gaussian levels
     DevBuf claimed;                          // duplicate claim bitmaps
@@ -1497,7 +1492,6 @@ struct SiftWork {
     float kern[N_LEVELS][2 * MAX_R + 1];
     int radius[N_LEVELS];
     float kern0[2 * MAX_R + 1]; int radius0 = 0;
-    size_t batches = 0;                      // batches enqueued on this work area
     struct Pend { int img_id; const uint8_t* d_bgr; int ws; hipEvent_t ev; };   // ev: recorded once the batch is enqueued (optional)
     std::vector<Pend> pend;
 };
@@ -1508,15 +1502,12 @@ constexpr int SIFT_SLOTS_MAX = 4;            // batch work areas (each with its 
 void mi_sift_release(mi355_ctx* ctx) {
     for (SiftWork* s : ctx->sift_slots) {
         if (!s) continue;
-        if (s->stream) { (void)hipStreamSynchronize(s->stream); if (s->own_stream) (void)hipStreamDestroy(s->stream); }
-        if (s->tail) { (void)hipStreamSynchronize(s->tail); (void)hipStreamDestroy(s->tail); }
+        if (s->stream) { (void)hipStreamSynchronize(s->stream); (void)hipStreamDestroy(s->stream); }
         if (s->done) (void)hipEventDestroy(s->done);
-        if (s->heavy_done) (void)hipEventDestroy(s->heavy_done);
         s->pyr.release(); s->claimed.release(); s->cand.release(); s->refined.release(); s->kps.release(); s->kresp.release(); s->sel.release(); s->counters.release(); s->rhist.release(); s->ccnt.release(); s->cube.release(); s->olist.release(); s->mins.release();
         delete s;
     }
     ctx->sift_slots.clear();
-    if (ctx->sift_heavy_stream) { (void)hipStreamDestroy(ctx->sift_heavy_stream); ctx->sift_heavy_stream = nullptr; }
     if (ctx->sift_in_ev) { (void)hipEventDestroy(ctx->sift_in_ev); ctx->sift_in_ev = nullptr; }
     for (int* p : ctx->pinned_chunks) (void)hipHostFree(p);
     ctx->pinned_chunks.clear();
@@ -1524,38 +1515,6 @@ void mi_sift_release(mi355_ctx* ctx) {
 }
 
 static int sift_run_batch(mi355_ctx* ctx, SiftWork* s);
-
-// CU masks (hipExtStreamCreateWithCUMask): bit b of the mask is CU b / 8 of XCD b % 8 on this chip (the driver deals the bits round robin
-// over the XCDs), so the low 8 k bits are k CUs of every XCD
-static void cu_mask_words(int num_cu, int per_xcd, bool complement, std::vector<uint32_t>& m) {
-    m.assign((size_t)(num_cu + 31) / 32, 0u);
-    for (int b = 0; b < num_cu; b++) { const bool in = b < 8 * per_xcd; if (in != complement) m[(size_t)b >> 5] |= 1u << (b & 31); }
-}
-// The streams of one batch work area.  Default: one in-order stream.  Option sift_split: the pyramid + extrema phase and the keypoint stages
-// on two streams (linked by events), so that the chip-filling kernels and the latency-bound ones can be given different queue priorities
-// (sift_prio) or different CUs (tail_cus / heavy_excl), or all work areas share ONE pyramid stream (sift_one_heavy).
-static int sift_make_streams(mi355_ctx* ctx, SiftWork* s) {
-    MI_HIP(hipEventCreateWithFlags(&s->done, hipEventDisableTiming));
-    if (!ctx->sift_split) { MI_HIP(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking)); return MI355_OK; }
-    MI_HIP(hipEventCreateWithFlags(&s->heavy_done, hipEventDisableTiming));
-    int least = 0, greatest = 0;
-    MI_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
-    std::vector<uint32_t> mask;
-    auto make = [&](hipStream_t* out, bool heavy) -> hipError_t {
-        if (ctx->tail_cus > 0 && (!heavy || ctx->heavy_excl)) {
-            cu_mask_words(ctx->num_cu, ctx->tail_cus, heavy, mask);
-            return hipExtStreamCreateWithCUMask(out, (uint32_t)mask.size(), mask.data());
-        }
-        if (ctx->sift_prio) return hipStreamCreateWithPriority(out, hipStreamNonBlocking, heavy ? greatest : least);
-        return hipStreamCreateWithFlags(out, hipStreamNonBlocking);
-    };
-    if (ctx->sift_one_heavy) {
-        if (!ctx->sift_heavy_stream) MI_HIP(make(&ctx->sift_heavy_stream, true));
-        s->stream = ctx->sift_heavy_stream; s->own_stream = false;
-    } else MI_HIP(make(&s->stream, true));
-    MI_HIP(make(&s->tail, false));
-    return MI355_OK;
-}
 
 // enqueues every partly filled batch
 int mi_sift_flush(mi355_ctx* ctx) {
@@ -1585,7 +1544,7 @@ int mi_resolve_features(mi355_ctx* ctx) {
     bool any = false;
     for (auto& kv : ctx->feats) if (kv.second.pending) { any = true; break; }
     if (!any) { ctx->batch_events_used = 0; return rc; }
-    for (SiftWork* s : ctx->sift_slots) if (s && s->stream) { MI_HIP(hipStreamSynchronize(s->stream)); if (s->tail) MI_HIP(hipStreamSynchronize(s->tail)); }
+    for (SiftWork* s : ctx->sift_slots) if (s && s->stream) MI_HIP(hipStreamSynchronize(s->stream));
     for (auto& kv : ctx->feats) {
         if (!kv.second.pending) continue;
         const int r = adopt_counts(ctx, kv.first, kv.second);
@@ -1635,7 +1594,6 @@ static inline size_t up64(size_t v) { return (v + 63) & ~(size_t)63; }
 static int sift_prepare(mi355_ctx* ctx, SiftWork* s, int w, int h, int nb, bool keepall) {
     if (s->w == w && s->h == h && s->nb == nb && s->keepall == keepall) return MI355_OK;
     MI_HIP(hipStreamSynchronize(s->stream));
-    if (s->tail) MI_HIP(hipStreamSynchronize(s->tail));
     if (s->radius0 == 0) {
         // Gaussian kernels (double math on the host, like the oracle): sigma_i = sqrt((s k^i)^2 - (s k^(i-1))^2)
         const double sigma = 1.6, k = std::pow(2.0, 1.0 / N_LAYERS);
@@ -1726,8 +1684,8 @@ int mi_sift_extract_dev(mi355_ctx* ctx, int img_id, const uint8_t* d_bgr, int w,
     const int slot = ctx->sift_next;
     if (!ctx->sift_slots[slot]) {
         ctx->sift_slots[slot] = new SiftWork();
-        const int rc = sift_make_streams(ctx, ctx->sift_slots[slot]);
-        if (rc != MI355_OK) return rc;
+        MI_HIP(hipStreamCreateWithFlags(&ctx->sift_slots[slot]->stream, hipStreamNonBlocking));
+        MI_HIP(hipEventCreateWithFlags(&ctx->sift_slots[slot]->done, hipEventDisableTiming));
     }
     SiftWork* s = ctx->sift_slots[slot];
     int rc = MI355_OK;
@@ -1777,20 +1735,14 @@ static int sift_run_batch(mi355_ctx* ctx, SiftWork* s) {
     const int n = (int)pend.size();
     if (n == 0) return MI355_OK;
     ctx->sift_next = (ctx->sift_next + 1) % SIFT_SLOTS;     // the next batch collects in the next work area
-    const hipStream_t st = s->stream;                 // pyramid + extrema
-    const hipStream_t tt = s->tail ? s->tail : st;    // keypoint stages
-    HeavyGeom hg;
-    hg.simds = 4 * (ctx->tail_cus > 0 && ctx->heavy_excl && s->tail ? ctx->num_cu - 8 * ctx->tail_cus : ctx->num_cu);
-    hg.waves_small = ctx->stream_waves_small; hg.waves_big = ctx->stream_waves_big;
-    const int xw = ctx->xwaves > 0 && ctx->xwaves < XWAVES ? ctx->xwaves : XWAVES;
+    const hipStream_t st = s->stream;
+    const hipStream_t tt = st;                        // (the keypoint stages; on a stream of their own, at a lower queue priority or on CUs of their own they only lose: profiles/r05_pipeline_layouts.txt)
     const int w = s->w, h = s->h;
     const int nf = ctx->p.nfeatures;
     const BatchStride bs = s->bs;
     // the frames were produced on the caller's stream
     MI_HIP(hipEventRecord(ctx->sift_in_ev, ctx->stream));
     MI_HIP(hipStreamWaitEvent(st, ctx->sift_in_ev, 0));
-    if (tt != st && s->batches > 0) MI_HIP(hipStreamWaitEvent(st, s->done, 0));      // the work area's previous batch: its keypoint stages still read the pyramid
-    s->batches++;
     // (measurement mode) the previous batch's pyramid + extrema first.  The wait stands BEFORE the memsets: an event recorded right
     // after a wait takes the end of the stream's last command as its time, which would put the waiting into the first bracket
     const bool serial_heavy = ctx->serial_heavy != 0;
@@ -1824,7 +1776,7 @@ static int sift_run_batch(mi355_ctx* ctx, SiftWork* s) {
             memcpy(a.k, s->kern0, sizeof(float) * (2 * s->radius0 + 1));
             const bool streams = blur_streams(a, true, s->radius0, ctx->blur_stream);
             ProfScope ps(ctx, streams ? "gauss_stream" : "gauss", level_bytes + (double)w * h * 3.0 * n, st);      // read the u8 frames, write level 0
-            if (!launch_blur<true>(st, s->radius0, a, ctx->blur_stream, nullptr, hg)) { ctx->set_error("sift: unsupported kernel radius"); return MI355_ERR_FAILED; }
+            if (!launch_blur<true>(st, s->radius0, a, ctx->blur_stream)) { ctx->set_error("sift: unsupported kernel radius"); return MI355_ERR_FAILED; }
         } else if (!ds_fused) {
             const OctaveDev& pv = s->P.oc[o - 1];
             ProfScope ps(ctx, "downsample", level_bytes * 2.0, st);
@@ -1845,7 +1797,7 @@ static int sift_run_batch(mi355_ctx* ctx, SiftWork* s) {
             }
             const bool streams = blur_streams(a, false, s->radius[i], ctx->blur_stream);
             ProfScope ps(ctx, streams ? "gauss_stream" : "gauss", level_bytes * 2.0, st);   // one read + one write of the level
-            if (!launch_blur<false>(st, s->radius[i], a, ctx->blur_stream, nullptr, hg)) { ctx->set_error("sift: unsupported kernel radius"); return MI355_ERR_FAILED; }
+            if (!launch_blur<false>(st, s->radius[i], a, ctx->blur_stream)) { ctx->set_error("sift: unsupported kernel radius"); return MI355_ERR_FAILED; }
         }
         {
             ProfScope ps(ctx, "extrema", level_bytes * 6.0, st);
@@ -1858,7 +1810,7 @@ static int sift_run_batch(mi355_ctx* ctx, SiftWork* s) {
                 // whole rounds of the 1024 x XWAVES wave slots: the largest k <= 2 whose segments stay >= 64 rows
                 int nseg = 1, L = oc.h;
                 for (int k = 2; k >= 1; k--) {
-                    const int ns = (hg.simds * xw * k) / (nstrip * n);
+                    const int ns = (1024 * XWAVES * k) / (nstrip * n);
                     if (ns < 1) continue;
                     const int l = (oc.h + ns - 1) / ns;
                     if (l >= 64 || k == 1) { L = l < 64 ? 64 : l; break; }
@@ -1877,7 +1829,6 @@ static int sift_run_batch(mi355_ctx* ctx, SiftWork* s) {
         MI_HIP(hipEventRecord(ctx->heavy_ev, st)); ctx->heavy_ev_valid = true;
     }
     // ---- phase 3: keypoint stages of all n frames ----
-    if (tt != st) { MI_HIP(hipEventRecord(s->heavy_done, st)); MI_HIP(hipStreamWaitEvent(tt, s->heavy_done, 0)); }
     {
         ProfScope ps(ctx, "refine", 0.0, tt);
         static const int refine_gx = [] { const char* e = getenv("MI355_REFINE_GX"); return e ? atoi(e) : 2; }();      // workgroups per candidate region: 32 x 64 regions x frames of mostly empty workgroups cost more to dispatch than the fits

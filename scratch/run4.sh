@@ -1,4 +1,4 @@
 #!/bin/bash
-nproc; cat /sys/fs/cgroup/cpu.max 2>/dev/null; grep -c processor /proc/cpuinfo; python -c "import os; print('affinity', len(os.sched_getaffinity(0)))"
-for t in 1 2 4 8 16 32; do MI355_ALIGN_DBG=1 MI355_HOST_THREADS=$t python scratch/align_c4.py 500 25 2>&1 | grep -E "cholesky|moments|threads" | tail -3; done
-python -m pytest tests/test_sift_reference_run.py -m gpu -x -q 2>&1 | tail -2
+python -m pytest tests/test_gpu_sift.py tests/test_sift_reference_run.py tests/test_gpu_configs.py -m gpu -x -q 2>&1 | grep -E "passed|failed|Error|assert" | tail -5
+python scratch/sift_time.py 96 4000 3000 32 2>&1 | grep -v amdgpu
+python scratch/pipe_time.py 96 4000 3000 32 "base:" "small3big2:stream_waves_small=3,stream_waves_big=2" "small3:stream_waves_small=3" "base:" "small3big2:stream_waves_small=3,stream_waves_big=2" 2>&1 | grep -v amdgpu
