@@ -11,7 +11,7 @@ o = oracle_lib.load_oracle_fast()
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 3)
 budget = float(sys.argv[2]) if len(sys.argv) > 2 else 120.0
 c = im.Context(0)
-t0 = time.time(); n = 0; bad = 0
+t0 = time.time(); n = 0; bad = 0; ns = 0; sbad = 0
 while time.time() - t0 < budget:
     k = int(rng.integers(2, 48))
     w = int(rng.integers(48, 460)); h = int(rng.integers(40, 340))
@@ -41,4 +41,17 @@ while time.time() - t0 < budget:
     ok = (ow, oh) == (r["cw"], r["ch"]) and np.array_equal(got, ref)
     n += 1
     if not ok: bad += 1; print("BLEND MISMATCH", k, sizes[:3], spread, yawmax, proj, band, None if keep is None else keep.tolist(), flush=True)
-print("blend soak: %d mosaics, %d mismatches, %.0f s" % (n, bad, time.time() - t0))
+    # the same canvas as stripes (mi355_mosaic_blended_rows_dev): a random cut into 2 .. 9 stripes must give the same bytes
+    if ok:
+        import torch
+        d_imgs = [torch.from_numpy(np.ascontiguousarray(a)).cuda() for a in imgs]
+        ptrs = [t.data_ptr() for t in d_imgs]
+        wv = [a.shape[1] for a in imgs]; hv = [a.shape[0] for a in imgs]; wsv = [a.strides[0] for a in imgs]
+        cuts = sorted(set([0, oh] + [int(v) for v in rng.integers(1, max(oh, 2), int(rng.integers(1, 9)))]))
+        sok = True
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            part, _, _, _ = c.MosaicBlendedDev(ptrs, wv, hv, wsv, h9s, keep=keep, band=band, row0=a, rows=b - a)
+            sok = sok and np.array_equal(part.cpu().numpy(), got[a:b])
+        ns += 1
+        if not sok: sbad += 1; print("STRIPE MISMATCH", k, sizes[:3], spread, yawmax, proj, band, cuts, flush=True)
+print("blend soak: %d mosaics, %d mismatches; %d cut into stripes, %d mismatches, %.0f s" % (n, bad, ns, sbad, time.time() - t0))
