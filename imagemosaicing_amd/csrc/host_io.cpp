@@ -264,7 +264,7 @@ int align_core(const std::vector<PairGroup>& groups, XY&& xy, int n_images, cons
     // summed first (21 products per point), then added to the blocks once
     tdbg("setup");
     std::vector<Moments> mom(groups.size());
-    parallel_chunks(groups.size(), npoints > 200000 ? (host_threads() < 8 ? host_threads() : 8) : 1, [&](size_t g0, size_t g1) {      // 3.2 ms on one thread at C4, 0.7 on eight; more threads only add their start-up
+    parallel_chunks(groups.size(), npoints > 60000 ? (host_threads() < 8 ? host_threads() : 8) : 1, [&](size_t g0, size_t g1) {      // 3.2 ms on one thread at C4, 0.7 on eight; more threads only add their start-up
         for (size_t gi = g0; gi < g1; gi++) {
             const PairGroup& g = groups[gi];
             const int oa = col[g.a], ob = col[g.b];
