@@ -569,12 +569,19 @@ __device__ __forceinline__ void inverse8_wave(const float* M, float* inv, float 
 }
 // the inversions inverse8_sparse hands back for a pivot search below the diagonal: with the wave's LDS scratch at hand and at least half of
 // the wave active, one lane's matrix after the other by the wave together; else (host, or few active lanes) the register routine per lane
+#ifndef MI355_PIVOT_WAVE_MAX
+#define MI355_PIVOT_WAVE_MAX 6
+#endif
+constexpr int PIVOT_WAVE_MAX = MI355_PIVOT_WAVE_MAX;
 __device__ __forceinline__ void pivot_dispatch(bool need, const float* M, float* inv, float eps, float* wl) {
     if (wl) {
         const unsigned long long active = __ballot(1);
         unsigned long long nm = __ballot(need);
         if (nm == 0) return;
-        if (__builtin_popcountll(active) >= 32) { for (; nm; nm &= nm - 1ull) inverse8_wave(M, inv, eps, wl, __builtin_ctzll(nm), active); return; }
+        // one matrix by the wave takes a fraction of what the register routine takes a lane -- but that routine runs for all the lanes that need it
+        // at once: a few matrices go to the wave (a pair of a strip survey: one draw in a thousand needs a pivot, and one lane held its pair for
+        // 15 x 50 us), many stay with their lanes (pairs of unrelated images, most of a window survey, draw degenerate configurations by the dozen)
+        if (__builtin_popcountll(active) >= 32 && __builtin_popcountll(nm) <= PIVOT_WAVE_MAX) { for (; nm; nm &= nm - 1ull) inverse8_wave(M, inv, eps, wl, __builtin_ctzll(nm), active); return; }
     }
     if (need) pivot_call(M, inv, eps);
 }

@@ -119,7 +119,7 @@ __device__ __forceinline__ int block_exclusive_scan_flags(bool flag, int tid, in
 }
 
 // the small shared arrays of a pair's workgroup (one object, so that the stages below can be functions)
-struct RShared {
+struct alignas(16) RShared {
     unsigned long long mask[5][RB / 64];
     unsigned wkey[RB / 64];
     float bestH[9], firstH[9], w[8], dX[8], T1[64], T2[64], t[128];
@@ -475,7 +475,7 @@ __device__ __forceinline__ void write_result(mi355_pair_result* out, int cnt, co
 template <int MODE>
 __device__ __forceinline__ void ransac_body(const RansacArgs& a) {
     constexpr bool BIG = MODE >= 1;
-    extern __shared__ float lds[];
+    extern __shared__ __attribute__((aligned(16))) float lds[];      // 16-byte aligned whatever the static LDS in front of it adds up to: the float4 point copies are read with ds_read_b128 (at 8 mod 16 the support loop took twice as long)
     __shared__ RShared sh;
 
     const int pair = blockIdx.x;
@@ -644,7 +644,7 @@ struct SplitBufs {
 };
 
 __global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(2, 2))) void ransac_split_classify(RansacArgs a, SplitBufs b) {
-    extern __shared__ float lds[];
+    extern __shared__ __attribute__((aligned(16))) float lds[];
     __shared__ RShared sh;
     const int pair = blockIdx.y, part = blockIdx.x, tid = threadIdx.x;
     const int n = a.n[pair];
@@ -665,7 +665,7 @@ __global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 }
 
 __global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(2, 2))) void ransac_split_evaluate(RansacArgs a, SplitBufs b) {
-    extern __shared__ float lds[];
+    extern __shared__ __attribute__((aligned(16))) float lds[];
     __shared__ RShared sh;
     __shared__ int s_pref[NCHUNK * (RB / 64) + 1];
     const int pair = blockIdx.y, part = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
@@ -758,7 +758,7 @@ __global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 }
 
 __global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(2, 2))) void ransac_split_finish(RansacArgs a, SplitBufs b, int pq_stride) {
-    extern __shared__ float lds[];
+    extern __shared__ __attribute__((aligned(16))) float lds[];
     __shared__ RShared sh;
     const int pair = blockIdx.x, tid = threadIdx.x;
     const int n = a.n[pair];

@@ -33,7 +33,7 @@ namespace {
 
 constexpr int S_OCT = 4, S_LAY = 2, S_NL = S_OCT * (S_LAY + 2);      // 16 layers
 constexpr int ORI_R = 6, ORI_WIN = 60, ORI_INC = 5, PATCH = 20;
-constexpr int SURF_MAX_KP = 8192;
+constexpr int SURF_MAX_KP = 32768;
 constexpr unsigned CAND_CAP = 1u << 21;
 
 struct SBox { int x1, y1, x2, y2; float w; };
@@ -516,10 +516,9 @@ __global__ __launch_bounds__(256) void surf_move_desc(const float* desc, const i
 
 // ---- pair stage ---------------------------------------------------------------------------------------------------------------------
 struct SPair { const float* d_i; const float2* xy_i; int n_i; const float* d_j; const float2* xy_j; int n_j; int img_i, img_j; };
-constexpr int SK = SURF_MAX_KP;
 
 // a lane per query: the train rows stream through LDS (64 rows x 128 floats), every lane reads the same row (broadcast)
-__global__ __launch_bounds__(256) void surf_bf(const SPair* pairs, int* nn_idx, float* nn_dist) {
+__global__ __launch_bounds__(256) void surf_bf(const SPair* pairs, int* nn_idx, float* nn_dist, int stride /* queries per pair in the nn arrays */) {
     __shared__ float s_t[64 * 128];
     const SPair pd = pairs[blockIdx.y];
     const int q = blockIdx.x * 256 + threadIdx.x;
@@ -546,26 +545,52 @@ __global__ __launch_bounds__(256) void surf_bf(const SPair* pairs, int* nn_idx, 
             if (acc < best) { best = acc; bi = t0 + t; }
         }
     }
-    if (q_ok) { nn_idx[(size_t)blockIdx.y * SK + q] = bi; nn_dist[(size_t)blockIdx.y * SK + q] = sqrtf(best); }
+    if (q_ok) { nn_idx[(size_t)blockIdx.y * stride + q] = bi; nn_dist[(size_t)blockIdx.y * stride + q] = sqrtf(best); }
 }
 
-// sort by (distance, query) and walk the thresholds (MosaicWithoutPos.cpp:5392, 5400-5424); one workgroup per pair
-__global__ __launch_bounds__(1024) void surf_select(const SPair* pairs, const int* nn_idx, const float* nn_dist, float match_dist, int max_features,
+// walk the thresholds, then sort what is left by (distance, query) (MosaicWithoutPos.cpp:5392, 5400-5424); one workgroup per pair.
+// The reference sorts ALL matches and counts the ones below distT for distT = match_dist, match_dist - 0.05, ... until at most max_features
+// are left; the survivors are the head of the sorted list.  Counting needs no order: every threshold is one pass of the workgroup over the
+// pair's matches (a few dozen per thread), and only the <= 400 survivors are sorted -- the same list as the head of the full sort
+// (which took 8 bytes of LDS per keypoint and capped the keypoints per image at 8192).
+__global__ __launch_bounds__(1024) void surf_select(const SPair* pairs, const int* nn_idx, const float* nn_dist, int stride, float match_dist, int max_features,
                                                     mi355_sfpoint* sel1, mi355_sfpoint* sel2, int* nsel) {
-    extern __shared__ unsigned long long s_key[];                     // SK keys
-    const int pair = blockIdx.x, tid = threadIdx.x;
+    constexpr int NS = 512;                                           // >= MI355_MAX_SELECTED, a power of two
+    static_assert(NS >= MI355_MAX_SELECTED, "survivor list");
+    __shared__ unsigned long long s_key[NS];
+    __shared__ int s_w[16], s_n;
+    const int pair = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const SPair pd = pairs[pair];
     const int M = pd.n_j > 0 ? pd.n_i : 0;
-    const size_t o = (size_t)pair * SK;
-    int N = 64;
-    while (N < M) N <<= 1;
-    for (int i = tid; i < N; i += 1024)
-        s_key[i] = (i < M && nn_idx[o + i] >= 0) ? (((unsigned long long)__float_as_uint(nn_dist[o + i]) << 32) | (unsigned)i) : ~0ull;   // distances >= 0: bit order = value order
+    const size_t o = (size_t)pair * stride;
+    float distT = match_dist;
+    int cnt;
+    for (;;) {                                                        // (the host bounds match_dist: the walk ends)
+        int c = 0;
+        for (int i = tid; i < M; i += 1024) c += (nn_idx[o + i] >= 0 && nn_dist[o + i] < distT) ? 1 : 0;
+        for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off);
+        __syncthreads();
+        if (lane == 0) s_w[wv] = c;
+        __syncthreads();
+        cnt = 0;
+        for (int q = 0; q < 16; q++) cnt += s_w[q];
+        if (cnt <= max_features) break;
+        distT = (float)((double)distT - 0.05);
+    }
+    if (cnt > MI355_MAX_SELECTED) cnt = MI355_MAX_SELECTED;          // (max_features <= 400: never)
+    if (tid == 0) s_n = 0;
+    for (int i = tid; i < NS; i += 1024) s_key[i] = ~0ull;
     __syncthreads();
-    for (int k = 2; k <= N; k <<= 1)
+    for (int i = tid; i < M; i += 1024)
+        if (nn_idx[o + i] >= 0 && nn_dist[o + i] < distT) {
+            const int slot = atomicAdd(&s_n, 1);
+            if (slot < NS) s_key[slot] = ((unsigned long long)__float_as_uint(nn_dist[o + i]) << 32) | (unsigned)i;      // distances >= 0: bit order = value order
+        }
+    __syncthreads();
+    for (int k = 2; k <= NS; k <<= 1)
         for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = tid; i < N; i += 1024) {
-                const int ixj = i ^ j;
+            if (tid < NS) {
+                const int i = tid, ixj = i ^ j;
                 if (ixj > i) {
                     const unsigned long long A = s_key[i], B = s_key[ixj];
                     const bool up = (i & k) == 0;
@@ -574,21 +599,6 @@ __global__ __launch_bounds__(1024) void surf_select(const SPair* pairs, const in
             }
             __syncthreads();
         }
-    __shared__ int s_cnt;
-    if (tid == 0) {
-        // count(distT) = sorted entries with distance < distT: binary search per threshold
-        float distT = match_dist;
-        int cnt;
-        do {
-            int lo = 0, hi = M;
-            while (lo < hi) { const int mid = (lo + hi) >> 1; const unsigned long long kk = s_key[mid]; const bool below = kk != ~0ull && __uint_as_float((unsigned)(kk >> 32)) < distT; if (below) lo = mid + 1; else hi = mid; }
-            cnt = lo;
-            distT = (float)((double)distT - 0.05);
-        } while (cnt > max_features);
-        s_cnt = cnt;
-    }
-    __syncthreads();
-    const int cnt = s_cnt < MI355_MAX_SELECTED ? s_cnt : MI355_MAX_SELECTED;
     for (int i = tid; i < cnt; i += 1024) {
         const int q = (int)(unsigned)(s_key[i] & 0xffffffffull), t = nn_idx[o + q];
         const float2 a = pd.xy_i[q], b = pd.xy_j[t];
@@ -623,7 +633,7 @@ void mi_surf_release(mi355_ctx* ctx) {
 }
 
 static int surf_extract_dev(mi355_ctx* ctx, int img_id, const uint8_t* d_bgr, int w, int h, int ws, float thr, int max_kp, int* n_kp) {
-    if (max_kp < 1 || max_kp > SURF_MAX_KP) { ctx->set_error("surf: max_kp must be in [1, 8192]"); return MI355_ERR_ARG; }
+    if (max_kp < 1 || max_kp > SURF_MAX_KP) { ctx->set_error("surf: max_kp must be in [1, 32768]"); return MI355_ERR_ARG; }
     if (w < 16 || h < 16 || w >= (1 << 14) || h >= (1 << 14) || ws < 3 * w) { ctx->set_error("surf: image geometry (16 <= w, h < 16384)"); return MI355_ERR_ARG; }
     const hipStream_t st = ctx->stream;
     const int sw = w + 1, sh = h + 1;
@@ -734,7 +744,8 @@ static int surf_extract_dev(mi355_ctx* ctx, int img_id, const uint8_t* d_bgr, in
     }
     SurfFeatures& f = surf_state(ctx)->feats[img_id];
     f.w = w; f.h = h;
-    MI_HIP(f.kp.reserve(sizeof(mi355_keypoint) * SURF_MAX_KP)); MI_HIP(f.desc.reserve((size_t)SURF_MAX_KP * 128 * 4)); MI_HIP(f.xy.reserve(sizeof(float2) * SURF_MAX_KP));
+    const size_t keep_max = cnt < (unsigned)max_kp ? (cnt > 0 ? cnt : 1) : (size_t)max_kp;      // the image's feature storage: what this extraction can keep, not the limit
+    MI_HIP(f.kp.reserve(sizeof(mi355_keypoint) * keep_max)); MI_HIP(f.desc.reserve(keep_max * 128 * 4)); MI_HIP(f.xy.reserve(sizeof(float2) * keep_max));
     {
         ProfScope ps(ctx, "surf_describe", 0.0, st);
         hipLaunchKernelGGL(surf_finalize, dim3((max_kp + 255) / 256), dim3(256), 0, st, dL.as<SurfLayers>(), ddet.as<float>(), dtr.as<float>(), dkeys.as<unsigned long long>(),
@@ -831,7 +842,8 @@ extern "C" int mi355_surf_match_pairs(mi355_ctx* ctx, const int32_t* pairs_ij, i
     if (n_pairs == 0) return MI355_OK;
     if (max_features < 1 || max_features > MI355_MAX_SELECTED) { ctx->set_error("surf_match_pairs: max_features must be in [1, 400]"); return MI355_ERR_ARG; }
     auto& feats = surf_state(ctx)->feats;
-    const int BATCH = 512;                                      // bounds the nn workspaces (512 x 8192 x 8 B)
+    const int BATCH = 512;                                      // bounds the nn workspaces (512 pairs x the batch's largest query count x 8 B)
+    if (!(match_dist == match_dist) || match_dist > 100.0f) { ctx->set_error("surf_match_pairs: match_dist must be a number <= 100 (descriptors are unit vectors)"); return MI355_ERR_ARG; }      // the threshold walk lowers it in steps of 0.05 until few enough matches are left
     DevBuf& dpd = ctx->buf("surf_pairs"); DevBuf& didx = ctx->buf("surf_nn_idx"); DevBuf& ddist = ctx->buf("surf_nn_dist");
     DevBuf& ds1 = ctx->buf("sel1"); DevBuf& ds2 = ctx->buf("sel2"); DevBuf& dns = ctx->buf("nsel"); DevBuf& dres = ctx->buf("pair_results");
     for (int b0 = 0; b0 < n_pairs; b0 += BATCH) {
@@ -846,16 +858,16 @@ extern "C" int mi355_surf_match_pairs(mi355_ctx* ctx, const int32_t* pairs_ij, i
             pd[p] = SPair{a.desc.as<float>(), a.xy.as<float2>(), a.n, b.desc.as<float>(), b.xy.as<float2>(), b.n, i, j};
             if (a.n > max_ni) max_ni = a.n;
         }
-        MI_HIP(dpd.reserve(sizeof(SPair) * nb)); MI_HIP(didx.reserve((size_t)nb * SK * 4)); MI_HIP(ddist.reserve((size_t)nb * SK * 4));
+        MI_HIP(dpd.reserve(sizeof(SPair) * nb)); const int nn_stride = (max_ni + 63) & ~63;
+        MI_HIP(didx.reserve((size_t)nb * nn_stride * 4)); MI_HIP(ddist.reserve((size_t)nb * nn_stride * 4));
         MI_HIP(ds1.reserve(sizeof(mi355_sfpoint) * MI355_MAX_SELECTED * (size_t)nb)); MI_HIP(ds2.reserve(sizeof(mi355_sfpoint) * MI355_MAX_SELECTED * (size_t)nb));
         MI_HIP(dns.reserve(sizeof(int) * nb)); MI_HIP(dres.reserve(sizeof(mi355_pair_result) * (size_t)nb));
         MI_HIP(hipMemcpyAsync(dpd.p, pd.data(), sizeof(SPair) * nb, hipMemcpyHostToDevice, ctx->stream));
         MI_HIP(hipStreamSynchronize(ctx->stream));
         {
             ProfScope ps(ctx, "surf_match", 0.0);
-            hipLaunchKernelGGL(surf_bf, dim3((max_ni + 255) / 256, nb), dim3(256), 0, ctx->stream, dpd.as<SPair>(), didx.as<int>(), ddist.as<float>());
-            MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(surf_select), hipFuncAttributeMaxDynamicSharedMemorySize, SK * 8));
-            hipLaunchKernelGGL(surf_select, dim3(nb), dim3(1024), SK * 8, ctx->stream, dpd.as<SPair>(), didx.as<int>(), ddist.as<float>(), match_dist, max_features,
+            hipLaunchKernelGGL(surf_bf, dim3((max_ni + 255) / 256, nb), dim3(256), 0, ctx->stream, dpd.as<SPair>(), didx.as<int>(), ddist.as<float>(), nn_stride);
+            hipLaunchKernelGGL(surf_select, dim3(nb), dim3(1024), 0, ctx->stream, dpd.as<SPair>(), didx.as<int>(), ddist.as<float>(), nn_stride, match_dist, max_features,
                                ds1.as<mi355_sfpoint>(), ds2.as<mi355_sfpoint>(), dns.as<int>());
         }
         MI_HIP(hipGetLastError());

@@ -96,12 +96,15 @@ def test_surf_gpu_vs_oracle():
     orc = ol.load_oracle_fast()
     ctx = im.Context(0)
     cases = [(strip(3, 640, 480, seed=3)[0], 50.0, 3000), ([terrain(333, 257, seed=5), terrain(200, 160, seed=6)], 50.0, 8192),
-             ([terrain(1100, 780, seed=7)], 400.0, 2000), ([np.full((120, 160, 3), 90, np.uint8)], 50.0, 100)]
+             ([terrain(1100, 780, seed=7)], 400.0, 2000), ([np.full((120, 160, 3), 90, np.uint8)], 50.0, 100),
+             ([terrain(2000, 1500, seed=9)], 2.0, 32768),      # 25 001 keypoints: every one kept, as the reference does (the limit was 8192 until round 5)
+             ([terrain(2000, 1500, seed=9)], 2.0, 20000)]      # ... and the strongest 20 000 of them
     for frames, thr, mk in cases:
         for k, img in enumerate(frames):
             kp, d = ctx.SurfExtract(k, img, thr, mk)
             okp, od = orc.surf(img, thr, mk)
             assert len(kp) == len(okp), (img.shape, len(kp), len(okp))
+            if mk > 8192: assert len(kp) > 8192
             for f in ("x", "y", "size", "angle", "response", "octave", "class_id"):
                 a, b = kp[f], okp[f]
                 same = a.view(np.uint32) == b.view(np.uint32) if a.dtype.kind == "f" else a == b
@@ -124,6 +127,31 @@ def test_surf_gpu_vs_oracle():
             assert int(r["n_in"]) == nin and np.array_equal(r["a"][:nin], i1[:nin]) and np.array_equal(r["b"][:nin], i2[:nin])
             assert np.array_equal(r["H"].view(np.uint32), Ho.view(np.uint32))
     assert len(pairs) == 12 and 5 <= int(res["accepted"].sum()) < 12
+    # ... and with more keypoints per image than the old limit: the threshold walk counts over all of them, the survivors are sorted
+    frames = strip(2, 1280, 960, seed=11)[0]
+    feats = []
+    for k, img in enumerate(frames):
+        kp, _ = ctx.SurfExtract(100 + k, img, 2.0, 32768)
+        feats.append(orc.surf(img, 2.0, 32768))
+        assert len(kp) == len(feats[-1][0]) > 8192
+    (k1, d1), (k2, d2) = feats
+    idx, dist = orc.bf_match_f32(d1, d2)                       # once: ~10 000 x 10 000 x 128 on one host core
+    xy1, xy2 = np.stack([k1["x"], k1["y"]], 1), np.stack([k2["x"], k2["y"]], 1)
+    seen = set()
+    for md, mf in ((0.5, 200), (0.3, 150), (0.12, 400), (2.5, 400), (0.04, 400), (0.5, 1)):
+        r = ctx.SurfMatchPairs(np.array([[100, 101]], np.int32), 2.5, 4, match_dist=md, max_features=mf)[0]
+        s1, s2 = orc.select_by_distance(idx, dist, xy1, xy2, md, mf)
+        ok, i1, i2, Ho = orc.ransac2d(s1, s2, 2.5, 1000, 4)
+        nin = len(i1)
+        assert int(r["n_selected"]) == len(s1), (md, mf, int(r["n_selected"]), len(s1))
+        assert int(r["accepted"]) == int(nin > 18)
+        if nin > 18:
+            assert int(r["n_in"]) == nin and np.array_equal(r["a"][:nin], i1[:nin]) and np.array_equal(r["b"][:nin], i2[:nin])
+            assert np.array_equal(r["H"].view(np.uint32), Ho.view(np.uint32))
+        seen.add(len(s1))
+    assert len(seen) >= 3 and max(seen) > 200
+    with pytest.raises(im.Mi355Error):
+        ctx.SurfMatchPairs(np.array([[100, 101]], np.int32), 2.5, 4, match_dist=float("inf"))
     ctx.close()
 
 
