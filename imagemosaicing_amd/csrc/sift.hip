@@ -832,12 +832,11 @@ __global__ __launch_bounds__(256) void refine_kernel(PyrDev P, const unsigned lo
 
 // The claim bitmaps (4 bits per pixel of every octave: 32 MB per 12 MP frame) are zero between batches: instead of clearing
 // them wholesale per batch, the bits this batch set -- exactly one per stored refined record -- are taken back.
-__global__ __launch_bounds__(256) void unclaim_kernel(PyrDev P, const Refined* ref, const unsigned* ref_count, unsigned ref_cap, BatchStride bs) {
-    const size_t fr = blockIdx.y;
+__device__ __forceinline__ void unclaim_body(const PyrDev& P, const Refined* ref, const unsigned* ref_count, unsigned ref_cap, const BatchStride& bs, size_t fr, unsigned first, unsigned step) {
     ref += fr * bs.refined; ref_count += fr * CNT_STRIDE;
     unsigned n = *ref_count;
     if (n > ref_cap) n = ref_cap;
-    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    for (unsigned i = first; i < n; i += step) {
         const Refined rr = ref[i];
         const size_t bit = ((size_t)rr.r * P.oc[rr.o].w + rr.c) * 4 + (size_t)rr.layer;
         atomicAnd(&P.claimed[rr.o][fr * bs.claimed + (bit >> 5)], ~(1u << (bit & 31)));
@@ -896,15 +895,21 @@ struct KpRec {
 // points have response >= T.  Pass 0 orients those; if that turns out to yield fewer than nfeatures keypoints
 // (points without any histogram peak), top-k raises a flag and pass 1 orients the rest -- same final result as
 // orienting everything, ~40x less work in the common case.
-__global__ __launch_bounds__(1024) void resp_threshold_kernel(const unsigned* resp /* |response| bits of the refined points */, const unsigned* ref_count, unsigned ref_cap,
+// The selection is one workgroup per frame walking ~67 000 responses three times (latency, not bandwidth: 32 workgroups on the whole
+// chip), taking the claim bits back is 2 M scattered atomics per batch (bandwidth): as two launches they cost their sum (112 + 88 us per
+// batch of 32), in ONE grid -- workgroup 0 of a frame selects, the others unclaim -- the longer of the two.
+constexpr int UNCLAIM_WGS = 32;                       // workgroups per frame beside the selecting one
+__global__ __launch_bounds__(1024) void select_unclaim_kernel(PyrDev P, const Refined* ref, BatchStride bs,
+                                                              const unsigned* resp /* |response| bits of the refined points */, const unsigned* ref_count, unsigned ref_cap,
                                                               unsigned want, unsigned* ctrl /* [0]=T bits [1]=fallback flag [2]=points >= T */, size_t resp_stride,
                                                               unsigned* list /* indices of the points >= T, what orientation pass 0 walks */) {
-    // one workgroup per frame: two-pass radix select over the 16-bit key (8 exponent + 8 mantissa bits) of the responses;
+    if (blockIdx.x > 0) { unclaim_body(P, ref, ref_count, ref_cap, bs, blockIdx.y, (blockIdx.x - 1) * 1024 + threadIdx.x, (gridDim.x - 1) * 1024); return; }
+    // two-pass radix select over the 16-bit key (8 exponent + 8 mantissa bits) of the responses;
     // T = lower edge of the first key (from the top) at which the count of points with key >= it reaches `want`
-    resp += (size_t)blockIdx.x * resp_stride; ref_count += (size_t)blockIdx.x * CNT_STRIDE; ctrl += (size_t)blockIdx.x * CNT_STRIDE;
-    list += (size_t)blockIdx.x * resp_stride;
+    resp += (size_t)blockIdx.y * resp_stride; ref_count += (size_t)blockIdx.y * CNT_STRIDE; ctrl += (size_t)blockIdx.y * CNT_STRIDE;
+    list += (size_t)blockIdx.y * resp_stride;
     __shared__ unsigned s_h[16][256];               // a private histogram per wave: LDS conflicts stay inside one wave
-    __shared__ unsigned s_sel[2];
+    __shared__ unsigned s_sel[2], s_cnt;
     const int tid = threadIdx.x, wv = tid >> 6;
     unsigned n = *ref_count;
     if (n > ref_cap) n = ref_cap;
@@ -913,14 +918,22 @@ __global__ __launch_bounds__(1024) void resp_threshold_kernel(const unsigned* re
         for (unsigned i = tid; i < n; i += 1024) list[i] = i;
         return;
     }
+    const unsigned nr = (n + 1023u) & ~1023u;
     unsigned above = 0, hi_sel = 0;
     for (int pass = 0; pass < 2; pass++) {
         for (int i = tid; i < 16 * 256; i += 1024) (&s_h[0][0])[i] = 0;
         __syncthreads();
-        for (unsigned i = tid; i < n; i += 1024) {
-            const unsigned key = (resp[i] >> 15) & 0xffffu;
-            if (pass == 0) atomicAdd(&s_h[wv][key >> 8], 1u);
-            else if ((key >> 8) == hi_sel) atomicAdd(&s_h[wv][key & 255u], 1u);
+        for (unsigned i0 = tid; i0 < nr; i0 += 8 * 1024) {
+            unsigned vv[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) { const unsigned i = i0 + 1024u * u; vv[u] = i < n ? resp[i] : 0u; }      // 8 loads in flight (one at a time: 65 round trips per pass)
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                if (i0 + 1024u * u >= n) continue;
+                const unsigned key = (vv[u] >> 15) & 0xffffu;
+                if (pass == 0) atomicAdd(&s_h[wv][key >> 8], 1u);
+                else if ((key >> 8) == hi_sel) atomicAdd(&s_h[wv][key & 255u], 1u);
+            }
         }
         __syncthreads();
         if (tid < 256) { unsigned t = 0; for (int w = 0; w < 16; w++) t += s_h[w][tid]; s_h[0][tid] = t; }
@@ -933,26 +946,33 @@ __global__ __launch_bounds__(1024) void resp_threshold_kernel(const unsigned* re
         }
         __syncthreads();
         if (pass == 0) { hi_sel = s_sel[0]; above = s_sel[1]; }
-        else if (tid == 0) { ctrl[0] = ((hi_sel << 8) | s_sel[0]) << 15; ctrl[1] = 0; ctrl[2] = 0; }
+        else if (tid == 0) { ctrl[0] = ((hi_sel << 8) | s_sel[0]) << 15; ctrl[1] = 0; s_cnt = 0; }
         __syncthreads();
     }
     // the points at or above the threshold, compacted (order free: the total order is established by top-k), so that the
     // orientation pass hands exactly one point to each wave instead of letting 4096 waves look for ~2300 among ~94 000
-    __threadfence_block();
     const unsigned T = ((hi_sel << 8) | s_sel[0]) << 15;
     const int lane = tid & 63;
-    for (unsigned i0 = 0; i0 < n; i0 += 1024) {
-        const unsigned i = i0 + tid;
-        const bool take = i < n && resp[i] >= T;
-        const unsigned long long m = __builtin_amdgcn_ballot_w64(take);
-        if (m) {
-            const int first = __builtin_ctzll(m);
-            unsigned base = 0;
-            if (lane == first) base = atomicAdd(&ctrl[2], (unsigned)__builtin_popcountll(m));
-            base = __shfl(base, first);
-            if (take) list[base + (unsigned)__builtin_popcountll(m & ((1ull << lane) - 1ull))] = i;
+    for (unsigned i0 = tid; i0 < nr; i0 += 8 * 1024) {
+        unsigned vv[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) { const unsigned i = i0 + 1024u * u; vv[u] = i < n ? resp[i] : 0u; }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const unsigned i = i0 + 1024u * u;
+            const bool take = i < n && vv[u] >= T;
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(take);
+            if (m) {
+                const int first = __builtin_ctzll(m);
+                unsigned base = 0;
+                if (lane == first) base = atomicAdd(&s_cnt, (unsigned)__builtin_popcountll(m));      // (LDS: a returning global atomic per wave and trip was a round trip each)
+                base = __shfl(base, first);
+                if (take) list[base + (unsigned)__builtin_popcountll(m & ((1ull << lane) - 1ull))] = i;
+            }
         }
     }
+    __syncthreads();
+    if (tid == 0) ctrl[2] = s_cnt;
 }
 
 constexpr int OCAP = 256;                     // emitted keypoints buffered per workgroup between flushes
@@ -1636,7 +1656,7 @@ static int sift_prepare(mi355_ctx* ctx, SiftWork* s, int w, int h, int nb, bool 
     const size_t B = (size_t)nb;
     MI_HIP(s->pyr.reserve(B * fl * sizeof(lvl_t)));
     MI_HIP(s->claimed.reserve(B * cl * sizeof(unsigned)));
-    MI_HIP(hipMemsetAsync(s->claimed.p, 0, B * cl * sizeof(unsigned), s->stream));      // kept zero between batches by unclaim_kernel
+    MI_HIP(hipMemsetAsync(s->claimed.p, 0, B * cl * sizeof(unsigned), s->stream));      // kept zero between batches (select_unclaim_kernel takes the bits back)
     MI_HIP(s->cand.reserve(B * s->bs.cand * sizeof(unsigned long long)));
     MI_HIP(s->refined.reserve(B * s->bs.refined * sizeof(Refined)));
     MI_HIP(s->kps.reserve(B * s->bs.kps * sizeof(KpRec)));
@@ -1855,8 +1875,8 @@ static int sift_run_batch(mi355_ctx* ctx, SiftWork* s) {
     } else {
     {
         ProfScope ps(ctx, "kp_select", 0.0, tt);
-        hipLaunchKernelGGL(unclaim_kernel, dim3(128, n), dim3(256), 0, tt, s->P, s->refined.as<Refined>(), cnt + 1, s->ref_cap, bs);
-        hipLaunchKernelGGL(resp_threshold_kernel, dim3(n), dim3(1024), 0, tt, s->rhist.as<unsigned>(), cnt + 1, s->ref_cap, (unsigned)nf + 256u, cnt + 8, bs.refined, s->olist.as<unsigned>());
+        hipLaunchKernelGGL(select_unclaim_kernel, dim3(1 + UNCLAIM_WGS, n), dim3(1024), 0, tt, s->P, s->refined.as<Refined>(), bs, s->rhist.as<unsigned>(), cnt + 1, s->ref_cap, (unsigned)nf + 256u, cnt + 8,
+                           bs.refined, s->olist.as<unsigned>());
     }
     for (int pass = 0; pass < 2; pass++) {       // pass 1 (everything below the response threshold) exits at once unless top-k asked for it
         {
