@@ -37,22 +37,19 @@ python profiles/rocpd_summary.py $DB $O/r05_rocprofv3_kernel_stats_bench_c4.txt
 rm -rf $O/trace3
 # the pair stage alone at C4 size (74 029 pairs x 3 calls) and the pipe / issue-rate micro-benchmarks its comments quote
 python scratch/match_time.py 500 182 > $O/r05_match_time_c4.txt 2>> $O/bench.err
-./scratch/mfma_bench > $O/r05_mfma_bench.txt 2>> $O/bench.err
-./scratch/valu_bench > $O/r05_valu_bench.txt 2>> $O/bench.err
 MI355_RANSAC_DBG=1 python scratch/ransac_time.py 300 > $O/r05_ransac_time.txt 2>&1
 python bench.py --as-rank 0,7 --of 8 --steps 8 --warmup 2 > $O/r05_rank_share_proxy_c3.json 2>> $O/bench.err
 python bench.py --as-rank 0,7 --of 8 --window 182 --steps 5 --warmup 1 > $O/r05_rank_share_proxy_c4.json 2>> $O/bench.err
 # the default compositing path shared by stripes (C5 size): the whole blended canvas on one GPU against a rank's stripe
 MI355_BENCH_NO_STANDALONE=1 python bench.py --as-rank 0,3,7 --of 8 --frames 2000 --layout block --window 182 --blend --steps 1 --warmup 1 > $O/r05_rank_share_proxy_c5_blend.json 2>> $O/bench.err
 python scratch/small_batch_time.py 2>&1 | grep "^ransac_split" > $O/r05_small_batch_time.txt
-./scratch/pk_rate > $O/r05_pk_rate.txt 2>> $O/bench.err
 python scratch/sift_time.py 96 4000 3000 32 > $O/r05_sift_time.txt 2>> $O/bench.err
 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29544 bench.py --gpus 2 --backend gloo --all-ranks-on-device0 --steps 2 --warmup 1 --frames 96 --no-cpu-baseline > $O/r05_bench_dryrun_2ranks_1device.json 2>> $O/bench.err
 # the blend's kernel breakdown (200 resident 12 MP chips) and the counters behind DESIGN's RANSAC paragraph
 bash scratch/prof_blend.sh 200 > /dev/null 2>&1; cp gpurun_out/prof_blend/blend_kernel_stats.txt $O/r05_blend_kernel_stats.txt; grep "^blend" gpurun_out/prof_blend/log.txt >> $O/r05_blend_kernel_stats.txt
 bash scratch/pmc_ransac.sh 2>/dev/null | grep "^p[123] " > $O/r05_pmc_ransac.txt
 # randomised parity soaks on this commit (GPU against the oracle): totals quoted in DESIGN.md
-( python scratch/soak_blend.py 48 60; python scratch/soak.py 41 100; python scratch/soak.py 47 60 large; python scratch/soak_ransac.py 42 100; python scratch/soak_match.py 43 60; python scratch/soak_pairs.py 44 80; python scratch/soak_mosaic.py 45 60; python scratch/soak_api.py 46 60 ) 2>&1 | grep -iv "^RCCL\|^HIP\|^ROCm\|^Host\|^Librccl\|amdgpu.ids" | grep -i "mismatch\|cases\|soak" > $O/r05_soak_totals.txt
+( python scratch/soak_blend.py 48 240; python scratch/soak.py 41 300; python scratch/soak.py 47 180 large; python scratch/soak_ransac.py 42 300; python scratch/soak_match.py 43 120; python scratch/soak_pairs.py 44 240; python scratch/soak_mosaic.py 45 120; python scratch/soak_api.py 46 120; python scratch/soak_surf.py 49 240 ) 2>&1 | grep -iv "^RCCL\|^HIP\|^ROCm\|^Host\|^Librccl\|amdgpu.ids" | grep -i "mismatch\|cases\|soak" > $O/r05_soak_totals.txt
 tail -3 $O/bench.err
 ls -la $O
 
