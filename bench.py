@@ -24,6 +24,7 @@ rank that cannot create that communicator fails the run instead of falling back.
 """
 import argparse
 import ctypes
+import gc
 import json
 import math
 import os
@@ -254,11 +255,18 @@ def rank_share_proxy(args):
         return r
 
     def timed(fn, n):
+        gc.collect(); gc.disable()  # (a generation-2 collection of the interpreter paused one step of the second rank measured for ~60 ms, whichever rank that was)
         torch.cuda.synchronize(); t0 = time.perf_counter()
+        marks = []
         for i in range(n):
             fn(100 + i)
+            marks.append(time.perf_counter())
         ctx.synchronize(); torch.cuda.synchronize()
-        return (time.perf_counter() - t0) / n * 1e3
+        t1 = time.perf_counter()
+        gc.enable()
+        if (os.environ.get("MI355_PROXY_STEPS") or os.environ.get("MI355_PROXY_MARKS")) and n > 1:
+            print("[proxy] host returns from the steps at (ms): %s, all done at %.2f" % ([round((m - t0) * 1e3, 2) for m in marks], (t1 - t0) * 1e3), file=sys.stderr, flush=True)
+        return (t1 - t0) / n * 1e3
 
     for i in range(max(args.warmup, 1)):
         r_all = full_step(1 + i)
@@ -301,6 +309,11 @@ def rank_share_proxy(args):
         for i in range(max(args.warmup, 1)):
             share_step(1 + i)
         t_r = timed(share_step, max(args.steps, 1))
+        step_ms = []
+        if os.environ.get("MI355_PROXY_STEPS"):                 # diagnostic: every step on its own, synchronised at its end
+            for i in range(max(args.steps, 1)):
+                step_ms.append(round(timed(share_step, 1), 2))
+            print("[proxy] rank %d steps one by one: %s" % (rk, step_ms), file=sys.stderr, flush=True)
         share_step(999, sync=True)
         # restore the survey's features for the next rank's matching (share_step re-extracted this rank's own frames only: same bytes)
         shares[str(rk)] = {"ms_per_step": t_r, "frames": len(own), "pairs": int(len(pairs)), "batches": -(-len(own) // BATCH), "phase_ms_synchronised": dict(ph)}
@@ -522,12 +535,14 @@ def main():
     PROF_EVERY = 1 if args.profile_all else 5
     ctx.set_option("profile_every:" + DOM, PROF_EVERY)
     ctx.profile_reset()
+    gc.collect(); gc.disable()      # the interpreter's cyclic collector is harness noise (a 60 ms pause at a fixed allocation count: found in the rank-share proxy)
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(100 + i)
     barrier()
     dt = time.perf_counter() - t0
+    gc.enable()
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev) if args.backend == "nccl" else torch.tensor([dt], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -89,42 +89,71 @@ __global__ __launch_bounds__(256) void pack_features_kernel(const PackSrc* src, 
     }
 }
 
-// accepted pair records to the front, order kept (what the reference pushes to the driver, MosaicWithoutPos.cpp:5201-5227)
-__global__ __launch_bounds__(256) void compact_results_kernel(const mi355_pair_result* in, int n, mi355_pair_result* out, int* n_out) {
-    // one workgroup: n is a rank's pair count (<= a few 10^4); records move 16 bytes per lane
-    __shared__ int s_base, s_w[4];
-    if (threadIdx.x == 0) s_base = 0;
+// accepted pair records to the front, order kept (what the reference pushes to the driver, MosaicWithoutPos.cpp:5201-5227).  Three launches:
+// accepted records per block of 256, an exclusive scan of the block counts by one workgroup, the moves (every lane of a wave helps moving the
+// wave's accepted records, 604 x 16 B each).  (One workgroup walking all blocks in turn -- a strided flag read, two barriers and the moves per
+// 256 records -- took 5.5 ms for C4's 74 029 records, 0.6 ms for a rank's share of them.)
+constexpr int CB = 256;
+__global__ __launch_bounds__(CB) void compact_count_kernel(const mi355_pair_result* in, int n, int* blk) {
+    __shared__ int s_w[CB / 64];
+    const int i = blockIdx.x * CB + threadIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(i < n && in[i].accepted != 0);
+    if (lane == 0) s_w[wv] = __builtin_popcountll(m);
     __syncthreads();
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    for (int i0 = 0; i0 < n; i0 += 256) {
-        const int i = i0 + threadIdx.x;
-        const bool acc = i < n && in[i].accepted != 0;
-        const unsigned long long m = __builtin_amdgcn_ballot_w64(acc);
-        if (lane == 0) s_w[wv] = __builtin_popcountll(m);
+    if (threadIdx.x == 0) { int t = 0; for (int q = 0; q < CB / 64; q++) t += s_w[q]; blk[blockIdx.x] = t; }
+}
+__global__ __launch_bounds__(1024) void compact_scan_kernel(int* blk /* counts in, exclusive offsets out */, int nblk, int* n_out) {
+    __shared__ int s_w[16], s_base;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid == 0) s_base = 0;
+    __syncthreads();
+    for (int b0 = 0; b0 < nblk; b0 += 1024) {
+        const int i = b0 + tid;
+        const int v = i < nblk ? blk[i] : 0;
+        int inc = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
+        if (lane == 63) s_w[wv] = inc;
         __syncthreads();
-        int off = s_base;
-        for (int q = 0; q < wv; q++) off += s_w[q];
-        const int pos = off + __builtin_popcountll(m & ((1ull << lane) - 1ull));
-        const int tot = s_w[0] + s_w[1] + s_w[2] + s_w[3];
-        // every lane of the wave helps moving the wave's accepted records (604 x 16 B each)
-        for (int l = 0; l < 64; l++) {
-            if (!((m >> l) & 1ull)) continue;
-            const int src_i = i0 + wv * 64 + l;
-            const int dst_i = off + __builtin_popcountll(m & ((1ull << l) - 1ull));
-            const uint4* s = reinterpret_cast<const uint4*>(in + src_i);
-            uint4* d = reinterpret_cast<uint4*>(out + dst_i);
-            for (int q = lane; q < (int)(sizeof(mi355_pair_result) / 16); q += 64) d[q] = s[q];
-        }
-        (void)pos;
+        int off = s_base, tot = 0;
+        for (int q = 0; q < 16; q++) { if (q < wv) off += s_w[q]; tot += s_w[q]; }
+        if (i < nblk) blk[i] = off + inc - v;
         __syncthreads();
-        if (threadIdx.x == 0) s_base += tot;
+        if (tid == 0) s_base += tot;
         __syncthreads();
     }
-    if (threadIdx.x == 0) *n_out = s_base;
+    if (tid == 0) *n_out = s_base;
+}
+__global__ __launch_bounds__(CB) void compact_move_kernel(const mi355_pair_result* in, int n, const int* blk_off, mi355_pair_result* out) {
+    __shared__ int s_w[CB / 64];
+    const int i0 = blockIdx.x * CB, i = i0 + threadIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(i < n && in[i].accepted != 0);
+    if (lane == 0) s_w[wv] = __builtin_popcountll(m);
+    __syncthreads();
+    int off = blk_off[blockIdx.x];
+    for (int q = 0; q < wv; q++) off += s_w[q];
+    for (unsigned long long r = m; r; r &= r - 1ull) {
+        const int l = __builtin_ctzll(r);
+        const uint4* s = reinterpret_cast<const uint4*>(in + (i0 + wv * 64 + l));
+        uint4* d = reinterpret_cast<uint4*>(out + (off + __builtin_popcountll(m & ((1ull << l) - 1ull))));
+        for (int q = lane; q < (int)(sizeof(mi355_pair_result) / 16); q += 64) d[q] = s[q];
+    }
 }
 static_assert(sizeof(mi355_pair_result) % 16 == 0, "pair record moves in 16-byte pieces");
 
 }  // namespace
+
+// caller holds the ctx lock; d_n_out: device int that receives the number of accepted records
+static int compact_accepted(mi355_ctx* ctx, const mi355_pair_result* d_in, int n, mi355_pair_result* d_out, int* d_n_out) {
+    const int nblk = (n + CB - 1) / CB;
+    DevBuf& dblk = ctx->buf("ag_res_blocks");
+    MI_HIP(dblk.reserve(sizeof(int) * (size_t)nblk));
+    hipLaunchKernelGGL(compact_count_kernel, dim3(nblk), dim3(CB), 0, ctx->stream, d_in, n, dblk.as<int>());
+    hipLaunchKernelGGL(compact_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, dblk.as<int>(), nblk, d_n_out);
+    hipLaunchKernelGGL(compact_move_kernel, dim3(nblk), dim3(CB), 0, ctx->stream, d_in, n, dblk.as<int>(), d_out);
+    MI_HIP(hipGetLastError());
+    return MI355_OK;
+}
 
 struct mi355_comm {
     ncclComm_t comm = nullptr;
@@ -369,8 +398,7 @@ extern "C" int mi355_allgather_results(mi355_ctx* ctx, const mi355_pair_result* 
         MI_HIP(hipMemcpyAsync(d_counts + rank, &n_send, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
     } else if (accepted_only && n_local > 0) {
         MI_HIP(dcomp.reserve(sizeof(mi355_pair_result) * (size_t)n_local));
-        hipLaunchKernelGGL(compact_results_kernel, dim3(1), dim3(256), 0, ctx->stream, d_local, n_local, dcomp.as<mi355_pair_result>(), d_counts + rank);
-        MI_HIP(hipGetLastError());
+        { const int rc = compact_accepted(ctx, d_local, n_local, dcomp.as<mi355_pair_result>(), d_counts + rank); if (rc != MI355_OK) return rc; }
         d_send = dcomp.as<mi355_pair_result>();
     } else {
         MI_HIP(hipMemcpyAsync(d_counts + rank, &n_send, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
@@ -412,8 +440,7 @@ extern "C" int mi355_compact_accepted_dev(mi355_ctx* ctx, const mi355_pair_resul
     if (n == 0) return MI355_OK;
     DevBuf& dcnt = ctx->buf("ag_res_counts");
     MI_HIP(dcnt.reserve(sizeof(int) * 64));
-    hipLaunchKernelGGL(compact_results_kernel, dim3(1), dim3(256), 0, ctx->stream, d_in, n, d_out, dcnt.as<int>());
-    MI_HIP(hipGetLastError());
+    { const int rc = compact_accepted(ctx, d_in, n, d_out, dcnt.as<int>()); if (rc != MI355_OK) return rc; }
     MI_HIP(hipMemcpyAsync(n_out, dcnt.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     MI_HIP(hipStreamSynchronize(ctx->stream));
     return MI355_OK;

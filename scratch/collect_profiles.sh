@@ -38,7 +38,7 @@ rm -rf $O/trace3
 # the pair stage alone at C4 size (74 029 pairs x 3 calls) and the pipe / issue-rate micro-benchmarks its comments quote
 python scratch/match_time.py 500 182 > $O/r05_match_time_c4.txt 2>> $O/bench.err
 MI355_RANSAC_DBG=1 python scratch/ransac_time.py 300 > $O/r05_ransac_time.txt 2>&1
-python bench.py --as-rank 0,7 --of 8 --steps 8 --warmup 2 > $O/r05_rank_share_proxy_c3.json 2>> $O/bench.err
+python bench.py --as-rank 0,3,7 --of 8 --steps 8 --warmup 2 > $O/r05_rank_share_proxy_c3.json 2>> $O/bench.err
 python bench.py --as-rank 0,7 --of 8 --window 182 --steps 5 --warmup 1 > $O/r05_rank_share_proxy_c4.json 2>> $O/bench.err
 # the default compositing path shared by stripes (C5 size): the whole blended canvas on one GPU against a rank's stripe
 MI355_BENCH_NO_STANDALONE=1 python bench.py --as-rank 0,3,7 --of 8 --frames 2000 --layout block --window 182 --blend --steps 1 --warmup 1 > $O/r05_rank_share_proxy_c5_blend.json 2>> $O/bench.err
@@ -49,7 +49,7 @@ python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.
 bash scratch/prof_blend.sh 200 > /dev/null 2>&1; cp gpurun_out/prof_blend/blend_kernel_stats.txt $O/r05_blend_kernel_stats.txt; grep "^blend" gpurun_out/prof_blend/log.txt >> $O/r05_blend_kernel_stats.txt
 bash scratch/pmc_ransac.sh 2>/dev/null | grep "^p[123] " > $O/r05_pmc_ransac.txt
 # randomised parity soaks on this commit (GPU against the oracle): totals quoted in DESIGN.md
-( python scratch/soak_blend.py 48 240; python scratch/soak.py 41 300; python scratch/soak.py 47 180 large; python scratch/soak_ransac.py 42 300; python scratch/soak_match.py 43 120; python scratch/soak_pairs.py 44 240; python scratch/soak_mosaic.py 45 120; python scratch/soak_api.py 46 120; python scratch/soak_surf.py 49 240 ) 2>&1 | grep -iv "^RCCL\|^HIP\|^ROCm\|^Host\|^Librccl\|amdgpu.ids" | grep -i "mismatch\|cases\|soak" > $O/r05_soak_totals.txt
+( python scratch/soak_blend.py 58 60; python scratch/soak.py 51 100; python scratch/soak.py 57 60 large; python scratch/soak_ransac.py 52 100; python scratch/soak_match.py 53 60; python scratch/soak_pairs.py 54 80; python scratch/soak_mosaic.py 55 60; python scratch/soak_api.py 56 60; python scratch/soak_surf.py 59 60 ) 2>&1 | grep -iv "^RCCL\|^HIP\|^ROCm\|^Host\|^Librccl\|amdgpu.ids" | grep -i "mismatch\|cases\|soak" > $O/r05_soak_totals.txt
 tail -3 $O/bench.err
 ls -la $O
 
