@@ -142,3 +142,34 @@ def test_rccl_collectives_world1():
     assert np.array_equal(r1[0]["a"].view(np.uint8), r1[1]["a"].view(np.uint8)) and np.array_equal(r1[0]["H"].view(np.uint32), r1[1]["H"].view(np.uint32))
     ex.close()
     ctx.close()
+
+
+def test_compaction_of_accepted_records_keeps_order_at_every_size():
+    """mi355_compact_accepted_dev (the first step of mi355_allgather_results): the accepted records to the front, order kept
+    (MosaicWithoutPos.cpp:5201-5227 pushes them in loop order).  Three launches -- accepted per block of 256, a scan of the block counts by one
+    workgroup in chunks of 1024 blocks, the moves -- so: sizes around the block and the chunk, none / all / sparse / dense accepted."""
+    import torch
+    import imagemosaicing_amd as im
+    ctx = im.Context(0)
+    rng = np.random.default_rng(5)
+    rec = im.PAIR_RESULT.itemsize
+    for n, p in [(1, 1.0), (1, 0.0), (255, 0.5), (256, 0.5), (257, 1.0), (5000, 0.03), (74029, 0.03), (262144 + 300, 0.4), (300000, 0.0), (270000, 1.0)]:
+        host = np.zeros(n, im.PAIR_RESULT)
+        host["accepted"] = (rng.random(n) < p).astype(host["accepted"].dtype)
+        host["i"] = np.arange(n); host["j"] = rng.integers(0, 1 << 20, n); host["n_in"] = rng.integers(0, 400, n)
+        host["H"] = rng.random((n, 9)).astype(np.float32)
+        raw = host.view(np.uint8).reshape(n, rec)
+        raw[:, -16:] = rng.integers(0, 256, (n, 16), dtype=np.uint8)          # the record's last 16-byte piece moves too
+        host = raw.view(im.PAIR_RESULT).reshape(n)
+        d_in = torch.from_numpy(raw.copy()).cuda()
+        d_out = torch.full((n, rec), 0xAB, dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()                                              # (the fill runs on torch's stream, the library on its own)
+        k = ctx.CompactAcceptedDev(d_in.data_ptr(), n, d_out.data_ptr())
+        want = raw[host["accepted"] != 0]
+        assert k == len(want), (n, p, k, len(want))
+        got = d_out.cpu().numpy()
+        if not np.array_equal(got[:k], want):
+            bad = np.where((got[:k] != want).any(1))[0]
+            raise AssertionError((n, p, len(bad), bad[:5].tolist(), bad[-3:].tolist(), [int(x) for x in np.where(got[bad[0]] != want[bad[0]])[0][:6]]))
+        assert (got[k:] == 0xAB).all(), (n, p)                               # nothing written behind the accepted records
+    ctx.close()
