@@ -98,6 +98,7 @@ def parse():
     ap.add_argument("--profile-all", action="store_true", help="bracket every kernel class with events (extra JSON field)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for single-GPU dry runs of the N>1 path)")
     ap.add_argument("--all-ranks-on-device0", action="store_true", help="dry run of the N>1 path on a 1-GPU box (use with --backend gloo)")
+    ap.add_argument("--align-input", default="records", choices=["records", "moments"], help="what the host alignment starts from: the accepted pair records (9664 B each; the default, what every earlier round timed) or their second moments formed on the device (mi355_allgather_moments / mi355_pair_moments_dev, 184 B each; same transforms bit for bit)")
     ap.add_argument("--as-rank", default=None, help="ONE-GPU PROXY of a rank's share of an --of G rank run (no launcher, no other rank): comma list of ranks, e.g. 0,7")
     ap.add_argument("--of", type=int, default=8, help="rank count the --as-rank proxy pretends to be part of")
     return ap.parse_args()
@@ -236,10 +237,17 @@ def rank_share_proxy(args):
     canvas = torch.empty(canvas_cap, dtype=torch.uint8, device=dev)
     ex = md.Exchange(ctx, "rccl", strict=True)                    # a communicator of one rank: the same calls as in the N-rank run
 
+    use_mom = args.align_input == "moments"
+
     def align_and_layout(r):
-        label = im.select_connected_results(r, F) if len(r) else np.zeros(F, np.int32)
+        # r: PAIR_RESULT records, or (--align-input moments) PAIR_MOMENTS records
+        if use_mom:
+            label = im.select_connected_moments(r, F) if len(r) else np.zeros(F, np.int32)
+        else:
+            label = im.select_connected_results(r, F) if len(r) else np.zeros(F, np.int32)
         label[0] = 1
-        T = im.global_affine_align_results(r, F, fixed=[1 if (k == 0 or label[k] == 0) else 0 for k in range(F)], label=label)
+        fixed_k = [1 if (k == 0 or label[k] == 0) else 0 for k in range(F)]
+        T = im.global_affine_align_moments(r, F, fixed=fixed_k, label=label) if use_mom else im.global_affine_align_results(r, F, fixed=fixed_k, label=label)
         h9 = T["m"].copy()
         h9[label == 0, 8] = 0.0
         cw, ch, cws, _ = im.mosaic_layout(wv, hv, h9)
@@ -249,7 +257,7 @@ def rank_share_proxy(args):
         for k in range(F):
             ctx.SiftExtractDev(k, fptr[k], w, h, ws)
         ctx.MatchPairsDev(all_pairs, results.data_ptr(), 2.5, seed)
-        r = ex.allgather_results(results, survey_pairs, accepted_only=True)
+        r = ex.allgather_moments(results, survey_pairs) if use_mom else ex.allgather_results(results, survey_pairs, accepted_only=True)
         h9, cw, ch, cws = align_and_layout(r)
         ctx.MosaicImagesRefinedDev(fptr, wv, hv, wsv, h9, canvas.data_ptr(), cw, ch, cws)
         return r
@@ -295,7 +303,10 @@ def rank_share_proxy(args):
             mark()
             ctx.MatchPairsDev(pairs, res_r.data_ptr(), 2.5, seed)
             mark()
-            ex.allgather_results(res_r, len(pairs), accepted_only=True)     # compaction + count and record all-gathers + D2H of this rank's records
+            if use_mom:
+                ex.allgather_moments(res_r, len(pairs))                     # compaction + moments + count and payload all-gathers + D2H of this rank's share
+            else:
+                ex.allgather_results(res_r, len(pairs), accepted_only=True)     # compaction + count and record all-gathers + D2H of this rank's records
             mark()
             h9, cw, ch, cws = align_and_layout(r_all)              # replicated on every rank: the whole survey's records
             mark()
@@ -342,7 +353,7 @@ def rank_share_proxy(args):
                  "note": "mi355_mosaic_blended_rows_dev: a rank forms the chips that reach its rows (+ the pyramids' reach), their ownership there and the rows of every blender level its output depends on; no exchange (replicas of frames + stripes)"}
     acc = int(len(r_all))
     feat_bytes = F * 319488 * (G - 1) / G                          # feature records a rank RECEIVES (2048 x (28 + 128) B per frame)
-    res_bytes = acc * 9664 * (G - 1) / G
+    res_bytes = acc * (184 if use_mom else 9664) * (G - 1) / G
     link = 153e9
     wire_ring_ms = (feat_bytes + res_bytes) / link * 1e3
     wire_direct_ms = (feat_bytes + res_bytes) / (7 * link) * 1e3
@@ -351,7 +362,7 @@ def rank_share_proxy(args):
            "metric": "image-pairs/sec (detect+match+H+warp), 4000x3000 UAV frames", "of_ranks": G, "ranks_run": ranks,
            "workload": "%d frames %dx%d, pair window %d (%d pairs), strong scaling: frames k mod %d, pairs i mod %d, canvas stripes" % (F, w, h, args.window, survey_pairs, G, G),
            "one_gpu_ms_per_step": t_one, "one_gpu_pairs_per_s": survey_pairs / t_one * 1e3, "frames_per_batch": {"one_gpu": batch_one, "rank": BATCH},
-           "share": shares, "accepted_records": acc,
+           "share": shares, "accepted_records": acc, "align_input": args.align_input,
            "wire_model_ms": {"ring_one_link_153GBs": wire_ring_ms, "direct_7_links": wire_direct_ms,
                              "bytes_received_per_rank": {"features": feat_bytes, "accepted_records": res_bytes},
                              "note": "not measurable on one GPU: xGMI time of the OTHER ranks' payloads, SURVEY section 5 link model"},
@@ -464,6 +475,18 @@ def main():
         stream.synchronize()
         return res_host.numpy().view(im.PAIR_RESULT).reshape(-1)[:k]
 
+    mom_dev = torch.zeros((max(n_pairs, 1), im.PAIR_MOMENTS.itemsize), dtype=torch.uint8, device=dev) if args.align_input == "moments" else None
+    mom_host = torch.empty((max(n_pairs, 1), im.PAIR_MOMENTS.itemsize), dtype=torch.uint8).pin_memory() if args.align_input == "moments" else None
+
+    def local_moments():
+        """--align-input moments without an exchange: the accepted records are compacted on the device, their second moments formed there, 184 B per pair cross PCIe"""
+        k = ctx.CompactAcceptedDev(results.data_ptr(), n_pairs, compact.data_ptr())
+        if k:
+            ctx.PairMomentsDev(compact.data_ptr(), k, mom_dev.data_ptr())
+            mom_host[:k].copy_(mom_dev[:k], non_blocking=True)
+        stream.synchronize()
+        return mom_host.numpy().view(im.PAIR_MOMENTS).reshape(-1)[:k]
+
     def step(seed):
         nonlocal phases
         t0 = time.perf_counter()
@@ -475,7 +498,16 @@ def main():
         if phases:
             ctx.synchronize(); t1 = time.perf_counter()
         ctx.MatchPairsDev(pairs, results.data_ptr(), 2.5, seed)
-        if exchange:
+        mom = None
+        if args.align_input == "moments":
+            # what the alignment needs of an accepted pair, formed on the device: 184 B instead of 9664 over xGMI and PCIe; the records stay in HBM
+            r = None
+            if exchange:
+                mom = ex.allgather_moments(results, n_pairs)
+                mom = mom[np.lexsort((mom["j"], mom["i"]))] if strong else local_moments()
+            else:
+                mom = local_moments()
+        elif exchange:
             # RCCL over xGMI: H + inlier lists of every accepted pair of the survey, on every rank's host
             r = ex.allgather_results(results, n_pairs, accepted_only=True)
             if strong:
@@ -489,17 +521,21 @@ def main():
             t2 = time.perf_counter()
         # Select_Connected_Matched_Images + the global alignment straight from the pair records (the m_vecMatchPairs copy of the adaptor
         # path is 28 M correspondences = 1.1 GB at C5; same sums in the same order, tests/test_cabi.py)
-        label = im.select_connected_results(r, F) if len(r) else np.zeros(F, np.int32)
+        if mom is not None:
+            label = im.select_connected_moments(mom, F) if len(mom) else np.zeros(F, np.int32)
+        else:
+            label = im.select_connected_results(r, F) if len(r) else np.zeros(F, np.int32)
         label[0] = 1
         ta = time.perf_counter()
-        T = im.global_affine_align_results(r, F, fixed=[1 if (k == 0 or label[k] == 0) else 0 for k in range(F)], label=label)
+        fixed_k = [1 if (k == 0 or label[k] == 0) else 0 for k in range(F)]
+        T = im.global_affine_align_moments(mom, F, fixed=fixed_k, label=label) if mom is not None else im.global_affine_align_results(r, F, fixed=fixed_k, label=label)
         td = time.perf_counter()
         h9 = T["m"].copy()
         h9[label == 0, 8] = 0.0                                     # invalid images are skipped by the warp (MWP.cpp:4646-4652)
         cw, ch, cws, _ = im.mosaic_layout(wv, hv, h9)
         if phases:
             state["host_parts_ms"] = {"select_connected": (ta - t2) * 1e3, "global_affine_align": (td - ta) * 1e3, "layout": (time.perf_counter() - td) * 1e3,
-                                      "correspondences": int(r["n_in"].astype(np.int64).sum())}
+                                      "correspondences": int((mom if mom is not None else r)["n_in"].astype(np.int64).sum()), "align_input": args.align_input}
         if cws * ch > canvas_cap:
             raise RuntimeError("canvas larger than provisioned (%d x %d)" % (cw, ch))
         if phases:
@@ -607,6 +643,13 @@ def main():
 
     # quality of the last step against ground truth (accepted pairs): corner transfer error in pixels
     r = state["r"]
+    if r is None:                                                   # --align-input moments: the records of the last step, fetched once, untimed
+        if exchange and strong:
+            r = ex.allgather_results(results, n_pairs, accepted_only=True)
+            r = r[np.lexsort((r["j"], r["i"]))]
+        else:
+            r = local_accepted()
+        state["r"] = r
     errs = []
     corners = np.array([[0, 0, 1], [w - 1, 0, 1], [w - 1, h - 1, 1], [0, h - 1, 1]], np.float64).T
     for rec in r:

@@ -19,9 +19,10 @@ PAIR_RESULT = np.dtype([("i", "<i4"), ("j", "<i4"), ("n_in", "<i4"), ("n_selecte
 CHIPINFO = np.dtype([("x0", "<i4"), ("y0", "<i4"), ("w", "<i4"), ("h", "<i4"), ("img", "<i4"),
                      ("sx", "<f4"), ("sy", "<f4"), ("quad", "<f4", (8,))])
 IMAGE_TRANSFORM = np.dtype([("m", "<f4", (9,)), ("fixed", "<i4")])
+PAIR_MOMENTS = np.dtype([("i", "<i4"), ("j", "<i4"), ("n_in", "<i4"), ("_pad", "<i4"), ("aa", "<f8", (6,)), ("ab", "<f8", (9,)), ("bb", "<f8", (6,))])
 FEATURE_HEADER = np.dtype([("img_id", "<i4"), ("n_kp", "<i4"), ("w", "<i4"), ("h", "<i4")])
 FEATURE_RECORD_BYTES = 319488
-assert SFPOINT.itemsize == 12 and KEYPOINT.itemsize == 28 and MATCHPAIR.itemsize == 40 and PAIR_RESULT.itemsize == 9664
+assert SFPOINT.itemsize == 12 and KEYPOINT.itemsize == 28 and MATCHPAIR.itemsize == 40 and PAIR_RESULT.itemsize == 9664 and PAIR_MOMENTS.itemsize == 184
 
 
 class Params(C.Structure):
@@ -342,6 +343,18 @@ class Context:
         self.L.mi355_free(ptr)
         return out
 
+    def PairMomentsDev(self, d_results, n, d_out):
+        """one PAIR_MOMENTS record per pair record, device to device (ctx stream)"""
+        self._chk(self.L.mi355_pair_moments_dev(self._h, C.c_void_p(int(d_results)), int(n), C.c_void_p(int(d_out))))
+
+    def AllGatherMoments(self, d_local, n_local):
+        """this rank's accepted pairs -> their second moments -> every rank's host (rank-major PAIR_MOMENTS array)"""
+        ptr, n = C.c_void_p(), C.c_int(0)
+        self._chk(self.L.mi355_allgather_moments(self._h, C.c_void_p(int(d_local)), int(n_local), C.byref(ptr), C.byref(n)))
+        out = _copy_out(ptr, n.value * PAIR_MOMENTS.itemsize, PAIR_MOMENTS)
+        self.L.mi355_free(ptr)
+        return out
+
     def SynthFrameDev(self, d_dst, w, h, ws, A6, seed, frame_seed, gain=1.0, noise=2.0):
         A6 = np.ascontiguousarray(A6, np.float32)
         self._chk(self.L.mi355_synth_frame_dev(self._h, C.c_void_p(int(d_dst)), int(w), int(h), int(ws), _p(A6), C.c_uint32(seed),
@@ -620,6 +633,37 @@ def global_affine_align_results(results, n_images, fixed=None, label=None):
     rc = load_library().mi355_global_affine_align_results(_p(r), len(r), int(n_images), _p(ff), _p(lb), _p(out))
     if rc != 0:
         raise Mi355Error(rc, "global_affine_align_results")
+    return out
+
+
+def pair_moments_host(results):
+    """the second moments of every record's inlier coordinates, summed on the host (what mi355_pair_moments_dev forms on the device)"""
+    r = np.ascontiguousarray(results, PAIR_RESULT)
+    out = np.zeros(len(r), PAIR_MOMENTS)
+    rc = load_library().mi355_pair_moments_host(_p(r), len(r), _p(out))
+    if rc != 0:
+        raise Mi355Error(rc, "pair_moments_host")
+    return out
+
+
+def select_connected_moments(moments, n_images):
+    m = np.ascontiguousarray(moments, PAIR_MOMENTS)
+    label = np.zeros(n_images, np.int32)
+    rc = load_library().mi355_select_connected_moments(_p(m), len(m), int(n_images), _p(label))
+    if rc != 0:
+        raise Mi355Error(rc, "select_connected_moments")
+    return label
+
+
+def global_affine_align_moments(moments, n_images, fixed=None, label=None):
+    """the global alignment from the pairs' second moments: the same bits as global_affine_align_results on the records they were formed from"""
+    m = np.ascontiguousarray(moments, PAIR_MOMENTS)
+    ff = None if fixed is None else np.ascontiguousarray(fixed, np.int32)
+    lb = None if label is None else np.ascontiguousarray(label, np.int32)
+    out = np.zeros(n_images, IMAGE_TRANSFORM)
+    rc = load_library().mi355_global_affine_align_moments(_p(m), len(m), int(n_images), _p(ff), _p(lb), _p(out))
+    if rc != 0:
+        raise Mi355Error(rc, "global_affine_align_moments")
     return out
 
 

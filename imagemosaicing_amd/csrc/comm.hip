@@ -139,6 +139,32 @@ __global__ __launch_bounds__(CB) void compact_move_kernel(const mi355_pair_resul
         for (int q = lane; q < (int)(sizeof(mi355_pair_result) / 16); q += 64) d[q] = s[q];
     }
 }
+// The second moments of a pair's inlier coordinates (mi355_pair_moments): a wave per pair record, lane t < 21 owns ONE of the 21 sums and walks
+// the inliers in order -- the chain of separately rounded double products and sums host_io.cpp pair_moments_host forms (this file is compiled
+// with -ffp-contract=off like the host file), so the alignment gives the same bits from either.
+__global__ __launch_bounds__(256) void pair_moments_kernel(const mi355_pair_result* in, int n, mi355_pair_moments* out) {
+    const int p = blockIdx.x * 4 + (threadIdx.x >> 6), t = threadIdx.x & 63;
+    if (p >= n) return;
+    const mi355_pair_result& e = in[p];
+    mi355_pair_moments& o = out[p];
+    const int cnt = (e.accepted && e.n_in > 0) ? (e.n_in < MI355_MAX_SELECTED ? e.n_in : MI355_MAX_SELECTED) : 0;
+    if (t == 0) { o.i = e.i; o.j = e.j; o.n_in = cnt; o._pad = 0; }
+    if (t >= 21) return;
+    // operands of this lane's product out of c = (xa, ya, 1, xb, yb, 1): aa 00 10 11 20 21 22 | ab row-major | bb like aa
+    int iu, iv;
+    if (t < 6)       { const int i = t < 1 ? 0 : (t < 3 ? 1 : 2), j = t - (i * (i + 1)) / 2; iu = i; iv = j; }
+    else if (t < 15) { const int q = t - 6; iu = q / 3; iv = 3 + q % 3; }
+    else             { const int q = t - 15, i = q < 1 ? 0 : (q < 3 ? 1 : 2), j = q - (i * (i + 1)) / 2; iu = 3 + i; iv = 3 + j; }
+    auto pick = [](int k, double xa, double ya, double xb, double yb) { return k == 0 ? xa : (k == 1 ? ya : (k == 3 ? xb : (k == 4 ? yb : 1.0))); };
+    double s = 0.0;
+    for (int k = 0; k < cnt; k++) {
+        const double xa = (double)e.a[k].x, ya = (double)e.a[k].y, xb = (double)e.b[k].x, yb = (double)e.b[k].y;
+        const double pr = pick(iu, xa, ya, xb, yb) * pick(iv, xa, ya, xb, yb);
+        s = s + pr;
+    }
+    if (t < 6) o.aa[t] = s; else if (t < 15) o.ab[t - 6] = s; else o.bb[t - 15] = s;
+}
+static_assert(sizeof(mi355_pair_moments) == 184, "moment record");
 static_assert(sizeof(mi355_pair_result) % 16 == 0, "pair record moves in 16-byte pieces");
 
 }  // namespace
@@ -443,5 +469,67 @@ extern "C" int mi355_compact_accepted_dev(mi355_ctx* ctx, const mi355_pair_resul
     { const int rc = compact_accepted(ctx, d_in, n, d_out, dcnt.as<int>()); if (rc != MI355_OK) return rc; }
     MI_HIP(hipMemcpyAsync(n_out, dcnt.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     MI_HIP(hipStreamSynchronize(ctx->stream));
+    return MI355_OK;
+}
+
+extern "C" int mi355_pair_moments_dev(mi355_ctx* ctx, const mi355_pair_result* d_results, int n, mi355_pair_moments* d_out) {
+    LOCKED_PROLOGUE
+    if (n < 0 || (n > 0 && (!d_results || !d_out))) return MI355_ERR_ARG;
+    if (n == 0) return MI355_OK;
+    hipLaunchKernelGGL(pair_moments_kernel, dim3((n + 3) / 4), dim3(256), 0, ctx->stream, d_results, n, d_out);
+    MI_HIP(hipGetLastError());
+    return MI355_OK;
+}
+
+// mi355_allgather_results' protocol (counts first, a rank with bad arguments sends -1, payload padded to the largest count) on the moments of
+// this rank's accepted pairs
+extern "C" int mi355_allgather_moments(mi355_ctx* ctx, const mi355_pair_result* d_local, int n_local, mi355_pair_moments** all, int* n_all) {
+    LOCKED_PROLOGUE
+    if (!ctx->comm) { ctx->set_error("allgather_moments: no communicator (mi355_comm_init)"); return MI355_ERR_ARG; }
+    if (all) *all = nullptr;
+    if (n_all) *n_all = 0;
+    const bool bad_local = n_local < 0 || (n_local > 0 && !d_local) || !all || !n_all;
+    if (bad_local) n_local = 0;
+    RcclApi* api = rccl_api();
+    const int world = ctx->comm->world, rank = ctx->comm->rank;
+    DevBuf& dcnt = ctx->buf("ag_res_counts");
+    MI_HIP(dcnt.reserve(sizeof(int) * (size_t)(world + 1)));
+    int* d_counts = dcnt.as<int>();
+    DevBuf& dcomp = ctx->buf("ag_res_compact");
+    int n_send = n_local;
+    if (bad_local) n_send = -1;
+    if (bad_local || n_local == 0) MI_HIP(hipMemcpyAsync(d_counts + rank, &n_send, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    else {
+        MI_HIP(dcomp.reserve(sizeof(mi355_pair_result) * (size_t)n_local));
+        const int rc = compact_accepted(ctx, d_local, n_local, dcomp.as<mi355_pair_result>(), d_counts + rank);
+        if (rc != MI355_OK) return rc;
+    }
+    MI_NCCL(api->AllGather(d_counts + rank, d_counts, sizeof(int), ncclChar, ctx->comm->comm, ctx->stream));
+    std::vector<int> counts(world);
+    MI_HIP(hipMemcpyAsync(counts.data(), d_counts, sizeof(int) * world, hipMemcpyDeviceToHost, ctx->stream));
+    MI_HIP(hipStreamSynchronize(ctx->stream));                  // (n_send's host copy is consumed)
+    int n_max = 1; size_t total = 0;
+    if (bad_local) { ctx->set_error("allgather_moments: bad arguments"); return MI355_ERR_ARG; }
+    for (int r = 0; r < world; r++) { if (counts[r] < 0) { ctx->set_error("allgather_moments: rank " + std::to_string(r) + " failed before the exchange"); return MI355_ERR_FAILED; } if (counts[r] > n_max) n_max = counts[r]; total += (size_t)counts[r]; }
+    n_send = counts[rank];
+    DevBuf& dall = ctx->buf("ag_mom_all");
+    MI_HIP(dall.reserve(sizeof(mi355_pair_moments) * (size_t)n_max * world));
+    mi355_pair_moments* my = dall.as<mi355_pair_moments>() + (size_t)n_max * rank;
+    if (n_send > 0) {
+        hipLaunchKernelGGL(pair_moments_kernel, dim3((n_send + 3) / 4), dim3(256), 0, ctx->stream, dcomp.as<mi355_pair_result>(), n_send, my);
+        MI_HIP(hipGetLastError());
+    }
+    MI_NCCL(api->AllGather(my, dall.p, sizeof(mi355_pair_moments) * (size_t)n_max, ncclChar, ctx->comm->comm, ctx->stream));
+    mi355_pair_moments* out = (mi355_pair_moments*)malloc(sizeof(mi355_pair_moments) * (total > 0 ? total : 1));
+    if (!out) return MI355_ERR_NOMEM;
+    size_t o = 0;
+    hipError_t e = hipSuccess;
+    for (int r = 0; r < world && e == hipSuccess; r++) {
+        if (counts[r] > 0) e = hipMemcpyAsync(out + o, dall.as<mi355_pair_moments>() + (size_t)n_max * r, sizeof(mi355_pair_moments) * (size_t)counts[r], hipMemcpyDeviceToHost, ctx->stream);
+        o += (size_t)counts[r];
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) { free(out); ctx->set_error(hipGetErrorString(e)); return MI355_ERR_DEVICE; }
+    *all = out; *n_all = (int)total;
     return MI355_OK;
 }

@@ -223,11 +223,12 @@ MI355_SIMD_CLONES static void chol_row_update(double* __restrict s, int n, const
 }
 
 struct PairGroup { int a, b; size_t first; int count; };                          // correspondences `first .. first + count` belong to images (a, b)
-struct Moments { double aa[6], ab[9], bb[6], vax[3], vay[3], vbx[3], vby[3]; };
+struct Moments { double aa[6], ab[9], bb[6]; };         // second moments of one image pair's correspondences: sum ca ca^T (lower triangle), sum ca cb^T, sum cb cb^T; ca = (xa, ya, 1)
 
-// xy(k, xa, ya, xb, yb): the k-th correspondence
-template <class XY>
-int align_core(const std::vector<PairGroup>& groups, XY&& xy, int n_images, const int32_t* fixed, mi355_image_transform* out) {
+// The system from the image pairs' second moments (on the host: align_core below; formed on the device: mi355_pair_moments_dev).  The right-hand
+// sides need no sums of their own: with image a fixed the equations' constant terms are -A, and sum cb (-xa) = -(sum ca cb^T) row 0 -- the same
+// products, negated; with b fixed sum ca xb = column 0 of that matrix.
+int align_from_moments(const std::vector<PairGroup>& groups, const std::vector<Moments>& mom, size_t npoints_hint, int n_images, const int32_t* fixed, mi355_image_transform* out) {
     static const bool align_dbg = getenv("MI355_ALIGN_DBG") != nullptr;
     const auto tdbg0 = std::chrono::steady_clock::now();
     auto tdbg = [&](const char* what) { if (align_dbg) fprintf(stderr, "[align] %-10s at %.3f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tdbg0).count()); };
@@ -249,57 +250,31 @@ int align_core(const std::vector<PairGroup>& groups, XY&& xy, int n_images, cons
     // lower band is stored: entry (i, j), i - bw <= j <= i, at Nb[i * W + (j - i + bw)] (a dense D x D matrix was 18 MB to clear per
     // call at 500 images, 288 MB at 2000).
     int bwb = 0;
-    size_t npoints = 0;
+    (void)npoints_hint;
     for (const PairGroup& g : groups) {
         if (g.a < 0 || g.a >= n_images || g.b < 0 || g.b >= n_images) return MI355_ERR_ARG;
         const int oa = col[g.a], ob = col[g.b];
         if (oa >= 0 && ob >= 0) { const int d = oa > ob ? oa - ob : ob - oa; if (d > bwb) bwb = d; }
-        npoints += (size_t)g.count;
     }
     const int bw = 3 * bwb + 2;                      // half bandwidth in scalar rows
     const size_t W = (size_t)bw + 1;
     std::vector<double> Nb((size_t)D * W, 0.0), bx(D, 0.0), by(D, 0.0);
     auto NL = [&](int i, int j) -> double& { return Nb[(size_t)i * W + (size_t)(j - i + bw)]; };     // i >= j >= i - bw
-    // rows: coefficients [xa ya 1] on image a's columns, -[xb yb 1] on image b's columns.  The second moments of one image pair are
-    // summed first (21 products per point), then added to the blocks once
+    // rows: coefficients [xa ya 1] on image a's columns, -[xb yb 1] on image b's columns
     tdbg("setup");
-    std::vector<Moments> mom(groups.size());
-    parallel_chunks(groups.size(), npoints > 60000 ? (host_threads() < 8 ? host_threads() : 8) : 1, [&](size_t g0, size_t g1) {      // 3.2 ms on one thread at C4, 0.7 on eight; more threads only add their start-up
-        for (size_t gi = g0; gi < g1; gi++) {
-            const PairGroup& g = groups[gi];
-            const int oa = col[g.a], ob = col[g.b];
-            Moments& m = mom[gi];
-            memset(&m, 0, sizeof(m));
-            if (oa < 0 && ob < 0) continue;
-            double Maa[3][3] = {{0}}, Mab[3][3] = {{0}}, Mbb[3][3] = {{0}}, Vax[3] = {0}, Vay[3] = {0}, Vbx[3] = {0}, Vby[3] = {0};
-            for (int k = 0; k < g.count; k++) {
-                float fxa, fya, fxb, fyb;
-                xy(g.first + (size_t)k, fxa, fya, fxb, fyb);
-                const double ca[3] = {fxa, fya, 1.0}, cb[3] = {fxb, fyb, 1.0};
-                double rx = 0.0, ry = 0.0;                 // right-hand sides after moving the fixed image's identity terms
-                if (oa < 0) { rx -= fxa; ry -= fya; }
-                if (ob < 0) { rx += fxb; ry += fyb; }
-                for (int i = 0; i < 3; i++) {
-                    for (int j = 0; j <= i; j++) { Maa[i][j] += ca[i] * ca[j]; Mbb[i][j] += cb[i] * cb[j]; }
-                    for (int j = 0; j < 3; j++) Mab[i][j] += ca[i] * cb[j];
-                    Vax[i] += ca[i] * rx; Vay[i] += ca[i] * ry; Vbx[i] += cb[i] * rx; Vby[i] += cb[i] * ry;
-                }
-            }
-            int t = 0;
-            for (int i = 0; i < 3; i++) for (int j = 0; j <= i; j++, t++) { m.aa[t] = Maa[i][j]; m.bb[t] = Mbb[i][j]; }
-            for (int i = 0; i < 3; i++) { for (int j = 0; j < 3; j++) m.ab[3 * i + j] = Mab[i][j]; m.vax[i] = Vax[i]; m.vay[i] = Vay[i]; m.vbx[i] = Vbx[i]; m.vby[i] = Vby[i]; }
-        }
-    });
     tdbg("moments");
     for (size_t gi = 0; gi < groups.size(); gi++) {
         const PairGroup& g = groups[gi];
         const int oa = col[g.a], ob = col[g.b];
         if (oa < 0 && ob < 0) continue;
         const Moments& m = mom[gi];
+        double vax[3] = {0.0, 0.0, 0.0}, vay[3] = {0.0, 0.0, 0.0}, vbx[3] = {0.0, 0.0, 0.0}, vby[3] = {0.0, 0.0, 0.0};
+        if (oa < 0) for (int i = 0; i < 3; i++) { vbx[i] = 0.0 - m.ab[i]; vby[i] = 0.0 - m.ab[3 + i]; }      // a fixed: sum cb[i] (-xa), sum cb[i] (-ya)
+        if (ob < 0) for (int i = 0; i < 3; i++) { vax[i] = m.ab[3 * i]; vay[i] = m.ab[3 * i + 1]; }            // b fixed: sum ca[i] xb, sum ca[i] yb
         int t = 0;
-        if (oa >= 0) for (int i = 0; i < 3; i++) { bx[3 * oa + i] += m.vax[i]; by[3 * oa + i] += m.vay[i]; for (int j = 0; j <= i; j++) NL(3 * oa + i, 3 * oa + j) += m.aa[t++]; }
+        if (oa >= 0) for (int i = 0; i < 3; i++) { bx[3 * oa + i] += vax[i]; by[3 * oa + i] += vay[i]; for (int j = 0; j <= i; j++) NL(3 * oa + i, 3 * oa + j) += m.aa[t++]; }
         t = 0;
-        if (ob >= 0) for (int i = 0; i < 3; i++) { bx[3 * ob + i] -= m.vbx[i]; by[3 * ob + i] -= m.vby[i]; for (int j = 0; j <= i; j++) NL(3 * ob + i, 3 * ob + j) += m.bb[t++]; }
+        if (ob >= 0) for (int i = 0; i < 3; i++) { bx[3 * ob + i] -= vbx[i]; by[3 * ob + i] -= vby[i]; for (int j = 0; j <= i; j++) NL(3 * ob + i, 3 * ob + j) += m.bb[t++]; }
         if (oa >= 0 && ob >= 0 && oa != ob) {
             for (int i = 0; i < 3; i++)
                 for (int j = 0; j < 3; j++) {
@@ -438,6 +413,36 @@ int align_core(const std::vector<PairGroup>& groups, XY&& xy, int n_images, cons
     }
     return MI355_OK;
 }
+
+// the second moments of a pair's correspondences, summed in correspondence order (21 products per point; mi355_pair_moments_dev forms the same sums)
+template <class XY>
+inline void pair_moments_host(const PairGroup& g, XY& xy, Moments& m) {
+    double Maa[3][3] = {{0}}, Mab[3][3] = {{0}}, Mbb[3][3] = {{0}};
+    for (int k = 0; k < g.count; k++) {
+        float fxa, fya, fxb, fyb;
+        xy(g.first + (size_t)k, fxa, fya, fxb, fyb);
+        const double ca[3] = {fxa, fya, 1.0}, cb[3] = {fxb, fyb, 1.0};
+        for (int i = 0; i < 3; i++) {
+            for (int j = 0; j <= i; j++) { Maa[i][j] += ca[i] * ca[j]; Mbb[i][j] += cb[i] * cb[j]; }
+            for (int j = 0; j < 3; j++) Mab[i][j] += ca[i] * cb[j];
+        }
+    }
+    int t = 0;
+    for (int i = 0; i < 3; i++) for (int j = 0; j <= i; j++, t++) { m.aa[t] = Maa[i][j]; m.bb[t] = Mbb[i][j]; }
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) m.ab[3 * i + j] = Mab[i][j];
+}
+// xy(k, xa, ya, xb, yb): the k-th correspondence.  A thread owns whole image pairs (their moments are summed per pair first, then added to the
+// blocks in pair order by one thread): the result does not depend on the number of threads.
+template <class XY>
+int align_core(const std::vector<PairGroup>& groups, XY&& xy, int n_images, const int32_t* fixed, mi355_image_transform* out) {
+    size_t npoints = 0;
+    for (const PairGroup& g : groups) npoints += (size_t)g.count;
+    std::vector<Moments> mom(groups.size());
+    parallel_chunks(groups.size(), npoints > 60000 ? (host_threads() < 8 ? host_threads() : 8) : 1, [&](size_t g0, size_t g1) {      // 3.2 ms on one thread at C4, 0.7 on eight; more threads only add their start-up
+        for (size_t gi = g0; gi < g1; gi++) pair_moments_host(groups[gi], xy, mom[gi]);
+    });
+    return align_from_moments(groups, mom, npoints, n_images, fixed, out);
+}
 }  // namespace
 
 extern "C" int mi355_global_affine_align(const mi355_match_point_pairs* v, int n, int n_images, const int32_t* fixed,
@@ -472,6 +477,44 @@ extern "C" int mi355_global_affine_align_results(const mi355_pair_result* r, int
                       n_images, fixed, out);
 }
 
+// ... and from the pairs' second moments (formed on the device by mi355_pair_moments_dev, or here): the same system, the same bits
+static_assert(sizeof(mi355_pair_moments) == 184 && sizeof(Moments) == 21 * sizeof(double), "moment record layout");
+extern "C" int mi355_pair_moments_host(const mi355_pair_result* r, int n, mi355_pair_moments* out) {
+    if (n < 0 || (n > 0 && (!r || !out))) return MI355_ERR_ARG;
+    for (int p = 0; p < n; p++) {
+        mi355_pair_moments& o = out[p];
+        memset(&o, 0, sizeof(o));
+        o.i = r[p].i; o.j = r[p].j;
+        if (!r[p].accepted || r[p].n_in <= 0) continue;
+        if (r[p].n_in > MI355_MAX_SELECTED) return MI355_ERR_ARG;
+        o.n_in = r[p].n_in;
+        const mi355_pair_result& e = r[p];
+        auto xy = [&e](size_t k, float& xa, float& ya, float& xb, float& yb) { xa = e.a[k].x; ya = e.a[k].y; xb = e.b[k].x; yb = e.b[k].y; };
+        Moments m;
+        pair_moments_host(PairGroup{e.i, e.j, 0, e.n_in}, xy, m);
+        memcpy(o.aa, m.aa, sizeof(m.aa)); memcpy(o.ab, m.ab, sizeof(m.ab)); memcpy(o.bb, m.bb, sizeof(m.bb));
+    }
+    return MI355_OK;
+}
+extern "C" int mi355_global_affine_align_moments(const mi355_pair_moments* mm, int n, int n_images, const int32_t* fixed, const int32_t* label,
+                                                 mi355_image_transform* out) {
+    if (n < 0 || n_images <= 0 || (n > 0 && !mm) || !out) return MI355_ERR_ARG;
+    std::vector<PairGroup> groups;
+    std::vector<Moments> mom;
+    size_t npoints = 0;
+    for (int p = 0; p < n; p++) {
+        if (mm[p].n_in <= 0) continue;
+        if (mm[p].i < 0 || mm[p].i >= n_images || mm[p].j < 0 || mm[p].j >= n_images || mm[p].n_in > MI355_MAX_SELECTED) return MI355_ERR_ARG;
+        if (label && !(label[mm[p].i] && label[mm[p].j])) continue;
+        groups.push_back(PairGroup{mm[p].i, mm[p].j, (size_t)p, mm[p].n_in});
+        Moments m;
+        memcpy(m.aa, mm[p].aa, sizeof(m.aa)); memcpy(m.ab, mm[p].ab, sizeof(m.ab)); memcpy(m.bb, mm[p].bb, sizeof(m.bb));
+        mom.push_back(m);
+        npoints += (size_t)mm[p].n_in;
+    }
+    return align_from_moments(groups, mom, npoints, n_images, fixed, out);
+}
+
 // Select_Connected_Matched_Images, MosaicWithoutPos.cpp:2754-2796: images are nodes, every image pair that has at
 // least one correspondence is an edge; label the largest connected group (union-find here instead of the
 // reference's O(E^2) cluster merge, same partition).
@@ -503,6 +546,10 @@ extern "C" int mi355_select_connected(const mi355_match_point_pairs* v, int n, i
 }
 
 // the same labelling straight from the pair records: an accepted pair with at least one inlier is an edge
+extern "C" int mi355_select_connected_moments(const mi355_pair_moments* m, int n, int n_images, int32_t* label) {
+    if (n < 0 || n_images <= 0 || (n > 0 && !m) || !label) return MI355_ERR_ARG;
+    return select_connected_core(n, [m](int p, int& a, int& b) { a = m[p].i; b = m[p].j; return m[p].n_in > 0; }, n_images, label);
+}
 extern "C" int mi355_select_connected_results(const mi355_pair_result* r, int n_pairs, int n_images, int32_t* label) {
     if (n_pairs < 0 || n_images <= 0 || (n_pairs > 0 && !r) || !label) return MI355_ERR_ARG;
     return select_connected_core(n_pairs, [r](int p, int& a, int& b) { a = r[p].i; b = r[p].j; return r[p].accepted && r[p].n_in > 0; }, n_images, label);

@@ -181,6 +181,28 @@ class Exchange:
         g, counts = allgather_pair_results(results[:n_local], accepted_only=accepted_only)
         return gathered_to_records(g, counts)
 
+    def allgather_moments(self, results, n_local):
+        """what the alignment needs of this rank's accepted pairs (PAIR_MOMENTS, 184 B per pair, formed on the device) from every rank (numpy, rank-major)"""
+        if self.transport == "rccl":
+            return self.ctx.AllGatherMoments(results.data_ptr(), n_local)
+        from .capi import PAIR_MOMENTS
+        local = compact_accepted(results[:n_local]).contiguous()
+        mom = torch.zeros((max(local.shape[0], 1), PAIR_MOMENTS.itemsize), dtype=torch.uint8, device=local.device)
+        if local.shape[0] > 0:
+            torch.cuda.current_stream(local.device).synchronize()
+            self.ctx.PairMomentsDev(local.data_ptr(), local.shape[0], mom.data_ptr())
+            self.ctx.synchronize()
+        mom = mom[:local.shape[0]]
+        if dist.is_initialized() and dist.get_world_size() > 1:
+            if dist.get_backend() != "nccl":
+                mom = mom.cpu()
+            g, counts = _allgather_rows(mom, None)
+        else:
+            g, counts = mom.unsqueeze(0), [mom.shape[0]]
+        g = g.cpu().numpy()
+        parts = [g[r, :c].reshape(-1).view(PAIR_MOMENTS) for r, c in enumerate(counts)]
+        return np.concatenate(parts) if parts else np.zeros(0, PAIR_MOMENTS)
+
     def close(self):
         if self.transport == "rccl":
             self.ctx.CommDestroy()

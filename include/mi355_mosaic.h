@@ -322,6 +322,26 @@ int  mi355_allgather_features(mi355_ctx* ctx, const int32_t* img_ids, int n_loca
 int  mi355_allgather_results(mi355_ctx* ctx, const mi355_pair_result* d_local, int n_local, int accepted_only,
                              mi355_pair_result** all, int* n_all);
 
+/* What the global alignment needs of an accepted pair (round 5): the second moments of its inlier coordinates -- the sums the normal
+ * equations of BundleAdjustmentSparse's system are made of (MosaicWithoutPos.cpp:6971-7202) -- instead of the 9664-byte record with its two
+ * inlier lists.  ca = (xa, ya, 1) from the record's a[], cb = (xb, yb, 1) from b[]; aa = sum ca ca^T (lower triangle, row-major: 00 10 11 20
+ * 21 22), ab = sum ca cb^T (row-major 3 x 3), bb = sum cb cb^T; doubles, summed in inlier order, every product and sum rounded separately:
+ * the device forms the very sums mi355_global_affine_align_results forms on the host, so the transforms are the same bits either way. */
+typedef struct { int32_t i, j, n_in, _pad; double aa[6], ab[9], bb[6]; } mi355_pair_moments;      /* 184 bytes */
+/* one record per pair record, on the device (a wave per pair); pairs that are not accepted get n_in = 0 and zero sums */
+int  mi355_pair_moments_dev(mi355_ctx* ctx, const mi355_pair_result* d_results, int n, mi355_pair_moments* d_out);
+/* the same sums on the host (callers without a device, tests) */
+int  mi355_pair_moments_host(const mi355_pair_result* r, int n, mi355_pair_moments* out);
+/* mi355_allgather_results for callers that only align: this rank's ACCEPTED pairs -> their moments (on the device) -> ncclAllGather -> host
+ * array, rank-major, the same on every rank (mi355_free).  52 x fewer bytes over xGMI and PCIe than the records (C5: 117 621 accepted pairs
+ * are 1.1 GB of records per rank), and the replicated host step starts from the sums instead of 28 M correspondences. */
+int  mi355_allgather_moments(mi355_ctx* ctx, const mi355_pair_result* d_local, int n_local, mi355_pair_moments** all, int* n_all);
+/* Select_Connected_Matched_Images / the global alignment from the moments (entries with n_in <= 0 are skipped): the same labels and, bit
+ * for bit, the same transforms as the _results forms give on the records the moments were formed from */
+int  mi355_select_connected_moments(const mi355_pair_moments* m, int n, int n_images, int32_t* label);
+int  mi355_global_affine_align_moments(const mi355_pair_moments* m, int n, int n_images, const int32_t* fixed, const int32_t* label,
+                                       mi355_image_transform* out);
+
 /* ---- measurement hooks (bench.py) ----------------------------------------------------------------------- */
 /* When enabled, every launch of the named kernel class is bracketed by hipEvents on the ctx stream. */
 int  mi355_profile_enable(mi355_ctx* ctx, int on);
