@@ -196,6 +196,11 @@ int host_threads() {
     }();
     return n;
 }
+inline void cpu_relax() {      // a waiting thread must not take issue slots from the hardware thread next to it (it may be the one that works)
+#if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
+    __builtin_ia32_pause();
+#endif
+}
 template <class F> void parallel_chunks(size_t n, int threads, F&& f) {          // f(begin, end) on contiguous chunks
     if (threads <= 1 || n < 2) { f((size_t)0, n); return; }
     std::vector<std::thread> th;
@@ -347,12 +352,17 @@ int align_from_moments(const std::vector<PairGroup>& groups, const std::vector<M
     }
     double work = 0.0;
     for (int i = 0; i < D; i++) work += (double)(i - fst[i]) * (double)(i - fst[i]);
-    // one thread up to ~1e8 multiply-subtracts (C4: 3.6e7, 1.3 ms): measured on the GPU box's host (256 logical CPUs behind a 16-CPU quota) a team
-    // of spinning threads only pays from C5's size on (5e8: 105 -> 47 ms), at C4's it costs 5 ms
-    const int team = (work > 1.5e8) ? host_threads() : 1;
+    // one thread per 2.5e7 multiply-subtracts, up to 16 (measured on the GPU box's host, C5's size, 5e8: 34 ms on one thread, 20 on four, 14 on eight,
+    // 12 on sixteen, 11.5 on thirty-two; C4's 3.6e7 stay on one thread: 1.3 ms, starting a team costs about that).  The team scales only since rows
+    // keep their owner and eight neighbouring rows share one (see `mine` below): before, two threads took twice as long as one.
+    int team = (int)(work / 2.5e7);
+    if (team > 16) team = 16;
+    if (team > host_threads()) team = host_threads();
+    if (team < 1) team = 1;
     constexpr int PW = 64;
     const size_t pts = ((size_t)bw + PW + 7) & ~(size_t)7;       // a panel's columns, transposed: PT[k - p0][i - p1] = L(i, k) for the rows i below the block
-    std::vector<double> PT((size_t)PW * pts, 0.0), DT((size_t)PW * (PW + 1), 0.0), DG(PW, 1.0);      // DT[(k - p0) * (PW + 1) + (j - k - 1)] = L(j, k) of the diagonal block, j > k
+    std::vector<double> PT_store((size_t)PW * pts + 8, 0.0), DT((size_t)PW * (PW + 1), 0.0), DG(PW, 1.0);      // DT[(k - p0) * (PW + 1) + (j - k - 1)] = L(j, k) of the diagonal block, j > k
+    double* const PT = PT_store.data() + ((64 - (reinterpret_cast<uintptr_t>(PT_store.data()) & 63)) & 63) / sizeof(double);      // on a cache-line boundary: eight rows' entries of a column share a line, and eight rows share an owner
     std::atomic<int> arrived{0}, generation{0}, failed{0};
     auto rowp = [&](int i) -> double* { return Nb.data() + (ptrdiff_t)i * (ptrdiff_t)W + (ptrdiff_t)(bw - i); };     // rowp(i)[j] = N(i, j), i - bw <= j <= i
     auto worker = [&](int tid) {
@@ -361,7 +371,7 @@ int align_from_moments(const std::vector<PairGroup>& groups, const std::vector<M
             if (team <= 1) return;
             gen++;
             if (arrived.fetch_add(1) + 1 == team) { arrived.store(0); generation.store(gen); }
-            else { int spins = 0; while (generation.load() < gen) { if (++spins > 4096) { std::this_thread::yield(); spins = 4000; } } }   // a phase takes microseconds: spin, but yield when the host has fewer cores than threads
+            else { int spins = 0; while (generation.load(std::memory_order_acquire) < gen) { cpu_relax(); if (++spins > 4096) { std::this_thread::yield(); spins = 4000; } } }   // a phase takes microseconds: spin, but yield when the host has fewer cores than threads
         };
         for (int p0 = 0; p0 < D; p0 += PW) {
             const int p1 = p0 + PW < D ? p0 + PW : D;
@@ -393,11 +403,17 @@ int align_from_moments(const std::vector<PairGroup>& groups, const std::vector<M
             const int i_end = p1 - 1 + bw < D - 1 ? p1 - 1 + bw : D - 1;             // last row that holds an entry in a column of the panel
             // rows dealt out one by one: row i of the trailing band has i - p1 + 1 entries to update, contiguous chunks would give the last
             // thread twice the mean
-            for (int i = p1 + tid; i <= i_end; i += team) {       // (B) the panel's columns of the rows below the block
+            // rows belong to threads in groups of eight, the same thread in every panel ((i / 8) mod team): a row's entries stay in that core's
+            // cache from panel to panel, and the eight doubles of a line of the transposed panel copy have one writer (dealt row by row from the
+            // panel's first row on, a row changed hands with every panel and neighbouring rows wrote into the same lines: two threads took twice
+            // as long as one)
+            auto mine = [&](int i) { return ((i >> 3) % team) == tid; };
+            for (int i = p1; i <= i_end; i++) {       // (B) the panel's columns of the rows below the block
+                if (!mine(i)) continue;
                 double* ri = rowp(i);
                 const int j0 = fst[i] > p0 ? fst[i] : p0;
                 for (int j = p0; j < j0 && j < p1; j++) PT[(size_t)(j - p0) * pts + (size_t)(i - p1)] = 0.0;      // left of the row's envelope (or the row does not reach the panel at all)
-                if (j0 < p1) chol_row_forward(ri + j0, p1 - j0, DG.data() + (j0 - p0), DT.data() + (size_t)(j0 - p0) * (PW + 1), (size_t)PW + 1, PT.data() + (size_t)(j0 - p0) * pts + (size_t)(i - p1), pts);
+                if (j0 < p1) chol_row_forward(ri + j0, p1 - j0, DG.data() + (j0 - p0), DT.data() + (size_t)(j0 - p0) * (PW + 1), (size_t)PW + 1, PT + (size_t)(j0 - p0) * pts + (size_t)(i - p1), pts);
             }
             barrier();
             // (C) the panel's products leave the trailing band, tile by tile of 64 trailing columns: the tile's part of the transposed panel copy
@@ -405,15 +421,15 @@ int align_from_moments(const std::vector<PairGroup>& groups, const std::vector<M
             // second level once per row: 16 GB at C5)
             constexpr int JT = 64;
             for (int jt = p1; jt <= i_end; jt += JT) {
-                for (int i = p1 + tid; i <= i_end; i += team) {
-                    if (i < jt || fst[i] >= p1) continue;          // above the tile / the row holds nothing in the panel's columns
+                for (int i = (jt > p1 ? jt : p1); i <= i_end; i++) {
+                    if (!mine(i) || fst[i] >= p1) continue;          // above the tile / the row holds nothing in the panel's columns
                     double* ri = rowp(i);
                     const int k0 = fst[i] > p0 ? fst[i] : p0;
                     const int j0 = fst[i] > p1 ? fst[i] : p1;
                     const int ja = j0 > jt ? j0 : jt, jb = i < jt + JT - 1 ? i : jt + JT - 1;
                     if (ja > jb) continue;
                     // the transposed copy holds L(j, k) for every row j of the trailing band, zeros left of row j's envelope
-                    chol_row_update(ri + ja, jb - ja + 1, ri + k0, p1 - k0, PT.data() + (size_t)(k0 - p0) * pts + (size_t)(ja - p1), pts);
+                    chol_row_update(ri + ja, jb - ja + 1, ri + k0, p1 - k0, PT + (size_t)(k0 - p0) * pts + (size_t)(ja - p1), pts);
                 }
             }
             barrier();
