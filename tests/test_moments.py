@@ -77,3 +77,35 @@ def test_device_moments_equal_host_moments_bit_for_bit():
             ex.close()
             assert m.tobytes() == want[acc].tobytes(), transport
     ctx.close()
+
+
+@pytest.mark.gpu
+def test_alignment_of_a_real_survey_from_device_moments():
+    """the same on the records a real pair stage leaves in HBM: a 13-frame survey, all pairs; labels and transforms from the device's moments
+    equal the ones from the records, and the exchange's moments are those of the accepted records in record order"""
+    import torch
+    import imagemosaicing_amd as im
+    from imagemosaicing_amd import dist as md
+    from tests.synth_survey import render_frames
+    ctx = im.Context(0)
+    w, h, F = 800, 600, 13
+    frames, A, gains, ws = render_frames(ctx, torch, F, w, h, per_row=5)
+    for k in range(F):
+        ctx.SiftExtractDev(k, frames[k].data_ptr(), w, h, ws)
+    pairs = im.pair_schedule(F, 182)
+    res = torch.zeros((len(pairs), im.PAIR_RESULT.itemsize), dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    ctx.MatchPairsDev(pairs, res.data_ptr(), 2.5, 3); ctx.synchronize()
+    r = res.cpu().numpy().reshape(-1).view(im.PAIR_RESULT)
+    assert 8 <= int(r["accepted"].sum()) < len(pairs)
+    ex = md.Exchange(ctx, "rccl", strict=True)
+    mom = ex.allgather_moments(res, len(pairs))
+    ex.close()
+    assert mom.tobytes() == im.pair_moments_host(r)[r["accepted"] != 0].tobytes()
+    label = im.select_connected_results(r, F)
+    assert np.array_equal(label, im.select_connected_moments(mom, F)) and label.sum() >= 8
+    fixed = [1 if (k == 0 or label[k] == 0) else 0 for k in range(F)]
+    a = im.global_affine_align_results(r, F, fixed=fixed, label=label)
+    b = im.global_affine_align_moments(mom, F, fixed=fixed, label=label)
+    assert a.tobytes() == b.tobytes()
+    ctx.close()
