@@ -11,7 +11,7 @@ from .capi import (  # noqa: F401
     SFPOINT, KEYPOINT, DMATCH, MATCHPAIR, PAIR_RESULT, CHIPINFO, IMAGE_TRANSFORM, FEATURE_HEADER, FEATURE_RECORD_BYTES, comm_unique_id, comm_available,
     mosaic_layout, blend_layout, pair_schedule, surf_pair_schedule, resample_by_overlap, write_match_pairs, load_match_pairs, write_match_pairs_txt,
     write_transforms, load_transforms, write_keypoints, load_keypoints, results_to_match_pairs, global_affine_align, select_connected,
-    global_affine_align_results, select_connected_results, pair_moments_host, select_connected_moments, global_affine_align_moments, PAIR_MOMENTS,
+    global_affine_align_results, select_connected_results, pair_moments_host, select_connected_moments, global_affine_align_moments, PAIR_MOMENTS, write_descriptors_xml, load_descriptors_xml,
 )
 
 __all__ = [n for n in dir() if not n.startswith("_")]

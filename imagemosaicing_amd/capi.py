@@ -591,6 +591,27 @@ def load_keypoints(path):
     return out
 
 
+def write_descriptors_xml(path, desc):
+    """discriptor_%d.xml (cv::FileStorage << "descriptor" << Mat CV_32F), OpenCV 2.4's XML layout (unpinned: the reference commits no such file)"""
+    d = np.ascontiguousarray(desc, np.float32)
+    if d.ndim != 2:
+        raise ValueError("descriptors: a 2-D array")
+    rc = load_library().mi355_write_descriptors_xml(path.encode(), _p(d), int(d.shape[0]), int(d.shape[1]))
+    if rc != 0:
+        raise Mi355Error(rc, "write_descriptors_xml")
+
+
+def load_descriptors_xml(path):
+    L = load_library()
+    ptr, r, c = C.c_void_p(), C.c_int(0), C.c_int(0)
+    rc = L.mi355_load_descriptors_xml(path.encode(), C.byref(ptr), C.byref(r), C.byref(c))
+    if rc != 0:
+        raise Mi355Error(rc, "load_descriptors_xml")
+    out = _copy_out(ptr, r.value * c.value * 4, np.float32).reshape(r.value, c.value)
+    L.mi355_free(ptr)
+    return out
+
+
 def results_to_match_pairs(results, fixed_flags=None):
     L = load_library()
     results = np.ascontiguousarray(results, PAIR_RESULT)

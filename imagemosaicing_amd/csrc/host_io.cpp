@@ -12,6 +12,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <cctype>
+#include <string>
 #include <fstream>
 #include <atomic>
 #include <thread>
@@ -164,6 +166,86 @@ extern "C" int mi355_results_to_match_pairs(const mi355_pair_result* r, int n_pa
         }
     }
     *v = out; *n = (int)total;
+    return MI355_OK;
+}
+
+// discriptor_%d.xml: cv::FileStorage << "descriptor" << Mat (CV_32F), as OpenCV 2.4's XML emitter lays it out (persistence.cpp, from memory of its
+// rules -- the reference commits no such file, so the bytes are unpinned): a scalar of a sequence goes on the current line behind one blank
+// unless the line would pass column 71 (then a new line, indented 4); floats that are integers print as "12.", the others as "%.8e"; the closing
+// tags follow the last number on its line.
+extern "C" int mi355_write_descriptors_xml(const char* path, const float* desc, int n_rows, int n_cols) {
+    if (!path || n_rows < 0 || n_cols < 0 || ((size_t)n_rows * n_cols > 0 && !desc)) return MI355_ERR_ARG;
+    FILE* f = fopen(path, "wb");
+    if (!f) return MI355_ERR_FAILED;
+    fprintf(f, "<?xml version=\"1.0\"?>\n<opencv_storage>\n<descriptor type_id=\"opencv-matrix\">\n  <rows>%d</rows>\n  <cols>%d</cols>\n  <dt>f</dt>\n  <data>", n_rows, n_cols);
+    std::string line;                                   // the current line of the data block (empty: straight behind "<data>")
+    bool first = true;
+    const size_t total = (size_t)n_rows * (size_t)n_cols;
+    for (size_t k = 0; k < total; k++) {
+        char buf[64];
+        const float v = desc[k];
+        uint32_t bits; memcpy(&bits, &v, 4);
+        if ((bits & 0x7f800000u) != 0x7f800000u) {
+            const int iv = (int)lrintf(v);
+            if ((float)iv == v) snprintf(buf, sizeof buf, "%d.", iv); else snprintf(buf, sizeof buf, "%.8e", v);
+        } else if (bits & 0x7fffffu) snprintf(buf, sizeof buf, ".Nan");
+        else snprintf(buf, sizeof buf, (bits >> 31) ? "-.Inf" : ".Inf");
+        const size_t len = strlen(buf);
+        if (first || (line.size() + len > 71 && line.size() + len - 4 > 10)) {
+            if (!first) fputs(line.c_str(), f);
+            fputc('\n', f);
+            line.assign(4, ' ');
+            first = false;
+        } else line.push_back(' ');
+        line += buf;
+    }
+    fputs(line.c_str(), f);
+    fputs("</data></descriptor>\n</opencv_storage>\n", f);
+    const bool ok = !ferror(f);
+    return (fclose(f) == 0 && ok) ? MI355_OK : MI355_ERR_FAILED;
+}
+extern "C" int mi355_load_descriptors_xml(const char* path, float** desc, int* n_rows, int* n_cols) {
+    if (!path || !desc || !n_rows || !n_cols) return MI355_ERR_ARG;
+    *desc = nullptr; *n_rows = *n_cols = 0;
+    FILE* f = fopen(path, "rb");
+    if (!f) return MI355_ERR_FAILED;
+    std::string t;
+    { char buf[65536]; size_t n; while ((n = fread(buf, 1, sizeof buf, f)) > 0) t.append(buf, n); }
+    fclose(f);
+    auto field = [&t](const char* open_tag, const char* close_tag, size_t from, size_t& a, size_t& b) {
+        a = t.find(open_tag, from);
+        if (a == std::string::npos) return false;
+        a += strlen(open_tag);
+        b = t.find(close_tag, a);
+        return b != std::string::npos;
+    };
+    size_t d0 = t.find("<descriptor");
+    if (d0 == std::string::npos) return MI355_ERR_FAILED;
+    size_t a, b;
+    if (!field("<rows>", "</rows>", d0, a, b)) return MI355_ERR_FAILED;
+    const long rows = strtol(t.c_str() + a, nullptr, 10);
+    if (!field("<cols>", "</cols>", d0, a, b)) return MI355_ERR_FAILED;
+    const long cols = strtol(t.c_str() + a, nullptr, 10);
+    if (!field("<dt>", "</dt>", d0, a, b) || t.compare(a, b - a, "f") != 0) return MI355_ERR_FAILED;      // CV_32F, one channel: what the reference writes
+    if (rows < 0 || cols < 0 || rows > (1 << 24) || cols > (1 << 16)) return MI355_ERR_FAILED;
+    if (!field("<data>", "</data>", d0, a, b)) return MI355_ERR_FAILED;
+    const size_t total = (size_t)rows * (size_t)cols;
+    float* out = (float*)malloc(sizeof(float) * (total ? total : 1));
+    if (!out) return MI355_ERR_NOMEM;
+    const char* p = t.c_str() + a; const char* end = t.c_str() + b;
+    size_t k = 0;
+    while (k < total) {
+        while (p < end && isspace((unsigned char)*p)) p++;
+        if (p >= end) break;
+        float v;
+        if (!strncmp(p, ".Nan", 4)) { v = NAN; p += 4; }
+        else if (!strncmp(p, ".Inf", 4)) { v = INFINITY; p += 4; }
+        else if (!strncmp(p, "-.Inf", 5)) { v = -INFINITY; p += 5; }
+        else { char* q = nullptr; v = strtof(p, &q); if (q == p) break; p = q; }
+        out[k++] = v;
+    }
+    if (k != total) { free(out); return MI355_ERR_FAILED; }
+    *desc = out; *n_rows = (int)rows; *n_cols = (int)cols;
     return MI355_OK;
 }
 

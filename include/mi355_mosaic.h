@@ -237,6 +237,14 @@ int  mi355_load_tran0(const char* path, mi355_image_transform** t, int* n);
 /* keypoint_%d.key (WriteSurfKeyPoints, MosaicWithoutPos.cpp:4691-4700): int32 n + n x 28-byte cv::KeyPoint */
 int  mi355_write_keypoints(const char* path, const mi355_keypoint* kp, int n);
 int  mi355_load_keypoints(const char* path, mi355_keypoint** kp, int* n);
+/* discriptor_%d.xml, the other half of WriteSurfKeyPoints / LoadSurfKeyPoints (MosaicWithoutPos.cpp:4685-4688, 4710-4711):
+ * cv::FileStorage fs(path, WRITE); fs << "descriptor" << Mat(n_rows x n_cols, CV_32F).  The text follows OpenCV 2.4's XML emitter
+ * (persistence.cpp: icvFloatToString -- integers as "12.", others "%.8e" --, lines of the <data> block wrapped at column 71, indent 4,
+ * the closing tags on the last data line).  PARITY UNPINNED: the reference commits no such file; a reader that takes any
+ * white-space-separated numbers (as cv::FileStorage does) makes files written by OpenCV readable whatever the wrapping.
+ * The live path never needs these files: features stay resident in HBM.  *desc -> mi355_free. */
+int  mi355_write_descriptors_xml(const char* path, const float* desc, int n_rows, int n_cols);
+int  mi355_load_descriptors_xml(const char* path, float** desc, int* n_rows, int* n_cols);
 /* Flatten accepted pair results into the driver's m_vecMatchPairs order (pair order, inlier order). */
 int  mi355_results_to_match_pairs(const mi355_pair_result* r, int n_pairs, const int32_t* fixed_flags /* per image or NULL */,
                                   mi355_match_point_pairs** v, int* n);

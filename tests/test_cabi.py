@@ -250,3 +250,35 @@ def test_alignment_bits_do_not_depend_on_the_thread_count(tmp_path):
         assert r.returncode == 0, r.stderr[-2000:]
         seen.add(r.stdout.strip().splitlines()[-1])
     assert len(seen) == 1, seen
+
+
+def test_descriptor_xml_layout_and_round_trip(tmp_path):
+    """discriptor_%d.xml, the cv::FileStorage half of WriteSurfKeyPoints / LoadSurfKeyPoints (MosaicWithoutPos.cpp:4685-4688, 4710-4711).  The
+    reference commits no such file: the layout is OpenCV 2.4's XML emitter as restated in host_io.cpp (UNPINNED) -- integers as "12.", other
+    floats "%.8e", data lines of at most 72 characters indented by 4, closing tags behind the last number -- and the reader takes any
+    white-space-separated numbers, so a file cv::FileStorage wrote reads whatever its wrapping."""
+    import imagemosaicing_amd as im
+    small = np.array([[0, 12, 255, 0.5], [3, -7, 1e-3, 16777216]], np.float32)
+    p = str(tmp_path / "discriptor_0.xml")
+    im.write_descriptors_xml(p, small)
+    text = open(p).read()
+    assert text == ('<?xml version="1.0"?>\n<opencv_storage>\n<descriptor type_id="opencv-matrix">\n  <rows>2</rows>\n  <cols>4</cols>\n  <dt>f</dt>\n  <data>\n'
+                    '    0. 12. 255. 5.00000000e-01 3. -7. 1.00000005e-03 16777216.</data></descriptor>\n</opencv_storage>\n')
+    assert np.array_equal(im.load_descriptors_xml(p), small)
+    rng = np.random.default_rng(2)
+    d = rng.integers(0, 256, (300, 128)).astype(np.float32)                 # SIFT: byte-valued floats
+    d[7, 5] = np.float32(1.0) / 3; d[9, 0] = np.inf; d[9, 1] = -np.inf
+    im.write_descriptors_xml(p, d)
+    lines = open(p).read().split("\n")
+    data = lines[7:-2]
+    assert all(l.startswith("    ") and not l.startswith("     ") for l in data) and max(len(l) for l in data[:-1]) <= 72 and min(len(l) for l in data[:-1]) >= 60
+    back = im.load_descriptors_xml(p)
+    assert back.shape == d.shape and np.array_equal(back.view(np.uint32), d.view(np.uint32))
+    # a file wrapped differently (and with OpenCV's header comment) reads the same
+    with open(p, "w") as f:
+        f.write('<?xml version="1.0"?>\n<opencv_storage>\n<descriptor type_id="opencv-matrix">\n<rows>2</rows><cols>4</cols><dt>f</dt>\n<data>\n0. 12.\n 255.\t5.00000000e-01 3. -7. 1.00000005e-03\n16777216.\n</data></descriptor></opencv_storage>\n')
+    assert np.array_equal(im.load_descriptors_xml(p), small)
+    im.write_descriptors_xml(p, np.zeros((0, 128), np.float32))
+    assert im.load_descriptors_xml(p).shape == (0, 128)
+    with pytest.raises(im.Mi355Error):
+        im.load_descriptors_xml(str(tmp_path / "missing.xml"))
