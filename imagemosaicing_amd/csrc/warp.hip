@@ -45,6 +45,24 @@ __device__ __forceinline__ void load_pair<3>(const uint8_t* s, float& b0, float&
     b1 = (float)(lo >> 24);  g1 = (float)(hi & 0xff);        r1 = (float)(hi >> 8);
 }
 
+// the two BGR pixel pairs of a 2 x 2 neighbourhood (rows s and s + ws): one 8-byte load per row where 8 bytes from s still lie inside the row's
+// pitch (6 are used), else the 4 + 2 byte form -- half the load instructions of a sample (the canvas kernel is bound by their number)
+__device__ __forceinline__ void load_quad3(const uint8_t* s, int ws, bool wide, float& b00, float& g00, float& r00, float& b01, float& g01, float& r01,
+                                           float& b10, float& g10, float& r10, float& b11, float& g11, float& r11) {
+    if (wide) {
+        uint64_t q0, q1;
+        __builtin_memcpy(&q0, s, 8);
+        __builtin_memcpy(&q1, s + ws, 8);
+        b00 = (float)(q0 & 0xff); g00 = (float)((q0 >> 8) & 0xff); r00 = (float)((q0 >> 16) & 0xff);
+        b01 = (float)((q0 >> 24) & 0xff); g01 = (float)((q0 >> 32) & 0xff); r01 = (float)((q0 >> 40) & 0xff);
+        b10 = (float)(q1 & 0xff); g10 = (float)((q1 >> 8) & 0xff); r10 = (float)((q1 >> 16) & 0xff);
+        b11 = (float)((q1 >> 24) & 0xff); g11 = (float)((q1 >> 32) & 0xff); r11 = (float)((q1 >> 40) & 0xff);
+    } else {
+        load_pair<3>(s, b00, g00, r00, b01, g01, r01);
+        load_pair<3>(s + ws, b10, g10, r10, b11, g11, r11);
+    }
+}
+
 // PART (chips only): 0 = pixels and validity mask, 1 = the validity mask alone (no source read), 2 = the pixels alone (the mask bytes
 // hold the ownership by then and stay as they are)
 template <int CH, bool CHIP, int PART>
@@ -84,8 +102,7 @@ __device__ __forceinline__ void warp_body(const WarpArgs& a) {
         if (PART == 1) {
         } else if (CH == 3) {
             float b00, g00, r00, b01, g01, r01, b10, g10, r10, b11, g11, r11;
-            load_pair<3>(s, b00, g00, r00, b01, g01, r01);
-            load_pair<3>(s + a.ws, b10, g10, r10, b11, g11, r11);
+            load_quad3(s, a.ws, 3 * xi + 8 <= a.ws, b00, g00, r00, b01, g01, r01, b10, g10, r10, b11, g11, r11);
             out[3 * k + 0] = hm::bilin(b00, b01, b10, b11, p, q);
             out[3 * k + 1] = hm::bilin(g00, g01, g10, g11, p, q);
             out[3 * k + 2] = hm::bilin(r00, r01, r10, r11, p, q);
@@ -283,8 +300,7 @@ __global__ __launch_bounds__(256) void mosaic_tile_kernel(const FrameDev* fr, in
                 // slower: 11.4 ms against 8.5 ms for the C3 canvas -- its barriers and 24 KB per workgroup cost more than the
                 // L1 / L2 hits they replace)
                 const uint8_t* g0 = f.src + (size_t)yi * f.ws + 3 * (size_t)xi;
-                load_pair<3>(g0, b00, g00, r00, b01, g01, r01);
-                load_pair<3>(g0 + f.ws, b10, g10, r10, b11, g11, r11);
+                load_quad3(g0, f.ws, 3 * xi + 8 <= f.ws, b00, g00, r00, b01, g01, r01, b10, g10, r10, b11, g11, r11);
                 const unsigned vb = hm::bilin(b00, b01, b10, b11, p, q), vg = hm::bilin(g00, g01, g10, g11, p, q), vr = hm::bilin(r00, r01, r10, r11, p, q);
                 // bytes 3k, 3k+1, 3k+2 of the row's 12: static positions
                 out[j][(3 * k) >> 2] |= vb << (8 * ((3 * k) & 3));
