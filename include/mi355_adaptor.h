@@ -24,6 +24,7 @@ struct BitmapImage {                                                            
     unsigned char* imageData; int width, height, widthStep, nChannels;
     BitmapImage() : imageData(NULL), width(0), height(0), widthStep(0), nChannels(0) {}
 };
+inline void ReleaseBitmap8U(BitmapImage*& p) { if (!p) return; delete[] p->imageData; p->imageData = NULL; delete p; p = NULL; }      // ImageIO.cpp:78-93
 struct MatchPointPairs { SfPoint ptA; int ptA_i, ptA_Fixed; SfPoint ptB; int ptB_i, ptB_Fixed; };            // MosaicWithoutPos.h:135-153
 struct ImageTransform { ProjectMat h; int fixed; };                                                          // MosaicWithoutPos.h:224-228
 // IplImage, OpenCV 2.4.0 core/types_c.h (field for field); stand-alone images own imageData through malloc
@@ -93,19 +94,32 @@ inline bool Ransac2D(const std::vector<MI355_NS SfPoint>& p1, const std::vector<
 
 // int SelectMatchPairs(const vector<DMatch>&, const vector<KeyPoint>&, const vector<KeyPoint>&, int nMatch, int width, int height,
 //                      int gridX, int gridY, vector<SfPoint>&, vector<SfPoint>&)                    MosaicWithoutPos.cpp:4977-4983
-// DMatch / KeyPoint are passed as the C-ABI PODs (identical field layout to cv::DMatch / cv::KeyPoint 2.4.0).
-inline int SelectMatchPairs(const std::vector<mi355_dmatch>& matches, const std::vector<mi355_keypoint>& kp1, const std::vector<mi355_keypoint>& kp2,
+// One body for both spellings of the element types: cv::DMatch / cv::KeyPoint (OpenCV 2.4.0 features2d.hpp: the reference's own call,
+// MosaicWithoutPos.cpp:5146-5153, compiles unchanged against this) and the C-ABI PODs mi355_dmatch / mi355_keypoint.  Nothing of OpenCV
+// is included here: the element types are template parameters and only .queryIdx/.trainIdx/.imgIdx/.distance and the point are read.
+namespace detail {
+inline float kp_x(const mi355_keypoint& k) { return k.x; }
+inline float kp_y(const mi355_keypoint& k) { return k.y; }
+template <class KP> inline float kp_x(const KP& k) { return k.pt.x; }      // cv::KeyPoint
+template <class KP> inline float kp_y(const KP& k) { return k.pt.y; }
+}  // namespace detail
+template <class DMatchT, class KeyPointT>
+inline int SelectMatchPairs(const std::vector<DMatchT>& matches, const std::vector<KeyPointT>& kp1, const std::vector<KeyPointT>& kp2,
                             int nMatch, int width, int height, int gridX, int gridY,
                             std::vector<MI355_NS SfPoint>& v1, std::vector<MI355_NS SfPoint>& v2) {
     v1.clear(); v2.clear();
     mi355_ctx* c = context();
     if (!c) return -1;
+    std::vector<mi355_dmatch> dm(matches.size());
+    for (size_t i = 0; i < matches.size(); i++) {
+        dm[i].queryIdx = matches[i].queryIdx; dm[i].trainIdx = matches[i].trainIdx; dm[i].imgIdx = matches[i].imgIdx; dm[i].distance = matches[i].distance;
+    }
     std::vector<float> xy1(kp1.size() * 2), xy2(kp2.size() * 2);
-    for (size_t i = 0; i < kp1.size(); i++) { xy1[2 * i] = kp1[i].x; xy1[2 * i + 1] = kp1[i].y; }
-    for (size_t i = 0; i < kp2.size(); i++) { xy2[2 * i] = kp2[i].x; xy2[2 * i + 1] = kp2[i].y; }
+    for (size_t i = 0; i < kp1.size(); i++) { xy1[2 * i] = detail::kp_x(kp1[i]); xy1[2 * i + 1] = detail::kp_y(kp1[i]); }
+    for (size_t i = 0; i < kp2.size(); i++) { xy2[2 * i] = detail::kp_x(kp2[i]); xy2[2 * i + 1] = detail::kp_y(kp2[i]); }
     std::vector<mi355_sfpoint> a(MI355_MAX_SELECTED), b(MI355_MAX_SELECTED);
     int n = 0;
-    const int rc = mi355_select_grid(c, matches.empty() ? NULL : &matches[0], (int)matches.size(), xy1.empty() ? NULL : &xy1[0], (int)kp1.size(),
+    const int rc = mi355_select_grid(c, dm.empty() ? NULL : &dm[0], (int)dm.size(), xy1.empty() ? NULL : &xy1[0], (int)kp1.size(),
                                      xy2.empty() ? NULL : &xy2[0], (int)kp2.size(), nMatch, width, height, gridX, gridY, &a[0], &b[0], &n);
     if (rc != MI355_OK) return rc;
     v1.resize(n); v2.resize(n);
@@ -114,7 +128,9 @@ inline int SelectMatchPairs(const std::vector<mi355_dmatch>& matches, const std:
 }
 
 // int ImageProjectionTransform(BitmapImage* pImage, BitmapImage*& pResult, float h[9])             MosaicImage.cpp:1613
-// pResult->imageData is malloc'd by the library: release with mi355_free (the reference uses ReleaseBitmap8U).
+// pResult is allocated the way CreateBitmap8U does (ImageIO.cpp:58-76: new BitmapImage, new unsigned char[widthStep * height]), so the
+// reference's callers go on releasing it with ReleaseBitmap8U (ImageIO.cpp:78-93: delete[] imageData, delete) -- stand-alone,
+// mi355ref::ReleaseBitmap8U is that function.  The library's own buffer (malloc) never leaves this function.
 inline int ImageProjectionTransform(MI355_NS BitmapImage* pImage, MI355_NS BitmapImage*& pResult, float h[9]) {
     if (pImage == NULL) return -1;
     mi355_ctx* c = context();
@@ -123,7 +139,10 @@ inline int ImageProjectionTransform(MI355_NS BitmapImage* pImage, MI355_NS Bitma
     const int rc = mi355_warp_image(c, pImage->imageData, pImage->width, pImage->height, pImage->widthStep, pImage->nChannels, h, &dst, &dw, &dh, &dws);
     if (rc != MI355_OK) return rc;
     pResult = new MI355_NS BitmapImage();
-    pResult->imageData = dst; pResult->width = dw; pResult->height = dh; pResult->widthStep = dws; pResult->nChannels = pImage->nChannels;
+    pResult->width = dw; pResult->height = dh; pResult->widthStep = dws; pResult->nChannels = pImage->nChannels;
+    pResult->imageData = new unsigned char[(size_t)dws * dh];
+    std::memcpy(pResult->imageData, dst, (size_t)dws * dh);
+    mi355_free(dst);
     return 0;
 }
 

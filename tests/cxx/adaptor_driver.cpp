@@ -3,7 +3,7 @@
 // LaplacianPyramidBlending / MergeImagesRefined).  tests/test_gpu_cxx.py writes the inputs as raw binary files, runs this
 // program on the GPU box and compares what it writes with the golden vectors / the Python-side results.
 //
-//   adaptor_driver <dir> ransac | warp | mosaic | blend | threads | surf
+//   adaptor_driver <dir> ransac | warp | mosaic | blend | threads | surf | sift | select
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -115,7 +115,7 @@ int main(int argc, char** argv) {
                 BitmapImage* r = NULL;
                 if (mi355::ImageProjectionTransform(&src, r, imgs[0].h9) != 0 || r->width != ref->width || r->height != ref->height ||
                     std::memcmp(r->imageData, ref->imageData, (size_t)r->widthStep * r->height) != 0) bad[t]++;
-                if (r) { mi355_free(r->imageData); delete r; }
+                ReleaseBitmap8U(r);                                          // ImageIO.cpp:78-93, as the reference's callers do
             }
         }));
         for (int t = 0; t < T; t++) th[t].join();
@@ -135,7 +135,7 @@ int main(int argc, char** argv) {
         const int hd[3] = {res->width, res->height, res->widthStep};
         std::memcpy(&out[0], hd, 12); std::memcpy(&out[12], res->imageData, (size_t)res->widthStep * res->height);
         spit(dir + "/warp.out", &out[0], out.size());
-        mi355_free(res->imageData); delete res;
+        ReleaseBitmap8U(res);
     } else if (mode == "mosaic" || mode == "blend") {
         std::vector<Img> imgs = read_images(dir + "/images.bin");
         const int n = (int)imgs.size();
@@ -182,6 +182,42 @@ int main(int argc, char** argv) {
         if (!v.empty()) std::memcpy(&out[8], &v[0], v.size() * sizeof(MatchPointPairs));
         spit(dir + "/sift.out", &out[0], out.size());
         for (int k = 0; k < n; k++) cvReleaseImage(&poses[k].pImg);
+    } else if (mode == "select") {
+        // SelectMatchPairs with element types shaped like cv::DMatch / cv::KeyPoint (OpenCV 2.4.0 features2d.hpp: KeyPoint carries
+        // Point2f pt, DMatch {queryIdx, trainIdx, imgIdx, distance}) -- the spelling of the reference's call, MosaicWithoutPos.cpp:5146-5153
+        // -- and once more with the C-ABI PODs; both must give the same lists.
+        // select.bin: int32 n_cases; per case int32 {K, nMatch, width, height}, K x mi355_dmatch, K x float2 kp1, K x float2 kp2
+        struct Point2f { float x, y; };
+        struct KeyPoint { Point2f pt; float size, angle, response; int octave, class_id; };
+        struct DMatch { int queryIdx, trainIdx, imgIdx; float distance; };
+        std::vector<unsigned char> raw = slurp(dir + "/select.bin");
+        const unsigned char* p = &raw[0];
+        int nc; std::memcpy(&nc, p, 4); p += 4;
+        std::vector<unsigned char> out;
+        for (int c = 0; c < nc; c++) {
+            int hd[4]; std::memcpy(hd, p, 16); p += 16;
+            const int K = hd[0];
+            std::vector<DMatch> m(K); std::vector<KeyPoint> k1(K), k2(K);
+            std::vector<mi355_dmatch> pm(K); std::vector<mi355_keypoint> q1(K), q2(K);
+            if (K) std::memcpy(&m[0], p, (size_t)16 * K);
+            if (K) std::memcpy(&pm[0], p, (size_t)16 * K);
+            p += (size_t)16 * K;
+            for (int i = 0; i < K; i++) { std::memcpy(&k1[i].pt, p + (size_t)8 * i, 8); std::memset(&q1[i], 0, sizeof q1[i]); q1[i].x = k1[i].pt.x; q1[i].y = k1[i].pt.y; }
+            p += (size_t)8 * K;
+            for (int i = 0; i < K; i++) { std::memcpy(&k2[i].pt, p + (size_t)8 * i, 8); std::memset(&q2[i], 0, sizeof q2[i]); q2[i].x = k2[i].pt.x; q2[i].y = k2[i].pt.y; }
+            p += (size_t)8 * K;
+            std::vector<SfPoint> v1, v2, w1, w2;
+            if (mi355::SelectMatchPairs(m, k1, k2, hd[1], hd[2], hd[3], 3, 3, v1, v2) != 0) return 6;
+            if (mi355::SelectMatchPairs(pm, q1, q2, hd[1], hd[2], hd[3], 3, 3, w1, w2) != 0) return 6;
+            if (v1.size() != w1.size() || v2.size() != w2.size() || v1.size() != v2.size()) return 7;
+            if (!v1.empty() && (std::memcmp(&v1[0], &w1[0], v1.size() * sizeof(SfPoint)) || std::memcmp(&v2[0], &w2[0], v2.size() * sizeof(SfPoint)))) return 7;
+            const int n = (int)v1.size();
+            const size_t o = out.size();
+            out.resize(o + 4 + (size_t)24 * n);
+            std::memcpy(&out[o], &n, 4);
+            if (n) { std::memcpy(&out[o + 4], &v1[0], (size_t)12 * n); std::memcpy(&out[o + 4 + (size_t)12 * n], &v2[0], (size_t)12 * n); }
+        }
+        spit(dir + "/select.out", out.empty() ? NULL : &out[0], out.size());
     } else return 2;
     std::printf("DONE %s\n", mode.c_str());
     return 0;

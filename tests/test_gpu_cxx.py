@@ -166,3 +166,31 @@ def test_cxx_adaptor_sift_one_call(tmp_path):
     want = im.results_to_match_pairs(res, fixed_flags=[1] + [0] * (len(frames) - 1))
     assert n_success == int(res["accepted"].sum()) and n_success >= 6
     assert np.array_equal(got.view(np.uint8), want.view(np.uint8))
+
+
+def test_cxx_adaptor_select_match_pairs_in_the_references_spelling(tmp_path):
+    """mi355::SelectMatchPairs(const vector<DMatch>&, const vector<KeyPoint>&, const vector<KeyPoint>&, ...) (MosaicWithoutPos.cpp:4977-4983)
+    called from C++ with element types laid out like cv::DMatch / cv::KeyPoint (the reference's own call, :5146-5153), and with the C-ABI
+    PODs: both equal the golden lists the compiled reference produced (math_golden.npz, s_*)"""
+    import imagemosaicing_amd as im
+    exe = build_driver(str(tmp_path))
+    g = math_golden()
+    with open(tmp_path / "select.bin", "wb") as f:
+        f.write(np.int32(len(g["s_kp1"])).tobytes())
+        for kp1, kp2, m, (w, h, K), nm in zip(g["s_kp1"], g["s_kp2"], g["s_m"], g["s_wh"], g["s_nm"]):
+            K = int(K)
+            f.write(np.array([K, int(nm), int(w), int(h)], np.int32).tobytes())
+            mm = np.zeros(K, im.DMATCH)
+            mm["queryIdx"] = m[:K, 0]; mm["trainIdx"] = m[:K, 1]
+            f.write(mm.tobytes())
+            f.write(np.ascontiguousarray(kp1[:K], np.float32).tobytes()); f.write(np.ascontiguousarray(kp2[:K], np.float32).tobytes())
+    run(exe, tmp_path, "select")
+    raw = open(tmp_path / "select.out", "rb").read()
+    o = 0
+    for o1, o2, no in zip(g["s_o1"], g["s_o2"], g["s_no"]):
+        n = int(np.frombuffer(raw[o:o + 4], np.int32)[0]); o += 4
+        assert n == int(no)
+        a1 = np.frombuffer(raw[o:o + 12 * n], im.SFPOINT); o += 12 * n
+        a2 = np.frombuffer(raw[o:o + 12 * n], im.SFPOINT); o += 12 * n
+        assert np.array_equal(a1, o1[:n]) and np.array_equal(a2, o2[:n])
+    assert o == len(raw)
