@@ -37,6 +37,9 @@ INC = os.path.join(OBJ, "blur16_asm.inc")              # generated text lives wi
 
 def generate():
     os.makedirs(OBJ, exist_ok=True)
+    stale = os.path.join(CSRC, "blur16_asm.inc")           # where rounds 3-4 wrote it: never regenerated any more, must not shadow the fresh one
+    if os.path.exists(stale):
+        os.remove(stale)
     if not os.path.exists(INC) or os.path.getmtime(INC) < os.path.getmtime(GEN):
         out = subprocess.run([sys.executable, GEN], capture_output=True, text=True, check=True).stdout
         with open(INC, "w") as f:

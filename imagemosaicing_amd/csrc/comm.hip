@@ -147,8 +147,11 @@ __global__ __launch_bounds__(256) void pair_moments_kernel(const mi355_pair_resu
     if (p >= n) return;
     const mi355_pair_result& e = in[p];
     mi355_pair_moments& o = out[p];
-    const int cnt = (e.accepted && e.n_in > 0) ? (e.n_in < MI355_MAX_SELECTED ? e.n_in : MI355_MAX_SELECTED) : 0;
-    if (t == 0) { o.i = e.i; o.j = e.j; o.n_in = cnt; o._pad = 0; }
+    // a malformed record (n_in beyond the 400 slots of the lists) keeps its n_in and gets no sums: mi355_global_affine_align_moments then
+    // answers MI355_ERR_ARG exactly like the record forms do (host_io.cpp), instead of aligning on a plausible-looking clamp
+    const int nin = (e.accepted && e.n_in > 0) ? e.n_in : 0;
+    const int cnt = nin <= MI355_MAX_SELECTED ? nin : 0;
+    if (t == 0) { o.i = e.i; o.j = e.j; o.n_in = nin; o._pad = 0; }
     if (t >= 21) return;
     // operands of this lane's product out of c = (xa, ya, 1, xb, yb, 1): aa 00 10 11 20 21 22 | ab row-major | bb like aa
     int iu, iv;

@@ -26,34 +26,34 @@ inline float dist2pts(float x1, float y1, float x2, float y2) {                 
 }
 
 float quad_area(const Pt c[4]) {                                                 // :1884-1932
-    const float v02x = c[0].x - c[2].x, v02y = c[0].y - c[2].y;
-    const float v13x = c[1].x - c[3].x, v13y = c[1].y - c[3].y;
-    const float L1 = std::sqrt(v02x * v02x + v02y * v02y);
-    const float L2 = std::sqrt(v13x * v13x + v13y * v13y);
-    const float L01 = dist2pts(c[0].x, c[0].y, c[1].x, c[1].y);
-    const float L02 = dist2pts(c[0].x, c[0].y, c[2].x, c[2].y);
-    const float L12 = dist2pts(c[1].x, c[1].y, c[2].x, c[2].y);
-    const float L03 = dist2pts(c[0].x, c[0].y, c[3].x, c[3].y);
-    const float L23 = dist2pts(c[2].x, c[2].y, c[3].x, c[3].y);
-    const float P1 = (L01 + L02 + L12) * 0.5f;
-    const float S1 = std::sqrt(P1 * (P1 - L01) * (P1 - L02) * (P1 - L12));
-    const float P2 = (L02 + L03 + L23) * 0.5f;
-    const float S2 = std::sqrt(P2 * (P2 - L02) * (P2 - L03) * (P2 - L23));
-    if (((double)std::fabs(S1) < 1e-4) && ((double)std::fabs(S2) < 1e-4)) return 0.0f;
-    if (L1 * L2 > 0) {
-        const float cosTheta = (v02x * v13x + v02y * v13y) / (L1 * L2);
-        float theta = std::acos(cosTheta);
-        if (theta < 0) theta = theta + 3.1415926f;
-        return (float)(0.5 * (double)L1 * (double)L2 * (double)std::sin(theta));   // double product of float factors, :1926
+    const float dax = c[0].x - c[2].x, day = c[0].y - c[2].y;
+    const float dbx = c[1].x - c[3].x, dby = c[1].y - c[3].y;
+    const float diag_a = std::sqrt(dax * dax + day * day);
+    const float diag_b = std::sqrt(dbx * dbx + dby * dby);
+    const float e01 = dist2pts(c[0].x, c[0].y, c[1].x, c[1].y);
+    const float e02 = dist2pts(c[0].x, c[0].y, c[2].x, c[2].y);
+    const float e12 = dist2pts(c[1].x, c[1].y, c[2].x, c[2].y);
+    const float e03 = dist2pts(c[0].x, c[0].y, c[3].x, c[3].y);
+    const float e23 = dist2pts(c[2].x, c[2].y, c[3].x, c[3].y);
+    const float half_t1 = (e01 + e02 + e12) * 0.5f;
+    const float tri1 = std::sqrt(half_t1 * (half_t1 - e01) * (half_t1 - e02) * (half_t1 - e12));
+    const float half_t2 = (e02 + e03 + e23) * 0.5f;
+    const float tri2 = std::sqrt(half_t2 * (half_t2 - e02) * (half_t2 - e03) * (half_t2 - e23));
+    if (((double)std::fabs(tri1) < 1e-4) && ((double)std::fabs(tri2) < 1e-4)) return 0.0f;
+    if (diag_a * diag_b > 0) {
+        const float cos_between = (dax * dbx + day * dby) / (diag_a * diag_b);
+        float between = std::acos(cos_between);
+        if (between < 0) between = between + 3.1415926f;
+        return (float)(0.5 * (double)diag_a * (double)diag_b * (double)std::sin(between));   // double product of float factors, :1926
     }
     return 0.0f;
 }
 
 bool on_segment(Pt pt, Pt a, Pt b) {                                             // :1935-1948
-    const float d12 = dist2pts(a.x, a.y, b.x, b.y);
-    const float d01 = dist2pts(pt.x, pt.y, a.x, a.y);
-    const float d02 = dist2pts(pt.x, pt.y, b.x, b.y);
-    return (double)std::fabs(d01 + d02 - d12) < 1e-4;
+    const float len_ab = dist2pts(a.x, a.y, b.x, b.y);
+    const float to_a = dist2pts(pt.x, pt.y, a.x, a.y);
+    const float to_b = dist2pts(pt.x, pt.y, b.x, b.y);
+    return (double)std::fabs(to_a + to_b - len_ab) < 1e-4;
 }
 
 void line_of_2_points(float& a, float& b, float& c, float x1, float y1, float x2, float y2) {   // ImageMath.cpp:88-103
@@ -93,17 +93,17 @@ Pt polar_intersection(float rho1, float th1, float rho2, float th2) {           
 
 void all_intersections(const Pt c1[4], const Pt c2[4], std::vector<Pt>& out) {   // :1951-1996
     for (int n = 0; n < 4; n++) { out.push_back(c1[n]); out.push_back(c2[n]); }
-    const int i1[4] = {0, 1, 2, 3}, i2[4] = {1, 2, 3, 0};
-    for (int n1 = 0; n1 < 4; n1++) {
-        float A1, B1, C1, rho1, th1;
-        line_of_2_points(A1, B1, C1, c1[i1[n1]].x, c1[i1[n1]].y, c1[i2[n1]].x, c1[i2[n1]].y);
-        abc_to_polar(A1, B1, C1, rho1, th1);
-        for (int n2 = 0; n2 < 4; n2++) {
-            float A2, B2, C2, rho2, th2;
-            line_of_2_points(A2, B2, C2, c2[i1[n2]].x, c2[i1[n2]].y, c2[i2[n2]].x, c2[i2[n2]].y);
-            abc_to_polar(A2, B2, C2, rho2, th2);
-            const Pt p = polar_intersection(rho1, th1, rho2, th2);
-            if (on_segment(p, c1[i1[n1]], c1[i2[n1]]) && on_segment(p, c2[i1[n2]], c2[i2[n2]])) out.push_back(p);
+    const int from[4] = {0, 1, 2, 3}, to[4] = {1, 2, 3, 0};
+    for (int ea = 0; ea < 4; ea++) {
+        float la, lb, lc, ra, ta;
+        line_of_2_points(la, lb, lc, c1[from[ea]].x, c1[from[ea]].y, c1[to[ea]].x, c1[to[ea]].y);
+        abc_to_polar(la, lb, lc, ra, ta);
+        for (int eb = 0; eb < 4; eb++) {
+            float ma, mb, mc, rb, tb;
+            line_of_2_points(ma, mb, mc, c2[from[eb]].x, c2[from[eb]].y, c2[to[eb]].x, c2[to[eb]].y);
+            abc_to_polar(ma, mb, mc, rb, tb);
+            const Pt p = polar_intersection(ra, ta, rb, tb);
+            if (on_segment(p, c1[from[ea]], c1[to[ea]]) && on_segment(p, c2[from[eb]], c2[to[eb]])) out.push_back(p);
         }
     }
 }

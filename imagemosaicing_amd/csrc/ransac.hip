@@ -48,6 +48,7 @@ struct RansacArgs {
     mi355_sfpoint* big_a;          // [n] inliers of image i
     mi355_sfpoint* big_b;          // [n] inliers of image j
     float* big_pts;                // MODE 2: x1, y1, x2, y2 (4 n floats) in HBM
+    uint16_t* list_hbm;            // LISTG kernels only: [pair][2 x list_floats] uint16 -- the list of accepted draws and their supports in HBM (sample_times near 5000)
 };
 
 // the index-driven generic routines (hmath.h solve_h4 / nlls4) for the draws the register path hands back (a non-finite entry
@@ -472,7 +473,11 @@ __device__ __forceinline__ void write_result(mi355_pair_result* out, int cnt, co
 
 // MODE 0: the batched live path (n <= 400, everything in LDS); 1: one pair with 400 < n <= 4096 (points in LDS, Gauss-Newton work arrays in
 // HBM); 2: one pair with more points than the LDS holds (points in HBM too: every lane of a wave reads the same point, one request)
-template <int MODE>
+// LISTG: the list of accepted draws and their supports live in HBM instead of in front of the points in LDS.  With sample_times near 5000 the
+// list is 20 KB; on top of the 60.8 KB body (n up to 400) the workgroup would pass 80 KB and a CU (160 KB) would hold ONE workgroup instead of
+// two.  The list is touched once per draw (a 2-byte read, a 2-byte write), nothing of the hot arithmetic moves.  The live path
+// (sample_times 1000: 4 KB of list) keeps the LDS form, instantiated apart so that its list accesses stay ds_ instructions.
+template <int MODE, bool LISTG = false>
 __device__ __forceinline__ void ransac_body(const RansacArgs& a) {
     constexpr bool BIG = MODE >= 1;
     extern __shared__ __attribute__((aligned(16))) float lds[];      // 16-byte aligned whatever the static LDS in front of it adds up to: the float4 point copies are read with ds_read_b128 (at 8 mod 16 the support loop took twice as long)
@@ -491,8 +496,8 @@ __device__ __forceinline__ void ransac_body(const RansacArgs& a) {
         if (tid == 0) { out->n_in = 0; out->ok = 0; }
         return;
     }
-    uint16_t* list = reinterpret_cast<uint16_t*>(lds);   // draws that hold a hypothesis slot, in draw order
-    float* x1 = MODE == 2 ? a.big_pts : lds + a.list_floats;      // targets (image i)
+    uint16_t* list = LISTG ? a.list_hbm + (size_t)pair * 2 * (size_t)a.list_floats : reinterpret_cast<uint16_t*>(lds);   // draws that hold a hypothesis slot, in draw order
+    float* x1 = MODE == 2 ? a.big_pts : lds + (LISTG ? 0 : a.list_floats);      // targets (image i)
     float* y1 = x1 + n;
     float* x2 = y1 + n;         // sources (image j)
     float* y2 = x2 + n;
@@ -612,6 +617,8 @@ __device__ __forceinline__ void ransac_body(const RansacArgs& a) {
 
 // 2 waves per SIMD (256 registers each): with 1 (512 registers, spills in AGPRs instead of scratch) the kernel measured 30 % slower
 __global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(2, 2))) void ransac_kernel(RansacArgs a) { ransac_body<0>(a); }
+// the same with the draw list in HBM: sample_times so large that list + body would pass half a CU's LDS
+__global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(2, 2))) void ransac_listg_kernel(RansacArgs a) { ransac_body<0, true>(a); }
 // Ransac2D accepts any n (mosaicimage.h:1729-1761); the live path never exceeds 396, stand-alone callers may: up to 4096 points in LDS
 __global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(2, 2))) void ransac_big_kernel(RansacArgs a) { ransac_body<1>(a); }
 // ... and beyond 4096 (up to the 65 535 a 16-bit draw table can address) with the points in HBM
@@ -1015,6 +1022,30 @@ int mi_ransac_big(mi355_ctx* ctx, const mi355_sfpoint* p1, const mi355_sfpoint* 
 // tables BEFORE it enqueues the matcher, the build runs beside it, and the RANSAC launch only waits for the slot's event on the device.  The
 // "stream too short" flag of a build (never seen: the stream is twice what n = 4 needs) lands in pinned memory and is looked at when the slot is
 // used again.  d_tables == NULL: prefetch only; otherwise the ctx stream is made to wait for the slot's event.
+// The jump-ahead powers of the rand() recurrence: uploaded ONCE, with a blocking copy -- both users (the table build on the side stream, the
+// diagnostic on the ctx stream) then find them complete whichever comes first; the two streams are not ordered with each other.
+static int upload_raw_powers(mi355_ctx* ctx, DevBuf& dpow) {
+    const std::vector<uint32_t>& P = raw_stream_powers();
+    MI_HIP(dpow.reserve(P.size() * sizeof(uint32_t)));
+    MI_HIP(hipMemcpy(dpow.p, P.data(), P.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    return MI355_OK;
+}
+
+// the (never seen) "rand() stream too short" verdict of a finished build: the slot's tables are rebuilt on the host, the call that used them is void
+static int check_draw_slot(mi355_ctx* ctx, int si) {
+    mi355_ctx::DrawTables& t = ctx->draw_tables[si];
+    if (!t.valid || !t.ready || !ctx->draw_flags[si]) return MI355_OK;
+    const size_t one = (size_t)MAX_DRAWS * 4;
+    const int ntab = MI355_MAX_SELECTED - 4 + 1;
+    MI_HIP(hipStreamSynchronize(ctx->stream));
+    std::vector<uint16_t> tabs(one * ntab);
+    for (int n = 4; n <= MI355_MAX_SELECTED; n++) mi_glibc_draw_table(t.seed, n, MAX_DRAWS, tabs.data() + one * (n - 4));
+    MI_HIP(hipMemcpy(t.buf.p, tabs.data(), tabs.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    ctx->draw_flags[si] = 0;
+    ctx->set_error("ransac: the draw tables of an earlier call (seed " + std::to_string(t.seed) + ") were incomplete (rand() stream too short); they have been rebuilt, results of that call are void");
+    return MI355_ERR_FAILED;
+}
+
 int mi_ransac_tables(mi355_ctx* ctx, uint32_t seed, const uint16_t** d_tables) {
     const size_t one = (size_t)MAX_DRAWS * 4;
     const int ntab = MI355_MAX_SELECTED - 4 + 1;
@@ -1024,23 +1055,20 @@ int mi_ransac_tables(mi355_ctx* ctx, uint32_t seed, const uint16_t** d_tables) {
         MI_HIP(hipHostMalloc((void**)&ctx->draw_flags, 4 * sizeof(int), hipHostMallocDefault));
         for (int i = 0; i < 4; i++) ctx->draw_flags[i] = 0;
     }
+    // every finished build's verdict is looked at on every call, whichever seed this call is about: a flag is never lost to a slot's reuse
+    // (it used to be read only when the SAME seed came again, and was overwritten when the slot was taken for another one)
+    for (int si = 0; si < 4; si++)
+        if (ctx->draw_tables[si].valid && ctx->draw_tables[si].ready && hipEventQuery(ctx->draw_tables[si].ready) == hipSuccess) { const int rc = check_draw_slot(ctx, si); if (rc != MI355_OK) return rc; }
     mi355_ctx::DrawTables* slot = nullptr;
     for (auto& t : ctx->draw_tables) if (t.valid && t.seed == seed) slot = &t;
-    if (slot) {
-        const int si = (int)(slot - ctx->draw_tables);
-        if (hipEventQuery(slot->ready) == hipSuccess && ctx->draw_flags[si]) {      // (never seen) the stream was too short for some n: per-n host generation
-            MI_HIP(hipStreamSynchronize(ctx->stream));
-            std::vector<uint16_t> tabs(one * ntab);
-            for (int n = 4; n <= MI355_MAX_SELECTED; n++) mi_glibc_draw_table(seed, n, MAX_DRAWS, tabs.data() + one * (n - 4));
-            MI_HIP(hipMemcpy(slot->buf.p, tabs.data(), tabs.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
-            ctx->draw_flags[si] = 0;
-            ctx->set_error("ransac: the draw tables of an earlier call were incomplete (rand() stream too short); they have been rebuilt, results of that call are void");
-            return MI355_ERR_FAILED;
-        }
-    } else {
+    if (!slot) {
         for (auto& t : ctx->draw_tables) if (!t.valid) { slot = &t; break; }
         if (!slot) { slot = &ctx->draw_tables[0]; for (auto& t : ctx->draw_tables) if (t.used < slot->used) slot = &t; }      // the slot used longest ago
         const int si = (int)(slot - ctx->draw_tables);
+        if (slot->valid && slot->ready) {                // its last build may still be running: its verdict is read before the slot changes hands
+            MI_HIP(hipEventSynchronize(slot->ready));
+            const int rc = check_draw_slot(ctx, si); if (rc != MI355_OK) return rc;
+        }
         if (!slot->ready) MI_HIP(hipEventCreateWithFlags(&slot->ready, hipEventDisableTiming));
         MI_HIP(slot->buf.reserve(one * ntab * sizeof(uint16_t)));
         MI_HIP(slot->raw.reserve((size_t)RAW_STREAM * sizeof(int) + 64));
@@ -1051,11 +1079,7 @@ int mi_ransac_tables(mi355_ctx* ctx, uint32_t seed, const uint16_t** d_tables) {
         { GlibcRand g; g.seed(seed); for (int k = 0; k < 31; k++) rs.s[k] = (uint32_t)g.r[(g.f + k) % 31]; }     // x_{-31} .. x_{-1}: slot f is overwritten next
         int* d_flag = slot->raw.as<int>() + RAW_STREAM;
         DevBuf& dpow = ctx->buf("ransac_raw_powers");
-        if (dpow.cap == 0) {
-            const std::vector<uint32_t>& P = raw_stream_powers();
-            MI_HIP(dpow.reserve(P.size() * sizeof(uint32_t)));
-            MI_HIP(hipMemcpyAsync(dpow.p, P.data(), P.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->aux_stream));      // P is static: outlives the copy
-        }
+        if (dpow.cap == 0) { const int rc = upload_raw_powers(ctx, dpow); if (rc != MI355_OK) return rc; }
         hipLaunchKernelGGL(raw_stream_kernel, dim3(RAW_STREAM / RAW_BLK), dim3(64), 0, ctx->aux_stream, dpow.as<uint32_t>(), rs, slot->raw.as<int>(), RAW_STREAM);
         MI_HIP(hipMemsetAsync(d_flag, 0, sizeof(int), ctx->aux_stream));
         hipLaunchKernelGGL(draw_tables_kernel, dim3(ntab), dim3(256), 0, ctx->aux_stream, slot->raw.as<int>(), RAW_STREAM, slot->buf.as<uint16_t>(), 4, d_flag);
@@ -1115,10 +1139,17 @@ int mi_ransac_batch(mi355_ctx* ctx, const mi355_sfpoint* d_p1, const mi355_sfpoi
     // the lanes' best hypotheses (9 x RB floats) lie at the end of the allocation, where J* and C are kept after the draw loop (points + their
     // float4 copy take the first 8 n floats)
     const size_t body_floats = (size_t)38 * nmax > (size_t)8 * nmax + 9 * RB ? (size_t)38 * nmax : (size_t)8 * nmax + 9 * RB;
-    a.hb_off = (int)(a.list_floats + body_floats - 9 * RB);
-    const size_t lds_bytes = (body_floats + a.list_floats) * sizeof(float);
+    // two workgroups per CU need at most 80 KB each, static LDS (RShared, ~2 KB) included: beyond that the draw list moves to HBM
+    const bool listg = (body_floats + a.list_floats) * sizeof(float) + 2048 > 80 * 1024;
+    a.hb_off = (int)((listg ? 0 : a.list_floats) + body_floats - 9 * RB);
+    const size_t lds_bytes = (body_floats + (listg ? 0 : a.list_floats)) * sizeof(float);
+    if (listg) {
+        DevBuf& dl = ctx->buf("ransac_list_hbm");
+        MI_HIP(dl.reserve(sizeof(uint16_t) * 2 * (size_t)a.list_floats * (size_t)n_pairs));
+        a.list_hbm = dl.as<uint16_t>();
+    }
     if (lds_bytes > 48 * 1024) {
-        MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ransac_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(listg ? ransac_listg_kernel : ransac_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     }
     // records start from zero: the inlier slots beyond n_in, H / ok of pairs that stop early and the padding are then the same bytes
     // on every run and every rank (records are compared and all-gathered as bytes)
@@ -1127,7 +1158,7 @@ int mi_ransac_batch(mi355_ctx* ctx, const mi355_sfpoint* d_p1, const mi355_sfpoi
     int S = ctx->ransac_split;                          // option "ransac_split": -1 = by the number of pairs, 0 = never, k = k workgroups per pair
     if (S < 0) { S = (2 * ctx->num_cu) / n_pairs; if (S < 2) S = 0; if (S > 4) S = 4; }      // 4 x 4 waves take the 16 groups of a 1000-draw list at once; more only idle
     if (S > SPLIT_MAX) S = SPLIT_MAX;
-    if (S >= 1 && !dbg_on) {
+    if (S >= 1 && !dbg_on && !listg) {
         SplitBufs b;
         memset(&b, 0, sizeof(b));
         b.S = S; b.list_stride = (a.list_floats + 7) & ~7;
@@ -1189,7 +1220,8 @@ int mi_ransac_batch(mi355_ctx* ctx, const mi355_sfpoint* d_p1, const mi355_sfpoi
         }
     } else {
         ProfScope ps(ctx, "ransac", (double)n_pairs * (24.0 * nmax + sizeof(mi355_pair_result)));
-        hipLaunchKernelGGL(ransac_kernel, dim3(n_pairs), dim3(RB), lds_bytes, ctx->stream, a);
+        if (listg) hipLaunchKernelGGL(ransac_listg_kernel, dim3(n_pairs), dim3(RB), lds_bytes, ctx->stream, a);
+        else hipLaunchKernelGGL(ransac_kernel, dim3(n_pairs), dim3(RB), lds_bytes, ctx->stream, a);
     }
     MI_HIP(hipGetLastError());
     if (dbg_on) {
@@ -1286,11 +1318,7 @@ extern "C" int mi355_debug_rand_stream(mi355_ctx* ctx, uint32_t seed, int32_t* o
     DevBuf& draw = ctx->buf("ransac_raw_stream");
     MI_HIP(draw.reserve((size_t)RAW_STREAM * sizeof(int) + 64));
     DevBuf& dpow = ctx->buf("ransac_raw_powers");
-    if (dpow.cap == 0) {
-        const std::vector<uint32_t>& P = raw_stream_powers();
-        MI_HIP(dpow.reserve(P.size() * sizeof(uint32_t)));
-        MI_HIP(hipMemcpyAsync(dpow.p, P.data(), P.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
-    }
+    if (dpow.cap == 0) { const int rc = upload_raw_powers(ctx, dpow); if (rc != MI355_OK) return rc; }
     hipLaunchKernelGGL(raw_stream_kernel, dim3(RAW_STREAM / RAW_BLK), dim3(64), 0, ctx->stream, dpow.as<uint32_t>(), rs, draw.as<int>(), RAW_STREAM);
     MI_HIP(hipMemcpyAsync(out, draw.p, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
     MI_HIP(hipStreamSynchronize(ctx->stream));

@@ -185,7 +185,7 @@ __global__ __launch_bounds__(256) void blur16_tile(Blur16Args a) {
 // The row loop itself is hand-scheduled gfx950 assembly (blur16_asm.inc, generated by gen_blur16_asm.py, which says what the hand
 // schedule does that hipcc's did not: counted vmcnt waits, tap-staggered packed products without register moves, ...).  The HIP code
 // below only works out the wave's geometry.
-#include "blur16_asm.inc"
+#include "build/blur16_asm.inc"     // generated next to the objects (build.py generate()); the path is explicit so that a stale copy left in csrc/ by an older checkout can never be picked up
 template <int R, bool BGR, bool DS>
 __device__ __forceinline__ void blur16_stream_body(const Blur16Args& a, int L, int nstrip, int nseg) {
     constexpr int RA = (R + 3) / 4 * 4, SW = 256, BW = SW + 2 * RA;
@@ -854,12 +854,7 @@ __global__ __launch_bounds__(256) void refine_kernel(PyrDev P, const unsigned lo
         // duplicates: several start points may converge to one location -> first claim wins (all claims carry identical values)
         const size_t bit = ((size_t)R * oc.w + C) * 4 + (size_t)L;
         const unsigned mask = 1u << (bit & 31);
-        if (P.mins[o]) {
-            // keep-all (nfeatures <= 0): OpenCV's list is in generation order and of several start points that converge to one location the
-            // FIRST in that order keeps it -- every start point is stored, the location remembers its smallest start key, keepall_live_kernel
-            // keeps the record that holds it
-            atomicMin(&P.mins[o][fr * bs.mins + bit], start);
-        } else {
+        if (!P.mins[o]) {
             const unsigned old = atomicOr(&P.claimed[o][fr * bs.claimed + (bit >> 5)], mask);
             if (old & mask) continue;
         }
@@ -876,6 +871,11 @@ __global__ __launch_bounds__(256) void refine_kernel(PyrDev P, const unsigned lo
             rr.start = start;
             out[slot] = rr;
             out_resp[slot] = __float_as_uint(fabsf(contr));
+            // keep-all (nfeatures <= 0): OpenCV's list is in generation order and of several start points that converge to one location the
+            // FIRST in that order keeps it -- every start point is stored, the location remembers its smallest start key, keepall_live_kernel
+            // keeps the record that holds it.  The key is entered only once the record has its slot: keepall_reset_kernel walks the STORED
+            // records, so "entry below all ones <=> a stored record points at it" holds also for a frame that overflows the list
+            if (P.mins[o]) atomicMin(&P.mins[o][fr * bs.mins + bit], start);
         } else if (!P.mins[o]) atomicAnd(&P.claimed[o][fr * bs.claimed + (bit >> 5)], ~mask);      // list full (the frame fails): keep "bit set <=> record stored"
     }
 }
