@@ -94,6 +94,12 @@ def _copy_out(ptr, nbytes, dtype):
     return raw.view(dtype)
 
 
+def _view_out(ptr, nbytes, dtype, copy):
+    """A library-owned host buffer as a numpy array of dtype: a private copy, or (copy=False) a view valid as long as the library says."""
+    raw = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(nbytes,))
+    return (raw.copy() if copy else raw).view(dtype)
+
+
 class Context:
     """One GPU context (mi355_create).  Methods are named after the reference functions they replace."""
 
@@ -253,8 +259,9 @@ class Context:
         self.L.mi355_free(dst)
         return buf, dw.value, dh.value, dws.value
 
-    def MosaicImagesRefined(self, imgs, h9s):
-        """CMosaicByPose::MosaicImagesRefined (float), MosaicWithoutPos.cpp:2194-2352."""
+    def MosaicImagesRefined(self, imgs, h9s, want_pixels=True):
+        """CMosaicByPose::MosaicImagesRefined (float), MosaicWithoutPos.cpp:2194-2352.  want_pixels=False: the canvas the library returns is
+        released without the numpy copy (bench.py times the C call, not this binding)."""
         n = len(imgs)
         imgs = [np.ascontiguousarray(i, np.uint8) for i in imgs]
         ptrs = (C.c_void_p * n)(*[i.ctypes.data for i in imgs])
@@ -265,7 +272,7 @@ class Context:
         canvas = C.c_void_p()
         cw, ch, cws = C.c_int(), C.c_int(), C.c_int()
         self._chk(self.L.mi355_mosaic_refined(self._h, ptrs, _p(w), _p(h), _p(ws), n, _p(h9s), C.byref(canvas), C.byref(cw), C.byref(ch), C.byref(cws)))
-        buf = _copy_out(canvas, ch.value * cws.value, np.uint8).reshape(ch.value, cws.value)
+        buf = _copy_out(canvas, ch.value * cws.value, np.uint8).reshape(ch.value, cws.value) if want_pixels else None
         self.L.mi355_free(canvas)
         return buf, cw.value, ch.value, cws.value
 
@@ -336,24 +343,56 @@ class Context:
         ids = np.ascontiguousarray(img_ids, np.int32)
         self._chk(self.L.mi355_allgather_features(self._h, _p(ids), len(ids), int(n_max_per_rank)))
 
-    def AllGatherResults(self, d_local, n_local, accepted_only=True):
+    def AllGatherResults(self, d_local, n_local, accepted_only=True, root=-1, copy=True, wait=True):
+        """mi355_allgather_results.  root < 0: every rank receives all ranks' records; root >= 0: only that rank (the others send and
+        get an empty array).  The library hands out a view of pinned memory it owns, valid until the next call: copy=True (default)
+        returns a private numpy copy, copy=False the view itself (bench.py: a 1.1 GB numpy copy per step would be the measurement).
+        wait=False (root >= 0, copy=False): MI355_GATHER_NO_WAIT -- the view is complete after the next synchronize()."""
+        assert wait or (root >= 0 and not copy)
         ptr, n = C.c_void_p(), C.c_int(0)
-        self._chk(self.L.mi355_allgather_results(self._h, C.c_void_p(int(d_local)), int(n_local), int(bool(accepted_only)), C.byref(ptr), C.byref(n)))
-        out = _copy_out(ptr, n.value * PAIR_RESULT.itemsize, PAIR_RESULT)
-        self.L.mi355_free(ptr)
-        return out
+        flags = (1 if accepted_only else 0) | (0 if wait else 2)
+        self._chk(self.L.mi355_allgather_results(self._h, C.c_void_p(int(d_local)), int(n_local), flags, int(root), C.byref(ptr), C.byref(n)))
+        if not ptr.value or n.value == 0:
+            return np.zeros(0, PAIR_RESULT)
+        return _view_out(ptr, n.value * PAIR_RESULT.itemsize, PAIR_RESULT, copy)
 
     def PairMomentsDev(self, d_results, n, d_out):
         """one PAIR_MOMENTS record per pair record, device to device (ctx stream)"""
         self._chk(self.L.mi355_pair_moments_dev(self._h, C.c_void_p(int(d_results)), int(n), C.c_void_p(int(d_out))))
 
-    def AllGatherMoments(self, d_local, n_local):
-        """this rank's accepted pairs -> their second moments -> every rank's host (rank-major PAIR_MOMENTS array)"""
+    def AllGatherMoments(self, d_local, n_local, copy=True):
+        """this rank's accepted pairs -> their second moments -> every rank's host (rank-major PAIR_MOMENTS array; pinned memory of the
+        library, see AllGatherResults for `copy`)"""
         ptr, n = C.c_void_p(), C.c_int(0)
         self._chk(self.L.mi355_allgather_moments(self._h, C.c_void_p(int(d_local)), int(n_local), C.byref(ptr), C.byref(n)))
-        out = _copy_out(ptr, n.value * PAIR_MOMENTS.itemsize, PAIR_MOMENTS)
-        self.L.mi355_free(ptr)
-        return out
+        if not ptr.value or n.value == 0:
+            return np.zeros(0, PAIR_MOMENTS)
+        return _view_out(ptr, n.value * PAIR_MOMENTS.itemsize, PAIR_MOMENTS, copy)
+
+    def StripeCover(self, w, h, h9s, row0, rows, blended=False, keep=None, band=5):
+        """mi355_mosaic_stripe_cover: need[k] = 1 when rendering canvas rows [row0, row0 + rows) reads frame k"""
+        n = len(w)
+        w = np.ascontiguousarray(w, np.int32); h = np.ascontiguousarray(h, np.int32)
+        h9s = np.ascontiguousarray(h9s, np.float32)
+        keep_a = None if keep is None else np.ascontiguousarray(keep, np.uint8)
+        need = np.zeros(n, np.uint8)
+        self._chk(self.L.mi355_mosaic_stripe_cover(self._h, int(bool(blended)), _p(w), _p(h), n, _p(h9s), _p(keep_a), int(band), int(row0), int(rows), _p(need)))
+        return need
+
+    def ExchangeFrames(self, d_frames, h, ws, need, owner=None, own_through_rccl=False):
+        """mi355_exchange_frames.  d_frames: per frame this rank's device pointer (0 / None where it does not hold the frame); need: [G, n]
+        uint8 table (the same on every rank).  Returns (pointers for the stripe calls -- 0 where the rank's stripe does not read the frame --,
+        bytes received, bytes sent)."""
+        n = len(d_frames)
+        ptrs = (C.c_void_p * max(n, 1))(*[int(p) if p else None for p in d_frames])
+        h = np.ascontiguousarray(h, np.int32); ws = np.ascontiguousarray(ws, np.int32)
+        need = np.ascontiguousarray(need, np.uint8)
+        assert need.ndim == 2 and need.shape[1] == n
+        own_a = None if owner is None else np.ascontiguousarray(owner, np.int32)
+        out = (C.c_void_p * max(n, 1))()
+        br, bs = C.c_uint64(0), C.c_uint64(0)
+        self._chk(self.L.mi355_exchange_frames(self._h, ptrs, _p(h), _p(ws), n, _p(own_a), _p(need), 1 if own_through_rccl else 0, out, C.byref(br), C.byref(bs)))
+        return [int(out[k] or 0) for k in range(n)], int(br.value), int(bs.value)
 
     def SynthFrameDev(self, d_dst, w, h, ws, A6, seed, frame_seed, gain=1.0, noise=2.0):
         A6 = np.ascontiguousarray(A6, np.float32)

@@ -82,6 +82,7 @@ extern "C" void mi355_destroy(mi355_ctx* ctx) {
     mi_surf_release(ctx);
     for (auto& kv : ctx->feats) kv.second.release();
     for (auto& kv : ctx->ws) kv.second.release();
+    for (auto& kv : ctx->hws) kv.second.release();
     for (auto& b : ctx->host_frames) b.release();
     for (hipEvent_t e : ctx->host_frame_ev) if (e) (void)hipEventDestroy(e);
     for (auto& t : ctx->draw_tables) { t.buf.release(); t.raw.release(); if (t.ready) (void)hipEventDestroy(t.ready); }
@@ -341,6 +342,26 @@ extern "C" int mi355_mosaic_blended_rows_dev(mi355_ctx* ctx, const uint8_t* cons
     LOCKED_PROLOGUE
     if (rows < 1) { ctx->set_error("mosaic_blended_rows_dev: bad stripe"); return MI355_ERR_ARG; }
     return mi_mosaic_blended_dev(ctx, d_imgs, w, h, ws, n, h9s, keep, band, d_rows, cw, ch, cws, row0, rows);
+}
+
+// The frames a stripe call reads: the stripe calls themselves with the device work left out (cover_only), so the list cannot drift from them.
+extern "C" int mi355_mosaic_stripe_cover(mi355_ctx* ctx, int blended, const int* w, const int* h, int n, const float* h9s, const uint8_t* keep, int band,
+                                         int row0, int rows, uint8_t* need) {
+    LOCKED_PROLOGUE
+    if (!w || !h || !h9s || !need || n <= 0) { ctx->set_error("mosaic_stripe_cover: bad arguments"); return MI355_ERR_ARG; }
+    memset(need, 0, (size_t)n);
+    std::vector<const uint8_t*> none((size_t)n, nullptr);
+    std::vector<int> ws((size_t)n);
+    for (int k = 0; k < n; k++) ws[k] = (3 * w[k] + 3) & ~3;
+    if (!blended) {
+        int cw = 0, ch = 0, cws = 0;
+        const int rc = mi355_mosaic_layout(w, h, n, h9s, &cw, &ch, &cws, nullptr);
+        if (rc != MI355_OK) { ctx->set_error("mosaic_stripe_cover: no image with h[8] != 0 / empty canvas"); return rc; }
+        return mi_mosaic_refined_dev(ctx, none.data(), w, h, ws.data(), n, h9s, nullptr, cw, ch, cws, row0, rows, need);
+    }
+    int cw = 0, ch = 0;
+    { const int rc = mi_blend_layout(w, h, n, h9s, keep, &cw, &ch); if (rc != MI355_OK) return rc; }
+    return mi_mosaic_blended_dev(ctx, none.data(), w, h, ws.data(), n, h9s, keep, band, nullptr, cw, ch, (cw * 3 + 3) & ~3, row0, rows, need);
 }
 
 extern "C" int mi355_blend_layout(const int* w, const int* h, int n, const float* h9s, const uint8_t* keep, int* cw, int* ch, int* cws) {

@@ -889,8 +889,8 @@ int mi_mosaic_blended(mi355_ctx* ctx, const uint8_t* const* imgs, const int* w, 
 // that reach its rows (+ the pyramids' reach: stripe_levels / stripe_mask_rows), their ownership there, and the rows of every canvas pyramid level
 // its output rows depend on -- the same values the whole canvas holds there, so stripes put side by side are the whole canvas byte for byte.
 int mi_mosaic_blended_dev(mi355_ctx* ctx, const uint8_t* const* d_imgs, const int* w, const int* h, const int* ws, int n, const float* h9s,
-                          const uint8_t* keep, int band, uint8_t* d_canvas, int cw, int ch, int cws, int row0, int rows) {
-    if (!d_canvas) return MI355_ERR_ARG;
+                          const uint8_t* keep, int band, uint8_t* d_canvas, int cw, int ch, int cws, int row0, int rows, uint8_t* cover_only) {
+    if (!d_canvas && !cover_only) return MI355_ERR_ARG;
     int lw = 0, lh = 0;
     { int rc = mi_blend_layout(w, h, n, h9s, keep, &lw, &lh); if (rc != MI355_OK) return rc; }
     if (lw != cw || lh != ch || cws < 3 * cw || (cws & 3)) { ctx->set_error("mosaic_blended_dev: canvas geometry does not match mi355_blend_layout"); return MI355_ERR_ARG; }
@@ -912,8 +912,9 @@ int mi_mosaic_blended_dev(mi355_ctx* ctx, const uint8_t* const* d_imgs, const in
     int nv = 0, gw = 0, gh = 0;
     mi355_chip_info* ci = nullptr;
     std::vector<int> bbox;
-    int rc = mi_chips_and_masks_dev(ctx, d_imgs, w, h, ws, n, h9s, keep, 1, &nv, &ci, chip_off, mask_off, &gw, &gh, 1, &bbox, 1, mr0, mr1);
+    int rc = mi_chips_and_masks_dev(ctx, d_imgs, w, h, ws, n, h9s, keep, 1, &nv, &ci, chip_off, mask_off, &gw, &gh, 1, &bbox, 1, mr0, mr1, cover_only);
     if (rc != MI355_OK) { free(ci); return rc; }
+    if (cover_only) return MI355_OK;                     // mi355_mosaic_stripe_cover: the frames whose chips reach the stripe (+ the pyramids' reach) are marked, nothing was enqueued
     std::vector<const uint8_t*> dc(nv > 0 ? nv : 1), dm(nv > 0 ? nv : 1);
     for (int v = 0; v < nv; v++) { dc[v] = ctx->buf("chip_imgs").as<uint8_t>() + chip_off[v]; dm[v] = ctx->buf("chip_masks").as<uint8_t>() + mask_off[v]; }
     const int* bb = (int)bbox.size() == 4 * nv && nv > 0 ? bbox.data() : nullptr;

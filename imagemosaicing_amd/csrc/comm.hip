@@ -8,8 +8,12 @@
 //                              frame's keypoints + descriptors (fixed-size records, 312 KB per frame), so that rank r can match
 //                              (i, j) for any j of the reference's window j in (i, i+182) (:5083-5084)
 //   mi355_allgather_results    after match+select+RANSAC of the rank's own pairs: the accepted pair records (H + inlier lists)
-//                              of all ranks land on every rank's host for Select_Connected_Matched_Images / global alignment
-// Both are ncclAllGather calls on the ctx stream; nothing else of the data path crosses ranks.
+//                              of all ranks land on every rank's host -- or, with a root, on the host of the one rank that runs the
+//                              reference's driver on the inlier lists (ncclSend / ncclRecv) -- in pinned memory the ctx keeps
+//   mi355_allgather_moments    the same pairs as 184-byte second moments: what the replicated alignment of every rank starts from
+//   mi355_exchange_frames      after the alignment: the frames a rank's canvas stripe reads and the rank does not hold, from their
+//                              owners (ncclSend / ncclRecv groups) -- frames are uploaded to ONE GPU each, not to all eight
+// All run on the ctx stream; nothing else of the data path crosses ranks.
 //
 // librccl is bound at run time (dlopen / dlsym) the first time a communicator is created: a process that already holds an RCCL
 // (PyTorch-ROCm bundles its own librccl.so.1 next to its own HIP runtime) must use THAT copy -- a second one from /opt/rocm
@@ -28,6 +32,10 @@ struct RcclApi {
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
     ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
     ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
@@ -48,9 +56,13 @@ RcclApi* rccl_api() {
         api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(dlsym(api.so, "ncclCommDestroy"));
         api.AllGather = reinterpret_cast<decltype(api.AllGather)>(dlsym(api.so, "ncclAllGather"));
         api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(dlsym(api.so, "ncclGetErrorString"));
+        api.Send = reinterpret_cast<decltype(api.Send)>(dlsym(api.so, "ncclSend"));
+        api.Recv = reinterpret_cast<decltype(api.Recv)>(dlsym(api.so, "ncclRecv"));
+        api.GroupStart = reinterpret_cast<decltype(api.GroupStart)>(dlsym(api.so, "ncclGroupStart"));
+        api.GroupEnd = reinterpret_cast<decltype(api.GroupEnd)>(dlsym(api.so, "ncclGroupEnd"));
         api.CommCount = reinterpret_cast<decltype(api.CommCount)>(dlsym(api.so, "ncclCommCount"));
         api.CommUserRank = reinterpret_cast<decltype(api.CommUserRank)>(dlsym(api.so, "ncclCommUserRank"));
-        if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.AllGather || !api.GetErrorString || !api.CommCount || !api.CommUserRank) api.err = "librccl lacks a required symbol";
+        if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.AllGather || !api.GetErrorString || !api.CommCount || !api.CommUserRank || !api.Send || !api.Recv || !api.GroupStart || !api.GroupEnd) api.err = "librccl lacks a required symbol";
     });
     return &api;
 }
@@ -404,17 +416,19 @@ extern "C" int mi355_allgather_features(mi355_ctx* ctx, const int32_t* img_ids, 
     return install_features(ctx, hdr.data(), dpay.p, (int)(nm * world), img_ids, n_local);      // own frames are resident already
 }
 
-extern "C" int mi355_allgather_results(mi355_ctx* ctx, const mi355_pair_result* d_local, int n_local, int accepted_only,
-                                       mi355_pair_result** all, int* n_all) {
+extern "C" int mi355_allgather_results(mi355_ctx* ctx, const mi355_pair_result* d_local, int n_local, int flags, int root,
+                                       const mi355_pair_result** all, int* n_all) {
     LOCKED_PROLOGUE
+    const int accepted_only = flags & MI355_GATHER_ACCEPTED_ONLY;
+    const bool no_wait = (flags & MI355_GATHER_NO_WAIT) != 0 && root >= 0;
     if (!ctx->comm) { ctx->set_error("allgather_results: no communicator (mi355_comm_init)"); return MI355_ERR_ARG; }
     if (all) *all = nullptr;
     if (n_all) *n_all = 0;
     // bad arguments of ONE rank travel as a negative count: every rank then returns an error after the first collective
-    const bool bad_local = n_local < 0 || (n_local > 0 && !d_local) || !all || !n_all;
-    if (bad_local) n_local = 0;
     RcclApi* api = rccl_api();
     const int world = ctx->comm->world, rank = ctx->comm->rank;
+    const bool bad_local = n_local < 0 || (n_local > 0 && !d_local) || !all || !n_all || root >= world;
+    if (bad_local) n_local = 0;
     // 1. counts (after the optional compaction)
     DevBuf& dcnt = ctx->buf("ag_res_counts");
     MI_HIP(dcnt.reserve(sizeof(int) * (size_t)(world + 1)));
@@ -440,24 +454,46 @@ extern "C" int mi355_allgather_results(mi355_ctx* ctx, const mi355_pair_result* 
     if (bad_local) { ctx->set_error("allgather_results: bad arguments"); return MI355_ERR_ARG; }
     for (int r = 0; r < world; r++) { if (counts[r] < 0) { ctx->set_error("allgather_results: rank " + std::to_string(r) + " failed before the exchange"); return MI355_ERR_FAILED; } if (counts[r] > n_max) n_max = counts[r]; total += (size_t)counts[r]; }
     n_send = counts[rank];
-    // 2. payload, padded to the largest rank's count
+    const size_t REC = sizeof(mi355_pair_result);
     DevBuf& dall = ctx->buf("ag_res_all");
-    MI_HIP(dall.reserve(sizeof(mi355_pair_result) * (size_t)n_max * world));
-    mi355_pair_result* my = dall.as<mi355_pair_result>() + (size_t)n_max * rank;
-    if (n_send > 0) MI_HIP(hipMemcpyAsync(my, d_send, sizeof(mi355_pair_result) * (size_t)n_send, hipMemcpyDeviceToDevice, ctx->stream));
-    MI_NCCL(api->AllGather(my, dall.p, sizeof(mi355_pair_result) * (size_t)n_max, ncclChar, ctx->comm->comm, ctx->stream));
-    // 3. to the host, rank-major, padding dropped
-    mi355_pair_result* out = (mi355_pair_result*)malloc(sizeof(mi355_pair_result) * (total > 0 ? total : 1));
-    if (!out) return MI355_ERR_NOMEM;
-    size_t o = 0;
-    hipError_t e = hipSuccess;
-    for (int r = 0; r < world && e == hipSuccess; r++) {
-        if (counts[r] > 0) e = hipMemcpyAsync(out + o, dall.as<mi355_pair_result>() + (size_t)n_max * r, sizeof(mi355_pair_result) * (size_t)counts[r], hipMemcpyDeviceToHost, ctx->stream);
-        o += (size_t)counts[r];
+    HostBuf& hall = ctx->hbuf("ag_res_host");            // pinned, kept by the ctx: the caller's view of the result until the next call
+    if (root < 0) {
+        // 2a. payload to every rank, padded to the largest rank's count
+        MI_HIP(dall.reserve(REC * (size_t)n_max * world));
+        mi355_pair_result* my = dall.as<mi355_pair_result>() + (size_t)n_max * rank;
+        if (n_send > 0) MI_HIP(hipMemcpyAsync(my, d_send, REC * (size_t)n_send, hipMemcpyDeviceToDevice, ctx->stream));
+        MI_NCCL(api->AllGather(my, dall.p, REC * (size_t)n_max, ncclChar, ctx->comm->comm, ctx->stream));
+        // 3a. to the host, rank-major, padding dropped
+        MI_HIP(hall.reserve(REC * (total > 0 ? total : 1)));
+        size_t o = 0;
+        for (int r = 0; r < world; r++) {
+            if (counts[r] > 0) MI_HIP(hipMemcpyAsync(hall.as<mi355_pair_result>() + o, dall.as<mi355_pair_result>() + (size_t)n_max * r, REC * (size_t)counts[r], hipMemcpyDeviceToHost, ctx->stream));
+            o += (size_t)counts[r];
+        }
+        MI_HIP(hipStreamSynchronize(ctx->stream));
+        *all = hall.as<mi355_pair_result>(); *n_all = (int)total;
+        return MI355_OK;
     }
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    if (e != hipSuccess) { free(out); ctx->set_error(hipGetErrorString(e)); return MI355_ERR_DEVICE; }
-    *all = out; *n_all = (int)total;
+    // 2b. payload to the root alone: every other rank's block lands at its rank-major offset (no padding), one copy takes it to the host
+    if (rank == root) {
+        MI_HIP(dall.reserve(REC * (total > 0 ? total : 1)));
+        std::vector<size_t> off(world, 0);
+        for (int r = 1; r < world; r++) off[r] = off[r - 1] + (size_t)counts[r - 1];
+        MI_NCCL(api->GroupStart());
+        for (int r = 0; r < world; r++)
+            if (r != root && counts[r] > 0) MI_NCCL(api->Recv(dall.as<mi355_pair_result>() + off[r], REC * (size_t)counts[r], ncclChar, r, ctx->comm->comm, ctx->stream));
+        MI_NCCL(api->GroupEnd());
+        if (n_send > 0) MI_HIP(hipMemcpyAsync(dall.as<mi355_pair_result>() + off[rank], d_send, REC * (size_t)n_send, hipMemcpyDeviceToDevice, ctx->stream));
+        MI_HIP(hall.reserve(REC * (total > 0 ? total : 1)));
+        if (total > 0) MI_HIP(hipMemcpyAsync(hall.p, dall.p, REC * total, hipMemcpyDeviceToHost, ctx->stream));
+        if (!no_wait) MI_HIP(hipStreamSynchronize(ctx->stream));      // MI355_GATHER_NO_WAIT: the copy runs beside the caller's host work (the replicated alignment)
+        *all = hall.as<mi355_pair_result>();
+    } else if (n_send > 0) {
+        MI_NCCL(api->GroupStart());
+        MI_NCCL(api->Send(d_send, REC * (size_t)n_send, ncclChar, root, ctx->comm->comm, ctx->stream));
+        MI_NCCL(api->GroupEnd());
+    }
+    *n_all = (int)total;
     return MI355_OK;
 }
 
@@ -486,7 +522,7 @@ extern "C" int mi355_pair_moments_dev(mi355_ctx* ctx, const mi355_pair_result* d
 
 // mi355_allgather_results' protocol (counts first, a rank with bad arguments sends -1, payload padded to the largest count) on the moments of
 // this rank's accepted pairs
-extern "C" int mi355_allgather_moments(mi355_ctx* ctx, const mi355_pair_result* d_local, int n_local, mi355_pair_moments** all, int* n_all) {
+extern "C" int mi355_allgather_moments(mi355_ctx* ctx, const mi355_pair_result* d_local, int n_local, const mi355_pair_moments** all, int* n_all) {
     LOCKED_PROLOGUE
     if (!ctx->comm) { ctx->set_error("allgather_moments: no communicator (mi355_comm_init)"); return MI355_ERR_ARG; }
     if (all) *all = nullptr;
@@ -523,16 +559,75 @@ extern "C" int mi355_allgather_moments(mi355_ctx* ctx, const mi355_pair_result* 
         MI_HIP(hipGetLastError());
     }
     MI_NCCL(api->AllGather(my, dall.p, sizeof(mi355_pair_moments) * (size_t)n_max, ncclChar, ctx->comm->comm, ctx->stream));
-    mi355_pair_moments* out = (mi355_pair_moments*)malloc(sizeof(mi355_pair_moments) * (total > 0 ? total : 1));
-    if (!out) return MI355_ERR_NOMEM;
+    HostBuf& hall = ctx->hbuf("ag_mom_host");
+    MI_HIP(hall.reserve(sizeof(mi355_pair_moments) * (total > 0 ? total : 1)));
     size_t o = 0;
-    hipError_t e = hipSuccess;
-    for (int r = 0; r < world && e == hipSuccess; r++) {
-        if (counts[r] > 0) e = hipMemcpyAsync(out + o, dall.as<mi355_pair_moments>() + (size_t)n_max * r, sizeof(mi355_pair_moments) * (size_t)counts[r], hipMemcpyDeviceToHost, ctx->stream);
+    for (int r = 0; r < world; r++) {
+        if (counts[r] > 0) MI_HIP(hipMemcpyAsync(hall.as<mi355_pair_moments>() + o, dall.as<mi355_pair_moments>() + (size_t)n_max * r, sizeof(mi355_pair_moments) * (size_t)counts[r], hipMemcpyDeviceToHost, ctx->stream));
         o += (size_t)counts[r];
     }
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    if (e != hipSuccess) { free(out); ctx->set_error(hipGetErrorString(e)); return MI355_ERR_DEVICE; }
-    *all = out; *n_all = (int)total;
+    MI_HIP(hipStreamSynchronize(ctx->stream));
+    *all = hall.as<mi355_pair_moments>(); *n_all = (int)total;
+    return MI355_OK;
+}
+
+// ---- frame ownership (primary form) ---------------------------------------------------------------------------------------
+// The reference composites in ONE address space: every image is in host memory when MosaicImagesRefined / LaplacianPyramidBlending walk them
+// (MosaicWithoutPos.cpp:4663, 4671; MosaicImage.cpp:2306-2460).  With one process per GPU a frame lives where it was extracted (k mod G,
+// :4861); a canvas stripe reads the frames that cross it.  Which ones is known on every rank once the transforms are (the alignment is
+// replicated), so the whole schedule is a table every rank walks alike: no negotiation, no counts, only the transfers themselves.
+extern "C" int mi355_exchange_frames(mi355_ctx* ctx, const uint8_t* const* d_frames, const int* h, const int* ws, int n, const int32_t* owner,
+                                     const uint8_t* need, int flags, const uint8_t** d_out, uint64_t* bytes_recv, uint64_t* bytes_sent) {
+    LOCKED_PROLOGUE
+    if (!ctx->comm) { ctx->set_error("exchange_frames: no communicator (mi355_comm_init)"); return MI355_ERR_ARG; }
+    if (n < 0 || (n > 0 && (!d_frames || !h || !ws || !need || !d_out))) { ctx->set_error("exchange_frames: bad arguments"); return MI355_ERR_ARG; }
+    RcclApi* api = rccl_api();
+    const int world = ctx->comm->world, rank = ctx->comm->rank;
+    const bool own_too = (flags & MI355_EXCHANGE_OWN_THROUGH_RCCL) != 0;
+    auto own = [&](int k) { return owner ? owner[k] : k % world; };
+    // this rank's landing area: one slot per frame it receives.  Everything that can fail on this rank alone is checked BEFORE the first
+    // transfer is posted (a rank that left early would leave its peers waiting inside ncclRecv); the table itself is the same everywhere.
+    std::vector<size_t> slot(n > 0 ? n : 1, (size_t)-1);
+    size_t arena = 0;
+    uint64_t rb = 0, sb = 0;
+    for (int k = 0; k < n; k++) {
+        const int o = own(k);
+        if (o < 0 || o >= world || h[k] < 1 || ws[k] < 1) { ctx->set_error("exchange_frames: bad owner / geometry of frame " + std::to_string(k)); return MI355_ERR_ARG; }
+        const size_t bytes = (size_t)ws[k] * h[k];
+        d_out[k] = nullptr;
+        bool sends = false;
+        for (int r = 0; r < world; r++) if (need[(size_t)r * n + k] && (r != o || own_too) && o == rank) { sends = true; if (r != rank) sb += bytes; }
+        if ((sends || (need[(size_t)rank * n + k] && o == rank)) && !d_frames[k]) { ctx->set_error("exchange_frames: this rank owns frame " + std::to_string(k) + " but holds no pointer to it"); return MI355_ERR_ARG; }
+        if (!need[(size_t)rank * n + k]) continue;
+        if (o == rank && !own_too) { d_out[k] = d_frames[k]; continue; }
+        slot[k] = arena; arena += (bytes + 255) & ~(size_t)255;
+        if (o != rank) rb += bytes;
+    }
+    DevBuf& dar = ctx->buf("frame_exchange");
+    MI_HIP(dar.reserve(arena + 256));
+    for (int k = 0; k < n; k++) if (slot[k] != (size_t)-1) d_out[k] = dar.as<uint8_t>() + slot[k];
+    constexpr int RUN = 64;                               // frames per ncclGroup: bounds the operations one group carries (C5: ~480 receives per rank in all)
+    for (int k0 = 0; k0 < n; k0 += RUN) {
+        const int k1 = k0 + RUN < n ? k0 + RUN : n;
+        bool any = false;
+        for (int k = k0; k < k1 && !any; k++) {
+            const int o = own(k);
+            for (int r = 0; r < world; r++) if (need[(size_t)r * n + k] && (r != o || own_too) && (o == rank || r == rank)) { any = true; break; }
+        }
+        if (!any) continue;
+        MI_NCCL(api->GroupStart());
+        for (int k = k0; k < k1; k++) {
+            const int o = own(k);
+            const size_t bytes = (size_t)ws[k] * h[k];
+            for (int r = 0; r < world; r++) {
+                if (!need[(size_t)r * n + k] || (r == o && !own_too)) continue;
+                if (o == rank) MI_NCCL(api->Send(d_frames[k], bytes, ncclChar, r, ctx->comm->comm, ctx->stream));
+                if (r == rank) MI_NCCL(api->Recv(dar.as<uint8_t>() + slot[k], bytes, ncclChar, o, ctx->comm->comm, ctx->stream));
+            }
+        }
+        MI_NCCL(api->GroupEnd());
+    }
+    if (bytes_recv) *bytes_recv = rb;
+    if (bytes_sent) *bytes_sent = sb;
     return MI355_OK;
 }

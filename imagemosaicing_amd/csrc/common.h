@@ -49,6 +49,24 @@ struct DevBuf {
     template <class T> T* as() const { return reinterpret_cast<T*>(p); }
 };
 
+// grow-only PINNED host buffer (hipHostMalloc): the landing area of the result exchange's device-to-host copies.  A fresh pageable
+// allocation per call (what mi355_allgather_results did until round 5) pays a page fault per 4 KB and a staging copy: 3.7 GB/s measured on
+// C5's 1.1 GB of records against the ~50 GB/s a pinned target takes from the same link.
+struct HostBuf {
+    void*  p = nullptr;
+    size_t cap = 0;
+    hipError_t reserve(size_t bytes) {
+        if (bytes <= cap) return hipSuccess;
+        if (p) { hipError_t e = hipHostFree(p); if (e != hipSuccess) return e; p = nullptr; cap = 0; }
+        const size_t want = bytes + bytes / 8 + 4096;
+        hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
+    template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
 // device-resident features of one image (what the reference keeps in d:/feature_temp files)
 struct Features {
     int n = 0;          // keypoints
@@ -89,6 +107,7 @@ struct mi355_ctx {
     std::string err;
     std::unordered_map<int, Features> feats;
     std::map<std::string, DevBuf> ws;                  // named grow-only workspaces
+    std::map<std::string, HostBuf> hws;                // named grow-only pinned host buffers (results handed to the caller stay valid until the next call that fills the same buffer)
     // RANSAC draw tables of every n in [4, 400] for the last seeds used (ransac.hip mi_ransac_tables): four slots, reused in turn (15.9 MB each;
     // built on a side stream so that a survey's new seed costs its pair stage nothing: the build runs beside the matcher)
     struct DrawTables { uint32_t seed = 0; bool valid = false; DevBuf buf, raw; hipEvent_t ready = nullptr; unsigned long long used = 0; };
@@ -126,6 +145,7 @@ struct mi355_ctx {
 
     void set_error(const std::string& s) { err = s; }
     DevBuf& buf(const std::string& name) { return ws[name]; }
+    HostBuf& hbuf(const std::string& name) { return hws[name]; }
     std::vector<int> deferred_dims;                    // per prepared entry: launch extent (groups of 4 columns, rows)
     std::vector<unsigned char> deferred_warps;         // warp.hip: the chips' warp arguments when mi_chips_and_masks_dev was asked to leave the pixels to mi_chip_pixels_prepare / _launch
     // profiling brackets
@@ -148,13 +168,13 @@ struct ProfScope {
 int mi_warp_image(mi355_ctx*, const uint8_t* src, int w, int h, int ws, int ch, const float* h9,
                   uint8_t** dst, int* dw, int* dh, int* dws);
 int mi_mosaic_refined_dev(mi355_ctx*, const uint8_t* const* d_imgs, const int* w, const int* h, const int* ws, int n,
-                          const float* h9s, uint8_t* d_canvas, int cw, int ch, int cws, int row0, int rows);
+                          const float* h9s, uint8_t* d_canvas, int cw, int ch, int cws, int row0, int rows, uint8_t* cover_only = nullptr);
 int mi_sift_flush(mi355_ctx*);                               // enqueues every partly filled batch (no wait)
 int mi_sift_flush_if_parked(mi355_ctx*, hipEvent_t ev);   // launches the batch still holding a parked frame with this event
 int mi_chips_and_masks_dev(mi355_ctx*, const uint8_t* const* imgs, const int* w, const int* h, const int* ws, int n,
                            const float* h9s, const uint8_t* keep, int find_masks, int* n_chips, mi355_chip_info** chips,
                            std::vector<size_t>& chip_off, std::vector<size_t>& mask_off, int* canvas_w, int* canvas_h, int imgs_on_device = 0,
-                           std::vector<int>* owned_bbox = nullptr, int defer_pixels = 0, int row_lo = 0, int row_hi = 0x7fffffff);      // row_lo .. row_hi: a stripe of the canvas (see warp.hip); find_masks: per chip {min col, min row, max col, max row} of its non-zero mask bytes (max < min: none)
+                           std::vector<int>* owned_bbox = nullptr, int defer_pixels = 0, int row_lo = 0, int row_hi = 0x7fffffff, uint8_t* cover_only = nullptr);      // row_lo .. row_hi: a stripe of the canvas (see warp.hip); find_masks: per chip {min col, min row, max col, max row} of its non-zero mask bytes (max < min: none)
 // defer_pixels: the chips' validity masks (and ownership) are made at once, their PIXELS only where asked for afterwards, chip by chip
 // (the blender needs them inside a chip's active window only); columns / rows inclusive, clipped to the chip
 int mi_chip_pixels_prepare(mi355_ctx*, int n, const int* chips, const int* win4);      // entry e = chip chips[e] inside win4[4e..]: arguments to the device
@@ -162,7 +182,7 @@ int mi_chip_pixels_launch(mi355_ctx*, int first, int count);                    
 int mi_mosaic_blended(mi355_ctx*, const uint8_t* const* imgs, const int* w, const int* h, const int* ws, int n, const float* h9s,
                       const uint8_t* keep, int band, uint8_t** out, int* ow, int* oh, int* ows);
 int mi_mosaic_blended_dev(mi355_ctx*, const uint8_t* const* d_imgs, const int* w, const int* h, const int* ws, int n, const float* h9s,
-                          const uint8_t* keep, int band, uint8_t* d_canvas, int cw, int ch, int cws, int row0 = 0, int rows = -1);      // rows >= 0: the stripe row0 .. row0 + rows - 1 of the canvas only
+                          const uint8_t* keep, int band, uint8_t* d_canvas, int cw, int ch, int cws, int row0 = 0, int rows = -1, uint8_t* cover_only = nullptr);      // rows >= 0: the stripe row0 .. row0 + rows - 1 of the canvas only
 int mi_blend_layout(const int* w, const int* h, int n, const float* h9s, const uint8_t* keep, int* cw, int* ch);
 int mi_multiband_blend(mi355_ctx*, const uint8_t* const* chips, const uint8_t* const* masks, const mi355_chip_info* info, int n,
                        int W, int H, int band, uint8_t** out, int* ow, int* oh, int* ows);

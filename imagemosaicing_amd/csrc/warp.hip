@@ -331,8 +331,9 @@ __global__ __launch_bounds__(256) void mosaic_tile_kernel(const FrameDev* fr, in
     }
 }
 
+// cover_only != NULL: no device work -- cover_only[k] = 1 for the frames this call would read (the stripe's cover list, mi355_mosaic_stripe_cover)
 int mi_mosaic_refined_dev(mi355_ctx* ctx, const uint8_t* const* d_imgs, const int* w, const int* h, const int* ws, int n,
-                          const float* h9s, uint8_t* d_canvas, int cw, int ch, int cws, int row0, int rows) {
+                          const float* h9s, uint8_t* d_canvas, int cw, int ch, int cws, int row0, int rows, uint8_t* cover_only) {
     int lw, lh, lws; float dG[2];
     int rc = mi355_mosaic_layout(w, h, n, h9s, &lw, &lh, &lws, dG);
     if (rc != MI355_OK) { ctx->set_error("mosaic_refined: no image with h[8] != 0 / empty canvas"); return rc; }
@@ -372,12 +373,14 @@ int mi_mosaic_refined_dev(mi355_ctx* ctx, const uint8_t* const* d_imgs, const in
         if (begY < row0) begY = row0;                                   // canvas stripe
         if (endY > row0 + rows - 1) endY = row0 + rows - 1;
         if (endX < begX || endY < begY) continue;
+        if (cover_only) { cover_only[k] = 1; continue; }
         if (!d_imgs[k] || w[k] < 2 || h[k] < 2 || ws[k] < 3 * w[k]) { ctx->set_error("mosaic_refined: bad image geometry"); return MI355_ERR_ARG; }
         f.src = d_imgs[k]; f.w = w[k]; f.h = h[k]; f.ws = ws[k];
         f.begX = begX; f.endX = endX; f.begY = begY; f.endY = endY;
         f.unit_den = (f.inv[6] == 0.0f && f.inv[7] == 0.0f && f.inv[8] == 1.0f) ? 1 : 0;
         fr.push_back(f);
     }
+    if (cover_only) return MI355_OK;
     const int nf = (int)fr.size();
     const int bx_n = (cw + MT_COARSE - 1) / MT_COARSE, by_n = (rows + MT_COARSE - 1) / MT_COARSE;
     DevBuf& dfr = ctx->buf("mosaic_frames");
@@ -646,7 +649,7 @@ __global__ __launch_bounds__(256) void mask_bbox_kernel(const ChipDev* chips, ui
 int mi_chips_and_masks_dev(mi355_ctx* ctx, const uint8_t* const* imgs, const int* w, const int* h, const int* ws, int n,
                            const float* h9s, const uint8_t* keep, int find_masks, int* n_chips, mi355_chip_info** chips_out,
                            std::vector<size_t>& chip_off, std::vector<size_t>& mask_off, int* cw_out, int* ch_out, int imgs_on_device,
-                           std::vector<int>* owned_bbox, int defer_pixels, int row_lo, int row_hi) {
+                           std::vector<int>* owned_bbox, int defer_pixels, int row_lo, int row_hi, uint8_t* cover_only) {
     if (!imgs || !w || !h || !ws || !h9s || n <= 0 || !n_chips || !chips_out) return MI355_ERR_ARG;
     // ---- layout, MosaicImage.cpp:2233-2343 (host, same float ops) ----
     float maxX = 0.0f, maxY = 0.0f, minX = 0.0f, minY = 0.0f;                     // :2234 (canvas always contains the origin)
@@ -706,6 +709,13 @@ int mi_chips_and_masks_dev(mi355_ctx* ctx, const uint8_t* const* imgs, const int
         cd[v].map_off = map_total;
         map_total += (size_t)mws * c.h;
         av.push_back(v);
+    }
+    if (cover_only) {                                        // the images whose chips this call would form: nothing else is done
+        for (int v : av) cover_only[kept[v]] = 1;
+        *n_chips = nv; *chips_out = nullptr;
+        if (cw_out) *cw_out = newW;
+        if (ch_out) *ch_out = newH;
+        return MI355_OK;
     }
     const int na = (int)av.size();
     DevBuf& dchips = ctx->buf("chip_imgs");

@@ -2,7 +2,7 @@
 
 Sharding (the reference's own rule, MosaicWithoutPos.cpp:4861 / :5066, threads -> ranks): rank r extracts the frames
 k mod G == r and matches the pairs (i, j) whose i it owns (mi355_pair_schedule); j runs over the reference's window
-j in (i, i+182) (:5083-5084), so every rank needs every frame's features before matching.  Two exchanges, nothing else of the
+j in (i, i+182) (:5083-5084), so every rank needs every frame's features before matching.  Three exchanges, nothing else of the
 data path crosses ranks:
 
   features   after detect+describe: all-gather of the fixed-size feature records (keypoints + u8 descriptors, 312 KB per
@@ -10,7 +10,11 @@ data path crosses ranks:
              d:/feature_temp files (:4874-4880 -> :5100-5103)
   results    after match + select + RANSAC: all-gather of the accepted pair records (H + inlier lists, 9664 B each) that
              feed Select_Connected_Matched_Images / global alignment -- PushMatchPairs under a mutex in the reference
-             (:5236, :10137-10145)
+             (:5236, :10137-10145) -- or, for surveys whose records weigh a gigabyte (C5), the records to ONE root rank (the one
+             that runs the unchanged driver) and their 184-byte second moments to every rank for the replicated alignment
+  frames     after the alignment: a rank holds only the frames it extracted; the frames its canvas stripe reads come from their
+             owners (mi355_exchange_frames: ncclSend / ncclRecv groups) -- the reference composites in one address space
+             (MosaicWithoutPos.cpp:4663 / :4671)
 
 Transports: "rccl" = the C ABI's own collectives (mi355_allgather_features / mi355_allgather_results: ncclAllGather over
 xGMI on the ctx stream; the product path, what bench.py runs with backend nccl); "torch" = the same packed records moved by
@@ -133,6 +137,7 @@ class Exchange:
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.rccl_ranks = None                         # what the communicator itself reports (ncclCommCount)
         self._payload = None
+        self._recv_frames = {}                         # torch transport of exchange_frames: the received frames, alive until the next call
         if transport == "rccl":
             ok = 1 if comm_available() else 0
             if self.world > 1:
@@ -174,17 +179,60 @@ class Exchange:
             block = gp[r].contiguous()
             self.ctx.InstallFeaturesDev(hdrs[r], block.data_ptr())
 
-    def allgather_results(self, results, n_local, accepted_only=True):
-        """results: uint8 device tensor [>= n_local, 9664] written by MatchPairsDev.  Returns all ranks' records (numpy, rank-major)."""
+    def allgather_results(self, results, n_local, accepted_only=True, root=-1, copy=True, wait=True):
+        """results: uint8 device tensor [>= n_local, 9664] written by MatchPairsDev.  root < 0: returns all ranks' records (numpy, rank-major)
+        on every rank; root >= 0: on that rank only (the others send and get an empty array) -- the rank that runs the reference's unchanged
+        driver on the inlier lists (MosaicWithoutPos.cpp:4575-4591).  copy=False: a view of the library's pinned buffer, valid until the next call."""
         if self.transport == "rccl":
-            return self.ctx.AllGatherResults(results.data_ptr(), n_local, accepted_only)
+            return self.ctx.AllGatherResults(results.data_ptr(), n_local, accepted_only, root=root, copy=copy, wait=wait)
         g, counts = allgather_pair_results(results[:n_local], accepted_only=accepted_only)
+        if root >= 0 and self.rank != root:
+            return np.zeros(0, PAIR_RESULT)
         return gathered_to_records(g, counts)
 
-    def allgather_moments(self, results, n_local):
+    def stripe_need(self, w, h, h9s, stripes, blended=False, keep=None, band=5):
+        """the G x n table of mi355_exchange_frames: row r = the frames rank r's stripe (row0, rows) reads; the same on every rank"""
+        return np.stack([self.ctx.StripeCover(w, h, h9s, r0, nr, blended=blended, keep=keep, band=band) for (r0, nr) in stripes])
+
+    def exchange_frames(self, frames, h, ws, need, owner=None, own_through_rccl=False):
+        """frames: per frame a torch uint8 device tensor where this rank holds it, else None.  Every frame this rank's stripe reads
+        (need[rank]) and does not hold comes from its owner (k mod G unless `owner` says otherwise).  Returns (device pointers for the
+        stripe calls, 0 where the stripe does not read the frame; bytes received; bytes sent); received frames stay alive until the next call."""
+        n = len(frames)
+        need = np.ascontiguousarray(need, np.uint8)
+        if self.transport == "rccl":
+            return self.ctx.ExchangeFrames([f.data_ptr() if f is not None else 0 for f in frames], h, ws, need, owner=owner, own_through_rccl=own_through_rccl)
+        own = (lambda k: int(owner[k])) if owner is not None else (lambda k: k % self.world)
+        self._recv_frames = {}
+        out, br, bs = [0] * n, 0, 0
+        for k in range(n):
+            o = own(k)
+            nbytes = int(ws[k]) * int(h[k])
+            if need[self.rank, k] and o == self.rank:
+                out[k] = frames[k].data_ptr()
+            for r in range(self.world):
+                if not need[r, k] or r == o:
+                    continue
+                if self.rank == o:
+                    t = frames[k].reshape(-1)[:nbytes]
+                    dist.send(t.cpu() if dist.get_backend() != "nccl" else t, dst=r)
+                    bs += nbytes
+                elif self.rank == r:
+                    dev = torch.device("cuda", torch.cuda.current_device())
+                    buf = torch.empty(nbytes, dtype=torch.uint8, device=dev if dist.get_backend() == "nccl" else "cpu")
+                    dist.recv(buf, src=o)
+                    buf = buf.to(dev)
+                    self._recv_frames[k] = buf
+                    out[k] = buf.data_ptr()
+                    br += nbytes
+        if torch.cuda.is_available():
+            torch.cuda.current_stream().synchronize()     # the ctx stream may be another one: the copies must have landed
+        return out, br, bs
+
+    def allgather_moments(self, results, n_local, copy=True):
         """what the alignment needs of this rank's accepted pairs (PAIR_MOMENTS, 184 B per pair, formed on the device) from every rank (numpy, rank-major)"""
         if self.transport == "rccl":
-            return self.ctx.AllGatherMoments(results.data_ptr(), n_local)
+            return self.ctx.AllGatherMoments(results.data_ptr(), n_local, copy=copy)
         from .capi import PAIR_MOMENTS
         local = compact_accepted(results[:n_local]).contiguous()
         mom = torch.zeros((max(local.shape[0], 1), PAIR_MOMENTS.itemsize), dtype=torch.uint8, device=local.device)

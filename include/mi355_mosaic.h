@@ -324,11 +324,22 @@ int  mi355_comm_info(mi355_ctx* ctx, int* rank, int* n_ranks);
  * A rank whose own arguments / features are bad still takes part in the collective (it sends records flagged img_id == -2),
  * so that EVERY rank returns the error together instead of the others hanging in ncclAllGather. */
 int  mi355_allgather_features(mi355_ctx* ctx, const int32_t* img_ids, int n_local, int n_max_per_rank);
-/* ncclAllGather of the pair records (PushMatchPairs, :10137-10145): d_local = this rank's n_local device records
- * (mi355_match_pairs_dev); accepted_only != 0 sends the accepted pairs only (C4: 96 % of the window pairs do not overlap).
- * *all: host array, rank-major, every rank receives the same -> mi355_free. */
-int  mi355_allgather_results(mi355_ctx* ctx, const mi355_pair_result* d_local, int n_local, int accepted_only,
-                             mi355_pair_result** all, int* n_all);
+/* The result exchange (PushMatchPairs, :10137-10145): d_local = this rank's n_local device records (mi355_match_pairs_dev);
+ * flags: MI355_GATHER_ACCEPTED_ONLY sends the accepted pairs only (C4: 96 % of the window pairs do not overlap);
+ * MI355_GATHER_NO_WAIT (root >= 0 only) returns on the root once the receives and the device-to-host copy are ENQUEUED: *all is complete
+ * after the next mi355_synchronize -- the 1.1 GB of C5 then cross PCIe while the host runs the alignment on the moments.
+ *   root < 0   ncclAllGather: every rank's host receives the records of all ranks (rank-major);
+ *   root >= 0  only rank `root`'s host does -- the rank that runs the reference's unchanged driver on the inlier lists
+ *              (Select_Connected_Matched_Images / BundleAdjustmentSparse, MosaicWithoutPos.cpp:4575-4591).  The other ranks ncclSend their
+ *              records to it and get *all = NULL; a deployment gives them the moments (mi355_allgather_moments) for the replicated
+ *              alignment that places their canvas stripes.  C5: 1.1 GB of records then cross PCIe on one rank instead of on eight.
+ * *n_all = the number of records of all ranks, on every rank.  *all points into PINNED host memory owned by the ctx (grown when needed, never
+ * shrunk): valid until the next mi355_allgather_results call on this ctx or mi355_destroy -- do NOT free it.  (Until round 5 this was a
+ * fresh malloc per call: page faults and a staged copy held the device-to-host leg to 3.7 GB/s.) */
+#define MI355_GATHER_ACCEPTED_ONLY 1
+#define MI355_GATHER_NO_WAIT       2
+int  mi355_allgather_results(mi355_ctx* ctx, const mi355_pair_result* d_local, int n_local, int flags, int root,
+                             const mi355_pair_result** all, int* n_all);
 
 /* What the global alignment needs of an accepted pair (round 5): the second moments of its inlier coordinates -- the sums the normal
  * equations of BundleAdjustmentSparse's system are made of (MosaicWithoutPos.cpp:6971-7202) -- instead of the 9664-byte record with its two
@@ -341,14 +352,36 @@ int  mi355_pair_moments_dev(mi355_ctx* ctx, const mi355_pair_result* d_results, 
 /* the same sums on the host (callers without a device, tests) */
 int  mi355_pair_moments_host(const mi355_pair_result* r, int n, mi355_pair_moments* out);
 /* mi355_allgather_results for callers that only align: this rank's ACCEPTED pairs -> their moments (on the device) -> ncclAllGather -> host
- * array, rank-major, the same on every rank (mi355_free).  52 x fewer bytes over xGMI and PCIe than the records (C5: 117 621 accepted pairs
- * are 1.1 GB of records per rank), and the replicated host step starts from the sums instead of 28 M correspondences. */
-int  mi355_allgather_moments(mi355_ctx* ctx, const mi355_pair_result* d_local, int n_local, mi355_pair_moments** all, int* n_all);
+ * array, rank-major, the same on every rank; pinned and owned by the ctx like mi355_allgather_results' (valid until the next
+ * mi355_allgather_moments call; do NOT free).  52 x fewer bytes over xGMI and PCIe than the records (C5: 117 621 accepted pairs are 1.1 GB of
+ * records per rank), and the replicated host step starts from the sums instead of 28 M correspondences. */
+int  mi355_allgather_moments(mi355_ctx* ctx, const mi355_pair_result* d_local, int n_local, const mi355_pair_moments** all, int* n_all);
 /* Select_Connected_Matched_Images / the global alignment from the moments (entries with n_in <= 0 are skipped): the same labels and, bit
  * for bit, the same transforms as the _results forms give on the records the moments were formed from */
 int  mi355_select_connected_moments(const mi355_pair_moments* m, int n, int n_images, int32_t* label);
 int  mi355_global_affine_align_moments(const mi355_pair_moments* m, int n, int n_images, const int32_t* fixed, const int32_t* label,
                                        mi355_image_transform* out);
+
+/* ---- frame ownership for the compositing phase (primary form) --------------------------------------------------------------
+ * A rank uploads and holds only the frames it extracts (k mod G == rank, MosaicWithoutPos.cpp:4861).  After the (replicated) alignment
+ * every rank knows every rank's canvas stripe and therefore which frames each stripe reads; a frame a stripe reads and its rank does not
+ * hold is sent by its owner over xGMI.  Replaces "every rank holds all N frames" (72 GB per GPU at C5; 8 x the PCIe upload). */
+/* need[k] = 1 when rendering canvas rows [row0, row0 + rows) reads frame k: exactly the frames mi355_mosaic_refined_dev (blended == 0) or
+ * mi355_mosaic_blended_rows_dev (blended != 0: keep, band as there; chips that reach the rows plus the blender pyramids' reach) dereference
+ * for these arguments -- computed by the same code paths with the device work left out.  Host geometry; ctx only carries the error text. */
+int  mi355_mosaic_stripe_cover(mi355_ctx* ctx, int blended, const int* w, const int* h, int n, const float* h9s, const uint8_t* keep, int band,
+                               int row0, int rows, uint8_t* need);
+/* The exchange.  d_frames[k]: this rank's device pointer of frame k where it holds it (owner[k] == its rank; owner == NULL: k mod G), else
+ * ignored.  need: G x n bytes, need[r * n + k] != 0 = rank r's stripe reads frame k (mi355_mosaic_stripe_cover with rank r's rows); the SAME
+ * table on every rank.  For every (r, k) with need set and r != owner[k] the owner ncclSends the frame (ws[k] * h[k] bytes) and rank r ncclRecvs
+ * it into storage owned by the ctx ("frame_exchange", grown when needed); the transfers are grouped by runs of 64 frames, every rank walks the
+ * same table in the same order.  d_out[k]: this rank's pointer to frame k afterwards -- its own frame, the received copy, or NULL when its
+ * stripe does not read it -- ready to be the d_imgs of the stripe calls.  Received copies stay valid until the next call.
+ * flags: MI355_EXCHANGE_OWN_THROUGH_RCCL also routes the rank's own needed frames through ncclSend / ncclRecv to itself (a communicator
+ * of one rank then exercises the whole path: tests).  bytes_recv / bytes_sent (NULL allowed): this rank's traffic.  Enqueued on the ctx stream. */
+#define MI355_EXCHANGE_OWN_THROUGH_RCCL 1
+int  mi355_exchange_frames(mi355_ctx* ctx, const uint8_t* const* d_frames, const int* h, const int* ws, int n, const int32_t* owner,
+                           const uint8_t* need, int flags, const uint8_t** d_out, uint64_t* bytes_recv, uint64_t* bytes_sent);
 
 /* ---- measurement hooks (bench.py) ----------------------------------------------------------------------- */
 /* When enabled, every launch of the named kernel class is bracketed by hipEvents on the ctx stream. */

@@ -23,7 +23,10 @@ def test_bench_contract_small():
     assert d["n_gpus"] == 1 and d["steps"] == 1 and d["higher_is_better"] is True and d["vs_baseline"] is None and d["data"] == "synthetic"
     assert "workload" in d["config"] and "model" not in d["config"]
     rf = d["roofline"]
-    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
+    assert rf["bound"] == "valu" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
+    assert rf["valu"]["frac"] > 0 and d["roofline_by_kernel"]["ransac_kernel"]["bound"] == "valu"      # adjacent pairs: the blur dominates, ransac_kernel listed beside it
+    hf = d["host_frames"]
+    assert hf["value"] > 0 and hf["pairs_accepted"] == 5 and "pageable host memory" in hf["sample"]      # what the adaptor's caller gets (host IplImages)
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0
     q = d["quality"]
@@ -57,6 +60,11 @@ def test_bench_two_ranks_strong_dry_run_on_one_gpu():
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["cpu_baseline"] is None
     assert d["config"]["frames"] == 9 and d["config"]["pairs"] == 8 and d["config"]["frames_per_gpu"] == 5 and d["config"]["pairs_per_gpu"] == 4
     assert d["quality"]["pairs_accepted"] == 8 and d["quality"]["images_aligned"] == 9 and d["quality"]["h_corner_err_px_median"] < 0.5
+    # SURVEY 8e primary form: a rank holds the 5 (4) frames it extracts and receives the ones its canvas stripe reads; the alignment is
+    # replicated from the moments and the records go to rank 0's host only
+    assert d["frames_resident"].startswith("owned") and d["align_input"].startswith("moments")
+    fx = d["frame_exchange_rank0"]
+    assert fx["frames_held"] == 5 and fx["bytes_received"] > 0 and fx["bytes_sent"] > 0 and fx["frames_read_by_the_stripe"] < 9
     # whole-job aggregate: the survey's 8 pairs per step
     assert abs(d["value"] - 8 / (d["ms_per_step"] / 1e3)) / d["value"] < 1e-6
 
@@ -78,3 +86,24 @@ def test_bench_plain_command_form_launches_its_ranks():
     assert d["n_gpus"] == 2 and d["scaling"] == "strong"
     assert d["transport"] == "torch" and d["rccl_ranks"] is None
     assert d["config"]["frames_per_gpu"] == 5 and d["quality"]["pairs_accepted"] == 8
+
+
+def test_bench_two_ranks_replicas_and_records_forms_still_run():
+    """the round-5 forms stay selectable: every frame on every rank (no exchange) and the records all-gathered to every rank"""
+    d = _two_ranks(["--frames", "9", "--frames-resident", "replicas", "--align-input", "records"])
+    assert d["frames_resident"] == "all frames on every rank" and d["align_input"] == "records" and "frame_exchange_rank0" not in d
+    assert d["quality"]["pairs_accepted"] == 8 and d["quality"]["images_aligned"] == 9
+
+
+def test_bench_window_line_quotes_the_kernel_that_dominates():
+    """with the reference's pair window the pair stage outweighs detect+describe: the line's roofline is ransac_kernel's, against the
+    f32 vector peak, from the counted lane-operation formula (VERDICT r05 #7)"""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-host-frames",
+                        "--frames", "150", "--width", "640", "--height", "480", "--window", "182"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    rf = d["roofline"]
+    assert rf["kernel"].startswith("ransac_kernel") and rf["bound"] == "valu" and rf["unit"] == "TFLOP/s" and rf["peak"] == 78.65
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and 0 < rf["frac"] < 1
+    assert rf["us_per_pair"] > 0 and rf["lane_ops_per_pair_mean"] > 1e6
+    assert d["roofline_by_kernel"]["blur16_stream"]["bound"] == "valu" and d["mfma"]["kernel"] == "bf_match_kernel"

@@ -70,6 +70,49 @@ WORKER = textwrap.dedent("""
         assert np.array_equal(T1["m"].view(np.uint32), T2["m"].view(np.uint32))
         c1.close()
         print("DIST_GPU_OK", len(ref), len(racc))
+    # ---- results to ONE root (the rank that runs the unchanged driver), moments to every rank -------------------------------------------------
+    root_only = ex.allgather_results(results, len(pairs), accepted_only=True, root=1)
+    if rank == 1:
+        root_only = root_only[np.lexsort((root_only["j"], root_only["i"]))]
+        assert np.array_equal(root_only.view(np.uint8), acc.view(np.uint8)), "records gathered on the root differ from the all-gathered ones"
+    else:
+        assert len(root_only) == 0
+    # ---- frame ownership (SURVEY 8e primary form): a rank holds the frames it extracted; its stripes read the others' through the exchange ----
+    from tests.synth_survey import affine3
+    Hgt = np.stack([(np.linalg.inv(affine3(A[0])) @ affine3(A[k])).reshape(9) for k in range(F)]).astype(np.float32)
+    wv, hv, wsv = [w] * F, [h] * F, [ws] * F
+    held = [frames[k] if k %% world == rank else None for k in range(F)]
+    full_ptr = [frames[k].data_ptr() for k in range(F)]
+    # (a) MosaicImagesRefined stripes
+    cw, ch, cws, _ = im.mosaic_layout(wv, hv, Hgt)
+    stripes = [((ch * r) // world, (ch * (r + 1)) // world - (ch * r) // world) for r in range(world)]
+    need = ex.stripe_need(wv, hv, Hgt, stripes)
+    ptrs, br, bs = ex.exchange_frames(held, hv, wsv, need)
+    assert br > 0 and bs > 0, (br, bs)
+    assert all((p != 0) == bool(need[rank, k]) for k, p in enumerate(ptrs))
+    row0, rows = stripes[rank]
+    a = torch.zeros(ch * cws, dtype=torch.uint8, device="cuda"); b = torch.zeros(ch * cws, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    ctx.MosaicImagesRefinedDev(ptrs, wv, hv, wsv, Hgt, a.data_ptr(), cw, ch, cws, row0, rows)
+    ctx.MosaicImagesRefinedDev(full_ptr, wv, hv, wsv, Hgt, b.data_ptr(), cw, ch, cws, row0, rows)
+    ctx.synchronize()
+    assert torch.equal(a, b) and int(a.count_nonzero()) > 0, "refined stripe from owner-only frames + exchange differs from the replicas' stripe"
+    # (b) LaplacianPyramidBlending stripes (chips that reach the rows + the pyramids' reach)
+    keep = im.resample_by_overlap(wv, hv, Hgt, 0.7)
+    bw_, bh_, _ = im.blend_layout(wv, hv, Hgt, keep)
+    bstripes = [((bh_ * r) // world, (bh_ * (r + 1)) // world - (bh_ * r) // world) for r in range(world)]
+    bneed = ex.stripe_need(wv, hv, Hgt, bstripes, blended=True, keep=keep, band=5)
+    assert bneed[rank].sum() < keep.sum() or F < 4, "the blended stripe should not need every kept frame"
+    bptrs, bbr, bbs = ex.exchange_frames(held, hv, wsv, bneed)
+    br0, brows = bstripes[rank]
+    o1, _, _, _ = ctx.MosaicBlendedDev(bptrs, wv, hv, wsv, Hgt, keep=keep, band=5, row0=br0, rows=brows)
+    o2, _, _, _ = ctx.MosaicBlendedDev(full_ptr, wv, hv, wsv, Hgt, keep=keep, band=5, row0=br0, rows=brows)
+    assert torch.equal(o1, o2) and int(o1.count_nonzero()) > 0, "blended stripe from owner-only frames + exchange differs from the replicas' stripe"
+    tot = torch.tensor([br + bbr, bs + bbs], dtype=torch.int64)
+    dist.all_reduce(tot)
+    assert int(tot[0]) == int(tot[1])                     # every byte sent was received
+    if rank == 0:
+        print("FRAME_EXCHANGE_OK", int(tot[0]))
     dist.barrier()
     ctx.close()
     dist.destroy_process_group()
@@ -93,7 +136,7 @@ def test_two_ranks_one_survey_equals_single_rank(tmp_path):
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), str(script)]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
-    assert "DIST_GPU_OK" in r.stdout
+    assert "DIST_GPU_OK" in r.stdout and "FRAME_EXCHANGE_OK" in r.stdout
 
 
 def test_rccl_collectives_world1():
@@ -172,4 +215,122 @@ def test_compaction_of_accepted_records_keeps_order_at_every_size():
             bad = np.where((got[:k] != want).any(1))[0]
             raise AssertionError((n, p, len(bad), bad[:5].tolist(), bad[-3:].tolist(), [int(x) for x in np.where(got[bad[0]] != want[bad[0]])[0][:6]]))
         assert (got[k:] == 0xAB).all(), (n, p)                               # nothing written behind the accepted records
+    ctx.close()
+
+
+def test_stripe_cover_is_exactly_what_the_stripe_calls_read():
+    """mi355_mosaic_stripe_cover (the table mi355_exchange_frames is driven by): the stripe calls succeed and give the whole canvas's rows
+    with every frame OUTSIDE the cover withheld (pointer 0), and fail when a frame INSIDE it is withheld -- for the last-write-wins canvas
+    (MosaicWithoutPos.cpp:2194) and for the blended one (MosaicImage.cpp:2205), at several cuts"""
+    import torch
+    import imagemosaicing_amd as im
+    from tests.synth_survey import render_frames, affine3
+    ctx = im.Context(0)
+    w, h, F = 640, 480, 12
+    frames, A, gains, ws = render_frames(ctx, torch, F, w, h, per_row=4)
+    H = np.stack([(np.linalg.inv(affine3(A[0])) @ affine3(A[k])).reshape(9) for k in range(F)]).astype(np.float32)
+    H[5, 8] = 0.0                                                      # an invalid image (h.m[8] == 0) is never read
+    wv, hv, wsv = [w] * F, [h] * F, [ws] * F
+    full = [frames[k].data_ptr() for k in range(F)]
+    cw, ch, cws, _ = im.mosaic_layout(wv, hv, H)
+    whole = torch.zeros(ch * cws, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    ctx.MosaicImagesRefinedDev(full, wv, hv, wsv, H, whole.data_ptr(), cw, ch, cws)
+    ctx.synchronize()
+    whole = whole.reshape(ch, cws)
+    keep = im.resample_by_overlap(wv, hv, H, 0.7)
+    bwhole, bw_, bh_, bws_ = ctx.MosaicBlendedDev(full, wv, hv, wsv, H, keep=keep, band=5)
+    some_partial = False
+    for G in (2, 3, 5):
+        for r in range(G):
+            row0, rows = (ch * r) // G, (ch * (r + 1)) // G - (ch * r) // G
+            need = ctx.StripeCover(wv, hv, H, row0, rows)
+            assert need[5] == 0
+            some_partial |= bool(0 < need.sum() < F - 1)
+            ptrs = [full[k] if need[k] else 0 for k in range(F)]
+            out = torch.zeros(ch * cws, dtype=torch.uint8, device="cuda")
+            torch.cuda.synchronize()
+            ctx.MosaicImagesRefinedDev(ptrs, wv, hv, wsv, H, out.data_ptr(), cw, ch, cws, row0, rows)
+            ctx.synchronize()
+            assert torch.equal(out.reshape(ch, cws)[row0:row0 + rows], whole[row0:row0 + rows])
+            k_in = int(np.flatnonzero(need)[0])
+            ptrs[k_in] = 0
+            with pytest.raises(im.Mi355Error):
+                ctx.MosaicImagesRefinedDev(ptrs, wv, hv, wsv, H, out.data_ptr(), cw, ch, cws, row0, rows)
+            # blended
+            b0, brows = (bh_ * r) // G, (bh_ * (r + 1)) // G - (bh_ * r) // G
+            bneed = ctx.StripeCover(wv, hv, H, b0, brows, blended=True, keep=keep, band=5)
+            assert bneed[5] == 0 and all(bneed[k] == 0 for k in range(F) if not keep[k])
+            bp = [full[k] if bneed[k] else 0 for k in range(F)]
+            o, _, _, _ = ctx.MosaicBlendedDev(bp, wv, hv, wsv, H, keep=keep, band=5, row0=b0, rows=brows)
+            assert torch.equal(o, bwhole[b0:b0 + brows])
+            bp[int(np.flatnonzero(bneed)[-1])] = 0
+            with pytest.raises(im.Mi355Error):
+                ctx.MosaicBlendedDev(bp, wv, hv, wsv, H, keep=keep, band=5, row0=b0, rows=brows)
+    assert some_partial                                                 # the cuts really left frames out
+    ctx.close()
+
+
+def test_owner_only_frames_plus_exchange_equal_replicas_rccl_world1():
+    """mi355_exchange_frames on the C ABI's own communicator (one rank: RCCL cannot place two on one device): with
+    MI355_EXCHANGE_OWN_THROUGH_RCCL every frame the stripe reads goes through ncclSend / ncclRecv (to itself) into the ctx's landing area,
+    in groups, and the stripes rendered from the RECEIVED copies are the replicas' stripes byte for byte -- both canvases.  Also: a root
+    gather of the pair records (root = 0 of 1) equals the all-gather, and the library's pinned result buffer is reused, not reallocated."""
+    import torch
+    import imagemosaicing_amd as im
+    from imagemosaicing_amd import dist as md
+    from tests.synth_survey import render_frames, affine3
+    ctx = im.Context(0)
+    w, h, F = 640, 480, 70                                               # more than one group of 64 frames
+    frames, A, gains, ws = render_frames(ctx, torch, F, w, h, per_row=10)
+    H = np.stack([(np.linalg.inv(affine3(A[0])) @ affine3(A[k])).reshape(9) for k in range(F)]).astype(np.float32)
+    wv, hv, wsv = [w] * F, [h] * F, [ws] * F
+    full = [frames[k].data_ptr() for k in range(F)]
+    ex = md.Exchange(ctx, "rccl")
+    cw, ch, cws, _ = im.mosaic_layout(wv, hv, H)
+    row0, rows = ch // 3, ch // 2
+    need = ex.stripe_need(wv, hv, H, [(row0, rows)])
+    assert 0 < need.sum() < F
+    ptrs, br, bs = ex.exchange_frames([frames[k] for k in range(F)], hv, wsv, need, own_through_rccl=True)
+    assert br == 0 and bs == 0                                           # nothing crossed ranks ...
+    assert all((p != 0) == bool(need[0, k]) for k, p in enumerate(ptrs))
+    assert all(p != full[k] for k, p in enumerate(ptrs) if p)            # ... but every frame read is the copy ncclRecv delivered
+    a = torch.zeros(ch * cws, dtype=torch.uint8, device="cuda"); b = torch.zeros(ch * cws, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    ctx.MosaicImagesRefinedDev(ptrs, wv, hv, wsv, H, a.data_ptr(), cw, ch, cws, row0, rows)
+    ctx.MosaicImagesRefinedDev(full, wv, hv, wsv, H, b.data_ptr(), cw, ch, cws, row0, rows)
+    ctx.synchronize()
+    assert torch.equal(a, b) and int(a.count_nonzero()) > 0
+    keep = im.resample_by_overlap(wv, hv, H, 0.7)
+    bw_, bh_, _ = im.blend_layout(wv, hv, H, keep)
+    b0, brows = bh_ // 4, bh_ // 3
+    bneed = ex.stripe_need(wv, hv, H, [(b0, brows)], blended=True, keep=keep, band=5)
+    bp, _, _ = ex.exchange_frames([frames[k] for k in range(F)], hv, wsv, bneed, own_through_rccl=True)
+    o1, _, _, _ = ctx.MosaicBlendedDev(bp, wv, hv, wsv, H, keep=keep, band=5, row0=b0, rows=brows)
+    o2, _, _, _ = ctx.MosaicBlendedDev(full, wv, hv, wsv, H, keep=keep, band=5, row0=b0, rows=brows)
+    assert torch.equal(o1, o2) and int(o1.count_nonzero()) > 0
+    # without the flag the rank's own frames are handed back as they are
+    p2, _, _ = ex.exchange_frames([frames[k] for k in range(F)], hv, wsv, need)
+    assert all(p == (full[k] if need[0, k] else 0) for k, p in enumerate(p2))
+    # a rank that owns a frame it cannot produce fails before any transfer is posted
+    with pytest.raises(im.Mi355Error):
+        ex.exchange_frames([None] * F, hv, wsv, need)
+    # pair records: root gather == all-gather; the result lives in the ctx's pinned buffer (same address on the second call)
+    for k in range(8):
+        ctx.SiftExtractDev(k, frames[k].data_ptr(), w, h, ws)
+    pairs = im.pair_schedule(8, 182)
+    results = torch.zeros((len(pairs), im.PAIR_RESULT.itemsize), dtype=torch.uint8, device="cuda")
+    ctx.MatchPairsDev(pairs, results.data_ptr(), 2.5, 4)
+    ctx.synchronize()
+    r_all = ex.allgather_results(results, len(pairs), accepted_only=True)
+    v1 = ex.allgather_results(results, len(pairs), accepted_only=True, root=0, copy=False)
+    addr1 = v1.ctypes.data
+    assert len(r_all) > 0 and np.array_equal(v1.view(np.uint8), r_all.view(np.uint8))
+    v2 = ex.allgather_results(results, len(pairs), accepted_only=True, root=-1, copy=False)
+    assert v2.ctypes.data == addr1 and np.array_equal(v2.view(np.uint8), r_all.view(np.uint8))
+    with pytest.raises(im.Mi355Error):
+        ex.allgather_results(results, len(pairs), accepted_only=True, root=1)      # no such rank
+    m1 = ex.allgather_moments(results, len(pairs))
+    assert len(m1) == len(r_all) and np.array_equal(m1["i"], r_all["i"]) and np.array_equal(m1["n_in"], r_all["n_in"])
+    ex.close()
     ctx.close()
