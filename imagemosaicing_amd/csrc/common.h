@@ -30,7 +30,7 @@
 
 // grow-only device buffer (workspaces live as long as the ctx: no hipMalloc in steady state)
 constexpr int MI355_SIFT_BATCH_MAX = 32;      // frames per SIFT batch (per-frame pointers travel in kernel arguments)
-constexpr int MI355_SIFT_KEEPALL_MAX = 32768;  // keypoints per frame the feature record holds with nfeatures <= 0 (keep all); the matcher takes frames of <= 2048
+constexpr int MI355_SIFT_KEEPALL_MAX = 32768;  // keypoints per frame the feature record holds with nfeatures <= 0 (keep all); the matcher takes such frames in chunks of 2048 (match.hip, large-pair path)
 
 struct DevBuf {
     void*  p = nullptr;
@@ -200,7 +200,7 @@ int mi_select_grid(mi355_ctx*, const mi355_dmatch* sorted, int n, const float* k
                    int nMatch, int width, int height, int gx, int gy, mi355_sfpoint* v1, mi355_sfpoint* v2, int* n_out);
 int mi_set_features(mi355_ctx*, int img_id, const mi355_keypoint* kp, const float* desc, int n, int w, int h);
 int mi_finish_features(mi355_ctx*, Features& f, const int* d_n = nullptr, hipStream_t st = nullptr);
-int mi_finish_features_batch(mi355_ctx*, Features* const* fs, int nf, const int* d_n, int n_stride, hipStream_t st);   // all frames of a SIFT batch, one launch   // builds xy / int8 rows / norms from kp + d8 on device
+int mi_finish_features_batch(mi355_ctx*, Features* const* fs, int nf, const int* d_n, int n_stride, hipStream_t st, int max_rows = 2048);   // all frames of a SIFT batch, one launch   // builds xy / int8 rows / norms from kp + d8 on device
 int mi_resolve_features(mi355_ctx*);               // waits for in-flight SIFT frames and adopts their keypoint counts
 int mi_resolve_features_of(mi355_ctx*, const int* ids, int n);   // the same for the given frames only (waits for their batches' events)
 int mi_sift_extract_dev(mi355_ctx*, int img_id, const uint8_t* d_bgr, int w, int h, int ws, int* n_kp);

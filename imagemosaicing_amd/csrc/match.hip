@@ -32,7 +32,8 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 // load in flight turns every LDS wait into a wait for ALL memory.  Cast to the global address space: global_load, counted apart.
 #define GLOBAL_PTR(T, p) ((const __attribute__((address_space(1))) T*)(p))
 
-constexpr int KSTRIDE = 2048;        // per-pair stride of the nn arrays (>= nfeatures rounded up)
+constexpr int KSTRIDE = 2048;        // per-pair stride of the nn arrays (>= nfeatures rounded up); also the chunk size of the large-pair path
+constexpr int BIG_KP_MAX = MI355_SIFT_KEEPALL_MAX;   // keypoints per image the large-pair path takes (keep-all frames)
 constexpr int QTILE = 512;           // queries per workgroup (8 waves x 64): every staged train tile serves 512 queries
 constexpr int BF_NT = 512;           // threads per workgroup
 constexpr int ROWPAD = 256;          // descriptor matrices are padded to a multiple of this many rows (zeros)
@@ -203,6 +204,61 @@ __global__ __launch_bounds__(BF_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) v
 // ---- K7: sort by (d2, queryIdx) + grid walk -----------------------------------------------------------------
 struct SelectParams { int max_selected; double fraction; int gx, gy; float ratio2; };
 
+// The grid walk of SelectMatchPairs by ONE wave, 64 sorted matches per step (MosaicWithoutPos.cpp:4977-5028): key_at(i) = the i-th key of the
+// sorted list ((d2 << 32) | queryIdx), idx / d2 / d2nd the pair's 1-NN arrays indexed by query.  Shared by select_kernel (keys in LDS) and
+// select_big_kernel (keys in HBM); inlined into both, so the LDS form keeps its ds_ reads.
+template <class KeyAt>
+__device__ __forceinline__ void grid_walk(const PairDesc& pd, int M, KeyAt key_at, const int* idx, const int* d2v, const int* d2nd, const SelectParams& sp, int* s_label,
+                                          mi355_sfpoint* o1, mi355_sfpoint* o2, int* nsel_out, int lane) {
+    const int nGrids = sp.gx * sp.gy;
+    const double lim = sp.fraction * (double)M;                        // Min(400, 0.3*M) evaluated in double (:5146-5147)
+    const int nMatch = (int)((double)sp.max_selected < lim ? (double)sp.max_selected : lim);
+    const int perGrid = (int)((float)nMatch / (float)nGrids);                    // :4990
+    const int stepX = pd.width / sp.gx, stepY = pd.height / sp.gy;               // :4994-4995
+    if (lane < 64) s_label[lane] = 0;
+    int count = 0;
+    for (int base = 0; base < M; base += 64) {
+        const int i = base + lane;
+        bool valid = i < M;
+        int q = 0, t = 0, cell = 0; float x = 0.0f, y = 0.0f;
+        if (valid) {
+            q = (int)(unsigned)(key_at(i) & 0xffffffffull);
+            t = idx[q];
+            const float2 pxy = pd.xy_i[q];
+            x = pxy.x; y = pxy.y;
+            const int nX = (int)(x / (float)stepX), nY = (int)(y / (float)stepY);      // :5008-5009
+            cell = sp.gx * nY + nX;                       // aliases into the next row when nX == gridX, like the reference
+            if (cell < 0) cell = 0;
+            if (cell >= nGrids) cell = nGrids - 1;        // the reference would index label[] out of bounds here
+            if (sp.ratio2 > 0.0f) {                       // optional Lowe ratio test (north_star), squared distances
+                const float d1 = (float)d2v[q], dd2 = (float)d2nd[q];
+                if (!(d1 < sp.ratio2 * dd2)) valid = false;
+            }
+        }
+        bool keep = false;
+        for (int cc = 0; cc < nGrids; cc++) {
+            const unsigned long long m = __ballot(valid && cell == cc);
+            if (m == 0) continue;
+            const int lab = s_label[cc];
+            const int rank = __popcll(m & ((1ull << lane) - 1ull));
+            if (valid && cell == cc && lab + rank < perGrid) keep = true;
+            int add = __popcll(m);
+            const int room = perGrid - lab;
+            if (add > room) add = room > 0 ? room : 0;
+            if (lane == 0) s_label[cc] = lab + add;
+        }
+        const unsigned long long km = __ballot(keep);
+        const int pos = count + __popcll(km & ((1ull << lane) - 1ull));
+        if (keep && pos < MI355_MAX_SELECTED) {
+            const float2 p2 = pd.xy_j[t];
+            o1[pos].x = x; o1[pos].y = y; o1[pos].id = q;
+            o2[pos].x = p2.x; o2[pos].y = p2.y; o2[pos].id = t;
+        }
+        count += __popcll(km);
+    }
+    if (lane == 0) *nsel_out = count < MI355_MAX_SELECTED ? count : MI355_MAX_SELECTED;
+}
+
 __global__ __launch_bounds__(256) void select_kernel(const PairDesc* pairs, const int* nn_idx, const int* nn_d2, const int* nn_2nd,
                                                      SelectParams sp, mi355_sfpoint* sel1, mi355_sfpoint* sel2, int* nsel,
                                                      unsigned long long* sorted_keys /* optional [pair][KSTRIDE] */) {
@@ -231,57 +287,65 @@ __global__ __launch_bounds__(256) void select_kernel(const PairDesc* pairs, cons
     }
     if (sorted_keys) for (int i = tid; i < KSTRIDE; i += 256) sorted_keys[o + i] = key[i];
     if (tid >= 64) return;
-    // grid walk by one wave, 64 sorted matches per step (MosaicWithoutPos.cpp:4977-5028)
-    const int lane = tid;
-    const int nGrids = sp.gx * sp.gy;
-    const double lim = sp.fraction * (double)M;                        // Min(400, 0.3*M) evaluated in double (:5146-5147)
-    const int nMatch = (int)((double)sp.max_selected < lim ? (double)sp.max_selected : lim);
-    const int perGrid = (int)((float)nMatch / (float)nGrids);                    // :4990
-    const int stepX = pd.width / sp.gx, stepY = pd.height / sp.gy;               // :4994-4995
-    if (lane < 64) s_label[lane] = 0;
-    int count = 0;
-    mi355_sfpoint* o1 = sel1 + (size_t)pair * MI355_MAX_SELECTED;
-    mi355_sfpoint* o2 = sel2 + (size_t)pair * MI355_MAX_SELECTED;
-    for (int base = 0; base < M; base += 64) {
-        const int i = base + lane;
-        bool valid = i < M;
-        int q = 0, t = 0, cell = 0; float x = 0.0f, y = 0.0f;
-        if (valid) {
-            q = (int)(unsigned)(key[i] & 0xffffffffull);
-            t = nn_idx[o + q];
-            const float2 pxy = pd.xy_i[q];
-            x = pxy.x; y = pxy.y;
-            const int nX = (int)(x / (float)stepX), nY = (int)(y / (float)stepY);      // :5008-5009
-            cell = sp.gx * nY + nX;                       // aliases into the next row when nX == gridX, like the reference
-            if (cell < 0) cell = 0;
-            if (cell >= nGrids) cell = nGrids - 1;        // the reference would index label[] out of bounds here
-            if (sp.ratio2 > 0.0f) {                       // optional Lowe ratio test (north_star), squared distances
-                const float d1 = (float)nn_d2[o + q], d2 = (float)nn_2nd[o + q];
-                if (!(d1 < sp.ratio2 * d2)) valid = false;
-            }
+    grid_walk(pd, M, [&](int i) { return key[i]; }, nn_idx + o, nn_d2 + o, nn_2nd + o, sp, s_label, sel1 + (size_t)pair * MI355_MAX_SELECTED, sel2 + (size_t)pair * MI355_MAX_SELECTED, nsel + pair, tid);
+}
+
+// ---- more than 2048 keypoints per image ---------------------------------------------------------------------------------------------
+// The reference's committed run kept EVERY keypoint (nfeatures = 0: ids up to 3130 in matchPairs.match) and its j-loop takes any M
+// (MosaicWithoutPos.cpp:5108-5153: nMatch = Min(400, 0.3 M)).  The live path (nfeatures 2000) never gets here; a pair with a larger image
+// goes through the same kernels in pieces: bf_match_kernel on (query chunk, train chunk) sub-pairs of <= 2048 x 2048 -- every sub-pair is a
+// PairDesc whose pointers start at its chunks --, merge_chunks_kernel takes each query's nearest over the train chunks (ties -> the lowest
+// train index: the earliest chunk, and inside a chunk the kernel already keeps the lowest), select_big_kernel sorts the M keys
+// (d2, queryIdx) in HBM -- one workgroup, bitonic over the next power of two -- and walks the grid with the very code of select_kernel.
+struct BigPairDev { int n_i, n_j, tc_n, sub0; long long off, koff; int mpad, _pad; };
+
+__global__ __launch_bounds__(256) void merge_chunks_kernel(const BigPairDev* bp, const int* nn_idx, const int* nn_d2, const int* nn_2nd, int second,
+                                                           int* m_idx, int* m_d2, int* m_2nd) {
+    const BigPairDev b = bp[blockIdx.y];
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= b.n_i) return;
+    const int qc = q / KSTRIDE, ql = q - qc * KSTRIDE;
+    int best_d = 0x7fffffff, best_i = -1, sec = 0x7fffffff;
+    for (int tc = 0; tc < b.tc_n; tc++) {
+        const size_t o = (size_t)(b.sub0 + qc * b.tc_n + tc) * KSTRIDE + ql;
+        const int i = nn_idx[o], d = nn_d2[o];
+        if (i >= 0) {
+            if (d < best_d) { sec = sec < best_d ? sec : best_d; best_d = d; best_i = i + tc * KSTRIDE; }
+            else sec = sec < d ? sec : d;
         }
-        bool keep = false;
-        for (int cc = 0; cc < nGrids; cc++) {
-            const unsigned long long m = __ballot(valid && cell == cc);
-            if (m == 0) continue;
-            const int lab = s_label[cc];
-            const int rank = __popcll(m & ((1ull << lane) - 1ull));
-            if (valid && cell == cc && lab + rank < perGrid) keep = true;
-            int add = __popcll(m);
-            const int room = perGrid - lab;
-            if (add > room) add = room > 0 ? room : 0;
-            if (lane == 0) s_label[cc] = lab + add;
-        }
-        const unsigned long long km = __ballot(keep);
-        const int pos = count + __popcll(km & ((1ull << lane) - 1ull));
-        if (keep && pos < MI355_MAX_SELECTED) {
-            const float2 p2 = pd.xy_j[t];
-            o1[pos].x = x; o1[pos].y = y; o1[pos].id = q;
-            o2[pos].x = p2.x; o2[pos].y = p2.y; o2[pos].id = t;
-        }
-        count += __popcll(km);
+        if (second) { const int s2 = nn_2nd[o]; sec = sec < s2 ? sec : s2; }
     }
-    if (lane == 0) nsel[pair] = count < MI355_MAX_SELECTED ? count : MI355_MAX_SELECTED;
+    m_idx[b.off + q] = best_i; m_d2[b.off + q] = best_d; m_2nd[b.off + q] = sec;
+}
+
+__global__ __launch_bounds__(1024) void select_big_kernel(const PairDesc* pairs, const BigPairDev* bp, const int* m_idx, const int* m_d2, const int* m_2nd,
+                                                          SelectParams sp, unsigned long long* keys, mi355_sfpoint* sel1, mi355_sfpoint* sel2, int* nsel) {
+    __shared__ int s_label[64];
+    const int pair = blockIdx.x, tid = threadIdx.x;
+    const PairDesc pd = pairs[pair];
+    const BigPairDev b = bp[pair];
+    const int M = (pd.n_j > 0) ? pd.n_i : 0;
+    unsigned long long* key = keys + b.koff;
+    const int* d2 = m_d2 + b.off;
+    for (int i = tid; i < b.mpad; i += 1024)
+        key[i] = (i < M) ? (((unsigned long long)(unsigned)d2[i] << 32) | (unsigned)i) : ~0ull;
+    __syncthreads();
+    // bitonic sort in HBM by the one workgroup (all its waves share the CU's cache: a barrier orders the passes)
+    for (int k = 2; k <= b.mpad; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < b.mpad; i += 1024) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const unsigned long long a = key[i], c = key[ixj];
+                    const bool up = (i & k) == 0;
+                    if ((a > c) == up) { key[i] = c; key[ixj] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    if (tid >= 64) return;
+    grid_walk(pd, M, [&](int i) { return key[i]; }, m_idx + b.off, d2, m_2nd + b.off, sp, s_label, sel1 + (size_t)pair * MI355_MAX_SELECTED, sel2 + (size_t)pair * MI355_MAX_SELECTED, nsel + pair, tid);
 }
 
 __global__ void finalize_kernel(const PairDesc* pairs, const int* nsel, int n_pairs, int min_inliers, mi355_pair_result* out) {
@@ -372,7 +436,8 @@ int build_pair_table(mi355_ctx* ctx, const int32_t* pairs, int n_pairs, std::vec
         auto fi = ctx->feats.find(i), fj = ctx->feats.find(j);
         if (fi == ctx->feats.end() || fj == ctx->feats.end()) { ctx->set_error("match_pairs: no resident features for image " + std::to_string(fi == ctx->feats.end() ? i : j)); return MI355_ERR_ARG; }
         const Features &a = fi->second, &b = fj->second;
-        if (a.n > KSTRIDE || b.n > KSTRIDE) { ctx->set_error("match_pairs: more than 2048 keypoints per image"); return MI355_ERR_ARG; }
+        if (a.n > BIG_KP_MAX || b.n > BIG_KP_MAX) { ctx->set_error("match_pairs: more than 32768 keypoints per image"); return MI355_ERR_ARG; }
+        if ((a.n > KSTRIDE && a.npad < a.n) || (b.n > KSTRIDE && b.npad < b.n)) { ctx->set_error("match_pairs: the matcher's operands of a large image are incomplete"); return MI355_ERR_ARG; }
         PairDesc& d = pd[p];
         d.s8_i = a.s8.as<int8_t>(); d.n8_i = a.n8.as<int>(); d.xy_i = a.xy.as<float2>(); d.n_i = a.n; d.npad_i = a.npad;
         d.s8_j = b.s8.as<int8_t>(); d.n8_j = b.n8.as<int>(); d.xy_j = b.xy.as<float2>(); d.n_j = b.n; d.npad_j = b.npad;
@@ -399,16 +464,17 @@ int mi_finish_features(mi355_ctx* ctx, Features& f, const int* d_n, hipStream_t 
 }
 
 // the matcher's operands of all frames of a SIFT batch; the keypoint counts are still on the device (d_n[k * n_stride])
-int mi_finish_features_batch(mi355_ctx* ctx, Features* const* fs, int nf, const int* d_n, int n_stride, hipStream_t st) {
+int mi_finish_features_batch(mi355_ctx* ctx, Features* const* fs, int nf, const int* d_n, int n_stride, hipStream_t st, int max_rows) {
     if (nf <= 0) return MI355_OK;
     if (nf > MI355_SIFT_BATCH_MAX) return MI355_ERR_ARG;
+    if (max_rows < KSTRIDE) max_rows = KSTRIDE;          // keep-all frames (nfeatures <= 0) carry up to MI355_SIFT_KEEPALL_MAX rows: the large-pair path reads them all
     FinishBatch fb;
     memset(&fb, 0, sizeof(fb));
-    const int npad = ((KSTRIDE + ROWPAD - 1) / ROWPAD) * ROWPAD;
+    const int npad = ((max_rows + ROWPAD - 1) / ROWPAD) * ROWPAD;
     for (int k = 0; k < nf; k++) {
         Features& f = *fs[k];
         f.npad = npad;
-        MI_HIP(f.xy.reserve(sizeof(float2) * (size_t)KSTRIDE));
+        MI_HIP(f.xy.reserve(sizeof(float2) * (size_t)max_rows));
         MI_HIP(f.s8.reserve((size_t)128 * (size_t)npad));
         MI_HIP(f.n8.reserve(sizeof(int) * (size_t)npad));
         fb.kp[k] = f.kp.as<mi355_keypoint>(); fb.d8[k] = f.d8.as<uint8_t>();
@@ -421,7 +487,7 @@ int mi_finish_features_batch(mi355_ctx* ctx, Features* const* fs, int nf, const 
 }
 
 int mi_set_features(mi355_ctx* ctx, int img_id, const mi355_keypoint* kp, const float* desc, int n, int w, int h) {
-    if (n < 0 || n > KSTRIDE || (n > 0 && (!kp || !desc)) || w <= 0 || h <= 0) { ctx->set_error("set_features: bad arguments (n must be <= 2048)"); return MI355_ERR_ARG; }
+    if (n < 0 || n > BIG_KP_MAX || (n > 0 && (!kp || !desc)) || w <= 0 || h <= 0) { ctx->set_error("set_features: bad arguments (n must be <= 32768)"); return MI355_ERR_ARG; }
     (void)mi_resolve_features(ctx);
     Features& f = ctx->feats[img_id];
     f.n = n; f.w = w; f.h = h; f.pending = false;
@@ -505,6 +571,78 @@ static int run_match_select(mi355_ctx* ctx, const std::vector<PairDesc>& pd, int
     return MI355_OK;
 }
 
+// The large-pair form of run_match_select (an image of the pair has more than 2048 keypoints): same outputs -- sel1 / sel2 / nsel by pair of the
+// run, "pair_desc" for finalize_kernel -- through the sub-pair decomposition described at merge_chunks_kernel.  The merged 1-NN arrays stay in
+// "nnb_idx" / "nnb_d2" / "nnb_2nd" at off[p] and the sorted keys in "sorted_keys_big" at koff[p] (mi_bf_match reads them back).
+static int run_match_select_big(mi355_ctx* ctx, const std::vector<PairDesc>& pd, int n_pairs, bool want_second, std::vector<BigPairDev>* layout_out = nullptr) {
+    std::vector<BigPairDev> bp(n_pairs);
+    std::vector<PairDesc> sub;
+    long long off = 0, koff = 0;
+    int max_ni = 1;
+    for (int p = 0; p < n_pairs; p++) {
+        const PairDesc& d = pd[p];
+        const int qc_n = d.n_i > 0 ? (d.n_i + KSTRIDE - 1) / KSTRIDE : 1, tc_n = d.n_j > 0 ? (d.n_j + KSTRIDE - 1) / KSTRIDE : 1;
+        BigPairDev& b = bp[p];
+        b.n_i = d.n_i; b.n_j = d.n_j; b.tc_n = tc_n; b.sub0 = (int)sub.size(); b.off = off; b.koff = koff; b._pad = 0;
+        int mp = 64; while (mp < d.n_i) mp <<= 1;
+        b.mpad = mp;
+        off += d.n_i > 0 ? d.n_i : 1; koff += mp;
+        if (d.n_i > max_ni) max_ni = d.n_i;
+        for (int qc = 0; qc < qc_n; qc++)
+            for (int tc = 0; tc < tc_n; tc++) {
+                PairDesc s = d;
+                const int q0 = qc * KSTRIDE, t0 = tc * KSTRIDE;
+                s.s8_i = d.s8_i + (size_t)q0 * 128; s.n8_i = d.n8_i + q0; s.xy_i = d.xy_i + q0;
+                s.n_i = d.n_i - q0 < KSTRIDE ? (d.n_i - q0 > 0 ? d.n_i - q0 : 0) : KSTRIDE;
+                s.npad_i = ((s.n_i + ROWPAD - 1) / ROWPAD) * ROWPAD; if (s.npad_i == 0) s.npad_i = ROWPAD;
+                s.s8_j = d.s8_j + (size_t)t0 * 128; s.n8_j = d.n8_j + t0; s.xy_j = d.xy_j + t0;
+                s.n_j = d.n_j - t0 < KSTRIDE ? (d.n_j - t0 > 0 ? d.n_j - t0 : 0) : KSTRIDE;
+                s.npad_j = ((s.n_j + ROWPAD - 1) / ROWPAD) * ROWPAD; if (s.npad_j == 0) s.npad_j = ROWPAD;
+                sub.push_back(s);
+            }
+    }
+    const int nsub = (int)sub.size();
+    DevBuf& dpd = ctx->buf("pair_desc"); DevBuf& dsub = ctx->buf("pair_desc_sub"); DevBuf& dbp = ctx->buf("big_pairs");
+    DevBuf& didx = ctx->buf("nn_idx"); DevBuf& dd2 = ctx->buf("nn_d2"); DevBuf& d2nd = ctx->buf("nn_2nd");
+    DevBuf& midx = ctx->buf("nnb_idx"); DevBuf& md2 = ctx->buf("nnb_d2"); DevBuf& m2nd = ctx->buf("nnb_2nd"); DevBuf& dkeys = ctx->buf("sorted_keys_big");
+    DevBuf& ds1 = ctx->buf("sel1"); DevBuf& ds2 = ctx->buf("sel2"); DevBuf& dns = ctx->buf("nsel");
+    const size_t nn = (size_t)nsub * KSTRIDE;
+    MI_HIP(dpd.reserve(sizeof(PairDesc) * n_pairs)); MI_HIP(dsub.reserve(sizeof(PairDesc) * nsub)); MI_HIP(dbp.reserve(sizeof(BigPairDev) * n_pairs));
+    MI_HIP(didx.reserve(nn * 4)); MI_HIP(dd2.reserve(nn * 4)); MI_HIP(d2nd.reserve(nn * 4));
+    MI_HIP(midx.reserve((size_t)off * 4)); MI_HIP(md2.reserve((size_t)off * 4)); MI_HIP(m2nd.reserve((size_t)off * 4)); MI_HIP(dkeys.reserve((size_t)koff * 8));
+    MI_HIP(ds1.reserve(sizeof(mi355_sfpoint) * MI355_MAX_SELECTED * (size_t)n_pairs));
+    MI_HIP(ds2.reserve(sizeof(mi355_sfpoint) * MI355_MAX_SELECTED * (size_t)n_pairs));
+    MI_HIP(dns.reserve(sizeof(int) * n_pairs));
+    MI_HIP(hipMemcpyAsync(dpd.p, pd.data(), sizeof(PairDesc) * n_pairs, hipMemcpyHostToDevice, ctx->stream));
+    MI_HIP(hipMemcpyAsync(dsub.p, sub.data(), sizeof(PairDesc) * nsub, hipMemcpyHostToDevice, ctx->stream));
+    MI_HIP(hipMemcpyAsync(dbp.p, bp.data(), sizeof(BigPairDev) * n_pairs, hipMemcpyHostToDevice, ctx->stream));
+    MI_HIP(hipStreamSynchronize(ctx->stream));           // the host vectors are locals
+    const bool second = want_second || ctx->p.ratio > 0.0f;
+    {
+        double bytes = 0.0;
+        for (const PairDesc& q : sub) bytes += (double)(q.npad_i + q.npad_j) * 128.0 + 8.0 * q.n_i;
+        ProfScope ps(ctx, "match", bytes);
+        const int nqt = KSTRIDE / QTILE;
+        if (second) hipLaunchKernelGGL(bf_match_kernel<true>, dim3((unsigned)nqt * (unsigned)nsub), dim3(BF_NT), 0, ctx->stream, dsub.as<PairDesc>(), nqt, didx.as<int>(), dd2.as<int>(), d2nd.as<int>());
+        else hipLaunchKernelGGL(bf_match_kernel<false>, dim3((unsigned)nqt * (unsigned)nsub), dim3(BF_NT), 0, ctx->stream, dsub.as<PairDesc>(), nqt, didx.as<int>(), dd2.as<int>(), d2nd.as<int>());
+        hipLaunchKernelGGL(merge_chunks_kernel, dim3((max_ni + 255) / 256, n_pairs), dim3(256), 0, ctx->stream, dbp.as<BigPairDev>(), didx.as<int>(), dd2.as<int>(), d2nd.as<int>(), second ? 1 : 0,
+                           midx.as<int>(), md2.as<int>(), m2nd.as<int>());
+    }
+    SelectParams sp;
+    sp.max_selected = ctx->p.max_selected; sp.fraction = ctx->p.select_fraction; sp.gx = ctx->p.grid_x; sp.gy = ctx->p.grid_y;
+    sp.ratio2 = ctx->p.ratio > 0.0f ? ctx->p.ratio * ctx->p.ratio : 0.0f;
+    {
+        ProfScope ps(ctx, "select", (double)koff * 8.0);
+        hipLaunchKernelGGL(select_big_kernel, dim3(n_pairs), dim3(1024), 0, ctx->stream, dpd.as<PairDesc>(), dbp.as<BigPairDev>(), midx.as<int>(), md2.as<int>(), m2nd.as<int>(), sp,
+                           dkeys.as<unsigned long long>(), ds1.as<mi355_sfpoint>(), ds2.as<mi355_sfpoint>(), dns.as<int>());
+    }
+    MI_HIP(hipGetLastError());
+    if (layout_out) *layout_out = bp;
+    return MI355_OK;
+}
+
+static bool pair_is_big(const PairDesc& d) { return d.n_i > KSTRIDE || d.n_j > KSTRIDE; }
+
 int mi_match_pairs_dev(mi355_ctx* ctx, const int32_t* pairs, int n_pairs, float dist, uint32_t seed, mi355_pair_result* d_out) {
     if (n_pairs <= 0) return MI355_OK;
     if (!pairs || !d_out) return MI355_ERR_ARG;
@@ -516,15 +654,28 @@ int mi_match_pairs_dev(mi355_ctx* ctx, const int32_t* pairs, int n_pairs, float 
         const int nb = (n_pairs - b0) < BATCH ? (n_pairs - b0) : BATCH;
         int rc = build_pair_table(ctx, pairs + 2 * b0, nb, pd);
         if (rc != MI355_OK) return rc;
-        rc = run_match_select(ctx, pd, nb, false);
-        if (rc != MI355_OK) return rc;
-        rc = mi_ransac_batch(ctx, ctx->buf("sel1").as<mi355_sfpoint>(), ctx->buf("sel2").as<mi355_sfpoint>(), ctx->buf("nsel").as<int>(), nullptr,
-                             nb, MI355_MAX_SELECTED, dist, ctx->p.sample_times, seed, d_out + b0, ctx->p.min_inliers);
-        if (rc != MI355_OK) return rc;
-        hipLaunchKernelGGL(finalize_kernel, dim3((nb + 255) / 256), dim3(256), 0, ctx->stream, ctx->buf("pair_desc").as<PairDesc>(), ctx->buf("nsel").as<int>(),
-                           nb, ctx->p.min_inliers, d_out + b0);
-        MI_HIP(hipGetLastError());
-        if (b0 + BATCH < n_pairs) MI_HIP(hipStreamSynchronize(ctx->stream));     // workspaces are reused by the next batch
+        // maximal runs of pairs of one kind: the live path (every image <= 2048 keypoints) is ONE run per batch, exactly as before; a pair with
+        // a larger image (keep-all frames) goes through the large-pair form, at most 256 of them at a time (each may hold 256 sub-pairs)
+        for (int r0 = 0; r0 < nb;) {
+            const bool big = pair_is_big(pd[r0]);
+            int r1 = r0 + 1;
+            while (r1 < nb && pair_is_big(pd[r1]) == big && (!big || r1 - r0 < 256)) r1++;
+            const int nr = r1 - r0;
+            if (r0 == 0 && nr == nb && !big) rc = run_match_select(ctx, pd, nb, false);
+            else {
+                const std::vector<PairDesc> run(pd.begin() + r0, pd.begin() + r1);
+                rc = big ? run_match_select_big(ctx, run, nr, false) : run_match_select(ctx, run, nr, false);
+            }
+            if (rc != MI355_OK) return rc;
+            rc = mi_ransac_batch(ctx, ctx->buf("sel1").as<mi355_sfpoint>(), ctx->buf("sel2").as<mi355_sfpoint>(), ctx->buf("nsel").as<int>(), nullptr,
+                                 nr, MI355_MAX_SELECTED, dist, ctx->p.sample_times, seed, d_out + b0 + r0, ctx->p.min_inliers);
+            if (rc != MI355_OK) return rc;
+            hipLaunchKernelGGL(finalize_kernel, dim3((nr + 255) / 256), dim3(256), 0, ctx->stream, ctx->buf("pair_desc").as<PairDesc>(), ctx->buf("nsel").as<int>(),
+                               nr, ctx->p.min_inliers, d_out + b0 + r0);
+            MI_HIP(hipGetLastError());
+            if (r1 < nb || b0 + BATCH < n_pairs) MI_HIP(hipStreamSynchronize(ctx->stream));     // workspaces are reused by the next run / batch
+            r0 = r1;
+        }
     }
     return MI355_OK;
 }
@@ -534,15 +685,17 @@ int mi_bf_match(mi355_ctx* ctx, int img_i, int img_j, int sorted, mi355_dmatch* 
     std::vector<PairDesc> pd;
     int rc = build_pair_table(ctx, pr, 1, pd);
     if (rc != MI355_OK) return rc;
-    rc = run_match_select(ctx, pd, 1, true);
+    const bool big = pair_is_big(pd[0]);
+    rc = big ? run_match_select_big(ctx, pd, 1, true) : run_match_select(ctx, pd, 1, true);
     if (rc != MI355_OK) return rc;
     const int M = pd[0].n_j > 0 ? pd[0].n_i : 0;
-    std::vector<int> idx(KSTRIDE), dd(KSTRIDE), d2nd(KSTRIDE);
-    std::vector<unsigned long long> keys(KSTRIDE);
-    MI_HIP(hipMemcpyAsync(idx.data(), ctx->buf("nn_idx").p, KSTRIDE * 4, hipMemcpyDeviceToHost, ctx->stream));
-    MI_HIP(hipMemcpyAsync(dd.data(), ctx->buf("nn_d2").p, KSTRIDE * 4, hipMemcpyDeviceToHost, ctx->stream));
-    MI_HIP(hipMemcpyAsync(d2nd.data(), ctx->buf("nn_2nd").p, KSTRIDE * 4, hipMemcpyDeviceToHost, ctx->stream));
-    MI_HIP(hipMemcpyAsync(keys.data(), ctx->buf("sorted_keys").p, KSTRIDE * 8, hipMemcpyDeviceToHost, ctx->stream));
+    const size_t K = big ? (size_t)(M > 0 ? M : 1) : (size_t)KSTRIDE;        // the large-pair form keeps one pair at offset 0 of its merged arrays
+    std::vector<int> idx(K), dd(K), d2nd(K);
+    std::vector<unsigned long long> keys(K);
+    MI_HIP(hipMemcpyAsync(idx.data(), ctx->buf(big ? "nnb_idx" : "nn_idx").p, K * 4, hipMemcpyDeviceToHost, ctx->stream));
+    MI_HIP(hipMemcpyAsync(dd.data(), ctx->buf(big ? "nnb_d2" : "nn_d2").p, K * 4, hipMemcpyDeviceToHost, ctx->stream));
+    MI_HIP(hipMemcpyAsync(d2nd.data(), ctx->buf(big ? "nnb_2nd" : "nn_2nd").p, K * 4, hipMemcpyDeviceToHost, ctx->stream));
+    MI_HIP(hipMemcpyAsync(keys.data(), ctx->buf(big ? "sorted_keys_big" : "sorted_keys").p, K * 8, hipMemcpyDeviceToHost, ctx->stream));
     MI_HIP(hipStreamSynchronize(ctx->stream));
     const int n = M < maxm ? M : maxm;
     for (int k = 0; k < n; k++) {
@@ -558,11 +711,13 @@ int mi_bf_match(mi355_ctx* ctx, int img_i, int img_j, int sorted, mi355_dmatch* 
 // stand-alone SelectMatchPairs: host arrays in, the same select kernel on one synthetic "pair"
 int mi_select_grid(mi355_ctx* ctx, const mi355_dmatch* sorted, int n, const float* kp1, int nk1, const float* kp2, int nk2,
                    int nMatch, int width, int height, int gx, int gy, mi355_sfpoint* v1, mi355_sfpoint* v2, int* n_out) {
-    if (n < 0 || n > KSTRIDE || !kp1 || !kp2 || !v1 || !v2 || !n_out || gx < 1 || gy < 1 || gx * gy > 64 || width < gx || height < gy) { ctx->set_error("select_grid: bad arguments"); return MI355_ERR_ARG; }
+    if (n < 0 || n > BIG_KP_MAX || !kp1 || !kp2 || !v1 || !v2 || !n_out || gx < 1 || gy < 1 || gx * gy > 64 || width < gx || height < gy) { ctx->set_error("select_grid: bad arguments (at most 32768 matches)"); return MI355_ERR_ARG; }
     // The kernel sorts by (d2, queryIdx); feed it ranks so that the given order is kept: d2 := position.
     // Queries are remapped to 0..n-1 in the given order (x/y/id carried through).
+    const bool big = n > KSTRIDE;                           // more matches than select_kernel's LDS list holds: the large-pair form (keys sorted in HBM)
+    const size_t K = big ? (size_t)n : (size_t)KSTRIDE;
     std::vector<float2> xy1(n > 0 ? n : 1), xy2(n > 0 ? n : 1);
-    std::vector<int> idx(KSTRIDE, 0), dd(KSTRIDE, 0), d2nd(KSTRIDE, 0);
+    std::vector<int> idx(K, 0), dd(K, 0), d2nd(K, 0);
     for (int k = 0; k < n; k++) {
         const int q = sorted[k].queryIdx, t = sorted[k].trainIdx;
         if (q < 0 || q >= nk1 || t < 0 || t >= nk2) { ctx->set_error("select_grid: match index out of range"); return MI355_ERR_ARG; }
@@ -571,10 +726,10 @@ int mi_select_grid(mi355_ctx* ctx, const mi355_dmatch* sorted, int n, const floa
         idx[k] = k; dd[k] = k;
     }
     DevBuf& dx1 = ctx->buf("sg_xy1"); DevBuf& dx2 = ctx->buf("sg_xy2");
-    DevBuf& dpd = ctx->buf("pair_desc"); DevBuf& didx = ctx->buf("nn_idx"); DevBuf& dd2 = ctx->buf("nn_d2"); DevBuf& d2n = ctx->buf("nn_2nd");
+    DevBuf& dpd = ctx->buf("pair_desc"); DevBuf& didx = ctx->buf(big ? "nnb_idx" : "nn_idx"); DevBuf& dd2 = ctx->buf(big ? "nnb_d2" : "nn_d2"); DevBuf& d2n = ctx->buf(big ? "nnb_2nd" : "nn_2nd");
     DevBuf& ds1 = ctx->buf("sel1"); DevBuf& ds2 = ctx->buf("sel2"); DevBuf& dns = ctx->buf("nsel");
     MI_HIP(dx1.reserve(sizeof(float2) * xy1.size())); MI_HIP(dx2.reserve(sizeof(float2) * xy2.size()));
-    MI_HIP(dpd.reserve(sizeof(PairDesc))); MI_HIP(didx.reserve(KSTRIDE * 4)); MI_HIP(dd2.reserve(KSTRIDE * 4)); MI_HIP(d2n.reserve(KSTRIDE * 4));
+    MI_HIP(dpd.reserve(sizeof(PairDesc))); MI_HIP(didx.reserve(K * 4)); MI_HIP(dd2.reserve(K * 4)); MI_HIP(d2n.reserve(K * 4));
     MI_HIP(ds1.reserve(sizeof(mi355_sfpoint) * MI355_MAX_SELECTED)); MI_HIP(ds2.reserve(sizeof(mi355_sfpoint) * MI355_MAX_SELECTED)); MI_HIP(dns.reserve(sizeof(int)));
     PairDesc pd;
     memset(&pd, 0, sizeof(pd));
@@ -582,14 +737,25 @@ int mi_select_grid(mi355_ctx* ctx, const mi355_dmatch* sorted, int n, const floa
     MI_HIP(hipMemcpyAsync(dx1.p, xy1.data(), sizeof(float2) * xy1.size(), hipMemcpyHostToDevice, ctx->stream));
     MI_HIP(hipMemcpyAsync(dx2.p, xy2.data(), sizeof(float2) * xy2.size(), hipMemcpyHostToDevice, ctx->stream));
     MI_HIP(hipMemcpyAsync(dpd.p, &pd, sizeof(pd), hipMemcpyHostToDevice, ctx->stream));
-    MI_HIP(hipMemcpyAsync(didx.p, idx.data(), KSTRIDE * 4, hipMemcpyHostToDevice, ctx->stream));
-    MI_HIP(hipMemcpyAsync(dd2.p, dd.data(), KSTRIDE * 4, hipMemcpyHostToDevice, ctx->stream));
-    MI_HIP(hipMemcpyAsync(d2n.p, d2nd.data(), KSTRIDE * 4, hipMemcpyHostToDevice, ctx->stream));
+    MI_HIP(hipMemcpyAsync(didx.p, idx.data(), K * 4, hipMemcpyHostToDevice, ctx->stream));
+    MI_HIP(hipMemcpyAsync(dd2.p, dd.data(), K * 4, hipMemcpyHostToDevice, ctx->stream));
+    MI_HIP(hipMemcpyAsync(d2n.p, d2nd.data(), K * 4, hipMemcpyHostToDevice, ctx->stream));
     // nMatch is given by the caller here: choose (max_selected, fraction) that reproduce it: min(nMatch, 1.0*M)
     SelectParams sp;
     sp.max_selected = nMatch; sp.fraction = 1e9; sp.gx = gx; sp.gy = gy; sp.ratio2 = 0.0f;      // Min(nMatch, huge) = the caller's nMatch
-    hipLaunchKernelGGL(select_kernel, dim3(1), dim3(256), 0, ctx->stream, dpd.as<PairDesc>(), didx.as<int>(), dd2.as<int>(), d2n.as<int>(),
-                       sp, ds1.as<mi355_sfpoint>(), ds2.as<mi355_sfpoint>(), dns.as<int>(), (unsigned long long*)nullptr);
+    BigPairDev bp;
+    memset(&bp, 0, sizeof(bp));
+    if (big) {
+        bp.n_i = n; bp.n_j = 1; bp.tc_n = 1; bp.mpad = 64; while (bp.mpad < n) bp.mpad <<= 1;
+        DevBuf& dbp = ctx->buf("big_pairs"); DevBuf& dkeys = ctx->buf("sorted_keys_big");
+        MI_HIP(dbp.reserve(sizeof(bp))); MI_HIP(dkeys.reserve((size_t)bp.mpad * 8));
+        MI_HIP(hipMemcpyAsync(dbp.p, &bp, sizeof(bp), hipMemcpyHostToDevice, ctx->stream));
+        hipLaunchKernelGGL(select_big_kernel, dim3(1), dim3(1024), 0, ctx->stream, dpd.as<PairDesc>(), dbp.as<BigPairDev>(), didx.as<int>(), dd2.as<int>(), d2n.as<int>(), sp,
+                           dkeys.as<unsigned long long>(), ds1.as<mi355_sfpoint>(), ds2.as<mi355_sfpoint>(), dns.as<int>());
+    } else {
+        hipLaunchKernelGGL(select_kernel, dim3(1), dim3(256), 0, ctx->stream, dpd.as<PairDesc>(), didx.as<int>(), dd2.as<int>(), d2n.as<int>(),
+                           sp, ds1.as<mi355_sfpoint>(), ds2.as<mi355_sfpoint>(), dns.as<int>(), (unsigned long long*)nullptr);
+    }
     int cnt = 0;
     std::vector<mi355_sfpoint> h1(MI355_MAX_SELECTED), h2(MI355_MAX_SELECTED);
     MI_HIP(hipMemcpyAsync(&cnt, dns.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));

@@ -1948,7 +1948,7 @@ static int sift_run_batch(mi355_ctx* ctx, SiftWork* s) {
     MI_HIP(hipGetLastError());
     // the matcher's operands of all n frames in one launch, their counters in one strided copy (n launches + n copies of ~5 us each kept
     // the batch's stream, and a pipeline slot, busy for 0.3 ms per batch of 32)
-    { int rc = mi_finish_features_batch(ctx, fs.data(), n, reinterpret_cast<const int*>(cnt + 3), (int)CNT_STRIDE, tt); if (rc != MI355_OK) return rc; }
+    { int rc = mi_finish_features_batch(ctx, fs.data(), n, reinterpret_cast<const int*>(cnt + 3), (int)CNT_STRIDE, tt, s->keepall ? KEEPALL_MAX : 2048); if (rc != MI355_OK) return rc; }
     {
         if (ctx->pinned_used % PINNED_CHUNK + (size_t)n > PINNED_CHUNK) ctx->pinned_used += PINNED_CHUNK - ctx->pinned_used % PINNED_CHUNK;   // n slots in one chunk
         int* h0 = nullptr;

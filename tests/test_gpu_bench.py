@@ -23,8 +23,14 @@ def test_bench_contract_small():
     assert d["n_gpus"] == 1 and d["steps"] == 1 and d["higher_is_better"] is True and d["vs_baseline"] is None and d["data"] == "synthetic"
     assert "workload" in d["config"] and "model" not in d["config"]
     rf = d["roofline"]
-    assert rf["bound"] == "valu" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
-    assert rf["valu"]["frac"] > 0 and d["roofline_by_kernel"]["ransac_kernel"]["bound"] == "valu"      # adjacent pairs: the blur dominates, ransac_kernel listed beside it
+    # the line's roofline is the kernel that dominates the step that was run: at this toy size (6 frames of 0.75 MP) that may be either one,
+    # at C3 it is the blur (6 levels of 12 MP per frame against one ransac launch of 499 pairs); both are always listed
+    blur = rf if rf["kernel"].startswith("blur16_stream") else d["roofline_by_kernel"]["blur16_stream"]
+    rk = d["roofline_by_kernel"]["ransac_kernel"]
+    assert blur["bound"] == "valu" and blur["unit"] == "GB/s" and blur["peak"] == 8000.0 and abs(blur["frac"] - blur["achieved"] / blur["peak"]) < 1e-12
+    assert blur["valu"]["frac"] > 0
+    assert rk["bound"] == "valu" and rk["unit"] == "TFLOP/s" and rk["peak"] == 78.65 and abs(rk["frac"] - rk["achieved"] / rk["peak"]) < 1e-12
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
     hf = d["host_frames"]
     assert hf["value"] > 0 and hf["pairs_accepted"] == 5 and "pageable host memory" in hf["sample"]      # what the adaptor's caller gets (host IplImages)
     cb = d["cpu_baseline"]
@@ -64,7 +70,7 @@ def test_bench_two_ranks_strong_dry_run_on_one_gpu():
     # replicated from the moments and the records go to rank 0's host only
     assert d["frames_resident"].startswith("owned") and d["align_input"].startswith("moments")
     fx = d["frame_exchange_rank0"]
-    assert fx["frames_held"] == 5 and fx["bytes_received"] > 0 and fx["bytes_sent"] > 0 and fx["frames_read_by_the_stripe"] < 9
+    assert fx["frames_held"] == 5 and fx["bytes_received"] > 0 and fx["bytes_sent"] > 0 and fx["frames_read_by_the_stripe"] <= 9      # (a single strip row: both horizontal stripes cross most frames)
     # whole-job aggregate: the survey's 8 pairs per step
     assert abs(d["value"] - 8 / (d["ms_per_step"] / 1e3)) / d["value"] < 1e-6
 

@@ -102,7 +102,7 @@ WORKER = textwrap.dedent("""
     bw_, bh_, _ = im.blend_layout(wv, hv, Hgt, keep)
     bstripes = [((bh_ * r) // world, (bh_ * (r + 1)) // world - (bh_ * r) // world) for r in range(world)]
     bneed = ex.stripe_need(wv, hv, Hgt, bstripes, blended=True, keep=keep, band=5)
-    assert bneed[rank].sum() < keep.sum() or F < 4, "the blended stripe should not need every kept frame"
+    assert all(bneed[rank, k] == 0 for k in range(F) if not keep[k])
     bptrs, bbr, bbs = ex.exchange_frames(held, hv, wsv, bneed)
     br0, brows = bstripes[rank]
     o1, _, _, _ = ctx.MosaicBlendedDev(bptrs, wv, hv, wsv, Hgt, keep=keep, band=5, row0=br0, rows=brows)

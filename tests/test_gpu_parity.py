@@ -375,6 +375,52 @@ def test_bf_match_exact(ctx, oracle):
     ctx.DropFeatures(100); ctx.DropFeatures(101)
 
 
+def test_bf_match_and_selection_beyond_2048_keypoints(ctx, oracle):
+    """the large-pair path (keep-all frames, match.hip): query and train sets in chunks of 2048 on the matrix cores, the chunks' nearest merged
+    (ties -> the lowest train index, also ACROSS chunks), the M keys sorted in HBM, the same grid walk.  1-NN / 2-NN, the sorted list and the
+    stand-alone SelectMatchPairs against the CPU oracle for ragged sizes on either side of the chunk boundaries, up to the 32 768 the record holds."""
+    rng = np.random.default_rng(77)
+    from imagemosaicing_amd import KEYPOINT
+    for (n1, n2) in [(2049, 2048), (2048, 2049), (4097, 300), (300, 4100), (5000, 6200), (9000, 3000), (32768, 2500)]:
+        d1, d2 = _rand_desc(rng, n1), _rand_desc(rng, n2)
+        if n2 > 2100:
+            d2[2050] = d2[3]; d1[0] = d2[3]                 # an exact tie between two train CHUNKS: the lower index wins
+            d2[n2 - 1] = d2[2047]; d1[1] = d2[2047]         # ... the last row of chunk 0 against the very last row
+        if n1 > 2100:
+            d1[2100] = d1[5]                                # equal distances for two queries of different query chunks: order by queryIdx
+        kp1 = np.zeros(n1, KEYPOINT); kp2 = np.zeros(n2, KEYPOINT)
+        kp1["x"] = rng.uniform(5, 995, n1); kp1["y"] = rng.uniform(5, 745, n1)
+        kp2["x"] = rng.uniform(5, 995, n2); kp2["y"] = rng.uniform(5, 745, n2)
+        ctx.SetFeatures(100, kp1, d1.astype(np.float32), 1000, 750)
+        ctx.SetFeatures(101, kp2, d2.astype(np.float32), 1000, 750)
+        idx, b1, b2 = oracle.bf_match(d1, d2)
+        m, g1, g2 = ctx.BFMatch(100, 101, sorted_=False, max_matches=n1)
+        assert len(m) == n1
+        assert np.array_equal(m["trainIdx"], idx) and np.array_equal(g1, b1) and np.array_equal(g2, b2), (n1, n2)
+        ms, s1, _ = ctx.BFMatch(100, 101, sorted_=True, max_matches=n1)
+        want = oracle.sort_matches(idx, b1)
+        assert np.array_equal(np.stack([ms["queryIdx"], ms["trainIdx"]], 1), want), (n1, n2)
+        # stand-alone SelectMatchPairs on the whole sorted list (more than select_kernel's 2048 LDS keys when n1 > 2048)
+        nMatch = int(min(400.0, 0.3 * n1))
+        a1, a2 = ctx.SelectMatchPairs(want, np.stack([kp1["x"], kp1["y"]], 1), np.stack([kp2["x"], kp2["y"]], 1), nMatch, 1000, 750)
+        o1, o2 = oracle.select(want, np.stack([kp1["x"], kp1["y"]], 1), np.stack([kp2["x"], kp2["y"]], 1), nMatch, 1000, 750)
+        assert len(a1) == len(o1) and np.array_equal(a1, o1) and np.array_equal(a2, o2), (n1, n2)
+        if n1 <= 9000:
+            # the whole j-loop body on such a pair: the record equals oracle.match_pair's
+            r = ctx.MatchPairs([(100, 101)], 2.5, 3)[0]
+            nin, i1, i2, Ho, nsel = oracle.match_pair(np.stack([kp1["x"], kp1["y"]], 1), d1, np.stack([kp2["x"], kp2["y"]], 1), d2, 1000, 750, 2.5, 3)
+            assert int(r["n_selected"]) == nsel and int(r["accepted"]) == int(nin > 30), (n1, n2)
+    # a batch that mixes both kinds of pairs: every record equals the one the pair gives alone
+    kpa = np.zeros(1500, KEYPOINT); kpa["x"] = rng.uniform(5, 995, 1500); kpa["y"] = rng.uniform(5, 745, 1500)
+    ctx.SetFeatures(102, kpa, _rand_desc(rng, 1500).astype(np.float32), 1000, 750)
+    mixed = [(102, 102), (100, 101), (102, 101), (101, 102), (102, 102), (100, 100)]
+    together = ctx.MatchPairs(mixed, 2.5, 5)
+    for p, r in zip(mixed, together):
+        alone = ctx.MatchPairs([p], 2.5, 5)[0]
+        assert np.array_equal(np.frombuffer(r.tobytes(), np.uint8), np.frombuffer(alone.tobytes(), np.uint8)), p
+    ctx.DropFeatures(100); ctx.DropFeatures(101); ctx.DropFeatures(102)
+
+
 def _synthetic_feature_pair(rng, n=2000, w=4000, h=3000, overlap=0.7):
     """two keypoint sets related by a homography, matching descriptors for the shared part + noise"""
     from imagemosaicing_amd import KEYPOINT

@@ -135,9 +135,37 @@ def test_gpu_keep_all_meets_the_reference_records_directly():
         assert np.array_equal(desc.astype(np.uint8), odesc), f"frame {k}: keep-all descriptors differ from the oracle's"
     assert tot >= (11836 if len(ks) == 20 else 1100), tot      # frames 0 and 1 alone appear in 1154 records
     assert ok == tot, f"{tot - ok} of {tot} records of the reference run are not in the GPU's keep-all output (index + float32 bits)"
-    # such frames hold more keypoints than the matcher takes: the pair stage says so
-    with pytest.raises(im.Mi355Error):
-        ctx.MatchPairs([(ks[0], ks[1])], 2.5, 1)
+    # The pair stage takes these frames as they are (VERDICT r05 missing #3): ~2 900 keypoints per image go through the large-pair path
+    # (match.hip: sub-pairs of <= 2048 x 2048 on the matrix cores, the chunks' nearest merged, the M keys sorted in HBM, the same grid
+    # walk, Ransac2D) -- the reference's j-loop takes any M (MosaicWithoutPos.cpp:5108-5153, nMatch = Min(400, 0.3 M)).  Every pair of
+    # the frames at hand against oracle.match_pair on the same features: n_selected, n_in, the inlier lists, the bits of H.
+    feats = {}
+    for k in ks:
+        kp, desc = ctx.GetFeatures(k, max_kp=32768)
+        assert len(kp) > 2048
+        feats[k] = (np.stack([kp["x"], kp["y"]], 1), desc.astype(np.uint8))
+    pairs = [(ks[a], ks[b]) for a in range(len(ks)) for b in range(a + 1, len(ks))]
+    if len(pairs) > 40:
+        pairs = pairs[:20] + pairs[-20:]
+    res = ctx.MatchPairs(pairs, 2.5, 1)
+    want = ol.parallel_map(lambda p: orc.match_pair(feats[p[0]][0], feats[p[0]][1], feats[p[1]][0], feats[p[1]][1], 1000, 750, 2.5, 1), pairs)
+    n_acc = 0
+    for r, (nin, i1, i2, Ho, nsel), p in zip(res, want, pairs):
+        assert int(r["n_selected"]) == nsel and int(r["accepted"]) == int(nin > 30), p
+        if nin > 30:
+            n_acc += 1
+            assert int(r["n_in"]) == nin and np.array_equal(r["a"][:nin], i1[:nin]) and np.array_equal(r["b"][:nin], i2[:nin]), p
+            assert np.array_equal(r["H"].view(np.uint32), Ho.view(np.uint32)), p
+    assert n_acc >= 1
+    r01 = res[0]
+    assert (int(r01["i"]), int(r01["j"])) == (0, 1) and int(r01["accepted"]) == 1 and int(r01["n_selected"]) == 396      # Min(400, 0.3 M) = 400 -> 44 per cell
+    # the pairwise motion of the reference's images 0 / 1 agrees with its global solution (tran0.txt row 1: tx 11.58, ty -100.62) to a few pixels
+    assert abs(float(r01["H"][2]) - 11.58) < 6 and abs(float(r01["H"][5]) + 100.62) < 6
+    # the pair's inliers are among the reference run's own inlier keypoints of that pair (same detector, same indices) for the most part
+    m = (mp["ai"] == 0) & (mp["bi"] == 1)
+    ref_ids = set(zip(mp["aid"][m].tolist(), mp["bid"][m].tolist()))
+    mine = set(zip(r01["a"]["id"][:int(r01["n_in"])].tolist(), r01["b"]["id"][:int(r01["n_in"])].tolist()))
+    assert len(mine & ref_ids) >= 0.5 * min(len(mine), len(ref_ids)), (len(mine), len(ref_ids), len(mine & ref_ids))
     ctx.close()
 
 
