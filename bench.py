@@ -125,6 +125,9 @@ def parse():
     ap.add_argument("--frames-resident", default="owned", choices=["owned", "replicas"],
                     help="strong scaling with N > 1: owned = a rank synthesises and holds only the frames it extracts (k mod N) and receives the frames its canvas stripe reads "
                          "from their owners inside the timed step (mi355_exchange_frames: SURVEY 8e's primary form); replicas = every rank holds all frames (no exchange)")
+    ap.add_argument("--frame-owner", default="blocks", choices=["blocks", "mod"],
+                    help="which rank extracts and holds frame k (strong scaling): blocks = contiguous runs of ceil(F/N) frames (a rank's frames lie in one band of the canvas, its stripe is dealt "
+                         "out to match: the frame exchange moves the bands' edges only); mod = k mod N, the reference's thread rule (MosaicWithoutPos.cpp:4861). Pairs stay i mod N either way")
     ap.add_argument("--no-host-frames", action="store_true", help="skip the untimed host-frame sample (frames in pageable host memory through mi355_sift_extract / mi355_mosaic_refined)")
     ap.add_argument("--align-input", default="auto", choices=["auto", "records", "moments"], help="auto = records on one GPU, and with N > 1 (strong) the moments on every rank + the records to rank 0's host only (mi355_allgather_results root = 0, the rank that would run the unchanged driver). What the host alignment starts from: the accepted pair records (9664 B each) or their second moments formed on the device (mi355_allgather_moments / mi355_pair_moments_dev, 184 B each; same transforms bit for bit)")
     ap.add_argument("--as-rank", default=None, help="ONE-GPU PROXY of a rank's share of an --of G rank run (no launcher, no other rank): comma list of ranks, e.g. 0,7")
@@ -338,8 +341,9 @@ def rank_share_proxy(args):
     mom_host = torch.empty((max(acc, 1), MOM), dtype=torch.uint8).pin_memory()
     ctx.set_option("sift_batch", BATCH)                           # a rank's own batch size (batch_for)
     shares = {}
+    owner = md.frame_owner(F, G, args.frame_owner)
     for rk in ranks:
-        own = md.owned_frames(F, rk, G)
+        own = md.owned_frames(F, rk, G, args.frame_owner)
         pairs = im.pair_schedule(F, args.window, rk, G)
         res_r = torch.zeros((max(len(pairs), 1), REC), dtype=torch.uint8, device=dev)
         comp_r = torch.zeros((max(len(pairs), 1), REC), dtype=torch.uint8, device=dev)
@@ -378,20 +382,26 @@ def rank_share_proxy(args):
             h9, cw, ch, cws = align_and_layout(mom_all if use_mom else r_all, use_mom)      # replicated on every rank: the whole survey
             mark()
             stripes = [((ch * q) // G, (ch * (q + 1)) // G - (ch * q) // G) for q in range(G)]
-            need = ex.stripe_need(wv, hv, h9, stripes)            # G host-geometry passes: every rank's cover list (the same table on every rank)
-            # world-1 communicator: the call walks the table and hands back the pointers of the frames the stripe reads (0 elsewhere); the transfers themselves are wire (modelled)
-            ptrs, _, _ = ex.exchange_frames([frames[k] for k in range(F)], hv, wsv, np.ascontiguousarray(need[rk:rk + 1]))
+            sidx = md.stripe_of_ranks(wv, hv, h9, owner, G)
+            row0, rows = stripes[int(sidx[rk])]
+            # the rank's own cover row: the frames that give its stripe a pixel (the tile kernel's walk without loads) ...
+            need_mine = ctx.StripeCover(wv, hv, h9, row0, rows, exact=True)
+            # ... and the exchange call on the one-rank communicator: the all-gather of the cover rows and the table walk are real, the
+            # transfers themselves are wire (modelled from the bytes below)
+            ptrs, _, _ = ex.exchange_frames([frames[k] for k in range(F)], hv, wsv, need_mine)
             mark()
-            row0, rows = stripes[rk]
             ctx.MosaicImagesRefinedDev(ptrs, wv, hv, wsv, h9, canvas.data_ptr(), cw, ch, cws, row0, rows)
             mark()
             if sync:
-                names = ["detect_describe", "feature_allgather_local", "match_select_ransac", "result_exchange_local_and_d2h", "host_alignment_replicated", "stripe_cover_lists", "warp_stripe"]
+                names = ["detect_describe", "feature_allgather_local", "match_select_ransac", "result_exchange_local_and_d2h", "host_alignment_replicated", "stripe_cover_and_exchange_call", "warp_stripe"]
                 ph.update({n: (t[i + 1] - t[i]) * 1e3 for i, n in enumerate(names)})
                 fb = float(h * ws)
-                xinfo.update({"frames_read_by_the_stripe": int(need[rk].sum()), "frames_received": int(sum(1 for k in range(F) if need[rk, k] and k % G != rk)),
-                              "bytes_received": fb * sum(1 for k in range(F) if need[rk, k] and k % G != rk),
-                              "bytes_sent": fb * sum(int(need[q, k]) for q in range(G) for k in own if q != rk)})
+                need = np.stack([ctx.StripeCover(wv, hv, h9, stripes[int(sidx[q])][0], stripes[int(sidx[q])][1], exact=True) for q in range(G)])      # every rank's row (untimed: a rank forms its own)
+                box = ctx.StripeCover(wv, hv, h9, row0, rows)
+                xinfo.update({"stripe": int(sidx[rk]), "frames_read_by_the_stripe": int(need[rk].sum()), "frames_whose_box_meets_the_stripe": int(box.sum()),
+                              "frames_received": int(sum(1 for k in range(F) if need[rk, k] and owner[k] != rk)),
+                              "bytes_received": fb * sum(1 for k in range(F) if need[rk, k] and owner[k] != rk),
+                              "bytes_sent": fb * sum(int(need[q, k]) for q in range(G) for k in own if q != rk), "owner_rule": args.frame_owner})
 
         for i in range(max(args.warmup, 1)):
             share_step(1 + i)
@@ -420,11 +430,13 @@ def rank_share_proxy(args):
             return min(ts[1:])
         whole = blend_ms(0, -1)
         bstripes = [((bh_ * q) // G, (bh_ * (q + 1)) // G - (bh_ * q) // G) for q in range(G)]
-        bneed = ex.stripe_need(wv, hv, h9b, bstripes, blended=True, keep=keep, band=5)
+        bsidx = md.stripe_of_ranks(wv, hv, h9b, owner, G)
         stripes_ms, bx = {}, {}
         for rk in ranks:
-            stripes_ms[str(rk)] = blend_ms(bstripes[rk][0], bstripes[rk][1])
-            bx[str(rk)] = {"frames_read_by_the_stripe": int(bneed[rk].sum()), "bytes_received": float(h * ws) * sum(1 for k in range(F) if bneed[rk, k] and k % G != rk)}
+            b0, bn = bstripes[int(bsidx[rk])]
+            bneed = ctx.StripeCover(wv, hv, h9b, b0, bn, blended=True, keep=keep, band=5)
+            stripes_ms[str(rk)] = blend_ms(b0, bn)
+            bx[str(rk)] = {"frames_read_by_the_stripe": int(bneed.sum()), "bytes_received": float(h * ws) * sum(1 for k in range(F) if bneed[k] and owner[k] != rk)}
         blend = {"canvas": [bw_, bh_], "chips": int(keep.sum()), "bands": 5, "whole_canvas_ms_one_gpu": whole, "stripe_ms": stripes_ms, "frame_exchange": bx,
                  "wire_ms_frames_direct_7_links": {q: v["bytes_received"] / (7 * 153e9) * 1e3 for q, v in bx.items()},
                  "speedup_of_the_slowest_stripe": whole / max(stripes_ms.values()),
@@ -447,7 +459,7 @@ def rank_share_proxy(args):
     t_pred = max(v["predicted_ms_per_step"] for v in per_rank.values())
     out = {"kind": "rank_share_proxy (ONE GPU; a proxy of a rank's share, NOT a measured scaling curve)",
            "metric": "image-pairs/sec (detect+match+H+warp), 4000x3000 UAV frames", "of_ranks": G, "ranks_run": ranks,
-           "workload": "%d frames %dx%d, pair window %d (%d pairs), strong scaling: frames k mod %d, pairs i mod %d, canvas stripes; frames held by their owners only" % (F, w, h, args.window, survey_pairs, G, G),
+           "workload": "%d frames %dx%d, pair window %d (%d pairs), strong scaling: frames %s, pairs i mod %d, canvas stripes; frames held by their owners only" % (F, w, h, args.window, survey_pairs, ("in %d blocks" % G) if args.frame_owner == "blocks" else ("k mod %d" % G), G),
            "one_gpu_ms_per_step": t_one, "one_gpu_pairs_per_s": survey_pairs / t_one * 1e3,
            "one_gpu_path": "bench.py's plain single-GPU step (device compaction, pinned copy of the accepted records, alignment from the records): not a path through the exchange",
            "frames_per_batch": {"one_gpu": batch_one, "rank": BATCH},
@@ -530,7 +542,8 @@ def main():
     # from their owners inside the timed step (--frames-resident owned, the default).  Every rank holding all N frames would be 8 x the PCIe
     # upload in a deployment and 72 GB per GPU at C5 (VERDICT r05 missing #2).
     owned_only = strong and world > 1 and args.frames_resident == "owned"
-    hold = md.owned_frames(F, rank, world) if owned_only else list(range(F))
+    owner = md.frame_owner(F, world, args.frame_owner)
+    hold = md.owned_frames(F, rank, world, args.frame_owner) if owned_only else list(range(F))
     slot_of = {k: i for i, k in enumerate(hold)}
     frames = torch.empty((len(hold), h * ws), dtype=torch.uint8, device=dev)
     for k in hold:
@@ -539,7 +552,7 @@ def main():
     fptr = {k: frames[slot_of[k]].data_ptr() for k in hold}
     held = [frames[slot_of[k]] if k in slot_of else None for k in range(F)]
     if strong:
-        own = md.owned_frames(F, rank, world)                              # k mod G == rank (MosaicWithoutPos.cpp:4861)
+        own = md.owned_frames(F, rank, world, args.frame_owner)            # the frames this rank extracts (and, with --frames-resident owned, the only ones it holds)
         pairs = im.pair_schedule(F, args.window, rank, world)              # i mod G == rank (:5066), j in (i, i+window) (:5083)
         survey_pairs = len(im.pair_schedule(F, args.window))
         n_max_frames = (F + world - 1) // world
@@ -647,15 +660,17 @@ def main():
             t3 = time.perf_counter()
         if strong and world > 1:
             stripes = [((ch * q) // world, (ch * (q + 1)) // world - (ch * q) // world) for q in range(world)]      # canvas stripes: every image in index order per stripe
+            mine = stripes[int(md.stripe_of_ranks(wv, hv, h9, owner, world)[rank])]      # the stripe that lies where this rank's own frames are (replicated geometry: the same deal on every rank)
             if owned_only:
-                # which frames every rank's stripe reads is host geometry on the replicated transforms: the same table on every rank, no negotiation;
-                # the frames this rank's stripe reads and does not hold come from their owners (ncclSend / ncclRecv over xGMI)
-                need = ex.stripe_need(wv, hv, h9, stripes)
-                ptrs, b_in, b_out = ex.exchange_frames(held, hv, wsv, need)
-                state["frame_exchange"] = {"bytes_received": b_in, "bytes_sent": b_out, "frames_read_by_the_stripe": int(need[rank].sum()), "frames_held": len(hold)}
+                # the frames that give this stripe at least one pixel (the tile kernel's walk without its loads, on this rank's device); the rows of
+                # all ranks are all-gathered inside the exchange, then every frame a stripe reads and its rank does not hold comes from its owner
+                # (ncclSend / ncclRecv over xGMI)
+                need_mine = ctx.StripeCover(wv, hv, h9, mine[0], mine[1], exact=True)
+                ptrs, b_in, b_out = ex.exchange_frames(held, hv, wsv, need_mine, owner=owner)
+                state["frame_exchange"] = {"bytes_received": b_in, "bytes_sent": b_out, "frames_read_by_the_stripe": int(need_mine.sum()), "frames_held": len(hold), "owner_rule": args.frame_owner}
             else:
                 ptrs = [fptr[k] for k in range(F)]
-            ctx.MosaicImagesRefinedDev(ptrs, wv, hv, wsv, h9, canvas.data_ptr(), cw, ch, cws, stripes[rank][0], stripes[rank][1])
+            ctx.MosaicImagesRefinedDev(ptrs, wv, hv, wsv, h9, canvas.data_ptr(), cw, ch, cws, mine[0], mine[1])
         else:
             ctx.MosaicImagesRefinedDev([fptr[k] for k in range(F)], wv, hv, wsv, h9, canvas.data_ptr(), cw, ch, cws)
         if phases:
@@ -786,8 +801,9 @@ def main():
         h9b = state["h9"]
         keep = im.resample_by_overlap(wv, hv, h9b, 0.7)                 # MosaicImage.cpp:2227-2230
         bw_, bh_, _ = im.blend_layout(wv, hv, h9b, keep)
-        row0 = (bh_ * rank) // world if world > 1 else 0
-        rows = ((bh_ * (rank + 1)) // world - row0) if world > 1 else -1
+        sidx = int(md.stripe_of_ranks(wv, hv, h9b, owner, world)[rank]) if world > 1 else 0
+        row0 = (bh_ * sidx) // world if world > 1 else 0
+        rows = ((bh_ * (sidx + 1)) // world - row0) if world > 1 else -1
         torch.cuda.synchronize()
         free0 = torch.cuda.mem_get_info()[0]
         tb = []
@@ -797,10 +813,9 @@ def main():
             t_b = time.perf_counter()
             if owned_only:
                 # the blended stripe reads the chips that reach its rows plus the pyramids' reach: those frames come from their owners (timed)
-                bstripes = [((bh_ * q) // world, (bh_ * (q + 1)) // world - (bh_ * q) // world) for q in range(world)]
-                bneed = ex.stripe_need(wv, hv, h9b, bstripes, blended=True, keep=keep, band=5)
-                bptrs, bb_in, bb_out = ex.exchange_frames(held, hv, wsv, bneed)
-                blend_x = {"bytes_received": bb_in, "bytes_sent": bb_out, "frames_read_by_the_stripe": int(bneed[rank].sum())}
+                bneed = ctx.StripeCover(wv, hv, h9b, row0, rows, blended=True, keep=keep, band=5)
+                bptrs, bb_in, bb_out = ex.exchange_frames(held, hv, wsv, bneed, owner=owner)
+                blend_x = {"bytes_received": bb_in, "bytes_sent": bb_out, "frames_read_by_the_stripe": int(bneed.sum())}
             else:
                 bptrs, blend_x = [fptr[k] for k in range(F)], None
             outb, bw_, bh_, bws_ = ctx.MosaicBlendedDev(bptrs, wv, hv, wsv, h9b, keep=keep, band=5, row0=row0, rows=rows)
@@ -870,7 +885,7 @@ def main():
                        "frames": F if strong else F * world, "pairs": survey_pairs, "frames_per_gpu": len(own), "pairs_per_gpu": n_pairs,
                        "frame": [w, h], "canvas": [state["cw"], state["ch"]],
                        "sharding": ("single GPU" if world == 1 else
-                                    ("frames k mod G, pairs i mod G, canvas stripes; %s all-gather of feature records and accepted pair records" % transport) if strong else
+                                    ("frames %s, pairs i mod G, canvas stripes; %s exchanges: feature records, pair records / moments, frames" % ("in blocks of ceil(F/G)" if args.frame_owner == "blocks" else "k mod G", transport)) if strong else
                                     ("independent strip per rank; %s all-gather of accepted pair records" % transport))},
             "roofline": {"bound": "valu", "bound_note": "a streaming stencil priced against HBM as SURVEY 8d asks (achieved / peak / frac are GB/s of algorithmic bytes), but what limits it is f32 vector instruction issue: see `valu` (PMC traffic = 1.06 x the algorithmic bytes: nothing is re-read)",
                          "kernel": "blur16_stream<R,D,BGR> (streaming separable Gaussian 16S -> 32F -> 16S, one pyramid level of all frames of a batch per launch: every level at least 512 columns wide, the base level straight from the BGR frames)",

@@ -369,29 +369,33 @@ class Context:
             return np.zeros(0, PAIR_MOMENTS)
         return _view_out(ptr, n.value * PAIR_MOMENTS.itemsize, PAIR_MOMENTS, copy)
 
-    def StripeCover(self, w, h, h9s, row0, rows, blended=False, keep=None, band=5):
-        """mi355_mosaic_stripe_cover: need[k] = 1 when rendering canvas rows [row0, row0 + rows) reads frame k"""
+    def StripeCover(self, w, h, h9s, row0, rows, blended=False, keep=None, band=5, exact=False):
+        """mi355_mosaic_stripe_cover: need[k] = 1 when rendering canvas rows [row0, row0 + rows) reads frame k.  exact (refined canvas only): the
+        frames that give at least one pixel its sample (a device pass), instead of every frame whose box meets the rows"""
         n = len(w)
         w = np.ascontiguousarray(w, np.int32); h = np.ascontiguousarray(h, np.int32)
         h9s = np.ascontiguousarray(h9s, np.float32)
         keep_a = None if keep is None else np.ascontiguousarray(keep, np.uint8)
         need = np.zeros(n, np.uint8)
-        self._chk(self.L.mi355_mosaic_stripe_cover(self._h, int(bool(blended)), _p(w), _p(h), n, _p(h9s), _p(keep_a), int(band), int(row0), int(rows), _p(need)))
+        mode = 1 if blended else (2 if exact else 0)
+        self._chk(self.L.mi355_mosaic_stripe_cover(self._h, mode, _p(w), _p(h), n, _p(h9s), _p(keep_a), int(band), int(row0), int(rows), _p(need)))
         return need
 
     def ExchangeFrames(self, d_frames, h, ws, need, owner=None, own_through_rccl=False):
         """mi355_exchange_frames.  d_frames: per frame this rank's device pointer (0 / None where it does not hold the frame); need: [G, n]
-        uint8 table (the same on every rank).  Returns (pointers for the stripe calls -- 0 where the rank's stripe does not read the frame --,
-        bytes received, bytes sent)."""
+        uint8 table (the same on every rank), or [n]: this rank's own row (the rows are all-gathered inside the call).  Returns (pointers for
+        the stripe calls -- 0 where the rank's stripe does not read the frame --, bytes received, bytes sent)."""
         n = len(d_frames)
         ptrs = (C.c_void_p * max(n, 1))(*[int(p) if p else None for p in d_frames])
         h = np.ascontiguousarray(h, np.int32); ws = np.ascontiguousarray(ws, np.int32)
         need = np.ascontiguousarray(need, np.uint8)
-        assert need.ndim == 2 and need.shape[1] == n
+        local = need.ndim == 1
+        assert need.shape[-1] == n
         own_a = None if owner is None else np.ascontiguousarray(owner, np.int32)
         out = (C.c_void_p * max(n, 1))()
         br, bs = C.c_uint64(0), C.c_uint64(0)
-        self._chk(self.L.mi355_exchange_frames(self._h, ptrs, _p(h), _p(ws), n, _p(own_a), _p(need), 1 if own_through_rccl else 0, out, C.byref(br), C.byref(bs)))
+        flags = (1 if own_through_rccl else 0) | (2 if local else 0)
+        self._chk(self.L.mi355_exchange_frames(self._h, ptrs, _p(h), _p(ws), n, _p(own_a), _p(need), flags, out, C.byref(br), C.byref(bs)))
         return [int(out[k] or 0) for k in range(n)], int(br.value), int(bs.value)
 
     def SynthFrameDev(self, d_dst, w, h, ws, A6, seed, frame_seed, gain=1.0, noise=2.0):

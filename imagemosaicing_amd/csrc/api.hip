@@ -345,19 +345,19 @@ extern "C" int mi355_mosaic_blended_rows_dev(mi355_ctx* ctx, const uint8_t* cons
 }
 
 // The frames a stripe call reads: the stripe calls themselves with the device work left out (cover_only), so the list cannot drift from them.
-extern "C" int mi355_mosaic_stripe_cover(mi355_ctx* ctx, int blended, const int* w, const int* h, int n, const float* h9s, const uint8_t* keep, int band,
+extern "C" int mi355_mosaic_stripe_cover(mi355_ctx* ctx, int mode, const int* w, const int* h, int n, const float* h9s, const uint8_t* keep, int band,
                                          int row0, int rows, uint8_t* need) {
     LOCKED_PROLOGUE
-    if (!w || !h || !h9s || !need || n <= 0) { ctx->set_error("mosaic_stripe_cover: bad arguments"); return MI355_ERR_ARG; }
+    if (!w || !h || !h9s || !need || n <= 0 || mode < 0 || mode > 2) { ctx->set_error("mosaic_stripe_cover: bad arguments"); return MI355_ERR_ARG; }
     memset(need, 0, (size_t)n);
     std::vector<const uint8_t*> none((size_t)n, nullptr);
     std::vector<int> ws((size_t)n);
     for (int k = 0; k < n; k++) ws[k] = (3 * w[k] + 3) & ~3;
-    if (!blended) {
+    if (mode != MI355_COVER_BLENDED) {
         int cw = 0, ch = 0, cws = 0;
         const int rc = mi355_mosaic_layout(w, h, n, h9s, &cw, &ch, &cws, nullptr);
         if (rc != MI355_OK) { ctx->set_error("mosaic_stripe_cover: no image with h[8] != 0 / empty canvas"); return rc; }
-        return mi_mosaic_refined_dev(ctx, none.data(), w, h, ws.data(), n, h9s, nullptr, cw, ch, cws, row0, rows, need);
+        return mi_mosaic_refined_dev(ctx, none.data(), w, h, ws.data(), n, h9s, nullptr, cw, ch, cws, row0, rows, need, mode == MI355_COVER_REFINED_EXACT ? 1 : 0);
     }
     int cw = 0, ch = 0;
     { const int rc = mi_blend_layout(w, h, n, h9s, keep, &cw, &ch); if (rc != MI355_OK) return rc; }

@@ -585,6 +585,23 @@ extern "C" int mi355_exchange_frames(mi355_ctx* ctx, const uint8_t* const* d_fra
     const int world = ctx->comm->world, rank = ctx->comm->rank;
     const bool own_too = (flags & MI355_EXCHANGE_OWN_THROUGH_RCCL) != 0;
     auto own = [&](int k) { return owner ? owner[k] : k % world; };
+    std::vector<uint8_t> table;
+    if (flags & MI355_EXCHANGE_NEED_IS_LOCAL) {
+        // `need` is this rank's own row (what ITS stripe reads: an exact cover comes from a pass on the rank's own device): the rows of all
+        // ranks are all-gathered first -- n bytes per rank, one ncclAllGather and one copy back
+        DevBuf& dn = ctx->buf("frame_need_rows");
+        const size_t row = ((size_t)n + 15) & ~(size_t)15;
+        MI_HIP(dn.reserve(row * world + 16));
+        MI_HIP(hipMemsetAsync(dn.as<uint8_t>() + row * rank, 0, row, ctx->stream));
+        if (n > 0) MI_HIP(hipMemcpyAsync(dn.as<uint8_t>() + row * rank, need, (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+        MI_NCCL(api->AllGather(dn.as<uint8_t>() + row * rank, dn.p, row, ncclChar, ctx->comm->comm, ctx->stream));
+        std::vector<uint8_t> padded(row * world);
+        MI_HIP(hipMemcpyAsync(padded.data(), dn.p, row * world, hipMemcpyDeviceToHost, ctx->stream));
+        MI_HIP(hipStreamSynchronize(ctx->stream));
+        table.resize((size_t)n * world);
+        for (int r = 0; r < world; r++) memcpy(table.data() + (size_t)r * n, padded.data() + row * r, (size_t)n);
+        need = table.data();
+    }
     // this rank's landing area: one slot per frame it receives.  Everything that can fail on this rank alone is checked BEFORE the first
     // transfer is posted (a rank that left early would leave its peers waiting inside ncclRecv); the table itself is the same everywhere.
     std::vector<size_t> slot(n > 0 ? n : 1, (size_t)-1);

@@ -168,7 +168,7 @@ struct ProfScope {
 int mi_warp_image(mi355_ctx*, const uint8_t* src, int w, int h, int ws, int ch, const float* h9,
                   uint8_t** dst, int* dw, int* dh, int* dws);
 int mi_mosaic_refined_dev(mi355_ctx*, const uint8_t* const* d_imgs, const int* w, const int* h, const int* ws, int n,
-                          const float* h9s, uint8_t* d_canvas, int cw, int ch, int cws, int row0, int rows, uint8_t* cover_only = nullptr);
+                          const float* h9s, uint8_t* d_canvas, int cw, int ch, int cws, int row0, int rows, uint8_t* cover_only = nullptr, int cover_exact = 0);
 int mi_sift_flush(mi355_ctx*);                               // enqueues every partly filled batch (no wait)
 int mi_sift_flush_if_parked(mi355_ctx*, hipEvent_t ev);   // launches the batch still holding a parked frame with this event
 int mi_chips_and_masks_dev(mi355_ctx*, const uint8_t* const* imgs, const int* w, const int* h, const int* ws, int n,

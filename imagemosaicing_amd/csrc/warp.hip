@@ -251,8 +251,12 @@ __global__ __launch_bounds__(256) void mosaic_lists_kernel(const FrameDev* fr, i
     counts[b] = cnt;
 }
 
+// COVER: no pixel is loaded or stored -- the walk only records which frames GIVE a sample to at least one pixel of these rows (used[list
+// entry] = 1).  A frame that covers a pixel but lies under a later one is never read by the real pass either, so `used` is exactly the set of
+// frames the real pass dereferences: what a rank must hold to render the stripe (mi355_mosaic_stripe_cover, mode 2).
+template <bool COVER>
 __global__ __launch_bounds__(256) void mosaic_tile_kernel(const FrameDev* fr, int n, const uint16_t* lists, const int* counts, int bx_n,
-                                                          uint8_t* canvas, int cw, int cws, int row0, int row_end, float dGx, float dGy) {
+                                                          uint8_t* canvas, int cw, int cws, int row0, int row_end, float dGx, float dGy, int* used) {
     const int tid = threadIdx.x;
     const int tx0 = blockIdx.x * MT_W, ty0 = row0 + blockIdx.y * MT_H;
     // a lane owns 4 adjacent pixels in each of MT_RPL rows (rows ty0 + (tid >> 5) + 8 j): the tile's list / image loads are paid
@@ -292,6 +296,10 @@ __global__ __launch_bounds__(256) void mosaic_tile_kernel(const FrameDev* fr, in
                 else hm::apply_div9(f.inv, xf, yf, xs, ys);
                 const bool ok = want && (xs >= 0.0f && xs < w1 && ys >= 0.0f && ys < h1);      // also rejects NaN
                 if (!ok) continue;
+                if constexpr (COVER) { used[list[e]] = 1; open &= ~(1u << (4 * j + k)); continue; }
+                // a frame the caller holds no copy of (exact cover lists: a frame whose box meets the rows but which lies under later frames
+                // everywhere there is never asked for): if it is asked for after all, say which one -- the host turns that into an error
+                if (f.src == nullptr) { *used = 1 + (int)list[e]; continue; }
                 const int xi = (int)xs, yi = (int)ys;
                 const float p = ys - (float)yi, q = xs - (float)xi;
                 float b00, g00, r00, b01, g01, r01, b10, g10, r10, b11, g11, r11;
@@ -310,7 +318,7 @@ __global__ __launch_bounds__(256) void mosaic_tile_kernel(const FrameDev* fr, in
             }
         }
     }
-    if (xg >= cw) return;
+    if (COVER || xg >= cw) return;
 #pragma unroll
     for (int j = 0; j < MT_RPL; j++) {
         const int yD = yB + 8 * j;
@@ -331,9 +339,11 @@ __global__ __launch_bounds__(256) void mosaic_tile_kernel(const FrameDev* fr, in
     }
 }
 
-// cover_only != NULL: no device work -- cover_only[k] = 1 for the frames this call would read (the stripe's cover list, mi355_mosaic_stripe_cover)
+// cover_only != NULL: cover_only[k] = 1 for the frames this call would read (the stripe's cover list, mi355_mosaic_stripe_cover), nothing is
+// rendered.  cover_exact == 0: every frame whose clipped canvas box meets the rows (host geometry alone: a superset); != 0: the frames that
+// give at least one pixel its sample -- the tile kernel's walk without its loads (what the rendering pass really dereferences).
 int mi_mosaic_refined_dev(mi355_ctx* ctx, const uint8_t* const* d_imgs, const int* w, const int* h, const int* ws, int n,
-                          const float* h9s, uint8_t* d_canvas, int cw, int ch, int cws, int row0, int rows, uint8_t* cover_only) {
+                          const float* h9s, uint8_t* d_canvas, int cw, int ch, int cws, int row0, int rows, uint8_t* cover_only, int cover_exact) {
     int lw, lh, lws; float dG[2];
     int rc = mi355_mosaic_layout(w, h, n, h9s, &lw, &lh, &lws, dG);
     if (rc != MI355_OK) { ctx->set_error("mosaic_refined: no image with h[8] != 0 / empty canvas"); return rc; }
@@ -343,6 +353,7 @@ int mi_mosaic_refined_dev(mi355_ctx* ctx, const uint8_t* const* d_imgs, const in
     if (rows <= 0) return MI355_OK;
     if (n > 65535) { ctx->set_error("mosaic_refined: at most 65535 images"); return MI355_ERR_ARG; }
     std::vector<FrameDev> fr;
+    std::vector<int> frame_of;                     // image index of fr[q]
     fr.reserve(n);
     for (int k = 0; k < n; k++) {                  // ascending image order = overwrite order (MosaicWithoutPos.cpp:2254)
         const float* m = h9s + 9 * k;
@@ -373,15 +384,17 @@ int mi_mosaic_refined_dev(mi355_ctx* ctx, const uint8_t* const* d_imgs, const in
         if (begY < row0) begY = row0;                                   // canvas stripe
         if (endY > row0 + rows - 1) endY = row0 + rows - 1;
         if (endX < begX || endY < begY) continue;
-        if (cover_only) { cover_only[k] = 1; continue; }
-        if (!d_imgs[k] || w[k] < 2 || h[k] < 2 || ws[k] < 3 * w[k]) { ctx->set_error("mosaic_refined: bad image geometry"); return MI355_ERR_ARG; }
-        f.src = d_imgs[k]; f.w = w[k]; f.h = h[k]; f.ws = ws[k];
+        if (cover_only && !cover_exact) { cover_only[k] = 1; continue; }
+        if (w[k] < 2 || h[k] < 2 || ws[k] < 3 * w[k]) { ctx->set_error("mosaic_refined: bad image geometry"); return MI355_ERR_ARG; }
+        f.src = cover_only ? nullptr : d_imgs[k]; f.w = w[k]; f.h = h[k]; f.ws = ws[k];      // NULL: the kernel reports it if the rows do read the frame
+        frame_of.push_back(k);
         f.begX = begX; f.endX = endX; f.begY = begY; f.endY = endY;
         f.unit_den = (f.inv[6] == 0.0f && f.inv[7] == 0.0f && f.inv[8] == 1.0f) ? 1 : 0;
         fr.push_back(f);
     }
-    if (cover_only) return MI355_OK;
+    if (cover_only && !cover_exact) return MI355_OK;
     const int nf = (int)fr.size();
+    if (cover_only && nf == 0) return MI355_OK;
     const int bx_n = (cw + MT_COARSE - 1) / MT_COARSE, by_n = (rows + MT_COARSE - 1) / MT_COARSE;
     DevBuf& dfr = ctx->buf("mosaic_frames");
     DevBuf& dl = ctx->buf("mosaic_lists");
@@ -391,16 +404,35 @@ int mi_mosaic_refined_dev(mi355_ctx* ctx, const uint8_t* const* d_imgs, const in
     MI_HIP(dc.reserve(sizeof(int) * (size_t)bx_n * by_n));
     if (nf > 0) MI_HIP(hipMemcpyAsync(dfr.p, fr.data(), sizeof(FrameDev) * (size_t)nf, hipMemcpyHostToDevice, ctx->stream));
     hipLaunchKernelGGL(mosaic_lists_kernel, dim3((bx_n * by_n + 255) / 256), dim3(256), 0, ctx->stream, dfr.as<FrameDev>(), nf, bx_n, by_n, row0, dl.as<uint16_t>(), dc.as<int>());
+    if (cover_only) {
+        DevBuf& du = ctx->buf("mosaic_used");
+        MI_HIP(du.reserve(sizeof(int) * (size_t)nf));
+        MI_HIP(hipMemsetAsync(du.p, 0, sizeof(int) * (size_t)nf, ctx->stream));
+        hipLaunchKernelGGL(mosaic_tile_kernel<true>, dim3((cw + MT_W - 1) / MT_W, (rows + MT_H - 1) / MT_H), dim3(256), 0, ctx->stream,
+                           dfr.as<FrameDev>(), nf, dl.as<uint16_t>(), dc.as<int>(), bx_n, (uint8_t*)nullptr, cw, cws, row0, row0 + rows, dG[0], dG[1], du.as<int>());
+        MI_HIP(hipGetLastError());
+        std::vector<int> used((size_t)nf);
+        MI_HIP(hipMemcpyAsync(used.data(), du.p, sizeof(int) * (size_t)nf, hipMemcpyDeviceToHost, ctx->stream));
+        MI_HIP(hipStreamSynchronize(ctx->stream));
+        for (int q = 0; q < nf; q++) if (used[q]) cover_only[frame_of[q]] = 1;
+        return MI355_OK;
+    }
+    DevBuf& derr = ctx->buf("mosaic_missing");
+    MI_HIP(derr.reserve(sizeof(int)));
+    MI_HIP(hipMemsetAsync(derr.p, 0, sizeof(int), ctx->stream));
     {
         // SURVEY 8(d) algorithmic figure: every image read once and written once (6 P per image)
         double bytes = 0.0;
         for (const FrameDev& f : fr) bytes += 6.0 * (double)f.w * f.h;
         ProfScope ps(ctx, "warp", bytes);
-        hipLaunchKernelGGL(mosaic_tile_kernel, dim3((cw + MT_W - 1) / MT_W, (rows + MT_H - 1) / MT_H), dim3(256), 0, ctx->stream,
-                           dfr.as<FrameDev>(), nf, dl.as<uint16_t>(), dc.as<int>(), bx_n, d_canvas, cw, cws, row0, row0 + rows, dG[0], dG[1]);
+        hipLaunchKernelGGL(mosaic_tile_kernel<false>, dim3((cw + MT_W - 1) / MT_W, (rows + MT_H - 1) / MT_H), dim3(256), 0, ctx->stream,
+                           dfr.as<FrameDev>(), nf, dl.as<uint16_t>(), dc.as<int>(), bx_n, d_canvas, cw, cws, row0, row0 + rows, dG[0], dG[1], derr.as<int>());
     }
     MI_HIP(hipGetLastError());
+    int missing = 0;
+    MI_HIP(hipMemcpyAsync(&missing, derr.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     MI_HIP(hipStreamSynchronize(ctx->stream));           // `fr` goes out of scope
+    if (missing) { ctx->set_error("mosaic_refined: these canvas rows read image " + std::to_string(frame_of[missing - 1]) + " but no pointer to it was given"); return MI355_ERR_ARG; }
     return MI355_OK;
 }
 

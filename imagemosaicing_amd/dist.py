@@ -32,9 +32,41 @@ from .capi import PAIR_RESULT, FEATURE_HEADER, FEATURE_RECORD_BYTES, comm_unique
 REC = PAIR_RESULT.itemsize
 
 
-def owned_frames(n_images, rank, world):
-    """frames rank `rank` extracts: k mod world == rank (MosaicWithoutPos.cpp:4861)"""
+def owned_frames(n_images, rank, world, rule="mod"):
+    """frames rank `rank` extracts and holds.  "mod": k mod world == rank, the reference's own rule for its threads (MosaicWithoutPos.cpp:4861).
+    "blocks": contiguous runs of ceil(n / world) frames -- the same load per rank, and frames that follow each other in a survey lie next to
+    each other on the ground (flight lines), so a rank's frames fall into ONE band of the canvas: with the stripes dealt out by
+    stripe_of_ranks() a stripe reads mostly its own rank's frames and mi355_exchange_frames moves the ones at the bands' edges only
+    (C5, middle rank: 20 GB per step with "mod" ownership and box covers)."""
+    if rule == "blocks":
+        per = -(-n_images // world)
+        return list(range(min(rank * per, n_images), min((rank + 1) * per, n_images)))
     return list(range(rank, n_images, world))
+
+
+def frame_owner(n_images, world, rule="mod"):
+    """owner[k] of every frame under `rule` (the `owner` argument of mi355_exchange_frames)"""
+    if rule == "blocks":
+        per = -(-n_images // world)
+        return np.minimum(np.arange(n_images) // per, world - 1).astype(np.int32)
+    return (np.arange(n_images) % world).astype(np.int32)
+
+
+def stripe_of_ranks(w, h, h9s, owner, world):
+    """which canvas stripe each rank renders: the ranks in the order of the mean canvas row of the frames they hold (frame centres through the
+    replicated transforms), so that a rank's stripe lies where its own frames are.  Pure host geometry on replicated data: the same answer on
+    every rank.  Returns stripe[rank]."""
+    h9s = np.asarray(h9s, np.float64).reshape(-1, 9)
+    owner = np.asarray(owner)
+    cx, cy = (np.asarray(w, np.float64) - 1) / 2, (np.asarray(h, np.float64) - 1) / 2
+    den = h9s[:, 6] * cx + h9s[:, 7] * cy + h9s[:, 8]
+    valid = h9s[:, 8] != 0
+    y = np.where(valid, (h9s[:, 3] * cx + h9s[:, 4] * cy + h9s[:, 5]) / np.where(valid, den, 1.0), 0.0)
+    mean_y = np.array([y[(owner == r) & valid].mean() if ((owner == r) & valid).any() else np.inf for r in range(world)])
+    order = np.argsort(mean_y, kind="stable")          # order[s] = the rank that takes stripe s
+    stripe = np.empty(world, np.int64)
+    stripe[order] = np.arange(world)
+    return stripe
 
 
 def init_comm(ctx, group=None):
@@ -190,9 +222,9 @@ class Exchange:
             return np.zeros(0, PAIR_RESULT)
         return gathered_to_records(g, counts)
 
-    def stripe_need(self, w, h, h9s, stripes, blended=False, keep=None, band=5):
+    def stripe_need(self, w, h, h9s, stripes, blended=False, keep=None, band=5, exact=False):
         """the G x n table of mi355_exchange_frames: row r = the frames rank r's stripe (row0, rows) reads; the same on every rank"""
-        return np.stack([self.ctx.StripeCover(w, h, h9s, r0, nr, blended=blended, keep=keep, band=band) for (r0, nr) in stripes])
+        return np.stack([self.ctx.StripeCover(w, h, h9s, r0, nr, blended=blended, keep=keep, band=band, exact=exact) for (r0, nr) in stripes])
 
     def exchange_frames(self, frames, h, ws, need, owner=None, own_through_rccl=False):
         """frames: per frame a torch uint8 device tensor where this rank holds it, else None.  Every frame this rank's stripe reads
@@ -202,6 +234,17 @@ class Exchange:
         need = np.ascontiguousarray(need, np.uint8)
         if self.transport == "rccl":
             return self.ctx.ExchangeFrames([f.data_ptr() if f is not None else 0 for f in frames], h, ws, need, owner=owner, own_through_rccl=own_through_rccl)
+        if need.ndim == 1:                             # this rank's own row: the rows of all ranks are gathered first
+            if self.world > 1:
+                rows = [torch.zeros(n, dtype=torch.uint8) for _ in range(self.world)]
+                mine = torch.from_numpy(need.copy())
+                if dist.get_backend() == "nccl":
+                    dev = torch.device("cuda", torch.cuda.current_device())
+                    rows = [r.to(dev) for r in rows]; mine = mine.to(dev)
+                dist.all_gather(rows, mine)
+                need = np.stack([r.cpu().numpy() for r in rows])
+            else:
+                need = need[None, :]
         own = (lambda k: int(owner[k])) if owner is not None else (lambda k: k % self.world)
         self._recv_frames = {}
         out, br, bs = [0] * n, 0, 0

@@ -366,10 +366,19 @@ int  mi355_global_affine_align_moments(const mi355_pair_moments* m, int n, int n
  * A rank uploads and holds only the frames it extracts (k mod G == rank, MosaicWithoutPos.cpp:4861).  After the (replicated) alignment
  * every rank knows every rank's canvas stripe and therefore which frames each stripe reads; a frame a stripe reads and its rank does not
  * hold is sent by its owner over xGMI.  Replaces "every rank holds all N frames" (72 GB per GPU at C5; 8 x the PCIe upload). */
-/* need[k] = 1 when rendering canvas rows [row0, row0 + rows) reads frame k: exactly the frames mi355_mosaic_refined_dev (blended == 0) or
- * mi355_mosaic_blended_rows_dev (blended != 0: keep, band as there; chips that reach the rows plus the blender pyramids' reach) dereference
- * for these arguments -- computed by the same code paths with the device work left out.  Host geometry; ctx only carries the error text. */
-int  mi355_mosaic_stripe_cover(mi355_ctx* ctx, int blended, const int* w, const int* h, int n, const float* h9s, const uint8_t* keep, int band,
+/* need[k] = 1 when rendering canvas rows [row0, row0 + rows) reads frame k.  mode:
+ *   MI355_COVER_REFINED        mi355_mosaic_refined_dev, by host geometry alone: every frame whose clipped canvas box meets the rows (a superset
+ *                              of what is read: a frame lying entirely under later frames is in it);
+ *   MI355_COVER_BLENDED        mi355_mosaic_blended_rows_dev (keep, band as there): the chips that reach the rows plus the blender pyramids' reach;
+ *   MI355_COVER_REFINED_EXACT  mi355_mosaic_refined_dev, exactly: the frames that GIVE at least one pixel of the rows its sample -- the tile
+ *                              kernel's own walk (descending image index, first valid sample wins, MosaicWithoutPos.cpp:2254-2348 read backwards)
+ *                              with its loads and stores left out, one extra launch and a 4-bytes-per-frame copy back; at C5, where ~60 frames
+ *                              cover a canvas pixel, a stripe reads 300-340 frames of the 640 whose boxes meet it.
+ * Every mode runs the stripe call's own code path with the pixel work left out, so the list cannot drift from what the call dereferences. */
+#define MI355_COVER_REFINED       0
+#define MI355_COVER_BLENDED       1
+#define MI355_COVER_REFINED_EXACT 2
+int  mi355_mosaic_stripe_cover(mi355_ctx* ctx, int mode, const int* w, const int* h, int n, const float* h9s, const uint8_t* keep, int band,
                                int row0, int rows, uint8_t* need);
 /* The exchange.  d_frames[k]: this rank's device pointer of frame k where it holds it (owner[k] == its rank; owner == NULL: k mod G), else
  * ignored.  need: G x n bytes, need[r * n + k] != 0 = rank r's stripe reads frame k (mi355_mosaic_stripe_cover with rank r's rows); the SAME
@@ -380,6 +389,9 @@ int  mi355_mosaic_stripe_cover(mi355_ctx* ctx, int blended, const int* w, const 
  * flags: MI355_EXCHANGE_OWN_THROUGH_RCCL also routes the rank's own needed frames through ncclSend / ncclRecv to itself (a communicator
  * of one rank then exercises the whole path: tests).  bytes_recv / bytes_sent (NULL allowed): this rank's traffic.  Enqueued on the ctx stream. */
 #define MI355_EXCHANGE_OWN_THROUGH_RCCL 1
+/* MI355_EXCHANGE_NEED_IS_LOCAL: `need` holds n bytes, this rank's OWN row (what its stripe reads, e.g. from MI355_COVER_REFINED_EXACT on its
+ * own device); the call all-gathers the rows of all ranks first (n bytes per rank). */
+#define MI355_EXCHANGE_NEED_IS_LOCAL   2
 int  mi355_exchange_frames(mi355_ctx* ctx, const uint8_t* const* d_frames, const int* h, const int* ws, int n, const int32_t* owner,
                            const uint8_t* need, int flags, const uint8_t** d_out, uint64_t* bytes_recv, uint64_t* bytes_sent);
 

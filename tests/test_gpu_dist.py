@@ -90,6 +90,23 @@ WORKER = textwrap.dedent("""
     ptrs, br, bs = ex.exchange_frames(held, hv, wsv, need)
     assert br > 0 and bs > 0, (br, bs)
     assert all((p != 0) == bool(need[rank, k]) for k, p in enumerate(ptrs))
+    # the same with frames owned in blocks, the stripes dealt out to where a rank's frames are, and every rank contributing only ITS exact row
+    owner_b = md.frame_owner(F, world, "blocks")
+    held_b = [frames[k] if owner_b[k] == rank else None for k in range(F)]
+    sidx = md.stripe_of_ranks(wv, hv, Hgt, owner_b, world)
+    assert sorted(sidx.tolist()) == list(range(world))
+    r0b, nrb = stripes[int(sidx[rank])]
+    row_b = ctx.StripeCover(wv, hv, Hgt, r0b, nrb, exact=True)
+    pb, brb, bsb = ex.exchange_frames(held_b, hv, wsv, row_b, owner=owner_b)
+    assert all((p != 0) == bool(row_b[k]) for k, p in enumerate(pb))
+    ab = torch.zeros(ch * cws, dtype=torch.uint8, device="cuda"); bb_ = torch.zeros(ch * cws, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    ctx.MosaicImagesRefinedDev(pb, wv, hv, wsv, Hgt, ab.data_ptr(), cw, ch, cws, r0b, nrb)
+    ctx.MosaicImagesRefinedDev(full_ptr, wv, hv, wsv, Hgt, bb_.data_ptr(), cw, ch, cws, r0b, nrb)
+    ctx.synchronize()
+    assert torch.equal(ab, bb_), "stripe from block-owned frames + exact cover rows differs from the replicas' stripe"
+    tb = torch.tensor([brb, bsb], dtype=torch.int64); dist.all_reduce(tb)
+    assert int(tb[0]) == int(tb[1])
     row0, rows = stripes[rank]
     a = torch.zeros(ch * cws, dtype=torch.uint8, device="cuda"); b = torch.zeros(ch * cws, dtype=torch.uint8, device="cuda")
     torch.cuda.synchronize()
@@ -220,7 +237,7 @@ def test_compaction_of_accepted_records_keeps_order_at_every_size():
 
 def test_stripe_cover_is_exactly_what_the_stripe_calls_read():
     """mi355_mosaic_stripe_cover (the table mi355_exchange_frames is driven by): the stripe calls succeed and give the whole canvas's rows
-    with every frame OUTSIDE the cover withheld (pointer 0), and fail when a frame INSIDE it is withheld -- for the last-write-wins canvas
+    with every frame OUTSIDE the cover withheld (pointer 0), and fail when a frame INSIDE the (exact) cover is withheld -- for the last-write-wins canvas
     (MosaicWithoutPos.cpp:2194) and for the blended one (MosaicImage.cpp:2205), at several cuts"""
     import torch
     import imagemosaicing_amd as im
@@ -240,7 +257,7 @@ def test_stripe_cover_is_exactly_what_the_stripe_calls_read():
     whole = whole.reshape(ch, cws)
     keep = im.resample_by_overlap(wv, hv, H, 0.7)
     bwhole, bw_, bh_, bws_ = ctx.MosaicBlendedDev(full, wv, hv, wsv, H, keep=keep, band=5)
-    some_partial = False
+    some_partial = some_exact_smaller = False
     for G in (2, 3, 5):
         for r in range(G):
             row0, rows = (ch * r) // G, (ch * (r + 1)) // G - (ch * r) // G
@@ -253,10 +270,20 @@ def test_stripe_cover_is_exactly_what_the_stripe_calls_read():
             ctx.MosaicImagesRefinedDev(ptrs, wv, hv, wsv, H, out.data_ptr(), cw, ch, cws, row0, rows)
             ctx.synchronize()
             assert torch.equal(out.reshape(ch, cws)[row0:row0 + rows], whole[row0:row0 + rows])
-            k_in = int(np.flatnonzero(need)[0])
-            ptrs[k_in] = 0
+            # the exact cover (the frames that GIVE a pixel of these rows its sample: the tile kernel's walk without its loads) is a subset of the
+            # box cover, and the stripe needs nothing else
+            exact = ctx.StripeCover(wv, hv, H, row0, rows, exact=True)
+            assert (exact <= need).all() and exact.sum() > 0
+            some_exact_smaller |= bool(exact.sum() < need.sum())
+            pe = [full[k] if exact[k] else 0 for k in range(F)]
+            out2 = torch.zeros(ch * cws, dtype=torch.uint8, device="cuda")
+            torch.cuda.synchronize()
+            ctx.MosaicImagesRefinedDev(pe, wv, hv, wsv, H, out2.data_ptr(), cw, ch, cws, row0, rows)
+            ctx.synchronize()
+            assert torch.equal(out2.reshape(ch, cws)[row0:row0 + rows], whole[row0:row0 + rows])
+            pe[int(np.flatnonzero(exact)[-1])] = 0                      # ... and nothing less: the kernel names the frame it misses
             with pytest.raises(im.Mi355Error):
-                ctx.MosaicImagesRefinedDev(ptrs, wv, hv, wsv, H, out.data_ptr(), cw, ch, cws, row0, rows)
+                ctx.MosaicImagesRefinedDev(pe, wv, hv, wsv, H, out2.data_ptr(), cw, ch, cws, row0, rows)
             # blended
             b0, brows = (bh_ * r) // G, (bh_ * (r + 1)) // G - (bh_ * r) // G
             bneed = ctx.StripeCover(wv, hv, H, b0, brows, blended=True, keep=keep, band=5)
@@ -267,7 +294,7 @@ def test_stripe_cover_is_exactly_what_the_stripe_calls_read():
             bp[int(np.flatnonzero(bneed)[-1])] = 0
             with pytest.raises(im.Mi355Error):
                 ctx.MosaicBlendedDev(bp, wv, hv, wsv, H, keep=keep, band=5, row0=b0, rows=brows)
-    assert some_partial                                                 # the cuts really left frames out
+    assert some_partial and some_exact_smaller                          # the cuts really left frames out, and the exact lists are shorter than the box lists somewhere
     ctx.close()
 
 
@@ -309,6 +336,16 @@ def test_owner_only_frames_plus_exchange_equal_replicas_rccl_world1():
     o1, _, _, _ = ctx.MosaicBlendedDev(bp, wv, hv, wsv, H, keep=keep, band=5, row0=b0, rows=brows)
     o2, _, _, _ = ctx.MosaicBlendedDev(full, wv, hv, wsv, H, keep=keep, band=5, row0=b0, rows=brows)
     assert torch.equal(o1, o2) and int(o1.count_nonzero()) > 0
+    # the rank's own row alone (exact cover from its own device): the rows are all-gathered inside the call (n bytes per rank)
+    exact = ctx.StripeCover(wv, hv, H, row0, rows, exact=True)
+    assert (exact <= need[0]).all()
+    pl, _, _ = ex.exchange_frames([frames[k] for k in range(F)], hv, wsv, exact, own_through_rccl=True)
+    assert all((p != 0) == bool(exact[k]) for k, p in enumerate(pl))
+    a2 = torch.zeros(ch * cws, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    ctx.MosaicImagesRefinedDev(pl, wv, hv, wsv, H, a2.data_ptr(), cw, ch, cws, row0, rows)
+    ctx.synchronize()
+    assert torch.equal(a2, b)
     # without the flag the rank's own frames are handed back as they are
     p2, _, _ = ex.exchange_frames([frames[k] for k in range(F)], hv, wsv, need)
     assert all(p == (full[k] if need[0, k] else 0) for k, p in enumerate(p2))
