@@ -399,7 +399,7 @@ extern "C" int mi355_set_option(mi355_ctx* ctx, const char* name, int value) {
         return MI355_OK;
     }
     {
-        struct { const char* n; int* p; } knobs[] = {{"ransac_split", &ctx->ransac_split}};
+        struct { const char* n; int* p; } knobs[] = {{"ransac_split", &ctx->ransac_split}, {"strict_frames", &ctx->strict_frames}};
         for (auto& k : knobs) if (std::string(name) == k.n) { *k.p = value; return MI355_OK; }
     }
     if (std::string(name) == "sift_flush") return mi_sift_flush(ctx);      // close the batch that is collecting frames now (no wait): the caller shapes the batches of a short survey

@@ -134,6 +134,7 @@ struct mi355_ctx {
     int sift_nslots = 3;                               // batch work areas in flight, each on its own stream (option "sift_slots", env MI355_SIFT_SLOTS)
     int xstream_min_w = 1500, xstream_min_frames = 4;  // extrema_stream for octaves at least this wide (and 3/4 as high) in batches of at least so many frames
     int sift_batch = 16;                               // frames per batch (option "sift_batch", env MI355_SIFT_BATCH)
+    int strict_frames = 0;                             // warp.hip: check that a stripe call reads none of the images it was given no pointer for (option "strict_frames": one extra cover pass per call)
     int ransac_split = -1;                             // ransac.hip: workgroups per pair when there are few pairs (-1: by the pair count, 0: never, k: k); option "ransac_split", env MI355_RANSAC_SPLIT
     hipEvent_t sift_in_ev = nullptr;                   // orders the SIFT streams after the caller's stream
     std::vector<int*> pinned_chunks;                   // pinned count slots, 8 ints per frame

@@ -297,9 +297,6 @@ __global__ __launch_bounds__(256) void mosaic_tile_kernel(const FrameDev* fr, in
                 const bool ok = want && (xs >= 0.0f && xs < w1 && ys >= 0.0f && ys < h1);      // also rejects NaN
                 if (!ok) continue;
                 if constexpr (COVER) { used[list[e]] = 1; open &= ~(1u << (4 * j + k)); continue; }
-                // a frame the caller holds no copy of (exact cover lists: a frame whose box meets the rows but which lies under later frames
-                // everywhere there is never asked for): if it is asked for after all, say which one -- the host turns that into an error
-                if (f.src == nullptr) { *used = 1 + (int)list[e]; continue; }
                 const int xi = (int)xs, yi = (int)ys;
                 const float p = ys - (float)yi, q = xs - (float)xi;
                 float b00, g00, r00, b01, g01, r01, b10, g10, r10, b11, g11, r11;
@@ -353,7 +350,7 @@ int mi_mosaic_refined_dev(mi355_ctx* ctx, const uint8_t* const* d_imgs, const in
     if (rows <= 0) return MI355_OK;
     if (n > 65535) { ctx->set_error("mosaic_refined: at most 65535 images"); return MI355_ERR_ARG; }
     std::vector<FrameDev> fr;
-    std::vector<int> frame_of;                     // image index of fr[q]
+    std::vector<int> frame_of, withheld;           // image index of fr[q]; images whose box meets the rows and that came without a pointer
     fr.reserve(n);
     for (int k = 0; k < n; k++) {                  // ascending image order = overwrite order (MosaicWithoutPos.cpp:2254)
         const float* m = h9s + 9 * k;
@@ -386,13 +383,23 @@ int mi_mosaic_refined_dev(mi355_ctx* ctx, const uint8_t* const* d_imgs, const in
         if (endX < begX || endY < begY) continue;
         if (cover_only && !cover_exact) { cover_only[k] = 1; continue; }
         if (w[k] < 2 || h[k] < 2 || ws[k] < 3 * w[k]) { ctx->set_error("mosaic_refined: bad image geometry"); return MI355_ERR_ARG; }
-        f.src = cover_only ? nullptr : d_imgs[k]; f.w = w[k]; f.h = h[k]; f.ws = ws[k];      // NULL: the kernel reports it if the rows do read the frame
+        // d_imgs[k] == NULL: the caller holds no copy of this image (owner-only frames, mi355_exchange_frames): it says the rows do not read
+        // it -- which is true of a frame that lies under later frames wherever its box meets the rows (MI355_COVER_REFINED_EXACT lists what
+        // IS read).  Such a frame is left out of the walk; with option "strict_frames" the statement is checked first (one cover pass).
+        if (!cover_only && !d_imgs[k]) { withheld.push_back(k); continue; }
+        f.src = cover_only ? nullptr : d_imgs[k]; f.w = w[k]; f.h = h[k]; f.ws = ws[k];
         frame_of.push_back(k);
         f.begX = begX; f.endX = endX; f.begY = begY; f.endY = endY;
         f.unit_den = (f.inv[6] == 0.0f && f.inv[7] == 0.0f && f.inv[8] == 1.0f) ? 1 : 0;
         fr.push_back(f);
     }
     if (cover_only && !cover_exact) return MI355_OK;
+    if (!withheld.empty() && ctx->strict_frames) {       // the caller's statement "these rows do not read the images I withhold", checked: one cover pass
+        std::vector<uint8_t> read((size_t)n, 0);
+        const int rc2 = mi_mosaic_refined_dev(ctx, d_imgs, w, h, ws, n, h9s, nullptr, cw, ch, cws, row0, rows, read.data(), 1);
+        if (rc2 != MI355_OK) return rc2;
+        for (int k : withheld) if (read[k]) { ctx->set_error("mosaic_refined: these canvas rows read image " + std::to_string(k) + " but no pointer to it was given"); return MI355_ERR_ARG; }
+    }
     const int nf = (int)fr.size();
     if (cover_only && nf == 0) return MI355_OK;
     const int bx_n = (cw + MT_COARSE - 1) / MT_COARSE, by_n = (rows + MT_COARSE - 1) / MT_COARSE;
@@ -417,22 +424,16 @@ int mi_mosaic_refined_dev(mi355_ctx* ctx, const uint8_t* const* d_imgs, const in
         for (int q = 0; q < nf; q++) if (used[q]) cover_only[frame_of[q]] = 1;
         return MI355_OK;
     }
-    DevBuf& derr = ctx->buf("mosaic_missing");
-    MI_HIP(derr.reserve(sizeof(int)));
-    MI_HIP(hipMemsetAsync(derr.p, 0, sizeof(int), ctx->stream));
     {
         // SURVEY 8(d) algorithmic figure: every image read once and written once (6 P per image)
         double bytes = 0.0;
         for (const FrameDev& f : fr) bytes += 6.0 * (double)f.w * f.h;
         ProfScope ps(ctx, "warp", bytes);
         hipLaunchKernelGGL(mosaic_tile_kernel<false>, dim3((cw + MT_W - 1) / MT_W, (rows + MT_H - 1) / MT_H), dim3(256), 0, ctx->stream,
-                           dfr.as<FrameDev>(), nf, dl.as<uint16_t>(), dc.as<int>(), bx_n, d_canvas, cw, cws, row0, row0 + rows, dG[0], dG[1], derr.as<int>());
+                           dfr.as<FrameDev>(), nf, dl.as<uint16_t>(), dc.as<int>(), bx_n, d_canvas, cw, cws, row0, row0 + rows, dG[0], dG[1], (int*)nullptr);
     }
     MI_HIP(hipGetLastError());
-    int missing = 0;
-    MI_HIP(hipMemcpyAsync(&missing, derr.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     MI_HIP(hipStreamSynchronize(ctx->stream));           // `fr` goes out of scope
-    if (missing) { ctx->set_error("mosaic_refined: these canvas rows read image " + std::to_string(frame_of[missing - 1]) + " but no pointer to it was given"); return MI355_ERR_ARG; }
     return MI355_OK;
 }
 

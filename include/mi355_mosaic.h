@@ -168,6 +168,10 @@ int  mi355_mosaic_layout(const int* w, const int* h, int n, const float* h9s, in
 /* Device-resident form: d_imgs[k] and d_canvas are device pointers; canvas must hold cws*ch bytes and is
  * zeroed by the call.  Only canvas rows [row0, row0+rows) are rendered (canvas stripes for multi-GPU,
  * SURVEY 8e); pass 0, ch for the whole canvas. */
+/* d_imgs[k] == NULL: the caller holds no copy of image k and thereby states that these rows do not read it (owner-only frames: the pointers
+ * mi355_exchange_frames returns; true of an image that lies under later ones wherever its box meets the rows, MI355_COVER_REFINED_EXACT); the
+ * image is left out of the walk.  mi355_set_option("strict_frames", 1) checks the statement first (one extra pass) and names an image that is
+ * read after all (MI355_ERR_ARG). */
 int  mi355_mosaic_refined_dev(mi355_ctx* ctx, const uint8_t* const* d_imgs, const int* w, const int* h, const int* ws, int n,
                               const float* h9s, uint8_t* d_canvas, int cw, int ch, int cws, int row0, int rows);
 

@@ -90,7 +90,14 @@ WORKER = textwrap.dedent("""
     ptrs, br, bs = ex.exchange_frames(held, hv, wsv, need)
     assert br > 0 and bs > 0, (br, bs)
     assert all((p != 0) == bool(need[rank, k]) for k, p in enumerate(ptrs))
-    # the same with frames owned in blocks, the stripes dealt out to where a rank's frames are, and every rank contributing only ITS exact row
+    row0, rows = stripes[rank]
+    a = torch.zeros(ch * cws, dtype=torch.uint8, device="cuda"); b = torch.zeros(ch * cws, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    ctx.MosaicImagesRefinedDev(ptrs, wv, hv, wsv, Hgt, a.data_ptr(), cw, ch, cws, row0, rows)
+    ctx.MosaicImagesRefinedDev(full_ptr, wv, hv, wsv, Hgt, b.data_ptr(), cw, ch, cws, row0, rows)
+    ctx.synchronize()
+    assert torch.equal(a, b) and int(a.count_nonzero()) > 0, "refined stripe from owner-only frames + exchange differs from the replicas' stripe"
+    # (received copies live until the next exchange: the stripe above was rendered first)  The same with frames owned in blocks, the stripes dealt out to where a rank's frames are, and every rank contributing only ITS exact row
     owner_b = md.frame_owner(F, world, "blocks")
     held_b = [frames[k] if owner_b[k] == rank else None for k in range(F)]
     sidx = md.stripe_of_ranks(wv, hv, Hgt, owner_b, world)
@@ -107,13 +114,6 @@ WORKER = textwrap.dedent("""
     assert torch.equal(ab, bb_), "stripe from block-owned frames + exact cover rows differs from the replicas' stripe"
     tb = torch.tensor([brb, bsb], dtype=torch.int64); dist.all_reduce(tb)
     assert int(tb[0]) == int(tb[1])
-    row0, rows = stripes[rank]
-    a = torch.zeros(ch * cws, dtype=torch.uint8, device="cuda"); b = torch.zeros(ch * cws, dtype=torch.uint8, device="cuda")
-    torch.cuda.synchronize()
-    ctx.MosaicImagesRefinedDev(ptrs, wv, hv, wsv, Hgt, a.data_ptr(), cw, ch, cws, row0, rows)
-    ctx.MosaicImagesRefinedDev(full_ptr, wv, hv, wsv, Hgt, b.data_ptr(), cw, ch, cws, row0, rows)
-    ctx.synchronize()
-    assert torch.equal(a, b) and int(a.count_nonzero()) > 0, "refined stripe from owner-only frames + exchange differs from the replicas' stripe"
     # (b) LaplacianPyramidBlending stripes (chips that reach the rows + the pyramids' reach)
     keep = im.resample_by_overlap(wv, hv, Hgt, 0.7)
     bw_, bh_, _ = im.blend_layout(wv, hv, Hgt, keep)
@@ -281,9 +281,11 @@ def test_stripe_cover_is_exactly_what_the_stripe_calls_read():
             ctx.MosaicImagesRefinedDev(pe, wv, hv, wsv, H, out2.data_ptr(), cw, ch, cws, row0, rows)
             ctx.synchronize()
             assert torch.equal(out2.reshape(ch, cws)[row0:row0 + rows], whole[row0:row0 + rows])
-            pe[int(np.flatnonzero(exact)[-1])] = 0                      # ... and nothing less: the kernel names the frame it misses
+            pe[int(np.flatnonzero(exact)[-1])] = 0                      # ... and nothing less: with the check switched on the call names the frame it misses
+            ctx.set_option("strict_frames", 1)
             with pytest.raises(im.Mi355Error):
                 ctx.MosaicImagesRefinedDev(pe, wv, hv, wsv, H, out2.data_ptr(), cw, ch, cws, row0, rows)
+            ctx.set_option("strict_frames", 0)
             # blended
             b0, brows = (bh_ * r) // G, (bh_ * (r + 1)) // G - (bh_ * r) // G
             bneed = ctx.StripeCover(wv, hv, H, b0, brows, blended=True, keep=keep, band=5)
