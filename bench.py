@@ -41,7 +41,7 @@ sys.path.insert(0, ROOT)
 DOM = "gauss_stream"       # profile class of the dominant kernel (blur16_stream): the only launches bracketed with events in the timed region
 SLOTS = int(os.environ.get("MI355_BENCH_SLOTS", "3"))   # batch work areas in flight (library default 3)
 BATCH = int(os.environ.get("MI355_BENCH_BATCH", "0"))   # frames per batch; 0 = chosen in main(): 32 (library default 16) unless the survey needs the HBM (C5, --blend)
-PMC_JSON = "r05_pmc_blur16_stream.json"   # committed rocprofv3 --pmc passes of this command (profiles/pmc_traffic.py)
+PMC_JSON = "r06_pmc_blur16_stream.json"   # committed rocprofv3 --pmc passes of this command (profiles/pmc_traffic.py)
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md (6.29 TB/s measured copy)
 VALU_PEAK_TOPS = 78.65     # f32 vector multiplies OR adds per second (T lane-operations/s): the 157.3 TFLOP/s vector peak counts an fma as two
 
