@@ -950,7 +950,7 @@ def main():
             out["roofline"] = dict(ransac_roof, dominant_because="ransac_kernel %.1f ms per step against %.1f ms of blur16_stream (exclusive pass)" % (ransac_roof["ms_per_step"], blur_step_ms))
         if state.get("frame_exchange"):
             out["frame_exchange_rank0"] = state["frame_exchange"]
-        out["frames_resident"] = ("owned (k mod N) + mi355_exchange_frames per step" if owned_only else "all frames on every rank") if world > 1 and strong else "single GPU"
+        out["frames_resident"] = (("owned (%s) + mi355_exchange_frames per step" % ("blocks of ceil(F/N)" if args.frame_owner == "blocks" else "k mod N")) if owned_only else "all frames on every rank") if world > 1 and strong else "single GPU"
         out["align_input"] = align_input + (" + records to rank 0's host (mi355_allgather_results root = 0, not waited for inside the step's host path)" if records_to_root else "")
     # ---- CPU baseline: rank 0 at N=1 only, bounded sample; its pairs double as a parity sample for the GPU records ----
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
