@@ -768,7 +768,7 @@ def main():
         if i_ms > 0:
             iso = {"achieved": (i_bytes / 1e9) / (i_ms / 1e3), "frac": (i_bytes / 1e9) / (i_ms / 1e3) / HBM_PEAK_GBS, "frames": nf_iso, "dominant_kernel_ms": i_ms,
                    "launches": int(i_n), "avg_launch_us": i_ms * 1e3 / max(i_n, 1),
-                   "note": "one batch work area in flight: no other kernel on the chip while a bracketed launch runs (what rocprofv3 --kernel-trace of scratch/sift_time.py ... serial reports: profiles/r05_rocprofv3_kernel_stats_serial_pass.txt), untimed extra pass"}
+                   "note": "one batch work area in flight: no other kernel on the chip while a bracketed launch runs (what rocprofv3 --kernel-trace of scratch/sift_time.py ... serial reports: profiles/r06_rocprofv3_kernel_stats_serial_pass.txt), untimed extra pass"}
 
     # quality of the last step against ground truth (accepted pairs): corner transfer error in pixels
     ctx.synchronize()
