@@ -602,26 +602,44 @@ extern "C" int mi355_exchange_frames(mi355_ctx* ctx, const uint8_t* const* d_fra
         for (int r = 0; r < world; r++) memcpy(table.data() + (size_t)r * n, padded.data() + row * r, (size_t)n);
         need = table.data();
     }
-    // this rank's landing area: one slot per frame it receives.  Everything that can fail on this rank alone is checked BEFORE the first
-    // transfer is posted (a rank that left early would leave its peers waiting inside ncclRecv); the table itself is the same everywhere.
+    // this rank's landing area: one slot per frame it receives.  Everything that can fail on this rank alone happens in `local`, BEFORE the
+    // first transfer is posted, and its verdict is all-gathered (one int per rank): a rank that left early would leave its peers waiting
+    // inside ncclRecv -- like the other exchanges, every rank returns the error together.
     std::vector<size_t> slot(n > 0 ? n : 1, (size_t)-1);
     size_t arena = 0;
     uint64_t rb = 0, sb = 0;
-    for (int k = 0; k < n; k++) {
-        const int o = own(k);
-        if (o < 0 || o >= world || h[k] < 1 || ws[k] < 1) { ctx->set_error("exchange_frames: bad owner / geometry of frame " + std::to_string(k)); return MI355_ERR_ARG; }
-        const size_t bytes = (size_t)ws[k] * h[k];
-        d_out[k] = nullptr;
-        bool sends = false;
-        for (int r = 0; r < world; r++) if (need[(size_t)r * n + k] && (r != o || own_too) && o == rank) { sends = true; if (r != rank) sb += bytes; }
-        if ((sends || (need[(size_t)rank * n + k] && o == rank)) && !d_frames[k]) { ctx->set_error("exchange_frames: this rank owns frame " + std::to_string(k) + " but holds no pointer to it"); return MI355_ERR_ARG; }
-        if (!need[(size_t)rank * n + k]) continue;
-        if (o == rank && !own_too) { d_out[k] = d_frames[k]; continue; }
-        slot[k] = arena; arena += (bytes + 255) & ~(size_t)255;
-        if (o != rank) rb += bytes;
-    }
     DevBuf& dar = ctx->buf("frame_exchange");
-    MI_HIP(dar.reserve(arena + 256));
+    auto local = [&]() -> int {
+        for (int k = 0; k < n; k++) {
+            const int o = own(k);
+            if (o < 0 || o >= world || h[k] < 1 || ws[k] < 1) { ctx->set_error("exchange_frames: bad owner / geometry of frame " + std::to_string(k)); return MI355_ERR_ARG; }
+            const size_t bytes = (size_t)ws[k] * h[k];
+            d_out[k] = nullptr;
+            bool sends = false;
+            for (int r = 0; r < world; r++) if (need[(size_t)r * n + k] && (r != o || own_too) && o == rank) { sends = true; if (r != rank) sb += bytes; }
+            if ((sends || (need[(size_t)rank * n + k] && o == rank)) && !d_frames[k]) { ctx->set_error("exchange_frames: this rank owns frame " + std::to_string(k) + " but holds no pointer to it"); return MI355_ERR_ARG; }
+            if (!need[(size_t)rank * n + k]) continue;
+            if (o == rank && !own_too) { d_out[k] = d_frames[k]; continue; }
+            slot[k] = arena; arena += (bytes + 255) & ~(size_t)255;
+            if (o != rank) rb += bytes;
+        }
+        MI_HIP(dar.reserve(arena + 256));
+        return MI355_OK;
+    };
+    const int rc_local = local();
+    const std::string err_local = rc_local != MI355_OK ? ctx->err : std::string();
+    {
+        DevBuf& dst = ctx->buf("frame_exchange_status");
+        MI_HIP(dst.reserve(sizeof(int) * (size_t)(world + 1)));
+        const int mine = rc_local;
+        MI_HIP(hipMemcpyAsync(dst.as<int>() + rank, &mine, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+        MI_NCCL(api->AllGather(dst.as<int>() + rank, dst.p, sizeof(int), ncclChar, ctx->comm->comm, ctx->stream));
+        std::vector<int> st(world);
+        MI_HIP(hipMemcpyAsync(st.data(), dst.p, sizeof(int) * (size_t)world, hipMemcpyDeviceToHost, ctx->stream));
+        MI_HIP(hipStreamSynchronize(ctx->stream));
+        if (rc_local != MI355_OK) { ctx->set_error(err_local); return rc_local; }
+        for (int r = 0; r < world; r++) if (st[r] != MI355_OK) { ctx->set_error("exchange_frames: rank " + std::to_string(r) + " failed before the exchange"); return MI355_ERR_FAILED; }
+    }
     for (int k = 0; k < n; k++) if (slot[k] != (size_t)-1) d_out[k] = dar.as<uint8_t>() + slot[k];
     constexpr int RUN = 64;                               // frames per ncclGroup: bounds the operations one group carries (C5: ~480 receives per rank in all)
     for (int k0 = 0; k0 < n; k0 += RUN) {

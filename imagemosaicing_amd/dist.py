@@ -153,6 +153,52 @@ def allgather_feature_records(hdr, payload, n_max=None):
     return hdrs, gp, counts
 
 
+def exchange_frames_torch(frames, h, ws, need, owner, rank, world):
+    """torch.distributed transport of mi355_exchange_frames (gloo CPU tests, 2-rank dry runs on one device): the same table, walked in
+    the same order by every rank -- owner sends, reader receives, frame after frame (a total order: no two ranks ever wait for each other
+    crosswise).  frames: per frame a uint8 tensor (any device) where this rank holds it, else None; need: [G, n] table or this rank's own
+    [n] row (then the rows are all-gathered first).  Returns (pointers, bytes received, bytes sent, {frame: received tensor})."""
+    n = len(frames)
+    need = np.ascontiguousarray(need, np.uint8)
+    nccl = dist.is_initialized() and dist.get_backend() == "nccl"
+    dev = next((f.device for f in frames if f is not None), torch.device("cpu"))
+    if need.ndim == 1:                                 # this rank's own row: the rows of all ranks are gathered first
+        if world > 1:
+            rows = [torch.zeros(n, dtype=torch.uint8) for _ in range(world)]
+            mine = torch.from_numpy(need.copy())
+            if nccl:
+                rows = [r.to(dev) for r in rows]; mine = mine.to(dev)
+            dist.all_gather(rows, mine)
+            need = np.stack([r.cpu().numpy() for r in rows])
+        else:
+            need = need[None, :]
+    own = (lambda k: int(owner[k])) if owner is not None else (lambda k: k % world)
+    recv = {}
+    out, br, bs = [0] * n, 0, 0
+    for k in range(n):
+        o = own(k)
+        nbytes = int(ws[k]) * int(h[k])
+        if need[rank, k] and o == rank:
+            out[k] = frames[k].data_ptr()
+        for r in range(world):
+            if not need[r, k] or r == o:
+                continue
+            if rank == o:
+                t = frames[k].reshape(-1)[:nbytes]
+                dist.send(t if nccl else t.cpu(), dst=r)
+                bs += nbytes
+            elif rank == r:
+                buf = torch.empty(nbytes, dtype=torch.uint8, device=dev if nccl else "cpu")
+                dist.recv(buf, src=o)
+                buf = buf.to(dev)
+                recv[k] = buf
+                out[k] = buf.data_ptr()
+                br += nbytes
+    if dev.type == "cuda":
+        torch.cuda.current_stream(dev).synchronize()  # the ctx stream may be another one: the copies must have landed
+    return out, br, bs, recv
+
+
 class Exchange:
     """The two exchanges of one rank's ctx.  transport "rccl": the library's own collectives on the ctx's communicator
     (init_comm); "torch": torch.distributed moves the same records.
@@ -234,42 +280,7 @@ class Exchange:
         need = np.ascontiguousarray(need, np.uint8)
         if self.transport == "rccl":
             return self.ctx.ExchangeFrames([f.data_ptr() if f is not None else 0 for f in frames], h, ws, need, owner=owner, own_through_rccl=own_through_rccl)
-        if need.ndim == 1:                             # this rank's own row: the rows of all ranks are gathered first
-            if self.world > 1:
-                rows = [torch.zeros(n, dtype=torch.uint8) for _ in range(self.world)]
-                mine = torch.from_numpy(need.copy())
-                if dist.get_backend() == "nccl":
-                    dev = torch.device("cuda", torch.cuda.current_device())
-                    rows = [r.to(dev) for r in rows]; mine = mine.to(dev)
-                dist.all_gather(rows, mine)
-                need = np.stack([r.cpu().numpy() for r in rows])
-            else:
-                need = need[None, :]
-        own = (lambda k: int(owner[k])) if owner is not None else (lambda k: k % self.world)
-        self._recv_frames = {}
-        out, br, bs = [0] * n, 0, 0
-        for k in range(n):
-            o = own(k)
-            nbytes = int(ws[k]) * int(h[k])
-            if need[self.rank, k] and o == self.rank:
-                out[k] = frames[k].data_ptr()
-            for r in range(self.world):
-                if not need[r, k] or r == o:
-                    continue
-                if self.rank == o:
-                    t = frames[k].reshape(-1)[:nbytes]
-                    dist.send(t.cpu() if dist.get_backend() != "nccl" else t, dst=r)
-                    bs += nbytes
-                elif self.rank == r:
-                    dev = torch.device("cuda", torch.cuda.current_device())
-                    buf = torch.empty(nbytes, dtype=torch.uint8, device=dev if dist.get_backend() == "nccl" else "cpu")
-                    dist.recv(buf, src=o)
-                    buf = buf.to(dev)
-                    self._recv_frames[k] = buf
-                    out[k] = buf.data_ptr()
-                    br += nbytes
-        if torch.cuda.is_available():
-            torch.cuda.current_stream().synchronize()     # the ctx stream may be another one: the copies must have landed
+        out, br, bs, self._recv_frames = exchange_frames_torch(frames, h, ws, need, owner, self.rank, self.world)
         return out, br, bs
 
     def allgather_moments(self, results, n_local, copy=True):

@@ -1,5 +1,5 @@
-"""CPU, world_size 2 over gloo: the N>1 path of the hot path -- frame / pair sharding and the two all-gathers (feature records,
-pair records) with the "torch" transport of imagemosaicing_amd/dist.py (the same records the C ABI moves over RCCL; the
+"""CPU, world_size 2 over gloo: the N>1 path of the hot path -- frame / pair sharding, the two all-gathers (feature records,
+pair records) and the frame exchange (owners send the frames a stripe reads) with the "torch" transport of imagemosaicing_amd/dist.py (the same records the C ABI moves over RCCL; the
 kernels around them are covered on the GPU by tests/test_gpu_dist.py)."""
 import os
 import socket
@@ -76,6 +76,36 @@ WORKER = textwrap.dedent("""
         sizes = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
         dist.all_gather(sizes, torch.tensor([len(mine)], dtype=torch.int64))
         assert mine <= allp and sum(int(x) for x in sizes) == len(allp) and all(a %% world == rank for a, b in mine)
+    # ---- frame ownership + exchange (SURVEY 8e primary form), torch transport of mi355_exchange_frames on CPU tensors ----------------------
+    Fx, hx, wsx = 11, 6, 16
+    for rule in ("mod", "blocks"):
+        owner = md.frame_owner(Fx, world, rule)
+        mine = md.owned_frames(Fx, rank, world, rule)
+        assert mine == [k for k in range(Fx) if owner[k] == rank] and sorted(set(owner.tolist())) == list(range(world))
+        held = [torch.full((hx * wsx,), 10 * k + 1, dtype=torch.uint8) if owner[k] == rank else None for k in range(Fx)]
+        rng2 = np.random.default_rng(5)                           # the same table on every rank
+        need = (rng2.random((world, Fx)) < 0.6).astype(np.uint8)
+        need[:, 3] = 0                                            # a frame nobody reads
+        for local_rows in (False, True):
+            ptrs, br, bs, recv = md.exchange_frames_torch(held, [hx] * Fx, [wsx] * Fx, need[rank] if local_rows else need, owner, rank, world)
+            for k in range(Fx):
+                if not need[rank, k]:
+                    assert ptrs[k] == 0 and k not in recv
+                elif owner[k] == rank:
+                    assert ptrs[k] == held[k].data_ptr() and k not in recv
+                else:
+                    assert ptrs[k] == recv[k].data_ptr() and bool((recv[k] == 10 * k + 1).all()) and recv[k].numel() == hx * wsx
+            assert br == hx * wsx * sum(1 for k in range(Fx) if need[rank, k] and owner[k] != rank)
+            assert bs == hx * wsx * sum(int(need[r, k]) for r in range(world) for k in mine if r != rank)
+            tot = torch.tensor([br, bs], dtype=torch.int64); dist.all_reduce(tot)
+            assert int(tot[0]) == int(tot[1])
+    # the stripes are dealt out to where a rank's frames lie: frames whose canvas row falls with the index -> rank 0 (low indices) gets the LAST stripe
+    w9 = [100] * Fx; h9 = [80] * Fx
+    Hs = np.tile(np.eye(3, dtype=np.float32).reshape(9), (Fx, 1)); Hs[:, 5] = 1000.0 - 90.0 * np.arange(Fx)
+    sidx = md.stripe_of_ranks(w9, h9, Hs, md.frame_owner(Fx, world, "blocks"), world)
+    assert sidx.tolist() == [1, 0]
+    Hs[:, 5] = 90.0 * np.arange(Fx)
+    assert md.stripe_of_ranks(w9, h9, Hs, md.frame_owner(Fx, world, "blocks"), world).tolist() == [0, 1]
     if rank == 0:
         print("GLOO_OK", counts, c2)
     dist.destroy_process_group()
