@@ -33,7 +33,7 @@ namespace {
 
 constexpr int S_OCT = 4, S_LAY = 2, S_NL = S_OCT * (S_LAY + 2);      // 16 layers
 constexpr int ORI_R = 6, ORI_WIN = 60, ORI_INC = 5, PATCH = 20;
-constexpr int SURF_MAX_KP = 32768;
+constexpr int SURF_MAX_KP = 1 << 21;      // = CAND_CAP: with max_kp at this value every Hessian maximum the candidate list can hold is kept, like the reference (MosaicWithoutPos.cpp:5313-5335)
 constexpr unsigned CAND_CAP = 1u << 21;
 
 struct SBox { int x1, y1, x2, y2; float w; };
@@ -633,7 +633,7 @@ void mi_surf_release(mi355_ctx* ctx) {
 }
 
 static int surf_extract_dev(mi355_ctx* ctx, int img_id, const uint8_t* d_bgr, int w, int h, int ws, float thr, int max_kp, int* n_kp) {
-    if (max_kp < 1 || max_kp > SURF_MAX_KP) { ctx->set_error("surf: max_kp must be in [1, 32768]"); return MI355_ERR_ARG; }
+    if (max_kp < 1 || max_kp > SURF_MAX_KP) { ctx->set_error("surf: max_kp must be in [1, 2097152]"); return MI355_ERR_ARG; }
     if (w < 16 || h < 16 || w >= (1 << 14) || h >= (1 << 14) || ws < 3 * w) { ctx->set_error("surf: image geometry (16 <= w, h < 16384)"); return MI355_ERR_ARG; }
     const hipStream_t st = ctx->stream;
     const int sw = w + 1, sh = h + 1;
@@ -662,7 +662,6 @@ static int surf_extract_dev(mi355_ctx* ctx, int img_id, const uint8_t* d_bgr, in
     DevBuf& dkps = ctx->buf("surf_kps"); DevBuf& ddesc = ctx->buf("surf_desc_tmp"); DevBuf& dtab = ctx->buf("surf_tables");
     MI_HIP(dgray.reserve((size_t)w * h)); MI_HIP(dS.reserve((size_t)sw * sh * 4)); MI_HIP(ddet.reserve(plane * 4)); MI_HIP(dtr.reserve(plane * 4));
     MI_HIP(dL.reserve(sizeof(SurfLayers))); MI_HIP(dkeys.reserve((size_t)CAND_CAP * 8)); MI_HIP(dcnt.reserve(64));
-    MI_HIP(dkps.reserve(sizeof(SurfKp) * SURF_MAX_KP)); MI_HIP(ddesc.reserve((size_t)SURF_MAX_KP * 128 * 4));
     // orientation disc + descriptor window weights (cv::getGaussianKernel rounding, oracle_surf.c gauss_taps)
     static OriTable h_tab; static float h_dw[PATCH * PATCH]; static bool tab_ready = false;
     static std::mutex tab_mu;
@@ -746,16 +745,19 @@ static int surf_extract_dev(mi355_ctx* ctx, int img_id, const uint8_t* d_bgr, in
     f.w = w; f.h = h;
     const size_t keep_max = cnt < (unsigned)max_kp ? (cnt > 0 ? cnt : 1) : (size_t)max_kp;      // the image's feature storage: what this extraction can keep, not the limit
     MI_HIP(f.kp.reserve(sizeof(mi355_keypoint) * keep_max)); MI_HIP(f.desc.reserve(keep_max * 128 * 4)); MI_HIP(f.xy.reserve(sizeof(float2) * keep_max));
+    // work areas and grids follow what this image really keeps (max_kp may be "all": 2^21), never less than the 32768 of rounds 1-5
+    const int launch_kp = (int)(keep_max > 32768 ? keep_max : (size_t)(max_kp < 32768 ? max_kp : 32768));
+    MI_HIP(dkps.reserve(sizeof(SurfKp) * (size_t)launch_kp)); MI_HIP(ddesc.reserve((size_t)launch_kp * 128 * 4));
     {
         ProfScope ps(ctx, "surf_describe", 0.0, st);
-        hipLaunchKernelGGL(surf_finalize, dim3((max_kp + 255) / 256), dim3(256), 0, st, dL.as<SurfLayers>(), ddet.as<float>(), dtr.as<float>(), dkeys.as<unsigned long long>(),
+        hipLaunchKernelGGL(surf_finalize, dim3((launch_kp + 255) / 256), dim3(256), 0, st, dL.as<SurfLayers>(), ddet.as<float>(), dtr.as<float>(), dkeys.as<unsigned long long>(),
                            d_count, CAND_CAP, max_kp, dkps.as<SurfKp>(), d_nkeep);
-        hipLaunchKernelGGL(surf_orient, dim3((max_kp + 3) / 4), dim3(256), 0, st, dS.as<uint32_t>(), w, h, d_tab, dkps.as<SurfKp>(), d_nkeep);
-        hipLaunchKernelGGL(surf_describe, dim3(max_kp), dim3(256), 0, st, dgray.as<uint8_t>(), w, h, d_dw, dkps.as<SurfKp>(), d_nkeep, ddesc.as<float>());
+        hipLaunchKernelGGL(surf_orient, dim3((launch_kp + 3) / 4), dim3(256), 0, st, dS.as<uint32_t>(), w, h, d_tab, dkps.as<SurfKp>(), d_nkeep);
+        hipLaunchKernelGGL(surf_describe, dim3(launch_kp), dim3(256), 0, st, dgray.as<uint8_t>(), w, h, d_dw, dkps.as<SurfKp>(), d_nkeep, ddesc.as<float>());
         DevBuf& dpos = ctx->buf("surf_pos");
-        MI_HIP(dpos.reserve(sizeof(int) * SURF_MAX_KP));
+        MI_HIP(dpos.reserve(sizeof(int) * (size_t)launch_kp));
         hipLaunchKernelGGL(surf_compact, dim3(1), dim3(1024), 0, st, dkps.as<SurfKp>(), d_nkeep, f.kp.as<mi355_keypoint>(), f.xy.as<float2>(), dpos.as<int>(), d_nout);
-        hipLaunchKernelGGL(surf_move_desc, dim3((max_kp + 1) / 2), dim3(256), 0, st, ddesc.as<float>(), dpos.as<int>(), d_nkeep, f.desc.as<float>());
+        hipLaunchKernelGGL(surf_move_desc, dim3((launch_kp + 1) / 2), dim3(256), 0, st, ddesc.as<float>(), dpos.as<int>(), d_nkeep, f.desc.as<float>());
     }
     MI_HIP(hipGetLastError());
     int n = 0;

@@ -237,7 +237,7 @@ inline int GetMatchedPairsOneToAllSurf(const PoseT* pImgPoses, const int nImages
         if (!im) return -1;
         fixed[i] = pImgPoses[i].fixed;
         int n = 0;
-        const int rc = mi355_surf_extract(c, i, (const uint8_t*)im->imageData, im->width, im->height, im->widthStep, (float)minHessian, 32768, NULL, NULL, &n);
+        const int rc = mi355_surf_extract(c, i, (const uint8_t*)im->imageData, im->width, im->height, im->widthStep, (float)minHessian, 1 << 21 /* every keypoint, like the reference */, NULL, NULL, &n);
         if (rc != MI355_OK) return rc;
     }
     int np = 0;

@@ -274,8 +274,8 @@ int  mi355_global_affine_align_results(const mi355_pair_result* r, int n_pairs, 
  * (every call site of it in the reference is commented out, :4461-4499; named in north_star).  cv::SURF's arithmetic is not
  * available: the definition is oracle/oracle_surf.c (parity unpinned).  SURF features live in their own id space of the ctx. */
 /* SurfFeatureDetector detector(minHessian).detect + SurfDescriptorExtractor.compute (:5313-5335): SURF(hessianThreshold, 4 octaves,
- * 2 layers, extended 128-float descriptors, oriented).  The reference keeps every keypoint; here the max_kp (<= 32768) strongest
- * by Hessian response are kept, ordered by (response descending, octave, layer, row, column).  desc128: n x 128 floats, unit norm;
+ * 2 layers, extended 128-float descriptors, oriented).  The reference keeps every keypoint; here the max_kp strongest by Hessian response
+ * are kept (max_kp <= 2^21 = the candidate list: pass that to keep all; an image with more maxima above the threshold than that fails), ordered by (response descending, octave, layer, row, column).  desc128: n x 128 floats, unit norm;
  * kp[].class_id = sign of the Laplacian.  Synchronous. */
 int  mi355_surf_extract(mi355_ctx* ctx, int img_id, const uint8_t* bgr, int w, int h, int width_step, float hessian_threshold, int max_kp,
                         mi355_keypoint* kp, float* desc128, int* n_kp);

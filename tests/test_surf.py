@@ -98,13 +98,15 @@ def test_surf_gpu_vs_oracle():
     cases = [(strip(3, 640, 480, seed=3)[0], 50.0, 3000), ([terrain(333, 257, seed=5), terrain(200, 160, seed=6)], 50.0, 8192),
              ([terrain(1100, 780, seed=7)], 400.0, 2000), ([np.full((120, 160, 3), 90, np.uint8)], 50.0, 100),
              ([terrain(2000, 1500, seed=9)], 2.0, 32768),      # 25 001 keypoints: every one kept, as the reference does (the limit was 8192 until round 5)
-             ([terrain(2000, 1500, seed=9)], 2.0, 20000)]      # ... and the strongest 20 000 of them
+             ([terrain(2000, 1500, seed=9)], 2.0, 20000),      # ... and the strongest 20 000 of them
+             ([terrain(2800, 2100, seed=13)], 1.0, 1 << 21)]   # keep ALL (round 6: max_kp up to the candidate list's 2^21): more than the 32 768 of rounds 1-5
     for frames, thr, mk in cases:
         for k, img in enumerate(frames):
             kp, d = ctx.SurfExtract(k, img, thr, mk)
             okp, od = orc.surf(img, thr, mk)
             assert len(kp) == len(okp), (img.shape, len(kp), len(okp))
             if mk > 8192: assert len(kp) > 8192
+            if mk > 32768: assert len(kp) > 32768, len(kp)
             for f in ("x", "y", "size", "angle", "response", "octave", "class_id"):
                 a, b = kp[f], okp[f]
                 same = a.view(np.uint32) == b.view(np.uint32) if a.dtype.kind == "f" else a == b
