@@ -177,7 +177,8 @@ def test_ransac2d_one_workgroup_per_pair_and_split_forms_agree(ctx, oracle):
                 assert ok2 == ok and len(i1) == nin and np.array_equal(i1["id"], ids[:nin]), (S, n, seed)
                 if nin >= 4:
                     assert np.array_equal(bits(H2), bits(H)), (S, n, seed, H2, H)
-            for n, of, st in [(396, 0.35, 1000), (396, 0.8, 1000), (57, 0.5, 1000), (31, 0.2, 1000), (9, 0.0, 1000), (4, 0.0, 1000), (396, 0.5, 1), (396, 0.5, 77), (200, 0.6, 4999), (13, 0.5, 5000)]:
+            for n, of, st in [(396, 0.35, 1000), (396, 0.8, 1000), (57, 0.5, 1000), (31, 0.2, 1000), (9, 0.0, 1000), (4, 0.0, 1000), (396, 0.5, 1), (396, 0.5, 77), (200, 0.6, 4999), (13, 0.5, 5000),
+                              (396, 0.5, 4999), (400, 0.3, 5000)]:      # the last two: draw list + body past 80 KB of LDS -> the list lives in HBM (ransac_listg_kernel)
                 p1, p2 = synth_pairs(n, of, seed=1000 + 31 * n + st, size=(4000, 3000))
                 a = oracle.ransac2d(p1, p2, 2.5, st, 5)
                 b = ctx.Ransac2D(p1, p2, 2.5, st, 5)
