@@ -384,11 +384,14 @@ def rank_share_proxy(args):
             stripes = [((ch * q) // G, (ch * (q + 1)) // G - (ch * q) // G) for q in range(G)]
             sidx = md.stripe_of_ranks(wv, hv, h9, owner, G)
             row0, rows = stripes[int(sidx[rk])]
-            # the rank's own cover row: the frames that give its stripe a pixel (the tile kernel's walk without loads) ...
-            need_mine = ctx.StripeCover(wv, hv, h9, row0, rows, exact=True)
-            # ... and the exchange call on the one-rank communicator: the all-gather of the cover rows and the table walk are real, the
-            # transfers themselves are wire (modelled from the bytes below)
-            ptrs, _, _ = ex.exchange_frames([frames[k] for k in range(F)], hv, wsv, need_mine)
+            if args.frames_resident == "replicas":
+                ptrs = fptr                                        # round 5's form: every rank holds every frame, nothing to obtain
+            else:
+                # the rank's own cover row: the frames that give its stripe a pixel (the tile kernel's walk without loads) ...
+                need_mine = ctx.StripeCover(wv, hv, h9, row0, rows, exact=True)
+                # ... and the exchange call on the one-rank communicator: the all-gather of the cover rows and the table walk are real, the
+                # transfers themselves are wire (modelled from the bytes below)
+                ptrs, _, _ = ex.exchange_frames([frames[k] for k in range(F)], hv, wsv, need_mine)
             mark()
             ctx.MosaicImagesRefinedDev(ptrs, wv, hv, wsv, h9, canvas.data_ptr(), cw, ch, cws, row0, rows)
             mark()
@@ -398,6 +401,8 @@ def rank_share_proxy(args):
                 fb = float(h * ws)
                 need = np.stack([ctx.StripeCover(wv, hv, h9, stripes[int(sidx[q])][0], stripes[int(sidx[q])][1], exact=True) for q in range(G)])      # every rank's row (untimed: a rank forms its own)
                 box = ctx.StripeCover(wv, hv, h9, row0, rows)
+                if args.frames_resident == "replicas":
+                    need = need * 0                                # nothing crosses ranks: the bytes below are zero
                 xinfo.update({"stripe": int(sidx[rk]), "frames_read_by_the_stripe": int(need[rk].sum()), "frames_whose_box_meets_the_stripe": int(box.sum()),
                               "frames_received": int(sum(1 for k in range(F) if need[rk, k] and owner[k] != rk)),
                               "bytes_received": fb * sum(1 for k in range(F) if need[rk, k] and owner[k] != rk),
@@ -459,7 +464,7 @@ def rank_share_proxy(args):
     t_pred = max(v["predicted_ms_per_step"] for v in per_rank.values())
     out = {"kind": "rank_share_proxy (ONE GPU; a proxy of a rank's share, NOT a measured scaling curve)",
            "metric": "image-pairs/sec (detect+match+H+warp), 4000x3000 UAV frames", "of_ranks": G, "ranks_run": ranks,
-           "workload": "%d frames %dx%d, pair window %d (%d pairs), strong scaling: frames %s, pairs i mod %d, canvas stripes; frames held by their owners only" % (F, w, h, args.window, survey_pairs, ("in %d blocks" % G) if args.frame_owner == "blocks" else ("k mod %d" % G), G),
+           "workload": "%d frames %dx%d, pair window %d (%d pairs), strong scaling: frames %s, pairs i mod %d, canvas stripes; %s" % (F, w, h, args.window, survey_pairs, ("in %d blocks" % G) if args.frame_owner == "blocks" else ("k mod %d" % G), G, "every frame on every rank (replicas)" if args.frames_resident == "replicas" else "frames held by their owners only"),
            "one_gpu_ms_per_step": t_one, "one_gpu_pairs_per_s": survey_pairs / t_one * 1e3,
            "one_gpu_path": "bench.py's plain single-GPU step (device compaction, pinned copy of the accepted records, alignment from the records): not a path through the exchange",
            "frames_per_batch": {"one_gpu": batch_one, "rank": BATCH},

@@ -585,26 +585,11 @@ extern "C" int mi355_exchange_frames(mi355_ctx* ctx, const uint8_t* const* d_fra
     const int world = ctx->comm->world, rank = ctx->comm->rank;
     const bool own_too = (flags & MI355_EXCHANGE_OWN_THROUGH_RCCL) != 0;
     auto own = [&](int k) { return owner ? owner[k] : k % world; };
-    std::vector<uint8_t> table;
-    if (flags & MI355_EXCHANGE_NEED_IS_LOCAL) {
-        // `need` is this rank's own row (what ITS stripe reads: an exact cover comes from a pass on the rank's own device): the rows of all
-        // ranks are all-gathered first -- n bytes per rank, one ncclAllGather and one copy back
-        DevBuf& dn = ctx->buf("frame_need_rows");
-        const size_t row = ((size_t)n + 15) & ~(size_t)15;
-        MI_HIP(dn.reserve(row * world + 16));
-        MI_HIP(hipMemsetAsync(dn.as<uint8_t>() + row * rank, 0, row, ctx->stream));
-        if (n > 0) MI_HIP(hipMemcpyAsync(dn.as<uint8_t>() + row * rank, need, (size_t)n, hipMemcpyHostToDevice, ctx->stream));
-        MI_NCCL(api->AllGather(dn.as<uint8_t>() + row * rank, dn.p, row, ncclChar, ctx->comm->comm, ctx->stream));
-        std::vector<uint8_t> padded(row * world);
-        MI_HIP(hipMemcpyAsync(padded.data(), dn.p, row * world, hipMemcpyDeviceToHost, ctx->stream));
-        MI_HIP(hipStreamSynchronize(ctx->stream));
-        table.resize((size_t)n * world);
-        for (int r = 0; r < world; r++) memcpy(table.data() + (size_t)r * n, padded.data() + row * r, (size_t)n);
-        need = table.data();
-    }
-    // this rank's landing area: one slot per frame it receives.  Everything that can fail on this rank alone happens in `local`, BEFORE the
-    // first transfer is posted, and its verdict is all-gathered (one int per rank): a rank that left early would leave its peers waiting
-    // inside ncclRecv -- like the other exchanges, every rank returns the error together.
+    // What can fail on this rank alone is checked BEFORE anything is posted -- geometry, "a rank holds the frames it owns", memory for its landing
+    // area -- and the verdict travels with the cover rows (one more byte per rank): a rank that left early would leave its peers waiting inside
+    // ncclRecv; like the other exchanges, every rank returns the error together.  The landing area depends on the rank's OWN row only.
+    const bool local_rows = (flags & MI355_EXCHANGE_NEED_IS_LOCAL) != 0;
+    const uint8_t* my_row = local_rows ? need : need + (size_t)rank * n;
     std::vector<size_t> slot(n > 0 ? n : 1, (size_t)-1);
     size_t arena = 0;
     uint64_t rb = 0, sb = 0;
@@ -613,13 +598,11 @@ extern "C" int mi355_exchange_frames(mi355_ctx* ctx, const uint8_t* const* d_fra
         for (int k = 0; k < n; k++) {
             const int o = own(k);
             if (o < 0 || o >= world || h[k] < 1 || ws[k] < 1) { ctx->set_error("exchange_frames: bad owner / geometry of frame " + std::to_string(k)); return MI355_ERR_ARG; }
-            const size_t bytes = (size_t)ws[k] * h[k];
             d_out[k] = nullptr;
-            bool sends = false;
-            for (int r = 0; r < world; r++) if (need[(size_t)r * n + k] && (r != o || own_too) && o == rank) { sends = true; if (r != rank) sb += bytes; }
-            if ((sends || (need[(size_t)rank * n + k] && o == rank)) && !d_frames[k]) { ctx->set_error("exchange_frames: this rank owns frame " + std::to_string(k) + " but holds no pointer to it"); return MI355_ERR_ARG; }
-            if (!need[(size_t)rank * n + k]) continue;
+            if (o == rank && !d_frames[k]) { ctx->set_error("exchange_frames: this rank owns frame " + std::to_string(k) + " but holds no pointer to it"); return MI355_ERR_ARG; }
+            if (!my_row[k]) continue;
             if (o == rank && !own_too) { d_out[k] = d_frames[k]; continue; }
+            const size_t bytes = (size_t)ws[k] * h[k];
             slot[k] = arena; arena += (bytes + 255) & ~(size_t)255;
             if (o != rank) rb += bytes;
         }
@@ -628,17 +611,31 @@ extern "C" int mi355_exchange_frames(mi355_ctx* ctx, const uint8_t* const* d_fra
     };
     const int rc_local = local();
     const std::string err_local = rc_local != MI355_OK ? ctx->err : std::string();
+    std::vector<uint8_t> table;
     {
-        DevBuf& dst = ctx->buf("frame_exchange_status");
-        MI_HIP(dst.reserve(sizeof(int) * (size_t)(world + 1)));
-        const int mine = rc_local;
-        MI_HIP(hipMemcpyAsync(dst.as<int>() + rank, &mine, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
-        MI_NCCL(api->AllGather(dst.as<int>() + rank, dst.p, sizeof(int), ncclChar, ctx->comm->comm, ctx->stream));
-        std::vector<int> st(world);
-        MI_HIP(hipMemcpyAsync(st.data(), dst.p, sizeof(int) * (size_t)world, hipMemcpyDeviceToHost, ctx->stream));
+        // one all-gather: [cover row (n bytes, only when the rows are local) | status byte], padded to 16 bytes per rank
+        const size_t nrow = local_rows ? (size_t)n : 0, row = (nrow + 1 + 15) & ~(size_t)15;
+        DevBuf& dn = ctx->buf("frame_need_rows");
+        MI_HIP(dn.reserve(row * world + 16));
+        std::vector<uint8_t> mine(row, 0), padded(row * world);
+        if (nrow) memcpy(mine.data(), need, nrow);
+        mine[nrow] = rc_local == MI355_OK ? 0 : 1;
+        MI_HIP(hipMemcpyAsync(dn.as<uint8_t>() + row * rank, mine.data(), row, hipMemcpyHostToDevice, ctx->stream));
+        MI_NCCL(api->AllGather(dn.as<uint8_t>() + row * rank, dn.p, row, ncclChar, ctx->comm->comm, ctx->stream));
+        MI_HIP(hipMemcpyAsync(padded.data(), dn.p, row * world, hipMemcpyDeviceToHost, ctx->stream));
         MI_HIP(hipStreamSynchronize(ctx->stream));
         if (rc_local != MI355_OK) { ctx->set_error(err_local); return rc_local; }
-        for (int r = 0; r < world; r++) if (st[r] != MI355_OK) { ctx->set_error("exchange_frames: rank " + std::to_string(r) + " failed before the exchange"); return MI355_ERR_FAILED; }
+        for (int r = 0; r < world; r++) if (padded[row * r + nrow]) { ctx->set_error("exchange_frames: rank " + std::to_string(r) + " failed before the exchange"); return MI355_ERR_FAILED; }
+        if (local_rows) {
+            table.resize((size_t)n * world);
+            for (int r = 0; r < world; r++) memcpy(table.data() + (size_t)r * n, padded.data() + row * r, (size_t)n);
+            need = table.data();
+        }
+    }
+    for (int k = 0; k < n; k++) {                         // what this rank sends
+        if (own(k) != rank) continue;
+        const size_t bytes = (size_t)ws[k] * h[k];
+        for (int r = 0; r < world; r++) if (r != rank && need[(size_t)r * n + k]) sb += bytes;
     }
     for (int k = 0; k < n; k++) if (slot[k] != (size_t)-1) d_out[k] = dar.as<uint8_t>() + slot[k];
     constexpr int RUN = 64;                               // frames per ncclGroup: bounds the operations one group carries (C5: ~480 receives per rank in all)

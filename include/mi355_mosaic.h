@@ -392,8 +392,9 @@ int  mi355_mosaic_stripe_cover(mi355_ctx* ctx, int mode, const int* w, const int
  * stripe does not read it -- ready to be the d_imgs of the stripe calls.  Received copies stay valid until the next call.
  * flags: MI355_EXCHANGE_OWN_THROUGH_RCCL also routes the rank's own needed frames through ncclSend / ncclRecv to itself (a communicator
  * of one rank then exercises the whole path: tests).  bytes_recv / bytes_sent (NULL allowed): this rank's traffic.  Enqueued on the ctx stream.
- * What can fail on one rank alone (an owned frame without a pointer, bad geometry, no memory for the landing area) is found BEFORE any transfer
- * is posted and its verdict is all-gathered (one int per rank): every rank returns the error together, none is left waiting in ncclRecv. */
+ * A rank must hold (d_frames[k] != NULL) every frame it owns.  What can fail on one rank alone (an owned frame without a pointer, bad geometry,
+ * no memory for the landing area) is found BEFORE any transfer is posted and its verdict travels with the cover rows (one all-gather): every
+ * rank returns the error together, none is left waiting in ncclRecv. */
 #define MI355_EXCHANGE_OWN_THROUGH_RCCL 1
 /* MI355_EXCHANGE_NEED_IS_LOCAL: `need` holds n bytes, this rank's OWN row (what its stripe reads, e.g. from MI355_COVER_REFINED_EXACT on its
  * own device); the call all-gathers the rows of all ranks first (n bytes per rank). */
