@@ -388,7 +388,8 @@ def rank_share_proxy(args):
                 ptrs = fptr                                        # round 5's form: every rank holds every frame, nothing to obtain
             else:
                 # the rank's own cover row: the frames that give its stripe a pixel (the tile kernel's walk without loads) ...
-                need_mine = ctx.StripeCover(wv, hv, h9, row0, rows, exact=True)
+                exact = md.exact_cover_pays(wv, hv, h9, cw, ch)
+                need_mine = ctx.StripeCover(wv, hv, h9, row0, rows, exact=exact)
                 # ... and the exchange call on the one-rank communicator: the all-gather of the cover rows and the table walk are real, the
                 # transfers themselves are wire (modelled from the bytes below)
                 ptrs, _, _ = ex.exchange_frames([frames[k] for k in range(F)], hv, wsv, need_mine)
@@ -399,14 +400,16 @@ def rank_share_proxy(args):
                 names = ["detect_describe", "feature_allgather_local", "match_select_ransac", "result_exchange_local_and_d2h", "host_alignment_replicated", "stripe_cover_and_exchange_call", "warp_stripe"]
                 ph.update({n: (t[i + 1] - t[i]) * 1e3 for i, n in enumerate(names)})
                 fb = float(h * ws)
-                need = np.stack([ctx.StripeCover(wv, hv, h9, stripes[int(sidx[q])][0], stripes[int(sidx[q])][1], exact=True) for q in range(G)])      # every rank's row (untimed: a rank forms its own)
+                exact = md.exact_cover_pays(wv, hv, h9, cw, ch)
+                need = np.stack([ctx.StripeCover(wv, hv, h9, stripes[int(sidx[q])][0], stripes[int(sidx[q])][1], exact=exact) for q in range(G)])      # every rank's row (untimed: a rank forms its own)
                 box = ctx.StripeCover(wv, hv, h9, row0, rows)
                 if args.frames_resident == "replicas":
                     need = need * 0                                # nothing crosses ranks: the bytes below are zero
                 xinfo.update({"stripe": int(sidx[rk]), "frames_read_by_the_stripe": int(need[rk].sum()), "frames_whose_box_meets_the_stripe": int(box.sum()),
                               "frames_received": int(sum(1 for k in range(F) if need[rk, k] and owner[k] != rk)),
                               "bytes_received": fb * sum(1 for k in range(F) if need[rk, k] and owner[k] != rk),
-                              "bytes_sent": fb * sum(int(need[q, k]) for q in range(G) for k in own if q != rk), "owner_rule": args.frame_owner})
+                              "bytes_sent": fb * sum(int(need[q, k]) for q in range(G) for k in own if q != rk), "owner_rule": args.frame_owner,
+                              "cover": "exact (device pass)" if exact else "by box (host geometry: the survey is thin, an exact list would cost more than the few frames it saves)"})
 
         for i in range(max(args.warmup, 1)):
             share_step(1 + i)
@@ -670,7 +673,7 @@ def main():
                 # the frames that give this stripe at least one pixel (the tile kernel's walk without its loads, on this rank's device); the rows of
                 # all ranks are all-gathered inside the exchange, then every frame a stripe reads and its rank does not hold comes from its owner
                 # (ncclSend / ncclRecv over xGMI)
-                need_mine = ctx.StripeCover(wv, hv, h9, mine[0], mine[1], exact=True)
+                need_mine = ctx.StripeCover(wv, hv, h9, mine[0], mine[1], exact=md.exact_cover_pays(wv, hv, h9, cw, ch))
                 ptrs, b_in, b_out = ex.exchange_frames(held, hv, wsv, need_mine, owner=owner)
                 state["frame_exchange"] = {"bytes_received": b_in, "bytes_sent": b_out, "frames_read_by_the_stripe": int(need_mine.sum()), "frames_held": len(hold), "owner_rule": args.frame_owner}
             else:

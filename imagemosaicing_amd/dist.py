@@ -52,6 +52,19 @@ def frame_owner(n_images, world, rule="mod"):
     return (np.arange(n_images) % world).astype(np.int32)
 
 
+def exact_cover_pays(w, h, h9s, cw, ch, threshold=8.0):
+    """whether a stripe's cover list should be formed exactly (mi355_mosaic_stripe_cover MI355_COVER_REFINED_EXACT: one device pass, ~0.5 ms
+    per C3 stripe) or by box (host geometry, microseconds).  The exact list is shorter where many frames lie on top of each other: the
+    measure is the mean number of frames per canvas pixel, sum of the frames' areas / canvas area -- C3's strip survey 3.0 (box 107 frames,
+    exact 97: the pass costs more than the ten frames' 0.3 ms of wire), C5's block 59 (641 -> 340: 10 ms of wire for 1.5).  Replicated
+    geometry: the same answer on every rank."""
+    h9s = np.asarray(h9s, np.float64).reshape(-1, 9)
+    valid = h9s[:, 8] != 0
+    a = h9s[:, 0] * h9s[:, 4] - h9s[:, 1] * h9s[:, 3]            # area scale of the (near-affine) frame -> canvas maps
+    area = float((np.abs(a) * np.asarray(w, np.float64) * np.asarray(h, np.float64))[valid].sum())
+    return area / max(float(cw) * float(ch), 1.0) > threshold
+
+
 def stripe_of_ranks(w, h, h9s, owner, world):
     """which canvas stripe each rank renders: the ranks in the order of the mean canvas row of the frames they hold (frame centres through the
     replicated transforms), so that a rank's stripe lies where its own frames are.  Pure host geometry on replicated data: the same answer on
