@@ -286,13 +286,13 @@ class Exchange:
         return np.stack([self.ctx.StripeCover(w, h, h9s, r0, nr, blended=blended, keep=keep, band=band, exact=exact) for (r0, nr) in stripes])
 
     def exchange_frames(self, frames, h, ws, need, owner=None, own_through_rccl=False):
-        """frames: per frame a torch uint8 device tensor where this rank holds it, else None.  Every frame this rank's stripe reads
+        """frames: per frame a torch uint8 device tensor (rccl transport: or its device address as an int) where this rank holds it, else None.  Every frame this rank's stripe reads
         (need[rank]) and does not hold comes from its owner (k mod G unless `owner` says otherwise).  Returns (device pointers for the
         stripe calls, 0 where the stripe does not read the frame; bytes received; bytes sent); received frames stay alive until the next call."""
         n = len(frames)
         need = np.ascontiguousarray(need, np.uint8)
         if self.transport == "rccl":
-            return self.ctx.ExchangeFrames([f.data_ptr() if f is not None else 0 for f in frames], h, ws, need, owner=owner, own_through_rccl=own_through_rccl)
+            return self.ctx.ExchangeFrames([(f if isinstance(f, int) else f.data_ptr()) if f is not None else 0 for f in frames], h, ws, need, owner=owner, own_through_rccl=own_through_rccl)
         out, br, bs, self._recv_frames = exchange_frames_torch(frames, h, ws, need, owner, self.rank, self.world)
         return out, br, bs
 

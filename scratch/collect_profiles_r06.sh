@@ -38,6 +38,7 @@ MI355_BENCH_NO_STANDALONE=1 python bench.py --as-rank 0,3,7 --of 8 --frames 2000
 MI355_BENCH_NO_STANDALONE=1 python bench.py --as-rank 0,7 --of 8 --frames 2000 --layout block --window 182 --steps 2 --warmup 1 --align-input records > $O/r06_rank_share_proxy_c5_records_everywhere.json 2>> $O/bench.err
 MI355_BENCH_NO_STANDALONE=1 python bench.py --as-rank 0,3,7 --of 8 --frames 2000 --layout block --window 182 --steps 2 --warmup 1 --frame-owner mod > $O/r06_rank_share_proxy_c5_owner_mod.json 2>> $O/bench.err
 python bench.py --as-rank 0,3,7 --of 8 --steps 8 --warmup 2 --frame-owner mod > $O/r06_rank_share_proxy_c3_owner_mod.json 2>> $O/bench.err
+python bench.py --as-rank 0,3,7 --of 8 --steps 8 --warmup 2 --frames-resident replicas > $O/r06_rank_share_proxy_c3_replicas.json 2>> $O/bench.err
 # 2 ranks on one device over gloo: the strong-scaling path end to end (owned frames, torch transport of the same records and frames)
 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29544 bench.py --gpus 2 --backend gloo --all-ranks-on-device0 --steps 2 --warmup 1 --frames 96 --no-cpu-baseline > $O/r06_bench_dryrun_2ranks_1device.json 2>> $O/bench.err
 python scratch/match_time.py 500 182 > $O/r06_match_time_c4.txt 2>> $O/bench.err
