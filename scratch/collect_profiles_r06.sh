@@ -29,8 +29,8 @@ MI355_BENCH_NO_STANDALONE=1 rocprofv3 --kernel-trace --stats -d $O/trace3 -o t -
 DB=$(find $O/trace3 -name "*.db" | head -1)
 python profiles/rocpd_summary.py $DB $O/r06_rocprofv3_kernel_stats_bench_c4.txt
 rm -rf $O/trace3
-MI355_BENCH_NO_STANDALONE=1 MI355_ALIGN_DBG=1 python bench.py --frames 2000 --layout block --blend --window 182 --steps 1 --warmup 1 > $O/r06_bench_c5_blend_n1.json 2> $O/r06_align_stages_c5.txt
-grep "^\[align\]" $O/r06_align_stages_c5.txt | tail -10 > $O/r06_align_stages_c5.tmp; mv $O/r06_align_stages_c5.tmp $O/r06_align_stages_c5.txt
+MI355_BENCH_NO_STANDALONE=1 python bench.py --frames 2000 --layout block --blend --window 182 --steps 1 --warmup 1 > $O/r06_bench_c5_blend_n1.json 2>> $O/bench.err
+MI355_ALIGN_DBG=1 python scratch/align_c5_synth.py 4 2>&1 | tail -12 > $O/r06_align_stages_c5.txt      # the C5-sized alignment on the box's host alone, stage by stage
 # a rank's share of an 8-rank run (owner-only frames in blocks, exact stripe covers, moments everywhere + records to rank 0) and the round-5 forms for comparison
 python bench.py --as-rank 0,3,7 --of 8 --steps 8 --warmup 2 > $O/r06_rank_share_proxy_c3.json 2>> $O/bench.err
 python bench.py --as-rank 0,3,7 --of 8 --window 182 --steps 5 --warmup 1 > $O/r06_rank_share_proxy_c4.json 2>> $O/bench.err
